@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors from the reference (ssspy 0.2.0).
+
+Runs ONLY in the build container, where the reference checkout is mounted at
+/root/reference:
+
+    python tests/golden/make_golden.py
+
+It imports the reference, runs the hot-path separators and operators on small
+seeded inputs and writes ``tests/golden/*.npz`` (inputs, explicit initial state,
+state after iterations 1, 2 and 10 captured through the reference's own
+callback hook, the full loss list and the final output).  Only the data is
+committed; the reference's source never leaves /root/reference.
+"""
+
+import functools
+import os
+import sys
+
+import numpy as np
+
+REFERENCE = os.environ.get("SSSPY_REFERENCE", "/root/reference")
+sys.path.insert(0, REFERENCE)
+
+from ssspy.algorithm import projection_back  # noqa: E402
+from ssspy.bss._update_spatial_model import update_by_ip1, update_by_iss1  # noqa: E402
+from ssspy.bss.ilrma import GaussILRMA  # noqa: E402
+from ssspy.bss.iva import AuxGaussIVA, AuxLaplaceIVA  # noqa: E402
+from ssspy.bss.mnmf import FastGaussMNMF  # noqa: E402
+from ssspy.linalg import eigh2, inv2  # noqa: E402
+from ssspy.special.flooring import add_flooring, max_flooring  # noqa: E402
+from ssspy.special.psd import to_psd  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SNAP_ITERS = (1, 2, 10)
+
+
+def gen_iid(seed, N, F, T):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+
+
+def gen_mixture(seed, N, F, T, Kt=4):
+    """Structured NMF-source mixture."""
+    rng = np.random.default_rng(seed)
+    R = (rng.random((N, F, Kt)) ** 4) @ (rng.random((N, Kt, T)) ** 4) + 1e-3
+    g1 = rng.standard_normal((N, F, T))
+    g2 = rng.standard_normal((N, F, T))
+    S = np.sqrt(R / 2) * (g1 + 1j * g2)
+    A = rng.standard_normal((F, N, N)) + 1j * rng.standard_normal((F, N, N))
+    return (A @ S.transpose(1, 0, 2)).transpose(1, 0, 2)
+
+
+def flooring_of(spec):
+    kind, eps = spec
+    if kind == "max":
+        return functools.partial(max_flooring, eps=eps)
+    if kind == "add":
+        return functools.partial(add_flooring, eps=eps)
+    return None
+
+
+class Snapshots:
+    """Callback that copies the separator state after selected iterations."""
+
+    def __init__(self, names):
+        self.names = names
+        self.count = -1  # the initial call happens before the first iteration
+        self.store = {}
+
+    def __call__(self, method):
+        self.count += 1
+        if self.count in SNAP_ITERS:
+            for name in self.names:
+                value = getattr(method, name, None)
+                if value is not None:
+                    self.store["it{}_{}".format(self.count, name)] = np.array(value, copy=True)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("{:40s} {:8.1f} KiB".format(name, os.path.getsize(path) / 1024))
+
+
+def meta(**kw):
+    return {"meta_" + k: np.asarray(v) for k, v in kw.items()}
+
+
+# --------------------------------------------------------------------------- ILRMA
+def run_ilrma(name, *, N, F, T, K, algo, seed, gen=gen_iid, domain=2, flooring=("max", 1e-10),
+              normalization=True, scale_restoration=True, n_iter=10):
+    X = gen(seed, N, F, T)
+    basis = np.random.default_rng(seed + 1).random((N, F, K))
+    activation = np.random.default_rng(seed + 2).random((N, K, T))
+    snap = Snapshots(["demix_filter", "output", "basis", "activation"])
+    m = GaussILRMA(
+        n_basis=K, spatial_algorithm=algo, domain=domain, flooring_fn=flooring_of(flooring),
+        callbacks=snap, normalization=normalization, scale_restoration=scale_restoration,
+        rng=np.random.default_rng(seed + 3),
+    )
+    Y = m(X, n_iter=n_iter, basis=basis, activation=activation)
+    out = dict(X=X, basis0=basis, activation0=activation, loss=np.array(m.loss), final_output=Y,
+               final_basis=m.basis, final_activation=m.activation)
+    if m.demix_filter is not None:
+        out["final_demix_filter"] = m.demix_filter
+    out.update(snap.store)
+    out.update(meta(kind="gauss_ilrma", algo=algo, domain=domain, n_basis=K, n_iter=n_iter,
+                    floor_kind=flooring[0], floor_eps=flooring[1], normalization=normalization,
+                    scale_restoration=scale_restoration))
+    save(name, **out)
+
+
+# --------------------------------------------------------------------------- IVA
+def run_iva(name, *, N, F, T, algo, contrast, seed, gen=gen_iid, flooring=("max", 1e-10),
+            scale_restoration=True, n_iter=10, keep_arrays=True):
+    X = gen(seed, N, F, T)
+    names = ["demix_filter", "output"] + (["variance"] if contrast == "gauss" else [])
+    snap = Snapshots(names)
+    cls = AuxLaplaceIVA if contrast == "laplace" else AuxGaussIVA
+    m = cls(spatial_algorithm=algo, flooring_fn=flooring_of(flooring), callbacks=snap,
+            scale_restoration=scale_restoration)
+    Y = m(X, n_iter=n_iter)
+    out = dict(loss=np.array(m.loss))
+    if keep_arrays:
+        out.update(X=X, final_output=Y)
+        if m.demix_filter is not None:
+            out["final_demix_filter"] = m.demix_filter
+        out.update(snap.store)
+    else:
+        # known-answer scalars only (config-1 sized case): the input is regenerated from the seed
+        out.update(kat_y000=Y[0, 0, 0], kat_energy=np.sum(np.abs(Y) ** 2),
+                   kat_abs_sum=np.sum(np.abs(Y)))
+    out.update(meta(kind="aux_iva", algo=algo, contrast=contrast, n_iter=n_iter, seed=seed,
+                    shape=(N, F, T), floor_kind=flooring[0], floor_eps=flooring[1],
+                    scale_restoration=scale_restoration))
+    save(name, **out)
+
+
+# --------------------------------------------------------------------------- MNMF
+def run_mnmf(name, *, M, F, T, K, seed, n_sources=None, gen=gen_iid, flooring=("max", 1e-10),
+             normalization=True, n_iter=10):
+    N = M if n_sources is None else n_sources
+    X = gen(seed, M, F, T)
+    basis = np.random.default_rng(seed + 1).random((N, F, K))
+    activation = np.random.default_rng(seed + 2).random((N, K, T))
+    spatial = np.random.default_rng(seed + 4).random((F, N, M))
+    snap = Snapshots(["diagonalizer", "spatial", "basis", "activation"])
+    m = FastGaussMNMF(n_basis=K, n_sources=n_sources, flooring_fn=flooring_of(flooring),
+                      callbacks=snap, normalization=normalization,
+                      rng=np.random.default_rng(seed + 3))
+    Y = m(X, n_iter=n_iter, basis=basis, activation=activation, spatial=spatial.copy())
+    out = dict(X=X, basis0=basis, activation0=activation, spatial0=spatial,
+               loss=np.array(m.loss), final_output=Y, final_basis=m.basis,
+               final_activation=m.activation, final_diagonalizer=m.diagonalizer,
+               final_spatial=m.spatial)
+    out.update(snap.store)
+    out.update(meta(kind="fast_gauss_mnmf", n_basis=K, n_sources=N, n_iter=n_iter,
+                    floor_kind=flooring[0], floor_eps=flooring[1], normalization=normalization))
+    save(name, **out)
+
+
+# --------------------------------------------------------------------------- operators
+def run_operators():
+    out = {}
+    # update_by_ip1: seeds/shapes in the style of the reference's operator unit tests
+    for N in (2, 3, 4, 8):
+        rng = np.random.default_rng(40 + N)
+        F, T = 9, 30
+        X = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+        W = rng.standard_normal((F, N, N)) + 1j * rng.standard_normal((F, N, N))
+        varphi = 1 / (rng.random((N, F, T)) + 0.1)
+        XX = (X[:, None] * X[None].conj()).transpose(2, 0, 1, 3)
+        U = np.mean(varphi.transpose(1, 0, 2)[:, :, None, None, :] * XX[:, None], axis=-1)
+        out["ip1_n{}_W".format(N)] = W
+        out["ip1_n{}_U".format(N)] = U
+        out["ip1_n{}_out".format(N)] = update_by_ip1(W.copy(), U)
+        out["ip1_n{}_out_add".format(N)] = update_by_ip1(
+            W.copy(), U, flooring_fn=functools.partial(add_flooring, eps=1e-3))
+        Y = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+        out["iss1_n{}_Y".format(N)] = Y
+        out["iss1_n{}_varphi".format(N)] = varphi
+        out["iss1_n{}_out".format(N)] = update_by_iss1(Y, varphi)
+        wt = varphi[:, :1, :]
+        out["iss1_n{}_out_bcast".format(N)] = update_by_iss1(Y, wt)
+        out["pb_n{}_filter".format(N)] = projection_back(W, reference_id=1)
+        out["pb_n{}_output".format(N)] = projection_back(Y, reference=X, reference_id=0)
+        out["pb_n{}_X".format(N)] = X
+        A = rng.standard_normal((F, T, N, N)) + 1j * rng.standard_normal((F, T, N, N))
+        H = A @ A.swapaxes(-2, -1).conj() - 0.5 * np.eye(N)  # indefinite Hermitian
+        out["psd_n{}_in".format(N)] = H
+        out["psd_n{}_out".format(N)] = to_psd(H)
+    rng = np.random.default_rng(7)
+    A = rng.standard_normal((16, 2, 2)) + 1j * rng.standard_normal((16, 2, 2))
+    B = rng.standard_normal((16, 2, 2)) + 1j * rng.standard_normal((16, 2, 2))
+    A = A @ A.swapaxes(-2, -1).conj()
+    B = B @ B.swapaxes(-2, -1).conj()
+    out["inv2_in"] = A
+    out["inv2_out"] = inv2(A)
+    lamb, z = eigh2(A, B)
+    out["eigh2_A"], out["eigh2_B"] = A, B
+    out["eigh2_lamb"], out["eigh2_z"] = lamb, z
+    save("operators", **out)
+
+
+def main():
+    # --- GaussILRMA, IP1 ---
+    run_ilrma("gilrma_ip1_n2", N=2, F=17, T=32, K=2, algo="IP", seed=0)            # KAT-1 of SURVEY 8c
+    run_ilrma("gilrma_ip1_n3", N=3, F=20, T=37, K=16, algo="IP1", seed=10, gen=gen_mixture)
+    run_ilrma("gilrma_ip1_n4", N=4, F=33, T=48, K=5, algo="IP", seed=20, gen=gen_mixture)
+    run_ilrma("gilrma_ip1_n4_p1", N=4, F=18, T=40, K=4, algo="IP", seed=30, domain=1)
+    run_ilrma("gilrma_ip1_n2_add", N=2, F=16, T=33, K=3, algo="IP", seed=40, flooring=("add", 1e-4))
+    run_ilrma("gilrma_ip1_n2_nofloor", N=2, F=16, T=33, K=3, algo="IP", seed=41, flooring=("none", 0.0))
+    run_ilrma("gilrma_ip1_n3_raw", N=3, F=19, T=34, K=4, algo="IP", seed=50,
+              normalization=False, scale_restoration=False)
+    # --- GaussILRMA, ISS1 ---
+    run_ilrma("gilrma_iss1_n2", N=2, F=17, T=32, K=2, algo="ISS", seed=0)          # KAT-2
+    run_ilrma("gilrma_iss1_n4", N=4, F=33, T=48, K=5, algo="ISS1", seed=20, gen=gen_mixture)
+    run_ilrma("gilrma_iss1_n3_p1", N=3, F=18, T=40, K=4, algo="ISS", seed=31, domain=1)
+    # --- AuxIVA ---
+    run_iva("auxlap_ip1_n2", N=2, F=33, T=40, algo="IP", contrast="laplace", seed=0)
+    run_iva("auxlap_ip1_n4", N=4, F=20, T=50, algo="IP1", contrast="laplace", seed=1, gen=gen_mixture)
+    run_iva("auxlap_iss1_n2", N=2, F=33, T=40, algo="ISS", contrast="laplace", seed=0)
+    run_iva("auxlap_iss1_n8", N=8, F=12, T=70, algo="ISS1", contrast="laplace", seed=2, gen=gen_mixture)
+    run_iva("auxgauss_ip1_n3", N=3, F=24, T=45, algo="IP", contrast="gauss", seed=3, gen=gen_mixture)
+    run_iva("auxgauss_iss1_n3", N=3, F=24, T=45, algo="ISS", contrast="gauss", seed=3, gen=gen_mixture)
+    run_iva("auxlap_ip1_n2_raw", N=2, F=20, T=36, algo="IP", contrast="laplace", seed=4,
+            scale_restoration=False)
+    # config 1 of BASELINE.json (N=2, F=257, T=128, 10 it): known-answer scalars (KAT-3 / KAT-4)
+    run_iva("kat_auxlap_ip1_config1", N=2, F=257, T=128, algo="IP", contrast="laplace", seed=0,
+            keep_arrays=False)
+    run_iva("kat_auxlap_iss1_config1", N=2, F=257, T=128, algo="ISS", contrast="laplace", seed=0,
+            keep_arrays=False)
+    # --- FastGaussMNMF ---
+    run_mnmf("fmnmf_ip1_m3", M=3, F=17, T=32, K=2, seed=0)                          # KAT-5
+    run_mnmf("fmnmf_ip1_m4", M=4, F=21, T=36, K=8, seed=5, gen=gen_mixture)
+    run_mnmf("fmnmf_ip1_m3_n2", M=3, F=16, T=30, K=3, seed=6, n_sources=2)
+    run_mnmf("fmnmf_ip1_m2_nonorm", M=2, F=16, T=30, K=3, seed=7, normalization=False)
+    # --- operators ---
+    run_operators()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,148 @@
+"""Pin the CPU oracle against the golden vectors generated from the reference.
+
+Every fixture under tests/golden/ (made by tests/golden/make_golden.py, which
+imports the reference in the build container) is replayed through ``oracle/``.
+Tolerances: the oracle follows the reference's expression structure, so state
+after 1/2/10 iterations must agree to ~1e-12 relative (Frobenius).
+"""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+from oracle import spatial as sp
+from oracle.ilrma import GaussILRMAOracle
+from oracle.iva import AuxIVAOracle
+from oracle.mnmf import FastGaussMNMFOracle
+
+TOL = 1e-11
+
+ILRMA_CASES = [
+    "gilrma_ip1_n2", "gilrma_ip1_n3", "gilrma_ip1_n4", "gilrma_ip1_n4_p1", "gilrma_ip1_n2_add",
+    "gilrma_ip1_n2_nofloor", "gilrma_ip1_n3_raw", "gilrma_iss1_n2", "gilrma_iss1_n4",
+    "gilrma_iss1_n3_p1",
+]
+IVA_CASES = [
+    "auxlap_ip1_n2", "auxlap_ip1_n4", "auxlap_iss1_n2", "auxlap_iss1_n8", "auxgauss_ip1_n3",
+    "auxgauss_iss1_n3", "auxlap_ip1_n2_raw",
+]
+MNMF_CASES = ["fmnmf_ip1_m3", "fmnmf_ip1_m4", "fmnmf_ip1_m3_n2", "fmnmf_ip1_m2_nonorm"]
+
+
+def _floor(g):
+    return (str(g["meta_floor_kind"]), float(g["meta_floor_eps"]))
+
+
+def _check_snapshots(g, k, model, names):
+    for name in names:
+        key = "it{}_{}".format(k, name)
+        if key in g:
+            assert rel_err(getattr(model, name), g[key]) < TOL, key
+
+
+@pytest.mark.parametrize("case", ILRMA_CASES)
+def test_gauss_ilrma(case):
+    g = load_golden(case)
+    m = GaussILRMAOracle(
+        n_basis=int(g["meta_n_basis"]), spatial_algorithm=str(g["meta_algo"]),
+        domain=float(g["meta_domain"]), flooring=_floor(g),
+        normalization=bool(g["meta_normalization"]),
+        scale_restoration=bool(g["meta_scale_restoration"]),
+    )
+    m.reset(g["X"], basis=g["basis0"], activation=g["activation0"])
+    losses = [m.compute_loss()]
+    for k in range(1, int(g["meta_n_iter"]) + 1):
+        m.update_once()
+        losses.append(m.compute_loss())
+        _check_snapshots(g, k, m, ["demix_filter", "output", "basis", "activation"])
+    np.testing.assert_allclose(losses, g["loss"], rtol=1e-10)
+    if m.scale_restoration:
+        m.restore_scale()
+    if m.demix_filter is not None:
+        m.output = sp.separate(m.input, m.demix_filter)
+        assert rel_err(m.demix_filter, g["final_demix_filter"]) < TOL
+    assert rel_err(m.output, g["final_output"]) < TOL
+
+
+def test_gauss_ilrma_kat1_scalars():
+    """KAT-1 of SURVEY.md section 8c, via run()."""
+    g = load_golden("gilrma_ip1_n2")
+    m = GaussILRMAOracle(n_basis=2, spatial_algorithm="IP")
+    Y = m.run(g["X"], n_iter=10, basis=g["basis0"], activation=g["activation0"])
+    assert m.loss[0] == pytest.approx(251.143395021126, rel=1e-11)
+    assert m.loss[10] == pytest.approx(53.191617258319, rel=1e-11)
+    assert Y[0, 0, 0] == pytest.approx(0.19347346183741757 - 0.2616337924299037j, rel=1e-10)
+    assert np.sum(np.abs(Y) ** 2) == pytest.approx(1107.737755038587, rel=1e-11)
+
+
+@pytest.mark.parametrize("case", IVA_CASES)
+def test_aux_iva(case):
+    g = load_golden(case)
+    m = AuxIVAOracle(
+        spatial_algorithm=str(g["meta_algo"]), contrast=str(g["meta_contrast"]),
+        flooring=_floor(g), scale_restoration=bool(g["meta_scale_restoration"]),
+    )
+    m.reset(g["X"])
+    losses = [m.compute_loss()]
+    for k in range(1, int(g["meta_n_iter"]) + 1):
+        m.update_once()
+        losses.append(m.compute_loss())
+        _check_snapshots(g, k, m, ["demix_filter", "output", "variance"])
+    np.testing.assert_allclose(losses, g["loss"], rtol=1e-10)
+    if m.scale_restoration:
+        m.restore_scale()
+    if m.demix_filter is not None:
+        m.output = sp.separate(m.input, m.demix_filter)
+        assert rel_err(m.demix_filter, g["final_demix_filter"]) < TOL
+    assert rel_err(m.output, g["final_output"]) < TOL
+
+
+@pytest.mark.parametrize("case,algo", [("kat_auxlap_ip1_config1", "IP"), ("kat_auxlap_iss1_config1", "ISS")])
+def test_aux_iva_config1_kat(case, algo):
+    """BASELINE.json configs[0] (N=2, F=257, T=128, 10 it): known-answer scalars."""
+    g = load_golden(case)
+    N, F, T = (int(v) for v in g["meta_shape"])
+    rng = np.random.default_rng(int(g["meta_seed"]))
+    X = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+    m = AuxIVAOracle(spatial_algorithm=algo, contrast="laplace")
+    Y = m.run(X, n_iter=int(g["meta_n_iter"]))
+    np.testing.assert_allclose(m.loss, g["loss"], rtol=1e-10)
+    assert Y[0, 0, 0] == pytest.approx(complex(g["kat_y000"]), rel=1e-9)
+    assert np.sum(np.abs(Y) ** 2) == pytest.approx(float(g["kat_energy"]), rel=1e-10)
+
+
+@pytest.mark.parametrize("case", MNMF_CASES)
+def test_fast_gauss_mnmf(case):
+    g = load_golden(case)
+    n_sources = int(g["meta_n_sources"])
+    m = FastGaussMNMFOracle(
+        n_basis=int(g["meta_n_basis"]), n_sources=n_sources, flooring=_floor(g),
+        normalization=bool(g["meta_normalization"]),
+    )
+    m.reset(g["X"], basis=g["basis0"], activation=g["activation0"], spatial=g["spatial0"].copy())
+    losses = [m.compute_loss()]
+    for k in range(1, int(g["meta_n_iter"]) + 1):
+        m.update_once()
+        losses.append(m.compute_loss())
+        _check_snapshots(g, k, m, ["diagonalizer", "spatial", "basis", "activation"])
+    np.testing.assert_allclose(losses, g["loss"], rtol=1e-10)
+    Y = m.separate(m.input)
+    assert rel_err(Y, g["final_output"]) < 1e-9
+
+
+@pytest.mark.parametrize("N", [2, 3, 4, 8])
+def test_operators(N):
+    g = load_golden("operators")
+    p = lambda s: g[s.format(N)]  # noqa: E731
+    assert rel_err(sp.update_by_ip1(p("ip1_n{}_W"), p("ip1_n{}_U")), p("ip1_n{}_out")) < TOL
+    assert rel_err(sp.update_by_ip1(p("ip1_n{}_W"), p("ip1_n{}_U"), ("add", 1e-3)), p("ip1_n{}_out_add")) < TOL
+    assert rel_err(sp.update_by_iss1(p("iss1_n{}_Y"), p("iss1_n{}_varphi")), p("iss1_n{}_out")) < TOL
+    assert rel_err(sp.update_by_iss1(p("iss1_n{}_Y"), p("iss1_n{}_varphi")[:, :1, :]), p("iss1_n{}_out_bcast")) < TOL
+    assert rel_err(sp.projection_back_filter(p("ip1_n{}_W"), 1), p("pb_n{}_filter")) < TOL
+    assert rel_err(sp.projection_back_output(p("iss1_n{}_Y"), p("pb_n{}_X"), 0), p("pb_n{}_output")) < TOL
+    assert rel_err(sp.to_psd(p("psd_n{}_in")), p("psd_n{}_out")) < TOL
+
+
+def test_inv2():
+    g = load_golden("operators")
+    assert rel_err(sp.inv2(g["inv2_in"]), g["inv2_out"]) < 1e-13
