@@ -1,0 +1,195 @@
+/*
+ * ssspy_amd.h -- C ABI of the MI355X (gfx950) hot-path library libssspy_amd.so
+ *
+ * Drop-in boundary for the iterative frequency-domain demixing path of
+ * tky823/ssspy v0.2.0.  The reference has no FFI layer:
+ * the "operators" below are the NumPy expression groups inside the reference's
+ * separator methods, and each entry point cites the reference lines it replaces.
+ *
+ * Conventions
+ *  - every array argument is a DEVICE pointer to C-contiguous fp64 / complex128
+ *    data (complex128 = two doubles, re then im, as numpy.complex128);
+ *  - shapes carry a leading batch axis B of independent mixtures; the reference
+ *    shapes follow it unchanged, e.g. X is (B, N, F, T), W is (B, F, N, N),
+ *    basis (B, N, F, K), activation (B, N, K, T);
+ *    N = n_sources = n_channels, F = n_bins, T = n_frames, K = n_basis;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); every
+ *    call only enqueues work and returns; nothing here synchronises;
+ *  - the callee never allocates or frees device memory: scratch is passed in
+ *    (`*_workspace_bytes` tells how much) and outputs are caller-allocated;
+ *  - return value: 0 on success, an SSSPY_ERR_* code otherwise
+ *    (ssspy_last_error() gives the message); no C++ exception crosses the ABI;
+ *  - singular per-bin systems (reference: numpy.linalg.LinAlgError from
+ *    np.linalg.solve / inv) are counted into the caller's `int *info` device
+ *    word; the host reads it when it next synchronises.
+ *  - flooring (reference: ssspy/special/flooring.py:6-18) is named by
+ *    (floor_kind, floor_eps): NONE = identity, MAX = max(x, eps), ADD = x + eps.
+ */
+#ifndef SSSPY_AMD_H
+#define SSSPY_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  SSSPY_OK = 0,
+  SSSPY_ERR_BADARG = 1,      /* shape / enum outside what the kernels support */
+  SSSPY_ERR_HIP = 2,         /* a HIP runtime call failed */
+  SSSPY_ERR_UNSUPPORTED = 3, /* valid reference configuration not built here */
+};
+
+enum { SSSPY_FLOOR_NONE = 0, SSSPY_FLOOR_MAX = 1, SSSPY_FLOOR_ADD = 2 };
+
+/* weight layouts accepted by ssspy_weighted_covariance */
+enum {
+  SSSPY_WEIGHT_UNIT = 0,       /* weight == 1, one weight set                    */
+  SSSPY_WEIGHT_FRAME = 1,      /* weight (B, S, T): broadcast over bins (AuxIVA) */
+  SSSPY_WEIGHT_BIN_FRAME = 2,  /* weight (B, S, F, T)                            */
+};
+
+/* contrast functions of AuxIVA (reference: iva.py:3093-3115, :3256-3289) */
+enum { SSSPY_CONTRAST_LAPLACE = 0, SSSPY_CONTRAST_GAUSS = 1 };
+
+#define SSSPY_MAX_SOURCES 8
+#define SSSPY_MAX_BASIS 64
+
+const char *ssspy_amd_version(void);
+const char *ssspy_last_error(void);
+
+/* ------------------------------------------------------------------ shared operators */
+
+/* Y[b,n,i,j] = sum_m W[b,i,n,m] X[b,m,i,j].   X (B,N,F,T), W (B,F,N,N), Y (B,N,F,T).
+ * In-place (Y == X) is allowed: every (bin, frame) column is read before it is written.
+ * replaces: ssspy/bss/ilrma.py:272-295, ssspy/bss/iva.py:171-194 (separate). */
+int ssspy_separate(const void *X, const void *W, void *Y, int B, int N, int F, int T,
+                   void *stream);
+
+/* U[b,i,s,a,c] = (1/T) sum_j weight[...] A[b,a,i,j] conj(A[b,c,i,j]), s < S.
+ * A (B,N,F,T) complex, U (B,F,S,N,N) complex, weight per `weight_kind`.
+ * replaces: the (F,N,N,N,T) broadcast + mean of ssspy/bss/ilrma.py:1500-1505,
+ * ssspy/bss/iva.py:1785-1791, ssspy/bss/mnmf.py:1504-1512. */
+int ssspy_weighted_covariance(const void *A, const double *weight, int weight_kind, void *U,
+                              int B, int N, int S, int F, int T, void *stream);
+
+/* C[b,i,a,c] = (1/T) sum_j A[b,a,i,j] conj(Bm[b,c,i,j]).  A, Bm (B,N,F,T), C (B,F,N,N).  replaces the X Y^H / Y Y^H / X X^H products of
+ * ssspy/algorithm/projection_back.py:104-110, ssspy/bss/ilrma.py:1941-1944,
+ * ssspy/bss/iva.py:2182-2185 (up to the 1/T factor, which cancels there). */
+int ssspy_cross_covariance(const void *A, const void *Bm, void *C, int B, int N, int F, int T,
+                           void *stream);
+
+/* One iterative-projection sweep, in place on W.  W (B,F,N,N), U (B,F,N,N,N).
+ * `info` (device int, may be NULL) is incremented once per singular bin.
+ * replaces: ssspy/bss/_update_spatial_model.py:17-78 (update_by_ip1, overwrite=True). */
+int ssspy_update_by_ip1(void *W, const void *U, int B, int F, int N, int floor_kind,
+                        double floor_eps, int *info, void *stream);
+
+/* One iterative-source-steering sweep expressed on per-bin statistics:
+ * given Vc[b,i,s] = (1/T) sum_j varphi_s y y^H (B,F,N,N,N) it runs the N rank-1
+ * steps of the reference on the N x N matrices and returns the accumulated
+ * transform G (B,F,N,N) such that Y_new[:,i,:] = G_i Y[:,i,:].
+ * replaces: ssspy/bss/_update_spatial_model.py:146-194 (update_by_iss1). */
+int ssspy_iss1_transform(const void *Vc, void *G, int B, int F, int N, int floor_kind,
+                         double floor_eps, void *stream);
+
+/* W <- W * (W^-1)[ref,:]^T.  W (B,F,N,N) in place.
+ * replaces: ssspy/algorithm/projection_back.py:87-99. */
+int ssspy_projection_back_filter(void *W, int B, int F, int N, int reference_id, int *info,
+                                 void *stream);
+
+/* scale[b,i,n] = ((X Y^H)(Y Y^H)^-1)[ref, n] from XY (B,F,N,N) and YY (B,F,N,N);
+ * G[b,i] = diag(scale) so that ssspy_separate(Y, G) applies it.
+ * replaces: ssspy/algorithm/projection_back.py:100-121. */
+int ssspy_projection_back_scale(const void *XY, const void *YY, void *G, int B, int F, int N,
+                                int reference_id, int *info, void *stream);
+
+/* W[b,i] = YX[b,i] (XX[b,i])^-1.   replaces: ssspy/bss/ilrma.py:1941-1944, iva.py:2182-2185 */
+int ssspy_demix_from_covariance(const void *YX, const void *XX, void *W, int B, int F, int N,
+                                int *info, void *stream);
+
+/* out[b] = sum_i log|det W[b,i]|.   W (B,F,N,N), out (B) doubles.
+ * replaces: np.linalg.slogdet at ssspy/bss/ilrma.py:534, iva.py:234, mnmf.py:1274. */
+int ssspy_sum_logdet(const void *W, double *out, int B, int F, int N, void *stream);
+
+/* ------------------------------------------------------------------ GaussILRMA (IP1/ISS1, MM) */
+
+/* Scratch (bytes) the ILRMA entry points below may use for one call; sized for the largest. */
+size_t ssspy_ilrma_workspace_bytes(int B, int N, int F, int T, int K);
+
+/* basis update: T <- floor(T * (sum_j V P/R^((p+2)/p) / sum_j V/R)^(p/(p+2))), R = T V,
+ * P = |W X|^2 (or |X|^2 when W == NULL: the ISS path passes the separated spectrogram).
+ * replaces: ssspy/bss/ilrma.py:1051-1128 (update_basis_mm, no partitioning). */
+int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const double *activation,
+                             int B, int N, int F, int T, int K, double domain, int floor_kind,
+                             double floor_eps, void *workspace, size_t workspace_bytes,
+                             void *stream);
+
+/* activation update (sum over bins with the NEW basis).
+ * replaces: ssspy/bss/ilrma.py:1130-1204 (update_activation_mm, no partitioning). */
+int ssspy_ilrma_update_activation(const void *X, const void *W, const double *basis,
+                                  double *activation, int B, int N, int F, int T, int K,
+                                  double domain, int floor_kind, double floor_eps, void *workspace,
+                                  size_t workspace_bytes, void *stream);
+
+/* U[b,i,n] = (1/T) sum_j x x^H / (T V)^(2/p)   ->  U (B,F,N,N,N).
+ * replaces: ssspy/bss/ilrma.py:1494-1505 (weights) + the covariance broadcast. */
+int ssspy_ilrma_weighted_covariance(const void *X, const double *basis, const double *activation,
+                                    void *U, int B, int N, int F, int T, int K, double domain,
+                                    void *stream);
+
+/* power normalisation from the static covariance C (B,F,N,N) = (1/T) sum_j x x^H:
+ * psi_n = floor(sqrt(mean_i w_in^H C_i w_in)); W[:,n,:] /= psi_n; basis[n] /= psi_n^p.
+ * replaces: ssspy/bss/ilrma.py:365-444 (normalize_by_power, demix-filter branch). */
+int ssspy_ilrma_normalize_filter(void *W, const void *C, double *basis, int B, int N, int F, int K,
+                                 double domain, int floor_kind, double floor_eps, void *stream);
+
+/* same for the ISS state: psi from |Y|^2 directly, Y /= psi, basis /= psi^p.
+ * replaces: ssspy/bss/ilrma.py:365-444 (normalize_by_power, demix_filter is None branch). */
+int ssspy_ilrma_normalize_output(void *Y, double *basis, int B, int N, int F, int T, int K,
+                                 double domain, int floor_kind, double floor_eps, void *workspace,
+                                 size_t workspace_bytes, void *stream);
+
+/* varphi[b,n,i,j] = 1 / (T V)^(2/p)   (B,N,F,T) doubles, for the ISS1 path.
+ * replaces: ssspy/bss/ilrma.py:1690-1694. */
+int ssspy_ilrma_iss_weight(const double *basis, const double *activation, double *varphi, int B,
+                           int N, int F, int T, int K, double domain, void *stream);
+
+/* out[b] = sum_{n,i} mean_j ( |y|^2 / R^(2/p) + (2/p) log R ), y = W x (or x when W == NULL);
+ * `out` (B doubles) is zeroed by the call.  The caller adds -2 * ssspy_sum_logdet.
+ * replaces: ssspy/bss/ilrma.py:1946-1965. */
+int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
+                          const double *activation, double *out, int B, int N, int F, int T, int K,
+                          double domain, void *stream);
+
+/* One whole update_once() of GaussILRMA(spatial_algorithm="IP1", source_algorithm="MM"):
+ * basis, activation, weighted covariance, IP1, power normalisation -- the five launches the
+ * host would otherwise issue one by one.  U (B,F,N,N,N) is caller-provided scratch.
+ * replaces: ssspy/bss/ilrma.py:900-922. */
+int ssspy_gauss_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis,
+                                 double *activation, void *U, int B, int N, int F, int T, int K,
+                                 double domain, int normalize, int floor_kind, double floor_eps,
+                                 void *workspace, size_t workspace_bytes, int *info, void *stream);
+
+/* ------------------------------------------------------------------ AuxIVA (IP1/ISS1) */
+
+/* r2[b,n,j] = sum_i |y_nij|^2 with y = W x (or y = X when W == NULL).   r2 (B,N,T).
+ * replaces: np.linalg.norm(Y, axis=1) at ssspy/bss/iva.py:1787,1962 (squared). */
+int ssspy_iva_frame_power(const void *X, const void *W, double *r2, int B, int N, int F, int T,
+                          void *stream);
+
+/* weight[b,n,j] = G'(r)/floor(2 r), r = sqrt(r2); Gauss also refreshes variance = r2 / F.
+ * replaces: ssspy/bss/iva.py:1788-1789, :1963-1964, :3105-3115, :3273-3289, :3465-3473. */
+int ssspy_iva_weight(const double *r2, double *weight, double *variance, int B, int N, int F, int T,
+                     int contrast, int floor_kind, double floor_eps, void *stream);
+
+/* out[b] = sum_n mean_j G(y_nj) from r2 (and variance for Gauss).
+ * replaces: ssspy/bss/iva.py:216-219, :2181-2187 (contrast part of the loss). */
+int ssspy_iva_loss_data(const double *r2, const double *variance, double *out, int B, int N, int F,
+                        int T, int contrast, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSSPY_AMD_H */

@@ -1,0 +1,110 @@
+"""Build libssspy_amd.so (HIP, gfx950) in-tree with hipcc.
+
+``python -m ssspy_amd._build`` or ``ssspy_amd._build.build()``.  hipcc cross-compiles
+for gfx950 without a GPU.  Objects go to ``build/`` (git-ignored), the shared library to
+``ssspy_amd/lib/libssspy_amd.so`` (git-ignored, but shipped to the GPU box by gpurun).
+The per-N instantiations of the MFMA kernels are separate translation units so the build
+runs in parallel.
+"""
+
+import concurrent.futures
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+OBJ_DIR = os.path.join(ROOT, "build", "obj")
+LIB_PATH = os.path.join(PKG, "lib", "libssspy_amd.so")
+
+ARCH = "gfx950"
+CXXFLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-munsafe-fp-atomics",
+            "-I" + INCLUDE, "-I" + CSRC]
+
+ILRMA_N = list(range(2, 9))
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC=...)")
+
+
+def _units():
+    """(source, object name, extra flags)"""
+    units = [
+        ("spatial_kernels.hip", "spatial_kernels.o", []),
+        ("ilrma_api.hip", "ilrma_api.o", []),
+        ("iva_kernels.hip", "iva_kernels.o", []),
+    ]
+    if os.path.exists(os.path.join(CSRC, "mnmf_kernels.hip")):
+        units.append(("mnmf_kernels.hip", "mnmf_kernels.o", []))
+    for n in ILRMA_N:
+        units.append(("ilrma_kernels.hip", "ilrma_kernels_n{}.o".format(n), ["-DSSSPY_N={}".format(n)]))
+    return units
+
+
+def _digest(paths, flags):
+    h = hashlib.sha256(" ".join(flags).encode())
+    for p in sorted(paths):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    hs.append(os.path.join(INCLUDE, "ssspy_amd.h"))
+    return hs
+
+
+def _compile(hipcc, src, obj, extra, verbose):
+    src_path = os.path.join(CSRC, src)
+    obj_path = os.path.join(OBJ_DIR, obj)
+    stamp = obj_path + ".sha"
+    digest = _digest([src_path] + _headers(), CXXFLAGS + extra)
+    if os.path.exists(obj_path) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return obj_path
+    cmd = [hipcc] + CXXFLAGS + extra + ["-c", src_path, "-o", obj_path]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed for {}:\n{}".format(src, res.stderr))
+    with open(stamp, "w") as f:
+        f.write(digest)
+    return obj_path
+
+
+def build(verbose=False, jobs=None):
+    """Compile every HIP translation unit for gfx950 and link the shared library."""
+    hipcc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    units = _units()
+    jobs = jobs or min(len(units), os.cpu_count() or 4)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
+        futs = [pool.submit(_compile, hipcc, s, o, e, verbose) for s, o, e in units]
+        objs = [f.result() for f in futs]
+    link_stamp = LIB_PATH + ".sha"
+    digest = _digest(objs, [])
+    if os.path.exists(LIB_PATH) and os.path.exists(link_stamp) and open(link_stamp).read() == digest:
+        return LIB_PATH
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("link failed:\n{}".format(res.stderr))
+    with open(link_stamp, "w") as f:
+        f.write(digest)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(verbose="-v" in sys.argv))

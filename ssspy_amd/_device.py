@@ -1,0 +1,54 @@
+"""Device-memory plumbing (PyTorch-ROCm tensors as HBM buffers, HIP streams).
+
+PyTorch is used only as an allocator / stream provider / host<->device copier; every
+arithmetic kernel on the hot path is in libssspy_amd.so.
+"""
+
+import numpy as np
+import torch
+
+
+def device(index=None):
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "ssspy_amd needs a HIP device (torch.cuda.is_available() is False); "
+            "the demixing hot path has no CPU fallback"
+        )
+    if index is None:
+        index = torch.cuda.current_device()
+    return torch.device("cuda", index)
+
+
+def to_device(array, dtype=None, dev=None):
+    """Copy a NumPy array into a fresh contiguous HBM buffer (never aliases the input)."""
+    a = np.ascontiguousarray(array, dtype=dtype)
+    return torch.from_numpy(a).to(dev or device(), copy=True)
+
+
+def to_host(tensor):
+    return tensor.detach().cpu().numpy()
+
+
+def empty(shape, dtype, dev=None):
+    return torch.empty(tuple(int(s) for s in shape), dtype=dtype, device=dev or device())
+
+
+def zeros(shape, dtype, dev=None):
+    return torch.zeros(tuple(int(s) for s in shape), dtype=dtype, device=dev or device())
+
+
+def ptr(tensor):
+    if tensor is None:
+        return None
+    assert tensor.is_contiguous(), "device buffers must be C-contiguous"
+    return tensor.data_ptr()
+
+
+def stream_handle():
+    """hipStream_t of torch's current stream as an integer for ctypes."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+c128 = torch.complex128
+f64 = torch.float64
+i32 = torch.int32

@@ -1,0 +1,95 @@
+"""ctypes binding of libssspy_amd.so (the C ABI declared in include/ssspy_amd.h).
+
+The product path has no CPU fallback: if the shared library is missing or an entry point
+fails, an exception is raised.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libssspy_amd.so")
+
+OK, ERR_BADARG, ERR_HIP, ERR_UNSUPPORTED = 0, 1, 2, 3
+FLOOR_NONE, FLOOR_MAX, FLOOR_ADD = 0, 1, 2
+WEIGHT_UNIT, WEIGHT_FRAME, WEIGHT_BIN_FRAME = 0, 1, 2
+CONTRAST_LAPLACE, CONTRAST_GAUSS = 0, 1
+MAX_SOURCES, MAX_BASIS = 8, 64
+
+_p, _i, _d, _z = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/ssspy_amd.h one to one
+PROTOTYPES = {
+    "ssspy_amd_version": (ctypes.c_char_p, []),
+    "ssspy_last_error": (ctypes.c_char_p, []),
+    "ssspy_separate": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "ssspy_weighted_covariance": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "ssspy_cross_covariance": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "ssspy_update_by_ip1": (_i, [_p, _p, _i, _i, _i, _i, _d, _p, _p]),
+    "ssspy_iss1_transform": (_i, [_p, _p, _i, _i, _i, _i, _d, _p]),
+    "ssspy_projection_back_filter": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "ssspy_projection_back_scale": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "ssspy_demix_from_covariance": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
+    "ssspy_sum_logdet": (_i, [_p, _p, _i, _i, _i, _p]),
+    "ssspy_ilrma_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "ssspy_ilrma_update_basis": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p, _z, _p]),
+    "ssspy_ilrma_update_activation": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p, _z, _p]),
+    "ssspy_ilrma_weighted_covariance": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p]),
+    "ssspy_ilrma_normalize_filter": (_i, [_p, _p, _p, _i, _i, _i, _i, _d, _i, _d, _p]),
+    "ssspy_ilrma_normalize_output": (_i, [_p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p, _z, _p]),
+    "ssspy_ilrma_iss_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _d, _p]),
+    "ssspy_ilrma_loss_data": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p]),
+    "ssspy_gauss_ilrma_ip1_update": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _i, _d,
+                                          _p, _z, _p, _p]),
+    "ssspy_iva_frame_power": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "ssspy_iva_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _d, _p]),
+    "ssspy_iva_loss_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    """libssspy_amd.so is missing, fails to load, or an entry point returned an error."""
+
+
+def load():
+    """Load the shared library (once) and attach the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            "{} not found: build it with `python -m ssspy_amd._build` "
+            "(there is no CPU fallback for the device path)".format(LIB_PATH)
+        )
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise HipLibraryError("cannot load {}: {}".format(LIB_PATH, e)) from e
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    """Translate a C-ABI status into the Python exception the reference would raise."""
+    if rc == OK:
+        return
+    msg = load().ssspy_last_error().decode()
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError("{}: {}".format(what, msg))
+    if rc == ERR_BADARG:
+        raise ValueError("{}: {}".format(what, msg))
+    raise HipLibraryError("{}: {} (status {})".format(what, msg, rc))
+
+
+def raise_if_singular(count, what):
+    """Device kernels count singular per-bin systems; the reference raises LinAlgError."""
+    if count:
+        raise np.linalg.LinAlgError("Singular matrix ({} bin(s) in {})".format(int(count), what))

@@ -1,0 +1,237 @@
+"""Thin Python wrappers over the C ABI: torch HBM tensors in, torch HBM tensors out.
+
+Shapes carry the leading batch axis B (see include/ssspy_amd.h).  Nothing here
+synchronises with the device.
+"""
+
+from . import _device as dv
+from . import _lib
+from ._device import ptr
+
+
+def _L():
+    return _lib.load()
+
+
+def _st():
+    return dv.stream_handle()
+
+
+def separate(X, W, out=None):
+    B, N, F, T = X.shape
+    if out is None:
+        out = dv.empty((B, N, F, T), dv.c128, X.device)
+    _lib.check(_L().ssspy_separate(ptr(X), ptr(W), ptr(out), B, N, F, T, _st()), "separate")
+    return out
+
+
+def weighted_covariance(A, weight=None, kind=_lib.WEIGHT_UNIT, n_sets=1, out=None):
+    B, N, F, T = A.shape
+    if out is None:
+        out = dv.empty((B, F, n_sets, N, N), dv.c128, A.device)
+    _lib.check(
+        _L().ssspy_weighted_covariance(ptr(A), ptr(weight), kind, ptr(out), B, N, n_sets, F, T, _st()),
+        "weighted_covariance",
+    )
+    return out
+
+
+def cross_covariance(A, Bm, out=None):
+    B, N, F, T = A.shape
+    if out is None:
+        out = dv.empty((B, F, N, N), dv.c128, A.device)
+    _lib.check(_L().ssspy_cross_covariance(ptr(A), ptr(Bm), ptr(out), B, N, F, T, _st()),
+               "cross_covariance")
+    return out
+
+
+def update_by_ip1(W, U, flooring, info=None):
+    B, F, N, _ = W.shape
+    _lib.check(
+        _L().ssspy_update_by_ip1(ptr(W), ptr(U), B, F, N, flooring[0], flooring[1], ptr(info), _st()),
+        "update_by_ip1",
+    )
+    return W
+
+
+def iss1_transform(Vc, flooring, out=None):
+    B, F, N = Vc.shape[0], Vc.shape[1], Vc.shape[-1]
+    if out is None:
+        out = dv.empty((B, F, N, N), dv.c128, Vc.device)
+    _lib.check(
+        _L().ssspy_iss1_transform(ptr(Vc), ptr(out), B, F, N, flooring[0], flooring[1], _st()),
+        "iss1_transform",
+    )
+    return out
+
+
+def projection_back_filter(W, reference_id, info=None):
+    B, F, N, _ = W.shape
+    _lib.check(
+        _L().ssspy_projection_back_filter(ptr(W), B, F, N, reference_id, ptr(info), _st()),
+        "projection_back_filter",
+    )
+    return W
+
+
+def projection_back_scale(XY, YY, reference_id, info=None, out=None):
+    B, F, N, _ = XY.shape
+    if out is None:
+        out = dv.empty((B, F, N, N), dv.c128, XY.device)
+    _lib.check(
+        _L().ssspy_projection_back_scale(ptr(XY), ptr(YY), ptr(out), B, F, N, reference_id,
+                                         ptr(info), _st()),
+        "projection_back_scale",
+    )
+    return out
+
+
+def demix_from_covariance(YX, XX, info=None, out=None):
+    B, F, N, _ = YX.shape
+    if out is None:
+        out = dv.empty((B, F, N, N), dv.c128, YX.device)
+    _lib.check(
+        _L().ssspy_demix_from_covariance(ptr(YX), ptr(XX), ptr(out), B, F, N, ptr(info), _st()),
+        "demix_from_covariance",
+    )
+    return out
+
+
+def sum_logdet(W, out=None):
+    B, F, N, _ = W.shape
+    if out is None:
+        out = dv.empty((B,), dv.f64, W.device)
+    _lib.check(_L().ssspy_sum_logdet(ptr(W), ptr(out), B, F, N, _st()), "sum_logdet")
+    return out
+
+
+# ----------------------------------------------------------------------------- ILRMA
+def ilrma_workspace(B, N, F, T, K, dev):
+    nbytes = int(_L().ssspy_ilrma_workspace_bytes(B, N, F, T, K))
+    return dv.empty(((nbytes + 7) // 8,), dv.f64, dev), nbytes
+
+
+def ilrma_update_basis(X, W, basis, activation, domain, flooring, ws, ws_bytes):
+    B, N, F, T = X.shape
+    K = basis.shape[-1]
+    _lib.check(
+        _L().ssspy_ilrma_update_basis(ptr(X), ptr(W), ptr(basis), ptr(activation), B, N, F, T, K,
+                                      domain, flooring[0], flooring[1], ptr(ws), ws_bytes, _st()),
+        "ilrma_update_basis",
+    )
+
+
+def ilrma_update_activation(X, W, basis, activation, domain, flooring, ws, ws_bytes):
+    B, N, F, T = X.shape
+    K = basis.shape[-1]
+    _lib.check(
+        _L().ssspy_ilrma_update_activation(ptr(X), ptr(W), ptr(basis), ptr(activation), B, N, F, T,
+                                           K, domain, flooring[0], flooring[1], ptr(ws), ws_bytes,
+                                           _st()),
+        "ilrma_update_activation",
+    )
+
+
+def ilrma_weighted_covariance(X, basis, activation, domain, out=None):
+    B, N, F, T = X.shape
+    K = basis.shape[-1]
+    if out is None:
+        out = dv.empty((B, F, N, N, N), dv.c128, X.device)
+    _lib.check(
+        _L().ssspy_ilrma_weighted_covariance(ptr(X), ptr(basis), ptr(activation), ptr(out), B, N, F,
+                                             T, K, domain, _st()),
+        "ilrma_weighted_covariance",
+    )
+    return out
+
+
+def ilrma_normalize_filter(W, C, basis, domain, flooring):
+    B, F, N, _ = W.shape
+    K = basis.shape[-1]
+    _lib.check(
+        _L().ssspy_ilrma_normalize_filter(ptr(W), ptr(C), ptr(basis), B, N, F, K, domain,
+                                          flooring[0], flooring[1], _st()),
+        "ilrma_normalize_filter",
+    )
+
+
+def ilrma_normalize_output(Y, basis, domain, flooring, ws, ws_bytes):
+    B, N, F, T = Y.shape
+    K = basis.shape[-1]
+    _lib.check(
+        _L().ssspy_ilrma_normalize_output(ptr(Y), ptr(basis), B, N, F, T, K, domain, flooring[0],
+                                          flooring[1], ptr(ws), ws_bytes, _st()),
+        "ilrma_normalize_output",
+    )
+
+
+def ilrma_iss_weight(basis, activation, domain, out=None):
+    B, N, F, K = basis.shape
+    T = activation.shape[-1]
+    if out is None:
+        out = dv.empty((B, N, F, T), dv.f64, basis.device)
+    _lib.check(
+        _L().ssspy_ilrma_iss_weight(ptr(basis), ptr(activation), ptr(out), B, N, F, T, K, domain,
+                                    _st()),
+        "ilrma_iss_weight",
+    )
+    return out
+
+
+def ilrma_loss_data(X, W, basis, activation, domain, out=None):
+    B, N, F, T = X.shape
+    K = basis.shape[-1]
+    if out is None:
+        out = dv.empty((B,), dv.f64, X.device)
+    _lib.check(
+        _L().ssspy_ilrma_loss_data(ptr(X), ptr(W), ptr(basis), ptr(activation), ptr(out), B, N, F,
+                                   T, K, domain, _st()),
+        "ilrma_loss_data",
+    )
+    return out
+
+
+def gauss_ilrma_ip1_update(X, C, W, basis, activation, U, domain, normalize, flooring, ws,
+                           ws_bytes, info):
+    B, N, F, T = X.shape
+    K = basis.shape[-1]
+    _lib.check(
+        _L().ssspy_gauss_ilrma_ip1_update(ptr(X), ptr(C), ptr(W), ptr(basis), ptr(activation),
+                                          ptr(U), B, N, F, T, K, domain, int(bool(normalize)),
+                                          flooring[0], flooring[1], ptr(ws), ws_bytes, ptr(info),
+                                          _st()),
+        "gauss_ilrma_ip1_update",
+    )
+
+
+# ------------------------------------------------------------------------------- IVA
+def iva_frame_power(X, W, out=None):
+    B, N, F, T = X.shape
+    if out is None:
+        out = dv.empty((B, N, T), dv.f64, X.device)
+    _lib.check(_L().ssspy_iva_frame_power(ptr(X), ptr(W), ptr(out), B, N, F, T, _st()),
+               "iva_frame_power")
+    return out
+
+
+def iva_weight(r2, n_bins, contrast, flooring, weight=None, variance=None):
+    B, N, T = r2.shape
+    if weight is None:
+        weight = dv.empty((B, N, T), dv.f64, r2.device)
+    _lib.check(
+        _L().ssspy_iva_weight(ptr(r2), ptr(weight), ptr(variance), B, N, n_bins, T, contrast,
+                              flooring[0], flooring[1], _st()),
+        "iva_weight",
+    )
+    return weight
+
+
+def iva_loss_data(r2, variance, n_bins, contrast, out=None):
+    B, N, T = r2.shape
+    if out is None:
+        out = dv.empty((B,), dv.f64, r2.device)
+    _lib.check(
+        _L().ssspy_iva_loss_data(ptr(r2), ptr(variance), ptr(out), B, N, n_bins, T, contrast, _st()),
+        "iva_loss_data",
+    )
+    return out

@@ -1,0 +1,83 @@
+"""Per-bin spatial update operators (NumPy in, NumPy out) running on the device.
+
+The operator-level seam of the reference (ssspy/bss/_update_spatial_model.py): pure
+functions on C-contiguous arrays.  Inputs may carry an extra leading batch axis.
+"""
+
+import functools
+from typing import Callable, Optional
+
+import numpy as np
+
+from .. import _device as dv
+from .. import _lib, _ops
+from ..special.flooring import max_flooring
+from ..utils.flooring import device_flooring
+
+EPS = 1e-10
+_DEFAULT_FLOOR = functools.partial(max_flooring, eps=EPS)
+
+
+def update_by_ip1(
+    demix_filter: np.ndarray,
+    weighted_covariance: np.ndarray,
+    flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = _DEFAULT_FLOOR,
+    overwrite: bool = True,
+) -> np.ndarray:
+    """Update demixing filters by iterative projection (ref: _update_spatial_model.py:17-78).
+
+    Args:
+        demix_filter: (n_bins, n_sources, n_channels) complex.
+        weighted_covariance: (n_bins, n_sources, n_channels, n_channels) complex.
+        flooring_fn: identity / max_flooring / add_flooring (optionally partial(..., eps=)).
+        overwrite: write the result back into ``demix_filter`` (and return it), as the
+            reference does.
+
+    Raises:
+        numpy.linalg.LinAlgError: if a bin's system ``W U_n`` is singular.
+    """
+    floor = device_flooring(flooring_fn)
+    batched = demix_filter.ndim == 4
+    W = dv.to_device(demix_filter if batched else demix_filter[None], dtype=np.complex128)
+    U = dv.to_device(weighted_covariance if batched else weighted_covariance[None],
+                     dtype=np.complex128)
+    info = dv.zeros((1,), dv.i32)
+    _ops.update_by_ip1(W, U, floor, info)
+    _lib.raise_if_singular(int(info.item()), "update_by_ip1")
+    out = dv.to_host(W)
+    out = out if batched else out[0]
+    if overwrite:
+        demix_filter[...] = out
+        return demix_filter
+    return out
+
+
+def update_by_iss1(
+    separated: np.ndarray,
+    weight: np.ndarray,
+    flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = _DEFAULT_FLOOR,
+) -> np.ndarray:
+    """Update separated spectrograms by iterative source steering (ref: :146-194).
+
+    Args:
+        separated: (n_sources, n_bins, n_frames) complex.
+        weight: (n_sources, n_bins, n_frames) or (n_sources, 1, n_frames) real.
+
+    Returns:
+        New array with the updated spectrograms.
+    """
+    floor = device_flooring(flooring_fn)
+    batched = separated.ndim == 4
+    Y = dv.to_device(separated if batched else separated[None], dtype=np.complex128)
+    wt = weight if batched else weight[None]
+    B, N, F, T = Y.shape
+    if wt.shape[2] == 1 and F != 1:
+        w = dv.to_device(wt[:, :, 0, :], dtype=np.float64)
+        kind = _lib.WEIGHT_FRAME
+    else:
+        w = dv.to_device(np.broadcast_to(wt, (B, N, F, T)), dtype=np.float64)
+        kind = _lib.WEIGHT_BIN_FRAME
+    Vc = _ops.weighted_covariance(Y, w, kind, N)
+    G = _ops.iss1_transform(Vc, floor)
+    out = dv.to_host(_ops.separate(Y, G))
+    return out if batched else out[0]

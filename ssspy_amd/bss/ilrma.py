@@ -1,0 +1,461 @@
+"""Independent low-rank matrix analysis (ILRMA) on MI355X.
+
+Drop-in separator classes for the reference's ``ssspy.bss.ilrma`` hot path
+(ssspy/bss/ilrma.py): same constructor arguments, ``__call__`` / ``update_once`` /
+``compute_loss`` protocol and state attributes, with every per-iteration computation done
+by the HIP kernels of ``libssspy_amd.so``.  Built here: ``GaussILRMA`` with
+``spatial_algorithm in {"IP", "IP1", "ISS", "ISS1"}``, ``source_algorithm="MM"``, no
+partitioning, power normalisation, projection-back scale restoration.  Configurations of
+the reference that are not built yet raise ``NotImplementedError`` (never a CPU fallback).
+
+Extension over the reference: ``input`` may be 4-D ``(n_mixtures, n_channels, n_bins,
+n_frames)``; the mixtures are independent and every attribute then carries the same
+leading axis (``loss`` entries become arrays of length ``n_mixtures``).
+"""
+
+import functools
+from typing import Callable, Iterable, List, Optional, Tuple, Union
+
+import numpy as np
+
+from .. import _device as dv
+from .. import _lib, _ops
+from ..special.flooring import identity, max_flooring
+from ..utils.flooring import choose_flooring_fn, device_flooring
+from ..utils.select_pair import sequential_pair_selector
+from ._device_state import DeviceStateMixin, Synced
+from .base import IterativeMethodBase
+
+__all__ = ["GaussILRMA"]
+
+spatial_algorithms = ["IP", "IP1", "IP2", "ISS", "ISS1", "ISS2", "IPA"]
+source_algorithms = ["MM", "ME"]
+EPS = 1e-10
+
+_IP1 = ("IP", "IP1")
+_ISS1 = ("ISS", "ISS1")
+_PROJECTION_BACK = ("projection_back",)
+_MDP = ("minimal_distortion_principle",)
+
+
+class ILRMABase(DeviceStateMixin, IterativeMethodBase):
+    """State handling shared by the ILRMA variants (ref: ssspy/bss/ilrma.py:32-579)."""
+
+    demix_filter = Synced(dv.c128)
+    output = Synced(dv.c128)
+    basis = Synced(dv.f64)
+    activation = Synced(dv.f64)
+
+    def __init__(
+        self,
+        n_basis: int,
+        partitioning: bool = False,
+        flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = functools.partial(
+            max_flooring, eps=EPS
+        ),
+        callbacks=None,
+        scale_restoration: Union[bool, str] = True,
+        record_loss: bool = True,
+        reference_id: int = 0,
+        rng: Optional[np.random.Generator] = None,
+    ) -> None:
+        super().__init__(callbacks=callbacks, record_loss=record_loss)
+        self.n_basis = n_basis
+        self.partitioning = partitioning
+        self.flooring_fn = identity if flooring_fn is None else flooring_fn
+        self.input = None
+        self.scale_restoration = scale_restoration
+        if reference_id is None and scale_restoration:
+            raise ValueError("Specify 'reference_id' if scale_restoration=True.")
+        self.reference_id = reference_id
+        self.rng = np.random.default_rng() if rng is None else rng
+
+    # -- shapes -----------------------------------------------------------------------
+    def _bind_input(self, input: np.ndarray) -> None:
+        if input.ndim not in (3, 4):
+            raise ValueError(
+                "input must be (n_channels, n_bins, n_frames) or "
+                "(n_mixtures, n_channels, n_bins, n_frames), got shape {}".format(input.shape)
+            )
+        self._batched = input.ndim == 4
+        self.input = input.copy()
+        X4 = self.input if self._batched else self.input[None]
+        self._X = dv.to_device(X4, dtype=np.complex128)
+        self._static_cov = None
+
+    def _lead(self) -> Tuple[int, ...]:
+        return (self._X.shape[0],) if self._batched else ()
+
+    def _C(self):
+        """Static covariance C_i = (1/T) sum_j x_ij x_ij^H, (B, F, N, N), computed once per call."""
+        if self._static_cov is None:
+            B, N, F, T = self._X.shape
+            self._static_cov = _ops.weighted_covariance(self._X).reshape(B, F, N, N)
+        return self._static_cov
+
+    # -- reset ------------------------------------------------------------------------
+    def _reset(self, flooring_fn="self", **kwargs) -> None:
+        """ref: ssspy/bss/ilrma.py:151-199."""
+        assert self.input is not None, "Specify data!"
+        flooring_fn = choose_flooring_fn(flooring_fn, method=self)
+        for key, value in kwargs.items():
+            setattr(self, key, value)
+        B, N, F, T = self._X.shape
+        self.n_sources, self.n_channels = N, N
+        self.n_bins, self.n_frames = F, T
+        if not self._state_has("demix_filter"):
+            W = np.tile(np.eye(N, dtype=np.complex128), self._lead() + (F, 1, 1))
+            self.demix_filter = W
+        elif not self._state_is_none("demix_filter"):
+            # private copy: the injected array is never written to
+            self.demix_filter = np.array(self.demix_filter, dtype=np.complex128, copy=True)
+        if self._state_is_none("demix_filter"):
+            # the reference calls separate(X, None) here, which fails as well
+            raise ValueError("demix_filter=None cannot be given at reset.")
+        self._state_set_dev("output", _ops.separate(self._X, self._state_dev("demix_filter")))
+        self._init_nmf(flooring_fn=flooring_fn, rng=self.rng)
+        self._floor = device_flooring(flooring_fn)
+        K = self.n_basis
+        self._ws, self._ws_bytes = _ops.ilrma_workspace(B, N, F, T, K, self._X.device)
+        self._U = None
+
+    def _init_nmf(self, flooring_fn="self", rng=None) -> None:
+        """ref: ssspy/bss/ilrma.py:201-270 (no partitioning)."""
+        flooring_fn = choose_flooring_fn(flooring_fn, method=self)
+        if rng is None:
+            rng = np.random.default_rng()
+        N, F, T, K = self.n_sources, self.n_bins, self.n_frames, self.n_basis
+        if self.partitioning:
+            raise NotImplementedError("partitioning=True is not built for the device path yet.")
+        if not self._state_has("basis"):
+            self.basis = flooring_fn(rng.random(self._lead() + (N, F, K)))
+        else:
+            self.basis = np.array(self.basis, dtype=np.float64, copy=True)
+        if not self._state_has("activation"):
+            self.activation = flooring_fn(rng.random(self._lead() + (N, K, T)))
+        else:
+            self.activation = np.array(self.activation, dtype=np.float64, copy=True)
+
+    # -- operators --------------------------------------------------------------------
+    def separate(self, input: np.ndarray, demix_filter: np.ndarray) -> np.ndarray:
+        """y_ij = W_i x_ij (ref: ssspy/bss/ilrma.py:272-295); NumPy in, NumPy out."""
+        batched = input.ndim == 4
+        X = dv.to_device(input if batched else input[None], dtype=np.complex128)
+        W = dv.to_device(demix_filter if batched else demix_filter[None], dtype=np.complex128)
+        Y = dv.to_host(_ops.separate(X, W))
+        return Y if batched else Y[0]
+
+    def reconstruct_nmf(self, basis, activation, latent=None) -> np.ndarray:
+        """R = T V (ref: ssspy/bss/ilrma.py:297-327); host-side convenience, not on the hot path."""
+        if latent is not None:
+            raise NotImplementedError("partitioning (latent) is not built for the device path yet.")
+        return basis @ activation
+
+    def _resolve_floor(self, flooring_fn):
+        if type(flooring_fn) is str and flooring_fn == "self":
+            return self._floor
+        return device_flooring(choose_flooring_fn(flooring_fn, method=self))
+
+    def _uses_filter(self) -> bool:
+        return not self._state_is_none("demix_filter")
+
+    # -- scale restoration ------------------------------------------------------------------
+    def restore_scale(self) -> None:
+        """ref: ssspy/bss/ilrma.py:538-555."""
+        scale_restoration = self.scale_restoration
+        assert scale_restoration, "Set self.scale_restoration=True."
+        if type(scale_restoration) is bool:
+            scale_restoration = _PROJECTION_BACK[0]
+        if scale_restoration in _PROJECTION_BACK:
+            self.apply_projection_back()
+        elif scale_restoration in _MDP:
+            self.apply_minimal_distortion_principle()
+        else:
+            raise ValueError("{} is not supported for scale restoration.".format(scale_restoration))
+
+    def apply_projection_back(self) -> None:
+        """ref: ssspy/bss/ilrma.py:557-565, :1969-1979; algorithm/projection_back.py:87-121."""
+        assert self.scale_restoration, "Set self.scale_restoration=True."
+        info = self._info_tensor()
+        if self._uses_filter():
+            W = self._state_dev("demix_filter")
+            _ops.projection_back_filter(W, self.reference_id, info)
+            self._state_touch("demix_filter")
+            self._state_set_dev("output", _ops.separate(self._X, W))
+        else:
+            Y = self._state_dev("output")
+            XY = _ops.cross_covariance(self._X, Y)
+            YY = _ops.cross_covariance(Y, Y)
+            G = _ops.projection_back_scale(XY, YY, self.reference_id, info)
+            _ops.separate(Y, G, out=Y)
+            self._state_touch("output")
+
+    def apply_minimal_distortion_principle(self) -> None:
+        raise NotImplementedError(
+            "scale_restoration='minimal_distortion_principle' is not built for the device path yet."
+        )
+
+    def _host_loss(self, data, logdet_sum):
+        """loss = data term - 2 sum_i log|det W_i|, combined on the host (B numbers each)."""
+        self._check_device_errors()
+        values = dv.to_host(data) - 2.0 * dv.to_host(logdet_sum)
+        return values.copy() if self._batched else values[0].item()
+
+
+class GaussILRMA(ILRMABase):
+    """Gauss-ILRMA (ref: ssspy/bss/ilrma.py:582-1989).
+
+    Args mirror the reference: ``n_basis``, ``spatial_algorithm`` ("IP"/"IP1"/"ISS"/"ISS1"
+    on device), ``source_algorithm`` ("MM"), ``domain`` in (0, 2], ``partitioning`` (False),
+    ``flooring_fn``, ``pair_selector``, ``callbacks``, ``normalization`` (True / "power" /
+    False), ``scale_restoration`` (True / "projection_back" / False), ``record_loss``,
+    ``reference_id``, ``rng``.
+    """
+
+    _ipa_default_kwargs = {"newton_iter": 1}
+    _default_kwargs = _ipa_default_kwargs
+
+    def __init__(
+        self,
+        n_basis: int,
+        spatial_algorithm: str = "IP",
+        source_algorithm: str = "MM",
+        domain: float = 2,
+        partitioning: bool = False,
+        flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = functools.partial(
+            max_flooring, eps=EPS
+        ),
+        pair_selector: Optional[Callable[[int], Iterable[Tuple[int, int]]]] = None,
+        callbacks: Optional[Union[Callable, List[Callable]]] = None,
+        normalization: Optional[Union[bool, str]] = True,
+        scale_restoration: Union[bool, str] = True,
+        record_loss: bool = True,
+        reference_id: int = 0,
+        rng: Optional[np.random.Generator] = None,
+        **kwargs,
+    ) -> None:
+        super().__init__(
+            n_basis=n_basis,
+            partitioning=partitioning,
+            flooring_fn=flooring_fn,
+            callbacks=callbacks,
+            scale_restoration=scale_restoration,
+            record_loss=record_loss,
+            reference_id=reference_id,
+            rng=rng,
+        )
+        assert spatial_algorithm in spatial_algorithms, "Not support {}.".format(spatial_algorithm)
+        assert source_algorithm in source_algorithms, "Not support {}.".format(source_algorithm)
+        assert 0 < domain <= 2, "domain parameter should be chosen from [0, 2]."
+        if source_algorithm == "ME":
+            assert domain == 2, "domain parameter should be 2 when you specify ME algorithm."
+        if spatial_algorithm not in _IP1 + _ISS1:
+            raise NotImplementedError(
+                "spatial_algorithm={!r} is not built for the device path yet "
+                "(available: IP, IP1, ISS, ISS1).".format(spatial_algorithm)
+            )
+        if source_algorithm != "MM":
+            raise NotImplementedError("source_algorithm='ME' is not built for the device path yet.")
+        if partitioning:
+            raise NotImplementedError("partitioning=True is not built for the device path yet.")
+        self.spatial_algorithm = spatial_algorithm
+        self.source_algorithm = source_algorithm
+        self.domain = domain
+        self.normalization = normalization
+        if pair_selector is None:
+            if spatial_algorithm in ["IP2", "ISS2"]:
+                self.pair_selector = sequential_pair_selector
+        else:
+            self.pair_selector = pair_selector
+        valid_keys = set(self._ipa_default_kwargs) if spatial_algorithm == "IPA" else set()
+        invalid_keys = set(kwargs) - valid_keys
+        assert invalid_keys == set(), "Invalid keywords {} are given.".format(invalid_keys)
+        # fails early (before any upload) when the floor cannot run on the device
+        device_flooring(self.flooring_fn)
+
+    def __call__(
+        self, input: np.ndarray, n_iter: int = 100, initial_call: bool = True, **kwargs
+    ) -> np.ndarray:
+        """Separate a frequency-domain multichannel mixture.
+
+        Args:
+            input: ``(n_channels, n_bins, n_frames)`` complex (or 4-D batch of such).
+            n_iter: number of ``update_once`` rounds.
+            initial_call: run loss/callbacks once before iterating.
+            kwargs: attributes to inject before initialisation (``basis``, ``activation``,
+                ``demix_filter``), as in the reference.
+
+        Returns:
+            Separated spectrograms, same shape as ``input``.
+        """
+        self._bind_input(input)
+        self._reset(flooring_fn=self.flooring_fn, **kwargs)
+        IterativeMethodBase.__call__(self, n_iter=n_iter, initial_call=initial_call)
+        if self.scale_restoration:
+            self.restore_scale()
+        if self._uses_filter():
+            self._state_set_dev("output", _ops.separate(self._X, self._state_dev("demix_filter")))
+        return self.output
+
+    def __repr__(self) -> str:
+        s = "GaussILRMA(n_basis={}, spatial_algorithm={}, source_algorithm={}, domain={}".format(
+            self.n_basis, self.spatial_algorithm, self.source_algorithm, self.domain
+        )
+        s += ", partitioning={}, normalization={}, scale_restoration={}, record_loss={}".format(
+            self.partitioning, self.normalization, self.scale_restoration, self.record_loss
+        )
+        if self.scale_restoration:
+            s += ", reference_id={}".format(self.reference_id)
+        return s + ")"
+
+    def _reset(self, flooring_fn="self", **kwargs) -> None:
+        """ref: ssspy/bss/ilrma.py:875-898."""
+        flooring_fn = choose_flooring_fn(flooring_fn, method=self)
+        super()._reset(flooring_fn=flooring_fn, **kwargs)
+        if self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"]:
+            self.demix_filter = None
+
+    # -- one iteration -----------------------------------------------------------------------
+    def _is_stock(self) -> bool:
+        cls = type(self)
+        return all(
+            getattr(cls, name) is getattr(GaussILRMA, name)
+            for name in ("update_source_model", "update_spatial_model", "normalize",
+                         "update_basis_mm", "update_activation_mm", "update_spatial_model_ip1",
+                         "normalize_by_power")
+        )
+
+    def update_once(self, flooring_fn="self") -> None:
+        """Source model (basis, activation), spatial model, normalisation.
+
+        ref: ssspy/bss/ilrma.py:900-922.  With the stock methods and the IP1 path the whole
+        iteration is one C-ABI call (five kernel launches on the current stream).
+        """
+        if self._uses_filter() and self._is_stock() and self._power_normalization_or_off():
+            floor = self._resolve_floor(flooring_fn)
+            B, N, F, T = self._X.shape
+            if self._U is None:
+                self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
+            _ops.gauss_ilrma_ip1_update(
+                self._X, self._C() if self.normalization else None,
+                self._state_dev("demix_filter"), self._state_dev("basis"),
+                self._state_dev("activation"), self._U, float(self.domain),
+                bool(self.normalization), floor, self._ws, self._ws_bytes, self._info_tensor(),
+            )
+            for name in ("demix_filter", "basis", "activation"):
+                self._state_touch(name)
+            return
+        self.update_source_model(flooring_fn=flooring_fn)
+        self.update_spatial_model(flooring_fn=flooring_fn)
+        if self.normalization:
+            self.normalize(flooring_fn=flooring_fn)
+
+    def _power_normalization_or_off(self) -> bool:
+        return (not self.normalization) or type(self.normalization) is bool \
+            or self.normalization == "power"
+
+    def update_source_model(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/ilrma.py:924-978."""
+        if self.source_algorithm == "MM":
+            self.update_source_model_mm(flooring_fn=flooring_fn)
+        else:
+            raise NotImplementedError("source_algorithm='ME' is not built for the device path yet.")
+
+    def update_source_model_mm(self, flooring_fn="self") -> None:
+        self.update_basis_mm(flooring_fn=flooring_fn)
+        self.update_activation_mm(flooring_fn=flooring_fn)
+
+    def _source_and_filter(self):
+        """(spectrogram tensor, filter tensor or None) whose |W x|^2 the MM updates use."""
+        if self._uses_filter():
+            return self._X, self._state_dev("demix_filter")
+        return self._state_dev("output"), None
+
+    def update_basis_mm(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/ilrma.py:1051-1128."""
+        src, W = self._source_and_filter()
+        _ops.ilrma_update_basis(src, W, self._state_dev("basis"), self._state_dev("activation"),
+                                float(self.domain), self._resolve_floor(flooring_fn), self._ws,
+                                self._ws_bytes)
+        self._state_touch("basis")
+
+    def update_activation_mm(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/ilrma.py:1130-1204."""
+        src, W = self._source_and_filter()
+        _ops.ilrma_update_activation(src, W, self._state_dev("basis"),
+                                     self._state_dev("activation"), float(self.domain),
+                                     self._resolve_floor(flooring_fn), self._ws, self._ws_bytes)
+        self._state_touch("activation")
+
+    def update_spatial_model(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/ilrma.py:1403-1438."""
+        if self.spatial_algorithm in _IP1:
+            self.update_spatial_model_ip1(flooring_fn=flooring_fn)
+        elif self.spatial_algorithm in _ISS1:
+            self.update_spatial_model_iss1(flooring_fn=flooring_fn)
+        else:
+            raise NotImplementedError("Not support {}.".format(self.spatial_algorithm))
+
+    def update_spatial_model_ip1(self, flooring_fn="self") -> None:
+        """Weighted covariance + iterative projection.  ref: ssspy/bss/ilrma.py:1440-1507."""
+        B, N, F, T = self._X.shape
+        if self._U is None:
+            self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
+        _ops.ilrma_weighted_covariance(self._X, self._state_dev("basis"),
+                                       self._state_dev("activation"), float(self.domain),
+                                       out=self._U)
+        _ops.update_by_ip1(self._state_dev("demix_filter"), self._U,
+                           self._resolve_floor(flooring_fn), self._info_tensor())
+        self._state_touch("demix_filter")
+
+    def update_spatial_model_iss1(self, flooring_fn="self") -> None:
+        """Iterative source steering on per-bin statistics.  ref: ssspy/bss/ilrma.py:1635-1696."""
+        Y = self._state_dev("output")
+        N = Y.shape[1]
+        varphi = _ops.ilrma_iss_weight(self._state_dev("basis"), self._state_dev("activation"),
+                                       float(self.domain))
+        Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
+        G = _ops.iss1_transform(Vc, self._resolve_floor(flooring_fn))
+        _ops.separate(Y, G, out=Y)
+        self._state_touch("output")
+
+    def normalize(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/ilrma.py:333-363."""
+        normalization = self.normalization
+        assert normalization, "Set normalization."
+        if type(normalization) is bool:
+            normalization = "power"
+        if normalization == "power":
+            self.normalize_by_power(flooring_fn=flooring_fn)
+        elif normalization == "projection_back":
+            raise NotImplementedError(
+                "normalization='projection_back' is not built for the device path yet."
+            )
+        else:
+            raise NotImplementedError("Normalization {} is not implemented.".format(normalization))
+
+    def normalize_by_power(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/ilrma.py:365-444 (no partitioning)."""
+        floor = self._resolve_floor(flooring_fn)
+        if self._uses_filter():
+            _ops.ilrma_normalize_filter(self._state_dev("demix_filter"), self._C(),
+                                        self._state_dev("basis"), float(self.domain), floor)
+            self._state_touch("demix_filter")
+        else:
+            _ops.ilrma_normalize_output(self._state_dev("output"), self._state_dev("basis"),
+                                        float(self.domain), floor, self._ws, self._ws_bytes)
+            self._state_touch("output")
+        self._state_touch("basis")
+
+    def compute_loss(self) -> float:
+        """Negative log-likelihood (ref: ssspy/bss/ilrma.py:1910-1967)."""
+        T, V = self._state_dev("basis"), self._state_dev("activation")
+        if self._uses_filter():
+            W = self._state_dev("demix_filter")
+            data = _ops.ilrma_loss_data(self._X, W, T, V, float(self.domain))
+        else:
+            Y = self._state_dev("output")
+            W = _ops.demix_from_covariance(_ops.cross_covariance(Y, self._X), self._C(),
+                                           self._info_tensor())
+            data = _ops.ilrma_loss_data(Y, None, T, V, float(self.domain))
+        return self._host_loss(data, _ops.sum_logdet(W))

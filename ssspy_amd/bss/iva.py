@@ -1,0 +1,434 @@
+"""Auxiliary-function independent vector analysis (AuxIVA) on MI355X.
+
+Drop-in separator classes for the ``AuxIVA`` family of the reference's ``ssspy.bss.iva``
+(ssspy/bss/iva.py:553-641, :1403-2214, :2976-3473): ``AuxIVA``, ``AuxLaplaceIVA`` and
+``AuxGaussIVA`` with ``spatial_algorithm in {"IP", "IP1", "ISS", "ISS1"}``.  The contrast
+functions of the reference are Python closures; the kernels implement the two the
+reference ships (Laplace: G = 2r; time-varying Gauss: G = F log(alpha) + r^2/alpha).  A
+user-supplied closure cannot run inside a kernel and raises ``NotImplementedError``.
+The gradient / natural-gradient / Fast / PDS / ADMM IVA variants are out of scope
+(SURVEY.md section 2, row 3).
+"""
+
+import functools
+from typing import Callable, Iterable, List, Optional, Tuple, Union
+
+import numpy as np
+
+from .. import _device as dv
+from .. import _lib, _ops
+from ..special.flooring import identity, max_flooring
+from ..utils.flooring import choose_flooring_fn, device_flooring
+from ..utils.select_pair import sequential_pair_selector
+from ._device_state import DeviceStateMixin, Synced
+from .base import IterativeMethodBase
+
+__all__ = ["AuxIVA", "AuxLaplaceIVA", "AuxGaussIVA"]
+
+spatial_algorithms = ["IP", "IP1", "IP2", "ISS", "ISS1", "ISS2", "IPA"]
+EPS = 1e-10
+
+_IP1 = ("IP", "IP1")
+_ISS1 = ("ISS", "ISS1")
+_PROJECTION_BACK = ("projection_back",)
+_MDP = ("minimal_distortion_principle",)
+
+
+class IVABase(DeviceStateMixin, IterativeMethodBase):
+    """ref: ssspy/bss/iva.py:48-281."""
+
+    demix_filter = Synced(dv.c128)
+    output = Synced(dv.c128)
+
+    def __init__(
+        self,
+        flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = functools.partial(
+            max_flooring, eps=EPS
+        ),
+        callbacks=None,
+        scale_restoration: Union[bool, str] = True,
+        record_loss: bool = True,
+        reference_id: int = 0,
+    ) -> None:
+        super().__init__(callbacks=callbacks, record_loss=record_loss)
+        self.flooring_fn = identity if flooring_fn is None else flooring_fn
+        self.input = None
+        self.scale_restoration = scale_restoration
+        if reference_id is None and scale_restoration:
+            raise ValueError("Specify 'reference_id' if scale_restoration=True.")
+        self.reference_id = reference_id
+
+    def _bind_input(self, input: np.ndarray) -> None:
+        if input.ndim not in (3, 4):
+            raise ValueError(
+                "input must be (n_channels, n_bins, n_frames) or "
+                "(n_mixtures, n_channels, n_bins, n_frames), got shape {}".format(input.shape)
+            )
+        self._batched = input.ndim == 4
+        self.input = input.copy()
+        X4 = self.input if self._batched else self.input[None]
+        self._X = dv.to_device(X4, dtype=np.complex128)
+        self._static_cov = None
+
+    def _lead(self) -> Tuple[int, ...]:
+        return (self._X.shape[0],) if self._batched else ()
+
+    def _C(self):
+        if self._static_cov is None:
+            B, N, F, T = self._X.shape
+            self._static_cov = _ops.weighted_covariance(self._X).reshape(B, F, N, N)
+        return self._static_cov
+
+    def _reset(self, **kwargs) -> None:
+        """ref: ssspy/bss/iva.py:138-169."""
+        assert self.input is not None, "Specify data!"
+        for key, value in kwargs.items():
+            setattr(self, key, value)
+        B, N, F, T = self._X.shape
+        self.n_sources, self.n_channels = N, N
+        self.n_bins, self.n_frames = F, T
+        if not self._state_has("demix_filter"):
+            self.demix_filter = np.tile(np.eye(N, dtype=np.complex128), self._lead() + (F, 1, 1))
+        elif not self._state_is_none("demix_filter"):
+            self.demix_filter = np.array(self.demix_filter, dtype=np.complex128, copy=True)
+        if self._state_is_none("demix_filter"):
+            raise ValueError("demix_filter=None cannot be given at reset.")
+        self._state_set_dev("output", _ops.separate(self._X, self._state_dev("demix_filter")))
+        self._floor = device_flooring(self.flooring_fn)
+
+    def separate(self, input: np.ndarray, demix_filter: np.ndarray) -> np.ndarray:
+        """y_ij = W_i x_ij (ref: ssspy/bss/iva.py:171-194); NumPy in, NumPy out."""
+        batched = input.ndim == 4
+        X = dv.to_device(input if batched else input[None], dtype=np.complex128)
+        W = dv.to_device(demix_filter if batched else demix_filter[None], dtype=np.complex128)
+        Y = dv.to_host(_ops.separate(X, W))
+        return Y if batched else Y[0]
+
+    def _uses_filter(self) -> bool:
+        return not self._state_is_none("demix_filter")
+
+    def _resolve_floor(self, flooring_fn):
+        if type(flooring_fn) is str and flooring_fn == "self":
+            return self._floor
+        return device_flooring(choose_flooring_fn(flooring_fn, method=self))
+
+    def _host_loss(self, data, logdet_sum):
+        self._check_device_errors()
+        values = dv.to_host(data) - 2.0 * dv.to_host(logdet_sum)
+        return values.copy() if self._batched else values[0].item()
+
+    def restore_scale(self) -> None:
+        """ref: ssspy/bss/iva.py:238-257."""
+        scale_restoration = self.scale_restoration
+        assert scale_restoration, "Set self.scale_restoration=True."
+        if type(scale_restoration) is bool:
+            scale_restoration = _PROJECTION_BACK[0]
+        if scale_restoration in _PROJECTION_BACK:
+            self.apply_projection_back()
+        elif scale_restoration in _MDP:
+            self.apply_minimal_distortion_principle()
+        else:
+            raise ValueError("{} is not supported for scale restoration.".format(scale_restoration))
+
+    def apply_projection_back(self) -> None:
+        """ref: ssspy/bss/iva.py:259-267, :2194-2204; algorithm/projection_back.py:87-121."""
+        assert self.scale_restoration, "Set self.scale_restoration=True."
+        info = self._info_tensor()
+        if self._uses_filter():
+            W = self._state_dev("demix_filter")
+            _ops.projection_back_filter(W, self.reference_id, info)
+            self._state_touch("demix_filter")
+            self._state_set_dev("output", _ops.separate(self._X, W))
+        else:
+            Y = self._state_dev("output")
+            XY = _ops.cross_covariance(self._X, Y)
+            YY = _ops.cross_covariance(Y, Y)
+            G = _ops.projection_back_scale(XY, YY, self.reference_id, info)
+            _ops.separate(Y, G, out=Y)
+            self._state_touch("output")
+
+    def apply_minimal_distortion_principle(self) -> None:
+        raise NotImplementedError(
+            "scale_restoration='minimal_distortion_principle' is not built for the device path yet."
+        )
+
+
+class AuxIVABase(IVABase):
+    """ref: ssspy/bss/iva.py:553-641."""
+
+    def __init__(
+        self,
+        contrast_fn: Callable[[np.ndarray], np.ndarray] = None,
+        d_contrast_fn: Callable[[np.ndarray], np.ndarray] = None,
+        flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = functools.partial(
+            max_flooring, eps=EPS
+        ),
+        callbacks=None,
+        scale_restoration: Union[bool, str] = True,
+        record_loss: bool = True,
+        reference_id: int = 0,
+    ) -> None:
+        super().__init__(
+            flooring_fn=flooring_fn,
+            callbacks=callbacks,
+            scale_restoration=scale_restoration,
+            record_loss=record_loss,
+            reference_id=reference_id,
+        )
+        self.contrast_fn = contrast_fn
+        self.d_contrast_fn = d_contrast_fn
+
+
+def _device_contrast(contrast_fn, d_contrast_fn):
+    """Which built-in contrast the pair of callables stands for (tag set by the subclasses)."""
+    a = getattr(contrast_fn, "_ssspy_amd_contrast", None)
+    b = getattr(d_contrast_fn, "_ssspy_amd_contrast", None)
+    if a is None or a != b:
+        raise NotImplementedError(
+            "AuxIVA on the device path supports the Laplace and time-varying Gauss contrasts "
+            "(use AuxLaplaceIVA / AuxGaussIVA); arbitrary contrast_fn / d_contrast_fn closures "
+            "cannot be evaluated inside the HIP kernels."
+        )
+    return a
+
+
+class AuxIVA(AuxIVABase):
+    """Auxiliary-function-based IVA (ref: ssspy/bss/iva.py:1403-2214)."""
+
+    _ipa_default_kwargs = {"newton_iter": 1}
+    _default_kwargs = _ipa_default_kwargs
+
+    def __init__(
+        self,
+        spatial_algorithm: str = "IP",
+        contrast_fn: Callable[[np.ndarray], np.ndarray] = None,
+        d_contrast_fn: Callable[[np.ndarray], np.ndarray] = None,
+        flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = functools.partial(
+            max_flooring, eps=EPS
+        ),
+        pair_selector: Optional[Callable[[int], Iterable[Tuple[int, int]]]] = None,
+        callbacks: Optional[Union[Callable, List[Callable]]] = None,
+        scale_restoration: Union[bool, str] = True,
+        record_loss: bool = True,
+        reference_id: int = 0,
+        **kwargs,
+    ) -> None:
+        super().__init__(
+            contrast_fn=contrast_fn,
+            d_contrast_fn=d_contrast_fn,
+            flooring_fn=flooring_fn,
+            callbacks=callbacks,
+            scale_restoration=scale_restoration,
+            record_loss=record_loss,
+            reference_id=reference_id,
+        )
+        assert spatial_algorithm in spatial_algorithms, "Not support {}.".format(spatial_algorithm)
+        if spatial_algorithm not in _IP1 + _ISS1:
+            raise NotImplementedError(
+                "spatial_algorithm={!r} is not built for the device path yet "
+                "(available: IP, IP1, ISS, ISS1).".format(spatial_algorithm)
+            )
+        self.spatial_algorithm = spatial_algorithm
+        if pair_selector is None:
+            if spatial_algorithm in ["IP2", "ISS2"]:
+                self.pair_selector = sequential_pair_selector
+        else:
+            self.pair_selector = pair_selector
+        valid_keys = set(self._ipa_default_kwargs) if spatial_algorithm == "IPA" else set()
+        invalid_keys = set(kwargs) - valid_keys
+        assert invalid_keys == set(), "Invalid keywords {} are given.".format(invalid_keys)
+        device_flooring(self.flooring_fn)
+
+    def __call__(
+        self, input: np.ndarray, n_iter: int = 100, initial_call: bool = True, **kwargs
+    ) -> np.ndarray:
+        """Separate a frequency-domain multichannel mixture (ref: ssspy/bss/iva.py:1637-1672)."""
+        self._contrast = _device_contrast(self.contrast_fn, self.d_contrast_fn)
+        self._bind_input(input)
+        self._reset(**kwargs)
+        IterativeMethodBase.__call__(self, n_iter=n_iter, initial_call=initial_call)
+        if self.scale_restoration:
+            self.restore_scale()
+        if self._uses_filter():
+            self._state_set_dev("output", _ops.separate(self._X, self._state_dev("demix_filter")))
+        return self.output
+
+    def __repr__(self) -> str:
+        s = "AuxIVA(spatial_algorithm={}, scale_restoration={}, record_loss={}".format(
+            self.spatial_algorithm, self.scale_restoration, self.record_loss
+        )
+        if self.scale_restoration:
+            s += ", reference_id={}".format(self.reference_id)
+        return s + ")"
+
+    def _reset(self, **kwargs) -> None:
+        """ref: ssspy/bss/iva.py:1687-1697."""
+        super()._reset(**kwargs)
+        if self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"]:
+            self.demix_filter = None
+        self._variance_dev = None
+
+    def _variance_tensor(self):
+        return None
+
+    def _weights(self, flooring_fn):
+        """Auxiliary weights varphi_nj = G'(r_nj) / floor(2 r_nj), (B, N, T)."""
+        if self._uses_filter():
+            r2 = _ops.iva_frame_power(self._X, self._state_dev("demix_filter"))
+        else:
+            r2 = _ops.iva_frame_power(self._state_dev("output"), None)
+        return _ops.iva_weight(r2, self.n_bins, self._contrast, self._resolve_floor(flooring_fn),
+                               variance=self._variance_tensor())
+
+    def update_once(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/iva.py:1699-1734."""
+        if self.spatial_algorithm in _IP1:
+            self.update_once_ip1(flooring_fn=flooring_fn)
+        elif self.spatial_algorithm in _ISS1:
+            self.update_once_iss1(flooring_fn=flooring_fn)
+        else:
+            raise NotImplementedError("Not support {}.".format(self.spatial_algorithm))
+
+    def update_once_ip1(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/iva.py:1736-1793."""
+        N = self.n_sources
+        weight = self._weights(flooring_fn)
+        U = _ops.weighted_covariance(self._X, weight, _lib.WEIGHT_FRAME, N)
+        _ops.update_by_ip1(self._state_dev("demix_filter"), U, self._resolve_floor(flooring_fn),
+                           self._info_tensor())
+        self._state_touch("demix_filter")
+
+    def update_once_iss1(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/iva.py:1917-1966 and _update_spatial_model.py:146-194."""
+        N = self.n_sources
+        Y = self._state_dev("output")
+        weight = self._weights(flooring_fn)
+        Vc = _ops.weighted_covariance(Y, weight, _lib.WEIGHT_FRAME, N)
+        G = _ops.iss1_transform(Vc, self._resolve_floor(flooring_fn))
+        _ops.separate(Y, G, out=Y)
+        self._state_touch("output")
+
+    def compute_loss(self) -> float:
+        """ref: ssspy/bss/iva.py:200-222 (filter state), :2177-2192 (ISS state)."""
+        if self._uses_filter():
+            W = self._state_dev("demix_filter")
+            r2 = _ops.iva_frame_power(self._X, W)
+        else:
+            Y = self._state_dev("output")
+            r2 = _ops.iva_frame_power(Y, None)
+            W = _ops.demix_from_covariance(_ops.cross_covariance(Y, self._X), self._C(),
+                                           self._info_tensor())
+        data = _ops.iva_loss_data(r2, self._variance_tensor(), self.n_bins, self._contrast)
+        return self._host_loss(data, _ops.sum_logdet(W))
+
+
+class AuxLaplaceIVA(AuxIVA):
+    """AuxIVA with the spherical Laplace source model (ref: ssspy/bss/iva.py:2976-3128)."""
+
+    def __init__(
+        self,
+        spatial_algorithm: str = "IP",
+        flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = functools.partial(
+            max_flooring, eps=EPS
+        ),
+        pair_selector: Optional[Callable[[int], Iterable[Tuple[int, int]]]] = None,
+        callbacks: Optional[Union[Callable, List[Callable]]] = None,
+        scale_restoration: Union[bool, str] = True,
+        record_loss: bool = True,
+        reference_id: int = 0,
+        **kwargs,
+    ) -> None:
+        def contrast_fn(y: np.ndarray) -> np.ndarray:
+            """G(y) = 2 ||y||_2 over bins; y (n_sources, n_bins, n_frames)."""
+            return 2 * np.linalg.norm(y, axis=1)
+
+        def d_contrast_fn(y: np.ndarray) -> np.ndarray:
+            """G'(r) = 2."""
+            return 2 * np.ones_like(y)
+
+        contrast_fn._ssspy_amd_contrast = _lib.CONTRAST_LAPLACE
+        d_contrast_fn._ssspy_amd_contrast = _lib.CONTRAST_LAPLACE
+        super().__init__(
+            spatial_algorithm=spatial_algorithm,
+            contrast_fn=contrast_fn,
+            d_contrast_fn=d_contrast_fn,
+            flooring_fn=flooring_fn,
+            pair_selector=pair_selector,
+            callbacks=callbacks,
+            scale_restoration=scale_restoration,
+            record_loss=record_loss,
+            reference_id=reference_id,
+            **kwargs,
+        )
+
+    def __repr__(self) -> str:
+        return "AuxLaplaceIVA" + super().__repr__()[len("AuxIVA"):]
+
+
+class AuxGaussIVA(AuxIVA):
+    """AuxIVA with the time-varying Gauss source model (ref: ssspy/bss/iva.py:3131-3473)."""
+
+    variance = Synced(dv.f64)
+
+    def __init__(
+        self,
+        spatial_algorithm: str = "IP",
+        flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = functools.partial(
+            max_flooring, eps=EPS
+        ),
+        pair_selector: Optional[Callable[[int], Iterable[Tuple[int, int]]]] = None,
+        callbacks: Optional[Union[Callable, List[Callable]]] = None,
+        scale_restoration: Union[bool, str] = True,
+        record_loss: bool = True,
+        reference_id: int = 0,
+        **kwargs,
+    ) -> None:
+        def contrast_fn(y: np.ndarray) -> np.ndarray:
+            """G(y) = n_bins log(alpha) + ||y||^2 / alpha."""
+            norm = np.linalg.norm(y, axis=1)
+            return self.n_bins * np.log(self.variance) + (norm**2) / self.variance
+
+        def d_contrast_fn(y: np.ndarray, variance: np.ndarray = None) -> np.ndarray:
+            """G'(r) = 2 r / alpha."""
+            alpha = self.variance if variance is None else variance
+            return 2 * y / alpha
+
+        contrast_fn._ssspy_amd_contrast = _lib.CONTRAST_GAUSS
+        d_contrast_fn._ssspy_amd_contrast = _lib.CONTRAST_GAUSS
+        super().__init__(
+            spatial_algorithm=spatial_algorithm,
+            contrast_fn=contrast_fn,
+            d_contrast_fn=d_contrast_fn,
+            flooring_fn=flooring_fn,
+            pair_selector=pair_selector,
+            callbacks=callbacks,
+            scale_restoration=scale_restoration,
+            record_loss=record_loss,
+            reference_id=reference_id,
+            **kwargs,
+        )
+
+    def __repr__(self) -> str:
+        return "AuxGaussIVA" + super().__repr__()[len("AuxIVA"):]
+
+    def _reset(self, **kwargs) -> None:
+        """ref: ssspy/bss/iva.py:3304-3317."""
+        super()._reset(**kwargs)
+        self.variance = np.ones(self._lead() + (self.n_sources, self.n_frames))
+
+    def _variance_tensor(self):
+        return self._state_dev("variance")
+
+    def update_once(self, flooring_fn="self") -> None:
+        """Refresh the variance, then the spatial update (ref: ssspy/bss/iva.py:3319-3337).
+
+        The variance refresh alpha_nj = mean_i |y_nij|^2 (:3465-3473) is fused into the weight
+        kernel (it is r^2 / n_bins of the same frame power).
+        """
+        super().update_once(flooring_fn=flooring_fn)
+        self._state_touch("variance")
+
+    def update_source_model(self) -> None:
+        """alpha_nj = mean_i |y_nij|^2 (ref: ssspy/bss/iva.py:3465-3473)."""
+        self._weights("self")
+        self._state_touch("variance")

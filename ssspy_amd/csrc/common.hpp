@@ -1,0 +1,136 @@
+// Shared device helpers for the gfx950 hot-path kernels (fp64 / complex128).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "ssspy_amd.h"
+
+namespace ssspy {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double2 c128;  // x = re, y = im; layout-compatible with numpy.complex128
+
+// ---------------------------------------------------------------- error plumbing
+extern thread_local char g_last_error[512];
+
+inline int fail(int code, const char *msg) {
+  std::snprintf(g_last_error, sizeof(g_last_error), "%s", msg);
+  return code;
+}
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    std::snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
+    return SSSPY_ERR_HIP;
+  }
+  return SSSPY_OK;
+}
+
+#define SSSPY_REQUIRE(cond, msg) \
+  do {                           \
+    if (!(cond)) return ::ssspy::fail(SSSPY_ERR_BADARG, msg); \
+  } while (0)
+
+
+// switch on a runtime n_sources to a compile-time NN (1..8)
+#define DISPATCH_N(N_, CALL)                                                            \
+  switch (N_) {                                                                         \
+    case 1: { constexpr int NN = 1; CALL; } break;                                      \
+    case 2: { constexpr int NN = 2; CALL; } break;                                      \
+    case 3: { constexpr int NN = 3; CALL; } break;                                      \
+    case 4: { constexpr int NN = 4; CALL; } break;                                      \
+    case 5: { constexpr int NN = 5; CALL; } break;                                      \
+    case 6: { constexpr int NN = 6; CALL; } break;                                      \
+    case 7: { constexpr int NN = 7; CALL; } break;                                      \
+    case 8: { constexpr int NN = 8; CALL; } break;                                      \
+    default: return ::ssspy::fail(SSSPY_ERR_UNSUPPORTED, "n_sources must be in [1, 8]"); \
+  }
+
+// ---------------------------------------------------------------- complex arithmetic
+__device__ __forceinline__ c128 cmake(double re, double im) { return make_double2(re, im); }
+__device__ __forceinline__ c128 cadd(c128 a, c128 b) { return cmake(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ c128 csub(c128 a, c128 b) { return cmake(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ c128 cconj(c128 a) { return cmake(a.x, -a.y); }
+__device__ __forceinline__ c128 cmul(c128 a, c128 b) {
+  return cmake(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// a * conj(b)
+__device__ __forceinline__ c128 cmulc(c128 a, c128 b) {
+  return cmake(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+// acc += a * b
+__device__ __forceinline__ void cfma(c128 &acc, c128 a, c128 b) {
+  acc.x = fma(a.x, b.x, acc.x);
+  acc.x = fma(-a.y, b.y, acc.x);
+  acc.y = fma(a.x, b.y, acc.y);
+  acc.y = fma(a.y, b.x, acc.y);
+}
+// acc -= a * b
+__device__ __forceinline__ void cfms(c128 &acc, c128 a, c128 b) {
+  acc.x = fma(-a.x, b.x, acc.x);
+  acc.x = fma(a.y, b.y, acc.x);
+  acc.y = fma(-a.x, b.y, acc.y);
+  acc.y = fma(-a.y, b.x, acc.y);
+}
+__device__ __forceinline__ c128 cscale(c128 a, double s) { return cmake(a.x * s, a.y * s); }
+__device__ __forceinline__ double cabs2(c128 a) { return fma(a.x, a.x, a.y * a.y); }
+__device__ __forceinline__ double cabs1(c128 a) { return fabs(a.x) + fabs(a.y); }
+__device__ __forceinline__ c128 crecip(c128 a) {
+  // Smith's algorithm: no overflow for well-scaled inputs, ~1 ulp
+  if (fabs(a.x) >= fabs(a.y)) {
+    double r = a.y / a.x;
+    double d = 1.0 / fma(a.y, r, a.x);
+    return cmake(d, -r * d);
+  } else {
+    double r = a.x / a.y;
+    double d = 1.0 / fma(a.x, r, a.y);
+    return cmake(r * d, -d);
+  }
+}
+__device__ __forceinline__ c128 cdiv(c128 a, c128 b) { return cmul(a, crecip(b)); }
+
+__device__ __forceinline__ double apply_floor(double x, int kind, double eps) {
+  // numpy.maximum propagates NaN; fmax would swallow it, so spell the compare out
+  if (kind == SSSPY_FLOOR_MAX) return (x < eps) ? eps : x;
+  if (kind == SSSPY_FLOOR_ADD) return x + eps;
+  return x;
+}
+
+// x^e with the exponents the MM updates use; domain == 2 takes the pow-free path
+__device__ __forceinline__ double pow_fast(double x, double e) { return pow(x, e); }
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// sum over the block; result valid in thread 0.  scratch: >= blockDim.x/64 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double *scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  double total = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) total += scratch[w];
+  }
+  return total;
+}
+
+__device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c) {
+  // v_mfma_f64_16x16x4_f64: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
+  // C/D: col = lane&15, row = (lane>>4) + 4*reg
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace ssspy

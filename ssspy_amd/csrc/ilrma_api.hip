@@ -1,0 +1,285 @@
+// C-ABI entry points of the Gauss-ILRMA path: dispatch over n_sources to the per-N MFMA
+// translation units (ilrma_kernels.hip, built with -DSSSPY_N=n) plus the small
+// normalisation / weight kernels that do not depend on N at compile time.
+#include "common.hpp"
+
+namespace ssspy {
+
+#define DECL_N(n)                                                                               \
+  int ilrma_basis_n##n(const void *, const void *, const double *, double *, const double *,   \
+                       int, int, int, int, double, int, double, hipStream_t);                  \
+  int ilrma_activation_n##n(const void *, const void *, const double *, double *, double *, int, \
+                            int, int, int, int, double, int, double, hipStream_t);             \
+  int ilrma_wcov_n##n(const void *, const double *, const double *, void *, int, int, int, int, \
+                      double, hipStream_t);                                                    \
+  int ilrma_loss_n##n(const void *, const void *, const double *, const double *, double *, int, \
+                      int, int, int, double, hipStream_t);
+DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
+#undef DECL_N
+
+#define ILRMA_DISPATCH(N_, fn, ...)                                                  \
+  switch (N_) {                                                                      \
+    case 2: return fn##_n2(__VA_ARGS__);                                             \
+    case 3: return fn##_n3(__VA_ARGS__);                                             \
+    case 4: return fn##_n4(__VA_ARGS__);                                             \
+    case 5: return fn##_n5(__VA_ARGS__);                                             \
+    case 6: return fn##_n6(__VA_ARGS__);                                             \
+    case 7: return fn##_n7(__VA_ARGS__);                                             \
+    case 8: return fn##_n8(__VA_ARGS__);                                             \
+    default: return fail(SSSPY_ERR_UNSUPPORTED, "ILRMA: n_sources must be in [2, 8]"); \
+  }
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline int ngroups_of(int N) { return N <= 4 ? 1 : (N + 1) / 2; }
+
+// number of bin chunks the activation pass splits into (partials are summed by the finalize
+// kernel): enough blocks to occupy the chip for small batches, one chunk for large ones.
+static inline int act_chunks(int B, int N, int F, int T, int K) {
+  const long long blocks0 = (long long)B * ngroups_of(N) * ((T + 63) / 64) * ((K + 15) / 16);
+  const int ntiles = (F + 15) / 16;
+  long long want = (512 + blocks0 - 1) / blocks0;
+  if (want < 1) want = 1;
+  if (want > 16) want = 16;
+  if (want > ntiles) want = ntiles;
+  return (int)want;
+}
+
+static inline size_t act_part_bytes(int B, int N, int F, int T, int K) {
+  return align256((size_t)B * act_chunks(B, N, F, T, K) * N * 2 * K * T * sizeof(double));
+}
+static inline size_t basis_tmp_bytes(int B, int N, int F, int K) {
+  return K > 16 ? align256((size_t)B * N * F * K * sizeof(double)) : 0;
+}
+
+// ------------------------------------------------------------------ power normalisation (filter)
+// one block per mixture; psi_n^2 = (1/F) sum_i Re(w_in C_i w_in^H), rows w_in of W_i.
+__global__ __launch_bounds__(256) void k_ilrma_normalize_filter(c128 *W, const c128 *__restrict__ C,
+                                                                double *basis, int N, int F,
+                                                                int K, double p, int floor_kind,
+                                                                double eps) {
+  __shared__ double scratch[4];
+  __shared__ double psi[SSSPY_MAX_SOURCES];
+  const int b = blockIdx.x;
+  c128 *Wb = W + (long long)b * F * N * N;
+  const c128 *Cb = C + (long long)b * F * N * N;
+  for (int n = 0; n < N; ++n) {
+    double local = 0.0;
+    for (int i = threadIdx.x; i < F; i += blockDim.x) {
+      const c128 *w = Wb + ((long long)i * N + n) * N;
+      const c128 *Ci = Cb + (long long)i * N * N;
+      double qf = 0.0;
+      for (int a = 0; a < N; ++a) {
+        c128 t = cmake(0.0, 0.0);  // t = sum_c C[a][c] conj(w[c])
+        for (int c = 0; c < N; ++c) {
+          const c128 u = Ci[a * N + c], wc = w[c];
+          t.x += u.x * wc.x + u.y * wc.y;
+          t.y += u.y * wc.x - u.x * wc.y;
+        }
+        qf += w[a].x * t.x - w[a].y * t.y;  // Re(w[a] * t)
+      }
+      local += qf;
+    }
+    const double total = block_sum(local, scratch);
+    if (threadIdx.x == 0) {
+      double v = total / (double)F;
+      v = v > 0.0 ? v : 0.0;
+      psi[n] = apply_floor(sqrt(v), floor_kind, eps);
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < F * N * N; e += blockDim.x) {
+    const int n = (e / N) % N;
+    c128 v = Wb[e];
+    Wb[e] = cmake(v.x / psi[n], v.y / psi[n]);
+  }
+  double *Tb = basis + (long long)b * N * F * K;
+  for (int e = threadIdx.x; e < N * F * K; e += blockDim.x) {
+    const int n = e / (F * K);
+    const double pp = (p == 2.0) ? psi[n] * psi[n] : pow(psi[n], p);
+    Tb[e] = Tb[e] / pp;
+  }
+}
+
+// ------------------------------------------------------------------ power normalisation (output)
+__global__ __launch_bounds__(256) void k_output_power(const c128 *__restrict__ Y, double *acc,
+                                                      int N, int F, int T) {
+  __shared__ double scratch[4];
+  const int i = blockIdx.x, n = blockIdx.y, b = blockIdx.z;
+  const c128 *row = Y + (((long long)b * N + n) * F + i) * T;
+  double local = 0.0;
+  for (int j = threadIdx.x; j < T; j += blockDim.x) local += cabs2(row[j]);
+  const double total = block_sum(local, scratch);
+  if (threadIdx.x == 0) atomicAdd(acc + b * N + n, total);
+}
+
+__global__ __launch_bounds__(256) void k_ilrma_normalize_output(c128 *Y, double *basis,
+                                                                const double *__restrict__ acc,
+                                                                int N, int F, int T, int K,
+                                                                double p, int floor_kind,
+                                                                double eps) {
+  const int i = blockIdx.x, n = blockIdx.y, b = blockIdx.z;
+  double v = acc[b * N + n] / ((double)F * (double)T);
+  const double psi = apply_floor(sqrt(v), floor_kind, eps);
+  c128 *row = Y + (((long long)b * N + n) * F + i) * T;
+  for (int j = threadIdx.x; j < T; j += blockDim.x) {
+    c128 y = row[j];
+    row[j] = cmake(y.x / psi, y.y / psi);
+  }
+  const double pp = (p == 2.0) ? psi * psi : pow(psi, p);
+  double *tr = basis + (((long long)b * N + n) * F + i) * K;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) tr[k] = tr[k] / pp;
+}
+
+// ------------------------------------------------------------------------------ ISS weight
+__global__ __launch_bounds__(256) void k_ilrma_iss_weight(const double *__restrict__ basis,
+                                                          const double *__restrict__ act,
+                                                          double *__restrict__ varphi, int N,
+                                                          int F, int T, int K, double p) {
+  const int i = blockIdx.x, n = blockIdx.y, b = blockIdx.z;
+  const double *tr = basis + (((long long)b * N + n) * F + i) * K;
+  const double *Vn = act + ((long long)b * N + n) * K * T;
+  double *out = varphi + (((long long)b * N + n) * F + i) * T;
+  for (int j = threadIdx.x; j < T; j += blockDim.x) {
+    double r = 0.0;
+    for (int k = 0; k < K; ++k) r = fma(tr[k], Vn[(long long)k * T + j], r);
+    out[j] = (p == 2.0) ? 1.0 / r : 1.0 / pow(r, 2.0 / p);
+  }
+}
+
+}  // namespace ssspy
+
+using namespace ssspy;
+
+extern "C" {
+
+size_t ssspy_ilrma_workspace_bytes(int B, int N, int F, int T, int K) {
+  if (B <= 0 || N <= 0 || F <= 0 || T <= 0 || K <= 0) return 0;
+  return act_part_bytes(B, N, F, T, K) + basis_tmp_bytes(B, N, F, K) +
+         align256((size_t)B * N * sizeof(double));
+}
+
+int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const double *activation,
+                             int B, int N, int F, int T, int K, double domain, int floor_kind,
+                             double floor_eps, void *workspace, size_t workspace_bytes,
+                             void *stream) {
+  SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0, "update_basis: bad argument");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_basis: n_basis must be in [1, 64]");
+  SSSPY_REQUIRE(domain > 0.0 && domain <= 2.0, "update_basis: domain must be in (0, 2]");
+  hipStream_t st = as_stream(stream);
+  double *out = basis;
+  if (K > 16) {
+    SSSPY_REQUIRE(workspace && workspace_bytes >= basis_tmp_bytes(B, N, F, K),
+                  "update_basis: workspace too small");
+    out = (double *)workspace;
+  }
+  auto run = [&]() -> int {
+    ILRMA_DISPATCH(N, ilrma_basis, X, W, basis, out, activation, B, F, T, K, domain, floor_kind,
+                   floor_eps, st);
+  };
+  int rc = run();
+  if (rc) return rc;
+  if (out != basis) {
+    hipError_t e = hipMemcpyAsync(basis, out, (size_t)B * N * F * K * sizeof(double),
+                                  hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+  }
+  return SSSPY_OK;
+}
+
+int ssspy_ilrma_update_activation(const void *X, const void *W, const double *basis,
+                                  double *activation, int B, int N, int F, int T, int K,
+                                  double domain, int floor_kind, double floor_eps, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+  SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0,
+                "update_activation: bad argument");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_activation: n_basis must be in [1, 64]");
+  SSSPY_REQUIRE(workspace && workspace_bytes >= act_part_bytes(B, N, F, T, K),
+                "update_activation: workspace too small");
+  const int chunks = act_chunks(B, N, F, T, K);
+  ILRMA_DISPATCH(N, ilrma_activation, X, W, basis, activation, (double *)workspace, chunks, B, F,
+                 T, K, domain, floor_kind, floor_eps, as_stream(stream));
+}
+
+int ssspy_ilrma_weighted_covariance(const void *X, const double *basis, const double *activation,
+                                    void *U, int B, int N, int F, int T, int K, double domain,
+                                    void *stream) {
+  SSSPY_REQUIRE(X && basis && activation && U && B > 0 && F > 0 && T > 0,
+                "ilrma_weighted_covariance: bad argument");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "ilrma_weighted_covariance: bad n_basis");
+  ILRMA_DISPATCH(N, ilrma_wcov, X, basis, activation, U, B, F, T, K, domain, as_stream(stream));
+}
+
+int ssspy_ilrma_normalize_filter(void *W, const void *C, double *basis, int B, int N, int F, int K,
+                                 double domain, int floor_kind, double floor_eps, void *stream) {
+  SSSPY_REQUIRE(W && C && basis && B > 0 && N >= 1 && N <= SSSPY_MAX_SOURCES,
+                "normalize_filter: bad argument");
+  hipLaunchKernelGGL(k_ilrma_normalize_filter, dim3(B), dim3(256), 0, as_stream(stream),
+                     (c128 *)W, (const c128 *)C, basis, N, F, K, domain, floor_kind, floor_eps);
+  return check_launch("k_ilrma_normalize_filter");
+}
+
+int ssspy_ilrma_normalize_output(void *Y, double *basis, int B, int N, int F, int T, int K,
+                                 double domain, int floor_kind, double floor_eps, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+  SSSPY_REQUIRE(Y && basis && B > 0 && N >= 1, "normalize_output: bad argument");
+  SSSPY_REQUIRE(workspace && workspace_bytes >= (size_t)B * N * sizeof(double),
+                "normalize_output: workspace too small");
+  hipStream_t st = as_stream(stream);
+  double *acc = (double *)workspace;
+  hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * N * sizeof(double), st);
+  if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+  dim3 grid(F, N, B), block(256);
+  hipLaunchKernelGGL(k_output_power, grid, block, 0, st, (const c128 *)Y, acc, N, F, T);
+  hipLaunchKernelGGL(k_ilrma_normalize_output, grid, block, 0, st, (c128 *)Y, basis, acc, N, F, T,
+                     K, domain, floor_kind, floor_eps);
+  return check_launch("k_ilrma_normalize_output");
+}
+
+int ssspy_ilrma_iss_weight(const double *basis, const double *activation, double *varphi, int B,
+                           int N, int F, int T, int K, double domain, void *stream) {
+  SSSPY_REQUIRE(basis && activation && varphi && B > 0, "iss_weight: bad argument");
+  dim3 grid(F, N, B), block(256);
+  hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, as_stream(stream), basis, activation,
+                     varphi, N, F, T, K, domain);
+  return check_launch("k_ilrma_iss_weight");
+}
+
+int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
+                          const double *activation, double *out, int B, int N, int F, int T, int K,
+                          double domain, void *stream) {
+  SSSPY_REQUIRE(X && basis && activation && out && B > 0, "ilrma_loss_data: bad argument");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "ilrma_loss_data: bad n_basis");
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)B * sizeof(double), st);
+  if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+  ILRMA_DISPATCH(N, ilrma_loss, X, W, basis, activation, out, B, F, T, K, domain, st);
+}
+
+int ssspy_gauss_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis,
+                                 double *activation, void *U, int B, int N, int F, int T, int K,
+                                 double domain, int normalize, int floor_kind, double floor_eps,
+                                 void *workspace, size_t workspace_bytes, int *info,
+                                 void *stream) {
+  SSSPY_REQUIRE(X && W && basis && activation && U, "gauss_ilrma_ip1_update: bad argument");
+  SSSPY_REQUIRE(!normalize || C, "gauss_ilrma_ip1_update: normalisation needs C");
+  int rc = ssspy_ilrma_update_basis(X, W, basis, activation, B, N, F, T, K, domain, floor_kind,
+                                    floor_eps, (char *)workspace + act_part_bytes(B, N, F, T, K),
+                                    workspace_bytes > act_part_bytes(B, N, F, T, K)
+                                        ? workspace_bytes - act_part_bytes(B, N, F, T, K)
+                                        : 0,
+                                    stream);
+  if (rc) return rc;
+  rc = ssspy_ilrma_update_activation(X, W, basis, activation, B, N, F, T, K, domain, floor_kind,
+                                     floor_eps, workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  rc = ssspy_ilrma_weighted_covariance(X, basis, activation, U, B, N, F, T, K, domain, stream);
+  if (rc) return rc;
+  rc = ssspy_update_by_ip1(W, U, B, F, N, floor_kind, floor_eps, info, stream);
+  if (rc) return rc;
+  if (normalize)
+    rc = ssspy_ilrma_normalize_filter(W, C, basis, B, N, F, K, domain, floor_kind, floor_eps,
+                                      stream);
+  return rc;
+}
+
+}  // extern "C"

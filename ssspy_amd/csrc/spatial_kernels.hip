@@ -1,0 +1,427 @@
+// Shared per-bin operators: separate, (weighted / cross) covariance, IP1, ISS1 transform,
+// projection back, log-determinant.  See include/ssspy_amd.h for the contract of each entry.
+#include "common.hpp"
+#include "cov_core.hpp"
+#include "smallmat.hpp"
+
+namespace ssspy {
+
+thread_local char g_last_error[512] = "";
+
+// ---------------------------------------------------------------------------------- separate
+// One block per (bin, mixture); lanes run along frames so every channel row is read and
+// every source row written as contiguous 16-byte elements.  W_i is wave-uniform.
+template <int N>
+__global__ __launch_bounds__(256) void k_separate(const c128 *__restrict__ X,
+                                                  const c128 *__restrict__ W, c128 *Y, int F,
+                                                  int T) {
+  const int i = blockIdx.x, b = blockIdx.y;
+  __shared__ c128 w[N * N];
+  if (threadIdx.x < N * N) w[threadIdx.x] = W[((long long)b * F + i) * (N * N) + threadIdx.x];
+  __syncthreads();
+  const long long row0 = ((long long)b * N) * F + i;
+  for (int j = threadIdx.x; j < T; j += blockDim.x) {
+    c128 x[N];
+#pragma unroll
+    for (int m = 0; m < N; ++m) x[m] = X[(row0 + (long long)m * F) * T + j];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      c128 y = cmake(0.0, 0.0);
+#pragma unroll
+      for (int m = 0; m < N; ++m) cfma(y, w[n * N + m], x[m]);
+      Y[(row0 + (long long)n * F) * T + j] = y;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- weighted covariance
+template <int N, int SG, int MODE>
+__global__ __launch_bounds__(256) void k_weighted_cov(const c128 *__restrict__ A,
+                                                      const double *__restrict__ weight,
+                                                      c128 *__restrict__ U, int S_total, int F,
+                                                      int T) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int b = blockIdx.y, s0 = blockIdx.z * SG;
+  const int i0 = blockIdx.x * 16;
+  const int bin = min(i0 + c, F - 1);
+  CovAcc<N, SG> acc;
+  acc.clear();
+  const int ntiles = (T + 15) >> 4;
+  for (int jt = wave; jt < ntiles; jt += nw) {
+    const int j = jt * 16 + 4 * q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = j + r;
+      const bool valid = jj < T;
+      const int jc = valid ? jj : T - 1;
+      c128 x[N];
+#pragma unroll
+      for (int m = 0; m < N; ++m) x[m] = A[(((long long)b * N + m) * F + bin) * T + jc];
+      double phi[SG];
+#pragma unroll
+      for (int s = 0; s < SG; ++s) {
+        const int sg = s0 + s;
+        double p = 0.0;
+        if (valid && sg < S_total) {
+          if (MODE == SSSPY_WEIGHT_UNIT) p = 1.0;
+          if (MODE == SSSPY_WEIGHT_FRAME) p = weight[((long long)b * S_total + sg) * T + jc];
+          if (MODE == SSSPY_WEIGHT_BIN_FRAME)
+            p = weight[(((long long)b * S_total + sg) * F + bin) * T + jc];
+        }
+        phi[s] = p;
+      }
+      acc.add(x, phi);
+    }
+  }
+  acc.fold_q();
+  cov_reduce_store<N, SG>(acc, lds, U, (long long)b * F, i0, F, S_total, s0,
+                          min(SG, S_total - s0), 1.0 / (double)T);
+}
+
+template <int N>
+constexpr int cov_group() {
+  return N <= 4 ? N : (N == 5 ? 3 : 2);
+}
+
+template <int N, int MODE>
+static int launch_weighted_cov(const c128 *A, const double *weight, c128 *U, int B, int S, int F,
+                               int T, hipStream_t st) {
+  constexpr int SG = (MODE == SSSPY_WEIGHT_UNIT) ? 1 : cov_group<N>();
+  const int groups = (S + SG - 1) / SG;
+  dim3 grid((F + 15) / 16, B, groups), block(256);
+  const size_t lds = 4 * cov_lds_doubles_per_wave<N, SG>() * sizeof(double);
+  hipLaunchKernelGGL((k_weighted_cov<N, SG, MODE>), grid, block, lds, st, A, weight, U, S, F, T);
+  return check_launch("k_weighted_cov");
+}
+
+template <int N>
+static int dispatch_weighted_cov(const c128 *A, const double *weight, int kind, c128 *U, int B,
+                                 int S, int F, int T, hipStream_t st) {
+  switch (kind) {
+    case SSSPY_WEIGHT_UNIT:
+      return launch_weighted_cov<N, SSSPY_WEIGHT_UNIT>(A, weight, U, B, S, F, T, st);
+    case SSSPY_WEIGHT_FRAME:
+      return launch_weighted_cov<N, SSSPY_WEIGHT_FRAME>(A, weight, U, B, S, F, T, st);
+    case SSSPY_WEIGHT_BIN_FRAME:
+      return launch_weighted_cov<N, SSSPY_WEIGHT_BIN_FRAME>(A, weight, U, B, S, F, T, st);
+  }
+  return fail(SSSPY_ERR_BADARG, "weighted_covariance: unknown weight_kind");
+}
+
+// ---------------------------------------------------------------------------- cross covariance
+// C[a][c] = (1/T) sum_j A_a conj(B_c); one block per (bin, mixture), lanes along frames,
+// block-wide tree fold per output (small outputs: Na*Nb <= 64).
+template <int NA, int NB>
+__global__ __launch_bounds__(256) void k_cross_cov(const c128 *__restrict__ A,
+                                                   const c128 *__restrict__ Bm,
+                                                   c128 *__restrict__ C, int F, int T) {
+  __shared__ double scratch[2 * 4];
+  const int i = blockIdx.x, b = blockIdx.y;
+  c128 acc[NA][NB];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int c = 0; c < NB; ++c) acc[a][c] = cmake(0.0, 0.0);
+  for (int j = threadIdx.x; j < T; j += blockDim.x) {
+    c128 xa[NA], xb[NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) xa[a] = A[(((long long)b * NA + a) * F + i) * T + j];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) xb[c] = Bm[(((long long)b * NB + c) * F + i) * T + j];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        const c128 z = cmulc(xa[a], xb[c]);
+        acc[a][c] = cadd(acc[a][c], z);
+      }
+  }
+  const double scale = 1.0 / (double)T;
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      const double re = block_sum(acc[a][c].x, scratch);
+      const double im = block_sum(acc[a][c].y, scratch + 4);
+      if (threadIdx.x == 0)
+        C[(((long long)b * F + i) * NA + a) * NB + c] = cmake(re * scale, im * scale);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- IP1
+// One lane per (mixture, bin): N sequential projections, each an N x N complex solve.
+template <int N>
+__global__ __launch_bounds__(64) void k_ip1(c128 *W, const c128 *__restrict__ U, long long nbins,
+                                            int floor_kind, double eps, int *info) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nbins) return;
+  Mat<N> Wm;
+  load_mat<N>(Wm, W + idx * (N * N));
+  bool ok = true;
+#pragma unroll 1
+  for (int n = 0; n < N; ++n) {
+    Mat<N> Un, A;
+    load_mat<N>(Un, U + (idx * N + n) * (N * N));
+    matmul<N>(A, Wm, Un);
+    c128 w[N];
+    ok = solve_unit<N>(A, n, w) && ok;
+    double qf = quad_form<N>(w, Un);
+    qf = qf < 0.0 ? 0.0 : qf;  // np.maximum(., 0): NaN propagates
+    const double d = apply_floor(sqrt(qf), floor_kind, eps);
+    // row n of W <- conj(w) / d  (static row select keeps W in registers)
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c)
+        if (r == n) Wm.a[r][c] = cmake(w[c].x / d, -w[c].y / d);
+  }
+  store_mat<N>(Wm, W + idx * (N * N));
+  if (!ok && info) atomicAdd(info, 1);
+}
+
+// -------------------------------------------------------------------------------- ISS1 transform
+// Runs the N rank-1 steering steps on the per-bin statistics.  With G the transform
+// accumulated so far, the current covariance of weight set s is G V0_s G^H; only two of
+// its entries are needed per (step n, set s): [s, n] and [n, n].
+template <int N>
+__global__ __launch_bounds__(64) void k_iss1_transform(const c128 *__restrict__ Vc, c128 *G,
+                                                       long long nbins, int floor_kind,
+                                                       double eps) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nbins) return;
+  Mat<N> Gm;
+  set_identity<N>(Gm);
+  const c128 *V0 = Vc + idx * (long long)(N * N * N);
+#pragma unroll 1
+  for (int n = 0; n < N; ++n) {
+    c128 gn[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c)
+        if (r == n) gn[c] = Gm.a[r][c];
+    c128 v[N];
+    double den_n = 1.0;
+#pragma unroll 1
+    for (int s = 0; s < N; ++s) {
+      // t = V0_s gn^H
+      c128 t[N];
+#pragma unroll
+      for (int a = 0; a < N; ++a) {
+        c128 acc = cmake(0.0, 0.0);
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+          const c128 u = V0[(s * N + a) * N + d];
+          // acc += u * conj(gn[d])
+          acc.x = fma(u.x, gn[d].x, acc.x);
+          acc.x = fma(u.y, gn[d].y, acc.x);
+          acc.y = fma(u.y, gn[d].x, acc.y);
+          acc.y = fma(-u.x, gn[d].y, acc.y);
+        }
+        t[a] = acc;
+      }
+      c128 num = cmake(0.0, 0.0), dn = cmake(0.0, 0.0);
+#pragma unroll
+      for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+          if (r == s) cfma(num, Gm.a[r][a], t[a]);
+#pragma unroll
+      for (int a = 0; a < N; ++a) cfma(dn, gn[a], t[a]);
+      const double den = apply_floor(dn.x, floor_kind, eps);
+      const double inv = 1.0 / den;
+      c128 vs = cmake(num.x * inv, num.y * inv);
+      if (s == n) {
+        den_n = den;
+        vs = cmake(1.0 - 1.0 / sqrt(den), 0.0);
+      }
+#pragma unroll
+      for (int r = 0; r < N; ++r)
+        if (r == s) v[r] = vs;
+    }
+    (void)den_n;
+    // G <- (I - v e_n^T) G : every row r loses v_r * (old row n)
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c) cfms(Gm.a[r][c], v[r], gn[c]);
+  }
+  store_mat<N>(Gm, G + idx * (N * N));
+}
+
+// ------------------------------------------------------------------------------ projection back
+template <int N>
+__global__ __launch_bounds__(64) void k_pb_filter(c128 *W, long long nbins, int ref, int *info) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nbins) return;
+  Mat<N> Wm, A, Inv;
+  load_mat<N>(Wm, W + idx * (N * N));
+  A = Wm;
+  const bool ok = invert<N>(A, Inv);
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    c128 s = cmake(0.0, 0.0);
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+      if (r == ref) s = Inv.a[r][n];
+#pragma unroll
+    for (int c = 0; c < N; ++c) Wm.a[n][c] = cmul(Wm.a[n][c], s);
+  }
+  store_mat<N>(Wm, W + idx * (N * N));
+  if (!ok && info) atomicAdd(info, 1);
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void k_pb_scale(const c128 *__restrict__ XY,
+                                                 const c128 *__restrict__ YY, c128 *G,
+                                                 long long nbins, int ref, int *info) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nbins) return;
+  Mat<N> A, Inv, Gm;
+  load_mat<N>(A, YY + idx * (N * N));
+  const bool ok = invert<N>(A, Inv);
+  const c128 *xy = XY + idx * (N * N) + ref * N;
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    c128 s = cmake(0.0, 0.0);
+#pragma unroll
+    for (int c = 0; c < N; ++c) cfma(s, xy[c], Inv.a[c][n]);
+#pragma unroll
+    for (int c = 0; c < N; ++c) Gm.a[n][c] = (c == n) ? s : cmake(0.0, 0.0);
+  }
+  store_mat<N>(Gm, G + idx * (N * N));
+  if (!ok && info) atomicAdd(info, 1);
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void k_demix_from_cov(const c128 *__restrict__ YX,
+                                                       const c128 *__restrict__ XX, c128 *W,
+                                                       long long nbins, int *info) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nbins) return;
+  Mat<N> A, Inv, Y, Wm;
+  load_mat<N>(A, XX + idx * (N * N));
+  load_mat<N>(Y, YX + idx * (N * N));
+  const bool ok = invert<N>(A, Inv);
+  matmul<N>(Wm, Y, Inv);
+  store_mat<N>(Wm, W + idx * (N * N));
+  if (!ok && info) atomicAdd(info, 1);
+}
+
+// one block per mixture
+template <int N>
+__global__ __launch_bounds__(256) void k_sum_logdet(const c128 *__restrict__ W, double *out,
+                                                    int F) {
+  __shared__ double scratch[4];
+  const int b = blockIdx.x;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < F; i += blockDim.x) {
+    Mat<N> A;
+    load_mat<N>(A, W + ((long long)b * F + i) * (N * N));
+    s += logabsdet<N>(A);
+  }
+  const double total = block_sum(s, scratch);
+  if (threadIdx.x == 0) out[b] = total;
+}
+
+}  // namespace ssspy
+
+using namespace ssspy;
+
+extern "C" {
+
+const char *ssspy_amd_version(void) { return "ssspy_amd 0.1.0 (gfx950)"; }
+const char *ssspy_last_error(void) { return g_last_error; }
+
+int ssspy_separate(const void *X, const void *W, void *Y, int B, int N, int F, int T,
+                   void *stream) {
+  SSSPY_REQUIRE(X && W && Y && B > 0 && F > 0 && T > 0, "separate: bad argument");
+  dim3 grid(F, B), block(256);
+  DISPATCH_N(N, hipLaunchKernelGGL((k_separate<NN>), grid, block, 0, as_stream(stream),
+                                   (const c128 *)X, (const c128 *)W, (c128 *)Y, F, T));
+  return check_launch("k_separate");
+}
+
+int ssspy_weighted_covariance(const void *A, const double *weight, int weight_kind, void *U, int B,
+                              int N, int S, int F, int T, void *stream) {
+  SSSPY_REQUIRE(A && U && B > 0 && F > 0 && T > 0 && S > 0, "weighted_covariance: bad argument");
+  SSSPY_REQUIRE(weight_kind == SSSPY_WEIGHT_UNIT || weight, "weighted_covariance: weight is NULL");
+  SSSPY_REQUIRE(weight_kind != SSSPY_WEIGHT_UNIT || S == 1, "weighted_covariance: UNIT needs S=1");
+  DISPATCH_N(N, return dispatch_weighted_cov<NN>((const c128 *)A, weight, weight_kind, (c128 *)U,
+                                                 B, S, F, T, as_stream(stream)));
+  return SSSPY_OK;
+}
+
+int ssspy_cross_covariance(const void *A, const void *Bm, void *C, int B, int N, int F, int T,
+                           void *stream) {
+  SSSPY_REQUIRE(A && Bm && C && B > 0 && F > 0 && T > 0, "cross_covariance: bad argument");
+  dim3 grid(F, B), block(256);
+  DISPATCH_N(N, hipLaunchKernelGGL((k_cross_cov<NN, NN>), grid, block, 0, as_stream(stream),
+                                   (const c128 *)A, (const c128 *)Bm, (c128 *)C, F, T));
+  return check_launch("k_cross_cov");
+}
+
+int ssspy_update_by_ip1(void *W, const void *U, int B, int F, int N, int floor_kind,
+                        double floor_eps, int *info, void *stream) {
+  SSSPY_REQUIRE(W && U && B > 0 && F > 0, "update_by_ip1: bad argument");
+  const long long nbins = (long long)B * F;
+  dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
+  DISPATCH_N(N, hipLaunchKernelGGL((k_ip1<NN>), grid, block, 0, as_stream(stream), (c128 *)W,
+                                   (const c128 *)U, nbins, floor_kind, floor_eps, info));
+  return check_launch("k_ip1");
+}
+
+int ssspy_iss1_transform(const void *Vc, void *G, int B, int F, int N, int floor_kind,
+                         double floor_eps, void *stream) {
+  SSSPY_REQUIRE(Vc && G && B > 0 && F > 0, "iss1_transform: bad argument");
+  const long long nbins = (long long)B * F;
+  dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
+  DISPATCH_N(N, hipLaunchKernelGGL((k_iss1_transform<NN>), grid, block, 0, as_stream(stream),
+                                   (const c128 *)Vc, (c128 *)G, nbins, floor_kind, floor_eps));
+  return check_launch("k_iss1_transform");
+}
+
+int ssspy_projection_back_filter(void *W, int B, int F, int N, int reference_id, int *info,
+                                 void *stream) {
+  SSSPY_REQUIRE(W && B > 0 && F > 0 && reference_id >= 0 && reference_id < N,
+                "projection_back_filter: bad argument");
+  const long long nbins = (long long)B * F;
+  dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
+  DISPATCH_N(N, hipLaunchKernelGGL((k_pb_filter<NN>), grid, block, 0, as_stream(stream),
+                                   (c128 *)W, nbins, reference_id, info));
+  return check_launch("k_pb_filter");
+}
+
+int ssspy_projection_back_scale(const void *XY, const void *YY, void *G, int B, int F, int N,
+                                int reference_id, int *info, void *stream) {
+  SSSPY_REQUIRE(XY && YY && G && B > 0 && F > 0 && reference_id >= 0 && reference_id < N,
+                "projection_back_scale: bad argument");
+  const long long nbins = (long long)B * F;
+  dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
+  DISPATCH_N(N, hipLaunchKernelGGL((k_pb_scale<NN>), grid, block, 0, as_stream(stream),
+                                   (const c128 *)XY, (const c128 *)YY, (c128 *)G, nbins,
+                                   reference_id, info));
+  return check_launch("k_pb_scale");
+}
+
+int ssspy_demix_from_covariance(const void *YX, const void *XX, void *W, int B, int F, int N,
+                                int *info, void *stream) {
+  SSSPY_REQUIRE(YX && XX && W && B > 0 && F > 0, "demix_from_covariance: bad argument");
+  const long long nbins = (long long)B * F;
+  dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
+  DISPATCH_N(N, hipLaunchKernelGGL((k_demix_from_cov<NN>), grid, block, 0, as_stream(stream),
+                                   (const c128 *)YX, (const c128 *)XX, (c128 *)W, nbins, info));
+  return check_launch("k_demix_from_cov");
+}
+
+int ssspy_sum_logdet(const void *W, double *out, int B, int F, int N, void *stream) {
+  SSSPY_REQUIRE(W && out && B > 0 && F > 0, "sum_logdet: bad argument");
+  dim3 grid(B), block(256);
+  DISPATCH_N(N, hipLaunchKernelGGL((k_sum_logdet<NN>), grid, block, 0, as_stream(stream),
+                                   (const c128 *)W, out, F));
+  return check_launch("k_sum_logdet");
+}
+
+}  // extern "C"
