@@ -26,6 +26,7 @@ CXXFLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-munsafe-fp
             "-I" + INCLUDE, "-I" + CSRC]
 
 ILRMA_N = list(range(2, 9))
+ILRMA_FAST_N = [2, 3, 4]
 
 
 def _hipcc():
@@ -46,6 +47,8 @@ def _units():
         units.append(("mnmf_kernels.hip", "mnmf_kernels.o", []))
     for n in ILRMA_N:
         units.append(("ilrma_kernels.hip", "ilrma_kernels_n{}.o".format(n), ["-DSSSPY_N={}".format(n)]))
+    for n in ILRMA_FAST_N:
+        units.append(("ilrma_fast.hip", "ilrma_fast_n{}.o".format(n), ["-DSSSPY_N={}".format(n)]))
     return units
 
 

@@ -42,6 +42,45 @@ class DeviceStateMixin:
 
     _batched = False
 
+    # -- input binding ------------------------------------------------------------------
+    def _bind_input(self, input) -> None:
+        """Keep a private copy of the mixture(s) and put them in HBM as (B, N, F, T) complex128.
+
+        ``input`` is a NumPy array (the reference contract; copied, ssspy/bss/ilrma.py:840) or,
+        as an extension, a complex128 tensor already resident on the HIP device (used as is:
+        the kernels never write to it).
+        """
+        if input.ndim not in (3, 4):
+            raise ValueError(
+                "input must be (n_channels, n_bins, n_frames) or "
+                "(n_mixtures, n_channels, n_bins, n_frames), got shape {}".format(
+                    tuple(input.shape))
+            )
+        self._batched = input.ndim == 4
+        if isinstance(input, torch.Tensor):
+            if not input.is_cuda or input.dtype != torch.complex128:
+                raise ValueError("a tensor input must be complex128 on the HIP device")
+            self.input = input
+            X4 = input if self._batched else input[None]
+            self._X = X4.contiguous()
+        else:
+            self.input = input.copy()
+            X4 = self.input if self._batched else self.input[None]
+            self._X = dv.to_device(X4, dtype=np.complex128)
+        self._static_cov = None
+
+    def _lead(self):
+        return (self._X.shape[0],) if self._batched else ()
+
+    def _C(self):
+        """Static covariance C_i = (1/T) sum_j x_ij x_ij^H, (B, F, N, N); once per call."""
+        if self._static_cov is None:
+            from .. import _ops
+
+            B, N, F, T = self._X.shape
+            self._static_cov = _ops.weighted_covariance(self._X).reshape(B, F, N, N)
+        return self._static_cov
+
     def _state(self):
         return self.__dict__.setdefault("_dev_state", {})
 

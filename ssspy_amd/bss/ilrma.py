@@ -70,29 +70,6 @@ class ILRMABase(DeviceStateMixin, IterativeMethodBase):
         self.reference_id = reference_id
         self.rng = np.random.default_rng() if rng is None else rng
 
-    # -- shapes -----------------------------------------------------------------------
-    def _bind_input(self, input: np.ndarray) -> None:
-        if input.ndim not in (3, 4):
-            raise ValueError(
-                "input must be (n_channels, n_bins, n_frames) or "
-                "(n_mixtures, n_channels, n_bins, n_frames), got shape {}".format(input.shape)
-            )
-        self._batched = input.ndim == 4
-        self.input = input.copy()
-        X4 = self.input if self._batched else self.input[None]
-        self._X = dv.to_device(X4, dtype=np.complex128)
-        self._static_cov = None
-
-    def _lead(self) -> Tuple[int, ...]:
-        return (self._X.shape[0],) if self._batched else ()
-
-    def _C(self):
-        """Static covariance C_i = (1/T) sum_j x_ij x_ij^H, (B, F, N, N), computed once per call."""
-        if self._static_cov is None:
-            B, N, F, T = self._X.shape
-            self._static_cov = _ops.weighted_covariance(self._X).reshape(B, F, N, N)
-        return self._static_cov
-
     # -- reset ------------------------------------------------------------------------
     def _reset(self, flooring_fn="self", **kwargs) -> None:
         """ref: ssspy/bss/ilrma.py:151-199."""

@@ -58,27 +58,6 @@ class IVABase(DeviceStateMixin, IterativeMethodBase):
             raise ValueError("Specify 'reference_id' if scale_restoration=True.")
         self.reference_id = reference_id
 
-    def _bind_input(self, input: np.ndarray) -> None:
-        if input.ndim not in (3, 4):
-            raise ValueError(
-                "input must be (n_channels, n_bins, n_frames) or "
-                "(n_mixtures, n_channels, n_bins, n_frames), got shape {}".format(input.shape)
-            )
-        self._batched = input.ndim == 4
-        self.input = input.copy()
-        X4 = self.input if self._batched else self.input[None]
-        self._X = dv.to_device(X4, dtype=np.complex128)
-        self._static_cov = None
-
-    def _lead(self) -> Tuple[int, ...]:
-        return (self._X.shape[0],) if self._batched else ()
-
-    def _C(self):
-        if self._static_cov is None:
-            B, N, F, T = self._X.shape
-            self._static_cov = _ops.weighted_covariance(self._X).reshape(B, F, N, N)
-        return self._static_cov
-
     def _reset(self, **kwargs) -> None:
         """ref: ssspy/bss/iva.py:138-169."""
         assert self.input is not None, "Specify data!"

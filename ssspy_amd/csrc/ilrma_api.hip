@@ -1,6 +1,8 @@
 // C-ABI entry points of the Gauss-ILRMA path: dispatch over n_sources to the per-N MFMA
 // translation units (ilrma_kernels.hip, built with -DSSSPY_N=n) plus the small
 // normalisation / weight kernels that do not depend on N at compile time.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace ssspy {
@@ -8,14 +10,37 @@ namespace ssspy {
 #define DECL_N(n)                                                                               \
   int ilrma_basis_n##n(const void *, const void *, const double *, double *, const double *,   \
                        int, int, int, int, double, int, double, hipStream_t);                  \
-  int ilrma_activation_n##n(const void *, const void *, const double *, double *, double *, int, \
-                            int, int, int, int, double, int, double, hipStream_t);             \
+  int ilrma_activation_n##n(const void *, const void *, const double *, const double *, double *, \
+                            int, int, int, int, int, double, hipStream_t);                     \
   int ilrma_wcov_n##n(const void *, const double *, const double *, void *, int, int, int, int, \
                       double, hipStream_t);                                                    \
   int ilrma_loss_n##n(const void *, const void *, const double *, const double *, double *, int, \
                       int, int, int, double, hipStream_t);
 DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
 #undef DECL_N
+
+// throughput variants (ilrma_fast.hip): domain == 2, n_basis <= 16, n_sources <= 4, even T
+#define DECL_FAST(n)                                                                           \
+  int ilrma_fast_basis_n##n(const void *, const void *, double *, const double *, int, int, int, \
+                            int, int, double, hipStream_t);                                    \
+  int ilrma_fast_activation_n##n(const void *, const void *, const double *, const double *,   \
+                                 double *, int, int, int, int, int, hipStream_t);              \
+  int ilrma_fast_wcov_n##n(const void *, const double *, const double *, void *, int, int, int, \
+                           int, hipStream_t);
+DECL_FAST(2) DECL_FAST(3) DECL_FAST(4)
+#undef DECL_FAST
+
+#define ILRMA_FAST_DISPATCH(N_, fn, ...)             \
+  switch (N_) {                                      \
+    case 2: return fn##_n2(__VA_ARGS__);             \
+    case 3: return fn##_n3(__VA_ARGS__);             \
+    default: return fn##_n4(__VA_ARGS__);            \
+  }
+
+static inline bool fast_path(int N, int T, int K, double domain) {
+  static const bool disabled = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;
+  return !disabled && N >= 2 && N <= 4 && K <= 16 && (T % 2 == 0) && domain == 2.0;
+}
 
 #define ILRMA_DISPATCH(N_, fn, ...)                                                  \
   switch (N_) {                                                                      \
@@ -50,6 +75,26 @@ static inline size_t act_part_bytes(int B, int N, int F, int T, int K) {
 static inline size_t basis_tmp_bytes(int B, int N, int F, int K) {
   return K > 16 ? align256((size_t)B * N * F * K * sizeof(double)) : 0;
 }
+
+// V <- floor(V * (sum_chunks num / sum_chunks den)^(p/(p+2)))
+__global__ __launch_bounds__(256) void k_ilrma_activation_finalize(double *act,
+                                                                   const double *__restrict__ part,
+                                                                   int N, int K, int T,
+                                                                   int nchunks, double p,
+                                                                   int floor_kind, double eps) {
+  const int b = blockIdx.z, n = blockIdx.y;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over K*T
+  if (e >= (long long)K * T) return;
+  double sn = 0.0, sd = 0.0;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const long long base = ((((long long)b * nchunks + ch) * N + n) * 2) * K * T;
+    sn += part[base + e];
+    sd += part[base + (long long)K * T + e];
+  }
+  double *dst = act + ((long long)b * N + n) * K * T + e;
+  *dst = apply_floor(((p == 2.0) ? sqrt(sn / sd) : pow(sn / sd, p / (p + 2.0))) * (*dst), floor_kind, eps);
+}
+
 
 // ------------------------------------------------------------------ power normalisation (filter)
 // one block per mixture; psi_n^2 = (1/F) sum_i Re(w_in C_i w_in^H), rows w_in of W_i.
@@ -166,6 +211,10 @@ int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const 
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_basis: n_basis must be in [1, 64]");
   SSSPY_REQUIRE(domain > 0.0 && domain <= 2.0, "update_basis: domain must be in (0, 2]");
   hipStream_t st = as_stream(stream);
+  if (fast_path(N, T, K, domain)) {
+    ILRMA_FAST_DISPATCH(N, ilrma_fast_basis, X, W, basis, activation, B, F, T, K, floor_kind,
+                        floor_eps, st);
+  }
   double *out = basis;
   if (K > 16) {
     SSSPY_REQUIRE(workspace && workspace_bytes >= basis_tmp_bytes(B, N, F, K),
@@ -196,8 +245,21 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
   SSSPY_REQUIRE(workspace && workspace_bytes >= act_part_bytes(B, N, F, T, K),
                 "update_activation: workspace too small");
   const int chunks = act_chunks(B, N, F, T, K);
-  ILRMA_DISPATCH(N, ilrma_activation, X, W, basis, activation, (double *)workspace, chunks, B, F,
-                 T, K, domain, floor_kind, floor_eps, as_stream(stream));
+  hipStream_t st = as_stream(stream);
+  auto run = [&]() -> int {
+    if (fast_path(N, T, K, domain)) {
+      ILRMA_FAST_DISPATCH(N, ilrma_fast_activation, X, W, basis, activation, (double *)workspace,
+                          chunks, B, F, T, K, st);
+    }
+    ILRMA_DISPATCH(N, ilrma_activation, X, W, basis, activation, (double *)workspace, chunks, B, F,
+                   T, K, domain, st);
+  };
+  int rc = run();
+  if (rc) return rc;
+  dim3 g2((unsigned)(((long long)K * T + 255) / 256), N, B);
+  hipLaunchKernelGGL(k_ilrma_activation_finalize, g2, dim3(256), 0, st, activation,
+                     (const double *)workspace, N, K, T, chunks, domain, floor_kind, floor_eps);
+  return check_launch("k_ilrma_activation_finalize");
 }
 
 int ssspy_ilrma_weighted_covariance(const void *X, const double *basis, const double *activation,
@@ -206,6 +268,10 @@ int ssspy_ilrma_weighted_covariance(const void *X, const double *basis, const do
   SSSPY_REQUIRE(X && basis && activation && U && B > 0 && F > 0 && T > 0,
                 "ilrma_weighted_covariance: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "ilrma_weighted_covariance: bad n_basis");
+  if (fast_path(N, T, K, domain)) {
+    ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, basis, activation, U, B, F, T, K,
+                        as_stream(stream));
+  }
   ILRMA_DISPATCH(N, ilrma_wcov, X, basis, activation, U, B, F, T, K, domain, as_stream(stream));
 }
 

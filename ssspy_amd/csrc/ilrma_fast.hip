@@ -1,0 +1,454 @@
+// Throughput kernels of the Gauss-ILRMA iteration for the common case
+//   domain == 2, n_basis <= 16, n_sources <= 4, n_frames even.
+// Same math and MFMA tilings as ilrma_kernels.hip (see the header comment there); what
+// changes is the scheduling, driven by the first rocprof PMC pass on MI355X (profiles/):
+// the generic kernels sat in s_waitcnt 71 % of the time at one wave per SIMD because every
+// tile did ~50 dependent global loads between short compute segments.  Here
+//   * a workgroup is 4 waves that share the operand tile that changes along the walk:
+//     bin-major kernels (basis, covariance): waves own 4 adjacent 16-bin tiles and walk the
+//     frame tiles together, the 16x16 activation tile of every source is staged once per
+//     workgroup in LDS (double buffered, one barrier per tile);
+//     frame-major kernel (activation): waves own 4 adjacent 16-frame tiles and walk the bin
+//     tiles together, the basis tile and the demixing matrices are staged in LDS;
+//   * the 16-byte x loads of the NEXT tile are issued into a second register set before
+//     the current tile is computed (software prefetch instead of occupancy);
+//   * the tile body is straight-line (no uniform branches, no pow) so hipcc can interleave
+//     MFMA issue with the fp64 VALU work of the neighbouring source;
+//   * 1/R is v_rcp_f64 + 2 Newton steps (~1 ulp) instead of the IEEE divide sequence;
+//   * accumulators stay with the wave that owns the bins: no cross-wave fold.
+// Compiled once per N (-DSSSPY_N=2..4).
+#include "common.hpp"
+#include "cov_core.hpp"
+
+#ifndef SSSPY_N
+#error "compile with -DSSSPY_N=<n_sources>"
+#endif
+#if SSSPY_N > 4
+#error "fast path is built for n_sources <= 4"
+#endif
+
+#define SSSPY_CAT_(a, b) a##b
+#define SSSPY_CAT(a, b) SSSPY_CAT_(a, b)
+#define LAUNCHER(name) SSSPY_CAT(SSSPY_CAT(name, _n), SSSPY_N)
+
+namespace ssspy {
+namespace SSSPY_CAT(ilrma_fast_n, SSSPY_N) {
+
+constexpr int N = SSSPY_N;
+constexpr int VROW = 18;  // doubles per staged row (16 + 2 pad: 144-byte stride, see header)
+
+__device__ __forceinline__ double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  return r;
+}
+
+__device__ __forceinline__ int tile_pi(int rho) { return 4 * (rho & 3) + (rho >> 2); }
+
+// ---- stage the activation tile V[b, n, 0:16, j0:j0+16] of every source into LDS rows of VROW
+// doubles (zero beyond K rows / T frames).  256 threads, N*16 rows * 8 double2 chunks.
+struct VStage {
+  double2 v[(N * 16 * 8 + 255) / 256];
+};
+
+__device__ __forceinline__ void vstage_load(VStage &st, const double *__restrict__ act_b, int K,
+                                            int T, int j0) {
+#pragma unroll
+  for (int u = 0; u < (N * 16 * 8 + 255) / 256; ++u) {
+    const int idx = threadIdx.x + 256 * u;
+    const int row = idx >> 3, chunk = idx & 7;  // row = n*16 + k
+    const int n = row >> 4, k = row & 15;
+    const int j = j0 + 2 * chunk;
+    double2 val = make_double2(0.0, 0.0);
+    if (idx < N * 16 * 8 && k < K && j < T)  // T even and j even: j+1 < T as well
+      val = *reinterpret_cast<const double2 *>(act_b + ((long long)n * K + k) * T + j);
+    st.v[u] = val;
+  }
+}
+
+__device__ __forceinline__ void vstage_store(const VStage &st, double *buf) {
+#pragma unroll
+  for (int u = 0; u < (N * 16 * 8 + 255) / 256; ++u) {
+    const int idx = threadIdx.x + 256 * u;
+    const int row = idx >> 3, chunk = idx & 7;
+    if (idx < N * 16 * 8)
+      *reinterpret_cast<double2 *>(buf + row * VROW + 2 * chunk) = st.v[u];
+  }
+}
+
+struct XTile {
+  c128 x[N][4];
+};
+
+// bin-major x tile: lane (c, q) reads frames j0+4q+r of bin `bin` (64 contiguous bytes/channel)
+__device__ __forceinline__ void xtile_load_binmajor(XTile &xt, const c128 *__restrict__ Xb, int F,
+                                                    int T, int bin, int j0, int q) {
+  const int j = j0 + 4 * q;
+#pragma unroll
+  for (int m = 0; m < N; ++m) {
+    const c128 *row = Xb + ((long long)m * F + bin) * T;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xt.x[m][r] = row[min(j + r, T - 1)];
+  }
+}
+
+// GEMM1 of the bin-major tile from the staged V: R[bin c, frame j0+4q+r] in register r
+__device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const double (&tb)[4], int c,
+                                                 int q) {
+  double4_t R = {0.0, 0.0, 0.0, 0.0};
+  const int col = tile_pi(c);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) R = mfma_f64(vs_n[(4 * ks + q) * VROW + col], tb[ks], R);
+  return R;
+}
+
+// =============================================================================== basis (pass 1)
+// grid: (ceil(F/64), 1, B); 256 threads; wave w owns bins [64*bx + 16w, +16).
+__global__ __launch_bounds__(256) void k_basis_fast(const c128 *__restrict__ X,
+                                                    const c128 *__restrict__ W, double *basis,
+                                                    const double *__restrict__ act, int F, int T,
+                                                    int K, int floor_kind, double eps) {
+  __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int b = blockIdx.z;
+  const int i0 = blockIdx.x * 64 + wave * 16;
+  const int bin = min(i0 + c, F - 1);
+  const c128 *Xb = X + (long long)b * N * F * T;
+  const double *act_b = act + (long long)b * N * K * T;
+
+  c128 w[N][N];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int m = 0; m < N; ++m)
+      w[n][m] = W ? W[(((long long)b * F + bin) * N + n) * N + m] : cmake(m == n ? 1.0 : 0.0, 0.0);
+  double tb[N][4];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kk = 4 * ks + q;
+      tb[n][ks] = kk < K ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
+    }
+  double4_t num[N], den[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    num[n] = double4_t{0.0, 0.0, 0.0, 0.0};
+    den[n] = double4_t{0.0, 0.0, 0.0, 0.0};
+  }
+
+  const int ntiles = (T + 15) >> 4;
+  VStage st;
+  XTile cur, nxt;
+  vstage_load(st, act_b, K, T, 0);
+  xtile_load_binmajor(cur, Xb, F, T, bin, 0, q);
+  vstage_store(st, vs[0]);
+  __syncthreads();
+
+  for (int jt = 0; jt < ntiles; ++jt) {
+    const int j0 = jt * 16;
+    const int jn = min(jt + 1, ntiles - 1) * 16;  // last iteration re-fetches its own tile
+    vstage_load(st, act_b, K, T, jn);
+    xtile_load_binmajor(nxt, Xb, F, T, bin, jn, q);
+    const double *vcur = vs[jt & 1];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const double *vn = vcur + n * 16 * VROW;
+      const double4_t R = rt_from_lds(vn, tb[n], c, q);
+      // GEMM2 B operand: V[k = c, frame j0+4q+r] (zero rows/frames were staged as zeros)
+      const double2 vb01 = *reinterpret_cast<const double2 *>(vn + c * VROW + 4 * q);
+      const double2 vb23 = *reinterpret_cast<const double2 *>(vn + c * VROW + 4 * q + 2);
+      const double vb[4] = {vb01.x, vb01.y, vb23.x, vb23.y};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        c128 y = cmake(0.0, 0.0);
+#pragma unroll
+        for (int m = 0; m < N; ++m) cfma(y, w[n][m], cur.x[m][r]);
+        const bool valid = j0 + 4 * q + r < T;
+        const double rinv = rcp_nr(R[r]);
+        const double bb = valid ? rinv : 0.0;
+        const double aa = valid ? cabs2(y) * rinv * rinv : 0.0;
+        num[n] = mfma_f64(aa, vb[r], num[n]);
+        den[n] = mfma_f64(bb, vb[r], den[n]);
+      }
+    }
+    vstage_store(st, vs[(jt + 1) & 1]);
+    __syncthreads();
+    cur = nxt;
+  }
+  // D: col = basis index c, row = q + 4r -> bin i0 + q + 4r
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ob = i0 + q + 4 * r;
+      if (ob < F && c < K) {
+        double *dst = basis + (((long long)b * N + n) * F + ob) * K + c;
+        *dst = apply_floor(sqrt(num[n][r] / den[n][r]) * (*dst), floor_kind, eps);
+      }
+    }
+}
+
+// ================================================================== weighted covariance (pass 3)
+// U[b,i,n] = (1/T) sum_j x x^H / R.  grid: (ceil(F/64), 1, B)
+__global__ __launch_bounds__(256) void k_wcov_fast(const c128 *__restrict__ X,
+                                                   const double *__restrict__ basis,
+                                                   const double *__restrict__ act,
+                                                   c128 *__restrict__ U, int F, int T, int K) {
+  __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int b = blockIdx.z;
+  const int i0 = blockIdx.x * 64 + wave * 16;
+  const int bin = min(i0 + c, F - 1);
+  const c128 *Xb = X + (long long)b * N * F * T;
+  const double *act_b = act + (long long)b * N * K * T;
+  double tb[N][4];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kk = 4 * ks + q;
+      tb[n][ks] = kk < K ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
+    }
+  CovAcc<N, N> acc;
+  acc.clear();
+  const int ntiles = (T + 15) >> 4;
+  VStage st;
+  XTile cur, nxt;
+  vstage_load(st, act_b, K, T, 0);
+  xtile_load_binmajor(cur, Xb, F, T, bin, 0, q);
+  vstage_store(st, vs[0]);
+  __syncthreads();
+  for (int jt = 0; jt < ntiles; ++jt) {
+    const int j0 = jt * 16;
+    const int jn = min(jt + 1, ntiles - 1) * 16;
+    vstage_load(st, act_b, K, T, jn);
+    xtile_load_binmajor(nxt, Xb, F, T, bin, jn, q);
+    const double *vcur = vs[jt & 1];
+    double4_t R[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) R[n] = rt_from_lds(vcur + n * 16 * VROW, tb[n], c, q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool valid = j0 + 4 * q + r < T;
+      c128 x[N];
+      double phi[N];
+#pragma unroll
+      for (int m = 0; m < N; ++m) x[m] = cur.x[m][r];
+#pragma unroll
+      for (int n = 0; n < N; ++n) phi[n] = valid ? rcp_nr(R[n][r]) : 0.0;
+      acc.add(x, phi);
+    }
+    vstage_store(st, vs[(jt + 1) & 1]);
+    __syncthreads();
+    cur = nxt;
+  }
+  acc.fold_q();
+  // lane (c, q) now holds the full sums of bin i0+c; the 4 q-lanes write a quarter each
+  const double scale = 1.0 / (double)T;
+  const int ob = i0 + c;
+  if (ob < F) {
+    c128 *dst = U + ((long long)b * F + ob) * (long long)(N * N * N);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      if ((n & 3) == q || N < 4) {
+        int e = 0;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+          if (N == 4 || q == 0) dst[(n * N + a) * N + a] = cmake(acc.diag[n][a] * scale, 0.0);
+#pragma unroll
+          for (int bb = a + 1; bb < N; ++bb) {
+            const c128 z = acc.off[n][e];
+            if (N == 4 || q == 0) {
+              dst[(n * N + a) * N + bb] = cmake(z.x * scale, z.y * scale);
+              dst[(n * N + bb) * N + a] = cmake(z.x * scale, -z.y * scale);
+            }
+            ++e;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ========================================================================= activation (pass 2)
+// grid: (ceil(T/64), chunks, B); wave w owns frames [64*bx + 16w, +16) and walks the bin tiles
+// of its chunk; the basis tile (all sources) and the 16 demixing matrices are staged in LDS.
+struct TStage {
+  double t[(N * 16 * 16 + 255) / 256];
+  c128 w;
+};
+
+__device__ __forceinline__ void tstage_load(TStage &st, const double *__restrict__ basis_b,
+                                            const c128 *__restrict__ W_b, int F, int K, int i0) {
+#pragma unroll
+  for (int u = 0; u < (N * 16 * 16 + 255) / 256; ++u) {
+    const int idx = threadIdx.x + 256 * u;  // (n, bin, k)
+    const int k = idx & 15, bl = (idx >> 4) & 15, n = idx >> 8;
+    const int bi = i0 + bl;
+    double v = 0.0;
+    if (idx < N * 256 && k < K && bi < F) v = basis_b[((long long)n * F + bi) * K + k];
+    st.t[u] = v;
+  }
+  {
+    const int idx = threadIdx.x;  // (bin, n, m), N*N*16 <= 256
+    const int bl = idx / (N * N), rem = idx % (N * N);
+    const int bi = min(i0 + bl, F - 1);
+    c128 v = cmake(0.0, 0.0);
+    if (idx < 16 * N * N)
+      v = W_b ? W_b[(long long)bi * (N * N) + rem] : cmake((rem / N) == (rem % N) ? 1.0 : 0.0, 0.0);
+    st.w = v;
+  }
+}
+
+constexpr int TROW = 17;  // doubles per staged basis row (16 + 1 pad)
+
+__device__ __forceinline__ void tstage_store(const TStage &st, double *tbuf, c128 *wbuf) {
+#pragma unroll
+  for (int u = 0; u < (N * 16 * 16 + 255) / 256; ++u) {
+    const int idx = threadIdx.x + 256 * u;
+    const int k = idx & 15, row = idx >> 4;  // row = n*16 + bin
+    if (idx < N * 256) tbuf[row * TROW + k] = st.t[u];
+  }
+  if (threadIdx.x < 16 * N * N) wbuf[threadIdx.x] = st.w;
+}
+
+__device__ __forceinline__ void xtile_load_framemajor(XTile &xt, const c128 *__restrict__ Xb, int F,
+                                                      int T, int i0, int jc, int q) {
+#pragma unroll
+  for (int m = 0; m < N; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int bi = min(i0 + q + 4 * r, F - 1);
+      xt.x[m][r] = Xb[((long long)m * F + bi) * T + jc];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_activation_fast(const c128 *__restrict__ X,
+                                                         const c128 *__restrict__ W,
+                                                         const double *__restrict__ basis,
+                                                         const double *__restrict__ act,
+                                                         double *__restrict__ part, int F, int T,
+                                                         int K, int tiles_per_chunk, int nchunks) {
+  __shared__ __attribute__((aligned(16))) double ts[2][N * 16 * TROW];
+  __shared__ __attribute__((aligned(16))) c128 ws[2][16 * N * N];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int b = blockIdx.z, chunk = blockIdx.y;
+  const int j0 = (blockIdx.x * 4 + wave) * 16;
+  const int jf = j0 + c;
+  const bool fvalid = jf < T;
+  const int jc = fvalid ? jf : T - 1;
+  const c128 *Xb = X + (long long)b * N * F * T;
+  const double *basis_b = basis + (long long)b * N * F * K;
+  const c128 *W_b = W ? W + (long long)b * F * N * N : nullptr;
+
+  double vb[N][4];  // GEMM1 B operand V[n, 4ks+q, frame]
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kk = 4 * ks + q;
+      vb[n][ks] = (kk < K && fvalid) ? act[(((long long)b * N + n) * K + kk) * T + jc] : 0.0;
+    }
+  double4_t numv[N], denv[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    numv[n] = double4_t{0.0, 0.0, 0.0, 0.0};
+    denv[n] = double4_t{0.0, 0.0, 0.0, 0.0};
+  }
+  const int ntiles = (F + 15) >> 4;
+  const int t_begin = chunk * tiles_per_chunk;
+  const int t_end = min(ntiles, t_begin + tiles_per_chunk);
+  TStage st;
+  XTile cur, nxt;
+  tstage_load(st, basis_b, W_b, F, K, t_begin * 16);
+  xtile_load_framemajor(cur, Xb, F, T, t_begin * 16, jc, q);
+  tstage_store(st, ts[0], ws[0]);
+  __syncthreads();
+  for (int it = t_begin; it < t_end; ++it) {
+    const int i0 = it * 16;
+    const int in = min(it + 1, t_end - 1) * 16;
+    tstage_load(st, basis_b, W_b, F, K, in);
+    xtile_load_framemajor(nxt, Xb, F, T, in, jc, q);
+    const int pb = (it - t_begin) & 1;
+    const double *tcur = ts[pb];
+    const c128 *wcur = ws[pb];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const double *tn = tcur + n * 16 * TROW;
+      // GEMM1: A[row = c -> bin i0+c][kk = q] = T[n, i0+c, 4ks+q]
+      double4_t R = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) R = mfma_f64(tn[c * TROW + 4 * ks + q], vb[n][ks], R);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int bl = q + 4 * r;
+        const c128 *wr = wcur + (bl * N + n) * N;
+        c128 y = cmake(0.0, 0.0);
+#pragma unroll
+        for (int m = 0; m < N; ++m) cfma(y, wr[m], cur.x[m][r]);
+        const bool valid = fvalid && (i0 + bl < F);
+        const double rinv = rcp_nr(R[r]);
+        const double bb = valid ? rinv : 0.0;
+        const double aa = valid ? cabs2(y) * rinv * rinv : 0.0;
+        // GEMM2: A[row = c -> basis index c][kk = q] = T[n, bin i0+q+4r, c] (zero-staged pads)
+        const double ta = tn[bl * TROW + c];
+        numv[n] = mfma_f64(ta, aa, numv[n]);
+        denv[n] = mfma_f64(ta, bb, denv[n]);
+      }
+    }
+    tstage_store(st, ts[pb ^ 1], ws[pb ^ 1]);
+    __syncthreads();
+    cur = nxt;
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ok = q + 4 * r;
+      if (ok < K && fvalid) {
+        const long long base = ((((long long)b * nchunks + chunk) * N + n) * 2) * K;
+        part[(base + ok) * T + jf] = numv[n][r];
+        part[(base + K + ok) * T + jf] = denv[n][r];
+      }
+    }
+}
+
+}  // namespace ilrma_fast_n<N>
+using namespace SSSPY_CAT(ilrma_fast_n, SSSPY_N);
+
+int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, double *basis, const double *act,
+                               int B, int F, int T, int K, int floor_kind, double eps,
+                               hipStream_t st) {
+  dim3 grid((F + 63) / 64, 1, B), block(256);
+  hipLaunchKernelGGL(k_basis_fast, grid, block, 0, st, (const c128 *)X, (const c128 *)W, basis,
+                     act, F, T, K, floor_kind, eps);
+  return check_launch("k_basis_fast");
+}
+
+int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *basis,
+                                    const double *act, double *part, int nchunks, int B, int F,
+                                    int T, int K, hipStream_t st) {
+  const int ntiles = (F + 15) / 16;
+  const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
+  dim3 grid((T + 63) / 64, nchunks, B), block(256);
+  hipLaunchKernelGGL(k_activation_fast, grid, block, 0, st, (const c128 *)X, (const c128 *)W,
+                     basis, act, part, F, T, K, tiles_per_chunk, nchunks);
+  return check_launch("k_activation_fast");
+}
+
+int LAUNCHER(ilrma_fast_wcov)(const void *X, const double *basis, const double *act, void *U,
+                              int B, int F, int T, int K, hipStream_t st) {
+  dim3 grid((F + 63) / 64, 1, B), block(256);
+  hipLaunchKernelGGL(k_wcov_fast, grid, block, 0, st, (const c128 *)X, basis, act, (c128 *)U, F, T,
+                     K);
+  return check_launch("k_wcov_fast");
+}
+
+}  // namespace ssspy

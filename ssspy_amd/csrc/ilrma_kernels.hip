@@ -362,25 +362,6 @@ __global__ __launch_bounds__(256) void k_ilrma_activation(const c128 *__restrict
   }
 }
 
-// V <- floor(V * (sum_chunks num / sum_chunks den)^(p/(p+2)))
-__global__ __launch_bounds__(256) void k_ilrma_activation_finalize(double *act,
-                                                                   const double *__restrict__ part,
-                                                                   int N, int K, int T,
-                                                                   int nchunks, double p,
-                                                                   int floor_kind, double eps) {
-  const int b = blockIdx.z, n = blockIdx.y;
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over K*T
-  if (e >= (long long)K * T) return;
-  double sn = 0.0, sd = 0.0;
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const long long base = ((((long long)b * nchunks + ch) * N + n) * 2) * K * T;
-    sn += part[base + e];
-    sd += part[base + (long long)K * T + e];
-  }
-  double *dst = act + ((long long)b * N + n) * K * T + e;
-  *dst = apply_floor(mm_ratio_pow(sn, sd, p) * (*dst), floor_kind, eps);
-}
-
 // ============================================================ pass 3: NMF-weighted covariance
 // U[b,i,n] = (1/T) sum_j x x^H / R^(2/p).  grid: (bin tiles, 1, B*NGROUPS)
 template <bool KSMALL>
@@ -537,9 +518,9 @@ int LAUNCHER(ilrma_basis)(const void *X, const void *W, const double *basis, dou
   return check_launch("k_ilrma_basis");
 }
 
-int LAUNCHER(ilrma_activation)(const void *X, const void *W, const double *basis, double *act,
-                               double *part, int nchunks, int B, int F, int T, int K, double p,
-                               int floor_kind, double eps, hipStream_t st) {
+int LAUNCHER(ilrma_activation)(const void *X, const void *W, const double *basis,
+                               const double *act, double *part, int nchunks, int B, int F, int T,
+                               int K, double p, hipStream_t st) {
   IlrmaDims d{B, F, T, K, p};
   const int ntiles = (F + 15) / 16;
   const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
@@ -551,12 +532,7 @@ int LAUNCHER(ilrma_activation)(const void *X, const void *W, const double *basis
   else
     hipLaunchKernelGGL((k_ilrma_activation<false>), grid, block, 0, st, (const c128 *)X,
                        (const c128 *)W, basis, act, part, d, ktiles, tiles_per_chunk, nchunks);
-  int rc = check_launch("k_ilrma_activation");
-  if (rc) return rc;
-  dim3 g2((unsigned)(((long long)K * T + 255) / 256), NSRC, B);
-  hipLaunchKernelGGL(k_ilrma_activation_finalize, g2, block, 0, st, act, part, NSRC, K, T,
-                     nchunks, p, floor_kind, eps);
-  return check_launch("k_ilrma_activation_finalize");
+  return check_launch("k_ilrma_activation");
 }
 
 int LAUNCHER(ilrma_wcov)(const void *X, const double *basis, const double *act, void *U, int B,
