@@ -143,7 +143,8 @@ int ssspy_ilrma_weighted_covariance(const void *X, const double *basis, const do
  * psi_n = floor(sqrt(mean_i w_in^H C_i w_in)); W[:,n,:] /= psi_n; basis[n] /= psi_n^p.
  * replaces: ssspy/bss/ilrma.py:365-444 (normalize_by_power, demix-filter branch). */
 int ssspy_ilrma_normalize_filter(void *W, const void *C, double *basis, int B, int N, int F, int K,
-                                 double domain, int floor_kind, double floor_eps, void *stream);
+                                 double domain, int floor_kind, double floor_eps, void *workspace,
+                                 size_t workspace_bytes, void *stream);
 
 /* same for the ISS state: psi from |Y|^2 directly, Y /= psi, basis /= psi^p.
  * replaces: ssspy/bss/ilrma.py:365-444 (normalize_by_power, demix_filter is None branch). */

@@ -145,12 +145,12 @@ def ilrma_weighted_covariance(X, basis, activation, domain, out=None):
     return out
 
 
-def ilrma_normalize_filter(W, C, basis, domain, flooring):
+def ilrma_normalize_filter(W, C, basis, domain, flooring, ws, ws_bytes):
     B, F, N, _ = W.shape
     K = basis.shape[-1]
     _lib.check(
         _L().ssspy_ilrma_normalize_filter(ptr(W), ptr(C), ptr(basis), B, N, F, K, domain,
-                                          flooring[0], flooring[1], _st()),
+                                          flooring[0], flooring[1], ptr(ws), ws_bytes, _st()),
         "ilrma_normalize_filter",
     )
 

@@ -416,7 +416,8 @@ class GaussILRMA(ILRMABase):
         floor = self._resolve_floor(flooring_fn)
         if self._uses_filter():
             _ops.ilrma_normalize_filter(self._state_dev("demix_filter"), self._C(),
-                                        self._state_dev("basis"), float(self.domain), floor)
+                                        self._state_dev("basis"), float(self.domain), floor,
+                                        self._ws, self._ws_bytes)
             self._state_touch("demix_filter")
         else:
             _ops.ilrma_normalize_output(self._state_dev("output"), self._state_dev("basis"),

@@ -75,6 +75,13 @@ static inline size_t act_part_bytes(int B, int N, int F, int T, int K) {
 static inline size_t basis_tmp_bytes(int B, int N, int F, int K) {
   return K > 16 ? align256((size_t)B * N * F * K * sizeof(double)) : 0;
 }
+static inline size_t qbuf_bytes(int B, int N, int F) {
+  return align256((size_t)B * F * N * sizeof(double));
+}
+
+int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, int F, int N,
+                   int floor_kind, double floor_eps, int *info, hipStream_t st);
+int row_power(const void *W, const void *C, double *qbuf, int B, int F, int N, hipStream_t st);
 
 // V <- floor(V * (sum_chunks num / sum_chunks den)^(p/(p+2)))
 __global__ __launch_bounds__(256) void k_ilrma_activation_finalize(double *act,
@@ -97,51 +104,40 @@ __global__ __launch_bounds__(256) void k_ilrma_activation_finalize(double *act,
 
 
 // ------------------------------------------------------------------ power normalisation (filter)
-// one block per mixture; psi_n^2 = (1/F) sum_i Re(w_in C_i w_in^H), rows w_in of W_i.
-__global__ __launch_bounds__(256) void k_ilrma_normalize_filter(c128 *W, const c128 *__restrict__ C,
-                                                                double *basis, int N, int F,
-                                                                int K, double p, int floor_kind,
-                                                                double eps) {
+// psi_n^2 = (1/F) sum_i q[i][n], q[i][n] = Re(w_in C_i w_in^H) = mean_j |y_nij|^2.
+// q comes from the IP1 kernel (fused iteration) or from k_row_power (stand-alone call).
+// grid: (ceil(F/64), B).  Every block folds q over all bins (fixed order: deterministic), then
+// scales the demixing rows and basis rows of its own 64 bins.
+__global__ __launch_bounds__(256) void k_norm_scale(c128 *W, double *basis,
+                                                    const double *__restrict__ qbuf, int N, int F,
+                                                    int K, double p, int floor_kind, double eps) {
   __shared__ double scratch[4];
   __shared__ double psi[SSSPY_MAX_SOURCES];
-  const int b = blockIdx.x;
-  c128 *Wb = W + (long long)b * F * N * N;
-  const c128 *Cb = C + (long long)b * F * N * N;
+  const int b = blockIdx.y;
+  const double *qb = qbuf + (long long)b * F * N;
   for (int n = 0; n < N; ++n) {
     double local = 0.0;
-    for (int i = threadIdx.x; i < F; i += blockDim.x) {
-      const c128 *w = Wb + ((long long)i * N + n) * N;
-      const c128 *Ci = Cb + (long long)i * N * N;
-      double qf = 0.0;
-      for (int a = 0; a < N; ++a) {
-        c128 t = cmake(0.0, 0.0);  // t = sum_c C[a][c] conj(w[c])
-        for (int c = 0; c < N; ++c) {
-          const c128 u = Ci[a * N + c], wc = w[c];
-          t.x += u.x * wc.x + u.y * wc.y;
-          t.y += u.y * wc.x - u.x * wc.y;
-        }
-        qf += w[a].x * t.x - w[a].y * t.y;  // Re(w[a] * t)
-      }
-      local += qf;
-    }
+    for (int i = threadIdx.x; i < F; i += blockDim.x) local += qb[(long long)i * N + n];
     const double total = block_sum(local, scratch);
     if (threadIdx.x == 0) {
       double v = total / (double)F;
-      v = v > 0.0 ? v : 0.0;
+      v = v < 0.0 ? 0.0 : v;
       psi[n] = apply_floor(sqrt(v), floor_kind, eps);
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < F * N * N; e += blockDim.x) {
+  const int i0 = blockIdx.x * 64;
+  const int nb = min(64, F - i0);
+  c128 *Wb = W + ((long long)b * F + i0) * N * N;
+  for (int e = threadIdx.x; e < nb * N * N; e += blockDim.x) {
     const int n = (e / N) % N;
-    c128 v = Wb[e];
+    const c128 v = Wb[e];
     Wb[e] = cmake(v.x / psi[n], v.y / psi[n]);
   }
-  double *Tb = basis + (long long)b * N * F * K;
-  for (int e = threadIdx.x; e < N * F * K; e += blockDim.x) {
-    const int n = e / (F * K);
+  for (int n = 0; n < N; ++n) {
     const double pp = (p == 2.0) ? psi[n] * psi[n] : pow(psi[n], p);
-    Tb[e] = Tb[e] / pp;
+    double *Tb = basis + (((long long)b * N + n) * F + i0) * K;
+    for (int e = threadIdx.x; e < nb * K; e += blockDim.x) Tb[e] = Tb[e] / pp;
   }
 }
 
@@ -199,7 +195,7 @@ extern "C" {
 
 size_t ssspy_ilrma_workspace_bytes(int B, int N, int F, int T, int K) {
   if (B <= 0 || N <= 0 || F <= 0 || T <= 0 || K <= 0) return 0;
-  return act_part_bytes(B, N, F, T, K) + basis_tmp_bytes(B, N, F, K) +
+  return act_part_bytes(B, N, F, T, K) + basis_tmp_bytes(B, N, F, K) + qbuf_bytes(B, N, F) +
          align256((size_t)B * N * sizeof(double));
 }
 
@@ -275,13 +271,25 @@ int ssspy_ilrma_weighted_covariance(const void *X, const double *basis, const do
   ILRMA_DISPATCH(N, ilrma_wcov, X, basis, activation, U, B, F, T, K, domain, as_stream(stream));
 }
 
+static int launch_norm_scale(void *W, double *basis, const double *qbuf, int B, int N, int F, int K,
+                             double domain, int floor_kind, double floor_eps, hipStream_t st) {
+  hipLaunchKernelGGL(k_norm_scale, dim3((F + 63) / 64, B), dim3(256), 0, st, (c128 *)W, basis,
+                     qbuf, N, F, K, domain, floor_kind, floor_eps);
+  return check_launch("k_norm_scale");
+}
+
 int ssspy_ilrma_normalize_filter(void *W, const void *C, double *basis, int B, int N, int F, int K,
-                                 double domain, int floor_kind, double floor_eps, void *stream) {
+                                 double domain, int floor_kind, double floor_eps, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
   SSSPY_REQUIRE(W && C && basis && B > 0 && N >= 1 && N <= SSSPY_MAX_SOURCES,
                 "normalize_filter: bad argument");
-  hipLaunchKernelGGL(k_ilrma_normalize_filter, dim3(B), dim3(256), 0, as_stream(stream),
-                     (c128 *)W, (const c128 *)C, basis, N, F, K, domain, floor_kind, floor_eps);
-  return check_launch("k_ilrma_normalize_filter");
+  SSSPY_REQUIRE(workspace && workspace_bytes >= qbuf_bytes(B, N, F),
+                "normalize_filter: workspace too small");
+  hipStream_t st = as_stream(stream);
+  double *qbuf = (double *)workspace;
+  int rc = row_power(W, C, qbuf, B, F, N, st);
+  if (rc) return rc;
+  return launch_norm_scale(W, basis, qbuf, B, N, F, K, domain, floor_kind, floor_eps, st);
 }
 
 int ssspy_ilrma_normalize_output(void *Y, double *basis, int B, int N, int F, int T, int K,
@@ -340,12 +348,15 @@ int ssspy_gauss_ilrma_ip1_update(const void *X, const void *C, void *W, double *
   if (rc) return rc;
   rc = ssspy_ilrma_weighted_covariance(X, basis, activation, U, B, N, F, T, K, domain, stream);
   if (rc) return rc;
-  rc = ssspy_update_by_ip1(W, U, B, F, N, floor_kind, floor_eps, info, stream);
+  if (!normalize) return ssspy_update_by_ip1(W, U, B, F, N, floor_kind, floor_eps, info, stream);
+  const size_t qoff = act_part_bytes(B, N, F, T, K) + basis_tmp_bytes(B, N, F, K);
+  SSSPY_REQUIRE(workspace_bytes >= qoff + qbuf_bytes(B, N, F),
+                "gauss_ilrma_ip1_update: workspace too small");
+  double *qbuf = (double *)((char *)workspace + qoff);
+  rc = ip1_with_power(W, U, C, qbuf, B, F, N, floor_kind, floor_eps, info, as_stream(stream));
   if (rc) return rc;
-  if (normalize)
-    rc = ssspy_ilrma_normalize_filter(W, C, basis, B, N, F, K, domain, floor_kind, floor_eps,
-                                      stream);
-  return rc;
+  return launch_norm_scale(W, basis, qbuf, B, N, F, K, domain, floor_kind, floor_eps,
+                           as_stream(stream));
 }
 
 }  // extern "C"

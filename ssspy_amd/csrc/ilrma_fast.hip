@@ -10,8 +10,12 @@
 //     workgroup in LDS (double buffered, one barrier per tile);
 //     frame-major kernel (activation): waves own 4 adjacent 16-frame tiles and walk the bin
 //     tiles together, the basis tile and the demixing matrices are staged in LDS;
-//   * the 16-byte x loads of the NEXT tile are issued into a second register set before
-//     the current tile is computed (software prefetch instead of occupancy);
+//   * basis and activation kernels are on a register diet (<= 256 VGPRs, demixing rows read
+//     from LDS) so two workgroups are resident per CU and the second wave of each SIMD fills
+//     the MFMA-dependency stalls of the first (measured: 1.66 -> 1.21 ms and 1.35 -> 1.00 ms
+//     at 128 mixtures); the covariance kernel keeps 64 fp64 accumulators per lane, cannot fit
+//     that budget, and instead prefetches the 16-byte x loads of the NEXT tile into a second
+//     register set at one wave per SIMD;
 //   * the tile body is straight-line (no uniform branches, no pow) so hipcc can interleave
 //     MFMA issue with the fp64 VALU work of the neighbouring source;
 //   * 1/R is v_rcp_f64 + 2 Newton steps (~1 ulp) instead of the IEEE divide sequence;
@@ -107,11 +111,15 @@ __device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const doubl
 
 // =============================================================================== basis (pass 1)
 // grid: (ceil(F/64), 1, B); 256 threads; wave w owns bins [64*bx + 16w, +16).
-__global__ __launch_bounds__(256) void k_basis_fast(const c128 *__restrict__ X,
-                                                    const c128 *__restrict__ W, double *basis,
-                                                    const double *__restrict__ act, int F, int T,
-                                                    int K, int floor_kind, double eps) {
+// Register diet for 2 waves per SIMD (<= 256 VGPR+AGPR): the demixing rows live in LDS and are
+// re-read per (source, channel); the second resident workgroup hides the x-load latency that
+// the one-wave version covered with a register prefetch.
+__global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ X,
+                                                       const c128 *__restrict__ W, double *basis,
+                                                       const double *__restrict__ act, int F,
+                                                       int T, int K, int floor_kind, double eps) {
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
+  __shared__ __attribute__((aligned(16))) c128 wl[4][16 * N * N];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
   const int b = blockIdx.z;
@@ -120,12 +128,14 @@ __global__ __launch_bounds__(256) void k_basis_fast(const c128 *__restrict__ X,
   const c128 *Xb = X + (long long)b * N * F * T;
   const double *act_b = act + (long long)b * N * K * T;
 
-  c128 w[N][N];
-#pragma unroll
-  for (int n = 0; n < N; ++n)
-#pragma unroll
-    for (int m = 0; m < N; ++m)
-      w[n][m] = W ? W[(((long long)b * F + bin) * N + n) * N + m] : cmake(m == n ? 1.0 : 0.0, 0.0);
+  // demixing matrices of the wave's 16 bins -> LDS (wave-private region, filled by the wave)
+  for (int e = lane; e < 16 * N * N; e += 64) {
+    const int bl = e / (N * N), rem = e % (N * N);
+    const int bi = min(i0 + bl, F - 1);
+    wl[wave][e] = W ? W[((long long)b * F + bi) * (N * N) + rem]
+                    : cmake((rem / N) == (rem % N) ? 1.0 : 0.0, 0.0);
+  }
+  const c128 *wmine = wl[wave] + c * N * N;
   double tb[N][4];
 #pragma unroll
   for (int n = 0; n < N; ++n)
@@ -143,31 +153,32 @@ __global__ __launch_bounds__(256) void k_basis_fast(const c128 *__restrict__ X,
 
   const int ntiles = (T + 15) >> 4;
   VStage st;
-  XTile cur, nxt;
+  XTile cur;
   vstage_load(st, act_b, K, T, 0);
-  xtile_load_binmajor(cur, Xb, F, T, bin, 0, q);
   vstage_store(st, vs[0]);
   __syncthreads();
 
   for (int jt = 0; jt < ntiles; ++jt) {
     const int j0 = jt * 16;
     const int jn = min(jt + 1, ntiles - 1) * 16;  // last iteration re-fetches its own tile
+    xtile_load_binmajor(cur, Xb, F, T, bin, j0, q);
     vstage_load(st, act_b, K, T, jn);
-    xtile_load_binmajor(nxt, Xb, F, T, bin, jn, q);
     const double *vcur = vs[jt & 1];
 #pragma unroll
     for (int n = 0; n < N; ++n) {
       const double *vn = vcur + n * 16 * VROW;
       const double4_t R = rt_from_lds(vn, tb[n], c, q);
-      // GEMM2 B operand: V[k = c, frame j0+4q+r] (zero rows/frames were staged as zeros)
       const double2 vb01 = *reinterpret_cast<const double2 *>(vn + c * VROW + 4 * q);
       const double2 vb23 = *reinterpret_cast<const double2 *>(vn + c * VROW + 4 * q + 2);
       const double vb[4] = {vb01.x, vb01.y, vb23.x, vb23.y};
+      c128 wr[N];
+#pragma unroll
+      for (int m = 0; m < N; ++m) wr[m] = wmine[n * N + m];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         c128 y = cmake(0.0, 0.0);
 #pragma unroll
-        for (int m = 0; m < N; ++m) cfma(y, w[n][m], cur.x[m][r]);
+        for (int m = 0; m < N; ++m) cfma(y, wr[m], cur.x[m][r]);
         const bool valid = j0 + 4 * q + r < T;
         const double rinv = rcp_nr(R[r]);
         const double bb = valid ? rinv : 0.0;
@@ -178,7 +189,6 @@ __global__ __launch_bounds__(256) void k_basis_fast(const c128 *__restrict__ X,
     }
     vstage_store(st, vs[(jt + 1) & 1]);
     __syncthreads();
-    cur = nxt;
   }
   // D: col = basis index c, row = q + 4r -> bin i0 + q + 4r
 #pragma unroll
@@ -329,7 +339,7 @@ __device__ __forceinline__ void xtile_load_framemajor(XTile &xt, const c128 *__r
     }
 }
 
-__global__ __launch_bounds__(256) void k_activation_fast(const c128 *__restrict__ X,
+__global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restrict__ X,
                                                          const c128 *__restrict__ W,
                                                          const double *__restrict__ basis,
                                                          const double *__restrict__ act,
@@ -366,16 +376,15 @@ __global__ __launch_bounds__(256) void k_activation_fast(const c128 *__restrict_
   const int t_begin = chunk * tiles_per_chunk;
   const int t_end = min(ntiles, t_begin + tiles_per_chunk);
   TStage st;
-  XTile cur, nxt;
+  XTile cur;
   tstage_load(st, basis_b, W_b, F, K, t_begin * 16);
-  xtile_load_framemajor(cur, Xb, F, T, t_begin * 16, jc, q);
   tstage_store(st, ts[0], ws[0]);
   __syncthreads();
   for (int it = t_begin; it < t_end; ++it) {
     const int i0 = it * 16;
     const int in = min(it + 1, t_end - 1) * 16;
+    xtile_load_framemajor(cur, Xb, F, T, i0, jc, q);
     tstage_load(st, basis_b, W_b, F, K, in);
-    xtile_load_framemajor(nxt, Xb, F, T, in, jc, q);
     const int pb = (it - t_begin) & 1;
     const double *tcur = ts[pb];
     const c128 *wcur = ws[pb];
@@ -405,7 +414,6 @@ __global__ __launch_bounds__(256) void k_activation_fast(const c128 *__restrict_
     }
     tstage_store(st, ts[pb ^ 1], ws[pb ^ 1]);
     __syncthreads();
-    cur = nxt;
   }
 #pragma unroll
   for (int n = 0; n < N; ++n)

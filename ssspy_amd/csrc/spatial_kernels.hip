@@ -152,9 +152,12 @@ __global__ __launch_bounds__(256) void k_cross_cov(const c128 *__restrict__ A,
 
 // ---------------------------------------------------------------------------------------- IP1
 // One lane per (mixture, bin): N sequential projections, each an N x N complex solve.
+// When C (static covariance) and qbuf are given, also writes the output power of the updated
+// rows, qbuf[bin][n] = Re(w_n C w_n^H), which the power normalisation needs.
 template <int N>
 __global__ __launch_bounds__(64) void k_ip1(c128 *W, const c128 *__restrict__ U, long long nbins,
-                                            int floor_kind, double eps, int *info) {
+                                            int floor_kind, double eps, int *info,
+                                            const c128 *__restrict__ C, double *qbuf) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nbins) return;
   Mat<N> Wm;
@@ -179,6 +182,37 @@ __global__ __launch_bounds__(64) void k_ip1(c128 *W, const c128 *__restrict__ U,
   }
   store_mat<N>(Wm, W + idx * (N * N));
   if (!ok && info) atomicAdd(info, 1);
+  if (C && qbuf) {
+    Mat<N> Cm;
+    load_mat<N>(Cm, C + idx * (N * N));
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      // y_n = sum_m W[n][m] x_m  =>  E|y_n|^2 = conj(v)^H C conj(v) with v = row n of W
+      c128 v[N];
+#pragma unroll
+      for (int m = 0; m < N; ++m) v[m] = cconj(Wm.a[n][m]);
+      qbuf[idx * N + n] = quad_form<N>(v, Cm);
+    }
+  }
+}
+
+// qbuf[bin][n] = Re(w_n C w_n^H) for the current W (stand-alone power statistic)
+template <int N>
+__global__ __launch_bounds__(64) void k_row_power(const c128 *__restrict__ W,
+                                                  const c128 *__restrict__ C, double *qbuf,
+                                                  long long nbins) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nbins) return;
+  Mat<N> Wm, Cm;
+  load_mat<N>(Wm, W + idx * (N * N));
+  load_mat<N>(Cm, C + idx * (N * N));
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    c128 v[N];
+#pragma unroll
+    for (int m = 0; m < N; ++m) v[m] = cconj(Wm.a[n][m]);
+    qbuf[idx * N + n] = quad_form<N>(v, Cm);
+  }
 }
 
 // -------------------------------------------------------------------------------- ISS1 transform
@@ -330,6 +364,24 @@ __global__ __launch_bounds__(256) void k_sum_logdet(const c128 *__restrict__ W, 
 
 using namespace ssspy;
 
+namespace ssspy {
+int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, int F, int N,
+                   int floor_kind, double floor_eps, int *info, hipStream_t st) {
+  const long long nbins = (long long)B * F;
+  dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
+  DISPATCH_N(N, hipLaunchKernelGGL((k_ip1<NN>), grid, block, 0, st, (c128 *)W, (const c128 *)U,
+                                   nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf));
+  return check_launch("k_ip1");
+}
+int row_power(const void *W, const void *C, double *qbuf, int B, int F, int N, hipStream_t st) {
+  const long long nbins = (long long)B * F;
+  dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
+  DISPATCH_N(N, hipLaunchKernelGGL((k_row_power<NN>), grid, block, 0, st, (const c128 *)W,
+                                   (const c128 *)C, qbuf, nbins));
+  return check_launch("k_row_power");
+}
+}  // namespace ssspy
+
 extern "C" {
 
 const char *ssspy_amd_version(void) { return "ssspy_amd 0.1.0 (gfx950)"; }
@@ -369,7 +421,8 @@ int ssspy_update_by_ip1(void *W, const void *U, int B, int F, int N, int floor_k
   const long long nbins = (long long)B * F;
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
   DISPATCH_N(N, hipLaunchKernelGGL((k_ip1<NN>), grid, block, 0, as_stream(stream), (c128 *)W,
-                                   (const c128 *)U, nbins, floor_kind, floor_eps, info));
+                                   (const c128 *)U, nbins, floor_kind, floor_eps, info,
+                                   (const c128 *)nullptr, (double *)nullptr));
   return check_launch("k_ip1");
 }
 
