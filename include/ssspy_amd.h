@@ -190,6 +190,45 @@ int ssspy_iva_weight(const double *r2, double *weight, double *variance, int B, 
 int ssspy_iva_loss_data(const double *r2, const double *variance, double *out, int B, int N, int F,
                         int T, int contrast, void *stream);
 
+/* ------------------------------------------------------------------ FastGaussMNMF (IP1) */
+
+/* steps of FastGaussMNMF.update_once, OR-ed into `steps` of ssspy_fastmnmf_update */
+enum {
+  SSSPY_MNMF_BASIS = 1,
+  SSSPY_MNMF_ACTIVATION = 2,
+  SSSPY_MNMF_DIAGONALIZER = 4,
+  SSSPY_MNMF_SPATIAL = 8,
+  SSSPY_MNMF_NORMALIZE = 16,
+  SSSPY_MNMF_ALL = 31,
+};
+
+size_t ssspy_fastmnmf_workspace_bytes(int B, int N, int M, int F, int T, int K);
+
+/* The selected steps of update_once(), in the reference's order: basis, activation,
+ * diagonaliser (IP1), spatial, power normalisation.
+ * X (B,M,F,T), Q (B,F,M,M), D (B,F,N,M), basis (B,N,F,K), activation (B,N,K,T),
+ * C (B,F,M,M) static covariance of X (needed by the normalisation step only).
+ * replaces: ssspy/bss/mnmf.py:1278-1303 and :1305-1360, :1362-1417, :1449-1514, :1635-1675,
+ * :632-678. */
+int ssspy_fastmnmf_update(const void *X, const void *C, void *Q, double *D, double *basis,
+                          double *activation, int B, int N, int M, int F, int T, int K, int steps,
+                          int floor_kind, double floor_eps, void *workspace, size_t workspace_bytes,
+                          int *info, void *stream);
+
+/* out[b] = sum_i mean_j sum_m ( |q x|^2 / R~ + log R~ ) (zeroed by the call); caller adds
+ * -2 sum logdet Q.   replaces: ssspy/bss/mnmf.py:1240-1258. */
+int ssspy_fastmnmf_loss_data(const void *X, const void *Q, const double *D, const double *basis,
+                             const double *activation, double *out, int B, int N, int M, int F,
+                             int T, int K, void *stream);
+
+/* Multichannel Wiener filter output Y (B,N,F,T) for reference channel `reference_id`:
+ * per (bin, frame) an M x M Hermitian eigen-decomposition (Jacobi) with floored eigenvalues.
+ * replaces: ssspy/bss/mnmf.py:1174-1217 (separate) incl. to_psd (special/psd.py:11-71). */
+int ssspy_fastmnmf_separate(const void *X, const void *Q, const double *D, const double *basis,
+                            const double *activation, void *Y, int B, int N, int M, int F, int T,
+                            int K, int reference_id, int floor_kind, double floor_eps,
+                            void *workspace, size_t workspace_bytes, int *info, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

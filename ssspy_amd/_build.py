@@ -27,6 +27,7 @@ CXXFLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-munsafe-fp
 
 ILRMA_N = list(range(2, 9))
 ILRMA_FAST_N = [2, 3, 4]
+MNMF_N = [2, 3, 4]
 
 
 def _hipcc():
@@ -43,8 +44,9 @@ def _units():
         ("ilrma_api.hip", "ilrma_api.o", []),
         ("iva_kernels.hip", "iva_kernels.o", []),
     ]
-    if os.path.exists(os.path.join(CSRC, "mnmf_kernels.hip")):
-        units.append(("mnmf_kernels.hip", "mnmf_kernels.o", []))
+    units.append(("mnmf_api.hip", "mnmf_api.o", []))
+    for n in MNMF_N:
+        units.append(("mnmf_kernels.hip", "mnmf_kernels_n{}.o".format(n), ["-DSSSPY_N={}".format(n)]))
     for n in ILRMA_N:
         units.append(("ilrma_kernels.hip", "ilrma_kernels_n{}.o".format(n), ["-DSSSPY_N={}".format(n)]))
     for n in ILRMA_FAST_N:

@@ -235,3 +235,48 @@ def iva_loss_data(r2, variance, n_bins, contrast, out=None):
         "iva_loss_data",
     )
     return out
+
+
+# ----------------------------------------------------------------------------- FastMNMF
+def fastmnmf_workspace(B, N, M, F, T, K, dev):
+    nbytes = int(_L().ssspy_fastmnmf_workspace_bytes(B, N, M, F, T, K))
+    return dv.empty(((nbytes + 7) // 8,), dv.f64, dev), nbytes
+
+
+def fastmnmf_update(X, C, Q, D, basis, activation, steps, flooring, ws, ws_bytes, info):
+    B, M, F, T = X.shape
+    N, K = basis.shape[1], basis.shape[-1]
+    _lib.check(
+        _L().ssspy_fastmnmf_update(ptr(X), ptr(C), ptr(Q), ptr(D), ptr(basis), ptr(activation), B,
+                                   N, M, F, T, K, steps, flooring[0], flooring[1], ptr(ws),
+                                   ws_bytes, ptr(info), _st()),
+        "fastmnmf_update",
+    )
+
+
+def fastmnmf_loss_data(X, Q, D, basis, activation, out=None):
+    B, M, F, T = X.shape
+    N, K = basis.shape[1], basis.shape[-1]
+    if out is None:
+        out = dv.empty((B,), dv.f64, X.device)
+    _lib.check(
+        _L().ssspy_fastmnmf_loss_data(ptr(X), ptr(Q), ptr(D), ptr(basis), ptr(activation), ptr(out),
+                                      B, N, M, F, T, K, _st()),
+        "fastmnmf_loss_data",
+    )
+    return out
+
+
+def fastmnmf_separate(X, Q, D, basis, activation, reference_id, flooring, ws, ws_bytes, info,
+                      out=None):
+    B, M, F, T = X.shape
+    N, K = basis.shape[1], basis.shape[-1]
+    if out is None:
+        out = dv.empty((B, N, F, T), dv.c128, X.device)
+    _lib.check(
+        _L().ssspy_fastmnmf_separate(ptr(X), ptr(Q), ptr(D), ptr(basis), ptr(activation), ptr(out),
+                                     B, N, M, F, T, K, reference_id, flooring[0], flooring[1],
+                                     ptr(ws), ws_bytes, ptr(info), _st()),
+        "fastmnmf_separate",
+    )
+    return out

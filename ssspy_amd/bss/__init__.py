@@ -1,4 +1,4 @@
-from . import base, ilrma, iva
+from . import base, ilrma, iva, mnmf
 from .base import IterativeMethodBase
 
-__all__ = ["IterativeMethodBase", "base", "ilrma", "iva"]
+__all__ = ["IterativeMethodBase", "base", "ilrma", "iva", "mnmf"]

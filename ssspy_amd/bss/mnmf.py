@@ -1,0 +1,308 @@
+"""Fast multichannel NMF (FastGaussMNMF) on MI355X.
+
+Drop-in separator for the reference's ``ssspy.bss.mnmf.FastGaussMNMF``
+(ssspy/bss/mnmf.py:1076-1675 on top of FastMNMFBase :417-678 and MNMFBase :21-297): jointly
+diagonalisable full-rank spatial model with per-bin diagonaliser ``Q`` (n_bins, n_channels,
+n_channels), diagonal spatial ``D`` (n_bins, n_sources, n_channels), NMF ``basis`` /
+``activation``; ``update_once`` = basis, activation, diagonaliser (IP1), spatial, power
+normalisation; output by the multichannel Wiener filter.  ``diagonalizer_algorithm="IP2"``,
+``partitioning`` and the full-rank ``GaussMNMF`` are not built yet (NotImplementedError).
+
+``instant_covariance`` (the (n_bins, n_frames, M, M) PSD-projected outer products the reference
+materialises at reset, mnmf.py:167-188) is never read by FastGaussMNMF's updates and is not
+computed here.
+"""
+
+import functools
+from typing import Callable, Iterable, List, Optional, Tuple, Union
+
+import numpy as np
+
+from .. import _device as dv
+from .. import _lib, _ops
+from ..special.flooring import identity, max_flooring
+from ..utils.flooring import choose_flooring_fn, device_flooring
+from ..utils.select_pair import sequential_pair_selector
+from ._device_state import DeviceStateMixin, Synced
+from .base import IterativeMethodBase
+
+__all__ = ["FastGaussMNMF"]
+
+diagonalizer_algorithms = ["IP", "IP1", "IP2"]
+EPS = 1e-10
+
+
+class MNMFBase(DeviceStateMixin, IterativeMethodBase):
+    """ref: ssspy/bss/mnmf.py:21-297."""
+
+    output = Synced(dv.c128)
+    basis = Synced(dv.f64)
+    activation = Synced(dv.f64)
+
+    def __init__(
+        self,
+        n_basis: int,
+        n_sources: Optional[int] = None,
+        partitioning: bool = False,
+        flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = functools.partial(
+            max_flooring, eps=EPS
+        ),
+        callbacks=None,
+        normalization: bool = True,
+        record_loss: bool = True,
+        reference_id: int = 0,
+        rng: Optional[np.random.Generator] = None,
+    ) -> None:
+        super().__init__(callbacks=callbacks, record_loss=record_loss)
+        self.n_basis = n_basis
+        self.n_sources = n_sources
+        self.partitioning = partitioning
+        self.flooring_fn = identity if flooring_fn is None else flooring_fn
+        self.normalization = normalization
+        self.input = None
+        self.reference_id = reference_id
+        self.rng = np.random.default_rng() if rng is None else rng
+
+    def __call__(
+        self, input: np.ndarray, n_iter: int = 100, initial_call: bool = True, **kwargs
+    ) -> np.ndarray:
+        """Separate a frequency-domain multichannel mixture (ref: ssspy/bss/mnmf.py:90-118)."""
+        self._bind_input(input)
+        self._reset(**kwargs)
+        IterativeMethodBase.__call__(self, n_iter=n_iter, initial_call=initial_call)
+        self._separate_dev()
+        return self.output
+
+    def _init_nmf(self, flooring_fn="self", rng=None) -> None:
+        """ref: ssspy/bss/mnmf.py:190-259 (no partitioning)."""
+        flooring_fn = choose_flooring_fn(flooring_fn, method=self)
+        if rng is None:
+            rng = np.random.default_rng()
+        N, F, T, K = self.n_sources, self.n_bins, self.n_frames, self.n_basis
+        if self.partitioning:
+            raise NotImplementedError("partitioning=True is not built for the device path yet.")
+        if not self._state_has("basis"):
+            self.basis = flooring_fn(rng.random(self._lead() + (N, F, K)))
+        else:
+            self.basis = np.array(self.basis, dtype=np.float64, copy=True)
+        if not self._state_has("activation"):
+            self.activation = flooring_fn(rng.random(self._lead() + (N, K, T)))
+        else:
+            self.activation = np.array(self.activation, dtype=np.float64, copy=True)
+
+    def reconstruct_nmf(self, basis, activation, latent=None) -> np.ndarray:
+        """Lambda = T V (ref: ssspy/bss/mnmf.py:264-297); host-side convenience."""
+        if latent is not None:
+            raise NotImplementedError("partitioning (latent) is not built for the device path yet.")
+        return basis @ activation
+
+
+class FastMNMFBase(MNMFBase):
+    """ref: ssspy/bss/mnmf.py:417-678."""
+
+    diagonalizer = Synced(dv.c128)
+    spatial = Synced(dv.f64)
+
+    def _reset(self, flooring_fn="self", **kwargs) -> None:
+        """ref: ssspy/bss/mnmf.py:499-540."""
+        assert self.input is not None, "Specify data!"
+        flooring_fn = choose_flooring_fn(flooring_fn, method=self)
+        for key, value in kwargs.items():
+            setattr(self, key, value)
+        B, M, F, T = self._X.shape
+        N = M if self.n_sources is None else self.n_sources
+        self.n_sources, self.n_channels = N, M
+        self.n_bins, self.n_frames = F, T
+        self._floor = device_flooring(flooring_fn)
+        self._init_nmf(flooring_fn=flooring_fn, rng=self.rng)
+        self._init_diagonalizer(rng=self.rng)
+        self._init_spatial(flooring_fn=flooring_fn, rng=self.rng)
+        self._ws, self._ws_bytes = _ops.fastmnmf_workspace(B, N, M, F, T, self.n_basis,
+                                                           self._X.device)
+        self._separate_dev()
+
+    def _init_diagonalizer(self, rng=None) -> None:
+        """ref: ssspy/bss/mnmf.py:542-564."""
+        M, F = self.n_channels, self.n_bins
+        if not self._state_has("diagonalizer"):
+            self.diagonalizer = np.tile(np.eye(M, dtype=np.complex128), self._lead() + (F, 1, 1))
+        else:
+            self.diagonalizer = np.array(self.diagonalizer, dtype=np.complex128, copy=True)
+
+    def _init_spatial(self, flooring_fn="self", rng=None) -> None:
+        """ref: ssspy/bss/mnmf.py:566-600."""
+        flooring_fn = choose_flooring_fn(flooring_fn, method=self)
+        if rng is None:
+            rng = np.random.default_rng()
+        N, M, F = self.n_sources, self.n_channels, self.n_bins
+        if not self._state_has("spatial"):
+            self.spatial = flooring_fn(rng.random(self._lead() + (F, N, M)))
+        else:
+            # private device copy (the reference keeps the caller's array; it is never mutated here)
+            self.spatial = np.array(self.spatial, dtype=np.float64, copy=True)
+
+    def _resolve_floor(self, flooring_fn):
+        if type(flooring_fn) is str and flooring_fn == "self":
+            return self._floor
+        return device_flooring(choose_flooring_fn(flooring_fn, method=self))
+
+    def _update(self, steps, flooring_fn="self") -> None:
+        need_c = bool(steps & _lib.MNMF_NORMALIZE)
+        _ops.fastmnmf_update(
+            self._X, self._C() if need_c else None, self._state_dev("diagonalizer"),
+            self._state_dev("spatial"), self._state_dev("basis"), self._state_dev("activation"),
+            steps, self._resolve_floor(flooring_fn), self._ws, self._ws_bytes, self._info_tensor(),
+        )
+        for name in ("diagonalizer", "spatial", "basis", "activation"):
+            self._state_touch(name)
+
+    def normalize(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/mnmf.py:602-630."""
+        normalization = self.normalization
+        assert normalization, "Set normalization."
+        if type(normalization) is bool:
+            normalization = "power"
+        if normalization == "power":
+            self.normalize_by_power(flooring_fn=flooring_fn)
+        else:
+            raise NotImplementedError("Normalization {} is not implemented.".format(normalization))
+
+    def normalize_by_power(self, flooring_fn="self") -> None:
+        """psi_m from mean |q_m^H x|^2; Q rows / psi, D / psi^2 (ref: ssspy/bss/mnmf.py:632-678)."""
+        self._update(_lib.MNMF_NORMALIZE, flooring_fn)
+
+
+class FastGaussMNMF(FastMNMFBase):
+    """FastMNMF on a Gaussian distribution (ref: ssspy/bss/mnmf.py:1076-1675)."""
+
+    def __init__(
+        self,
+        n_basis: int,
+        n_sources: Optional[int] = None,
+        diagonalizer_algorithm: str = "IP",
+        partitioning: bool = False,
+        flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = functools.partial(
+            max_flooring, eps=EPS
+        ),
+        pair_selector: Optional[Callable[[int], Iterable[Tuple[int, int]]]] = None,
+        callbacks: Optional[Union[Callable, List[Callable]]] = None,
+        normalization: bool = True,
+        record_loss: bool = True,
+        reference_id: int = 0,
+        rng: Optional[np.random.Generator] = None,
+    ) -> None:
+        super().__init__(
+            n_basis,
+            n_sources=n_sources,
+            partitioning=partitioning,
+            flooring_fn=flooring_fn,
+            callbacks=callbacks,
+            normalization=normalization,
+            record_loss=record_loss,
+            reference_id=reference_id,
+            rng=rng,
+        )
+        assert diagonalizer_algorithm in diagonalizer_algorithms, "Not support {}.".format(
+            diagonalizer_algorithm
+        )
+        assert not partitioning, "partitioning function is not supported."
+        if diagonalizer_algorithm == "IP2":
+            raise NotImplementedError(
+                "diagonalizer_algorithm='IP2' is not built for the device path yet."
+            )
+        self.diagonalizer_algorithm = diagonalizer_algorithm
+        if pair_selector is None:
+            if diagonalizer_algorithm == "IP2":
+                self.pair_selector = sequential_pair_selector
+        else:
+            self.pair_selector = pair_selector
+        device_flooring(self.flooring_fn)
+
+    def __repr__(self) -> str:
+        s = "FastGaussMNMF(n_basis={}".format(self.n_basis)
+        if self.n_sources is not None:
+            s += ", n_sources={}".format(self.n_sources)
+        if hasattr(self, "n_channels"):
+            s += ", n_channels={}".format(self.n_channels)
+        s += ", diagonalizer_algorithm={}, partitioning={}, record_loss={}, reference_id={})".format(
+            self.diagonalizer_algorithm, self.partitioning, self.record_loss, self.reference_id
+        )
+        return s
+
+    def _separate_dev(self) -> None:
+        Y = _ops.fastmnmf_separate(
+            self._X, self._state_dev("diagonalizer"), self._state_dev("spatial"),
+            self._state_dev("basis"), self._state_dev("activation"), self.reference_id,
+            self._floor, self._ws, self._ws_bytes, self._info_tensor(),
+        )
+        self._state_set_dev("output", Y)
+
+    def separate(self, input: np.ndarray) -> np.ndarray:
+        """Multichannel Wiener filter with the current parameters (ref: mnmf.py:1174-1217)."""
+        batched = input.ndim == 4
+        X = dv.to_device(input if batched else input[None], dtype=np.complex128)
+        Y = _ops.fastmnmf_separate(
+            X, self._state_dev("diagonalizer"), self._state_dev("spatial"),
+            self._state_dev("basis"), self._state_dev("activation"), self.reference_id,
+            self._floor, self._ws, self._ws_bytes, self._info_tensor(),
+        )
+        self._check_device_errors()
+        out = dv.to_host(Y)
+        return out if batched else out[0]
+
+    def compute_loss(self) -> float:
+        """ref: ssspy/bss/mnmf.py:1219-1261."""
+        Q = self._state_dev("diagonalizer")
+        data = _ops.fastmnmf_loss_data(self._X, Q, self._state_dev("spatial"),
+                                       self._state_dev("basis"), self._state_dev("activation"))
+        logdet = _ops.sum_logdet(Q)
+        self._check_device_errors()
+        values = dv.to_host(data) - 2.0 * dv.to_host(logdet)
+        return values.copy() if self._batched else values[0].item()
+
+    def compute_logdet(self, diagonalizer: np.ndarray) -> np.ndarray:
+        """log|det Q_i| per bin (ref: ssspy/bss/mnmf.py:1263-1276); host-side convenience."""
+        return np.linalg.slogdet(diagonalizer)[1]
+
+    def update_once(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/mnmf.py:1278-1303; one C-ABI call for the whole iteration."""
+        cls = type(self)
+        stock = all(
+            getattr(cls, name) is getattr(FastGaussMNMF, name)
+            for name in ("update_basis", "update_activation", "update_diagonalizer",
+                         "update_spatial", "normalize", "normalize_by_power")
+        )
+        if stock and (not self.normalization or type(self.normalization) is bool
+                      or self.normalization == "power"):
+            steps = _lib.MNMF_ALL if self.normalization else _lib.MNMF_ALL & ~_lib.MNMF_NORMALIZE
+            self._update(steps, flooring_fn)
+            return
+        self.update_basis(flooring_fn=flooring_fn)
+        self.update_activation(flooring_fn=flooring_fn)
+        self.update_diagonalizer(flooring_fn=flooring_fn)
+        self.update_spatial()
+        if self.normalization:
+            self.normalize(flooring_fn=flooring_fn)
+
+    def update_basis(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/mnmf.py:1305-1360."""
+        self._update(_lib.MNMF_BASIS, flooring_fn)
+
+    def update_activation(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/mnmf.py:1362-1417."""
+        self._update(_lib.MNMF_ACTIVATION, flooring_fn)
+
+    def update_diagonalizer(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/mnmf.py:1419-1447."""
+        if self.diagonalizer_algorithm in ["IP", "IP1"]:
+            self.update_diagonalizer_ip1(flooring_fn=flooring_fn)
+        else:
+            raise NotImplementedError("Not support {}.".format(self.diagonalizer_algorithm))
+
+    def update_diagonalizer_ip1(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/mnmf.py:1449-1514."""
+        self._update(_lib.MNMF_DIAGONALIZER, flooring_fn)
+
+    def update_spatial(self) -> None:
+        """ref: ssspy/bss/mnmf.py:1635-1675."""
+        self._update(_lib.MNMF_SPATIAL, "self")

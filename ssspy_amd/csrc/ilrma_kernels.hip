@@ -21,6 +21,7 @@
 // This file is compiled once per N (-DSSSPY_N=<n>) to keep build time parallel.
 #include "common.hpp"
 #include "cov_core.hpp"
+#include "nmf_tile.hpp"
 
 #ifndef SSSPY_N
 #error "compile with -DSSSPY_N=<n_sources>"
@@ -43,46 +44,6 @@ struct IlrmaDims {
   int B, F, T, K;
   double p;  // domain
 };
-
-// frame permutation inside a bin-major tile: D row rho = q + 4r  <->  frame j0 + 4q + r
-__device__ __forceinline__ int tile_pi(int rho) { return 4 * (rho & 3) + (rho >> 2); }
-
-// ---------------------------------------------------------------- bin-major GEMM1: R^T tile
-// returns R[bin i0+c, frame j0+4q+r] in register r of lane (c, q).
-// tb[ks]: B operand, basis[n, bin(c), 4ks+q] (0 when 4ks+q >= K), hoisted by the caller when
-// KSMALL; otherwise loaded here.
-template <bool KSMALL>
-__device__ __forceinline__ double4_t nmf_rt_tile(const double *__restrict__ Vn,  // V[b,n] (K,T)
-                                                 const double *__restrict__ Tn_bin,  // T[b,n,bin,:]
-                                                 const double (&tb)[4], int K, int T, int j0,
-                                                 int c, int q) {
-  double4_t R = {0.0, 0.0, 0.0, 0.0};
-  const int jf = j0 + tile_pi(c);
-  const bool fvalid = jf < T;
-  const int jc = fvalid ? jf : T - 1;
-  if (KSMALL) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks * 4 < K) {
-        const int kk = ks * 4 + q;
-        double a = Vn[(long long)(kk < K ? kk : K - 1) * T + jc];
-        a = (kk < K && fvalid) ? a : 0.0;
-        R = mfma_f64(a, tb[ks], R);
-      }
-    }
-  } else {
-    for (int k0 = 0; k0 < K; k0 += 4) {
-      const int kk = k0 + q;
-      const int kc = kk < K ? kk : K - 1;
-      double a = Vn[(long long)kc * T + jc];
-      a = (kk < K && fvalid) ? a : 0.0;
-      double t = Tn_bin[kc];
-      t = kk < K ? t : 0.0;
-      R = mfma_f64(a, t, R);
-    }
-  }
-  return R;
-}
 
 // a = P / R^((p+2)/p), b = 1/R
 __device__ __forceinline__ void mm_weights(double P, double R, double p, bool valid, double &a,

@@ -1,0 +1,212 @@
+// C-ABI entry points of the FastGaussMNMF path (kernels: mnmf_kernels.hip, one unit per N).
+#include "common.hpp"
+
+namespace ssspy {
+
+#define DECL_N(n)                                                                                \
+  int mnmf_basis_n##n(const void *, const void *, const double *, const double *, double *,     \
+                      const double *, int, int, int, int, int, int, double, hipStream_t);       \
+  int mnmf_activation_n##n(const void *, const void *, const double *, const double *,          \
+                           const double *, double *, int, int, int, int, int, int, hipStream_t); \
+  int mnmf_wcov_n##n(const void *, const double *, const double *, const double *, void *, int, \
+                     int, int, int, int, hipStream_t);                                          \
+  int mnmf_spatial_n##n(const void *, const void *, double *, const double *, const double *,   \
+                        int, int, int, int, int, hipStream_t);                                  \
+  int mnmf_loss_n##n(const void *, const void *, const double *, const double *, const double *, \
+                     double *, int, int, int, int, int, hipStream_t);                           \
+  int mnmf_norm_scale_n##n(void *, double *, const double *, int, int, int, int, double,        \
+                           hipStream_t);                                                        \
+  int mnmf_separate_n##n(const void *, const void *, void *, const double *, const double *,    \
+                         const double *, void *, int, int, int, int, int, int, int, double,     \
+                         int *, hipStream_t);
+DECL_N(2) DECL_N(3) DECL_N(4)
+#undef DECL_N
+
+#define MNMF_DISPATCH(N_, fn, ...)                                                       \
+  switch (N_) {                                                                          \
+    case 2: return fn##_n2(__VA_ARGS__);                                                 \
+    case 3: return fn##_n3(__VA_ARGS__);                                                 \
+    case 4: return fn##_n4(__VA_ARGS__);                                                 \
+    default: return fail(SSSPY_ERR_UNSUPPORTED, "FastMNMF: n_sources must be in [2, 4]"); \
+  }
+
+int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, int F, int N,
+                   int floor_kind, double floor_eps, int *info, hipStream_t st);
+int row_power(const void *W, const void *C, double *qbuf, int B, int F, int N, hipStream_t st);
+
+static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static inline int mnmf_chunks(int B, int F, int T, int K) {
+  const long long blocks0 = (long long)B * ((T + 63) / 64) * ((K + 15) / 16);
+  const int ntiles = (F + 15) / 16;
+  long long want = (512 + blocks0 - 1) / blocks0;
+  if (want < 1) want = 1;
+  if (want > 16) want = 16;
+  if (want > ntiles) want = ntiles;
+  return (int)want;
+}
+
+struct MnmfWs {
+  size_t part, btmp, U, qbuf, qinv, total;
+};
+
+static inline MnmfWs mnmf_ws(int B, int N, int M, int F, int T, int K) {
+  MnmfWs w;
+  size_t off = 0;
+  w.part = off;
+  off += al((size_t)B * mnmf_chunks(B, F, T, K) * N * 2 * K * T * sizeof(double));
+  w.btmp = off;
+  off += K > 16 ? al((size_t)B * N * F * K * sizeof(double)) : 0;
+  w.U = off;
+  off += al((size_t)B * F * M * M * M * 2 * sizeof(double));
+  w.qbuf = off;
+  off += al((size_t)B * F * M * sizeof(double));
+  w.qinv = off;
+  off += al((size_t)B * F * M * M * 2 * sizeof(double));
+  w.total = off;
+  return w;
+}
+
+// V <- floor(V * sqrt(sum_chunks num / sum_chunks den))
+__global__ __launch_bounds__(256) void k_mnmf_activation_finalize(double *act,
+                                                                  const double *__restrict__ part,
+                                                                  int N, int K, int T, int nchunks,
+                                                                  int floor_kind, double eps) {
+  const int b = blockIdx.z, n = blockIdx.y;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)K * T) return;
+  double sn = 0.0, sd = 0.0;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const long long base = ((((long long)b * nchunks + ch) * N + n) * 2) * K * T;
+    sn += part[base + e];
+    sd += part[base + (long long)K * T + e];
+  }
+  double *dst = act + ((long long)b * N + n) * K * T + e;
+  *dst = apply_floor((*dst) * sqrt(sn / sd), floor_kind, eps);
+}
+
+static int step_basis(const void *X, const void *Q, const double *D, double *basis,
+                      const double *act, int B, int N, int M, int F, int T, int K, int fk,
+                      double eps, char *ws, const MnmfWs &w, hipStream_t st) {
+  double *out = K > 16 ? (double *)(ws + w.btmp) : basis;
+  auto run = [&]() -> int {
+    MNMF_DISPATCH(N, mnmf_basis, X, Q, D, basis, out, act, B, M, F, T, K, fk, eps, st);
+  };
+  int rc = run();
+  if (rc) return rc;
+  if (out != basis) {
+    hipError_t e = hipMemcpyAsync(basis, out, (size_t)B * N * F * K * sizeof(double),
+                                  hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+  }
+  return SSSPY_OK;
+}
+
+static int step_activation(const void *X, const void *Q, const double *D, const double *basis,
+                           double *act, int B, int N, int M, int F, int T, int K, int fk,
+                           double eps, char *ws, const MnmfWs &w, hipStream_t st) {
+  const int chunks = mnmf_chunks(B, F, T, K);
+  double *part = (double *)(ws + w.part);
+  auto run = [&]() -> int {
+    MNMF_DISPATCH(N, mnmf_activation, X, Q, D, basis, act, part, chunks, B, M, F, T, K, st);
+  };
+  int rc = run();
+  if (rc) return rc;
+  dim3 g2((unsigned)(((long long)K * T + 255) / 256), N, B);
+  hipLaunchKernelGGL(k_mnmf_activation_finalize, g2, dim3(256), 0, st, act, part, N, K, T, chunks,
+                     fk, eps);
+  return check_launch("k_mnmf_activation_finalize");
+}
+
+}  // namespace ssspy
+
+using namespace ssspy;
+
+extern "C" {
+
+size_t ssspy_fastmnmf_workspace_bytes(int B, int N, int M, int F, int T, int K) {
+  if (B <= 0 || N <= 0 || M <= 0 || F <= 0 || T <= 0 || K <= 0) return 0;
+  return mnmf_ws(B, N, M, F, T, K).total;
+}
+
+int ssspy_fastmnmf_update(const void *X, const void *C, void *Q, double *D, double *basis,
+                          double *activation, int B, int N, int M, int F, int T, int K, int steps,
+                          int floor_kind, double floor_eps, void *workspace, size_t workspace_bytes,
+                          int *info, void *stream) {
+  SSSPY_REQUIRE(X && Q && D && basis && activation && B > 0 && F > 0 && T > 0,
+                "fastmnmf_update: bad argument");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_update: n_basis must be in [1, 64]");
+  const MnmfWs w = mnmf_ws(B, N, M, F, T, K);
+  SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "fastmnmf_update: workspace too small");
+  SSSPY_REQUIRE(!(steps & SSSPY_MNMF_NORMALIZE) || C, "fastmnmf_update: normalisation needs C");
+  hipStream_t st = as_stream(stream);
+  char *ws = (char *)workspace;
+  int rc = SSSPY_OK;
+  if (steps & SSSPY_MNMF_BASIS) {
+    rc = step_basis(X, Q, D, basis, activation, B, N, M, F, T, K, floor_kind, floor_eps, ws, w, st);
+    if (rc) return rc;
+  }
+  if (steps & SSSPY_MNMF_ACTIVATION) {
+    rc = step_activation(X, Q, D, basis, activation, B, N, M, F, T, K, floor_kind, floor_eps, ws, w,
+                         st);
+    if (rc) return rc;
+  }
+  double *qbuf = (double *)(ws + w.qbuf);
+  bool have_q = false;
+  if (steps & SSSPY_MNMF_DIAGONALIZER) {
+    void *U = ws + w.U;
+    auto run = [&]() -> int {
+      MNMF_DISPATCH(N, mnmf_wcov, X, D, basis, activation, U, B, M, F, T, K, st);
+    };
+    rc = run();
+    if (rc) return rc;
+    // IP1 on the M x M diagonaliser with M weighted covariances per bin
+    rc = ip1_with_power(Q, U, C, C ? qbuf : nullptr, B, F, M, floor_kind, floor_eps, info, st);
+    if (rc) return rc;
+    have_q = C != nullptr;
+  }
+  if (steps & SSSPY_MNMF_SPATIAL) {
+    auto run = [&]() -> int {
+      MNMF_DISPATCH(N, mnmf_spatial, X, Q, D, basis, activation, B, M, F, T, K, st);
+    };
+    rc = run();
+    if (rc) return rc;
+  }
+  if (steps & SSSPY_MNMF_NORMALIZE) {
+    if (!have_q) {
+      rc = row_power(Q, C, qbuf, B, F, M, st);
+      if (rc) return rc;
+    }
+    auto run = [&]() -> int {
+      MNMF_DISPATCH(N, mnmf_norm_scale, Q, D, qbuf, B, M, F, floor_kind, floor_eps, st);
+    };
+    rc = run();
+  }
+  return rc;
+}
+
+int ssspy_fastmnmf_loss_data(const void *X, const void *Q, const double *D, const double *basis,
+                             const double *activation, double *out, int B, int N, int M, int F,
+                             int T, int K, void *stream) {
+  SSSPY_REQUIRE(X && Q && D && basis && activation && out && B > 0, "fastmnmf_loss_data: bad argument");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_loss_data: bad n_basis");
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)B * sizeof(double), st);
+  if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+  MNMF_DISPATCH(N, mnmf_loss, X, Q, D, basis, activation, out, B, M, F, T, K, st);
+}
+
+int ssspy_fastmnmf_separate(const void *X, const void *Q, const double *D, const double *basis,
+                            const double *activation, void *Y, int B, int N, int M, int F, int T,
+                            int K, int reference_id, int floor_kind, double floor_eps,
+                            void *workspace, size_t workspace_bytes, int *info, void *stream) {
+  SSSPY_REQUIRE(X && Q && D && basis && activation && Y && B > 0, "fastmnmf_separate: bad argument");
+  SSSPY_REQUIRE(reference_id >= 0 && reference_id < M, "fastmnmf_separate: bad reference_id");
+  const MnmfWs w = mnmf_ws(B, N, M, F, T, K);
+  SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "fastmnmf_separate: workspace too small");
+  void *Qinv = (char *)workspace + w.qinv;
+  MNMF_DISPATCH(N, mnmf_separate, X, Q, Qinv, D, basis, activation, Y, B, M, F, T, K, reference_id,
+                floor_kind, floor_eps, info, as_stream(stream));
+}
+
+}  // extern "C"

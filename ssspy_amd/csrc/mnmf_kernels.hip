@@ -1,0 +1,878 @@
+// FastGaussMNMF (jointly diagonalisable full-rank spatial model) kernels for gfx950.
+//
+// State (reference layout, leading batch axis B): X (B,M,F,T) c128, diagonaliser Q (B,F,M,M) c128,
+// diagonal spatial D (B,F,N,M) f64, basis T (B,N,F,K), activation V (B,N,K,T).
+// With lambda_nij = (T V)_nij, R~_ijm = sum_n lambda_nij d_inm and y~_imj = |(Q_i x_ij)_m| the
+// four multiplicative updates + the IP1 update of Q all reduce, per (bin, frame), to a handful of
+// fp64 operations on N + M numbers followed by a contraction over frames or over bins -- the same
+// shape as the ILRMA passes, so the same two MFMA tile orientations are used (ilrma_kernels.hip):
+//   bin-major tile   : basis update, diagonaliser covariance, spatial update, loss
+//   frame-major tile : activation update
+// Compiled once per N (-DSSSPY_N=2..4); M (channels) is a template parameter dispatched at launch.
+#include "common.hpp"
+#include "cov_core.hpp"
+#include "nmf_tile.hpp"
+#include "smallmat.hpp"
+
+#ifndef SSSPY_N
+#error "compile with -DSSSPY_N=<n_sources>"
+#endif
+
+#define SSSPY_CAT_(a, b) a##b
+#define SSSPY_CAT(a, b) SSSPY_CAT_(a, b)
+#define LAUNCHER(name) SSSPY_CAT(SSSPY_CAT(name, _n), SSSPY_N)
+
+namespace ssspy {
+namespace SSSPY_CAT(mnmf_n, SSSPY_N) {
+
+constexpr int N = SSSPY_N;
+
+struct Dims {
+  int B, F, T, K;
+};
+
+// per-(bin, frame) quantities: qx2[m] = |(Q x)_m|^2, g[m] = 1 / R~_m, R~_m = sum_n lam[n] D[n][m]
+template <int M>
+__device__ __forceinline__ void frame_terms(const c128 (&Q)[M][M], const double (&D)[N][M],
+                                            const c128 (&x)[M], const double (&lam)[N],
+                                            double (&qx2)[M], double (&rc)[M]) {
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    c128 y = cmake(0.0, 0.0);
+#pragma unroll
+    for (int a = 0; a < M; ++a) cfma(y, Q[m][a], x[a]);
+    qx2[m] = cabs2(y);
+    double r = 0.0;
+#pragma unroll
+    for (int n = 0; n < N; ++n) r = fma(lam[n], D[n][m], r);
+    rc[m] = r;
+  }
+}
+
+template <int M>
+__device__ __forceinline__ void load_bin(c128 (&Q)[M][M], double (&D)[N][M],
+                                         const c128 *__restrict__ Qp,
+                                         const double *__restrict__ Dp) {
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int a = 0; a < M; ++a) Q[m][a] = Qp[m * M + a];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int m = 0; m < M; ++m) D[n][m] = Dp[n * M + m];
+}
+
+// ================================================================================ basis update
+// t_nik <- floor(t_nik sqrt( sum_j v_nkj A_nij / sum_j v_nkj Bq_nij )),
+// A_nij = sum_m d_inm y~^2/R~^2, Bq_nij = sum_m d_inm / R~.   grid: (bin tiles, k tiles, B)
+template <int M, bool KSMALL>
+__global__ __launch_bounds__(256) void k_mnmf_basis(const c128 *__restrict__ X,
+                                                    const c128 *__restrict__ Q,
+                                                    const double *__restrict__ Dsp,
+                                                    const double *basis, double *basis_out,
+                                                    const double *__restrict__ act, Dims d,
+                                                    int floor_kind, double eps) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int F = d.F, T = d.T, K = d.K;
+  const int b = blockIdx.z, kt = blockIdx.y;
+  const int i0 = blockIdx.x * 16;
+  const int bin = min(i0 + c, F - 1);
+  c128 Qb[M][M];
+  double Db[N][M];
+  load_bin<M>(Qb, Db, Q + ((long long)b * F + bin) * (M * M), Dsp + ((long long)b * F + bin) * (N * M));
+  double tb[N][4];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kk = ks * 4 + q;
+      tb[n][ks] = (KSMALL && kk < K) ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
+    }
+  double4_t num[N], den[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    num[n] = double4_t{0.0, 0.0, 0.0, 0.0};
+    den[n] = double4_t{0.0, 0.0, 0.0, 0.0};
+  }
+  const int ntiles = (T + 15) >> 4;
+  const int k2 = kt * 16 + c;
+  const bool k2valid = k2 < K;
+  const int k2c = k2valid ? k2 : K - 1;
+  for (int jt = wave; jt < ntiles; jt += nw) {
+    const int j0 = jt * 16;
+    double4_t lamR[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+      lamR[n] = nmf_rt_tile<KSMALL>(act + ((long long)b * N + n) * K * T,
+                                    basis + (((long long)b * N + n) * F + bin) * K, tb[n], K, T, j0,
+                                    c, q);
+    double a[N][4], bq[N][4];
+    bool fval[4];
+    int jcl[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = j0 + 4 * q + r;
+      fval[r] = jj < T;
+      jcl[r] = fval[r] ? jj : T - 1;
+      c128 x[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = X[(((long long)b * M + m) * F + bin) * T + jcl[r]];
+      double lam[N], qx2[M], rc[M];
+#pragma unroll
+      for (int n = 0; n < N; ++n) lam[n] = lamR[n][r];
+      frame_terms<M>(Qb, Db, x, lam, qx2, rc);
+      double g[M], h[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        g[m] = 1.0 / rc[m];
+        h[m] = qx2[m] * g[m] * g[m];
+      }
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          sa = fma(Db[n][m], h[m], sa);
+          sb = fma(Db[n][m], g[m], sb);
+        }
+        a[n][r] = fval[r] ? sa : 0.0;
+        bq[n][r] = fval[r] ? sb : 0.0;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const double *Vn = act + ((long long)b * N + n) * K * T;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double vb = Vn[(long long)k2c * T + jcl[r]];
+        vb = (k2valid && fval[r]) ? vb : 0.0;
+        num[n] = mfma_f64(a[n][r], vb, num[n]);
+        den[n] = mfma_f64(bq[n][r], vb, den[n]);
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      lds[((wave * N + n) * 2 + 0) * 256 + r * 64 + lane] = num[n][r];
+      lds[((wave * N + n) * 2 + 1) * 256 + r * 64 + lane] = den[n][r];
+    }
+  __syncthreads();
+  for (int e = threadIdx.x; e < N * 256; e += blockDim.x) {
+    const int n = e >> 8, r = (e >> 6) & 3, ln = e & 63;
+    double sn = 0.0, sd = 0.0;
+    for (int wv = 0; wv < nw; ++wv) {
+      sn += lds[((wv * N + n) * 2 + 0) * 256 + r * 64 + ln];
+      sd += lds[((wv * N + n) * 2 + 1) * 256 + r * 64 + ln];
+    }
+    const int ob = i0 + (ln >> 4) + 4 * r, ok = kt * 16 + (ln & 15);
+    if (ob < F && ok < K) {
+      const long long o = (((long long)b * N + n) * F + ob) * K + ok;
+      basis_out[o] = apply_floor(basis[o] * sqrt(sn / sd), floor_kind, eps);
+    }
+  }
+}
+
+// =========================================================================== activation update
+// grid: (frame groups, bin chunks, B * ktiles); partials part[b][chunk][n][nd][K][T]
+template <int M, bool KSMALL>
+__global__ __launch_bounds__(256) void k_mnmf_activation(const c128 *__restrict__ X,
+                                                         const c128 *__restrict__ Q,
+                                                         const double *__restrict__ Dsp,
+                                                         const double *__restrict__ basis,
+                                                         const double *__restrict__ act,
+                                                         double *__restrict__ part, Dims d,
+                                                         int ktiles, int tiles_per_chunk,
+                                                         int nchunks) {
+  __shared__ c128 ql[16 * M * M];
+  __shared__ double dl[16 * N * M];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int F = d.F, T = d.T, K = d.K;
+  const int kt = blockIdx.z % ktiles, b = blockIdx.z / ktiles;
+  const int chunk = blockIdx.y;
+  const int j0 = (blockIdx.x * nw + wave) * 16;
+  const int jf = j0 + c;
+  const bool fvalid = jf < T;
+  const int jc = fvalid ? jf : T - 1;
+  double vb[N][4];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kk = ks * 4 + q;
+      vb[n][ks] = (KSMALL && kk < K && fvalid) ? act[(((long long)b * N + n) * K + kk) * T + jc] : 0.0;
+    }
+  double4_t numv[N], denv[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    numv[n] = double4_t{0.0, 0.0, 0.0, 0.0};
+    denv[n] = double4_t{0.0, 0.0, 0.0, 0.0};
+  }
+  const int ntiles = (F + 15) >> 4;
+  const int t_begin = chunk * tiles_per_chunk;
+  const int t_end = min(ntiles, t_begin + tiles_per_chunk);
+  const int k2 = kt * 16 + c;
+  const bool k2valid = k2 < K;
+  const int k2c = k2valid ? k2 : K - 1;
+  for (int it = t_begin; it < t_end; ++it) {
+    const int i0 = it * 16;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 16 * M * M; e += blockDim.x) {
+      const int bi = min(i0 + e / (M * M), F - 1);
+      ql[e] = Q[((long long)b * F + bi) * (M * M) + e % (M * M)];
+    }
+    for (int e = threadIdx.x; e < 16 * N * M; e += blockDim.x) {
+      const int bi = min(i0 + e / (N * M), F - 1);
+      dl[e] = Dsp[((long long)b * F + bi) * (N * M) + e % (N * M)];
+    }
+    __syncthreads();
+    double4_t lamR[N];
+    const int ab = min(i0 + c, F - 1);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const double *Tn = basis + ((long long)b * N + n) * F * K;
+      double4_t R = {0.0, 0.0, 0.0, 0.0};
+      if (KSMALL) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks * 4 < K) {
+            const int kk = ks * 4 + q;
+            double ta = Tn[(long long)ab * K + (kk < K ? kk : K - 1)];
+            ta = kk < K ? ta : 0.0;
+            R = mfma_f64(ta, vb[n][ks], R);
+          }
+        }
+      } else {
+        for (int k0 = 0; k0 < K; k0 += 4) {
+          const int kk = k0 + q, kc = kk < K ? kk : K - 1;
+          double ta = Tn[(long long)ab * K + kc];
+          ta = kk < K ? ta : 0.0;
+          double v = act[(((long long)b * N + n) * K + kc) * T + jc];
+          v = (kk < K && fvalid) ? v : 0.0;
+          R = mfma_f64(ta, v, R);
+        }
+      }
+      lamR[n] = R;
+    }
+    double a[N][4], bq[N][4];
+    bool bval[4];
+    int bcl[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int bl = q + 4 * r;
+      bval[r] = i0 + bl < F;
+      bcl[r] = bval[r] ? i0 + bl : F - 1;
+      c128 x[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = X[(((long long)b * M + m) * F + bcl[r]) * T + jc];
+      c128 Qb[M][M];
+      double Db[N][M];
+      load_bin<M>(Qb, Db, ql + bl * M * M, dl + bl * N * M);
+      double lam[N], qx2[M], rc[M];
+#pragma unroll
+      for (int n = 0; n < N; ++n) lam[n] = lamR[n][r];
+      frame_terms<M>(Qb, Db, x, lam, qx2, rc);
+      double g[M], h[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        g[m] = 1.0 / rc[m];
+        h[m] = qx2[m] * g[m] * g[m];
+      }
+      const bool valid = bval[r] && fvalid;
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          sa = fma(Db[n][m], h[m], sa);
+          sb = fma(Db[n][m], g[m], sb);
+        }
+        a[n][r] = valid ? sa : 0.0;
+        bq[n][r] = valid ? sb : 0.0;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const double *Tn = basis + ((long long)b * N + n) * F * K;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double ta = Tn[(long long)bcl[r] * K + k2c];
+        ta = (k2valid && bval[r]) ? ta : 0.0;
+        numv[n] = mfma_f64(ta, a[n][r], numv[n]);
+        denv[n] = mfma_f64(ta, bq[n][r], denv[n]);
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ok = kt * 16 + q + 4 * r;
+      if (ok < K && fvalid) {
+        const long long base = ((((long long)b * nchunks + chunk) * N + n) * 2) * K;
+        part[(base + ok) * T + jf] = numv[n][r];
+        part[(base + K + ok) * T + jf] = denv[n][r];
+      }
+    }
+}
+
+// ============================================================ diagonaliser covariance (for IP1)
+// U[b,i,m] = (1/T) sum_j x x^H / R~_ijm    -> (B,F,M,M,M).   grid: (bin tiles, 1, B)
+template <int M, bool KSMALL>
+__global__ __launch_bounds__(256) void k_mnmf_wcov(const c128 *__restrict__ X,
+                                                   const double *__restrict__ Dsp,
+                                                   const double *__restrict__ basis,
+                                                   const double *__restrict__ act,
+                                                   c128 *__restrict__ U, Dims d) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int F = d.F, T = d.T, K = d.K;
+  const int b = blockIdx.z;
+  const int i0 = blockIdx.x * 16;
+  const int bin = min(i0 + c, F - 1);
+  double Db[N][M];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int m = 0; m < M; ++m) Db[n][m] = Dsp[((long long)b * F + bin) * (N * M) + n * M + m];
+  double tb[N][4];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kk = ks * 4 + q;
+      tb[n][ks] = (KSMALL && kk < K) ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
+    }
+  CovAcc<M, M> acc;
+  acc.clear();
+  const int ntiles = (T + 15) >> 4;
+  for (int jt = wave; jt < ntiles; jt += nw) {
+    const int j0 = jt * 16;
+    double4_t lamR[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+      lamR[n] = nmf_rt_tile<KSMALL>(act + ((long long)b * N + n) * K * T,
+                                    basis + (((long long)b * N + n) * F + bin) * K, tb[n], K, T, j0,
+                                    c, q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = j0 + 4 * q + r;
+      const bool valid = jj < T;
+      const int jc = valid ? jj : T - 1;
+      c128 x[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = X[(((long long)b * M + m) * F + bin) * T + jc];
+      double phi[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        double rr = 0.0;
+#pragma unroll
+        for (int n = 0; n < N; ++n) rr = fma(lamR[n][r], Db[n][m], rr);
+        phi[m] = valid ? 1.0 / rr : 0.0;
+      }
+      acc.add(x, phi);
+    }
+  }
+  acc.fold_q();
+  cov_reduce_store<M, M>(acc, lds, U, (long long)b * F, i0, F, M, 0, M, 1.0 / (double)T);
+}
+
+// ================================================================================ spatial update
+// d_inm <- d_inm sqrt( sum_j lam y~^2 / R~^2  /  sum_j lam / R~ )  (no floor).  grid: (bin tiles,1,B)
+template <int M, bool KSMALL>
+__global__ __launch_bounds__(256) void k_mnmf_spatial(const c128 *__restrict__ X,
+                                                      const c128 *__restrict__ Q, double *Dsp,
+                                                      const double *__restrict__ basis,
+                                                      const double *__restrict__ act, Dims d) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int F = d.F, T = d.T, K = d.K;
+  const int b = blockIdx.z;
+  const int i0 = blockIdx.x * 16;
+  const int bin = min(i0 + c, F - 1);
+  c128 Qb[M][M];
+  double Db[N][M];
+  load_bin<M>(Qb, Db, Q + ((long long)b * F + bin) * (M * M), Dsp + ((long long)b * F + bin) * (N * M));
+  double tb[N][4];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kk = ks * 4 + q;
+      tb[n][ks] = (KSMALL && kk < K) ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
+    }
+  double sn[N][M], sd[N][M];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int m = 0; m < M; ++m) sn[n][m] = sd[n][m] = 0.0;
+  const int ntiles = (T + 15) >> 4;
+  for (int jt = wave; jt < ntiles; jt += nw) {
+    const int j0 = jt * 16;
+    double4_t lamR[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+      lamR[n] = nmf_rt_tile<KSMALL>(act + ((long long)b * N + n) * K * T,
+                                    basis + (((long long)b * N + n) * F + bin) * K, tb[n], K, T, j0,
+                                    c, q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = j0 + 4 * q + r;
+      const bool valid = jj < T;
+      const int jc = valid ? jj : T - 1;
+      c128 x[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = X[(((long long)b * M + m) * F + bin) * T + jc];
+      double lam[N], qx2[M], rc[M];
+#pragma unroll
+      for (int n = 0; n < N; ++n) lam[n] = lamR[n][r];
+      frame_terms<M>(Qb, Db, x, lam, qx2, rc);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const double g = 1.0 / rc[m];
+        const double h = qx2[m] * g * g;
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+          sn[n][m] += valid ? lam[n] * h : 0.0;
+          sd[n][m] += valid ? lam[n] * g : 0.0;
+        }
+      }
+    }
+  }
+  // fold q lanes, then waves (LDS: [wave][nd][n*M+m][16 bins])
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      double v = sn[n][m];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      double w = sd[n][m];
+      w += __shfl_xor(w, 16, 64);
+      w += __shfl_xor(w, 32, 64);
+      if (q == 0) {
+        lds[((wave * 2 + 0) * (N * M) + n * M + m) * 16 + c] = v;
+        lds[((wave * 2 + 1) * (N * M) + n * M + m) * 16 + c] = w;
+      }
+    }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 16 * N * M; e += blockDim.x) {
+    const int cb = e & 15, nm = e >> 4;
+    double a = 0.0, bb = 0.0;
+    for (int wv = 0; wv < nw; ++wv) {
+      a += lds[((wv * 2 + 0) * (N * M) + nm) * 16 + cb];
+      bb += lds[((wv * 2 + 1) * (N * M) + nm) * 16 + cb];
+    }
+    const int ob = i0 + cb;
+    if (ob < F) {
+      double *dst = Dsp + ((long long)b * F + ob) * (N * M) + nm;
+      *dst = sqrt(a / bb) * (*dst);
+    }
+  }
+}
+
+// ======================================================================================= loss
+// out[b] += sum_i (1/T) sum_j sum_m ( y~^2 / R~ + log R~ )
+template <int M, bool KSMALL>
+__global__ __launch_bounds__(256) void k_mnmf_loss(const c128 *__restrict__ X,
+                                                   const c128 *__restrict__ Q,
+                                                   const double *__restrict__ Dsp,
+                                                   const double *__restrict__ basis,
+                                                   const double *__restrict__ act, double *out,
+                                                   Dims d) {
+  __shared__ double scratch[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int F = d.F, T = d.T, K = d.K;
+  const int b = blockIdx.z;
+  const int i0 = blockIdx.x * 16;
+  const bool binvalid = i0 + c < F;
+  const int bin = min(i0 + c, F - 1);
+  c128 Qb[M][M];
+  double Db[N][M];
+  load_bin<M>(Qb, Db, Q + ((long long)b * F + bin) * (M * M), Dsp + ((long long)b * F + bin) * (N * M));
+  double tb[N][4];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kk = ks * 4 + q;
+      tb[n][ks] = (KSMALL && kk < K) ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
+    }
+  double local = 0.0;
+  const int ntiles = (T + 15) >> 4;
+  for (int jt = wave; jt < ntiles; jt += nw) {
+    const int j0 = jt * 16;
+    double4_t lamR[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+      lamR[n] = nmf_rt_tile<KSMALL>(act + ((long long)b * N + n) * K * T,
+                                    basis + (((long long)b * N + n) * F + bin) * K, tb[n], K, T, j0,
+                                    c, q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = j0 + 4 * q + r;
+      const bool valid = binvalid && jj < T;
+      const int jc = jj < T ? jj : T - 1;
+      c128 x[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = X[(((long long)b * M + m) * F + bin) * T + jc];
+      double lam[N], qx2[M], rc[M];
+#pragma unroll
+      for (int n = 0; n < N; ++n) lam[n] = lamR[n][r];
+      frame_terms<M>(Qb, Db, x, lam, qx2, rc);
+      double term = 0.0;
+#pragma unroll
+      for (int m = 0; m < M; ++m) term += qx2[m] / rc[m] + log(rc[m]);
+      local += valid ? term : 0.0;
+    }
+  }
+  const double total = block_sum(local, scratch);
+  if (threadIdx.x == 0) atomicAdd(out + b, total / (double)T);
+}
+
+// ================================================================ normalisation of Q rows and D
+// psi_m = floor(sqrt(mean_i q[i][m])); Q[:,m,:] /= psi_m; D[:,:,m] /= psi_m^2. grid (ceil(F/64), B)
+template <int M>
+__global__ __launch_bounds__(256) void k_mnmf_norm_scale(c128 *Q, double *Dsp,
+                                                         const double *__restrict__ qbuf, int F,
+                                                         int floor_kind, double eps) {
+  __shared__ double scratch[4];
+  __shared__ double psi[M];
+  const int b = blockIdx.y;
+  const double *qb = qbuf + (long long)b * F * M;
+  for (int m = 0; m < M; ++m) {
+    double local = 0.0;
+    for (int i = threadIdx.x; i < F; i += blockDim.x) local += qb[(long long)i * M + m];
+    const double total = block_sum(local, scratch);
+    if (threadIdx.x == 0) {
+      double v = total / (double)F;
+      v = v < 0.0 ? 0.0 : v;
+      psi[m] = apply_floor(sqrt(v), floor_kind, eps);
+    }
+  }
+  __syncthreads();
+  const int i0 = blockIdx.x * 64;
+  const int nb = min(64, F - i0);
+  c128 *Qb = Q + ((long long)b * F + i0) * M * M;
+  for (int e = threadIdx.x; e < nb * M * M; e += blockDim.x) {
+    const int m = (e / M) % M;
+    const c128 v = Qb[e];
+    Qb[e] = cmake(v.x / psi[m], v.y / psi[m]);
+  }
+  double *Db = Dsp + ((long long)b * F + i0) * N * M;
+  for (int e = threadIdx.x; e < nb * N * M; e += blockDim.x) {
+    const int m = e % M;
+    Db[e] = Db[e] / (psi[m] * psi[m]);
+  }
+}
+
+// ================================================================= multichannel Wiener filter
+// Hermitian eigen-decomposition by cyclic complex Jacobi rotations (fixed sweep count, no
+// branches): A = P diag(lam) P^H.  One lane owns one M x M matrix.
+template <int M>
+__device__ __forceinline__ void jacobi_eigh(c128 (&A)[M][M], c128 (&P)[M][M]) {
+#pragma unroll
+  for (int r = 0; r < M; ++r)
+#pragma unroll
+    for (int cc = 0; cc < M; ++cc) P[r][cc] = cmake(r == cc ? 1.0 : 0.0, 0.0);
+#pragma unroll 1
+  for (int sweep = 0; sweep < 10; ++sweep) {
+#pragma unroll
+    for (int p = 0; p < M - 1; ++p)
+#pragma unroll
+      for (int qq = p + 1; qq < M; ++qq) {
+        const c128 apq = A[p][qq];
+        const double mag2 = cabs2(apq);
+        const double mag = sqrt(mag2);
+        const bool tiny = mag2 < 1e-300;
+        const double inv = tiny ? 0.0 : 1.0 / mag;
+        const c128 u = tiny ? cmake(1.0, 0.0) : cmake(apq.x * inv, apq.y * inv);
+        const double app = A[p][p].x, aqq = A[qq][qq].x;
+        const double tau = tiny ? 0.0 : (aqq - app) * 0.5 * inv;
+        const double t = tiny ? 0.0 : ((tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau)));
+        const double cs = 1.0 / sqrt(1.0 + t * t);
+        const double sn = t * cs;
+        const c128 su = cmake(sn * u.x, sn * u.y);         // s u
+        const c128 sub = cmake(sn * u.x, -sn * u.y);       // s conj(u)
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+          if (k != p && k != qq) {
+            const c128 akp = A[k][p], akq = A[k][qq];
+            // A'_kp = c A_kp - s conj(u) A_kq ; A'_kq = s u A_kp + c A_kq
+            c128 nkp = cmake(cs * akp.x, cs * akp.y);
+            cfms(nkp, sub, akq);
+            c128 nkq = cmake(cs * akq.x, cs * akq.y);
+            cfma(nkq, su, akp);
+            A[k][p] = nkp;
+            A[p][k] = cconj(nkp);
+            A[k][qq] = nkq;
+            A[qq][k] = cconj(nkq);
+          }
+        }
+        A[p][p] = cmake(app - t * mag, 0.0);
+        A[qq][qq] = cmake(aqq + t * mag, 0.0);
+        A[p][qq] = cmake(0.0, 0.0);
+        A[qq][p] = cmake(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+          const c128 vkp = P[k][p], vkq = P[k][qq];
+          c128 nkp = cmake(cs * vkp.x, cs * vkp.y);
+          cfms(nkp, sub, vkq);
+          c128 nkq = cmake(cs * vkq.x, cs * vkq.y);
+          cfma(nkq, su, vkp);
+          P[k][p] = nkp;
+          P[k][qq] = nkq;
+        }
+      }
+  }
+}
+
+// Qinv[b,i] = Q[b,i]^-1
+template <int M>
+__global__ __launch_bounds__(64) void k_mnmf_qinv(const c128 *__restrict__ Q, c128 *Qinv,
+                                                  long long nbins, int *info) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nbins) return;
+  Mat<M> A, Inv;
+  load_mat<M>(A, Q + idx * (M * M));
+  const bool ok = invert<M>(A, Inv);
+  store_mat<M>(Inv, Qinv + idx * (M * M));
+  if (!ok && info) atomicAdd(info, 1);
+}
+
+// grid: (F, B); lanes along frames.  Y_n = sum_m lam_n d_nm q~[ref][m] s_m,
+// s = Q~^H R^-1 x, R = to_psd(sum_m R~_m q~_m q~_m^H) (eigenvalues floored).
+template <int M>
+__global__ __launch_bounds__(256) void k_mnmf_separate(const c128 *__restrict__ X,
+                                                       const c128 *__restrict__ Qinv,
+                                                       const double *__restrict__ Dsp,
+                                                       const double *__restrict__ basis,
+                                                       const double *__restrict__ act, c128 *Y,
+                                                       Dims d, int ref, int floor_kind,
+                                                       double eps) {
+  const int i = blockIdx.x, b = blockIdx.y;
+  const int F = d.F, T = d.T, K = d.K;
+  __shared__ c128 qt[M * M];
+  __shared__ double dd[N * M];
+  if (threadIdx.x < M * M) qt[threadIdx.x] = Qinv[((long long)b * F + i) * (M * M) + threadIdx.x];
+  if (threadIdx.x < N * M) dd[threadIdx.x] = Dsp[((long long)b * F + i) * (N * M) + threadIdx.x];
+  __syncthreads();
+  for (int j = threadIdx.x; j < T; j += blockDim.x) {
+    double lam[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const double *tr = basis + (((long long)b * N + n) * F + i) * K;
+      const double *Vn = act + ((long long)b * N + n) * K * T;
+      double r = 0.0;
+      for (int k = 0; k < K; ++k) r = fma(tr[k], Vn[(long long)k * T + j], r);
+      lam[n] = r;
+    }
+    double rc[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      double r = 0.0;
+#pragma unroll
+      for (int n = 0; n < N; ++n) r = fma(lam[n], dd[n * M + m], r);
+      rc[m] = r;
+    }
+    // R = sum_m rc[m] q~_m q~_m^H  (q~_m = column m of Q^-1), Hermitian by construction
+    c128 A[M][M], P[M][M];
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+      for (int c2 = a; c2 < M; ++c2) {
+        c128 s = cmake(0.0, 0.0);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const c128 z = cmulc(qt[a * M + m], qt[c2 * M + m]);
+          s.x = fma(rc[m], z.x, s.x);
+          s.y = fma(rc[m], z.y, s.y);
+        }
+        if (a == c2) s.y = 0.0;
+        A[a][c2] = s;
+        A[c2][a] = cconj(s);
+      }
+    jacobi_eigh<M>(A, P);
+    c128 x[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] = X[(((long long)b * M + m) * F + i) * T + j];
+    // z = P diag(1/floor(lam)) P^H x
+    c128 z[M];
+#pragma unroll
+    for (int a = 0; a < M; ++a) z[a] = cmake(0.0, 0.0);
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      c128 proj = cmake(0.0, 0.0);  // p_k^H x
+#pragma unroll
+      for (int a = 0; a < M; ++a) {
+        const c128 pk = P[a][k];
+        proj.x += pk.x * x[a].x + pk.y * x[a].y;
+        proj.y += pk.x * x[a].y - pk.y * x[a].x;
+      }
+      const double ev = apply_floor(A[k][k].x, floor_kind, eps);
+      proj = cmake(proj.x / ev, proj.y / ev);
+#pragma unroll
+      for (int a = 0; a < M; ++a) cfma(z[a], P[a][k], proj);
+    }
+    // s_m = sum_c conj(q~[c][m]) z_c ;  Y_n = sum_m lam_n d_nm q~[ref][m] s_m
+    c128 sm[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      c128 s = cmake(0.0, 0.0);
+#pragma unroll
+      for (int c2 = 0; c2 < M; ++c2) {
+        const c128 qv = qt[c2 * M + m];
+        s.x += qv.x * z[c2].x + qv.y * z[c2].y;
+        s.y += qv.x * z[c2].y - qv.y * z[c2].x;
+      }
+      sm[m] = cmul(qt[ref * M + m], s);
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      c128 y = cmake(0.0, 0.0);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const double wgt = lam[n] * dd[n * M + m];
+        y.x = fma(wgt, sm[m].x, y.x);
+        y.y = fma(wgt, sm[m].y, y.y);
+      }
+      Y[(((long long)b * N + n) * F + i) * T + j] = y;
+    }
+  }
+}
+
+}  // namespace mnmf_n<N>
+using namespace SSSPY_CAT(mnmf_n, SSSPY_N);
+
+#define MNMF_DISPATCH_M(M_, CALL)                                                          \
+  switch (M_) {                                                                            \
+    case 2: { constexpr int MM = 2; CALL; } break;                                         \
+    case 3: { constexpr int MM = 3; CALL; } break;                                         \
+    case 4: { constexpr int MM = 4; CALL; } break;                                         \
+    default: return fail(SSSPY_ERR_UNSUPPORTED, "FastMNMF: n_channels must be in [2, 4]"); \
+  }
+
+static inline int kt_count(int K) { return (K + 15) / 16; }
+template <int M>
+constexpr int cov_lds_mm() {
+  return cov_lds_doubles_per_wave<M, M>();
+}
+
+int LAUNCHER(mnmf_basis)(const void *X, const void *Q, const double *Dsp, const double *basis,
+                         double *basis_out, const double *act, int B, int M, int F, int T, int K,
+                         int floor_kind, double eps, hipStream_t st) {
+  Dims d{B, F, T, K};
+  dim3 grid((F + 15) / 16, kt_count(K), B), block(256);
+  const size_t lds = (size_t)4 * N * 2 * 256 * sizeof(double);
+  MNMF_DISPATCH_M(M, {
+    if (K <= 16)
+      hipLaunchKernelGGL((k_mnmf_basis<MM, true>), grid, block, lds, st, (const c128 *)X,
+                         (const c128 *)Q, Dsp, basis, basis_out, act, d, floor_kind, eps);
+    else
+      hipLaunchKernelGGL((k_mnmf_basis<MM, false>), grid, block, lds, st, (const c128 *)X,
+                         (const c128 *)Q, Dsp, basis, basis_out, act, d, floor_kind, eps);
+  });
+  return check_launch("k_mnmf_basis");
+}
+
+int LAUNCHER(mnmf_activation)(const void *X, const void *Q, const double *Dsp, const double *basis,
+                              const double *act, double *part, int nchunks, int B, int M, int F,
+                              int T, int K, hipStream_t st) {
+  Dims d{B, F, T, K};
+  const int ntiles = (F + 15) / 16;
+  const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
+  const int ktiles = kt_count(K);
+  dim3 grid((T + 63) / 64, nchunks, B * ktiles), block(256);
+  MNMF_DISPATCH_M(M, {
+    if (K <= 16)
+      hipLaunchKernelGGL((k_mnmf_activation<MM, true>), grid, block, 0, st, (const c128 *)X,
+                         (const c128 *)Q, Dsp, basis, act, part, d, ktiles, tiles_per_chunk,
+                         nchunks);
+    else
+      hipLaunchKernelGGL((k_mnmf_activation<MM, false>), grid, block, 0, st, (const c128 *)X,
+                         (const c128 *)Q, Dsp, basis, act, part, d, ktiles, tiles_per_chunk,
+                         nchunks);
+  });
+  return check_launch("k_mnmf_activation");
+}
+
+int LAUNCHER(mnmf_wcov)(const void *X, const double *Dsp, const double *basis, const double *act,
+                        void *U, int B, int M, int F, int T, int K, hipStream_t st) {
+  Dims d{B, F, T, K};
+  dim3 grid((F + 15) / 16, 1, B), block(256);
+  MNMF_DISPATCH_M(M, {
+    const size_t lds = (size_t)4 * cov_lds_mm<MM>() * sizeof(double);
+    if (K <= 16)
+      hipLaunchKernelGGL((k_mnmf_wcov<MM, true>), grid, block, lds, st, (const c128 *)X, Dsp, basis,
+                         act, (c128 *)U, d);
+    else
+      hipLaunchKernelGGL((k_mnmf_wcov<MM, false>), grid, block, lds, st, (const c128 *)X, Dsp,
+                         basis, act, (c128 *)U, d);
+  });
+  return check_launch("k_mnmf_wcov");
+}
+
+int LAUNCHER(mnmf_spatial)(const void *X, const void *Q, double *Dsp, const double *basis,
+                           const double *act, int B, int M, int F, int T, int K, hipStream_t st) {
+  Dims d{B, F, T, K};
+  dim3 grid((F + 15) / 16, 1, B), block(256);
+  MNMF_DISPATCH_M(M, {
+    const size_t lds = (size_t)4 * 2 * N * MM * 16 * sizeof(double);
+    if (K <= 16)
+      hipLaunchKernelGGL((k_mnmf_spatial<MM, true>), grid, block, lds, st, (const c128 *)X,
+                         (const c128 *)Q, Dsp, basis, act, d);
+    else
+      hipLaunchKernelGGL((k_mnmf_spatial<MM, false>), grid, block, lds, st, (const c128 *)X,
+                         (const c128 *)Q, Dsp, basis, act, d);
+  });
+  return check_launch("k_mnmf_spatial");
+}
+
+int LAUNCHER(mnmf_loss)(const void *X, const void *Q, const double *Dsp, const double *basis,
+                        const double *act, double *out, int B, int M, int F, int T, int K,
+                        hipStream_t st) {
+  Dims d{B, F, T, K};
+  dim3 grid((F + 15) / 16, 1, B), block(256);
+  MNMF_DISPATCH_M(M, {
+    if (K <= 16)
+      hipLaunchKernelGGL((k_mnmf_loss<MM, true>), grid, block, 0, st, (const c128 *)X,
+                         (const c128 *)Q, Dsp, basis, act, out, d);
+    else
+      hipLaunchKernelGGL((k_mnmf_loss<MM, false>), grid, block, 0, st, (const c128 *)X,
+                         (const c128 *)Q, Dsp, basis, act, out, d);
+  });
+  return check_launch("k_mnmf_loss");
+}
+
+int LAUNCHER(mnmf_norm_scale)(void *Q, double *Dsp, const double *qbuf, int B, int M, int F,
+                              int floor_kind, double eps, hipStream_t st) {
+  dim3 grid((F + 63) / 64, B), block(256);
+  MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_norm_scale<MM>), grid, block, 0, st, (c128 *)Q, Dsp,
+                                        qbuf, F, floor_kind, eps));
+  return check_launch("k_mnmf_norm_scale");
+}
+
+int LAUNCHER(mnmf_separate)(const void *X, const void *Q, void *Qinv, const double *Dsp,
+                            const double *basis, const double *act, void *Y, int B, int M, int F,
+                            int T, int K, int ref, int floor_kind, double eps, int *info,
+                            hipStream_t st) {
+  Dims d{B, F, T, K};
+  const long long nbins = (long long)B * F;
+  MNMF_DISPATCH_M(M, {
+    hipLaunchKernelGGL((k_mnmf_qinv<MM>), dim3((unsigned)((nbins + 63) / 64)), dim3(64), 0, st,
+                       (const c128 *)Q, (c128 *)Qinv, nbins, info);
+    hipLaunchKernelGGL((k_mnmf_separate<MM>), dim3(F, B), dim3(256), 0, st, (const c128 *)X,
+                       (const c128 *)Qinv, Dsp, basis, act, (c128 *)Y, d, ref, floor_kind, eps);
+  });
+  return check_launch("k_mnmf_separate");
+}
+
+}  // namespace ssspy

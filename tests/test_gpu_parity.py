@@ -291,3 +291,86 @@ def test_aux_iva_iss_config3_shape_against_oracle():
     Y = m(X, n_iter=3)
     assert rel_err(Y, Yr) < TOL
     np.testing.assert_allclose(m.loss, ref.loss, rtol=LOSS_RTOL)
+
+
+# ------------------------------------------------------------------------------- FastGaussMNMF
+MNMF_CASES = ["fmnmf_ip1_m3", "fmnmf_ip1_m4", "fmnmf_ip1_m3_n2", "fmnmf_ip1_m2_nonorm"]
+
+
+@pytest.mark.parametrize("case", MNMF_CASES)
+def test_fast_gauss_mnmf_against_golden(case):
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+
+    g = load_golden(case)
+    snap = Snap(["diagonalizer", "spatial", "basis", "activation"])
+    m = FastGaussMNMF(n_basis=int(g["meta_n_basis"]), n_sources=int(g["meta_n_sources"]),
+                      flooring_fn=_flooring_fn(g), callbacks=snap,
+                      normalization=bool(g["meta_normalization"]))
+    sp0 = g["spatial0"].copy()
+    Y = m(g["X"], n_iter=int(g["meta_n_iter"]), basis=g["basis0"], activation=g["activation0"],
+          spatial=sp0)
+    assert np.array_equal(sp0, g["spatial0"])
+    _compare_snapshots(g, snap)
+    np.testing.assert_allclose(m.loss, g["loss"], rtol=LOSS_RTOL)
+    assert rel_err(m.diagonalizer, g["final_diagonalizer"]) < TOL
+    assert rel_err(m.spatial, g["final_spatial"]) < TOL
+    assert rel_err(Y, g["final_output"]) < 1e-7  # Wiener filter: eigh + solve, cond(R)-amplified
+
+
+def test_fast_gauss_mnmf_step_methods_match_fused_update():
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+
+    g = load_golden("fmnmf_ip1_m4")
+
+    class Stepwise(FastGaussMNMF):
+        def update_spatial(self):
+            super().update_spatial()
+
+    outs = []
+    for cls in (FastGaussMNMF, Stepwise):
+        m = cls(n_basis=int(g["meta_n_basis"]))
+        m(g["X"], n_iter=3, basis=g["basis0"], activation=g["activation0"], spatial=g["spatial0"])
+        outs.append((m.diagonalizer, m.spatial, m.basis, m.activation))
+    for a, b in zip(*outs):
+        assert rel_err(b, a) < 1e-12
+
+
+def test_fast_gauss_mnmf_config4_shape_against_oracle():
+    """configs[3] channel/source/basis counts (N=M=4, K=8) at an oracle-sized F x T, 3 iterations."""
+    from oracle.mnmf import FastGaussMNMFOracle
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    M, F, T, K = 4, 65, 96, 8
+    X = nmf_mixture(21, M, F, T)
+    basis = np.random.default_rng(1).random((M, F, K))
+    act = np.random.default_rng(2).random((M, K, T))
+    spatial = np.random.default_rng(4).random((F, M, M))
+    ref = FastGaussMNMFOracle(n_basis=K)
+    Yr = ref.run(X, n_iter=3, basis=basis, activation=act, spatial=spatial.copy())
+    m = FastGaussMNMF(n_basis=K)
+    Y = m(X, n_iter=3, basis=basis, activation=act, spatial=spatial)
+    np.testing.assert_allclose(m.loss, ref.loss, rtol=LOSS_RTOL)
+    assert rel_err(m.diagonalizer, ref.diagonalizer) < TOL
+    assert rel_err(Y, Yr) < 1e-7
+
+
+def test_wiener_filter_floors_small_eigenvalues():
+    """to_psd inside separate(): with a huge floor every eigenvalue is clamped, so R = eps I and the
+    output is x-independent of the spatial model's conditioning: Y_n = R_n[ref,:] x / eps."""
+    import functools
+    from oracle.mnmf import FastGaussMNMFOracle
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+    from ssspy_amd.special.flooring import max_flooring
+    from ssspy_amd.utils.dataset import iid_mixture
+
+    M, F, T, K = 3, 9, 20, 2
+    X = iid_mixture(3, M, F, T)
+    kw = dict(basis=np.random.default_rng(1).random((M, F, K)),
+              activation=np.random.default_rng(2).random((M, K, T)),
+              spatial=np.random.default_rng(4).random((F, M, M)))
+    ref = FastGaussMNMFOracle(n_basis=K, flooring=("max", 1e3))
+    Yr = ref.run(X, n_iter=0, **{k: v.copy() for k, v in kw.items()})
+    m = FastGaussMNMF(n_basis=K, flooring_fn=functools.partial(max_flooring, eps=1e3))
+    Y = m(X, n_iter=0, **kw)
+    assert rel_err(Y, Yr) < 1e-9
