@@ -121,8 +121,9 @@ def main():
     if distributed:
         import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        from ssspy_amd import parallel
+
+        parallel.init_from_env(backend="nccl")  # RCCL; used for the barrier and the timing max only
     n_gpus = world if distributed else 1
 
     from ssspy_amd import _device as dv
@@ -154,9 +155,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = parallel.max_over_ranks(elapsed, dev)
     sep._check_device_errors()
 
     # per-kernel-group durations from the HIP events of the timed region (this rank)
