@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Timings of the BASELINE.json configs that are not the bench line (parity-test cases):
+configs[2] AuxIVA-ISS (N=8, F=2049, T=1024) and configs[3] FastGaussMNMF (N=M=4, F=1025, T=512, K=8).
+
+    python benchmarks/other_configs.py [--iters 20]
+
+Prints one JSON object per config: iterations/s of update_once() (record_loss=False), the
+algorithmic-bytes rate of SURVEY.md 8d, and the one-off costs outside the loop.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from ssspy_amd.utils.dataset import nmf_mixture  # noqa: E402
+
+
+def timed(fn, n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1)
+    args = ap.parse_args()
+    from ssspy_amd.bss.iva import AuxLaplaceIVA
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+
+    # configs[2]: AuxIVA-ISS, 8 sources
+    N, F, T = 8, 2049, 1024
+    X = nmf_mixture(3000, N, F, T)
+    if args.batch > 1:
+        X = np.stack([X] * args.batch)
+    m = AuxLaplaceIVA(spatial_algorithm="ISS", record_loss=False)
+    m._contrast = 0
+    m._bind_input(X)
+    m._reset()
+    for _ in range(3):
+        m.update_once()
+    dt = timed(m.update_once, args.iters)
+    B = args.batch
+    print(json.dumps({"config": "configs[2] AuxLaplaceIVA-ISS N=8 F=2049 T=1024 batch={}".format(B),
+                      "ms_per_iter": round(dt * 1e3, 3), "mixture_iterations_per_s": round(B / dt, 2),
+                      "algorithmic_GBs": round(2 * 16 * N * F * T * B / dt / 1e9, 1)}))
+    del m
+    torch.cuda.empty_cache()
+
+    # configs[3]: FastGaussMNMF
+    M, F, T, K = 4, 1025, 512, 8
+    X = nmf_mixture(4000, M, F, T)
+    if args.batch > 1:
+        X = np.stack([X] * args.batch)
+    m = FastGaussMNMF(n_basis=K, record_loss=False, rng=np.random.default_rng(0))
+    m._bind_input(X)
+    t0 = time.perf_counter()
+    m._reset()
+    torch.cuda.synchronize()
+    t_reset = time.perf_counter() - t0
+    for _ in range(3):
+        m.update_once()
+    dt = timed(m.update_once, args.iters)
+    ds = timed(m._separate_dev, 3)
+    print(json.dumps({"config": "configs[3] FastGaussMNMF-IP1 N=M=4 F=1025 T=512 K=8 batch={}".format(B),
+                      "ms_per_iter": round(dt * 1e3, 3), "mixture_iterations_per_s": round(B / dt, 2),
+                      "algorithmic_GBs": round(4 * 16 * M * F * T * B / dt / 1e9, 1),
+                      "wiener_separate_ms": round(ds * 1e3, 3), "reset_s": round(t_reset, 3)}))
+
+
+if __name__ == "__main__":
+    main()
