@@ -94,6 +94,18 @@ int ssspy_update_by_ip1(void *W, const void *U, int B, int F, int N, int floor_k
 int ssspy_iss1_transform(const void *Vc, void *G, int B, int F, int N, int floor_kind,
                          double floor_eps, void *stream);
 
+/* Largest n_frames the fused ISS kernel holds in registers for N sources (0 if N unsupported). */
+int ssspy_iss1_fused_max_frames(int N);
+
+/* One whole update_by_iss1 sweep set, in place on Y (B,N,F,T): a bin's N x T slab stays in the
+ * registers of one workgroup through the N rank-1 steps (one read + one write of Y).
+ * weight: (B,N,T) for SSSPY_WEIGHT_FRAME, (B,N,F,T) for SSSPY_WEIGHT_BIN_FRAME.
+ * r2_next (B,N,T), optional: receives sum_i |y_new|^2 (zeroed by the call) -- the frame powers the
+ * next AuxIVA iteration needs, saving its separate pass.
+ * replaces: ssspy/bss/_update_spatial_model.py:146-194 (update_by_iss1). */
+int ssspy_iss1_fused(void *Y, const double *weight, int weight_kind, double *r2_next, int B, int N,
+                     int F, int T, int floor_kind, double floor_eps, void *stream);
+
 /* W <- W * (W^-1)[ref,:]^T.  W (B,F,N,N) in place.
  * replaces: ssspy/algorithm/projection_back.py:87-99. */
 int ssspy_projection_back_filter(void *W, int B, int F, int N, int reference_id, int *info,

@@ -43,6 +43,7 @@ def _units():
         ("spatial_kernels.hip", "spatial_kernels.o", []),
         ("ilrma_api.hip", "ilrma_api.o", []),
         ("iva_kernels.hip", "iva_kernels.o", []),
+        ("iss_fused.hip", "iss_fused.o", []),
     ]
     units.append(("mnmf_api.hip", "mnmf_api.o", []))
     for n in MNMF_N:

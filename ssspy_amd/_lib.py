@@ -29,6 +29,8 @@ PROTOTYPES = {
     "ssspy_cross_covariance": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "ssspy_update_by_ip1": (_i, [_p, _p, _i, _i, _i, _i, _d, _p, _p]),
     "ssspy_iss1_transform": (_i, [_p, _p, _i, _i, _i, _i, _d, _p]),
+    "ssspy_iss1_fused_max_frames": (_i, [_i]),
+    "ssspy_iss1_fused": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p]),
     "ssspy_projection_back_filter": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "ssspy_projection_back_scale": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "ssspy_demix_from_covariance": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),

@@ -65,6 +65,21 @@ def iss1_transform(Vc, flooring, out=None):
     return out
 
 
+def iss1_fused_max_frames(n_sources):
+    return int(_L().ssspy_iss1_fused_max_frames(n_sources))
+
+
+def iss1_fused(Y, weight, kind, flooring, r2_next=None):
+    """In-place fused ISS1 on Y; optionally accumulates the next iteration's frame powers."""
+    B, N, F, T = Y.shape
+    _lib.check(
+        _L().ssspy_iss1_fused(ptr(Y), ptr(weight), kind, ptr(r2_next), B, N, F, T, flooring[0],
+                              flooring[1], _st()),
+        "iss1_fused",
+    )
+    return Y
+
+
 def projection_back_filter(W, reference_id, info=None):
     B, F, N, _ = W.shape
     _lib.check(

@@ -77,7 +77,10 @@ def update_by_iss1(
     else:
         w = dv.to_device(np.broadcast_to(wt, (B, N, F, T)), dtype=np.float64)
         kind = _lib.WEIGHT_BIN_FRAME
-    Vc = _ops.weighted_covariance(Y, w, kind, N)
-    G = _ops.iss1_transform(Vc, floor)
-    out = dv.to_host(_ops.separate(Y, G))
+    if T <= _ops.iss1_fused_max_frames(N):
+        out = dv.to_host(_ops.iss1_fused(Y, w, kind, floor))  # Y is a private device copy
+    else:
+        Vc = _ops.weighted_covariance(Y, w, kind, N)
+        G = _ops.iss1_transform(Vc, floor)
+        out = dv.to_host(_ops.separate(Y, G))
     return out if batched else out[0]

@@ -391,9 +391,13 @@ class GaussILRMA(ILRMABase):
         N = Y.shape[1]
         varphi = _ops.ilrma_iss_weight(self._state_dev("basis"), self._state_dev("activation"),
                                        float(self.domain))
-        Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
-        G = _ops.iss1_transform(Vc, self._resolve_floor(flooring_fn))
-        _ops.separate(Y, G, out=Y)
+        floor = self._resolve_floor(flooring_fn)
+        if Y.shape[-1] <= _ops.iss1_fused_max_frames(N):
+            _ops.iss1_fused(Y, varphi, _lib.WEIGHT_BIN_FRAME, floor)
+        else:
+            Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
+            G = _ops.iss1_transform(Vc, floor)
+            _ops.separate(Y, G, out=Y)
         self._state_touch("output")
 
     def normalize(self, flooring_fn="self") -> None:

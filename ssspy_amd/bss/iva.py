@@ -125,6 +125,7 @@ class IVABase(DeviceStateMixin, IterativeMethodBase):
             G = _ops.projection_back_scale(XY, YY, self.reference_id, info)
             _ops.separate(Y, G, out=Y)
             self._state_touch("output")
+            self.__dict__["_r2_cache"] = None
 
     def apply_minimal_distortion_principle(self) -> None:
         raise NotImplementedError(
@@ -245,19 +246,23 @@ class AuxIVA(AuxIVABase):
         super()._reset(**kwargs)
         if self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"]:
             self.demix_filter = None
-        self._variance_dev = None
+        self._r2_cache = None  # frame powers of the CURRENT output (ISS state), if known
 
     def _variance_tensor(self):
         return None
 
     def _weights(self, flooring_fn):
         """Auxiliary weights varphi_nj = G'(r_nj) / floor(2 r_nj), (B, N, T)."""
+        return _ops.iva_weight(self._frame_power(), self.n_bins, self._contrast,
+                               self._resolve_floor(flooring_fn), variance=self._variance_tensor())
+
+    def _frame_power(self):
+        """r_nj^2 = sum_i |y_nij|^2 of the current estimate, (B, N, T)."""
         if self._uses_filter():
-            r2 = _ops.iva_frame_power(self._X, self._state_dev("demix_filter"))
-        else:
-            r2 = _ops.iva_frame_power(self._state_dev("output"), None)
-        return _ops.iva_weight(r2, self.n_bins, self._contrast, self._resolve_floor(flooring_fn),
-                               variance=self._variance_tensor())
+            return _ops.iva_frame_power(self._X, self._state_dev("demix_filter"))
+        if self._r2_cache is None:
+            self._r2_cache = _ops.iva_frame_power(self._state_dev("output"), None)
+        return self._r2_cache
 
     def update_once(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/iva.py:1699-1734."""
@@ -282,9 +287,17 @@ class AuxIVA(AuxIVABase):
         N = self.n_sources
         Y = self._state_dev("output")
         weight = self._weights(flooring_fn)
-        Vc = _ops.weighted_covariance(Y, weight, _lib.WEIGHT_FRAME, N)
-        G = _ops.iss1_transform(Vc, self._resolve_floor(flooring_fn))
-        _ops.separate(Y, G, out=Y)
+        floor = self._resolve_floor(flooring_fn)
+        if self.n_frames <= _ops.iss1_fused_max_frames(N):
+            # one read + one write of Y; the kernel also leaves the next iteration's frame powers
+            r2_next = dv.empty(tuple(weight.shape), dv.f64, Y.device)
+            _ops.iss1_fused(Y, weight, _lib.WEIGHT_FRAME, floor, r2_next)
+            self._r2_cache = r2_next
+        else:
+            Vc = _ops.weighted_covariance(Y, weight, _lib.WEIGHT_FRAME, N)
+            G = _ops.iss1_transform(Vc, floor)
+            _ops.separate(Y, G, out=Y)
+            self._r2_cache = None
         self._state_touch("output")
 
     def compute_loss(self) -> float:
@@ -294,7 +307,7 @@ class AuxIVA(AuxIVABase):
             r2 = _ops.iva_frame_power(self._X, W)
         else:
             Y = self._state_dev("output")
-            r2 = _ops.iva_frame_power(Y, None)
+            r2 = self._frame_power()
             W = _ops.demix_from_covariance(_ops.cross_covariance(Y, self._X), self._C(),
                                            self._info_tensor())
         data = _ops.iva_loss_data(r2, self._variance_tensor(), self.n_bins, self._contrast)

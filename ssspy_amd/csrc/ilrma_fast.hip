@@ -21,6 +21,8 @@
 //   * 1/R is v_rcp_f64 + 2 Newton steps (~1 ulp) instead of the IEEE divide sequence;
 //   * accumulators stay with the wave that owns the bins: no cross-wave fold.
 // Compiled once per N (-DSSSPY_N=2..4).
+#include <cstdlib>
+
 #include "common.hpp"
 #include "cov_core.hpp"
 
@@ -119,7 +121,8 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
                                                        const double *__restrict__ act, int F,
                                                        int T, int K, int floor_kind, double eps) {
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
-  __shared__ __attribute__((aligned(16))) c128 wl[4][16 * N * N];
+  constexpr int WSTRIDE = N * N + 1;  // 16-byte slots per bin: odd, so 16 bins never share a bank
+  __shared__ __attribute__((aligned(16))) c128 wl[4][16 * WSTRIDE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
   const int b = blockIdx.z;
@@ -132,10 +135,10 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
   for (int e = lane; e < 16 * N * N; e += 64) {
     const int bl = e / (N * N), rem = e % (N * N);
     const int bi = min(i0 + bl, F - 1);
-    wl[wave][e] = W ? W[((long long)b * F + bi) * (N * N) + rem]
-                    : cmake((rem / N) == (rem % N) ? 1.0 : 0.0, 0.0);
+    wl[wave][bl * WSTRIDE + rem] = W ? W[((long long)b * F + bi) * (N * N) + rem]
+                                     : cmake((rem / N) == (rem % N) ? 1.0 : 0.0, 0.0);
   }
-  const c128 *wmine = wl[wave] + c * N * N;
+  const c128 *wmine = wl[wave] + c * WSTRIDE;
   double tb[N][4];
 #pragma unroll
   for (int n = 0; n < N; ++n)
@@ -204,77 +207,92 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
 }
 
 // ================================================================== weighted covariance (pass 3)
-// U[b,i,n] = (1/T) sum_j x x^H / R.  grid: (ceil(F/64), 1, B)
-__global__ __launch_bounds__(256) void k_wcov_fast(const c128 *__restrict__ X,
-                                                   const double *__restrict__ basis,
-                                                   const double *__restrict__ act,
-                                                   c128 *__restrict__ U, int F, int T, int K) {
+// U[b,i,n] = (1/T) sum_j x x^H / R.
+// The N Hermitian accumulators of a bin (N*N*N reals) do not fit a 256-register budget next to the
+// x tile, so the weight sets (sources) are split over waves: a workgroup is WB bin tiles x NG
+// source groups of SG sources (N = 4: 2 bin tiles x 2 groups of 2).  Each wave recomputes the
+// x x^H products it needs; the x loads of the two group-waves hit the same L1 lines.
+// fp64 MFMA and fp64 VALU do not overlap on gfx950 (benchmarks/micro/f64_rates.hip), so what the
+// second resident wave per SIMD hides is LDS / HBM latency, not arithmetic.
+constexpr int WC_SG = N >= 4 ? 2 : N;            // sources per wave
+constexpr int WC_NG = (N + WC_SG - 1) / WC_SG;   // source groups
+constexpr int WC_WB = 4 / WC_NG;                 // bin tiles per workgroup
+
+__global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X,
+                                                      const double *__restrict__ basis,
+                                                      const double *__restrict__ act,
+                                                      c128 *__restrict__ U, int F, int T, int K) {
+  constexpr int SG = WC_SG;
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
   const int b = blockIdx.z;
-  const int i0 = blockIdx.x * 64 + wave * 16;
+  const int g = wave % WC_NG, wb = wave / WC_NG;
+  const int s0 = g * SG;
+  const int i0 = (blockIdx.x * WC_WB + wb) * 16;
   const int bin = min(i0 + c, F - 1);
   const c128 *Xb = X + (long long)b * N * F * T;
   const double *act_b = act + (long long)b * N * K * T;
-  double tb[N][4];
+  double tb[SG][4];
 #pragma unroll
-  for (int n = 0; n < N; ++n)
+  for (int s = 0; s < SG; ++s)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int kk = 4 * ks + q;
-      tb[n][ks] = kk < K ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
+      const int kk = 4 * ks + q, n = min(s0 + s, N - 1);
+      tb[s][ks] = kk < K ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
     }
-  CovAcc<N, N> acc;
+  CovAcc<N, SG> acc;
   acc.clear();
   const int ntiles = (T + 15) >> 4;
   VStage st;
-  XTile cur, nxt;
+  XTile cur;
   vstage_load(st, act_b, K, T, 0);
-  xtile_load_binmajor(cur, Xb, F, T, bin, 0, q);
   vstage_store(st, vs[0]);
   __syncthreads();
   for (int jt = 0; jt < ntiles; ++jt) {
     const int j0 = jt * 16;
     const int jn = min(jt + 1, ntiles - 1) * 16;
+    xtile_load_binmajor(cur, Xb, F, T, bin, j0, q);
     vstage_load(st, act_b, K, T, jn);
-    xtile_load_binmajor(nxt, Xb, F, T, bin, jn, q);
     const double *vcur = vs[jt & 1];
-    double4_t R[N];
+    double4_t R[SG];
 #pragma unroll
-    for (int n = 0; n < N; ++n) R[n] = rt_from_lds(vcur + n * 16 * VROW, tb[n], c, q);
+    for (int s = 0; s < SG; ++s)
+      R[s] = rt_from_lds(vcur + min(s0 + s, N - 1) * 16 * VROW, tb[s], c, q);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool valid = j0 + 4 * q + r < T;
       c128 x[N];
-      double phi[N];
+      double phi[SG];
 #pragma unroll
       for (int m = 0; m < N; ++m) x[m] = cur.x[m][r];
 #pragma unroll
-      for (int n = 0; n < N; ++n) phi[n] = valid ? rcp_nr(R[n][r]) : 0.0;
+      for (int s = 0; s < SG; ++s) phi[s] = (valid && s0 + s < N) ? rcp_nr(R[s][r]) : 0.0;
       acc.add(x, phi);
     }
     vstage_store(st, vs[(jt + 1) & 1]);
     __syncthreads();
-    cur = nxt;
   }
   acc.fold_q();
-  // lane (c, q) now holds the full sums of bin i0+c; the 4 q-lanes write a quarter each
+  // every q-lane holds the full sums of bin i0+c for this wave's SG sources; spread the stores:
+  // lane q writes rows a with (a & 3) == q
   const double scale = 1.0 / (double)T;
   const int ob = i0 + c;
   if (ob < F) {
     c128 *dst = U + ((long long)b * F + ob) * (long long)(N * N * N);
 #pragma unroll
-    for (int n = 0; n < N; ++n) {
-      if ((n & 3) == q || N < 4) {
+    for (int s = 0; s < SG; ++s) {
+      const int n = s0 + s;
+      if (n < N) {
         int e = 0;
 #pragma unroll
         for (int a = 0; a < N; ++a) {
-          if (N == 4 || q == 0) dst[(n * N + a) * N + a] = cmake(acc.diag[n][a] * scale, 0.0);
+          const bool mine = (a & 3) == q;
+          if (mine) dst[(n * N + a) * N + a] = cmake(acc.diag[s][a] * scale, 0.0);
 #pragma unroll
           for (int bb = a + 1; bb < N; ++bb) {
-            const c128 z = acc.off[n][e];
-            if (N == 4 || q == 0) {
+            const c128 z = acc.off[s][e];
+            if (mine) {
               dst[(n * N + a) * N + bb] = cmake(z.x * scale, z.y * scale);
               dst[(n * N + bb) * N + a] = cmake(z.x * scale, -z.y * scale);
             }
@@ -453,7 +471,7 @@ int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *
 
 int LAUNCHER(ilrma_fast_wcov)(const void *X, const double *basis, const double *act, void *U,
                               int B, int F, int T, int K, hipStream_t st) {
-  dim3 grid((F + 63) / 64, 1, B), block(256);
+  dim3 grid((F + 16 * WC_WB - 1) / (16 * WC_WB), 1, B), block(256);
   hipLaunchKernelGGL(k_wcov_fast, grid, block, 0, st, (const c128 *)X, basis, act, (c128 *)U, F, T,
                      K);
   return check_launch("k_wcov_fast");
