@@ -98,7 +98,7 @@ def timed_steps(sep, steps, stepwise_events):
 
         _ops.ilrma_weighted_covariance(sep._X, sep._state_dev("basis"),
                                        sep._state_dev("activation"), float(sep.domain),
-                                       out=sep._U)
+                                       sep._ws, sep._ws_bytes, out=sep._U)
         marks[3].record()
         _ops.update_by_ip1(sep._state_dev("demix_filter"), sep._U, sep._floor, sep._info_tensor())
         sep._state_touch("demix_filter")

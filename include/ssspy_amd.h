@@ -127,7 +127,9 @@ int ssspy_sum_logdet(const void *W, double *out, int B, int F, int N, void *stre
 
 /* ------------------------------------------------------------------ GaussILRMA (IP1/ISS1, MM) */
 
-/* Scratch (bytes) the ILRMA entry points below may use for one call; sized for the largest. */
+/* Scratch (bytes) for the ILRMA entry points below: one buffer of this size serves all of them
+ * (each uses its own region: bin-chunk partials of the activation pass, frame-chunk partials of
+ * the basis / covariance passes for small batches, per-bin powers for the normalisation). */
 size_t ssspy_ilrma_workspace_bytes(int B, int N, int F, int T, int K);
 
 /* basis update: T <- floor(T * (sum_j V P/R^((p+2)/p) / sum_j V/R)^(p/(p+2))), R = T V,
@@ -149,7 +151,7 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
  * replaces: ssspy/bss/ilrma.py:1494-1505 (weights) + the covariance broadcast. */
 int ssspy_ilrma_weighted_covariance(const void *X, const double *basis, const double *activation,
                                     void *U, int B, int N, int F, int T, int K, double domain,
-                                    void *stream);
+                                    void *workspace, size_t workspace_bytes, void *stream);
 
 /* power normalisation from the static covariance C (B,F,N,N) = (1/T) sum_j x x^H:
  * psi_n = floor(sqrt(mean_i w_in^H C_i w_in)); W[:,n,:] /= psi_n; basis[n] /= psi_n^p.

@@ -147,14 +147,14 @@ def ilrma_update_activation(X, W, basis, activation, domain, flooring, ws, ws_by
     )
 
 
-def ilrma_weighted_covariance(X, basis, activation, domain, out=None):
+def ilrma_weighted_covariance(X, basis, activation, domain, ws, ws_bytes, out=None):
     B, N, F, T = X.shape
     K = basis.shape[-1]
     if out is None:
         out = dv.empty((B, F, N, N, N), dv.c128, X.device)
     _lib.check(
         _L().ssspy_ilrma_weighted_covariance(ptr(X), ptr(basis), ptr(activation), ptr(out), B, N, F,
-                                             T, K, domain, _st()),
+                                             T, K, domain, ptr(ws), ws_bytes, _st()),
         "ilrma_weighted_covariance",
     )
     return out

@@ -380,7 +380,7 @@ class GaussILRMA(ILRMABase):
             self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
         _ops.ilrma_weighted_covariance(self._X, self._state_dev("basis"),
                                        self._state_dev("activation"), float(self.domain),
-                                       out=self._U)
+                                       self._ws, self._ws_bytes, out=self._U)
         _ops.update_by_ip1(self._state_dev("demix_filter"), self._U,
                            self._resolve_floor(flooring_fn), self._info_tensor())
         self._state_touch("demix_filter")

@@ -22,11 +22,11 @@ DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
 // throughput variants (ilrma_fast.hip): domain == 2, n_basis <= 16, n_sources <= 4, even T
 #define DECL_FAST(n)                                                                           \
   int ilrma_fast_basis_n##n(const void *, const void *, double *, const double *, int, int, int, \
-                            int, int, double, hipStream_t);                                    \
+                            int, int, double, int, double *, hipStream_t);                     \
   int ilrma_fast_activation_n##n(const void *, const void *, const double *, const double *,   \
                                  double *, int, int, int, int, int, hipStream_t);              \
   int ilrma_fast_wcov_n##n(const void *, const double *, const double *, void *, int, int, int, \
-                           int, hipStream_t);
+                           int, int, hipStream_t);
 DECL_FAST(2) DECL_FAST(3) DECL_FAST(4)
 #undef DECL_FAST
 
@@ -80,7 +80,28 @@ static inline size_t qbuf_bytes(int B, int N, int F) {
 }
 
 int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, int F, int N,
-                   int floor_kind, double floor_eps, int *info, hipStream_t st);
+                   int floor_kind, double floor_eps, int *info, hipStream_t st, int nchunks);
+int sum_chunks(void *dst, const void *src, long long count, int nchunks, hipStream_t st);
+
+// frame chunks of the bin-major fast kernels (basis, covariance): 1 for large batches; for small
+// ones enough blocks to put ~2 waves on every SIMD
+static inline int frame_chunks(int B, int F, int T) {
+  const long long blocks0 = (long long)B * ((F + 63) / 64);
+  const int ntiles = (T + 15) / 16;
+  long long want = (512 + blocks0 - 1) / blocks0;
+  if (want < 1) want = 1;
+  if (want > 16) want = 16;
+  if (want > ntiles) want = ntiles;
+  return (int)want;
+}
+static inline size_t basis_part_bytes(int B, int N, int F, int T, int K) {
+  const int ch = frame_chunks(B, F, T);
+  return ch > 1 ? align256((size_t)B * ch * N * F * K * 2 * sizeof(double)) : 0;
+}
+static inline size_t u_part_bytes(int B, int N, int F, int T) {
+  const int ch = frame_chunks(B, F, T);
+  return ch > 1 ? align256((size_t)ch * B * F * N * N * N * 2 * sizeof(double)) : 0;
+}
 int row_power(const void *W, const void *C, double *qbuf, int B, int F, int N, hipStream_t st);
 
 // V <- floor(V * (sum_chunks num / sum_chunks den)^(p/(p+2)))
@@ -193,10 +214,32 @@ using namespace ssspy;
 
 extern "C" {
 
+// One scratch layout for every ILRMA entry point: callers pass the same buffer everywhere.
+struct IlrmaWs {
+  size_t act_part, btmp, qbuf, psi, bpart, upart, total;
+};
+static inline IlrmaWs ilrma_ws(int B, int N, int F, int T, int K) {
+  IlrmaWs w;
+  size_t off = 0;
+  w.act_part = off;
+  off += act_part_bytes(B, N, F, T, K);
+  w.btmp = off;
+  off += basis_tmp_bytes(B, N, F, K);
+  w.qbuf = off;
+  off += qbuf_bytes(B, N, F);
+  w.psi = off;
+  off += align256((size_t)B * N * sizeof(double));
+  w.bpart = off;
+  off += basis_part_bytes(B, N, F, T, K);
+  w.upart = off;
+  off += u_part_bytes(B, N, F, T);
+  w.total = off;
+  return w;
+}
+
 size_t ssspy_ilrma_workspace_bytes(int B, int N, int F, int T, int K) {
   if (B <= 0 || N <= 0 || F <= 0 || T <= 0 || K <= 0) return 0;
-  return act_part_bytes(B, N, F, T, K) + basis_tmp_bytes(B, N, F, K) + qbuf_bytes(B, N, F) +
-         align256((size_t)B * N * sizeof(double));
+  return ilrma_ws(B, N, F, T, K).total;
 }
 
 int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const double *activation,
@@ -206,17 +249,15 @@ int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const 
   SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0, "update_basis: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_basis: n_basis must be in [1, 64]");
   SSSPY_REQUIRE(domain > 0.0 && domain <= 2.0, "update_basis: domain must be in (0, 2]");
+  const IlrmaWs w = ilrma_ws(B, N, F, T, K);
+  SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "update_basis: workspace too small");
+  char *ws = (char *)workspace;
   hipStream_t st = as_stream(stream);
   if (fast_path(N, T, K, domain)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_basis, X, W, basis, activation, B, F, T, K, floor_kind,
-                        floor_eps, st);
+                        floor_eps, frame_chunks(B, F, T), (double *)(ws + w.bpart), st);
   }
-  double *out = basis;
-  if (K > 16) {
-    SSSPY_REQUIRE(workspace && workspace_bytes >= basis_tmp_bytes(B, N, F, K),
-                  "update_basis: workspace too small");
-    out = (double *)workspace;
-  }
+  double *out = K > 16 ? (double *)(ws + w.btmp) : basis;
   auto run = [&]() -> int {
     ILRMA_DISPATCH(N, ilrma_basis, X, W, basis, out, activation, B, F, T, K, domain, floor_kind,
                    floor_eps, st);
@@ -238,37 +279,53 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
   SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0,
                 "update_activation: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_activation: n_basis must be in [1, 64]");
-  SSSPY_REQUIRE(workspace && workspace_bytes >= act_part_bytes(B, N, F, T, K),
-                "update_activation: workspace too small");
+  const IlrmaWs w = ilrma_ws(B, N, F, T, K);
+  SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "update_activation: workspace too small");
+  double *part = (double *)((char *)workspace + w.act_part);
   const int chunks = act_chunks(B, N, F, T, K);
   hipStream_t st = as_stream(stream);
   auto run = [&]() -> int {
     if (fast_path(N, T, K, domain)) {
-      ILRMA_FAST_DISPATCH(N, ilrma_fast_activation, X, W, basis, activation, (double *)workspace,
-                          chunks, B, F, T, K, st);
+      ILRMA_FAST_DISPATCH(N, ilrma_fast_activation, X, W, basis, activation, part, chunks, B, F, T,
+                          K, st);
     }
-    ILRMA_DISPATCH(N, ilrma_activation, X, W, basis, activation, (double *)workspace, chunks, B, F,
-                   T, K, domain, st);
+    ILRMA_DISPATCH(N, ilrma_activation, X, W, basis, activation, part, chunks, B, F, T, K, domain,
+                   st);
   };
   int rc = run();
   if (rc) return rc;
   dim3 g2((unsigned)(((long long)K * T + 255) / 256), N, B);
   hipLaunchKernelGGL(k_ilrma_activation_finalize, g2, dim3(256), 0, st, activation,
-                     (const double *)workspace, N, K, T, chunks, domain, floor_kind, floor_eps);
+                     (const double *)part, N, K, T, chunks, domain, floor_kind, floor_eps);
   return check_launch("k_ilrma_activation_finalize");
+}
+
+// covariance into `dst`; returns the number of partial chunks left at dst (chunk c at
+// dst + c * B*F*N^3): 1 means dst holds the final U.
+static int wcov_into(const void *X, const double *basis, const double *activation, void *dst, int B,
+                     int N, int F, int T, int K, double domain, int chunks, hipStream_t st) {
+  if (fast_path(N, T, K, domain)) {
+    ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, basis, activation, dst, B, F, T, K, chunks, st);
+  }
+  ILRMA_DISPATCH(N, ilrma_wcov, X, basis, activation, dst, B, F, T, K, domain, st);
 }
 
 int ssspy_ilrma_weighted_covariance(const void *X, const double *basis, const double *activation,
                                     void *U, int B, int N, int F, int T, int K, double domain,
-                                    void *stream) {
+                                    void *workspace, size_t workspace_bytes, void *stream) {
   SSSPY_REQUIRE(X && basis && activation && U && B > 0 && F > 0 && T > 0,
                 "ilrma_weighted_covariance: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "ilrma_weighted_covariance: bad n_basis");
-  if (fast_path(N, T, K, domain)) {
-    ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, basis, activation, U, B, F, T, K,
-                        as_stream(stream));
-  }
-  ILRMA_DISPATCH(N, ilrma_wcov, X, basis, activation, U, B, F, T, K, domain, as_stream(stream));
+  const IlrmaWs w = ilrma_ws(B, N, F, T, K);
+  SSSPY_REQUIRE(workspace && workspace_bytes >= w.total,
+                "ilrma_weighted_covariance: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int chunks = fast_path(N, T, K, domain) ? frame_chunks(B, F, T) : 1;
+  if (chunks == 1) return wcov_into(X, basis, activation, U, B, N, F, T, K, domain, 1, st);
+  void *upart = (char *)workspace + w.upart;
+  int rc = wcov_into(X, basis, activation, upart, B, N, F, T, K, domain, chunks, st);
+  if (rc) return rc;
+  return sum_chunks(U, upart, (long long)B * F * N * N * N, chunks, st);
 }
 
 static int launch_norm_scale(void *W, double *basis, const double *qbuf, int B, int N, int F, int K,
@@ -283,10 +340,10 @@ int ssspy_ilrma_normalize_filter(void *W, const void *C, double *basis, int B, i
                                  size_t workspace_bytes, void *stream) {
   SSSPY_REQUIRE(W && C && basis && B > 0 && N >= 1 && N <= SSSPY_MAX_SOURCES,
                 "normalize_filter: bad argument");
+  hipStream_t st = as_stream(stream);
   SSSPY_REQUIRE(workspace && workspace_bytes >= qbuf_bytes(B, N, F),
                 "normalize_filter: workspace too small");
-  hipStream_t st = as_stream(stream);
-  double *qbuf = (double *)workspace;
+  double *qbuf = (double *)workspace;  // any B*F*N doubles of scratch
   int rc = row_power(W, C, qbuf, B, F, N, st);
   if (rc) return rc;
   return launch_norm_scale(W, basis, qbuf, B, N, F, K, domain, floor_kind, floor_eps, st);
@@ -336,27 +393,27 @@ int ssspy_gauss_ilrma_ip1_update(const void *X, const void *C, void *W, double *
                                  void *stream) {
   SSSPY_REQUIRE(X && W && basis && activation && U, "gauss_ilrma_ip1_update: bad argument");
   SSSPY_REQUIRE(!normalize || C, "gauss_ilrma_ip1_update: normalisation needs C");
+  const IlrmaWs w = ilrma_ws(B, N, F, T, K);
+  SSSPY_REQUIRE(workspace && workspace_bytes >= w.total,
+                "gauss_ilrma_ip1_update: workspace too small");
+  char *ws = (char *)workspace;
+  hipStream_t st = as_stream(stream);
   int rc = ssspy_ilrma_update_basis(X, W, basis, activation, B, N, F, T, K, domain, floor_kind,
-                                    floor_eps, (char *)workspace + act_part_bytes(B, N, F, T, K),
-                                    workspace_bytes > act_part_bytes(B, N, F, T, K)
-                                        ? workspace_bytes - act_part_bytes(B, N, F, T, K)
-                                        : 0,
-                                    stream);
+                                    floor_eps, workspace, workspace_bytes, stream);
   if (rc) return rc;
   rc = ssspy_ilrma_update_activation(X, W, basis, activation, B, N, F, T, K, domain, floor_kind,
                                      floor_eps, workspace, workspace_bytes, stream);
   if (rc) return rc;
-  rc = ssspy_ilrma_weighted_covariance(X, basis, activation, U, B, N, F, T, K, domain, stream);
+  // covariance: for small batches the frame chunks stay as partial sums and IP1 adds them up
+  const int chunks = fast_path(N, T, K, domain) ? frame_chunks(B, F, T) : 1;
+  void *ucov = chunks > 1 ? (void *)(ws + w.upart) : U;
+  rc = wcov_into(X, basis, activation, ucov, B, N, F, T, K, domain, chunks, st);
   if (rc) return rc;
-  if (!normalize) return ssspy_update_by_ip1(W, U, B, F, N, floor_kind, floor_eps, info, stream);
-  const size_t qoff = act_part_bytes(B, N, F, T, K) + basis_tmp_bytes(B, N, F, K);
-  SSSPY_REQUIRE(workspace_bytes >= qoff + qbuf_bytes(B, N, F),
-                "gauss_ilrma_ip1_update: workspace too small");
-  double *qbuf = (double *)((char *)workspace + qoff);
-  rc = ip1_with_power(W, U, C, qbuf, B, F, N, floor_kind, floor_eps, info, as_stream(stream));
-  if (rc) return rc;
-  return launch_norm_scale(W, basis, qbuf, B, N, F, K, domain, floor_kind, floor_eps,
-                           as_stream(stream));
+  double *qbuf = (double *)(ws + w.qbuf);
+  rc = ip1_with_power(W, ucov, normalize ? C : nullptr, normalize ? qbuf : nullptr, B, F, N,
+                      floor_kind, floor_eps, info, st, chunks);
+  if (rc || !normalize) return rc;
+  return launch_norm_scale(W, basis, qbuf, B, N, F, K, domain, floor_kind, floor_eps, st);
 }
 
 }  // extern "C"

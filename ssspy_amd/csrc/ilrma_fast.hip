@@ -116,10 +116,14 @@ __device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const doubl
 // Register diet for 2 waves per SIMD (<= 256 VGPR+AGPR): the demixing rows live in LDS and are
 // re-read per (source, channel); the second resident workgroup hides the x-load latency that
 // the one-wave version covered with a register prefetch.
+// Small batches: blockIdx.y splits the frame tiles into `nchunks` ranges so the grid fills the
+// chip; the block then writes its partial num/den to `part` ([b][chunk][n][bin][k][2]) and
+// k_basis_finalize applies the update.  nchunks == 1 updates the basis in place.
 __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ X,
                                                        const c128 *__restrict__ W, double *basis,
                                                        const double *__restrict__ act, int F,
-                                                       int T, int K, int floor_kind, double eps) {
+                                                       int T, int K, int floor_kind, double eps,
+                                                       int nchunks, double *__restrict__ part) {
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
   constexpr int WSTRIDE = N * N + 1;  // 16-byte slots per bin: odd, so 16 bins never share a bank
   __shared__ __attribute__((aligned(16))) c128 wl[4][16 * WSTRIDE];
@@ -155,18 +159,20 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
   }
 
   const int ntiles = (T + 15) >> 4;
+  const int tpc = (ntiles + nchunks - 1) / nchunks;
+  const int jt_begin = blockIdx.y * tpc, jt_end = min(ntiles, jt_begin + tpc);
   VStage st;
   XTile cur;
-  vstage_load(st, act_b, K, T, 0);
+  vstage_load(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
   vstage_store(st, vs[0]);
   __syncthreads();
 
-  for (int jt = 0; jt < ntiles; ++jt) {
+  for (int jt = jt_begin; jt < jt_end; ++jt) {
     const int j0 = jt * 16;
-    const int jn = min(jt + 1, ntiles - 1) * 16;  // last iteration re-fetches its own tile
+    const int jn = min(jt + 1, jt_end - 1) * 16;  // last iteration re-fetches its own tile
     xtile_load_binmajor(cur, Xb, F, T, bin, j0, q);
     vstage_load(st, act_b, K, T, jn);
-    const double *vcur = vs[jt & 1];
+    const double *vcur = vs[(jt - jt_begin) & 1];
 #pragma unroll
     for (int n = 0; n < N; ++n) {
       const double *vn = vcur + n * 16 * VROW;
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
         den[n] = mfma_f64(bb, vb[r], den[n]);
       }
     }
-    vstage_store(st, vs[(jt + 1) & 1]);
+    vstage_store(st, vs[(jt - jt_begin + 1) & 1]);
     __syncthreads();
   }
   // D: col = basis index c, row = q + 4r -> bin i0 + q + 4r
@@ -200,10 +206,34 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
     for (int r = 0; r < 4; ++r) {
       const int ob = i0 + q + 4 * r;
       if (ob < F && c < K) {
-        double *dst = basis + (((long long)b * N + n) * F + ob) * K + c;
-        *dst = apply_floor(sqrt(num[n][r] / den[n][r]) * (*dst), floor_kind, eps);
+        if (nchunks == 1) {
+          double *dst = basis + (((long long)b * N + n) * F + ob) * K + c;
+          *dst = apply_floor(sqrt(num[n][r] / den[n][r]) * (*dst), floor_kind, eps);
+        } else {
+          double *dst = part + ((((long long)(b * nchunks + blockIdx.y) * N + n) * F + ob) * K + c) * 2;
+          dst[0] = num[n][r];
+          dst[1] = den[n][r];
+        }
       }
     }
+}
+
+// basis <- floor(basis * sqrt(sum_chunks num / sum_chunks den)); one thread per (b, n, bin, k)
+__global__ __launch_bounds__(256) void k_basis_finalize(double *basis,
+                                                        const double *__restrict__ part,
+                                                        long long per_mixture, int nchunks,
+                                                        int floor_kind, double eps) {
+  const int b = blockIdx.y;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= per_mixture) return;
+  double sn = 0.0, sd = 0.0;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const double *src = part + (((long long)b * nchunks + ch) * per_mixture + e) * 2;
+    sn += src[0];
+    sd += src[1];
+  }
+  double *dst = basis + (long long)b * per_mixture + e;
+  *dst = apply_floor(sqrt(sn / sd) * (*dst), floor_kind, eps);
 }
 
 // ================================================================== weighted covariance (pass 3)
@@ -218,10 +248,13 @@ constexpr int WC_SG = N >= 4 ? 2 : N;            // sources per wave
 constexpr int WC_NG = (N + WC_SG - 1) / WC_SG;   // source groups
 constexpr int WC_WB = 4 / WC_NG;                 // bin tiles per workgroup
 
+// blockIdx.y = frame chunk (small batches); chunk c writes its partial sums (already scaled by 1/T)
+// to U + c * chunk_stride; k_ip1 adds the chunks up.
 __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X,
                                                       const double *__restrict__ basis,
                                                       const double *__restrict__ act,
-                                                      c128 *__restrict__ U, int F, int T, int K) {
+                                                      c128 *__restrict__ U, int F, int T, int K,
+                                                      int nchunks, long long chunk_stride) {
   constexpr int SG = WC_SG;
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -244,17 +277,19 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
   CovAcc<N, SG> acc;
   acc.clear();
   const int ntiles = (T + 15) >> 4;
+  const int tpc = (ntiles + nchunks - 1) / nchunks;
+  const int jt_begin = blockIdx.y * tpc, jt_end = min(ntiles, jt_begin + tpc);
   VStage st;
   XTile cur;
-  vstage_load(st, act_b, K, T, 0);
+  vstage_load(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
   vstage_store(st, vs[0]);
   __syncthreads();
-  for (int jt = 0; jt < ntiles; ++jt) {
+  for (int jt = jt_begin; jt < jt_end; ++jt) {
     const int j0 = jt * 16;
-    const int jn = min(jt + 1, ntiles - 1) * 16;
+    const int jn = min(jt + 1, jt_end - 1) * 16;
     xtile_load_binmajor(cur, Xb, F, T, bin, j0, q);
     vstage_load(st, act_b, K, T, jn);
-    const double *vcur = vs[jt & 1];
+    const double *vcur = vs[(jt - jt_begin) & 1];
     double4_t R[SG];
 #pragma unroll
     for (int s = 0; s < SG; ++s)
@@ -270,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
       for (int s = 0; s < SG; ++s) phi[s] = (valid && s0 + s < N) ? rcp_nr(R[s][r]) : 0.0;
       acc.add(x, phi);
     }
-    vstage_store(st, vs[(jt + 1) & 1]);
+    vstage_store(st, vs[(jt - jt_begin + 1) & 1]);
     __syncthreads();
   }
   acc.fold_q();
@@ -279,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
   const double scale = 1.0 / (double)T;
   const int ob = i0 + c;
   if (ob < F) {
-    c128 *dst = U + ((long long)b * F + ob) * (long long)(N * N * N);
+    c128 *dst = U + blockIdx.y * chunk_stride + ((long long)b * F + ob) * (long long)(N * N * N);
 #pragma unroll
     for (int s = 0; s < SG; ++s) {
       const int n = s0 + s;
@@ -450,12 +485,17 @@ __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restri
 using namespace SSSPY_CAT(ilrma_fast_n, SSSPY_N);
 
 int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, double *basis, const double *act,
-                               int B, int F, int T, int K, int floor_kind, double eps,
-                               hipStream_t st) {
-  dim3 grid((F + 63) / 64, 1, B), block(256);
+                               int B, int F, int T, int K, int floor_kind, double eps, int nchunks,
+                               double *part, hipStream_t st) {
+  dim3 grid((F + 63) / 64, nchunks, B), block(256);
   hipLaunchKernelGGL(k_basis_fast, grid, block, 0, st, (const c128 *)X, (const c128 *)W, basis,
-                     act, F, T, K, floor_kind, eps);
-  return check_launch("k_basis_fast");
+                     act, F, T, K, floor_kind, eps, nchunks, part);
+  int rc = check_launch("k_basis_fast");
+  if (rc || nchunks == 1) return rc;
+  const long long per_mixture = (long long)N * F * K;
+  hipLaunchKernelGGL(k_basis_finalize, dim3((unsigned)((per_mixture + 255) / 256), B), block, 0, st,
+                     basis, part, per_mixture, nchunks, floor_kind, eps);
+  return check_launch("k_basis_finalize");
 }
 
 int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *basis,
@@ -469,11 +509,12 @@ int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *
   return check_launch("k_activation_fast");
 }
 
+// U must hold nchunks * B*F*N^3 elements; chunk c's partial lands at U + c * B*F*N^3.
 int LAUNCHER(ilrma_fast_wcov)(const void *X, const double *basis, const double *act, void *U,
-                              int B, int F, int T, int K, hipStream_t st) {
-  dim3 grid((F + 16 * WC_WB - 1) / (16 * WC_WB), 1, B), block(256);
+                              int B, int F, int T, int K, int nchunks, hipStream_t st) {
+  dim3 grid((F + 16 * WC_WB - 1) / (16 * WC_WB), nchunks, B), block(256);
   hipLaunchKernelGGL(k_wcov_fast, grid, block, 0, st, (const c128 *)X, basis, act, (c128 *)U, F, T,
-                     K);
+                     K, nchunks, (long long)B * F * N * N * N);
   return check_launch("k_wcov_fast");
 }
 
