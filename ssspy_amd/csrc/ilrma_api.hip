@@ -132,18 +132,31 @@ __global__ __launch_bounds__(256) void k_ilrma_activation_finalize(double *act,
 __global__ __launch_bounds__(256) void k_norm_scale(c128 *W, double *basis,
                                                     const double *__restrict__ qbuf, int N, int F,
                                                     int K, double p, int floor_kind, double eps) {
-  __shared__ double scratch[4];
+  __shared__ double wsum[4][SSSPY_MAX_SOURCES];
   __shared__ double psi[SSSPY_MAX_SOURCES];
   const int b = blockIdx.y;
   const double *qb = qbuf + (long long)b * F * N;
-  for (int n = 0; n < N; ++n) {
+  // thread t walks the flat (bin, n) array with a stride that keeps its source index fixed
+  {
+    const int n = threadIdx.x % N;
+    const int stride = (blockDim.x / N) * N;
     double local = 0.0;
-    for (int i = threadIdx.x; i < F; i += blockDim.x) local += qb[(long long)i * N + n];
-    const double total = block_sum(local, scratch);
-    if (threadIdx.x == 0) {
-      double v = total / (double)F;
+    if (threadIdx.x < stride)
+      for (int e = threadIdx.x; e < F * N; e += stride) local += qb[e];
+    // lanes with equal (lane % N) hold the same source; fold them inside the wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int n2 = 0; n2 < N; ++n2) {
+      const double mine = (n == n2) ? local : 0.0;
+      const double tot = wave_sum(mine);
+      if (lane == 0) wsum[wave][n2] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+      double v = 0.0;
+      for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) v += wsum[wv][threadIdx.x];
+      v = v / (double)F;
       v = v < 0.0 ? 0.0 : v;
-      psi[n] = apply_floor(sqrt(v), floor_kind, eps);
+      psi[threadIdx.x] = apply_floor(sqrt(v), floor_kind, eps);
     }
   }
   __syncthreads();
@@ -404,14 +417,19 @@ int ssspy_gauss_ilrma_ip1_update(const void *X, const void *C, void *W, double *
   rc = ssspy_ilrma_update_activation(X, W, basis, activation, B, N, F, T, K, domain, floor_kind,
                                      floor_eps, workspace, workspace_bytes, stream);
   if (rc) return rc;
-  // covariance: for small batches the frame chunks stay as partial sums and IP1 adds them up
+  // covariance: for small batches the frame chunks are partial sums, folded by a wide kernel
+  // (a lane of the IP1 kernel owns a whole bin and would add them up serially)
   const int chunks = fast_path(N, T, K, domain) ? frame_chunks(B, F, T) : 1;
   void *ucov = chunks > 1 ? (void *)(ws + w.upart) : U;
   rc = wcov_into(X, basis, activation, ucov, B, N, F, T, K, domain, chunks, st);
   if (rc) return rc;
+  if (chunks > 1) {
+    rc = sum_chunks(U, ucov, (long long)B * F * N * N * N, chunks, st);
+    if (rc) return rc;
+  }
   double *qbuf = (double *)(ws + w.qbuf);
-  rc = ip1_with_power(W, ucov, normalize ? C : nullptr, normalize ? qbuf : nullptr, B, F, N,
-                      floor_kind, floor_eps, info, st, chunks);
+  rc = ip1_with_power(W, U, normalize ? C : nullptr, normalize ? qbuf : nullptr, B, F, N,
+                      floor_kind, floor_eps, info, st, 1);
   if (rc || !normalize) return rc;
   return launch_norm_scale(W, basis, qbuf, B, N, F, K, domain, floor_kind, floor_eps, st);
 }
