@@ -125,6 +125,32 @@ int ssspy_demix_from_covariance(const void *YX, const void *XX, void *W, int B, 
  * replaces: np.linalg.slogdet at ssspy/bss/ilrma.py:534, iva.py:234, mnmf.py:1274. */
 int ssspy_sum_logdet(const void *W, double *out, int B, int F, int N, void *stream);
 
+/* ------------------------------------------------------------------ batched small linear algebra */
+/* Device counterparts of ssspy.linalg / ssspy.special.psd: `n` independent matrices, one per lane. */
+
+/* X = A^-1 B.  A (n,N,N), B (n,N,nrhs), X (n,N,nrhs) complex128; N <= 8; LU with partial pivoting.
+ * replaces: ssspy/linalg/_solve.py:9-21 (np.linalg.solve). */
+int ssspy_solve(const void *A, const void *Bm, void *X, long long n, int N, int nrhs, int *info,
+                void *stream);
+
+/* closed-form 2x2 inverse.  replaces: ssspy/linalg/inv.py:4-54 (inv2). */
+int ssspy_inv2(const void *A, void *out, long long n, void *stream);
+
+/* Hermitian eigen-decomposition (cyclic complex Jacobi): lamb (n,M) ascending, V (n,M,M) unit
+ * eigenvectors in columns (phase convention differs from LAPACK; A V = V diag(lamb) holds).
+ * replaces: np.linalg.eigh at ssspy/linalg/eigh.py:77,157,198 and ssspy/special/psd.py:54. */
+int ssspy_eigh(const void *A, double *lamb, void *V, long long n, int M, void *stream);
+
+/* Hermitise, floor the eigenvalues, rebuild, Hermitise.  replaces: ssspy/special/psd.py:11-71. */
+int ssspy_to_psd(const void *A, void *out, long long n, int M, int floor_kind, double floor_eps,
+                 void *stream);
+
+/* generalised 2x2 Hermitian eigenproblem via Cholesky of B; type 1: A z = l B z, 2: A B z = l z,
+ * 3: B A z = l z.  lamb (n,2) ascending, Z (n,2,2).  `info` counts non-positive-definite B.
+ * replaces: ssspy/linalg/eigh.py:84-207 (eigh2 / _eigh). */
+int ssspy_eigh2(const void *A, const void *Bm, double *lamb, void *Z, long long n, int type,
+                int *info, void *stream);
+
 /* ------------------------------------------------------------------ GaussILRMA (IP1/ISS1, MM) */
 
 /* Scratch (bytes) for the ILRMA entry points below: one buffer of this size serves all of them

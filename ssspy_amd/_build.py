@@ -44,6 +44,7 @@ def _units():
         ("ilrma_api.hip", "ilrma_api.o", []),
         ("iva_kernels.hip", "iva_kernels.o", []),
         ("iss_fused.hip", "iss_fused.o", []),
+        ("linalg_kernels.hip", "linalg_kernels.o", []),
     ]
     units.append(("mnmf_api.hip", "mnmf_api.o", []))
     for n in MNMF_N:

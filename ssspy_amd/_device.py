@@ -22,6 +22,8 @@ def device(index=None):
 def to_device(array, dtype=None, dev=None):
     """Copy a NumPy array into a fresh contiguous HBM buffer (never aliases the input)."""
     a = np.ascontiguousarray(array, dtype=dtype)
+    if not a.flags.writeable:  # e.g. a view of an .npz member or a broadcast: torch wants writable
+        a = a.copy()
     return torch.from_numpy(a).to(dev or device(), copy=True)
 
 

@@ -19,6 +19,7 @@ CONTRAST_LAPLACE, CONTRAST_GAUSS = 0, 1
 MAX_SOURCES, MAX_BASIS = 8, 64
 
 _p, _i, _d, _z = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+_q = ctypes.c_longlong
 
 # name -> (restype, argtypes); mirrors include/ssspy_amd.h one to one
 PROTOTYPES = {
@@ -35,6 +36,11 @@ PROTOTYPES = {
     "ssspy_projection_back_scale": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "ssspy_demix_from_covariance": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "ssspy_sum_logdet": (_i, [_p, _p, _i, _i, _i, _p]),
+    "ssspy_solve": (_i, [_p, _p, _p, _q, _i, _i, _p, _p]),
+    "ssspy_inv2": (_i, [_p, _p, _q, _p]),
+    "ssspy_eigh": (_i, [_p, _p, _p, _q, _i, _p]),
+    "ssspy_to_psd": (_i, [_p, _p, _q, _i, _i, _d, _p]),
+    "ssspy_eigh2": (_i, [_p, _p, _p, _p, _q, _i, _p, _p]),
     "ssspy_ilrma_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "ssspy_ilrma_update_basis": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p, _z, _p]),
     "ssspy_ilrma_update_activation": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p, _z, _p]),

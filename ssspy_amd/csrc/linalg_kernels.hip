@@ -1,0 +1,290 @@
+// Batched small dense linear algebra (one matrix per lane): solve, inv2, Hermitian eigh,
+// generalised 2x2 eigh, PSD projection.  Device counterparts of ssspy.linalg / ssspy.special.psd.
+#include "common.hpp"
+#include "smallmat.hpp"
+
+namespace ssspy {
+
+// cyclic complex Jacobi (see mnmf_kernels.hip for the rotation algebra): A = P diag(A_kk) P^H
+template <int M>
+__device__ __forceinline__ void jacobi_eigh_la(c128 (&A)[M][M], c128 (&P)[M][M], int sweeps) {
+#pragma unroll
+  for (int r = 0; r < M; ++r)
+#pragma unroll
+    for (int cc = 0; cc < M; ++cc) P[r][cc] = cmake(r == cc ? 1.0 : 0.0, 0.0);
+#pragma unroll 1
+  for (int sweep = 0; sweep < sweeps; ++sweep) {
+#pragma unroll
+    for (int p = 0; p < M - 1; ++p)
+#pragma unroll
+      for (int qq = p + 1; qq < M; ++qq) {
+        const c128 apq = A[p][qq];
+        const double mag2 = cabs2(apq);
+        const double mag = sqrt(mag2);
+        const bool tiny = mag2 < 1e-300;
+        const double inv = tiny ? 0.0 : 1.0 / mag;
+        const c128 u = tiny ? cmake(1.0, 0.0) : cmake(apq.x * inv, apq.y * inv);
+        const double app = A[p][p].x, aqq = A[qq][qq].x;
+        const double tau = tiny ? 0.0 : (aqq - app) * 0.5 * inv;
+        const double t = tiny ? 0.0 : ((tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau)));
+        const double cs = 1.0 / sqrt(1.0 + t * t);
+        const double sn = t * cs;
+        const c128 su = cmake(sn * u.x, sn * u.y);
+        const c128 sub = cmake(sn * u.x, -sn * u.y);
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+          if (k != p && k != qq) {
+            const c128 akp = A[k][p], akq = A[k][qq];
+            c128 nkp = cmake(cs * akp.x, cs * akp.y);
+            cfms(nkp, sub, akq);
+            c128 nkq = cmake(cs * akq.x, cs * akq.y);
+            cfma(nkq, su, akp);
+            A[k][p] = nkp;
+            A[p][k] = cconj(nkp);
+            A[k][qq] = nkq;
+            A[qq][k] = cconj(nkq);
+          }
+        }
+        A[p][p] = cmake(app - t * mag, 0.0);
+        A[qq][qq] = cmake(aqq + t * mag, 0.0);
+        A[p][qq] = cmake(0.0, 0.0);
+        A[qq][p] = cmake(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+          const c128 vkp = P[k][p], vkq = P[k][qq];
+          c128 nkp = cmake(cs * vkp.x, cs * vkp.y);
+          cfms(nkp, sub, vkq);
+          c128 nkq = cmake(cs * vkq.x, cs * vkq.y);
+          cfma(nkq, su, vkp);
+          P[k][p] = nkp;
+          P[k][qq] = nkq;
+        }
+      }
+  }
+}
+
+template <int M>
+__device__ __forceinline__ void hermitize(c128 (&A)[M][M]) {
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+    A[r][r] = cmake(A[r][r].x, 0.0);
+#pragma unroll
+    for (int cc = r + 1; cc < M; ++cc) {
+      const c128 h = cmake(0.5 * (A[r][cc].x + A[cc][r].x), 0.5 * (A[r][cc].y - A[cc][r].y));
+      A[r][cc] = h;
+      A[cc][r] = cconj(h);
+    }
+  }
+}
+
+// X = A^-1 B, B (N x nrhs)
+template <int N>
+__global__ __launch_bounds__(64) void k_solve(const c128 *__restrict__ A, const c128 *__restrict__ Bm,
+                                              c128 *X, long long n, int nrhs, int *info) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  Mat<N> Am, Inv;
+  load_mat<N>(Am, A + idx * (N * N));
+  const bool ok = invert<N>(Am, Inv);
+  for (int c = 0; c < nrhs; ++c) {
+    c128 col[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) col[r] = Bm[(idx * N + r) * nrhs + c];
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      c128 acc = cmake(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < N; ++k) cfma(acc, Inv.a[r][k], col[k]);
+      X[(idx * N + r) * nrhs + c] = acc;
+    }
+  }
+  if (!ok && info) atomicAdd(info, 1);
+}
+
+// closed-form 2x2 inverse (no pivoting), ref: ssspy/linalg/inv.py:4-54
+__global__ __launch_bounds__(256) void k_inv2(const c128 *__restrict__ A, c128 *out, long long n) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const c128 a = A[idx * 4], b = A[idx * 4 + 1], c = A[idx * 4 + 2], d = A[idx * 4 + 3];
+  const c128 det = csub(cmul(a, d), cmul(b, c));
+  out[idx * 4] = cdiv(d, det);
+  out[idx * 4 + 1] = cdiv(cmake(-b.x, -b.y), det);
+  out[idx * 4 + 2] = cdiv(cmake(-c.x, -c.y), det);
+  out[idx * 4 + 3] = cdiv(a, det);
+}
+
+// Hermitian eigen-decomposition, eigenvalues ascending (as numpy.linalg.eigh), unit eigenvectors.
+// mode 0: write lamb (n, M) and V (n, M, M);  mode 1 (to_psd): floor eigenvalues, rebuild into V.
+template <int M>
+__global__ __launch_bounds__(64) void k_eigh(const c128 *__restrict__ A, double *lamb, c128 *V,
+                                             long long n, int mode, int floor_kind, double eps) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  c128 Am[M][M], P[M][M];
+#pragma unroll
+  for (int r = 0; r < M; ++r)
+#pragma unroll
+    for (int c = 0; c < M; ++c) Am[r][c] = A[(idx * M + r) * M + c];
+  hermitize<M>(Am);
+  jacobi_eigh_la<M>(Am, P, M <= 2 ? 2 : 12);
+  if (mode == 0) {
+    // rank of every eigenvalue (ties broken by index) -> ascending order without dynamic indexing
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      int rank = 0;
+#pragma unroll
+      for (int j = 0; j < M; ++j)
+        rank += (Am[j][j].x < Am[k][k].x || (Am[j][j].x == Am[k][k].x && j < k)) ? 1 : 0;
+      lamb[idx * M + rank] = Am[k][k].x;
+#pragma unroll
+      for (int r = 0; r < M; ++r) V[(idx * M + r) * M + rank] = P[r][k];
+    }
+  } else {
+    c128 R[M][M];
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+      for (int c = 0; c < M; ++c) {
+        c128 acc = cmake(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+          const double ev = apply_floor(Am[k][k].x, floor_kind, eps);
+          const c128 z = cmulc(P[r][k], P[c][k]);
+          acc.x = fma(ev, z.x, acc.x);
+          acc.y = fma(ev, z.y, acc.y);
+        }
+        R[r][c] = acc;
+      }
+    hermitize<M>(R);
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+      for (int c = 0; c < M; ++c) V[(idx * M + r) * M + c] = R[r][c];
+  }
+}
+
+// generalised 2x2 Hermitian eigenproblem via Cholesky of B (ref: ssspy/linalg/eigh.py:164-207)
+//   type 1: A z = lamb B z   (C = L^-1 A L^-H, z = L^-H y)
+//   type 2: A B z = lamb z   (C = L^H A L,    z = L^-H y)
+//   type 3: B A z = lamb z   (C = L^H A L,    z = L y)
+__global__ __launch_bounds__(256) void k_eigh2(const c128 *__restrict__ A, const c128 *__restrict__ Bm,
+                                               double *lamb, c128 *Z, long long n, int type,
+                                               int *info) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const c128 a00 = A[idx * 4], a01 = A[idx * 4 + 1], a10 = A[idx * 4 + 2], a11 = A[idx * 4 + 3];
+  const double b00 = Bm[idx * 4].x, b11 = Bm[idx * 4 + 3].x;
+  const c128 b10 = Bm[idx * 4 + 2];
+  // Cholesky B = L L^H (numpy uses the lower triangle)
+  const double l00 = sqrt(b00);
+  const c128 l10 = cmake(b10.x / l00, b10.y / l00);
+  const double d = b11 - cabs2(l10);
+  const double l11 = sqrt(d);
+  if (!(b00 > 0.0) || !(d > 0.0)) {
+    if (info) atomicAdd(info, 1);
+  }
+  c128 Cm[2][2], P[2][2];
+  if (type == 1) {
+    // Li = L^-1 = [[1/l00, 0], [-l10/(l00 l11), 1/l11]]
+    const double i00 = 1.0 / l00, i11 = 1.0 / l11;
+    const c128 i10 = cmake(-l10.x * i00 * i11, -l10.y * i00 * i11);
+    // M1 = Li A
+    const c128 m00 = cscale(a00, i00), m01 = cscale(a01, i00);
+    const c128 m10 = cadd(cmul(i10, a00), cscale(a10, i11));
+    const c128 m11 = cadd(cmul(i10, a01), cscale(a11, i11));
+    // C = M1 Li^H, Li^H = [[i00, conj(i10)], [0, i11]]
+    Cm[0][0] = cscale(m00, i00);
+    Cm[0][1] = cadd(cmulc(m00, i10), cscale(m01, i11));
+    Cm[1][0] = cscale(m10, i00);
+    Cm[1][1] = cadd(cmulc(m10, i10), cscale(m11, i11));
+  } else {
+    // C = L^H A L, L = [[l00, 0], [l10, l11]], L^H = [[l00, conj(l10)], [0, l11]]
+    const c128 m00 = cadd(cscale(a00, l00), cmulc(a10, l10));   // (L^H A) row 0: l00 a0* + conj(l10) a1*
+    const c128 m01 = cadd(cscale(a01, l00), cmulc(a11, l10));
+    const c128 m10 = cscale(a10, l11), m11 = cscale(a11, l11);
+    Cm[0][0] = cadd(cscale(m00, l00), cmul(m01, l10));
+    Cm[0][1] = cscale(m01, l11);
+    Cm[1][0] = cadd(cscale(m10, l00), cmul(m11, l10));
+    Cm[1][1] = cscale(m11, l11);
+  }
+  hermitize<2>(Cm);
+  jacobi_eigh_la<2>(Cm, P, 2);
+  const bool swap = Cm[1][1].x < Cm[0][0].x;
+  const int k0 = swap ? 1 : 0, k1 = swap ? 0 : 1;
+  lamb[idx * 2] = swap ? Cm[1][1].x : Cm[0][0].x;
+  lamb[idx * 2 + 1] = swap ? Cm[0][0].x : Cm[1][1].x;
+  c128 y0[2] = {swap ? P[0][1] : P[0][0], swap ? P[1][1] : P[1][0]};
+  c128 y1[2] = {swap ? P[0][0] : P[0][1], swap ? P[1][0] : P[1][1]};
+  (void)k0;
+  (void)k1;
+  c128 z0[2], z1[2];
+  if (type == 3) {
+    // z = L y
+    z0[0] = cscale(y0[0], l00);
+    z0[1] = cadd(cmul(l10, y0[0]), cscale(y0[1], l11));
+    z1[0] = cscale(y1[0], l00);
+    z1[1] = cadd(cmul(l10, y1[0]), cscale(y1[1], l11));
+  } else {
+    // z = L^-H y, L^-H = [[1/l00, -conj(l10)/(l00 l11)], [0, 1/l11]]
+    const double i00 = 1.0 / l00, i11 = 1.0 / l11;
+    const c128 i01 = cmake(-l10.x * i00 * i11, l10.y * i00 * i11);
+    z0[0] = cadd(cscale(y0[0], i00), cmul(i01, y0[1]));
+    z0[1] = cscale(y0[1], i11);
+    z1[0] = cadd(cscale(y1[0], i00), cmul(i01, y1[1]));
+    z1[1] = cscale(y1[1], i11);
+  }
+  Z[idx * 4] = z0[0];
+  Z[idx * 4 + 1] = z1[0];
+  Z[idx * 4 + 2] = z0[1];
+  Z[idx * 4 + 3] = z1[1];
+}
+
+}  // namespace ssspy
+
+using namespace ssspy;
+
+extern "C" {
+
+int ssspy_solve(const void *A, const void *Bm, void *X, long long n, int N, int nrhs, int *info,
+                void *stream) {
+  SSSPY_REQUIRE(A && Bm && X && n > 0 && nrhs > 0, "solve: bad argument");
+  dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  DISPATCH_N(N, hipLaunchKernelGGL((k_solve<NN>), grid, block, 0, as_stream(stream),
+                                   (const c128 *)A, (const c128 *)Bm, (c128 *)X, n, nrhs, info));
+  return check_launch("k_solve");
+}
+
+int ssspy_inv2(const void *A, void *out, long long n, void *stream) {
+  SSSPY_REQUIRE(A && out && n > 0, "inv2: bad argument");
+  hipLaunchKernelGGL(k_inv2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     (const c128 *)A, (c128 *)out, n);
+  return check_launch("k_inv2");
+}
+
+int ssspy_eigh(const void *A, double *lamb, void *V, long long n, int M, void *stream) {
+  SSSPY_REQUIRE(A && lamb && V && n > 0, "eigh: bad argument");
+  dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  DISPATCH_N(M, hipLaunchKernelGGL((k_eigh<NN>), grid, block, 0, as_stream(stream), (const c128 *)A,
+                                   lamb, (c128 *)V, n, 0, 0, 0.0));
+  return check_launch("k_eigh");
+}
+
+int ssspy_to_psd(const void *A, void *out, long long n, int M, int floor_kind, double floor_eps,
+                 void *stream) {
+  SSSPY_REQUIRE(A && out && n > 0, "to_psd: bad argument");
+  dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  DISPATCH_N(M, hipLaunchKernelGGL((k_eigh<NN>), grid, block, 0, as_stream(stream), (const c128 *)A,
+                                   (double *)nullptr, (c128 *)out, n, 1, floor_kind, floor_eps));
+  return check_launch("k_to_psd");
+}
+
+int ssspy_eigh2(const void *A, const void *Bm, double *lamb, void *Z, long long n, int type,
+                int *info, void *stream) {
+  SSSPY_REQUIRE(A && Bm && lamb && Z && n > 0, "eigh2: bad argument");
+  SSSPY_REQUIRE(type >= 1 && type <= 3, "eigh2: type must be 1, 2 or 3");
+  hipLaunchKernelGGL(k_eigh2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     (const c128 *)A, (const c128 *)Bm, lamb, (c128 *)Z, n, type, info);
+  return check_launch("k_eigh2");
+}
+
+}  // extern "C"

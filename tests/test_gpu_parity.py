@@ -374,3 +374,77 @@ def test_wiener_filter_floors_small_eigenvalues():
     m = FastGaussMNMF(n_basis=K, flooring_fn=functools.partial(max_flooring, eps=1e3))
     Y = m(X, n_iter=0, **kw)
     assert rel_err(Y, Yr) < 1e-9
+
+
+# ------------------------------------------------------------------------------- linalg / special
+def test_inv2_against_golden_and_identity():
+    from ssspy_amd.linalg import inv2
+
+    g = load_golden("operators")
+    assert rel_err(inv2(g["inv2_in"]), g["inv2_out"]) < 1e-13
+    X = np.random.default_rng(0).standard_normal((5, 3, 2, 2))
+    out = inv2(X)
+    assert out.dtype == np.float64
+    assert np.allclose(X @ out, np.eye(2), atol=1e-10)
+
+
+@pytest.mark.parametrize("N", [2, 3, 4, 8])
+def test_solve_matches_numpy(N):
+    from ssspy_amd.linalg import solve
+
+    rng = np.random.default_rng(N)
+    A = rng.standard_normal((7, 5, N, N)) + 1j * rng.standard_normal((7, 5, N, N))
+    b = rng.standard_normal((7, 5, N)) + 1j * rng.standard_normal((7, 5, N))
+    Bm = rng.standard_normal((7, 5, N, 3)) + 1j * rng.standard_normal((7, 5, N, 3))
+    assert rel_err(solve(A, b), np.linalg.solve(A, b[..., None])[..., 0]) < 1e-11
+    assert rel_err(solve(A, Bm), np.linalg.solve(A, Bm)) < 1e-11
+    with pytest.raises(np.linalg.LinAlgError):
+        solve(np.zeros((2, N, N), dtype=complex), np.ones((2, N), dtype=complex))
+
+
+@pytest.mark.parametrize("M", [2, 3, 4, 6])
+def test_eigh_properties(M):
+    """The reference's own property checks (tests/package/linalg/test_eigh.py): A z = lamb z,
+    ascending eigenvalues; plus agreement with LAPACK eigenvalues and unitarity."""
+    from ssspy_amd.linalg import eigh
+
+    rng = np.random.default_rng(10 + M)
+    A = rng.standard_normal((4, 9, M, M)) + 1j * rng.standard_normal((4, 9, M, M))
+    A = A @ A.swapaxes(-2, -1).conj() - 0.3 * np.eye(M)
+    lamb, V = eigh(A)
+    assert np.all(np.diff(lamb, axis=-1) >= 0)
+    assert rel_err(lamb, np.linalg.eigvalsh(A)) < 1e-12
+    assert rel_err(A @ V, V * lamb[..., None, :]) < 1e-12
+    assert rel_err(V.swapaxes(-2, -1).conj() @ V, np.broadcast_to(np.eye(M), V.shape)) < 1e-12
+
+
+@pytest.mark.parametrize("type", [1, 2, 3])
+def test_eigh2_generalised(type):
+    from ssspy_amd.linalg import eigh2
+
+    g = load_golden("operators")
+    A, B = g["eigh2_A"], g["eigh2_B"]
+    lamb, z = eigh2(A, B, type=type)
+    zk = z  # columns are eigenvectors
+    if type == 1:
+        assert rel_err(A @ zk, (B @ zk) * lamb[..., None, :]) < 1e-11
+        assert rel_err(lamb, g["eigh2_lamb"]) < 1e-12
+        # same eigenvectors as the reference up to a per-column phase
+        ref = g["eigh2_z"]
+        phase = np.sum(ref.conj() * zk, axis=-2, keepdims=True)
+        assert rel_err(zk * (phase.conj() / np.abs(phase)), ref) < 1e-10
+    elif type == 2:
+        assert rel_err(A @ B @ zk, zk * lamb[..., None, :]) < 1e-11
+    else:
+        assert rel_err(B @ A @ zk, zk * lamb[..., None, :]) < 1e-11
+    assert np.all(lamb[..., 0] <= lamb[..., 1])
+
+
+@pytest.mark.parametrize("N", [2, 3, 4, 8])
+def test_to_psd_against_golden(N):
+    from ssspy_amd.special import to_psd
+
+    g = load_golden("operators")
+    out = to_psd(g["psd_n{}_in".format(N)])
+    assert rel_err(out, g["psd_n{}_out".format(N)]) < 1e-11
+    assert np.all(np.linalg.eigvalsh(out) > 0)
