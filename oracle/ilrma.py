@@ -29,7 +29,8 @@ class GaussILRMAOracle:
         reference_id=0,
         rng=None,
     ):
-        assert spatial_algorithm in ("IP", "IP1", "ISS", "ISS1")
+        assert spatial_algorithm in ("IP", "IP1", "IP2", "ISS", "ISS1", "ISS2")
+        self.pairs = None  # None = the reference's default selector for the algorithm
         self.n_basis = n_basis
         self.spatial_algorithm = spatial_algorithm
         self.domain = domain
@@ -43,7 +44,7 @@ class GaussILRMAOracle:
 
     @property
     def uses_filter(self):
-        return self.spatial_algorithm in ("IP", "IP1")
+        return self.spatial_algorithm in ("IP", "IP1", "IP2")
 
     # -- initialisation ----------------------------------------------------
     def reset(self, X, basis=None, activation=None, demix_filter=None):
@@ -102,7 +103,17 @@ class GaussILRMAOracle:
         """ref: ssspy/bss/ilrma.py:1440-1507 (IP1), :1635-1696 (ISS1)."""
         p = self.domain
         varphi = 1 / ((self.basis @ self.activation) ** (2 / p))
-        if self.uses_filter:
+        N = self.n_sources
+        if self.spatial_algorithm == "IP2":
+            # ref: ssspy/bss/ilrma.py:1509-1633 (default pair_selector: sequential, :796-798)
+            U = sp.weighted_covariance(self.input, varphi)
+            pairs = self.pairs if self.pairs is not None else sp.sequential_pairs(N)
+            self.demix_filter = sp.update_by_ip2(self.demix_filter, U, self.flooring, pairs)
+        elif self.spatial_algorithm == "ISS2":
+            # ref: ssspy/bss/ilrma.py:1698-1792
+            pairs = self.pairs if self.pairs is not None else sp.sequential_pairs(N)
+            self.output = sp.update_by_iss2(self.output, varphi, self.flooring, pairs)
+        elif self.uses_filter:
             U = sp.weighted_covariance(self.input, varphi)
             self.demix_filter = sp.update_by_ip1(self.demix_filter, U, self.flooring)
         else:

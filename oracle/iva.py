@@ -26,8 +26,9 @@ class AuxIVAOracle:
         record_loss=True,
         reference_id=0,
     ):
-        assert spatial_algorithm in ("IP", "IP1", "ISS", "ISS1")
+        assert spatial_algorithm in ("IP", "IP1", "IP2", "ISS", "ISS1", "ISS2")
         assert contrast in ("laplace", "gauss")
+        self.pairs = None
         self.spatial_algorithm = spatial_algorithm
         self.contrast = contrast
         self.flooring = flooring
@@ -38,7 +39,7 @@ class AuxIVAOracle:
 
     @property
     def uses_filter(self):
-        return self.spatial_algorithm in ("IP", "IP1")
+        return self.spatial_algorithm in ("IP", "IP1", "IP2")
 
     def reset(self, X, demix_filter=None):
         """ref: ssspy/bss/iva.py:138-169 (IVABase._reset), :1687-1697, :3304-3317."""
@@ -65,11 +66,11 @@ class AuxIVAOracle:
             return 2 * r
         return self.n_bins * np.log(self.variance) + (r**2) / self.variance
 
-    def d_contrast_fn(self, r):
+    def d_contrast_fn(self, r, variance=None):
         """ref: ssspy/bss/iva.py:3105-3115 (Laplace), :3273-3289 (Gauss)."""
         if self.contrast == "laplace":
             return 2 * np.ones_like(r)
-        return 2 * r / self.variance
+        return 2 * r / (self.variance if variance is None else variance)
 
     def _current_output(self):
         if self.demix_filter is None:
@@ -81,8 +82,30 @@ class AuxIVAOracle:
         Y = self._current_output()
         if self.contrast == "gauss":
             self.variance = np.mean(np.abs(Y) ** 2, axis=1)
+        N = self.n_sources
+        if self.spatial_algorithm == "IP2":
+            # ref: ssspy/bss/iva.py:1795-1915 (AuxIVA), :3339-3463 (AuxGaussIVA): the weights are
+            # recomputed for every pair from the current filters
+            W = self.demix_filter.copy()
+            pairs = self.pairs if self.pairs is not None else sp.sequential_pairs(N)
+            for m, n in pairs:
+                Y_mn = sp.separate(self.input, W[:, (m, n), :])
+                norm = np.linalg.norm(Y_mn, axis=1)
+                if self.contrast == "gauss":
+                    dG = self.d_contrast_fn(norm, variance=self.variance[(m, n), :])
+                else:
+                    dG = self.d_contrast_fn(norm)
+                U_mn = sp.weighted_covariance(self.input, dG / sp.floor(2 * norm, self.flooring))
+                W[:, (m, n), :] = sp.update_by_ip2_one_pair(W, U_mn, (m, n), self.flooring)
+            self.demix_filter = W
+            return
         r = np.linalg.norm(Y, axis=1)  # (N, T)
         weight = self.d_contrast_fn(r) / sp.floor(2 * r, self.flooring)
+        if self.spatial_algorithm == "ISS2":
+            # ref: ssspy/bss/iva.py:1968-2066
+            pairs = self.pairs if self.pairs is not None else sp.sequential_pairs(N)
+            self.output = sp.update_by_iss2(Y, weight[:, None, :], self.flooring, pairs)
+            return
         if self.uses_filter:
             U = sp.weighted_covariance(self.input, weight)
             self.demix_filter = sp.update_by_ip1(self.demix_filter, U, self.flooring)

@@ -139,3 +139,88 @@ def inv2(X):
     det = a * d - b * c
     out = np.stack([np.stack([d, -b], axis=-1), np.stack([-c, a], axis=-1)], axis=-2)
     return out / det[..., None, None]
+
+
+def eigh2(A, B):
+    """Generalised 2x2 Hermitian eigenproblem A z = lamb B z via Cholesky of B.
+
+    ref: ssspy/linalg/eigh.py:84-207 (eigh2 -> _eigh, type=1, inv=inv2).
+    """
+    L = np.linalg.cholesky(B)
+    Li = inv2(L)
+    C = Li @ A @ Li.swapaxes(-2, -1).conj()
+    lamb, y = np.linalg.eigh(C)
+    return lamb, Li.swapaxes(-2, -1).conj() @ y
+
+
+def sequential_pairs(n_sources, stop=None, step=1):
+    """ref: ssspy/utils/select_pair.py:5-44."""
+    stop = n_sources if stop is None else stop
+    return [(m % n_sources, (m + 1) % n_sources) for m in range(0, stop, step)]
+
+
+def update_by_ip2_one_pair(W, U_pair, pair, flooring=DEFAULT_FLOOR):
+    """Pairwise iterative projection for sources (m, n).  ref: _update_spatial_model.py:317-395.
+
+    W (F, N, N), U_pair (F, 2, N, N) -> new rows (F, 2, N).
+    """
+    m, n = pair
+    F, N, M = W.shape
+    U_m, U_n = U_pair[:, 0], U_pair[:, 1]
+    E_mn = np.tile(np.eye(M, N)[:, (m, n)], (F, 1, 1))
+    P_m = solve(W @ U_m, E_mn)
+    P_n = solve(W @ U_n, E_mn)
+    PUP_m = P_m.transpose(0, 2, 1).conj() @ U_m @ P_m
+    PUP_n = P_n.transpose(0, 2, 1).conj() @ U_n @ P_n
+    _, H = eigh2(PUP_m, PUP_n)
+    H = H[..., ::-1]
+    h_m, h_n = H.transpose(2, 0, 1)
+    q = np.maximum(np.einsum("fa,fab,fb->f", h_m.conj(), PUP_m, h_m).real, 0)
+    h_m = h_m / floor(np.sqrt(q), flooring)[:, None]
+    q = np.maximum(np.einsum("fa,fab,fb->f", h_n.conj(), PUP_n, h_n).real, 0)
+    h_n = h_n / floor(np.sqrt(q), flooring)[:, None]
+    w_m = P_m @ h_m[..., None]
+    w_n = P_n @ h_n[..., None]
+    return np.concatenate([w_m, w_n], axis=-1).transpose(0, 2, 1).conj()
+
+
+def update_by_ip2(W, U, flooring=DEFAULT_FLOOR, pairs=None):
+    """ref: ssspy/bss/_update_spatial_model.py:81-143.  pairs: list of (m, n); default sequential."""
+    W = W.copy()
+    N = W.shape[1]
+    if pairs is None:
+        pairs = sequential_pairs(N)
+    for m, n in pairs:
+        W[:, (m, n), :] = update_by_ip2_one_pair(W, U[:, (m, n)], (m, n), flooring)
+    return W
+
+
+def update_by_iss2(Y, varphi, flooring=DEFAULT_FLOOR, pairs=None):
+    """Pairwise iterative source steering.  ref: ssspy/bss/_update_spatial_model.py:197-314."""
+    N = Y.shape[0]
+    if pairs is None:
+        pairs = sequential_pairs(N, stop=N, step=2)
+    for m, n in pairs:
+        m, n = m % N, n % N
+        sub = [s for s in range(N) if s not in (m, n)]
+        Y_main = Y[[m, n]]  # the pair in the order given (the reference's ascend / descend branches)
+        v_main = varphi[[m, n]]
+        YY_main = (Y_main[:, None] * Y_main[None].conj()).transpose(2, 0, 1, 3)  # (F, 2, 2, T)
+        Ym = Y_main.transpose(1, 0, 2)  # (F, 2, T)
+        Y_new = Y.copy()
+        if sub:
+            Y_sub = Y[sub]
+            v_sub = varphi[sub]
+            YY_sub = (Y_main[:, None] * Y_sub[None].conj()).transpose(1, 2, 0, 3)  # (S, F, 2, T)
+            G_sub = np.mean(v_sub[:, :, None, None, :] * YY_main[None], axis=-1)
+            Fv = np.mean(v_sub[:, :, None, :] * YY_sub, axis=-1)
+            Q = (-inv2(G_sub) @ Fv[..., None])[..., 0].transpose(1, 0, 2)  # (F, S, 2)
+            Y_new[sub] = Y_sub + (Q.conj() @ Ym).transpose(1, 0, 2)
+        G_main = np.mean(v_main[:, :, None, None, :] * YY_main[None], axis=-1)  # (2, F, 2, 2)
+        _, H = eigh2(G_main[0], G_main[1])
+        h = H.transpose(2, 0, 1)  # (2, F, 2)
+        q = np.einsum("kfa,kfab,kfb->kf", h.conj(), G_main, h).real
+        P = h / floor(np.sqrt(np.maximum(q, 0)), flooring)[..., None]
+        Y_new[[m, n]] = (P.transpose(1, 0, 2).conj() @ Ym).transpose(1, 0, 2)
+        Y = Y_new
+    return Y

@@ -27,6 +27,18 @@ def rel_err(a, b):
     return np.linalg.norm((a - b).ravel()) / (denom if denom > 0 else 1.0)
 
 
+def rel_err_up_to_phase(a, b, name):
+    """Relative error after removing a unit-modulus factor per (bin, source): the pairwise updates
+    (IP2 / ISS2) inherit the arbitrary phase of 2x2 eigenvectors until scale restoration
+    ("eigenvector phase ambiguity").  `name` is "demix_filter" (.., F, N, N:
+    one phase per row) or "output" (.., N, F, T: one phase per source and bin)."""
+    a, b = np.asarray(a), np.asarray(b)
+    inner = np.sum(a * b.conj(), axis=-1, keepdims=True)
+    mag = np.abs(inner)
+    phase = np.where(mag > 0, inner / np.where(mag > 0, mag, 1), 1)
+    return rel_err(a * phase.conj(), b)
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden

@@ -217,6 +217,16 @@ def main():
     run_ilrma("gilrma_iss1_n2", N=2, F=17, T=32, K=2, algo="ISS", seed=0)          # KAT-2
     run_ilrma("gilrma_iss1_n4", N=4, F=33, T=48, K=5, algo="ISS1", seed=20, gen=gen_mixture)
     run_ilrma("gilrma_iss1_n3_p1", N=3, F=18, T=40, K=4, algo="ISS", seed=31, domain=1)
+    # --- pairwise updates (IP2 / ISS2); eigenvector phases make pre-projection-back filters and
+    #     spectrograms comparable only up to a per-source phase
+    run_ilrma("gilrma_ip2_n3", N=3, F=18, T=40, K=4, algo="IP2", seed=60, gen=gen_mixture)
+    run_ilrma("gilrma_ip2_n2", N=2, F=17, T=32, K=2, algo="IP2", seed=61)
+    run_ilrma("gilrma_iss2_n4", N=4, F=18, T=40, K=4, algo="ISS2", seed=62, gen=gen_mixture)
+    run_ilrma("gilrma_iss2_n3", N=3, F=17, T=36, K=3, algo="ISS2", seed=63)
+    run_iva("auxlap_ip2_n3", N=3, F=20, T=44, algo="IP2", contrast="laplace", seed=64, gen=gen_mixture)
+    run_iva("auxlap_iss2_n4", N=4, F=20, T=44, algo="ISS2", contrast="laplace", seed=65, gen=gen_mixture)
+    run_iva("auxgauss_ip2_n2", N=2, F=24, T=40, algo="IP2", contrast="gauss", seed=66)
+    run_iva("auxgauss_iss2_n3", N=3, F=20, T=44, algo="ISS2", contrast="gauss", seed=67, gen=gen_mixture)
     # --- AuxIVA ---
     run_iva("auxlap_ip1_n2", N=2, F=33, T=40, algo="IP", contrast="laplace", seed=0)
     run_iva("auxlap_ip1_n4", N=4, F=20, T=50, algo="IP1", contrast="laplace", seed=1, gen=gen_mixture)
