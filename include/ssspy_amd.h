@@ -51,10 +51,15 @@ enum {
 };
 
 /* contrast functions of AuxIVA (reference: iva.py:3093-3115, :3256-3289) */
-enum { SSSPY_CONTRAST_LAPLACE = 0, SSSPY_CONTRAST_GAUSS = 1 };
+enum {
+  SSSPY_CONTRAST_LAPLACE = 0,
+  SSSPY_CONTRAST_GAUSS = 1,       /* refreshes variance = r2 / F, then G' = 2r / variance  */
+  SSSPY_CONTRAST_GAUSS_FIXED = 2, /* uses the given variance unchanged (AuxGaussIVA IP2)   */
+};
 
 #define SSSPY_MAX_SOURCES 8
 #define SSSPY_MAX_BASIS 64
+#define SSSPY_MAX_PAIRS 32
 
 const char *ssspy_amd_version(void);
 const char *ssspy_last_error(void);
@@ -93,6 +98,21 @@ int ssspy_update_by_ip1(void *W, const void *U, int B, int F, int N, int floor_k
  * replaces: ssspy/bss/_update_spatial_model.py:146-194 (update_by_iss1). */
 int ssspy_iss1_transform(const void *Vc, void *G, int B, int F, int N, int floor_kind,
                          double floor_eps, void *stream);
+
+/* Pairwise iterative projection, in place on W (B,F,N,N).  `pairs` is a HOST array of 2*n_pairs
+ * ints (m0,n0,m1,n1,...), walked in order inside the kernel.  pair_only == 0: U (B,F,N,N,N) holds
+ * one covariance per source; pair_only != 0: U (B,F,2,N,N) holds the pair's own two covariances and
+ * n_pairs must be 1 (the AuxIVA form, where the weights are recomputed for every pair).  Rows come out with the arbitrary
+ * phase of the 2x2 eigenvectors (fixed by scale restoration).
+ * replaces: ssspy/bss/_update_spatial_model.py:81-143 (update_by_ip2), :317-395 (one pair). */
+int ssspy_update_by_ip2(void *W, const void *U, int pair_only, const int *pairs, int n_pairs, int B,
+                        int F, int N, int floor_kind, double floor_eps, int *info, void *stream);
+
+/* Pairwise iterative source steering on per-bin statistics Vc (B,F,N,N,N) (as ssspy_iss1_transform):
+ * returns G (B,F,N,N) with Y_new[:,i,:] = G_i Y[:,i,:].
+ * replaces: ssspy/bss/_update_spatial_model.py:197-314 (update_by_iss2). */
+int ssspy_iss2_transform(const void *Vc, void *G, const int *pairs, int n_pairs, int B, int F,
+                         int N, int floor_kind, double floor_eps, int *info, void *stream);
 
 /* Largest n_frames the fused ISS kernel holds in registers for N sources (0 if N unsupported). */
 int ssspy_iss1_fused_max_frames(int N);
@@ -254,6 +274,13 @@ int ssspy_fastmnmf_update(const void *X, const void *C, void *Q, double *D, doub
                           double *activation, int B, int N, int M, int F, int T, int K, int steps,
                           int floor_kind, double floor_eps, void *workspace, size_t workspace_bytes,
                           int *info, void *stream);
+
+/* U[b,i,m] = (1/T) sum_j x x^H / R~_ijm  -> (B,F,M,M,M): the covariances the diagonaliser update
+ * (IP1 inside ssspy_fastmnmf_update, or ssspy_update_by_ip2 for diagonalizer_algorithm="IP2") needs.
+ * replaces: ssspy/bss/mnmf.py:1504-1512, :1621-1629. */
+int ssspy_fastmnmf_diagonalizer_covariance(const void *X, const double *D, const double *basis,
+                                           const double *activation, void *U, int B, int N, int M,
+                                           int F, int T, int K, void *stream);
 
 /* out[b] = sum_i mean_j sum_m ( |q x|^2 / R~ + log R~ ) (zeroed by the call); caller adds
  * -2 sum logdet Q.   replaces: ssspy/bss/mnmf.py:1240-1258. */

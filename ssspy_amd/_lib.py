@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_PKG, "lib", "libssspy_amd.so")
 OK, ERR_BADARG, ERR_HIP, ERR_UNSUPPORTED = 0, 1, 2, 3
 FLOOR_NONE, FLOOR_MAX, FLOOR_ADD = 0, 1, 2
 WEIGHT_UNIT, WEIGHT_FRAME, WEIGHT_BIN_FRAME = 0, 1, 2
-CONTRAST_LAPLACE, CONTRAST_GAUSS = 0, 1
+CONTRAST_LAPLACE, CONTRAST_GAUSS, CONTRAST_GAUSS_FIXED = 0, 1, 2
+MAX_PAIRS = 32
 MAX_SOURCES, MAX_BASIS = 8, 64
 
 _p, _i, _d, _z = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
@@ -30,6 +31,8 @@ PROTOTYPES = {
     "ssspy_cross_covariance": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "ssspy_update_by_ip1": (_i, [_p, _p, _i, _i, _i, _i, _d, _p, _p]),
     "ssspy_iss1_transform": (_i, [_p, _p, _i, _i, _i, _i, _d, _p]),
+    "ssspy_update_by_ip2": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
+    "ssspy_iss2_transform": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
     "ssspy_iss1_fused_max_frames": (_i, [_i]),
     "ssspy_iss1_fused": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p]),
     "ssspy_projection_back_filter": (_i, [_p, _i, _i, _i, _i, _p, _p]),
@@ -57,6 +60,7 @@ PROTOTYPES = {
     "ssspy_fastmnmf_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "ssspy_fastmnmf_update": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p,
                                    _z, _p, _p]),
+    "ssspy_fastmnmf_diagonalizer_covariance": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ssspy_fastmnmf_loss_data": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ssspy_fastmnmf_separate": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p,
                                      _z, _p, _p]),

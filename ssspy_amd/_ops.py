@@ -65,6 +65,39 @@ def iss1_transform(Vc, flooring, out=None):
     return out
 
 
+def _pair_array(pairs):
+    import ctypes
+
+    flat = [int(v) for pair in pairs for v in pair]
+    return (ctypes.c_int * len(flat))(*flat), len(flat) // 2
+
+
+def update_by_ip2(W, U, pairs, flooring, info=None, pair_only=False):
+    """Pairwise iterative projection in place on W; U (B,F,N,N,N), or with pair_only the pair's own
+    two covariances (B,F,2,N,N)."""
+    B, F, N, _ = W.shape
+    arr, n_pairs = _pair_array(pairs)
+    _lib.check(
+        _L().ssspy_update_by_ip2(ptr(W), ptr(U), int(bool(pair_only)), arr, n_pairs, B, F, N,
+                                 flooring[0], flooring[1], ptr(info), _st()),
+        "update_by_ip2",
+    )
+    return W
+
+
+def iss2_transform(Vc, pairs, flooring, info=None, out=None):
+    B, F, N = Vc.shape[0], Vc.shape[1], Vc.shape[-1]
+    if out is None:
+        out = dv.empty((B, F, N, N), dv.c128, Vc.device)
+    arr, n_pairs = _pair_array(pairs)
+    _lib.check(
+        _L().ssspy_iss2_transform(ptr(Vc), ptr(out), arr, n_pairs, B, F, N, flooring[0],
+                                  flooring[1], ptr(info), _st()),
+        "iss2_transform",
+    )
+    return out
+
+
 def iss1_fused_max_frames(n_sources):
     return int(_L().ssspy_iss1_fused_max_frames(n_sources))
 
@@ -267,6 +300,19 @@ def fastmnmf_update(X, C, Q, D, basis, activation, steps, flooring, ws, ws_bytes
                                    ws_bytes, ptr(info), _st()),
         "fastmnmf_update",
     )
+
+
+def fastmnmf_diagonalizer_covariance(X, D, basis, activation, out=None):
+    B, M, F, T = X.shape
+    N, K = basis.shape[1], basis.shape[-1]
+    if out is None:
+        out = dv.empty((B, F, M, M, M), dv.c128, X.device)
+    _lib.check(
+        _L().ssspy_fastmnmf_diagonalizer_covariance(ptr(X), ptr(D), ptr(basis), ptr(activation),
+                                                    ptr(out), B, N, M, F, T, K, _st()),
+        "fastmnmf_diagonalizer_covariance",
+    )
+    return out
 
 
 def fastmnmf_loss_data(X, Q, D, basis, activation, out=None):

@@ -13,6 +13,7 @@ from .. import _device as dv
 from .. import _lib, _ops
 from ..special.flooring import max_flooring
 from ..utils.flooring import device_flooring
+from ..utils.select_pair import resolve_pairs, sequential_pair_selector
 
 EPS = 1e-10
 _DEFAULT_FLOOR = functools.partial(max_flooring, eps=EPS)
@@ -84,3 +85,59 @@ def update_by_iss1(
         G = _ops.iss1_transform(Vc, floor)
         out = dv.to_host(_ops.separate(Y, G))
     return out if batched else out[0]
+
+
+def update_by_ip2(
+    demix_filter: np.ndarray,
+    weighted_covariance: np.ndarray,
+    flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = _DEFAULT_FLOOR,
+    pair_selector=None,
+    overwrite: bool = True,
+) -> np.ndarray:
+    """Update demixing filters by pairwise iterative projection (ref: :81-143).
+
+    The two rows of a pair come out with the arbitrary phase of a 2 x 2 eigenvector (as in the
+    reference, where it is LAPACK's); scale restoration removes it.
+    """
+    floor = device_flooring(flooring_fn)
+    N = demix_filter.shape[-2]
+    W = dv.to_device(demix_filter[None], dtype=np.complex128)
+    U = dv.to_device(weighted_covariance[None], dtype=np.complex128)
+    info = dv.zeros((1,), dv.i32)
+    _ops.update_by_ip2(W, U, resolve_pairs(pair_selector, N), floor, info)
+    _lib.raise_if_singular(int(info.item()), "update_by_ip2")
+    out = dv.to_host(W)[0]
+    if overwrite:
+        demix_filter[...] = out
+        return demix_filter
+    return out
+
+
+def update_by_iss2(
+    separated: np.ndarray,
+    weight: np.ndarray,
+    flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = _DEFAULT_FLOOR,
+    pair_selector=None,
+) -> np.ndarray:
+    """Update separated spectrograms by pairwise iterative source steering (ref: :197-314).
+
+    Default pairs: (0,1), (2,3), ... as in the reference (sequential selector with step 2).
+    """
+    floor = device_flooring(flooring_fn)
+    Y = dv.to_device(separated[None], dtype=np.complex128)
+    B, N, F, T = Y.shape
+    if pair_selector is None:
+        pair_selector = functools.partial(sequential_pair_selector, stop=N, step=2)
+    wt = weight[None]
+    if wt.shape[2] == 1 and F != 1:
+        w = dv.to_device(wt[:, :, 0, :], dtype=np.float64)
+        kind = _lib.WEIGHT_FRAME
+    else:
+        w = dv.to_device(np.broadcast_to(wt, (B, N, F, T)), dtype=np.float64)
+        kind = _lib.WEIGHT_BIN_FRAME
+    info = dv.zeros((1,), dv.i32)
+    Vc = _ops.weighted_covariance(Y, w, kind, N)
+    G = _ops.iss2_transform(Vc, resolve_pairs(pair_selector, N), floor, info)
+    out = dv.to_host(_ops.separate(Y, G))[0]
+    _lib.raise_if_singular(int(info.item()), "update_by_iss2")
+    return out

@@ -22,7 +22,7 @@ from .. import _device as dv
 from .. import _lib, _ops
 from ..special.flooring import identity, max_flooring
 from ..utils.flooring import choose_flooring_fn, device_flooring
-from ..utils.select_pair import sequential_pair_selector
+from ..utils.select_pair import resolve_pairs, sequential_pair_selector
 from ._device_state import DeviceStateMixin, Synced
 from .base import IterativeMethodBase
 
@@ -34,6 +34,8 @@ EPS = 1e-10
 
 _IP1 = ("IP", "IP1")
 _ISS1 = ("ISS", "ISS1")
+_IP2 = ("IP2",)
+_ISS2 = ("ISS2",)
 _PROJECTION_BACK = ("projection_back",)
 _MDP = ("minimal_distortion_principle",)
 
@@ -226,10 +228,10 @@ class GaussILRMA(ILRMABase):
         assert 0 < domain <= 2, "domain parameter should be chosen from [0, 2]."
         if source_algorithm == "ME":
             assert domain == 2, "domain parameter should be 2 when you specify ME algorithm."
-        if spatial_algorithm not in _IP1 + _ISS1:
+        if spatial_algorithm not in _IP1 + _ISS1 + _IP2 + _ISS2:
             raise NotImplementedError(
                 "spatial_algorithm={!r} is not built for the device path yet "
-                "(available: IP, IP1, ISS, ISS1).".format(spatial_algorithm)
+                "(available: IP, IP1, IP2, ISS, ISS1, ISS2).".format(spatial_algorithm)
             )
         if source_algorithm != "MM":
             raise NotImplementedError("source_algorithm='ME' is not built for the device path yet.")
@@ -308,7 +310,8 @@ class GaussILRMA(ILRMABase):
         ref: ssspy/bss/ilrma.py:900-922.  With the stock methods and the IP1 path the whole
         iteration is one C-ABI call (five kernel launches on the current stream).
         """
-        if self._uses_filter() and self._is_stock() and self._power_normalization_or_off():
+        if (self.spatial_algorithm in _IP1 and self._uses_filter() and self._is_stock()
+                and self._power_normalization_or_off()):
             floor = self._resolve_floor(flooring_fn)
             B, N, F, T = self._X.shape
             if self._U is None:
@@ -370,8 +373,37 @@ class GaussILRMA(ILRMABase):
             self.update_spatial_model_ip1(flooring_fn=flooring_fn)
         elif self.spatial_algorithm in _ISS1:
             self.update_spatial_model_iss1(flooring_fn=flooring_fn)
+        elif self.spatial_algorithm in _IP2:
+            self.update_spatial_model_ip2(flooring_fn=flooring_fn)
+        elif self.spatial_algorithm in _ISS2:
+            self.update_spatial_model_iss2(flooring_fn=flooring_fn)
         else:
             raise NotImplementedError("Not support {}.".format(self.spatial_algorithm))
+
+    def update_spatial_model_ip2(self, flooring_fn="self") -> None:
+        """Weighted covariance + pairwise iterative projection.  ref: ssspy/bss/ilrma.py:1509-1633."""
+        B, N, F, T = self._X.shape
+        if self._U is None:
+            self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
+        _ops.ilrma_weighted_covariance(self._X, self._state_dev("basis"),
+                                       self._state_dev("activation"), float(self.domain),
+                                       self._ws, self._ws_bytes, out=self._U)
+        _ops.update_by_ip2(self._state_dev("demix_filter"), self._U,
+                           resolve_pairs(getattr(self, "pair_selector", None), N),
+                           self._resolve_floor(flooring_fn), self._info_tensor())
+        self._state_touch("demix_filter")
+
+    def update_spatial_model_iss2(self, flooring_fn="self") -> None:
+        """Pairwise iterative source steering on per-bin statistics.  ref: ilrma.py:1698-1792."""
+        Y = self._state_dev("output")
+        N = Y.shape[1]
+        varphi = _ops.ilrma_iss_weight(self._state_dev("basis"), self._state_dev("activation"),
+                                       float(self.domain))
+        Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
+        G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N),
+                                self._resolve_floor(flooring_fn), self._info_tensor())
+        _ops.separate(Y, G, out=Y)
+        self._state_touch("output")
 
     def update_spatial_model_ip1(self, flooring_fn="self") -> None:
         """Weighted covariance + iterative projection.  ref: ssspy/bss/ilrma.py:1440-1507."""

@@ -19,7 +19,7 @@ from .. import _device as dv
 from .. import _lib, _ops
 from ..special.flooring import identity, max_flooring
 from ..utils.flooring import choose_flooring_fn, device_flooring
-from ..utils.select_pair import sequential_pair_selector
+from ..utils.select_pair import resolve_pairs, sequential_pair_selector
 from ._device_state import DeviceStateMixin, Synced
 from .base import IterativeMethodBase
 
@@ -30,6 +30,8 @@ EPS = 1e-10
 
 _IP1 = ("IP", "IP1")
 _ISS1 = ("ISS", "ISS1")
+_IP2 = ("IP2",)
+_ISS2 = ("ISS2",)
 _PROJECTION_BACK = ("projection_back",)
 _MDP = ("minimal_distortion_principle",)
 
@@ -203,10 +205,10 @@ class AuxIVA(AuxIVABase):
             reference_id=reference_id,
         )
         assert spatial_algorithm in spatial_algorithms, "Not support {}.".format(spatial_algorithm)
-        if spatial_algorithm not in _IP1 + _ISS1:
+        if spatial_algorithm not in _IP1 + _ISS1 + _IP2 + _ISS2:
             raise NotImplementedError(
                 "spatial_algorithm={!r} is not built for the device path yet "
-                "(available: IP, IP1, ISS, ISS1).".format(spatial_algorithm)
+                "(available: IP, IP1, IP2, ISS, ISS1, ISS2).".format(spatial_algorithm)
             )
         self.spatial_algorithm = spatial_algorithm
         if pair_selector is None:
@@ -270,8 +272,44 @@ class AuxIVA(AuxIVABase):
             self.update_once_ip1(flooring_fn=flooring_fn)
         elif self.spatial_algorithm in _ISS1:
             self.update_once_iss1(flooring_fn=flooring_fn)
+        elif self.spatial_algorithm in _IP2:
+            self.update_once_ip2(flooring_fn=flooring_fn)
+        elif self.spatial_algorithm in _ISS2:
+            self.update_once_iss2(flooring_fn=flooring_fn)
         else:
             raise NotImplementedError("Not support {}.".format(self.spatial_algorithm))
+
+    def _pair_weight_contrast(self):
+        """Contrast code for the per-pair weights of IP2 (the Gauss model keeps its variance)."""
+        return self._contrast
+
+    def update_once_ip2(self, flooring_fn="self") -> None:
+        """Pairwise iterative projection; the auxiliary weights are recomputed for every pair from
+        the current filters.  ref: ssspy/bss/iva.py:1795-1915."""
+        N = self.n_sources
+        floor = self._resolve_floor(flooring_fn)
+        W = self._state_dev("demix_filter")
+        for m, n in resolve_pairs(getattr(self, "pair_selector", None), N):
+            r2 = _ops.iva_frame_power(self._X, W)
+            weight = _ops.iva_weight(r2, self.n_bins, self._pair_weight_contrast(), floor,
+                                     variance=self._variance_tensor())
+            w_pair = weight[:, [m, n], :].contiguous()  # gather of two rows (data movement only)
+            U_pair = _ops.weighted_covariance(self._X, w_pair, _lib.WEIGHT_FRAME, 2)
+            _ops.update_by_ip2(W, U_pair, [(m, n)], floor, self._info_tensor(), pair_only=True)
+        self._state_touch("demix_filter")
+
+    def update_once_iss2(self, flooring_fn="self") -> None:
+        """Pairwise iterative source steering.  ref: ssspy/bss/iva.py:1968-2066."""
+        N = self.n_sources
+        Y = self._state_dev("output")
+        weight = self._weights(flooring_fn)
+        floor = self._resolve_floor(flooring_fn)
+        Vc = _ops.weighted_covariance(Y, weight, _lib.WEIGHT_FRAME, N)
+        G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N), floor,
+                                self._info_tensor())
+        _ops.separate(Y, G, out=Y)
+        self._r2_cache = None
+        self._state_touch("output")
 
     def update_once_ip1(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/iva.py:1736-1793."""
@@ -422,5 +460,14 @@ class AuxGaussIVA(AuxIVA):
 
     def update_source_model(self) -> None:
         """alpha_nj = mean_i |y_nij|^2 (ref: ssspy/bss/iva.py:3465-3473)."""
-        self._weights("self")
+        _ops.iva_weight(self._frame_power(), self.n_bins, _lib.CONTRAST_GAUSS, self._floor,
+                        variance=self._variance_tensor())
         self._state_touch("variance")
+
+    def _pair_weight_contrast(self):
+        return _lib.CONTRAST_GAUSS_FIXED
+
+    def update_once_ip2(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/iva.py:3319-3337 (variance refresh) + :3339-3463 (pairs, fixed variance)."""
+        self.update_source_model()
+        super().update_once_ip2(flooring_fn=flooring_fn)

@@ -5,8 +5,9 @@ Drop-in separator for the reference's ``ssspy.bss.mnmf.FastGaussMNMF``
 diagonalisable full-rank spatial model with per-bin diagonaliser ``Q`` (n_bins, n_channels,
 n_channels), diagonal spatial ``D`` (n_bins, n_sources, n_channels), NMF ``basis`` /
 ``activation``; ``update_once`` = basis, activation, diagonaliser (IP1), spatial, power
-normalisation; output by the multichannel Wiener filter.  ``diagonalizer_algorithm="IP2"``,
-``partitioning`` and the full-rank ``GaussMNMF`` are not built yet (NotImplementedError).
+normalisation; output by the multichannel Wiener filter.  ``diagonalizer_algorithm`` may be "IP" /
+"IP1" or "IP2" (pairwise).  ``partitioning`` and the full-rank ``GaussMNMF`` are not built yet
+(NotImplementedError).
 
 ``instant_covariance`` (the (n_bins, n_frames, M, M) PSD-projected outer products the reference
 materialises at reset, mnmf.py:167-188) is never read by FastGaussMNMF's updates and is not
@@ -22,7 +23,7 @@ from .. import _device as dv
 from .. import _lib, _ops
 from ..special.flooring import identity, max_flooring
 from ..utils.flooring import choose_flooring_fn, device_flooring
-from ..utils.select_pair import sequential_pair_selector
+from ..utils.select_pair import resolve_pairs, sequential_pair_selector
 from ._device_state import DeviceStateMixin, Synced
 from .base import IterativeMethodBase
 
@@ -206,10 +207,6 @@ class FastGaussMNMF(FastMNMFBase):
             diagonalizer_algorithm
         )
         assert not partitioning, "partitioning function is not supported."
-        if diagonalizer_algorithm == "IP2":
-            raise NotImplementedError(
-                "diagonalizer_algorithm='IP2' is not built for the device path yet."
-            )
         self.diagonalizer_algorithm = diagonalizer_algorithm
         if pair_selector is None:
             if diagonalizer_algorithm == "IP2":
@@ -272,8 +269,9 @@ class FastGaussMNMF(FastMNMFBase):
             for name in ("update_basis", "update_activation", "update_diagonalizer",
                          "update_spatial", "normalize", "normalize_by_power")
         )
-        if stock and (not self.normalization or type(self.normalization) is bool
-                      or self.normalization == "power"):
+        if stock and self.diagonalizer_algorithm in ["IP", "IP1"] and (
+                not self.normalization or type(self.normalization) is bool
+                or self.normalization == "power"):
             steps = _lib.MNMF_ALL if self.normalization else _lib.MNMF_ALL & ~_lib.MNMF_NORMALIZE
             self._update(steps, flooring_fn)
             return
@@ -296,8 +294,20 @@ class FastGaussMNMF(FastMNMFBase):
         """ref: ssspy/bss/mnmf.py:1419-1447."""
         if self.diagonalizer_algorithm in ["IP", "IP1"]:
             self.update_diagonalizer_ip1(flooring_fn=flooring_fn)
+        elif self.diagonalizer_algorithm in ["IP2"]:
+            self.update_diagonalizer_ip2(flooring_fn=flooring_fn)
         else:
             raise NotImplementedError("Not support {}.".format(self.diagonalizer_algorithm))
+
+    def update_diagonalizer_ip2(self, flooring_fn="self") -> None:
+        """Pairwise iterative projection on Q.  ref: ssspy/bss/mnmf.py:1516-1633."""
+        U = _ops.fastmnmf_diagonalizer_covariance(
+            self._X, self._state_dev("spatial"), self._state_dev("basis"),
+            self._state_dev("activation"))
+        _ops.update_by_ip2(self._state_dev("diagonalizer"), U,
+                           resolve_pairs(getattr(self, "pair_selector", None), self.n_channels),
+                           self._resolve_floor(flooring_fn), self._info_tensor())
+        self._state_touch("diagonalizer")
 
     def update_diagonalizer_ip1(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/mnmf.py:1449-1514."""

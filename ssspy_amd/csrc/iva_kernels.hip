@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256) void k_iva_weight(const double *__restrict__ r
     const double alpha = p / (double)F;
     variance[e] = alpha;
     dG = 2.0 * r / alpha;
+  } else if (contrast == SSSPY_CONTRAST_GAUSS_FIXED) {
+    dG = 2.0 * r / variance[e];
   } else {
     dG = 2.0;
   }
@@ -108,7 +110,9 @@ int ssspy_iva_frame_power(const void *X, const void *W, double *r2, int B, int N
 int ssspy_iva_weight(const double *r2, double *weight, double *variance, int B, int N, int F, int T,
                      int contrast, int floor_kind, double floor_eps, void *stream) {
   SSSPY_REQUIRE(r2 && weight && B > 0, "iva_weight: bad argument");
-  SSSPY_REQUIRE(contrast == SSSPY_CONTRAST_LAPLACE || (contrast == SSSPY_CONTRAST_GAUSS && variance),
+  SSSPY_REQUIRE(contrast == SSSPY_CONTRAST_LAPLACE ||
+                    ((contrast == SSSPY_CONTRAST_GAUSS || contrast == SSSPY_CONTRAST_GAUSS_FIXED) &&
+                     variance),
                 "iva_weight: bad contrast / variance");
   const long long total = (long long)B * N * T;
   hipLaunchKernelGGL(k_iva_weight, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,

@@ -185,6 +185,14 @@ int ssspy_fastmnmf_update(const void *X, const void *C, void *Q, double *D, doub
   return rc;
 }
 
+int ssspy_fastmnmf_diagonalizer_covariance(const void *X, const double *D, const double *basis,
+                                           const double *activation, void *U, int B, int N, int M,
+                                           int F, int T, int K, void *stream) {
+  SSSPY_REQUIRE(X && D && basis && activation && U && B > 0, "fastmnmf_diagonalizer_covariance: bad argument");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_diagonalizer_covariance: bad n_basis");
+  MNMF_DISPATCH(N, mnmf_wcov, X, D, basis, activation, U, B, M, F, T, K, as_stream(stream));
+}
+
 int ssspy_fastmnmf_loss_data(const void *X, const void *Q, const double *D, const double *basis,
                              const double *activation, double *out, int B, int N, int M, int F,
                              int T, int K, void *stream) {

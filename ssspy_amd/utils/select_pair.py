@@ -15,3 +15,15 @@ def combination_pair_selector(n_sources, sort=False):
     """Yield every unordered pair once, in lexicographic order."""
     for pair in itertools.combinations(range(n_sources), 2):
         yield tuple(sorted(pair)) if sort else pair
+
+
+def resolve_pairs(pair_selector, n_sources):
+    """Materialise a pair selector into the list of (m, n) the kernels walk; negative indices wrap
+    as in the reference (ssspy/bss/_update_spatial_model.py:241-244)."""
+    if pair_selector is None:
+        pair_selector = sequential_pair_selector
+    pairs = [(int(m) % n_sources, int(n) % n_sources) for m, n in pair_selector(n_sources)]
+    for m, n in pairs:
+        if m == n:
+            raise ValueError("a pair must name two different sources, got ({}, {})".format(m, n))
+    return pairs

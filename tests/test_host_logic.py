@@ -57,7 +57,7 @@ def test_constructor_argument_checks():
     with pytest.raises(AssertionError):
         GaussILRMA(n_basis=2, newton_iter=3)  # IPA keyword without IPA
     with pytest.raises(NotImplementedError):
-        GaussILRMA(n_basis=2, spatial_algorithm="IP2")
+        GaussILRMA(n_basis=2, spatial_algorithm="IPA")
     with pytest.raises(NotImplementedError):
         GaussILRMA(n_basis=2, flooring_fn=lambda x: x)
     with pytest.raises(ValueError):
