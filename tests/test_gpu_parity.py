@@ -510,3 +510,56 @@ def test_fast_gauss_mnmf_ip2_against_oracle_loss():
     np.testing.assert_allclose(m.loss, ref.loss, rtol=1e-8)
     assert rel_err(m.spatial, ref.spatial) < 1e-7
     assert rel_err(Y, Yr) < 1e-6
+
+
+# ------------------------------------------------------------------------------- full BASELINE sizes
+def test_aux_iva_iss_config3_full_size_properties():
+    """BASELINE.json configs[2] (AuxLaplaceIVA-ISS, N=8, F=2049, T=1024): size-independent
+    properties -- the auxiliary-function loss never increases, the fused ISS kernel's state stays a
+    linear transform of the input (Y_i = W_i X_i with the least-squares W_i reproduces Y), and
+    projection back makes the reference channel reconstruct exactly (sum_n y_n = x_ref)."""
+    from ssspy_amd.bss.iva import AuxLaplaceIVA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    N, F, T = 8, 2049, 1024
+    X = nmf_mixture(3000, N, F, T)
+    m = AuxLaplaceIVA(spatial_algorithm="ISS")
+    Y = m(X, n_iter=12)
+    loss = np.array(m.loss)
+    assert np.all(np.diff(loss) <= 1e-9 * np.abs(loss[:-1]))
+    assert m.demix_filter is None and Y.shape == X.shape
+    assert rel_err(Y.sum(axis=0), X[0]) < 1e-9
+    # linearity per bin: least-squares filter from (Y, X) reproduces Y on a sample of bins
+    for i in (0, 1024, 2048):
+        Xi, Yi = X[:, i, :], Y[:, i, :]
+        Wi = Yi @ Xi.conj().T @ np.linalg.inv(Xi @ Xi.conj().T)
+        assert rel_err(Wi @ Xi, Yi) < 1e-9
+
+
+def test_fast_gauss_mnmf_config4_full_size_properties():
+    """BASELINE.json configs[3] (FastGaussMNMF, N=M=4, F=1025, T=512, K=8): the loss is non-increasing
+    over the iterations (MM + IP guarantee), the power normalisation holds
+    (mean_{i,j} |q_m^H x|^2 = 1), the Wiener filter outputs sum to the reference channel, and the
+    first iterations match the oracle."""
+    from oracle.mnmf import FastGaussMNMFOracle
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    M, F, T, K = 4, 1025, 512, 8
+    X = nmf_mixture(4000, M, F, T)
+    kw = dict(basis=np.random.default_rng(1).random((M, F, K)),
+              activation=np.random.default_rng(2).random((M, K, T)),
+              spatial=np.random.default_rng(4).random((F, M, M)))
+    m = FastGaussMNMF(n_basis=K)
+    Y = m(X, n_iter=15, **kw)
+    loss = np.array(m.loss)
+    assert np.all(np.diff(loss) <= 1e-9 * np.abs(loss[:-1]))
+    QX = m.diagonalizer @ X.transpose(1, 0, 2)
+    np.testing.assert_allclose(np.mean(np.abs(QX) ** 2, axis=(0, 2)), 1.0, rtol=1e-10)
+    assert rel_err(Y.sum(axis=0), X[0]) < 1e-8  # sum_n W_n = R^-1 sum_n R_n = I on the reference row
+    ref = FastGaussMNMFOracle(n_basis=K, record_loss=True)
+    ref.reset(X, **{k: v.copy() for k, v in kw.items()})
+    ref_loss = [ref.compute_loss()]
+    ref.update_once()
+    ref_loss.append(ref.compute_loss())
+    np.testing.assert_allclose(loss[:2], ref_loss, rtol=LOSS_RTOL)
