@@ -9,6 +9,8 @@
 //   bin-major tile   : basis update, diagonaliser covariance, spatial update, loss
 //   frame-major tile : activation update
 // Compiled once per N (-DSSSPY_N=2..4); M (channels) is a template parameter dispatched at launch.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "cov_core.hpp"
 #include "nmf_tile.hpp"
@@ -478,6 +480,267 @@ __global__ __launch_bounds__(256) void k_mnmf_spatial(const c128 *__restrict__ X
   }
 }
 
+// ============================================================== throughput variants (K <= 16, even T)
+// Same restructuring as ilrma_fast.hip: the 4 waves of a workgroup own 4 adjacent 16-bin tiles and
+// walk the frame tiles together; the activation tile of every source is staged once per workgroup in
+// LDS (double buffered, one barrier per tile); x of the next tile is prefetched into registers; 1/R~
+// is v_rcp_f64 + 2 Newton steps; accumulators stay with the owning wave (no cross-wave fold).
+constexpr int VROW = 18;
+
+__device__ __forceinline__ double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  return r;
+}
+
+struct VStage {
+  double2 v[(N * 16 * 8 + 255) / 256];
+};
+__device__ __forceinline__ void vstage_load(VStage &st, const double *__restrict__ act_b, int K,
+                                            int T, int j0) {
+#pragma unroll
+  for (int u = 0; u < (N * 16 * 8 + 255) / 256; ++u) {
+    const int idx = threadIdx.x + 256 * u;
+    const int row = idx >> 3, chunk = idx & 7;
+    const int n = row >> 4, k = row & 15;
+    const int j = j0 + 2 * chunk;
+    double2 val = make_double2(0.0, 0.0);
+    if (idx < N * 16 * 8 && k < K && j < T)
+      val = *reinterpret_cast<const double2 *>(act_b + ((long long)n * K + k) * T + j);
+    st.v[u] = val;
+  }
+}
+__device__ __forceinline__ void vstage_store(const VStage &st, double *buf) {
+#pragma unroll
+  for (int u = 0; u < (N * 16 * 8 + 255) / 256; ++u) {
+    const int idx = threadIdx.x + 256 * u;
+    const int row = idx >> 3, chunk = idx & 7;
+    if (idx < N * 16 * 8) *reinterpret_cast<double2 *>(buf + row * VROW + 2 * chunk) = st.v[u];
+  }
+}
+__device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const double (&tb)[4], int c,
+                                                 int q) {
+  double4_t R = {0.0, 0.0, 0.0, 0.0};
+  const int col = tile_pi(c);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) R = mfma_f64(vs_n[(4 * ks + q) * VROW + col], tb[ks], R);
+  return R;
+}
+template <int M>
+struct XTileM {
+  c128 x[M][4];
+};
+template <int M>
+__device__ __forceinline__ void xtile_load(XTileM<M> &xt, const c128 *__restrict__ Xb, int F, int T,
+                                           int bin, int j0, int q) {
+  const int j = j0 + 4 * q;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const c128 *row = Xb + ((long long)m * F + bin) * T;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xt.x[m][r] = row[min(j + r, T - 1)];
+  }
+}
+
+// which of the three bin-major passes a kernel instance performs
+enum { MODE_BASIS = 0, MODE_WCOV = 1, MODE_SPATIAL = 2 };
+
+// grid: (ceil(F/64), 1, B); wave w owns bins [64 bx + 16 w, +16)
+template <int M, int MODE>
+__global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restrict__ X,
+                                                            const c128 *__restrict__ Q, double *Dsp,
+                                                            double *basis,
+                                                            const double *__restrict__ act,
+                                                            c128 *__restrict__ U, int F, int T, int K,
+                                                            int floor_kind, double eps) {
+  __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int b = blockIdx.z;
+  const int i0 = blockIdx.x * 64 + wave * 16;
+  const int bin = min(i0 + c, F - 1);
+  const c128 *Xb = X + (long long)b * M * F * T;
+  const double *act_b = act + (long long)b * N * K * T;
+  c128 Qb[M][M];
+  double Db[N][M];
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int a2 = 0; a2 < M; ++a2)
+      Qb[m][a2] = (MODE != MODE_WCOV) ? Q[((long long)b * F + bin) * (M * M) + m * M + a2]
+                                      : cmake(0.0, 0.0);  // the covariance pass does not need Q
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int m = 0; m < M; ++m) Db[n][m] = Dsp[((long long)b * F + bin) * (N * M) + n * M + m];
+  double tb[N][4];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kk = 4 * ks + q;
+      tb[n][ks] = kk < K ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
+    }
+  // accumulators of the three modes (only the selected mode's are live)
+  double4_t num[N], den[N];
+  CovAcc<M, M> acc;
+  double sn[N][M], sd[N][M];
+  if (MODE == MODE_BASIS) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      num[n] = double4_t{0.0, 0.0, 0.0, 0.0};
+      den[n] = double4_t{0.0, 0.0, 0.0, 0.0};
+    }
+  }
+  if (MODE == MODE_WCOV) acc.clear();
+  if (MODE == MODE_SPATIAL) {
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int m = 0; m < M; ++m) sn[n][m] = sd[n][m] = 0.0;
+  }
+  const int ntiles = (T + 15) >> 4;
+  VStage st;
+  XTileM<M> cur, nxt;
+  vstage_load(st, act_b, K, T, 0);
+  xtile_load<M>(cur, Xb, F, T, bin, 0, q);
+  vstage_store(st, vs[0]);
+  __syncthreads();
+  for (int jt = 0; jt < ntiles; ++jt) {
+    const int j0 = jt * 16;
+    const int jn = min(jt + 1, ntiles - 1) * 16;
+    vstage_load(st, act_b, K, T, jn);
+    xtile_load<M>(nxt, Xb, F, T, bin, jn, q);
+    const double *vcur = vs[jt & 1];
+    double4_t lamR[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) lamR[n] = rt_from_lds(vcur + n * 16 * VROW, tb[n], c, q);
+    double a[N][4], bq[N][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool valid = j0 + 4 * q + r < T;
+      c128 x[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = cur.x[m][r];
+      double lam[N], qx2[M], rc[M];
+#pragma unroll
+      for (int n = 0; n < N; ++n) lam[n] = lamR[n][r];
+      if (MODE == MODE_WCOV) {
+        double phi[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          double rr = 0.0;
+#pragma unroll
+          for (int n = 0; n < N; ++n) rr = fma(lam[n], Db[n][m], rr);
+          phi[m] = valid ? rcp_nr(rr) : 0.0;
+        }
+        acc.add(x, phi);
+      } else {
+        frame_terms<M>(Qb, Db, x, lam, qx2, rc);
+        double g[M], h[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          g[m] = rcp_nr(rc[m]);
+          h[m] = qx2[m] * g[m] * g[m];
+        }
+        if (MODE == MODE_BASIS) {
+#pragma unroll
+          for (int n = 0; n < N; ++n) {
+            double sa = 0.0, sb = 0.0;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+              sa = fma(Db[n][m], h[m], sa);
+              sb = fma(Db[n][m], g[m], sb);
+            }
+            a[n][r] = valid ? sa : 0.0;
+            bq[n][r] = valid ? sb : 0.0;
+          }
+        } else {
+#pragma unroll
+          for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+              sn[n][m] += valid ? lam[n] * h[m] : 0.0;
+              sd[n][m] += valid ? lam[n] * g[m] : 0.0;
+            }
+        }
+      }
+    }
+    if (MODE == MODE_BASIS) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        const double *vn = vcur + n * 16 * VROW;
+        const double2 v01 = *reinterpret_cast<const double2 *>(vn + c * VROW + 4 * q);
+        const double2 v23 = *reinterpret_cast<const double2 *>(vn + c * VROW + 4 * q + 2);
+        const double vb[4] = {v01.x, v01.y, v23.x, v23.y};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          num[n] = mfma_f64(a[n][r], vb[r], num[n]);
+          den[n] = mfma_f64(bq[n][r], vb[r], den[n]);
+        }
+      }
+    }
+    vstage_store(st, vs[(jt + 1) & 1]);
+    __syncthreads();
+    cur = nxt;
+  }
+  if (MODE == MODE_BASIS) {
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ob = i0 + q + 4 * r;
+        if (ob < F && c < K) {
+          double *dst = basis + (((long long)b * N + n) * F + ob) * K + c;
+          *dst = apply_floor((*dst) * sqrt(num[n][r] / den[n][r]), floor_kind, eps);
+        }
+      }
+  }
+  if (MODE == MODE_WCOV) {
+    acc.fold_q();
+    const double scale = 1.0 / (double)T;
+    const int ob = i0 + c;
+    if (ob < F && q == 0) {
+      c128 *dst = U + ((long long)b * F + ob) * (long long)(M * M * M);
+#pragma unroll
+      for (int s = 0; s < M; ++s) {
+        int e = 0;
+#pragma unroll
+        for (int aa = 0; aa < M; ++aa) {
+          dst[(s * M + aa) * M + aa] = cmake(acc.diag[s][aa] * scale, 0.0);
+#pragma unroll
+          for (int bb = aa + 1; bb < M; ++bb) {
+            const c128 z = acc.off[s][e];
+            dst[(s * M + aa) * M + bb] = cmake(z.x * scale, z.y * scale);
+            dst[(s * M + bb) * M + aa] = cmake(z.x * scale, -z.y * scale);
+            ++e;
+          }
+        }
+      }
+    }
+  }
+  if (MODE == MODE_SPATIAL) {
+    const int ob = i0 + c;
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        double v = sn[n][m], w = sd[n][m];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        w += __shfl_xor(w, 16, 64);
+        w += __shfl_xor(w, 32, 64);
+        if (q == 0 && ob < F) {
+          double *dst = Dsp + ((long long)b * F + ob) * (N * M) + n * M + m;
+          *dst = sqrt(v / w) * Db[n][m];
+        }
+      }
+  }
+}
+
 // ======================================================================================= loss
 // out[b] += sum_i (1/T) sum_j sum_m ( y~^2 / R~ + log R~ )
 template <int M, bool KSMALL>
@@ -766,10 +1029,24 @@ constexpr int cov_lds_mm() {
   return cov_lds_doubles_per_wave<M, M>();
 }
 
+// The bin-split variants put only ceil(F/64) workgroups per mixture on the chip: they pay off once
+// the batch supplies >= 2 workgroups per CU (measured: +15 % at 64 mixtures, -45 % at 1).
+static inline bool mnmf_fast_ok(int B, int F, int T, int K) {
+  static const bool disabled = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;
+  return !disabled && K <= 16 && (T % 2 == 0) && (long long)B * ((F + 63) / 64) >= 512;
+}
+
 int LAUNCHER(mnmf_basis)(const void *X, const void *Q, const double *Dsp, const double *basis,
                          double *basis_out, const double *act, int B, int M, int F, int T, int K,
                          int floor_kind, double eps, hipStream_t st) {
   Dims d{B, F, T, K};
+  if (mnmf_fast_ok(B, F, T, K) && basis_out == basis) {
+    dim3 fgrid((F + 63) / 64, 1, B);
+    MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_BASIS>), fgrid, dim3(256), 0,
+                                          st, (const c128 *)X, (const c128 *)Q, (double *)Dsp,
+                                          basis_out, act, (c128 *)nullptr, F, T, K, floor_kind, eps));
+    return check_launch("k_mnmf_basis_fast");
+  }
   dim3 grid((F + 15) / 16, kt_count(K), B), block(256);
   const size_t lds = (size_t)4 * N * 2 * 256 * sizeof(double);
   MNMF_DISPATCH_M(M, {
@@ -807,6 +1084,13 @@ int LAUNCHER(mnmf_activation)(const void *X, const void *Q, const double *Dsp, c
 int LAUNCHER(mnmf_wcov)(const void *X, const double *Dsp, const double *basis, const double *act,
                         void *U, int B, int M, int F, int T, int K, hipStream_t st) {
   Dims d{B, F, T, K};
+  if (mnmf_fast_ok(B, F, T, K)) {
+    dim3 fgrid((F + 63) / 64, 1, B);
+    MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_WCOV>), fgrid, dim3(256), 0,
+                                          st, (const c128 *)X, (const c128 *)nullptr, (double *)Dsp,
+                                          (double *)basis, act, (c128 *)U, F, T, K, 0, 0.0));
+    return check_launch("k_mnmf_wcov_fast");
+  }
   dim3 grid((F + 15) / 16, 1, B), block(256);
   MNMF_DISPATCH_M(M, {
     const size_t lds = (size_t)4 * cov_lds_mm<MM>() * sizeof(double);
@@ -823,6 +1107,13 @@ int LAUNCHER(mnmf_wcov)(const void *X, const double *Dsp, const double *basis, c
 int LAUNCHER(mnmf_spatial)(const void *X, const void *Q, double *Dsp, const double *basis,
                            const double *act, int B, int M, int F, int T, int K, hipStream_t st) {
   Dims d{B, F, T, K};
+  if (mnmf_fast_ok(B, F, T, K)) {
+    dim3 fgrid((F + 63) / 64, 1, B);
+    MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_SPATIAL>), fgrid, dim3(256),
+                                          0, st, (const c128 *)X, (const c128 *)Q, Dsp,
+                                          (double *)basis, act, (c128 *)nullptr, F, T, K, 0, 0.0));
+    return check_launch("k_mnmf_spatial_fast");
+  }
   dim3 grid((F + 15) / 16, 1, B), block(256);
   MNMF_DISPATCH_M(M, {
     const size_t lds = (size_t)4 * 2 * N * MM * 16 * sizeof(double);
