@@ -563,3 +563,35 @@ def test_fast_gauss_mnmf_config4_full_size_properties():
     ref.update_once()
     ref_loss.append(ref.compute_loss())
     np.testing.assert_allclose(loss[:2], ref_loss, rtol=LOSS_RTOL)
+
+
+# ------------------------------------------------------------------------------- large-batch code paths
+def test_large_batch_paths_against_oracle():
+    """With >= 512 workgroups per launch the kernels switch to their large-batch form (no frame
+    chunking in the ILRMA fast path, bin-split FastMNMF kernels) -- the one bench.py times.  600 tiny
+    mixtures; first, middle and last are checked against the oracle."""
+    from oracle.ilrma import GaussILRMAOracle
+    from oracle.mnmf import FastGaussMNMFOracle
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    B, N, F, T, K = 600, 3, 18, 32, 4
+    rng = np.random.default_rng(5)
+    X = np.stack([nmf_mixture(7000 + b, N, F, T) for b in range(B)])
+    basis, act = rng.random((B, N, F, K)), rng.random((B, N, K, T))
+    spatial = rng.random((B, F, N, N))
+    m = GaussILRMA(n_basis=K)
+    Y = m(X, n_iter=3, basis=basis, activation=act)
+    mm = FastGaussMNMF(n_basis=K)
+    Ym = mm(X, n_iter=3, basis=basis, activation=act, spatial=spatial)
+    for b in (0, 301, B - 1):
+        ref = GaussILRMAOracle(n_basis=K)
+        Yr = ref.run(X[b], n_iter=3, basis=basis[b], activation=act[b])
+        assert rel_err(Y[b], Yr) < TOL
+        np.testing.assert_allclose(np.asarray(m.loss)[:, b], ref.loss, rtol=LOSS_RTOL)
+        refm = FastGaussMNMFOracle(n_basis=K)
+        Yrm = refm.run(X[b], n_iter=3, basis=basis[b], activation=act[b], spatial=spatial[b].copy())
+        np.testing.assert_allclose(np.asarray(mm.loss)[:, b], refm.loss, rtol=LOSS_RTOL)
+        assert rel_err(mm.diagonalizer[b], refm.diagonalizer) < TOL
+        assert rel_err(Ym[b], Yrm) < 1e-7
