@@ -741,6 +741,176 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
   }
 }
 
+// ------------------------------------------------------------ activation, frame-major fast variant
+// grid: (ceil(T/64), chunks, B); wave w owns frames [64 bx + 16 w, +16) and walks the bin tiles of
+// its chunk; the basis tile of every source, the 16 diagonalisers and the 16 spatial matrices of the
+// tile are staged in LDS (double buffered, one barrier per bin tile).
+constexpr int TROW = 17;
+
+template <int M>
+struct TStageM {
+  double t[(N * 256 + 255) / 256];
+  c128 qv;
+  double dv;
+};
+
+template <int M>
+__device__ __forceinline__ void tstage_load(TStageM<M> &st, const double *__restrict__ basis_b,
+                                            const c128 *__restrict__ Q_b,
+                                            const double *__restrict__ D_b, int F, int K, int i0) {
+#pragma unroll
+  for (int u = 0; u < (N * 256 + 255) / 256; ++u) {
+    const int idx = threadIdx.x + 256 * u;  // (n, bin, k)
+    const int k = idx & 15, bl = (idx >> 4) & 15, n = idx >> 8;
+    const int bi = i0 + bl;
+    double v = 0.0;
+    if (idx < N * 256 && k < K && bi < F) v = basis_b[((long long)n * F + bi) * K + k];
+    st.t[u] = v;
+  }
+  {
+    const int idx = threadIdx.x;
+    const int bi = min(i0 + idx / (M * M), F - 1);
+    st.qv = idx < 16 * M * M ? Q_b[(long long)bi * (M * M) + idx % (M * M)] : cmake(0.0, 0.0);
+    const int bj = min(i0 + idx / (N * M), F - 1);
+    st.dv = idx < 16 * N * M ? D_b[(long long)bj * (N * M) + idx % (N * M)] : 0.0;
+  }
+}
+
+template <int M>
+__device__ __forceinline__ void tstage_store(const TStageM<M> &st, double *tbuf, c128 *qbuf,
+                                             double *dbuf) {
+#pragma unroll
+  for (int u = 0; u < (N * 256 + 255) / 256; ++u) {
+    const int idx = threadIdx.x + 256 * u;
+    const int k = idx & 15, row = idx >> 4;
+    if (idx < N * 256) tbuf[row * TROW + k] = st.t[u];
+  }
+  if (threadIdx.x < 16 * M * M) qbuf[threadIdx.x] = st.qv;
+  if (threadIdx.x < 16 * N * M) dbuf[threadIdx.x] = st.dv;
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void k_mnmf_activation_fast(const c128 *__restrict__ X,
+                                                              const c128 *__restrict__ Q,
+                                                              const double *__restrict__ Dsp,
+                                                              const double *__restrict__ basis,
+                                                              const double *__restrict__ act,
+                                                              double *__restrict__ part, int F,
+                                                              int T, int K, int tiles_per_chunk,
+                                                              int nchunks) {
+  __shared__ __attribute__((aligned(16))) double ts[2][N * 16 * TROW];
+  __shared__ __attribute__((aligned(16))) c128 ql[2][16 * M * M];
+  __shared__ __attribute__((aligned(16))) double dl[2][16 * N * M];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int b = blockIdx.z, chunk = blockIdx.y;
+  const int j0 = (blockIdx.x * 4 + wave) * 16;
+  const int jf = j0 + c;
+  const bool fvalid = jf < T;
+  const int jc = fvalid ? jf : T - 1;
+  const c128 *Xb = X + (long long)b * M * F * T;
+  const double *basis_b = basis + (long long)b * N * F * K;
+  const c128 *Q_b = Q + (long long)b * F * M * M;
+  const double *D_b = Dsp + (long long)b * F * N * M;
+  double vb[N][4];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kk = 4 * ks + q;
+      vb[n][ks] = (kk < K && fvalid) ? act[(((long long)b * N + n) * K + kk) * T + jc] : 0.0;
+    }
+  double4_t numv[N], denv[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    numv[n] = double4_t{0.0, 0.0, 0.0, 0.0};
+    denv[n] = double4_t{0.0, 0.0, 0.0, 0.0};
+  }
+  const int ntiles = (F + 15) >> 4;
+  const int t_begin = chunk * tiles_per_chunk;
+  const int t_end = min(ntiles, t_begin + tiles_per_chunk);
+  TStageM<M> st;
+  tstage_load<M>(st, basis_b, Q_b, D_b, F, K, t_begin * 16);
+  tstage_store<M>(st, ts[0], ql[0], dl[0]);
+  __syncthreads();
+  for (int it = t_begin; it < t_end; ++it) {
+    const int i0 = it * 16;
+    const int in = min(it + 1, t_end - 1) * 16;
+    c128 x[M][4];
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        x[m][r] = Xb[((long long)m * F + min(i0 + q + 4 * r, F - 1)) * T + jc];
+    tstage_load<M>(st, basis_b, Q_b, D_b, F, K, in);
+    const int pb = (it - t_begin) & 1;
+    const double *tcur = ts[pb];
+    double4_t lamR[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      double4_t R = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        R = mfma_f64(tcur[(n * 16 + c) * TROW + 4 * ks + q], vb[n][ks], R);
+      lamR[n] = R;
+    }
+    double a[N][4], bq[N][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int bl = q + 4 * r;
+      const bool valid = fvalid && (i0 + bl < F);
+      c128 Qb[M][M];
+      double Db[N][M];
+      load_bin<M>(Qb, Db, ql[pb] + bl * M * M, dl[pb] + bl * N * M);
+      c128 xr[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) xr[m] = x[m][r];
+      double lam[N], qx2[M], rc[M];
+#pragma unroll
+      for (int n = 0; n < N; ++n) lam[n] = lamR[n][r];
+      frame_terms<M>(Qb, Db, xr, lam, qx2, rc);
+      double g[M], h[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        g[m] = rcp_nr(rc[m]);
+        h[m] = qx2[m] * g[m] * g[m];
+      }
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          sa = fma(Db[n][m], h[m], sa);
+          sb = fma(Db[n][m], g[m], sb);
+        }
+        a[n][r] = valid ? sa : 0.0;
+        bq[n][r] = valid ? sb : 0.0;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double ta = tcur[(n * 16 + q + 4 * r) * TROW + c];
+        numv[n] = mfma_f64(ta, a[n][r], numv[n]);
+        denv[n] = mfma_f64(ta, bq[n][r], denv[n]);
+      }
+    tstage_store<M>(st, ts[pb ^ 1], ql[pb ^ 1], dl[pb ^ 1]);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ok = q + 4 * r;
+      if (ok < K && fvalid) {
+        const long long base = ((((long long)b * nchunks + chunk) * N + n) * 2) * K;
+        part[(base + ok) * T + jf] = numv[n][r];
+        part[(base + K + ok) * T + jf] = denv[n][r];
+      }
+    }
+}
+
 // ======================================================================================= loss
 // out[b] += sum_i (1/T) sum_j sum_m ( y~^2 / R~ + log R~ )
 template <int M, bool KSMALL>
@@ -1068,6 +1238,13 @@ int LAUNCHER(mnmf_activation)(const void *X, const void *Q, const double *Dsp, c
   const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
   const int ktiles = kt_count(K);
   dim3 grid((T + 63) / 64, nchunks, B * ktiles), block(256);
+  static const bool no_fast = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;
+  if (!no_fast && K <= 16) {
+    MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_activation_fast<MM>), grid, block, 0, st,
+                                          (const c128 *)X, (const c128 *)Q, Dsp, basis, act, part, F,
+                                          T, K, tiles_per_chunk, nchunks));
+    return check_launch("k_mnmf_activation_fast");
+  }
   MNMF_DISPATCH_M(M, {
     if (K <= 16)
       hipLaunchKernelGGL((k_mnmf_activation<MM, true>), grid, block, 0, st, (const c128 *)X,
