@@ -28,7 +28,11 @@ class GaussILRMAOracle:
         record_loss=True,
         reference_id=0,
         rng=None,
+        model=("gauss", None),
     ):
+        # model: ("gauss", None) GaussILRMA | ("t", dof) TILRMA | ("ggd", beta) GGDILRMA
+        assert model[0] in ("gauss", "t", "ggd")
+        self.model = model
         assert spatial_algorithm in ("IP", "IP1", "IP2", "ISS", "ISS1", "ISS2")
         self.pairs = None  # None = the reference's default selector for the algorithm
         self.n_basis = n_basis
@@ -79,30 +83,58 @@ class GaussILRMAOracle:
     # -- one iteration -----------------------------------------------------
     def update_basis(self):
         """ref: ssspy/bss/ilrma.py:1051-1128 (update_basis_mm, no partitioning)."""
-        p = self.domain
-        Y2 = np.abs(self._current_output()) ** 2
         T, V = self.basis, self.activation
         TV = T @ V
-        TVp2p = TV ** ((p + 2) / p)
-        num = np.sum((V[:, None, :, :] / TVp2p[:, :, None, :]) * Y2[:, :, None, :], axis=3)
+        numer, expo = self._mm_numerator(self._current_output(), TV)
+        num = np.sum(V[:, None, :, :] * numer[:, :, None, :], axis=3)
         den = np.sum(V[:, None, :, :] / TV[:, :, None, :], axis=3)
-        self.basis = sp.floor(((num / den) ** (p / (p + 2))) * T, self.flooring)
+        self.basis = sp.floor(((num / den) ** expo) * T, self.flooring)
+
+    def _mm_numerator(self, Y, TV):
+        """Per-(n,i,j) factor of the MM numerator and the exponent of the ratio.
+
+        Gauss: |y|^2 / TV^((p+2)/p), p/(p+2)                 ref: ssspy/bss/ilrma.py:1116-1125
+        t    : |y|^2 / (R~ TV), p/(p+2)                      ref: :2505-2518
+        GGD  : (beta/2) |y|^beta / TV^((beta+p)/p), p/(beta+p)  ref: :3810-3821
+        """
+        p = self.domain
+        kind, param = self.model
+        Y2 = np.abs(Y) ** 2
+        if kind == "gauss":
+            return Y2 / TV ** ((p + 2) / p), p / (p + 2)
+        if kind == "t":
+            nu_nu2 = param / (param + 2)
+            R_tilde = nu_nu2 * TV ** (2 / p) + (1 - nu_nu2) * Y2
+            return Y2 / (R_tilde * TV), p / (p + 2)
+        beta = param
+        return (beta / 2) * np.abs(Y) ** beta / TV ** ((beta + p) / p), p / (beta + p)
+
+    def _spatial_weight(self, Y):
+        """varphi = 1 / R~.  ref: ssspy/bss/ilrma.py:1494-1498 (Gauss), :2915-2935 (t), :3987-4011 (GGD)."""
+        p = self.domain
+        kind, param = self.model
+        TV = self.basis @ self.activation
+        if kind == "gauss":
+            return 1 / TV ** (2 / p)
+        if kind == "t":
+            nu_nu2 = param / (param + 2)
+            return 1 / (nu_nu2 * TV ** (2 / p) + (1 - nu_nu2) * np.abs(Y) ** 2)
+        beta = param
+        Y2b = sp.floor(np.abs(Y) ** (2 - beta), self.flooring)
+        return 1 / ((2 / beta) * Y2b * TV ** (beta / p))
 
     def update_activation(self):
         """ref: ssspy/bss/ilrma.py:1130-1204 (update_activation_mm, no partitioning)."""
-        p = self.domain
-        Y2 = np.abs(self._current_output()) ** 2
         T, V = self.basis, self.activation
         TV = T @ V
-        TVp2p = TV ** ((p + 2) / p)
-        num = np.sum((T[:, :, :, None] / TVp2p[:, :, None, :]) * Y2[:, :, None, :], axis=1)
+        numer, expo = self._mm_numerator(self._current_output(), TV)
+        num = np.sum(T[:, :, :, None] * numer[:, :, None, :], axis=1)
         den = np.sum(T[:, :, :, None] / TV[:, :, None, :], axis=1)
-        self.activation = sp.floor(((num / den) ** (p / (p + 2))) * V, self.flooring)
+        self.activation = sp.floor(((num / den) ** expo) * V, self.flooring)
 
     def update_spatial(self):
         """ref: ssspy/bss/ilrma.py:1440-1507 (IP1), :1635-1696 (ISS1)."""
-        p = self.domain
-        varphi = 1 / ((self.basis @ self.activation) ** (2 / p))
+        varphi = self._spatial_weight(self._current_output())
         N = self.n_sources
         if self.spatial_algorithm == "IP2":
             # ref: ssspy/bss/ilrma.py:1509-1633 (default pair_selector: sequential, :796-798)
@@ -149,7 +181,13 @@ class GaussILRMAOracle:
             Y = sp.separate(self.input, W)
         Y2 = np.abs(Y) ** 2
         TV = self.basis @ self.activation
-        loss = Y2 / (TV ** (2 / p)) + (2 / p) * np.log(TV)
+        kind, param = self.model
+        if kind == "gauss":
+            loss = Y2 / (TV ** (2 / p)) + (2 / p) * np.log(TV)
+        elif kind == "t":  # ref: ssspy/bss/ilrma.py:3301-3305
+            loss = (1 + param / 2) * np.log(1 + (2 / param) * Y2 / (TV ** (2 / p))) + (2 / p) * np.log(TV)
+        else:  # ref: ssspy/bss/ilrma.py:4377-4381
+            loss = np.abs(Y) ** param / TV ** (param / p) + (2 / p) * np.log(TV)
         loss = np.sum(loss.mean(axis=-1), axis=0) - 2 * sp.logdet(W)
         return loss.sum(axis=0).item()
 

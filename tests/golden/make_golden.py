@@ -24,7 +24,7 @@ sys.path.insert(0, REFERENCE)
 
 from ssspy.algorithm import projection_back  # noqa: E402
 from ssspy.bss._update_spatial_model import update_by_ip1, update_by_iss1  # noqa: E402
-from ssspy.bss.ilrma import GaussILRMA  # noqa: E402
+from ssspy.bss.ilrma import GGDILRMA, TILRMA, GaussILRMA  # noqa: E402
 from ssspy.bss.iva import AuxGaussIVA, AuxLaplaceIVA  # noqa: E402
 from ssspy.bss.mnmf import FastGaussMNMF  # noqa: E402
 from ssspy.linalg import eigh2, inv2  # noqa: E402
@@ -89,16 +89,20 @@ def meta(**kw):
 
 # --------------------------------------------------------------------------- ILRMA
 def run_ilrma(name, *, N, F, T, K, algo, seed, gen=gen_iid, domain=2, flooring=("max", 1e-10),
-              normalization=True, scale_restoration=True, n_iter=10):
+              normalization=True, scale_restoration=True, n_iter=10, model=("gauss", None)):
     X = gen(seed, N, F, T)
     basis = np.random.default_rng(seed + 1).random((N, F, K))
     activation = np.random.default_rng(seed + 2).random((N, K, T))
     snap = Snapshots(["demix_filter", "output", "basis", "activation"])
-    m = GaussILRMA(
-        n_basis=K, spatial_algorithm=algo, domain=domain, flooring_fn=flooring_of(flooring),
-        callbacks=snap, normalization=normalization, scale_restoration=scale_restoration,
-        rng=np.random.default_rng(seed + 3),
-    )
+    common = dict(spatial_algorithm=algo, domain=domain, flooring_fn=flooring_of(flooring),
+                  callbacks=snap, normalization=normalization, scale_restoration=scale_restoration,
+                  rng=np.random.default_rng(seed + 3))
+    if model[0] == "t":
+        m = TILRMA(n_basis=K, dof=model[1], **common)
+    elif model[0] == "ggd":
+        m = GGDILRMA(n_basis=K, beta=model[1], **common)
+    else:
+        m = GaussILRMA(n_basis=K, **common)
     Y = m(X, n_iter=n_iter, basis=basis, activation=activation)
     out = dict(X=X, basis0=basis, activation0=activation, loss=np.array(m.loss), final_output=Y,
                final_basis=m.basis, final_activation=m.activation)
@@ -106,6 +110,7 @@ def run_ilrma(name, *, N, F, T, K, algo, seed, gen=gen_iid, domain=2, flooring=(
         out["final_demix_filter"] = m.demix_filter
     out.update(snap.store)
     out.update(meta(kind="gauss_ilrma", algo=algo, domain=domain, n_basis=K, n_iter=n_iter,
+                    model=model[0], model_param=(0.0 if model[1] is None else model[1]),
                     floor_kind=flooring[0], floor_eps=flooring[1], normalization=normalization,
                     scale_restoration=scale_restoration))
     save(name, **out)
@@ -227,6 +232,14 @@ def main():
     run_iva("auxlap_iss2_n4", N=4, F=20, T=44, algo="ISS2", contrast="laplace", seed=65, gen=gen_mixture)
     run_iva("auxgauss_ip2_n2", N=2, F=24, T=40, algo="IP2", contrast="gauss", seed=66)
     run_iva("auxgauss_iss2_n3", N=3, F=20, T=44, algo="ISS2", contrast="gauss", seed=67, gen=gen_mixture)
+    # --- heavy-tailed source models (TILRMA, GGDILRMA)
+    run_ilrma("tilrma_ip1_n3", N=3, F=18, T=40, K=4, algo="IP", seed=70, gen=gen_mixture, model=("t", 5.0))
+    run_ilrma("tilrma_iss1_n2_p1", N=2, F=17, T=33, K=3, algo="ISS", seed=71, domain=1, model=("t", 100.0))
+    run_ilrma("tilrma_ip2_n3", N=3, F=16, T=36, K=4, algo="IP2", seed=72, gen=gen_mixture, model=("t", 8.0))
+    run_ilrma("ggdilrma_ip1_n3", N=3, F=18, T=40, K=4, algo="IP", seed=73, gen=gen_mixture, model=("ggd", 1.0))
+    run_ilrma("ggdilrma_iss1_n2", N=2, F=17, T=33, K=3, algo="ISS", seed=74, model=("ggd", 1.5))
+    run_ilrma("ggdilrma_iss2_n3_p1", N=3, F=16, T=36, K=4, algo="ISS2", seed=75, domain=1, gen=gen_mixture,
+              model=("ggd", 0.7))
     # --- AuxIVA ---
     run_iva("auxlap_ip1_n2", N=2, F=33, T=40, algo="IP", contrast="laplace", seed=0)
     run_iva("auxlap_ip1_n4", N=4, F=20, T=50, algo="IP1", contrast="laplace", seed=1, gen=gen_mixture)

@@ -21,7 +21,14 @@ ILRMA_CASES = [
     "gilrma_ip1_n2", "gilrma_ip1_n3", "gilrma_ip1_n4", "gilrma_ip1_n4_p1", "gilrma_ip1_n2_add",
     "gilrma_ip1_n2_nofloor", "gilrma_ip1_n3_raw", "gilrma_iss1_n2", "gilrma_iss1_n4",
     "gilrma_iss1_n3_p1", "gilrma_ip2_n3", "gilrma_ip2_n2", "gilrma_iss2_n4", "gilrma_iss2_n3",
+    "tilrma_ip1_n3", "tilrma_iss1_n2_p1", "tilrma_ip2_n3", "ggdilrma_ip1_n3", "ggdilrma_iss1_n2",
+    "ggdilrma_iss2_n3_p1",
 ]
+
+
+def _model(g):
+    kind = str(g["meta_model"]) if "meta_model" in g else "gauss"
+    return (kind, None if kind == "gauss" else float(g["meta_model_param"]))
 IVA_CASES = [
     "auxlap_ip1_n2", "auxlap_ip1_n4", "auxlap_iss1_n2", "auxlap_iss1_n8", "auxgauss_ip1_n3",
     "auxgauss_iss1_n3", "auxlap_ip1_n2_raw", "auxlap_ip2_n3", "auxlap_iss2_n4", "auxgauss_ip2_n2",
@@ -42,7 +49,9 @@ def _check_snapshots(g, k, model, names):
             if pairwise and name in ("demix_filter", "output"):
                 assert rel_err_up_to_phase(getattr(model, name), g[key], name) < 1e-9, key
             else:
-                assert rel_err(getattr(model, name), g[key]) < TOL, key
+                # heavy-tailed models with phase-ambiguous pairwise updates amplify rounding more
+                tol = 1e-9 if pairwise else TOL
+                assert rel_err(getattr(model, name), g[key]) < tol, key
 
 
 @pytest.mark.parametrize("case", ILRMA_CASES)
@@ -52,7 +61,7 @@ def test_gauss_ilrma(case):
         n_basis=int(g["meta_n_basis"]), spatial_algorithm=str(g["meta_algo"]),
         domain=float(g["meta_domain"]), flooring=_floor(g),
         normalization=bool(g["meta_normalization"]),
-        scale_restoration=bool(g["meta_scale_restoration"]),
+        scale_restoration=bool(g["meta_scale_restoration"]), model=_model(g),
     )
     m.reset(g["X"], basis=g["basis0"], activation=g["activation0"])
     losses = [m.compute_loss()]
