@@ -57,6 +57,10 @@ enum {
   SSSPY_CONTRAST_GAUSS_FIXED = 2, /* uses the given variance unchanged (AuxGaussIVA IP2)   */
 };
 
+/* source models of ILRMA (reference classes GaussILRMA / TILRMA / GGDILRMA); `model_param` is
+ * unused, the degree of freedom nu, or the shape beta respectively */
+enum { SSSPY_SOURCE_GAUSS = 0, SSSPY_SOURCE_T = 1, SSSPY_SOURCE_GGD = 2 };
+
 #define SSSPY_MAX_SOURCES 8
 #define SSSPY_MAX_BASIS 64
 #define SSSPY_MAX_PAIRS 32
@@ -178,26 +182,37 @@ int ssspy_eigh2(const void *A, const void *Bm, double *lamb, void *Z, long long 
  * the basis / covariance passes for small batches, per-bin powers for the normalisation). */
 size_t ssspy_ilrma_workspace_bytes(int B, int N, int F, int T, int K);
 
-/* basis update: T <- floor(T * (sum_j V P/R^((p+2)/p) / sum_j V/R)^(p/(p+2))), R = T V,
- * P = |W X|^2 (or |X|^2 when W == NULL: the ISS path passes the separated spectrogram).
- * replaces: ssspy/bss/ilrma.py:1051-1128 (update_basis_mm, no partitioning). */
+/* The ILRMA entry points take the source model as (source_model, model_param):
+ *   GAUSS: numerator P/R^((p+2)/p), exponent p/(p+2), varphi = 1/R^(2/p)       (ilrma.py:582-1989)
+ *   T    : numerator P/(R~ R), R~ = nu/(nu+2) R^(2/p) + 2/(nu+2) P, varphi = 1/R~  (:1992-3334)
+ *   GGD  : numerator (beta/2) P^(beta/2)/R^((beta+p)/p), exponent p/(beta+p),
+ *          varphi = 1/((2/beta) floor(P^((2-beta)/2)) R^(beta/p))                (:3337-4410)
+ * with R = (T V)_nij, P = |y_nij|^2, p = domain. */
+
+/* basis update: T <- floor(T * (sum_j V num / sum_j V/R)^expo).  y = W x, or y = X when W == NULL
+ * (the ISS state passes the separated spectrogram).
+ * replaces: ssspy/bss/ilrma.py:1051-1128, :2470-2521, :3745-3824 (update_basis_mm, no partitioning). */
 int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const double *activation,
-                             int B, int N, int F, int T, int K, double domain, int floor_kind,
-                             double floor_eps, void *workspace, size_t workspace_bytes,
-                             void *stream);
+                             int B, int N, int F, int T, int K, double domain, int source_model,
+                             double model_param, int floor_kind, double floor_eps, void *workspace,
+                             size_t workspace_bytes, void *stream);
 
 /* activation update (sum over bins with the NEW basis).
- * replaces: ssspy/bss/ilrma.py:1130-1204 (update_activation_mm, no partitioning). */
+ * replaces: ssspy/bss/ilrma.py:1130-1204, :2523-2600, :3826-3905 (update_activation_mm). */
 int ssspy_ilrma_update_activation(const void *X, const void *W, const double *basis,
                                   double *activation, int B, int N, int F, int T, int K,
-                                  double domain, int floor_kind, double floor_eps, void *workspace,
+                                  double domain, int source_model, double model_param,
+                                  int floor_kind, double floor_eps, void *workspace,
                                   size_t workspace_bytes, void *stream);
 
-/* U[b,i,n] = (1/T) sum_j x x^H / (T V)^(2/p)   ->  U (B,F,N,N,N).
- * replaces: ssspy/bss/ilrma.py:1494-1505 (weights) + the covariance broadcast. */
-int ssspy_ilrma_weighted_covariance(const void *X, const double *basis, const double *activation,
-                                    void *U, int B, int N, int F, int T, int K, double domain,
-                                    void *workspace, size_t workspace_bytes, void *stream);
+/* U[b,i,n] = (1/T) sum_j varphi_nij x x^H  ->  U (B,F,N,N,N).  W is read only by the heavy-tailed
+ * models (varphi depends on |w x|^2); the floor only by GGD.
+ * replaces: ssspy/bss/ilrma.py:1494-1505, :2915-2942, :3990-4018 (weights + covariance broadcast). */
+int ssspy_ilrma_weighted_covariance(const void *X, const void *W, const double *basis,
+                                    const double *activation, void *U, int B, int N, int F, int T,
+                                    int K, double domain, int source_model, double model_param,
+                                    int floor_kind, double floor_eps, void *workspace,
+                                    size_t workspace_bytes, void *stream);
 
 /* power normalisation from the static covariance C (B,F,N,N) = (1/T) sum_j x x^H:
  * psi_n = floor(sqrt(mean_i w_in^H C_i w_in)); W[:,n,:] /= psi_n; basis[n] /= psi_n^p.
@@ -212,26 +227,30 @@ int ssspy_ilrma_normalize_output(void *Y, double *basis, int B, int N, int F, in
                                  double domain, int floor_kind, double floor_eps, void *workspace,
                                  size_t workspace_bytes, void *stream);
 
-/* varphi[b,n,i,j] = 1 / (T V)^(2/p)   (B,N,F,T) doubles, for the ISS1 path.
- * replaces: ssspy/bss/ilrma.py:1690-1694. */
-int ssspy_ilrma_iss_weight(const double *basis, const double *activation, double *varphi, int B,
-                           int N, int F, int T, int K, double domain, void *stream);
+/* varphi[b,n,i,j] (B,N,F,T) doubles for the ISS paths; Y (the separated spectrogram) is read only
+ * by the heavy-tailed models.
+ * replaces: ssspy/bss/ilrma.py:1690-1694, :3125-3143, :4202-4220. */
+int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *activation,
+                           double *varphi, int B, int N, int F, int T, int K, double domain,
+                           int source_model, double model_param, int floor_kind, double floor_eps,
+                           void *stream);
 
-/* out[b] = sum_{n,i} mean_j ( |y|^2 / R^(2/p) + (2/p) log R ), y = W x (or x when W == NULL);
- * `out` (B doubles) is zeroed by the call.  The caller adds -2 * ssspy_sum_logdet.
- * replaces: ssspy/bss/ilrma.py:1946-1965. */
+/* out[b] = sum_{n,i} mean_j ( data term of the model + (2/p) log R ), y = W x (or x when
+ * W == NULL); `out` (B doubles) is zeroed by the call.  The caller adds -2 * ssspy_sum_logdet.
+ * replaces: ssspy/bss/ilrma.py:1946-1965, :3291-3310, :4367-4386. */
 int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
                           const double *activation, double *out, int B, int N, int F, int T, int K,
-                          double domain, void *stream);
+                          double domain, int source_model, double model_param, void *stream);
 
-/* One whole update_once() of GaussILRMA(spatial_algorithm="IP1", source_algorithm="MM"):
- * basis, activation, weighted covariance, IP1, power normalisation -- the five launches the
- * host would otherwise issue one by one.  U (B,F,N,N,N) is caller-provided scratch.
- * replaces: ssspy/bss/ilrma.py:900-922. */
-int ssspy_gauss_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis,
-                                 double *activation, void *U, int B, int N, int F, int T, int K,
-                                 double domain, int normalize, int floor_kind, double floor_eps,
-                                 void *workspace, size_t workspace_bytes, int *info, void *stream);
+/* One whole update_once() of an ILRMA with spatial_algorithm="IP1", source_algorithm="MM": basis,
+ * activation, weighted covariance, IP1, power normalisation -- the launches the host would otherwise
+ * issue one by one.  U (B,F,N,N,N) is caller-provided scratch.
+ * replaces: ssspy/bss/ilrma.py:900-922 (and the TILRMA / GGDILRMA equivalents). */
+int ssspy_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis, double *activation,
+                           void *U, int B, int N, int F, int T, int K, double domain,
+                           int source_model, double model_param, int normalize, int floor_kind,
+                           double floor_eps, void *workspace, size_t workspace_bytes, int *info,
+                           void *stream);
 
 /* ------------------------------------------------------------------ AuxIVA (IP1/ISS1) */
 

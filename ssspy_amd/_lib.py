@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libssspy_amd.so")
 OK, ERR_BADARG, ERR_HIP, ERR_UNSUPPORTED = 0, 1, 2, 3
 FLOOR_NONE, FLOOR_MAX, FLOOR_ADD = 0, 1, 2
 WEIGHT_UNIT, WEIGHT_FRAME, WEIGHT_BIN_FRAME = 0, 1, 2
+SOURCE_GAUSS, SOURCE_T, SOURCE_GGD = 0, 1, 2
 CONTRAST_LAPLACE, CONTRAST_GAUSS, CONTRAST_GAUSS_FIXED = 0, 1, 2
 MAX_PAIRS = 32
 MAX_SOURCES, MAX_BASIS = 8, 64
@@ -45,15 +46,18 @@ PROTOTYPES = {
     "ssspy_to_psd": (_i, [_p, _p, _q, _i, _i, _d, _p]),
     "ssspy_eigh2": (_i, [_p, _p, _p, _p, _q, _i, _p, _p]),
     "ssspy_ilrma_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
-    "ssspy_ilrma_update_basis": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p, _z, _p]),
-    "ssspy_ilrma_update_activation": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p, _z, _p]),
-    "ssspy_ilrma_weighted_covariance": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _z, _p]),
+    "ssspy_ilrma_update_basis": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _i, _d, _p, _z,
+                                      _p]),
+    "ssspy_ilrma_update_activation": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _i, _d, _p,
+                                           _z, _p]),
+    "ssspy_ilrma_weighted_covariance": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _i,
+                                             _d, _p, _z, _p]),
     "ssspy_ilrma_normalize_filter": (_i, [_p, _p, _p, _i, _i, _i, _i, _d, _i, _d, _p, _z, _p]),
     "ssspy_ilrma_normalize_output": (_i, [_p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p, _z, _p]),
-    "ssspy_ilrma_iss_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _d, _p]),
-    "ssspy_ilrma_loss_data": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p]),
-    "ssspy_gauss_ilrma_ip1_update": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _i, _d,
-                                          _p, _z, _p, _p]),
+    "ssspy_ilrma_iss_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _i, _d, _p]),
+    "ssspy_ilrma_loss_data": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p]),
+    "ssspy_ilrma_ip1_update": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _i, _i, _d,
+                                    _p, _z, _p, _p]),
     "ssspy_iva_frame_power": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "ssspy_iva_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _d, _p]),
     "ssspy_iva_loss_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),

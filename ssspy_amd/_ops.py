@@ -159,35 +159,41 @@ def ilrma_workspace(B, N, F, T, K, dev):
     return dv.empty(((nbytes + 7) // 8,), dv.f64, dev), nbytes
 
 
-def ilrma_update_basis(X, W, basis, activation, domain, flooring, ws, ws_bytes):
+GAUSS = (_lib.SOURCE_GAUSS, 0.0)  # source model as (SSSPY_SOURCE_*, model_param); see include/ssspy_amd.h
+
+
+def ilrma_update_basis(X, W, basis, activation, domain, flooring, ws, ws_bytes, model=GAUSS):
     B, N, F, T = X.shape
     K = basis.shape[-1]
     _lib.check(
         _L().ssspy_ilrma_update_basis(ptr(X), ptr(W), ptr(basis), ptr(activation), B, N, F, T, K,
-                                      domain, flooring[0], flooring[1], ptr(ws), ws_bytes, _st()),
+                                      domain, model[0], model[1], flooring[0], flooring[1], ptr(ws),
+                                      ws_bytes, _st()),
         "ilrma_update_basis",
     )
 
 
-def ilrma_update_activation(X, W, basis, activation, domain, flooring, ws, ws_bytes):
+def ilrma_update_activation(X, W, basis, activation, domain, flooring, ws, ws_bytes, model=GAUSS):
     B, N, F, T = X.shape
     K = basis.shape[-1]
     _lib.check(
         _L().ssspy_ilrma_update_activation(ptr(X), ptr(W), ptr(basis), ptr(activation), B, N, F, T,
-                                           K, domain, flooring[0], flooring[1], ptr(ws), ws_bytes,
-                                           _st()),
+                                           K, domain, model[0], model[1], flooring[0], flooring[1],
+                                           ptr(ws), ws_bytes, _st()),
         "ilrma_update_activation",
     )
 
 
-def ilrma_weighted_covariance(X, basis, activation, domain, ws, ws_bytes, out=None):
+def ilrma_weighted_covariance(X, basis, activation, domain, ws, ws_bytes, out=None, W=None,
+                              model=GAUSS, flooring=(0, 0.0)):
     B, N, F, T = X.shape
     K = basis.shape[-1]
     if out is None:
         out = dv.empty((B, F, N, N, N), dv.c128, X.device)
     _lib.check(
-        _L().ssspy_ilrma_weighted_covariance(ptr(X), ptr(basis), ptr(activation), ptr(out), B, N, F,
-                                             T, K, domain, ptr(ws), ws_bytes, _st()),
+        _L().ssspy_ilrma_weighted_covariance(ptr(X), ptr(W), ptr(basis), ptr(activation), ptr(out),
+                                             B, N, F, T, K, domain, model[0], model[1], flooring[0],
+                                             flooring[1], ptr(ws), ws_bytes, _st()),
         "ilrma_weighted_covariance",
     )
     return out
@@ -213,42 +219,41 @@ def ilrma_normalize_output(Y, basis, domain, flooring, ws, ws_bytes):
     )
 
 
-def ilrma_iss_weight(basis, activation, domain, out=None):
+def ilrma_iss_weight(basis, activation, domain, out=None, Y=None, model=GAUSS, flooring=(0, 0.0)):
     B, N, F, K = basis.shape
     T = activation.shape[-1]
     if out is None:
         out = dv.empty((B, N, F, T), dv.f64, basis.device)
     _lib.check(
-        _L().ssspy_ilrma_iss_weight(ptr(basis), ptr(activation), ptr(out), B, N, F, T, K, domain,
-                                    _st()),
+        _L().ssspy_ilrma_iss_weight(ptr(Y), ptr(basis), ptr(activation), ptr(out), B, N, F, T, K,
+                                    domain, model[0], model[1], flooring[0], flooring[1], _st()),
         "ilrma_iss_weight",
     )
     return out
 
 
-def ilrma_loss_data(X, W, basis, activation, domain, out=None):
+def ilrma_loss_data(X, W, basis, activation, domain, out=None, model=GAUSS):
     B, N, F, T = X.shape
     K = basis.shape[-1]
     if out is None:
         out = dv.empty((B,), dv.f64, X.device)
     _lib.check(
         _L().ssspy_ilrma_loss_data(ptr(X), ptr(W), ptr(basis), ptr(activation), ptr(out), B, N, F,
-                                   T, K, domain, _st()),
+                                   T, K, domain, model[0], model[1], _st()),
         "ilrma_loss_data",
     )
     return out
 
 
-def gauss_ilrma_ip1_update(X, C, W, basis, activation, U, domain, normalize, flooring, ws,
-                           ws_bytes, info):
+def ilrma_ip1_update(X, C, W, basis, activation, U, domain, normalize, flooring, ws, ws_bytes,
+                     info, model=GAUSS):
     B, N, F, T = X.shape
     K = basis.shape[-1]
     _lib.check(
-        _L().ssspy_gauss_ilrma_ip1_update(ptr(X), ptr(C), ptr(W), ptr(basis), ptr(activation),
-                                          ptr(U), B, N, F, T, K, domain, int(bool(normalize)),
-                                          flooring[0], flooring[1], ptr(ws), ws_bytes, ptr(info),
-                                          _st()),
-        "gauss_ilrma_ip1_update",
+        _L().ssspy_ilrma_ip1_update(ptr(X), ptr(C), ptr(W), ptr(basis), ptr(activation), ptr(U), B,
+                                    N, F, T, K, domain, model[0], model[1], int(bool(normalize)),
+                                    flooring[0], flooring[1], ptr(ws), ws_bytes, ptr(info), _st()),
+        "ilrma_ip1_update",
     )
 
 

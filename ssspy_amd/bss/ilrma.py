@@ -3,9 +3,10 @@
 Drop-in separator classes for the reference's ``ssspy.bss.ilrma`` hot path
 (ssspy/bss/ilrma.py): same constructor arguments, ``__call__`` / ``update_once`` /
 ``compute_loss`` protocol and state attributes, with every per-iteration computation done
-by the HIP kernels of ``libssspy_amd.so``.  Built here: ``GaussILRMA`` with
-``spatial_algorithm in {"IP", "IP1", "ISS", "ISS1"}``, ``source_algorithm="MM"``, no
-partitioning, power normalisation, projection-back scale restoration.  Configurations of
+by the HIP kernels of ``libssspy_amd.so``.  Built here: ``GaussILRMA``, ``TILRMA`` and
+``GGDILRMA`` with ``spatial_algorithm in {"IP", "IP1", "IP2", "ISS", "ISS1", "ISS2"}``,
+``source_algorithm="MM"``, no partitioning, power normalisation, projection-back scale
+restoration.  Configurations of
 the reference that are not built yet raise ``NotImplementedError`` (never a CPU fallback).
 
 Extension over the reference: ``input`` may be 4-D ``(n_mixtures, n_channels, n_bins,
@@ -26,7 +27,7 @@ from ..utils.select_pair import resolve_pairs, sequential_pair_selector
 from ._device_state import DeviceStateMixin, Synced
 from .base import IterativeMethodBase
 
-__all__ = ["GaussILRMA"]
+__all__ = ["GaussILRMA", "TILRMA", "GGDILRMA"]
 
 spatial_algorithms = ["IP", "IP1", "IP2", "ISS", "ISS1", "ISS2", "IPA"]
 source_algorithms = ["MM", "ME"]
@@ -181,7 +182,273 @@ class ILRMABase(DeviceStateMixin, IterativeMethodBase):
         return values.copy() if self._batched else values[0].item()
 
 
-class GaussILRMA(ILRMABase):
+class _MMILRMA(ILRMABase):
+    """Everything the three source models share: the iteration, the MM updates, the spatial
+    updates, normalisation, loss.  The model enters only as ``_model`` = (SSSPY_SOURCE_*, param),
+    which the kernels branch on (include/ssspy_amd.h)."""
+
+    _model = _ops.GAUSS
+    _name = "ILRMA"
+
+    def _configure(self, spatial_algorithm, source_algorithm, domain, partitioning, normalization,
+                   pair_selector) -> None:
+        if spatial_algorithm not in _IP1 + _ISS1 + _IP2 + _ISS2:
+            raise NotImplementedError(
+                "spatial_algorithm={!r} is not built for the device path yet "
+                "(available: IP, IP1, IP2, ISS, ISS1, ISS2).".format(spatial_algorithm)
+            )
+        if source_algorithm != "MM":
+            raise NotImplementedError("source_algorithm='ME' is not built for the device path yet.")
+        if partitioning:
+            raise NotImplementedError("partitioning=True is not built for the device path yet.")
+        self.spatial_algorithm = spatial_algorithm
+        self.source_algorithm = source_algorithm
+        self.domain = domain
+        self.normalization = normalization
+        if pair_selector is None:
+            if spatial_algorithm in ["IP2", "ISS2"]:
+                self.pair_selector = sequential_pair_selector
+        else:
+            self.pair_selector = pair_selector
+        # fails early (before any upload) when the floor cannot run on the device
+        device_flooring(self.flooring_fn)
+
+    def __call__(
+        self, input: np.ndarray, n_iter: int = 100, initial_call: bool = True, **kwargs
+    ) -> np.ndarray:
+        """Separate a frequency-domain multichannel mixture.
+
+        Args:
+            input: ``(n_channels, n_bins, n_frames)`` complex (or 4-D batch of such).
+            n_iter: number of ``update_once`` rounds.
+            initial_call: run loss/callbacks once before iterating.
+            kwargs: attributes to inject before initialisation (``basis``, ``activation``,
+                ``demix_filter``), as in the reference.
+
+        Returns:
+            Separated spectrograms, same shape as ``input``.
+        """
+        self._bind_input(input)
+        self._reset(flooring_fn=self.flooring_fn, **kwargs)
+        IterativeMethodBase.__call__(self, n_iter=n_iter, initial_call=initial_call)
+        if self.scale_restoration:
+            self.restore_scale()
+        if self._uses_filter():
+            self._state_set_dev("output", _ops.separate(self._X, self._state_dev("demix_filter")))
+        return self.output
+
+    def __repr__(self) -> str:
+        s = "{}(n_basis={}{}, spatial_algorithm={}, source_algorithm={}, domain={}".format(
+            type(self).__name__, self.n_basis, self._repr_model(), self.spatial_algorithm,
+            self.source_algorithm, self.domain
+        )
+        s += ", partitioning={}, normalization={}, scale_restoration={}, record_loss={}".format(
+            self.partitioning, self.normalization, self.scale_restoration, self.record_loss
+        )
+        if self.scale_restoration:
+            s += ", reference_id={}".format(self.reference_id)
+        return s + ")"
+
+    def _repr_model(self) -> str:
+        return ""
+
+    def _reset(self, flooring_fn="self", **kwargs) -> None:
+        """ref: ssspy/bss/ilrma.py:875-898."""
+        flooring_fn = choose_flooring_fn(flooring_fn, method=self)
+        super()._reset(flooring_fn=flooring_fn, **kwargs)
+        if self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"]:
+            self.demix_filter = None
+
+    # -- one iteration -----------------------------------------------------------------------
+    def _is_stock(self) -> bool:
+        cls = type(self)
+        return all(
+            getattr(cls, name) is getattr(_MMILRMA, name)
+            for name in ("update_source_model", "update_spatial_model", "normalize",
+                         "update_basis_mm", "update_activation_mm", "update_spatial_model_ip1",
+                         "normalize_by_power")
+        )
+
+    def update_once(self, flooring_fn="self") -> None:
+        """Source model (basis, activation), spatial model, normalisation.
+
+        ref: ssspy/bss/ilrma.py:900-922.  With the stock methods and the IP1 path the whole
+        iteration is one C-ABI call (five kernel launches on the current stream).
+        """
+        if (self.spatial_algorithm in _IP1 and self._uses_filter() and self._is_stock()
+                and self._power_normalization_or_off()):
+            floor = self._resolve_floor(flooring_fn)
+            B, N, F, T = self._X.shape
+            if self._U is None:
+                self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
+            _ops.ilrma_ip1_update(
+                self._X, self._C() if self.normalization else None,
+                self._state_dev("demix_filter"), self._state_dev("basis"),
+                self._state_dev("activation"), self._U, float(self.domain),
+                bool(self.normalization), floor, self._ws, self._ws_bytes, self._info_tensor(),
+                model=self._model,
+            )
+            for name in ("demix_filter", "basis", "activation"):
+                self._state_touch(name)
+            return
+        self.update_source_model(flooring_fn=flooring_fn)
+        self.update_spatial_model(flooring_fn=flooring_fn)
+        if self.normalization:
+            self.normalize(flooring_fn=flooring_fn)
+
+    def _power_normalization_or_off(self) -> bool:
+        return (not self.normalization) or type(self.normalization) is bool \
+            or self.normalization == "power"
+
+    def update_source_model(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/ilrma.py:924-978."""
+        if self.source_algorithm == "MM":
+            self.update_source_model_mm(flooring_fn=flooring_fn)
+        else:
+            raise NotImplementedError("source_algorithm='ME' is not built for the device path yet.")
+
+    def update_source_model_mm(self, flooring_fn="self") -> None:
+        self.update_basis_mm(flooring_fn=flooring_fn)
+        self.update_activation_mm(flooring_fn=flooring_fn)
+
+    def _source_and_filter(self):
+        """(spectrogram tensor, filter tensor or None) whose |W x|^2 the MM updates use."""
+        if self._uses_filter():
+            return self._X, self._state_dev("demix_filter")
+        return self._state_dev("output"), None
+
+    def update_basis_mm(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/ilrma.py:1051-1128."""
+        src, W = self._source_and_filter()
+        _ops.ilrma_update_basis(src, W, self._state_dev("basis"), self._state_dev("activation"),
+                                float(self.domain), self._resolve_floor(flooring_fn), self._ws,
+                                self._ws_bytes, model=self._model)
+        self._state_touch("basis")
+
+    def update_activation_mm(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/ilrma.py:1130-1204."""
+        src, W = self._source_and_filter()
+        _ops.ilrma_update_activation(src, W, self._state_dev("basis"),
+                                     self._state_dev("activation"), float(self.domain),
+                                     self._resolve_floor(flooring_fn), self._ws, self._ws_bytes,
+                                     model=self._model)
+        self._state_touch("activation")
+
+    def update_spatial_model(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/ilrma.py:1403-1438."""
+        if self.spatial_algorithm in _IP1:
+            self.update_spatial_model_ip1(flooring_fn=flooring_fn)
+        elif self.spatial_algorithm in _ISS1:
+            self.update_spatial_model_iss1(flooring_fn=flooring_fn)
+        elif self.spatial_algorithm in _IP2:
+            self.update_spatial_model_ip2(flooring_fn=flooring_fn)
+        elif self.spatial_algorithm in _ISS2:
+            self.update_spatial_model_iss2(flooring_fn=flooring_fn)
+        else:
+            raise NotImplementedError("Not support {}.".format(self.spatial_algorithm))
+
+    def update_spatial_model_ip2(self, flooring_fn="self") -> None:
+        """Weighted covariance + pairwise iterative projection.  ref: ssspy/bss/ilrma.py:1509-1633."""
+        B, N, F, T = self._X.shape
+        if self._U is None:
+            self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
+        _ops.ilrma_weighted_covariance(self._X, self._state_dev("basis"),
+                                       self._state_dev("activation"), float(self.domain),
+                                       self._ws, self._ws_bytes, out=self._U,
+                                       W=self._state_dev("demix_filter"), model=self._model,
+                                       flooring=self._resolve_floor(flooring_fn))
+        _ops.update_by_ip2(self._state_dev("demix_filter"), self._U,
+                           resolve_pairs(getattr(self, "pair_selector", None), N),
+                           self._resolve_floor(flooring_fn), self._info_tensor())
+        self._state_touch("demix_filter")
+
+    def update_spatial_model_iss2(self, flooring_fn="self") -> None:
+        """Pairwise iterative source steering on per-bin statistics.  ref: ilrma.py:1698-1792."""
+        Y = self._state_dev("output")
+        N = Y.shape[1]
+        varphi = _ops.ilrma_iss_weight(self._state_dev("basis"), self._state_dev("activation"),
+                                       float(self.domain), Y=Y, model=self._model,
+                                       flooring=self._resolve_floor(flooring_fn))
+        Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
+        G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N),
+                                self._resolve_floor(flooring_fn), self._info_tensor())
+        _ops.separate(Y, G, out=Y)
+        self._state_touch("output")
+
+    def update_spatial_model_ip1(self, flooring_fn="self") -> None:
+        """Weighted covariance + iterative projection.  ref: ssspy/bss/ilrma.py:1440-1507."""
+        B, N, F, T = self._X.shape
+        if self._U is None:
+            self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
+        _ops.ilrma_weighted_covariance(self._X, self._state_dev("basis"),
+                                       self._state_dev("activation"), float(self.domain),
+                                       self._ws, self._ws_bytes, out=self._U,
+                                       W=self._state_dev("demix_filter"), model=self._model,
+                                       flooring=self._resolve_floor(flooring_fn))
+        _ops.update_by_ip1(self._state_dev("demix_filter"), self._U,
+                           self._resolve_floor(flooring_fn), self._info_tensor())
+        self._state_touch("demix_filter")
+
+    def update_spatial_model_iss1(self, flooring_fn="self") -> None:
+        """Iterative source steering on per-bin statistics.  ref: ssspy/bss/ilrma.py:1635-1696."""
+        Y = self._state_dev("output")
+        N = Y.shape[1]
+        varphi = _ops.ilrma_iss_weight(self._state_dev("basis"), self._state_dev("activation"),
+                                       float(self.domain), Y=Y, model=self._model,
+                                       flooring=self._resolve_floor(flooring_fn))
+        floor = self._resolve_floor(flooring_fn)
+        if Y.shape[-1] <= _ops.iss1_fused_max_frames(N):
+            _ops.iss1_fused(Y, varphi, _lib.WEIGHT_BIN_FRAME, floor)
+        else:
+            Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
+            G = _ops.iss1_transform(Vc, floor)
+            _ops.separate(Y, G, out=Y)
+        self._state_touch("output")
+
+    def normalize(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/ilrma.py:333-363."""
+        normalization = self.normalization
+        assert normalization, "Set normalization."
+        if type(normalization) is bool:
+            normalization = "power"
+        if normalization == "power":
+            self.normalize_by_power(flooring_fn=flooring_fn)
+        elif normalization == "projection_back":
+            raise NotImplementedError(
+                "normalization='projection_back' is not built for the device path yet."
+            )
+        else:
+            raise NotImplementedError("Normalization {} is not implemented.".format(normalization))
+
+    def normalize_by_power(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/ilrma.py:365-444 (no partitioning)."""
+        floor = self._resolve_floor(flooring_fn)
+        if self._uses_filter():
+            _ops.ilrma_normalize_filter(self._state_dev("demix_filter"), self._C(),
+                                        self._state_dev("basis"), float(self.domain), floor,
+                                        self._ws, self._ws_bytes)
+            self._state_touch("demix_filter")
+        else:
+            _ops.ilrma_normalize_output(self._state_dev("output"), self._state_dev("basis"),
+                                        float(self.domain), floor, self._ws, self._ws_bytes)
+            self._state_touch("output")
+        self._state_touch("basis")
+
+    def compute_loss(self) -> float:
+        """Negative log-likelihood (ref: ssspy/bss/ilrma.py:1910-1967)."""
+        T, V = self._state_dev("basis"), self._state_dev("activation")
+        if self._uses_filter():
+            W = self._state_dev("demix_filter")
+            data = _ops.ilrma_loss_data(self._X, W, T, V, float(self.domain), model=self._model)
+        else:
+            Y = self._state_dev("output")
+            W = _ops.demix_from_covariance(_ops.cross_covariance(Y, self._X), self._C(),
+                                           self._info_tensor())
+            data = _ops.ilrma_loss_data(Y, None, T, V, float(self.domain), model=self._model)
+        return self._host_loss(data, _ops.sum_logdet(W))
+
+
+class GaussILRMA(_MMILRMA):
     """Gauss-ILRMA (ref: ssspy/bss/ilrma.py:582-1989).
 
     Args mirror the reference: ``n_basis``, ``spatial_algorithm`` ("IP"/"IP1"/"ISS"/"ISS1"
@@ -228,248 +495,118 @@ class GaussILRMA(ILRMABase):
         assert 0 < domain <= 2, "domain parameter should be chosen from [0, 2]."
         if source_algorithm == "ME":
             assert domain == 2, "domain parameter should be 2 when you specify ME algorithm."
-        if spatial_algorithm not in _IP1 + _ISS1 + _IP2 + _ISS2:
-            raise NotImplementedError(
-                "spatial_algorithm={!r} is not built for the device path yet "
-                "(available: IP, IP1, IP2, ISS, ISS1, ISS2).".format(spatial_algorithm)
-            )
-        if source_algorithm != "MM":
-            raise NotImplementedError("source_algorithm='ME' is not built for the device path yet.")
-        if partitioning:
-            raise NotImplementedError("partitioning=True is not built for the device path yet.")
-        self.spatial_algorithm = spatial_algorithm
-        self.source_algorithm = source_algorithm
-        self.domain = domain
-        self.normalization = normalization
-        if pair_selector is None:
-            if spatial_algorithm in ["IP2", "ISS2"]:
-                self.pair_selector = sequential_pair_selector
-        else:
-            self.pair_selector = pair_selector
         valid_keys = set(self._ipa_default_kwargs) if spatial_algorithm == "IPA" else set()
         invalid_keys = set(kwargs) - valid_keys
         assert invalid_keys == set(), "Invalid keywords {} are given.".format(invalid_keys)
-        # fails early (before any upload) when the floor cannot run on the device
-        device_flooring(self.flooring_fn)
+        self._configure(spatial_algorithm, source_algorithm, domain, partitioning, normalization,
+                        pair_selector)
 
-    def __call__(
-        self, input: np.ndarray, n_iter: int = 100, initial_call: bool = True, **kwargs
-    ) -> np.ndarray:
-        """Separate a frequency-domain multichannel mixture.
 
-        Args:
-            input: ``(n_channels, n_bins, n_frames)`` complex (or 4-D batch of such).
-            n_iter: number of ``update_once`` rounds.
-            initial_call: run loss/callbacks once before iterating.
-            kwargs: attributes to inject before initialisation (``basis``, ``activation``,
-                ``demix_filter``), as in the reference.
+class TILRMA(_MMILRMA):
+    """ILRMA on the Student-t distribution (ref: ssspy/bss/ilrma.py:1992-3334).
 
-        Returns:
-            Separated spectrograms, same shape as ``input``.
-        """
-        self._bind_input(input)
-        self._reset(flooring_fn=self.flooring_fn, **kwargs)
-        IterativeMethodBase.__call__(self, n_iter=n_iter, initial_call=initial_call)
-        if self.scale_restoration:
-            self.restore_scale()
-        if self._uses_filter():
-            self._state_set_dev("output", _ops.separate(self._X, self._state_dev("demix_filter")))
-        return self.output
+    Args as the reference: ``n_basis``, ``dof`` (degree of freedom nu > 0), then the
+    ``GaussILRMA`` arguments.  ``spatial_algorithm="IPA"`` raises ``ValueError`` as upstream.
+    """
 
-    def __repr__(self) -> str:
-        s = "GaussILRMA(n_basis={}, spatial_algorithm={}, source_algorithm={}, domain={}".format(
-            self.n_basis, self.spatial_algorithm, self.source_algorithm, self.domain
+    def __init__(
+        self,
+        n_basis: int,
+        dof: float,
+        spatial_algorithm: str = "IP",
+        source_algorithm: str = "MM",
+        domain: float = 2,
+        partitioning: bool = False,
+        flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = functools.partial(
+            max_flooring, eps=EPS
+        ),
+        pair_selector: Optional[Callable[[int], Iterable[Tuple[int, int]]]] = None,
+        callbacks: Optional[Union[Callable, List[Callable]]] = None,
+        normalization: Optional[Union[bool, str]] = True,
+        scale_restoration: Union[bool, str] = True,
+        record_loss: bool = True,
+        reference_id: int = 0,
+        rng: Optional[np.random.Generator] = None,
+    ) -> None:
+        super().__init__(
+            n_basis=n_basis,
+            partitioning=partitioning,
+            flooring_fn=flooring_fn,
+            callbacks=callbacks,
+            scale_restoration=scale_restoration,
+            record_loss=record_loss,
+            reference_id=reference_id,
+            rng=rng,
         )
-        s += ", partitioning={}, normalization={}, scale_restoration={}, record_loss={}".format(
-            self.partitioning, self.normalization, self.scale_restoration, self.record_loss
+        assert spatial_algorithm in spatial_algorithms, "Not support {}.".format(spatial_algorithms)
+        assert source_algorithm in source_algorithms, "Not support {}.".format(source_algorithm)
+        assert 0 < domain <= 2, "domain parameter should be chosen from [0, 2]."
+        if spatial_algorithm == "IPA":
+            raise ValueError("IPA is not supported for t-ILRMA.")
+        if source_algorithm == "ME":
+            assert domain == 2, "domain parameter should be 2 when you specify ME algorithm."
+        assert dof > 0, "dof should be positive."
+        self.dof = dof
+        self._configure(spatial_algorithm, source_algorithm, domain, partitioning, normalization,
+                        pair_selector)
+
+    @property
+    def _model(self):
+        return (_lib.SOURCE_T, float(self.dof))
+
+    def _repr_model(self) -> str:
+        return ", dof={}".format(self.dof)
+
+
+class GGDILRMA(_MMILRMA):
+    """ILRMA on the generalised Gaussian distribution (ref: ssspy/bss/ilrma.py:3337-4410).
+
+    Args as the reference: ``n_basis``, ``beta`` (shape parameter in (0, 2)), then the
+    ``GaussILRMA`` arguments (``source_algorithm`` must be "MM").
+    """
+
+    def __init__(
+        self,
+        n_basis: int,
+        beta: float,
+        spatial_algorithm: str = "IP",
+        source_algorithm: str = "MM",
+        domain: float = 2,
+        partitioning: bool = False,
+        flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = functools.partial(
+            max_flooring, eps=EPS
+        ),
+        pair_selector: Optional[Callable[[int], Iterable[Tuple[int, int]]]] = None,
+        callbacks: Optional[Union[Callable, List[Callable]]] = None,
+        normalization: Optional[Union[bool, str]] = True,
+        scale_restoration: Union[bool, str] = True,
+        record_loss: bool = True,
+        reference_id: int = 0,
+        rng: Optional[np.random.Generator] = None,
+    ) -> None:
+        super().__init__(
+            n_basis=n_basis,
+            partitioning=partitioning,
+            flooring_fn=flooring_fn,
+            callbacks=callbacks,
+            scale_restoration=scale_restoration,
+            record_loss=record_loss,
+            reference_id=reference_id,
+            rng=rng,
         )
-        if self.scale_restoration:
-            s += ", reference_id={}".format(self.reference_id)
-        return s + ")"
+        assert 0 < beta < 2, "Shape parameter {} shoule be chosen from (0, 2).".format(beta)
+        assert spatial_algorithm in spatial_algorithms, "Not support {}.".format(spatial_algorithms)
+        assert source_algorithm == "MM", "Not support {}.".format(source_algorithm)
+        assert 0 < domain <= 2, "domain parameter should be chosen from [0, 2]."
+        if spatial_algorithm == "IPA":
+            raise ValueError("IPA is not supported for GGD-ILRMA.")
+        self.beta = beta
+        self._configure(spatial_algorithm, source_algorithm, domain, partitioning, normalization,
+                        pair_selector)
 
-    def _reset(self, flooring_fn="self", **kwargs) -> None:
-        """ref: ssspy/bss/ilrma.py:875-898."""
-        flooring_fn = choose_flooring_fn(flooring_fn, method=self)
-        super()._reset(flooring_fn=flooring_fn, **kwargs)
-        if self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"]:
-            self.demix_filter = None
+    @property
+    def _model(self):
+        return (_lib.SOURCE_GGD, float(self.beta))
 
-    # -- one iteration -----------------------------------------------------------------------
-    def _is_stock(self) -> bool:
-        cls = type(self)
-        return all(
-            getattr(cls, name) is getattr(GaussILRMA, name)
-            for name in ("update_source_model", "update_spatial_model", "normalize",
-                         "update_basis_mm", "update_activation_mm", "update_spatial_model_ip1",
-                         "normalize_by_power")
-        )
-
-    def update_once(self, flooring_fn="self") -> None:
-        """Source model (basis, activation), spatial model, normalisation.
-
-        ref: ssspy/bss/ilrma.py:900-922.  With the stock methods and the IP1 path the whole
-        iteration is one C-ABI call (five kernel launches on the current stream).
-        """
-        if (self.spatial_algorithm in _IP1 and self._uses_filter() and self._is_stock()
-                and self._power_normalization_or_off()):
-            floor = self._resolve_floor(flooring_fn)
-            B, N, F, T = self._X.shape
-            if self._U is None:
-                self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
-            _ops.gauss_ilrma_ip1_update(
-                self._X, self._C() if self.normalization else None,
-                self._state_dev("demix_filter"), self._state_dev("basis"),
-                self._state_dev("activation"), self._U, float(self.domain),
-                bool(self.normalization), floor, self._ws, self._ws_bytes, self._info_tensor(),
-            )
-            for name in ("demix_filter", "basis", "activation"):
-                self._state_touch(name)
-            return
-        self.update_source_model(flooring_fn=flooring_fn)
-        self.update_spatial_model(flooring_fn=flooring_fn)
-        if self.normalization:
-            self.normalize(flooring_fn=flooring_fn)
-
-    def _power_normalization_or_off(self) -> bool:
-        return (not self.normalization) or type(self.normalization) is bool \
-            or self.normalization == "power"
-
-    def update_source_model(self, flooring_fn="self") -> None:
-        """ref: ssspy/bss/ilrma.py:924-978."""
-        if self.source_algorithm == "MM":
-            self.update_source_model_mm(flooring_fn=flooring_fn)
-        else:
-            raise NotImplementedError("source_algorithm='ME' is not built for the device path yet.")
-
-    def update_source_model_mm(self, flooring_fn="self") -> None:
-        self.update_basis_mm(flooring_fn=flooring_fn)
-        self.update_activation_mm(flooring_fn=flooring_fn)
-
-    def _source_and_filter(self):
-        """(spectrogram tensor, filter tensor or None) whose |W x|^2 the MM updates use."""
-        if self._uses_filter():
-            return self._X, self._state_dev("demix_filter")
-        return self._state_dev("output"), None
-
-    def update_basis_mm(self, flooring_fn="self") -> None:
-        """ref: ssspy/bss/ilrma.py:1051-1128."""
-        src, W = self._source_and_filter()
-        _ops.ilrma_update_basis(src, W, self._state_dev("basis"), self._state_dev("activation"),
-                                float(self.domain), self._resolve_floor(flooring_fn), self._ws,
-                                self._ws_bytes)
-        self._state_touch("basis")
-
-    def update_activation_mm(self, flooring_fn="self") -> None:
-        """ref: ssspy/bss/ilrma.py:1130-1204."""
-        src, W = self._source_and_filter()
-        _ops.ilrma_update_activation(src, W, self._state_dev("basis"),
-                                     self._state_dev("activation"), float(self.domain),
-                                     self._resolve_floor(flooring_fn), self._ws, self._ws_bytes)
-        self._state_touch("activation")
-
-    def update_spatial_model(self, flooring_fn="self") -> None:
-        """ref: ssspy/bss/ilrma.py:1403-1438."""
-        if self.spatial_algorithm in _IP1:
-            self.update_spatial_model_ip1(flooring_fn=flooring_fn)
-        elif self.spatial_algorithm in _ISS1:
-            self.update_spatial_model_iss1(flooring_fn=flooring_fn)
-        elif self.spatial_algorithm in _IP2:
-            self.update_spatial_model_ip2(flooring_fn=flooring_fn)
-        elif self.spatial_algorithm in _ISS2:
-            self.update_spatial_model_iss2(flooring_fn=flooring_fn)
-        else:
-            raise NotImplementedError("Not support {}.".format(self.spatial_algorithm))
-
-    def update_spatial_model_ip2(self, flooring_fn="self") -> None:
-        """Weighted covariance + pairwise iterative projection.  ref: ssspy/bss/ilrma.py:1509-1633."""
-        B, N, F, T = self._X.shape
-        if self._U is None:
-            self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
-        _ops.ilrma_weighted_covariance(self._X, self._state_dev("basis"),
-                                       self._state_dev("activation"), float(self.domain),
-                                       self._ws, self._ws_bytes, out=self._U)
-        _ops.update_by_ip2(self._state_dev("demix_filter"), self._U,
-                           resolve_pairs(getattr(self, "pair_selector", None), N),
-                           self._resolve_floor(flooring_fn), self._info_tensor())
-        self._state_touch("demix_filter")
-
-    def update_spatial_model_iss2(self, flooring_fn="self") -> None:
-        """Pairwise iterative source steering on per-bin statistics.  ref: ilrma.py:1698-1792."""
-        Y = self._state_dev("output")
-        N = Y.shape[1]
-        varphi = _ops.ilrma_iss_weight(self._state_dev("basis"), self._state_dev("activation"),
-                                       float(self.domain))
-        Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
-        G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N),
-                                self._resolve_floor(flooring_fn), self._info_tensor())
-        _ops.separate(Y, G, out=Y)
-        self._state_touch("output")
-
-    def update_spatial_model_ip1(self, flooring_fn="self") -> None:
-        """Weighted covariance + iterative projection.  ref: ssspy/bss/ilrma.py:1440-1507."""
-        B, N, F, T = self._X.shape
-        if self._U is None:
-            self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
-        _ops.ilrma_weighted_covariance(self._X, self._state_dev("basis"),
-                                       self._state_dev("activation"), float(self.domain),
-                                       self._ws, self._ws_bytes, out=self._U)
-        _ops.update_by_ip1(self._state_dev("demix_filter"), self._U,
-                           self._resolve_floor(flooring_fn), self._info_tensor())
-        self._state_touch("demix_filter")
-
-    def update_spatial_model_iss1(self, flooring_fn="self") -> None:
-        """Iterative source steering on per-bin statistics.  ref: ssspy/bss/ilrma.py:1635-1696."""
-        Y = self._state_dev("output")
-        N = Y.shape[1]
-        varphi = _ops.ilrma_iss_weight(self._state_dev("basis"), self._state_dev("activation"),
-                                       float(self.domain))
-        floor = self._resolve_floor(flooring_fn)
-        if Y.shape[-1] <= _ops.iss1_fused_max_frames(N):
-            _ops.iss1_fused(Y, varphi, _lib.WEIGHT_BIN_FRAME, floor)
-        else:
-            Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
-            G = _ops.iss1_transform(Vc, floor)
-            _ops.separate(Y, G, out=Y)
-        self._state_touch("output")
-
-    def normalize(self, flooring_fn="self") -> None:
-        """ref: ssspy/bss/ilrma.py:333-363."""
-        normalization = self.normalization
-        assert normalization, "Set normalization."
-        if type(normalization) is bool:
-            normalization = "power"
-        if normalization == "power":
-            self.normalize_by_power(flooring_fn=flooring_fn)
-        elif normalization == "projection_back":
-            raise NotImplementedError(
-                "normalization='projection_back' is not built for the device path yet."
-            )
-        else:
-            raise NotImplementedError("Normalization {} is not implemented.".format(normalization))
-
-    def normalize_by_power(self, flooring_fn="self") -> None:
-        """ref: ssspy/bss/ilrma.py:365-444 (no partitioning)."""
-        floor = self._resolve_floor(flooring_fn)
-        if self._uses_filter():
-            _ops.ilrma_normalize_filter(self._state_dev("demix_filter"), self._C(),
-                                        self._state_dev("basis"), float(self.domain), floor,
-                                        self._ws, self._ws_bytes)
-            self._state_touch("demix_filter")
-        else:
-            _ops.ilrma_normalize_output(self._state_dev("output"), self._state_dev("basis"),
-                                        float(self.domain), floor, self._ws, self._ws_bytes)
-            self._state_touch("output")
-        self._state_touch("basis")
-
-    def compute_loss(self) -> float:
-        """Negative log-likelihood (ref: ssspy/bss/ilrma.py:1910-1967)."""
-        T, V = self._state_dev("basis"), self._state_dev("activation")
-        if self._uses_filter():
-            W = self._state_dev("demix_filter")
-            data = _ops.ilrma_loss_data(self._X, W, T, V, float(self.domain))
-        else:
-            Y = self._state_dev("output")
-            W = _ops.demix_from_covariance(_ops.cross_covariance(Y, self._X), self._C(),
-                                           self._info_tensor())
-            data = _ops.ilrma_loss_data(Y, None, T, V, float(self.domain))
-        return self._host_loss(data, _ops.sum_logdet(W))
+    def _repr_model(self) -> str:
+        return ", beta={}".format(self.beta)

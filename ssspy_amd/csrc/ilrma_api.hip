@@ -4,18 +4,19 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "ilrma_params.hpp"
 
 namespace ssspy {
 
 #define DECL_N(n)                                                                               \
   int ilrma_basis_n##n(const void *, const void *, const double *, double *, const double *,   \
-                       int, int, int, int, double, int, double, hipStream_t);                  \
+                       IlrmaDims, hipStream_t);                                                \
   int ilrma_activation_n##n(const void *, const void *, const double *, const double *, double *, \
-                            int, int, int, int, int, double, hipStream_t);                     \
-  int ilrma_wcov_n##n(const void *, const double *, const double *, void *, int, int, int, int, \
-                      double, hipStream_t);                                                    \
-  int ilrma_loss_n##n(const void *, const void *, const double *, const double *, double *, int, \
-                      int, int, int, double, hipStream_t);
+                            int, IlrmaDims, hipStream_t);                                      \
+  int ilrma_wcov_n##n(const void *, const void *, const double *, const double *, void *,       \
+                      IlrmaDims, hipStream_t);                                                 \
+  int ilrma_loss_n##n(const void *, const void *, const double *, const double *, double *,     \
+                      IlrmaDims, hipStream_t);
 DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
 #undef DECL_N
 
@@ -37,9 +38,17 @@ DECL_FAST(2) DECL_FAST(3) DECL_FAST(4)
     default: return fn##_n4(__VA_ARGS__);            \
   }
 
-static inline bool fast_path(int N, int T, int K, double domain) {
+static inline bool fast_path(int N, int T, int K, double domain, int model = SSSPY_SOURCE_GAUSS) {
   static const bool disabled = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;
-  return !disabled && N >= 2 && N <= 4 && K <= 16 && (T % 2 == 0) && domain == 2.0;
+  return !disabled && model == SSSPY_SOURCE_GAUSS && N >= 2 && N <= 4 && K <= 16 &&
+         (T % 2 == 0) && domain == 2.0;
+}
+
+static inline int check_model(int model, double param) {
+  if (model == SSSPY_SOURCE_GAUSS) return SSSPY_OK;
+  if (model == SSSPY_SOURCE_T && param > 0.0) return SSSPY_OK;
+  if (model == SSSPY_SOURCE_GGD && param > 0.0 && param < 2.0) return SSSPY_OK;
+  return fail(SSSPY_ERR_BADARG, "bad source model / model_param (t: dof > 0, GGD: 0 < beta < 2)");
 }
 
 #define ILRMA_DISPATCH(N_, fn, ...)                                                  \
@@ -108,8 +117,7 @@ int row_power(const void *W, const void *C, double *qbuf, int B, int F, int N, h
 __global__ __launch_bounds__(256) void k_ilrma_activation_finalize(double *act,
                                                                    const double *__restrict__ part,
                                                                    int N, int K, int T,
-                                                                   int nchunks, double p,
-                                                                   int floor_kind, double eps) {
+                                                                   int nchunks, IlrmaDims d) {
   const int b = blockIdx.z, n = blockIdx.y;
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over K*T
   if (e >= (long long)K * T) return;
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(256) void k_ilrma_activation_finalize(double *act,
     sd += part[base + (long long)K * T + e];
   }
   double *dst = act + ((long long)b * N + n) * K * T + e;
-  *dst = apply_floor(((p == 2.0) ? sqrt(sn / sd) : pow(sn / sd, p / (p + 2.0))) * (*dst), floor_kind, eps);
+  *dst = apply_floor(mm_ratio_pow(sn, sd, d) * (*dst), d.floor_kind, d.floor_eps);
 }
 
 
@@ -206,18 +214,21 @@ __global__ __launch_bounds__(256) void k_ilrma_normalize_output(c128 *Y, double 
 }
 
 // ------------------------------------------------------------------------------ ISS weight
-__global__ __launch_bounds__(256) void k_ilrma_iss_weight(const double *__restrict__ basis,
+__global__ __launch_bounds__(256) void k_ilrma_iss_weight(const c128 *__restrict__ Y,
+                                                          const double *__restrict__ basis,
                                                           const double *__restrict__ act,
                                                           double *__restrict__ varphi, int N,
-                                                          int F, int T, int K, double p) {
+                                                          IlrmaDims d) {
   const int i = blockIdx.x, n = blockIdx.y, b = blockIdx.z;
+  const int F = d.F, T = d.T, K = d.K;
   const double *tr = basis + (((long long)b * N + n) * F + i) * K;
   const double *Vn = act + ((long long)b * N + n) * K * T;
-  double *out = varphi + (((long long)b * N + n) * F + i) * T;
+  const long long row = (((long long)b * N + n) * F + i) * T;
   for (int j = threadIdx.x; j < T; j += blockDim.x) {
     double r = 0.0;
     for (int k = 0; k < K; ++k) r = fma(tr[k], Vn[(long long)k * T + j], r);
-    out[j] = (p == 2.0) ? 1.0 / r : 1.0 / pow(r, 2.0 / p);
+    const double P = (d.model != SSSPY_SOURCE_GAUSS) ? cabs2(Y[row + j]) : 0.0;
+    varphi[row + j] = spatial_weight(P, r, d);
   }
 }
 
@@ -255,27 +266,32 @@ size_t ssspy_ilrma_workspace_bytes(int B, int N, int F, int T, int K) {
   return ilrma_ws(B, N, F, T, K).total;
 }
 
+static IlrmaDims make_dims(int B, int F, int T, int K, double domain, int model, double mparam,
+                           int floor_kind, double floor_eps) {
+  return IlrmaDims{B, F, T, K, domain, model, mparam, floor_kind, floor_eps};
+}
+
 int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const double *activation,
-                             int B, int N, int F, int T, int K, double domain, int floor_kind,
-                             double floor_eps, void *workspace, size_t workspace_bytes,
-                             void *stream) {
+                             int B, int N, int F, int T, int K, double domain, int source_model,
+                             double model_param, int floor_kind, double floor_eps, void *workspace,
+                             size_t workspace_bytes, void *stream) {
   SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0, "update_basis: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_basis: n_basis must be in [1, 64]");
   SSSPY_REQUIRE(domain > 0.0 && domain <= 2.0, "update_basis: domain must be in (0, 2]");
+  int rc = check_model(source_model, model_param);
+  if (rc) return rc;
   const IlrmaWs w = ilrma_ws(B, N, F, T, K);
   SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "update_basis: workspace too small");
   char *ws = (char *)workspace;
   hipStream_t st = as_stream(stream);
-  if (fast_path(N, T, K, domain)) {
+  if (fast_path(N, T, K, domain, source_model)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_basis, X, W, basis, activation, B, F, T, K, floor_kind,
                         floor_eps, frame_chunks(B, F, T), (double *)(ws + w.bpart), st);
   }
+  const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   double *out = K > 16 ? (double *)(ws + w.btmp) : basis;
-  auto run = [&]() -> int {
-    ILRMA_DISPATCH(N, ilrma_basis, X, W, basis, out, activation, B, F, T, K, domain, floor_kind,
-                   floor_eps, st);
-  };
-  int rc = run();
+  auto run = [&]() -> int { ILRMA_DISPATCH(N, ilrma_basis, X, W, basis, out, activation, d, st); };
+  rc = run();
   if (rc) return rc;
   if (out != basis) {
     hipError_t e = hipMemcpyAsync(basis, out, (size_t)B * N * F * K * sizeof(double),
@@ -287,56 +303,65 @@ int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const 
 
 int ssspy_ilrma_update_activation(const void *X, const void *W, const double *basis,
                                   double *activation, int B, int N, int F, int T, int K,
-                                  double domain, int floor_kind, double floor_eps, void *workspace,
+                                  double domain, int source_model, double model_param,
+                                  int floor_kind, double floor_eps, void *workspace,
                                   size_t workspace_bytes, void *stream) {
   SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0,
                 "update_activation: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_activation: n_basis must be in [1, 64]");
+  int rc = check_model(source_model, model_param);
+  if (rc) return rc;
   const IlrmaWs w = ilrma_ws(B, N, F, T, K);
   SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "update_activation: workspace too small");
   double *part = (double *)((char *)workspace + w.act_part);
   const int chunks = act_chunks(B, N, F, T, K);
   hipStream_t st = as_stream(stream);
+  const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   auto run = [&]() -> int {
-    if (fast_path(N, T, K, domain)) {
+    if (fast_path(N, T, K, domain, source_model)) {
       ILRMA_FAST_DISPATCH(N, ilrma_fast_activation, X, W, basis, activation, part, chunks, B, F, T,
                           K, st);
     }
-    ILRMA_DISPATCH(N, ilrma_activation, X, W, basis, activation, part, chunks, B, F, T, K, domain,
-                   st);
+    ILRMA_DISPATCH(N, ilrma_activation, X, W, basis, activation, part, chunks, d, st);
   };
-  int rc = run();
+  rc = run();
   if (rc) return rc;
   dim3 g2((unsigned)(((long long)K * T + 255) / 256), N, B);
   hipLaunchKernelGGL(k_ilrma_activation_finalize, g2, dim3(256), 0, st, activation,
-                     (const double *)part, N, K, T, chunks, domain, floor_kind, floor_eps);
+                     (const double *)part, N, K, T, chunks, d);
   return check_launch("k_ilrma_activation_finalize");
 }
 
-// covariance into `dst`; returns the number of partial chunks left at dst (chunk c at
-// dst + c * B*F*N^3): 1 means dst holds the final U.
-static int wcov_into(const void *X, const double *basis, const double *activation, void *dst, int B,
-                     int N, int F, int T, int K, double domain, int chunks, hipStream_t st) {
-  if (fast_path(N, T, K, domain)) {
-    ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, basis, activation, dst, B, F, T, K, chunks, st);
+// covariance into `dst`; with `chunks` > 1 (Gauss fast path, small batches) chunk c lands at
+// dst + c * B*F*N^3 and the caller folds them.
+static int wcov_into(const void *X, const void *W, const double *basis, const double *activation,
+                     void *dst, int N, const IlrmaDims &d, int chunks, hipStream_t st) {
+  if (fast_path(N, d.T, d.K, d.p, d.model)) {
+    ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, basis, activation, dst, d.B, d.F, d.T, d.K, chunks,
+                        st);
   }
-  ILRMA_DISPATCH(N, ilrma_wcov, X, basis, activation, dst, B, F, T, K, domain, st);
+  ILRMA_DISPATCH(N, ilrma_wcov, X, W, basis, activation, dst, d, st);
 }
 
-int ssspy_ilrma_weighted_covariance(const void *X, const double *basis, const double *activation,
-                                    void *U, int B, int N, int F, int T, int K, double domain,
-                                    void *workspace, size_t workspace_bytes, void *stream) {
+int ssspy_ilrma_weighted_covariance(const void *X, const void *W, const double *basis,
+                                    const double *activation, void *U, int B, int N, int F, int T,
+                                    int K, double domain, int source_model, double model_param,
+                                    int floor_kind, double floor_eps, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
   SSSPY_REQUIRE(X && basis && activation && U && B > 0 && F > 0 && T > 0,
                 "ilrma_weighted_covariance: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "ilrma_weighted_covariance: bad n_basis");
+  int rc = check_model(source_model, model_param);
+  if (rc) return rc;
   const IlrmaWs w = ilrma_ws(B, N, F, T, K);
   SSSPY_REQUIRE(workspace && workspace_bytes >= w.total,
                 "ilrma_weighted_covariance: workspace too small");
   hipStream_t st = as_stream(stream);
-  const int chunks = fast_path(N, T, K, domain) ? frame_chunks(B, F, T) : 1;
-  if (chunks == 1) return wcov_into(X, basis, activation, U, B, N, F, T, K, domain, 1, st);
+  const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
+  const int chunks = fast_path(N, T, K, domain, source_model) ? frame_chunks(B, F, T) : 1;
+  if (chunks == 1) return wcov_into(X, W, basis, activation, U, N, d, 1, st);
   void *upart = (char *)workspace + w.upart;
-  int rc = wcov_into(X, basis, activation, upart, B, N, F, T, K, domain, chunks, st);
+  rc = wcov_into(X, W, basis, activation, upart, N, d, chunks, st);
   if (rc) return rc;
   return sum_chunks(U, upart, (long long)B * F * N * N * N, chunks, st);
 }
@@ -379,49 +404,60 @@ int ssspy_ilrma_normalize_output(void *Y, double *basis, int B, int N, int F, in
   return check_launch("k_ilrma_normalize_output");
 }
 
-int ssspy_ilrma_iss_weight(const double *basis, const double *activation, double *varphi, int B,
-                           int N, int F, int T, int K, double domain, void *stream) {
+int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *activation,
+                           double *varphi, int B, int N, int F, int T, int K, double domain,
+                           int source_model, double model_param, int floor_kind, double floor_eps,
+                           void *stream) {
   SSSPY_REQUIRE(basis && activation && varphi && B > 0, "iss_weight: bad argument");
+  SSSPY_REQUIRE(source_model == SSSPY_SOURCE_GAUSS || Y, "iss_weight: this model needs Y");
+  int rc = check_model(source_model, model_param);
+  if (rc) return rc;
+  const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   dim3 grid(F, N, B), block(256);
-  hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, as_stream(stream), basis, activation,
-                     varphi, N, F, T, K, domain);
+  hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, as_stream(stream), (const c128 *)Y, basis,
+                     activation, varphi, N, d);
   return check_launch("k_ilrma_iss_weight");
 }
 
 int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
                           const double *activation, double *out, int B, int N, int F, int T, int K,
-                          double domain, void *stream) {
+                          double domain, int source_model, double model_param, void *stream) {
   SSSPY_REQUIRE(X && basis && activation && out && B > 0, "ilrma_loss_data: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "ilrma_loss_data: bad n_basis");
+  int rc = check_model(source_model, model_param);
+  if (rc) return rc;
   hipStream_t st = as_stream(stream);
   hipError_t e = hipMemsetAsync(out, 0, (size_t)B * sizeof(double), st);
   if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
-  ILRMA_DISPATCH(N, ilrma_loss, X, W, basis, activation, out, B, F, T, K, domain, st);
+  const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, SSSPY_FLOOR_NONE, 0.0);
+  ILRMA_DISPATCH(N, ilrma_loss, X, W, basis, activation, out, d, st);
 }
 
-int ssspy_gauss_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis,
-                                 double *activation, void *U, int B, int N, int F, int T, int K,
-                                 double domain, int normalize, int floor_kind, double floor_eps,
-                                 void *workspace, size_t workspace_bytes, int *info,
-                                 void *stream) {
-  SSSPY_REQUIRE(X && W && basis && activation && U, "gauss_ilrma_ip1_update: bad argument");
-  SSSPY_REQUIRE(!normalize || C, "gauss_ilrma_ip1_update: normalisation needs C");
+int ssspy_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis, double *activation,
+                           void *U, int B, int N, int F, int T, int K, double domain,
+                           int source_model, double model_param, int normalize, int floor_kind,
+                           double floor_eps, void *workspace, size_t workspace_bytes, int *info,
+                           void *stream) {
+  SSSPY_REQUIRE(X && W && basis && activation && U, "ilrma_ip1_update: bad argument");
+  SSSPY_REQUIRE(!normalize || C, "ilrma_ip1_update: normalisation needs C");
   const IlrmaWs w = ilrma_ws(B, N, F, T, K);
-  SSSPY_REQUIRE(workspace && workspace_bytes >= w.total,
-                "gauss_ilrma_ip1_update: workspace too small");
+  SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "ilrma_ip1_update: workspace too small");
   char *ws = (char *)workspace;
   hipStream_t st = as_stream(stream);
-  int rc = ssspy_ilrma_update_basis(X, W, basis, activation, B, N, F, T, K, domain, floor_kind,
-                                    floor_eps, workspace, workspace_bytes, stream);
+  int rc = ssspy_ilrma_update_basis(X, W, basis, activation, B, N, F, T, K, domain, source_model,
+                                    model_param, floor_kind, floor_eps, workspace, workspace_bytes,
+                                    stream);
   if (rc) return rc;
-  rc = ssspy_ilrma_update_activation(X, W, basis, activation, B, N, F, T, K, domain, floor_kind,
-                                     floor_eps, workspace, workspace_bytes, stream);
+  rc = ssspy_ilrma_update_activation(X, W, basis, activation, B, N, F, T, K, domain, source_model,
+                                     model_param, floor_kind, floor_eps, workspace, workspace_bytes,
+                                     stream);
   if (rc) return rc;
   // covariance: for small batches the frame chunks are partial sums, folded by a wide kernel
   // (a lane of the IP1 kernel owns a whole bin and would add them up serially)
-  const int chunks = fast_path(N, T, K, domain) ? frame_chunks(B, F, T) : 1;
+  const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
+  const int chunks = fast_path(N, T, K, domain, source_model) ? frame_chunks(B, F, T) : 1;
   void *ucov = chunks > 1 ? (void *)(ws + w.upart) : U;
-  rc = wcov_into(X, basis, activation, ucov, B, N, F, T, K, domain, chunks, st);
+  rc = wcov_into(X, W, basis, activation, ucov, N, d, chunks, st);
   if (rc) return rc;
   if (chunks > 1) {
     rc = sum_chunks(U, ucov, (long long)B * F * N * N * N, chunks, st);

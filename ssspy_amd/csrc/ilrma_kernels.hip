@@ -21,6 +21,7 @@
 // This file is compiled once per N (-DSSSPY_N=<n>) to keep build time parallel.
 #include "common.hpp"
 #include "cov_core.hpp"
+#include "ilrma_params.hpp"
 #include "nmf_tile.hpp"
 
 #ifndef SSSPY_N
@@ -40,30 +41,6 @@ constexpr int NSRC = SSSPY_N;
 constexpr int SGRP = NSRC <= 4 ? NSRC : 2;  // sources per wave pass
 constexpr int NGROUPS = (NSRC + SGRP - 1) / SGRP;
 
-struct IlrmaDims {
-  int B, F, T, K;
-  double p;  // domain
-};
-
-// a = P / R^((p+2)/p), b = 1/R
-__device__ __forceinline__ void mm_weights(double P, double R, double p, bool valid, double &a,
-                                           double &b) {
-  const double rinv = 1.0 / R;
-  double aa;
-  if (p == 2.0) {
-    aa = P * rinv * rinv;
-  } else {
-    aa = P / pow(R, (p + 2.0) / p);
-  }
-  a = valid ? aa : 0.0;
-  b = valid ? rinv : 0.0;
-}
-
-__device__ __forceinline__ double mm_ratio_pow(double num, double den, double p) {
-  const double ratio = num / den;
-  return (p == 2.0) ? sqrt(ratio) : pow(ratio, p / (p + 2.0));
-}
-
 // ======================================================================== pass 1: basis update
 // grid: (bin tiles, k tiles, B * NGROUPS); block: NW waves, wave w takes frame tiles w, w+NW, ...
 template <bool KSMALL>
@@ -71,7 +48,7 @@ __global__ __launch_bounds__(256) void k_ilrma_basis(const c128 *__restrict__ X,
                                                      const c128 *__restrict__ W,
                                                      const double *basis, double *basis_out,
                                                      const double *__restrict__ act,
-                                                     IlrmaDims d, int floor_kind, double eps) {
+                                                     IlrmaDims d) {
   constexpr int N = NSRC, SG = SGRP;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -144,7 +121,7 @@ __global__ __launch_bounds__(256) void k_ilrma_basis(const c128 *__restrict__ X,
         c128 y = cmake(0.0, 0.0);
 #pragma unroll
         for (int m = 0; m < N; ++m) cfma(y, w[s][m], x[m][r]);
-        mm_weights(cabs2(y), R[r], d.p, fval[r], a[r], bb[r]);
+        mm_weights(cabs2(y), R[r], d, fval[r], a[r], bb[r]);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -177,7 +154,7 @@ __global__ __launch_bounds__(256) void k_ilrma_basis(const c128 *__restrict__ X,
     const int n = s0 + s;
     if (ob < F && ok < K && n < N) {
       const long long o = (((long long)b * N + n) * F + ob) * K + ok;
-      basis_out[o] = apply_floor(mm_ratio_pow(sn, sd, d.p) * basis[o], floor_kind, eps);
+      basis_out[o] = apply_floor(mm_ratio_pow(sn, sd, d) * basis[o], d.floor_kind, d.floor_eps);
     }
   }
 }
@@ -295,7 +272,7 @@ __global__ __launch_bounds__(256) void k_ilrma_activation(const c128 *__restrict
         c128 y = cmake(0.0, 0.0);
 #pragma unroll
         for (int m = 0; m < N; ++m) cfma(y, wr[m], x[m][r]);
-        mm_weights(cabs2(y), R[r], d.p, bval[r] && fvalid, a[r], bb[r]);
+        mm_weights(cabs2(y), R[r], d, bval[r] && fvalid, a[r], bb[r]);
       }
       // GEMM2: numV[k = kt*16 + (q+4r'), frame] += T[n, bin i0+q+4r, k2] * a[r]
 #pragma unroll
@@ -326,7 +303,10 @@ __global__ __launch_bounds__(256) void k_ilrma_activation(const c128 *__restrict
 // ============================================================ pass 3: NMF-weighted covariance
 // U[b,i,n] = (1/T) sum_j x x^H / R^(2/p).  grid: (bin tiles, 1, B*NGROUPS)
 template <bool KSMALL>
+// For the heavy-tailed models the weight also depends on |y|^2 = |w x|^2: W gives the demixing rows
+// (NULL = X already holds the separated spectrogram, the ISS state).
 __global__ __launch_bounds__(256) void k_ilrma_wcov(const c128 *__restrict__ X,
+                                                    const c128 *__restrict__ W,
                                                     const double *__restrict__ basis,
                                                     const double *__restrict__ act,
                                                     c128 *__restrict__ U, IlrmaDims d) {
@@ -350,6 +330,16 @@ __global__ __launch_bounds__(256) void k_ilrma_wcov(const c128 *__restrict__ X,
       if (KSMALL && kk < K) t = basis[(((long long)b * N + n) * F + bin) * K + kk];
       tb[s][ks] = t;
     }
+  }
+  const bool need_y = d.model != SSSPY_SOURCE_GAUSS;
+  c128 w[SG][N];
+#pragma unroll
+  for (int s = 0; s < SG; ++s) {
+    const int n = min(s0 + s, N - 1);
+#pragma unroll
+    for (int m = 0; m < N; ++m)
+      w[s][m] = (need_y && W) ? W[(((long long)b * F + bin) * N + n) * N + m]
+                              : cmake(m == n ? 1.0 : 0.0, 0.0);
   }
   CovAcc<N, SG> acc;
   acc.clear();
@@ -375,8 +365,14 @@ __global__ __launch_bounds__(256) void k_ilrma_wcov(const c128 *__restrict__ X,
       double phi[SG];
 #pragma unroll
       for (int s = 0; s < SG; ++s) {
-        const double rr = R[s][r];
-        const double ph = (d.p == 2.0) ? 1.0 / rr : 1.0 / pow(rr, 2.0 / d.p);
+        double P = 0.0;
+        if (need_y) {
+          c128 y = cmake(0.0, 0.0);
+#pragma unroll
+          for (int m = 0; m < N; ++m) cfma(y, w[s][m], x[m]);
+          P = cabs2(y);
+        }
+        const double ph = spatial_weight(P, R[s][r], d);
         phi[s] = (valid && s0 + s < N) ? ph : 0.0;
       }
       acc.add(x, phi);
@@ -444,10 +440,7 @@ __global__ __launch_bounds__(256) void k_ilrma_loss(const c128 *__restrict__ X,
 #pragma unroll
         for (int m = 0; m < N; ++m)
           cfma(y, w[s][m], X[(((long long)b * N + m) * F + bin) * T + jc]);
-        const double rr = R[r];
-        const double lr = log(rr);
-        const double term = (d.p == 2.0) ? cabs2(y) / rr + lr
-                                         : cabs2(y) / pow(rr, 2.0 / d.p) + (2.0 / d.p) * lr;
+        const double term = loss_term(cabs2(y), R[r], d);
         local += valid ? term : 0.0;
       }
     }
@@ -465,29 +458,26 @@ using namespace SSSPY_CAT(ilrma_n, SSSPY_N);
 // basis_out may alias basis only when K <= 16 (one k tile per bin: nobody else reads the rows a
 // block rewrites); for K > 16 the caller passes a scratch buffer and copies back.
 int LAUNCHER(ilrma_basis)(const void *X, const void *W, const double *basis, double *basis_out,
-                          const double *act, int B, int F, int T, int K, double p, int floor_kind,
-                          double eps, hipStream_t st) {
-  IlrmaDims d{B, F, T, K, p};
-  dim3 grid((F + 15) / 16, kt_count(K), B * NGROUPS), block(256);
+                          const double *act, IlrmaDims d, hipStream_t st) {
+  dim3 grid((d.F + 15) / 16, kt_count(d.K), d.B * NGROUPS), block(256);
   const size_t lds = (size_t)4 * SGRP * 2 * 256 * sizeof(double);
-  if (K <= 16)
+  if (d.K <= 16)
     hipLaunchKernelGGL((k_ilrma_basis<true>), grid, block, lds, st, (const c128 *)X,
-                       (const c128 *)W, basis, basis_out, act, d, floor_kind, eps);
+                       (const c128 *)W, basis, basis_out, act, d);
   else
     hipLaunchKernelGGL((k_ilrma_basis<false>), grid, block, lds, st, (const c128 *)X,
-                       (const c128 *)W, basis, basis_out, act, d, floor_kind, eps);
+                       (const c128 *)W, basis, basis_out, act, d);
   return check_launch("k_ilrma_basis");
 }
 
 int LAUNCHER(ilrma_activation)(const void *X, const void *W, const double *basis,
-                               const double *act, double *part, int nchunks, int B, int F, int T,
-                               int K, double p, hipStream_t st) {
-  IlrmaDims d{B, F, T, K, p};
-  const int ntiles = (F + 15) / 16;
+                               const double *act, double *part, int nchunks, IlrmaDims d,
+                               hipStream_t st) {
+  const int ntiles = (d.F + 15) / 16;
   const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
-  const int ktiles = kt_count(K);
-  dim3 grid((T + 63) / 64, nchunks, B * NGROUPS * ktiles), block(256);
-  if (K <= 16)
+  const int ktiles = kt_count(d.K);
+  dim3 grid((d.T + 63) / 64, nchunks, d.B * NGROUPS * ktiles), block(256);
+  if (d.K <= 16)
     hipLaunchKernelGGL((k_ilrma_activation<true>), grid, block, 0, st, (const c128 *)X,
                        (const c128 *)W, basis, act, part, d, ktiles, tiles_per_chunk, nchunks);
   else
@@ -496,25 +486,23 @@ int LAUNCHER(ilrma_activation)(const void *X, const void *W, const double *basis
   return check_launch("k_ilrma_activation");
 }
 
-int LAUNCHER(ilrma_wcov)(const void *X, const double *basis, const double *act, void *U, int B,
-                         int F, int T, int K, double p, hipStream_t st) {
-  IlrmaDims d{B, F, T, K, p};
-  dim3 grid((F + 15) / 16, 1, B * NGROUPS), block(256);
+int LAUNCHER(ilrma_wcov)(const void *X, const void *W, const double *basis, const double *act,
+                         void *U, IlrmaDims d, hipStream_t st) {
+  dim3 grid((d.F + 15) / 16, 1, d.B * NGROUPS), block(256);
   const size_t lds = (size_t)4 * cov_lds_doubles_per_wave<NSRC, SGRP>() * sizeof(double);
-  if (K <= 16)
-    hipLaunchKernelGGL((k_ilrma_wcov<true>), grid, block, lds, st, (const c128 *)X, basis, act,
-                       (c128 *)U, d);
+  if (d.K <= 16)
+    hipLaunchKernelGGL((k_ilrma_wcov<true>), grid, block, lds, st, (const c128 *)X, (const c128 *)W,
+                       basis, act, (c128 *)U, d);
   else
-    hipLaunchKernelGGL((k_ilrma_wcov<false>), grid, block, lds, st, (const c128 *)X, basis, act,
-                       (c128 *)U, d);
+    hipLaunchKernelGGL((k_ilrma_wcov<false>), grid, block, lds, st, (const c128 *)X,
+                       (const c128 *)W, basis, act, (c128 *)U, d);
   return check_launch("k_ilrma_wcov");
 }
 
 int LAUNCHER(ilrma_loss)(const void *X, const void *W, const double *basis, const double *act,
-                         double *out, int B, int F, int T, int K, double p, hipStream_t st) {
-  IlrmaDims d{B, F, T, K, p};
-  dim3 grid((F + 15) / 16, 1, B * NGROUPS), block(256);
-  if (K <= 16)
+                         double *out, IlrmaDims d, hipStream_t st) {
+  dim3 grid((d.F + 15) / 16, 1, d.B * NGROUPS), block(256);
+  if (d.K <= 16)
     hipLaunchKernelGGL((k_ilrma_loss<true>), grid, block, 0, st, (const c128 *)X, (const c128 *)W,
                        basis, act, out, d);
   else

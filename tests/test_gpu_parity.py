@@ -22,6 +22,8 @@ ILRMA_CASES = [
     "gilrma_ip1_n2", "gilrma_ip1_n3", "gilrma_ip1_n4", "gilrma_ip1_n4_p1", "gilrma_ip1_n2_add",
     "gilrma_ip1_n2_nofloor", "gilrma_ip1_n3_raw", "gilrma_iss1_n2", "gilrma_iss1_n4",
     "gilrma_iss1_n3_p1", "gilrma_ip2_n3", "gilrma_ip2_n2", "gilrma_iss2_n4", "gilrma_iss2_n3",
+    "tilrma_ip1_n3", "tilrma_iss1_n2_p1", "tilrma_ip2_n3", "ggdilrma_ip1_n3", "ggdilrma_iss1_n2",
+    "ggdilrma_iss2_n3_p1",
 ]
 IVA_CASES = [
     "auxlap_ip1_n2", "auxlap_ip1_n4", "auxlap_iss1_n2", "auxlap_iss1_n8", "auxgauss_ip1_n3",
@@ -103,13 +105,24 @@ def test_ip1_singular_raises_linalgerror():
 
 
 # ------------------------------------------------------------------------------- GaussILRMA
+def _ilrma_class(model):
+    """(class, extra ctor kwargs) for a source model given as ("gauss"|"t"|"ggd", param)."""
+    from ssspy_amd.bss.ilrma import GGDILRMA, TILRMA, GaussILRMA
+
+    if model[0] == "t":
+        return functools.partial(TILRMA, dof=model[1])
+    if model[0] == "ggd":
+        return functools.partial(GGDILRMA, beta=model[1])
+    return GaussILRMA
+
+
 @pytest.mark.parametrize("case", ILRMA_CASES)
 def test_gauss_ilrma_against_golden(case):
-    from ssspy_amd.bss.ilrma import GaussILRMA
-
     g = load_golden(case)
+    model = (str(g["meta_model"]), float(g["meta_model_param"])) if "meta_model" in g \
+        else ("gauss", None)
     snap = Snap(["demix_filter", "output", "basis", "activation"])
-    m = GaussILRMA(
+    m = _ilrma_class(model)(
         n_basis=int(g["meta_n_basis"]), spatial_algorithm=str(g["meta_algo"]),
         domain=float(g["meta_domain"]), flooring_fn=_flooring_fn(g), callbacks=snap,
         normalization=bool(g["meta_normalization"]),
@@ -146,6 +159,65 @@ def test_gauss_ilrma_step_methods_match_fused_update():
         m = cls(n_basis=int(g["meta_n_basis"]))
         outs.append(m(g["X"], n_iter=4, basis=g["basis0"], activation=g["activation0"]))
     assert rel_err(outs[1], outs[0]) < 1e-12
+
+
+@pytest.mark.parametrize("model", [("t", 3.0), ("ggd", 1.2)])
+@pytest.mark.parametrize("N,K,algo,domain", [(2, 2, "ISS2", 2), (4, 16, "IP", 2), (5, 20, "IP2", 1),
+                                             (8, 3, "ISS", 2), (4, 8, "IP1", 1.5)])
+def test_heavy_tailed_ilrma_sweep_against_oracle(model, N, K, algo, domain):
+    """TILRMA / GGDILRMA over source counts, n_basis (incl. > 16), domains and all spatial updates."""
+    from oracle.ilrma import GaussILRMAOracle
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    F, T = 19, 41
+    X = nmf_mixture(11 + N, N, F, T)
+    basis = np.random.default_rng(3).random((N, F, K))
+    act = np.random.default_rng(4).random((N, K, T))
+    ref = GaussILRMAOracle(n_basis=K, spatial_algorithm=algo, domain=domain, model=model,
+                           scale_restoration=False)
+    Yr = ref.run(X, n_iter=4, basis=basis, activation=act)
+    m = _ilrma_class(model)(n_basis=K, spatial_algorithm=algo, domain=domain,
+                            scale_restoration=False)
+    Y = m(X, n_iter=4, basis=basis, activation=act)
+    err = rel_err_up_to_phase(Y, Yr, "output") if algo in ("IP2", "ISS2") else rel_err(Y, Yr)
+    assert err < TOL
+    assert rel_err(m.basis, ref.basis) < TOL and rel_err(m.activation, ref.activation) < TOL
+    np.testing.assert_allclose(m.loss, ref.loss, rtol=LOSS_RTOL)
+
+
+def test_heavy_tailed_ilrma_batch_and_stepwise():
+    """Batched TILRMA == per-mixture runs; fused update_once == the step methods."""
+    from ssspy_amd.bss.ilrma import TILRMA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    N, F, T, K = 3, 33, 64, 4
+    Xb = np.stack([nmf_mixture(s, N, F, T) for s in (1, 2, 3)])
+    basis = np.random.default_rng(5).random((3, N, F, K))
+    act = np.random.default_rng(6).random((3, N, K, T))
+    Yb = TILRMA(n_basis=K, dof=4.0)(Xb, n_iter=3, basis=basis, activation=act)
+
+    class Stepwise(TILRMA):
+        def normalize(self, flooring_fn="self"):
+            super().normalize(flooring_fn=flooring_fn)
+
+    for b in range(3):
+        for cls in (TILRMA, Stepwise):
+            Y = cls(n_basis=K, dof=4.0)(Xb[b], n_iter=3, basis=basis[b], activation=act[b])
+            assert rel_err(Y, Yb[b]) < 1e-12
+
+
+def test_heavy_tailed_ilrma_constructor_contract():
+    from ssspy_amd.bss.ilrma import GGDILRMA, TILRMA
+
+    with pytest.raises(ValueError):
+        TILRMA(n_basis=2, dof=3, spatial_algorithm="IPA")
+    with pytest.raises(ValueError):
+        GGDILRMA(n_basis=2, beta=1.0, spatial_algorithm="IPA")
+    with pytest.raises(AssertionError):
+        GGDILRMA(n_basis=2, beta=2.0)
+    with pytest.raises(AssertionError):
+        GGDILRMA(n_basis=2, beta=1.0, source_algorithm="ME")
+    assert "dof=3" in repr(TILRMA(n_basis=2, dof=3)) and repr(TILRMA(2, 3)).startswith("TILRMA(")
 
 
 @pytest.mark.parametrize("K", [1, 7, 16, 17, 40])
