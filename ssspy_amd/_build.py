@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(PKG, "lib", "libssspy_amd.so")
 
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-munsafe-fp-atomics",
-            "-I" + INCLUDE, "-I" + CSRC]
+            "-I" + INCLUDE, "-I" + CSRC] + os.environ.get("SSSPY_AMD_EXTRA_CXXFLAGS", "").split()
 
 ILRMA_N = list(range(2, 9))
 ILRMA_FAST_N = [2, 3, 4]

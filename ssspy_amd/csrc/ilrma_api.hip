@@ -23,11 +23,11 @@ DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
 // throughput variants (ilrma_fast.hip): domain == 2, n_basis <= 16, n_sources <= 4, even T
 #define DECL_FAST(n)                                                                           \
   int ilrma_fast_basis_n##n(const void *, const void *, double *, const double *, int, int, int, \
-                            int, int, double, int, double *, hipStream_t);                     \
+                            int, int, double, double *, hipStream_t);                          \
   int ilrma_fast_activation_n##n(const void *, const void *, const double *, const double *,   \
                                  double *, int, int, int, int, int, hipStream_t);              \
   int ilrma_fast_wcov_n##n(const void *, const double *, const double *, void *, int, int, int, \
-                           int, int, hipStream_t);
+                           int, void *, hipStream_t);
 DECL_FAST(2) DECL_FAST(3) DECL_FAST(4)
 #undef DECL_FAST
 
@@ -92,24 +92,13 @@ int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, i
                    int floor_kind, double floor_eps, int *info, hipStream_t st, int nchunks);
 int sum_chunks(void *dst, const void *src, long long count, int nchunks, hipStream_t st);
 
-// frame chunks of the bin-major fast kernels (basis, covariance): 1 for large batches; for small
-// ones enough blocks to put ~2 waves on every SIMD
-static inline int frame_chunks(int B, int F, int T) {
-  const long long blocks0 = (long long)B * ((F + 63) / 64);
-  const int ntiles = (T + 15) / 16;
-  long long want = (512 + blocks0 - 1) / blocks0;
-  if (want < 1) want = 1;
-  if (want > 16) want = 16;
-  if (want > ntiles) want = ntiles;
-  return (int)want;
+// scratch of the bin-major fast kernels (basis, covariance): partial sums of the at most 512
+// split blocks of the last scheduling round (TailPlan in ilrma_fast.hip)
+static inline size_t basis_part_bytes(int N) {
+  return N <= 4 ? align256((size_t)512 * N * 64 * 16 * 2 * sizeof(double)) : 0;
 }
-static inline size_t basis_part_bytes(int B, int N, int F, int T, int K) {
-  const int ch = frame_chunks(B, F, T);
-  return ch > 1 ? align256((size_t)B * ch * N * F * K * 2 * sizeof(double)) : 0;
-}
-static inline size_t u_part_bytes(int B, int N, int F, int T) {
-  const int ch = frame_chunks(B, F, T);
-  return ch > 1 ? align256((size_t)ch * B * F * N * N * N * 2 * sizeof(double)) : 0;
+static inline size_t u_part_bytes(int N) {
+  return N <= 4 ? align256((size_t)512 * 64 * N * N * N * 2 * sizeof(double)) : 0;
 }
 int row_power(const void *W, const void *C, double *qbuf, int B, int F, int N, hipStream_t st);
 
@@ -254,9 +243,9 @@ static inline IlrmaWs ilrma_ws(int B, int N, int F, int T, int K) {
   w.psi = off;
   off += align256((size_t)B * N * sizeof(double));
   w.bpart = off;
-  off += basis_part_bytes(B, N, F, T, K);
+  off += basis_part_bytes(N);
   w.upart = off;
-  off += u_part_bytes(B, N, F, T);
+  off += u_part_bytes(N);
   w.total = off;
   return w;
 }
@@ -286,7 +275,7 @@ int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const 
   hipStream_t st = as_stream(stream);
   if (fast_path(N, T, K, domain, source_model)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_basis, X, W, basis, activation, B, F, T, K, floor_kind,
-                        floor_eps, frame_chunks(B, F, T), (double *)(ws + w.bpart), st);
+                        floor_eps, (double *)(ws + w.bpart), st);
   }
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   double *out = K > 16 ? (double *)(ws + w.btmp) : basis;
@@ -332,15 +321,13 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
   return check_launch("k_ilrma_activation_finalize");
 }
 
-// covariance into `dst`; with `chunks` > 1 (Gauss fast path, small batches) chunk c lands at
-// dst + c * B*F*N^3 and the caller folds them.
+// U[b,i,n] for every model; `upart` is the fast path's scratch for split blocks
 static int wcov_into(const void *X, const void *W, const double *basis, const double *activation,
-                     void *dst, int N, const IlrmaDims &d, int chunks, hipStream_t st) {
+                     void *U, int N, const IlrmaDims &d, void *upart, hipStream_t st) {
   if (fast_path(N, d.T, d.K, d.p, d.model)) {
-    ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, basis, activation, dst, d.B, d.F, d.T, d.K, chunks,
-                        st);
+    ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, basis, activation, U, d.B, d.F, d.T, d.K, upart, st);
   }
-  ILRMA_DISPATCH(N, ilrma_wcov, X, W, basis, activation, dst, d, st);
+  ILRMA_DISPATCH(N, ilrma_wcov, X, W, basis, activation, U, d, st);
 }
 
 int ssspy_ilrma_weighted_covariance(const void *X, const void *W, const double *basis,
@@ -358,12 +345,7 @@ int ssspy_ilrma_weighted_covariance(const void *X, const void *W, const double *
                 "ilrma_weighted_covariance: workspace too small");
   hipStream_t st = as_stream(stream);
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
-  const int chunks = fast_path(N, T, K, domain, source_model) ? frame_chunks(B, F, T) : 1;
-  if (chunks == 1) return wcov_into(X, W, basis, activation, U, N, d, 1, st);
-  void *upart = (char *)workspace + w.upart;
-  rc = wcov_into(X, W, basis, activation, upart, N, d, chunks, st);
-  if (rc) return rc;
-  return sum_chunks(U, upart, (long long)B * F * N * N * N, chunks, st);
+  return wcov_into(X, W, basis, activation, U, N, d, (char *)workspace + w.upart, st);
 }
 
 static int launch_norm_scale(void *W, double *basis, const double *qbuf, int B, int N, int F, int K,
@@ -452,17 +434,9 @@ int ssspy_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis,
                                      model_param, floor_kind, floor_eps, workspace, workspace_bytes,
                                      stream);
   if (rc) return rc;
-  // covariance: for small batches the frame chunks are partial sums, folded by a wide kernel
-  // (a lane of the IP1 kernel owns a whole bin and would add them up serially)
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
-  const int chunks = fast_path(N, T, K, domain, source_model) ? frame_chunks(B, F, T) : 1;
-  void *ucov = chunks > 1 ? (void *)(ws + w.upart) : U;
-  rc = wcov_into(X, W, basis, activation, ucov, N, d, chunks, st);
+  rc = wcov_into(X, W, basis, activation, U, N, d, ws + w.upart, st);
   if (rc) return rc;
-  if (chunks > 1) {
-    rc = sum_chunks(U, ucov, (long long)B * F * N * N * N, chunks, st);
-    if (rc) return rc;
-  }
   double *qbuf = (double *)(ws + w.qbuf);
   rc = ip1_with_power(W, U, normalize ? C : nullptr, normalize ? qbuf : nullptr, B, F, N,
                       floor_kind, floor_eps, info, st, 1);

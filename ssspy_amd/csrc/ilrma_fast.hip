@@ -54,6 +54,63 @@ __device__ __forceinline__ double rcp_nr(double x) {
 
 __device__ __forceinline__ int tile_pi(int rho) { return 4 * (rho & 3) + (rho >> 2); }
 
+// Two-level schedule of the bin-major kernels.  A work item is (mixture, bin group) walking all
+// frame tiles; the chip holds SLOTS workgroups at once (2 per CU).  Items that fill whole rounds of
+// SLOTS run unsplit and finish their bins in place; the remaining `tail` items are split into
+// `split` frame chunks each, so the last round is 1/split as long instead of leaving most CUs idle
+// (128 mixtures x 17 groups = 2176 items = 4.25 rounds: 5 rounds unsplit, 4.25 split).  Split blocks
+// write partial sums to a scratch area indexed [tail item][chunk]; a small second kernel folds them.
+// Small batches are the same formula with full == 0.
+constexpr int SLOTS = 512;
+struct TailPlan {
+  int full, tail, split, groups;  // blocks = full + tail * split; groups = bin groups per mixture
+};
+
+static inline TailPlan make_tail_plan(int B, int groups, int ntiles) {
+  TailPlan p;
+  const long long items = (long long)B * groups;
+  p.groups = groups;
+  p.full = (int)(items / SLOTS) * SLOTS;
+  p.tail = (int)(items - p.full);
+  p.split = 1;
+  if (p.tail > 0) {
+    int s = SLOTS / p.tail;
+    s = s > 16 ? 16 : s;
+    s = s > ntiles ? ntiles : s;
+    if (s > 1) {
+      const int tpc = (ntiles + s - 1) / s;
+      s = (ntiles + tpc - 1) / tpc;  // no empty chunks
+    }
+    p.split = s < 1 ? 1 : s;
+  }
+  if (p.split == 1) {
+    p.full += p.tail;
+    p.tail = 0;
+  }
+  return p;
+}
+
+struct BlockWork {
+  int b, group, chunk, nchunks, tail_idx;
+};
+__device__ __forceinline__ BlockWork block_work(const TailPlan &p) {
+  BlockWork w;
+  int item = blockIdx.x;
+  w.chunk = 0;
+  w.nchunks = 1;
+  w.tail_idx = 0;
+  if (item >= p.full) {
+    const int t = item - p.full;
+    w.tail_idx = t / p.split;
+    w.chunk = t - w.tail_idx * p.split;
+    w.nchunks = p.split;
+    item = p.full + w.tail_idx;
+  }
+  w.b = item / p.groups;
+  w.group = item - w.b * p.groups;
+  return w;
+}
+
 // ---- stage the activation tile V[b, n, 0:16, j0:j0+16] of every source into LDS rows of VROW
 // doubles (zero beyond K rows / T frames).  256 threads, N*16 rows * 8 double2 chunks.
 struct VStage {
@@ -80,8 +137,10 @@ __device__ __forceinline__ void vstage_store(const VStage &st, double *buf) {
   for (int u = 0; u < (N * 16 * 8 + 255) / 256; ++u) {
     const int idx = threadIdx.x + 256 * u;
     const int row = idx >> 3, chunk = idx & 7;
-    if (idx < N * 16 * 8)
-      *reinterpret_cast<double2 *>(buf + row * VROW + 2 * chunk) = st.v[u];
+    if (idx < N * 16 * 8) {  // frame f of the tile lives in slot tile_pi(f)
+      buf[row * VROW + tile_pi(2 * chunk)] = st.v[u].x;
+      buf[row * VROW + tile_pi(2 * chunk + 1)] = st.v[u].y;
+    }
   }
 }
 
@@ -89,19 +148,57 @@ struct XTile {
   c128 x[N][4];
 };
 
-// bin-major x tile: lane (c, q) reads frames j0+4q+r of bin `bin` (64 contiguous bytes/channel)
+// bin-major x tile: lane (c, q) reads frames j0+q+4r of bin `bin`, so one load instruction
+// (fixed r) takes 64 contiguous bytes per bin from the 4 q-lanes: 16 half cache lines instead of the
+// 32 quarter lines of a "4 consecutive frames per lane" split (TCP tag-conflict stalls, profiles/)
 __device__ __forceinline__ void xtile_load_binmajor(XTile &xt, const c128 *__restrict__ Xb, int F,
                                                     int T, int bin, int j0, int q) {
-  const int j = j0 + 4 * q;
+  const int j = j0 + q;
 #pragma unroll
   for (int m = 0; m < N; ++m) {
     const c128 *row = Xb + ((long long)m * F + bin) * T;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xt.x[m][r] = row[min(j + r, T - 1)];
+    for (int r = 0; r < 4; ++r) xt.x[m][r] = row[min(j + 4 * r, T - 1)];
   }
 }
 
-// GEMM1 of the bin-major tile from the staged V: R[bin c, frame j0+4q+r] in register r
+// The same tile, fetched with coalesced addresses and transposed through a wave-private LDS
+// patch: a load instruction takes 4 bin rows x 256 contiguous bytes (lane = frame), the patch
+// turns (lane = frame, register = bin) into (lane = bin, register = frame).  Two channels per
+// pass so the patch stays at 8.5 KB per wave; rows are 17 slots apart, which makes both the
+// frame-major writes and the bin-major reads bank-conflict free.  LDS operations of one wave are
+// processed in order, so no barrier is needed.  (Measured on the covariance kernel, whose 2 waves
+// per bin tile made the texture addresser the limiter: 1.32 -> see profiles/.)
+constexpr int XPATCH = 2 * 16 * 17;  // c128 slots per wave
+
+__device__ __forceinline__ void xtile_load_transposed(XTile &xt, const c128 *__restrict__ Xb, int F,
+                                                      int T, int i0, int j0, int c, int q,
+                                                      c128 *patch) {
+  const int jf = min(j0 + c, T - 1);
+#pragma unroll
+  for (int m = 0; m < N; ++m)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+      xt.x[m][rr] = Xb[((long long)m * F + min(i0 + 4 * rr + q, F - 1)) * T + jf];
+#pragma unroll
+  for (int m0 = 0; m0 < N; m0 += 2) {
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+      if (m0 + mm < N) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) patch[(mm * 16 + 4 * rr + q) * 17 + c] = xt.x[m0 + mm][rr];
+      }
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+      if (m0 + mm < N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xt.x[m0 + mm][r] = patch[(mm * 16 + c) * 17 + q + 4 * r];
+      }
+  }
+}
+
+// GEMM1 of the bin-major tile from the staged V: R[bin c, frame j0+q+4r] in register r
+// (D row q+4r reads slot tile_pi(q+4r) = 4q+r, which holds frame tile_pi(4q+r) = q+4r)
 __device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const double (&tb)[4], int c,
                                                  int q) {
   double4_t R = {0.0, 0.0, 0.0, 0.0};
@@ -116,21 +213,21 @@ __device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const doubl
 // Register diet for 2 waves per SIMD (<= 256 VGPR+AGPR): the demixing rows live in LDS and are
 // re-read per (source, channel); the second resident workgroup hides the x-load latency that
 // the one-wave version covered with a register prefetch.
-// Small batches: blockIdx.y splits the frame tiles into `nchunks` ranges so the grid fills the
-// chip; the block then writes its partial num/den to `part` ([b][chunk][n][bin][k][2]) and
-// k_basis_finalize applies the update.  nchunks == 1 updates the basis in place.
+// grid: 1-D, see TailPlan.  Unsplit blocks update their 64 bins in place; split blocks write
+// partial num/den to `part` ([tail item][chunk][n][64 bins][16][2]) for k_basis_finalize.
 __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ X,
                                                        const c128 *__restrict__ W, double *basis,
                                                        const double *__restrict__ act, int F,
                                                        int T, int K, int floor_kind, double eps,
-                                                       int nchunks, double *__restrict__ part) {
+                                                       TailPlan plan, double *__restrict__ part) {
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
   constexpr int WSTRIDE = N * N + 1;  // 16-byte slots per bin: odd, so 16 bins never share a bank
   __shared__ __attribute__((aligned(16))) c128 wl[4][16 * WSTRIDE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int b = blockIdx.z;
-  const int i0 = blockIdx.x * 64 + wave * 16;
+  const BlockWork work = block_work(plan);
+  const int b = work.b, nchunks = work.nchunks;
+  const int i0 = work.group * 64 + wave * 16;
   const int bin = min(i0 + c, F - 1);
   const c128 *Xb = X + (long long)b * N * F * T;
   const double *act_b = act + (long long)b * N * K * T;
@@ -160,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
 
   const int ntiles = (T + 15) >> 4;
   const int tpc = (ntiles + nchunks - 1) / nchunks;
-  const int jt_begin = blockIdx.y * tpc, jt_end = min(ntiles, jt_begin + tpc);
+  const int jt_begin = work.chunk * tpc, jt_end = min(ntiles, jt_begin + tpc);
   VStage st;
   XTile cur;
   vstage_load(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
@@ -188,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
         c128 y = cmake(0.0, 0.0);
 #pragma unroll
         for (int m = 0; m < N; ++m) cfma(y, wr[m], cur.x[m][r]);
-        const bool valid = j0 + 4 * q + r < T;
+        const bool valid = j0 + q + 4 * r < T;
         const double rinv = rcp_nr(R[r]);
         const double bb = valid ? rinv : 0.0;
         const double aa = valid ? cabs2(y) * rinv * rinv : 0.0;
@@ -210,7 +307,8 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
           double *dst = basis + (((long long)b * N + n) * F + ob) * K + c;
           *dst = apply_floor(sqrt(num[n][r] / den[n][r]) * (*dst), floor_kind, eps);
         } else {
-          double *dst = part + ((((long long)(b * nchunks + blockIdx.y) * N + n) * F + ob) * K + c) * 2;
+          const long long slot = (long long)work.tail_idx * nchunks + work.chunk;
+          double *dst = part + (((slot * N + n) * 64 + (ob - work.group * 64)) * 16 + c) * 2;
           dst[0] = num[n][r];
           dst[1] = den[n][r];
         }
@@ -218,21 +316,26 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
     }
 }
 
-// basis <- floor(basis * sqrt(sum_chunks num / sum_chunks den)); one thread per (b, n, bin, k)
+// basis <- floor(basis * sqrt(sum_chunks num / sum_chunks den)) for the split (tail) items;
+// grid: (N*64*16/256, tail items); one thread per (n, local bin, k)
 __global__ __launch_bounds__(256) void k_basis_finalize(double *basis,
-                                                        const double *__restrict__ part,
-                                                        long long per_mixture, int nchunks,
-                                                        int floor_kind, double eps) {
-  const int b = blockIdx.y;
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= per_mixture) return;
+                                                        const double *__restrict__ part, int F,
+                                                        int K, TailPlan plan, int floor_kind,
+                                                        double eps) {
+  const int tail_idx = blockIdx.y;
+  const int item = plan.full + tail_idx;
+  const int b = item / plan.groups, group = item - b * plan.groups;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (n, local bin, k16)
+  const int k = e & 15, lb = (e >> 4) & 63, n = e >> 10;
+  const int bin = group * 64 + lb;
+  if (n >= N || k >= K || bin >= F) return;
   double sn = 0.0, sd = 0.0;
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const double *src = part + (((long long)b * nchunks + ch) * per_mixture + e) * 2;
+  for (int ch = 0; ch < plan.split; ++ch) {
+    const double *src = part + ((((long long)tail_idx * plan.split + ch) * N + n) * 1024 + (e & 1023)) * 2;
     sn += src[0];
     sd += src[1];
   }
-  double *dst = basis + (long long)b * per_mixture + e;
+  double *dst = basis + (((long long)b * N + n) * F + bin) * K + k;
   *dst = apply_floor(sqrt(sn / sd) * (*dst), floor_kind, eps);
 }
 
@@ -248,21 +351,25 @@ constexpr int WC_SG = N >= 4 ? 2 : N;            // sources per wave
 constexpr int WC_NG = (N + WC_SG - 1) / WC_SG;   // source groups
 constexpr int WC_WB = 4 / WC_NG;                 // bin tiles per workgroup
 
-// blockIdx.y = frame chunk (small batches); chunk c writes its partial sums (already scaled by 1/T)
-// to U + c * chunk_stride; k_ip1 adds the chunks up.
+constexpr int WC_BINS = 16 * WC_WB;              // bins per workgroup
+
+// grid: 1-D, see TailPlan.  Unsplit blocks store U directly; split blocks store their partial sums
+// (already scaled by 1/T) to `upart` ([tail item][chunk][WC_BINS][N][N][N]) for k_wcov_fold.
 __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X,
                                                       const double *__restrict__ basis,
                                                       const double *__restrict__ act,
                                                       c128 *__restrict__ U, int F, int T, int K,
-                                                      int nchunks, long long chunk_stride) {
+                                                      TailPlan plan, c128 *__restrict__ upart) {
   constexpr int SG = WC_SG;
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
+  __shared__ __attribute__((aligned(16))) c128 xpatch[4][XPATCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int b = blockIdx.z;
+  const BlockWork work = block_work(plan);
+  const int b = work.b, nchunks = work.nchunks;
   const int g = wave % WC_NG, wb = wave / WC_NG;
   const int s0 = g * SG;
-  const int i0 = (blockIdx.x * WC_WB + wb) * 16;
+  const int i0 = (work.group * WC_WB + wb) * 16;
   const int bin = min(i0 + c, F - 1);
   const c128 *Xb = X + (long long)b * N * F * T;
   const double *act_b = act + (long long)b * N * K * T;
@@ -278,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
   acc.clear();
   const int ntiles = (T + 15) >> 4;
   const int tpc = (ntiles + nchunks - 1) / nchunks;
-  const int jt_begin = blockIdx.y * tpc, jt_end = min(ntiles, jt_begin + tpc);
+  const int jt_begin = work.chunk * tpc, jt_end = min(ntiles, jt_begin + tpc);
   VStage st;
   XTile cur;
   vstage_load(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
@@ -287,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
   for (int jt = jt_begin; jt < jt_end; ++jt) {
     const int j0 = jt * 16;
     const int jn = min(jt + 1, jt_end - 1) * 16;
-    xtile_load_binmajor(cur, Xb, F, T, bin, j0, q);
+    xtile_load_transposed(cur, Xb, F, T, i0, j0, c, q, xpatch[wave]);
     vstage_load(st, act_b, K, T, jn);
     const double *vcur = vs[(jt - jt_begin) & 1];
     double4_t R[SG];
@@ -296,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
       R[s] = rt_from_lds(vcur + min(s0 + s, N - 1) * 16 * VROW, tb[s], c, q);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool valid = j0 + 4 * q + r < T;
+      const bool valid = j0 + q + 4 * r < T;
       c128 x[N];
       double phi[SG];
 #pragma unroll
@@ -314,7 +421,10 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
   const double scale = 1.0 / (double)T;
   const int ob = i0 + c;
   if (ob < F) {
-    c128 *dst = U + blockIdx.y * chunk_stride + ((long long)b * F + ob) * (long long)(N * N * N);
+    c128 *dst = nchunks == 1
+                    ? U + ((long long)b * F + ob) * (long long)(N * N * N)
+                    : upart + (((long long)work.tail_idx * nchunks + work.chunk) * WC_BINS +
+                               (ob - work.group * WC_BINS)) * (long long)(N * N * N);
 #pragma unroll
     for (int s = 0; s < SG; ++s) {
       const int n = s0 + s;
@@ -337,6 +447,26 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
       }
     }
   }
+}
+
+// U[tail items] = sum of their chunks; grid: (WC_BINS*N^3/256 rounded up, tail items)
+__global__ __launch_bounds__(256) void k_wcov_fold(c128 *__restrict__ U,
+                                                   const c128 *__restrict__ upart, int F,
+                                                   TailPlan plan) {
+  constexpr int PER = WC_BINS * N * N * N;
+  const int tail_idx = blockIdx.y;
+  const int item = plan.full + tail_idx;
+  const int b = item / plan.groups, group = item - b * plan.groups;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lb = e / (N * N * N);
+  if (e >= PER || group * WC_BINS + lb >= F) return;
+  double re = 0.0, im = 0.0;
+  for (int ch = 0; ch < plan.split; ++ch) {
+    const c128 v = upart[((long long)tail_idx * plan.split + ch) * PER + e];
+    re += v.x;
+    im += v.y;
+  }
+  U[((long long)b * F + group * WC_BINS) * (long long)(N * N * N) + e] = cmake(re, im);
 }
 
 // ========================================================================= activation (pass 2)
@@ -484,17 +614,18 @@ __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restri
 }  // namespace ilrma_fast_n<N>
 using namespace SSSPY_CAT(ilrma_fast_n, SSSPY_N);
 
+// `part` must hold ilrma_fast_part_bytes() bytes (used only when some items are split)
 int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, double *basis, const double *act,
-                               int B, int F, int T, int K, int floor_kind, double eps, int nchunks,
+                               int B, int F, int T, int K, int floor_kind, double eps,
                                double *part, hipStream_t st) {
-  dim3 grid((F + 63) / 64, nchunks, B), block(256);
+  const TailPlan plan = make_tail_plan(B, (F + 63) / 64, (T + 15) / 16);
+  dim3 grid(plan.full + plan.tail * plan.split), block(256);
   hipLaunchKernelGGL(k_basis_fast, grid, block, 0, st, (const c128 *)X, (const c128 *)W, basis,
-                     act, F, T, K, floor_kind, eps, nchunks, part);
+                     act, F, T, K, floor_kind, eps, plan, part);
   int rc = check_launch("k_basis_fast");
-  if (rc || nchunks == 1) return rc;
-  const long long per_mixture = (long long)N * F * K;
-  hipLaunchKernelGGL(k_basis_finalize, dim3((unsigned)((per_mixture + 255) / 256), B), block, 0, st,
-                     basis, part, per_mixture, nchunks, floor_kind, eps);
+  if (rc || plan.tail == 0) return rc;
+  hipLaunchKernelGGL(k_basis_finalize, dim3(N * 64 * 16 / 256, plan.tail), block, 0, st, basis,
+                     part, F, K, plan, floor_kind, eps);
   return check_launch("k_basis_finalize");
 }
 
@@ -509,13 +640,18 @@ int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *
   return check_launch("k_activation_fast");
 }
 
-// U must hold nchunks * B*F*N^3 elements; chunk c's partial lands at U + c * B*F*N^3.
+// `upart` must hold ilrma_fast_part_bytes() bytes (used only when some items are split)
 int LAUNCHER(ilrma_fast_wcov)(const void *X, const double *basis, const double *act, void *U,
-                              int B, int F, int T, int K, int nchunks, hipStream_t st) {
-  dim3 grid((F + 16 * WC_WB - 1) / (16 * WC_WB), nchunks, B), block(256);
+                              int B, int F, int T, int K, void *upart, hipStream_t st) {
+  const TailPlan plan = make_tail_plan(B, (F + WC_BINS - 1) / WC_BINS, (T + 15) / 16);
+  dim3 grid(plan.full + plan.tail * plan.split), block(256);
   hipLaunchKernelGGL(k_wcov_fast, grid, block, 0, st, (const c128 *)X, basis, act, (c128 *)U, F, T,
-                     K, nchunks, (long long)B * F * N * N * N);
-  return check_launch("k_wcov_fast");
+                     K, plan, (c128 *)upart);
+  int rc = check_launch("k_wcov_fast");
+  if (rc || plan.tail == 0) return rc;
+  hipLaunchKernelGGL(k_wcov_fold, dim3((WC_BINS * N * N * N + 255) / 256, plan.tail), block, 0, st,
+                     (c128 *)U, (const c128 *)upart, F, plan);
+  return check_launch("k_wcov_fold");
 }
 
 }  // namespace ssspy
