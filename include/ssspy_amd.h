@@ -315,6 +315,41 @@ int ssspy_fastmnmf_separate(const void *X, const void *Q, const double *D, const
                             int K, int reference_id, int floor_kind, double floor_eps,
                             void *workspace, size_t workspace_bytes, int *info, void *stream);
 
+/* ------------------------------------------------------------------ GaussMNMF (full-rank SCM)
+ * State: basis (B,N,F,K) f64, activation (B,N,K,T) f64, spatial (B,N,F,M,M) c128 Hermitian PSD
+ * (the reference's `spatial` (N,F,M,M) with a batch axis).  n_channels M in [2, 4], no partitioning.
+ * R_ij = to_psd(sum_n lambda_nij H_ni); the instantaneous covariance to_psd(x x^H) of
+ * MNMFBase._init_instant_covariance (ssspy/bss/mnmf.py:167-188) is applied in closed form. */
+enum {
+  SSSPY_GMNMF_BASIS = 1,
+  SSSPY_GMNMF_ACTIVATION = 2,
+  SSSPY_GMNMF_SPATIAL = 4,
+  SSSPY_GMNMF_NORMALIZE = 8,
+  SSSPY_GMNMF_ALL = 15
+};
+
+size_t ssspy_gmnmf_workspace_bytes(int B, int N, int M, int F, int T, int K);
+
+/* The steps of update_once() selected by `steps`, in the reference's order: basis, activation,
+ * spatial (H <- to_psd(P^-1 # H Q H), the matrix geometric mean of linalg/mean.py:6-83 type 2),
+ * unit-trace normalisation of H with the scale moved into the basis.
+ * replaces: ssspy/bss/mnmf.py:806-834, :836-901, :903-968, :970-1016, :391-414. */
+int ssspy_gmnmf_update(const void *X, double *basis, double *activation, void *spatial, int B,
+                       int N, int M, int F, int T, int K, int steps, int floor_kind,
+                       double floor_eps, void *workspace, size_t workspace_bytes, void *stream);
+
+/* out[b] = sum_i mean_j ( tr(R^-1 XX) + log det R ); `out` (B doubles) is zeroed by the call.
+ * replaces: ssspy/bss/mnmf.py:765-804. */
+int ssspy_gmnmf_loss(const void *X, const double *basis, const double *activation,
+                     const void *spatial, double *out, int B, int N, int M, int F, int T, int K,
+                     int floor_kind, double floor_eps, void *stream);
+
+/* multichannel Wiener filter: Y[b,n,i,j] = (lambda_nij H_ni R_ij^-1 x_ij)[reference_id]
+ * -> Y (B,N,F,T) c128.  replaces: ssspy/bss/mnmf.py:729-763. */
+int ssspy_gmnmf_separate(const void *X, const double *basis, const double *activation,
+                         const void *spatial, void *Y, int B, int N, int M, int F, int T, int K,
+                         int reference_id, int floor_kind, double floor_eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,7 @@ def _units():
         ("iss_fused.hip", "iss_fused.o", []),
         ("linalg_kernels.hip", "linalg_kernels.o", []),
         ("pairwise_kernels.hip", "pairwise_kernels.o", []),
+        ("gmnmf_kernels.hip", "gmnmf_kernels.o", []),
     ]
     units.append(("mnmf_api.hip", "mnmf_api.o", []))
     for n in MNMF_N:

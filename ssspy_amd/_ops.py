@@ -346,3 +346,46 @@ def fastmnmf_separate(X, Q, D, basis, activation, reference_id, flooring, ws, ws
         "fastmnmf_separate",
     )
     return out
+
+
+# ------------------------------------------------------------------------- GaussMNMF
+def gmnmf_workspace(B, N, M, F, T, K, dev):
+    nbytes = int(_L().ssspy_gmnmf_workspace_bytes(B, N, M, F, T, K))
+    return dv.empty(((nbytes + 7) // 8,), dv.f64, dev), nbytes
+
+
+def gmnmf_update(X, basis, activation, spatial, steps, flooring, ws, ws_bytes):
+    B, M, F, T = X.shape
+    N, K = basis.shape[1], basis.shape[-1]
+    _lib.check(
+        _L().ssspy_gmnmf_update(ptr(X), ptr(basis), ptr(activation), ptr(spatial), B, N, M, F, T,
+                                K, steps, flooring[0], flooring[1], ptr(ws), ws_bytes, _st()),
+        "gmnmf_update",
+    )
+
+
+def gmnmf_loss(X, basis, activation, spatial, flooring, out=None):
+    B, M, F, T = X.shape
+    N, K = basis.shape[1], basis.shape[-1]
+    if out is None:
+        out = dv.empty((B,), dv.f64, X.device)
+    _lib.check(
+        _L().ssspy_gmnmf_loss(ptr(X), ptr(basis), ptr(activation), ptr(spatial), ptr(out), B, N, M,
+                              F, T, K, flooring[0], flooring[1], _st()),
+        "gmnmf_loss",
+    )
+    return out
+
+
+def gmnmf_separate(X, basis, activation, spatial, reference_id, flooring, out=None):
+    B, M, F, T = X.shape
+    N, K = basis.shape[1], basis.shape[-1]
+    if out is None:
+        out = dv.empty((B, N, F, T), dv.c128, X.device)
+    _lib.check(
+        _L().ssspy_gmnmf_separate(ptr(X), ptr(basis), ptr(activation), ptr(spatial), ptr(out), B,
+                                  N, M, F, T, K, int(reference_id), flooring[0], flooring[1],
+                                  _st()),
+        "gmnmf_separate",
+    )
+    return out

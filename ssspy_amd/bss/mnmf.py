@@ -1,4 +1,4 @@
-"""Fast multichannel NMF (FastGaussMNMF) on MI355X.
+"""Multichannel NMF (FastGaussMNMF, GaussMNMF) on MI355X.
 
 Drop-in separator for the reference's ``ssspy.bss.mnmf.FastGaussMNMF``
 (ssspy/bss/mnmf.py:1076-1675 on top of FastMNMFBase :417-678 and MNMFBase :21-297): jointly
@@ -6,8 +6,9 @@ diagonalisable full-rank spatial model with per-bin diagonaliser ``Q`` (n_bins, 
 n_channels), diagonal spatial ``D`` (n_bins, n_sources, n_channels), NMF ``basis`` /
 ``activation``; ``update_once`` = basis, activation, diagonaliser (IP1), spatial, power
 normalisation; output by the multichannel Wiener filter.  ``diagonalizer_algorithm`` may be "IP" /
-"IP1" or "IP2" (pairwise).  ``partitioning`` and the full-rank ``GaussMNMF`` are not built yet
-(NotImplementedError).
+"IP1" or "IP2" (pairwise).  ``GaussMNMF`` (ssspy/bss/mnmf.py:681-1073) is the full-rank model:
+``spatial`` (n_sources, n_bins, M, M) Hermitian PSD, updated by a matrix geometric mean.
+``partitioning`` is not built yet (NotImplementedError).
 
 ``instant_covariance`` (the (n_bins, n_frames, M, M) PSD-projected outer products the reference
 materialises at reset, mnmf.py:167-188) is never read by FastGaussMNMF's updates and is not
@@ -27,7 +28,7 @@ from ..utils.select_pair import resolve_pairs, sequential_pair_selector
 from ._device_state import DeviceStateMixin, Synced
 from .base import IterativeMethodBase
 
-__all__ = ["FastGaussMNMF"]
+__all__ = ["FastGaussMNMF", "GaussMNMF"]
 
 diagonalizer_algorithms = ["IP", "IP1", "IP2"]
 EPS = 1e-10
@@ -316,3 +317,175 @@ class FastGaussMNMF(FastMNMFBase):
     def update_spatial(self) -> None:
         """ref: ssspy/bss/mnmf.py:1635-1675."""
         self._update(_lib.MNMF_SPATIAL, "self")
+
+
+class MNMF(MNMFBase):
+    """Full-rank spatial covariance MNMF state (ref: ssspy/bss/mnmf.py:300-414)."""
+
+    spatial = Synced(dv.c128)
+
+    def _reset(self, **kwargs) -> None:
+        """ref: ssspy/bss/mnmf.py:139-165."""
+        assert self.input is not None, "Specify data!"
+        for key, value in kwargs.items():
+            setattr(self, key, value)
+        B, M, F, T = self._X.shape
+        N = M if self.n_sources is None else self.n_sources
+        self.n_sources, self.n_channels = N, M
+        self.n_bins, self.n_frames = F, T
+        self._floor = device_flooring(self.flooring_fn)
+        self._init_nmf(rng=self.rng)
+        self._ws, self._ws_bytes = _ops.gmnmf_workspace(B, N, M, F, T, self.n_basis, self._X.device)
+        self._separate_dev()
+
+    def _init_nmf(self, rng=None) -> None:
+        """NMF parameters, then H = I / M per source and bin.  ref: ssspy/bss/mnmf.py:327-353."""
+        super()._init_nmf(rng=rng)
+        N, M, F = self.n_sources, self.n_channels, self.n_bins
+        if not self._state_has("spatial"):
+            eye = np.eye(M, dtype=np.complex128) / M
+            self.spatial = np.tile(eye, self._lead() + (N, F, 1, 1))
+        else:
+            self.spatial = np.array(self.spatial, dtype=np.complex128, copy=True)
+
+    @property
+    def instant_covariance(self) -> np.ndarray:
+        """to_psd(x x^H), (n_bins, n_frames, M, M) (ref: ssspy/bss/mnmf.py:167-188).  The device
+        kernels apply it in closed form; this host-side view exists for callbacks that read it."""
+        X = self.input
+        lead = X.ndim - 3
+        XX = X[..., :, None, :, :] * X[..., None, :, :, :].conj()
+        XX = np.moveaxis(XX, (lead, lead + 1), (-2, -1))
+        kind, eps = self._floor
+        lamb, P = np.linalg.eigh((XX + XX.swapaxes(-2, -1).conj()) / 2)
+        lamb = np.maximum(lamb, eps) if kind == _lib.FLOOR_MAX else (
+            lamb + eps if kind == _lib.FLOOR_ADD else lamb)
+        out = (P * lamb[..., None, :]) @ P.swapaxes(-2, -1).conj()
+        return (out + out.swapaxes(-2, -1).conj()) / 2
+
+    def reconstruct_mnmf(self, basis, activation, spatial, latent=None) -> np.ndarray:
+        """R_ij = sum_n lambda_nij H_ni (ref: ssspy/bss/mnmf.py:355-389); host-side convenience."""
+        Lamb = self.reconstruct_nmf(basis, activation, latent=latent)
+        return np.sum(Lamb[..., :, :, :, None, None] * spatial[..., :, :, None, :, :], axis=-5)
+
+    def normalize(self, axis1=-2, axis2=-1) -> None:
+        """Unit trace of H, scale moved into the basis (ref: ssspy/bss/mnmf.py:391-414)."""
+        self._update(_lib.GMNMF_NORMALIZE)
+
+
+class GaussMNMF(MNMF):
+    """MNMF on a Gaussian distribution (ref: ssspy/bss/mnmf.py:681-1073).
+
+    Args as the reference: ``n_basis``, ``n_sources`` (default: number of channels),
+    ``partitioning`` (False on the device path), ``flooring_fn``, ``callbacks``,
+    ``normalization``, ``record_loss``, ``reference_id``, ``rng``.  n_channels in [2, 4].
+    """
+
+    def __init__(
+        self,
+        n_basis: int,
+        n_sources: Optional[int] = None,
+        partitioning: bool = False,
+        flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = functools.partial(
+            max_flooring, eps=EPS
+        ),
+        callbacks: Optional[Union[Callable, List[Callable]]] = None,
+        normalization: Union[bool, str] = True,
+        record_loss: bool = True,
+        reference_id: int = 0,
+        rng: Optional[np.random.Generator] = None,
+    ) -> None:
+        super().__init__(
+            n_basis,
+            n_sources=n_sources,
+            partitioning=partitioning,
+            flooring_fn=flooring_fn,
+            callbacks=callbacks,
+            normalization=normalization,
+            record_loss=record_loss,
+            reference_id=reference_id,
+            rng=rng,
+        )
+        if partitioning:
+            raise NotImplementedError("partitioning=True is not built for the device path yet.")
+        device_flooring(self.flooring_fn)
+
+    def __repr__(self) -> str:
+        s = "GaussMNMF(n_basis={}".format(self.n_basis)
+        if self.n_sources is not None:
+            s += ", n_sources={}".format(self.n_sources)
+        if hasattr(self, "n_channels"):
+            s += ", n_channels={}".format(self.n_channels)
+        s += ", partitioning={}, normalization={}, record_loss={}, reference_id={})".format(
+            self.partitioning, self.normalization, self.record_loss, self.reference_id
+        )
+        return s
+
+    def _resolve_floor(self, flooring_fn):
+        if type(flooring_fn) is str and flooring_fn == "self":
+            return self._floor
+        return device_flooring(choose_flooring_fn(flooring_fn, method=self))
+
+    def _update(self, steps, flooring_fn="self") -> None:
+        _ops.gmnmf_update(self._X, self._state_dev("basis"), self._state_dev("activation"),
+                          self._state_dev("spatial"), steps, self._resolve_floor(flooring_fn),
+                          self._ws, self._ws_bytes)
+        for name in ("basis", "activation", "spatial"):
+            self._state_touch(name)
+
+    def _separate_dev(self) -> None:
+        Y = _ops.gmnmf_separate(self._X, self._state_dev("basis"), self._state_dev("activation"),
+                                self._state_dev("spatial"), self.reference_id, self._floor)
+        self._state_set_dev("output", Y)
+
+    def separate(self, input: np.ndarray) -> np.ndarray:
+        """Multichannel Wiener filter with the current parameters (ref: mnmf.py:729-763)."""
+        batched = input.ndim == 4
+        X = dv.to_device(input if batched else input[None], dtype=np.complex128)
+        Y = _ops.gmnmf_separate(X, self._state_dev("basis"), self._state_dev("activation"),
+                                self._state_dev("spatial"), self.reference_id, self._floor)
+        self._check_device_errors()
+        out = dv.to_host(Y)
+        return out if batched else out[0]
+
+    def compute_loss(self) -> float:
+        """mean_j [tr(R^-1 XX) + log det R] summed over bins (ref: ssspy/bss/mnmf.py:765-804)."""
+        data = _ops.gmnmf_loss(self._X, self._state_dev("basis"), self._state_dev("activation"),
+                               self._state_dev("spatial"), self._floor)
+        self._check_device_errors()
+        values = dv.to_host(data)
+        return values.copy() if self._batched else values[0].item()
+
+    def compute_logdet(self, reconstructed: np.ndarray) -> np.ndarray:
+        """log det R (ref: ssspy/bss/mnmf.py:791-804); host-side convenience."""
+        return np.linalg.slogdet(reconstructed)[1]
+
+    def update_once(self, flooring_fn="self") -> None:
+        """basis, activation, spatial, unit-trace normalisation (ref: ssspy/bss/mnmf.py:806-834);
+        one C-ABI call when the step methods are the stock ones."""
+        cls = type(self)
+        stock = all(
+            getattr(cls, name) is getattr(GaussMNMF, name)
+            for name in ("update_basis", "update_activation", "update_spatial", "normalize")
+        )
+        if stock:
+            steps = _lib.GMNMF_ALL if self.normalization else _lib.GMNMF_ALL & ~_lib.GMNMF_NORMALIZE
+            self._update(steps, flooring_fn)
+            return
+        self.update_basis(flooring_fn=flooring_fn)
+        self.update_activation(flooring_fn=flooring_fn)
+        self.update_spatial(flooring_fn=flooring_fn)
+        if self.normalization:
+            self.normalize(axis1=-2, axis2=-1)
+
+    def update_basis(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/mnmf.py:836-901."""
+        self._update(_lib.GMNMF_BASIS, flooring_fn)
+
+    def update_activation(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/mnmf.py:903-968."""
+        self._update(_lib.GMNMF_ACTIVATION, flooring_fn)
+
+    def update_spatial(self, flooring_fn="self") -> None:
+        """H <- to_psd(P^-1 # H Q H) (ref: ssspy/bss/mnmf.py:970-1016)."""
+        self._update(_lib.GMNMF_SPATIAL, flooring_fn)

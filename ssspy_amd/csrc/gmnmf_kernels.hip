@@ -1,0 +1,597 @@
+// GaussMNMF: multichannel NMF with full-rank spatial covariance matrices (no partitioning).
+//
+// Model: lambda_nij = sum_k t_nik v_nkj, H_ni (M x M Hermitian), R_ij = to_psd(sum_n lambda_nij H_ni).
+// Every (bin, frame) point owns an M x M eigenproblem (the eigenvalue floor of to_psd), so the
+// unit of work is "one lane = one point": the lane forms R, runs the Jacobi sweeps in registers,
+// and gets R^-1 = P diag(1/floor(lam)) P^H for free from the same decomposition.  The reference's
+// instantaneous covariance XX_ij = to_psd(x x^H) is never materialised: its eigenvalues are
+// (|x|^2, 0, ..., 0), so after the floor it is  c1 * x x^H + c0 * I  with
+//   max floor: c1 = (max(|x|^2, eps) - eps) / |x|^2, c0 = eps;  add floor: c1 = 1, c0 = eps.
+// Traces of the MM rules then reduce to quadratic forms in u = R^-1 x:
+//   tr(R^-1 XX R^-1 H_n) = c1 u^H H_n u + c0 tr(R^-1 H_n R^-1),   tr(R^-1 H_n).
+//
+// replaces: ssspy/bss/mnmf.py:681-1073 (GaussMNMF), :300-414 (MNMF), special/psd.py, linalg/mean.py.
+#include "common.hpp"
+#include "hermitian.hpp"
+#include "ssspy_amd.h"
+
+namespace ssspy {
+
+constexpr int GM_NMAX = SSSPY_MAX_SOURCES;
+
+// coefficients of XX = c1 x x^H + c0 I after the eigenvalue floor
+__device__ __forceinline__ void xx_floor_coeffs(double s, int floor_kind, double eps, double &c1,
+                                                double &c0) {
+  if (floor_kind == SSSPY_FLOOR_MAX) {
+    c0 = eps;
+    c1 = s > 0.0 ? (fmax(s, eps) - eps) / s : 0.0;
+  } else if (floor_kind == SSSPY_FLOOR_ADD) {
+    c0 = eps;
+    c1 = 1.0;
+  } else {
+    c0 = 0.0;
+    c1 = 1.0;
+  }
+}
+
+// Per-point state: lambda_n, R^-1 (Hermitian), floored eigenvalues of R, u = R^-1 x.
+template <int M>
+struct Point {
+  double lam[GM_NMAX];
+  c128 Rinv[M][M];
+  double ev[M];
+  c128 x[M], u[M];
+};
+
+// Hs: spatial matrices of this bin in LDS [n][M*M]; Ts: basis rows of this bin in LDS [n][K]
+template <int M>
+__device__ __forceinline__ void point_setup(Point<M> &pt, const c128 *__restrict__ Xb,
+                                            const double *__restrict__ act_b, const c128 *Hs,
+                                            const double *Ts, int N, int F, int T, int K, int i,
+                                            int j, int floor_kind, double eps) {
+  c128 R[M][M], P[M][M];
+#pragma unroll
+  for (int a = 0; a < M; ++a)
+#pragma unroll
+    for (int c = 0; c < M; ++c) R[a][c] = cmake(0.0, 0.0);
+#pragma unroll
+  for (int n = 0; n < GM_NMAX; ++n) {
+    double l = 0.0;
+    if (n < N) {
+      for (int k = 0; k < K; ++k) l = fma(Ts[n * K + k], act_b[((long long)n * K + k) * T + j], l);
+#pragma unroll
+      for (int a = 0; a < M; ++a)
+#pragma unroll
+        for (int c = 0; c < M; ++c) {
+          const c128 h = Hs[n * M * M + a * M + c];
+          R[a][c].x = fma(l, h.x, R[a][c].x);
+          R[a][c].y = fma(l, h.y, R[a][c].y);
+        }
+    }
+    pt.lam[n] = l;
+  }
+  psd_eigen<M>(R, P, pt.ev, floor_kind, eps);
+  double w[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) w[k] = 1.0 / pt.ev[k];
+  herm_rebuild<M>(P, w, pt.Rinv);
+#pragma unroll
+  for (int m = 0; m < M; ++m) pt.x[m] = Xb[((long long)m * F + i) * T + j];
+#pragma unroll
+  for (int a = 0; a < M; ++a) {
+    c128 s = cmake(0.0, 0.0);
+#pragma unroll
+    for (int c = 0; c < M; ++c) cfma(s, pt.Rinv[a][c], pt.x[c]);
+    pt.u[a] = s;
+  }
+}
+
+// stage H[b, :, i] and basis[b, :, i, :] of one bin in LDS
+template <int M>
+__device__ __forceinline__ void stage_bin(c128 *Hs, double *Ts, const c128 *__restrict__ H,
+                                          const double *__restrict__ basis, int b, int N, int F,
+                                          int K, int i) {
+  for (int e = threadIdx.x; e < N * M * M; e += blockDim.x) {
+    const int n = e / (M * M), rem = e % (M * M);
+    Hs[e] = H[(((long long)b * N + n) * F + i) * (M * M) + rem];
+  }
+  for (int e = threadIdx.x; e < N * K; e += blockDim.x) {
+    const int n = e / K, k = e % K;
+    Ts[e] = basis[(((long long)b * N + n) * F + i) * K + k];
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------ traces
+// A[b,n,i,j] = tr(R^-1 XX R^-1 H_n), Bt[b,n,i,j] = tr(R^-1 H_n).  grid: (ceil(T/128), F, B)
+template <int M>
+__global__ __launch_bounds__(128) void k_gmnmf_traces(const c128 *__restrict__ X,
+                                                      const double *__restrict__ basis,
+                                                      const double *__restrict__ act,
+                                                      const c128 *__restrict__ H,
+                                                      double *__restrict__ A,
+                                                      double *__restrict__ Bt, int N, int F, int T,
+                                                      int K, int floor_kind, double eps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  c128 *Hs = reinterpret_cast<c128 *>(smem);
+  double *Ts = reinterpret_cast<double *>(Hs + N * M * M);
+  const int i = blockIdx.y, b = blockIdx.z;
+  stage_bin<M>(Hs, Ts, H, basis, b, N, F, K, i);
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= T) return;
+  Point<M> pt;
+  point_setup<M>(pt, X + (long long)b * M * F * T, act + (long long)b * N * K * T, Hs, Ts, N, F, T,
+                 K, i, j, floor_kind, eps);
+  double s = 0.0;
+#pragma unroll
+  for (int m = 0; m < M; ++m) s += cabs2(pt.x[m]);
+  double c1, c0;
+  xx_floor_coeffs(s, floor_kind, eps, c1, c0);
+  for (int n = 0; n < N; ++n) {
+    const c128 *Hn = Hs + n * M * M;
+    // G = R^-1 H_n ; tr(G), tr(G R^-1), u^H H_n u
+    double trG = 0.0, trGR = 0.0;
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+      for (int c = 0; c < M; ++c) {
+        c128 g = cmake(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < M; ++k) cfma(g, pt.Rinv[a][k], Hn[k * M + c]);
+        if (a == c) trG += g.x;
+        // Re(G_ac Rinv_ca)
+        trGR = fma(g.x, pt.Rinv[c][a].x, trGR);
+        trGR = fma(-g.y, pt.Rinv[c][a].y, trGR);
+      }
+    double q = 0.0;
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+      c128 hu = cmake(0.0, 0.0);
+#pragma unroll
+      for (int c = 0; c < M; ++c) cfma(hu, Hn[a * M + c], pt.u[c]);
+      q = fma(pt.u[a].x, hu.x, q);
+      q = fma(pt.u[a].y, hu.y, q);
+    }
+    const long long o = (((long long)b * N + n) * F + i) * T + j;
+    A[o] = fma(c1, q, c0 * trGR);
+    Bt[o] = trG;
+  }
+}
+
+// basis[b,n,i,k] <- floor(basis * sqrt(sum_j V A / sum_j V Bt)).  grid: (F, N, B), 256 threads;
+// wave w takes k = w, w+4, ...
+__global__ __launch_bounds__(256) void k_gmnmf_basis(double *basis, const double *__restrict__ act,
+                                                     const double *__restrict__ A,
+                                                     const double *__restrict__ Bt, int N, int F,
+                                                     int T, int K, int floor_kind, double eps) {
+  const int i = blockIdx.x, n = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long row = (((long long)b * N + n) * F + i) * T;
+  for (int k = wave; k < K; k += 4) {
+    const double *v = act + (((long long)b * N + n) * K + k) * T;
+    double sn = 0.0, sd = 0.0;
+    for (int j = lane; j < T; j += 64) {
+      const double vv = v[j];
+      sn = fma(vv, A[row + j], sn);
+      sd = fma(vv, Bt[row + j], sd);
+    }
+    sn = wave_sum(sn);
+    sd = wave_sum(sd);
+    if (lane == 0) {
+      double *dst = basis + (((long long)b * N + n) * F + i) * K + k;
+      *dst = apply_floor(*dst * sqrt(sn / sd), floor_kind, eps);
+    }
+  }
+}
+
+// act[b,n,k,j] <- floor(act * sqrt(sum_i T A / sum_i T Bt)).  grid: (ceil(T/256), ceil(K/8), N*B)
+__global__ __launch_bounds__(256) void k_gmnmf_activation(const double *__restrict__ basis,
+                                                          double *act, const double *__restrict__ A,
+                                                          const double *__restrict__ Bt, int N,
+                                                          int F, int T, int K, int floor_kind,
+                                                          double eps) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k0 = blockIdx.y * 8;
+  const int n = blockIdx.z % N, b = blockIdx.z / N;
+  if (j >= T) return;
+  double sn[8], sd[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) sn[kk] = sd[kk] = 0.0;
+  const double *tb = basis + ((long long)b * N + n) * F * K;
+  const long long base = ((long long)b * N + n) * F * T + j;
+  for (int i = 0; i < F; ++i) {
+    const double a = A[base + (long long)i * T], bt = Bt[base + (long long)i * T];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const double t = k0 + kk < K ? tb[(long long)i * K + k0 + kk] : 0.0;
+      sn[kk] = fma(t, a, sn[kk]);
+      sd[kk] = fma(t, bt, sd[kk]);
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk)
+    if (k0 + kk < K) {
+      double *dst = act + (((long long)b * N + n) * K + k0 + kk) * T + j;
+      *dst = apply_floor(*dst * sqrt(sn[kk] / sd[kk]), floor_kind, eps);
+    }
+}
+
+// ---------------------------------------------------------------------------- spatial update
+// Pacc[b,n,i] = sum_j lambda R^-1 ; Qacc[b,n,i] = sum_j lambda R^-1 XX R^-1, both stored as the
+// M*M complex entries of a Hermitian matrix.  grid: (F, B), one wave: lanes take frames, the
+// per-chunk matrices go through LDS and thread (n, entry) folds the chunk with the N weights.
+constexpr int GM_PB = 64;  // points per chunk (= block size of k_gmnmf_spatial_acc)
+
+template <int M>
+__global__ __launch_bounds__(GM_PB) void k_gmnmf_spatial_acc(const c128 *__restrict__ X,
+                                                           const double *__restrict__ basis,
+                                                           const double *__restrict__ act,
+                                                           const c128 *__restrict__ H,
+                                                           c128 *__restrict__ Pacc,
+                                                           c128 *__restrict__ Qacc, int N, int F,
+                                                           int T, int K, int floor_kind,
+                                                           double eps) {
+  constexpr int E = 2 * M * M;          // complex entries per point: R^-1 then R^-1 XX R^-1
+  constexpr int ROW = 2 * E + GM_NMAX;  // doubles per point in LDS
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  c128 *Hs = reinterpret_cast<c128 *>(smem);
+  double *Ts = reinterpret_cast<double *>(Hs + N * M * M);
+  double *pts = Ts + ((N * K + 1) & ~1);  // [GM_PB][ROW]
+  const int i = blockIdx.x, b = blockIdx.y;
+  stage_bin<M>(Hs, Ts, H, basis, b, N, F, K, i);
+  const c128 *Xb = X + (long long)b * M * F * T;
+  const double *act_b = act + (long long)b * N * K * T;
+  // accumulators: this thread owns output slots idx = tid, tid + GM_PB, ... of the N*E complex sums
+  constexpr int SLOTS = (GM_NMAX * E + GM_PB - 1) / GM_PB;
+  c128 accum[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) accum[s] = cmake(0.0, 0.0);
+  for (int j0 = 0; j0 < T; j0 += GM_PB) {
+    const int j = j0 + threadIdx.x;
+    double *mine = pts + threadIdx.x * ROW;
+    if (j < T) {
+      Point<M> pt;
+      point_setup<M>(pt, Xb, act_b, Hs, Ts, N, F, T, K, i, j, floor_kind, eps);
+      double s = 0.0;
+#pragma unroll
+      for (int m = 0; m < M; ++m) s += cabs2(pt.x[m]);
+      double c1, c0;
+      xx_floor_coeffs(s, floor_kind, eps, c1, c0);
+#pragma unroll
+      for (int a = 0; a < M; ++a)
+#pragma unroll
+        for (int c = 0; c < M; ++c) {
+          // (R^-1 XX R^-1)_ac = c1 u_a conj(u_c) + c0 (R^-1 R^-1)_ac
+          c128 r2 = cmake(0.0, 0.0);
+#pragma unroll
+          for (int k = 0; k < M; ++k) cfma(r2, pt.Rinv[a][k], pt.Rinv[k][c]);
+          const c128 uu = cmulc(pt.u[a], pt.u[c]);
+          mine[2 * (a * M + c)] = pt.Rinv[a][c].x;
+          mine[2 * (a * M + c) + 1] = pt.Rinv[a][c].y;
+          mine[2 * (M * M + a * M + c)] = fma(c1, uu.x, c0 * r2.x);
+          mine[2 * (M * M + a * M + c) + 1] = fma(c1, uu.y, c0 * r2.y);
+        }
+#pragma unroll
+      for (int n = 0; n < GM_NMAX; ++n) mine[2 * E + n] = pt.lam[n];
+    } else {
+      for (int e = 0; e < ROW; ++e) mine[e] = 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int idx = threadIdx.x + GM_PB * s;
+      if (idx < N * E) {
+        const int n = idx / E, e = idx % E;
+        double re = accum[s].x, im = accum[s].y;
+        for (int p = 0; p < GM_PB; ++p) {
+          const double *row = pts + p * ROW;
+          const double l = row[2 * E + n];
+          re = fma(l, row[2 * e], re);
+          im = fma(l, row[2 * e + 1], im);
+        }
+        accum[s] = cmake(re, im);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int idx = threadIdx.x + GM_PB * s;
+    if (idx < N * E) {
+      const int n = idx / E, e = idx % E;
+      const long long o = (((long long)b * N + n) * F + i) * (M * M);
+      if (e < M * M)
+        Pacc[o + e] = accum[s];
+      else
+        Qacc[o + e - M * M] = accum[s];
+    }
+  }
+}
+
+// H <- to_psd(P^-1 # (H Q H)) with P, HQH floored first.  One lane per (b, n, i).
+template <int M>
+__global__ __launch_bounds__(64) void k_gmnmf_spatial_update(c128 *H,
+                                                             const c128 *__restrict__ Pacc,
+                                                             const c128 *__restrict__ Qacc,
+                                                             long long count, int floor_kind,
+                                                             double eps) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= count) return;
+  c128 Hm[M][M], Qm[M][M], Tm[M][M], C[M][M], Pv[M][M];
+  double lam[M], w[M];
+#pragma unroll
+  for (int a = 0; a < M; ++a)
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+      Hm[a][c] = H[idx * (M * M) + a * M + c];
+      Qm[a][c] = Qacc[idx * (M * M) + a * M + c];
+    }
+  // HQH, floored
+  matmul<M>(Hm, Qm, Tm);
+  matmul<M>(Tm, Hm, C);
+  psd_eigen<M>(C, Pv, lam, floor_kind, eps);
+  c128 HQH[M][M];
+  herm_rebuild<M>(Pv, lam, HQH);
+  // P floored, P^(1/2), P^(-1/2)
+#pragma unroll
+  for (int a = 0; a < M; ++a)
+#pragma unroll
+    for (int c = 0; c < M; ++c) C[a][c] = Pacc[idx * (M * M) + a * M + c];
+  psd_eigen<M>(C, Pv, lam, floor_kind, eps);
+  c128 Ph[M][M], Pih[M][M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) w[k] = sqrt(lam[k]);
+  herm_rebuild<M>(Pv, w, Ph);
+#pragma unroll
+  for (int k = 0; k < M; ++k) w[k] = 1.0 / w[k];
+  herm_rebuild<M>(Pv, w, Pih);
+  // (P^1/2 HQH P^1/2)^1/2
+  matmul<M>(Ph, HQH, Tm);
+  matmul<M>(Tm, Ph, C);
+  hermitize<M>(C);
+  jacobi_eigh<M>(C, Pv);
+#pragma unroll
+  for (int k = 0; k < M; ++k) w[k] = sqrt(fmax(C[k][k].x, 0.0));
+  herm_rebuild<M>(Pv, w, Qm);
+  // G = P^-1/2 (...) P^-1/2, floored
+  matmul<M>(Pih, Qm, Tm);
+  matmul<M>(Tm, Pih, C);
+  psd_eigen<M>(C, Pv, lam, floor_kind, eps);
+  herm_rebuild<M>(Pv, lam, Hm);
+#pragma unroll
+  for (int a = 0; a < M; ++a)
+#pragma unroll
+    for (int c = 0; c < M; ++c) H[idx * (M * M) + a * M + c] = Hm[a][c];
+}
+
+// unit trace of H, the scale goes to the basis: H /= tr H, basis[n, i, :] *= tr H.
+// ref: ssspy/bss/mnmf.py:391-414.  One lane per (b, n, i).
+__global__ __launch_bounds__(64) void k_gmnmf_normalize(c128 *H, double *basis, long long count,
+                                                        int M, int K) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= count) return;
+  c128 *h = H + idx * (M * M);
+  double tr = 0.0;
+  for (int a = 0; a < M; ++a) tr += h[a * M + a].x;
+  for (int e = 0; e < M * M; ++e) h[e] = cmake(h[e].x / tr, h[e].y / tr);
+  for (int k = 0; k < K; ++k) basis[idx * K + k] *= tr;
+}
+
+// ------------------------------------------------------------------------------------- loss
+// out[b] += sum_i mean_j ( tr(R^-1 XX) + log det R ).  grid: (ceil(T/128), F, B)
+template <int M>
+__global__ __launch_bounds__(128) void k_gmnmf_loss(const c128 *__restrict__ X,
+                                                    const double *__restrict__ basis,
+                                                    const double *__restrict__ act,
+                                                    const c128 *__restrict__ H, double *out, int N,
+                                                    int F, int T, int K, int floor_kind,
+                                                    double eps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[2];
+  c128 *Hs = reinterpret_cast<c128 *>(smem);
+  double *Ts = reinterpret_cast<double *>(Hs + N * M * M);
+  const int i = blockIdx.y, b = blockIdx.z;
+  stage_bin<M>(Hs, Ts, H, basis, b, N, F, K, i);
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  double term = 0.0;
+  if (j < T) {
+    Point<M> pt;
+    point_setup<M>(pt, X + (long long)b * M * F * T, act + (long long)b * N * K * T, Hs, Ts, N, F,
+                   T, K, i, j, floor_kind, eps);
+    double s = 0.0, xu = 0.0, trR = 0.0, ld = 0.0;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      s += cabs2(pt.x[m]);
+      xu = fma(pt.x[m].x, pt.u[m].x, xu);
+      xu = fma(pt.x[m].y, pt.u[m].y, xu);
+      trR += pt.Rinv[m][m].x;
+      ld += log(pt.ev[m]);
+    }
+    double c1, c0;
+    xx_floor_coeffs(s, floor_kind, eps, c1, c0);
+    term = fma(c1, xu, c0 * trR) + ld;
+  }
+  const double total = block_sum(term, red);
+  if (threadIdx.x == 0) atomicAdd(out + b, total / (double)T);
+}
+
+// --------------------------------------------------------------------------- Wiener filter
+// Y[b,n,i,j] = lambda_n (H_n R^-1 x)[ref].  grid: (ceil(T/128), F, B)
+template <int M>
+__global__ __launch_bounds__(128) void k_gmnmf_separate(const c128 *__restrict__ X,
+                                                        const double *__restrict__ basis,
+                                                        const double *__restrict__ act,
+                                                        const c128 *__restrict__ H,
+                                                        c128 *__restrict__ Y, int N, int F, int T,
+                                                        int K, int ref, int floor_kind,
+                                                        double eps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  c128 *Hs = reinterpret_cast<c128 *>(smem);
+  double *Ts = reinterpret_cast<double *>(Hs + N * M * M);
+  const int i = blockIdx.y, b = blockIdx.z;
+  stage_bin<M>(Hs, Ts, H, basis, b, N, F, K, i);
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= T) return;
+  Point<M> pt;
+  point_setup<M>(pt, X + (long long)b * M * F * T, act + (long long)b * N * K * T, Hs, Ts, N, F, T,
+                 K, i, j, floor_kind, eps);
+  for (int n = 0; n < N; ++n) {
+    c128 y = cmake(0.0, 0.0);
+#pragma unroll
+    for (int c = 0; c < M; ++c) cfma(y, Hs[n * M * M + ref * M + c], pt.u[c]);
+    Y[(((long long)b * N + n) * F + i) * T + j] = cscale(y, pt.lam[n]);
+  }
+}
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct GmnmfWs {
+  size_t a, bt, pacc, qacc, total;
+};
+static inline GmnmfWs gmnmf_ws(int B, int N, int M, int F, int T) {
+  GmnmfWs w;
+  size_t off = 0;
+  w.a = off;
+  off += align256((size_t)B * N * F * T * sizeof(double));
+  w.bt = off;
+  off += align256((size_t)B * N * F * T * sizeof(double));
+  w.pacc = off;
+  off += align256((size_t)B * N * F * M * M * 2 * sizeof(double));
+  w.qacc = off;
+  off += align256((size_t)B * N * F * M * M * 2 * sizeof(double));
+  w.total = off;
+  return w;
+}
+
+static inline size_t bin_smem(int N, int M, int K) {
+  return (size_t)N * M * M * sizeof(c128) + (size_t)((N * K + 1) & ~1) * sizeof(double);
+}
+
+#define GM_DISPATCH_M(M_, CALL)                                                              \
+  switch (M_) {                                                                              \
+    case 2: { constexpr int MM = 2; CALL; } break;                                           \
+    case 3: { constexpr int MM = 3; CALL; } break;                                           \
+    case 4: { constexpr int MM = 4; CALL; } break;                                           \
+    default: return fail(SSSPY_ERR_UNSUPPORTED, "GaussMNMF: n_channels must be in [2, 4]");  \
+  }
+
+static int check_dims(int B, int N, int M, int F, int T, int K) {
+  SSSPY_REQUIRE(B > 0 && F > 0 && T > 0, "GaussMNMF: bad shape");
+  SSSPY_REQUIRE(N >= 1 && N <= SSSPY_MAX_SOURCES, "GaussMNMF: n_sources must be in [1, 8]");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "GaussMNMF: n_basis must be in [1, 64]");
+  if (M < 2 || M > 4) return fail(SSSPY_ERR_UNSUPPORTED, "GaussMNMF: n_channels must be in [2, 4]");
+  return SSSPY_OK;
+}
+
+static int launch_traces(const void *X, const double *basis, const double *act, const void *H,
+                         double *A, double *Bt, int B, int N, int M, int F, int T, int K,
+                         int floor_kind, double eps, hipStream_t st) {
+  dim3 grid((T + 127) / 128, F, B), block(128);
+  GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_traces<MM>), grid, block, bin_smem(N, M, K), st,
+                                      (const c128 *)X, basis, act, (const c128 *)H, A, Bt, N, F, T,
+                                      K, floor_kind, eps));
+  return check_launch("k_gmnmf_traces");
+}
+
+}  // namespace ssspy
+
+using namespace ssspy;
+
+extern "C" {
+
+size_t ssspy_gmnmf_workspace_bytes(int B, int N, int M, int F, int T, int K) {
+  (void)K;
+  if (B <= 0 || N <= 0 || M <= 0 || F <= 0 || T <= 0) return 0;
+  return gmnmf_ws(B, N, M, F, T).total;
+}
+
+int ssspy_gmnmf_update(const void *X, double *basis, double *activation, void *spatial, int B,
+                       int N, int M, int F, int T, int K, int steps, int floor_kind,
+                       double floor_eps, void *workspace, size_t workspace_bytes, void *stream) {
+  SSSPY_REQUIRE(X && basis && activation && spatial, "gmnmf_update: null argument");
+  int rc = check_dims(B, N, M, F, T, K);
+  if (rc) return rc;
+  const GmnmfWs w = gmnmf_ws(B, N, M, F, T);
+  SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "gmnmf_update: workspace too small");
+  char *ws = (char *)workspace;
+  double *A = (double *)(ws + w.a), *Bt = (double *)(ws + w.bt);
+  c128 *Pacc = (c128 *)(ws + w.pacc), *Qacc = (c128 *)(ws + w.qacc);
+  hipStream_t st = as_stream(stream);
+  if (steps & SSSPY_GMNMF_BASIS) {
+    rc = launch_traces(X, basis, activation, spatial, A, Bt, B, N, M, F, T, K, floor_kind,
+                       floor_eps, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gmnmf_basis, dim3(F, N, B), dim3(256), 0, st, basis,
+                       (const double *)activation, (const double *)A, (const double *)Bt, N, F, T,
+                       K, floor_kind, floor_eps);
+    rc = check_launch("k_gmnmf_basis");
+    if (rc) return rc;
+  }
+  if (steps & SSSPY_GMNMF_ACTIVATION) {
+    rc = launch_traces(X, basis, activation, spatial, A, Bt, B, N, M, F, T, K, floor_kind,
+                       floor_eps, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gmnmf_activation, dim3((T + 255) / 256, (K + 7) / 8, N * B), dim3(256), 0,
+                       st, (const double *)basis, activation, (const double *)A,
+                       (const double *)Bt, N, F, T, K, floor_kind, floor_eps);
+    rc = check_launch("k_gmnmf_activation");
+    if (rc) return rc;
+  }
+  if (steps & SSSPY_GMNMF_SPATIAL) {
+    const size_t smem = bin_smem(N, M, K) + (size_t)GM_PB * (4 * M * M + GM_NMAX) * sizeof(double);
+    GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_spatial_acc<MM>), dim3(F, B), dim3(GM_PB), smem, st,
+                                        (const c128 *)X, (const double *)basis,
+                                        (const double *)activation, (const c128 *)spatial, Pacc,
+                                        Qacc, N, F, T, K, floor_kind, floor_eps));
+    rc = check_launch("k_gmnmf_spatial_acc");
+    if (rc) return rc;
+    const long long count = (long long)B * N * F;
+    GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_spatial_update<MM>),
+                                        dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st,
+                                        (c128 *)spatial, (const c128 *)Pacc, (const c128 *)Qacc,
+                                        count, floor_kind, floor_eps));
+    rc = check_launch("k_gmnmf_spatial_update");
+    if (rc) return rc;
+  }
+  if (steps & SSSPY_GMNMF_NORMALIZE) {
+    const long long count = (long long)B * N * F;
+    hipLaunchKernelGGL(k_gmnmf_normalize, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st,
+                       (c128 *)spatial, basis, count, M, K);
+    rc = check_launch("k_gmnmf_normalize");
+    if (rc) return rc;
+  }
+  return SSSPY_OK;
+}
+
+int ssspy_gmnmf_loss(const void *X, const double *basis, const double *activation,
+                     const void *spatial, double *out, int B, int N, int M, int F, int T, int K,
+                     int floor_kind, double floor_eps, void *stream) {
+  SSSPY_REQUIRE(X && basis && activation && spatial && out, "gmnmf_loss: null argument");
+  int rc = check_dims(B, N, M, F, T, K);
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)B * sizeof(double), st);
+  if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+  dim3 grid((T + 127) / 128, F, B), block(128);
+  GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_loss<MM>), grid, block, bin_smem(N, M, K), st,
+                                      (const c128 *)X, basis, activation, (const c128 *)spatial,
+                                      out, N, F, T, K, floor_kind, floor_eps));
+  return check_launch("k_gmnmf_loss");
+}
+
+int ssspy_gmnmf_separate(const void *X, const double *basis, const double *activation,
+                         const void *spatial, void *Y, int B, int N, int M, int F, int T, int K,
+                         int reference_id, int floor_kind, double floor_eps, void *stream) {
+  SSSPY_REQUIRE(X && basis && activation && spatial && Y, "gmnmf_separate: null argument");
+  int rc = check_dims(B, N, M, F, T, K);
+  if (rc) return rc;
+  SSSPY_REQUIRE(reference_id >= 0 && reference_id < M, "gmnmf_separate: bad reference_id");
+  dim3 grid((T + 127) / 128, F, B), block(128);
+  GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_separate<MM>), grid, block, bin_smem(N, M, K),
+                                      as_stream(stream), (const c128 *)X, basis, activation,
+                                      (const c128 *)spatial, (c128 *)Y, N, F, T, K, reference_id,
+                                      floor_kind, floor_eps));
+  return check_launch("k_gmnmf_separate");
+}
+
+}  // extern "C"

@@ -13,6 +13,7 @@
 
 #include "common.hpp"
 #include "cov_core.hpp"
+#include "hermitian.hpp"
 #include "nmf_tile.hpp"
 #include "smallmat.hpp"
 
@@ -1008,66 +1009,6 @@ __global__ __launch_bounds__(256) void k_mnmf_norm_scale(c128 *Q, double *Dsp,
 }
 
 // ================================================================= multichannel Wiener filter
-// Hermitian eigen-decomposition by cyclic complex Jacobi rotations (fixed sweep count, no
-// branches): A = P diag(lam) P^H.  One lane owns one M x M matrix.
-template <int M>
-__device__ __forceinline__ void jacobi_eigh(c128 (&A)[M][M], c128 (&P)[M][M]) {
-#pragma unroll
-  for (int r = 0; r < M; ++r)
-#pragma unroll
-    for (int cc = 0; cc < M; ++cc) P[r][cc] = cmake(r == cc ? 1.0 : 0.0, 0.0);
-#pragma unroll 1
-  for (int sweep = 0; sweep < 10; ++sweep) {
-#pragma unroll
-    for (int p = 0; p < M - 1; ++p)
-#pragma unroll
-      for (int qq = p + 1; qq < M; ++qq) {
-        const c128 apq = A[p][qq];
-        const double mag2 = cabs2(apq);
-        const double mag = sqrt(mag2);
-        const bool tiny = mag2 < 1e-300;
-        const double inv = tiny ? 0.0 : 1.0 / mag;
-        const c128 u = tiny ? cmake(1.0, 0.0) : cmake(apq.x * inv, apq.y * inv);
-        const double app = A[p][p].x, aqq = A[qq][qq].x;
-        const double tau = tiny ? 0.0 : (aqq - app) * 0.5 * inv;
-        const double t = tiny ? 0.0 : ((tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau)));
-        const double cs = 1.0 / sqrt(1.0 + t * t);
-        const double sn = t * cs;
-        const c128 su = cmake(sn * u.x, sn * u.y);         // s u
-        const c128 sub = cmake(sn * u.x, -sn * u.y);       // s conj(u)
-#pragma unroll
-        for (int k = 0; k < M; ++k) {
-          if (k != p && k != qq) {
-            const c128 akp = A[k][p], akq = A[k][qq];
-            // A'_kp = c A_kp - s conj(u) A_kq ; A'_kq = s u A_kp + c A_kq
-            c128 nkp = cmake(cs * akp.x, cs * akp.y);
-            cfms(nkp, sub, akq);
-            c128 nkq = cmake(cs * akq.x, cs * akq.y);
-            cfma(nkq, su, akp);
-            A[k][p] = nkp;
-            A[p][k] = cconj(nkp);
-            A[k][qq] = nkq;
-            A[qq][k] = cconj(nkq);
-          }
-        }
-        A[p][p] = cmake(app - t * mag, 0.0);
-        A[qq][qq] = cmake(aqq + t * mag, 0.0);
-        A[p][qq] = cmake(0.0, 0.0);
-        A[qq][p] = cmake(0.0, 0.0);
-#pragma unroll
-        for (int k = 0; k < M; ++k) {
-          const c128 vkp = P[k][p], vkq = P[k][qq];
-          c128 nkp = cmake(cs * vkp.x, cs * vkp.y);
-          cfms(nkp, sub, vkq);
-          c128 nkq = cmake(cs * vkq.x, cs * vkq.y);
-          cfma(nkq, su, vkp);
-          P[k][p] = nkp;
-          P[k][qq] = nkq;
-        }
-      }
-  }
-}
-
 // Qinv[b,i] = Q[b,i]^-1
 template <int M>
 __global__ __launch_bounds__(64) void k_mnmf_qinv(const c128 *__restrict__ Q, c128 *Qinv,

@@ -26,7 +26,7 @@ from ssspy.algorithm import projection_back  # noqa: E402
 from ssspy.bss._update_spatial_model import update_by_ip1, update_by_iss1  # noqa: E402
 from ssspy.bss.ilrma import GGDILRMA, TILRMA, GaussILRMA  # noqa: E402
 from ssspy.bss.iva import AuxGaussIVA, AuxLaplaceIVA  # noqa: E402
-from ssspy.bss.mnmf import FastGaussMNMF  # noqa: E402
+from ssspy.bss.mnmf import FastGaussMNMF, GaussMNMF  # noqa: E402
 from ssspy.linalg import eigh2, inv2  # noqa: E402
 from ssspy.special.flooring import add_flooring, max_flooring  # noqa: E402
 from ssspy.special.psd import to_psd  # noqa: E402
@@ -77,6 +77,13 @@ class Snapshots:
                     self.store["it{}_{}".format(self.count, name)] = np.array(value, copy=True)
 
 
+ONLY = sys.argv[1:]  # optional name prefixes: regenerate only those fixtures
+
+
+def skipped(name):
+    return bool(ONLY) and not any(name.startswith(p) for p in ONLY)
+
+
 def save(name, **arrays):
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **arrays)
@@ -90,6 +97,8 @@ def meta(**kw):
 # --------------------------------------------------------------------------- ILRMA
 def run_ilrma(name, *, N, F, T, K, algo, seed, gen=gen_iid, domain=2, flooring=("max", 1e-10),
               normalization=True, scale_restoration=True, n_iter=10, model=("gauss", None)):
+    if skipped(name):
+        return
     X = gen(seed, N, F, T)
     basis = np.random.default_rng(seed + 1).random((N, F, K))
     activation = np.random.default_rng(seed + 2).random((N, K, T))
@@ -119,6 +128,8 @@ def run_ilrma(name, *, N, F, T, K, algo, seed, gen=gen_iid, domain=2, flooring=(
 # --------------------------------------------------------------------------- IVA
 def run_iva(name, *, N, F, T, algo, contrast, seed, gen=gen_iid, flooring=("max", 1e-10),
             scale_restoration=True, n_iter=10, keep_arrays=True):
+    if skipped(name):
+        return
     X = gen(seed, N, F, T)
     names = ["demix_filter", "output"] + (["variance"] if contrast == "gauss" else [])
     snap = Snapshots(names)
@@ -145,6 +156,8 @@ def run_iva(name, *, N, F, T, algo, contrast, seed, gen=gen_iid, flooring=("max"
 # --------------------------------------------------------------------------- MNMF
 def run_mnmf(name, *, M, F, T, K, seed, n_sources=None, gen=gen_iid, flooring=("max", 1e-10),
              normalization=True, n_iter=10):
+    if skipped(name):
+        return
     N = M if n_sources is None else n_sources
     X = gen(seed, M, F, T)
     basis = np.random.default_rng(seed + 1).random((N, F, K))
@@ -165,8 +178,43 @@ def run_mnmf(name, *, M, F, T, K, seed, n_sources=None, gen=gen_iid, flooring=("
     save(name, **out)
 
 
+def random_psd(seed, N, F, M):
+    """Well-conditioned random Hermitian PSD matrices with unit trace, (N, F, M, M)."""
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((N, F, M, M)) + 1j * rng.standard_normal((N, F, M, M))
+    H = A @ A.swapaxes(-2, -1).conj() + 0.5 * np.eye(M)
+    return H / np.real(np.trace(H, axis1=-2, axis2=-1))[..., None, None]
+
+
+def run_gmnmf(name, *, M, F, T, K, seed, n_sources=None, gen=gen_iid, flooring=("max", 1e-10),
+              normalization=True, n_iter=10, spatial_init=False):
+    if skipped(name):
+        return
+    N = M if n_sources is None else n_sources
+    X = gen(seed, M, F, T)
+    basis = np.random.default_rng(seed + 1).random((N, F, K))
+    activation = np.random.default_rng(seed + 2).random((N, K, T))
+    init = dict(basis=basis, activation=activation)
+    if spatial_init:
+        init["spatial"] = random_psd(seed + 4, N, F, M)
+    snap = Snapshots(["spatial", "basis", "activation"])
+    m = GaussMNMF(n_basis=K, n_sources=n_sources, flooring_fn=flooring_of(flooring),
+                  callbacks=snap, normalization=normalization, rng=np.random.default_rng(seed + 3))
+    Y = m(X, n_iter=n_iter, **{k: v.copy() for k, v in init.items()})
+    out = dict(X=X, basis0=basis, activation0=activation, loss=np.array(m.loss), final_output=Y,
+               final_basis=m.basis, final_activation=m.activation, final_spatial=m.spatial)
+    if spatial_init:
+        out["spatial0"] = init["spatial"]
+    out.update(snap.store)
+    out.update(meta(kind="gauss_mnmf", n_basis=K, n_sources=N, n_iter=n_iter,
+                    floor_kind=flooring[0], floor_eps=flooring[1], normalization=normalization))
+    save(name, **out)
+
+
 # --------------------------------------------------------------------------- operators
 def run_operators():
+    if skipped("operators"):
+        return
     out = {}
     # update_by_ip1: seeds/shapes in the style of the reference's operator unit tests
     for N in (2, 3, 4, 8):
@@ -259,6 +307,12 @@ def main():
     run_mnmf("fmnmf_ip1_m4", M=4, F=21, T=36, K=8, seed=5, gen=gen_mixture)
     run_mnmf("fmnmf_ip1_m3_n2", M=3, F=16, T=30, K=3, seed=6, n_sources=2)
     run_mnmf("fmnmf_ip1_m2_nonorm", M=2, F=16, T=30, K=3, seed=7, normalization=False)
+    # --- GaussMNMF (full-rank spatial covariance) ---
+    run_gmnmf("gmnmf_m2", M=2, F=12, T=20, K=2, seed=80)
+    run_gmnmf("gmnmf_m3", M=3, F=10, T=24, K=3, seed=81, gen=gen_mixture, spatial_init=True)
+    run_gmnmf("gmnmf_m4_n3", M=4, F=9, T=22, K=4, seed=82, n_sources=3, spatial_init=True)
+    run_gmnmf("gmnmf_m2_nonorm_add", M=2, F=10, T=18, K=2, seed=83, normalization=False,
+              flooring=("add", 1e-6))
     # --- operators ---
     run_operators()
 

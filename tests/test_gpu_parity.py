@@ -396,6 +396,67 @@ def test_fast_gauss_mnmf_against_golden(case):
     assert rel_err(Y, g["final_output"]) < 1e-7  # Wiener filter: eigh + solve, cond(R)-amplified
 
 
+GMNMF_CASES = ["gmnmf_m2", "gmnmf_m3", "gmnmf_m4_n3", "gmnmf_m2_nonorm_add"]
+
+
+@pytest.mark.parametrize("case", GMNMF_CASES)
+def test_gauss_mnmf_against_golden(case):
+    """Full-rank MNMF against the reference: 10 iterations of per-point eigen-floors, inverses and
+    a matrix geometric mean.  Held to 1e-7 (cond(R)-amplified round-off; the reference's own
+    regression tolerance for this class is atol 1e-7)."""
+    from ssspy_amd.bss.mnmf import GaussMNMF
+
+    g = load_golden(case)
+    snap = Snap(["spatial", "basis", "activation"])
+    m = GaussMNMF(n_basis=int(g["meta_n_basis"]), n_sources=int(g["meta_n_sources"]),
+                  flooring_fn=_flooring_fn(g), callbacks=snap,
+                  normalization=bool(g["meta_normalization"]))
+    init = dict(basis=g["basis0"], activation=g["activation0"])
+    if "spatial0" in g:
+        init["spatial"] = g["spatial0"].copy()
+    Y = m(g["X"], n_iter=int(g["meta_n_iter"]), **init)
+    for key, value in snap.store.items():
+        assert rel_err(value, g[key]) < 1e-7, key
+    assert len(snap.store) == 9
+    np.testing.assert_allclose(m.loss, g["loss"], rtol=1e-8)
+    assert all(type(v) is float for v in m.loss)
+    assert rel_err(m.spatial, g["final_spatial"]) < 1e-7
+    assert rel_err(m.basis, g["final_basis"]) < 1e-7
+    assert rel_err(Y, g["final_output"]) < 1e-7
+    assert m.spatial.shape == g["final_spatial"].shape and Y.dtype == np.complex128
+
+
+def test_gauss_mnmf_steps_batch_and_oracle():
+    """Step methods == fused update; batched == per-mixture; larger shape against the oracle
+    (K = 20 > 16, n_sources = 5 > n_channels = 4, T not a multiple of the block)."""
+    from oracle.gmnmf import GaussMNMFOracle
+    from ssspy_amd.bss.mnmf import GaussMNMF
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    M, N, F, T, K = 4, 5, 13, 150, 20
+    Xb = np.stack([nmf_mixture(s, M, F, T) for s in (31, 32)])
+    basis = np.random.default_rng(7).random((2, N, F, K))
+    act = np.random.default_rng(8).random((2, N, K, T))
+
+    class Stepwise(GaussMNMF):
+        def normalize(self, axis1=-2, axis2=-1):
+            super().normalize(axis1=axis1, axis2=axis2)
+
+    mb = GaussMNMF(n_basis=K, n_sources=N)
+    Yb = mb(Xb, n_iter=3, basis=basis, activation=act)
+    assert np.asarray(mb.loss).shape == (4, 2)
+    for b in range(2):
+        ref = GaussMNMFOracle(n_basis=K, n_sources=N)
+        Yr = ref.run(Xb[b], n_iter=3, basis=basis[b], activation=act[b])
+        assert rel_err(Yb[b], Yr) < 1e-7
+        assert rel_err(mb.spatial[b], ref.spatial) < 1e-7
+        np.testing.assert_allclose(np.asarray(mb.loss)[:, b], ref.loss, rtol=1e-8)
+        for cls in (GaussMNMF, Stepwise):
+            m = cls(n_basis=K, n_sources=N)
+            Y = m(Xb[b], n_iter=3, basis=basis[b], activation=act[b])
+            assert rel_err(Y, Yb[b]) < 1e-11
+
+
 def test_fast_gauss_mnmf_step_methods_match_fused_update():
     from ssspy_amd.bss.mnmf import FastGaussMNMF
 

@@ -13,6 +13,7 @@ from conftest import load_golden, rel_err, rel_err_up_to_phase
 from oracle import spatial as sp
 from oracle.ilrma import GaussILRMAOracle
 from oracle.iva import AuxIVAOracle
+from oracle.gmnmf import GaussMNMFOracle
 from oracle.mnmf import FastGaussMNMFOracle
 
 TOL = 1e-11
@@ -144,6 +145,34 @@ def test_fast_gauss_mnmf(case):
     np.testing.assert_allclose(losses, g["loss"], rtol=1e-10)
     Y = m.separate(m.input)
     assert rel_err(Y, g["final_output"]) < 1e-9
+
+
+GMNMF_CASES = ["gmnmf_m2", "gmnmf_m3", "gmnmf_m4_n3", "gmnmf_m2_nonorm_add"]
+
+
+@pytest.mark.parametrize("case", GMNMF_CASES)
+def test_gauss_mnmf(case):
+    """Full-rank MNMF: Hermitian eigen-floors and a matrix geometric mean sit in the loop, so the
+    restatement is held to 1e-8 (the reference's own regression tolerance is atol 1e-7)."""
+    g = load_golden(case)
+    m = GaussMNMFOracle(
+        n_basis=int(g["meta_n_basis"]), n_sources=int(g["meta_n_sources"]), flooring=_floor(g),
+        normalization=bool(g["meta_normalization"]),
+    )
+    init = dict(basis=g["basis0"], activation=g["activation0"])
+    if "spatial0" in g:
+        init["spatial"] = g["spatial0"]
+    m.reset(g["X"], **init)
+    losses = [m.compute_loss()]
+    for k in range(1, int(g["meta_n_iter"]) + 1):
+        m.update_once()
+        losses.append(m.compute_loss())
+        for name in ("spatial", "basis", "activation"):
+            key = "it{}_{}".format(k, name)
+            if key in g:
+                assert rel_err(getattr(m, name), g[key]) < 1e-8, key
+    np.testing.assert_allclose(losses, g["loss"], rtol=1e-9)
+    assert rel_err(m.separate(m.input), g["final_output"]) < 1e-8
 
 
 @pytest.mark.parametrize("N", [2, 3, 4, 8])
