@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     args = ap.parse_args()
     from ssspy_amd.bss.iva import AuxLaplaceIVA
-    from ssspy_amd.bss.mnmf import FastGaussMNMF
+    from ssspy_amd.bss.mnmf import FastGaussMNMF, GaussMNMF
 
     # configs[2]: AuxIVA-ISS, 8 sources
     N, F, T = 8, 2049, 1024
@@ -77,6 +77,32 @@ def main():
                       "ms_per_iter": round(dt * 1e3, 3), "mixture_iterations_per_s": round(B / dt, 2),
                       "algorithmic_GBs": round(4 * 16 * M * F * T * B / dt / 1e9, 1),
                       "wiener_separate_ms": round(ds * 1e3, 3), "reset_s": round(t_reset, 3)}))
+    del m
+    torch.cuda.empty_cache()
+
+    # GaussMNMF (full-rank SCM) on the configs[3] shape; the CPU figure is the oracle on a
+    # 1/16-size slice of the same mixture scaled up (the full shape needs ~10 GB of temporaries)
+    m = GaussMNMF(n_basis=K, record_loss=False, rng=np.random.default_rng(0))
+    m._bind_input(X)
+    m._reset()
+    for _ in range(2):
+        m.update_once()
+    dt = timed(m.update_once, max(3, args.iters // 4))
+    ds = timed(m._separate_dev, 3)
+    out = {"config": "GaussMNMF N=M=4 F=1025 T=512 K=8 batch={}".format(B),
+           "ms_per_iter": round(dt * 1e3, 3), "mixture_iterations_per_s": round(B / dt, 2),
+           "wiener_separate_ms": round(ds * 1e3, 3)}
+    if args.batch == 1:
+        from oracle.gmnmf import GaussMNMFOracle
+
+        Fs = 64
+        ref = GaussMNMFOracle(n_basis=K, record_loss=False, rng=np.random.default_rng(0))
+        ref.reset(X[:, :Fs, :])
+        ref.update_once()
+        t0 = time.perf_counter()
+        ref.update_once()
+        out["cpu_oracle_s_per_iter_extrapolated"] = round((time.perf_counter() - t0) * F / Fs, 2)
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

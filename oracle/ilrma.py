@@ -29,10 +29,20 @@ class GaussILRMAOracle:
         reference_id=0,
         rng=None,
         model=("gauss", None),
+        source_algorithm="MM",
+        partitioning=False,
     ):
         # model: ("gauss", None) GaussILRMA | ("t", dof) TILRMA | ("ggd", beta) GGDILRMA
         assert model[0] in ("gauss", "t", "ggd")
         self.model = model
+        # "ME": same numerator / denominator as MM, exponent 1, domain 2 only, Gauss and t models
+        # (ref: ssspy/bss/ilrma.py:1249-1401, :2659-2830)
+        assert source_algorithm in ("MM", "ME")
+        assert source_algorithm == "MM" or (domain == 2 and model[0] != "ggd")
+        self.source_algorithm = source_algorithm
+        # partitioning: shared basis (F, K) / activation (K, T) assigned to sources by the latent
+        # variables Z (N, K), columns of Z sum to one (ref: ssspy/bss/ilrma.py:201-270, :297-327)
+        self.partitioning = partitioning
         assert spatial_algorithm in ("IP", "IP1", "IP2", "ISS", "ISS1", "ISS2")
         self.pairs = None  # None = the reference's default selector for the algorithm
         self.n_basis = n_basis
@@ -51,7 +61,7 @@ class GaussILRMAOracle:
         return self.spatial_algorithm in ("IP", "IP1", "IP2")
 
     # -- initialisation ----------------------------------------------------
-    def reset(self, X, basis=None, activation=None, demix_filter=None):
+    def reset(self, X, basis=None, activation=None, demix_filter=None, latent=None):
         """ref: ssspy/bss/ilrma.py:151-199 (ILRMABase._reset), :201-270 (_init_nmf), :875-898."""
         self.input = X.copy()
         N, F, T = X.shape
@@ -63,15 +73,23 @@ class GaussILRMAOracle:
             W = demix_filter.copy()
         self.demix_filter = W
         self.output = sp.separate(self.input, W)
+        lead = () if self.partitioning else (N,)
         if basis is None:
-            basis = sp.floor(self.rng.random((N, F, self.n_basis)), self.flooring)
+            basis = sp.floor(self.rng.random(lead + (F, self.n_basis)), self.flooring)
         else:
             basis = basis.copy()
         if activation is None:
-            activation = sp.floor(self.rng.random((N, self.n_basis, T)), self.flooring)
+            activation = sp.floor(self.rng.random(lead + (self.n_basis, T)), self.flooring)
         else:
             activation = activation.copy()
         self.basis, self.activation = basis, activation
+        if self.partitioning:
+            if latent is None:
+                latent = self.rng.random((N, self.n_basis))
+                latent = sp.floor(latent / latent.sum(axis=0), self.flooring)
+            else:
+                latent = latent.copy()
+            self.latent = latent
         if not self.uses_filter:
             self.demix_filter = None
 
@@ -80,15 +98,42 @@ class GaussILRMAOracle:
             return self.output
         return sp.separate(self.input, self.demix_filter)
 
+    def _tv(self):
+        """Source model R_nij.  ref: ssspy/bss/ilrma.py:297-327 (reconstruct_nmf)."""
+        if self.partitioning:
+            return np.einsum("nk,ik,kj->nij", self.latent, self.basis, self.activation)
+        return self.basis @ self.activation
+
+    def _expo(self, expo):
+        return 1 if self.source_algorithm == "ME" else expo
+
     # -- one iteration -----------------------------------------------------
+    def update_latent(self):
+        """z_nk <- z_nk (sum_ij t v numer / sum_ij t v / R)^e, columns renormalised.
+
+        ref: ssspy/bss/ilrma.py:1007-1049 (MM), :1206-1247 (ME), :2384-2432, :3698-3743.
+        """
+        Z, T, V = self.latent, self.basis, self.activation
+        R = self._tv()
+        numer, expo = self._mm_numerator(self._current_output(), R)
+        num = np.einsum("ik,kj,nij->nk", T, V, numer)
+        den = np.einsum("ik,kj,nij->nk", T, V, 1 / R)
+        Z = ((num / den) ** self._expo(expo)) * Z
+        self.latent = Z / Z.sum(axis=0)
+
     def update_basis(self):
-        """ref: ssspy/bss/ilrma.py:1051-1128 (update_basis_mm, no partitioning)."""
+        """ref: ssspy/bss/ilrma.py:1051-1128 (update_basis_mm)."""
         T, V = self.basis, self.activation
-        TV = T @ V
+        TV = self._tv()
         numer, expo = self._mm_numerator(self._current_output(), TV)
-        num = np.sum(V[:, None, :, :] * numer[:, :, None, :], axis=3)
-        den = np.sum(V[:, None, :, :] / TV[:, :, None, :], axis=3)
-        self.basis = sp.floor(((num / den) ** expo) * T, self.flooring)
+        if self.partitioning:
+            Z = self.latent
+            num = np.einsum("nk,kj,nij->ik", Z, V, numer)
+            den = np.einsum("nk,kj,nij->ik", Z, V, 1 / TV)
+        else:
+            num = np.sum(V[:, None, :, :] * numer[:, :, None, :], axis=3)
+            den = np.sum(V[:, None, :, :] / TV[:, :, None, :], axis=3)
+        self.basis = sp.floor(((num / den) ** self._expo(expo)) * T, self.flooring)
 
     def _mm_numerator(self, Y, TV):
         """Per-(n,i,j) factor of the MM numerator and the exponent of the ratio.
@@ -113,7 +158,7 @@ class GaussILRMAOracle:
         """varphi = 1 / R~.  ref: ssspy/bss/ilrma.py:1494-1498 (Gauss), :2915-2935 (t), :3987-4011 (GGD)."""
         p = self.domain
         kind, param = self.model
-        TV = self.basis @ self.activation
+        TV = self._tv()
         if kind == "gauss":
             return 1 / TV ** (2 / p)
         if kind == "t":
@@ -124,13 +169,18 @@ class GaussILRMAOracle:
         return 1 / ((2 / beta) * Y2b * TV ** (beta / p))
 
     def update_activation(self):
-        """ref: ssspy/bss/ilrma.py:1130-1204 (update_activation_mm, no partitioning)."""
+        """ref: ssspy/bss/ilrma.py:1130-1204 (update_activation_mm)."""
         T, V = self.basis, self.activation
-        TV = T @ V
+        TV = self._tv()
         numer, expo = self._mm_numerator(self._current_output(), TV)
-        num = np.sum(T[:, :, :, None] * numer[:, :, None, :], axis=1)
-        den = np.sum(T[:, :, :, None] / TV[:, :, None, :], axis=1)
-        self.activation = sp.floor(((num / den) ** expo) * V, self.flooring)
+        if self.partitioning:
+            Z = self.latent
+            num = np.einsum("nk,ik,nij->kj", Z, T, numer)
+            den = np.einsum("nk,ik,nij->kj", Z, T, 1 / TV)
+        else:
+            num = np.sum(T[:, :, :, None] * numer[:, :, None, :], axis=1)
+            den = np.sum(T[:, :, :, None] / TV[:, :, None, :], axis=1)
+        self.activation = sp.floor(((num / den) ** self._expo(expo)) * V, self.flooring)
 
     def update_spatial(self):
         """ref: ssspy/bss/ilrma.py:1440-1507 (IP1), :1635-1696 (ISS1)."""
@@ -156,7 +206,13 @@ class GaussILRMAOracle:
         p = self.domain
         Y = self._current_output()
         psi = sp.floor(np.sqrt(np.mean(np.abs(Y) ** 2, axis=(-2, -1))), self.flooring)
-        self.basis = self.basis / (psi[:, None, None] ** p)
+        if self.partitioning:
+            Z_psi = self.latent / (psi[:, None] ** p)
+            scale = Z_psi.sum(axis=0)
+            self.basis = self.basis * scale[None, :]
+            self.latent = Z_psi / scale
+        else:
+            self.basis = self.basis / (psi[:, None, None] ** p)
         if self.demix_filter is None:
             self.output = Y / psi[:, None, None]
         else:
@@ -164,6 +220,8 @@ class GaussILRMAOracle:
 
     def update_once(self):
         """ref: ssspy/bss/ilrma.py:900-922."""
+        if self.partitioning:
+            self.update_latent()
         self.update_basis()
         self.update_activation()
         self.update_spatial()
@@ -180,7 +238,7 @@ class GaussILRMAOracle:
             W = self.demix_filter
             Y = sp.separate(self.input, W)
         Y2 = np.abs(Y) ** 2
-        TV = self.basis @ self.activation
+        TV = self._tv()
         kind, param = self.model
         if kind == "gauss":
             loss = Y2 / (TV ** (2 / p)) + (2 / p) * np.log(TV)

@@ -96,14 +96,23 @@ def meta(**kw):
 
 # --------------------------------------------------------------------------- ILRMA
 def run_ilrma(name, *, N, F, T, K, algo, seed, gen=gen_iid, domain=2, flooring=("max", 1e-10),
-              normalization=True, scale_restoration=True, n_iter=10, model=("gauss", None)):
+              normalization=True, scale_restoration=True, n_iter=10, model=("gauss", None),
+              source_algorithm="MM", partitioning=False):
     if skipped(name):
         return
     X = gen(seed, N, F, T)
-    basis = np.random.default_rng(seed + 1).random((N, F, K))
-    activation = np.random.default_rng(seed + 2).random((N, K, T))
-    snap = Snapshots(["demix_filter", "output", "basis", "activation"])
-    common = dict(spatial_algorithm=algo, domain=domain, flooring_fn=flooring_of(flooring),
+    init = {}
+    if partitioning:
+        basis = np.random.default_rng(seed + 1).random((F, K))
+        activation = np.random.default_rng(seed + 2).random((K, T))
+        latent = np.random.default_rng(seed + 5).random((N, K))
+        init["latent"] = latent / latent.sum(axis=0)
+    else:
+        basis = np.random.default_rng(seed + 1).random((N, F, K))
+        activation = np.random.default_rng(seed + 2).random((N, K, T))
+    snap = Snapshots(["demix_filter", "output", "basis", "activation", "latent"])
+    common = dict(spatial_algorithm=algo, source_algorithm=source_algorithm, domain=domain,
+                  partitioning=partitioning, flooring_fn=flooring_of(flooring),
                   callbacks=snap, normalization=normalization, scale_restoration=scale_restoration,
                   rng=np.random.default_rng(seed + 3))
     if model[0] == "t":
@@ -112,14 +121,19 @@ def run_ilrma(name, *, N, F, T, K, algo, seed, gen=gen_iid, domain=2, flooring=(
         m = GGDILRMA(n_basis=K, beta=model[1], **common)
     else:
         m = GaussILRMA(n_basis=K, **common)
-    Y = m(X, n_iter=n_iter, basis=basis, activation=activation)
+    Y = m(X, n_iter=n_iter, basis=basis, activation=activation,
+          **{k: v.copy() for k, v in init.items()})
     out = dict(X=X, basis0=basis, activation0=activation, loss=np.array(m.loss), final_output=Y,
                final_basis=m.basis, final_activation=m.activation)
+    if partitioning:
+        out["latent0"] = init["latent"]
+        out["final_latent"] = m.latent
     if m.demix_filter is not None:
         out["final_demix_filter"] = m.demix_filter
     out.update(snap.store)
     out.update(meta(kind="gauss_ilrma", algo=algo, domain=domain, n_basis=K, n_iter=n_iter,
                     model=model[0], model_param=(0.0 if model[1] is None else model[1]),
+                    source_algorithm=source_algorithm, partitioning=partitioning,
                     floor_kind=flooring[0], floor_eps=flooring[1], normalization=normalization,
                     scale_restoration=scale_restoration))
     save(name, **out)
@@ -288,6 +302,23 @@ def main():
     run_ilrma("ggdilrma_iss1_n2", N=2, F=17, T=33, K=3, algo="ISS", seed=74, model=("ggd", 1.5))
     run_ilrma("ggdilrma_iss2_n3_p1", N=3, F=16, T=36, K=4, algo="ISS2", seed=75, domain=1, gen=gen_mixture,
               model=("ggd", 0.7))
+    # --- ME source updates and partitioning (latent variables) ---
+    run_ilrma("gilrma_me_ip1_n3", N=3, F=18, T=40, K=4, algo="IP", seed=90, gen=gen_mixture,
+              source_algorithm="ME")
+    run_ilrma("tilrma_me_iss1_n2", N=2, F=17, T=34, K=3, algo="ISS", seed=91, model=("t", 6.0),
+              source_algorithm="ME")
+    run_ilrma("gilrma_part_ip1_n3", N=3, F=18, T=40, K=6, algo="IP", seed=92, gen=gen_mixture,
+              partitioning=True)
+    run_ilrma("gilrma_part_iss1_n2_p1", N=2, F=17, T=34, K=5, algo="ISS", seed=93, domain=1,
+              partitioning=True)
+    run_ilrma("gilrma_part_me_ip2_n3", N=3, F=16, T=36, K=6, algo="IP2", seed=94, gen=gen_mixture,
+              partitioning=True, source_algorithm="ME")
+    run_ilrma("tilrma_part_ip1_n2", N=2, F=18, T=40, K=4, algo="IP", seed=95, model=("t", 5.0),
+              partitioning=True)
+    run_ilrma("ggdilrma_part_iss1_n3", N=3, F=16, T=36, K=6, algo="ISS", seed=96, gen=gen_mixture,
+              model=("ggd", 1.3), partitioning=True)
+    run_ilrma("tilrma_part_me_nonorm_n2", N=2, F=16, T=34, K=4, algo="IP", seed=97, model=("t", 4.0),
+              partitioning=True, source_algorithm="ME", normalization=False)
     # --- AuxIVA ---
     run_iva("auxlap_ip1_n2", N=2, F=33, T=40, algo="IP", contrast="laplace", seed=0)
     run_iva("auxlap_ip1_n4", N=4, F=20, T=50, algo="IP1", contrast="laplace", seed=1, gen=gen_mixture)

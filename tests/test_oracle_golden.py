@@ -24,6 +24,9 @@ ILRMA_CASES = [
     "gilrma_iss1_n3_p1", "gilrma_ip2_n3", "gilrma_ip2_n2", "gilrma_iss2_n4", "gilrma_iss2_n3",
     "tilrma_ip1_n3", "tilrma_iss1_n2_p1", "tilrma_ip2_n3", "ggdilrma_ip1_n3", "ggdilrma_iss1_n2",
     "ggdilrma_iss2_n3_p1",
+    "gilrma_me_ip1_n3", "tilrma_me_iss1_n2", "gilrma_part_ip1_n3", "gilrma_part_iss1_n2_p1",
+    "gilrma_part_me_ip2_n3", "tilrma_part_ip1_n2", "ggdilrma_part_iss1_n3",
+    "tilrma_part_me_nonorm_n2",
 ]
 
 
@@ -63,13 +66,18 @@ def test_gauss_ilrma(case):
         domain=float(g["meta_domain"]), flooring=_floor(g),
         normalization=bool(g["meta_normalization"]),
         scale_restoration=bool(g["meta_scale_restoration"]), model=_model(g),
+        source_algorithm=str(g["meta_source_algorithm"]) if "meta_source_algorithm" in g else "MM",
+        partitioning=bool(g["meta_partitioning"]) if "meta_partitioning" in g else False,
     )
-    m.reset(g["X"], basis=g["basis0"], activation=g["activation0"])
+    init = dict(basis=g["basis0"], activation=g["activation0"])
+    if m.partitioning:
+        init["latent"] = g["latent0"]
+    m.reset(g["X"], **init)
     losses = [m.compute_loss()]
     for k in range(1, int(g["meta_n_iter"]) + 1):
         m.update_once()
         losses.append(m.compute_loss())
-        _check_snapshots(g, k, m, ["demix_filter", "output", "basis", "activation"])
+        _check_snapshots(g, k, m, ["demix_filter", "output", "basis", "activation", "latent"])
     np.testing.assert_allclose(losses, g["loss"], rtol=1e-10)
     if m.scale_restoration:
         m.restore_scale()
