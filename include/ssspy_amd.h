@@ -60,6 +60,9 @@ enum {
 /* source models of ILRMA (reference classes GaussILRMA / TILRMA / GGDILRMA); `model_param` is
  * unused, the degree of freedom nu, or the shape beta respectively */
 enum { SSSPY_SOURCE_GAUSS = 0, SSSPY_SOURCE_T = 1, SSSPY_SOURCE_GGD = 2 };
+/* OR-ed into `source_model`: source_algorithm="ME" -- the same numerator / denominator sums with
+ * exponent 1 (domain must be 2; Gauss and t models; ssspy/bss/ilrma.py:1249-1401, :2659-2830) */
+enum { SSSPY_SOURCE_ME = 0x100 };
 
 #define SSSPY_MAX_SOURCES 8
 #define SSSPY_MAX_BASIS 64

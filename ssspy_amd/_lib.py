@@ -16,6 +16,7 @@ OK, ERR_BADARG, ERR_HIP, ERR_UNSUPPORTED = 0, 1, 2, 3
 FLOOR_NONE, FLOOR_MAX, FLOOR_ADD = 0, 1, 2
 WEIGHT_UNIT, WEIGHT_FRAME, WEIGHT_BIN_FRAME = 0, 1, 2
 SOURCE_GAUSS, SOURCE_T, SOURCE_GGD = 0, 1, 2
+SOURCE_ME = 0x100  # OR-ed into the model: source_algorithm="ME"
 CONTRAST_LAPLACE, CONTRAST_GAUSS, CONTRAST_GAUSS_FIXED = 0, 1, 2
 MAX_PAIRS = 32
 MAX_SOURCES, MAX_BASIS = 8, 64

@@ -187,7 +187,14 @@ class _MMILRMA(ILRMABase):
     updates, normalisation, loss.  The model enters only as ``_model`` = (SSSPY_SOURCE_*, param),
     which the kernels branch on (include/ssspy_amd.h)."""
 
-    _model = _ops.GAUSS
+    _base_model = _ops.GAUSS
+
+    @property
+    def _model(self):
+        kind, param = self._base_model
+        if self.source_algorithm == "ME":
+            kind |= _lib.SOURCE_ME
+        return (kind, param)
     _name = "ILRMA"
 
     def _configure(self, spatial_algorithm, source_algorithm, domain, partitioning, normalization,
@@ -197,8 +204,6 @@ class _MMILRMA(ILRMABase):
                 "spatial_algorithm={!r} is not built for the device path yet "
                 "(available: IP, IP1, IP2, ISS, ISS1, ISS2).".format(spatial_algorithm)
             )
-        if source_algorithm != "MM":
-            raise NotImplementedError("source_algorithm='ME' is not built for the device path yet.")
         if partitioning:
             raise NotImplementedError("partitioning=True is not built for the device path yet.")
         self.spatial_algorithm = spatial_algorithm
@@ -266,7 +271,8 @@ class _MMILRMA(ILRMABase):
             getattr(cls, name) is getattr(_MMILRMA, name)
             for name in ("update_source_model", "update_spatial_model", "normalize",
                          "update_basis_mm", "update_activation_mm", "update_spatial_model_ip1",
-                         "normalize_by_power")
+                         "normalize_by_power", "update_source_model_me", "update_basis_me",
+                         "update_activation_me")
         )
 
     def update_once(self, flooring_fn="self") -> None:
@@ -304,8 +310,33 @@ class _MMILRMA(ILRMABase):
         """ref: ssspy/bss/ilrma.py:924-978."""
         if self.source_algorithm == "MM":
             self.update_source_model_mm(flooring_fn=flooring_fn)
+        elif self.source_algorithm == "ME":
+            self.update_source_model_me(flooring_fn=flooring_fn)
         else:
-            raise NotImplementedError("source_algorithm='ME' is not built for the device path yet.")
+            raise ValueError(
+                "{}-algorithm-based source model updates are not supported.".format(
+                    self.source_algorithm
+                )
+            )
+
+    def update_source_model_me(self, flooring_fn="self") -> None:
+        """Same sums as MM with exponent 1 (ref: ssspy/bss/ilrma.py:980-1005, :1249-1401)."""
+        if self.domain != 2:
+            raise ValueError("Domain parameter is expected 2, but given {}.".format(self.domain))
+        self.update_basis_me(flooring_fn=flooring_fn)
+        self.update_activation_me(flooring_fn=flooring_fn)
+
+    def update_basis_me(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/ilrma.py:1249-1325."""
+        if self.source_algorithm != "ME":
+            raise ValueError("update_basis_me needs source_algorithm='ME'.")
+        self.update_basis_mm(flooring_fn=flooring_fn)
+
+    def update_activation_me(self, flooring_fn="self") -> None:
+        """ref: ssspy/bss/ilrma.py:1327-1401."""
+        if self.source_algorithm != "ME":
+            raise ValueError("update_activation_me needs source_algorithm='ME'.")
+        self.update_activation_mm(flooring_fn=flooring_fn)
 
     def update_source_model_mm(self, flooring_fn="self") -> None:
         self.update_basis_mm(flooring_fn=flooring_fn)
@@ -551,7 +582,7 @@ class TILRMA(_MMILRMA):
                         pair_selector)
 
     @property
-    def _model(self):
+    def _base_model(self):
         return (_lib.SOURCE_T, float(self.dof))
 
     def _repr_model(self) -> str:
@@ -605,7 +636,7 @@ class GGDILRMA(_MMILRMA):
                         pair_selector)
 
     @property
-    def _model(self):
+    def _base_model(self):
         return (_lib.SOURCE_GGD, float(self.beta))
 
     def _repr_model(self) -> str:

@@ -44,7 +44,13 @@ static inline bool fast_path(int N, int T, int K, double domain, int model = SSS
          (T % 2 == 0) && domain == 2.0;
 }
 
-static inline int check_model(int model, double param) {
+static inline int check_model(int source_model, double param, double domain = 2.0) {
+  const int model = source_model & 0xff;
+  const bool me = (source_model & SSSPY_SOURCE_ME) != 0;
+  if ((source_model & ~(0xff | SSSPY_SOURCE_ME)) != 0)
+    return fail(SSSPY_ERR_BADARG, "bad source model flags");
+  if (me && (domain != 2.0 || model == SSSPY_SOURCE_GGD))
+    return fail(SSSPY_ERR_BADARG, "ME source updates need domain == 2 and a Gauss or t model");
   if (model == SSSPY_SOURCE_GAUSS) return SSSPY_OK;
   if (model == SSSPY_SOURCE_T && param > 0.0) return SSSPY_OK;
   if (model == SSSPY_SOURCE_GGD && param > 0.0 && param < 2.0) return SSSPY_OK;
@@ -257,7 +263,8 @@ size_t ssspy_ilrma_workspace_bytes(int B, int N, int F, int T, int K) {
 
 static IlrmaDims make_dims(int B, int F, int T, int K, double domain, int model, double mparam,
                            int floor_kind, double floor_eps) {
-  return IlrmaDims{B, F, T, K, domain, model, mparam, floor_kind, floor_eps};
+  return IlrmaDims{B, F, T, K, domain, model & 0xff, (model & SSSPY_SOURCE_ME) ? 1 : 0, mparam,
+                   floor_kind, floor_eps};
 }
 
 int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const double *activation,
@@ -267,7 +274,7 @@ int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const 
   SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0, "update_basis: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_basis: n_basis must be in [1, 64]");
   SSSPY_REQUIRE(domain > 0.0 && domain <= 2.0, "update_basis: domain must be in (0, 2]");
-  int rc = check_model(source_model, model_param);
+  int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
   const IlrmaWs w = ilrma_ws(B, N, F, T, K);
   SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "update_basis: workspace too small");
@@ -298,7 +305,7 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
   SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0,
                 "update_activation: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_activation: n_basis must be in [1, 64]");
-  int rc = check_model(source_model, model_param);
+  int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
   const IlrmaWs w = ilrma_ws(B, N, F, T, K);
   SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "update_activation: workspace too small");
@@ -338,7 +345,7 @@ int ssspy_ilrma_weighted_covariance(const void *X, const void *W, const double *
   SSSPY_REQUIRE(X && basis && activation && U && B > 0 && F > 0 && T > 0,
                 "ilrma_weighted_covariance: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "ilrma_weighted_covariance: bad n_basis");
-  int rc = check_model(source_model, model_param);
+  int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
   const IlrmaWs w = ilrma_ws(B, N, F, T, K);
   SSSPY_REQUIRE(workspace && workspace_bytes >= w.total,
@@ -392,7 +399,7 @@ int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *act
                            void *stream) {
   SSSPY_REQUIRE(basis && activation && varphi && B > 0, "iss_weight: bad argument");
   SSSPY_REQUIRE(source_model == SSSPY_SOURCE_GAUSS || Y, "iss_weight: this model needs Y");
-  int rc = check_model(source_model, model_param);
+  int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   dim3 grid(F, N, B), block(256);
@@ -406,7 +413,7 @@ int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
                           double domain, int source_model, double model_param, void *stream) {
   SSSPY_REQUIRE(X && basis && activation && out && B > 0, "ilrma_loss_data: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "ilrma_loss_data: bad n_basis");
-  int rc = check_model(source_model, model_param);
+  int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
   hipStream_t st = as_stream(stream);
   hipError_t e = hipMemsetAsync(out, 0, (size_t)B * sizeof(double), st);

@@ -9,6 +9,7 @@ struct IlrmaDims {
   int B, F, T, K;
   double p;       // domain
   int model;      // SSSPY_SOURCE_GAUSS / _T / _GGD
+  int me;         // 1: "ME" source updates (same sums, exponent 1; ref: ssspy/bss/ilrma.py:1249-1401)
   double mparam;  // dof (t) or beta (GGD)
   int floor_kind;
   double floor_eps;
@@ -37,6 +38,7 @@ __device__ __forceinline__ void mm_weights(double P, double R, const IlrmaDims &
 
 __device__ __forceinline__ double mm_ratio_pow(double num, double den, const IlrmaDims &d) {
   const double ratio = num / den;
+  if (d.me) return ratio;
   if (d.model == SSSPY_SOURCE_GGD) return pow(ratio, d.p / (d.mparam + d.p));
   return (d.p == 2.0) ? sqrt(ratio) : pow(ratio, d.p / (d.p + 2.0));
 }

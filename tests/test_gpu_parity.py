@@ -23,7 +23,7 @@ ILRMA_CASES = [
     "gilrma_ip1_n2_nofloor", "gilrma_ip1_n3_raw", "gilrma_iss1_n2", "gilrma_iss1_n4",
     "gilrma_iss1_n3_p1", "gilrma_ip2_n3", "gilrma_ip2_n2", "gilrma_iss2_n4", "gilrma_iss2_n3",
     "tilrma_ip1_n3", "tilrma_iss1_n2_p1", "tilrma_ip2_n3", "ggdilrma_ip1_n3", "ggdilrma_iss1_n2",
-    "ggdilrma_iss2_n3_p1",
+    "ggdilrma_iss2_n3_p1", "gilrma_me_ip1_n3", "tilrma_me_iss1_n2",
 ]
 IVA_CASES = [
     "auxlap_ip1_n2", "auxlap_ip1_n4", "auxlap_iss1_n2", "auxlap_iss1_n8", "auxgauss_ip1_n3",
@@ -127,6 +127,7 @@ def test_gauss_ilrma_against_golden(case):
         domain=float(g["meta_domain"]), flooring_fn=_flooring_fn(g), callbacks=snap,
         normalization=bool(g["meta_normalization"]),
         scale_restoration=bool(g["meta_scale_restoration"]),
+        source_algorithm=str(g["meta_source_algorithm"]) if "meta_source_algorithm" in g else "MM",
     )
     b0, a0 = g["basis0"].copy(), g["activation0"].copy()
     Y = m(g["X"], n_iter=int(g["meta_n_iter"]), basis=b0, activation=a0)
