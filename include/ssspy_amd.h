@@ -255,6 +255,36 @@ int ssspy_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis,
                            double floor_eps, void *workspace, size_t workspace_bytes, int *info,
                            void *stream);
 
+/* ---- partitioning (latent variables): basis (B,F,K), activation (B,K,T), latent (B,N,K) with
+ * R_nij = sum_k z_nk t_ik v_kj (ssspy/bss/ilrma.py:297-327).  Every entry point above that takes
+ * (basis, activation) runs unchanged on the expanded pair
+ *   Teff[b,n,i,k] = z_nk t_ik (B,N,F,K),  Vrep[b,n,k,j] = v_kj (B,N,K,T). */
+int ssspy_ilrma_partition_expand(const double *basis, const double *activation,
+                                 const double *latent, double *Teff, double *Vrep, int B, int N,
+                                 int F, int T, int K, void *stream);
+
+enum { SSSPY_PARTITION_LATENT = 1, SSSPY_PARTITION_BASIS = 2, SSSPY_PARTITION_ACTIVATION = 4 };
+
+/* The selected source-model updates in the reference's order (latent, basis, activation), each
+ * from fresh sums; Teff / Vrep are scratch on entry and hold the expansion of the final
+ * parameters on return.  y = W x, or X itself when W == NULL.
+ * replaces: ssspy/bss/ilrma.py:1007-1049 (update_latent_mm), :1051-1128, :1130-1204 with
+ * partitioning=True, their ME forms (:1206-1401) and the TILRMA / GGDILRMA equivalents. */
+int ssspy_ilrma_partition_update(const void *X, const void *W, double *basis, double *activation,
+                                 double *latent, double *Teff, double *Vrep, int B, int N, int F,
+                                 int T, int K, double domain, int source_model, double model_param,
+                                 int steps, int floor_kind, double floor_eps, void *workspace,
+                                 size_t workspace_bytes, void *stream);
+
+/* power normalisation with partitioning: psi_n as above from (W, C) -- pass Y == NULL -- or from
+ * the separated spectrogram Y (W == C == NULL); W rows (or Y) /= psi_n;
+ * z_nk <- (z_nk / psi_n^p) / s_k, t_ik <- t_ik s_k with s_k = sum_n z_nk / psi_n^p.
+ * replaces: ssspy/bss/ilrma.py:365-444 (normalize_by_power, partitioning branch). */
+int ssspy_ilrma_partition_normalize(void *W, const void *C, void *Y, double *basis, double *latent,
+                                    int B, int N, int F, int T, int K, double domain,
+                                    int floor_kind, double floor_eps, void *workspace,
+                                    size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------ AuxIVA (IP1/ISS1) */
 
 /* r2[b,n,j] = sum_i |y_nij|^2 with y = W x (or y = X when W == NULL).   r2 (B,N,T).

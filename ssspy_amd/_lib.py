@@ -16,6 +16,7 @@ OK, ERR_BADARG, ERR_HIP, ERR_UNSUPPORTED = 0, 1, 2, 3
 FLOOR_NONE, FLOOR_MAX, FLOOR_ADD = 0, 1, 2
 WEIGHT_UNIT, WEIGHT_FRAME, WEIGHT_BIN_FRAME = 0, 1, 2
 SOURCE_GAUSS, SOURCE_T, SOURCE_GGD = 0, 1, 2
+PARTITION_LATENT, PARTITION_BASIS, PARTITION_ACTIVATION = 1, 2, 4
 SOURCE_ME = 0x100  # OR-ed into the model: source_algorithm="ME"
 CONTRAST_LAPLACE, CONTRAST_GAUSS, CONTRAST_GAUSS_FIXED = 0, 1, 2
 MAX_PAIRS = 32
@@ -59,6 +60,11 @@ PROTOTYPES = {
     "ssspy_ilrma_loss_data": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p]),
     "ssspy_ilrma_ip1_update": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _i, _i, _d,
                                     _p, _z, _p, _p]),
+    "ssspy_ilrma_partition_expand": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "ssspy_ilrma_partition_update": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d,
+                                          _i, _i, _d, _p, _z, _p]),
+    "ssspy_ilrma_partition_normalize": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p,
+                                             _z, _p]),
     "ssspy_iva_frame_power": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "ssspy_iva_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _d, _p]),
     "ssspy_iva_loss_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),

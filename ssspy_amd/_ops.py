@@ -257,6 +257,41 @@ def ilrma_ip1_update(X, C, W, basis, activation, U, domain, normalize, flooring,
     )
 
 
+def ilrma_partition_expand(basis, activation, latent, Teff, Vrep):
+    B, N, F, K = Teff.shape
+    T = Vrep.shape[-1]
+    _lib.check(
+        _L().ssspy_ilrma_partition_expand(ptr(basis), ptr(activation), ptr(latent), ptr(Teff),
+                                          ptr(Vrep), B, N, F, T, K, _st()),
+        "ilrma_partition_expand",
+    )
+
+
+def ilrma_partition_update(X, W, basis, activation, latent, Teff, Vrep, domain, steps, flooring, ws,
+                           ws_bytes, model=GAUSS):
+    B, N, F, T = X.shape
+    K = basis.shape[-1]
+    _lib.check(
+        _L().ssspy_ilrma_partition_update(ptr(X), ptr(W), ptr(basis), ptr(activation), ptr(latent),
+                                          ptr(Teff), ptr(Vrep), B, N, F, T, K, domain, model[0],
+                                          model[1], steps, flooring[0], flooring[1], ptr(ws),
+                                          ws_bytes, _st()),
+        "ilrma_partition_update",
+    )
+
+
+def ilrma_partition_normalize(W, C, Y, basis, latent, domain, flooring, ws, ws_bytes):
+    B, N, K = latent.shape
+    F = basis.shape[-2]
+    T = Y.shape[-1] if Y is not None else 1
+    _lib.check(
+        _L().ssspy_ilrma_partition_normalize(ptr(W), ptr(C), ptr(Y), ptr(basis), ptr(latent), B, N,
+                                             F, T, K, domain, flooring[0], flooring[1], ptr(ws),
+                                             ws_bytes, _st()),
+        "ilrma_partition_normalize",
+    )
+
+
 # ------------------------------------------------------------------------------- IVA
 def iva_frame_power(X, W, out=None):
     B, N, F, T = X.shape

@@ -48,6 +48,7 @@ class ILRMABase(DeviceStateMixin, IterativeMethodBase):
     output = Synced(dv.c128)
     basis = Synced(dv.f64)
     activation = Synced(dv.f64)
+    latent = Synced(dv.f64)
 
     def __init__(
         self,
@@ -100,21 +101,30 @@ class ILRMABase(DeviceStateMixin, IterativeMethodBase):
         self._U = None
 
     def _init_nmf(self, flooring_fn="self", rng=None) -> None:
-        """ref: ssspy/bss/ilrma.py:201-270 (no partitioning)."""
+        """ref: ssspy/bss/ilrma.py:201-270.  With partitioning the basis (F, K) and activation (K, T)
+        are shared and ``latent`` (N, K), columns summing to one, assigns them to the sources."""
         flooring_fn = choose_flooring_fn(flooring_fn, method=self)
         if rng is None:
             rng = np.random.default_rng()
         N, F, T, K = self.n_sources, self.n_bins, self.n_frames, self.n_basis
-        if self.partitioning:
-            raise NotImplementedError("partitioning=True is not built for the device path yet.")
+        src = () if self.partitioning else (N,)
         if not self._state_has("basis"):
-            self.basis = flooring_fn(rng.random(self._lead() + (N, F, K)))
+            self.basis = flooring_fn(rng.random(self._lead() + src + (F, K)))
         else:
             self.basis = np.array(self.basis, dtype=np.float64, copy=True)
         if not self._state_has("activation"):
-            self.activation = flooring_fn(rng.random(self._lead() + (N, K, T)))
+            self.activation = flooring_fn(rng.random(self._lead() + src + (K, T)))
         else:
             self.activation = np.array(self.activation, dtype=np.float64, copy=True)
+        if self.partitioning:
+            if not self._state_has("latent"):
+                Z = rng.random(self._lead() + (N, K))
+                self.latent = flooring_fn(Z / Z.sum(axis=-2, keepdims=True))
+            else:
+                self.latent = np.array(self.latent, dtype=np.float64, copy=True)
+            B = self._X.shape[0]
+            self._Teff = dv.empty((B, N, F, K), dv.f64, self._X.device)
+            self._Vrep = dv.empty((B, N, K, T), dv.f64, self._X.device)
 
     # -- operators --------------------------------------------------------------------
     def separate(self, input: np.ndarray, demix_filter: np.ndarray) -> np.ndarray:
@@ -128,8 +138,17 @@ class ILRMABase(DeviceStateMixin, IterativeMethodBase):
     def reconstruct_nmf(self, basis, activation, latent=None) -> np.ndarray:
         """R = T V (ref: ssspy/bss/ilrma.py:297-327); host-side convenience, not on the hot path."""
         if latent is not None:
-            raise NotImplementedError("partitioning (latent) is not built for the device path yet.")
+            return np.einsum("...nk,...ik,...kj->...nij", latent, basis, activation)
         return basis @ activation
+
+    def _nmf_pair(self):
+        """Device (basis, activation) in the per-source layout every kernel takes: the state itself,
+        or with partitioning the expansion (z_nk t_ik, v_kj) rebuilt from the current parameters."""
+        if not self.partitioning:
+            return self._state_dev("basis"), self._state_dev("activation")
+        _ops.ilrma_partition_expand(self._state_dev("basis"), self._state_dev("activation"),
+                                    self._state_dev("latent"), self._Teff, self._Vrep)
+        return self._Teff, self._Vrep
 
     def _resolve_floor(self, flooring_fn):
         if type(flooring_fn) is str and flooring_fn == "self":
@@ -204,8 +223,6 @@ class _MMILRMA(ILRMABase):
                 "spatial_algorithm={!r} is not built for the device path yet "
                 "(available: IP, IP1, IP2, ISS, ISS1, ISS2).".format(spatial_algorithm)
             )
-        if partitioning:
-            raise NotImplementedError("partitioning=True is not built for the device path yet.")
         self.spatial_algorithm = spatial_algorithm
         self.source_algorithm = source_algorithm
         self.domain = domain
@@ -272,7 +289,7 @@ class _MMILRMA(ILRMABase):
             for name in ("update_source_model", "update_spatial_model", "normalize",
                          "update_basis_mm", "update_activation_mm", "update_spatial_model_ip1",
                          "normalize_by_power", "update_source_model_me", "update_basis_me",
-                         "update_activation_me")
+                         "update_activation_me", "update_source_model_mm")
         )
 
     def update_once(self, flooring_fn="self") -> None:
@@ -282,7 +299,7 @@ class _MMILRMA(ILRMABase):
         iteration is one C-ABI call (five kernel launches on the current stream).
         """
         if (self.spatial_algorithm in _IP1 and self._uses_filter() and self._is_stock()
-                and self._power_normalization_or_off()):
+                and self._power_normalization_or_off() and not self.partitioning):
             floor = self._resolve_floor(flooring_fn)
             B, N, F, T = self._X.shape
             if self._U is None:
@@ -323,6 +340,8 @@ class _MMILRMA(ILRMABase):
         """Same sums as MM with exponent 1 (ref: ssspy/bss/ilrma.py:980-1005, :1249-1401)."""
         if self.domain != 2:
             raise ValueError("Domain parameter is expected 2, but given {}.".format(self.domain))
+        if self.partitioning:
+            self.update_latent_me()
         self.update_basis_me(flooring_fn=flooring_fn)
         self.update_activation_me(flooring_fn=flooring_fn)
 
@@ -339,8 +358,30 @@ class _MMILRMA(ILRMABase):
         self.update_activation_mm(flooring_fn=flooring_fn)
 
     def update_source_model_mm(self, flooring_fn="self") -> None:
+        if self.partitioning:
+            self.update_latent_mm()
         self.update_basis_mm(flooring_fn=flooring_fn)
         self.update_activation_mm(flooring_fn=flooring_fn)
+
+    def _partition_update(self, steps, flooring_fn="self") -> None:
+        src, W = self._source_and_filter()
+        _ops.ilrma_partition_update(src, W, self._state_dev("basis"), self._state_dev("activation"),
+                                    self._state_dev("latent"), self._Teff, self._Vrep,
+                                    float(self.domain), steps, self._resolve_floor(flooring_fn),
+                                    self._ws, self._ws_bytes, model=self._model)
+
+    def update_latent_mm(self) -> None:
+        """ref: ssspy/bss/ilrma.py:1007-1049 (and :2384-2432, :3698-3743)."""
+        self._partition_update(_lib.PARTITION_LATENT)
+        self._state_touch("latent")
+
+    def update_latent_me(self) -> None:
+        """ref: ssspy/bss/ilrma.py:1206-1247 (and :2610-2657)."""
+        if self.source_algorithm != "ME":
+            raise ValueError("update_latent_me needs source_algorithm='ME'.")
+        if self.domain != 2:
+            raise ValueError("Domain parameter is expected 2, but given {}.".format(self.domain))
+        self.update_latent_mm()
 
     def _source_and_filter(self):
         """(spectrogram tensor, filter tensor or None) whose |W x|^2 the MM updates use."""
@@ -350,6 +391,10 @@ class _MMILRMA(ILRMABase):
 
     def update_basis_mm(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/ilrma.py:1051-1128."""
+        if self.partitioning:
+            self._partition_update(_lib.PARTITION_BASIS, flooring_fn)
+            self._state_touch("basis")
+            return
         src, W = self._source_and_filter()
         _ops.ilrma_update_basis(src, W, self._state_dev("basis"), self._state_dev("activation"),
                                 float(self.domain), self._resolve_floor(flooring_fn), self._ws,
@@ -358,6 +403,10 @@ class _MMILRMA(ILRMABase):
 
     def update_activation_mm(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/ilrma.py:1130-1204."""
+        if self.partitioning:
+            self._partition_update(_lib.PARTITION_ACTIVATION, flooring_fn)
+            self._state_touch("activation")
+            return
         src, W = self._source_and_filter()
         _ops.ilrma_update_activation(src, W, self._state_dev("basis"),
                                      self._state_dev("activation"), float(self.domain),
@@ -383,8 +432,7 @@ class _MMILRMA(ILRMABase):
         B, N, F, T = self._X.shape
         if self._U is None:
             self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
-        _ops.ilrma_weighted_covariance(self._X, self._state_dev("basis"),
-                                       self._state_dev("activation"), float(self.domain),
+        _ops.ilrma_weighted_covariance(self._X, *self._nmf_pair(), float(self.domain),
                                        self._ws, self._ws_bytes, out=self._U,
                                        W=self._state_dev("demix_filter"), model=self._model,
                                        flooring=self._resolve_floor(flooring_fn))
@@ -397,8 +445,7 @@ class _MMILRMA(ILRMABase):
         """Pairwise iterative source steering on per-bin statistics.  ref: ilrma.py:1698-1792."""
         Y = self._state_dev("output")
         N = Y.shape[1]
-        varphi = _ops.ilrma_iss_weight(self._state_dev("basis"), self._state_dev("activation"),
-                                       float(self.domain), Y=Y, model=self._model,
+        varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y, model=self._model,
                                        flooring=self._resolve_floor(flooring_fn))
         Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
         G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N),
@@ -411,8 +458,7 @@ class _MMILRMA(ILRMABase):
         B, N, F, T = self._X.shape
         if self._U is None:
             self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
-        _ops.ilrma_weighted_covariance(self._X, self._state_dev("basis"),
-                                       self._state_dev("activation"), float(self.domain),
+        _ops.ilrma_weighted_covariance(self._X, *self._nmf_pair(), float(self.domain),
                                        self._ws, self._ws_bytes, out=self._U,
                                        W=self._state_dev("demix_filter"), model=self._model,
                                        flooring=self._resolve_floor(flooring_fn))
@@ -424,8 +470,7 @@ class _MMILRMA(ILRMABase):
         """Iterative source steering on per-bin statistics.  ref: ssspy/bss/ilrma.py:1635-1696."""
         Y = self._state_dev("output")
         N = Y.shape[1]
-        varphi = _ops.ilrma_iss_weight(self._state_dev("basis"), self._state_dev("activation"),
-                                       float(self.domain), Y=Y, model=self._model,
+        varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y, model=self._model,
                                        flooring=self._resolve_floor(flooring_fn))
         floor = self._resolve_floor(flooring_fn)
         if Y.shape[-1] <= _ops.iss1_fused_max_frames(N):
@@ -454,6 +499,16 @@ class _MMILRMA(ILRMABase):
     def normalize_by_power(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/ilrma.py:365-444 (no partitioning)."""
         floor = self._resolve_floor(flooring_fn)
+        if self.partitioning:
+            filt = self._uses_filter()
+            _ops.ilrma_partition_normalize(
+                self._state_dev("demix_filter") if filt else None, self._C() if filt else None,
+                None if filt else self._state_dev("output"), self._state_dev("basis"),
+                self._state_dev("latent"), float(self.domain), floor, self._ws, self._ws_bytes)
+            self._state_touch("demix_filter" if filt else "output")
+            self._state_touch("basis")
+            self._state_touch("latent")
+            return
         if self._uses_filter():
             _ops.ilrma_normalize_filter(self._state_dev("demix_filter"), self._C(),
                                         self._state_dev("basis"), float(self.domain), floor,
@@ -467,7 +522,7 @@ class _MMILRMA(ILRMABase):
 
     def compute_loss(self) -> float:
         """Negative log-likelihood (ref: ssspy/bss/ilrma.py:1910-1967)."""
-        T, V = self._state_dev("basis"), self._state_dev("activation")
+        T, V = self._nmf_pair()
         if self._uses_filter():
             W = self._state_dev("demix_filter")
             data = _ops.ilrma_loss_data(self._X, W, T, V, float(self.domain), model=self._model)

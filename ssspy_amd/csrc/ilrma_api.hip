@@ -132,9 +132,11 @@ __global__ __launch_bounds__(256) void k_ilrma_activation_finalize(double *act,
 // q comes from the IP1 kernel (fused iteration) or from k_row_power (stand-alone call).
 // grid: (ceil(F/64), B).  Every block folds q over all bins (fixed order: deterministic), then
 // scales the demixing rows and basis rows of its own 64 bins.
+// basis == NULL (partitioning): only W is scaled and psi is published to psi_out (B, N)
 __global__ __launch_bounds__(256) void k_norm_scale(c128 *W, double *basis,
                                                     const double *__restrict__ qbuf, int N, int F,
-                                                    int K, double p, int floor_kind, double eps) {
+                                                    int K, double p, int floor_kind, double eps,
+                                                    double *psi_out) {
   __shared__ double wsum[4][SSSPY_MAX_SOURCES];
   __shared__ double psi[SSSPY_MAX_SOURCES];
   const int b = blockIdx.y;
@@ -171,6 +173,8 @@ __global__ __launch_bounds__(256) void k_norm_scale(c128 *W, double *basis,
     const c128 v = Wb[e];
     Wb[e] = cmake(v.x / psi[n], v.y / psi[n]);
   }
+  if (psi_out && blockIdx.x == 0 && threadIdx.x < N) psi_out[b * N + threadIdx.x] = psi[threadIdx.x];
+  if (!basis) return;
   for (int n = 0; n < N; ++n) {
     const double pp = (p == 2.0) ? psi[n] * psi[n] : pow(psi[n], p);
     double *Tb = basis + (((long long)b * N + n) * F + i0) * K;
@@ -194,18 +198,132 @@ __global__ __launch_bounds__(256) void k_ilrma_normalize_output(c128 *Y, double 
                                                                 const double *__restrict__ acc,
                                                                 int N, int F, int T, int K,
                                                                 double p, int floor_kind,
-                                                                double eps) {
+                                                                double eps, double *psi_out) {
   const int i = blockIdx.x, n = blockIdx.y, b = blockIdx.z;
   double v = acc[b * N + n] / ((double)F * (double)T);
   const double psi = apply_floor(sqrt(v), floor_kind, eps);
+  if (psi_out && i == 0 && threadIdx.x == 0) psi_out[b * N + n] = psi;
   c128 *row = Y + (((long long)b * N + n) * F + i) * T;
   for (int j = threadIdx.x; j < T; j += blockDim.x) {
     c128 y = row[j];
     row[j] = cmake(y.x / psi, y.y / psi);
   }
+  if (!basis) return;
   const double pp = (p == 2.0) ? psi * psi : pow(psi, p);
   double *tr = basis + (((long long)b * N + n) * F + i) * K;
   for (int k = threadIdx.x; k < K; k += blockDim.x) tr[k] = tr[k] / pp;
+}
+
+// ------------------------------------------------------- partitioning (latent variables Z)
+// Shared basis t (B,F,K) / activation v (B,K,T) are assigned to the sources by z (B,N,K):
+// R_nij = sum_k z_nk t_ik v_kj.  Every kernel of the non-partitioned path runs unchanged on the
+// expanded pair Teff[b,n,i,k] = z_nk t_ik, Vrep[b,n,k,j] = v_kj; the three parameter updates
+// then recombine the per-source sums those kernels produce.
+// ref: ssspy/bss/ilrma.py:297-327 (reconstruct_nmf), :1007-1049, :1094-1128, :1170-1204.
+__global__ __launch_bounds__(256) void k_partition_expand(const double *__restrict__ basis,
+                                                          const double *__restrict__ act,
+                                                          const double *__restrict__ latent,
+                                                          double *__restrict__ Teff,
+                                                          double *__restrict__ Vrep, int N, int F,
+                                                          int T, int K) {
+  const int n = blockIdx.y, b = blockIdx.z;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const double *z = latent + ((long long)b * N + n) * K;
+  if (e < (long long)F * K) Teff[((long long)b * N + n) * F * K + e] = z[e % K] * basis[(long long)b * F * K + e];
+  if (e < (long long)K * T) Vrep[((long long)b * N + n) * K * T + e] = act[(long long)b * K * T + e];
+}
+
+// z_nk <- z_nk (sum_i t_ik S_nik / sum_i t_ik D_nik)^e, then every column of z sums to one.
+// raw: (B,N,F,K,2) basis-type sums over frames with the shared v.  grid: (B), 256 threads.
+__global__ __launch_bounds__(256) void k_partition_latent(const double *__restrict__ raw,
+                                                          const double *__restrict__ basis,
+                                                          double *latent, int N, int F, int K,
+                                                          IlrmaDims d) {
+  __shared__ double znew[SSSPY_MAX_SOURCES * SSSPY_MAX_BASIS];
+  const int b = blockIdx.x;
+  for (int e = threadIdx.x; e < N * K; e += blockDim.x) {
+    const int n = e / K, k = e % K;
+    double sn = 0.0, sd = 0.0;
+    for (int i = 0; i < F; ++i) {
+      const double t = basis[((long long)b * F + i) * K + k];
+      const double *r = raw + ((((long long)b * N + n) * F + i) * K + k) * 2;
+      sn = fma(t, r[0], sn);
+      sd = fma(t, r[1], sd);
+    }
+    znew[e] = mm_ratio_pow(sn, sd, d) * latent[((long long)b * N + n) * K + k];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < N * K; e += blockDim.x) {
+    const int k = e % K;
+    double col = 0.0;
+    for (int n = 0; n < N; ++n) col += znew[n * K + k];
+    latent[(long long)b * N * K + e] = znew[e] / col;
+  }
+}
+
+// t_ik <- floor(t_ik (sum_n z_nk S_nik / sum_n z_nk D_nik)^e).  one thread per (b, i, k)
+__global__ __launch_bounds__(256) void k_partition_basis(const double *__restrict__ raw,
+                                                         const double *__restrict__ latent,
+                                                         double *basis, int N, int F, int K,
+                                                         IlrmaDims d) {
+  const int b = blockIdx.y;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (i, k)
+  if (e >= (long long)F * K) return;
+  const int k = (int)(e % K);
+  double sn = 0.0, sd = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const double z = latent[((long long)b * N + n) * K + k];
+    const double *r = raw + (((long long)b * N + n) * F * K + e) * 2;
+    sn = fma(z, r[0], sn);
+    sd = fma(z, r[1], sd);
+  }
+  double *dst = basis + (long long)b * F * K + e;
+  *dst = apply_floor(mm_ratio_pow(sn, sd, d) * (*dst), d.floor_kind, d.floor_eps);
+}
+
+// v_kj <- floor(v_kj (sum_n num_nkj / sum_n den_nkj)^e); the per-source sums over bins were taken
+// with Teff, so they already carry z_nk.  part: [b][chunk][n][2][K][T].  one thread per (b, k, j)
+__global__ __launch_bounds__(256) void k_partition_activation(const double *__restrict__ part,
+                                                              double *act, int N, int K, int T,
+                                                              int nchunks, IlrmaDims d) {
+  const int b = blockIdx.y;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (k, j)
+  if (e >= (long long)K * T) return;
+  double sn = 0.0, sd = 0.0;
+  for (int ch = 0; ch < nchunks; ++ch)
+    for (int n = 0; n < N; ++n) {
+      const long long base = ((((long long)b * nchunks + ch) * N + n) * 2) * K * T;
+      sn += part[base + e];
+      sd += part[base + (long long)K * T + e];
+    }
+  double *dst = act + (long long)b * K * T + e;
+  *dst = apply_floor(mm_ratio_pow(sn, sd, d) * (*dst), d.floor_kind, d.floor_eps);
+}
+
+// z <- (z / psi^p) / scale, t <- t * scale, scale_k = sum_n z_nk / psi_n^p.  grid: (B)
+// ref: ssspy/bss/ilrma.py:418-427 (normalize_by_power, partitioning branch).
+__global__ __launch_bounds__(256) void k_partition_normalize(double *basis, double *latent,
+                                                             const double *__restrict__ psi, int N,
+                                                             int F, int K, double p) {
+  __shared__ double scale[SSSPY_MAX_BASIS];
+  const int b = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    double s = 0.0;
+    for (int n = 0; n < N; ++n) {
+      const double ps = psi[b * N + n];
+      s += latent[((long long)b * N + n) * K + k] / ((p == 2.0) ? ps * ps : pow(ps, p));
+    }
+    scale[k] = s;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < N * K; e += blockDim.x) {
+    const int n = e / K, k = e % K;
+    const double ps = psi[b * N + n];
+    double *z = latent + (long long)b * N * K + e;
+    *z = (*z / ((p == 2.0) ? ps * ps : pow(ps, p))) / scale[k];
+  }
+  for (long long e = threadIdx.x; e < (long long)F * K; e += blockDim.x)
+    basis[(long long)b * F * K + e] *= scale[e % K];
 }
 
 // ------------------------------------------------------------------------------ ISS weight
@@ -235,7 +353,7 @@ extern "C" {
 
 // One scratch layout for every ILRMA entry point: callers pass the same buffer everywhere.
 struct IlrmaWs {
-  size_t act_part, btmp, qbuf, psi, bpart, upart, total;
+  size_t act_part, btmp, qbuf, psi, bpart, upart, praw, total;
 };
 static inline IlrmaWs ilrma_ws(int B, int N, int F, int T, int K) {
   IlrmaWs w;
@@ -252,6 +370,8 @@ static inline IlrmaWs ilrma_ws(int B, int N, int F, int T, int K) {
   off += basis_part_bytes(N);
   w.upart = off;
   off += u_part_bytes(N);
+  w.praw = off;  // (num, den) basis sums of the partitioned updates
+  off += align256((size_t)B * N * F * K * 2 * sizeof(double));
   w.total = off;
   return w;
 }
@@ -264,7 +384,7 @@ size_t ssspy_ilrma_workspace_bytes(int B, int N, int F, int T, int K) {
 static IlrmaDims make_dims(int B, int F, int T, int K, double domain, int model, double mparam,
                            int floor_kind, double floor_eps) {
   return IlrmaDims{B, F, T, K, domain, model & 0xff, (model & SSSPY_SOURCE_ME) ? 1 : 0, mparam,
-                   floor_kind, floor_eps};
+                   floor_kind, floor_eps, 0};
 }
 
 int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const double *activation,
@@ -358,7 +478,7 @@ int ssspy_ilrma_weighted_covariance(const void *X, const void *W, const double *
 static int launch_norm_scale(void *W, double *basis, const double *qbuf, int B, int N, int F, int K,
                              double domain, int floor_kind, double floor_eps, hipStream_t st) {
   hipLaunchKernelGGL(k_norm_scale, dim3((F + 63) / 64, B), dim3(256), 0, st, (c128 *)W, basis,
-                     qbuf, N, F, K, domain, floor_kind, floor_eps);
+                     qbuf, N, F, K, domain, floor_kind, floor_eps, (double *)nullptr);
   return check_launch("k_norm_scale");
 }
 
@@ -389,7 +509,7 @@ int ssspy_ilrma_normalize_output(void *Y, double *basis, int B, int N, int F, in
   dim3 grid(F, N, B), block(256);
   hipLaunchKernelGGL(k_output_power, grid, block, 0, st, (const c128 *)Y, acc, N, F, T);
   hipLaunchKernelGGL(k_ilrma_normalize_output, grid, block, 0, st, (c128 *)Y, basis, acc, N, F, T,
-                     K, domain, floor_kind, floor_eps);
+                     K, domain, floor_kind, floor_eps, (double *)nullptr);
   return check_launch("k_ilrma_normalize_output");
 }
 
@@ -449,6 +569,113 @@ int ssspy_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis,
                       floor_kind, floor_eps, info, st, 1);
   if (rc || !normalize) return rc;
   return launch_norm_scale(W, basis, qbuf, B, N, F, K, domain, floor_kind, floor_eps, st);
+}
+
+int ssspy_ilrma_partition_expand(const double *basis, const double *activation,
+                                 const double *latent, double *Teff, double *Vrep, int B, int N,
+                                 int F, int T, int K, void *stream) {
+  SSSPY_REQUIRE(basis && activation && latent && Teff && Vrep && B > 0 && N >= 1 && F > 0 &&
+                    T > 0 && K >= 1,
+                "partition_expand: bad argument");
+  const long long per = (long long)K * (F > T ? F : T);
+  hipLaunchKernelGGL(k_partition_expand, dim3((unsigned)((per + 255) / 256), N, B), dim3(256), 0,
+                     as_stream(stream), basis, activation, latent, Teff, Vrep, N, F, T, K);
+  return check_launch("k_partition_expand");
+}
+
+int ssspy_ilrma_partition_update(const void *X, const void *W, double *basis, double *activation,
+                                 double *latent, double *Teff, double *Vrep, int B, int N, int F,
+                                 int T, int K, double domain, int source_model, double model_param,
+                                 int steps, int floor_kind, double floor_eps, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+  SSSPY_REQUIRE(X && basis && activation && latent && Teff && Vrep && B > 0 && F > 0 && T > 0,
+                "partition_update: bad argument");
+  SSSPY_REQUIRE(N >= 1 && N <= SSSPY_MAX_SOURCES, "partition_update: n_sources must be in [1, 8]");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "partition_update: n_basis must be in [1, 64]");
+  SSSPY_REQUIRE(domain > 0.0 && domain <= 2.0, "partition_update: domain must be in (0, 2]");
+  int rc = check_model(source_model, model_param, domain);
+  if (rc) return rc;
+  const IlrmaWs w = ilrma_ws(B, N, F, T, K);
+  SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "partition_update: workspace too small");
+  char *ws = (char *)workspace;
+  double *raw = (double *)(ws + w.praw);
+  double *part = (double *)(ws + w.act_part);
+  hipStream_t st = as_stream(stream);
+  const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
+  IlrmaDims draw = d;
+  draw.raw = 1;
+  auto basis_sums = [&]() -> int {
+    int r = ssspy_ilrma_partition_expand(basis, activation, latent, Teff, Vrep, B, N, F, T, K, stream);
+    if (r) return r;
+    ILRMA_DISPATCH(N, ilrma_basis, X, W, Teff, raw, Vrep, draw, st);
+  };
+  if (steps & SSSPY_PARTITION_LATENT) {
+    rc = basis_sums();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_partition_latent, dim3(B), dim3(256), 0, st, (const double *)raw,
+                       (const double *)basis, latent, N, F, K, d);
+    rc = check_launch("k_partition_latent");
+    if (rc) return rc;
+  }
+  if (steps & SSSPY_PARTITION_BASIS) {
+    rc = basis_sums();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_partition_basis, dim3((unsigned)(((long long)F * K + 255) / 256), B),
+                       dim3(256), 0, st, (const double *)raw, (const double *)latent, basis, N, F,
+                       K, d);
+    rc = check_launch("k_partition_basis");
+    if (rc) return rc;
+  }
+  if (steps & SSSPY_PARTITION_ACTIVATION) {
+    rc = ssspy_ilrma_partition_expand(basis, activation, latent, Teff, Vrep, B, N, F, T, K, stream);
+    if (rc) return rc;
+    const int chunks = act_chunks(B, N, F, T, K);
+    auto run = [&]() -> int {
+      ILRMA_DISPATCH(N, ilrma_activation, X, W, Teff, Vrep, part, chunks, d, st);
+    };
+    rc = run();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_partition_activation, dim3((unsigned)(((long long)K * T + 255) / 256), B),
+                       dim3(256), 0, st, (const double *)part, activation, N, K, T, chunks, d);
+    rc = check_launch("k_partition_activation");
+    if (rc) return rc;
+  }
+  return ssspy_ilrma_partition_expand(basis, activation, latent, Teff, Vrep, B, N, F, T, K, stream);
+}
+
+int ssspy_ilrma_partition_normalize(void *W, const void *C, void *Y, double *basis, double *latent,
+                                    int B, int N, int F, int T, int K, double domain,
+                                    int floor_kind, double floor_eps, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+  SSSPY_REQUIRE(basis && latent && B > 0 && N >= 1 && N <= SSSPY_MAX_SOURCES,
+                "partition_normalize: bad argument");
+  SSSPY_REQUIRE((W && C && !Y) || (Y && !W), "partition_normalize: pass (W, C) or Y");
+  const IlrmaWs w = ilrma_ws(B, N, F, T, K);
+  SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "partition_normalize: workspace too small");
+  char *ws = (char *)workspace;
+  double *qbuf = (double *)(ws + w.qbuf), *psi = (double *)(ws + w.psi);
+  hipStream_t st = as_stream(stream);
+  if (W) {
+    int rc = row_power(W, C, qbuf, B, F, N, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_norm_scale, dim3((F + 63) / 64, B), dim3(256), 0, st, (c128 *)W,
+                       (double *)nullptr, (const double *)qbuf, N, F, K, domain, floor_kind,
+                       floor_eps, psi);
+    rc = check_launch("k_norm_scale");
+    if (rc) return rc;
+  } else {
+    hipError_t e = hipMemsetAsync(qbuf, 0, (size_t)B * N * sizeof(double), st);
+    if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+    dim3 grid(F, N, B), block(256);
+    hipLaunchKernelGGL(k_output_power, grid, block, 0, st, (const c128 *)Y, qbuf, N, F, T);
+    hipLaunchKernelGGL(k_ilrma_normalize_output, grid, block, 0, st, (c128 *)Y, (double *)nullptr,
+                       (const double *)qbuf, N, F, T, K, domain, floor_kind, floor_eps, psi);
+    int rc = check_launch("k_ilrma_normalize_output");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_partition_normalize, dim3(B), dim3(256), 0, st, basis, latent,
+                     (const double *)psi, N, F, K, domain);
+  return check_launch("k_partition_normalize");
 }
 
 }  // extern "C"

@@ -154,7 +154,12 @@ __global__ __launch_bounds__(256) void k_ilrma_basis(const c128 *__restrict__ X,
     const int n = s0 + s;
     if (ob < F && ok < K && n < N) {
       const long long o = (((long long)b * N + n) * F + ob) * K + ok;
-      basis_out[o] = apply_floor(mm_ratio_pow(sn, sd, d) * basis[o], d.floor_kind, d.floor_eps);
+      if (d.raw) {
+        basis_out[2 * o] = sn;
+        basis_out[2 * o + 1] = sd;
+      } else {
+        basis_out[o] = apply_floor(mm_ratio_pow(sn, sd, d) * basis[o], d.floor_kind, d.floor_eps);
+      }
     }
   }
 }

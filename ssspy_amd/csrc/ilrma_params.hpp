@@ -13,6 +13,7 @@ struct IlrmaDims {
   double mparam;  // dof (t) or beta (GGD)
   int floor_kind;
   double floor_eps;
+  int raw;  // basis kernel: 1 = store the (num, den) sums as pairs instead of applying the update
 };
 
 // a = numerator factor of the MM update, b = 1/R          (R = (T V)_nij, P = |y_nij|^2)

@@ -23,7 +23,9 @@ ILRMA_CASES = [
     "gilrma_ip1_n2_nofloor", "gilrma_ip1_n3_raw", "gilrma_iss1_n2", "gilrma_iss1_n4",
     "gilrma_iss1_n3_p1", "gilrma_ip2_n3", "gilrma_ip2_n2", "gilrma_iss2_n4", "gilrma_iss2_n3",
     "tilrma_ip1_n3", "tilrma_iss1_n2_p1", "tilrma_ip2_n3", "ggdilrma_ip1_n3", "ggdilrma_iss1_n2",
-    "ggdilrma_iss2_n3_p1", "gilrma_me_ip1_n3", "tilrma_me_iss1_n2",
+    "ggdilrma_iss2_n3_p1", "gilrma_me_ip1_n3", "tilrma_me_iss1_n2", "gilrma_part_ip1_n3",
+    "gilrma_part_iss1_n2_p1", "gilrma_part_me_ip2_n3", "tilrma_part_ip1_n2", "ggdilrma_part_iss1_n3",
+    "tilrma_part_me_nonorm_n2",
 ]
 IVA_CASES = [
     "auxlap_ip1_n2", "auxlap_ip1_n4", "auxlap_iss1_n2", "auxlap_iss1_n8", "auxgauss_ip1_n3",
@@ -121,17 +123,24 @@ def test_gauss_ilrma_against_golden(case):
     g = load_golden(case)
     model = (str(g["meta_model"]), float(g["meta_model_param"])) if "meta_model" in g \
         else ("gauss", None)
-    snap = Snap(["demix_filter", "output", "basis", "activation"])
+    snap = Snap(["demix_filter", "output", "basis", "activation", "latent"])
+    partitioning = bool(g["meta_partitioning"]) if "meta_partitioning" in g else False
     m = _ilrma_class(model)(
         n_basis=int(g["meta_n_basis"]), spatial_algorithm=str(g["meta_algo"]),
+        partitioning=partitioning,
         domain=float(g["meta_domain"]), flooring_fn=_flooring_fn(g), callbacks=snap,
         normalization=bool(g["meta_normalization"]),
         scale_restoration=bool(g["meta_scale_restoration"]),
         source_algorithm=str(g["meta_source_algorithm"]) if "meta_source_algorithm" in g else "MM",
     )
     b0, a0 = g["basis0"].copy(), g["activation0"].copy()
-    Y = m(g["X"], n_iter=int(g["meta_n_iter"]), basis=b0, activation=a0)
+    extra = {"latent": g["latent0"].copy()} if partitioning else {}
+    Y = m(g["X"], n_iter=int(g["meta_n_iter"]), basis=b0, activation=a0, **extra)
     assert np.array_equal(b0, g["basis0"]) and np.array_equal(a0, g["activation0"])  # not mutated
+    if partitioning:
+        assert np.array_equal(extra["latent"], g["latent0"])
+        assert rel_err(m.latent, g["final_latent"]) < TOL
+        assert m.basis.shape == g["final_basis"].shape
     _compare_snapshots(g, snap)
     np.testing.assert_allclose(m.loss, g["loss"], rtol=LOSS_RTOL)
     assert all(type(v) is float for v in m.loss)
@@ -205,6 +214,33 @@ def test_heavy_tailed_ilrma_batch_and_stepwise():
         for cls in (TILRMA, Stepwise):
             Y = cls(n_basis=K, dof=4.0)(Xb[b], n_iter=3, basis=basis[b], activation=act[b])
             assert rel_err(Y, Yb[b]) < 1e-12
+
+
+@pytest.mark.parametrize("model,algo,src", [(("gauss", None), "ISS2", "MM"), (("t", 3.0), "IP", "ME"),
+                                            (("ggd", 1.4), "IP2", "MM")])
+def test_partitioned_ilrma_batch_against_oracle(model, algo, src):
+    """partitioning=True with n_basis > 16 and 5 sources, batched == per-mixture oracle runs."""
+    from oracle.ilrma import GaussILRMAOracle
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    N, F, T, K = 5, 21, 46, 20
+    Xb = np.stack([nmf_mixture(s, N, F, T) for s in (41, 42)])
+    basis = np.random.default_rng(9).random((2, F, K))
+    act = np.random.default_rng(10).random((2, K, T))
+    lat = np.random.default_rng(11).random((2, N, K))
+    lat = lat / lat.sum(axis=1, keepdims=True)
+    m = _ilrma_class(model)(n_basis=K, spatial_algorithm=algo, source_algorithm=src,
+                            partitioning=True, scale_restoration=False)
+    Yb = m(Xb, n_iter=3, basis=basis, activation=act, latent=lat)
+    assert m.latent.shape == (2, N, K) and m.basis.shape == (2, F, K)
+    for b in range(2):
+        ref = GaussILRMAOracle(n_basis=K, spatial_algorithm=algo, model=model, source_algorithm=src,
+                               partitioning=True, scale_restoration=False)
+        Yr = ref.run(Xb[b], n_iter=3, basis=basis[b], activation=act[b], latent=lat[b])
+        err = rel_err_up_to_phase(Yb[b], Yr, "output") if algo in ("IP2", "ISS2") else rel_err(Yb[b], Yr)
+        assert err < TOL
+        assert rel_err(m.latent[b], ref.latent) < TOL and rel_err(m.basis[b], ref.basis) < TOL
+        np.testing.assert_allclose(np.asarray(m.loss)[:, b], ref.loss, rtol=LOSS_RTOL)
 
 
 def test_heavy_tailed_ilrma_constructor_contract():
