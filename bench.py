@@ -216,6 +216,23 @@ def main():
         "roofline": roofline,
     }
 
+    # ---- the same batch with record_loss=True semantics (SURVEY 8d asks for both): every iteration
+    # is followed by compute_loss(), which syncs the host once per iteration as the reference does
+    if not args.no_single and n_gpus == 1:
+        nl = max(3, min(10, args.steps))
+        sep.compute_loss()
+        torch.cuda.synchronize()
+        tl = time.perf_counter()
+        for _ in range(nl):
+            sep.update_once()
+            sep.compute_loss()
+        torch.cuda.synchronize()
+        dtl = (time.perf_counter() - tl) / nl
+        out["with_record_loss"] = {
+            "workload": "same batch, update_once() + compute_loss() per iteration, {} iterations".format(nl),
+            "ms_per_step": round(1e3 * dtl, 4), "iterations_per_s": round(B / dtl, 2),
+        }
+
     # ---- configs[1] exactly: ONE mixture, fused update_once (one C-ABI call per iteration)
     if not args.no_single and n_gpus == 1:
         sep1 = make_separator(X[:1].clone(), K, seed=2000)

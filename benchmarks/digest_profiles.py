@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/<tag>/ (written by benchmarks/profile_round.sh) into the tracked files under
+profiles/: the bench line, the rocprofv3 per-kernel statistics, and the HBM traffic of the three
+pass kernels per launch (FETCH_SIZE / WRITE_SIZE in KB; the read side is doubled on gfx950 as
+MI355X_MICROARCH.md prescribes: FETCH_SIZE tallies 128-byte requests as 64 bytes).
+
+    python benchmarks/digest_profiles.py <tag>
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+
+bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+B = bench["config"]["batch_per_gpu"]
+json.dump(bench, open(os.path.join(dst, "{}_bench_b{}.json".format(tag, B)), "w"), indent=1)
+
+stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    rows = [r for r in csv.DictReader(open(stats[0]))]
+    keep = [r for r in rows if float(r.get("Percentage", 0) or 0) >= 0.01]
+    with open(os.path.join(dst, "{}_bench_b{}_kernel_stats.csv".format(tag, B)), "w") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        for r in keep:
+            r["Name"] = r["Name"][:120]
+            w.writerow(r)
+
+KERNELS = {"k_basis_fast": "k_ilrma_basis", "k_activation_fast": "k_ilrma_activation",
+           "k_wcov_fast": "k_ilrma_wcov"}
+
+
+def counter(path, name):
+    acc = collections.defaultdict(list)
+    for p in glob.glob(os.path.join(src, path, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(p)):
+            if r["Counter_Name"] != name:
+                continue
+            for k in KERNELS:
+                if k + "(" in r["Kernel_Name"] or r["Kernel_Name"].endswith(k) or "::" + k in r["Kernel_Name"]:
+                    acc[k].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items() if v}
+
+
+fetch, write = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
+algo = 16.0 * bench["config"]["n_sources"] * bench["config"]["n_bins"] * bench["config"]["n_frames"] * B
+traffic = {}
+for k, label in KERNELS.items():
+    if k in fetch and k in write:
+        hbm = (2.0 * fetch[k] + write[k]) * 1024.0
+        traffic[label] = {
+            "kernel": k, "FETCH_SIZE_KB_raw": round(fetch[k]), "WRITE_SIZE_KB_raw": round(write[k]),
+            "hbm_bytes_per_launch_batch{}".format(B): round(hbm),
+            "algorithmic_bytes_per_launch_batch{}".format(B): round(algo),
+            "ratio": round(hbm / algo, 3),
+            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (no tracing), "
+                    "bench.py --batch {}; read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE "
+                    "tallies 128-B requests as 64 B)".format(B),
+        }
+if traffic:
+    json.dump(traffic, open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
+oc = os.path.join(src, "other_configs.txt")
+if os.path.exists(oc):
+    shutil.copy(oc, os.path.join(dst, "{}_other_configs.txt".format(tag)))
+print(json.dumps({"bench_value": bench["value"], "roofline": bench["roofline"], "traffic": traffic}, indent=1))

@@ -1,0 +1,24 @@
+#!/bin/bash
+# End-of-round measurement on the GPU box (run through gpurun from the repo root):
+#   benchmarks/profile_round.sh <tag>
+# Writes under gpurun_out/<tag>/: bench.json (default bench.py run), stats/ (rocprofv3
+# --kernel-trace --stats of a short bench run), fetch/ and write/ (separate --pmc passes for the HBM
+# traffic of the three pass kernels), other_configs.txt.  benchmarks/digest_profiles.py turns these
+# into the tracked files under profiles/.
+set -u
+tag=${1:-r01}
+root=$GRAFT_REPO_ROOT
+out=$root/gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+cd $root
+python bench.py > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- \
+  python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-single > $out/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- \
+  python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-single > $out/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- \
+  python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-single > $out/write.log 2>&1
+python benchmarks/other_configs.py > $out/other_configs.txt 2>&1
+python benchmarks/other_configs.py --batch 32 >> $out/other_configs.txt 2>&1
+tail -c 600 $out/bench.json
