@@ -27,7 +27,9 @@ DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
   int ilrma_fast_activation_n##n(const void *, const void *, const double *, const double *,   \
                                  double *, int, int, int, int, int, hipStream_t);              \
   int ilrma_fast_wcov_n##n(const void *, const double *, const double *, void *, int, int, int, \
-                           int, void *, hipStream_t);
+                           int, void *, hipStream_t);                                          \
+  int ilrma_fast_loss_n##n(const void *, const void *, const double *, const double *, double *, \
+                           int, int, int, int, hipStream_t);
 DECL_FAST(2) DECL_FAST(3) DECL_FAST(4)
 #undef DECL_FAST
 
@@ -538,6 +540,9 @@ int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
   hipStream_t st = as_stream(stream);
   hipError_t e = hipMemsetAsync(out, 0, (size_t)B * sizeof(double), st);
   if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+  if (fast_path(N, T, K, domain, source_model & 0xff)) {
+    ILRMA_FAST_DISPATCH(N, ilrma_fast_loss, X, W, basis, activation, out, B, F, T, K, st);
+  }
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, SSSPY_FLOOR_NONE, 0.0);
   ILRMA_DISPATCH(N, ilrma_loss, X, W, basis, activation, out, d, st);
 }

@@ -339,6 +339,85 @@ __global__ __launch_bounds__(256) void k_basis_finalize(double *basis,
   *dst = apply_floor(sqrt(sn / sd) * (*dst), floor_kind, eps);
 }
 
+// ================================================================================ loss data
+// out[b] += sum_{n,i} mean_j ( |y|^2 / R + log R ), the data term of compute_loss().  Same walk as
+// the basis pass without its second GEMM; the logarithms are taken on the product of the four R
+// values a lane holds per source and tile (R >= floor^2 * K, so four of them stay far inside the
+// fp64 range), which cuts the dominant cost, the fp64 log, by four.
+__global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X,
+                                                      const c128 *__restrict__ W,
+                                                      const double *__restrict__ basis,
+                                                      const double *__restrict__ act,
+                                                      double *__restrict__ out, int F, int T, int K,
+                                                      TailPlan plan) {
+  __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
+  constexpr int WSTRIDE = N * N + 1;
+  __shared__ __attribute__((aligned(16))) c128 wl[4][16 * WSTRIDE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const BlockWork work = block_work(plan);
+  const int b = work.b, nchunks = work.nchunks;
+  const int i0 = work.group * 64 + wave * 16;
+  const bool bin_valid = i0 + c < F;
+  const int bin = min(i0 + c, F - 1);
+  const c128 *Xb = X + (long long)b * N * F * T;
+  const double *act_b = act + (long long)b * N * K * T;
+  for (int e = lane; e < 16 * N * N; e += 64) {
+    const int bl = e / (N * N), rem = e % (N * N);
+    const int bi = min(i0 + bl, F - 1);
+    wl[wave][bl * WSTRIDE + rem] = W ? W[((long long)b * F + bi) * (N * N) + rem]
+                                     : cmake((rem / N) == (rem % N) ? 1.0 : 0.0, 0.0);
+  }
+  const c128 *wmine = wl[wave] + c * WSTRIDE;
+  double tb[N][4];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kk = 4 * ks + q;
+      tb[n][ks] = kk < K ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
+    }
+  const int ntiles = (T + 15) >> 4;
+  const int tpc = (ntiles + nchunks - 1) / nchunks;
+  const int jt_begin = work.chunk * tpc, jt_end = min(ntiles, jt_begin + tpc);
+  VStage st;
+  XTile cur;
+  vstage_load(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
+  vstage_store(st, vs[0]);
+  __syncthreads();
+  double acc = 0.0;
+  for (int jt = jt_begin; jt < jt_end; ++jt) {
+    const int j0 = jt * 16;
+    const int jn = min(jt + 1, jt_end - 1) * 16;
+    xtile_load_binmajor(cur, Xb, F, T, bin, j0, q);
+    vstage_load(st, act_b, K, T, jn);
+    const double *vcur = vs[(jt - jt_begin) & 1];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const double4_t R = rt_from_lds(vcur + n * 16 * VROW, tb[n], c, q);
+      c128 wr[N];
+#pragma unroll
+      for (int m = 0; m < N; ++m) wr[m] = wmine[n * N + m];
+      double prod = 1.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        c128 y = cmake(0.0, 0.0);
+#pragma unroll
+        for (int m = 0; m < N; ++m) cfma(y, wr[m], cur.x[m][r]);
+        const bool valid = bin_valid && (j0 + q + 4 * r < T);
+        const double rr = valid ? R[r] : 1.0;
+        acc = fma(valid ? cabs2(y) : 0.0, rcp_nr(rr), acc);
+        prod *= rr;
+      }
+      acc += log(prod);
+    }
+    vstage_store(st, vs[(jt - jt_begin + 1) & 1]);
+    __syncthreads();
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) atomicAdd(out + b, acc / (double)T);
+}
+
 // ================================================================== weighted covariance (pass 3)
 // U[b,i,n] = (1/T) sum_j x x^H / R.
 // The N Hermitian accumulators of a bin (N*N*N reals) do not fit a 256-register budget next to the
@@ -638,6 +717,16 @@ int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *
   hipLaunchKernelGGL(k_activation_fast, grid, block, 0, st, (const c128 *)X, (const c128 *)W,
                      basis, act, part, F, T, K, tiles_per_chunk, nchunks);
   return check_launch("k_activation_fast");
+}
+
+// `out` (B doubles) must be zeroed by the caller
+int LAUNCHER(ilrma_fast_loss)(const void *X, const void *W, const double *basis, const double *act,
+                              double *out, int B, int F, int T, int K, hipStream_t st) {
+  const TailPlan plan = make_tail_plan(B, (F + 63) / 64, (T + 15) / 16);
+  dim3 grid(plan.full + plan.tail * plan.split), block(256);
+  hipLaunchKernelGGL(k_loss_fast, grid, block, 0, st, (const c128 *)X, (const c128 *)W, basis, act,
+                     out, F, T, K, plan);
+  return check_launch("k_loss_fast");
 }
 
 // `upart` must hold ilrma_fast_part_bytes() bytes (used only when some items are split)
