@@ -12,6 +12,7 @@ is Appendix A of SURVEY.md: basis, activation, spatial, normalise.
 import numpy as np
 
 from . import spatial as sp
+from .ipa import update_by_ipa
 
 
 class GaussILRMAOracle:
@@ -43,7 +44,9 @@ class GaussILRMAOracle:
         # partitioning: shared basis (F, K) / activation (K, T) assigned to sources by the latent
         # variables Z (N, K), columns of Z sum to one (ref: ssspy/bss/ilrma.py:201-270, :297-327)
         self.partitioning = partitioning
-        assert spatial_algorithm in ("IP", "IP1", "IP2", "ISS", "ISS1", "ISS2")
+        assert spatial_algorithm in ("IP", "IP1", "IP2", "ISS", "ISS1", "ISS2", "IPA")
+        # IPA keyword arguments of the reference (defaults: ssspy/bss/ilrma.py:749, iva.py:1579)
+        self.lqpqm_normalization, self.newton_iter = True, 1
         self.pairs = None  # None = the reference's default selector for the algorithm
         self.n_basis = n_basis
         self.spatial_algorithm = spatial_algorithm
@@ -195,6 +198,10 @@ class GaussILRMAOracle:
             # ref: ssspy/bss/ilrma.py:1698-1792
             pairs = self.pairs if self.pairs is not None else sp.sequential_pairs(N)
             self.output = sp.update_by_iss2(self.output, varphi, self.flooring, pairs)
+        elif self.spatial_algorithm == "IPA":
+            # ref: ssspy/bss/ilrma.py:1794-1908
+            self.output = update_by_ipa(self.output, varphi, self.flooring,
+                                        self.lqpqm_normalization, self.newton_iter)
         elif self.uses_filter:
             U = sp.weighted_covariance(self.input, varphi)
             self.demix_filter = sp.update_by_ip1(self.demix_filter, U, self.flooring)

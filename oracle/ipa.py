@@ -1,0 +1,140 @@
+"""Oracle: iterative projection with adjustment (IPA) and the LQPQM solver it sits on.
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
+
+Restates ``update_by_ipa`` (ssspy/bss/_update_spatial_model.py:398-513) and ``lqpqm2`` /
+``solve_equation`` / ``_find_largest_root`` (ssspy/linalg/lqpqm.py:13-352, linalg/cubic.py) one
+frequency bin at a time -- the unit the device kernel works on.  Two deliberate simplifications
+against the reference, both exact unless noted:
+
+* the Newton loop of ``solve_equation`` runs ``max_iter`` steps for every bin; the reference stops
+  early only when ALL bins have converged at once (lqpqm.py:165-169), which changes results by at
+  most the convergence threshold;
+* the degenerate branch ``||v|| < floor(0)`` of ``lqpqm2`` returns a scaled eigenvector whose
+  phase is LAPACK's (lqpqm.py:78-92); it is restated, but no parity is claimed for it.
+"""
+
+import numpy as np
+
+from . import spatial as sp
+
+
+def floor0(flooring):
+    """flooring_fn(0) of the reference: the threshold of its "is zero" tests."""
+    return float(sp.floor(np.zeros(()), flooring))
+
+
+def largest_cubic_root(A, B, C):
+    """Largest real root of x^3 + A x^2 + B x + C as the reference's Cardano code returns it.
+
+    ref: ssspy/linalg/lqpqm.py:292-331, ssspy/linalg/cubic.py (polar complex cube root).
+    """
+    P = -(A**2) / 3 + B
+    Q = (2 * A**3) / 27 - (A * B) / 3 + C
+    disc = (Q / 2) ** 2 + (P / 3) ** 3
+    w = -Q / 2 + np.sqrt(complex(disc))
+    U = np.cbrt(abs(w)) * np.exp(1j * np.angle(w) / 3)
+    if U == 0:
+        X1 = np.cbrt(-Q)
+        V = -P / 3  # U replaced by 1 in the reference
+        U = 1.0
+    else:
+        V = -P / (3 * U)
+        X1 = U + V
+    omega = (-1 + 1j * np.sqrt(3)) / 2
+    X2 = (U * omega + V * omega.conjugate()).real
+    X3 = (U * omega.conjugate() + V * omega).real
+    roots = [np.real(X1)]
+    if P < 0 and not (disc > 0):
+        roots += [X2, X3]
+    return max(roots) - A / 3
+
+
+def solve_equation(phi, v, z, flooring, max_iter):
+    """Largest root lambda of  lambda^2 sum_l phi_l |v_l|^2 / (lambda - phi_l)^2 - lambda + z = 0.
+
+    ref: ssspy/linalg/lqpqm.py:112-200 (normalization=True).
+    """
+    f0 = floor0(flooring)
+    mask = phi * np.abs(v) ** 2 >= f0
+    phi = mask * phi
+    v = mask * v
+    l_max = int(np.argmax(phi))
+    phi_max = float(sp.floor(phi[l_max], flooring))
+    v_max = v[l_max] / phi_max
+    phi, v, z = phi / phi_max, v / phi_max, z / phi_max
+    A = -(abs(v_max) ** 2 + 2 + z)
+    B = 1 + 2 * z
+    C = -z
+    lamb = largest_cubic_root(A, B, C)
+    if not lamb > 1:
+        lamb = 1 + f0
+    lamb = max(lamb, z)
+    for _ in range(max_iter):
+        f = lamb**2 * np.sum(phi * np.abs(v) ** 2 / (lamb - phi) ** 2) - lamb + z
+        df = -2 * lamb * np.sum((phi * np.abs(v)) ** 2 / (lamb - phi) ** 3) - 1
+        mu = lamb - f / df
+        lamb = mu if mu > 1 else (1 + lamb) / 2
+    return lamb * phi_max
+
+
+def lqpqm2(H, v, z, flooring, max_iter):
+    """argmin of the log-quadratically penalised quadratic (type 2).  ref: lqpqm.py:13-110."""
+    phi, sigma = np.linalg.eigh(H)
+    if np.linalg.norm(v) < floor0(flooring):
+        lamb = max(z, phi[-1])
+        return np.sqrt(max((lamb - z) / phi[-1], 0.0)) * sigma[:, -1]
+    v_t = sigma.conj().T @ v
+    lamb = solve_equation(phi, v_t, z, flooring, max_iter)
+    return sigma @ (phi * v_t / (lamb - phi))
+
+
+def ipa_transform_bin(U, s, flooring, normalization, max_iter):
+    """The N x N update matrix of one bin for source ``s``: y <- G y.
+
+    U (N, N, N): U[n] = mean_j varphi_nj y_j y_j^H (not yet PSD-floored).
+    ref: ssspy/bss/_update_spatial_model.py:425-511.
+    """
+    N = U.shape[0]
+    U = sp.to_psd(U, flooring)
+    rest = [m for m in range(N) if m != s]
+    U_s = U[s]
+    lam, P = np.linalg.eigh(U_s)
+    U_s_inv = (P / sp.floor(lam, flooring)) @ P.conj().T  # _psd_inv: a second floor on top of to_psd
+    a = np.real(U[rest, s, s])
+    b = U[rest, s, rest]
+    Ui = U_s_inv.conj()
+    C = Ui[np.ix_(rest, rest)]
+    d = Ui[rest, s]
+    Cd = np.linalg.solve(C, d)
+    zz = np.real(U_s_inv[s, s]) - np.real(np.vdot(d, Cd))
+    a_sqrt = np.sqrt(a)
+    H = C / np.outer(a_sqrt, a_sqrt)
+    v = -b / a_sqrt - a_sqrt * Cd
+    if normalization:
+        tr = np.real(np.trace(H))
+        H, zz = H / tr, zz / tr
+    q = lqpqm2(H, v, zz, flooring, max_iter) / a_sqrt - b / a
+    q_tilde = np.zeros(N, dtype=np.complex128)
+    q_tilde[s] = 1.0
+    q_tilde[rest] = -q.conj()
+    Uq = np.linalg.solve(U_s, q_tilde)
+    den = sp.floor(np.sqrt(max(np.real(np.vdot(q_tilde, Uq)), 0.0)), flooring)
+    p = Uq / den
+    G = np.eye(N, dtype=np.complex128)
+    G[s, :] = p.conj()
+    G[rest, s] = q.conj()
+    return G
+
+
+def update_by_ipa(Y, varphi, flooring=sp.DEFAULT_FLOOR, normalization=True, max_iter=1):
+    """One IPA sweep over the sources.  Y (N, F, T), varphi (N, F, T) or (N, 1, T) -> new Y."""
+    N, F, T = Y.shape
+    Y = Y.copy()
+    for s in range(N):
+        YY = Y[:, None] * Y[None, :].conj()  # (a, b, F, T)
+        U = np.mean(varphi[:, None, None] * YY, axis=-1).transpose(3, 0, 1, 2)  # (F, n, a, b)
+        G = np.stack([ipa_transform_bin(U[i], s, flooring, normalization, max_iter)
+                      for i in range(F)])
+        Y = sp.separate(Y, G)
+    return Y

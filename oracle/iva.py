@@ -12,6 +12,7 @@ Python closures: ``"laplace"`` (G = 2r, G' = 2) or ``"gauss"``
 import numpy as np
 
 from . import spatial as sp
+from .ipa import update_by_ipa
 
 
 class AuxIVAOracle:
@@ -26,7 +27,9 @@ class AuxIVAOracle:
         record_loss=True,
         reference_id=0,
     ):
-        assert spatial_algorithm in ("IP", "IP1", "IP2", "ISS", "ISS1", "ISS2")
+        assert spatial_algorithm in ("IP", "IP1", "IP2", "ISS", "ISS1", "ISS2", "IPA")
+        # IPA keyword arguments of the reference (defaults: ssspy/bss/ilrma.py:749, iva.py:1579)
+        self.lqpqm_normalization, self.newton_iter = True, 1
         assert contrast in ("laplace", "gauss")
         self.pairs = None
         self.spatial_algorithm = spatial_algorithm
@@ -105,6 +108,11 @@ class AuxIVAOracle:
             # ref: ssspy/bss/iva.py:1968-2066
             pairs = self.pairs if self.pairs is not None else sp.sequential_pairs(N)
             self.output = sp.update_by_iss2(Y, weight[:, None, :], self.flooring, pairs)
+            return
+        if self.spatial_algorithm == "IPA":
+            # ref: ssspy/bss/iva.py:2068-2175
+            self.output = update_by_ipa(Y, weight[:, None, :], self.flooring,
+                                        self.lqpqm_normalization, self.newton_iter)
             return
         if self.uses_filter:
             U = sp.weighted_covariance(self.input, weight)

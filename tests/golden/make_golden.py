@@ -23,7 +23,7 @@ REFERENCE = os.environ.get("SSSPY_REFERENCE", "/root/reference")
 sys.path.insert(0, REFERENCE)
 
 from ssspy.algorithm import projection_back  # noqa: E402
-from ssspy.bss._update_spatial_model import update_by_ip1, update_by_iss1  # noqa: E402
+from ssspy.bss._update_spatial_model import update_by_ip1, update_by_ipa, update_by_iss1  # noqa: E402
 from ssspy.bss.ilrma import GGDILRMA, TILRMA, GaussILRMA  # noqa: E402
 from ssspy.bss.iva import AuxGaussIVA, AuxLaplaceIVA  # noqa: E402
 from ssspy.bss.mnmf import FastGaussMNMF, GaussMNMF  # noqa: E402
@@ -225,6 +225,26 @@ def run_gmnmf(name, *, M, F, T, K, seed, n_sources=None, gen=gen_iid, flooring=(
     save(name, **out)
 
 
+def run_ipa_operators():
+    """update_by_ipa on random spectrograms: per-source-count cases incl. broadcast weights."""
+    if skipped("ipa_operators"):
+        return
+    out = {}
+    for N in (2, 3, 4, 5):
+        rng = np.random.default_rng(140 + N)
+        F, T = 8, 36
+        Y = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+        varphi = 1 / (rng.random((N, F, T)) + 0.1)
+        out["n{}_Y".format(N)] = Y
+        out["n{}_varphi".format(N)] = varphi
+        out["n{}_out".format(N)] = update_by_ipa(Y.copy(), varphi)
+        out["n{}_out_nonorm_it3".format(N)] = update_by_ipa(Y.copy(), varphi, normalization=False,
+                                                            max_iter=3)
+        out["n{}_out_bcast_add".format(N)] = update_by_ipa(
+            Y.copy(), varphi[:, :1, :], flooring_fn=functools.partial(add_flooring, eps=1e-4))
+    save("ipa_operators", **out)
+
+
 # --------------------------------------------------------------------------- operators
 def run_operators():
     if skipped("operators"):
@@ -344,6 +364,14 @@ def main():
     run_gmnmf("gmnmf_m4_n3", M=4, F=9, T=22, K=4, seed=82, n_sources=3, spatial_init=True)
     run_gmnmf("gmnmf_m2_nonorm_add", M=2, F=10, T=18, K=2, seed=83, normalization=False,
               flooring=("add", 1e-6))
+    # --- IPA (iterative projection with adjustment, LQPQM solver) ---
+    run_ipa_operators()
+    run_ilrma("gilrma_ipa_n3", N=3, F=18, T=40, K=4, algo="IPA", seed=100, gen=gen_mixture)
+    run_ilrma("gilrma_ipa_n2_p1", N=2, F=17, T=34, K=3, algo="IPA", seed=101, domain=1)
+    run_ilrma("gilrma_ipa_part_n4", N=4, F=12, T=44, K=6, algo="IPA", seed=102, gen=gen_mixture,
+              partitioning=True)
+    run_iva("auxlap_ipa_n3", N=3, F=20, T=44, algo="IPA", contrast="laplace", seed=103, gen=gen_mixture)
+    run_iva("auxgauss_ipa_n2", N=2, F=24, T=40, algo="IPA", contrast="gauss", seed=104)
     # --- operators ---
     run_operators()
 

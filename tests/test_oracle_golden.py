@@ -26,7 +26,7 @@ ILRMA_CASES = [
     "ggdilrma_iss2_n3_p1",
     "gilrma_me_ip1_n3", "tilrma_me_iss1_n2", "gilrma_part_ip1_n3", "gilrma_part_iss1_n2_p1",
     "gilrma_part_me_ip2_n3", "tilrma_part_ip1_n2", "ggdilrma_part_iss1_n3",
-    "tilrma_part_me_nonorm_n2",
+    "tilrma_part_me_nonorm_n2", "gilrma_ipa_n3", "gilrma_ipa_n2_p1", "gilrma_ipa_part_n4",
 ]
 
 
@@ -36,7 +36,7 @@ def _model(g):
 IVA_CASES = [
     "auxlap_ip1_n2", "auxlap_ip1_n4", "auxlap_iss1_n2", "auxlap_iss1_n8", "auxgauss_ip1_n3",
     "auxgauss_iss1_n3", "auxlap_ip1_n2_raw", "auxlap_ip2_n3", "auxlap_iss2_n4", "auxgauss_ip2_n2",
-    "auxgauss_iss2_n3",
+    "auxgauss_iss2_n3", "auxlap_ipa_n3", "auxgauss_ipa_n2",
 ]
 MNMF_CASES = ["fmnmf_ip1_m3", "fmnmf_ip1_m4", "fmnmf_ip1_m3_n2", "fmnmf_ip1_m2_nonorm"]
 
@@ -194,6 +194,19 @@ def test_operators(N):
     assert rel_err(sp.projection_back_filter(p("ip1_n{}_W"), 1), p("pb_n{}_filter")) < TOL
     assert rel_err(sp.projection_back_output(p("iss1_n{}_Y"), p("pb_n{}_X"), 0), p("pb_n{}_output")) < TOL
     assert rel_err(sp.to_psd(p("psd_n{}_in")), p("psd_n{}_out")) < TOL
+
+
+@pytest.mark.parametrize("N", [2, 3, 4, 5])
+def test_ipa_operator(N):
+    from oracle.ipa import update_by_ipa
+
+    g = load_golden("ipa_operators")
+    Y, varphi = g["n{}_Y".format(N)], g["n{}_varphi".format(N)]
+    assert rel_err(update_by_ipa(Y, varphi), g["n{}_out".format(N)]) < 1e-11
+    assert rel_err(update_by_ipa(Y, varphi, normalization=False, max_iter=3),
+                   g["n{}_out_nonorm_it3".format(N)]) < 1e-11
+    assert rel_err(update_by_ipa(Y, varphi[:, :1, :], flooring=("add", 1e-4)),
+                   g["n{}_out_bcast_add".format(N)]) < 1e-11
 
 
 def test_inv2():
