@@ -47,6 +47,7 @@ def _units():
         ("linalg_kernels.hip", "linalg_kernels.o", []),
         ("pairwise_kernels.hip", "pairwise_kernels.o", []),
         ("gmnmf_kernels.hip", "gmnmf_kernels.o", []),
+        ("ipa_kernels.hip", "ipa_kernels.o", []),
     ]
     units.append(("mnmf_api.hip", "mnmf_api.o", []))
     for n in MNMF_N:

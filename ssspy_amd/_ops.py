@@ -98,6 +98,31 @@ def iss2_transform(Vc, pairs, flooring, info=None, out=None):
     return out
 
 
+def ipa_transform(Vc, source_idx, normalization, max_iter, flooring, info=None, out=None):
+    B, F, N = Vc.shape[0], Vc.shape[1], Vc.shape[-1]
+    if out is None:
+        out = dv.empty((B, F, N, N), dv.c128, Vc.device)
+    _lib.check(
+        _L().ssspy_ipa_transform(ptr(Vc), ptr(out), int(source_idx), B, F, N,
+                                 int(bool(normalization)), int(max_iter), flooring[0], flooring[1],
+                                 ptr(info), _st()),
+        "ipa_transform",
+    )
+    return out
+
+
+def update_by_ipa(Y, weight, kind, normalization, max_iter, flooring, info=None):
+    """One IPA sweep in place on the device spectrogram Y (B, N, F, T): per source, weighted
+    covariance of the current Y -> update matrix -> Y <- G Y."""
+    N = Y.shape[1]
+    Vc = G = None
+    for s in range(N):
+        Vc = weighted_covariance(Y, weight, kind, N, out=Vc)
+        G = ipa_transform(Vc, s, normalization, max_iter, flooring, info, out=G)
+        separate(Y, G, out=Y)
+    return Y
+
+
 def iss1_fused_max_frames(n_sources):
     return int(_L().ssspy_iss1_fused_max_frames(n_sources))
 

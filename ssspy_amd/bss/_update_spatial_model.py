@@ -141,3 +141,35 @@ def update_by_iss2(
     out = dv.to_host(_ops.separate(Y, G))[0]
     _lib.raise_if_singular(int(info.item()), "update_by_iss2")
     return out
+
+
+def update_by_ipa(
+    separated: np.ndarray,
+    weight: np.ndarray,
+    normalization: bool = True,
+    flooring_fn: Optional[Callable[[np.ndarray], np.ndarray]] = _DEFAULT_FLOOR,
+    max_iter: int = 1,
+) -> np.ndarray:
+    """Update separated spectrograms by iterative projection with adjustment (ref: :398-513).
+
+    Args:
+        separated: (n_sources, n_bins, n_frames) complex, n_sources in [2, 4].
+        weight: (n_sources, n_bins, n_frames) or (n_sources, 1, n_frames) real.
+        normalization: unit-trace normalisation of the LQPQM problem.
+        max_iter: Newton steps of the LQPQM solver (every bin runs all of them).
+    """
+    floor = device_flooring(flooring_fn)
+    Y = dv.to_device(separated[None], dtype=np.complex128)
+    B, N, F, T = Y.shape
+    wt = weight[None]
+    if wt.shape[2] == 1 and F != 1:
+        w = dv.to_device(wt[:, :, 0, :], dtype=np.float64)
+        kind = _lib.WEIGHT_FRAME
+    else:
+        w = dv.to_device(np.broadcast_to(wt, (B, N, F, T)), dtype=np.float64)
+        kind = _lib.WEIGHT_BIN_FRAME
+    info = dv.zeros((1,), dv.i32)
+    _ops.update_by_ipa(Y, w, kind, normalization, max_iter, floor, info)
+    out = dv.to_host(Y)[0]
+    _lib.raise_if_singular(int(info.item()), "update_by_ipa")
+    return out

@@ -37,6 +37,7 @@ _IP1 = ("IP", "IP1")
 _ISS1 = ("ISS", "ISS1")
 _IP2 = ("IP2",)
 _ISS2 = ("ISS2",)
+_IPA = ("IPA",)
 _PROJECTION_BACK = ("projection_back",)
 _MDP = ("minimal_distortion_principle",)
 
@@ -218,11 +219,6 @@ class _MMILRMA(ILRMABase):
 
     def _configure(self, spatial_algorithm, source_algorithm, domain, partitioning, normalization,
                    pair_selector) -> None:
-        if spatial_algorithm not in _IP1 + _ISS1 + _IP2 + _ISS2:
-            raise NotImplementedError(
-                "spatial_algorithm={!r} is not built for the device path yet "
-                "(available: IP, IP1, IP2, ISS, ISS1, ISS2).".format(spatial_algorithm)
-            )
         self.spatial_algorithm = spatial_algorithm
         self.source_algorithm = source_algorithm
         self.domain = domain
@@ -424,8 +420,22 @@ class _MMILRMA(ILRMABase):
             self.update_spatial_model_ip2(flooring_fn=flooring_fn)
         elif self.spatial_algorithm in _ISS2:
             self.update_spatial_model_iss2(flooring_fn=flooring_fn)
+        elif self.spatial_algorithm in _IPA:
+            self.update_spatial_model_ipa(flooring_fn=flooring_fn)
         else:
             raise NotImplementedError("Not support {}.".format(self.spatial_algorithm))
+
+    def update_spatial_model_ipa(self, flooring_fn="self") -> None:
+        """Iterative projection with adjustment on per-bin statistics: per source, weighted
+        covariance of the current output, LQPQM update matrix, Y <- G Y.
+        ref: ssspy/bss/ilrma.py:1794-1908."""
+        Y = self._state_dev("output")
+        varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y,
+                                       model=self._model,
+                                       flooring=self._resolve_floor(flooring_fn))
+        _ops.update_by_ipa(Y, varphi, _lib.WEIGHT_BIN_FRAME, self.lqpqm_normalization,
+                           self.newton_iter, self._resolve_floor(flooring_fn), self._info_tensor())
+        self._state_touch("output")
 
     def update_spatial_model_ip2(self, flooring_fn="self") -> None:
         """Weighted covariance + pairwise iterative projection.  ref: ssspy/bss/ilrma.py:1509-1633."""
@@ -544,7 +554,7 @@ class GaussILRMA(_MMILRMA):
     ``reference_id``, ``rng``.
     """
 
-    _ipa_default_kwargs = {"newton_iter": 1}
+    _ipa_default_kwargs = {"lqpqm_normalization": True, "newton_iter": 1}
     _default_kwargs = _ipa_default_kwargs
 
     def __init__(
@@ -584,6 +594,11 @@ class GaussILRMA(_MMILRMA):
         valid_keys = set(self._ipa_default_kwargs) if spatial_algorithm == "IPA" else set()
         invalid_keys = set(kwargs) - valid_keys
         assert invalid_keys == set(), "Invalid keywords {} are given.".format(invalid_keys)
+        for key, value in kwargs.items():
+            setattr(self, key, value)
+        for key in valid_keys:
+            if not hasattr(self, key):
+                setattr(self, key, self._default_kwargs[key])
         self._configure(spatial_algorithm, source_algorithm, domain, partitioning, normalization,
                         pair_selector)
 

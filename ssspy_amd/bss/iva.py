@@ -32,6 +32,7 @@ _IP1 = ("IP", "IP1")
 _ISS1 = ("ISS", "ISS1")
 _IP2 = ("IP2",)
 _ISS2 = ("ISS2",)
+_IPA = ("IPA",)
 _PROJECTION_BACK = ("projection_back",)
 _MDP = ("minimal_distortion_principle",)
 
@@ -177,7 +178,7 @@ def _device_contrast(contrast_fn, d_contrast_fn):
 class AuxIVA(AuxIVABase):
     """Auxiliary-function-based IVA (ref: ssspy/bss/iva.py:1403-2214)."""
 
-    _ipa_default_kwargs = {"newton_iter": 1}
+    _ipa_default_kwargs = {"lqpqm_normalization": True, "newton_iter": 1}
     _default_kwargs = _ipa_default_kwargs
 
     def __init__(
@@ -205,11 +206,6 @@ class AuxIVA(AuxIVABase):
             reference_id=reference_id,
         )
         assert spatial_algorithm in spatial_algorithms, "Not support {}.".format(spatial_algorithm)
-        if spatial_algorithm not in _IP1 + _ISS1 + _IP2 + _ISS2:
-            raise NotImplementedError(
-                "spatial_algorithm={!r} is not built for the device path yet "
-                "(available: IP, IP1, IP2, ISS, ISS1, ISS2).".format(spatial_algorithm)
-            )
         self.spatial_algorithm = spatial_algorithm
         if pair_selector is None:
             if spatial_algorithm in ["IP2", "ISS2"]:
@@ -219,6 +215,11 @@ class AuxIVA(AuxIVABase):
         valid_keys = set(self._ipa_default_kwargs) if spatial_algorithm == "IPA" else set()
         invalid_keys = set(kwargs) - valid_keys
         assert invalid_keys == set(), "Invalid keywords {} are given.".format(invalid_keys)
+        for key, value in kwargs.items():
+            setattr(self, key, value)
+        for key in valid_keys:
+            if not hasattr(self, key):
+                setattr(self, key, self._default_kwargs[key])
         device_flooring(self.flooring_fn)
 
     def __call__(
@@ -276,8 +277,19 @@ class AuxIVA(AuxIVABase):
             self.update_once_ip2(flooring_fn=flooring_fn)
         elif self.spatial_algorithm in _ISS2:
             self.update_once_iss2(flooring_fn=flooring_fn)
+        elif self.spatial_algorithm in _IPA:
+            self.update_once_ipa(flooring_fn=flooring_fn)
         else:
             raise NotImplementedError("Not support {}.".format(self.spatial_algorithm))
+
+    def update_once_ipa(self, flooring_fn="self") -> None:
+        """Iterative projection with adjustment.  ref: ssspy/bss/iva.py:2068-2175."""
+        Y = self._state_dev("output")
+        weight = self._weights(flooring_fn)
+        _ops.update_by_ipa(Y, weight, _lib.WEIGHT_FRAME, self.lqpqm_normalization,
+                           self.newton_iter, self._resolve_floor(flooring_fn), self._info_tensor())
+        self._r2_cache = None
+        self._state_touch("output")
 
     def _pair_weight_contrast(self):
         """Contrast code for the per-pair weights of IP2 (the Gauss model keeps its variance)."""

@@ -1,0 +1,335 @@
+// Iterative projection with adjustment (IPA): the per-bin update matrix of one source step.
+//
+// One lane owns one bin.  Given the weighted covariances of the CURRENT separated spectrogram,
+// U[n] = mean_j varphi_nj y_j y_j^H for every weight set n, the lane floors them (to_psd), forms
+// the (N-1)-dimensional log-quadratically penalised quadratic problem of source s, solves it
+// (Hermitian Jacobi eigen-decomposition, Cardano start value, Newton steps on the secular
+// equation), and writes the N x N matrix G with  y <- G y:
+//   row s of G = p^H,  G[m][s] = conj(q_m) for m != s,  identity elsewhere.
+// The caller runs  weighted_covariance -> this -> separate  once per source.
+//
+// replaces: ssspy/bss/_update_spatial_model.py:398-513 (update_by_ipa), :611-645 (_psd_inv),
+//           ssspy/linalg/lqpqm.py:13-352 (lqpqm2, solve_equation, _find_largest_root),
+//           ssspy/linalg/cubic.py (polar complex cube root).
+// Two differences from the reference: every bin runs `max_iter` Newton steps (the reference stops
+// early only when all bins have converged at once); the ||v|| ~ 0 branch returns a scaled
+// eigenvector whose phase is the decomposition's.
+#include "common.hpp"
+#include "hermitian.hpp"
+#include "smallmat.hpp"
+#include "ssspy_amd.h"
+
+namespace ssspy {
+
+__device__ __forceinline__ double floor_of_zero(int floor_kind, double eps) {
+  return apply_floor(0.0, floor_kind, eps);
+}
+
+// largest real root of x^3 + A x^2 + B x + C, computed the way the reference does (complex
+// Cardano with the principal polar cube root, whose real part is kept even when it is not the real
+// root: the value only seeds the Newton iteration and is range-checked afterwards)
+__device__ __forceinline__ double largest_cubic_root(double A, double B, double C) {
+  const double P = -(A * A) / 3.0 + B;
+  const double Q = (2.0 * A * A * A) / 27.0 - (A * B) / 3.0 + C;
+  const double disc = (Q * 0.5) * (Q * 0.5) + (P / 3.0) * (P / 3.0) * (P / 3.0);
+  // w = -Q/2 + sqrt(disc) (principal complex square root)
+  const double wr = -0.5 * Q + (disc >= 0.0 ? sqrt(disc) : 0.0);
+  const double wi = disc >= 0.0 ? 0.0 : sqrt(-disc);
+  const double mag = sqrt(wr * wr + wi * wi);
+  double ur, ui, vr, vi, x1;
+  if (mag == 0.0) {
+    ur = 1.0;
+    ui = 0.0;
+    vr = -P / 3.0;
+    vi = 0.0;
+    x1 = cbrt(-Q);
+  } else {
+    const double m3 = cbrt(mag), th = atan2(wi, wr) / 3.0;
+    ur = m3 * cos(th);
+    ui = m3 * sin(th);
+    // V = -P / (3 U)
+    const double den = 3.0 * (ur * ur + ui * ui);
+    vr = -P * ur / den;
+    vi = P * ui / den;
+    x1 = ur + vr;
+  }
+  double root = x1;
+  if (P < 0.0 && !(disc > 0.0)) {
+    const double h = 0.8660254037844386;  // sqrt(3)/2
+    // Re(U w + V conj(w)), Re(U conj(w) + V w), w = (-1 + i sqrt(3)) / 2
+    const double x2 = -0.5 * ur - h * ui - 0.5 * vr + h * vi;
+    const double x3 = -0.5 * ur + h * ui - 0.5 * vr - h * vi;
+    root = fmax(root, fmax(x2, x3));
+  }
+  return root - A / 3.0;
+}
+
+// y = argmin of the LQPQM (type 2) with H = sigma diag(phi) sigma^H.  ref: lqpqm.py:13-110
+template <int L>
+__device__ __forceinline__ void lqpqm2(c128 (&H)[L][L], const c128 (&v)[L], double z,
+                                       int floor_kind, double eps, int max_iter, c128 (&y)[L]) {
+  c128 sigma[L][L];
+  jacobi_eigh<L>(H, sigma);
+  double phi[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) phi[l] = H[l][l].x;
+  const double f0 = floor_of_zero(floor_kind, eps);
+  double vnorm2 = 0.0;
+#pragma unroll
+  for (int l = 0; l < L; ++l) vnorm2 += cabs2(v[l]);
+  if (sqrt(vnorm2) < f0) {
+    // v = 0: a scaled top eigenvector
+    double pmax = phi[0];
+    int arg = 0;
+#pragma unroll
+    for (int l = 1; l < L; ++l)
+      if (phi[l] > pmax) {
+        pmax = phi[l];
+        arg = l;
+      }
+    const double lamb = fmax(z, pmax);
+    const double scale = sqrt(fmax((lamb - z) / pmax, 0.0));
+#pragma unroll
+    for (int a = 0; a < L; ++a) {
+      c128 col = cmake(0.0, 0.0);
+#pragma unroll
+      for (int l = 0; l < L; ++l)
+        if (l == arg) col = sigma[a][l];
+      y[a] = cscale(col, scale);
+    }
+    return;
+  }
+  c128 vt[L];  // sigma^H v
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    c128 s = cmake(0.0, 0.0);
+#pragma unroll
+    for (int a = 0; a < L; ++a) {
+      const c128 t = cmulc(v[a], sigma[a][l]);  // v_a conj(sigma_al)
+      s.x += t.x;
+      s.y += t.y;
+    }
+    vt[l] = s;
+  }
+  // ---- solve_equation (normalization=True), ref: lqpqm.py:112-200
+  double ph[L], w2[L];  // masked, normalised phi and |v|^2
+  double pmax = 0.0, v2max = 0.0;
+  bool first = true;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const bool keep = phi[l] * cabs2(vt[l]) >= f0;
+    ph[l] = keep ? phi[l] : 0.0;
+    w2[l] = keep ? cabs2(vt[l]) : 0.0;
+    if (first || ph[l] > pmax) {
+      pmax = ph[l];
+      v2max = w2[l];
+      first = false;
+    }
+  }
+  const double pm = apply_floor(pmax, floor_kind, eps);
+  const double inv = 1.0 / pm;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    ph[l] *= inv;
+    w2[l] *= inv * inv;
+  }
+  const double zn = z * inv;
+  const double A = -(v2max * inv * inv + 2.0 + zn), Bc = 1.0 + 2.0 * zn, Cc = -zn;
+  double lamb = largest_cubic_root(A, Bc, Cc);
+  if (!(lamb > 1.0)) lamb = 1.0 + f0;
+  lamb = fmax(lamb, zn);
+  for (int it = 0; it < max_iter; ++it) {
+    double s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const double dl = lamb - ph[l];
+      s2 += ph[l] * w2[l] / (dl * dl);
+      s3 += ph[l] * ph[l] * w2[l] / (dl * dl * dl);
+    }
+    const double f = lamb * lamb * s2 - lamb + zn;
+    const double df = -2.0 * lamb * s3 - 1.0;
+    const double mu = lamb - f / df;
+    lamb = mu > 1.0 ? mu : 0.5 * (1.0 + lamb);
+  }
+  lamb *= pm;
+  // y = sigma (phi * vt / (lamb - phi)) with the unmasked phi, vt
+#pragma unroll
+  for (int a = 0; a < L; ++a) y[a] = cmake(0.0, 0.0);
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const double g = phi[l] / (lamb - phi[l]);
+    const c128 coef = cscale(vt[l], g);
+#pragma unroll
+    for (int a = 0; a < L; ++a) cfma(y[a], sigma[a][l], coef);
+  }
+}
+
+// index of the m-th source other than S
+template <int S>
+__device__ __forceinline__ constexpr int rest_index(int m) {
+  return m < S ? m : m + 1;
+}
+
+// Vc: (nbins, N, N, N) weighted covariances; G: (nbins, N, N).  One lane per bin.
+template <int N, int S>
+__global__ __launch_bounds__(64) void k_ipa_transform(const c128 *__restrict__ Vc,
+                                                      c128 *__restrict__ G, long long nbins,
+                                                      int normalization, int max_iter,
+                                                      int floor_kind, double eps, int *info) {
+  constexpr int L = N - 1;
+  const long long bin = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (bin >= nbins) return;
+  const c128 *Ub = Vc + bin * (long long)(N * N * N);
+  c128 M[N][N], P[N][N];
+  double lam[N];
+  // a_m = Re to_psd(U[m])[S][S], b_m = to_psd(U[m])[S][m] for the other sources
+  double a[L];
+  c128 b[L];
+#pragma unroll
+  for (int mm = 0; mm < L; ++mm) {
+    const int m = rest_index<S>(mm);
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c) M[r][c] = Ub[(m * N + r) * N + c];
+    psd_eigen<N>(M, P, lam, floor_kind, eps);
+    double ass = 0.0;
+    c128 bsm = cmake(0.0, 0.0);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      ass = fma(lam[k], cabs2(P[S][k]), ass);
+      const c128 t = cmulc(P[S][k], P[m][k]);
+      bsm.x = fma(lam[k], t.x, bsm.x);
+      bsm.y = fma(lam[k], t.y, bsm.y);
+    }
+    a[mm] = ass;
+    b[mm] = bsm;
+  }
+  // U_S: eigen-decomposition with the floor of to_psd; _psd_inv floors the floored values again
+#pragma unroll
+  for (int r = 0; r < N; ++r)
+#pragma unroll
+    for (int c = 0; c < N; ++c) M[r][c] = Ub[(S * N + r) * N + c];
+  psd_eigen<N>(M, P, lam, floor_kind, eps);
+  double w[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) w[k] = 1.0 / apply_floor(lam[k], floor_kind, eps);
+  c128 Uinv[N][N];
+  herm_rebuild<N>(P, w, Uinv);
+  // C = conj(Uinv)[rest][rest], d = conj(Uinv)[rest][S]
+  Mat<L> C;
+  c128 Cm[L][L], d[L], rhs[L][1];
+#pragma unroll
+  for (int r = 0; r < L; ++r) {
+#pragma unroll
+    for (int c = 0; c < L; ++c) {
+      Cm[r][c] = cconj(Uinv[rest_index<S>(r)][rest_index<S>(c)]);
+      C.a[r][c] = Cm[r][c];
+    }
+    d[r] = cconj(Uinv[rest_index<S>(r)][S]);
+    rhs[r][0] = d[r];
+  }
+  const bool ok = lu_forward<L, 1>(C, rhs);
+  lu_backward<L, 1>(C, rhs);
+  if (!ok && info) atomicAdd(info, 1);
+  double dCd = 0.0;
+#pragma unroll
+  for (int r = 0; r < L; ++r) dCd += d[r].x * rhs[r][0].x + d[r].y * rhs[r][0].y;
+  double z = Uinv[S][S].x - dCd;
+  double as[L];
+#pragma unroll
+  for (int r = 0; r < L; ++r) as[r] = sqrt(a[r]);
+  c128 H[L][L], v[L];
+  double tr = 0.0;
+#pragma unroll
+  for (int r = 0; r < L; ++r) {
+#pragma unroll
+    for (int c = 0; c < L; ++c) {
+      const double sc = 1.0 / (as[r] * as[c]);
+      H[r][c] = cscale(Cm[r][c], sc);
+    }
+    tr += H[r][r].x;
+    // v = -b / a_sqrt - a_sqrt * Cd
+    v[r] = cmake(-b[r].x / as[r] - as[r] * rhs[r][0].x, -b[r].y / as[r] - as[r] * rhs[r][0].y);
+  }
+  if (normalization) {
+    const double it = 1.0 / tr;
+#pragma unroll
+    for (int r = 0; r < L; ++r)
+#pragma unroll
+      for (int c = 0; c < L; ++c) H[r][c] = cscale(H[r][c], it);
+    z *= it;
+  }
+  hermitize<L>(H);
+  c128 qc[L];
+  lqpqm2<L>(H, v, z, floor_kind, eps, max_iter, qc);
+  // q = q_check / a_sqrt - b / a ; q~ = e_S - E conj(q)
+  c128 q[L], qt[N];
+#pragma unroll
+  for (int r = 0; r < L; ++r)
+    q[r] = cmake(qc[r].x / as[r] - b[r].x / a[r], qc[r].y / as[r] - b[r].y / a[r]);
+#pragma unroll
+  for (int m = 0; m < N; ++m) qt[m] = cmake(m == S ? 1.0 : 0.0, 0.0);
+#pragma unroll
+  for (int r = 0; r < L; ++r) qt[rest_index<S>(r)] = cmake(-q[r].x, q[r].y);
+  // Uq = U_S^-1 q~ (single floor), p = Uq / floor(sqrt(max(q~^H Uq, 0)))
+#pragma unroll
+  for (int k = 0; k < N; ++k) w[k] = 1.0 / lam[k];
+  herm_rebuild<N>(P, w, Uinv);
+  c128 Uq[N];
+  double quq = 0.0;
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    c128 s = cmake(0.0, 0.0);
+#pragma unroll
+    for (int c = 0; c < N; ++c) cfma(s, Uinv[r][c], qt[c]);
+    Uq[r] = s;
+    quq += qt[r].x * s.x + qt[r].y * s.y;
+  }
+  const double den = apply_floor(sqrt(fmax(quq, 0.0)), floor_kind, eps);
+  c128 *Gb = G + bin * (long long)(N * N);
+#pragma unroll
+  for (int r = 0; r < N; ++r)
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      c128 g = cmake(r == c ? 1.0 : 0.0, 0.0);
+      if (r == S) g = cmake(Uq[c].x / den, -Uq[c].y / den);  // conj(p_c)
+      Gb[r * N + c] = g;
+    }
+#pragma unroll
+  for (int r = 0; r < L; ++r) Gb[rest_index<S>(r) * N + S] = cmake(q[r].x, -q[r].y);
+}
+
+template <int N, int S>
+static int launch_one(const void *Vc, void *G, long long nbins, int normalization, int max_iter,
+                      int floor_kind, double eps, int *info, hipStream_t st) {
+  dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
+  hipLaunchKernelGGL((k_ipa_transform<N, S>), grid, block, 0, st, (const c128 *)Vc, (c128 *)G,
+                     nbins, normalization, max_iter, floor_kind, eps, info);
+  return check_launch("k_ipa_transform");
+}
+
+}  // namespace ssspy
+
+using namespace ssspy;
+
+extern "C" int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int B, int F, int N,
+                                   int normalization, int max_iter, int floor_kind,
+                                   double floor_eps, int *info, void *stream) {
+  SSSPY_REQUIRE(Vc && G && B > 0 && F > 0, "ipa_transform: bad argument");
+  SSSPY_REQUIRE(source_idx >= 0 && source_idx < N, "ipa_transform: bad source index");
+  SSSPY_REQUIRE(max_iter >= 0, "ipa_transform: max_iter must be non-negative");
+  if (N < 2 || N > 4)
+    return fail(SSSPY_ERR_UNSUPPORTED, "IPA is built for n_sources in [2, 4]");
+  const long long nbins = (long long)B * F;
+  hipStream_t st = as_stream(stream);
+#define IPA_CASE(N_, S_)                                                                     \
+  if (N == N_ && source_idx == S_)                                                           \
+    return launch_one<N_, S_>(Vc, G, nbins, normalization, max_iter, floor_kind, floor_eps, \
+                              info, st);
+  IPA_CASE(2, 0) IPA_CASE(2, 1)
+  IPA_CASE(3, 0) IPA_CASE(3, 1) IPA_CASE(3, 2)
+  IPA_CASE(4, 0) IPA_CASE(4, 1) IPA_CASE(4, 2) IPA_CASE(4, 3)
+#undef IPA_CASE
+  return fail(SSSPY_ERR_UNSUPPORTED, "ipa_transform: unsupported (n_sources, source) pair");
+}

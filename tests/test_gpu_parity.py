@@ -25,12 +25,12 @@ ILRMA_CASES = [
     "tilrma_ip1_n3", "tilrma_iss1_n2_p1", "tilrma_ip2_n3", "ggdilrma_ip1_n3", "ggdilrma_iss1_n2",
     "ggdilrma_iss2_n3_p1", "gilrma_me_ip1_n3", "tilrma_me_iss1_n2", "gilrma_part_ip1_n3",
     "gilrma_part_iss1_n2_p1", "gilrma_part_me_ip2_n3", "tilrma_part_ip1_n2", "ggdilrma_part_iss1_n3",
-    "tilrma_part_me_nonorm_n2",
+    "tilrma_part_me_nonorm_n2", "gilrma_ipa_n3", "gilrma_ipa_n2_p1", "gilrma_ipa_part_n4",
 ]
 IVA_CASES = [
     "auxlap_ip1_n2", "auxlap_ip1_n4", "auxlap_iss1_n2", "auxlap_iss1_n8", "auxgauss_ip1_n3",
     "auxgauss_iss1_n3", "auxlap_ip1_n2_raw", "auxlap_ip2_n3", "auxlap_iss2_n4", "auxgauss_ip2_n2",
-    "auxgauss_iss2_n3",
+    "auxgauss_iss2_n3", "auxlap_ipa_n3", "auxgauss_ipa_n2",
 ]
 
 
@@ -95,6 +95,32 @@ def test_operators_against_golden(N):
     assert rel_err(projection_back(p("ip1_n{}_W"), reference_id=1), p("pb_n{}_filter")) < 1e-11
     assert rel_err(projection_back(p("iss1_n{}_Y"), reference=p("pb_n{}_X"), reference_id=0),
                    p("pb_n{}_output")) < 1e-11
+
+
+@pytest.mark.parametrize("N", [2, 3, 4])
+def test_ipa_operator_against_golden(N):
+    """update_by_ipa (LQPQM solver per bin) against the reference: default, no normalisation with
+    three Newton steps, broadcast weights with an additive floor."""
+    from ssspy_amd.bss._update_spatial_model import update_by_ipa
+    from ssspy_amd.special.flooring import add_flooring
+
+    g = load_golden("ipa_operators")
+    Y, varphi = g["n{}_Y".format(N)], g["n{}_varphi".format(N)]
+    Y0 = Y.copy()
+    assert rel_err(update_by_ipa(Y, varphi), g["n{}_out".format(N)]) < 1e-10
+    assert np.array_equal(Y, Y0)
+    assert rel_err(update_by_ipa(Y, varphi, normalization=False, max_iter=3),
+                   g["n{}_out_nonorm_it3".format(N)]) < 1e-10
+    out = update_by_ipa(Y, varphi[:, :1, :], flooring_fn=functools.partial(add_flooring, eps=1e-4))
+    assert rel_err(out, g["n{}_out_bcast_add".format(N)]) < 1e-10
+
+
+def test_ipa_unsupported_source_count():
+    from ssspy_amd.bss._update_spatial_model import update_by_ipa
+
+    g = load_golden("ipa_operators")
+    with pytest.raises(NotImplementedError):
+        update_by_ipa(g["n5_Y"], g["n5_varphi"])
 
 
 def test_ip1_singular_raises_linalgerror():

@@ -56,8 +56,11 @@ def test_constructor_argument_checks():
         GaussILRMA(n_basis=2, domain=3)
     with pytest.raises(AssertionError):
         GaussILRMA(n_basis=2, newton_iter=3)  # IPA keyword without IPA
-    with pytest.raises(NotImplementedError):
-        GaussILRMA(n_basis=2, spatial_algorithm="IPA")
+    ipa = GaussILRMA(n_basis=2, spatial_algorithm="IPA", newton_iter=3)
+    assert ipa.newton_iter == 3 and ipa.lqpqm_normalization is True  # reference defaults
+    with pytest.raises(AssertionError):
+        GaussILRMA(n_basis=2, spatial_algorithm="IPA", bogus=1)
+    assert AuxLaplaceIVA(spatial_algorithm="IPA").newton_iter == 1
     with pytest.raises(NotImplementedError):
         GaussILRMA(n_basis=2, flooring_fn=lambda x: x)
     with pytest.raises(ValueError):
