@@ -258,7 +258,7 @@ int ssspy_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis,
 /* IPA (iterative projection with adjustment), one source step: from the weighted covariances of
  * the current separated spectrogram, Vc (B,F,N,N,N) = ssspy_weighted_covariance(Y, weight), the
  * update matrix G (B,F,N,N) of source `source_idx`; the caller then applies ssspy_separate(Y, G)
- * and repeats for the next source.  n_sources in [2, 4].
+ * and repeats for the next source.  n_sources in [2, 8].
  * replaces: ssspy/bss/_update_spatial_model.py:398-513 (update_by_ipa body), linalg/lqpqm.py:13-352
  * (lqpqm2 with `max_iter` Newton steps per bin). */
 int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int B, int F, int N,

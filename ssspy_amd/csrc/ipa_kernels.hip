@@ -171,8 +171,10 @@ __device__ __forceinline__ constexpr int rest_index(int m) {
 }
 
 // Vc: (nbins, N, N, N) weighted covariances; G: (nbins, N, N).  One lane per bin.
+// (one wave per SIMD: the N x N working set of the larger source counts wants the whole 512-entry
+// register file; the grid has only B*F lanes anyway)
 template <int N, int S>
-__global__ __launch_bounds__(64) void k_ipa_transform(const c128 *__restrict__ Vc,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ipa_transform(const c128 *__restrict__ Vc,
                                                       c128 *__restrict__ G, long long nbins,
                                                       int normalization, int max_iter,
                                                       int floor_kind, double eps, int *info) {
@@ -319,8 +321,8 @@ extern "C" int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int 
   SSSPY_REQUIRE(Vc && G && B > 0 && F > 0, "ipa_transform: bad argument");
   SSSPY_REQUIRE(source_idx >= 0 && source_idx < N, "ipa_transform: bad source index");
   SSSPY_REQUIRE(max_iter >= 0, "ipa_transform: max_iter must be non-negative");
-  if (N < 2 || N > 4)
-    return fail(SSSPY_ERR_UNSUPPORTED, "IPA is built for n_sources in [2, 4]");
+  if (N < 2 || N > SSSPY_MAX_SOURCES)
+    return fail(SSSPY_ERR_UNSUPPORTED, "IPA is built for n_sources in [2, 8]");
   const long long nbins = (long long)B * F;
   hipStream_t st = as_stream(stream);
 #define IPA_CASE(N_, S_)                                                                     \
@@ -330,6 +332,12 @@ extern "C" int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int 
   IPA_CASE(2, 0) IPA_CASE(2, 1)
   IPA_CASE(3, 0) IPA_CASE(3, 1) IPA_CASE(3, 2)
   IPA_CASE(4, 0) IPA_CASE(4, 1) IPA_CASE(4, 2) IPA_CASE(4, 3)
+  IPA_CASE(5, 0) IPA_CASE(5, 1) IPA_CASE(5, 2) IPA_CASE(5, 3) IPA_CASE(5, 4)
+  IPA_CASE(6, 0) IPA_CASE(6, 1) IPA_CASE(6, 2) IPA_CASE(6, 3) IPA_CASE(6, 4) IPA_CASE(6, 5)
+  IPA_CASE(7, 0) IPA_CASE(7, 1) IPA_CASE(7, 2) IPA_CASE(7, 3) IPA_CASE(7, 4) IPA_CASE(7, 5)
+  IPA_CASE(7, 6)
+  IPA_CASE(8, 0) IPA_CASE(8, 1) IPA_CASE(8, 2) IPA_CASE(8, 3) IPA_CASE(8, 4) IPA_CASE(8, 5)
+  IPA_CASE(8, 6) IPA_CASE(8, 7)
 #undef IPA_CASE
   return fail(SSSPY_ERR_UNSUPPORTED, "ipa_transform: unsupported (n_sources, source) pair");
 }

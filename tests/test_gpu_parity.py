@@ -97,7 +97,7 @@ def test_operators_against_golden(N):
                    p("pb_n{}_output")) < 1e-11
 
 
-@pytest.mark.parametrize("N", [2, 3, 4])
+@pytest.mark.parametrize("N", [2, 3, 4, 5])
 def test_ipa_operator_against_golden(N):
     """update_by_ipa (LQPQM solver per bin) against the reference: default, no normalisation with
     three Newton steps, broadcast weights with an additive floor."""
@@ -115,12 +115,15 @@ def test_ipa_operator_against_golden(N):
     assert rel_err(out, g["n{}_out_bcast_add".format(N)]) < 1e-10
 
 
-def test_ipa_unsupported_source_count():
+def test_ipa_eight_sources_against_oracle():
+    from oracle.ipa import update_by_ipa as oracle_ipa
     from ssspy_amd.bss._update_spatial_model import update_by_ipa
 
-    g = load_golden("ipa_operators")
-    with pytest.raises(NotImplementedError):
-        update_by_ipa(g["n5_Y"], g["n5_varphi"])
+    rng = np.random.default_rng(208)
+    N, F, T = 8, 5, 60
+    Y = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+    varphi = 1 / (rng.random((N, F, T)) + 0.1)
+    assert rel_err(update_by_ipa(Y, varphi, max_iter=2), oracle_ipa(Y, varphi, max_iter=2)) < 1e-10
 
 
 def test_ip1_singular_raises_linalgerror():
