@@ -133,10 +133,22 @@ int ssspy_iss1_fused_max_frames(int N);
 int ssspy_iss1_fused(void *Y, const double *weight, int weight_kind, double *r2_next, int B, int N,
                      int F, int T, int floor_kind, double floor_eps, void *stream);
 
-/* W <- W * (W^-1)[ref,:]^T.  W (B,F,N,N) in place.
+/* W <- W * (W^-1)[ref,:]^T.  W (B,F,N,N) in place.  G (B,F,N,N), optional: receives
+ * diag((W^-1)[ref, :]), the scales (projection-back normalisation needs them for the basis).
  * replaces: ssspy/algorithm/projection_back.py:87-99. */
-int ssspy_projection_back_filter(void *W, int B, int F, int N, int reference_id, int *info,
+int ssspy_projection_back_filter(void *W, void *G, int B, int F, int N, int reference_id, int *info,
                                  void *stream);
+
+/* minimal distortion principle: G[b,i] = diag(conj(z_n)), z_n = sum_j y_n conj(x_ref) / sum_j |y_n|^2,
+ * from YX = ssspy_cross_covariance(Y, X) and YY = ssspy_cross_covariance(Y, Y); apply with
+ * ssspy_separate(Y, G).   replaces: ssspy/algorithm/minimal_distortion_principle.py:6-43. */
+int ssspy_mdp_scale(const void *YX, const void *YY, void *G, int B, int F, int N, int reference_id,
+                    void *stream);
+
+/* basis[b,n,i,:] *= |G[b,i,n,n]|^domain, the basis side of normalization="projection_back".
+ * replaces: ssspy/bss/ilrma.py:518-522. */
+int ssspy_ilrma_scale_basis(double *basis, const void *G, int B, int N, int F, int K, double domain,
+                            void *stream);
 
 /* scale[b,i,n] = ((X Y^H)(Y Y^H)^-1)[ref, n] from XY (B,F,N,N) and YY (B,F,N,N);
  * G[b,i] = diag(scale) so that ssspy_separate(Y, G) applies it.

@@ -208,8 +208,24 @@ class GaussILRMAOracle:
         else:
             self.output = sp.update_by_iss1(self.output, varphi, self.flooring)
 
+    def normalize_by_projection_back(self):
+        """ref: ssspy/bss/ilrma.py:446-522."""
+        p = self.domain
+        if self.demix_filter is None:
+            Yf = self.output.transpose(1, 0, 2)
+            Xf = self.input.transpose(1, 0, 2)
+            YH = Yf.transpose(0, 2, 1).conj()
+            scale = ((Xf @ YH) @ np.linalg.inv(Yf @ YH))[..., self.reference_id, :]  # (F, N)
+            self.output = (Yf * scale[..., None]).swapaxes(-3, -2)
+        else:
+            scale = np.linalg.inv(self.demix_filter)[:, self.reference_id, :]
+            self.demix_filter = self.demix_filter * scale[:, :, None]
+        self.basis = self.basis * (np.abs(scale.T) ** p)[:, :, None]
+
     def normalize(self):
-        """ref: ssspy/bss/ilrma.py:365-444 (normalize_by_power, no partitioning)."""
+        """ref: ssspy/bss/ilrma.py:365-444 (normalize_by_power)."""
+        if self.normalization == "projection_back":
+            return self.normalize_by_projection_back()
         p = self.domain
         Y = self._current_output()
         psi = sp.floor(np.sqrt(np.mean(np.abs(Y) ** 2, axis=(-2, -1))), self.flooring)
@@ -258,9 +274,15 @@ class GaussILRMAOracle:
 
     # -- driver --------------------------------------------------------------
     def restore_scale(self):
-        """ref: ssspy/bss/ilrma.py:538-565, :1969-1979 (projection back)."""
+        """Projection back (default) or the minimal distortion principle.  ref: ssspy/bss/ilrma.py:538-579, :1969-1989."""
+        mdp = self.scale_restoration == "minimal_distortion_principle"
         if self.demix_filter is None:
-            self.output = sp.projection_back_output(self.output, self.input, self.reference_id)
+            fn = sp.minimal_distortion_output if mdp else sp.projection_back_output
+            self.output = fn(self.output, self.input, self.reference_id)
+        elif mdp:
+            Y = sp.minimal_distortion_output(sp.separate(self.input, self.demix_filter),
+                                             self.input, self.reference_id)
+            self.output, self.demix_filter = Y, sp.demix_from_output(Y, self.input)
         else:
             self.demix_filter = sp.projection_back_filter(self.demix_filter, self.reference_id)
             self.output = sp.separate(self.input, self.demix_filter)

@@ -133,9 +133,15 @@ class AuxIVAOracle:
         return loss.item()
 
     def restore_scale(self):
-        """ref: ssspy/bss/iva.py:238-267, :2194-2204."""
+        """Projection back (default) or the minimal distortion principle.  ref: ssspy/bss/iva.py:238-281, :2194-2214."""
+        mdp = self.scale_restoration == "minimal_distortion_principle"
         if self.demix_filter is None:
-            self.output = sp.projection_back_output(self.output, self.input, self.reference_id)
+            fn = sp.minimal_distortion_output if mdp else sp.projection_back_output
+            self.output = fn(self.output, self.input, self.reference_id)
+        elif mdp:
+            Y = sp.minimal_distortion_output(sp.separate(self.input, self.demix_filter),
+                                             self.input, self.reference_id)
+            self.output, self.demix_filter = Y, sp.demix_from_output(Y, self.input)
         else:
             self.demix_filter = sp.projection_back_filter(self.demix_filter, self.reference_id)
             self.output = sp.separate(self.input, self.demix_filter)

@@ -112,6 +112,16 @@ def projection_back_output(Y, X, reference_id=0):
     return (Yf * scale[..., None]).swapaxes(-3, -2)
 
 
+def minimal_distortion_output(Y, X, reference_id=0):
+    """conj(z) y with z = <y, x_ref> / <y, y> per (source, bin).
+
+    ref: ssspy/algorithm/minimal_distortion_principle.py:6-43.
+    """
+    num = np.sum(Y * X[reference_id].conj(), axis=-1, keepdims=True)
+    den = np.sum(np.abs(Y) ** 2, axis=-1, keepdims=True)
+    return (num / den).conj() * Y
+
+
 def demix_from_output(Y, X):
     """W_i = Y_i X_i^H (X_i X_i^H)^-1.  ref: ssspy/bss/ilrma.py:1938-1944, ssspy/bss/iva.py:2180-2185."""
     Xf, Yf = X.transpose(1, 0, 2), Y.transpose(1, 0, 2)

@@ -138,13 +138,29 @@ def iss1_fused(Y, weight, kind, flooring, r2_next=None):
     return Y
 
 
-def projection_back_filter(W, reference_id, info=None):
+def projection_back_filter(W, reference_id, info=None, scale_out=None):
     B, F, N, _ = W.shape
     _lib.check(
-        _L().ssspy_projection_back_filter(ptr(W), B, F, N, reference_id, ptr(info), _st()),
+        _L().ssspy_projection_back_filter(ptr(W), ptr(scale_out), B, F, N, reference_id, ptr(info),
+                                          _st()),
         "projection_back_filter",
     )
     return W
+
+
+def mdp_scale(YX, YY, reference_id, out=None):
+    B, F, N, _ = YX.shape
+    if out is None:
+        out = dv.empty((B, F, N, N), dv.c128, YX.device)
+    _lib.check(_L().ssspy_mdp_scale(ptr(YX), ptr(YY), ptr(out), B, F, N, int(reference_id), _st()),
+               "mdp_scale")
+    return out
+
+
+def ilrma_scale_basis(basis, G, domain):
+    B, N, F, K = basis.shape
+    _lib.check(_L().ssspy_ilrma_scale_basis(ptr(basis), ptr(G), B, N, F, K, domain, _st()),
+               "ilrma_scale_basis")
 
 
 def projection_back_scale(XY, YY, reference_id, info=None, out=None):

@@ -191,9 +191,27 @@ class ILRMABase(DeviceStateMixin, IterativeMethodBase):
             self._state_touch("output")
 
     def apply_minimal_distortion_principle(self) -> None:
-        raise NotImplementedError(
-            "scale_restoration='minimal_distortion_principle' is not built for the device path yet."
-        )
+        """Per (bin, source) scale z = <y, x_ref> / <y, y>, output conj(z) y; with a filter state the
+        filter is re-fitted as Y X^H (X X^H)^-1 like the reference.
+        ref: ssspy/bss/ilrma.py:567-579, :1981-1989; algorithm/minimal_distortion_principle.py:6-43."""
+        assert self.scale_restoration, "Set self.scale_restoration=True."
+        if self.reference_id is None:
+            raise NotImplementedError("reference_id=None (all channels) is not built for the device path.")
+        filt = self._uses_filter()
+        if filt:
+            Y = _ops.separate(self._X, self._state_dev("demix_filter"))
+        else:
+            Y = self._state_dev("output")
+        G = _ops.mdp_scale(_ops.cross_covariance(Y, self._X), _ops.cross_covariance(Y, Y),
+                           self.reference_id)
+        _ops.separate(Y, G, out=Y)
+        if filt:
+            W = _ops.demix_from_covariance(_ops.cross_covariance(Y, self._X), self._C(),
+                                           self._info_tensor())
+            self._state_set_dev("demix_filter", W)
+            self._state_set_dev("output", Y)
+        else:
+            self._state_touch("output")
 
     def _host_loss(self, data, logdet_sum):
         """loss = data term - 2 sum_i log|det W_i|, combined on the host (B numbers each)."""
@@ -500,11 +518,32 @@ class _MMILRMA(ILRMABase):
         if normalization == "power":
             self.normalize_by_power(flooring_fn=flooring_fn)
         elif normalization == "projection_back":
-            raise NotImplementedError(
-                "normalization='projection_back' is not built for the device path yet."
-            )
+            self.normalize_by_projection_back()
         else:
             raise NotImplementedError("Normalization {} is not implemented.".format(normalization))
+
+    def normalize_by_projection_back(self) -> None:
+        """Projection back as the per-iteration normalisation; the basis takes |scale|^p.
+        ref: ssspy/bss/ilrma.py:446-522."""
+        if self.partitioning:
+            raise NotImplementedError(
+                "Projection-back-based normalization is not applicable with partitioning function."
+            )
+        reference_id = 0 if self.reference_id is None else self.reference_id
+        info = self._info_tensor()
+        if self._uses_filter():
+            W = self._state_dev("demix_filter")
+            G = dv.empty(tuple(W.shape), dv.c128, W.device)
+            _ops.projection_back_filter(W, reference_id, info, scale_out=G)
+            self._state_touch("demix_filter")
+        else:
+            Y = self._state_dev("output")
+            G = _ops.projection_back_scale(_ops.cross_covariance(self._X, Y),
+                                           _ops.cross_covariance(Y, Y), reference_id, info)
+            _ops.separate(Y, G, out=Y)
+            self._state_touch("output")
+        _ops.ilrma_scale_basis(self._state_dev("basis"), G, float(self.domain))
+        self._state_touch("basis")
 
     def normalize_by_power(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/ilrma.py:365-444 (no partitioning)."""

@@ -131,9 +131,27 @@ class IVABase(DeviceStateMixin, IterativeMethodBase):
             self.__dict__["_r2_cache"] = None
 
     def apply_minimal_distortion_principle(self) -> None:
-        raise NotImplementedError(
-            "scale_restoration='minimal_distortion_principle' is not built for the device path yet."
-        )
+        """Per (bin, source) scale z = <y, x_ref> / <y, y>, output conj(z) y; with a filter state the
+        filter is re-fitted as Y X^H (X X^H)^-1 like the reference.
+        ref: ssspy/bss/iva.py:269-281, :2206-2214; algorithm/minimal_distortion_principle.py:6-43."""
+        assert self.scale_restoration, "Set self.scale_restoration=True."
+        if self.reference_id is None:
+            raise NotImplementedError("reference_id=None (all channels) is not built for the device path.")
+        filt = self._uses_filter()
+        if filt:
+            Y = _ops.separate(self._X, self._state_dev("demix_filter"))
+        else:
+            Y = self._state_dev("output")
+        G = _ops.mdp_scale(_ops.cross_covariance(Y, self._X), _ops.cross_covariance(Y, Y),
+                           self.reference_id)
+        _ops.separate(Y, G, out=Y)
+        if filt:
+            W = _ops.demix_from_covariance(_ops.cross_covariance(Y, self._X), self._C(),
+                                           self._info_tensor())
+            self._state_set_dev("demix_filter", W)
+            self._state_set_dev("output", Y)
+        else:
+            self._state_touch("output")
 
 
 class AuxIVABase(IVABase):

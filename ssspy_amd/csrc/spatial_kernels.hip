@@ -296,7 +296,8 @@ __global__ __launch_bounds__(64) void k_iss1_transform(const c128 *__restrict__ 
 
 // ------------------------------------------------------------------------------ projection back
 template <int N>
-__global__ __launch_bounds__(64) void k_pb_filter(c128 *W, long long nbins, int ref, int *info) {
+__global__ __launch_bounds__(64) void k_pb_filter(c128 *W, c128 *G, long long nbins, int ref,
+                                                  int *info) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nbins) return;
   Mat<N> Wm, A, Inv;
@@ -311,9 +312,41 @@ __global__ __launch_bounds__(64) void k_pb_filter(c128 *W, long long nbins, int 
       if (r == ref) s = Inv.a[r][n];
 #pragma unroll
     for (int c = 0; c < N; ++c) Wm.a[n][c] = cmul(Wm.a[n][c], s);
+    if (G) {
+#pragma unroll
+      for (int c = 0; c < N; ++c) G[idx * (N * N) + n * N + c] = (c == n) ? s : cmake(0.0, 0.0);
+    }
   }
   store_mat<N>(Wm, W + idx * (N * N));
   if (!ok && info) atomicAdd(info, 1);
+}
+
+// G = diag(conj(z_n)), z_n = (sum_j y_n conj(x_ref)) / (sum_j |y_n|^2), from the covariances
+// YX[n][m] = mean_j y_n conj(x_m) and YY[n][n] = mean_j |y_n|^2.
+// ref: ssspy/algorithm/minimal_distortion_principle.py:6-43 (reference_id given).
+__global__ __launch_bounds__(64) void k_mdp_scale(const c128 *__restrict__ YX,
+                                                  const c128 *__restrict__ YY, c128 *G,
+                                                  long long nbins, int N, int ref) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nbins) return;
+  for (int n = 0; n < N; ++n) {
+    const c128 num = YX[idx * (N * N) + n * N + ref];
+    const double den = YY[idx * (N * N) + n * N + n].x;
+    for (int c = 0; c < N; ++c)
+      G[idx * (N * N) + n * N + c] = (c == n) ? cmake(num.x / den, -num.y / den) : cmake(0.0, 0.0);
+  }
+}
+
+// basis[b,n,i,:] *= |G[b,i,n,n]|^p  (ref: ssspy/bss/ilrma.py:518-522)
+__global__ __launch_bounds__(256) void k_scale_basis_by_diag(double *basis,
+                                                             const c128 *__restrict__ G, int N,
+                                                             int F, int K, double p) {
+  const int i = blockIdx.x, n = blockIdx.y, b = blockIdx.z;
+  const c128 g = G[(((long long)b * F + i) * N + n) * N + n];
+  const double a2 = cabs2(g);
+  const double sc = (p == 2.0) ? a2 : pow(a2, 0.5 * p);
+  double *row = basis + (((long long)b * N + n) * F + i) * K;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) row[k] *= sc;
 }
 
 template <int N>
@@ -463,15 +496,35 @@ int ssspy_iss1_transform(const void *Vc, void *G, int B, int F, int N, int floor
   return check_launch("k_iss1_transform");
 }
 
-int ssspy_projection_back_filter(void *W, int B, int F, int N, int reference_id, int *info,
+int ssspy_projection_back_filter(void *W, void *G, int B, int F, int N, int reference_id, int *info,
                                  void *stream) {
   SSSPY_REQUIRE(W && B > 0 && F > 0 && reference_id >= 0 && reference_id < N,
                 "projection_back_filter: bad argument");
   const long long nbins = (long long)B * F;
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
   DISPATCH_N(N, hipLaunchKernelGGL((k_pb_filter<NN>), grid, block, 0, as_stream(stream),
-                                   (c128 *)W, nbins, reference_id, info));
+                                   (c128 *)W, (c128 *)G, nbins, reference_id, info));
   return check_launch("k_pb_filter");
+}
+
+int ssspy_mdp_scale(const void *YX, const void *YY, void *G, int B, int F, int N, int reference_id,
+                    void *stream) {
+  SSSPY_REQUIRE(YX && YY && G && B > 0 && F > 0 && N >= 1 && reference_id >= 0 &&
+                    reference_id < N,
+                "mdp_scale: bad argument");
+  const long long nbins = (long long)B * F;
+  hipLaunchKernelGGL(k_mdp_scale, dim3((unsigned)((nbins + 63) / 64)), dim3(64), 0,
+                     as_stream(stream), (const c128 *)YX, (const c128 *)YY, (c128 *)G, nbins, N,
+                     reference_id);
+  return check_launch("k_mdp_scale");
+}
+
+int ssspy_ilrma_scale_basis(double *basis, const void *G, int B, int N, int F, int K, double domain,
+                            void *stream) {
+  SSSPY_REQUIRE(basis && G && B > 0 && N >= 1 && F > 0 && K >= 1, "scale_basis: bad argument");
+  hipLaunchKernelGGL(k_scale_basis_by_diag, dim3(F, N, B), dim3(256), 0, as_stream(stream), basis,
+                     (const c128 *)G, N, F, K, domain);
+  return check_launch("k_scale_basis_by_diag");
 }
 
 int ssspy_projection_back_scale(const void *XY, const void *YY, void *G, int B, int F, int N,

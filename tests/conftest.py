@@ -42,3 +42,10 @@ def rel_err_up_to_phase(a, b, name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def option(value):
+    """A golden's meta entry that is a bool in most fixtures and a keyword (e.g. "projection_back")
+    in some."""
+    v = np.asarray(value)
+    return str(v) if v.dtype.kind in "US" else bool(v)

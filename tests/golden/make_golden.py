@@ -372,6 +372,19 @@ def main():
               partitioning=True)
     run_iva("auxlap_ipa_n3", N=3, F=20, T=44, algo="IPA", contrast="laplace", seed=103, gen=gen_mixture)
     run_iva("auxgauss_ipa_n2", N=2, F=24, T=40, algo="IPA", contrast="gauss", seed=104)
+    # --- scale restoration by the minimal distortion principle, projection-back normalisation ---
+    run_ilrma("gilrma_mdp_ip1_n3", N=3, F=16, T=36, K=3, algo="IP", seed=110, gen=gen_mixture,
+              scale_restoration="minimal_distortion_principle")
+    run_ilrma("gilrma_mdp_iss1_n2", N=2, F=16, T=34, K=3, algo="ISS", seed=111,
+              scale_restoration="minimal_distortion_principle")
+    run_ilrma("gilrma_pbnorm_ip1_n3", N=3, F=16, T=36, K=3, algo="IP", seed=112, gen=gen_mixture,
+              normalization="projection_back")
+    run_ilrma("gilrma_pbnorm_iss1_n2_p1", N=2, F=16, T=34, K=3, algo="ISS", seed=113, domain=1,
+              normalization="projection_back")
+    run_iva("auxlap_mdp_ip1_n3", N=3, F=20, T=44, algo="IP", contrast="laplace", seed=114,
+            gen=gen_mixture, scale_restoration="minimal_distortion_principle")
+    run_iva("auxlap_mdp_iss1_n2", N=2, F=20, T=40, algo="ISS", contrast="laplace", seed=115,
+            scale_restoration="minimal_distortion_principle")
     # --- operators ---
     run_operators()
 

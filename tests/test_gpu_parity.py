@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden, rel_err, rel_err_up_to_phase
+from conftest import option as _option
 
 pytestmark = pytest.mark.gpu
 
@@ -26,11 +27,13 @@ ILRMA_CASES = [
     "ggdilrma_iss2_n3_p1", "gilrma_me_ip1_n3", "tilrma_me_iss1_n2", "gilrma_part_ip1_n3",
     "gilrma_part_iss1_n2_p1", "gilrma_part_me_ip2_n3", "tilrma_part_ip1_n2", "ggdilrma_part_iss1_n3",
     "tilrma_part_me_nonorm_n2", "gilrma_ipa_n3", "gilrma_ipa_n2_p1", "gilrma_ipa_part_n4",
+    "gilrma_mdp_ip1_n3", "gilrma_mdp_iss1_n2", "gilrma_pbnorm_ip1_n3", "gilrma_pbnorm_iss1_n2_p1",
 ]
 IVA_CASES = [
     "auxlap_ip1_n2", "auxlap_ip1_n4", "auxlap_iss1_n2", "auxlap_iss1_n8", "auxgauss_ip1_n3",
     "auxgauss_iss1_n3", "auxlap_ip1_n2_raw", "auxlap_ip2_n3", "auxlap_iss2_n4", "auxgauss_ip2_n2",
-    "auxgauss_iss2_n3", "auxlap_ipa_n3", "auxgauss_ipa_n2",
+    "auxgauss_iss2_n3", "auxlap_ipa_n3", "auxgauss_ipa_n2", "auxlap_mdp_ip1_n3",
+    "auxlap_mdp_iss1_n2",
 ]
 
 
@@ -158,8 +161,8 @@ def test_gauss_ilrma_against_golden(case):
         n_basis=int(g["meta_n_basis"]), spatial_algorithm=str(g["meta_algo"]),
         partitioning=partitioning,
         domain=float(g["meta_domain"]), flooring_fn=_flooring_fn(g), callbacks=snap,
-        normalization=bool(g["meta_normalization"]),
-        scale_restoration=bool(g["meta_scale_restoration"]),
+        normalization=_option(g["meta_normalization"]),
+        scale_restoration=_option(g["meta_scale_restoration"]),
         source_algorithm=str(g["meta_source_algorithm"]) if "meta_source_algorithm" in g else "MM",
     )
     b0, a0 = g["basis0"].copy(), g["activation0"].copy()
@@ -396,7 +399,7 @@ def test_aux_iva_against_golden(case):
     snap = Snap(["demix_filter", "output"] + (["variance"] if contrast == "gauss" else []))
     cls = AuxLaplaceIVA if contrast == "laplace" else AuxGaussIVA
     m = cls(spatial_algorithm=str(g["meta_algo"]), flooring_fn=_flooring_fn(g), callbacks=snap,
-            scale_restoration=bool(g["meta_scale_restoration"]))
+            scale_restoration=_option(g["meta_scale_restoration"]))
     Y = m(g["X"], n_iter=int(g["meta_n_iter"]))
     _compare_snapshots(g, snap)
     np.testing.assert_allclose(m.loss, g["loss"], rtol=LOSS_RTOL)
@@ -450,7 +453,7 @@ def test_fast_gauss_mnmf_against_golden(case):
     snap = Snap(["diagonalizer", "spatial", "basis", "activation"])
     m = FastGaussMNMF(n_basis=int(g["meta_n_basis"]), n_sources=int(g["meta_n_sources"]),
                       flooring_fn=_flooring_fn(g), callbacks=snap,
-                      normalization=bool(g["meta_normalization"]))
+                      normalization=_option(g["meta_normalization"]))
     sp0 = g["spatial0"].copy()
     Y = m(g["X"], n_iter=int(g["meta_n_iter"]), basis=g["basis0"], activation=g["activation0"],
           spatial=sp0)
@@ -476,7 +479,7 @@ def test_gauss_mnmf_against_golden(case):
     snap = Snap(["spatial", "basis", "activation"])
     m = GaussMNMF(n_basis=int(g["meta_n_basis"]), n_sources=int(g["meta_n_sources"]),
                   flooring_fn=_flooring_fn(g), callbacks=snap,
-                  normalization=bool(g["meta_normalization"]))
+                  normalization=_option(g["meta_normalization"]))
     init = dict(basis=g["basis0"], activation=g["activation0"])
     if "spatial0" in g:
         init["spatial"] = g["spatial0"].copy()

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden, rel_err, rel_err_up_to_phase
+from conftest import option as _option
 from oracle import spatial as sp
 from oracle.ilrma import GaussILRMAOracle
 from oracle.iva import AuxIVAOracle
@@ -27,6 +28,7 @@ ILRMA_CASES = [
     "gilrma_me_ip1_n3", "tilrma_me_iss1_n2", "gilrma_part_ip1_n3", "gilrma_part_iss1_n2_p1",
     "gilrma_part_me_ip2_n3", "tilrma_part_ip1_n2", "ggdilrma_part_iss1_n3",
     "tilrma_part_me_nonorm_n2", "gilrma_ipa_n3", "gilrma_ipa_n2_p1", "gilrma_ipa_part_n4",
+    "gilrma_mdp_ip1_n3", "gilrma_mdp_iss1_n2", "gilrma_pbnorm_ip1_n3", "gilrma_pbnorm_iss1_n2_p1",
 ]
 
 
@@ -36,7 +38,8 @@ def _model(g):
 IVA_CASES = [
     "auxlap_ip1_n2", "auxlap_ip1_n4", "auxlap_iss1_n2", "auxlap_iss1_n8", "auxgauss_ip1_n3",
     "auxgauss_iss1_n3", "auxlap_ip1_n2_raw", "auxlap_ip2_n3", "auxlap_iss2_n4", "auxgauss_ip2_n2",
-    "auxgauss_iss2_n3", "auxlap_ipa_n3", "auxgauss_ipa_n2",
+    "auxgauss_iss2_n3", "auxlap_ipa_n3", "auxgauss_ipa_n2", "auxlap_mdp_ip1_n3",
+    "auxlap_mdp_iss1_n2",
 ]
 MNMF_CASES = ["fmnmf_ip1_m3", "fmnmf_ip1_m4", "fmnmf_ip1_m3_n2", "fmnmf_ip1_m2_nonorm"]
 
@@ -64,8 +67,8 @@ def test_gauss_ilrma(case):
     m = GaussILRMAOracle(
         n_basis=int(g["meta_n_basis"]), spatial_algorithm=str(g["meta_algo"]),
         domain=float(g["meta_domain"]), flooring=_floor(g),
-        normalization=bool(g["meta_normalization"]),
-        scale_restoration=bool(g["meta_scale_restoration"]), model=_model(g),
+        normalization=_option(g["meta_normalization"]),
+        scale_restoration=_option(g["meta_scale_restoration"]), model=_model(g),
         source_algorithm=str(g["meta_source_algorithm"]) if "meta_source_algorithm" in g else "MM",
         partitioning=bool(g["meta_partitioning"]) if "meta_partitioning" in g else False,
     )
@@ -105,7 +108,7 @@ def test_aux_iva(case):
     g = load_golden(case)
     m = AuxIVAOracle(
         spatial_algorithm=str(g["meta_algo"]), contrast=str(g["meta_contrast"]),
-        flooring=_floor(g), scale_restoration=bool(g["meta_scale_restoration"]),
+        flooring=_floor(g), scale_restoration=_option(g["meta_scale_restoration"]),
     )
     m.reset(g["X"])
     losses = [m.compute_loss()]
@@ -142,7 +145,7 @@ def test_fast_gauss_mnmf(case):
     n_sources = int(g["meta_n_sources"])
     m = FastGaussMNMFOracle(
         n_basis=int(g["meta_n_basis"]), n_sources=n_sources, flooring=_floor(g),
-        normalization=bool(g["meta_normalization"]),
+        normalization=_option(g["meta_normalization"]),
     )
     m.reset(g["X"], basis=g["basis0"], activation=g["activation0"], spatial=g["spatial0"].copy())
     losses = [m.compute_loss()]
@@ -165,7 +168,7 @@ def test_gauss_mnmf(case):
     g = load_golden(case)
     m = GaussMNMFOracle(
         n_basis=int(g["meta_n_basis"]), n_sources=int(g["meta_n_sources"]), flooring=_floor(g),
-        normalization=bool(g["meta_normalization"]),
+        normalization=_option(g["meta_normalization"]),
     )
     init = dict(basis=g["basis0"], activation=g["activation0"])
     if "spatial0" in g:
