@@ -34,14 +34,56 @@ __device__ __forceinline__ void xx_floor_coeffs(double s, int floor_kind, double
   }
 }
 
-// Per-point state: lambda_n, R^-1 (Hermitian), floored eigenvalues of R, u = R^-1 x.
+// Per-point state: lambda_n, R^-1 (Hermitian), log det R (both of the floored R), u = R^-1 x.
 template <int M>
 struct Point {
   double lam[GM_NMAX];
   c128 Rinv[M][M];
-  double ev[M];
+  double logdet;
   c128 x[M], u[M];
 };
+
+// R^-1 and log det of to_psd(R).  The eigenvalue floor rarely does anything (R is a positive
+// combination of PSD matrices), so the common path avoids the eigen-decomposition:
+//   add floor:  to_psd(R) = R + eps I exactly -> Cholesky of that;
+//   max floor:  if 1 / ||R^-1||_F > eps then every eigenvalue exceeds eps and to_psd(R) = R;
+//   otherwise (or when Cholesky meets a non-positive pivot) the Jacobi path applies the floor.
+template <int M>
+__device__ __forceinline__ void psd_inverse(c128 (&R)[M][M], c128 (&Rinv)[M][M], double &logdet,
+                                            int floor_kind, double eps) {
+  hermitize<M>(R);
+  c128 Lw[M][M];
+#pragma unroll
+  for (int a = 0; a < M; ++a)
+#pragma unroll
+    for (int c = 0; c < M; ++c) Lw[a][c] = R[a][c];
+  if (floor_kind == SSSPY_FLOOR_ADD) {
+#pragma unroll
+    for (int a = 0; a < M; ++a) Lw[a][a].x += eps;
+  }
+  bool ok = chol_inverse<M>(Lw, Rinv, logdet);
+  if (ok && floor_kind == SSSPY_FLOOR_MAX) {
+    double fro = 0.0;
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+      for (int c = 0; c < M; ++c) fro += cabs2(Rinv[a][c]);
+    ok = fro * eps * eps < 1.0;  // 1 / ||R^-1||_F > eps
+  }
+  if (!ok) {
+    c128 P[M][M];
+    double ev[M], w[M];
+    psd_eigen<M>(R, P, ev, floor_kind, eps);
+    double ld = 0.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      w[k] = 1.0 / ev[k];
+      ld += log(ev[k]);
+    }
+    herm_rebuild<M>(P, w, Rinv);
+    logdet = ld;
+  }
+}
 
 // Hs: spatial matrices of this bin in LDS [n][M*M]; Ts: basis rows of this bin in LDS [n][K]
 template <int M>
@@ -49,7 +91,7 @@ __device__ __forceinline__ void point_setup(Point<M> &pt, const c128 *__restrict
                                             const double *__restrict__ act_b, const c128 *Hs,
                                             const double *Ts, int N, int F, int T, int K, int i,
                                             int j, int floor_kind, double eps) {
-  c128 R[M][M], P[M][M];
+  c128 R[M][M];
 #pragma unroll
   for (int a = 0; a < M; ++a)
 #pragma unroll
@@ -70,11 +112,7 @@ __device__ __forceinline__ void point_setup(Point<M> &pt, const c128 *__restrict
     }
     pt.lam[n] = l;
   }
-  psd_eigen<M>(R, P, pt.ev, floor_kind, eps);
-  double w[M];
-#pragma unroll
-  for (int k = 0; k < M; ++k) w[k] = 1.0 / pt.ev[k];
-  herm_rebuild<M>(P, w, pt.Rinv);
+  psd_inverse<M>(R, pt.Rinv, pt.logdet, floor_kind, eps);
 #pragma unroll
   for (int m = 0; m < M; ++m) pt.x[m] = Xb[((long long)m * F + i) * T + j];
 #pragma unroll
@@ -127,21 +165,31 @@ __global__ __launch_bounds__(128) void k_gmnmf_traces(const c128 *__restrict__ X
   for (int m = 0; m < M; ++m) s += cabs2(pt.x[m]);
   double c1, c0;
   xx_floor_coeffs(s, floor_kind, eps, c1, c0);
+  // tr(R^-1 H_n) = sum_ak Re(Rinv_ak H_ka) and tr(R^-1 H_n R^-1) = sum_ak Re(R2_ak H_ka) with
+  // R2 = R^-1 R^-1 formed once per point: M^2 products per source instead of M^3
+  c128 R2[M][M];
+#pragma unroll
+  for (int a = 0; a < M; ++a)
+#pragma unroll
+    for (int c = a; c < M; ++c) {
+      c128 r2 = cmake(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < M; ++k) cfma(r2, pt.Rinv[a][k], pt.Rinv[k][c]);
+      R2[a][c] = r2;
+      R2[c][a] = cconj(r2);
+    }
   for (int n = 0; n < N; ++n) {
     const c128 *Hn = Hs + n * M * M;
-    // G = R^-1 H_n ; tr(G), tr(G R^-1), u^H H_n u
     double trG = 0.0, trGR = 0.0;
 #pragma unroll
     for (int a = 0; a < M; ++a)
 #pragma unroll
-      for (int c = 0; c < M; ++c) {
-        c128 g = cmake(0.0, 0.0);
-#pragma unroll
-        for (int k = 0; k < M; ++k) cfma(g, pt.Rinv[a][k], Hn[k * M + c]);
-        if (a == c) trG += g.x;
-        // Re(G_ac Rinv_ca)
-        trGR = fma(g.x, pt.Rinv[c][a].x, trGR);
-        trGR = fma(-g.y, pt.Rinv[c][a].y, trGR);
+      for (int k = 0; k < M; ++k) {
+        const c128 h = Hn[k * M + a];
+        trG = fma(pt.Rinv[a][k].x, h.x, trG);
+        trG = fma(-pt.Rinv[a][k].y, h.y, trG);
+        trGR = fma(R2[a][k].x, h.x, trGR);
+        trGR = fma(-R2[a][k].y, h.y, trGR);
       }
     double q = 0.0;
 #pragma unroll
@@ -184,22 +232,29 @@ __global__ __launch_bounds__(256) void k_gmnmf_basis(double *basis, const double
   }
 }
 
-// act[b,n,k,j] <- floor(act * sqrt(sum_i T A / sum_i T Bt)).  grid: (ceil(T/256), ceil(K/8), N*B)
-__global__ __launch_bounds__(256) void k_gmnmf_activation(const double *__restrict__ basis,
-                                                          double *act, const double *__restrict__ A,
-                                                          const double *__restrict__ Bt, int N,
-                                                          int F, int T, int K, int floor_kind,
-                                                          double eps) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k0 = blockIdx.y * 8;
+// Activation sums: acc[b,n,0,k,j] += sum_{i in chunk} T A, acc[b,n,1,k,j] += sum T Bt.
+// grid: (ceil(T/64), bin chunks of 4*GM_ACT_BINS, N*B); wave w walks its own GM_ACT_BINS bins,
+// lanes are frames, the four waves fold through LDS and one atomic add per (k, frame) leaves.
+constexpr int GM_ACT_BINS = 32;
+
+__global__ __launch_bounds__(256) void k_gmnmf_activation_sums(const double *__restrict__ basis,
+                                                               const double *__restrict__ A,
+                                                               const double *__restrict__ Bt,
+                                                               double *__restrict__ acc, int N,
+                                                               int F, int T, int K, int k0) {
+  __shared__ double fold[4][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
   const int n = blockIdx.z % N, b = blockIdx.z / N;
-  if (j >= T) return;
+  const int i_begin = (blockIdx.y * 4 + wave) * GM_ACT_BINS;
+  const int i_end = min(F, i_begin + GM_ACT_BINS);
+  const int jc = min(j, T - 1);
   double sn[8], sd[8];
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) sn[kk] = sd[kk] = 0.0;
   const double *tb = basis + ((long long)b * N + n) * F * K;
-  const long long base = ((long long)b * N + n) * F * T + j;
-  for (int i = 0; i < F; ++i) {
+  const long long base = ((long long)b * N + n) * F * T + jc;
+  for (int i = i_begin; i < i_end; ++i) {
     const double a = A[base + (long long)i * T], bt = Bt[base + (long long)i * T];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
@@ -209,30 +264,83 @@ __global__ __launch_bounds__(256) void k_gmnmf_activation(const double *__restri
     }
   }
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk)
-    if (k0 + kk < K) {
-      double *dst = act + (((long long)b * N + n) * K + k0 + kk) * T + j;
-      *dst = apply_floor(*dst * sqrt(sn[kk] / sd[kk]), floor_kind, eps);
+  for (int kk = 0; kk < 8; ++kk) {
+    fold[wave][kk][lane] = sn[kk];
+    fold[wave][8 + kk][lane] = sd[kk];
+  }
+  __syncthreads();
+  // 16 rows x 64 frames = 1024 sums, 4 per thread
+  for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+    const int row = e >> 6, ln = e & 63;
+    const int kk = row & 7, nd = row >> 3;
+    const int jj = blockIdx.x * 64 + ln;
+    if (jj < T && k0 + kk < K) {
+      const double v = fold[0][row][ln] + fold[1][row][ln] + fold[2][row][ln] + fold[3][row][ln];
+      atomicAdd(acc + ((((long long)b * N + n) * 2 + nd) * K + k0 + kk) * T + jj, v);
     }
+  }
+}
+
+// act <- floor(act * sqrt(num / den)) from the accumulated sums.  one thread per (b, n, k, j)
+__global__ __launch_bounds__(256) void k_gmnmf_activation_apply(double *act,
+                                                                const double *__restrict__ acc,
+                                                                long long count, int K, int T,
+                                                                int floor_kind, double eps) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  const long long kt = (long long)K * T;
+  const long long bn = e / kt, rem = e % kt;
+  const double sn = acc[(bn * 2) * kt + rem], sd = acc[(bn * 2 + 1) * kt + rem];
+  act[e] = apply_floor(act[e] * sqrt(sn / sd), floor_kind, eps);
 }
 
 // ---------------------------------------------------------------------------- spatial update
-// Pacc[b,n,i] = sum_j lambda R^-1 ; Qacc[b,n,i] = sum_j lambda R^-1 XX R^-1, both stored as the
-// M*M complex entries of a Hermitian matrix.  grid: (F, B), one wave: lanes take frames, the
-// per-chunk matrices go through LDS and thread (n, entry) folds the chunk with the N weights.
+// Pacc[b,n,i] = sum_j lambda R^-1 ; Qacc[b,n,i] = sum_j lambda R^-1 XX R^-1, both Hermitian and
+// stored packed as M*M doubles (diagonal, then re/im of the upper triangle).  grid: (F, B), one
+// wave: lanes take frames, the per-chunk matrices go through LDS and thread (n, entry) folds the
+// chunk with the N weights.
 constexpr int GM_PB = 64;  // points per chunk (= block size of k_gmnmf_spatial_acc)
+
+template <int M>
+__device__ __forceinline__ void pack_hermitian(const c128 (&A)[M][M], double *dst) {
+  int e = 0;
+#pragma unroll
+  for (int a = 0; a < M; ++a) dst[e++] = A[a][a].x;
+#pragma unroll
+  for (int a = 0; a < M; ++a)
+#pragma unroll
+    for (int c = a + 1; c < M; ++c) {
+      dst[e++] = A[a][c].x;
+      dst[e++] = A[a][c].y;
+    }
+}
+
+template <int M>
+__device__ __forceinline__ void unpack_hermitian(const double *src, c128 (&A)[M][M]) {
+  int e = 0;
+#pragma unroll
+  for (int a = 0; a < M; ++a) A[a][a] = cmake(src[e++], 0.0);
+#pragma unroll
+  for (int a = 0; a < M; ++a)
+#pragma unroll
+    for (int c = a + 1; c < M; ++c) {
+      const c128 z = cmake(src[e], src[e + 1]);
+      e += 2;
+      A[a][c] = z;
+      A[c][a] = cconj(z);
+    }
+}
 
 template <int M>
 __global__ __launch_bounds__(GM_PB) void k_gmnmf_spatial_acc(const c128 *__restrict__ X,
                                                            const double *__restrict__ basis,
                                                            const double *__restrict__ act,
                                                            const c128 *__restrict__ H,
-                                                           c128 *__restrict__ Pacc,
-                                                           c128 *__restrict__ Qacc, int N, int F,
+                                                           double *__restrict__ PQacc, int N, int F,
                                                            int T, int K, int floor_kind,
                                                            double eps) {
-  constexpr int E = 2 * M * M;          // complex entries per point: R^-1 then R^-1 XX R^-1
-  constexpr int ROW = 2 * E + GM_NMAX;  // doubles per point in LDS
+  constexpr int E = 2 * M * M;     // packed doubles per point: R^-1 then R^-1 XX R^-1
+  constexpr int ROW = E + GM_NMAX;  // doubles per point in LDS
   extern __shared__ __attribute__((aligned(16))) char smem[];
   c128 *Hs = reinterpret_cast<c128 *>(smem);
   double *Ts = reinterpret_cast<double *>(Hs + N * M * M);
@@ -241,11 +349,11 @@ __global__ __launch_bounds__(GM_PB) void k_gmnmf_spatial_acc(const c128 *__restr
   stage_bin<M>(Hs, Ts, H, basis, b, N, F, K, i);
   const c128 *Xb = X + (long long)b * M * F * T;
   const double *act_b = act + (long long)b * N * K * T;
-  // accumulators: this thread owns output slots idx = tid, tid + GM_PB, ... of the N*E complex sums
+  // accumulators: this thread owns output slots idx = tid, tid + GM_PB, ... of the N*E sums
   constexpr int SLOTS = (GM_NMAX * E + GM_PB - 1) / GM_PB;
-  c128 accum[SLOTS];
+  double accum[SLOTS];
 #pragma unroll
-  for (int s = 0; s < SLOTS; ++s) accum[s] = cmake(0.0, 0.0);
+  for (int s = 0; s < SLOTS; ++s) accum[s] = 0.0;
   for (int j0 = 0; j0 < T; j0 += GM_PB) {
     const int j = j0 + threadIdx.x;
     double *mine = pts + threadIdx.x * ROW;
@@ -257,22 +365,21 @@ __global__ __launch_bounds__(GM_PB) void k_gmnmf_spatial_acc(const c128 *__restr
       for (int m = 0; m < M; ++m) s += cabs2(pt.x[m]);
       double c1, c0;
       xx_floor_coeffs(s, floor_kind, eps, c1, c0);
+      c128 Q[M][M];  // R^-1 XX R^-1 = c1 u u^H + c0 R^-1 R^-1
 #pragma unroll
       for (int a = 0; a < M; ++a)
 #pragma unroll
-        for (int c = 0; c < M; ++c) {
-          // (R^-1 XX R^-1)_ac = c1 u_a conj(u_c) + c0 (R^-1 R^-1)_ac
+        for (int c = a; c < M; ++c) {
           c128 r2 = cmake(0.0, 0.0);
 #pragma unroll
           for (int k = 0; k < M; ++k) cfma(r2, pt.Rinv[a][k], pt.Rinv[k][c]);
           const c128 uu = cmulc(pt.u[a], pt.u[c]);
-          mine[2 * (a * M + c)] = pt.Rinv[a][c].x;
-          mine[2 * (a * M + c) + 1] = pt.Rinv[a][c].y;
-          mine[2 * (M * M + a * M + c)] = fma(c1, uu.x, c0 * r2.x);
-          mine[2 * (M * M + a * M + c) + 1] = fma(c1, uu.y, c0 * r2.y);
+          Q[a][c] = cmake(fma(c1, uu.x, c0 * r2.x), fma(c1, uu.y, c0 * r2.y));
         }
+      pack_hermitian<M>(pt.Rinv, mine);
+      pack_hermitian<M>(Q, mine + M * M);
 #pragma unroll
-      for (int n = 0; n < GM_NMAX; ++n) mine[2 * E + n] = pt.lam[n];
+      for (int n = 0; n < GM_NMAX; ++n) mine[E + n] = pt.lam[n];
     } else {
       for (int e = 0; e < ROW; ++e) mine[e] = 0.0;
     }
@@ -282,14 +389,9 @@ __global__ __launch_bounds__(GM_PB) void k_gmnmf_spatial_acc(const c128 *__restr
       const int idx = threadIdx.x + GM_PB * s;
       if (idx < N * E) {
         const int n = idx / E, e = idx % E;
-        double re = accum[s].x, im = accum[s].y;
-        for (int p = 0; p < GM_PB; ++p) {
-          const double *row = pts + p * ROW;
-          const double l = row[2 * E + n];
-          re = fma(l, row[2 * e], re);
-          im = fma(l, row[2 * e + 1], im);
-        }
-        accum[s] = cmake(re, im);
+        double v = accum[s];
+        for (int p = 0; p < GM_PB; ++p) v = fma(pts[p * ROW + E + n], pts[p * ROW + e], v);
+        accum[s] = v;
       }
     }
     __syncthreads();
@@ -299,11 +401,7 @@ __global__ __launch_bounds__(GM_PB) void k_gmnmf_spatial_acc(const c128 *__restr
     const int idx = threadIdx.x + GM_PB * s;
     if (idx < N * E) {
       const int n = idx / E, e = idx % E;
-      const long long o = (((long long)b * N + n) * F + i) * (M * M);
-      if (e < M * M)
-        Pacc[o + e] = accum[s];
-      else
-        Qacc[o + e - M * M] = accum[s];
+      PQacc[(((long long)b * N + n) * F + i) * E + e] = accum[s];
     }
   }
 }
@@ -311,8 +409,7 @@ __global__ __launch_bounds__(GM_PB) void k_gmnmf_spatial_acc(const c128 *__restr
 // H <- to_psd(P^-1 # (H Q H)) with P, HQH floored first.  One lane per (b, n, i).
 template <int M>
 __global__ __launch_bounds__(64) void k_gmnmf_spatial_update(c128 *H,
-                                                             const c128 *__restrict__ Pacc,
-                                                             const c128 *__restrict__ Qacc,
+                                                             const double *__restrict__ PQacc,
                                                              long long count, int floor_kind,
                                                              double eps) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -322,10 +419,8 @@ __global__ __launch_bounds__(64) void k_gmnmf_spatial_update(c128 *H,
 #pragma unroll
   for (int a = 0; a < M; ++a)
 #pragma unroll
-    for (int c = 0; c < M; ++c) {
-      Hm[a][c] = H[idx * (M * M) + a * M + c];
-      Qm[a][c] = Qacc[idx * (M * M) + a * M + c];
-    }
+    for (int c = 0; c < M; ++c) Hm[a][c] = H[idx * (M * M) + a * M + c];
+  unpack_hermitian<M>(PQacc + idx * (2 * M * M) + M * M, Qm);
   // HQH, floored
   matmul<M>(Hm, Qm, Tm);
   matmul<M>(Tm, Hm, C);
@@ -333,10 +428,7 @@ __global__ __launch_bounds__(64) void k_gmnmf_spatial_update(c128 *H,
   c128 HQH[M][M];
   herm_rebuild<M>(Pv, lam, HQH);
   // P floored, P^(1/2), P^(-1/2)
-#pragma unroll
-  for (int a = 0; a < M; ++a)
-#pragma unroll
-    for (int c = 0; c < M; ++c) C[a][c] = Pacc[idx * (M * M) + a * M + c];
+  unpack_hermitian<M>(PQacc + idx * (2 * M * M), C);
   psd_eigen<M>(C, Pv, lam, floor_kind, eps);
   c128 Ph[M][M], Pih[M][M];
 #pragma unroll
@@ -398,18 +490,17 @@ __global__ __launch_bounds__(128) void k_gmnmf_loss(const c128 *__restrict__ X,
     Point<M> pt;
     point_setup<M>(pt, X + (long long)b * M * F * T, act + (long long)b * N * K * T, Hs, Ts, N, F,
                    T, K, i, j, floor_kind, eps);
-    double s = 0.0, xu = 0.0, trR = 0.0, ld = 0.0;
+    double s = 0.0, xu = 0.0, trR = 0.0;
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       s += cabs2(pt.x[m]);
       xu = fma(pt.x[m].x, pt.u[m].x, xu);
       xu = fma(pt.x[m].y, pt.u[m].y, xu);
       trR += pt.Rinv[m][m].x;
-      ld += log(pt.ev[m]);
     }
     double c1, c0;
     xx_floor_coeffs(s, floor_kind, eps, c1, c0);
-    term = fma(c1, xu, c0 * trR) + ld;
+    term = fma(c1, xu, c0 * trR) + pt.logdet;
   }
   const double total = block_sum(term, red);
   if (threadIdx.x == 0) atomicAdd(out + b, total / (double)T);
@@ -446,19 +537,19 @@ __global__ __launch_bounds__(128) void k_gmnmf_separate(const c128 *__restrict__
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct GmnmfWs {
-  size_t a, bt, pacc, qacc, total;
+  size_t a, bt, pq, vacc, total;
 };
-static inline GmnmfWs gmnmf_ws(int B, int N, int M, int F, int T) {
+static inline GmnmfWs gmnmf_ws(int B, int N, int M, int F, int T, int K) {
   GmnmfWs w;
   size_t off = 0;
   w.a = off;
   off += align256((size_t)B * N * F * T * sizeof(double));
   w.bt = off;
   off += align256((size_t)B * N * F * T * sizeof(double));
-  w.pacc = off;
+  w.pq = off;  // packed Hermitian sums of the spatial update
   off += align256((size_t)B * N * F * M * M * 2 * sizeof(double));
-  w.qacc = off;
-  off += align256((size_t)B * N * F * M * M * 2 * sizeof(double));
+  w.vacc = off;  // activation sums (num, den)
+  off += align256((size_t)B * N * 2 * K * T * sizeof(double));
   w.total = off;
   return w;
 }
@@ -500,9 +591,8 @@ using namespace ssspy;
 extern "C" {
 
 size_t ssspy_gmnmf_workspace_bytes(int B, int N, int M, int F, int T, int K) {
-  (void)K;
-  if (B <= 0 || N <= 0 || M <= 0 || F <= 0 || T <= 0) return 0;
-  return gmnmf_ws(B, N, M, F, T).total;
+  if (B <= 0 || N <= 0 || M <= 0 || F <= 0 || T <= 0 || K <= 0) return 0;
+  return gmnmf_ws(B, N, M, F, T, K).total;
 }
 
 int ssspy_gmnmf_update(const void *X, double *basis, double *activation, void *spatial, int B,
@@ -511,11 +601,11 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, void *s
   SSSPY_REQUIRE(X && basis && activation && spatial, "gmnmf_update: null argument");
   int rc = check_dims(B, N, M, F, T, K);
   if (rc) return rc;
-  const GmnmfWs w = gmnmf_ws(B, N, M, F, T);
+  const GmnmfWs w = gmnmf_ws(B, N, M, F, T, K);
   SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "gmnmf_update: workspace too small");
   char *ws = (char *)workspace;
   double *A = (double *)(ws + w.a), *Bt = (double *)(ws + w.bt);
-  c128 *Pacc = (c128 *)(ws + w.pacc), *Qacc = (c128 *)(ws + w.qacc);
+  double *PQ = (double *)(ws + w.pq), *vacc = (double *)(ws + w.vacc);
   hipStream_t st = as_stream(stream);
   if (steps & SSSPY_GMNMF_BASIS) {
     rc = launch_traces(X, basis, activation, spatial, A, Bt, B, N, M, F, T, K, floor_kind,
@@ -531,25 +621,36 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, void *s
     rc = launch_traces(X, basis, activation, spatial, A, Bt, B, N, M, F, T, K, floor_kind,
                        floor_eps, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gmnmf_activation, dim3((T + 255) / 256, (K + 7) / 8, N * B), dim3(256), 0,
-                       st, (const double *)basis, activation, (const double *)A,
-                       (const double *)Bt, N, F, T, K, floor_kind, floor_eps);
-    rc = check_launch("k_gmnmf_activation");
+    const long long count = (long long)B * N * K * T;
+    hipError_t e = hipMemsetAsync(vacc, 0, (size_t)count * 2 * sizeof(double), st);
+    if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+    const int chunks = (F + 4 * GM_ACT_BINS - 1) / (4 * GM_ACT_BINS);
+    for (int k0 = 0; k0 < K; k0 += 8) {
+      hipLaunchKernelGGL(k_gmnmf_activation_sums, dim3((T + 63) / 64, chunks, N * B), dim3(256), 0,
+                         st, (const double *)basis, (const double *)A, (const double *)Bt, vacc, N,
+                         F, T, K, k0);
+      rc = check_launch("k_gmnmf_activation_sums");
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_gmnmf_activation_apply, dim3((unsigned)((count + 255) / 256)), dim3(256),
+                       0, st, activation, (const double *)vacc, count, K, T, floor_kind,
+                       floor_eps);
+    rc = check_launch("k_gmnmf_activation_apply");
     if (rc) return rc;
   }
   if (steps & SSSPY_GMNMF_SPATIAL) {
-    const size_t smem = bin_smem(N, M, K) + (size_t)GM_PB * (4 * M * M + GM_NMAX) * sizeof(double);
+    const size_t smem = bin_smem(N, M, K) + (size_t)GM_PB * (2 * M * M + GM_NMAX) * sizeof(double);
     GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_spatial_acc<MM>), dim3(F, B), dim3(GM_PB), smem, st,
                                         (const c128 *)X, (const double *)basis,
-                                        (const double *)activation, (const c128 *)spatial, Pacc,
-                                        Qacc, N, F, T, K, floor_kind, floor_eps));
+                                        (const double *)activation, (const c128 *)spatial, PQ, N,
+                                        F, T, K, floor_kind, floor_eps));
     rc = check_launch("k_gmnmf_spatial_acc");
     if (rc) return rc;
     const long long count = (long long)B * N * F;
     GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_spatial_update<MM>),
                                         dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st,
-                                        (c128 *)spatial, (const c128 *)Pacc, (const c128 *)Qacc,
-                                        count, floor_kind, floor_eps));
+                                        (c128 *)spatial, (const double *)PQ, count, floor_kind,
+                                        floor_eps));
     rc = check_launch("k_gmnmf_spatial_update");
     if (rc) return rc;
   }

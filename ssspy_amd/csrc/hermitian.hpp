@@ -138,4 +138,64 @@ __device__ __forceinline__ void psd_eigen(c128 (&A)[M][M], c128 (&P)[M][M], doub
   for (int k = 0; k < M; ++k) lam[k] = apply_floor(A[k][k].x, floor_kind, eps);
 }
 
+// Inverse and log-determinant of a Hermitian positive definite matrix by Cholesky (A = L L^H,
+// A^-1 = L^-H L^-1).  Returns false when a pivot is not positive (A is destroyed either way).
+template <int M>
+__device__ __forceinline__ bool chol_inverse(c128 (&A)[M][M], c128 (&Inv)[M][M], double &logdet) {
+  bool ok = true;
+  double ld = 0.0;
+  // in-place lower Cholesky: A[r][c], r >= c, becomes L
+#pragma unroll
+  for (int c = 0; c < M; ++c) {
+    double d = A[c][c].x;
+#pragma unroll
+    for (int k = 0; k < c; ++k) d -= cabs2(A[c][k]);
+    ok = ok && (d > 0.0);
+    const double dd = d > 0.0 ? d : 1.0;
+    const double l = sqrt(dd), il = 1.0 / l;
+    ld += log(dd);
+    A[c][c] = cmake(l, 0.0);
+#pragma unroll
+    for (int r = c + 1; r < M; ++r) {
+      c128 s = A[r][c];
+#pragma unroll
+      for (int k = 0; k < c; ++k) cfms(s, A[r][k], cconj(A[c][k]));
+      A[r][c] = cscale(s, il);
+    }
+  }
+  logdet = ld;
+  // Linv (lower): forward substitution on the identity
+  c128 Li[M][M];
+#pragma unroll
+  for (int c = 0; c < M; ++c) {
+#pragma unroll
+    for (int r = 0; r < M; ++r) Li[r][c] = cmake(0.0, 0.0);
+    Li[c][c] = cmake(1.0 / A[c][c].x, 0.0);
+#pragma unroll
+    for (int r = c + 1; r < M; ++r) {
+      c128 s = cmake(0.0, 0.0);
+#pragma unroll
+      for (int k = c; k < r; ++k) cfms(s, A[r][k], Li[k][c]);
+      Li[r][c] = cscale(s, 1.0 / A[r][r].x);
+    }
+  }
+  // Inv = Linv^H Linv
+#pragma unroll
+  for (int a = 0; a < M; ++a)
+#pragma unroll
+    for (int b = a; b < M; ++b) {
+      c128 s = cmake(0.0, 0.0);
+#pragma unroll
+      for (int k = b; k < M; ++k) {
+        const c128 t = cmulc(Li[k][b], Li[k][a]);  // conj(Li[k][a]) Li[k][b]
+        s.x += t.x;
+        s.y += t.y;
+      }
+      if (a == b) s.y = 0.0;
+      Inv[a][b] = s;
+      Inv[b][a] = cconj(s);
+    }
+  return ok;
+}
+
 }  // namespace ssspy

@@ -526,6 +526,29 @@ def test_gauss_mnmf_steps_batch_and_oracle():
             assert rel_err(Y, Yb[b]) < 1e-11
 
 
+def test_gauss_mnmf_active_eigenvalue_floor():
+    """A large floor (0.3) makes to_psd clip eigenvalues at many points, which sends those lanes
+    down the eigen-decomposition path instead of the Cholesky shortcut."""
+    from oracle.gmnmf import GaussMNMFOracle
+    from ssspy_amd.bss.mnmf import GaussMNMF
+    from ssspy_amd.special.flooring import max_flooring
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    M, F, T, K = 3, 9, 70, 3
+    X = 0.3 * nmf_mixture(51, M, F, T)
+    basis = np.random.default_rng(12).random((M, F, K))
+    act = np.random.default_rng(13).random((M, K, T))
+    ref = GaussMNMFOracle(n_basis=K, flooring=("max", 0.3))
+    Yr = ref.run(X, n_iter=3, basis=basis, activation=act)
+    lam = np.linalg.eigvalsh(np.sum((ref.basis @ ref.activation)[:, :, :, None, None]
+                                    * ref.spatial[:, :, None], axis=0))
+    assert 0.05 < np.mean(lam < 0.3) < 0.95  # the floor is really active, and not everywhere
+    m = GaussMNMF(n_basis=K, flooring_fn=functools.partial(max_flooring, eps=0.3))
+    Y = m(X, n_iter=3, basis=basis, activation=act)
+    assert rel_err(Y, Yr) < 1e-8 and rel_err(m.spatial, ref.spatial) < 1e-8
+    np.testing.assert_allclose(m.loss, ref.loss, rtol=1e-9)
+
+
 def test_fast_gauss_mnmf_step_methods_match_fused_update():
     from ssspy_amd.bss.mnmf import FastGaussMNMF
 
