@@ -380,18 +380,24 @@ enum {
   SSSPY_GMNMF_ACTIVATION = 2,
   SSSPY_GMNMF_SPATIAL = 4,
   SSSPY_GMNMF_NORMALIZE = 8,
-  SSSPY_GMNMF_ALL = 15
+  SSSPY_GMNMF_ALL = 15,
+  SSSPY_GMNMF_LATENT = 16 /* partitioning only; runs last, as in update_once() */
 };
 
 size_t ssspy_gmnmf_workspace_bytes(int B, int N, int M, int F, int T, int K);
 
 /* The steps of update_once() selected by `steps`, in the reference's order: basis, activation,
  * spatial (H <- to_psd(P^-1 # H Q H), the matrix geometric mean of linalg/mean.py:6-83 type 2),
- * unit-trace normalisation of H with the scale moved into the basis.
- * replaces: ssspy/bss/mnmf.py:806-834, :836-901, :903-968, :970-1016, :391-414. */
-int ssspy_gmnmf_update(const void *X, double *basis, double *activation, void *spatial, int B,
-                       int N, int M, int F, int T, int K, int steps, int floor_kind,
-                       double floor_eps, void *workspace, size_t workspace_bytes, void *stream);
+ * unit-trace normalisation of H with the scale moved into the basis, latent variables.
+ * latent == NULL: basis (B,N,F,K), activation (B,N,K,T).  latent (B,N,K) given (partitioning):
+ * basis (B,F,K) and activation (B,K,T) are shared, lambda_nij = sum_k z_nk t_ik v_kj, and the
+ * normalisation leaves the basis alone.  ssspy_gmnmf_loss / _separate take the per-source pair
+ * that ssspy_ilrma_partition_expand writes.
+ * replaces: ssspy/bss/mnmf.py:806-834, :836-901, :903-968, :970-1016, :391-414, :1018-1073. */
+int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double *latent,
+                       void *spatial, int B, int N, int M, int F, int T, int K, int steps,
+                       int floor_kind, double floor_eps, void *workspace, size_t workspace_bytes,
+                       void *stream);
 
 /* out[b] = sum_i mean_j ( tr(R^-1 XX) + log det R ); `out` (B doubles) is zeroed by the call.
  * replaces: ssspy/bss/mnmf.py:765-804. */

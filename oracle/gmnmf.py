@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
 
-Restates ``GaussMNMF`` of the reference without partitioning:
+Restates ``GaussMNMF`` of the reference, with and without partitioning:
 source model ``lambda_nij = sum_k t_nik v_nkj``, spatial covariance ``H_ni`` (M x M Hermitian),
 model covariance ``R_ij = to_psd(sum_n lambda_nij H_ni)``.  All updates are the reference's MM
 rules; the matrix geometric mean is written through Hermitian square roots (the reference goes
@@ -43,7 +43,10 @@ class GaussMNMFOracle:
         record_loss=True,
         reference_id=0,
         rng=None,
+        partitioning=False,
     ):
+        # partitioning: shared basis (F, K) / activation (K, T), latent Z (N, K)
+        self.partitioning = partitioning
         self.n_basis = n_basis
         self.n_sources = n_sources
         self.flooring = flooring
@@ -53,7 +56,7 @@ class GaussMNMFOracle:
         self.rng = np.random.default_rng() if rng is None else rng
         self.loss = [] if record_loss else None
 
-    def reset(self, X, basis=None, activation=None, spatial=None):
+    def reset(self, X, basis=None, activation=None, spatial=None, latent=None):
         """ref: ssspy/bss/mnmf.py:139-165 (_reset), :167-188, :190-259, :327-353."""
         self.input = X.copy()
         M, F, T = X.shape
@@ -62,14 +65,20 @@ class GaussMNMFOracle:
         self.n_bins, self.n_frames = F, T
         XX = (X[:, None] * X[None, :].conj()).transpose(2, 3, 0, 1)  # (F, T, M, M)
         self.instant_covariance = sp.to_psd(XX, self.flooring)
+        lead = () if self.partitioning else (N,)
         if basis is None:
-            basis = sp.floor(self.rng.random((N, F, self.n_basis)), self.flooring)
+            basis = sp.floor(self.rng.random(lead + (F, self.n_basis)), self.flooring)
         else:
             basis = basis.copy()
         if activation is None:
-            activation = sp.floor(self.rng.random((N, self.n_basis, T)), self.flooring)
+            activation = sp.floor(self.rng.random(lead + (self.n_basis, T)), self.flooring)
         else:
             activation = activation.copy()
+        if self.partitioning:
+            if latent is None:
+                latent = self.rng.random((N, self.n_basis))
+                latent = sp.floor(latent / latent.sum(axis=0), self.flooring)
+            self.latent = latent.copy()
         if spatial is None:
             spatial = np.tile(np.eye(M, dtype=X.dtype) / M, (N, F, 1, 1))
         else:
@@ -79,7 +88,10 @@ class GaussMNMFOracle:
 
     # shared intermediates -----------------------------------------------------
     def _lamb(self):
-        return self.basis @ self.activation  # (N, F, T)
+        """(N, F, T).  ref: ssspy/bss/mnmf.py:264-297."""
+        if self.partitioning:
+            return np.einsum("nk,ik,kj->nij", self.latent, self.basis, self.activation)
+        return self.basis @ self.activation
 
     def _model_covariance(self, Lamb):
         """R_ij = to_psd(sum_n lambda_nij H_ni) -> (F, T, M, M).  ref: mnmf.py:355-389, :878-879."""
@@ -100,16 +112,24 @@ class GaussMNMFOracle:
         """ref: ssspy/bss/mnmf.py:836-901."""
         a, b = self._traces()
         V = self.activation
-        num = np.sum(V[:, None, :, :] * a[:, :, None, :], axis=-1)
-        den = np.sum(V[:, None, :, :] * b[:, :, None, :], axis=-1)
+        if self.partitioning:
+            num = np.einsum("nk,kj,nij->ik", self.latent, V, a)
+            den = np.einsum("nk,kj,nij->ik", self.latent, V, b)
+        else:
+            num = np.sum(V[:, None, :, :] * a[:, :, None, :], axis=-1)
+            den = np.sum(V[:, None, :, :] * b[:, :, None, :], axis=-1)
         self.basis = sp.floor(self.basis * np.sqrt(num / den), self.flooring)
 
     def update_activation(self):
         """ref: ssspy/bss/mnmf.py:903-968."""
         a, b = self._traces()
         T = self.basis
-        num = np.sum(T[:, :, :, None] * a[:, :, None, :], axis=1)
-        den = np.sum(T[:, :, :, None] * b[:, :, None, :], axis=1)
+        if self.partitioning:
+            num = np.einsum("nk,ik,nij->kj", self.latent, T, a)
+            den = np.einsum("nk,ik,nij->kj", self.latent, T, b)
+        else:
+            num = np.sum(T[:, :, :, None] * a[:, :, None, :], axis=1)
+            den = np.sum(T[:, :, :, None] * b[:, :, None, :], axis=1)
         self.activation = sp.floor(self.activation * np.sqrt(num / den), self.flooring)
 
     def update_spatial(self):
@@ -129,7 +149,19 @@ class GaussMNMFOracle:
         """Unit trace of H, scale moved into the basis.  ref: ssspy/bss/mnmf.py:391-414."""
         trace = np.real(np.trace(self.spatial, axis1=-2, axis2=-1))  # (N, F)
         self.spatial = self.spatial / trace[..., None, None]
-        self.basis = trace[:, :, None] * self.basis
+        if not self.partitioning:  # with partitioning the scale cannot move into the shared basis
+            self.basis = trace[:, :, None] * self.basis
+
+    def update_latent(self):
+        """z_nk <- z_nk sqrt(sum_ij t v a / sum_ij t v b), columns renormalised.
+
+        ref: ssspy/bss/mnmf.py:1018-1073.
+        """
+        a, b = self._traces()
+        num = np.einsum("ik,kj,nij->nk", self.basis, self.activation, a)
+        den = np.einsum("ik,kj,nij->nk", self.basis, self.activation, b)
+        Z = self.latent * np.sqrt(num / den)
+        self.latent = Z / Z.sum(axis=0)
 
     def update_once(self):
         """ref: ssspy/bss/mnmf.py:806-834."""
@@ -138,6 +170,8 @@ class GaussMNMFOracle:
         self.update_spatial()
         if self.normalization:
             self.normalize()
+        if self.partitioning:
+            self.update_latent()
 
     def compute_loss(self):
         """ref: ssspy/bss/mnmf.py:765-804."""

@@ -72,7 +72,7 @@ PROTOTYPES = {
     "ssspy_iva_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _d, _p]),
     "ssspy_iva_loss_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ssspy_gmnmf_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
-    "ssspy_gmnmf_update": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p, _z, _p]),
+    "ssspy_gmnmf_update": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p, _z, _p]),
     "ssspy_gmnmf_loss": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _d, _p]),
     "ssspy_gmnmf_separate": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p]),
     "ssspy_fastmnmf_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
@@ -84,6 +84,7 @@ PROTOTYPES = {
                                      _z, _p, _p]),
 }
 GMNMF_BASIS, GMNMF_ACTIVATION, GMNMF_SPATIAL, GMNMF_NORMALIZE, GMNMF_ALL = 1, 2, 4, 8, 15
+GMNMF_LATENT = 16
 MNMF_BASIS, MNMF_ACTIVATION, MNMF_DIAGONALIZER, MNMF_SPATIAL, MNMF_NORMALIZE, MNMF_ALL = 1, 2, 4, 8, 16, 31
 
 _lib = None

@@ -430,12 +430,13 @@ def gmnmf_workspace(B, N, M, F, T, K, dev):
     return dv.empty(((nbytes + 7) // 8,), dv.f64, dev), nbytes
 
 
-def gmnmf_update(X, basis, activation, spatial, steps, flooring, ws, ws_bytes):
+def gmnmf_update(X, basis, activation, spatial, steps, flooring, ws, ws_bytes, latent=None):
     B, M, F, T = X.shape
-    N, K = basis.shape[1], basis.shape[-1]
+    N, K = spatial.shape[1], basis.shape[-1]
     _lib.check(
-        _L().ssspy_gmnmf_update(ptr(X), ptr(basis), ptr(activation), ptr(spatial), B, N, M, F, T,
-                                K, steps, flooring[0], flooring[1], ptr(ws), ws_bytes, _st()),
+        _L().ssspy_gmnmf_update(ptr(X), ptr(basis), ptr(activation), ptr(latent), ptr(spatial), B,
+                                N, M, F, T, K, steps, flooring[0], flooring[1], ptr(ws), ws_bytes,
+                                _st()),
         "gmnmf_update",
     )
 

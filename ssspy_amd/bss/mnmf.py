@@ -8,7 +8,7 @@ n_channels), diagonal spatial ``D`` (n_bins, n_sources, n_channels), NMF ``basis
 normalisation; output by the multichannel Wiener filter.  ``diagonalizer_algorithm`` may be "IP" /
 "IP1" or "IP2" (pairwise).  ``GaussMNMF`` (ssspy/bss/mnmf.py:681-1073) is the full-rank model:
 ``spatial`` (n_sources, n_bins, M, M) Hermitian PSD, updated by a matrix geometric mean.
-``partitioning`` is not built yet (NotImplementedError).
+``GaussMNMF(partitioning=True)`` keeps a shared basis / activation and latent variables.
 
 ``instant_covariance`` (the (n_bins, n_frames, M, M) PSD-projected outer products the reference
 materialises at reset, mnmf.py:167-188) is never read by FastGaussMNMF's updates and is not
@@ -40,6 +40,7 @@ class MNMFBase(DeviceStateMixin, IterativeMethodBase):
     output = Synced(dv.c128)
     basis = Synced(dv.f64)
     activation = Synced(dv.f64)
+    latent = Synced(dv.f64)
 
     def __init__(
         self,
@@ -76,27 +77,44 @@ class MNMFBase(DeviceStateMixin, IterativeMethodBase):
         return self.output
 
     def _init_nmf(self, flooring_fn="self", rng=None) -> None:
-        """ref: ssspy/bss/mnmf.py:190-259 (no partitioning)."""
+        """ref: ssspy/bss/mnmf.py:190-259."""
         flooring_fn = choose_flooring_fn(flooring_fn, method=self)
         if rng is None:
             rng = np.random.default_rng()
         N, F, T, K = self.n_sources, self.n_bins, self.n_frames, self.n_basis
-        if self.partitioning:
-            raise NotImplementedError("partitioning=True is not built for the device path yet.")
+        src = () if self.partitioning else (N,)
         if not self._state_has("basis"):
-            self.basis = flooring_fn(rng.random(self._lead() + (N, F, K)))
+            self.basis = flooring_fn(rng.random(self._lead() + src + (F, K)))
         else:
             self.basis = np.array(self.basis, dtype=np.float64, copy=True)
         if not self._state_has("activation"):
-            self.activation = flooring_fn(rng.random(self._lead() + (N, K, T)))
+            self.activation = flooring_fn(rng.random(self._lead() + src + (K, T)))
         else:
             self.activation = np.array(self.activation, dtype=np.float64, copy=True)
+        if self.partitioning:
+            if not self._state_has("latent"):
+                Z = rng.random(self._lead() + (N, K))
+                self.latent = flooring_fn(Z / Z.sum(axis=-2, keepdims=True))
+            else:
+                self.latent = np.array(self.latent, dtype=np.float64, copy=True)
+            B = self._X.shape[0]
+            self._Teff = dv.empty((B, N, F, K), dv.f64, self._X.device)
+            self._Vrep = dv.empty((B, N, K, T), dv.f64, self._X.device)
 
     def reconstruct_nmf(self, basis, activation, latent=None) -> np.ndarray:
         """Lambda = T V (ref: ssspy/bss/mnmf.py:264-297); host-side convenience."""
         if latent is not None:
-            raise NotImplementedError("partitioning (latent) is not built for the device path yet.")
+            return np.einsum("...nk,...ik,...kj->...nij", latent, basis, activation)
         return basis @ activation
+
+    def _nmf_pair(self):
+        """Device (basis, activation) in the per-source layout the kernels take (the expansion
+        (z_nk t_ik, v_kj) with partitioning)."""
+        if not self.partitioning:
+            return self._state_dev("basis"), self._state_dev("activation")
+        _ops.ilrma_partition_expand(self._state_dev("basis"), self._state_dev("activation"),
+                                    self._state_dev("latent"), self._Teff, self._Vrep)
+        return self._Teff, self._Vrep
 
 
 class FastMNMFBase(MNMFBase):
@@ -406,8 +424,6 @@ class GaussMNMF(MNMF):
             reference_id=reference_id,
             rng=rng,
         )
-        if partitioning:
-            raise NotImplementedError("partitioning=True is not built for the device path yet.")
         device_flooring(self.flooring_fn)
 
     def __repr__(self) -> str:
@@ -427,31 +443,31 @@ class GaussMNMF(MNMF):
         return device_flooring(choose_flooring_fn(flooring_fn, method=self))
 
     def _update(self, steps, flooring_fn="self") -> None:
+        latent = self._state_dev("latent") if self.partitioning else None
         _ops.gmnmf_update(self._X, self._state_dev("basis"), self._state_dev("activation"),
                           self._state_dev("spatial"), steps, self._resolve_floor(flooring_fn),
-                          self._ws, self._ws_bytes)
-        for name in ("basis", "activation", "spatial"):
+                          self._ws, self._ws_bytes, latent=latent)
+        for name in ("basis", "activation", "spatial") + (("latent",) if self.partitioning else ()):
             self._state_touch(name)
 
     def _separate_dev(self) -> None:
-        Y = _ops.gmnmf_separate(self._X, self._state_dev("basis"), self._state_dev("activation"),
-                                self._state_dev("spatial"), self.reference_id, self._floor)
+        Y = _ops.gmnmf_separate(self._X, *self._nmf_pair(), self._state_dev("spatial"),
+                                self.reference_id, self._floor)
         self._state_set_dev("output", Y)
 
     def separate(self, input: np.ndarray) -> np.ndarray:
         """Multichannel Wiener filter with the current parameters (ref: mnmf.py:729-763)."""
         batched = input.ndim == 4
         X = dv.to_device(input if batched else input[None], dtype=np.complex128)
-        Y = _ops.gmnmf_separate(X, self._state_dev("basis"), self._state_dev("activation"),
-                                self._state_dev("spatial"), self.reference_id, self._floor)
+        Y = _ops.gmnmf_separate(X, *self._nmf_pair(), self._state_dev("spatial"),
+                                self.reference_id, self._floor)
         self._check_device_errors()
         out = dv.to_host(Y)
         return out if batched else out[0]
 
     def compute_loss(self) -> float:
         """mean_j [tr(R^-1 XX) + log det R] summed over bins (ref: ssspy/bss/mnmf.py:765-804)."""
-        data = _ops.gmnmf_loss(self._X, self._state_dev("basis"), self._state_dev("activation"),
-                               self._state_dev("spatial"), self._floor)
+        data = _ops.gmnmf_loss(self._X, *self._nmf_pair(), self._state_dev("spatial"), self._floor)
         self._check_device_errors()
         values = dv.to_host(data)
         return values.copy() if self._batched else values[0].item()
@@ -466,10 +482,13 @@ class GaussMNMF(MNMF):
         cls = type(self)
         stock = all(
             getattr(cls, name) is getattr(GaussMNMF, name)
-            for name in ("update_basis", "update_activation", "update_spatial", "normalize")
+            for name in ("update_basis", "update_activation", "update_spatial", "normalize",
+                         "update_latent")
         )
         if stock:
             steps = _lib.GMNMF_ALL if self.normalization else _lib.GMNMF_ALL & ~_lib.GMNMF_NORMALIZE
+            if self.partitioning:
+                steps |= _lib.GMNMF_LATENT
             self._update(steps, flooring_fn)
             return
         self.update_basis(flooring_fn=flooring_fn)
@@ -477,6 +496,8 @@ class GaussMNMF(MNMF):
         self.update_spatial(flooring_fn=flooring_fn)
         if self.normalization:
             self.normalize(axis1=-2, axis2=-1)
+        if self.partitioning:
+            self.update_latent(flooring_fn=flooring_fn)
 
     def update_basis(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/mnmf.py:836-901."""
@@ -489,3 +510,8 @@ class GaussMNMF(MNMF):
     def update_spatial(self, flooring_fn="self") -> None:
         """H <- to_psd(P^-1 # H Q H) (ref: ssspy/bss/mnmf.py:970-1016)."""
         self._update(_lib.GMNMF_SPATIAL, flooring_fn)
+
+    def update_latent(self, flooring_fn="self") -> None:
+        """z_nk <- z_nk sqrt(num / den), columns renormalised (ref: ssspy/bss/mnmf.py:1018-1073)."""
+        assert self.partitioning, "update_latent needs partitioning=True."
+        self._update(_lib.GMNMF_LATENT, flooring_fn)

@@ -208,10 +208,12 @@ __global__ __launch_bounds__(128) void k_gmnmf_traces(const c128 *__restrict__ X
 
 // basis[b,n,i,k] <- floor(basis * sqrt(sum_j V A / sum_j V Bt)).  grid: (F, N, B), 256 threads;
 // wave w takes k = w, w+4, ...
+// raw != NULL (partitioning): the (num, den) pairs go to raw[b,n,i,k,2] instead
 __global__ __launch_bounds__(256) void k_gmnmf_basis(double *basis, const double *__restrict__ act,
                                                      const double *__restrict__ A,
                                                      const double *__restrict__ Bt, int N, int F,
-                                                     int T, int K, int floor_kind, double eps) {
+                                                     int T, int K, int floor_kind, double eps,
+                                                     double *raw) {
   const int i = blockIdx.x, n = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long row = (((long long)b * N + n) * F + i) * T;
@@ -226,9 +228,95 @@ __global__ __launch_bounds__(256) void k_gmnmf_basis(double *basis, const double
     sn = wave_sum(sn);
     sd = wave_sum(sd);
     if (lane == 0) {
-      double *dst = basis + (((long long)b * N + n) * F + i) * K + k;
-      *dst = apply_floor(*dst * sqrt(sn / sd), floor_kind, eps);
+      const long long o = (((long long)b * N + n) * F + i) * K + k;
+      if (raw) {
+        raw[2 * o] = sn;
+        raw[2 * o + 1] = sd;
+      } else {
+        basis[o] = apply_floor(basis[o] * sqrt(sn / sd), floor_kind, eps);
+      }
     }
+  }
+}
+
+// ---- partitioning (latent variables Z): shared t (B,F,K), v (B,K,T); the kernels above run on the
+// expansion Teff = z t, Vrep = v and these recombine their per-source sums.
+// ref: ssspy/bss/mnmf.py:836-901, :903-968, :1018-1073 (partitioning branches).
+__global__ __launch_bounds__(256) void k_gm_expand(const double *__restrict__ basis,
+                                                   const double *__restrict__ act,
+                                                   const double *__restrict__ latent,
+                                                   double *__restrict__ Teff,
+                                                   double *__restrict__ Vrep, int N, int F, int T,
+                                                   int K) {
+  const int n = blockIdx.y, b = blockIdx.z;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const double *z = latent + ((long long)b * N + n) * K;
+  if (e < (long long)F * K)
+    Teff[((long long)b * N + n) * F * K + e] = z[e % K] * basis[(long long)b * F * K + e];
+  if (e < (long long)K * T) Vrep[((long long)b * N + n) * K * T + e] = act[(long long)b * K * T + e];
+}
+
+// t_ik <- floor(t_ik sqrt(sum_n z_nk S_nik / sum_n z_nk D_nik)).  one thread per (b, i, k)
+__global__ __launch_bounds__(256) void k_gm_part_basis(const double *__restrict__ raw,
+                                                       const double *__restrict__ latent,
+                                                       double *basis, int N, int F, int K,
+                                                       int floor_kind, double eps) {
+  const int b = blockIdx.y;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)F * K) return;
+  const int k = (int)(e % K);
+  double sn = 0.0, sd = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const double z = latent[((long long)b * N + n) * K + k];
+    const double *r = raw + (((long long)b * N + n) * F * K + e) * 2;
+    sn = fma(z, r[0], sn);
+    sd = fma(z, r[1], sd);
+  }
+  double *dst = basis + (long long)b * F * K + e;
+  *dst = apply_floor(*dst * sqrt(sn / sd), floor_kind, eps);
+}
+
+// v_kj <- floor(v_kj sqrt(sum_n num_nkj / sum_n den_nkj)); the sums were taken with Teff and
+// carry z_nk already.  acc: [b][n][2][K][T].  one thread per (b, k, j)
+__global__ __launch_bounds__(256) void k_gm_part_activation(const double *__restrict__ acc,
+                                                            double *act, int N, int K, int T,
+                                                            int floor_kind, double eps) {
+  const int b = blockIdx.y;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)K * T) return;
+  const long long kt = (long long)K * T;
+  double sn = 0.0, sd = 0.0;
+  for (int n = 0; n < N; ++n) {
+    sn += acc[(((long long)b * N + n) * 2) * kt + e];
+    sd += acc[(((long long)b * N + n) * 2 + 1) * kt + e];
+  }
+  double *dst = act + (long long)b * kt + e;
+  *dst = apply_floor(*dst * sqrt(sn / sd), floor_kind, eps);
+}
+
+// z_nk <- z_nk sqrt(sum_i t_ik S_nik / sum_i t_ik D_nik), columns renormalised.  grid: (B)
+__global__ __launch_bounds__(256) void k_gm_part_latent(const double *__restrict__ raw,
+                                                        const double *__restrict__ basis,
+                                                        double *latent, int N, int F, int K) {
+  __shared__ double znew[SSSPY_MAX_SOURCES * SSSPY_MAX_BASIS];
+  const int b = blockIdx.x;
+  for (int e = threadIdx.x; e < N * K; e += blockDim.x) {
+    const int n = e / K, k = e % K;
+    double sn = 0.0, sd = 0.0;
+    for (int i = 0; i < F; ++i) {
+      const double t = basis[((long long)b * F + i) * K + k];
+      const double *r = raw + ((((long long)b * N + n) * F + i) * K + k) * 2;
+      sn = fma(t, r[0], sn);
+      sd = fma(t, r[1], sd);
+    }
+    znew[e] = latent[((long long)b * N + n) * K + k] * sqrt(sn / sd);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < N * K; e += blockDim.x) {
+    const int k = e % K;
+    double col = 0.0;
+    for (int n = 0; n < N; ++n) col += znew[n * K + k];
+    latent[(long long)b * N * K + e] = znew[e] / col;
   }
 }
 
@@ -466,7 +554,8 @@ __global__ __launch_bounds__(64) void k_gmnmf_normalize(c128 *H, double *basis, 
   double tr = 0.0;
   for (int a = 0; a < M; ++a) tr += h[a * M + a].x;
   for (int e = 0; e < M * M; ++e) h[e] = cmake(h[e].x / tr, h[e].y / tr);
-  for (int k = 0; k < K; ++k) basis[idx * K + k] *= tr;
+  if (basis)  // with partitioning the scale cannot move into the shared basis (mnmf.py:404-413)
+    for (int k = 0; k < K; ++k) basis[idx * K + k] *= tr;
 }
 
 // ------------------------------------------------------------------------------------- loss
@@ -537,7 +626,7 @@ __global__ __launch_bounds__(128) void k_gmnmf_separate(const c128 *__restrict__
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct GmnmfWs {
-  size_t a, bt, pq, vacc, total;
+  size_t a, bt, pq, vacc, teff, vrep, raw, total;
 };
 static inline GmnmfWs gmnmf_ws(int B, int N, int M, int F, int T, int K) {
   GmnmfWs w;
@@ -550,6 +639,12 @@ static inline GmnmfWs gmnmf_ws(int B, int N, int M, int F, int T, int K) {
   off += align256((size_t)B * N * F * M * M * 2 * sizeof(double));
   w.vacc = off;  // activation sums (num, den)
   off += align256((size_t)B * N * 2 * K * T * sizeof(double));
+  w.teff = off;  // partitioning: expanded pair and the (num, den) basis sums
+  off += align256((size_t)B * N * F * K * sizeof(double));
+  w.vrep = off;
+  off += align256((size_t)B * N * K * T * sizeof(double));
+  w.raw = off;
+  off += align256((size_t)B * N * F * K * 2 * sizeof(double));
   w.total = off;
   return w;
 }
@@ -595,10 +690,12 @@ size_t ssspy_gmnmf_workspace_bytes(int B, int N, int M, int F, int T, int K) {
   return gmnmf_ws(B, N, M, F, T, K).total;
 }
 
-int ssspy_gmnmf_update(const void *X, double *basis, double *activation, void *spatial, int B,
-                       int N, int M, int F, int T, int K, int steps, int floor_kind,
-                       double floor_eps, void *workspace, size_t workspace_bytes, void *stream) {
+int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double *latent,
+                       void *spatial, int B, int N, int M, int F, int T, int K, int steps,
+                       int floor_kind, double floor_eps, void *workspace, size_t workspace_bytes,
+                       void *stream) {
   SSSPY_REQUIRE(X && basis && activation && spatial, "gmnmf_update: null argument");
+  SSSPY_REQUIRE(latent || !(steps & SSSPY_GMNMF_LATENT), "gmnmf_update: latent step without latent");
   int rc = check_dims(B, N, M, F, T, K);
   if (rc) return rc;
   const GmnmfWs w = gmnmf_ws(B, N, M, F, T, K);
@@ -606,20 +703,47 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, void *s
   char *ws = (char *)workspace;
   double *A = (double *)(ws + w.a), *Bt = (double *)(ws + w.bt);
   double *PQ = (double *)(ws + w.pq), *vacc = (double *)(ws + w.vacc);
+  double *Teff = (double *)(ws + w.teff), *Vrep = (double *)(ws + w.vrep);
+  double *raw = (double *)(ws + w.raw);
   hipStream_t st = as_stream(stream);
+  const bool part = latent != nullptr;
+  // the per-source (basis, activation) pair every kernel takes: the state itself, or the expansion
+  const double *Tn = basis, *Vn = activation;
+  auto refresh = [&]() -> int {
+    if (!part) return SSSPY_OK;
+    const long long per = (long long)K * (F > T ? F : T);
+    hipLaunchKernelGGL(k_gm_expand, dim3((unsigned)((per + 255) / 256), N, B), dim3(256), 0, st,
+                       (const double *)basis, (const double *)activation, (const double *)latent,
+                       Teff, Vrep, N, F, T, K);
+    Tn = Teff;
+    Vn = Vrep;
+    return check_launch("k_gm_expand");
+  };
+  auto basis_sums = [&](double *raw_out) -> int {
+    int r = refresh();
+    if (r) return r;
+    r = launch_traces(X, Tn, Vn, spatial, A, Bt, B, N, M, F, T, K, floor_kind, floor_eps, st);
+    if (r) return r;
+    hipLaunchKernelGGL(k_gmnmf_basis, dim3(F, N, B), dim3(256), 0, st, basis, Vn,
+                       (const double *)A, (const double *)Bt, N, F, T, K, floor_kind, floor_eps,
+                       raw_out);
+    return check_launch("k_gmnmf_basis");
+  };
   if (steps & SSSPY_GMNMF_BASIS) {
-    rc = launch_traces(X, basis, activation, spatial, A, Bt, B, N, M, F, T, K, floor_kind,
-                       floor_eps, st);
+    rc = basis_sums(part ? raw : nullptr);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gmnmf_basis, dim3(F, N, B), dim3(256), 0, st, basis,
-                       (const double *)activation, (const double *)A, (const double *)Bt, N, F, T,
-                       K, floor_kind, floor_eps);
-    rc = check_launch("k_gmnmf_basis");
-    if (rc) return rc;
+    if (part) {
+      hipLaunchKernelGGL(k_gm_part_basis, dim3((unsigned)(((long long)F * K + 255) / 256), B),
+                         dim3(256), 0, st, (const double *)raw, (const double *)latent, basis, N,
+                         F, K, floor_kind, floor_eps);
+      rc = check_launch("k_gm_part_basis");
+      if (rc) return rc;
+    }
   }
   if (steps & SSSPY_GMNMF_ACTIVATION) {
-    rc = launch_traces(X, basis, activation, spatial, A, Bt, B, N, M, F, T, K, floor_kind,
-                       floor_eps, st);
+    rc = refresh();
+    if (rc) return rc;
+    rc = launch_traces(X, Tn, Vn, spatial, A, Bt, B, N, M, F, T, K, floor_kind, floor_eps, st);
     if (rc) return rc;
     const long long count = (long long)B * N * K * T;
     hipError_t e = hipMemsetAsync(vacc, 0, (size_t)count * 2 * sizeof(double), st);
@@ -627,23 +751,30 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, void *s
     const int chunks = (F + 4 * GM_ACT_BINS - 1) / (4 * GM_ACT_BINS);
     for (int k0 = 0; k0 < K; k0 += 8) {
       hipLaunchKernelGGL(k_gmnmf_activation_sums, dim3((T + 63) / 64, chunks, N * B), dim3(256), 0,
-                         st, (const double *)basis, (const double *)A, (const double *)Bt, vacc, N,
-                         F, T, K, k0);
+                         st, Tn, (const double *)A, (const double *)Bt, vacc, N, F, T, K, k0);
       rc = check_launch("k_gmnmf_activation_sums");
       if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_gmnmf_activation_apply, dim3((unsigned)((count + 255) / 256)), dim3(256),
-                       0, st, activation, (const double *)vacc, count, K, T, floor_kind,
-                       floor_eps);
-    rc = check_launch("k_gmnmf_activation_apply");
+    if (part) {
+      hipLaunchKernelGGL(k_gm_part_activation, dim3((unsigned)(((long long)K * T + 255) / 256), B),
+                         dim3(256), 0, st, (const double *)vacc, activation, N, K, T, floor_kind,
+                         floor_eps);
+      rc = check_launch("k_gm_part_activation");
+    } else {
+      hipLaunchKernelGGL(k_gmnmf_activation_apply, dim3((unsigned)((count + 255) / 256)),
+                         dim3(256), 0, st, activation, (const double *)vacc, count, K, T,
+                         floor_kind, floor_eps);
+      rc = check_launch("k_gmnmf_activation_apply");
+    }
     if (rc) return rc;
   }
   if (steps & SSSPY_GMNMF_SPATIAL) {
+    rc = refresh();
+    if (rc) return rc;
     const size_t smem = bin_smem(N, M, K) + (size_t)GM_PB * (2 * M * M + GM_NMAX) * sizeof(double);
     GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_spatial_acc<MM>), dim3(F, B), dim3(GM_PB), smem, st,
-                                        (const c128 *)X, (const double *)basis,
-                                        (const double *)activation, (const c128 *)spatial, PQ, N,
-                                        F, T, K, floor_kind, floor_eps));
+                                        (const c128 *)X, Tn, Vn, (const c128 *)spatial, PQ, N, F,
+                                        T, K, floor_kind, floor_eps));
     rc = check_launch("k_gmnmf_spatial_acc");
     if (rc) return rc;
     const long long count = (long long)B * N * F;
@@ -657,8 +788,16 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, void *s
   if (steps & SSSPY_GMNMF_NORMALIZE) {
     const long long count = (long long)B * N * F;
     hipLaunchKernelGGL(k_gmnmf_normalize, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st,
-                       (c128 *)spatial, basis, count, M, K);
+                       (c128 *)spatial, part ? (double *)nullptr : basis, count, M, K);
     rc = check_launch("k_gmnmf_normalize");
+    if (rc) return rc;
+  }
+  if (steps & SSSPY_GMNMF_LATENT) {
+    rc = basis_sums(raw);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gm_part_latent, dim3(B), dim3(256), 0, st, (const double *)raw,
+                       (const double *)basis, latent, N, F, K);
+    rc = check_launch("k_gm_part_latent");
     if (rc) return rc;
   }
   return SSSPY_OK;

@@ -201,26 +201,35 @@ def random_psd(seed, N, F, M):
 
 
 def run_gmnmf(name, *, M, F, T, K, seed, n_sources=None, gen=gen_iid, flooring=("max", 1e-10),
-              normalization=True, n_iter=10, spatial_init=False):
+              normalization=True, n_iter=10, spatial_init=False, partitioning=False):
     if skipped(name):
         return
     N = M if n_sources is None else n_sources
     X = gen(seed, M, F, T)
-    basis = np.random.default_rng(seed + 1).random((N, F, K))
-    activation = np.random.default_rng(seed + 2).random((N, K, T))
+    lead = () if partitioning else (N,)
+    basis = np.random.default_rng(seed + 1).random(lead + (F, K))
+    activation = np.random.default_rng(seed + 2).random(lead + (K, T))
     init = dict(basis=basis, activation=activation)
+    if partitioning:
+        latent = np.random.default_rng(seed + 5).random((N, K))
+        init["latent"] = latent / latent.sum(axis=0)
     if spatial_init:
         init["spatial"] = random_psd(seed + 4, N, F, M)
-    snap = Snapshots(["spatial", "basis", "activation"])
-    m = GaussMNMF(n_basis=K, n_sources=n_sources, flooring_fn=flooring_of(flooring),
+    snap = Snapshots(["spatial", "basis", "activation", "latent"])
+    m = GaussMNMF(n_basis=K, n_sources=n_sources, partitioning=partitioning,
+                  flooring_fn=flooring_of(flooring),
                   callbacks=snap, normalization=normalization, rng=np.random.default_rng(seed + 3))
     Y = m(X, n_iter=n_iter, **{k: v.copy() for k, v in init.items()})
     out = dict(X=X, basis0=basis, activation0=activation, loss=np.array(m.loss), final_output=Y,
                final_basis=m.basis, final_activation=m.activation, final_spatial=m.spatial)
     if spatial_init:
         out["spatial0"] = init["spatial"]
+    if partitioning:
+        out["latent0"] = init["latent"]
+        out["final_latent"] = m.latent
     out.update(snap.store)
     out.update(meta(kind="gauss_mnmf", n_basis=K, n_sources=N, n_iter=n_iter,
+                    partitioning=partitioning,
                     floor_kind=flooring[0], floor_eps=flooring[1], normalization=normalization))
     save(name, **out)
 
@@ -364,6 +373,9 @@ def main():
     run_gmnmf("gmnmf_m4_n3", M=4, F=9, T=22, K=4, seed=82, n_sources=3, spatial_init=True)
     run_gmnmf("gmnmf_m2_nonorm_add", M=2, F=10, T=18, K=2, seed=83, normalization=False,
               flooring=("add", 1e-6))
+    run_gmnmf("gmnmf_part_m3", M=3, F=10, T=24, K=5, seed=84, gen=gen_mixture, spatial_init=True,
+              partitioning=True)
+    run_gmnmf("gmnmf_part_m2_n3", M=2, F=11, T=20, K=4, seed=85, n_sources=3, partitioning=True)
     # --- IPA (iterative projection with adjustment, LQPQM solver) ---
     run_ipa_operators()
     run_ilrma("gilrma_ipa_n3", N=3, F=18, T=40, K=4, algo="IPA", seed=100, gen=gen_mixture)

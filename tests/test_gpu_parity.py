@@ -465,7 +465,8 @@ def test_fast_gauss_mnmf_against_golden(case):
     assert rel_err(Y, g["final_output"]) < 1e-7  # Wiener filter: eigh + solve, cond(R)-amplified
 
 
-GMNMF_CASES = ["gmnmf_m2", "gmnmf_m3", "gmnmf_m4_n3", "gmnmf_m2_nonorm_add"]
+GMNMF_CASES = ["gmnmf_m2", "gmnmf_m3", "gmnmf_m4_n3", "gmnmf_m2_nonorm_add", "gmnmf_part_m3",
+               "gmnmf_part_m2_n3"]
 
 
 @pytest.mark.parametrize("case", GMNMF_CASES)
@@ -476,17 +477,22 @@ def test_gauss_mnmf_against_golden(case):
     from ssspy_amd.bss.mnmf import GaussMNMF
 
     g = load_golden(case)
-    snap = Snap(["spatial", "basis", "activation"])
+    snap = Snap(["spatial", "basis", "activation", "latent"])
+    part = bool(g["meta_partitioning"]) if "meta_partitioning" in g else False
     m = GaussMNMF(n_basis=int(g["meta_n_basis"]), n_sources=int(g["meta_n_sources"]),
-                  flooring_fn=_flooring_fn(g), callbacks=snap,
+                  partitioning=part, flooring_fn=_flooring_fn(g), callbacks=snap,
                   normalization=_option(g["meta_normalization"]))
     init = dict(basis=g["basis0"], activation=g["activation0"])
     if "spatial0" in g:
         init["spatial"] = g["spatial0"].copy()
+    if part:
+        init["latent"] = g["latent0"].copy()
     Y = m(g["X"], n_iter=int(g["meta_n_iter"]), **init)
     for key, value in snap.store.items():
         assert rel_err(value, g[key]) < 1e-7, key
-    assert len(snap.store) == 9
+    assert len(snap.store) == (12 if part else 9)
+    if part:
+        assert rel_err(m.latent, g["final_latent"]) < 1e-7
     np.testing.assert_allclose(m.loss, g["loss"], rtol=1e-8)
     assert all(type(v) is float for v in m.loss)
     assert rel_err(m.spatial, g["final_spatial"]) < 1e-7

@@ -158,7 +158,8 @@ def test_fast_gauss_mnmf(case):
     assert rel_err(Y, g["final_output"]) < 1e-9
 
 
-GMNMF_CASES = ["gmnmf_m2", "gmnmf_m3", "gmnmf_m4_n3", "gmnmf_m2_nonorm_add"]
+GMNMF_CASES = ["gmnmf_m2", "gmnmf_m3", "gmnmf_m4_n3", "gmnmf_m2_nonorm_add", "gmnmf_part_m3",
+               "gmnmf_part_m2_n3"]
 
 
 @pytest.mark.parametrize("case", GMNMF_CASES)
@@ -169,16 +170,19 @@ def test_gauss_mnmf(case):
     m = GaussMNMFOracle(
         n_basis=int(g["meta_n_basis"]), n_sources=int(g["meta_n_sources"]), flooring=_floor(g),
         normalization=_option(g["meta_normalization"]),
+        partitioning=bool(g["meta_partitioning"]) if "meta_partitioning" in g else False,
     )
     init = dict(basis=g["basis0"], activation=g["activation0"])
     if "spatial0" in g:
         init["spatial"] = g["spatial0"]
+    if m.partitioning:
+        init["latent"] = g["latent0"]
     m.reset(g["X"], **init)
     losses = [m.compute_loss()]
     for k in range(1, int(g["meta_n_iter"]) + 1):
         m.update_once()
         losses.append(m.compute_loss())
-        for name in ("spatial", "basis", "activation"):
+        for name in ("spatial", "basis", "activation", "latent"):
             key = "it{}_{}".format(k, name)
             if key in g:
                 assert rel_err(getattr(m, name), g[key]) < 1e-8, key
