@@ -411,6 +411,23 @@ int ssspy_gmnmf_separate(const void *X, const double *basis, const double *activ
                          const void *spatial, void *Y, int B, int N, int M, int F, int T, int K,
                          int reference_id, int floor_kind, double floor_eps, void *stream);
 
+/* ------------------------------------------------------------------ STFT / ISTFT
+ * The transforms the reference's workflow takes from SciPy either side of a separator
+ * (tests/package/bss/test_ilrma.py, test_iva.py, test_mnmf.py: scipy.signal.stft(x, window="hann",
+ * nperseg=n_fft, noverlap=n_fft - hop) and scipy.signal.istft), with SciPy's defaults:
+ * boundary="zeros", padded=True, one-sided, scaling="spectrum".  n_fft a power of two <= 4096.
+ * x (B, C, n_samples) f64 -> Z (B, C, n_fft/2+1, ssspy_stft_frames(...)) c128; `window` (n_fft) f64
+ * on the device, `window_sum` its sum. */
+int ssspy_stft_frames(long long n_samples, int n_fft, int hop);
+int ssspy_stft(const double *x, void *Z, const double *window, double window_sum, int B, int C,
+               long long n_samples, int n_fft, int hop, void *stream);
+
+/* Z (B, C, n_fft/2+1, n_frames) -> x (B, C, ssspy_istft_samples(...)); `segments` is scratch of
+ * B*C*n_frames*n_fft doubles. */
+long long ssspy_istft_samples(int n_frames, int n_fft, int hop);
+int ssspy_istft(const void *Z, double *x, const double *window, double window_sum,
+                double *segments, int B, int C, int n_frames, int n_fft, int hop, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,7 @@ def _units():
         ("pairwise_kernels.hip", "pairwise_kernels.o", []),
         ("gmnmf_kernels.hip", "gmnmf_kernels.o", []),
         ("ipa_kernels.hip", "ipa_kernels.o", []),
+        ("stft_kernels.hip", "stft_kernels.o", []),
     ]
     units.append(("mnmf_api.hip", "mnmf_api.o", []))
     for n in MNMF_N:

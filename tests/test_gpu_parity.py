@@ -826,3 +826,50 @@ def test_large_batch_paths_against_oracle():
         np.testing.assert_allclose(np.asarray(mm.loss)[:, b], refm.loss, rtol=LOSS_RTOL)
         assert rel_err(mm.diagonalizer[b], refm.diagonalizer) < TOL
         assert rel_err(Ym[b], Yrm) < 1e-7
+
+
+# ------------------------------------------------------------------------------- STFT / ISTFT
+@pytest.mark.parametrize("n_fft,hop,L", [(64, 16, 1000), (256, 128, 4097), (1024, 256, 9000),
+                                         (4096, 1024, 20000), (128, 128, 777)])
+def test_stft_istft_against_scipy(n_fft, hop, L):
+    """The transforms the reference's workflow takes from scipy.signal, with SciPy's defaults."""
+    import scipy.signal as ss
+
+    from ssspy_amd.transform import istft, stft
+
+    rng = np.random.default_rng(n_fft + hop)
+    x = rng.standard_normal((3, L))
+    _, _, Zr = ss.stft(x, window="hann", nperseg=n_fft, noverlap=n_fft - hop)
+    Z = stft(x, n_fft=n_fft, hop_length=hop)
+    assert Z.shape == Zr.shape and Z.dtype == np.complex128
+    assert rel_err(Z, Zr) < 1e-12
+    _, yr = ss.istft(Zr, window="hann", nperseg=n_fft, noverlap=n_fft - hop)
+    y = istft(Zr, n_fft=n_fft, hop_length=hop)
+    assert y.shape == yr.shape
+    assert rel_err(y, yr) < 1e-12
+    if hop <= n_fft // 2:  # NOLA holds: perfect reconstruction
+        assert rel_err(y[:, :L], x) < 1e-12
+
+
+def test_waveform_to_waveform_stays_on_device():
+    """stft -> separator -> istft with device tensors between the stages == the SciPy / NumPy path."""
+    import scipy.signal as ss
+    import torch
+
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.transform import istft, stft
+
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 6000))
+    Zd = stft(x, n_fft=256, hop_length=64, device_output=True)
+    assert isinstance(Zd, torch.Tensor) and Zd.is_cuda
+    basis, act = rng.random((2, 129, 3)), rng.random((2, 3, Zd.shape[-1]))
+    m = GaussILRMA(n_basis=3)
+    m(Zd, n_iter=3, basis=basis, activation=act)
+    yd = istft(m._state_dev("output")[0], n_fft=256, hop_length=64, device_output=True)
+    assert yd.is_cuda
+    # the same through SciPy and host arrays
+    _, _, Zr = ss.stft(x, window="hann", nperseg=256, noverlap=192)
+    Y2 = GaussILRMA(n_basis=3)(Zr, n_iter=3, basis=basis, activation=act)
+    _, yr = ss.istft(Y2, window="hann", nperseg=256, noverlap=192)
+    assert rel_err(yd.cpu().numpy(), yr) < 1e-9
