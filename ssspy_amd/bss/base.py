@@ -21,31 +21,25 @@ class IterativeMethodBase:
         record_loss: append ``compute_loss()`` to ``self.loss`` at the same points.
     """
 
-    def __init__(
-        self,
-        callbacks: Optional[Union[Callable, List[Callable]]] = None,
-        record_loss: bool = True,
-    ) -> None:
-        if callbacks is None:
-            self.callbacks = None
-        elif callable(callbacks):
-            self.callbacks = [callbacks]
-        else:
-            self.callbacks = callbacks
-        self.record_loss = record_loss
-        self.loss = [] if record_loss else None
+    def __init__(self, callbacks: Optional[Union[Callable, List[Callable]]] = None,
+                 record_loss: bool = True) -> None:
+        # a single callable is wrapped; a list is kept as given (the reference keeps the object)
+        self.callbacks = [callbacks] if callable(callbacks) else callbacks
+        self.record_loss = bool(record_loss)
+        self.loss = [] if self.record_loss else None
 
     def _after_step(self) -> None:
+        """Loss bookkeeping, then the callbacks: the tail of every round and of the initial call."""
         if self.record_loss:
             self.loss.append(self.compute_loss())
-        if self.callbacks is not None:
-            for callback in self.callbacks:
-                callback(self)
+        for hook in self.callbacks or ():
+            hook(self)
 
     def __call__(self, *args, n_iter: int = 100, initial_call: bool = True, **kwargs) -> np.ndarray:
+        rounds = int(n_iter)
         if initial_call:
             self._after_step()
-        for _ in range(n_iter):
+        for _ in range(rounds):
             self.update_once()
             self._after_step()
 
