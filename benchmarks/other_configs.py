@@ -58,6 +58,24 @@ def main():
     del m
     torch.cuda.empty_cache()
 
+    # configs[1] shape with the ISS update (state is the separated spectrogram, no filter)
+    from ssspy_amd.bss.ilrma import GaussILRMA
+
+    N, F, T, K = 4, 1025, 512, 16
+    X = nmf_mixture(1000, N, F, T)
+    if args.batch > 1:
+        X = np.stack([X] * args.batch)
+    m = GaussILRMA(n_basis=K, spatial_algorithm="ISS", record_loss=False, rng=np.random.default_rng(0))
+    m._bind_input(X)
+    m._reset(flooring_fn=m.flooring_fn)
+    for _ in range(3):
+        m.update_once()
+    dt = timed(m.update_once, args.iters)
+    print(json.dumps({"config": "GaussILRMA-ISS N=4 F=1025 T=512 K=16 batch={}".format(B),
+                      "ms_per_iter": round(dt * 1e3, 3), "mixture_iterations_per_s": round(B / dt, 2)}))
+    del m
+    torch.cuda.empty_cache()
+
     # configs[3]: FastGaussMNMF
     M, F, T, K = 4, 1025, 512, 8
     X = nmf_mixture(4000, M, F, T)

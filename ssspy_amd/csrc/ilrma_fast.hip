@@ -215,6 +215,8 @@ __device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const doubl
 // the one-wave version covered with a register prefetch.
 // grid: 1-D, see TailPlan.  Unsplit blocks update their 64 bins in place; split blocks write
 // partial num/den to `part` ([tail item][chunk][n][64 bins][16][2]) for k_basis_finalize.
+// HAS_W = false: the ISS / IPA state passes the separated spectrogram itself (y = x_n, no filter)
+template <bool HAS_W>
 __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ X,
                                                        const c128 *__restrict__ W, double *basis,
                                                        const double *__restrict__ act, int F,
@@ -282,9 +284,12 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
       for (int m = 0; m < N; ++m) wr[m] = wmine[n * N + m];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        c128 y = cmake(0.0, 0.0);
+        c128 y = cur.x[n][r];
+        if (HAS_W) {
+          y = cmake(0.0, 0.0);
 #pragma unroll
-        for (int m = 0; m < N; ++m) cfma(y, wr[m], cur.x[m][r]);
+          for (int m = 0; m < N; ++m) cfma(y, wr[m], cur.x[m][r]);
+        }
         const bool valid = j0 + q + 4 * r < T;
         const double rinv = rcp_nr(R[r]);
         const double bb = valid ? rinv : 0.0;
@@ -344,6 +349,8 @@ __global__ __launch_bounds__(256) void k_basis_finalize(double *basis,
 // the basis pass without its second GEMM; the logarithms are taken on the product of the four R
 // values a lane holds per source and tile (R >= floor^2 * K, so four of them stay far inside the
 // fp64 range), which cuts the dominant cost, the fp64 log, by four.
+// HAS_W = false: the ISS / IPA state passes the separated spectrogram itself (y = x_n, no filter)
+template <bool HAS_W>
 __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X,
                                                       const c128 *__restrict__ W,
                                                       const double *__restrict__ basis,
@@ -401,9 +408,12 @@ __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X
       double prod = 1.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        c128 y = cmake(0.0, 0.0);
+        c128 y = cur.x[n][r];
+        if (HAS_W) {
+          y = cmake(0.0, 0.0);
 #pragma unroll
-        for (int m = 0; m < N; ++m) cfma(y, wr[m], cur.x[m][r]);
+          for (int m = 0; m < N; ++m) cfma(y, wr[m], cur.x[m][r]);
+        }
         const bool valid = bin_valid && (j0 + q + 4 * r < T);
         const double rr = valid ? R[r] : 1.0;
         acc = fma(valid ? cabs2(y) : 0.0, rcp_nr(rr), acc);
@@ -601,6 +611,8 @@ __device__ __forceinline__ void xtile_load_framemajor(XTile &xt, const c128 *__r
     }
 }
 
+// HAS_W = false: the ISS / IPA state passes the separated spectrogram itself (y = x_n, no filter)
+template <bool HAS_W>
 __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restrict__ X,
                                                          const c128 *__restrict__ W,
                                                          const double *__restrict__ basis,
@@ -661,9 +673,12 @@ __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restri
       for (int r = 0; r < 4; ++r) {
         const int bl = q + 4 * r;
         const c128 *wr = wcur + (bl * N + n) * N;
-        c128 y = cmake(0.0, 0.0);
+        c128 y = cur.x[n][r];
+        if (HAS_W) {
+          y = cmake(0.0, 0.0);
 #pragma unroll
-        for (int m = 0; m < N; ++m) cfma(y, wr[m], cur.x[m][r]);
+          for (int m = 0; m < N; ++m) cfma(y, wr[m], cur.x[m][r]);
+        }
         const bool valid = fvalid && (i0 + bl < F);
         const double rinv = rcp_nr(R[r]);
         const double bb = valid ? rinv : 0.0;
@@ -699,8 +714,12 @@ int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, double *basis, cons
                                double *part, hipStream_t st) {
   const TailPlan plan = make_tail_plan(B, (F + 63) / 64, (T + 15) / 16);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
-  hipLaunchKernelGGL(k_basis_fast, grid, block, 0, st, (const c128 *)X, (const c128 *)W, basis,
-                     act, F, T, K, floor_kind, eps, plan, part);
+  if (W)
+    hipLaunchKernelGGL(k_basis_fast<true>, grid, block, 0, st, (const c128 *)X, (const c128 *)W,
+                       basis, act, F, T, K, floor_kind, eps, plan, part);
+  else
+    hipLaunchKernelGGL(k_basis_fast<false>, grid, block, 0, st, (const c128 *)X, (const c128 *)W,
+                       basis, act, F, T, K, floor_kind, eps, plan, part);
   int rc = check_launch("k_basis_fast");
   if (rc || plan.tail == 0) return rc;
   hipLaunchKernelGGL(k_basis_finalize, dim3(N * 64 * 16 / 256, plan.tail), block, 0, st, basis,
@@ -714,8 +733,12 @@ int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *
   const int ntiles = (F + 15) / 16;
   const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
   dim3 grid((T + 63) / 64, nchunks, B), block(256);
-  hipLaunchKernelGGL(k_activation_fast, grid, block, 0, st, (const c128 *)X, (const c128 *)W,
-                     basis, act, part, F, T, K, tiles_per_chunk, nchunks);
+  if (W)
+    hipLaunchKernelGGL(k_activation_fast<true>, grid, block, 0, st, (const c128 *)X,
+                       (const c128 *)W, basis, act, part, F, T, K, tiles_per_chunk, nchunks);
+  else
+    hipLaunchKernelGGL(k_activation_fast<false>, grid, block, 0, st, (const c128 *)X,
+                       (const c128 *)W, basis, act, part, F, T, K, tiles_per_chunk, nchunks);
   return check_launch("k_activation_fast");
 }
 
@@ -724,8 +747,12 @@ int LAUNCHER(ilrma_fast_loss)(const void *X, const void *W, const double *basis,
                               double *out, int B, int F, int T, int K, hipStream_t st) {
   const TailPlan plan = make_tail_plan(B, (F + 63) / 64, (T + 15) / 16);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
-  hipLaunchKernelGGL(k_loss_fast, grid, block, 0, st, (const c128 *)X, (const c128 *)W, basis, act,
-                     out, F, T, K, plan);
+  if (W)
+    hipLaunchKernelGGL(k_loss_fast<true>, grid, block, 0, st, (const c128 *)X, (const c128 *)W,
+                       basis, act, out, F, T, K, plan);
+  else
+    hipLaunchKernelGGL(k_loss_fast<false>, grid, block, 0, st, (const c128 *)X, (const c128 *)W,
+                       basis, act, out, F, T, K, plan);
   return check_launch("k_loss_fast");
 }
 
