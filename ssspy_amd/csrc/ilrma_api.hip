@@ -97,8 +97,7 @@ static inline size_t qbuf_bytes(int B, int N, int F) {
 }
 
 int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, int F, int N,
-                   int floor_kind, double floor_eps, int *info, hipStream_t st, int nchunks);
-int sum_chunks(void *dst, const void *src, long long count, int nchunks, hipStream_t st);
+                   int floor_kind, double floor_eps, int *info, hipStream_t st);
 
 // scratch of the bin-major fast kernels (basis, covariance): partial sums of the at most 512
 // split blocks of the last scheduling round (TailPlan in ilrma_fast.hip)
@@ -571,7 +570,7 @@ int ssspy_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis,
   if (rc) return rc;
   double *qbuf = (double *)(ws + w.qbuf);
   rc = ip1_with_power(W, U, normalize ? C : nullptr, normalize ? qbuf : nullptr, B, F, N,
-                      floor_kind, floor_eps, info, st, 1);
+                      floor_kind, floor_eps, info, st);
   if (rc || !normalize) return rc;
   return launch_norm_scale(W, basis, qbuf, B, N, F, K, domain, floor_kind, floor_eps, st);
 }

@@ -31,7 +31,7 @@ DECL_N(2) DECL_N(3) DECL_N(4)
   }
 
 int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, int F, int N,
-                   int floor_kind, double floor_eps, int *info, hipStream_t st, int nchunks);
+                   int floor_kind, double floor_eps, int *info, hipStream_t st);
 int row_power(const void *W, const void *C, double *qbuf, int B, int F, int N, hipStream_t st);
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -161,7 +161,7 @@ int ssspy_fastmnmf_update(const void *X, const void *C, void *Q, double *D, doub
     rc = run();
     if (rc) return rc;
     // IP1 on the M x M diagonaliser with M weighted covariances per bin
-    rc = ip1_with_power(Q, U, C, C ? qbuf : nullptr, B, F, M, floor_kind, floor_eps, info, st, 1);
+    rc = ip1_with_power(Q, U, C, C ? qbuf : nullptr, B, F, M, floor_kind, floor_eps, info, st);
     if (rc) return rc;
     have_q = C != nullptr;
   }

@@ -155,11 +155,9 @@ __global__ __launch_bounds__(256) void k_cross_cov(const c128 *__restrict__ A,
 // When C (static covariance) and qbuf are given, also writes the output power of the updated
 // rows, qbuf[bin][n] = Re(w_n C w_n^H), which the power normalisation needs.
 template <int N>
-// U may arrive as `nchunks` partial sums, chunk c at U + c * chunk_stride (small-batch covariance).
 __global__ __launch_bounds__(64) void k_ip1(c128 *W, const c128 *__restrict__ U, long long nbins,
                                             int floor_kind, double eps, int *info,
-                                            const c128 *__restrict__ C, double *qbuf, int nchunks,
-                                            long long chunk_stride) {
+                                            const c128 *__restrict__ C, double *qbuf) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nbins) return;
   Mat<N> Wm;
@@ -169,13 +167,6 @@ __global__ __launch_bounds__(64) void k_ip1(c128 *W, const c128 *__restrict__ U,
   for (int n = 0; n < N; ++n) {
     Mat<N> Un, A;
     load_mat<N>(Un, U + (idx * N + n) * (N * N));
-    for (int ch = 1; ch < nchunks; ++ch) {
-      const c128 *Uc = U + ch * chunk_stride + (idx * N + n) * (N * N);
-#pragma unroll
-      for (int r = 0; r < N; ++r)
-#pragma unroll
-        for (int cc = 0; cc < N; ++cc) Un.a[r][cc] = cadd(Un.a[r][cc], Uc[r * N + cc]);
-    }
     matmul<N>(A, Wm, Un);
     c128 w[N];
     ok = solve_unit<N>(A, n, w) && ok;
@@ -408,31 +399,14 @@ using namespace ssspy;
 
 namespace ssspy {
 int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, int F, int N,
-                   int floor_kind, double floor_eps, int *info, hipStream_t st, int nchunks) {
+                   int floor_kind, double floor_eps, int *info, hipStream_t st) {
   const long long nbins = (long long)B * F;
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
-  const long long stride = nbins * N * N * N;
   DISPATCH_N(N, hipLaunchKernelGGL((k_ip1<NN>), grid, block, 0, st, (c128 *)W, (const c128 *)U,
-                                   nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf,
-                                   nchunks, stride));
+                                   nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf));
   return check_launch("k_ip1");
 }
 
-// dst[e] = sum_c src[c * count + e]  (complex128 elements)
-__global__ __launch_bounds__(256) void k_sum_chunks(c128 *dst, const c128 *__restrict__ src,
-                                                    long long count, int nchunks) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= count) return;
-  c128 s = src[e];
-  for (int ch = 1; ch < nchunks; ++ch) s = cadd(s, src[ch * count + e]);
-  dst[e] = s;
-}
-
-int sum_chunks(void *dst, const void *src, long long count, int nchunks, hipStream_t st) {
-  hipLaunchKernelGGL(k_sum_chunks, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
-                     (c128 *)dst, (const c128 *)src, count, nchunks);
-  return check_launch("k_sum_chunks");
-}
 int row_power(const void *W, const void *C, double *qbuf, int B, int F, int N, hipStream_t st) {
   const long long nbins = (long long)B * F;
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
@@ -482,7 +456,7 @@ int ssspy_update_by_ip1(void *W, const void *U, int B, int F, int N, int floor_k
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
   DISPATCH_N(N, hipLaunchKernelGGL((k_ip1<NN>), grid, block, 0, as_stream(stream), (c128 *)W,
                                    (const c128 *)U, nbins, floor_kind, floor_eps, info,
-                                   (const c128 *)nullptr, (double *)nullptr, 1, 0LL));
+                                   (const c128 *)nullptr, (double *)nullptr));
   return check_launch("k_ip1");
 }
 
