@@ -45,7 +45,7 @@ def counter(path, name):
             if r["Counter_Name"] != name:
                 continue
             for k in KERNELS:
-                if k + "(" in r["Kernel_Name"] or r["Kernel_Name"].endswith(k) or "::" + k in r["Kernel_Name"]:
+                if "::" + k in r["Kernel_Name"] or r["Kernel_Name"].startswith(k):
                     acc[k].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items() if v}
 
