@@ -589,6 +589,7 @@ __device__ __forceinline__ void tstage_load(TStage &st, const double *__restrict
 }
 
 constexpr int TROW = 17;  // doubles per staged basis row (16 + 1 pad)
+constexpr int AWSTRIDE = N * N + 1;  // 16-byte slots per staged demixing matrix
 
 __device__ __forceinline__ void tstage_store(const TStage &st, double *tbuf, c128 *wbuf) {
 #pragma unroll
@@ -597,7 +598,10 @@ __device__ __forceinline__ void tstage_store(const TStage &st, double *tbuf, c12
     const int k = idx & 15, row = idx >> 4;  // row = n*16 + bin
     if (idx < N * 256) tbuf[row * TROW + k] = st.t[u];
   }
-  if (threadIdx.x < 16 * N * N) wbuf[threadIdx.x] = st.w;
+  // one 16-byte slot of padding per bin: lanes of different q read different bins at once, and an
+  // unpadded N*N-slot stride (256 B at N = 4) would put them all on the same banks
+  if (threadIdx.x < 16 * N * N)
+    wbuf[(threadIdx.x / (N * N)) * AWSTRIDE + threadIdx.x % (N * N)] = st.w;
 }
 
 __device__ __forceinline__ void xtile_load_framemajor(XTile &xt, const c128 *__restrict__ Xb, int F,
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restri
                                                          double *__restrict__ part, int F, int T,
                                                          int K, int tiles_per_chunk, int nchunks) {
   __shared__ __attribute__((aligned(16))) double ts[2][N * 16 * TROW];
-  __shared__ __attribute__((aligned(16))) c128 ws[2][16 * N * N];
+  __shared__ __attribute__((aligned(16))) c128 ws[2][16 * AWSTRIDE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
   const int b = blockIdx.z, chunk = blockIdx.y;
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int bl = q + 4 * r;
-        const c128 *wr = wcur + (bl * N + n) * N;
+        const c128 *wr = wcur + bl * AWSTRIDE + n * N;
         c128 y = cur.x[n][r];
         if (HAS_W) {
           y = cmake(0.0, 0.0);
