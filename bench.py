@@ -184,7 +184,10 @@ def main():
         except Exception:
             traffic = None
     roofline = {
-        "bound": "hbm", "kernel": "k_ilrma_" + dominant, "achieved": round(achieved, 1),
+        # the name rocprofv3 reports for this launch (tuned path of ilrma_fast.hip at these shapes)
+        "bound": "hbm", "kernel": {"basis": "k_basis_fast", "activation": "k_activation_fast",
+                                   "wcov": "k_wcov_fast"}[dominant],
+        "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": traffic,
         "bytes_per_launch": pass_bytes, "avg_launch_ms": round(avg_ms[dominant], 4),
