@@ -179,3 +179,25 @@ def test_fast_gauss_mnmf_option_sweep():
         Yr = ref.run(X, n_iter=n_iter, **init)
         assert rel_err(Y, Yr) < 1e-7 and rel_err(m.diagonalizer, ref.diagonalizer) < TOL
         np.testing.assert_allclose(m.loss, ref.loss, rtol=1e-9)
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 2, 1), (2, 5, 7, 1), (3, 16, 16, 16), (4, 17, 18, 16),
+                                   (4, 64, 1024, 16), (2, 1025, 2, 3), (4, 15, 510, 9), (8, 3, 33, 2),
+                                   (4, 129, 66, 64)])
+@pytest.mark.parametrize("algo", ["IP", "ISS"])
+def test_gauss_ilrma_edge_shapes(shape, algo):
+    """Tiny, ragged and lopsided shapes: one bin, two frames, tiles with a single valid row or
+    column, n_basis 1 and 64, odd n_frames (generic kernels) next to even (tuned kernels)."""
+    from oracle.ilrma import GaussILRMAOracle
+    from ssspy_amd.bss.ilrma import GaussILRMA
+
+    N, F, T, K = shape
+    X = _mixture(900 + F, N, F, T)
+    rng = np.random.default_rng(F * T)
+    basis, act = rng.random((N, F, K)), rng.random((N, K, T))
+    m = GaussILRMA(n_basis=K, spatial_algorithm=algo)
+    Y = m(X, n_iter=2, basis=basis, activation=act)
+    ref = GaussILRMAOracle(n_basis=K, spatial_algorithm=algo)
+    Yr = ref.run(X, n_iter=2, basis=basis, activation=act)
+    assert rel_err(Y, Yr) < TOL, shape
+    np.testing.assert_allclose(m.loss, ref.loss, rtol=1e-9)
