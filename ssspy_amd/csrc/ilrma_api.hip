@@ -23,13 +23,13 @@ DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
 // throughput variants (ilrma_fast.hip): domain == 2, n_basis <= 16, n_sources <= 4, even T
 #define DECL_FAST(n)                                                                           \
   int ilrma_fast_basis_n##n(const void *, const void *, double *, const double *, int, int, int, \
-                            int, int, double, double *, hipStream_t);                          \
+                            int, int, double, double *, int, double, int, hipStream_t);        \
   int ilrma_fast_activation_n##n(const void *, const void *, const double *, const double *,   \
-                                 double *, int, int, int, int, int, hipStream_t);              \
-  int ilrma_fast_wcov_n##n(const void *, const double *, const double *, void *, int, int, int, \
-                           int, void *, hipStream_t);                                          \
+                                 double *, int, int, int, int, int, int, double, hipStream_t); \
+  int ilrma_fast_wcov_n##n(const void *, const void *, const double *, const double *, void *, \
+                           int, int, int, int, void *, int, double, hipStream_t);              \
   int ilrma_fast_loss_n##n(const void *, const void *, const double *, const double *, double *, \
-                           int, int, int, int, hipStream_t);
+                           int, int, int, int, int, double, hipStream_t);
 DECL_FAST(2) DECL_FAST(3) DECL_FAST(4)
 #undef DECL_FAST
 
@@ -40,11 +40,16 @@ DECL_FAST(2) DECL_FAST(3) DECL_FAST(4)
     default: return fn##_n4(__VA_ARGS__);            \
   }
 
-static inline bool fast_path(int N, int T, int K, double domain, int model = SSSPY_SOURCE_GAUSS) {
+// the tuned kernels: domain 2, Gauss or Student-t model (MM or ME), n_sources <= 4, n_basis <= 16,
+// even n_frames; `source_model` may carry the SSSPY_SOURCE_ME flag
+static inline bool fast_path(int N, int T, int K, double domain, int source_model = SSSPY_SOURCE_GAUSS) {
   static const bool disabled = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;
-  return !disabled && model == SSSPY_SOURCE_GAUSS && N >= 2 && N <= 4 && K <= 16 &&
-         (T % 2 == 0) && domain == 2.0;
+  const int base = source_model & 0xff;
+  return !disabled && (base == SSSPY_SOURCE_GAUSS || base == SSSPY_SOURCE_T) && N >= 2 && N <= 4 &&
+         K <= 16 && (T % 2 == 0) && domain == 2.0;
 }
+static inline int is_t(int source_model) { return (source_model & 0xff) == SSSPY_SOURCE_T; }
+static inline int is_me(int source_model) { return (source_model & SSSPY_SOURCE_ME) ? 1 : 0; }
 
 static inline int check_model(int source_model, double param, double domain = 2.0) {
   const int model = source_model & 0xff;
@@ -403,7 +408,8 @@ int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const 
   hipStream_t st = as_stream(stream);
   if (fast_path(N, T, K, domain, source_model)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_basis, X, W, basis, activation, B, F, T, K, floor_kind,
-                        floor_eps, (double *)(ws + w.bpart), st);
+                        floor_eps, (double *)(ws + w.bpart), is_t(source_model), model_param,
+                        is_me(source_model), st);
   }
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   double *out = K > 16 ? (double *)(ws + w.btmp) : basis;
@@ -437,7 +443,7 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
   auto run = [&]() -> int {
     if (fast_path(N, T, K, domain, source_model)) {
       ILRMA_FAST_DISPATCH(N, ilrma_fast_activation, X, W, basis, activation, part, chunks, B, F, T,
-                          K, st);
+                          K, is_t(source_model), model_param, st);
     }
     ILRMA_DISPATCH(N, ilrma_activation, X, W, basis, activation, part, chunks, d, st);
   };
@@ -452,8 +458,9 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
 // U[b,i,n] for every model; `upart` is the fast path's scratch for split blocks
 static int wcov_into(const void *X, const void *W, const double *basis, const double *activation,
                      void *U, int N, const IlrmaDims &d, void *upart, hipStream_t st) {
-  if (fast_path(N, d.T, d.K, d.p, d.model)) {
-    ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, basis, activation, U, d.B, d.F, d.T, d.K, upart, st);
+  if (fast_path(N, d.T, d.K, d.p, d.model) && (d.model == SSSPY_SOURCE_GAUSS || W)) {
+    ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, W, basis, activation, U, d.B, d.F, d.T, d.K, upart,
+                        d.model == SSSPY_SOURCE_T, d.mparam, st);
   }
   ILRMA_DISPATCH(N, ilrma_wcov, X, W, basis, activation, U, d, st);
 }
@@ -539,8 +546,9 @@ int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
   hipStream_t st = as_stream(stream);
   hipError_t e = hipMemsetAsync(out, 0, (size_t)B * sizeof(double), st);
   if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
-  if (fast_path(N, T, K, domain, source_model & 0xff)) {
-    ILRMA_FAST_DISPATCH(N, ilrma_fast_loss, X, W, basis, activation, out, B, F, T, K, st);
+  if (fast_path(N, T, K, domain, source_model)) {
+    ILRMA_FAST_DISPATCH(N, ilrma_fast_loss, X, W, basis, activation, out, B, F, T, K,
+                        is_t(source_model), model_param, st);
   }
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, SSSPY_FLOOR_NONE, 0.0);
   ILRMA_DISPATCH(N, ilrma_loss, X, W, basis, activation, out, d, st);

@@ -61,6 +61,13 @@ __device__ __forceinline__ int tile_pi(int rho) { return 4 * (rho & 3) + (rho >>
 // (128 mixtures x 17 groups = 2176 items = 4.25 rounds: 5 rounds unsplit, 4.25 split).  Split blocks
 // write partial sums to a scratch area indexed [tail item][chunk]; a small second kernel folds them.
 // Small batches are the same formula with full == 0.
+// Source model of the tuned kernels (domain 2): Gauss, or Student-t with R~ = w R + (1 - w) |y|^2,
+// w = nu / (nu + 2) (ref: ssspy/bss/ilrma.py:2505-2518, :2915-2935); `me`: exponent 1 instead of 1/2.
+struct FastModel {
+  double w, w1, nu;
+  int me;
+};
+
 constexpr int SLOTS = 512;
 struct TailPlan {
   int full, tail, split, groups;  // blocks = full + tail * split; groups = bin groups per mixture
@@ -216,12 +223,13 @@ __device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const doubl
 // grid: 1-D, see TailPlan.  Unsplit blocks update their 64 bins in place; split blocks write
 // partial num/den to `part` ([tail item][chunk][n][64 bins][16][2]) for k_basis_finalize.
 // HAS_W = false: the ISS / IPA state passes the separated spectrogram itself (y = x_n, no filter)
-template <bool HAS_W>
+template <bool HAS_W, bool TMODEL>
 __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ X,
                                                        const c128 *__restrict__ W, double *basis,
                                                        const double *__restrict__ act, int F,
                                                        int T, int K, int floor_kind, double eps,
-                                                       TailPlan plan, double *__restrict__ part) {
+                                                       TailPlan plan, double *__restrict__ part,
+                                                       FastModel fm) {
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
   constexpr int WSTRIDE = N * N + 1;  // 16-byte slots per bin: odd, so 16 bins never share a bank
   __shared__ __attribute__((aligned(16))) c128 wl[4][16 * WSTRIDE];
@@ -293,7 +301,9 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
         const bool valid = j0 + q + 4 * r < T;
         const double rinv = rcp_nr(R[r]);
         const double bb = valid ? rinv : 0.0;
-        const double aa = valid ? cabs2(y) * rinv * rinv : 0.0;
+        const double pw = cabs2(y);
+        const double wgt = TMODEL ? rcp_nr(fma(fm.w, R[r], fm.w1 * pw)) : rinv;
+        const double aa = valid ? pw * wgt * rinv : 0.0;
         num[n] = mfma_f64(aa, vb[r], num[n]);
         den[n] = mfma_f64(bb, vb[r], den[n]);
       }
@@ -310,7 +320,8 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
       if (ob < F && c < K) {
         if (nchunks == 1) {
           double *dst = basis + (((long long)b * N + n) * F + ob) * K + c;
-          *dst = apply_floor(sqrt(num[n][r] / den[n][r]) * (*dst), floor_kind, eps);
+          const double ratio = num[n][r] / den[n][r];
+          *dst = apply_floor((fm.me ? ratio : sqrt(ratio)) * (*dst), floor_kind, eps);
         } else {
           const long long slot = (long long)work.tail_idx * nchunks + work.chunk;
           double *dst = part + (((slot * N + n) * 64 + (ob - work.group * 64)) * 16 + c) * 2;
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
 __global__ __launch_bounds__(256) void k_basis_finalize(double *basis,
                                                         const double *__restrict__ part, int F,
                                                         int K, TailPlan plan, int floor_kind,
-                                                        double eps) {
+                                                        double eps, int me) {
   const int tail_idx = blockIdx.y;
   const int item = plan.full + tail_idx;
   const int b = item / plan.groups, group = item - b * plan.groups;
@@ -341,7 +352,8 @@ __global__ __launch_bounds__(256) void k_basis_finalize(double *basis,
     sd += src[1];
   }
   double *dst = basis + (((long long)b * N + n) * F + bin) * K + k;
-  *dst = apply_floor(sqrt(sn / sd) * (*dst), floor_kind, eps);
+  const double ratio = sn / sd;
+  *dst = apply_floor((me ? ratio : sqrt(ratio)) * (*dst), floor_kind, eps);
 }
 
 // ================================================================================ loss data
@@ -350,13 +362,13 @@ __global__ __launch_bounds__(256) void k_basis_finalize(double *basis,
 // values a lane holds per source and tile (R >= floor^2 * K, so four of them stay far inside the
 // fp64 range), which cuts the dominant cost, the fp64 log, by four.
 // HAS_W = false: the ISS / IPA state passes the separated spectrogram itself (y = x_n, no filter)
-template <bool HAS_W>
+template <bool HAS_W, bool TMODEL>
 __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X,
                                                       const c128 *__restrict__ W,
                                                       const double *__restrict__ basis,
                                                       const double *__restrict__ act,
                                                       double *__restrict__ out, int F, int T, int K,
-                                                      TailPlan plan) {
+                                                      TailPlan plan, FastModel fm) {
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
   constexpr int WSTRIDE = N * N + 1;
   __shared__ __attribute__((aligned(16))) c128 wl[4][16 * WSTRIDE];
@@ -405,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X
       c128 wr[N];
 #pragma unroll
       for (int m = 0; m < N; ++m) wr[m] = wmine[n * N + m];
-      double prod = 1.0;
+      double prod = 1.0, prod_t = 1.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         c128 y = cur.x[n][r];
@@ -416,10 +428,15 @@ __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X
         }
         const bool valid = bin_valid && (j0 + q + 4 * r < T);
         const double rr = valid ? R[r] : 1.0;
-        acc = fma(valid ? cabs2(y) : 0.0, rcp_nr(rr), acc);
+        const double pr = (valid ? cabs2(y) : 0.0) * rcp_nr(rr);
+        if (TMODEL)
+          prod_t *= fma(2.0 / fm.nu, pr, 1.0);  // (1 + nu/2) log(1 + (2/nu) P / R), ilrma.py:3301-3305
+        else
+          acc += pr;
         prod *= rr;
       }
       acc += log(prod);
+      if (TMODEL) acc = fma(1.0 + 0.5 * fm.nu, log(prod_t), acc);
     }
     vstage_store(st, vs[(jt - jt_begin + 1) & 1]);
     __syncthreads();
@@ -444,14 +461,20 @@ constexpr int WC_BINS = 16 * WC_WB;              // bins per workgroup
 
 // grid: 1-D, see TailPlan.  Unsplit blocks store U directly; split blocks store their partial sums
 // (already scaled by 1/T) to `upart` ([tail item][chunk][WC_BINS][N][N][N]) for k_wcov_fold.
+// TMODEL: varphi = 1 / (w R + (1 - w) |w_n^H x|^2), so the wave also needs its bins' demixing rows
+template <bool TMODEL>
 __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X,
+                                                      const c128 *__restrict__ W,
                                                       const double *__restrict__ basis,
                                                       const double *__restrict__ act,
                                                       c128 *__restrict__ U, int F, int T, int K,
-                                                      TailPlan plan, c128 *__restrict__ upart) {
+                                                      TailPlan plan, c128 *__restrict__ upart,
+                                                      FastModel fm) {
   constexpr int SG = WC_SG;
+  constexpr int WSTRIDE = N * N + 1;
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
   __shared__ __attribute__((aligned(16))) c128 xpatch[4][XPATCH];
+  __shared__ __attribute__((aligned(16))) c128 wlc[TMODEL ? 4 * 16 * WSTRIDE : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
   const BlockWork work = block_work(plan);
@@ -470,6 +493,13 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
       const int kk = 4 * ks + q, n = min(s0 + s, N - 1);
       tb[s][ks] = kk < K ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
     }
+  c128 *wmine = wlc + (TMODEL ? (wave * 16 + c) * WSTRIDE : 0);
+  if (TMODEL) {
+    for (int e = lane; e < 16 * N * N; e += 64) {
+      const int bl = e / (N * N), rem = e % (N * N);
+      wlc[(wave * 16 + bl) * WSTRIDE + rem] = W[((long long)b * F + min(i0 + bl, F - 1)) * (N * N) + rem];
+    }
+  }
   CovAcc<N, SG> acc;
   acc.clear();
   const int ntiles = (T + 15) >> 4;
@@ -498,7 +528,16 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
 #pragma unroll
       for (int m = 0; m < N; ++m) x[m] = cur.x[m][r];
 #pragma unroll
-      for (int s = 0; s < SG; ++s) phi[s] = (valid && s0 + s < N) ? rcp_nr(R[s][r]) : 0.0;
+      for (int s = 0; s < SG; ++s) {
+        double den = R[s][r];
+        if (TMODEL) {
+          c128 y = cmake(0.0, 0.0);
+#pragma unroll
+          for (int m = 0; m < N; ++m) cfma(y, wmine[min(s0 + s, N - 1) * N + m], x[m]);
+          den = fma(fm.w, den, fm.w1 * cabs2(y));
+        }
+        phi[s] = (valid && s0 + s < N) ? rcp_nr(den) : 0.0;
+      }
       acc.add(x, phi);
     }
     vstage_store(st, vs[(jt - jt_begin + 1) & 1]);
@@ -616,13 +655,14 @@ __device__ __forceinline__ void xtile_load_framemajor(XTile &xt, const c128 *__r
 }
 
 // HAS_W = false: the ISS / IPA state passes the separated spectrogram itself (y = x_n, no filter)
-template <bool HAS_W>
+template <bool HAS_W, bool TMODEL>
 __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restrict__ X,
                                                          const c128 *__restrict__ W,
                                                          const double *__restrict__ basis,
                                                          const double *__restrict__ act,
                                                          double *__restrict__ part, int F, int T,
-                                                         int K, int tiles_per_chunk, int nchunks) {
+                                                         int K, int tiles_per_chunk, int nchunks,
+                                                         FastModel fm) {
   __shared__ __attribute__((aligned(16))) double ts[2][N * 16 * TROW];
   __shared__ __attribute__((aligned(16))) c128 ws[2][16 * AWSTRIDE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -686,7 +726,9 @@ __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restri
         const bool valid = fvalid && (i0 + bl < F);
         const double rinv = rcp_nr(R[r]);
         const double bb = valid ? rinv : 0.0;
-        const double aa = valid ? cabs2(y) * rinv * rinv : 0.0;
+        const double pw = cabs2(y);
+        const double wgt = TMODEL ? rcp_nr(fma(fm.w, R[r], fm.w1 * pw)) : rinv;
+        const double aa = valid ? pw * wgt * rinv : 0.0;
         // GEMM2: A[row = c -> basis index c][kk = q] = T[n, bin i0+q+4r, c] (zero-staged pads)
         const double ta = tn[bl * TROW + c];
         numv[n] = mfma_f64(ta, aa, numv[n]);
@@ -712,66 +754,92 @@ __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restri
 }  // namespace ilrma_fast_n<N>
 using namespace SSSPY_CAT(ilrma_fast_n, SSSPY_N);
 
-// `part` must hold ilrma_fast_part_bytes() bytes (used only when some items are split)
+// (tmodel, nu, me): Gauss (0) or Student-t (1) source model with dof nu; me = exponent 1
+static inline FastModel make_fast_model(int tmodel, double nu, int me) {
+  FastModel fm;
+  fm.nu = tmodel ? nu : 1.0;
+  fm.w = tmodel ? nu / (nu + 2.0) : 1.0;
+  fm.w1 = 1.0 - fm.w;
+  fm.me = me;
+  return fm;
+}
+
+#define SSSPY_FAST_LAUNCH2(kernel, A, Bv, ...)                                            \
+  do {                                                                                    \
+    if (A) {                                                                              \
+      if (Bv)                                                                             \
+        hipLaunchKernelGGL((kernel<true, true>), grid, block, 0, st, __VA_ARGS__);        \
+      else                                                                                \
+        hipLaunchKernelGGL((kernel<true, false>), grid, block, 0, st, __VA_ARGS__);       \
+    } else {                                                                              \
+      if (Bv)                                                                             \
+        hipLaunchKernelGGL((kernel<false, true>), grid, block, 0, st, __VA_ARGS__);       \
+      else                                                                                \
+        hipLaunchKernelGGL((kernel<false, false>), grid, block, 0, st, __VA_ARGS__);      \
+    }                                                                                     \
+  } while (0)
+
+// `part` must hold the scratch of ilrma_api.hip's basis_part_bytes() (used only when items are split)
 int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, double *basis, const double *act,
                                int B, int F, int T, int K, int floor_kind, double eps,
-                               double *part, hipStream_t st) {
+                               double *part, int tmodel, double nu, int me, hipStream_t st) {
   const TailPlan plan = make_tail_plan(B, (F + 63) / 64, (T + 15) / 16);
+  const FastModel fm = make_fast_model(tmodel, nu, me);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
-  if (W)
-    hipLaunchKernelGGL(k_basis_fast<true>, grid, block, 0, st, (const c128 *)X, (const c128 *)W,
-                       basis, act, F, T, K, floor_kind, eps, plan, part);
-  else
-    hipLaunchKernelGGL(k_basis_fast<false>, grid, block, 0, st, (const c128 *)X, (const c128 *)W,
-                       basis, act, F, T, K, floor_kind, eps, plan, part);
+  SSSPY_FAST_LAUNCH2(k_basis_fast, W != nullptr, tmodel != 0, (const c128 *)X, (const c128 *)W,
+                     basis, act, F, T, K, floor_kind, eps, plan, part, fm);
   int rc = check_launch("k_basis_fast");
   if (rc || plan.tail == 0) return rc;
   hipLaunchKernelGGL(k_basis_finalize, dim3(N * 64 * 16 / 256, plan.tail), block, 0, st, basis,
-                     part, F, K, plan, floor_kind, eps);
+                     part, F, K, plan, floor_kind, eps, me);
   return check_launch("k_basis_finalize");
 }
 
 int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *basis,
                                     const double *act, double *part, int nchunks, int B, int F,
-                                    int T, int K, hipStream_t st) {
+                                    int T, int K, int tmodel, double nu, hipStream_t st) {
   const int ntiles = (F + 15) / 16;
   const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
+  const FastModel fm = make_fast_model(tmodel, nu, 0);
   dim3 grid((T + 63) / 64, nchunks, B), block(256);
-  if (W)
-    hipLaunchKernelGGL(k_activation_fast<true>, grid, block, 0, st, (const c128 *)X,
-                       (const c128 *)W, basis, act, part, F, T, K, tiles_per_chunk, nchunks);
-  else
-    hipLaunchKernelGGL(k_activation_fast<false>, grid, block, 0, st, (const c128 *)X,
-                       (const c128 *)W, basis, act, part, F, T, K, tiles_per_chunk, nchunks);
+  SSSPY_FAST_LAUNCH2(k_activation_fast, W != nullptr, tmodel != 0, (const c128 *)X,
+                     (const c128 *)W, basis, act, part, F, T, K, tiles_per_chunk, nchunks, fm);
   return check_launch("k_activation_fast");
 }
 
 // `out` (B doubles) must be zeroed by the caller
 int LAUNCHER(ilrma_fast_loss)(const void *X, const void *W, const double *basis, const double *act,
-                              double *out, int B, int F, int T, int K, hipStream_t st) {
+                              double *out, int B, int F, int T, int K, int tmodel, double nu,
+                              hipStream_t st) {
   const TailPlan plan = make_tail_plan(B, (F + 63) / 64, (T + 15) / 16);
+  const FastModel fm = make_fast_model(tmodel, nu, 0);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
-  if (W)
-    hipLaunchKernelGGL(k_loss_fast<true>, grid, block, 0, st, (const c128 *)X, (const c128 *)W,
-                       basis, act, out, F, T, K, plan);
-  else
-    hipLaunchKernelGGL(k_loss_fast<false>, grid, block, 0, st, (const c128 *)X, (const c128 *)W,
-                       basis, act, out, F, T, K, plan);
+  SSSPY_FAST_LAUNCH2(k_loss_fast, W != nullptr, tmodel != 0, (const c128 *)X, (const c128 *)W,
+                     basis, act, out, F, T, K, plan, fm);
   return check_launch("k_loss_fast");
 }
 
-// `upart` must hold ilrma_fast_part_bytes() bytes (used only when some items are split)
-int LAUNCHER(ilrma_fast_wcov)(const void *X, const double *basis, const double *act, void *U,
-                              int B, int F, int T, int K, void *upart, hipStream_t st) {
+// `upart` must hold u_part_bytes() of ilrma_api.hip (used only when some items are split);
+// W is read by the t model only
+int LAUNCHER(ilrma_fast_wcov)(const void *X, const void *W, const double *basis, const double *act,
+                              void *U, int B, int F, int T, int K, void *upart, int tmodel,
+                              double nu, hipStream_t st) {
   const TailPlan plan = make_tail_plan(B, (F + WC_BINS - 1) / WC_BINS, (T + 15) / 16);
+  const FastModel fm = make_fast_model(tmodel, nu, 0);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
-  hipLaunchKernelGGL(k_wcov_fast, grid, block, 0, st, (const c128 *)X, basis, act, (c128 *)U, F, T,
-                     K, plan, (c128 *)upart);
+  if (tmodel)
+    hipLaunchKernelGGL(k_wcov_fast<true>, grid, block, 0, st, (const c128 *)X, (const c128 *)W,
+                       basis, act, (c128 *)U, F, T, K, plan, (c128 *)upart, fm);
+  else
+    hipLaunchKernelGGL(k_wcov_fast<false>, grid, block, 0, st, (const c128 *)X, (const c128 *)W,
+                       basis, act, (c128 *)U, F, T, K, plan, (c128 *)upart, fm);
   int rc = check_launch("k_wcov_fast");
   if (rc || plan.tail == 0) return rc;
   hipLaunchKernelGGL(k_wcov_fold, dim3((WC_BINS * N * N * N + 255) / 256, plan.tail), block, 0, st,
                      (c128 *)U, (const c128 *)upart, F, plan);
   return check_launch("k_wcov_fold");
 }
+
+#undef SSSPY_FAST_LAUNCH2
 
 }  // namespace ssspy
