@@ -411,6 +411,24 @@ int ssspy_gmnmf_separate(const void *X, const double *basis, const double *activ
                          const void *spatial, void *Y, int B, int N, int M, int F, int T, int K,
                          int reference_id, int floor_kind, double floor_eps, void *stream);
 
+/* ------------------------------------------------------------------ Hermitian matrix functions
+ * One matrix per lane, M in [2, 8]; arrays flattened to (n, M, M) c128.
+ * generalised eigh through the Cholesky factor of B, eigenvalues ascending -> lamb (n, M), Z (n, M, M):
+ *   type 1: A z = lamb B z; 2: A B z = lamb z; 3: B A z = lamb z.   replaces: ssspy/linalg/eigh.py:8-81, :164-207 */
+int ssspy_eigh_general(const void *A, const void *Bm, double *lamb, void *Z, long long n, int M,
+                       int type, int *info, void *stream);
+/* inverse == 0: X^(1/2); inverse == 1: P diag(1 / floor(sqrt(lam))) P^H.  replaces: linalg/sqrtm.py:8-64 */
+int ssspy_sqrtmh(const void *X, void *out, long long n, int M, int inverse, int floor_kind,
+                 double floor_eps, void *stream);
+/* geometric mean: type 1: A # B; 2: A^-1 # B; 3: A # B^-1.   replaces: ssspy/linalg/mean.py:6-83 */
+int ssspy_gmeanmh(const void *A, const void *Bm, void *G, long long n, int M, int type,
+                  void *stream);
+/* y = argmin of the log-quadratically penalised quadratic (type 2): H (n, L, L) Hermitian, v (n, L),
+ * z (n) -> y (n, L), L in [1, 7], `max_iter` Newton steps per problem.
+ * replaces: ssspy/linalg/lqpqm.py:13-352 (lqpqm2 with singular_fn = "x < flooring_fn(0)"). */
+int ssspy_lqpqm2(const void *H, const void *v, const double *z, void *y, long long n, int L,
+                 int max_iter, int floor_kind, double floor_eps, void *stream);
+
 /* ------------------------------------------------------------------ STFT / ISTFT
  * The transforms the reference's workflow takes from SciPy either side of a separator
  * (tests/package/bss/test_ilrma.py, test_iva.py, test_mnmf.py: scipy.signal.stft(x, window="hann",

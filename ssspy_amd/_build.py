@@ -49,6 +49,7 @@ def _units():
         ("gmnmf_kernels.hip", "gmnmf_kernels.o", []),
         ("ipa_kernels.hip", "ipa_kernels.o", []),
         ("stft_kernels.hip", "stft_kernels.o", []),
+        ("hermitian_ops.hip", "hermitian_ops.o", []),
     ]
     units.append(("mnmf_api.hip", "mnmf_api.o", []))
     for n in MNMF_N:

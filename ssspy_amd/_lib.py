@@ -75,6 +75,10 @@ PROTOTYPES = {
     "ssspy_gmnmf_update": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p, _z, _p]),
     "ssspy_gmnmf_loss": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _d, _p]),
     "ssspy_gmnmf_separate": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p]),
+    "ssspy_eigh_general": (_i, [_p, _p, _p, _p, _q, _i, _i, _p, _p]),
+    "ssspy_sqrtmh": (_i, [_p, _p, _q, _i, _i, _i, _d, _p]),
+    "ssspy_gmeanmh": (_i, [_p, _p, _p, _q, _i, _i, _p]),
+    "ssspy_lqpqm2": (_i, [_p, _p, _p, _p, _q, _i, _i, _i, _d, _p]),
     "ssspy_stft_frames": (_i, [_q, _i, _i]),
     "ssspy_stft": (_i, [_p, _p, _p, _d, _i, _i, _q, _i, _i, _p]),
     "ssspy_istft_samples": (_q, [_i, _i, _i]),

@@ -302,6 +302,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   for (int r = 0; r < L; ++r) Gb[rest_index<S>(r) * N + S] = cmake(q[r].x, -q[r].y);
 }
 
+// standalone LQPQM2 (ssspy.linalg.lqpqm2): H (n, L, L), v (n, L), z (n) -> y (n, L)
+template <int L>
+__global__ __launch_bounds__(64) void k_lqpqm2(const c128 *__restrict__ H, const c128 *__restrict__ v,
+                                               const double *__restrict__ z, c128 *y, long long n,
+                                               int max_iter, int floor_kind, double eps) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  c128 Hm[L][L], vv[L], yy[L];
+#pragma unroll
+  for (int r = 0; r < L; ++r) {
+    vv[r] = v[idx * L + r];
+#pragma unroll
+    for (int c = 0; c < L; ++c) Hm[r][c] = H[(idx * L + r) * L + c];
+  }
+  hermitize<L>(Hm);
+  lqpqm2<L>(Hm, vv, z[idx], floor_kind, eps, max_iter, yy);
+#pragma unroll
+  for (int r = 0; r < L; ++r) y[idx * L + r] = yy[r];
+}
+
 template <int N, int S>
 static int launch_one(const void *Vc, void *G, long long nbins, int normalization, int max_iter,
                       int floor_kind, double eps, int *info, hipStream_t st) {
@@ -340,4 +360,21 @@ extern "C" int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int 
   IPA_CASE(8, 6) IPA_CASE(8, 7)
 #undef IPA_CASE
   return fail(SSSPY_ERR_UNSUPPORTED, "ipa_transform: unsupported (n_sources, source) pair");
+}
+
+extern "C" int ssspy_lqpqm2(const void *H, const void *v, const double *z, void *y, long long n,
+                            int L, int max_iter, int floor_kind, double floor_eps, void *stream) {
+  SSSPY_REQUIRE(H && v && z && y && n > 0 && max_iter >= 0, "lqpqm2: bad argument");
+  if (L < 1 || L > 7) return fail(SSSPY_ERR_UNSUPPORTED, "lqpqm2: dimension must be in [1, 7]");
+  dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  hipStream_t st = as_stream(stream);
+#define LQ_CASE(L_)                                                                          \
+  if (L == L_) {                                                                             \
+    hipLaunchKernelGGL((k_lqpqm2<L_>), grid, block, 0, st, (const c128 *)H, (const c128 *)v, z, \
+                       (c128 *)y, n, max_iter, floor_kind, floor_eps);                       \
+    return check_launch("k_lqpqm2");                                                         \
+  }
+  LQ_CASE(1) LQ_CASE(2) LQ_CASE(3) LQ_CASE(4) LQ_CASE(5) LQ_CASE(6) LQ_CASE(7)
+#undef LQ_CASE
+  return SSSPY_ERR_UNSUPPORTED;
 }

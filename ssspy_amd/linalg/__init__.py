@@ -13,7 +13,7 @@ from .. import _device as dv
 from .. import _lib
 from .._device import ptr
 
-__all__ = ["solve", "inv2", "eigh", "eigh2"]
+__all__ = ["solve", "inv2", "eigh", "eigh2", "sqrtmh", "invsqrtmh", "gmeanmh", "lqpqm2"]
 
 
 def _flat(a, tail):
@@ -66,14 +66,32 @@ def eigh(A: np.ndarray, B: Optional[np.ndarray] = None, type: int = 1
          ) -> Union[np.ndarray, Tuple[np.ndarray, np.ndarray]]:
     """Hermitian (generalised when ``B`` is given) eigen-decomposition, eigenvalues ascending.
 
-    Standard problem: M <= 8, cyclic complex Jacobi on the device.  Generalised problem: built
-    for 2 x 2 (``eigh2``).  Eigenvectors are unit-norm (standard) with an arbitrary phase that
-    differs from LAPACK's.  ref: ssspy/linalg/eigh.py:8-81.
+    M <= 8, cyclic complex Jacobi on the device; the generalised problem goes through the Cholesky
+    factor of ``B`` like the reference (type 1: ``A z = lamb B z``; 2: ``A B z = lamb z``;
+    3: ``B A z = lamb z``).  Eigenvectors carry an arbitrary phase that differs from LAPACK's.
+    ref: ssspy/linalg/eigh.py:8-81, :164-207.
     """
     if B is not None:
-        if np.asarray(A).shape[-1] != 2:
-            raise NotImplementedError("generalised eigh is built for 2 x 2 matrices (eigh2) only.")
-        return eigh2(A, B, type=type)
+        if np.asarray(A).shape[-1] == 2:
+            return eigh2(A, B, type=type)
+        if type not in (1, 2, 3):
+            raise ValueError("Invalid type={} is given.".format(type))
+        A, B = np.asarray(A), np.asarray(B)
+        lead = np.broadcast_shapes(A.shape[:-2], B.shape[:-2])
+        M = A.shape[-1]
+        _, n, Af = _flat(np.broadcast_to(A, lead + (M, M)), 2)
+        _, _, Bf = _flat(np.broadcast_to(B, lead + (M, M)), 2)
+        dA, dB = dv.to_device(Af), dv.to_device(Bf)
+        lamb = dv.empty((n, M), dv.f64, dA.device)
+        Z = dv.empty((n, M, M), dv.c128, dA.device)
+        info = dv.zeros((1,), dv.i32)
+        _lib.check(_lib.load().ssspy_eigh_general(ptr(dA), ptr(dB), ptr(lamb), ptr(Z), n, M, type,
+                                                  ptr(info), dv.stream_handle()), "eigh")
+        if int(info.item()):
+            raise np.linalg.LinAlgError("Matrix is not positive definite")
+        z = dv.to_host(Z).reshape(lead + (M, M))
+        complex_in = np.iscomplexobj(A) or np.iscomplexobj(B)
+        return dv.to_host(lamb).reshape(lead + (M,)), (z if complex_in else z.real)
     A = np.asarray(A)
     lead, n, Af = _flat(A, 2)
     M = Af.shape[-1]
@@ -112,3 +130,73 @@ def eigh2(A: np.ndarray, B: Optional[np.ndarray] = None, type: int = 1
     z = dv.to_host(Z).reshape(lead + (2, 2))
     complex_in = np.iscomplexobj(A) or np.iscomplexobj(B)
     return dv.to_host(lamb).reshape(lead + (2,)), (z if complex_in else z.real)
+
+
+def _hermitian_fn(X, inverse, flooring):
+    X = np.asarray(X)
+    lead, n, Xf = _flat(X, 2)
+    M = Xf.shape[-1]
+    dX = dv.to_device(Xf)
+    out = dv.empty((n, M, M), dv.c128, dX.device)
+    _lib.check(_lib.load().ssspy_sqrtmh(ptr(dX), ptr(out), n, M, int(inverse), flooring[0],
+                                        flooring[1], dv.stream_handle()), "sqrtmh")
+    res = dv.to_host(out).reshape(lead + (M, M))
+    return res if np.iscomplexobj(X) else res.real
+
+
+def sqrtmh(X: np.ndarray) -> np.ndarray:
+    """Square root of positive semidefinite Hermitian matrices (ref: ssspy/linalg/sqrtm.py:8-24)."""
+    return _hermitian_fn(X, False, (_lib.FLOOR_NONE, 0.0))
+
+
+def invsqrtmh(X: np.ndarray, flooring_fn=None) -> np.ndarray:
+    """Inverse square root, ``P diag(1 / flooring_fn(sqrt(lamb))) P^H`` (ref: sqrtm.py:27-64)."""
+    from ..utils.flooring import device_flooring
+
+    return _hermitian_fn(X, True, device_flooring(flooring_fn))
+
+
+def gmeanmh(A: np.ndarray, B: np.ndarray, type: int = 1) -> np.ndarray:
+    """Geometric mean of Hermitian positive definite matrices (ref: ssspy/linalg/mean.py:6-83):
+    type 1: ``A # B``; type 2: ``A^-1 # B``; type 3: ``A # B^-1``."""
+    if type not in (1, 2, 3):
+        raise ValueError("Invalid type={} is given.".format(type))
+    A, B = np.asarray(A), np.asarray(B)
+    lead = np.broadcast_shapes(A.shape[:-2], B.shape[:-2])
+    M = A.shape[-1]
+    _, n, Af = _flat(np.broadcast_to(A, lead + (M, M)), 2)
+    _, _, Bf = _flat(np.broadcast_to(B, lead + (M, M)), 2)
+    dA, dB = dv.to_device(Af), dv.to_device(Bf)
+    G = dv.empty((n, M, M), dv.c128, dA.device)
+    _lib.check(_lib.load().ssspy_gmeanmh(ptr(dA), ptr(dB), ptr(G), n, M, type, dv.stream_handle()),
+               "gmeanmh")
+    res = dv.to_host(G).reshape(lead + (M, M))
+    return res if (np.iscomplexobj(A) or np.iscomplexobj(B)) else res.real
+
+
+def lqpqm2(H: np.ndarray, v: np.ndarray, z: np.ndarray, flooring_fn="default",
+           singular_fn="flooring", max_iter: int = 10) -> np.ndarray:
+    """Log-quadratically penalised quadratic minimisation, type 2 (ref: ssspy/linalg/lqpqm.py:13-110).
+
+    H (n_bins, L, L) Hermitian, v (n_bins, L), z (n_bins,) -> y (n_bins, L).  Every problem runs
+    ``max_iter`` Newton steps; ``singular_fn`` must be the reference's default ("flooring").
+    """
+    import functools
+
+    from ..special.flooring import max_flooring
+    from ..utils.flooring import device_flooring
+
+    if singular_fn != "flooring":
+        raise NotImplementedError("singular_fn other than 'flooring' is not built for the device path.")
+    if isinstance(flooring_fn, str) and flooring_fn == "default":
+        flooring_fn = functools.partial(max_flooring, eps=1e-10)
+    floor = device_flooring(flooring_fn)
+    H, v, z = np.asarray(H), np.asarray(v), np.asarray(z, dtype=np.float64)
+    n, L = v.shape
+    dH = dv.to_device(np.ascontiguousarray(H, dtype=np.complex128))
+    dvv = dv.to_device(np.ascontiguousarray(v, dtype=np.complex128))
+    dz = dv.to_device(np.ascontiguousarray(z))
+    y = dv.empty((n, L), dv.c128, dH.device)
+    _lib.check(_lib.load().ssspy_lqpqm2(ptr(dH), ptr(dvv), ptr(dz), ptr(y), n, L, int(max_iter),
+                                        floor[0], floor[1], dv.stream_handle()), "lqpqm2")
+    return dv.to_host(y)

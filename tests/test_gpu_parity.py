@@ -873,3 +873,92 @@ def test_waveform_to_waveform_stays_on_device():
     Y2 = GaussILRMA(n_basis=3)(Zr, n_iter=3, basis=basis, activation=act)
     _, yr = ss.istft(Y2, window="hann", nperseg=256, noverlap=192)
     assert rel_err(yd.cpu().numpy(), yr) < 1e-9
+
+
+# ------------------------------------------------------------ Hermitian matrix functions (linalg)
+def _psd(rng, lead, M, T=32, complex_=True):
+    x = rng.standard_normal(lead + (M, T))
+    if complex_:
+        x = x + 1j * rng.standard_normal(lead + (M, T))
+    return np.mean(x[..., :, None, :] * x[..., None, :, :].conj(), axis=-1)
+
+
+@pytest.mark.parametrize("M", [3, 4, 6, 8])
+@pytest.mark.parametrize("type", [1, 2, 3])
+def test_generalized_eigh(M, type):
+    """The reference's property checks for the generalised problem (tests/package/linalg/test_eigh.py),
+    beyond 2 x 2; eigenvalues also against the Cholesky route in NumPy."""
+    from ssspy_amd.linalg import eigh
+
+    rng = np.random.default_rng(111 + M)
+    A, B = _psd(rng, (5,), M), _psd(rng, (5,), M)
+    lamb, z = eigh(A, B, type=type)
+    assert lamb.shape == (5, M) and z.shape == (5, M, M)
+    assert np.all(np.diff(lamb, axis=-1) >= 0)
+    if type == 1:
+        lhs, rhs = A @ z, lamb[:, None, :] * (B @ z)
+    elif type == 2:
+        lhs, rhs = A @ B @ z, lamb[:, None, :] * z
+    else:
+        lhs, rhs = B @ A @ z, lamb[:, None, :] * z
+    assert rel_err(lhs, rhs) < 1e-11
+    L = np.linalg.cholesky(B)
+    Li = np.linalg.inv(L)
+    C = Li @ A @ Li.swapaxes(-2, -1).conj() if type == 1 else L.swapaxes(-2, -1).conj() @ A @ L
+    np.testing.assert_allclose(lamb, np.linalg.eigvalsh(C), rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize("M", [3, 4])
+@pytest.mark.parametrize("is_complex", [True, False])
+def test_sqrtmh_invsqrtmh(M, is_complex):
+    """tests/package/linalg/test_sqrtm.py on the device."""
+    from ssspy_amd.linalg import invsqrtmh, sqrtmh
+    from ssspy_amd.special.flooring import max_flooring
+
+    rng = np.random.default_rng(0)
+    X = _psd(rng, (2,), M, complex_=is_complex)
+    S = sqrtmh(X)
+    assert S.dtype == X.dtype and rel_err(S @ S, X) < 1e-12
+    for flooring_fn in (None, functools.partial(max_flooring, eps=1e-10)):
+        Xi = invsqrtmh(X, flooring_fn=flooring_fn)
+        assert rel_err(np.linalg.inv(Xi) @ np.linalg.inv(Xi), X) < 1e-10
+
+
+@pytest.mark.parametrize("type", [1, 2, 3])
+def test_gmeanmh(type):
+    """tests/package/linalg/test_gmean.py: the Riccati property of each type, same data."""
+    from ssspy_amd.linalg import gmeanmh
+
+    rng = np.random.default_rng(0)
+    size = (16, 32, 4, 1)
+
+    def create_psd():
+        x = rng.random(size) + 1j * rng.random(size)
+        return np.mean(x * x.transpose(0, 1, 3, 2).conj(), axis=0)
+
+    A, B = create_psd(), create_psd()
+    G = gmeanmh(A, B, type=type)
+    if type == 1:
+        assert np.allclose(G @ np.linalg.inv(A) @ G, B)
+    elif type == 2:
+        assert np.allclose(G @ A @ G, B)
+    else:
+        assert np.allclose(G @ np.linalg.inv(A) @ G, np.linalg.inv(B))
+    assert rel_err(G, G.swapaxes(-2, -1).conj()) < 1e-13
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 5, 7])
+def test_lqpqm2_against_oracle(L):
+    from oracle.ipa import lqpqm2 as oracle_lqpqm2
+    from ssspy_amd.linalg import lqpqm2
+
+    rng = np.random.default_rng(40 + L)
+    n = 33
+    H = _psd(rng, (n,), L, T=12)
+    H = H / np.real(np.trace(H, axis1=-2, axis2=-1))[:, None, None]
+    v = rng.standard_normal((n, L)) + 1j * rng.standard_normal((n, L))
+    z = rng.random(n) * 2.0
+    for max_iter in (1, 10):
+        y = lqpqm2(H, v, z, max_iter=max_iter)
+        yr = np.stack([oracle_lqpqm2(H[i], v[i], z[i], ("max", 1e-10), max_iter) for i in range(n)])
+        assert rel_err(y, yr) < 1e-10
