@@ -9,7 +9,7 @@ namespace ssspy {
 
 // Hermitian eigen-decomposition by cyclic complex Jacobi rotations: A = P diag(lam) P^H, with lam
 // left on the diagonal of A.  Straight-line sweeps (no data-dependent branches inside a sweep);
-// the sweep loop ends when every lane of the wave has a negligible off-diagonal, at most 10 sweeps.
+// the sweep loop ends when every lane of the wave has a negligible off-diagonal, at most 12 sweeps.
 template <int M>
 __device__ __forceinline__ void jacobi_eigh(c128 (&A)[M][M], c128 (&P)[M][M]) {
 #pragma unroll
@@ -17,7 +17,7 @@ __device__ __forceinline__ void jacobi_eigh(c128 (&A)[M][M], c128 (&P)[M][M]) {
 #pragma unroll
     for (int cc = 0; cc < M; ++cc) P[r][cc] = cmake(r == cc ? 1.0 : 0.0, 0.0);
 #pragma unroll 1
-  for (int sweep = 0; sweep < 10; ++sweep) {
+  for (int sweep = 0; sweep < 12; ++sweep) {
     double off = 0.0, diag = 0.0;
 #pragma unroll
     for (int p = 0; p < M; ++p) {

@@ -1,81 +1,10 @@
 // Batched small dense linear algebra (one matrix per lane): solve, inv2, Hermitian eigh,
 // generalised 2x2 eigh, PSD projection.  Device counterparts of ssspy.linalg / ssspy.special.psd.
 #include "common.hpp"
+#include "hermitian.hpp"
 #include "smallmat.hpp"
 
 namespace ssspy {
-
-// cyclic complex Jacobi (see mnmf_kernels.hip for the rotation algebra): A = P diag(A_kk) P^H
-template <int M>
-__device__ __forceinline__ void jacobi_eigh_la(c128 (&A)[M][M], c128 (&P)[M][M], int sweeps) {
-#pragma unroll
-  for (int r = 0; r < M; ++r)
-#pragma unroll
-    for (int cc = 0; cc < M; ++cc) P[r][cc] = cmake(r == cc ? 1.0 : 0.0, 0.0);
-#pragma unroll 1
-  for (int sweep = 0; sweep < sweeps; ++sweep) {
-#pragma unroll
-    for (int p = 0; p < M - 1; ++p)
-#pragma unroll
-      for (int qq = p + 1; qq < M; ++qq) {
-        const c128 apq = A[p][qq];
-        const double mag2 = cabs2(apq);
-        const double mag = sqrt(mag2);
-        const bool tiny = mag2 < 1e-300;
-        const double inv = tiny ? 0.0 : 1.0 / mag;
-        const c128 u = tiny ? cmake(1.0, 0.0) : cmake(apq.x * inv, apq.y * inv);
-        const double app = A[p][p].x, aqq = A[qq][qq].x;
-        const double tau = tiny ? 0.0 : (aqq - app) * 0.5 * inv;
-        const double t = tiny ? 0.0 : ((tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau)));
-        const double cs = 1.0 / sqrt(1.0 + t * t);
-        const double sn = t * cs;
-        const c128 su = cmake(sn * u.x, sn * u.y);
-        const c128 sub = cmake(sn * u.x, -sn * u.y);
-#pragma unroll
-        for (int k = 0; k < M; ++k) {
-          if (k != p && k != qq) {
-            const c128 akp = A[k][p], akq = A[k][qq];
-            c128 nkp = cmake(cs * akp.x, cs * akp.y);
-            cfms(nkp, sub, akq);
-            c128 nkq = cmake(cs * akq.x, cs * akq.y);
-            cfma(nkq, su, akp);
-            A[k][p] = nkp;
-            A[p][k] = cconj(nkp);
-            A[k][qq] = nkq;
-            A[qq][k] = cconj(nkq);
-          }
-        }
-        A[p][p] = cmake(app - t * mag, 0.0);
-        A[qq][qq] = cmake(aqq + t * mag, 0.0);
-        A[p][qq] = cmake(0.0, 0.0);
-        A[qq][p] = cmake(0.0, 0.0);
-#pragma unroll
-        for (int k = 0; k < M; ++k) {
-          const c128 vkp = P[k][p], vkq = P[k][qq];
-          c128 nkp = cmake(cs * vkp.x, cs * vkp.y);
-          cfms(nkp, sub, vkq);
-          c128 nkq = cmake(cs * vkq.x, cs * vkq.y);
-          cfma(nkq, su, vkp);
-          P[k][p] = nkp;
-          P[k][qq] = nkq;
-        }
-      }
-  }
-}
-
-template <int M>
-__device__ __forceinline__ void hermitize(c128 (&A)[M][M]) {
-#pragma unroll
-  for (int r = 0; r < M; ++r) {
-    A[r][r] = cmake(A[r][r].x, 0.0);
-#pragma unroll
-    for (int cc = r + 1; cc < M; ++cc) {
-      const c128 h = cmake(0.5 * (A[r][cc].x + A[cc][r].x), 0.5 * (A[r][cc].y - A[cc][r].y));
-      A[r][cc] = h;
-      A[cc][r] = cconj(h);
-    }
-  }
-}
 
 // X = A^-1 B, B (N x nrhs)
 template <int N>
@@ -126,7 +55,7 @@ __global__ __launch_bounds__(64) void k_eigh(const c128 *__restrict__ A, double 
 #pragma unroll
     for (int c = 0; c < M; ++c) Am[r][c] = A[(idx * M + r) * M + c];
   hermitize<M>(Am);
-  jacobi_eigh_la<M>(Am, P, M <= 2 ? 2 : 12);
+  jacobi_eigh<M>(Am, P);
   if (mode == 0) {
     // rank of every eigenvalue (ties broken by index) -> ascending order without dynamic indexing
 #pragma unroll
@@ -208,7 +137,7 @@ __global__ __launch_bounds__(256) void k_eigh2(const c128 *__restrict__ A, const
     Cm[1][1] = cscale(m11, l11);
   }
   hermitize<2>(Cm);
-  jacobi_eigh_la<2>(Cm, P, 2);
+  jacobi_eigh<2>(Cm, P);
   const bool swap = Cm[1][1].x < Cm[0][0].x;
   const int k0 = swap ? 1 : 0, k1 = swap ? 0 : 1;
   lamb[idx * 2] = swap ? Cm[1][1].x : Cm[0][0].x;
