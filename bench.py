@@ -144,7 +144,7 @@ def main():
     def fence():
         torch.cuda.synchronize()
         if distributed:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     # warm-up (untimed)
