@@ -52,6 +52,22 @@ inline int check_launch(const char *what) {
 
 // ---------------------------------------------------------------- complex arithmetic
 __device__ __forceinline__ c128 cmake(double re, double im) { return make_double2(re, im); }
+
+// Two consecutive doubles of a real row, as one 16-byte load that only needs 8-byte alignment (rows
+// of an odd length start on odd multiples of 8 bytes; gfx950 global loads are dword-aligned).  The
+// second element is read only when it belongs to the row: (p[0], p[1]) if j + 1 < len,
+// (p[0], 0) if j + 1 == len, zeros beyond.
+typedef double double2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ double2 load_pair_in_row(const double *__restrict__ row, int j, int len) {
+  double2 val = make_double2(0.0, 0.0);
+  if (j + 1 < len) {
+    const double2_a8 v = *reinterpret_cast<const double2_a8 *>(row + j);
+    val = make_double2(v.x, v.y);
+  } else if (j < len) {
+    val.x = row[j];
+  }
+  return val;
+}
 __device__ __forceinline__ c128 cadd(c128 a, c128 b) { return cmake(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ c128 csub(c128 a, c128 b) { return cmake(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ c128 cconj(c128 a) { return cmake(a.x, -a.y); }

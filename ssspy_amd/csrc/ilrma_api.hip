@@ -20,7 +20,7 @@ namespace ssspy {
 DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
 #undef DECL_N
 
-// throughput variants (ilrma_fast.hip): domain == 2, n_basis <= 16, n_sources <= 4, even T
+// throughput variants (ilrma_fast.hip): domain == 2, n_basis <= 16, n_sources <= 4
 #define DECL_FAST(n)                                                                           \
   int ilrma_fast_basis_n##n(const void *, const void *, double *, const double *, int, int, int, \
                             int, int, double, double *, int, double, int, hipStream_t);        \
@@ -40,13 +40,13 @@ DECL_FAST(2) DECL_FAST(3) DECL_FAST(4)
     default: return fn##_n4(__VA_ARGS__);            \
   }
 
-// the tuned kernels: domain 2, Gauss or Student-t model (MM or ME), n_sources <= 4, n_basis <= 16,
-// even n_frames; `source_model` may carry the SSSPY_SOURCE_ME flag
+// the tuned kernels: domain 2, Gauss or Student-t model (MM or ME), n_sources <= 4, n_basis <= 16;
+// `source_model` may carry the SSSPY_SOURCE_ME flag
 static inline bool fast_path(int N, int T, int K, double domain, int source_model = SSSPY_SOURCE_GAUSS) {
   static const bool disabled = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;
   const int base = source_model & 0xff;
   return !disabled && (base == SSSPY_SOURCE_GAUSS || base == SSSPY_SOURCE_T) && N >= 2 && N <= 4 &&
-         K <= 16 && (T % 2 == 0) && domain == 2.0;
+         K <= 16 && domain == 2.0;
 }
 static inline int is_t(int source_model) { return (source_model & 0xff) == SSSPY_SOURCE_T; }
 static inline int is_me(int source_model) { return (source_model & SSSPY_SOURCE_ME) ? 1 : 0; }

@@ -1,5 +1,5 @@
 // Throughput kernels of the Gauss-ILRMA iteration for the common case
-//   domain == 2, n_basis <= 16, n_sources <= 4, n_frames even.
+//   domain == 2, n_basis <= 16, n_sources <= 4.
 // Same math and MFMA tilings as ilrma_kernels.hip (see the header comment there); what
 // changes is the scheduling, driven by the first rocprof PMC pass on MI355X (profiles/):
 // the generic kernels sat in s_waitcnt 71 % of the time at one wave per SIMD because every
@@ -133,8 +133,7 @@ __device__ __forceinline__ void vstage_load(VStage &st, const double *__restrict
     const int n = row >> 4, k = row & 15;
     const int j = j0 + 2 * chunk;
     double2 val = make_double2(0.0, 0.0);
-    if (idx < N * 16 * 8 && k < K && j < T)  // T even and j even: j+1 < T as well
-      val = *reinterpret_cast<const double2 *>(act_b + ((long long)n * K + k) * T + j);
+    if (idx < N * 16 * 8 && k < K) val = load_pair_in_row(act_b + ((long long)n * K + k) * T, j, T);
     st.v[u] = val;
   }
 }

@@ -509,8 +509,7 @@ __device__ __forceinline__ void vstage_load(VStage &st, const double *__restrict
     const int n = row >> 4, k = row & 15;
     const int j = j0 + 2 * chunk;
     double2 val = make_double2(0.0, 0.0);
-    if (idx < N * 16 * 8 && k < K && j < T)
-      val = *reinterpret_cast<const double2 *>(act_b + ((long long)n * K + k) * T + j);
+    if (idx < N * 16 * 8 && k < K) val = load_pair_in_row(act_b + ((long long)n * K + k) * T, j, T);
     st.v[u] = val;
   }
 }
@@ -1144,7 +1143,7 @@ constexpr int cov_lds_mm() {
 // the batch supplies >= 2 workgroups per CU (measured: +15 % at 64 mixtures, -45 % at 1).
 static inline bool mnmf_fast_ok(int B, int F, int T, int K) {
   static const bool disabled = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;
-  return !disabled && K <= 16 && (T % 2 == 0) && (long long)B * ((F + 63) / 64) >= 512;
+  return !disabled && K <= 16 && (long long)B * ((F + 63) / 64) >= 512;
 }
 
 int LAUNCHER(mnmf_basis)(const void *X, const void *Q, const double *Dsp, const double *basis,

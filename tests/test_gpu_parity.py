@@ -797,17 +797,19 @@ def test_fast_gauss_mnmf_config4_full_size_properties():
 
 
 # ------------------------------------------------------------------------------- large-batch code paths
-def test_large_batch_paths_against_oracle():
+@pytest.mark.parametrize("T", [32, 33])
+def test_large_batch_paths_against_oracle(T):
     """With >= 512 workgroups per launch the kernels switch to their large-batch form (no frame
     chunking in the ILRMA fast path, bin-split FastMNMF kernels) -- the one bench.py times.  600 tiny
-    mixtures; first, middle and last are checked against the oracle."""
+    mixtures; first, middle and last are checked against the oracle.  T = 33: rows of an odd length
+    (activation rows that start 8 bytes off a 16-byte boundary, last row ending the buffer)."""
     from oracle.ilrma import GaussILRMAOracle
     from oracle.mnmf import FastGaussMNMFOracle
     from ssspy_amd.bss.ilrma import GaussILRMA
     from ssspy_amd.bss.mnmf import FastGaussMNMF
     from ssspy_amd.utils.dataset import nmf_mixture
 
-    B, N, F, T, K = 600, 3, 18, 32, 4
+    B, N, F, K = 600, 3, 18, 4
     rng = np.random.default_rng(5)
     X = np.stack([nmf_mixture(7000 + b, N, F, T) for b in range(B)])
     basis, act = rng.random((B, N, F, K)), rng.random((B, N, K, T))

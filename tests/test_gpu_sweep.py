@@ -79,7 +79,7 @@ def test_ilrma_option_sweep(chunk):
     cases = ILRMA_SWEEP[chunk::8]
     assert len(ILRMA_SWEEP) > 600
     for idx, (model, part, algo, src, norm, scale) in enumerate(cases):
-        N, F, T, K = (3, 9, 26, 4) if idx % 2 else (2, 8, 24, 3)
+        N, F, T, K = (3, 9, 25, 4) if idx % 2 else (2, 8, 24, 3)
         X = _mixture(300 + idx, N, F, T)
         rng = np.random.default_rng(idx)
         lead = () if part else (N,)
@@ -183,11 +183,12 @@ def test_fast_gauss_mnmf_option_sweep():
 
 @pytest.mark.parametrize("shape", [(2, 1, 2, 1), (2, 5, 7, 1), (3, 16, 16, 16), (4, 17, 18, 16),
                                    (4, 64, 1024, 16), (2, 1025, 2, 3), (4, 15, 510, 9), (8, 3, 33, 2),
-                                   (4, 129, 66, 64)])
+                                   (4, 129, 66, 64), (4, 70, 513, 16), (3, 33, 31, 5), (2, 20, 3, 2),
+                                   (4, 16, 17, 16)])
 @pytest.mark.parametrize("algo", ["IP", "ISS"])
 def test_gauss_ilrma_edge_shapes(shape, algo):
     """Tiny, ragged and lopsided shapes: one bin, two frames, tiles with a single valid row or
-    column, n_basis 1 and 64, odd n_frames (generic kernels) next to even (tuned kernels)."""
+    column, n_basis 1 and 64, odd and even n_frames."""
     from oracle.ilrma import GaussILRMAOracle
     from ssspy_amd.bss.ilrma import GaussILRMA
 
