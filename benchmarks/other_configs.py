@@ -35,92 +35,106 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--only", default="", help="comma-separated subset of iva_iss,ilrma_iss,fastmnmf,gmnmf")
     args = ap.parse_args()
+    only = [t for t in args.only.split(",") if t]
+
+    def want(tag):
+        return not only or tag in only
+
+    B = args.batch
     from ssspy_amd.bss.iva import AuxLaplaceIVA
     from ssspy_amd.bss.mnmf import FastGaussMNMF, GaussMNMF
 
-    # configs[2]: AuxIVA-ISS, 8 sources
-    N, F, T = 8, 2049, 1024
-    X = nmf_mixture(3000, N, F, T)
-    if args.batch > 1:
-        X = np.stack([X] * args.batch)
-    m = AuxLaplaceIVA(spatial_algorithm="ISS", record_loss=False)
-    m._contrast = 0
-    m._bind_input(X)
-    m._reset()
-    for _ in range(3):
-        m.update_once()
-    dt = timed(m.update_once, args.iters)
-    B = args.batch
-    print(json.dumps({"config": "configs[2] AuxLaplaceIVA-ISS N=8 F=2049 T=1024 batch={}".format(B),
-                      "ms_per_iter": round(dt * 1e3, 3), "mixture_iterations_per_s": round(B / dt, 2),
-                      "algorithmic_GBs": round(2 * 16 * N * F * T * B / dt / 1e9, 1)}))
-    del m
-    torch.cuda.empty_cache()
+    if want("iva_iss"):
+        # configs[2]: AuxIVA-ISS, 8 sources
+        N, F, T = 8, 2049, 1024
+        X = nmf_mixture(3000, N, F, T)
+        if args.batch > 1:
+            X = np.stack([X] * args.batch)
+        m = AuxLaplaceIVA(spatial_algorithm="ISS", record_loss=False)
+        m._contrast = 0
+        m._bind_input(X)
+        m._reset()
+        for _ in range(3):
+            m.update_once()
+        dt = timed(m.update_once, args.iters)
+        print(json.dumps({"config": "configs[2] AuxLaplaceIVA-ISS N=8 F=2049 T=1024 batch={}".format(B),
+                          "ms_per_iter": round(dt * 1e3, 3), "mixture_iterations_per_s": round(B / dt, 2),
+                          "algorithmic_GBs": round(2 * 16 * N * F * T * B / dt / 1e9, 1)}))
+        del m
+        torch.cuda.empty_cache()
 
-    # configs[1] shape with the ISS update (state is the separated spectrogram, no filter)
-    from ssspy_amd.bss.ilrma import GaussILRMA
+    if want("ilrma_iss"):
+        # configs[1] shape with the ISS update (state is the separated spectrogram, no filter)
+        from ssspy_amd.bss.ilrma import GaussILRMA
 
-    N, F, T, K = 4, 1025, 512, 16
-    X = nmf_mixture(1000, N, F, T)
-    if args.batch > 1:
-        X = np.stack([X] * args.batch)
-    m = GaussILRMA(n_basis=K, spatial_algorithm="ISS", record_loss=False, rng=np.random.default_rng(0))
-    m._bind_input(X)
-    m._reset(flooring_fn=m.flooring_fn)
-    for _ in range(3):
-        m.update_once()
-    dt = timed(m.update_once, args.iters)
-    print(json.dumps({"config": "GaussILRMA-ISS N=4 F=1025 T=512 K=16 batch={}".format(B),
-                      "ms_per_iter": round(dt * 1e3, 3), "mixture_iterations_per_s": round(B / dt, 2)}))
-    del m
-    torch.cuda.empty_cache()
+        N, F, T, K = 4, 1025, 512, 16
+        X = nmf_mixture(1000, N, F, T)
+        if args.batch > 1:
+            X = np.stack([X] * args.batch)
+        m = GaussILRMA(n_basis=K, spatial_algorithm="ISS", record_loss=False, rng=np.random.default_rng(0))
+        m._bind_input(X)
+        m._reset(flooring_fn=m.flooring_fn)
+        for _ in range(3):
+            m.update_once()
+        dt = timed(m.update_once, args.iters)
+        print(json.dumps({"config": "GaussILRMA-ISS N=4 F=1025 T=512 K=16 batch={}".format(B),
+                          "ms_per_iter": round(dt * 1e3, 3), "mixture_iterations_per_s": round(B / dt, 2)}))
+        del m
+        torch.cuda.empty_cache()
 
-    # configs[3]: FastGaussMNMF
-    M, F, T, K = 4, 1025, 512, 8
-    X = nmf_mixture(4000, M, F, T)
-    if args.batch > 1:
-        X = np.stack([X] * args.batch)
-    m = FastGaussMNMF(n_basis=K, record_loss=False, rng=np.random.default_rng(0))
-    m._bind_input(X)
-    t0 = time.perf_counter()
-    m._reset()
-    torch.cuda.synchronize()
-    t_reset = time.perf_counter() - t0
-    for _ in range(3):
-        m.update_once()
-    dt = timed(m.update_once, args.iters)
-    ds = timed(m._separate_dev, 3)
-    print(json.dumps({"config": "configs[3] FastGaussMNMF-IP1 N=M=4 F=1025 T=512 K=8 batch={}".format(B),
-                      "ms_per_iter": round(dt * 1e3, 3), "mixture_iterations_per_s": round(B / dt, 2),
-                      "algorithmic_GBs": round(4 * 16 * M * F * T * B / dt / 1e9, 1),
-                      "wiener_separate_ms": round(ds * 1e3, 3), "reset_s": round(t_reset, 3)}))
-    del m
-    torch.cuda.empty_cache()
-
-    # GaussMNMF (full-rank SCM) on the configs[3] shape; the CPU figure is the oracle on a
-    # 1/16-size slice of the same mixture scaled up (the full shape needs ~10 GB of temporaries)
-    m = GaussMNMF(n_basis=K, record_loss=False, rng=np.random.default_rng(0))
-    m._bind_input(X)
-    m._reset()
-    for _ in range(2):
-        m.update_once()
-    dt = timed(m.update_once, max(3, args.iters // 4))
-    ds = timed(m._separate_dev, 3)
-    out = {"config": "GaussMNMF N=M=4 F=1025 T=512 K=8 batch={}".format(B),
-           "ms_per_iter": round(dt * 1e3, 3), "mixture_iterations_per_s": round(B / dt, 2),
-           "wiener_separate_ms": round(ds * 1e3, 3)}
-    if args.batch == 1:
-        from oracle.gmnmf import GaussMNMFOracle
-
-        Fs = 64
-        ref = GaussMNMFOracle(n_basis=K, record_loss=False, rng=np.random.default_rng(0))
-        ref.reset(X[:, :Fs, :])
-        ref.update_once()
+    if want("fastmnmf"):
+        # configs[3]: FastGaussMNMF
+        M, F, T, K = 4, 1025, 512, 8
+        X = nmf_mixture(4000, M, F, T)
+        if args.batch > 1:
+            X = np.stack([X] * args.batch)
+        m = FastGaussMNMF(n_basis=K, record_loss=False, rng=np.random.default_rng(0))
+        m._bind_input(X)
         t0 = time.perf_counter()
-        ref.update_once()
-        out["cpu_oracle_s_per_iter_extrapolated"] = round((time.perf_counter() - t0) * F / Fs, 2)
-    print(json.dumps(out))
+        m._reset()
+        torch.cuda.synchronize()
+        t_reset = time.perf_counter() - t0
+        for _ in range(3):
+            m.update_once()
+        dt = timed(m.update_once, args.iters)
+        ds = timed(m._separate_dev, 3)
+        print(json.dumps({"config": "configs[3] FastGaussMNMF-IP1 N=M=4 F=1025 T=512 K=8 batch={}".format(B),
+                          "ms_per_iter": round(dt * 1e3, 3), "mixture_iterations_per_s": round(B / dt, 2),
+                          "algorithmic_GBs": round(4 * 16 * M * F * T * B / dt / 1e9, 1),
+                          "wiener_separate_ms": round(ds * 1e3, 3), "reset_s": round(t_reset, 3)}))
+        del m
+        torch.cuda.empty_cache()
+
+    if want("gmnmf"):
+        # GaussMNMF (full-rank SCM) on the configs[3] shape; the CPU figure is the oracle on a
+        # 1/16-size slice of the same mixture scaled up (the full shape needs ~10 GB of temporaries)
+        M, F, T, K = 4, 1025, 512, 8
+        X = nmf_mixture(4000, M, F, T)
+        if args.batch > 1:
+            X = np.stack([X] * args.batch)
+        m = GaussMNMF(n_basis=K, record_loss=False, rng=np.random.default_rng(0))
+        m._bind_input(X)
+        m._reset()
+        for _ in range(2):
+            m.update_once()
+        dt = timed(m.update_once, max(3, args.iters // 4))
+        ds = timed(m._separate_dev, 3)
+        out = {"config": "GaussMNMF N=M=4 F=1025 T=512 K=8 batch={}".format(B),
+               "ms_per_iter": round(dt * 1e3, 3), "mixture_iterations_per_s": round(B / dt, 2),
+               "wiener_separate_ms": round(ds * 1e3, 3)}
+        if args.batch == 1:
+            from oracle.gmnmf import GaussMNMFOracle
+
+            Fs = 64
+            ref = GaussMNMFOracle(n_basis=K, record_loss=False, rng=np.random.default_rng(0))
+            ref.reset(X[:, :Fs, :])
+            ref.update_once()
+            t0 = time.perf_counter()
+            ref.update_once()
+            out["cpu_oracle_s_per_iter_extrapolated"] = round((time.perf_counter() - t0) * F / Fs, 2)
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":

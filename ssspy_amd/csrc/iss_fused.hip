@@ -6,8 +6,15 @@
 // workgroup: thread t keeps its FPT frames of all N rows in VGPRs, so the N sequential rank-1 sweeps
 // run on chip; per sweep only 3N reals (num_{n'} complex, den_{n'} real) cross lanes:
 //   row-level  : 4 DPP butterfly steps inside each 16-lane row (full-rate VALU, no LDS traffic)
-//   block-level: 16 row partials through LDS, one barrier, totals broadcast with v_readlane so the
-//                steering coefficients v_{n'} are wave-uniform scalars in the update.
+//   block-level: 16 row partials through LDS, one barrier; lane n' < N adds up the partials of its
+//                source and forms the steering coefficient v_{n'} (one divide / square root per
+//                sweep instead of N in every thread: 7.4 -> 6.4 ms at configs[2] x 32 mixtures),
+//                v_readlane then hands the N coefficients to every thread as wave-uniform scalars.
+// Tried and dropped (profiles/r01_other_configs.txt): 512-thread workgroups that prefetch the next
+// bin's slab with LDS-direct loads (global_load_lds_dwordx4, 128 KB of LDS) while sweeping the
+// current one -- the load latency hides, but the cross-lane reduction (12 DPP/add instructions per
+// value and wave, independent of the frames per thread) doubles per SIMD and the kernel got slower
+// (8.1 ms).
 // While the updated slab is written back, |y|^2 is accumulated per (source, frame) over the bins of
 // the block and added atomically to r2_next: the frame powers r_nj^2 of the NEXT iteration's
 // auxiliary weights, which would otherwise need their own pass over Y (2 passes).
@@ -37,27 +44,75 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// All-reduce NV per-thread doubles over a 256-thread block; on return v[k] holds the block total in
-// every thread (wave-uniform).  `part` is 16 * NV doubles of LDS; callers alternate two buffers so
-// one barrier per call suffices.
-template <int NV>
-__device__ __forceinline__ void block_allsum(double (&v)[NV], double *part) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// The N sequential rank-1 sweeps of one bin on the register-resident slab y[n][f] (thread-owned
+// frames), weights phi[n][f]; `part` is the two-buffer LDS scratch of the block reduction (one barrier per sweep), `parity` its state.
+// ref: ssspy/bss/_update_spatial_model.py:146-194.
+template <int N, int FPT, int NW>
+__device__ __forceinline__ void iss_sweeps(c128 (&y)[N][FPT], const double (&phi)[N][FPT],
+                                           double (*part)[NW * 4 * 3 * N], int &parity, double invT,
+                                           int floor_kind, double eps) {
 #pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = row_allsum(v[k]);
-  if ((lane & 15) == 0) {
-    double *dst = part + (wave * 4 + (lane >> 4)) * NV;
+  for (int n = 0; n < N; ++n) {
+    // per source s: sum_j phi_s y_s conj(y_n) (complex) and sum_j phi_s |y_n|^2, SGR sources at a
+    // time (register budget).  Block totals: 16-lane rows by DPP, row partials through LDS; lane
+    // s < N then owns source s: it adds up the partials of its three sums and forms the steering
+    // coefficient v_s, which v_readlane hands to every thread as a wave-uniform scalar (SGPR
+    // operands of the update)
+    constexpr int SGR = N > 4 ? 4 : N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *pp = part[parity];
+    parity ^= 1;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) dst[k] = v[k];
+    for (int s0 = 0; s0 < N; s0 += SGR) {
+      double red[3 * SGR];
+#pragma unroll
+      for (int k = 0; k < 3 * SGR; ++k) red[k] = 0.0;
+#pragma unroll
+      for (int f = 0; f < FPT; ++f) {
+        const c128 yn = y[n][f];
+        const double pn = cabs2(yn);
+#pragma unroll
+        for (int ss = 0; ss < SGR; ++ss) {
+          const int s = s0 + ss < N ? s0 + ss : N - 1;
+          const double w = phi[s][f];
+          const c128 z = cmulc(y[s][f], yn);
+          red[3 * ss] = fma(w, z.x, red[3 * ss]);
+          red[3 * ss + 1] = fma(w, z.y, red[3 * ss + 1]);
+          red[3 * ss + 2] = fma(w, pn, red[3 * ss + 2]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3 * SGR; ++k) red[k] = row_allsum(red[k]);
+      if ((lane & 15) == 0) {
+        double *dst = pp + (wave * 4 + (lane >> 4)) * (3 * N) + 3 * s0;
+#pragma unroll
+        for (int k = 0; k < 3 * SGR; ++k)
+          if (3 * s0 + k < 3 * N) dst[k] = red[k];
+      }
+    }
+    __syncthreads();
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    if (lane < N) {
+#pragma unroll
+      for (int p = 0; p < NW * 4; ++p) {
+        t0 += pp[p * (3 * N) + 3 * lane];
+        t1 += pp[p * (3 * N) + 3 * lane + 1];
+        t2 += pp[p * (3 * N) + 3 * lane + 2];
+      }
+    }
+    const double den = apply_floor(t2 * invT, floor_kind, eps);
+    const double vx = lane == n ? 1.0 - 1.0 / sqrt(den) : t0 * invT / den;
+    const double vy = lane == n ? 0.0 : t1 * invT / den;
+    c128 v[N];
+#pragma unroll
+    for (int s = 0; s < N; ++s) v[s] = cmake(readlane_f64(vx, s), readlane_f64(vy, s));
+#pragma unroll
+    for (int f = 0; f < FPT; ++f) {
+      const c128 yn = y[n][f];
+#pragma unroll
+      for (int s = 0; s < N; ++s) cfms(y[s][f], v[s], yn);
+    }
   }
-  __syncthreads();
-  double tot = 0.0;
-  if (lane < NV) {
-#pragma unroll
-    for (int p = 0; p < 16; ++p) tot += part[p * NV + lane];
-  }
-#pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = readlane_f64(tot, k);
 }
 
 // grid: (ceil(F / bins_per_block), B); 256 threads; thread t owns frames t + 256 f, f < FPT.
@@ -66,7 +121,7 @@ template <int N, int FPT, bool PER_BIN>
 __global__ __launch_bounds__(256) void k_iss1_fused(c128 *Y, const double *__restrict__ weight,
                                                     double *r2_next, int F, int T,
                                                     int bins_per_block, int floor_kind, double eps) {
-  __shared__ double part[2][16 * 3 * N];
+  __shared__ double part[2][4 * 4 * 3 * N];
   const int b = blockIdx.y;
   const int i_begin = blockIdx.x * bins_per_block;
   const int i_end = min(F, i_begin + bins_per_block);
@@ -99,44 +154,7 @@ __global__ __launch_bounds__(256) void k_iss1_fused(c128 *Y, const double *__res
         if (PER_BIN)
           phi[n][f] = fv[f] ? weight[(((long long)b * N + n) * F + i) * T + jj[f]] : 0.0;
       }
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      // red[3s] + i red[3s+1] = sum_j phi_s y_s conj(y_n);  red[3s+2] = sum_j phi_s |y_n|^2
-      double red[3 * N];
-#pragma unroll
-      for (int s = 0; s < N; ++s) red[3 * s] = red[3 * s + 1] = red[3 * s + 2] = 0.0;
-#pragma unroll
-      for (int f = 0; f < FPT; ++f) {
-        const c128 yn = y[n][f];
-        const double pn = cabs2(yn);
-#pragma unroll
-        for (int s = 0; s < N; ++s) {
-          const double w = phi[s][f];
-          const c128 z = cmulc(y[s][f], yn);
-          red[3 * s] = fma(w, z.x, red[3 * s]);
-          red[3 * s + 1] = fma(w, z.y, red[3 * s + 1]);
-          red[3 * s + 2] = fma(w, pn, red[3 * s + 2]);
-        }
-      }
-      block_allsum<3 * N>(red, part[parity]);
-      parity ^= 1;
-      c128 v[N];
-#pragma unroll
-      for (int s = 0; s < N; ++s) {
-        const double den = apply_floor(red[3 * s + 2] * invT, floor_kind, eps);
-        if (s == n) {
-          v[s] = cmake(1.0 - 1.0 / sqrt(den), 0.0);
-        } else {
-          v[s] = cmake(red[3 * s] * invT / den, red[3 * s + 1] * invT / den);
-        }
-      }
-#pragma unroll
-      for (int f = 0; f < FPT; ++f) {
-        const c128 yn = y[n][f];
-#pragma unroll
-        for (int s = 0; s < N; ++s) cfms(y[s][f], v[s], yn);
-      }
-    }
+    iss_sweeps<N, FPT, 4>(y, phi, part, parity, invT, floor_kind, eps);
 #pragma unroll
     for (int n = 0; n < N; ++n)
 #pragma unroll
