@@ -237,10 +237,13 @@ int ssspy_ilrma_normalize_filter(void *W, const void *C, double *basis, int B, i
                                  size_t workspace_bytes, void *stream);
 
 /* same for the ISS state: psi from |Y|^2 directly, Y /= psi, basis /= psi^p.
+ * frame_power (B,N,T), optional: sum_i |y_nij|^2 of the CURRENT Y, as ssspy_iss1_fused leaves it in
+ * r2_next -- saves the pass over Y that computes the power; NULL: computed here.
  * replaces: ssspy/bss/ilrma.py:365-444 (normalize_by_power, demix_filter is None branch). */
-int ssspy_ilrma_normalize_output(void *Y, double *basis, int B, int N, int F, int T, int K,
-                                 double domain, int floor_kind, double floor_eps, void *workspace,
-                                 size_t workspace_bytes, void *stream);
+int ssspy_ilrma_normalize_output(void *Y, double *basis, const double *frame_power, int B, int N,
+                                 int F, int T, int K, double domain, int floor_kind,
+                                 double floor_eps, void *workspace, size_t workspace_bytes,
+                                 void *stream);
 
 /* varphi[b,n,i,j] (B,N,F,T) doubles for the ISS paths; Y (the separated spectrogram) is read only
  * by the heavy-tailed models.

@@ -250,12 +250,14 @@ def ilrma_normalize_filter(W, C, basis, domain, flooring, ws, ws_bytes):
     )
 
 
-def ilrma_normalize_output(Y, basis, domain, flooring, ws, ws_bytes):
+def ilrma_normalize_output(Y, basis, domain, flooring, ws, ws_bytes, frame_power=None):
+    """frame_power (B,N,T): sum over bins of |Y|^2 of the current Y when the caller already has it."""
     B, N, F, T = Y.shape
     K = basis.shape[-1]
     _lib.check(
-        _L().ssspy_ilrma_normalize_output(ptr(Y), ptr(basis), B, N, F, T, K, domain, flooring[0],
-                                          flooring[1], ptr(ws), ws_bytes, _st()),
+        _L().ssspy_ilrma_normalize_output(ptr(Y), ptr(basis), ptr(frame_power), B, N, F, T, K,
+                                          domain, flooring[0], flooring[1], ptr(ws), ws_bytes,
+                                          _st()),
         "ilrma_normalize_output",
     )
 

@@ -106,21 +106,37 @@ class DeviceStateMixin:
 
     def _state_set_host(self, name, value, dtype=None):
         if value is None:
-            self._state()[name] = {"host": None, "dev": None, "none": True, "dtype": dtype}
+            self._state()[name] = {"host": None, "dev": None, "none": True, "dtype": dtype,
+                                   "rev": self._next_rev()}
         else:
             if isinstance(value, torch.Tensor):
                 value = value.detach().cpu().numpy()
-            self._state()[name] = {"host": value, "dev": None, "none": False, "dtype": dtype}
+            self._state()[name] = {"host": value, "dev": None, "none": False, "dtype": dtype,
+                                   "rev": self._next_rev()}
 
     def _state_set_dev(self, name, tensor):
         """Device buffer is now the truth (host cache dropped)."""
         st = self._state()
         dtype = st[name]["dtype"] if name in st else None
-        st[name] = {"host": None, "dev": tensor, "none": False, "dtype": dtype}
+        st[name] = {"host": None, "dev": tensor, "none": False, "dtype": dtype,
+                    "rev": self._next_rev()}
 
     def _state_touch(self, name):
         """A kernel rewrote the device buffer in place: drop the host cache."""
-        self._state()[name]["host"] = None
+        ent = self._state()[name]
+        ent["host"] = None
+        ent["rev"] = self._next_rev()
+
+    def _next_rev(self):
+        self.__dict__["_state_serial"] = self.__dict__.get("_state_serial", 0) + 1
+        return self.__dict__["_state_serial"]
+
+    def _state_rev(self, name):
+        """Serial number of the current contents of a state variable: changes whenever the value is
+        replaced (host assignment, new device buffer) or rewritten in place (_state_touch).  Lets a
+        by-product of one kernel (e.g. the frame powers the fused ISS sweep leaves behind) be reused
+        by a later step only while the buffer it describes is still the same."""
+        return self._state()[name].get("rev", 0)
 
     def _state_is_none(self, name):
         return self._state()[name]["none"]

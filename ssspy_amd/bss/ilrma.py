@@ -501,13 +501,18 @@ class _MMILRMA(ILRMABase):
         varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y, model=self._model,
                                        flooring=self._resolve_floor(flooring_fn))
         floor = self._resolve_floor(flooring_fn)
+        frame_power = None
         if Y.shape[-1] <= _ops.iss1_fused_max_frames(N):
-            _ops.iss1_fused(Y, varphi, _lib.WEIGHT_BIN_FRAME, floor)
+            # the sweep also leaves sum_i |y_nij|^2 of the new Y: the power normalisation that
+            # follows in update_once() reads it instead of making its own pass over Y
+            frame_power = dv.empty((Y.shape[0], N, Y.shape[-1]), dv.f64, Y.device)
+            _ops.iss1_fused(Y, varphi, _lib.WEIGHT_BIN_FRAME, floor, r2_next=frame_power)
         else:
             Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
             G = _ops.iss1_transform(Vc, floor)
             _ops.separate(Y, G, out=Y)
         self._state_touch("output")
+        self._iss_frame_power = (frame_power, self._state_rev("output"))
 
     def normalize(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/ilrma.py:333-363."""
@@ -564,8 +569,12 @@ class _MMILRMA(ILRMABase):
                                         self._ws, self._ws_bytes)
             self._state_touch("demix_filter")
         else:
-            _ops.ilrma_normalize_output(self._state_dev("output"), self._state_dev("basis"),
-                                        float(self.domain), floor, self._ws, self._ws_bytes)
+            Y = self._state_dev("output")
+            frame_power, rev = getattr(self, "_iss_frame_power", (None, None))
+            if rev != self._state_rev("output"):
+                frame_power = None  # Y was replaced or rewritten since the sweep
+            _ops.ilrma_normalize_output(Y, self._state_dev("basis"), float(self.domain), floor,
+                                        self._ws, self._ws_bytes, frame_power=frame_power)
             self._state_touch("output")
         self._state_touch("basis")
 

@@ -191,11 +191,14 @@ __global__ __launch_bounds__(256) void k_norm_scale(c128 *W, double *basis,
 // ------------------------------------------------------------------ power normalisation (output)
 __global__ __launch_bounds__(256) void k_output_power(const c128 *__restrict__ Y, double *acc,
                                                       int N, int F, int T) {
+  // grid: (ceil(F / 16), N, B): 16 consecutive bin rows (one contiguous run) per block
   __shared__ double scratch[4];
-  const int i = blockIdx.x, n = blockIdx.y, b = blockIdx.z;
-  const c128 *row = Y + (((long long)b * N + n) * F + i) * T;
+  const int n = blockIdx.y, b = blockIdx.z;
+  const int i0 = blockIdx.x * 16;
+  const long long len = (long long)min(16, F - i0) * T;
+  const c128 *run = Y + (((long long)b * N + n) * F + i0) * T;
   double local = 0.0;
-  for (int j = threadIdx.x; j < T; j += blockDim.x) local += cabs2(row[j]);
+  for (long long e = threadIdx.x; e < len; e += blockDim.x) local += cabs2(run[e]);
   const double total = block_sum(local, scratch);
   if (threadIdx.x == 0) atomicAdd(acc + b * N + n, total);
 }
@@ -333,22 +336,53 @@ __global__ __launch_bounds__(256) void k_partition_normalize(double *basis, doub
 }
 
 // ------------------------------------------------------------------------------ ISS weight
+// grid: (ceil(F / ISSW_BINS), N, B).  A thread owns a frame and ISSW_BINS bins: each activation
+// value is loaded once per ISSW_BINS outputs and the basis entries are wave-uniform (scalar loads),
+// so the kernel is bound by the varphi write (one block per bin re-read the whole K x T activation
+// from L2 for every row: 0.82 ms at 32 mixtures of configs[1], against 0.54 GB of output).
+constexpr int ISSW_BINS = 16;
 __global__ __launch_bounds__(256) void k_ilrma_iss_weight(const c128 *__restrict__ Y,
                                                           const double *__restrict__ basis,
                                                           const double *__restrict__ act,
                                                           double *__restrict__ varphi, int N,
                                                           IlrmaDims d) {
-  const int i = blockIdx.x, n = blockIdx.y, b = blockIdx.z;
+  const int n = blockIdx.y, b = blockIdx.z;
   const int F = d.F, T = d.T, K = d.K;
-  const double *tr = basis + (((long long)b * N + n) * F + i) * K;
+  const int i0 = blockIdx.x * ISSW_BINS;
+  const int nb = min(ISSW_BINS, F - i0);
+  const double *tr = basis + (((long long)b * N + n) * F + i0) * K;
   const double *Vn = act + ((long long)b * N + n) * K * T;
-  const long long row = (((long long)b * N + n) * F + i) * T;
+  const long long row0 = (((long long)b * N + n) * F + i0) * T;
   for (int j = threadIdx.x; j < T; j += blockDim.x) {
-    double r = 0.0;
-    for (int k = 0; k < K; ++k) r = fma(tr[k], Vn[(long long)k * T + j], r);
-    const double P = (d.model != SSSPY_SOURCE_GAUSS) ? cabs2(Y[row + j]) : 0.0;
-    varphi[row + j] = spatial_weight(P, r, d);
+    double r[ISSW_BINS];
+#pragma unroll
+    for (int ib = 0; ib < ISSW_BINS; ++ib) r[ib] = 0.0;
+    for (int k = 0; k < K; ++k) {
+      const double v = Vn[(long long)k * T + j];
+#pragma unroll
+      for (int ib = 0; ib < ISSW_BINS; ++ib) r[ib] = fma(tr[min(ib, nb - 1) * K + k], v, r[ib]);
+    }
+#pragma unroll
+    for (int ib = 0; ib < ISSW_BINS; ++ib) {
+      if (ib < nb) {
+        const long long e = row0 + (long long)ib * T + j;
+        const double P = (d.model != SSSPY_SOURCE_GAUSS) ? cabs2(Y[e]) : 0.0;
+        varphi[e] = spatial_weight(P, r[ib], d);
+      }
+    }
   }
+}
+
+// acc[b, n] = sum_j frame_power[b, n, j]; grid: (N, B)
+__global__ __launch_bounds__(256) void k_power_from_frames(const double *__restrict__ fp,
+                                                           double *acc, int N, int T) {
+  __shared__ double scratch[4];
+  const int n = blockIdx.x, b = blockIdx.y;
+  const double *row = fp + ((long long)b * N + n) * T;
+  double local = 0.0;
+  for (int j = threadIdx.x; j < T; j += blockDim.x) local += row[j];
+  const double total = block_sum(local, scratch);
+  if (threadIdx.x == 0) acc[b * N + n] = total;
 }
 
 }  // namespace ssspy
@@ -504,18 +538,24 @@ int ssspy_ilrma_normalize_filter(void *W, const void *C, double *basis, int B, i
   return launch_norm_scale(W, basis, qbuf, B, N, F, K, domain, floor_kind, floor_eps, st);
 }
 
-int ssspy_ilrma_normalize_output(void *Y, double *basis, int B, int N, int F, int T, int K,
-                                 double domain, int floor_kind, double floor_eps, void *workspace,
-                                 size_t workspace_bytes, void *stream) {
+int ssspy_ilrma_normalize_output(void *Y, double *basis, const double *frame_power, int B, int N,
+                                 int F, int T, int K, double domain, int floor_kind,
+                                 double floor_eps, void *workspace, size_t workspace_bytes,
+                                 void *stream) {
   SSSPY_REQUIRE(Y && basis && B > 0 && N >= 1, "normalize_output: bad argument");
   SSSPY_REQUIRE(workspace && workspace_bytes >= (size_t)B * N * sizeof(double),
                 "normalize_output: workspace too small");
   hipStream_t st = as_stream(stream);
   double *acc = (double *)workspace;
-  hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * N * sizeof(double), st);
-  if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
   dim3 grid(F, N, B), block(256);
-  hipLaunchKernelGGL(k_output_power, grid, block, 0, st, (const c128 *)Y, acc, N, F, T);
+  if (frame_power) {
+    hipLaunchKernelGGL(k_power_from_frames, dim3(N, B), block, 0, st, frame_power, acc, N, T);
+  } else {
+    hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * N * sizeof(double), st);
+    if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+    hipLaunchKernelGGL(k_output_power, dim3((F + 15) / 16, N, B), block, 0, st, (const c128 *)Y, acc,
+                       N, F, T);
+  }
   hipLaunchKernelGGL(k_ilrma_normalize_output, grid, block, 0, st, (c128 *)Y, basis, acc, N, F, T,
                      K, domain, floor_kind, floor_eps, (double *)nullptr);
   return check_launch("k_ilrma_normalize_output");
@@ -530,7 +570,7 @@ int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *act
   int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
-  dim3 grid(F, N, B), block(256);
+  dim3 grid((F + ISSW_BINS - 1) / ISSW_BINS, N, B), block(256);
   hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, as_stream(stream), (const c128 *)Y, basis,
                      activation, varphi, N, d);
   return check_launch("k_ilrma_iss_weight");
@@ -679,7 +719,8 @@ int ssspy_ilrma_partition_normalize(void *W, const void *C, void *Y, double *bas
     hipError_t e = hipMemsetAsync(qbuf, 0, (size_t)B * N * sizeof(double), st);
     if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
     dim3 grid(F, N, B), block(256);
-    hipLaunchKernelGGL(k_output_power, grid, block, 0, st, (const c128 *)Y, qbuf, N, F, T);
+    hipLaunchKernelGGL(k_output_power, dim3((F + 15) / 16, N, B), block, 0, st, (const c128 *)Y, qbuf,
+                       N, F, T);
     hipLaunchKernelGGL(k_ilrma_normalize_output, grid, block, 0, st, (c128 *)Y, (double *)nullptr,
                        (const double *)qbuf, N, F, T, K, domain, floor_kind, floor_eps, psi);
     int rc = check_launch("k_ilrma_normalize_output");
