@@ -236,6 +236,35 @@ def main():
             "ms_per_step": round(1e3 * dtl, 4), "iterations_per_s": round(B / dtl, 2),
         }
 
+    # ---- the metric's AuxIVA leg: AuxLaplaceIVA (IP1) on the same resident batch, two passes over X
+    # per iteration (frame powers, weighted covariance)
+    if not args.no_single and n_gpus == 1:
+        from ssspy_amd.bss.iva import AuxLaplaceIVA, _device_contrast
+
+        iva = AuxLaplaceIVA(spatial_algorithm="IP", record_loss=False)
+        iva._contrast = _device_contrast(iva.contrast_fn, iva.d_contrast_fn)
+        iva._bind_input(X)
+        iva._reset()
+        iva._C()
+        for _ in range(3):
+            iva.update_once()
+        torch.cuda.synchronize()
+        ni = max(5, args.steps)
+        ti = time.perf_counter()
+        for _ in range(ni):
+            iva.update_once()
+        torch.cuda.synchronize()
+        dti = (time.perf_counter() - ti) / ni
+        iva._check_device_errors()
+        out["auxiva_ip"] = {
+            "workload": "AuxLaplaceIVA-IP1, same batch ({} x N={} F={} T={}), {} iterations".format(
+                B, N, F, T, ni),
+            "ms_per_step": round(1e3 * dti, 4), "iterations_per_s": round(B / dti, 2),
+            "achieved_GBs": round(2 * pass_bytes / dti / 1e9, 1),
+            "frac_of_hbm_peak": round(2 * pass_bytes / dti / 1e9 / HBM_PEAK_GBS, 4),
+        }
+        del iva
+
     # ---- configs[1] exactly: ONE mixture, fused update_once (one C-ABI call per iteration)
     if not args.no_single and n_gpus == 1:
         sep1 = make_separator(X[:1].clone(), K, seed=2000)
