@@ -576,6 +576,74 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
   }
 }
 
+// The same pass with per-frame weights phi[b, s, j] (B, N, T) instead of the NMF variance: the
+// weighted covariance of AuxIVA (ref: ssspy/bss/iva.py:1816-1840).  No activation tile to stage, so
+// no barrier in the walk; items are never split here (the launcher takes this kernel only when the
+// batch fills the chip, see ilrma_fast_wcov_frame).  grid: B * ceil(F / WC_BINS) workgroups.
+__global__ __launch_bounds__(256, 2) void k_wcov_frame_fast(const c128 *__restrict__ X,
+                                                            const double *__restrict__ weight,
+                                                            c128 *__restrict__ U, int F, int T,
+                                                            int groups) {
+  constexpr int SG = WC_SG;
+  __shared__ __attribute__((aligned(16))) c128 xpatch[4][XPATCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x / groups, group = blockIdx.x - b * groups;
+  const int g = wave % WC_NG, wb = wave / WC_NG;
+  const int s0 = g * SG;
+  const int i0 = (group * WC_WB + wb) * 16;
+  const c128 *Xb = X + (long long)b * N * F * T;
+  const double *wgt = weight + (long long)b * N * T;
+  CovAcc<N, SG> acc;
+  acc.clear();
+  const int ntiles = (T + 15) >> 4;
+  XTile cur;
+  for (int jt = 0; jt < ntiles; ++jt) {
+    const int j0 = jt * 16;
+    xtile_load_transposed(cur, Xb, F, T, i0, j0, c, q, xpatch[wave]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = j0 + q + 4 * r;
+      const bool valid = j < T;
+      c128 x[N];
+      double phi[SG];
+#pragma unroll
+      for (int m = 0; m < N; ++m) x[m] = cur.x[m][r];
+#pragma unroll
+      for (int s = 0; s < SG; ++s)
+        phi[s] = (valid && s0 + s < N) ? wgt[(long long)(s0 + s) * T + j] : 0.0;
+      acc.add(x, phi);
+    }
+  }
+  acc.fold_q();
+  const double scale = 1.0 / (double)T;
+  const int ob = i0 + c;
+  if (ob < F) {
+    c128 *dst = U + ((long long)b * F + ob) * (long long)(N * N * N);
+#pragma unroll
+    for (int s = 0; s < SG; ++s) {
+      const int n = s0 + s;
+      if (n < N) {
+        int e = 0;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+          const bool mine = (a & 3) == q;
+          if (mine) dst[(n * N + a) * N + a] = cmake(acc.diag[s][a] * scale, 0.0);
+#pragma unroll
+          for (int bb = a + 1; bb < N; ++bb) {
+            const c128 z = acc.off[s][e];
+            if (mine) {
+              dst[(n * N + a) * N + bb] = cmake(z.x * scale, z.y * scale);
+              dst[(n * N + bb) * N + a] = cmake(z.x * scale, -z.y * scale);
+            }
+            ++e;
+          }
+        }
+      }
+    }
+  }
+}
+
 // U[tail items] = sum of their chunks; grid: (WC_BINS*N^3/256 rounded up, tail items)
 __global__ __launch_bounds__(256) void k_wcov_fold(c128 *__restrict__ U,
                                                    const c128 *__restrict__ upart, int F,
@@ -837,6 +905,20 @@ int LAUNCHER(ilrma_fast_wcov)(const void *X, const void *W, const double *basis,
   hipLaunchKernelGGL(k_wcov_fold, dim3((WC_BINS * N * N * N + 255) / 256, plan.tail), block, 0, st,
                      (c128 *)U, (const c128 *)upart, F, plan);
   return check_launch("k_wcov_fold");
+}
+
+// Frame-weighted covariance U (B,F,N,N,N) from weight (B,N,T).  Returns -1 without launching when
+// the batch is too small for unsplit items to fill the chip (the caller then takes the generic
+// kernel, whose waves split the frames), otherwise the status of the launch.
+int LAUNCHER(ilrma_fast_wcov_frame)(const void *X, const double *weight, void *U, int B, int F,
+                                    int T, hipStream_t st) {
+  static const bool disabled = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;
+  const int groups = (F + WC_BINS - 1) / WC_BINS;
+  const long long items = (long long)B * groups;
+  if (disabled || items < SLOTS) return -1;
+  hipLaunchKernelGGL(k_wcov_frame_fast, dim3((unsigned)items), dim3(256), 0, st, (const c128 *)X,
+                     weight, (c128 *)U, F, T, groups);
+  return check_launch("k_wcov_frame_fast");
 }
 
 #undef SSSPY_FAST_LAUNCH2

@@ -5,6 +5,10 @@
 #include "smallmat.hpp"
 
 namespace ssspy {
+// ilrma_fast.hip (one translation unit per N)
+int ilrma_fast_wcov_frame_n2(const void *, const double *, void *, int, int, int, hipStream_t);
+int ilrma_fast_wcov_frame_n3(const void *, const double *, void *, int, int, int, hipStream_t);
+int ilrma_fast_wcov_frame_n4(const void *, const double *, void *, int, int, int, hipStream_t);
 
 thread_local char g_last_error[512] = "";
 
@@ -435,6 +439,14 @@ int ssspy_weighted_covariance(const void *A, const double *weight, int weight_ki
   SSSPY_REQUIRE(A && U && B > 0 && F > 0 && T > 0 && S > 0, "weighted_covariance: bad argument");
   SSSPY_REQUIRE(weight_kind == SSSPY_WEIGHT_UNIT || weight, "weighted_covariance: weight is NULL");
   SSSPY_REQUIRE(weight_kind != SSSPY_WEIGHT_UNIT || S == 1, "weighted_covariance: UNIT needs S=1");
+  if (weight_kind == SSSPY_WEIGHT_FRAME && S == N && N >= 2 && N <= 4) {
+    // AuxIVA's per-iteration pass: the tuned tile walk when the batch fills the chip
+    int rc = -1;
+    if (N == 2) rc = ilrma_fast_wcov_frame_n2(A, weight, U, B, F, T, as_stream(stream));
+    if (N == 3) rc = ilrma_fast_wcov_frame_n3(A, weight, U, B, F, T, as_stream(stream));
+    if (N == 4) rc = ilrma_fast_wcov_frame_n4(A, weight, U, B, F, T, as_stream(stream));
+    if (rc >= 0) return rc;
+  }
   DISPATCH_N(N, return dispatch_weighted_cov<NN>((const c128 *)A, weight, weight_kind, (c128 *)U,
                                                  B, S, F, T, as_stream(stream)));
   return SSSPY_OK;

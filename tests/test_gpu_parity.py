@@ -825,12 +825,14 @@ def test_fast_gauss_mnmf_config4_full_size_properties():
 @pytest.mark.parametrize("T", [32, 33])
 def test_large_batch_paths_against_oracle(T):
     """With >= 512 workgroups per launch the kernels switch to their large-batch form (no frame
-    chunking in the ILRMA fast path, bin-split FastMNMF kernels) -- the one bench.py times.  600 tiny
+    chunking in the ILRMA fast path, bin-split FastMNMF kernels, AuxIVA's tuned covariance walk) -- the one bench.py times.  600 tiny
     mixtures; first, middle and last are checked against the oracle.  T = 33: rows of an odd length
     (activation rows that start 8 bytes off a 16-byte boundary, last row ending the buffer)."""
     from oracle.ilrma import GaussILRMAOracle
+    from oracle.iva import AuxIVAOracle
     from oracle.mnmf import FastGaussMNMFOracle
     from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.bss.iva import AuxLaplaceIVA
     from ssspy_amd.bss.mnmf import FastGaussMNMF
     from ssspy_amd.utils.dataset import nmf_mixture
 
@@ -843,7 +845,13 @@ def test_large_batch_paths_against_oracle(T):
     Y = m(X, n_iter=3, basis=basis, activation=act)
     mm = FastGaussMNMF(n_basis=K)
     Ym = mm(X, n_iter=3, basis=basis, activation=act, spatial=spatial)
+    mi = AuxLaplaceIVA(spatial_algorithm="IP")  # frame-weighted covariance, tuned tile walk
+    Yi = mi(X, n_iter=3)
     for b in (0, 301, B - 1):
+        refi = AuxIVAOracle(spatial_algorithm="IP", contrast="laplace")
+        Yri = refi.run(X[b], n_iter=3)
+        assert rel_err(Yi[b], Yri) < TOL
+        np.testing.assert_allclose(np.asarray(mi.loss)[:, b], refi.loss, rtol=LOSS_RTOL)
         ref = GaussILRMAOracle(n_basis=K)
         Yr = ref.run(X[b], n_iter=3, basis=basis[b], activation=act[b])
         assert rel_err(Y[b], Yr) < TOL
