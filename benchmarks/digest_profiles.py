@@ -23,9 +23,17 @@ bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlin
 B = bench["config"]["batch_per_gpu"]
 json.dump(bench, open(os.path.join(dst, "{}_bench_b{}.json".format(tag, B)), "w"), indent=1)
 
-stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+
+
+def latest(pattern):
+    """gpurun merges every run's files into the same directory: take the newest match only."""
+    found = glob.glob(pattern, recursive=True)
+    return max(found, key=os.path.getmtime) if found else None
+
+
+stats = latest(os.path.join(src, "stats", "**", "*kernel_stats.csv"))
 if stats:
-    rows = [r for r in csv.DictReader(open(stats[0]))]
+    rows = [r for r in csv.DictReader(open(stats))]
     keep = [r for r in rows if float(r.get("Percentage", 0) or 0) >= 0.01]
     with open(os.path.join(dst, "{}_bench_b{}_kernel_stats.csv".format(tag, B)), "w") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
@@ -40,7 +48,8 @@ KERNELS = {"k_basis_fast": "k_ilrma_basis", "k_activation_fast": "k_ilrma_activa
 
 def counter(path, name):
     acc = collections.defaultdict(list)
-    for p in glob.glob(os.path.join(src, path, "**", "*counter_collection.csv"), recursive=True):
+    newest = latest(os.path.join(src, path, "**", "*counter_collection.csv"))
+    for p in [newest] if newest else []:
         for r in csv.DictReader(open(p)):
             if r["Counter_Name"] != name:
                 continue
