@@ -137,7 +137,7 @@ def main():
         x0_host = nmf_mixture(1000, N, F, T)
         X[0] = torch.from_numpy(x0_host).to(dev)
     sep = make_separator(X, K, seed=2000 + rank)
-    B_, N_, F_, T_ = X.shape
+    # scratch of the covariance -> IP1 pair, which timed_steps() launches one kernel group at a time
     sep._U = dv.empty((B, F, N, N, N), dv.c128, dev)
     sep._C()  # static covariance, computed once per call (outside the iteration loop)
 
