@@ -53,6 +53,32 @@ inline int check_launch(const char *what) {
 // ---------------------------------------------------------------- complex arithmetic
 __device__ __forceinline__ c128 cmake(double re, double im) { return make_double2(re, im); }
 
+// Workgroup id -> work item such that consecutive items run on the same XCD.  The dispatcher is
+// observed to place workgroup id on XCD id % 8 (MI355X_MICROARCH.md, "Workgroup dispatch"; a speed
+// assumption only): ids {x, x + 8, x + 16, ...} get the contiguous item range of XCD x, so the
+// operand every item of a mixture shares (its activation / basis tile, 0.26 - 0.5 MB) is pulled
+// into one L2 instead of eight.  Bijective on [0, n) for any n.
+__device__ __forceinline__ int xcd_contiguous(int id, int n) {
+  const int per = n >> 3, rem = n & 7;
+  const int xcd = id & 7, slot = id >> 3;
+  return xcd * per + min(xcd, rem) + slot;
+}
+
+// the same for a 3-D grid (x fastest): the XCD-contiguous item as (x, y, z)
+struct GridItem {
+  int x, y, z;
+};
+__device__ __forceinline__ GridItem xcd_contiguous_grid() {
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int item = xcd_contiguous(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z),
+                                  gx * gy * gridDim.z);
+  GridItem g;
+  g.x = item % gx;
+  g.y = (item / gx) % gy;
+  g.z = item / (gx * gy);
+  return g;
+}
+
 // Two consecutive doubles of a real row, as one 16-byte load that only needs 8-byte alignment (rows
 // of an odd length start on odd multiples of 8 bytes; gfx950 global loads are dword-aligned).  The
 // second element is read only when it belongs to the row: (p[0], p[1]) if j + 1 < len,

@@ -103,6 +103,7 @@ struct BlockWork {
 __device__ __forceinline__ BlockWork block_work(const TailPlan &p) {
   BlockWork w;
   int item = blockIdx.x;
+  if (item < p.full) item = xcd_contiguous(item, p.full);
   w.chunk = 0;
   w.nchunks = 1;
   w.tail_idx = 0;
@@ -588,7 +589,8 @@ __global__ __launch_bounds__(256, 2) void k_wcov_frame_fast(const c128 *__restri
   __shared__ __attribute__((aligned(16))) c128 xpatch[4][XPATCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int b = blockIdx.x / groups, group = blockIdx.x - b * groups;
+  const int item = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int b = item / groups, group = item - b * groups;
   const int g = wave % WC_NG, wb = wave / WC_NG;
   const int s0 = g * SG;
   const int i0 = (group * WC_WB + wb) * 16;
@@ -734,8 +736,11 @@ __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restri
   __shared__ __attribute__((aligned(16))) c128 ws[2][16 * AWSTRIDE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int b = blockIdx.z, chunk = blockIdx.y;
-  const int j0 = (blockIdx.x * 4 + wave) * 16;
+  // (frame group, bin chunk, mixture) from the XCD-contiguous item: the frame groups of one
+  // (mixture, chunk) share the staged basis tiles and demixing matrices
+  const GridItem gi = xcd_contiguous_grid();
+  const int chunk = gi.y, b = gi.z;
+  const int j0 = (gi.x * 4 + wave) * 16;
   const int jf = j0 + c;
   const bool fvalid = jf < T;
   const int jc = fvalid ? jf : T - 1;

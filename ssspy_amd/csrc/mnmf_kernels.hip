@@ -559,8 +559,9 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int b = blockIdx.z;
-  const int i0 = blockIdx.x * 64 + wave * 16;
+  const GridItem gi = xcd_contiguous_grid();  // bin groups of a mixture share its activation tile
+  const int b = gi.z;
+  const int i0 = gi.x * 64 + wave * 16;
   const int bin = min(i0 + c, F - 1);
   const c128 *Xb = X + (long long)b * M * F * T;
   const double *act_b = act + (long long)b * N * K * T;
@@ -803,8 +804,9 @@ __global__ __launch_bounds__(256) void k_mnmf_activation_fast(const c128 *__rest
   __shared__ __attribute__((aligned(16))) double dl[2][16 * N * M];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int b = blockIdx.z, chunk = blockIdx.y;
-  const int j0 = (blockIdx.x * 4 + wave) * 16;
+  const GridItem gi = xcd_contiguous_grid();  // frame groups of a (mixture, chunk) share its tiles
+  const int b = gi.z, chunk = gi.y;
+  const int j0 = (gi.x * 4 + wave) * 16;
   const int jf = j0 + c;
   const bool fvalid = jf < T;
   const int jc = fvalid ? jf : T - 1;
