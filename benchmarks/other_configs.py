@@ -35,7 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--only", default="", help="comma-separated subset of iva_iss,iva_ip,ilrma_iss,fastmnmf,gmnmf")
+    ap.add_argument("--only", default="", help="comma-separated subset of iva_iss,iva_ip,ilrma_iss,ilrma_models,fastmnmf,gmnmf")
     args = ap.parse_args()
     only = [t for t in args.only.split(",") if t]
 
@@ -103,6 +103,30 @@ def main():
                           "ms_per_iter": round(dt * 1e3, 3), "mixture_iterations_per_s": round(B / dt, 2)}))
         del m
         torch.cuda.empty_cache()
+
+    if want("ilrma_models"):
+        # the other source models / domain on the configs[1] shape (IP1)
+        from ssspy_amd.bss.ilrma import GGDILRMA, TILRMA, GaussILRMA
+
+        N, F, T, K = 4, 1025, 512, 16
+        X = nmf_mixture(1000, N, F, T)
+        if args.batch > 1:
+            X = np.stack([X] * args.batch)
+        for name, make in (("TILRMA dof=4", lambda: TILRMA(n_basis=K, dof=4.0, record_loss=False, rng=np.random.default_rng(0))),
+                           ("GGDILRMA beta=1", lambda: GGDILRMA(n_basis=K, beta=1.0, record_loss=False, rng=np.random.default_rng(0))),
+                           ("GaussILRMA domain=1", lambda: GaussILRMA(n_basis=K, domain=1, record_loss=False, rng=np.random.default_rng(0)))):
+            m = make()
+            m._bind_input(X)
+            m._reset(flooring_fn=m.flooring_fn)
+            m._C()
+            for _ in range(3):
+                m.update_once()
+            dt = timed(m.update_once, args.iters)
+            print(json.dumps({"config": "{}-IP N=4 F=1025 T=512 K=16 batch={}".format(name, B),
+                              "ms_per_iter": round(dt * 1e3, 3),
+                              "mixture_iterations_per_s": round(B / dt, 2)}))
+            del m
+            torch.cuda.empty_cache()
 
     if want("fastmnmf"):
         # configs[3]: FastGaussMNMF

@@ -27,7 +27,7 @@ DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
   int ilrma_fast_activation_n##n(const void *, const void *, const double *, const double *,   \
                                  double *, int, int, int, int, int, int, double, hipStream_t); \
   int ilrma_fast_wcov_n##n(const void *, const void *, const double *, const double *, void *, \
-                           int, int, int, int, void *, int, double, hipStream_t);              \
+                           int, int, int, int, void *, int, double, int, double, hipStream_t); \
   int ilrma_fast_loss_n##n(const void *, const void *, const double *, const double *, double *, \
                            int, int, int, int, int, double, hipStream_t);
 DECL_FAST(2) DECL_FAST(3) DECL_FAST(4)
@@ -40,15 +40,25 @@ DECL_FAST(2) DECL_FAST(3) DECL_FAST(4)
     default: return fn##_n4(__VA_ARGS__);            \
   }
 
-// the tuned kernels: domain 2, Gauss or Student-t model (MM or ME), n_sources <= 4, n_basis <= 16;
-// `source_model` may carry the SSSPY_SOURCE_ME flag
+// the tuned kernels: n_sources <= 4, n_basis <= 16 and one of the models ilrma_fast.hip carries
+// (its FM_* ids): Gauss at domain 2 (MM or ME) or 1, Student-t and GGD at domain 2;
+// `source_model` may carry the SSSPY_SOURCE_ME flag.  -1: generic kernels.
+static inline int fast_model_id(double domain, int source_model) {
+  const int base = source_model & 0xff;
+  const bool me = (source_model & SSSPY_SOURCE_ME) != 0;
+  if (domain == 2.0) {
+    if (base == SSSPY_SOURCE_GAUSS) return 0;
+    if (base == SSSPY_SOURCE_T) return 1;
+    if (base == SSSPY_SOURCE_GGD) return 2;
+  }
+  if (domain == 1.0 && base == SSSPY_SOURCE_GAUSS && !me) return 3;
+  return -1;
+}
 static inline bool fast_path(int N, int T, int K, double domain, int source_model = SSSPY_SOURCE_GAUSS) {
   static const bool disabled = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;
-  const int base = source_model & 0xff;
-  return !disabled && (base == SSSPY_SOURCE_GAUSS || base == SSSPY_SOURCE_T) && N >= 2 && N <= 4 &&
-         K <= 16 && domain == 2.0;
+  (void)T;
+  return !disabled && fast_model_id(domain, source_model) >= 0 && N >= 2 && N <= 4 && K <= 16;
 }
-static inline int is_t(int source_model) { return (source_model & 0xff) == SSSPY_SOURCE_T; }
 static inline int is_me(int source_model) { return (source_model & SSSPY_SOURCE_ME) ? 1 : 0; }
 
 static inline int check_model(int source_model, double param, double domain = 2.0) {
@@ -442,8 +452,8 @@ int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const 
   hipStream_t st = as_stream(stream);
   if (fast_path(N, T, K, domain, source_model)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_basis, X, W, basis, activation, B, F, T, K, floor_kind,
-                        floor_eps, (double *)(ws + w.bpart), is_t(source_model), model_param,
-                        is_me(source_model), st);
+                        floor_eps, (double *)(ws + w.bpart), fast_model_id(domain, source_model),
+                        model_param, is_me(source_model), st);
   }
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   double *out = K > 16 ? (double *)(ws + w.btmp) : basis;
@@ -477,7 +487,7 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
   auto run = [&]() -> int {
     if (fast_path(N, T, K, domain, source_model)) {
       ILRMA_FAST_DISPATCH(N, ilrma_fast_activation, X, W, basis, activation, part, chunks, B, F, T,
-                          K, is_t(source_model), model_param, st);
+                          K, fast_model_id(domain, source_model), model_param, st);
     }
     ILRMA_DISPATCH(N, ilrma_activation, X, W, basis, activation, part, chunks, d, st);
   };
@@ -494,7 +504,7 @@ static int wcov_into(const void *X, const void *W, const double *basis, const do
                      void *U, int N, const IlrmaDims &d, void *upart, hipStream_t st) {
   if (fast_path(N, d.T, d.K, d.p, d.model) && (d.model == SSSPY_SOURCE_GAUSS || W)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, W, basis, activation, U, d.B, d.F, d.T, d.K, upart,
-                        d.model == SSSPY_SOURCE_T, d.mparam, st);
+                        fast_model_id(d.p, d.model), d.mparam, d.floor_kind, d.floor_eps, st);
   }
   ILRMA_DISPATCH(N, ilrma_wcov, X, W, basis, activation, U, d, st);
 }
@@ -588,7 +598,7 @@ int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
   if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
   if (fast_path(N, T, K, domain, source_model)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_loss, X, W, basis, activation, out, B, F, T, K,
-                        is_t(source_model), model_param, st);
+                        fast_model_id(domain, source_model), model_param, st);
   }
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, SSSPY_FLOOR_NONE, 0.0);
   ILRMA_DISPATCH(N, ilrma_loss, X, W, basis, activation, out, d, st);

@@ -61,12 +61,57 @@ __device__ __forceinline__ int tile_pi(int rho) { return 4 * (rho & 3) + (rho >>
 // (128 mixtures x 17 groups = 2176 items = 4.25 rounds: 5 rounds unsplit, 4.25 split).  Split blocks
 // write partial sums to a scratch area indexed [tail item][chunk]; a small second kernel folds them.
 // Small batches are the same formula with full == 0.
-// Source model of the tuned kernels (domain 2): Gauss, or Student-t with R~ = w R + (1 - w) |y|^2,
-// w = nu / (nu + 2) (ref: ssspy/bss/ilrma.py:2505-2518, :2915-2935); `me`: exponent 1 instead of 1/2.
+// Source models of the tuned kernels (R = (T V)_nij, P = |y_nij|^2; ref: ssspy/bss/ilrma.py):
+//   FM_GAUSS  domain 2: a = P / R^2,           varphi = 1 / R                        (:1116-1125, :1494-1498)
+//   FM_T      domain 2: a = P / (R~ R), varphi = 1 / R~, R~ = w R + (1 - w) P, w = nu / (nu + 2)
+//                                                                              (:2505-2518, :2915-2935)
+//   FM_GGD    domain 2: a = (beta / 2) (P / R)^(beta/2) / R,
+//                       varphi = 1 / ((2 / beta) floor(P^((2 - beta)/2)) R^(beta/2))  (:3810-3821, :3987-4011)
+//   FM_GAUSS1 domain 1: a = P / R^3,           varphi = 1 / R^2
+// `expo`: exponent of the (num / den) ratio: p / (p + 2), 1 for the ME updates, p / (beta + p) for GGD.
+constexpr int FM_GAUSS = 0, FM_T = 1, FM_GGD = 2, FM_GAUSS1 = 3;
 struct FastModel {
-  double w, w1, nu;
-  int me;
+  double w, w1, nu, beta, expo;
+  int floor_kind;
+  double floor_eps;
 };
+
+// x^e for x >= 0 through exp2 / log2 (about 1e-14 relative over the dynamic range met here, and
+// less than half the instructions of the correctly rounded pow)
+__device__ __forceinline__ double pow_nonneg(double x, double e) {
+  return x > 0.0 ? exp2(e * log2(x)) : 0.0;
+}
+
+__device__ __forceinline__ double ratio_pow(double ratio, double expo) {
+  if (expo == 0.5) return sqrt(ratio);
+  if (expo == 1.0) return ratio;
+  return pow(ratio, expo);
+}
+
+// numerator factor a of the multiplicative updates (rinv = 1 / R)
+template <int MODEL>
+__device__ __forceinline__ double mm_num_factor(double pw, double R, double rinv,
+                                                const FastModel &fm);
+template <>
+__device__ __forceinline__ double mm_num_factor<FM_GAUSS>(double pw, double, double rinv,
+                                                          const FastModel &) {
+  return pw * rinv * rinv;
+}
+template <>
+__device__ __forceinline__ double mm_num_factor<FM_T>(double pw, double R, double rinv,
+                                                      const FastModel &fm) {
+  return pw * rcp_nr(fma(fm.w, R, fm.w1 * pw)) * rinv;
+}
+template <>
+__device__ __forceinline__ double mm_num_factor<FM_GGD>(double pw, double, double rinv,
+                                                        const FastModel &fm) {
+  return 0.5 * fm.beta * pow_nonneg(pw * rinv, 0.5 * fm.beta) * rinv;
+}
+template <>
+__device__ __forceinline__ double mm_num_factor<FM_GAUSS1>(double pw, double, double rinv,
+                                                           const FastModel &) {
+  return pw * rinv * rinv * rinv;
+}
 
 constexpr int SLOTS = 512;
 struct TailPlan {
@@ -223,7 +268,7 @@ __device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const doubl
 // grid: 1-D, see TailPlan.  Unsplit blocks update their 64 bins in place; split blocks write
 // partial num/den to `part` ([tail item][chunk][n][64 bins][16][2]) for k_basis_finalize.
 // HAS_W = false: the ISS / IPA state passes the separated spectrogram itself (y = x_n, no filter)
-template <bool HAS_W, bool TMODEL>
+template <bool HAS_W, int MODEL>
 __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ X,
                                                        const c128 *__restrict__ W, double *basis,
                                                        const double *__restrict__ act, int F,
@@ -302,8 +347,7 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
         const double rinv = rcp_nr(R[r]);
         const double bb = valid ? rinv : 0.0;
         const double pw = cabs2(y);
-        const double wgt = TMODEL ? rcp_nr(fma(fm.w, R[r], fm.w1 * pw)) : rinv;
-        const double aa = valid ? pw * wgt * rinv : 0.0;
+        const double aa = valid ? mm_num_factor<MODEL>(pw, R[r], rinv, fm) : 0.0;
         num[n] = mfma_f64(aa, vb[r], num[n]);
         den[n] = mfma_f64(bb, vb[r], den[n]);
       }
@@ -321,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
         if (nchunks == 1) {
           double *dst = basis + (((long long)b * N + n) * F + ob) * K + c;
           const double ratio = num[n][r] / den[n][r];
-          *dst = apply_floor((fm.me ? ratio : sqrt(ratio)) * (*dst), floor_kind, eps);
+          *dst = apply_floor(ratio_pow(ratio, fm.expo) * (*dst), floor_kind, eps);
         } else {
           const long long slot = (long long)work.tail_idx * nchunks + work.chunk;
           double *dst = part + (((slot * N + n) * 64 + (ob - work.group * 64)) * 16 + c) * 2;
@@ -337,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
 __global__ __launch_bounds__(256) void k_basis_finalize(double *basis,
                                                         const double *__restrict__ part, int F,
                                                         int K, TailPlan plan, int floor_kind,
-                                                        double eps, int me) {
+                                                        double eps, double expo) {
   const int tail_idx = blockIdx.y;
   const int item = plan.full + tail_idx;
   const int b = item / plan.groups, group = item - b * plan.groups;
@@ -353,7 +397,7 @@ __global__ __launch_bounds__(256) void k_basis_finalize(double *basis,
   }
   double *dst = basis + (((long long)b * N + n) * F + bin) * K + k;
   const double ratio = sn / sd;
-  *dst = apply_floor((me ? ratio : sqrt(ratio)) * (*dst), floor_kind, eps);
+  *dst = apply_floor(ratio_pow(ratio, expo) * (*dst), floor_kind, eps);
 }
 
 // ================================================================================ loss data
@@ -362,7 +406,7 @@ __global__ __launch_bounds__(256) void k_basis_finalize(double *basis,
 // values a lane holds per source and tile (R >= floor^2 * K, so four of them stay far inside the
 // fp64 range), which cuts the dominant cost, the fp64 log, by four.
 // HAS_W = false: the ISS / IPA state passes the separated spectrogram itself (y = x_n, no filter)
-template <bool HAS_W, bool TMODEL>
+template <bool HAS_W, int MODEL>
 __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X,
                                                       const c128 *__restrict__ W,
                                                       const double *__restrict__ basis,
@@ -428,15 +472,20 @@ __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X
         }
         const bool valid = bin_valid && (j0 + q + 4 * r < T);
         const double rr = valid ? R[r] : 1.0;
-        const double pr = (valid ? cabs2(y) : 0.0) * rcp_nr(rr);
-        if (TMODEL)
+        const double ri = rcp_nr(rr);
+        const double pr = (valid ? cabs2(y) : 0.0) * ri;
+        if (MODEL == FM_T)
           prod_t *= fma(2.0 / fm.nu, pr, 1.0);  // (1 + nu/2) log(1 + (2/nu) P / R), ilrma.py:3301-3305
+        else if (MODEL == FM_GGD)
+          acc += pow_nonneg(pr, 0.5 * fm.beta);  // (P / R)^(beta/2), ilrma.py:4377-4381
+        else if (MODEL == FM_GAUSS1)
+          acc += pr * ri;                        // P / R^2
         else
           acc += pr;
         prod *= rr;
       }
-      acc += log(prod);
-      if (TMODEL) acc = fma(1.0 + 0.5 * fm.nu, log(prod_t), acc);
+      acc += (MODEL == FM_GAUSS1 ? 2.0 : 1.0) * log(prod);  // (2 / p) log R
+      if (MODEL == FM_T) acc = fma(1.0 + 0.5 * fm.nu, log(prod_t), acc);
     }
     vstage_store(st, vs[(jt - jt_begin + 1) & 1]);
     __syncthreads();
@@ -461,8 +510,8 @@ constexpr int WC_BINS = 16 * WC_WB;              // bins per workgroup
 
 // grid: 1-D, see TailPlan.  Unsplit blocks store U directly; split blocks store their partial sums
 // (already scaled by 1/T) to `upart` ([tail item][chunk][WC_BINS][N][N][N]) for k_wcov_fold.
-// TMODEL: varphi = 1 / (w R + (1 - w) |w_n^H x|^2), so the wave also needs its bins' demixing rows
-template <bool TMODEL>
+// t and GGD models: varphi depends on |w_n^H x|^2, so the wave also needs its bins' demixing rows
+template <int MODEL>
 __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X,
                                                       const c128 *__restrict__ W,
                                                       const double *__restrict__ basis,
@@ -474,7 +523,8 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
   constexpr int WSTRIDE = N * N + 1;
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
   __shared__ __attribute__((aligned(16))) c128 xpatch[4][XPATCH];
-  __shared__ __attribute__((aligned(16))) c128 wlc[TMODEL ? 4 * 16 * WSTRIDE : 1];
+  constexpr bool NEEDS_Y = MODEL == FM_T || MODEL == FM_GGD;
+  __shared__ __attribute__((aligned(16))) c128 wlc[NEEDS_Y ? 4 * 16 * WSTRIDE : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
   const BlockWork work = block_work(plan);
@@ -493,8 +543,8 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
       const int kk = 4 * ks + q, n = min(s0 + s, N - 1);
       tb[s][ks] = kk < K ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
     }
-  c128 *wmine = wlc + (TMODEL ? (wave * 16 + c) * WSTRIDE : 0);
-  if (TMODEL) {
+  c128 *wmine = wlc + (NEEDS_Y ? (wave * 16 + c) * WSTRIDE : 0);
+  if (NEEDS_Y) {
     for (int e = lane; e < 16 * N * N; e += 64) {
       const int bl = e / (N * N), rem = e % (N * N);
       wlc[(wave * 16 + bl) * WSTRIDE + rem] = W[((long long)b * F + min(i0 + bl, F - 1)) * (N * N) + rem];
@@ -530,12 +580,20 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
 #pragma unroll
       for (int s = 0; s < SG; ++s) {
         double den = R[s][r];
-        if (TMODEL) {
+        if (NEEDS_Y) {
           c128 y = cmake(0.0, 0.0);
 #pragma unroll
           for (int m = 0; m < N; ++m) cfma(y, wmine[min(s0 + s, N - 1) * N + m], x[m]);
-          den = fma(fm.w, den, fm.w1 * cabs2(y));
+          const double pw = cabs2(y);
+          if (MODEL == FM_T) {
+            den = fma(fm.w, den, fm.w1 * pw);
+          } else {  // GGD: (2 / beta) floor(P^((2 - beta) / 2)) R^(beta / 2)
+            const double y2b = apply_floor(pow_nonneg(pw, 0.5 * (2.0 - fm.beta)), fm.floor_kind,
+                                           fm.floor_eps);
+            den = (2.0 / fm.beta) * y2b * pow_nonneg(den, 0.5 * fm.beta);
+          }
         }
+        if (MODEL == FM_GAUSS1) den = den * den;  // R^(2/p), p = 1
         phi[s] = (valid && s0 + s < N) ? rcp_nr(den) : 0.0;
       }
       acc.add(x, phi);
@@ -724,7 +782,7 @@ __device__ __forceinline__ void xtile_load_framemajor(XTile &xt, const c128 *__r
 }
 
 // HAS_W = false: the ISS / IPA state passes the separated spectrogram itself (y = x_n, no filter)
-template <bool HAS_W, bool TMODEL>
+template <bool HAS_W, int MODEL>
 __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restrict__ X,
                                                          const c128 *__restrict__ W,
                                                          const double *__restrict__ basis,
@@ -799,8 +857,7 @@ __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restri
         const double rinv = rcp_nr(R[r]);
         const double bb = valid ? rinv : 0.0;
         const double pw = cabs2(y);
-        const double wgt = TMODEL ? rcp_nr(fma(fm.w, R[r], fm.w1 * pw)) : rinv;
-        const double aa = valid ? pw * wgt * rinv : 0.0;
+        const double aa = valid ? mm_num_factor<MODEL>(pw, R[r], rinv, fm) : 0.0;
         // GEMM2: A[row = c -> basis index c][kk = q] = T[n, bin i0+q+4r, c] (zero-staged pads)
         const double ta = tn[bl * TROW + c];
         numv[n] = mfma_f64(ta, aa, numv[n]);
@@ -826,85 +883,98 @@ __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restri
 }  // namespace ilrma_fast_n<N>
 using namespace SSSPY_CAT(ilrma_fast_n, SSSPY_N);
 
-// (tmodel, nu, me): Gauss (0) or Student-t (1) source model with dof nu; me = exponent 1
-static inline FastModel make_fast_model(int tmodel, double nu, int me) {
+// fmodel: FM_*; mparam: dof (t) / beta (GGD); me: exponent 1 instead of p / (p + 2)
+static inline FastModel make_fast_model(int fmodel, double mparam, int me, int floor_kind = 0,
+                                        double floor_eps = 0.0) {
   FastModel fm;
-  fm.nu = tmodel ? nu : 1.0;
-  fm.w = tmodel ? nu / (nu + 2.0) : 1.0;
+  const bool t = fmodel == FM_T;
+  fm.nu = t ? mparam : 1.0;
+  fm.w = t ? mparam / (mparam + 2.0) : 1.0;
   fm.w1 = 1.0 - fm.w;
-  fm.me = me;
+  fm.beta = fmodel == FM_GGD ? mparam : 2.0;
+  const double p = fmodel == FM_GAUSS1 ? 1.0 : 2.0;
+  fm.expo = me ? 1.0 : (fmodel == FM_GGD ? p / (fm.beta + p) : p / (p + 2.0));
+  fm.floor_kind = floor_kind;
+  fm.floor_eps = floor_eps;
   return fm;
 }
 
-#define SSSPY_FAST_LAUNCH2(kernel, A, Bv, ...)                                            \
-  do {                                                                                    \
-    if (A) {                                                                              \
-      if (Bv)                                                                             \
-        hipLaunchKernelGGL((kernel<true, true>), grid, block, 0, st, __VA_ARGS__);        \
-      else                                                                                \
-        hipLaunchKernelGGL((kernel<true, false>), grid, block, 0, st, __VA_ARGS__);       \
-    } else {                                                                              \
-      if (Bv)                                                                             \
-        hipLaunchKernelGGL((kernel<false, true>), grid, block, 0, st, __VA_ARGS__);       \
-      else                                                                                \
-        hipLaunchKernelGGL((kernel<false, false>), grid, block, 0, st, __VA_ARGS__);      \
-    }                                                                                     \
+#define SSSPY_FAST_LAUNCH_M(kernel, HW, ...)                                              \
+  switch (fmodel) {                                                                       \
+    case FM_T: hipLaunchKernelGGL((kernel<HW, FM_T>), grid, block, 0, st, __VA_ARGS__); break;     \
+    case FM_GGD: hipLaunchKernelGGL((kernel<HW, FM_GGD>), grid, block, 0, st, __VA_ARGS__); break; \
+    case FM_GAUSS1:                                                                       \
+      hipLaunchKernelGGL((kernel<HW, FM_GAUSS1>), grid, block, 0, st, __VA_ARGS__);       \
+      break;                                                                              \
+    default: hipLaunchKernelGGL((kernel<HW, FM_GAUSS>), grid, block, 0, st, __VA_ARGS__); break;   \
+  }
+#define SSSPY_FAST_LAUNCH2(kernel, A, ...)                  \
+  do {                                                      \
+    if (A) {                                                \
+      SSSPY_FAST_LAUNCH_M(kernel, true, __VA_ARGS__)        \
+    } else {                                                \
+      SSSPY_FAST_LAUNCH_M(kernel, false, __VA_ARGS__)       \
+    }                                                       \
   } while (0)
 
 // `part` must hold the scratch of ilrma_api.hip's basis_part_bytes() (used only when items are split)
 int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, double *basis, const double *act,
                                int B, int F, int T, int K, int floor_kind, double eps,
-                               double *part, int tmodel, double nu, int me, hipStream_t st) {
+                               double *part, int fmodel, double mparam, int me, hipStream_t st) {
   const TailPlan plan = make_tail_plan(B, (F + 63) / 64, (T + 15) / 16);
-  const FastModel fm = make_fast_model(tmodel, nu, me);
+  const FastModel fm = make_fast_model(fmodel, mparam, me);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
-  SSSPY_FAST_LAUNCH2(k_basis_fast, W != nullptr, tmodel != 0, (const c128 *)X, (const c128 *)W,
+  SSSPY_FAST_LAUNCH2(k_basis_fast, W != nullptr, (const c128 *)X, (const c128 *)W,
                      basis, act, F, T, K, floor_kind, eps, plan, part, fm);
   int rc = check_launch("k_basis_fast");
   if (rc || plan.tail == 0) return rc;
   hipLaunchKernelGGL(k_basis_finalize, dim3(N * 64 * 16 / 256, plan.tail), block, 0, st, basis,
-                     part, F, K, plan, floor_kind, eps, me);
+                     part, F, K, plan, floor_kind, eps, fm.expo);
   return check_launch("k_basis_finalize");
 }
 
 int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *basis,
                                     const double *act, double *part, int nchunks, int B, int F,
-                                    int T, int K, int tmodel, double nu, hipStream_t st) {
+                                    int T, int K, int fmodel, double mparam, hipStream_t st) {
   const int ntiles = (F + 15) / 16;
   const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
-  const FastModel fm = make_fast_model(tmodel, nu, 0);
+  const FastModel fm = make_fast_model(fmodel, mparam, 0);
   dim3 grid((T + 63) / 64, nchunks, B), block(256);
-  SSSPY_FAST_LAUNCH2(k_activation_fast, W != nullptr, tmodel != 0, (const c128 *)X,
+  SSSPY_FAST_LAUNCH2(k_activation_fast, W != nullptr, (const c128 *)X,
                      (const c128 *)W, basis, act, part, F, T, K, tiles_per_chunk, nchunks, fm);
   return check_launch("k_activation_fast");
 }
 
 // `out` (B doubles) must be zeroed by the caller
 int LAUNCHER(ilrma_fast_loss)(const void *X, const void *W, const double *basis, const double *act,
-                              double *out, int B, int F, int T, int K, int tmodel, double nu,
+                              double *out, int B, int F, int T, int K, int fmodel, double mparam,
                               hipStream_t st) {
   const TailPlan plan = make_tail_plan(B, (F + 63) / 64, (T + 15) / 16);
-  const FastModel fm = make_fast_model(tmodel, nu, 0);
+  const FastModel fm = make_fast_model(fmodel, mparam, 0);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
-  SSSPY_FAST_LAUNCH2(k_loss_fast, W != nullptr, tmodel != 0, (const c128 *)X, (const c128 *)W,
+  SSSPY_FAST_LAUNCH2(k_loss_fast, W != nullptr, (const c128 *)X, (const c128 *)W,
                      basis, act, out, F, T, K, plan, fm);
   return check_launch("k_loss_fast");
 }
 
 // `upart` must hold u_part_bytes() of ilrma_api.hip (used only when some items are split);
-// W is read by the t model only
+// W is read by the t and GGD models only; the floor is GGD's (on |y|^(2 - beta))
 int LAUNCHER(ilrma_fast_wcov)(const void *X, const void *W, const double *basis, const double *act,
-                              void *U, int B, int F, int T, int K, void *upart, int tmodel,
-                              double nu, hipStream_t st) {
+                              void *U, int B, int F, int T, int K, void *upart, int fmodel,
+                              double mparam, int floor_kind, double floor_eps, hipStream_t st) {
   const TailPlan plan = make_tail_plan(B, (F + WC_BINS - 1) / WC_BINS, (T + 15) / 16);
-  const FastModel fm = make_fast_model(tmodel, nu, 0);
+  const FastModel fm = make_fast_model(fmodel, mparam, 0, floor_kind, floor_eps);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
-  if (tmodel)
-    hipLaunchKernelGGL(k_wcov_fast<true>, grid, block, 0, st, (const c128 *)X, (const c128 *)W,
-                       basis, act, (c128 *)U, F, T, K, plan, (c128 *)upart, fm);
-  else
-    hipLaunchKernelGGL(k_wcov_fast<false>, grid, block, 0, st, (const c128 *)X, (const c128 *)W,
-                       basis, act, (c128 *)U, F, T, K, plan, (c128 *)upart, fm);
+#define SSSPY_WCOV_LAUNCH(M)                                                                     \
+  hipLaunchKernelGGL(k_wcov_fast<M>, grid, block, 0, st, (const c128 *)X, (const c128 *)W, basis, \
+                     act, (c128 *)U, F, T, K, plan, (c128 *)upart, fm)
+  switch (fmodel) {
+    case FM_T: SSSPY_WCOV_LAUNCH(FM_T); break;
+    case FM_GGD: SSSPY_WCOV_LAUNCH(FM_GGD); break;
+    case FM_GAUSS1: SSSPY_WCOV_LAUNCH(FM_GAUSS1); break;
+    default: SSSPY_WCOV_LAUNCH(FM_GAUSS); break;
+  }
+#undef SSSPY_WCOV_LAUNCH
   int rc = check_launch("k_wcov_fast");
   if (rc || plan.tail == 0) return rc;
   hipLaunchKernelGGL(k_wcov_fold, dim3((WC_BINS * N * N * N + 255) / 256, plan.tail), block, 0, st,
@@ -927,5 +997,6 @@ int LAUNCHER(ilrma_fast_wcov_frame)(const void *X, const double *weight, void *U
 }
 
 #undef SSSPY_FAST_LAUNCH2
+#undef SSSPY_FAST_LAUNCH_M
 
 }  // namespace ssspy

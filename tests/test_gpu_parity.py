@@ -252,6 +252,56 @@ def test_heavy_tailed_ilrma_sweep_against_oracle(model, N, K, algo, domain):
     np.testing.assert_allclose(m.loss, ref.loss, rtol=LOSS_RTOL)
 
 
+@pytest.mark.parametrize("algo", ["IP", "ISS", "IP2"])
+@pytest.mark.parametrize("N,K,F,T,domain", [(4, 16, 70, 130, 1), (3, 5, 33, 47, 1), (2, 16, 20, 64, 1),
+                                            (4, 7, 33, 48, 1.5), (4, 16, 70, 130, 2)])
+def test_gauss_ilrma_domain_sweep_against_oracle(algo, N, K, F, T, domain):
+    """Amplitude-domain (domain = 1) Gauss-ILRMA runs on the tuned kernels (R^3 / R^2 instead of
+    powers, cube-root update), other domains on the generic ones; several frame tiles, ragged
+    edges, split and unsplit work items."""
+    from oracle.ilrma import GaussILRMAOracle
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    X = nmf_mixture(40 + N + F, N, F, T)
+    rng = np.random.default_rng(N * K)
+    basis, act = rng.random((N, F, K)), rng.random((N, K, T))
+    ref = GaussILRMAOracle(n_basis=K, spatial_algorithm=algo, domain=domain)
+    Yr = ref.run(X, n_iter=3, basis=basis, activation=act)
+    m = GaussILRMA(n_basis=K, spatial_algorithm=algo, domain=domain)
+    Y = m(X, n_iter=3, basis=basis, activation=act)
+    assert rel_err(Y, Yr) < TOL
+    assert rel_err(m.basis, ref.basis) < TOL and rel_err(m.activation, ref.activation) < TOL
+    np.testing.assert_allclose(m.loss, ref.loss, rtol=LOSS_RTOL)
+
+
+@pytest.mark.parametrize("beta", [0.5, 1.0, 1.9])
+@pytest.mark.parametrize("algo", ["IP", "ISS"])
+def test_ggd_ilrma_tuned_kernels_against_oracle(beta, algo):
+    """GGD-ILRMA at domain 2 on the tuned kernels: shape parameters across (0, 2), 4 sources,
+    n_basis 16, several frame tiles, and a batch large enough for unsplit work items."""
+    from oracle.ilrma import GaussILRMAOracle
+    from ssspy_amd.bss.ilrma import GGDILRMA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    N, K, F, T = 4, 16, 70, 130
+    X = nmf_mixture(91, N, F, T)
+    rng = np.random.default_rng(17)
+    basis, act = rng.random((N, F, K)), rng.random((N, K, T))
+    ref = GaussILRMAOracle(n_basis=K, spatial_algorithm=algo, model=("ggd", beta))
+    Yr = ref.run(X, n_iter=3, basis=basis, activation=act)
+    m = GGDILRMA(n_basis=K, beta=beta, spatial_algorithm=algo)
+    Y = m(X, n_iter=3, basis=basis, activation=act)
+    assert rel_err(Y, Yr) < TOL
+    assert rel_err(m.basis, ref.basis) < TOL and rel_err(m.activation, ref.activation) < TOL
+    np.testing.assert_allclose(m.loss, ref.loss, rtol=LOSS_RTOL)
+    nb = 260  # 520 (mixture, 64-bin group) items: 512 unsplit + 8 split
+    Xb = np.stack([X] * nb)
+    mb = GGDILRMA(n_basis=K, beta=beta, spatial_algorithm=algo)
+    Yb = mb(Xb, n_iter=3, basis=np.stack([basis] * nb), activation=np.stack([act] * nb))
+    assert rel_err(Yb[0], Y) < 1e-12 and rel_err(Yb[-1], Y) < 1e-12
+
+
 def test_heavy_tailed_ilrma_batch_and_stepwise():
     """Batched TILRMA == per-mixture runs; fused update_once == the step methods."""
     from ssspy_amd.bss.ilrma import TILRMA
