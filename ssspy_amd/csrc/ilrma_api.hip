@@ -20,7 +20,7 @@ namespace ssspy {
 DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
 #undef DECL_N
 
-// throughput variants (ilrma_fast.hip): domain == 2, n_basis <= 16, n_sources <= 4
+// throughput variants (ilrma_fast.hip): n_basis <= 16, n_sources <= 4, models of fast_model_id()
 #define DECL_FAST(n)                                                                           \
   int ilrma_fast_basis_n##n(const void *, const void *, double *, const double *, int, int, int, \
                             int, int, double, double *, int, double, int, hipStream_t);        \

@@ -1,5 +1,6 @@
-// Throughput kernels of the Gauss-ILRMA iteration for the common case
-//   domain == 2, n_basis <= 16, n_sources <= 4.
+// Throughput kernels of the ILRMA iteration for the common case
+//   n_basis <= 16, n_sources <= 4, source model one of FM_* below (Gauss at domain 2 or 1,
+//   Student-t and GGD at domain 2).
 // Same math and MFMA tilings as ilrma_kernels.hip (see the header comment there); what
 // changes is the scheduling, driven by the first rocprof PMC pass on MI355X (profiles/):
 // the generic kernels sat in s_waitcnt 71 % of the time at one wave per SIMD because every
