@@ -219,9 +219,11 @@ __device__ __forceinline__ void xtile_load_binmajor(XTile &xt, const c128 *__res
 // patch: a load instruction takes 4 bin rows x 256 contiguous bytes (lane = frame), the patch
 // turns (lane = frame, register = bin) into (lane = bin, register = frame).  Two channels per
 // pass so the patch stays at 8.5 KB per wave; rows are 17 slots apart, which makes both the
-// frame-major writes and the bin-major reads bank-conflict free.  LDS operations of one wave are
-// processed in order, so no barrier is needed.  (Measured on the covariance kernel, whose 2 waves
-// per bin tile made the texture addresser the limiter: 1.32 -> see profiles/.)
+// frame-major writes and the bin-major reads bank-conflict free.  The patch is wave-private, so no
+// workgroup barrier is needed -- but the exchange is between lanes, which the per-thread memory
+// model does not order: every write and read phase is fenced explicitly (see below).  (Measured on
+// the covariance kernel, whose 2 waves per bin tile made the texture addresser the limiter:
+// 1.32 -> 1.10 ms.)
 constexpr int XPATCH = 2 * 16 * 17;  // c128 slots per wave
 
 __device__ __forceinline__ void xtile_load_transposed(XTile &xt, const c128 *__restrict__ Xb, int F,
@@ -235,12 +237,20 @@ __device__ __forceinline__ void xtile_load_transposed(XTile &xt, const c128 *__r
       xt.x[m][rr] = Xb[((long long)m * F + min(i0 + 4 * rr + q, F - 1)) * T + jf];
 #pragma unroll
   for (int m0 = 0; m0 < N; m0 += 2) {
+    // The patch is reused by every pass and every tile, and the exchange is between LANES: nothing
+    // in the per-thread memory model orders this pass's writes after the previous pass's reads
+    // (measured: without the wait a barrier-free walk returned wrong tiles for N >= 3).  Drain the
+    // wave's outstanding LDS reads and pin the order for the compiler.
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
 #pragma unroll
     for (int mm = 0; mm < 2; ++mm)
       if (m0 + mm < N) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) patch[(mm * 16 + 4 * rr + q) * 17 + c] = xt.x[m0 + mm][rr];
       }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // the writes of all lanes have landed
 #pragma unroll
     for (int mm = 0; mm < 2; ++mm)
       if (m0 + mm < N) {
@@ -522,7 +532,6 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
                                                       FastModel fm) {
   constexpr int SG = WC_SG;
   constexpr int WSTRIDE = N * N + 1;
-  __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
   __shared__ __attribute__((aligned(16))) c128 xpatch[4][XPATCH];
   constexpr bool NEEDS_Y = MODEL == FM_T || MODEL == FM_GGD;
   __shared__ __attribute__((aligned(16))) c128 wlc[NEEDS_Y ? 4 * 16 * WSTRIDE : 1];
@@ -556,21 +565,29 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
   const int ntiles = (T + 15) >> 4;
   const int tpc = (ntiles + nchunks - 1) / nchunks;
   const int jt_begin = work.chunk * tpc, jt_end = min(ntiles, jt_begin + tpc);
-  VStage st;
   XTile cur;
-  vstage_load(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
-  vstage_store(st, vs[0]);
-  __syncthreads();
+  if (NEEDS_Y) __syncthreads();
   for (int jt = jt_begin; jt < jt_end; ++jt) {
     const int j0 = jt * 16;
-    const int jn = min(jt + 1, jt_end - 1) * 16;
-    xtile_load_transposed(cur, Xb, F, T, i0, j0, c, q, xpatch[wave]);
-    vstage_load(st, act_b, K, T, jn);
-    const double *vcur = vs[(jt - jt_begin) & 1];
-    double4_t R[SG];
+    // GEMM1 A operand straight from global memory: V[n, 4ks+q, j0+c] (the activation of a mixture
+    // is 0.26 MB, shared by all its items on this XCD: L2 hits), 128-byte runs per (ks, q)
+    double va[SG][4];
+    const int jv = j0 + c;
 #pragma unroll
     for (int s = 0; s < SG; ++s)
-      R[s] = rt_from_lds(vcur + min(s0 + s, N - 1) * 16 * VROW, tb[s], c, q);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int kk = 4 * ks + q, n = min(s0 + s, N - 1);
+        va[s][ks] = (kk < K && jv < T) ? act_b[((long long)n * K + kk) * T + jv] : 0.0;
+      }
+    xtile_load_transposed(cur, Xb, F, T, i0, j0, c, q, xpatch[wave]);
+    double4_t R[SG];
+#pragma unroll
+    for (int s = 0; s < SG; ++s) {
+      R[s] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) R[s] = mfma_f64(va[s][ks], tb[s][ks], R[s]);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool valid = j0 + q + 4 * r < T;
@@ -599,8 +616,6 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
       }
       acc.add(x, phi);
     }
-    vstage_store(st, vs[(jt - jt_begin + 1) & 1]);
-    __syncthreads();
   }
   acc.fold_q();
   // every q-lane holds the full sums of bin i0+c for this wave's SG sources; spread the stores:
