@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the separators against the CPU oracle (a development tool; the
+fixed cases live in tests/).  Shapes are drawn to cross tile edges (16 / 32 / 64 bins, 16 / 64
+frames), the split / unsplit work-item boundary and every option of the ILRMA / AuxIVA classes.
+
+    python benchmarks/fuzz_parity.py [n_cases] [seed]
+"""
+import os
+import sys
+import traceback
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle.ilrma import GaussILRMAOracle  # noqa: E402
+from oracle.iva import AuxIVAOracle  # noqa: E402
+from ssspy_amd.bss.ilrma import GGDILRMA, TILRMA, GaussILRMA  # noqa: E402
+from ssspy_amd.bss.iva import AuxGaussIVA, AuxLaplaceIVA  # noqa: E402
+from ssspy_amd.utils.dataset import nmf_mixture  # noqa: E402
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    bad = 0
+    for case in range(n_cases):
+        N = int(rng.integers(2, 5))
+        F = int(rng.choice([1, 3, 15, 16, 17, 31, 33, 63, 64, 65, 70, 129]))
+        T = int(rng.choice([2, 5, 15, 16, 17, 31, 32, 33, 47, 64, 65, 100, 130]))
+        K = int(rng.choice([1, 2, 3, 4, 7, 8, 15, 16]))
+        B = int(rng.choice([1, 1, 1, 2, 5, 40]))
+        algo = str(rng.choice(["IP", "ISS", "IP2", "ISS2"]))
+        if T < 2 * N:
+            T = 2 * N + 3
+        kind = str(rng.choice(["gauss", "gauss", "t", "ggd", "gauss_p1", "iva_lap", "iva_gauss"]))
+        X = np.stack([nmf_mixture(int(rng.integers(1 << 30)), N, F, T) for _ in range(B)])
+        tag = (kind, algo, N, F, T, K, B)
+        try:
+            if kind.startswith("iva"):
+                cls = AuxLaplaceIVA if kind == "iva_lap" else AuxGaussIVA
+                m = cls(spatial_algorithm=algo)
+                Y = m(X, n_iter=3)
+                for b in {0, B - 1}:
+                    ref = AuxIVAOracle(spatial_algorithm=algo,
+                                       contrast="laplace" if kind == "iva_lap" else "gauss")
+                    Yr = ref.run(X[b], n_iter=3)
+                    e = rel(Y[b], Yr)
+                    el = np.max(np.abs(np.asarray(m.loss)[:, b] / np.asarray(ref.loss) - 1))
+                    if not (e < 1e-7 and el < 1e-8):
+                        bad += 1
+                        print("MISMATCH", tag, b, e, el)
+                continue
+            model = {"gauss": ("gauss", None), "gauss_p1": ("gauss", None), "t": ("t", 4.0),
+                     "ggd": ("ggd", float(rng.choice([0.7, 1.0, 1.6])))}[kind]
+            domain = 1 if kind == "gauss_p1" else 2
+            src = "MM" if kind in ("ggd", "gauss_p1") else str(rng.choice(["MM", "ME"]))
+            norm = rng.choice([True, False])
+            basis = rng.random((B, N, F, K)) + 0.05
+            act = rng.random((B, N, K, T)) + 0.05
+            kw = dict(n_basis=K, spatial_algorithm=algo, source_algorithm=src, domain=domain,
+                      normalization=bool(norm))
+            if kind == "t":
+                m = TILRMA(dof=model[1], **kw)
+            elif kind == "ggd":
+                m = GGDILRMA(beta=model[1], **kw)
+            else:
+                m = GaussILRMA(**kw)
+            Y = m(X, n_iter=3, basis=basis, activation=act)
+            for b in {0, B - 1}:
+                ref = GaussILRMAOracle(model=model, **kw)
+                Yr = ref.run(X[b], n_iter=3, basis=basis[b], activation=act[b])
+                e = rel(Y[b], Yr)
+                eb = rel(m.basis[b], ref.basis)
+                el = np.max(np.abs(np.asarray(m.loss)[:, b] / np.asarray(ref.loss) - 1))
+                if not (e < 1e-7 and eb < 1e-7 and el < 1e-8):
+                    bad += 1
+                    print("MISMATCH", tag, src, bool(norm), b, e, eb, el)
+        except Exception as exc:  # singular bins etc.: both sides should agree on raising
+            print("EXC", tag, type(exc).__name__, str(exc)[:100])
+            if not isinstance(exc, np.linalg.LinAlgError):
+                traceback.print_exc()
+                bad += 1
+    print("cases", n_cases, "mismatches", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
