@@ -116,14 +116,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Dry run of the N > 1 control flow on a one-GPU box (development only): every rank on device 0,
+    # gloo for the barrier and the timing max.  The driver's runs use neither variable.
+    backend = os.environ.get("SSSPY_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("SSSPY_BENCH_ONE_DEVICE") else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if distributed:
         import torch.distributed as dist
 
         from ssspy_amd import parallel
 
-        parallel.init_from_env(backend="nccl")  # RCCL; used for the barrier and the timing max only
+        if backend == "nccl":
+            parallel.init_from_env(backend="nccl")  # RCCL; the barrier and the timing max only
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = world if distributed else 1
 
     from ssspy_amd import _device as dv
@@ -144,7 +151,10 @@ def main():
     def fence():
         torch.cuda.synchronize()
         if distributed:
-            dist.barrier(device_ids=[local_rank])
+            if backend == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     # warm-up (untimed)
@@ -155,7 +165,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
-        elapsed = parallel.max_over_ranks(elapsed, dev)
+        elapsed = parallel.max_over_ranks(elapsed, dev if backend == "nccl" else None)
     sep._check_device_errors()
 
     # per-kernel-group durations from the HIP events of the timed region (this rank)
