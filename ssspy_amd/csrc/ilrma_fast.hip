@@ -262,12 +262,14 @@ __device__ __forceinline__ void xtile_load_transposed(XTile &xt, const c128 *__r
 
 // GEMM1 of the bin-major tile from the staged V: R[bin c, frame j0+q+4r] in register r
 // (D row q+4r reads slot tile_pi(q+4r) = 4q+r, which holds frame tile_pi(4q+r) = q+4r)
+// ksteps = ceil(K / 4): k-slabs beyond n_basis are zero on both sides and are skipped
 __device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const double (&tb)[4], int c,
-                                                 int q) {
+                                                 int q, int ksteps) {
   double4_t R = {0.0, 0.0, 0.0, 0.0};
   const int col = tile_pi(c);
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) R = mfma_f64(vs_n[(4 * ks + q) * VROW + col], tb[ks], R);
+  for (int ks = 0; ks < 4; ++ks)
+    if (ks < ksteps) R = mfma_f64(vs_n[(4 * ks + q) * VROW + col], tb[ks], R);
   return R;
 }
 
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
 #pragma unroll
     for (int n = 0; n < N; ++n) {
       const double *vn = vcur + n * 16 * VROW;
-      const double4_t R = rt_from_lds(vn, tb[n], c, q);
+      const double4_t R = rt_from_lds(vn, tb[n], c, q, (K + 3) >> 2);
       const double2 vb01 = *reinterpret_cast<const double2 *>(vn + c * VROW + 4 * q);
       const double2 vb23 = *reinterpret_cast<const double2 *>(vn + c * VROW + 4 * q + 2);
       const double vb[4] = {vb01.x, vb01.y, vb23.x, vb23.y};
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X
     const double *vcur = vs[(jt - jt_begin) & 1];
 #pragma unroll
     for (int n = 0; n < N; ++n) {
-      const double4_t R = rt_from_lds(vcur + n * 16 * VROW, tb[n], c, q);
+      const double4_t R = rt_from_lds(vcur + n * 16 * VROW, tb[n], c, q, (K + 3) >> 2);
       c128 wr[N];
 #pragma unroll
       for (int m = 0; m < N; ++m) wr[m] = wmine[n * N + m];
@@ -586,7 +588,8 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
     for (int s = 0; s < SG; ++s) {
       R[s] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) R[s] = mfma_f64(va[s][ks], tb[s][ks], R[s]);
+      for (int ks = 0; ks < 4; ++ks)
+        if (ks < ((K + 3) >> 2)) R[s] = mfma_f64(va[s][ks], tb[s][ks], R[s]);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -858,7 +861,8 @@ __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restri
       // GEMM1: A[row = c -> bin i0+c][kk = q] = T[n, i0+c, 4ks+q]
       double4_t R = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) R = mfma_f64(tn[c * TROW + 4 * ks + q], vb[n][ks], R);
+      for (int ks = 0; ks < 4; ++ks)
+        if (ks < ((K + 3) >> 2)) R = mfma_f64(tn[c * TROW + 4 * ks + q], vb[n][ks], R);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int bl = q + 4 * r;
