@@ -6,7 +6,8 @@ Restates ``AuxIVA`` / ``AuxLaplaceIVA`` / ``AuxGaussIVA`` of the reference for
 ``spatial_algorithm in {"IP","IP1","ISS","ISS1"}`` (SURVEY.md section 8 rows
 a12-a15, Appendix C).  The contrast is named by a string instead of a pair of
 Python closures: ``"laplace"`` (G = 2r, G' = 2) or ``"gauss"``
-(G = F log(alpha) + r^2/alpha, G' = 2r/alpha, alpha refreshed every iteration).
+(G = F log(alpha) + r^2/alpha, G' = 2r/alpha, alpha refreshed every iteration); ``("power", p)``
+is the user-closure case of the generic ``AuxIVA`` class, G_R(r) = r^p, G' = p r^(p-1).
 """
 
 import numpy as np
@@ -30,7 +31,7 @@ class AuxIVAOracle:
         assert spatial_algorithm in ("IP", "IP1", "IP2", "ISS", "ISS1", "ISS2", "IPA")
         # IPA keyword arguments of the reference (defaults: ssspy/bss/ilrma.py:749, iva.py:1579)
         self.lqpqm_normalization, self.newton_iter = True, 1
-        assert contrast in ("laplace", "gauss")
+        assert contrast in ("laplace", "gauss") or (type(contrast) is tuple and contrast[0] == "power")
         self.pairs = None
         self.spatial_algorithm = spatial_algorithm
         self.contrast = contrast
@@ -67,12 +68,16 @@ class AuxIVAOracle:
         r = np.linalg.norm(Y, axis=1)
         if self.contrast == "laplace":
             return 2 * r
+        if type(self.contrast) is tuple:
+            return r ** self.contrast[1]
         return self.n_bins * np.log(self.variance) + (r**2) / self.variance
 
     def d_contrast_fn(self, r, variance=None):
         """ref: ssspy/bss/iva.py:3105-3115 (Laplace), :3273-3289 (Gauss)."""
         if self.contrast == "laplace":
             return 2 * np.ones_like(r)
+        if type(self.contrast) is tuple:
+            return self.contrast[1] * r ** (self.contrast[1] - 1)
         return 2 * r / (self.variance if variance is None else variance)
 
     def _current_output(self):

@@ -94,7 +94,10 @@ def update_by_iss1(Y, varphi, flooring=DEFAULT_FLOOR):
 
 
 def projection_back_filter(W, reference_id=0):
-    """W <- W * (W^-1)[ref, :]^T (row scaling).  ref: ssspy/algorithm/projection_back.py:87-99."""
+    """W <- W * (W^-1)[ref, :]^T (row scaling).  ref: ssspy/algorithm/projection_back.py:87-99;
+    reference_id=None: every channel, stacked on a new leading axis (:92-95)."""
+    if reference_id is None:
+        return np.stack([projection_back_filter(W, c) for c in range(W.shape[-1])])
     scale = np.linalg.inv(W)[..., reference_id, :]
     return W * scale[..., None]
 
@@ -102,8 +105,11 @@ def projection_back_filter(W, reference_id=0):
 def projection_back_output(Y, X, reference_id=0):
     """Least-squares scale of Y on the reference channel of X.
 
-    ref: ssspy/algorithm/projection_back.py:100-121.  Y, X (N, F, T) -> (N, F, T).
+    ref: ssspy/algorithm/projection_back.py:100-121.  Y, X (N, F, T) -> (N, F, T);
+    reference_id=None: every channel, (n_channels, N, F, T) (:113-116).
     """
+    if reference_id is None:
+        return np.stack([projection_back_output(Y, X, c) for c in range(X.shape[0])])
     Yf = Y.transpose(1, 0, 2)
     Xf = X.transpose(1, 0, 2)
     YH = Yf.transpose(0, 2, 1).conj()
@@ -115,8 +121,10 @@ def projection_back_output(Y, X, reference_id=0):
 def minimal_distortion_output(Y, X, reference_id=0):
     """conj(z) y with z = <y, x_ref> / <y, y> per (source, bin).
 
-    ref: ssspy/algorithm/minimal_distortion_principle.py:6-43.
+    ref: ssspy/algorithm/minimal_distortion_principle.py:6-43 (reference_id=None: every channel, :34-35).
     """
+    if reference_id is None:
+        return np.stack([minimal_distortion_output(Y, X, c) for c in range(X.shape[0])])
     num = np.sum(Y * X[reference_id].conj(), axis=-1, keepdims=True)
     den = np.sum(np.abs(Y) ** 2, axis=-1, keepdims=True)
     return (num / den).conj() * Y

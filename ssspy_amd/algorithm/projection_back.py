@@ -22,10 +22,13 @@ def projection_back(
         data_or_filter: demixing filters (n_bins, n_sources, n_channels) when ``reference``
             is None, else separated spectrograms (n_sources, n_bins, n_frames).
         reference: the mixture (n_channels, n_bins, n_frames) for the spectrogram form.
-        reference_id: reference channel.
+        reference_id: reference channel; ``None`` = every channel in turn, stacked on a new leading
+            axis of length n_channels (ref: projection_back.py:92-95, :113-116).
     """
     if reference_id is None:
-        raise NotImplementedError("reference_id=None (all channels) is not built for the device path.")
+        n_channels = data_or_filter.shape[-1] if reference is None else reference.shape[0]
+        return np.stack([projection_back(data_or_filter, reference=reference, reference_id=c)
+                         for c in range(n_channels)], axis=0)
     info = dv.zeros((1,), dv.i32)
     if reference is None:
         W = dv.to_device(data_or_filter[None], dtype=np.complex128)

@@ -101,8 +101,20 @@ class DeviceStateMixin:
             host = dv.to_host(ent["dev"])
             if not self._batched:
                 host = host[0]
+            # a snapshot of the device buffer, which stays the truth: writing into the snapshot
+            # would be lost silently, so it is read-only -- state is changed by assigning the
+            # attribute (``m.basis = new``), which uploads
+            host.flags.writeable = False
             ent["host"] = host
         return ent["host"]
+
+    def _final_output(self):
+        """What ``__call__`` returns: the host copy of ``output``.  The iteration is over, so the
+        array is handed out writable like the reference's (which returns ``self.output`` itself)."""
+        out = self.output
+        if isinstance(out, np.ndarray):
+            out.flags.writeable = True
+        return out
 
     def _state_set_host(self, name, value, dtype=None):
         if value is None:

@@ -195,9 +195,19 @@ class ILRMABase(DeviceStateMixin, IterativeMethodBase):
         filter is re-fitted as Y X^H (X X^H)^-1 like the reference.
         ref: ssspy/bss/ilrma.py:567-579, :1981-1989; algorithm/minimal_distortion_principle.py:6-43."""
         assert self.scale_restoration, "Set self.scale_restoration=True."
-        if self.reference_id is None:
-            raise NotImplementedError("reference_id=None (all channels) is not built for the device path.")
         filt = self._uses_filter()
+        if self.reference_id is None:
+            # reachable only by clearing the attribute after construction; as in the reference the
+            # estimate gains a leading channel axis (minimal_distortion_principle.py:34-35) and a
+            # filter state cannot take that shape
+            if filt:
+                raise ValueError("reference_id=None needs the output state (ISS / IPA), not filters.")
+            from ..algorithm import minimal_distortion_principle as _mdp
+
+            Y, X = dv.to_host(self._state_dev("output")), dv.to_host(self._X)
+            out = np.stack([_mdp(y, reference=x, reference_id=None) for y, x in zip(Y, X)])
+            self.output = out if self._batched else out[0]
+            return
         if filt:
             Y = _ops.separate(self._X, self._state_dev("demix_filter"))
         else:
@@ -271,7 +281,7 @@ class _MMILRMA(ILRMABase):
             self.restore_scale()
         if self._uses_filter():
             self._state_set_dev("output", _ops.separate(self._X, self._state_dev("demix_filter")))
-        return self.output
+        return self._final_output()
 
     def __repr__(self) -> str:
         s = "{}(n_basis={}{}, spatial_algorithm={}, source_algorithm={}, domain={}".format(

@@ -5,7 +5,10 @@ Drop-in separator classes for the ``AuxIVA`` family of the reference's ``ssspy.b
 ``AuxGaussIVA`` with ``spatial_algorithm in {"IP", "IP1", "ISS", "ISS1"}``.  The contrast
 functions of the reference are Python closures; the kernels implement the two the
 reference ships (Laplace: G = 2r; time-varying Gauss: G = F log(alpha) + r^2/alpha).  A
-user-supplied closure cannot run inside a kernel and raises ``NotImplementedError``.
+user-supplied ``d_contrast_fn`` is evaluated on the host on the (n_sources, n_frames) frame norms
+the device produces (a few KB per iteration; both passes over the spectrogram stay in the kernels);
+a user-supplied ``contrast_fn`` takes the whole estimate and is evaluated on a host copy of it,
+only when the loss is recorded.
 The gradient / natural-gradient / Fast / PDS / ADMM IVA variants are out of scope
 (SURVEY.md section 2, row 3).
 """
@@ -128,16 +131,25 @@ class IVABase(DeviceStateMixin, IterativeMethodBase):
             G = _ops.projection_back_scale(XY, YY, self.reference_id, info)
             _ops.separate(Y, G, out=Y)
             self._state_touch("output")
-            self.__dict__["_r2_cache"] = None
 
     def apply_minimal_distortion_principle(self) -> None:
         """Per (bin, source) scale z = <y, x_ref> / <y, y>, output conj(z) y; with a filter state the
         filter is re-fitted as Y X^H (X X^H)^-1 like the reference.
         ref: ssspy/bss/iva.py:269-281, :2206-2214; algorithm/minimal_distortion_principle.py:6-43."""
         assert self.scale_restoration, "Set self.scale_restoration=True."
-        if self.reference_id is None:
-            raise NotImplementedError("reference_id=None (all channels) is not built for the device path.")
         filt = self._uses_filter()
+        if self.reference_id is None:
+            # reachable only by clearing the attribute after construction; as in the reference the
+            # estimate gains a leading channel axis (minimal_distortion_principle.py:34-35) and a
+            # filter state cannot take that shape
+            if filt:
+                raise ValueError("reference_id=None needs the output state (ISS / IPA), not filters.")
+            from ..algorithm import minimal_distortion_principle as _mdp
+
+            Y, X = dv.to_host(self._state_dev("output")), dv.to_host(self._X)
+            out = np.stack([_mdp(y, reference=x, reference_id=None) for y, x in zip(Y, X)])
+            self.output = out if self._batched else out[0]
+            return
         if filt:
             Y = _ops.separate(self._X, self._state_dev("demix_filter"))
         else:
@@ -181,15 +193,17 @@ class AuxIVABase(IVABase):
 
 
 def _device_contrast(contrast_fn, d_contrast_fn):
-    """Which built-in contrast the pair of callables stands for (tag set by the subclasses)."""
+    """Which built-in contrast the pair of callables stands for (tag set by the subclasses), or
+    None for user closures.  A closure cannot run inside a kernel, and it does not have to: the
+    reference applies ``d_contrast_fn`` to the (n_sources, n_frames) frame norms only
+    (ssspy/bss/iva.py:1787-1789), a few KB that the frame-power kernel produces -- the closure runs
+    on the host on that array between the two passes over the spectrogram, which stay on the device."""
     a = getattr(contrast_fn, "_ssspy_amd_contrast", None)
     b = getattr(d_contrast_fn, "_ssspy_amd_contrast", None)
     if a is None or a != b:
-        raise NotImplementedError(
-            "AuxIVA on the device path supports the Laplace and time-varying Gauss contrasts "
-            "(use AuxLaplaceIVA / AuxGaussIVA); arbitrary contrast_fn / d_contrast_fn closures "
-            "cannot be evaluated inside the HIP kernels."
-        )
+        if d_contrast_fn is None:
+            raise ValueError("Specify d_contrast_fn (and contrast_fn when record_loss=True).")
+        return None
     return a
 
 
@@ -252,7 +266,7 @@ class AuxIVA(AuxIVABase):
             self.restore_scale()
         if self._uses_filter():
             self._state_set_dev("output", _ops.separate(self._X, self._state_dev("demix_filter")))
-        return self.output
+        return self._final_output()
 
     def __repr__(self) -> str:
         s = "AuxIVA(spatial_algorithm={}, scale_restoration={}, record_loss={}".format(
@@ -267,23 +281,47 @@ class AuxIVA(AuxIVABase):
         super()._reset(**kwargs)
         if self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"]:
             self.demix_filter = None
-        self._r2_cache = None  # frame powers of the CURRENT output (ISS state), if known
+        # frame powers of the output (ISS state) as (tensor, revision of `output` they describe): any
+        # later write to the output -- a kernel, scale restoration, an assignment by a callback --
+        # changes the revision and retires the cache
+        self._r2_cache = None
 
     def _variance_tensor(self):
         return None
 
     def _weights(self, flooring_fn):
         """Auxiliary weights varphi_nj = G'(r_nj) / floor(2 r_nj), (B, N, T)."""
-        return _ops.iva_weight(self._frame_power(), self.n_bins, self._contrast,
-                               self._resolve_floor(flooring_fn), variance=self._variance_tensor())
+        return self._weights_from_power(self._frame_power(), self._contrast, flooring_fn)
+
+    def _weights_from_power(self, r2, contrast, flooring_fn):
+        if contrast is None:
+            return self._host_weights(r2, flooring_fn)
+        return _ops.iva_weight(r2, self.n_bins, contrast, self._resolve_floor(flooring_fn),
+                               variance=self._variance_tensor())
+
+    def _host_weights(self, r2, flooring_fn):
+        """User closure on the frame norms: r (n_sources, n_frames) per mixture comes down, the
+        weights go back up (ref: ssspy/bss/iva.py:1787-1789, :1962-1964)."""
+        if type(flooring_fn) is str and flooring_fn == "self":
+            flooring_fn = self.flooring_fn
+        flooring_fn = choose_flooring_fn(flooring_fn, method=self)
+        self._check_device_errors()
+        r = np.sqrt(dv.to_host(r2))  # (B, N, T)
+        weight = np.stack([np.asarray(self.d_contrast_fn(rb) / flooring_fn(2 * rb), dtype=np.float64)
+                           for rb in r])
+        if weight.shape != r.shape:
+            raise ValueError("d_contrast_fn must map (n_sources, n_frames) to the same shape.")
+        return dv.to_device(weight, dtype=np.float64, dev=r2.device)
 
     def _frame_power(self):
         """r_nj^2 = sum_i |y_nij|^2 of the current estimate, (B, N, T)."""
         if self._uses_filter():
             return _ops.iva_frame_power(self._X, self._state_dev("demix_filter"))
-        if self._r2_cache is None:
-            self._r2_cache = _ops.iva_frame_power(self._state_dev("output"), None)
-        return self._r2_cache
+        cache = self._r2_cache
+        if cache is None or cache[1] != self._state_rev("output"):
+            cache = (_ops.iva_frame_power(self._state_dev("output"), None), self._state_rev("output"))
+            self._r2_cache = cache
+        return cache[0]
 
     def update_once(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/iva.py:1699-1734."""
@@ -306,7 +344,6 @@ class AuxIVA(AuxIVABase):
         weight = self._weights(flooring_fn)
         _ops.update_by_ipa(Y, weight, _lib.WEIGHT_FRAME, self.lqpqm_normalization,
                            self.newton_iter, self._resolve_floor(flooring_fn), self._info_tensor())
-        self._r2_cache = None
         self._state_touch("output")
 
     def _pair_weight_contrast(self):
@@ -321,8 +358,7 @@ class AuxIVA(AuxIVABase):
         W = self._state_dev("demix_filter")
         for m, n in resolve_pairs(getattr(self, "pair_selector", None), N):
             r2 = _ops.iva_frame_power(self._X, W)
-            weight = _ops.iva_weight(r2, self.n_bins, self._pair_weight_contrast(), floor,
-                                     variance=self._variance_tensor())
+            weight = self._weights_from_power(r2, self._pair_weight_contrast(), flooring_fn)
             w_pair = weight[:, [m, n], :].contiguous()  # gather of two rows (data movement only)
             U_pair = _ops.weighted_covariance(self._X, w_pair, _lib.WEIGHT_FRAME, 2)
             _ops.update_by_ip2(W, U_pair, [(m, n)], floor, self._info_tensor(), pair_only=True)
@@ -338,7 +374,6 @@ class AuxIVA(AuxIVABase):
         G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N), floor,
                                 self._info_tensor())
         _ops.separate(Y, G, out=Y)
-        self._r2_cache = None
         self._state_touch("output")
 
     def update_once_ip1(self, flooring_fn="self") -> None:
@@ -360,26 +395,42 @@ class AuxIVA(AuxIVABase):
             # one read + one write of Y; the kernel also leaves the next iteration's frame powers
             r2_next = dv.empty(tuple(weight.shape), dv.f64, Y.device)
             _ops.iss1_fused(Y, weight, _lib.WEIGHT_FRAME, floor, r2_next)
-            self._r2_cache = r2_next
+            self._state_touch("output")
+            self._r2_cache = (r2_next, self._state_rev("output"))
         else:
             Vc = _ops.weighted_covariance(Y, weight, _lib.WEIGHT_FRAME, N)
             G = _ops.iss1_transform(Vc, floor)
             _ops.separate(Y, G, out=Y)
-            self._r2_cache = None
-        self._state_touch("output")
+            self._state_touch("output")
 
     def compute_loss(self) -> float:
         """ref: ssspy/bss/iva.py:200-222 (filter state), :2177-2192 (ISS state)."""
         if self._uses_filter():
             W = self._state_dev("demix_filter")
-            r2 = _ops.iva_frame_power(self._X, W)
         else:
-            Y = self._state_dev("output")
-            r2 = self._frame_power()
-            W = _ops.demix_from_covariance(_ops.cross_covariance(Y, self._X), self._C(),
-                                           self._info_tensor())
+            W = _ops.demix_from_covariance(_ops.cross_covariance(self._state_dev("output"), self._X),
+                                           self._C(), self._info_tensor())
+        if self._contrast is None:
+            return self._host_contrast_loss(W)
+        r2 = self._frame_power()
         data = _ops.iva_loss_data(r2, self._variance_tensor(), self.n_bins, self._contrast)
         return self._host_loss(data, _ops.sum_logdet(W))
+
+    def _host_contrast_loss(self, W):
+        """Loss with a user ``contrast_fn``: the closure takes the whole separated spectrogram
+        (ssspy/bss/iva.py:216, :2181), so the estimate crosses PCIe once per recorded loss -- the
+        price of an opaque Python callable, paid only with ``record_loss=True``."""
+        if self.contrast_fn is None:
+            raise ValueError("Specify contrast_fn to record the loss.")
+        if self._uses_filter():
+            Y = dv.to_host(_ops.separate(self._X, W))
+        else:
+            Y = dv.to_host(self._state_dev("output"))
+        self._check_device_errors()
+        logdet = dv.to_host(_ops.sum_logdet(W))
+        values = np.array([np.sum(np.mean(self.contrast_fn(Yb), axis=1), axis=0) for Yb in Y])
+        values = values - 2.0 * logdet
+        return values.copy() if self._batched else values[0].item()
 
 
 class AuxLaplaceIVA(AuxIVA):

@@ -74,7 +74,7 @@ class MNMFBase(DeviceStateMixin, IterativeMethodBase):
         self._reset(**kwargs)
         IterativeMethodBase.__call__(self, n_iter=n_iter, initial_call=initial_call)
         self._separate_dev()
-        return self.output
+        return self._final_output()
 
     def _init_nmf(self, flooring_fn="self", rng=None) -> None:
         """ref: ssspy/bss/mnmf.py:190-259."""
@@ -106,6 +106,17 @@ class MNMFBase(DeviceStateMixin, IterativeMethodBase):
         if latent is not None:
             return np.einsum("...nk,...ik,...kj->...nij", latent, basis, activation)
         return basis @ activation
+
+    def _check_separate_input(self, input) -> None:
+        """``separate(input)`` filters with the parameters of the bound call, whose activation has
+        one column per frame and one set per mixture: another spectrogram must have that shape (the
+        reference fails with a broadcasting error; the kernels would read out of bounds)."""
+        want = tuple(self._X.shape) if input.ndim == 4 else tuple(self._X.shape[1:])
+        if tuple(input.shape) != want or (input.ndim == 4) != self._batched:
+            raise ValueError(
+                "separate() expects a spectrogram of shape {} (the one the parameters were fitted "
+                "on), got {}.".format(want if input.ndim == 4 or not self._batched
+                                      else tuple(self._X.shape), tuple(input.shape)))
 
     def _nmf_pair(self):
         """Device (basis, activation) in the per-source layout the kernels take (the expansion
@@ -256,6 +267,7 @@ class FastGaussMNMF(FastMNMFBase):
     def separate(self, input: np.ndarray) -> np.ndarray:
         """Multichannel Wiener filter with the current parameters (ref: mnmf.py:1174-1217)."""
         batched = input.ndim == 4
+        self._check_separate_input(input)
         X = dv.to_device(input if batched else input[None], dtype=np.complex128)
         Y = _ops.fastmnmf_separate(
             X, self._state_dev("diagonalizer"), self._state_dev("spatial"),
@@ -458,6 +470,7 @@ class GaussMNMF(MNMF):
     def separate(self, input: np.ndarray) -> np.ndarray:
         """Multichannel Wiener filter with the current parameters (ref: mnmf.py:729-763)."""
         batched = input.ndim == 4
+        self._check_separate_input(input)
         X = dv.to_device(input if batched else input[None], dtype=np.complex128)
         Y = _ops.gmnmf_separate(X, *self._nmf_pair(), self._state_dev("spatial"),
                                 self.reference_id, self._floor)

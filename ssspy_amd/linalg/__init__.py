@@ -31,6 +31,7 @@ def solve(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     """
     a = np.asarray(a)
     b = np.asarray(b)
+    real = not (np.iscomplexobj(a) or np.iscomplexobj(b))  # np.linalg.solve keeps real systems real
     vector = a.ndim == b.ndim + 1
     if vector:
         b = b[..., None]
@@ -47,6 +48,8 @@ def solve(a: np.ndarray, b: np.ndarray) -> np.ndarray:
                                        dv.stream_handle()), "solve")
     _lib.raise_if_singular(int(info.item()), "solve")
     x = dv.to_host(dX).reshape(lead + (N, nrhs))
+    if real:
+        x = np.ascontiguousarray(x.real)
     return x[..., 0] if vector else x
 
 

@@ -57,12 +57,16 @@ def run_sharded(process_shard: Callable[[int, int], np.ndarray], n_mixtures: int
     """
     rank, world = rank_world()
     lo, hi = shard_bounds(n_mixtures, rank, world)
-    local = process_shard(lo, hi)
+    # more ranks than mixtures: the surplus ranks own an empty block, launch nothing (the C ABI
+    # rejects an empty batch) and still take part in the gather
+    local = process_shard(lo, hi) if hi > lo else None
     if not gather or world == 1:
         return local
     parts = [None] * world
-    dist.all_gather_object(parts, np.asarray(local))
-    parts = [p for p in parts if p.shape[0] > 0]
+    dist.all_gather_object(parts, None if local is None else np.asarray(local))
+    parts = [p for p in parts if p is not None and p.shape[0] > 0]
+    if not parts:
+        return np.empty((0,))
     return np.concatenate(parts, axis=0)
 
 

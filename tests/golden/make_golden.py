@@ -22,10 +22,10 @@ import numpy as np
 REFERENCE = os.environ.get("SSSPY_REFERENCE", "/root/reference")
 sys.path.insert(0, REFERENCE)
 
-from ssspy.algorithm import projection_back  # noqa: E402
+from ssspy.algorithm import minimal_distortion_principle, projection_back  # noqa: E402
 from ssspy.bss._update_spatial_model import update_by_ip1, update_by_ipa, update_by_iss1  # noqa: E402
 from ssspy.bss.ilrma import GGDILRMA, TILRMA, GaussILRMA  # noqa: E402
-from ssspy.bss.iva import AuxGaussIVA, AuxLaplaceIVA  # noqa: E402
+from ssspy.bss.iva import AuxGaussIVA, AuxIVA, AuxLaplaceIVA  # noqa: E402
 from ssspy.bss.mnmf import FastGaussMNMF, GaussMNMF  # noqa: E402
 from ssspy.linalg import eigh2, inv2  # noqa: E402
 from ssspy.special.flooring import add_flooring, max_flooring  # noqa: E402
@@ -254,6 +254,54 @@ def run_ipa_operators():
     save("ipa_operators", **out)
 
 
+# --------------------------------------------------------------------------- boundary cases
+POWER_CONTRAST_P = 1.5  # G_R(r) = r^p: neither of the two contrasts the kernels implement
+
+
+def power_contrast_fn(y):
+    return np.linalg.norm(y, axis=1) ** POWER_CONTRAST_P
+
+
+def power_d_contrast_fn(r):
+    return POWER_CONTRAST_P * r ** (POWER_CONTRAST_P - 1)
+
+
+def run_generic_auxiva(name, *, N, F, T, algo, seed, gen=gen_iid, n_iter=10):
+    """The generic AuxIVA class with user closures (ssspy/bss/iva.py:1582-1635)."""
+    if skipped(name):
+        return
+    X = gen(seed, N, F, T)
+    snap = Snapshots(["demix_filter", "output"])
+    m = AuxIVA(spatial_algorithm=algo, contrast_fn=power_contrast_fn,
+               d_contrast_fn=power_d_contrast_fn, callbacks=snap)
+    Y = m(X, n_iter=n_iter)
+    out = dict(X=X, loss=np.array(m.loss), final_output=Y)
+    if m.demix_filter is not None:
+        out["final_demix_filter"] = m.demix_filter
+    out.update(snap.store)
+    out.update(meta(kind="aux_iva_generic", algo=algo, n_iter=n_iter, power=POWER_CONTRAST_P))
+    save(name, **out)
+
+
+def run_all_channel_restoration():
+    """projection_back / minimal_distortion_principle with reference_id=None (every channel)."""
+    if skipped("restoration_all_channels"):
+        return
+    out = {}
+    for N in (2, 3, 4):
+        rng = np.random.default_rng(160 + N)
+        F, T = 7, 26
+        X = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+        Y = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+        W = rng.standard_normal((F, N, N)) + 1j * rng.standard_normal((F, N, N))
+        out["n{}_X".format(N)], out["n{}_Y".format(N)], out["n{}_W".format(N)] = X, Y, W
+        out["n{}_pb_filter".format(N)] = projection_back(W, reference_id=None)
+        out["n{}_pb_output".format(N)] = projection_back(Y, reference=X, reference_id=None)
+        out["n{}_mdp_output".format(N)] = minimal_distortion_principle(Y, reference=X,
+                                                                      reference_id=None)
+    save("restoration_all_channels", **out)
+
+
 # --------------------------------------------------------------------------- operators
 def run_operators():
     if skipped("operators"):
@@ -397,6 +445,11 @@ def main():
             gen=gen_mixture, scale_restoration="minimal_distortion_principle")
     run_iva("auxlap_mdp_iss1_n2", N=2, F=20, T=40, algo="ISS", contrast="laplace", seed=115,
             scale_restoration="minimal_distortion_principle")
+    # --- boundary: user contrast closures, all-channel scale restoration ---
+    run_generic_auxiva("auxgeneric_ip1_n3", N=3, F=20, T=44, algo="IP", seed=120, gen=gen_mixture)
+    run_generic_auxiva("auxgeneric_iss1_n2", N=2, F=24, T=40, algo="ISS", seed=121)
+    run_generic_auxiva("auxgeneric_ip2_n3", N=3, F=18, T=40, algo="IP2", seed=122, gen=gen_mixture)
+    run_all_channel_restoration()
     # --- operators ---
     run_operators()
 

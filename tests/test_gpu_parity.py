@@ -1047,3 +1047,129 @@ def test_lqpqm2_against_oracle(L):
         y = lqpqm2(H, v, z, max_iter=max_iter)
         yr = np.stack([oracle_lqpqm2(H[i], v[i], z[i], ("max", 1e-10), max_iter) for i in range(n)])
         assert rel_err(y, yr) < 1e-10
+
+
+# ------------------------------------------------------------------------------- boundary (round 2)
+@pytest.mark.parametrize("case", ["auxgeneric_ip1_n3", "auxgeneric_iss1_n2", "auxgeneric_ip2_n3"])
+def test_generic_aux_iva_user_closures_against_golden(case):
+    """The generic AuxIVA class with user closures (G_R(r) = r^1.5, not a built-in contrast):
+    d_contrast_fn runs on the host on the (n_sources, n_frames) frame norms, contrast_fn on a host
+    copy of the estimate when the loss is recorded; both passes over the spectrogram stay on the
+    device.  ref: ssspy/bss/iva.py:1582-1635, :1785-1791, :2177-2192."""
+    from ssspy_amd.bss.iva import AuxIVA
+
+    g = load_golden(case)
+    p = float(g["meta_power"])
+    algo = str(g["meta_algo"])
+    snap = Snap(["demix_filter", "output"])
+    m = AuxIVA(spatial_algorithm=algo, contrast_fn=lambda y: np.linalg.norm(y, axis=1) ** p,
+               d_contrast_fn=lambda r: p * r ** (p - 1), callbacks=snap)
+    Y = m(g["X"], n_iter=int(g["meta_n_iter"]))
+    np.testing.assert_allclose(m.loss, g["loss"], rtol=LOSS_RTOL)
+    _compare_snapshots(g, snap)
+    assert rel_err(Y, g["final_output"]) < TOL
+    # batched: the closures see one mixture at a time
+    mb = AuxIVA(spatial_algorithm=algo, contrast_fn=lambda y: np.linalg.norm(y, axis=1) ** p,
+                d_contrast_fn=lambda r: p * r ** (p - 1))
+    Yb = mb(np.stack([g["X"], 2 * g["X"]]), n_iter=int(g["meta_n_iter"]))
+    assert rel_err(Yb[0], g["final_output"]) < TOL
+    np.testing.assert_allclose(np.asarray(mb.loss)[:, 0], g["loss"], rtol=LOSS_RTOL)
+
+
+def test_all_channel_scale_restoration_against_golden():
+    """projection_back / minimal_distortion_principle with reference_id=None: every channel in turn,
+    stacked on a new leading axis (ref: projection_back.py:92-95, :113-116; mdp :34-35)."""
+    from ssspy_amd.algorithm import minimal_distortion_principle, projection_back
+
+    g = load_golden("restoration_all_channels")
+    for N in (2, 3, 4):
+        X, Y, W = (g["n{}_{}".format(N, k)] for k in "XYW")
+        out = projection_back(W, reference_id=None)
+        assert out.shape == g["n{}_pb_filter".format(N)].shape
+        assert rel_err(out, g["n{}_pb_filter".format(N)]) < 1e-11
+        out = projection_back(Y, reference=X, reference_id=None)
+        assert out.shape == (N, N) + Y.shape[1:]
+        assert rel_err(out, g["n{}_pb_output".format(N)]) < 1e-11
+        out = minimal_distortion_principle(Y, reference=X, reference_id=None)
+        assert rel_err(out, g["n{}_mdp_output".format(N)]) < 1e-11
+
+
+def test_iss_frame_power_cache_follows_output_writes():
+    """AuxIVA in the ISS state keeps the frame powers the fused sweep leaves behind; any later write
+    to ``output`` (minimal-distortion scaling at the end of a call, an assignment from user code)
+    must retire them: continuing to iterate afterwards equals the oracle doing the same."""
+    from oracle import spatial as sp
+    from oracle.iva import AuxIVAOracle
+    from ssspy_amd.bss.iva import AuxLaplaceIVA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    X = nmf_mixture(77, 3, 24, 40)
+    m = AuxLaplaceIVA(spatial_algorithm="ISS", scale_restoration="minimal_distortion_principle")
+    m(X, n_iter=3)
+    m.update_once()  # weights must come from the rescaled output, not the pre-MDP frame powers
+    ref = AuxIVAOracle(spatial_algorithm="ISS", contrast="laplace",
+                       scale_restoration="minimal_distortion_principle")
+    ref.run(X, n_iter=3)
+    ref.update_once()
+    assert rel_err(m.output, ref.output) < TOL
+    assert m.compute_loss() == pytest.approx(ref.compute_loss(), rel=LOSS_RTOL)
+    m.output = 3.0 * ref.output  # assignment from user code
+    ref.output = 3.0 * ref.output
+    m.update_once()
+    ref.update_once()
+    assert rel_err(m.output, ref.output) < TOL
+    assert sp is not None
+
+
+def test_state_snapshots_are_read_only_and_assignment_uploads():
+    """Attributes read during the iteration are snapshots of HBM buffers: an in-place edit would be
+    lost, so it fails loudly; assigning the attribute takes effect.  The array ``__call__`` returns
+    is writable like the reference's."""
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    X = nmf_mixture(5, 2, 16, 24)
+    seen = {}
+
+    def cb(method):
+        seen["flag"] = method.basis.flags.writeable
+        with pytest.raises(ValueError):
+            method.demix_filter[...] = 0
+
+    m = GaussILRMA(n_basis=3, callbacks=cb, rng=np.random.default_rng(0))
+    Y = m(X, n_iter=1)
+    assert seen["flag"] is False
+    Y *= 1.0  # returned estimate is writable
+    new_basis = np.full_like(m.basis, 0.5)
+    m.basis = new_basis
+    m.update_activation_mm()
+    from oracle.ilrma import GaussILRMAOracle
+    assert np.array_equal(m.basis, new_basis)
+    assert GaussILRMAOracle is not None
+
+
+def test_mnmf_separate_rejects_other_shapes():
+    from ssspy_amd.bss.mnmf import FastGaussMNMF, GaussMNMF
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    X = nmf_mixture(9, 2, 12, 20)
+    for cls in (FastGaussMNMF, GaussMNMF):
+        m = cls(n_basis=2, rng=np.random.default_rng(0))
+        m(X, n_iter=1)
+        assert m.separate(X).shape == X.shape
+        with pytest.raises(ValueError):
+            m.separate(np.concatenate([X, X], axis=-1))  # more frames than the activation has
+        with pytest.raises(ValueError):
+            m.separate(np.stack([X, X]))  # a batch against single-mixture parameters
+
+
+def test_solve_keeps_real_systems_real():
+    from ssspy_amd.linalg import solve
+
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((5, 4, 4)) + 4 * np.eye(4)
+    b = rng.standard_normal((5, 4))
+    x = solve(a, b)
+    assert x.dtype == np.float64
+    np.testing.assert_allclose(x, np.linalg.solve(a, b[..., None])[..., 0], rtol=1e-10)
+    assert solve(a.astype(complex), b).dtype == np.complex128

@@ -69,10 +69,46 @@ def test_constructor_argument_checks():
         AuxLaplaceIVA(spatial_algorithm="nope")
 
 
-def test_generic_auxiva_needs_known_contrast():
-    m = AuxIVA(contrast_fn=lambda y: y, d_contrast_fn=lambda y: y)
-    with pytest.raises(NotImplementedError):
+def test_generic_auxiva_contrast_resolution():
+    """Tagged built-ins run in the kernels; user closures are host-evaluated on the frame norms
+    (resolved to None here); a missing d_contrast_fn is an argument error before any device work."""
+    from ssspy_amd.bss.iva import _device_contrast
+
+    lap = AuxLaplaceIVA()
+    assert _device_contrast(lap.contrast_fn, lap.d_contrast_fn) == _lib.CONTRAST_LAPLACE
+    assert _device_contrast(lambda y: y, lambda r: r) is None
+    m = AuxIVA(contrast_fn=lambda y: y, d_contrast_fn=None)
+    with pytest.raises(ValueError):
         m(np.zeros((2, 4, 8), dtype=complex), n_iter=1)
+
+
+def test_nmf_mixture_bytes_are_pinned():
+    """The benchmark inputs are regenerated on every box from the seed; their SHA-256 is committed
+     and the generator avoids BLAS / pow so the bytes do not depend on the CPU."""
+    import json
+    import os
+
+    from ssspy_amd.utils.dataset import nmf_mixture, nmf_mixture_batch, sha256_of
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    pins = json.load(open(os.path.join(here, "golden", "input_sha256.json")))
+    for name in ("configs0_seed0_N2_F257_T128", "configs1_seed1000_N4_F1025_T512",
+                 "configs3_seed4000_N4_F1025_T512"):
+        pin = pins[name]
+        assert sha256_of(nmf_mixture(pin["seed"], *pin["shape"])) == pin["sha256"], name
+    batch = nmf_mixture_batch(0, 3, 2, 257, 128, workers=3)
+    assert sha256_of(batch[0]) == pins["configs0_seed0_N2_F257_T128"]["sha256"]
+    assert np.array_equal(batch[2], nmf_mixture(2, 2, 257, 128))
+
+
+def test_run_sharded_skips_empty_blocks():
+    from ssspy_amd.parallel import run_sharded, shard_bounds
+
+    assert shard_bounds(1, 1, 2) == (1, 1)
+    seen = []
+    out = run_sharded(lambda lo, hi: seen.append((lo, hi)) or np.arange(lo, hi), 3)
+    assert seen == [(0, 3)] and list(out) == [0, 1, 2]
+    assert run_sharded(lambda lo, hi: 1 / 0, 0) is None  # nothing to do: never called
 
 
 def test_callbacks_and_loss_protocol():

@@ -125,6 +125,36 @@ def test_aux_iva(case):
     assert rel_err(m.output, g["final_output"]) < TOL
 
 
+@pytest.mark.parametrize("case", ["auxgeneric_ip1_n3", "auxgeneric_iss1_n2", "auxgeneric_ip2_n3"])
+def test_generic_aux_iva_with_user_closures(case):
+    """The reference's generic AuxIVA class driven by user closures (G_R(r) = r^1.5)."""
+    g = load_golden(case)
+    algo = str(g["meta_algo"])
+    m = AuxIVAOracle(spatial_algorithm=algo, contrast=("power", float(g["meta_power"])))
+    m.reset(g["X"])
+    losses = [m.compute_loss()]
+    for k in range(1, int(g["meta_n_iter"]) + 1):
+        m.update_once()
+        losses.append(m.compute_loss())
+        if algo != "IP2":
+            _check_snapshots(g, k, m, ["demix_filter", "output"])
+    np.testing.assert_allclose(losses, g["loss"], rtol=1e-10)
+    m.restore_scale()
+    if m.demix_filter is not None:
+        m.output = sp.separate(m.input, m.demix_filter)
+    assert rel_err(m.output, g["final_output"]) < 1e-9
+
+
+def test_all_channel_scale_restoration():
+    """projection_back / minimal_distortion_principle with reference_id=None."""
+    g = load_golden("restoration_all_channels")
+    for N in (2, 3, 4):
+        X, Y, W = (g["n{}_{}".format(N, k)] for k in "XYW")
+        assert rel_err(sp.projection_back_filter(W, None), g["n{}_pb_filter".format(N)]) < TOL
+        assert rel_err(sp.projection_back_output(Y, X, None), g["n{}_pb_output".format(N)]) < TOL
+        assert rel_err(sp.minimal_distortion_output(Y, X, None), g["n{}_mdp_output".format(N)]) < TOL
+
+
 @pytest.mark.parametrize("case,algo", [("kat_auxlap_ip1_config1", "IP"), ("kat_auxlap_iss1_config1", "ISS")])
 def test_aux_iva_config1_kat(case, algo):
     """BASELINE.json configs[0] (N=2, F=257, T=128, 10 it): known-answer scalars."""
