@@ -2,14 +2,23 @@
 """Benchmark of the demixing hot path: GaussILRMA-IP1 update_once() on MI355X.
 
 Contract (one JSON line on rank 0): see the task statement.  A *step* is one
-``update_once()`` (basis, activation, weighted covariance, IP1, normalisation) over the
-rank's batch of independent synthetic mixtures of BASELINE.json configs[1] shape
-(N=4 sources/channels, F=1025 bins, T=512 frames, n_basis=16), fp64/complex128, inputs
-resident in HBM before the timed region.  With --gpus N every rank owns its own
-``--batch`` mixtures (configs[4]: 128 per GPU); there is no data-path collective, only the
+``update_once()`` -- the product's fused C-ABI call: basis, activation, weighted covariance, IP1,
+normalisation -- over the rank's batch of independent synthetic mixtures of BASELINE.json
+configs[1] shape (N=4 sources/channels, F=1025 bins, T=512 frames, n_basis=16),
+fp64/complex128, inputs resident in HBM before the timed region.  Mixture b of rank r is
+``nmf_mixture(seed = 1000 + r*batch + b)``, regenerated on the host; the SHA-256 of
+mixture 0 is checked against tests/golden/input_sha256.json.  With --gpus N every rank owns its
+own ``--batch`` mixtures (configs[4]: 128 per GPU); there is no data-path collective, only the
 barrier and the max-over-ranks of the elapsed time.
 
-    python bench.py                       # 1 GPU, 128 mixtures, finishes in ~1-2 min
+After the timed region, on rank 0 at N=1 (none of it is part of ``value``):
+  * a second loop over the same steps with HIP events around every kernel group -> ``roofline``;
+  * ``with_record_loss`` (the reference default), the AuxIVA-IP leg of the metric;
+  * ``configs``: BASELINE configs[1] literally (one mixture), configs[2] (AuxIVA-ISS, N=8,
+    F=2049, T=1024) and configs[3] (FastGaussMNMF, N=M=4, K=8), one mixture and a batch each,
+    every one with its own CPU baseline (the matching oracle class on this box's host cores).
+
+    python bench.py                       # 1 GPU, 128 mixtures, finishes in ~2-3 min
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
 """
@@ -42,60 +51,53 @@ def parse_args():
     ap.add_argument("--basis", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=6)
-    ap.add_argument("--no-single", action="store_true", help="skip the batch=1 (configs[1]) leg")
+    ap.add_argument("--no-extra", "--no-single", dest="no_extra", action="store_true",
+                    help="only the headline (skip the loss / AuxIVA / other-config legs)")
+    ap.add_argument("--other-batch", type=int, default=32,
+                    help="mixtures in the batched configs[2] / configs[3] legs")
     return ap.parse_args()
 
 
-def device_mixtures(B, N, F, T, seed, dev):
-    """Structured NMF-source mixtures (SURVEY.md 8d formula) generated in HBM with torch's
-    generator (allocation/plumbing only); mixture 0 of rank 0 is replaced by the host-seeded
-    one the CPU baseline uses."""
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(seed)
-    X = torch.empty((B, N, F, T), dtype=torch.complex128, device=dev)
-    chunk = 8
-    for b0 in range(0, B, chunk):
-        nb = min(chunk, B - b0)
-        R = (torch.rand((nb, N, F, 4), generator=gen, device=dev, dtype=torch.float64) ** 4) @ (
-            torch.rand((nb, N, 4, T), generator=gen, device=dev, dtype=torch.float64) ** 4) + 1e-3
-        g = torch.randn((nb, N, F, T, 2), generator=gen, device=dev, dtype=torch.float64)
-        S = torch.sqrt(R / 2).unsqueeze(-1) * g
-        S = torch.view_as_complex(S.contiguous())
-        A = torch.view_as_complex(
-            torch.randn((nb, F, N, N, 2), generator=gen, device=dev, dtype=torch.float64))
-        X[b0:b0 + nb] = (A @ S.permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
-    return X
-
-
-def make_separator(X, K, seed):
+def make_separator(X, K, seed, record_loss=False):
     """GaussILRMA bound to device-resident mixtures, with seeded NMF initial state."""
     from ssspy_amd.bss.ilrma import GaussILRMA
 
-    B, N, F, T = X.shape
-    sep = GaussILRMA(n_basis=K, spatial_algorithm="IP", record_loss=False,
+    sep = GaussILRMA(n_basis=K, spatial_algorithm="IP", record_loss=record_loss,
                      rng=np.random.default_rng(seed))
     sep._bind_input(X)
     sep._reset(flooring_fn=sep.flooring_fn)
+    sep._C()  # static covariance, computed once per call (outside the iteration loop)
     return sep
 
 
-def timed_steps(sep, steps, stepwise_events):
-    """Run `steps` update_once() rounds; with stepwise_events, bracket every kernel group with
-    HIP events on the launch stream (torch's current stream is the one the C ABI receives)."""
+def time_loop(fn, n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def kernel_group_events(sep, steps):
+    """The same `steps` iterations as separate kernel groups (equal to the fused call:
+    tests/test_gpu_parity.py::test_gauss_ilrma_step_methods_match_fused_update), with HIP events on
+    the launch stream (torch's current stream is the one the C ABI receives) around each."""
+    from ssspy_amd import _device as dv
+    from ssspy_amd import _ops
+
     names = ("basis", "activation", "wcov", "ip1", "normalize")
+    B, N, F, T = sep._X.shape
+    if sep._U is None:
+        sep._U = dv.empty((B, F, N, N, N), dv.c128, sep._X.device)
     ev = []
     for _ in range(steps):
-        if not stepwise_events:
-            sep.update_once()
-            continue
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
         marks[0].record()
         sep.update_basis_mm()
         marks[1].record()
         sep.update_activation_mm()
         marks[2].record()
-        from ssspy_amd import _ops
-
         _ops.ilrma_weighted_covariance(sep._X, sep._state_dev("basis"),
                                        sep._state_dev("activation"), float(sep.domain),
                                        sep._ws, sep._ws_bytes, out=sep._U)
@@ -106,7 +108,138 @@ def timed_steps(sep, steps, stepwise_events):
         sep.normalize()
         marks[5].record()
         ev.append(marks)
-    return names, ev
+    torch.cuda.synchronize()
+    dur = {name: 0.0 for name in names}
+    for marks in ev:
+        for k, name in enumerate(names):
+            dur[name] += marks[k].elapsed_time(marks[k + 1])
+    return {name: dur[name] / max(1, len(ev)) for name in names}
+
+
+def blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+
+        return max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        return 1
+
+
+def cpu_leg(make_ref, n_iters, what):
+    """Median seconds per update_once() of an oracle instance on the host (1 warm-up iteration)."""
+    ref = make_ref()
+    ref.update_once()
+    times = []
+    for _ in range(n_iters):
+        c0 = time.perf_counter()
+        ref.update_once()
+        times.append(time.perf_counter() - c0)
+    med = float(np.median(times))
+    threads = blas_threads()
+    return {
+        "value": round(1.0 / med, 4), "unit": "iterations/s", "cores": threads, "kind": "port",
+        "sample": "{} (NumPy restatement of the reference, same broadcast structure) on 1 mixture, "
+                  "median of {} iterations after 1 warm-up; host has {} logical CPUs; NumPy ufuncs "
+                  "are single-threaded, BLAS may use {} threads".format(what, n_iters, os.cpu_count(),
+                                                                       threads),
+        "s_per_iter_median": round(med, 4),
+    }
+
+
+def rate_entry(workload, dt, n_mixtures, bytes_per_mixture_iter):
+    gbs = bytes_per_mixture_iter * n_mixtures / dt / 1e9
+    return {"workload": workload, "ms_per_step": round(1e3 * dt, 4),
+            "iterations_per_s": round(n_mixtures / dt, 2), "achieved_GBs": round(gbs, 1),
+            "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+
+def other_configs(args, dev, x0_host, pins, cpu_configs1):
+    """BASELINE configs[1] literally, configs[2] and configs[3]: update_once() with
+    record_loss=False, one mixture and a batch, algorithmic bytes of SURVEY.md 8d, CPU baseline."""
+    from ssspy_amd.bss.iva import AuxLaplaceIVA, _device_contrast
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+    from ssspy_amd.utils.dataset import nmf_mixture_batch, sha256_of
+
+    out = {}
+    cpu = not args.no_cpu_baseline
+    Bo = args.other_batch
+
+    # ---- configs[1]: ONE mixture, GaussILRMA-IP1 (33.6 MB: the working set sits in the caches)
+    N, F, T, K = 4, 1025, 512, 16
+    sep1 = make_separator(torch.from_numpy(x0_host[None]).to(dev), K, seed=2000)
+    for _ in range(20):
+        sep1.update_once()
+    dt = time_loop(sep1.update_once, 300)
+    sep1._check_device_errors()
+    ent = rate_entry("configs[1]: GaussILRMA-IP1 N=4 F=1025 T=512 n_basis=16, 1 mixture, 300 "
+                     "iterations", dt, 1, 3 * 16.0 * N * F * T)
+    if cpu_configs1 is not None:
+        ent["cpu_baseline"] = cpu_configs1  # same oracle on the same mixture as the headline's
+    out["configs1_single"] = ent
+    del sep1
+
+    # ---- configs[2]: AuxLaplaceIVA-ISS, N=8, F=2049, T=1024 (2 passes: read Y, write Y)
+    N, F, T = 8, 2049, 1024
+    Xh = nmf_mixture_batch(3000, Bo, N, F, T)
+    sha_ok = sha256_of(Xh[0]) == pins["configs2_seed3000_N8_F2049_T1024"]["sha256"]
+    ent = {"input_sha256_ok": sha_ok}
+    for tag, nb, iters in (("single", 1, 100), ("batch", Bo, 20)):
+        m = AuxLaplaceIVA(spatial_algorithm="ISS", record_loss=False)
+        m._contrast = _device_contrast(m.contrast_fn, m.d_contrast_fn)
+        m._bind_input(torch.from_numpy(Xh[:nb]).to(dev))
+        m._reset()
+        for _ in range(3):
+            m.update_once()
+        dt = time_loop(m.update_once, iters)
+        m._check_device_errors()
+        ent[tag] = rate_entry("configs[2]: AuxLaplaceIVA-ISS N=8 F=2049 T=1024, {} mixture(s), {} "
+                              "iterations".format(nb, iters), dt, nb, 2 * 16.0 * N * F * T)
+        del m
+        torch.cuda.empty_cache()
+    if cpu:
+        from oracle.iva import AuxIVAOracle
+
+        def make():
+            ref = AuxIVAOracle(spatial_algorithm="ISS", contrast="laplace", record_loss=False)
+            ref.reset(Xh[0])
+            return ref
+
+        ent["cpu_baseline"] = cpu_leg(make, 2, "oracle.iva.AuxIVAOracle.update_once (ISS)")
+    out["configs2"] = ent
+    del Xh
+
+    # ---- configs[3]: FastGaussMNMF-IP1, N=M=4, F=1025, T=512, n_basis=8 (4 passes)
+    M, F, T, K = 4, 1025, 512, 8
+    Xh = nmf_mixture_batch(4000, Bo, M, F, T)
+    sha_ok = sha256_of(Xh[0]) == pins["configs3_seed4000_N4_F1025_T512"]["sha256"]
+    ent = {"input_sha256_ok": sha_ok}
+    for tag, nb, iters in (("single", 1, 100), ("batch", Bo, 20)):
+        m = FastGaussMNMF(n_basis=K, record_loss=False, rng=np.random.default_rng(0))
+        m._bind_input(torch.from_numpy(Xh[:nb]).to(dev))
+        m._reset()
+        for _ in range(3):
+            m.update_once()
+        dt = time_loop(m.update_once, iters)
+        ent[tag] = rate_entry("configs[3]: FastGaussMNMF-IP1 N=M=4 F=1025 T=512 n_basis=8, {} "
+                              "mixture(s), {} iterations".format(nb, iters), dt, nb,
+                              4 * 16.0 * M * F * T)
+        ent[tag]["wiener_separate_ms"] = round(1e3 * time_loop(m._separate_dev, 3), 3)
+        m._check_device_errors()
+        del m
+        torch.cuda.empty_cache()
+    if cpu:
+        from oracle.mnmf import FastGaussMNMFOracle
+
+        def make():
+            ref = FastGaussMNMFOracle(n_basis=K, record_loss=False)
+            ref.reset(Xh[0], basis=np.random.default_rng(1).random((M, F, K)),
+                      activation=np.random.default_rng(2).random((M, K, T)),
+                      spatial=np.random.default_rng(4).random((F, M, M)))
+            return ref
+
+        ent["cpu_baseline"] = cpu_leg(make, 3, "oracle.mnmf.FastGaussMNMFOracle.update_once")
+    out["configs3"] = ent
+    return out
 
 
 def main():
@@ -116,8 +249,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    # Dry run of the N > 1 control flow on a one-GPU box (development only): every rank on device 0,
-    # gloo for the barrier and the timing max.  The driver's runs use neither variable.
+    # Dry run of the N > 1 control flow on a one-GPU box (development / tests only): every rank on
+    # device 0, gloo for the barrier and the timing max.  The driver's runs use neither variable.
     backend = os.environ.get("SSSPY_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("SSSPY_BENCH_ONE_DEVICE") else local_rank
     torch.cuda.set_device(dev_index)
@@ -133,20 +266,21 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = world if distributed else 1
 
-    from ssspy_amd import _device as dv
-    from ssspy_amd import _ops
-    from ssspy_amd.utils.dataset import nmf_mixture
+    from ssspy_amd.utils.dataset import nmf_mixture_batch, sha256_of
 
     N, F, T, K, B = args.sources, args.bins, args.frames, args.basis, args.batch
-    X = device_mixtures(B, N, F, T, seed=1000 + rank, dev=dev)
-    x0_host = None
-    if rank == 0:
-        x0_host = nmf_mixture(1000, N, F, T)
-        X[0] = torch.from_numpy(x0_host).to(dev)
+    pins = json.load(open(os.path.join(ROOT, "tests", "golden", "input_sha256.json")))
+    first_seed = 1000 + rank * B
+    Xh = nmf_mixture_batch(first_seed, B, N, F, T)
+    x0_host = Xh[0].copy()
+    x0_sha = sha256_of(x0_host)
+    pin = pins.get("configs1_seed1000_N4_F1025_T512")
+    sha_ok = None
+    if rank == 0 and (N, F, T) == tuple(pin["shape"]):
+        sha_ok = x0_sha == pin["sha256"]
+    X = torch.from_numpy(Xh).to(dev)
+    del Xh
     sep = make_separator(X, K, seed=2000 + rank)
-    # scratch of the covariance -> IP1 pair, which timed_steps() launches one kernel group at a time
-    sep._U = dv.empty((B, F, N, N, N), dv.c128, dev)
-    sep._C()  # static covariance, computed once per call (outside the iteration loop)
 
     def fence():
         torch.cuda.synchronize()
@@ -157,51 +291,56 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up (untimed)
-    timed_steps(sep, args.warmup, stepwise_events=True)
+    # ---- the timed region: exactly `steps` update_once() calls (one fused C-ABI call each)
+    for _ in range(args.warmup):
+        sep.update_once()
     fence()
     t0 = time.perf_counter()
-    names, events = timed_steps(sep, args.steps, stepwise_events=True)
+    for _ in range(args.steps):
+        sep.update_once()
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
         elapsed = parallel.max_over_ranks(elapsed, dev if backend == "nccl" else None)
     sep._check_device_errors()
 
-    # per-kernel-group durations from the HIP events of the timed region (this rank)
-    dur_ms = {name: 0.0 for name in names}
-    for marks in events:
-        for k, name in enumerate(names):
-            dur_ms[name] += marks[k].elapsed_time(marks[k + 1])
-    avg_ms = {name: dur_ms[name] / max(1, len(events)) for name in names}
-
     if rank != 0:
         if distributed:
             dist.destroy_process_group()
         return
+
+    # ---- second loop, same steps as separate kernel groups under HIP events -> roofline
+    avg_ms = kernel_group_events(sep, args.steps)
+    sep._check_device_errors()
 
     units = B * n_gpus * args.steps  # mixture-iterations
     value = units / elapsed
     pass_bytes = 16.0 * N * F * T * B  # one compulsory pass over the rank's X
     dominant = max(("basis", "activation", "wcov"), key=lambda k: avg_ms[k])
     achieved = pass_bytes / (avg_ms[dominant] * 1e-3) / 1e9
+    kernel_names = {"basis": "k_basis_fast", "activation": "k_activation_fast", "wcov": "k_wcov_fast"}
     traffic = None
+    traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_ilrma_" + dominant, {}).get(
-                "hbm_bytes_per_launch_batch{}".format(B))
+            tj = json.load(open(tpath))
+            traffic = tj.get("k_ilrma_" + dominant, {}).get("hbm_bytes_per_launch_batch{}".format(B))
+            traffic_source = "profiles/roofline_traffic.json ({})".format(tj.get("_round", "r01"))
         except Exception:
             traffic = None
     roofline = {
         # the name rocprofv3 reports for this launch (tuned path of ilrma_fast.hip at these shapes)
-        "bound": "hbm", "kernel": {"basis": "k_basis_fast", "activation": "k_activation_fast",
-                                   "wcov": "k_wcov_fast"}[dominant],
+        "bound": "hbm", "kernel": kernel_names[dominant],
         "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": traffic,
+        "traffic": traffic, "traffic_source": traffic_source,
         "bytes_per_launch": pass_bytes, "avg_launch_ms": round(avg_ms[dominant], 4),
         "per_kernel_ms": {k: round(v, 4) for k, v in avg_ms.items()},
+        "per_kernel_frac": {k: round(pass_bytes / (avg_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                            for k in ("basis", "activation", "wcov")},
+        "measured": "HIP events around each kernel group in a second loop of the same steps "
+                    "(the timed region runs the fused update_once())",
         "iteration_achieved": round(3 * pass_bytes / (elapsed / args.steps) / 1e9, 1),
         "iteration_frac": round(3 * pass_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
     }
@@ -221,34 +360,41 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "BASELINE configs[1] GaussILRMA-IP1/MM (N=M={}, F={}, T={}, n_basis={}) x {} "
-                        "independent mixtures per GPU (configs[4] shard), record_loss=False"
-                        .format(N, F, T, K, B),
+                        "independent mixtures per GPU (configs[4] shard), record_loss=False, "
+                        "update_once() = one fused C-ABI call".format(N, F, T, K, B),
             "batch_per_gpu": B, "global_batch": B * n_gpus, "n_sources": N, "n_bins": F,
             "n_frames": T, "n_basis": K, "parallelism": "mixtures sharded, no collective",
+            "input": "nmf_mixture(seed=1000+b) per mixture b (SURVEY 8d)",
+            "input_sha256_mixture0": x0_sha, "input_sha256_ok": sha_ok,
         },
         "roofline": roofline,
     }
 
-    # ---- the same batch with record_loss=True semantics (SURVEY 8d asks for both): every iteration
-    # is followed by compute_loss(), which syncs the host once per iteration as the reference does
-    if not args.no_single and n_gpus == 1:
+    extra = not args.no_extra and n_gpus == 1
+    # ---- the same batch with record_loss=True semantics (SURVEY 8d asks for both): the separator's
+    # own loop, update_once() then the loss bookkeeping of IterativeMethodBase
+    if extra:
         nl = max(3, min(10, args.steps))
-        sep.compute_loss()
+        sep.record_loss, sep.loss = True, []
+        sep._after_step()
         torch.cuda.synchronize()
         tl = time.perf_counter()
         for _ in range(nl):
             sep.update_once()
-            sep.compute_loss()
+            sep._after_step()
         torch.cuda.synchronize()
         dtl = (time.perf_counter() - tl) / nl
+        sep.record_loss, sep.loss = False, None
         out["with_record_loss"] = {
-            "workload": "same batch, update_once() + compute_loss() per iteration, {} iterations".format(nl),
+            "workload": "same batch, update_once() + loss per iteration (record_loss=True), {} "
+                        "iterations".format(nl),
             "ms_per_step": round(1e3 * dtl, 4), "iterations_per_s": round(B / dtl, 2),
+            "frac": round(3 * pass_bytes / dtl / 1e9 / HBM_PEAK_GBS, 4),
         }
 
     # ---- the metric's AuxIVA leg: AuxLaplaceIVA (IP1) on the same resident batch, two passes over X
     # per iteration (frame powers, weighted covariance)
-    if not args.no_single and n_gpus == 1:
+    if extra:
         from ssspy_amd.bss.iva import AuxLaplaceIVA, _device_contrast
 
         iva = AuxLaplaceIVA(spatial_algorithm="IP", record_loss=False)
@@ -258,74 +404,34 @@ def main():
         iva._C()
         for _ in range(3):
             iva.update_once()
-        torch.cuda.synchronize()
         ni = max(5, args.steps)
-        ti = time.perf_counter()
-        for _ in range(ni):
-            iva.update_once()
-        torch.cuda.synchronize()
-        dti = (time.perf_counter() - ti) / ni
+        dti = time_loop(iva.update_once, ni)
         iva._check_device_errors()
-        out["auxiva_ip"] = {
-            "workload": "AuxLaplaceIVA-IP1, same batch ({} x N={} F={} T={}), {} iterations".format(
-                B, N, F, T, ni),
-            "ms_per_step": round(1e3 * dti, 4), "iterations_per_s": round(B / dti, 2),
-            "achieved_GBs": round(2 * pass_bytes / dti / 1e9, 1),
-            "frac_of_hbm_peak": round(2 * pass_bytes / dti / 1e9 / HBM_PEAK_GBS, 4),
-        }
+        out["auxiva_ip"] = rate_entry(
+            "AuxLaplaceIVA-IP1, same batch ({} x N={} F={} T={}), {} iterations".format(B, N, F, T, ni),
+            dti, B, 2 * 16.0 * N * F * T)
         del iva
 
-    # ---- configs[1] exactly: ONE mixture, fused update_once (one C-ABI call per iteration)
-    if not args.no_single and n_gpus == 1:
-        sep1 = make_separator(X[:1].clone(), K, seed=2000)
-        sep1._C()
-        for _ in range(10):
-            sep1.update_once()
-        torch.cuda.synchronize()
-        n1 = 200
-        t1 = time.perf_counter()
-        for _ in range(n1):
-            sep1.update_once()
-        torch.cuda.synchronize()
-        dt1 = time.perf_counter() - t1
-        out["single_mixture"] = {
-            "workload": "configs[1]: 1 mixture, {} iterations".format(n1),
-            "iterations_per_s": round(n1 / dt1, 1), "ms_per_iter": round(1e3 * dt1 / n1, 4),
-            "achieved_GBs": round(3 * 16.0 * N * F * T * n1 / dt1 / 1e9, 1),
-        }
-
-    # ---- CPU baseline: the NumPy oracle (reference expression structure) on the host cores
+    # ---- CPU baseline of the headline: the NumPy oracle (reference expression structure)
     if not args.no_cpu_baseline and n_gpus == 1:
         from oracle.ilrma import GaussILRMAOracle
 
-        ref = GaussILRMAOracle(n_basis=K, spatial_algorithm="IP", record_loss=False)
-        ref.reset(x0_host, basis=np.random.default_rng(1).random((N, F, K)),
-                  activation=np.random.default_rng(2).random((N, K, T)))
-        ref.update_once()  # warm-up
-        times = []
-        for _ in range(args.cpu_iters):
-            c0 = time.perf_counter()
-            ref.update_once()
-            times.append(time.perf_counter() - c0)
-        med = float(np.median(times))
-        blas_threads = 1
-        try:
-            from threadpoolctl import threadpool_info
+        def make():
+            ref = GaussILRMAOracle(n_basis=K, spatial_algorithm="IP", record_loss=False)
+            ref.reset(x0_host, basis=np.random.default_rng(1).random((N, F, K)),
+                      activation=np.random.default_rng(2).random((N, K, T)))
+            return ref
 
-            blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-        except Exception:
-            pass
-        out["cpu_baseline"] = {
-            "value": round(1.0 / med, 4), "unit": "iterations/s", "cores": blas_threads,
-            "kind": "port",
-            "sample": "oracle.ilrma.GaussILRMAOracle.update_once (NumPy restatement of the "
-                      "reference, same broadcast structure) on 1 mixture of configs[1], median of "
-                      "{} iterations after 1 warm-up; host has {} logical CPUs; NumPy ufuncs are "
-                      "single-threaded, BLAS may use {} threads".format(
-                          args.cpu_iters, os.cpu_count(), blas_threads),
-            "s_per_iter_median": round(med, 4),
-        }
-        out["speedup_vs_cpu_per_mixture_iteration"] = round(value * med, 1)
+        out["cpu_baseline"] = cpu_leg(make, args.cpu_iters,
+                                      "oracle.ilrma.GaussILRMAOracle.update_once on configs[1]")
+        out["speedup_vs_cpu_per_mixture_iteration"] = round(
+            value * out["cpu_baseline"]["s_per_iter_median"], 1)
+
+    # ---- the other BASELINE configs, each with its own CPU baseline
+    if extra:
+        del sep, X
+        torch.cuda.empty_cache()
+        out["configs"] = other_configs(args, dev, x0_host, pins, out.get("cpu_baseline"))
 
     print(json.dumps(out))
     if distributed:
