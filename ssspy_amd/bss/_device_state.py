@@ -104,16 +104,18 @@ class DeviceStateMixin:
             # a snapshot of the device buffer, which stays the truth: writing into the snapshot
             # would be lost silently, so it is read-only -- state is changed by assigning the
             # attribute (``m.basis = new``), which uploads
-            host.flags.writeable = False
-            ent["host"] = host
+            view = host.view()
+            view.flags.writeable = False
+            ent["host"], ent["host_rw"] = view, host
         return ent["host"]
 
     def _final_output(self):
         """What ``__call__`` returns: the host copy of ``output``.  The iteration is over, so the
         array is handed out writable like the reference's (which returns ``self.output`` itself)."""
         out = self.output
-        if isinstance(out, np.ndarray):
-            out.flags.writeable = True
+        ent = self._state().get("output", {})
+        if ent.get("host") is out and ent.get("host_rw") is not None:
+            return ent["host_rw"]  # the same memory as the read-only snapshot, writable
         return out
 
     def _state_set_host(self, name, value, dtype=None):
@@ -136,7 +138,7 @@ class DeviceStateMixin:
     def _state_touch(self, name):
         """A kernel rewrote the device buffer in place: drop the host cache."""
         ent = self._state()[name]
-        ent["host"] = None
+        ent["host"] = ent["host_rw"] = None
         ent["rev"] = self._next_rev()
 
     def _next_rev(self):
