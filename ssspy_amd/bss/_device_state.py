@@ -168,6 +168,12 @@ class DeviceStateMixin:
             if ent["dtype"] is not None:
                 np_dtype = np.complex128 if ent["dtype"] == dv.c128 else np.float64
             ent["dev"] = dv.to_device(host, dtype=np_dtype)
+            # from here on the device copy is what the kernels see: hand out the host value
+            # read-only so that an in-place edit cannot be lost silently (see _state_get)
+            if isinstance(ent["host"], np.ndarray):
+                view = ent["host"].view()
+                view.flags.writeable = False
+                ent["host"] = view
         return ent["dev"]
 
     # -- singular-matrix reporting ------------------------------------------------------

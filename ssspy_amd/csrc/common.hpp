@@ -173,6 +173,33 @@ __device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// ---------------------------------------------------------------- buffer (SRD) addressing
+// A row of a tensor addressed as (wave-uniform base in SGPRs) + (32-bit per-lane byte offset): the
+// only per-lane address state is the offset, where flat global loads keep a 64-bit address per
+// access alive in VGPRs (the register-resident ISS slab kernel has none to spare).  Build the
+// descriptor from wave-uniform values only.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ c128 buffer_load_c128(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  return cmake(__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2]));
+}
+__device__ __forceinline__ double buffer_load_f64(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
+  return __hiloint2double((int)v[1], (int)v[0]);
+}
+__device__ __forceinline__ void buffer_store_c128(__amdgpu_buffer_rsrc_t r, unsigned byte_off, c128 z) {
+  u32x4_t v;
+  v[0] = (unsigned)__double2loint(z.x);
+  v[1] = (unsigned)__double2hiint(z.x);
+  v[2] = (unsigned)__double2loint(z.y);
+  v[3] = (unsigned)__double2hiint(z.y);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 0);
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace ssspy

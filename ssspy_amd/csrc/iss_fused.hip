@@ -4,17 +4,24 @@
 // times, each sweep two full-size temporaries and a rewrite of Y.  Bins are independent, and one
 // bin's slab Y_i (N x T complex128: 128 KB at N=8, T=1024) fits the register file of a 256-thread
 // workgroup: thread t keeps its FPT frames of all N rows in VGPRs, so the N sequential rank-1 sweeps
-// run on chip; per sweep only 3N reals (num_{n'} complex, den_{n'} real) cross lanes:
-//   row-level  : 4 DPP butterfly steps inside each 16-lane row (full-rate VALU, no LDS traffic)
-//   block-level: 16 row partials through LDS, one barrier; lane n' < N adds up the partials of its
-//                source and forms the steering coefficient v_{n'} (one divide / square root per
-//                sweep instead of N in every thread: 7.4 -> 6.4 ms at configs[2] x 32 mixtures),
-//                v_readlane then hands the N coefficients to every thread as wave-uniform scalars.
-// Tried and dropped (profiles/r01_other_configs.txt): 512-thread workgroups that prefetch the next
-// bin's slab with LDS-direct loads (global_load_lds_dwordx4, 128 KB of LDS) while sweeping the
-// current one -- the load latency hides, but the cross-lane reduction (12 DPP/add instructions per
-// value and wave, independent of the frames per thread) doubles per SIMD and the kernel got slower
-// (8.1 ms).
+// run on chip; per sweep only 3N reals (num_{n'} complex, den_{n'} real) cross lanes.
+//
+// Round-2 structure (configs[2] x 32 mixtures: 6.46 -> see profiles/): the kernel is sized for TWO
+// workgroups per CU (<= 256 VGPRs, <= 80 KB LDS) so that one workgroup's slab load / store overlaps
+// the other's sweeps -- at one workgroup per CU load, 8 sweeps and store of a bin ran back to back:
+//   * registers hold the slab (128 VGPRs at N*FPT = 32) and the frame weights (64); the frame-power
+//     accumulators of the next iteration's weights moved to LDS (thread-private slots, one
+//     read-modify-write per slab instead of one per sweep for the weights);
+//   * the cross-lane reduction is a reduce-scatter on gfx950's row swaps: v_permlane32_swap and
+//     v_permlane16_swap fold the two 32-lane halves and the row pairs at 1.5 instructions per value
+//     while halving the number of live values each time (12 -> 6 -> 3 per source group), then 4 DPP
+//     butterfly steps finish the remaining 3 values inside the 16-lane rows: 63 instead of 144
+//     instructions per group of 4 sources, and 4 partials per value in LDS instead of 16;
+//   * lane n' < N adds up the 4 wave partials of its source and forms the steering coefficient
+//     v_{n'} (one divide / square root per sweep instead of N in every thread); v_readlane hands the
+//     N coefficients to every thread as wave-uniform scalars.
+// Tried and dropped in round 1 (profiles/r01_other_configs.txt): 512-thread workgroups that prefetch
+// the next bin's slab with LDS-direct loads (128 KB of LDS) -- the cross-lane work doubled per SIMD.
 // While the updated slab is written back, |y|^2 is accumulated per (source, frame) over the bins of
 // the block and added atomically to r2_next: the frame powers r_nj^2 of the NEXT iteration's
 // auxiliary weights, which would otherwise need their own pass over Y (2 passes).
@@ -44,60 +51,100 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// v_permlane32_swap: rows 2-3 of the first operand trade places with rows 0-1 of the second, so the
+// sum of the two results is x folded over the 32-lane halves in lanes 0-31 (x[l] + x[l+32]) and y
+// folded in lanes 32-63.  Two values in, one live value out.
+__device__ __forceinline__ double fold_halves(double x, double y) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
+// v_permlane16_swap: odd rows of the first operand trade places with even rows of the second: the
+// sum is x folded over each row pair in the even rows, y folded in the odd rows.
+__device__ __forceinline__ double fold_row_pairs(double x, double y) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
+// Wave totals of NV (multiple of 4) per-lane values by reduce-scatter: afterwards every lane of row
+// r holds, in v[u] (u < NV / 4), the wave total of the input value 4 u + iss_row_slot(r).
+__device__ __forceinline__ int iss_row_slot(int row) { return ((row & 1) << 1) | (row >> 1); }
+
+template <int NV>
+__device__ __forceinline__ void wave_reduce_scatter(double (&v)[NV]) {
+  static_assert(NV % 4 == 0, "pad the value list to a multiple of 4");
+#pragma unroll
+  for (int p = 0; p < NV / 2; ++p) v[p] = fold_halves(v[2 * p], v[2 * p + 1]);
+#pragma unroll
+  for (int u = 0; u < NV / 4; ++u) v[u] = fold_row_pairs(v[2 * u], v[2 * u + 1]);
+#pragma unroll
+  for (int u = 0; u < NV / 4; ++u) v[u] = row_allsum(v[u]);
+}
+
+template <int N>
+struct IssShape {
+  static constexpr int SGR = N > 4 ? 4 : N;                 // sources per reduction group
+  static constexpr int NG = (N + SGR - 1) / SGR;            // groups
+  static constexpr int NVP = ((3 * SGR + 3) / 4) * 4;       // values per group, padded
+  static constexpr int PART = 4 * NG * NVP;                 // doubles per parity buffer (4 waves)
+};
+
 // The N sequential rank-1 sweeps of one bin on the register-resident slab y[n][f] (thread-owned
-// frames), weights phi[n][f]; `part` is the two-buffer LDS scratch of the block reduction (one barrier per sweep), `parity` its state.
-// ref: ssspy/bss/_update_spatial_model.py:146-194.
-template <int N, int FPT, int NW>
+// frames), weights phi[n][f]; `part` is the two-buffer LDS scratch of the block reduction (one
+// barrier per sweep), `parity` its state.  ref: ssspy/bss/_update_spatial_model.py:146-194.
+template <int N, int FPT>
 __device__ __forceinline__ void iss_sweeps(c128 (&y)[N][FPT], const double (&phi)[N][FPT],
-                                           double (*part)[NW * 4 * 3 * N], int &parity, double invT,
-                                           int floor_kind, double eps) {
+                                           double *part, int &parity, double invT, int floor_kind,
+                                           double eps) {
+  using S = IssShape<N>;
+  constexpr int SGR = S::SGR, NG = S::NG, NVP = S::NVP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = iss_row_slot(lane >> 4);
 #pragma unroll
   for (int n = 0; n < N; ++n) {
     // per source s: sum_j phi_s y_s conj(y_n) (complex) and sum_j phi_s |y_n|^2, SGR sources at a
-    // time (register budget).  Block totals: 16-lane rows by DPP, row partials through LDS; lane
-    // s < N then owns source s: it adds up the partials of its three sums and forms the steering
-    // coefficient v_s, which v_readlane hands to every thread as a wave-uniform scalar (SGPR
-    // operands of the update)
-    constexpr int SGR = N > 4 ? 4 : N;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *pp = part[parity];
+    // time (register budget)
+    double *pp = part + parity * S::PART;
     parity ^= 1;
 #pragma unroll
-    for (int s0 = 0; s0 < N; s0 += SGR) {
-      double red[3 * SGR];
+    for (int g = 0; g < NG; ++g) {
+      double red[NVP];
 #pragma unroll
-      for (int k = 0; k < 3 * SGR; ++k) red[k] = 0.0;
+      for (int k = 0; k < NVP; ++k) red[k] = 0.0;
 #pragma unroll
       for (int f = 0; f < FPT; ++f) {
         const c128 yn = y[n][f];
         const double pn = cabs2(yn);
 #pragma unroll
         for (int ss = 0; ss < SGR; ++ss) {
-          const int s = s0 + ss < N ? s0 + ss : N - 1;
-          const double w = phi[s][f];
-          const c128 z = cmulc(y[s][f], yn);
-          red[3 * ss] = fma(w, z.x, red[3 * ss]);
-          red[3 * ss + 1] = fma(w, z.y, red[3 * ss + 1]);
-          red[3 * ss + 2] = fma(w, pn, red[3 * ss + 2]);
+          const int s = g * SGR + ss;
+          if (s < N) {
+            const double w = phi[s][f];
+            const c128 z = cmulc(y[s][f], yn);
+            red[3 * ss] = fma(w, z.x, red[3 * ss]);
+            red[3 * ss + 1] = fma(w, z.y, red[3 * ss + 1]);
+            red[3 * ss + 2] = fma(w, pn, red[3 * ss + 2]);
+          }
         }
       }
-#pragma unroll
-      for (int k = 0; k < 3 * SGR; ++k) red[k] = row_allsum(red[k]);
+      wave_reduce_scatter<NVP>(red);
       if ((lane & 15) == 0) {
-        double *dst = pp + (wave * 4 + (lane >> 4)) * (3 * N) + 3 * s0;
 #pragma unroll
-        for (int k = 0; k < 3 * SGR; ++k)
-          if (3 * s0 + k < 3 * N) dst[k] = red[k];
+        for (int u = 0; u < NVP / 4; ++u) pp[(wave * NG + g) * NVP + 4 * u + slot] = red[u];
       }
     }
     __syncthreads();
     double t0 = 0.0, t1 = 0.0, t2 = 0.0;
     if (lane < N) {
+      const int g = lane / SGR, ss = lane - g * SGR;
 #pragma unroll
-      for (int p = 0; p < NW * 4; ++p) {
-        t0 += pp[p * (3 * N) + 3 * lane];
-        t1 += pp[p * (3 * N) + 3 * lane + 1];
-        t2 += pp[p * (3 * N) + 3 * lane + 2];
+      for (int wv = 0; wv < 4; ++wv) {
+        const double *src = pp + (wv * NG + g) * NVP + 3 * ss;
+        t0 += src[0];
+        t1 += src[1];
+        t2 += src[2];
       }
     }
     const double den = apply_floor(t2 * invT, floor_kind, eps);
@@ -118,57 +165,74 @@ __device__ __forceinline__ void iss_sweeps(c128 (&y)[N][FPT], const double (&phi
 // grid: (ceil(F / bins_per_block), B); 256 threads; thread t owns frames t + 256 f, f < FPT.
 // weight: (B, N, T) when !PER_BIN, (B, N, F, T) when PER_BIN.
 template <int N, int FPT, bool PER_BIN>
-__global__ __launch_bounds__(256) void k_iss1_fused(c128 *Y, const double *__restrict__ weight,
-                                                    double *r2_next, int F, int T,
-                                                    int bins_per_block, int floor_kind, double eps) {
-  __shared__ double part[2][4 * 4 * 3 * N];
+__global__ __launch_bounds__(256, 2) void k_iss1_fused(c128 *Y, const double *__restrict__ weight,
+                                                       double *r2_next, int F, int T,
+                                                       int bins_per_block, int floor_kind,
+                                                       double eps) {
+  __shared__ double part[2 * IssShape<N>::PART];
+  __shared__ double r2s[N * FPT * 256];  // [n][f][thread]: thread-private slots, no barrier needed
   const int b = blockIdx.y;
   const int i_begin = blockIdx.x * bins_per_block;
   const int i_end = min(F, i_begin + bins_per_block);
   const double invT = 1.0 / (double)T;
+  // thread-varying part of every address: one unsigned frame index per owned frame, so the loads
+  // and stores take the (scalar row base + 32-bit lane offset) form and no 64-bit address lives in
+  // VGPRs across the sweeps
   bool fv[FPT];
-  int jj[FPT];
+  unsigned jj[FPT];
 #pragma unroll
   for (int f = 0; f < FPT; ++f) {
     const int j = threadIdx.x + 256 * f;
     fv[f] = j < T;
     jj[f] = fv[f] ? j : T - 1;
   }
-  double phi[N][FPT], r2acc[N][FPT];
+  double phi[N][FPT];
 #pragma unroll
   for (int n = 0; n < N; ++n)
 #pragma unroll
     for (int f = 0; f < FPT; ++f) {
-      r2acc[n][f] = 0.0;
-      phi[n][f] = (!PER_BIN && fv[f]) ? weight[((long long)b * N + n) * T + jj[f]] : 0.0;
+      r2s[(n * FPT + f) * 256 + threadIdx.x] = 0.0;
+      const double wv = PER_BIN ? 0.0 : weight[((long long)b * N + n) * T + jj[f]];
+      phi[n][f] = fv[f] ? wv : 0.0;
     }
   int parity = 0;
   for (int i = i_begin; i < i_end; ++i) {
     c128 y[N][FPT];
 #pragma unroll
-    for (int n = 0; n < N; ++n)
+    for (int n = 0; n < N; ++n) {
+      const long long row = (((long long)b * N + n) * F + i) * T;  // wave-uniform
+      const __amdgpu_buffer_rsrc_t yr = make_rsrc(Y + row, (unsigned)T * 16u);
+      const __amdgpu_buffer_rsrc_t wr = make_rsrc(weight + (PER_BIN ? row : 0), (unsigned)T * 8u);
 #pragma unroll
       for (int f = 0; f < FPT; ++f) {
-        const c128 v = Y[(((long long)b * N + n) * F + i) * T + jj[f]];
-        y[n][f] = fv[f] ? v : cmake(0.0, 0.0);
-        if (PER_BIN)
-          phi[n][f] = fv[f] ? weight[(((long long)b * N + n) * F + i) * T + jj[f]] : 0.0;
+        // frames beyond T re-read frame T-1 (finite data) with weight 0: they add nothing to the
+        // sums and are never stored, and the loads stay unconditional
+        y[n][f] = buffer_load_c128(yr, jj[f] * 16u);
+        if (PER_BIN) {
+          const double wv = buffer_load_f64(wr, jj[f] * 8u);
+          phi[n][f] = fv[f] ? wv : 0.0;
+        }
       }
-    iss_sweeps<N, FPT, 4>(y, phi, part, parity, invT, floor_kind, eps);
+    }
+    iss_sweeps<N, FPT>(y, phi, part, parity, invT, floor_kind, eps);
 #pragma unroll
-    for (int n = 0; n < N; ++n)
+    for (int n = 0; n < N; ++n) {
+      const long long row = (((long long)b * N + n) * F + i) * T;
+      const __amdgpu_buffer_rsrc_t yr = make_rsrc(Y + row, (unsigned)T * 16u);
 #pragma unroll
       for (int f = 0; f < FPT; ++f) {
-        if (fv[f]) Y[(((long long)b * N + n) * F + i) * T + jj[f]] = y[n][f];
-        r2acc[n][f] += cabs2(y[n][f]);
+        if (fv[f]) buffer_store_c128(yr, jj[f] * 16u, y[n][f]);
+        r2s[(n * FPT + f) * 256 + threadIdx.x] += cabs2(y[n][f]);
       }
+    }
   }
   if (r2_next) {
 #pragma unroll
     for (int n = 0; n < N; ++n)
 #pragma unroll
       for (int f = 0; f < FPT; ++f)
-        if (fv[f]) atomicAdd(r2_next + ((long long)b * N + n) * T + jj[f], r2acc[n][f]);
+        if (fv[f])
+          atomicAdd(r2_next + ((long long)b * N + n) * T + jj[f], r2s[(n * FPT + f) * 256 + threadIdx.x]);
   }
 }
 
@@ -180,7 +244,7 @@ constexpr int iss_max_fpt() {
 template <int N, int FPT>
 static int launch_iss(void *Y, const double *weight, bool per_bin, double *r2_next, int B, int F,
                       int T, int floor_kind, double eps, hipStream_t st) {
-  // a few bins per block amortise the weight loads and the r2 atomics; keep >= ~2 blocks per CU
+  // a few bins per block amortise the weight loads and the r2 atomics; keep >= ~4 blocks per CU
   long long want_blocks = 1024;
   int bpb = (int)(((long long)B * F + want_blocks - 1) / want_blocks);
   if (bpb < 1) bpb = 1;
