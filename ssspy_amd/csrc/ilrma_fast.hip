@@ -26,6 +26,7 @@
 
 #include "common.hpp"
 #include "cov_core.hpp"
+#include "tail_plan.hpp"
 
 #ifndef SSSPY_N
 #error "compile with -DSSSPY_N=<n_sources>"
@@ -55,13 +56,6 @@ __device__ __forceinline__ double rcp_nr(double x) {
 
 __device__ __forceinline__ int tile_pi(int rho) { return 4 * (rho & 3) + (rho >> 2); }
 
-// Two-level schedule of the bin-major kernels.  A work item is (mixture, bin group) walking all
-// frame tiles; the chip holds SLOTS workgroups at once (2 per CU).  Items that fill whole rounds of
-// SLOTS run unsplit and finish their bins in place; the remaining `tail` items are split into
-// `split` frame chunks each, so the last round is 1/split as long instead of leaving most CUs idle
-// (128 mixtures x 17 groups = 2176 items = 4.25 rounds: 5 rounds unsplit, 4.25 split).  Split blocks
-// write partial sums to a scratch area indexed [tail item][chunk]; a small second kernel folds them.
-// Small batches are the same formula with full == 0.
 // Source models of the tuned kernels (R = (T V)_nij, P = |y_nij|^2; ref: ssspy/bss/ilrma.py):
 //   FM_GAUSS  domain 2: a = P / R^2,           varphi = 1 / R                        (:1116-1125, :1494-1498)
 //   FM_T      domain 2: a = P / (R~ R), varphi = 1 / R~, R~ = w R + (1 - w) P, w = nu / (nu + 2)
@@ -112,57 +106,6 @@ template <>
 __device__ __forceinline__ double mm_num_factor<FM_GAUSS1>(double pw, double, double rinv,
                                                            const FastModel &) {
   return pw * rinv * rinv * rinv;
-}
-
-constexpr int SLOTS = 512;
-struct TailPlan {
-  int full, tail, split, groups;  // blocks = full + tail * split; groups = bin groups per mixture
-};
-
-static inline TailPlan make_tail_plan(int B, int groups, int ntiles) {
-  TailPlan p;
-  const long long items = (long long)B * groups;
-  p.groups = groups;
-  p.full = (int)(items / SLOTS) * SLOTS;
-  p.tail = (int)(items - p.full);
-  p.split = 1;
-  if (p.tail > 0) {
-    int s = SLOTS / p.tail;
-    s = s > 16 ? 16 : s;
-    s = s > ntiles ? ntiles : s;
-    if (s > 1) {
-      const int tpc = (ntiles + s - 1) / s;
-      s = (ntiles + tpc - 1) / tpc;  // no empty chunks
-    }
-    p.split = s < 1 ? 1 : s;
-  }
-  if (p.split == 1) {
-    p.full += p.tail;
-    p.tail = 0;
-  }
-  return p;
-}
-
-struct BlockWork {
-  int b, group, chunk, nchunks, tail_idx;
-};
-__device__ __forceinline__ BlockWork block_work(const TailPlan &p) {
-  BlockWork w;
-  int item = blockIdx.x;
-  if (item < p.full) item = xcd_contiguous(item, p.full);
-  w.chunk = 0;
-  w.nchunks = 1;
-  w.tail_idx = 0;
-  if (item >= p.full) {
-    const int t = item - p.full;
-    w.tail_idx = t / p.split;
-    w.chunk = t - w.tail_idx * p.split;
-    w.nchunks = p.split;
-    item = p.full + w.tail_idx;
-  }
-  w.b = item / p.groups;
-  w.group = item - w.b * p.groups;
-  return w;
 }
 
 // ---- stage the activation tile V[b, n, 0:16, j0:j0+16] of every source into LDS rows of VROW

@@ -5,13 +5,14 @@ namespace ssspy {
 
 #define DECL_N(n)                                                                                \
   int mnmf_basis_n##n(const void *, const void *, const double *, const double *, double *,     \
-                      const double *, int, int, int, int, int, int, double, hipStream_t);       \
+                      const double *, int, int, int, int, int, int, double, double *,           \
+                      hipStream_t);                                                             \
   int mnmf_activation_n##n(const void *, const void *, const double *, const double *,          \
                            const double *, double *, int, int, int, int, int, int, hipStream_t); \
   int mnmf_wcov_n##n(const void *, const double *, const double *, const double *, void *, int, \
-                     int, int, int, int, hipStream_t);                                          \
+                     int, int, int, int, double *, hipStream_t);                                \
   int mnmf_spatial_n##n(const void *, const void *, double *, const double *, const double *,   \
-                        int, int, int, int, int, hipStream_t);                                  \
+                        int, int, int, int, int, double *, hipStream_t);                        \
   int mnmf_loss_n##n(const void *, const void *, const double *, const double *, const double *, \
                      double *, int, int, int, int, int, hipStream_t);                           \
   int mnmf_norm_scale_n##n(void *, double *, const double *, int, int, int, int, double,        \
@@ -47,8 +48,16 @@ static inline int mnmf_chunks(int B, int F, int T, int K) {
 }
 
 struct MnmfWs {
-  size_t part, btmp, U, qbuf, qinv, total;
+  size_t part, btmp, U, qbuf, qinv, tail, total;
 };
+
+// partial sums of the split work items of the bin-major kernels' last scheduling round
+// (tail_plan.hpp; at most 512 (item, chunk) slots; mnmf_tail_doubles() in mnmf_kernels.hip)
+static inline size_t mnmf_tail_bytes(int N, int M) {
+  size_t a = (size_t)N * 64 * 16 * 2, b = (size_t)64 * M * M * M * 2, c = (size_t)64 * N * M * 2;
+  size_t m = a > b ? (a > c ? a : c) : (b > c ? b : c);
+  return 512 * m * sizeof(double);
+}
 
 static inline MnmfWs mnmf_ws(int B, int N, int M, int F, int T, int K) {
   MnmfWs w;
@@ -63,6 +72,8 @@ static inline MnmfWs mnmf_ws(int B, int N, int M, int F, int T, int K) {
   off += al((size_t)B * F * M * sizeof(double));
   w.qinv = off;
   off += al((size_t)B * F * M * M * 2 * sizeof(double));
+  w.tail = off;
+  off += al(mnmf_tail_bytes(N, M));
   w.total = off;
   return w;
 }
@@ -90,7 +101,8 @@ static int step_basis(const void *X, const void *Q, const double *D, double *bas
                       double eps, char *ws, const MnmfWs &w, hipStream_t st) {
   double *out = K > 16 ? (double *)(ws + w.btmp) : basis;
   auto run = [&]() -> int {
-    MNMF_DISPATCH(N, mnmf_basis, X, Q, D, basis, out, act, B, M, F, T, K, fk, eps, st);
+    MNMF_DISPATCH(N, mnmf_basis, X, Q, D, basis, out, act, B, M, F, T, K, fk, eps,
+                  (double *)(ws + w.tail), st);
   };
   int rc = run();
   if (rc) return rc;
@@ -156,7 +168,8 @@ int ssspy_fastmnmf_update(const void *X, const void *C, void *Q, double *D, doub
   if (steps & SSSPY_MNMF_DIAGONALIZER) {
     void *U = ws + w.U;
     auto run = [&]() -> int {
-      MNMF_DISPATCH(N, mnmf_wcov, X, D, basis, activation, U, B, M, F, T, K, st);
+      MNMF_DISPATCH(N, mnmf_wcov, X, D, basis, activation, U, B, M, F, T, K,
+                    (double *)(ws + w.tail), st);
     };
     rc = run();
     if (rc) return rc;
@@ -167,7 +180,8 @@ int ssspy_fastmnmf_update(const void *X, const void *C, void *Q, double *D, doub
   }
   if (steps & SSSPY_MNMF_SPATIAL) {
     auto run = [&]() -> int {
-      MNMF_DISPATCH(N, mnmf_spatial, X, Q, D, basis, activation, B, M, F, T, K, st);
+      MNMF_DISPATCH(N, mnmf_spatial, X, Q, D, basis, activation, B, M, F, T, K,
+                    (double *)(ws + w.tail), st);
     };
     rc = run();
     if (rc) return rc;
@@ -190,7 +204,9 @@ int ssspy_fastmnmf_diagonalizer_covariance(const void *X, const double *D, const
                                            int F, int T, int K, void *stream) {
   SSSPY_REQUIRE(X && D && basis && activation && U && B > 0, "fastmnmf_diagonalizer_covariance: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_diagonalizer_covariance: bad n_basis");
-  MNMF_DISPATCH(N, mnmf_wcov, X, D, basis, activation, U, B, M, F, T, K, as_stream(stream));
+  // no workspace at this entry point: the generic (unsplit) covariance kernel
+  MNMF_DISPATCH(N, mnmf_wcov, X, D, basis, activation, U, B, M, F, T, K, (double *)nullptr,
+                as_stream(stream));
 }
 
 int ssspy_fastmnmf_loss_data(const void *X, const void *Q, const double *D, const double *basis,

@@ -16,6 +16,7 @@
 #include "hermitian.hpp"
 #include "nmf_tile.hpp"
 #include "smallmat.hpp"
+#include "tail_plan.hpp"
 
 #ifndef SSSPY_N
 #error "compile with -DSSSPY_N=<n_sources>"
@@ -521,12 +522,14 @@ __device__ __forceinline__ void vstage_store(const VStage &st, double *buf) {
     if (idx < N * 16 * 8) *reinterpret_cast<double2 *>(buf + row * VROW + 2 * chunk) = st.v[u];
   }
 }
+// ksteps = ceil(K / 4): k-slabs beyond n_basis are zero on both sides and are skipped
 __device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const double (&tb)[4], int c,
-                                                 int q) {
+                                                 int q, int ksteps) {
   double4_t R = {0.0, 0.0, 0.0, 0.0};
   const int col = tile_pi(c);
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) R = mfma_f64(vs_n[(4 * ks + q) * VROW + col], tb[ks], R);
+  for (int ks = 0; ks < 4; ++ks)
+    if (ks < ksteps) R = mfma_f64(vs_n[(4 * ks + q) * VROW + col], tb[ks], R);
   return R;
 }
 template <int M>
@@ -548,21 +551,34 @@ __device__ __forceinline__ void xtile_load(XTileM<M> &xt, const c128 *__restrict
 // which of the three bin-major passes a kernel instance performs
 enum { MODE_BASIS = 0, MODE_WCOV = 1, MODE_SPATIAL = 2 };
 
-// grid: (ceil(F/64), 1, B); wave w owns bins [64 bx + 16 w, +16)
+// grid: 1-D, see TailPlan (tail_plan.hpp): a work item is (mixture, 64-bin group), wave w owns bins
+// [64 group + 16 w, +16).  Unsplit items finish their bins in place; the split items of the last
+// scheduling round write partial sums to `tailpart` ([tail item][chunk][...]) and a small kernel
+// folds them (k_mnmf_basis_finalize / k_mnmf_wcov_fold / k_mnmf_spatial_finalize).
+template <int M>
+constexpr int mnmf_tail_doubles() {
+  // per (tail item, chunk): basis N*64*16*2, covariance 64*M^3 complex, spatial 64*N*M*2
+  constexpr int a = N * 64 * 16 * 2, b = 64 * M * M * M * 2, c = 64 * N * M * 2;
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
+}
+
 template <int M, int MODE>
 __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restrict__ X,
-                                                            const c128 *__restrict__ Q, double *Dsp,
-                                                            double *basis,
-                                                            const double *__restrict__ act,
-                                                            c128 *__restrict__ U, int F, int T, int K,
-                                                            int floor_kind, double eps) {
+                                                               const c128 *__restrict__ Q,
+                                                               double *Dsp, double *basis,
+                                                               const double *__restrict__ act,
+                                                               c128 *__restrict__ U, int F, int T,
+                                                               int K, int floor_kind, double eps,
+                                                               TailPlan plan,
+                                                               double *__restrict__ tailpart) {
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const GridItem gi = xcd_contiguous_grid();  // bin groups of a mixture share its activation tile
-  const int b = gi.z;
-  const int i0 = gi.x * 64 + wave * 16;
+  const BlockWork work = block_work(plan);  // XCD-contiguous: a mixture's groups share its V tile
+  const int b = work.b, nchunks = work.nchunks;
+  const int i0 = work.group * 64 + wave * 16;
   const int bin = min(i0 + c, F - 1);
+  const int ksteps = (K + 3) >> 2;
   const c128 *Xb = X + (long long)b * M * F * T;
   const double *act_b = act + (long long)b * N * K * T;
   c128 Qb[M][M];
@@ -604,21 +620,23 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
       for (int m = 0; m < M; ++m) sn[n][m] = sd[n][m] = 0.0;
   }
   const int ntiles = (T + 15) >> 4;
+  const int tpc = (ntiles + nchunks - 1) / nchunks;
+  const int jt_begin = work.chunk * tpc, jt_end = min(ntiles, jt_begin + tpc);
   VStage st;
   XTileM<M> cur, nxt;
-  vstage_load(st, act_b, K, T, 0);
-  xtile_load<M>(cur, Xb, F, T, bin, 0, q);
+  vstage_load(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
+  xtile_load<M>(cur, Xb, F, T, bin, min(jt_begin, ntiles - 1) * 16, q);
   vstage_store(st, vs[0]);
   __syncthreads();
-  for (int jt = 0; jt < ntiles; ++jt) {
+  for (int jt = jt_begin; jt < jt_end; ++jt) {
     const int j0 = jt * 16;
-    const int jn = min(jt + 1, ntiles - 1) * 16;
+    const int jn = min(jt + 1, jt_end - 1) * 16;
     vstage_load(st, act_b, K, T, jn);
     xtile_load<M>(nxt, Xb, F, T, bin, jn, q);
-    const double *vcur = vs[jt & 1];
+    const double *vcur = vs[(jt - jt_begin) & 1];
     double4_t lamR[N];
 #pragma unroll
-    for (int n = 0; n < N; ++n) lamR[n] = rt_from_lds(vcur + n * 16 * VROW, tb[n], c, q);
+    for (int n = 0; n < N; ++n) lamR[n] = rt_from_lds(vcur + n * 16 * VROW, tb[n], c, q, ksteps);
     double a[N][4], bq[N][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -684,10 +702,12 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
         }
       }
     }
-    vstage_store(st, vs[(jt + 1) & 1]);
+    vstage_store(st, vs[(jt - jt_begin + 1) & 1]);
     __syncthreads();
     cur = nxt;
   }
+  const long long slot = (long long)work.tail_idx * nchunks + work.chunk;
+  double *tp = tailpart + slot * mnmf_tail_doubles<M>();
   if (MODE == MODE_BASIS) {
 #pragma unroll
     for (int n = 0; n < N; ++n)
@@ -695,8 +715,14 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
       for (int r = 0; r < 4; ++r) {
         const int ob = i0 + q + 4 * r;
         if (ob < F && c < K) {
-          double *dst = basis + (((long long)b * N + n) * F + ob) * K + c;
-          *dst = apply_floor((*dst) * sqrt(num[n][r] / den[n][r]), floor_kind, eps);
+          if (nchunks == 1) {
+            double *dst = basis + (((long long)b * N + n) * F + ob) * K + c;
+            *dst = apply_floor((*dst) * sqrt(num[n][r] / den[n][r]), floor_kind, eps);
+          } else {
+            double *dst = tp + ((n * 64 + (ob - work.group * 64)) * 16 + c) * 2;
+            dst[0] = num[n][r];
+            dst[1] = den[n][r];
+          }
         }
       }
   }
@@ -705,7 +731,9 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
     const double scale = 1.0 / (double)T;
     const int ob = i0 + c;
     if (ob < F && q == 0) {
-      c128 *dst = U + ((long long)b * F + ob) * (long long)(M * M * M);
+      c128 *dst = nchunks == 1 ? U + ((long long)b * F + ob) * (long long)(M * M * M)
+                               : reinterpret_cast<c128 *>(tp) +
+                                     (long long)(ob - work.group * 64) * (M * M * M);
 #pragma unroll
       for (int s = 0; s < M; ++s) {
         int e = 0;
@@ -735,11 +763,87 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
         w += __shfl_xor(w, 16, 64);
         w += __shfl_xor(w, 32, 64);
         if (q == 0 && ob < F) {
-          double *dst = Dsp + ((long long)b * F + ob) * (N * M) + n * M + m;
-          *dst = sqrt(v / w) * Db[n][m];
+          if (nchunks == 1) {
+            double *dst = Dsp + ((long long)b * F + ob) * (N * M) + n * M + m;
+            *dst = sqrt(v / w) * Db[n][m];
+          } else {
+            double *dst = tp + (((ob - work.group * 64) * N + n) * M + m) * 2;
+            dst[0] = v;
+            dst[1] = w;
+          }
         }
       }
   }
+}
+
+// ---- folds of the split (tail) items; grid.y = tail item, one thread per output value
+// basis <- floor(basis * sqrt(sum num / sum den)); grid: (N*64*16/256, tail)
+template <int M>
+__global__ __launch_bounds__(256) void k_mnmf_basis_finalize(double *basis,
+                                                             const double *__restrict__ tailpart,
+                                                             int F, int K, TailPlan plan,
+                                                             int floor_kind, double eps) {
+  const int tail_idx = blockIdx.y;
+  const int item = plan.full + tail_idx;
+  const int b = item / plan.groups, group = item - b * plan.groups;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (n, local bin, k16)
+  const int k = e & 15, lb = (e >> 4) & 63, n = e >> 10;
+  const int bin = group * 64 + lb;
+  if (n >= N || k >= K || bin >= F) return;
+  double sn = 0.0, sd = 0.0;
+  for (int ch = 0; ch < plan.split; ++ch) {
+    const double *src = tailpart + ((long long)tail_idx * plan.split + ch) * mnmf_tail_doubles<M>() +
+                        (long long)e * 2;
+    sn += src[0];
+    sd += src[1];
+  }
+  double *dst = basis + (((long long)b * N + n) * F + bin) * K + k;
+  *dst = apply_floor((*dst) * sqrt(sn / sd), floor_kind, eps);
+}
+
+// U[tail items] = sum of their chunks; grid: (64*M^3/256 rounded up, tail)
+template <int M>
+__global__ __launch_bounds__(256) void k_mnmf_wcov_fold(c128 *__restrict__ U,
+                                                        const double *__restrict__ tailpart, int F,
+                                                        TailPlan plan) {
+  constexpr int PER = 64 * M * M * M;
+  const int tail_idx = blockIdx.y;
+  const int item = plan.full + tail_idx;
+  const int b = item / plan.groups, group = item - b * plan.groups;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lb = e / (M * M * M);
+  if (e >= PER || group * 64 + lb >= F) return;
+  double re = 0.0, im = 0.0;
+  for (int ch = 0; ch < plan.split; ++ch) {
+    const c128 v = reinterpret_cast<const c128 *>(
+        tailpart + ((long long)tail_idx * plan.split + ch) * mnmf_tail_doubles<M>())[e];
+    re += v.x;
+    im += v.y;
+  }
+  U[((long long)b * F + group * 64) * (long long)(M * M * M) + e] = cmake(re, im);
+}
+
+// d <- d * sqrt(sum a / sum b); grid: (64*N*M/256 rounded up, tail)
+template <int M>
+__global__ __launch_bounds__(256) void k_mnmf_spatial_finalize(double *Dsp,
+                                                               const double *__restrict__ tailpart,
+                                                               int F, TailPlan plan) {
+  constexpr int PER = 64 * N * M;
+  const int tail_idx = blockIdx.y;
+  const int item = plan.full + tail_idx;
+  const int b = item / plan.groups, group = item - b * plan.groups;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (local bin, n, m)
+  const int lb = e / (N * M);
+  if (e >= PER || group * 64 + lb >= F) return;
+  double a = 0.0, bb = 0.0;
+  for (int ch = 0; ch < plan.split; ++ch) {
+    const double *src = tailpart + ((long long)tail_idx * plan.split + ch) * mnmf_tail_doubles<M>() +
+                        (long long)e * 2;
+    a += src[0];
+    bb += src[1];
+  }
+  double *dst = Dsp + ((long long)b * F + group * 64) * (N * M) + e;
+  *dst = sqrt(a / bb) * (*dst);
 }
 
 // ------------------------------------------------------------ activation, frame-major fast variant
@@ -1141,22 +1245,32 @@ constexpr int cov_lds_mm() {
   return cov_lds_doubles_per_wave<M, M>();
 }
 
-// The bin-split variants put only ceil(F/64) workgroups per mixture on the chip: they pay off once
-// the batch supplies >= 2 workgroups per CU (measured: +15 % at 64 mixtures, -45 % at 1).
+// The bin-split variants run on the two-level schedule of tail_plan.hpp: whole rounds of 512
+// workgroups unsplit, the remainder (or a small batch) split along the frames.
 static inline bool mnmf_fast_ok(int B, int F, int T, int K) {
   static const bool disabled = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;
-  return !disabled && K <= 16 && (long long)B * ((F + 63) / 64) >= 512;
+  return !disabled && K <= 16;
+}
+static inline TailPlan mnmf_plan(int B, int F, int T) {
+  // these kernels hold one workgroup per CU (x prefetch in registers, > 256 VGPR + AGPR)
+  return make_tail_plan(B, (F + 63) / 64, (T + 15) / 16, 256);
 }
 
 int LAUNCHER(mnmf_basis)(const void *X, const void *Q, const double *Dsp, const double *basis,
                          double *basis_out, const double *act, int B, int M, int F, int T, int K,
-                         int floor_kind, double eps, hipStream_t st) {
+                         int floor_kind, double eps, double *tailpart, hipStream_t st) {
   Dims d{B, F, T, K};
   if (mnmf_fast_ok(B, F, T, K) && basis_out == basis) {
-    dim3 fgrid((F + 63) / 64, 1, B);
-    MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_BASIS>), fgrid, dim3(256), 0,
-                                          st, (const c128 *)X, (const c128 *)Q, (double *)Dsp,
-                                          basis_out, act, (c128 *)nullptr, F, T, K, floor_kind, eps));
+    const TailPlan plan = mnmf_plan(B, F, T);
+    dim3 fgrid(plan.full + plan.tail * plan.split);
+    MNMF_DISPATCH_M(M, {
+      hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_BASIS>), fgrid, dim3(256), 0, st,
+                         (const c128 *)X, (const c128 *)Q, (double *)Dsp, basis_out, act,
+                         (c128 *)nullptr, F, T, K, floor_kind, eps, plan, tailpart);
+      if (plan.tail > 0)
+        hipLaunchKernelGGL((k_mnmf_basis_finalize<MM>), dim3(N * 64 * 16 / 256, plan.tail), dim3(256),
+                           0, st, basis_out, tailpart, F, K, plan, floor_kind, eps);
+    });
     return check_launch("k_mnmf_basis_fast");
   }
   dim3 grid((F + 15) / 16, kt_count(K), B), block(256);
@@ -1201,13 +1315,20 @@ int LAUNCHER(mnmf_activation)(const void *X, const void *Q, const double *Dsp, c
 }
 
 int LAUNCHER(mnmf_wcov)(const void *X, const double *Dsp, const double *basis, const double *act,
-                        void *U, int B, int M, int F, int T, int K, hipStream_t st) {
+                        void *U, int B, int M, int F, int T, int K, double *tailpart,
+                        hipStream_t st) {
   Dims d{B, F, T, K};
-  if (mnmf_fast_ok(B, F, T, K)) {
-    dim3 fgrid((F + 63) / 64, 1, B);
-    MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_WCOV>), fgrid, dim3(256), 0,
-                                          st, (const c128 *)X, (const c128 *)nullptr, (double *)Dsp,
-                                          (double *)basis, act, (c128 *)U, F, T, K, 0, 0.0));
+  if (mnmf_fast_ok(B, F, T, K) && tailpart) {
+    const TailPlan plan = mnmf_plan(B, F, T);
+    dim3 fgrid(plan.full + plan.tail * plan.split);
+    MNMF_DISPATCH_M(M, {
+      hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_WCOV>), fgrid, dim3(256), 0, st,
+                         (const c128 *)X, (const c128 *)nullptr, (double *)Dsp, (double *)basis, act,
+                         (c128 *)U, F, T, K, 0, 0.0, plan, tailpart);
+      if (plan.tail > 0)
+        hipLaunchKernelGGL((k_mnmf_wcov_fold<MM>), dim3((64 * MM * MM * MM + 255) / 256, plan.tail),
+                           dim3(256), 0, st, (c128 *)U, tailpart, F, plan);
+    });
     return check_launch("k_mnmf_wcov_fast");
   }
   dim3 grid((F + 15) / 16, 1, B), block(256);
@@ -1224,13 +1345,20 @@ int LAUNCHER(mnmf_wcov)(const void *X, const double *Dsp, const double *basis, c
 }
 
 int LAUNCHER(mnmf_spatial)(const void *X, const void *Q, double *Dsp, const double *basis,
-                           const double *act, int B, int M, int F, int T, int K, hipStream_t st) {
+                           const double *act, int B, int M, int F, int T, int K, double *tailpart,
+                           hipStream_t st) {
   Dims d{B, F, T, K};
   if (mnmf_fast_ok(B, F, T, K)) {
-    dim3 fgrid((F + 63) / 64, 1, B);
-    MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_SPATIAL>), fgrid, dim3(256),
-                                          0, st, (const c128 *)X, (const c128 *)Q, Dsp,
-                                          (double *)basis, act, (c128 *)nullptr, F, T, K, 0, 0.0));
+    const TailPlan plan = mnmf_plan(B, F, T);
+    dim3 fgrid(plan.full + plan.tail * plan.split);
+    MNMF_DISPATCH_M(M, {
+      hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_SPATIAL>), fgrid, dim3(256), 0, st,
+                         (const c128 *)X, (const c128 *)Q, Dsp, (double *)basis, act,
+                         (c128 *)nullptr, F, T, K, 0, 0.0, plan, tailpart);
+      if (plan.tail > 0)
+        hipLaunchKernelGGL((k_mnmf_spatial_finalize<MM>), dim3((64 * N * MM + 255) / 256, plan.tail),
+                           dim3(256), 0, st, Dsp, tailpart, F, plan);
+    });
     return check_launch("k_mnmf_spatial_fast");
   }
   dim3 grid((F + 15) / 16, 1, B), block(256);
