@@ -1,0 +1,186 @@
+// Tile plumbing shared by the throughput ("fast") pass kernels of ILRMA and FastMNMF: staging of the
+// activation tile in LDS, the two ways a wave fetches its 16-bin x 16-frame x tile, GEMM1 from the
+// staged tile, the Newton reciprocal.  NS = sources (rows of the NMF pair), NC = channels of X.
+// Lane layout of a wave throughout: lane = 16 q + c, c = bin inside the wave's 16-bin tile, q = frame
+// sub-group; register r of lane (c, q) holds frame j0 + q + 4 r.
+#pragma once
+
+#include "common.hpp"
+
+namespace ssspy {
+namespace fast {
+
+constexpr int VROW = 18;  // doubles per staged row (16 + 2 pad: 144-byte stride)
+
+__device__ __forceinline__ double rcp_nr(double x) {
+  // v_rcp_f64 + 2 Newton steps: exact to ~1 ulp (benchmarks/micro/rcp_precision.hip)
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  return r;
+}
+
+__device__ __forceinline__ int tile_pi(int rho) { return 4 * (rho & 3) + (rho >> 2); }
+
+// ---- stage the activation tile V[b, n, 0:16, j0:j0+16] of every source into LDS rows of VROW
+// doubles (zero beyond K rows / T frames).  256 threads, NS*16 rows * 8 double2 chunks.
+template <int NS>
+struct VStage {
+  double2 v[(NS * 16 * 8 + 255) / 256];
+};
+
+template <int NS>
+__device__ __forceinline__ void vstage_load(VStage<NS> &st, const double *__restrict__ act_b, int K,
+                                            int T, int j0) {
+#pragma unroll
+  for (int u = 0; u < (NS * 16 * 8 + 255) / 256; ++u) {
+    const int idx = threadIdx.x + 256 * u;
+    const int row = idx >> 3, chunk = idx & 7;  // row = n*16 + k
+    const int n = row >> 4, k = row & 15;
+    const int j = j0 + 2 * chunk;
+    double2 val = make_double2(0.0, 0.0);
+    if (idx < NS * 16 * 8 && k < K) val = load_pair_in_row(act_b + ((long long)n * K + k) * T, j, T);
+    st.v[u] = val;
+  }
+}
+
+template <int NS>
+__device__ __forceinline__ void vstage_store(const VStage<NS> &st, double *buf) {
+#pragma unroll
+  for (int u = 0; u < (NS * 16 * 8 + 255) / 256; ++u) {
+    const int idx = threadIdx.x + 256 * u;
+    const int row = idx >> 3, chunk = idx & 7;
+    if (idx < NS * 16 * 8) {  // frame f of the tile lives in slot tile_pi(f)
+      buf[row * VROW + tile_pi(2 * chunk)] = st.v[u].x;
+      buf[row * VROW + tile_pi(2 * chunk + 1)] = st.v[u].y;
+    }
+  }
+}
+
+template <int NC>
+struct XTile {
+  c128 x[NC][4];
+};
+
+// bin-major x tile: lane (c, q) reads frames j0+q+4r of bin `bin`, so one load instruction
+// (fixed r) takes 64 contiguous bytes per bin from the 4 q-lanes: 16 half cache lines instead of the
+// 32 quarter lines of a "4 consecutive frames per lane" split (TCP tag-conflict stalls, profiles/)
+template <int NC>
+__device__ __forceinline__ void xtile_load_binmajor(XTile<NC> &xt, const c128 *__restrict__ Xb,
+                                                    int F, int T, int bin, int j0, int q) {
+  const int j = j0 + q;
+#pragma unroll
+  for (int m = 0; m < NC; ++m) {
+    const c128 *row = Xb + ((long long)m * F + bin) * T;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xt.x[m][r] = row[min(j + 4 * r, T - 1)];
+  }
+}
+
+// The same loads through a buffer descriptor of the mixture's tensor (base in SGPRs): the per-lane
+// address state is ONE 32-bit offset per tile -- channel stride in the scalar offset, the four
+// frames in the instruction's immediate -- where the flat form keeps a 64-bit address per load.
+// Frames beyond T are not clamped: they read the next row (finite data; zeros past the end of the
+// tensor) and the caller masks them.  Needs NC * F * T * 16 < 2^32.
+template <int NC>
+__device__ __forceinline__ void xtile_load_binmajor_buf(XTile<NC> &xt, __amdgpu_buffer_rsrc_t xr,
+                                                        int F, int T, int bin, int j0, int q) {
+  const unsigned voff = ((unsigned)bin * (unsigned)T + (unsigned)(j0 + q)) * 16u;
+#pragma unroll
+  for (int m = 0; m < NC; ++m) {
+    const unsigned soff = (unsigned)m * (unsigned)F * (unsigned)T * 16u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xr, voff + 64u * r, soff, 0);
+      xt.x[m][r] = cmake(__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2]));
+    }
+  }
+}
+
+// The same tile, fetched with coalesced addresses and transposed through a wave-private LDS
+// patch: a load instruction takes 4 bin rows x 256 contiguous bytes (lane = frame), the patch
+// turns (lane = frame, register = bin) into (lane = bin, register = frame).  Two channels per
+// pass so the patch stays at 8.5 KB per wave; rows are 17 slots apart, which makes both the
+// frame-major writes and the bin-major reads bank-conflict free.  The patch is wave-private, so no
+// workgroup barrier is needed -- but the exchange is between lanes, which the per-thread memory
+// model does not order: every write and read phase is fenced explicitly (see below).  (Measured on
+// the covariance kernel, whose 2 waves per bin tile made the texture addresser the limiter:
+// 1.32 -> 1.10 ms.)
+constexpr int XPATCH = 2 * 16 * 17;  // c128 slots per wave
+
+template <int NC>
+__device__ __forceinline__ void xtile_load_transposed(XTile<NC> &xt, const c128 *__restrict__ Xb,
+                                                      int F, int T, int i0, int j0, int c, int q,
+                                                      c128 *patch) {
+  const int jf = min(j0 + c, T - 1);
+#pragma unroll
+  for (int m = 0; m < NC; ++m)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+      xt.x[m][rr] = Xb[((long long)m * F + min(i0 + 4 * rr + q, F - 1)) * T + jf];
+#pragma unroll
+  for (int m0 = 0; m0 < NC; m0 += 2) {
+    // The patch is reused by every pass and every tile, and the exchange is between LANES: nothing
+    // in the per-thread memory model orders this pass's writes after the previous pass's reads
+    // (measured: without the wait a barrier-free walk returned wrong tiles for N >= 3).  Drain the
+    // wave's outstanding LDS reads and pin the order for the compiler.
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+      if (m0 + mm < NC) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) patch[(mm * 16 + 4 * rr + q) * 17 + c] = xt.x[m0 + mm][rr];
+      }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // the writes of all lanes have landed
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+      if (m0 + mm < NC) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xt.x[m0 + mm][r] = patch[(mm * 16 + c) * 17 + q + 4 * r];
+      }
+  }
+}
+
+// GEMM1 of the bin-major tile from the staged V: R[bin c, frame j0+q+4r] in register r
+// (D row q+4r reads slot tile_pi(q+4r) = 4q+r, which holds frame tile_pi(4q+r) = q+4r)
+// ksteps = ceil(K / 4): k-slabs beyond n_basis are zero on both sides and are skipped
+__device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const double (&tb)[4], int c,
+                                                 int q, int ksteps) {
+  double4_t R = {0.0, 0.0, 0.0, 0.0};
+  const int col = tile_pi(c);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    if (ks < ksteps) R = mfma_f64(vs_n[(4 * ks + q) * VROW + col], tb[ks], R);
+  return R;
+}
+
+// The same with the B operand (the basis rows of the wave's 16 bins) read from LDS as well:
+// tl_n[k * 16 + c] = T[n, bin c, k], zero beyond n_basis -- for kernels that cannot afford the 32
+// VGPRs of a hoisted operand (FastMNMF keeps every source's GEMM1 output live at once)
+__device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const double *tl_n, int c,
+                                                 int q, int ksteps) {
+  double4_t R = {0.0, 0.0, 0.0, 0.0};
+  const int col = tile_pi(c);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    if (ks < ksteps) R = mfma_f64(vs_n[(4 * ks + q) * VROW + col], tl_n[(4 * ks + q) * 16 + c], R);
+  return R;
+}
+
+// stage T[n, i0 + 0..15, 0..K) of every source into a wave-private LDS block tl[n][k][bin]
+template <int NS>
+__device__ __forceinline__ void stage_basis_rows(double *tl, const double *__restrict__ basis_b,
+                                                 int F, int K, int i0, int lane) {
+  for (int e = lane; e < NS * 256; e += 64) {
+    const int k = e & 15, bl = (e >> 4) & 15, n = e >> 8;
+    const int bi = min(i0 + bl, F - 1);
+    tl[(n * 16 + k) * 16 + bl] = k < K ? basis_b[((long long)n * F + bi) * K + k] : 0.0;
+  }
+}
+
+}  // namespace fast
+}  // namespace ssspy

@@ -26,6 +26,7 @@
 
 #include "common.hpp"
 #include "cov_core.hpp"
+#include "fast_tiles.hpp"
 #include "tail_plan.hpp"
 
 #ifndef SSSPY_N
@@ -43,18 +44,13 @@ namespace ssspy {
 namespace SSSPY_CAT(ilrma_fast_n, SSSPY_N) {
 
 constexpr int N = SSSPY_N;
-constexpr int VROW = 18;  // doubles per staged row (16 + 2 pad: 144-byte stride, see header)
-
-__device__ __forceinline__ double rcp_nr(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-x, r, 1.0);
-  r = fma(r, e, r);
-  return r;
-}
-
-__device__ __forceinline__ int tile_pi(int rho) { return 4 * (rho & 3) + (rho >> 2); }
+using fast::rcp_nr;
+using fast::rt_from_lds;
+using fast::tile_pi;
+using fast::VROW;
+using fast::XPATCH;
+typedef fast::VStage<N> VStage;
+typedef fast::XTile<N> XTile;
 
 // Source models of the tuned kernels (R = (T V)_nij, P = |y_nij|^2; ref: ssspy/bss/ilrma.py):
 //   FM_GAUSS  domain 2: a = P / R^2,           varphi = 1 / R                        (:1116-1125, :1494-1498)
@@ -106,114 +102,6 @@ template <>
 __device__ __forceinline__ double mm_num_factor<FM_GAUSS1>(double pw, double, double rinv,
                                                            const FastModel &) {
   return pw * rinv * rinv * rinv;
-}
-
-// ---- stage the activation tile V[b, n, 0:16, j0:j0+16] of every source into LDS rows of VROW
-// doubles (zero beyond K rows / T frames).  256 threads, N*16 rows * 8 double2 chunks.
-struct VStage {
-  double2 v[(N * 16 * 8 + 255) / 256];
-};
-
-__device__ __forceinline__ void vstage_load(VStage &st, const double *__restrict__ act_b, int K,
-                                            int T, int j0) {
-#pragma unroll
-  for (int u = 0; u < (N * 16 * 8 + 255) / 256; ++u) {
-    const int idx = threadIdx.x + 256 * u;
-    const int row = idx >> 3, chunk = idx & 7;  // row = n*16 + k
-    const int n = row >> 4, k = row & 15;
-    const int j = j0 + 2 * chunk;
-    double2 val = make_double2(0.0, 0.0);
-    if (idx < N * 16 * 8 && k < K) val = load_pair_in_row(act_b + ((long long)n * K + k) * T, j, T);
-    st.v[u] = val;
-  }
-}
-
-__device__ __forceinline__ void vstage_store(const VStage &st, double *buf) {
-#pragma unroll
-  for (int u = 0; u < (N * 16 * 8 + 255) / 256; ++u) {
-    const int idx = threadIdx.x + 256 * u;
-    const int row = idx >> 3, chunk = idx & 7;
-    if (idx < N * 16 * 8) {  // frame f of the tile lives in slot tile_pi(f)
-      buf[row * VROW + tile_pi(2 * chunk)] = st.v[u].x;
-      buf[row * VROW + tile_pi(2 * chunk + 1)] = st.v[u].y;
-    }
-  }
-}
-
-struct XTile {
-  c128 x[N][4];
-};
-
-// bin-major x tile: lane (c, q) reads frames j0+q+4r of bin `bin`, so one load instruction
-// (fixed r) takes 64 contiguous bytes per bin from the 4 q-lanes: 16 half cache lines instead of the
-// 32 quarter lines of a "4 consecutive frames per lane" split (TCP tag-conflict stalls, profiles/)
-__device__ __forceinline__ void xtile_load_binmajor(XTile &xt, const c128 *__restrict__ Xb, int F,
-                                                    int T, int bin, int j0, int q) {
-  const int j = j0 + q;
-#pragma unroll
-  for (int m = 0; m < N; ++m) {
-    const c128 *row = Xb + ((long long)m * F + bin) * T;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xt.x[m][r] = row[min(j + 4 * r, T - 1)];
-  }
-}
-
-// The same tile, fetched with coalesced addresses and transposed through a wave-private LDS
-// patch: a load instruction takes 4 bin rows x 256 contiguous bytes (lane = frame), the patch
-// turns (lane = frame, register = bin) into (lane = bin, register = frame).  Two channels per
-// pass so the patch stays at 8.5 KB per wave; rows are 17 slots apart, which makes both the
-// frame-major writes and the bin-major reads bank-conflict free.  The patch is wave-private, so no
-// workgroup barrier is needed -- but the exchange is between lanes, which the per-thread memory
-// model does not order: every write and read phase is fenced explicitly (see below).  (Measured on
-// the covariance kernel, whose 2 waves per bin tile made the texture addresser the limiter:
-// 1.32 -> 1.10 ms.)
-constexpr int XPATCH = 2 * 16 * 17;  // c128 slots per wave
-
-__device__ __forceinline__ void xtile_load_transposed(XTile &xt, const c128 *__restrict__ Xb, int F,
-                                                      int T, int i0, int j0, int c, int q,
-                                                      c128 *patch) {
-  const int jf = min(j0 + c, T - 1);
-#pragma unroll
-  for (int m = 0; m < N; ++m)
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
-      xt.x[m][rr] = Xb[((long long)m * F + min(i0 + 4 * rr + q, F - 1)) * T + jf];
-#pragma unroll
-  for (int m0 = 0; m0 < N; m0 += 2) {
-    // The patch is reused by every pass and every tile, and the exchange is between LANES: nothing
-    // in the per-thread memory model orders this pass's writes after the previous pass's reads
-    // (measured: without the wait a barrier-free walk returned wrong tiles for N >= 3).  Drain the
-    // wave's outstanding LDS reads and pin the order for the compiler.
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-#pragma unroll
-    for (int mm = 0; mm < 2; ++mm)
-      if (m0 + mm < N) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) patch[(mm * 16 + 4 * rr + q) * 17 + c] = xt.x[m0 + mm][rr];
-      }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // the writes of all lanes have landed
-#pragma unroll
-    for (int mm = 0; mm < 2; ++mm)
-      if (m0 + mm < N) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xt.x[m0 + mm][r] = patch[(mm * 16 + c) * 17 + q + 4 * r];
-      }
-  }
-}
-
-// GEMM1 of the bin-major tile from the staged V: R[bin c, frame j0+q+4r] in register r
-// (D row q+4r reads slot tile_pi(q+4r) = 4q+r, which holds frame tile_pi(4q+r) = q+4r)
-// ksteps = ceil(K / 4): k-slabs beyond n_basis are zero on both sides and are skipped
-__device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const double (&tb)[4], int c,
-                                                 int q, int ksteps) {
-  double4_t R = {0.0, 0.0, 0.0, 0.0};
-  const int col = tile_pi(c);
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
-    if (ks < ksteps) R = mfma_f64(vs_n[(4 * ks + q) * VROW + col], tb[ks], R);
-  return R;
 }
 
 // =============================================================================== basis (pass 1)
@@ -271,15 +159,15 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
   const int jt_begin = work.chunk * tpc, jt_end = min(ntiles, jt_begin + tpc);
   VStage st;
   XTile cur;
-  vstage_load(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
-  vstage_store(st, vs[0]);
+  fast::vstage_load<N>(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
+  fast::vstage_store<N>(st, vs[0]);
   __syncthreads();
 
   for (int jt = jt_begin; jt < jt_end; ++jt) {
     const int j0 = jt * 16;
     const int jn = min(jt + 1, jt_end - 1) * 16;  // last iteration re-fetches its own tile
-    xtile_load_binmajor(cur, Xb, F, T, bin, j0, q);
-    vstage_load(st, act_b, K, T, jn);
+    fast::xtile_load_binmajor<N>(cur, Xb, F, T, bin, j0, q);
+    fast::vstage_load<N>(st, act_b, K, T, jn);
     const double *vcur = vs[(jt - jt_begin) & 1];
 #pragma unroll
     for (int n = 0; n < N; ++n) {
@@ -308,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
         den[n] = mfma_f64(bb, vb[r], den[n]);
       }
     }
-    vstage_store(st, vs[(jt - jt_begin + 1) & 1]);
+    fast::vstage_store<N>(st, vs[(jt - jt_begin + 1) & 1]);
     __syncthreads();
   }
   // D: col = basis index c, row = q + 4r -> bin i0 + q + 4r
@@ -401,15 +289,15 @@ __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X
   const int jt_begin = work.chunk * tpc, jt_end = min(ntiles, jt_begin + tpc);
   VStage st;
   XTile cur;
-  vstage_load(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
-  vstage_store(st, vs[0]);
+  fast::vstage_load<N>(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
+  fast::vstage_store<N>(st, vs[0]);
   __syncthreads();
   double acc = 0.0;
   for (int jt = jt_begin; jt < jt_end; ++jt) {
     const int j0 = jt * 16;
     const int jn = min(jt + 1, jt_end - 1) * 16;
-    xtile_load_binmajor(cur, Xb, F, T, bin, j0, q);
-    vstage_load(st, act_b, K, T, jn);
+    fast::xtile_load_binmajor<N>(cur, Xb, F, T, bin, j0, q);
+    fast::vstage_load<N>(st, act_b, K, T, jn);
     const double *vcur = vs[(jt - jt_begin) & 1];
 #pragma unroll
     for (int n = 0; n < N; ++n) {
@@ -443,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X
       acc += (MODEL == FM_GAUSS1 ? 2.0 : 1.0) * log(prod);  // (2 / p) log R
       if (MODEL == FM_T) acc = fma(1.0 + 0.5 * fm.nu, log(prod_t), acc);
     }
-    vstage_store(st, vs[(jt - jt_begin + 1) & 1]);
+    fast::vstage_store<N>(st, vs[(jt - jt_begin + 1) & 1]);
     __syncthreads();
   }
   acc = wave_sum(acc);
@@ -525,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
         const int kk = 4 * ks + q, n = min(s0 + s, N - 1);
         va[s][ks] = (kk < K && jv < T) ? act_b[((long long)n * K + kk) * T + jv] : 0.0;
       }
-    xtile_load_transposed(cur, Xb, F, T, i0, j0, c, q, xpatch[wave]);
+    fast::xtile_load_transposed<N>(cur, Xb, F, T, i0, j0, c, q, xpatch[wave]);
     double4_t R[SG];
 #pragma unroll
     for (int s = 0; s < SG; ++s) {
@@ -622,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void k_wcov_frame_fast(const c128 *__restri
   XTile cur;
   for (int jt = 0; jt < ntiles; ++jt) {
     const int j0 = jt * 16;
-    xtile_load_transposed(cur, Xb, F, T, i0, j0, c, q, xpatch[wave]);
+    fast::xtile_load_transposed<N>(cur, Xb, F, T, i0, j0, c, q, xpatch[wave]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int j = j0 + q + 4 * r;
