@@ -374,20 +374,21 @@ def main():
     # ---- the same batch with record_loss=True semantics (SURVEY 8d asks for both): the separator's
     # own loop, update_once() then the loss bookkeeping of IterativeMethodBase
     if extra:
-        nl = max(3, min(10, args.steps))
+        nl = max(3, args.steps)
         sep.record_loss, sep.loss = True, []
-        sep._after_step()
+        assert sep._iterate_with_deferred_loss(2, True)  # warm-up of the loss variants
+        sep.loss = []
         torch.cuda.synchronize()
         tl = time.perf_counter()
-        for _ in range(nl):
-            sep.update_once()
-            sep._after_step()
+        ok = sep._iterate_with_deferred_loss(nl, True)  # the loop __call__ runs with record_loss=True
         torch.cuda.synchronize()
         dtl = (time.perf_counter() - tl) / nl
+        assert ok and len(sep.loss) == nl + 1
         sep.record_loss, sep.loss = False, None
         out["with_record_loss"] = {
-            "workload": "same batch, update_once() + loss per iteration (record_loss=True), {} "
-                        "iterations".format(nl),
+            "workload": "same batch, the separator's record_loss=True loop ({} iterations + the "
+                        "initial and final loss): loss of iteration t as a by-product of the basis "
+                        "pass of iteration t+1, one dedicated loss pass at the end".format(nl),
             "ms_per_step": round(1e3 * dtl, 4), "iterations_per_s": round(B / dtl, 2),
             "frac": round(3 * pass_bytes / dtl / 1e9 / HBM_PEAK_GBS, 4),
         }

@@ -270,6 +270,24 @@ int ssspy_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis,
                            double floor_eps, void *workspace, size_t workspace_bytes, int *info,
                            void *stream);
 
+/* The same update_once(), which also leaves the negative log-likelihood of the state AT ENTRY:
+ * loss_data[b] (B doubles, zeroed by the call) = the data term ssspy_ilrma_loss_data would give,
+ * logdet[b] = ssspy_sum_logdet(W) before W is rewritten; loss = loss_data - 2 logdet.  The data term
+ * is a by-product of the basis pass (which forms |y|^2 and R under the same parameters), so a loop
+ * with record_loss=True costs three passes over X per iteration, not four: the loss after iteration t
+ * comes out of iteration t + 1, and only the last one needs ssspy_ilrma_loss_data.  Returns
+ * SSSPY_ERR_UNSUPPORTED (before touching any state) for shapes outside the tuned kernels
+ * (n_basis > 16, n_sources > 4, fractional domains), which have no such by-product.
+ * replaces: ssspy/bss/base.py:68-77 around ssspy/bss/ilrma.py:900-922 and :1946-1965. */
+/* 1 when ssspy_ilrma_ip1_update_deferred_loss has the by-product for this shape and model, else 0. */
+int ssspy_ilrma_deferred_loss_supported(int N, int T, int K, double domain, int source_model);
+int ssspy_ilrma_ip1_update_deferred_loss(const void *X, const void *C, void *W, double *basis,
+                                         double *activation, void *U, int B, int N, int F, int T,
+                                         int K, double domain, int source_model, double model_param,
+                                         int normalize, int floor_kind, double floor_eps,
+                                         void *workspace, size_t workspace_bytes, int *info,
+                                         double *loss_data, double *logdet, void *stream);
+
 /* IPA (iterative projection with adjustment), one source step: from the weighted covariances of
  * the current separated spectrogram, Vc (B,F,N,N,N) = ssspy_weighted_covariance(Y, weight), the
  * update matrix G (B,F,N,N) of source `source_idx`; the caller then applies ssspy_separate(Y, G)

@@ -300,6 +300,26 @@ def ilrma_ip1_update(X, C, W, basis, activation, U, domain, normalize, flooring,
     )
 
 
+def ilrma_deferred_loss_supported(N, T, K, domain, model=GAUSS):
+    return bool(_L().ssspy_ilrma_deferred_loss_supported(N, T, K, domain, model[0]))
+
+
+def ilrma_ip1_update_deferred_loss(X, C, W, basis, activation, U, domain, normalize, flooring, ws,
+                                   ws_bytes, info, loss_data, logdet, model=GAUSS):
+    """The fused update_once() that also leaves the loss of the state at entry (data term, log-dets);
+    returns False without touching the state when the shape has no such by-product."""
+    B, N, F, T = X.shape
+    K = basis.shape[-1]
+    rc = _L().ssspy_ilrma_ip1_update_deferred_loss(
+        ptr(X), ptr(C), ptr(W), ptr(basis), ptr(activation), ptr(U), B, N, F, T, K, domain, model[0],
+        model[1], int(bool(normalize)), flooring[0], flooring[1], ptr(ws), ws_bytes, ptr(info),
+        ptr(loss_data), ptr(logdet), _st())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return False
+    _lib.check(rc, "ilrma_ip1_update_deferred_loss")
+    return True
+
+
 def ilrma_partition_expand(basis, activation, latent, Teff, Vrep):
     B, N, F, K = Teff.shape
     T = Vrep.shape[-1]

@@ -276,7 +276,8 @@ class _MMILRMA(ILRMABase):
         """
         self._bind_input(input)
         self._reset(flooring_fn=self.flooring_fn, **kwargs)
-        IterativeMethodBase.__call__(self, n_iter=n_iter, initial_call=initial_call)
+        if not self._iterate_with_deferred_loss(int(n_iter), initial_call):
+            IterativeMethodBase.__call__(self, n_iter=n_iter, initial_call=initial_call)
         if self.scale_restoration:
             self.restore_scale()
         if self._uses_filter():
@@ -305,6 +306,59 @@ class _MMILRMA(ILRMABase):
         if self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"]:
             self.demix_filter = None
 
+    # -- the loop with the loss as a by-product ----------------------------------------------
+    def _fused_ip1(self) -> bool:
+        """True when update_once() is the single fused C-ABI call (stock methods, IP1 on filters)."""
+        return (self.spatial_algorithm in _IP1 and self._uses_filter() and self._is_stock()
+                and self._power_normalization_or_off() and not self.partitioning)
+
+    def _iterate_with_deferred_loss(self, n_iter: int, initial_call: bool) -> bool:
+        """``record_loss=True`` without a fourth pass over the mixture per iteration.
+
+        The loss after iteration t is the negative log-likelihood of the state the basis pass of
+        iteration t + 1 reads, and that pass forms |y|^2 and R anyway: the fused update leaves the
+        data term (and the log-determinants, taken before IP1 rewrites the filters) as by-products,
+        so only the loss after the LAST iteration needs the dedicated pass.  The list is assembled
+        at the end from one download -- which is why this path is taken only when nothing can look
+        at ``self.loss`` in between: no callbacks, and ``update_once`` / ``compute_loss`` not
+        overridden.  Otherwise (returns False) the reference's loop order runs unchanged.
+        ref: ssspy/bss/base.py:68-77, ssspy/bss/ilrma.py:1910-1967."""
+        cls = type(self)
+        if not (self.record_loss and not self.callbacks and n_iter > 0 and self._fused_ip1()
+                and cls.update_once is _MMILRMA.update_once
+                and cls.compute_loss is _MMILRMA.compute_loss):
+            return False
+        B, N, F, T = self._X.shape
+        dev = self._X.device
+        if not _ops.ilrma_deferred_loss_supported(N, T, self.n_basis, float(self.domain), self._model):
+            return False  # shapes / models outside the tuned kernels have no such by-product
+        if self._U is None:
+            self._U = dv.empty((B, F, N, N, N), dv.c128, dev)
+        data = dv.zeros((n_iter + 1, B), dv.f64, dev)
+        logdet = dv.zeros((n_iter + 1, B), dv.f64, dev)
+        C = self._C() if self.normalization else None
+        W, Tb, Vb = (self._state_dev(k) for k in ("demix_filter", "basis", "activation"))
+        args = (self._X, C, W, Tb, Vb, self._U, float(self.domain), bool(self.normalization),
+                self._floor, self._ws, self._ws_bytes, self._info_tensor())
+        for t in range(n_iter):
+            if t == 0 and not initial_call:
+                # the reference records nothing before the first iteration in this case
+                _ops.ilrma_ip1_update(*args, model=self._model)
+            elif not _ops.ilrma_ip1_update_deferred_loss(*args, data[t], logdet[t],
+                                                         model=self._model):
+                raise RuntimeError("deferred loss unavailable although reported as supported")
+        for name in ("demix_filter", "basis", "activation"):
+            self._state_touch(name)
+        _ops.ilrma_loss_data(self._X, W, Tb, Vb, float(self.domain), out=data[n_iter],
+                             model=self._model)
+        _ops.sum_logdet(W, out=logdet[n_iter])
+        self._check_device_errors()
+        values = dv.to_host(data) - 2.0 * dv.to_host(logdet)
+        if not initial_call:
+            values = values[1:]
+        self.loss.extend(v.copy() if self._batched else v[0].item() for v in values)
+        return True
+
     # -- one iteration -----------------------------------------------------------------------
     def _is_stock(self) -> bool:
         cls = type(self)
@@ -322,8 +376,7 @@ class _MMILRMA(ILRMABase):
         ref: ssspy/bss/ilrma.py:900-922.  With the stock methods and the IP1 path the whole
         iteration is one C-ABI call (five kernel launches on the current stream).
         """
-        if (self.spatial_algorithm in _IP1 and self._uses_filter() and self._is_stock()
-                and self._power_normalization_or_off() and not self.partitioning):
+        if self._fused_ip1():
             floor = self._resolve_floor(flooring_fn)
             B, N, F, T = self._X.shape
             if self._U is None:

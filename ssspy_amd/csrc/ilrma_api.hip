@@ -23,7 +23,8 @@ DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
 // throughput variants (ilrma_fast.hip): n_basis <= 16, n_sources <= 4, models of fast_model_id()
 #define DECL_FAST(n)                                                                           \
   int ilrma_fast_basis_n##n(const void *, const void *, double *, const double *, int, int, int, \
-                            int, int, double, double *, int, double, int, hipStream_t);        \
+                            int, int, double, double *, int, double, int, double *,            \
+                            hipStream_t);                                                      \
   int ilrma_fast_activation_n##n(const void *, const void *, const double *, const double *,   \
                                  double *, int, int, int, int, int, int, double, hipStream_t); \
   int ilrma_fast_wcov_n##n(const void *, const void *, const double *, const double *, void *, \
@@ -437,10 +438,15 @@ static IlrmaDims make_dims(int B, int F, int T, int K, double domain, int model,
                    floor_kind, floor_eps, 0};
 }
 
-int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const double *activation,
+// Basis update; with loss_out (B zeroed doubles) the tuned kernel also leaves the data term of the loss
+// of the state at entry there.  Returns 1 (not an error code of the ABI) when loss_out was requested
+// but the shape takes the generic kernels, which have no such by-product: the caller then makes the
+// dedicated loss pass.
+static int update_basis_impl(const void *X, const void *W, double *basis, const double *activation,
                              int B, int N, int F, int T, int K, double domain, int source_model,
                              double model_param, int floor_kind, double floor_eps, void *workspace,
-                             size_t workspace_bytes, void *stream) {
+                             size_t workspace_bytes, double *loss_out, bool *loss_done,
+                             void *stream) {
   SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0, "update_basis: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_basis: n_basis must be in [1, 64]");
   SSSPY_REQUIRE(domain > 0.0 && domain <= 2.0, "update_basis: domain must be in (0, 2]");
@@ -450,10 +456,12 @@ int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const 
   SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "update_basis: workspace too small");
   char *ws = (char *)workspace;
   hipStream_t st = as_stream(stream);
+  if (loss_done) *loss_done = false;
   if (fast_path(N, T, K, domain, source_model)) {
+    if (loss_done) *loss_done = loss_out != nullptr;
     ILRMA_FAST_DISPATCH(N, ilrma_fast_basis, X, W, basis, activation, B, F, T, K, floor_kind,
                         floor_eps, (double *)(ws + w.bpart), fast_model_id(domain, source_model),
-                        model_param, is_me(source_model), st);
+                        model_param, is_me(source_model), loss_out, st);
   }
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   double *out = K > 16 ? (double *)(ws + w.btmp) : basis;
@@ -466,6 +474,15 @@ int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const 
     if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
   }
   return SSSPY_OK;
+}
+
+int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const double *activation,
+                             int B, int N, int F, int T, int K, double domain, int source_model,
+                             double model_param, int floor_kind, double floor_eps, void *workspace,
+                             size_t workspace_bytes, void *stream) {
+  return update_basis_impl(X, W, basis, activation, B, N, F, T, K, domain, source_model, model_param,
+                           floor_kind, floor_eps, workspace, workspace_bytes, nullptr, nullptr,
+                           stream);
 }
 
 int ssspy_ilrma_update_activation(const void *X, const void *W, const double *basis,
@@ -604,21 +621,39 @@ int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
   ILRMA_DISPATCH(N, ilrma_loss, X, W, basis, activation, out, d, st);
 }
 
-int ssspy_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis, double *activation,
+static int ip1_update_impl(const void *X, const void *C, void *W, double *basis, double *activation,
                            void *U, int B, int N, int F, int T, int K, double domain,
                            int source_model, double model_param, int normalize, int floor_kind,
                            double floor_eps, void *workspace, size_t workspace_bytes, int *info,
-                           void *stream) {
+                           double *loss_data, double *logdet, void *stream) {
   SSSPY_REQUIRE(X && W && basis && activation && U, "ilrma_ip1_update: bad argument");
   SSSPY_REQUIRE(!normalize || C, "ilrma_ip1_update: normalisation needs C");
+  SSSPY_REQUIRE((loss_data == nullptr) == (logdet == nullptr),
+                "ilrma_ip1_update: loss_data and logdet go together");
   const IlrmaWs w = ilrma_ws(B, N, F, T, K);
   SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "ilrma_ip1_update: workspace too small");
   char *ws = (char *)workspace;
   hipStream_t st = as_stream(stream);
-  int rc = ssspy_ilrma_update_basis(X, W, basis, activation, B, N, F, T, K, domain, source_model,
-                                    model_param, floor_kind, floor_eps, workspace, workspace_bytes,
-                                    stream);
+  int rc;
+  if (loss_data) {
+    // (the Student-t data term is not linear in the pass's accumulators; no by-product there)
+    if (!ssspy_ilrma_deferred_loss_supported(N, T, K, domain, source_model))
+      return fail(SSSPY_ERR_UNSUPPORTED,
+                  "ilrma_ip1_update_deferred_loss: this shape takes the generic kernels, which have "
+                  "no loss by-product (use ssspy_ilrma_loss_data + ssspy_ilrma_ip1_update)");
+    // loss of the state at entry: log-determinants now (IP1 rewrites W below), data term as a
+    // by-product of the basis pass
+    rc = ssspy_sum_logdet(W, logdet, B, F, N, stream);
+    if (rc) return rc;
+    hipError_t e = hipMemsetAsync(loss_data, 0, (size_t)B * sizeof(double), st);
+    if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+  }
+  bool loss_done = false;
+  rc = update_basis_impl(X, W, basis, activation, B, N, F, T, K, domain, source_model, model_param,
+                         floor_kind, floor_eps, workspace, workspace_bytes, loss_data, &loss_done,
+                         stream);
   if (rc) return rc;
+  if (loss_data && !loss_done) return fail(SSSPY_ERR_UNSUPPORTED, "ilrma_ip1_update: no loss by-product");
   rc = ssspy_ilrma_update_activation(X, W, basis, activation, B, N, F, T, K, domain, source_model,
                                      model_param, floor_kind, floor_eps, workspace, workspace_bytes,
                                      stream);
@@ -631,6 +666,32 @@ int ssspy_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis,
                       floor_kind, floor_eps, info, st);
   if (rc || !normalize) return rc;
   return launch_norm_scale(W, basis, qbuf, B, N, F, K, domain, floor_kind, floor_eps, st);
+}
+
+int ssspy_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis, double *activation,
+                           void *U, int B, int N, int F, int T, int K, double domain,
+                           int source_model, double model_param, int normalize, int floor_kind,
+                           double floor_eps, void *workspace, size_t workspace_bytes, int *info,
+                           void *stream) {
+  return ip1_update_impl(X, C, W, basis, activation, U, B, N, F, T, K, domain, source_model,
+                         model_param, normalize, floor_kind, floor_eps, workspace, workspace_bytes,
+                         info, nullptr, nullptr, stream);
+}
+
+int ssspy_ilrma_deferred_loss_supported(int N, int T, int K, double domain, int source_model) {
+  return fast_path(N, T, K, domain, source_model) && fast_model_id(domain, source_model) != 1;
+}
+
+int ssspy_ilrma_ip1_update_deferred_loss(const void *X, const void *C, void *W, double *basis,
+                                         double *activation, void *U, int B, int N, int F, int T,
+                                         int K, double domain, int source_model, double model_param,
+                                         int normalize, int floor_kind, double floor_eps,
+                                         void *workspace, size_t workspace_bytes, int *info,
+                                         double *loss_data, double *logdet, void *stream) {
+  SSSPY_REQUIRE(loss_data && logdet, "ilrma_ip1_update_deferred_loss: bad argument");
+  return ip1_update_impl(X, C, W, basis, activation, U, B, N, F, T, K, domain, source_model,
+                         model_param, normalize, floor_kind, floor_eps, workspace, workspace_bytes,
+                         info, loss_data, logdet, stream);
 }
 
 int ssspy_ilrma_partition_expand(const double *basis, const double *activation,

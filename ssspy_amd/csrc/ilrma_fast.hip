@@ -79,6 +79,31 @@ __device__ __forceinline__ double ratio_pow(double ratio, double expo) {
   return pow(ratio, expo);
 }
 
+// sum of log(x_i) without a log per value: the running product of the mantissas (each in [0.5, 1))
+// and the integer sum of the exponents; the mantissa product is renormalised before it can
+// underflow (every 16 factors is ample: >= 2^-16), one log at the very end.  2 VALU instructions per
+// value instead of the ~40 of an fp64 log; the rounding of the product adds ~1e-16 per factor to a
+// sum of logs of magnitude >= 1.
+struct LogSum {
+  double mant;
+  int expo;
+  __device__ __forceinline__ void clear() {
+    mant = 1.0;
+    expo = 0;
+  }
+  __device__ __forceinline__ void mul(double x) {
+    mant *= __builtin_amdgcn_frexp_mant(x);
+    expo += __builtin_amdgcn_frexp_exp(x);
+  }
+  __device__ __forceinline__ void renorm() {
+    expo += __builtin_amdgcn_frexp_exp(mant);
+    mant = __builtin_amdgcn_frexp_mant(mant);
+  }
+  __device__ __forceinline__ double value() const {
+    return log(mant) + 0.6931471805599453094 * (double)expo;
+  }
+};
+
 // numerator factor a of the multiplicative updates (rinv = 1 / R)
 template <int MODEL>
 __device__ __forceinline__ double mm_num_factor(double pw, double R, double rinv,
@@ -112,13 +137,18 @@ __device__ __forceinline__ double mm_num_factor<FM_GAUSS1>(double pw, double, do
 // grid: 1-D, see TailPlan.  Unsplit blocks update their 64 bins in place; split blocks write
 // partial num/den to `part` ([tail item][chunk][n][64 bins][16][2]) for k_basis_finalize.
 // HAS_W = false: the ISS / IPA state passes the separated spectrogram itself (y = x_n, no filter)
-template <bool HAS_W, int MODEL>
+// LOSS: also accumulate the data term of the negative log-likelihood of the state the pass sees,
+// sum_{n,i} mean_j (|y|^2 / R + log R) (model variants as in k_loss_fast; not the t model, whose
+// term is not linear in the accumulators), into loss_out[b]: the pass already forms |y|^2 and R
+// under the current (W, T, V), so the loss of iteration t comes out of the basis pass of iteration
+// t + 1 instead of a fourth pass over X (ref: ssspy/bss/ilrma.py:1946-1965).
+template <bool HAS_W, int MODEL, bool LOSS>
 __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ X,
                                                        const c128 *__restrict__ W, double *basis,
                                                        const double *__restrict__ act, int F,
                                                        int T, int K, int floor_kind, double eps,
                                                        TailPlan plan, double *__restrict__ part,
-                                                       FastModel fm) {
+                                                       FastModel fm, double *__restrict__ loss_out) {
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
   constexpr int WSTRIDE = N * N + 1;  // 16-byte slots per bin: odd, so 16 bins never share a bank
   __shared__ __attribute__((aligned(16))) c128 wl[4][16 * WSTRIDE];
@@ -128,6 +158,10 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
   const int b = work.b, nchunks = work.nchunks;
   const int i0 = work.group * 64 + wave * 16;
   const int bin = min(i0 + c, F - 1);
+  const bool bin_valid = i0 + c < F;
+  double lacc = 0.0;
+  LogSum lr;  // log R of everything this lane visits
+  lr.clear();
   const c128 *Xb = X + (long long)b * N * F * T;
   const double *act_b = act + (long long)b * N * K * T;
 
@@ -194,12 +228,22 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
         const double aa = valid ? mm_num_factor<MODEL>(pw, R[r], rinv, fm) : 0.0;
         num[n] = mfma_f64(aa, vb[r], num[n]);
         den[n] = mfma_f64(bb, vb[r], den[n]);
+        if (LOSS) {
+          // log R of every element (and the t model's log(1 + (2/nu) P/R)): LogSum, no log here.
+          // The P/R part of the other models needs nothing per element: see the epilogue.
+          const bool lv = valid && bin_valid;
+          lr.mul(lv ? R[r] : 1.0);
+        }
       }
     }
+    if (LOSS) lr.renorm();
     fast::vstage_store<N>(st, vs[(jt - jt_begin + 1) & 1]);
     __syncthreads();
   }
   // D: col = basis index c, row = q + 4r -> bin i0 + q + 4r
+  // Loss by-product: sum_j a_nij R_nij = sum_k t_nik num_nik with the basis the pass started from, and
+  // a R is the model's data term up to a constant (Gauss P/R, domain 1 P/R^2, GGD (beta/2)(P/R)^(beta/2)):
+  // it falls out of the finished accumulators (the split items' share is added by k_basis_finalize).
 #pragma unroll
   for (int n = 0; n < N; ++n)
 #pragma unroll
@@ -208,8 +252,10 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
       if (ob < F && c < K) {
         if (nchunks == 1) {
           double *dst = basis + (((long long)b * N + n) * F + ob) * K + c;
+          const double told = *dst;
+          if (LOSS) lacc = fma(told, num[n][r], lacc);
           const double ratio = num[n][r] / den[n][r];
-          *dst = apply_floor(ratio_pow(ratio, fm.expo) * (*dst), floor_kind, eps);
+          *dst = apply_floor(ratio_pow(ratio, fm.expo) * told, floor_kind, eps);
         } else {
           const long long slot = (long long)work.tail_idx * nchunks + work.chunk;
           double *dst = part + (((slot * N + n) * 64 + (ob - work.group * 64)) * 16 + c) * 2;
@@ -218,37 +264,54 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
         }
       }
     }
+  if (LOSS) {
+    if (MODEL == FM_GGD) lacc *= 2.0 / fm.beta;
+    lacc += (MODEL == FM_GAUSS1 ? 2.0 : 1.0) * lr.value();  // (2 / p) log R
+    lacc = wave_sum(lacc);
+    if (lane == 0) atomicAdd(loss_out + b, lacc / (double)T);
+  }
 }
 
 // basis <- floor(basis * sqrt(sum_chunks num / sum_chunks den)) for the split (tail) items;
 // grid: (N*64*16/256, tail items); one thread per (n, local bin, k)
+// loss_out / loss_scale: the split items' share of the loss by-product sum_k t num (see k_basis_fast)
 __global__ __launch_bounds__(256) void k_basis_finalize(double *basis,
                                                         const double *__restrict__ part, int F,
                                                         int K, TailPlan plan, int floor_kind,
-                                                        double eps, double expo) {
+                                                        double eps, double expo,
+                                                        double *__restrict__ loss_out,
+                                                        double loss_scale) {
   const int tail_idx = blockIdx.y;
   const int item = plan.full + tail_idx;
   const int b = item / plan.groups, group = item - b * plan.groups;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (n, local bin, k16)
   const int k = e & 15, lb = (e >> 4) & 63, n = e >> 10;
   const int bin = group * 64 + lb;
-  if (n >= N || k >= K || bin >= F) return;
-  double sn = 0.0, sd = 0.0;
-  for (int ch = 0; ch < plan.split; ++ch) {
-    const double *src = part + ((((long long)tail_idx * plan.split + ch) * N + n) * 1024 + (e & 1023)) * 2;
-    sn += src[0];
-    sd += src[1];
+  double contrib = 0.0;
+  if (n < N && k < K && bin < F) {
+    double sn = 0.0, sd = 0.0;
+    for (int ch = 0; ch < plan.split; ++ch) {
+      const double *src =
+          part + ((((long long)tail_idx * plan.split + ch) * N + n) * 1024 + (e & 1023)) * 2;
+      sn += src[0];
+      sd += src[1];
+    }
+    double *dst = basis + (((long long)b * N + n) * F + bin) * K + k;
+    const double told = *dst;
+    contrib = told * sn;
+    const double ratio = sn / sd;
+    *dst = apply_floor(ratio_pow(ratio, expo) * told, floor_kind, eps);
   }
-  double *dst = basis + (((long long)b * N + n) * F + bin) * K + k;
-  const double ratio = sn / sd;
-  *dst = apply_floor(ratio_pow(ratio, expo) * (*dst), floor_kind, eps);
+  if (loss_out) {  // uniform per launch
+    contrib = wave_sum(contrib);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss_out + b, contrib * loss_scale);
+  }
 }
 
 // ================================================================================ loss data
 // out[b] += sum_{n,i} mean_j ( |y|^2 / R + log R ), the data term of compute_loss().  Same walk as
-// the basis pass without its second GEMM; the logarithms are taken on the product of the four R
-// values a lane holds per source and tile (R >= floor^2 * K, so four of them stay far inside the
-// fp64 range), which cuts the dominant cost, the fp64 log, by four.
+// the basis pass without its second GEMM; the logarithms are summed as a mantissa product and an
+// exponent sum (LogSum): no fp64 log in the walk at all.
 // HAS_W = false: the ISS / IPA state passes the separated spectrogram itself (y = x_n, no filter)
 template <bool HAS_W, int MODEL>
 __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X,
@@ -293,6 +356,9 @@ __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X
   fast::vstage_store<N>(st, vs[0]);
   __syncthreads();
   double acc = 0.0;
+  LogSum lr, lt;
+  lr.clear();
+  lt.clear();
   for (int jt = jt_begin; jt < jt_end; ++jt) {
     const int j0 = jt * 16;
     const int jn = min(jt + 1, jt_end - 1) * 16;
@@ -305,7 +371,6 @@ __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X
       c128 wr[N];
 #pragma unroll
       for (int m = 0; m < N; ++m) wr[m] = wmine[n * N + m];
-      double prod = 1.0, prod_t = 1.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         c128 y = cur.x[n][r];
@@ -319,21 +384,23 @@ __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X
         const double ri = rcp_nr(rr);
         const double pr = (valid ? cabs2(y) : 0.0) * ri;
         if (MODEL == FM_T)
-          prod_t *= fma(2.0 / fm.nu, pr, 1.0);  // (1 + nu/2) log(1 + (2/nu) P / R), ilrma.py:3301-3305
+          lt.mul(fma(2.0 / fm.nu, pr, 1.0));  // (1 + nu/2) log(1 + (2/nu) P / R), ilrma.py:3301-3305
         else if (MODEL == FM_GGD)
           acc += pow_nonneg(pr, 0.5 * fm.beta);  // (P / R)^(beta/2), ilrma.py:4377-4381
         else if (MODEL == FM_GAUSS1)
           acc += pr * ri;                        // P / R^2
         else
           acc += pr;
-        prod *= rr;
+        lr.mul(rr);
       }
-      acc += (MODEL == FM_GAUSS1 ? 2.0 : 1.0) * log(prod);  // (2 / p) log R
-      if (MODEL == FM_T) acc = fma(1.0 + 0.5 * fm.nu, log(prod_t), acc);
     }
+    lr.renorm();
+    if (MODEL == FM_T) lt.renorm();
     fast::vstage_store<N>(st, vs[(jt - jt_begin + 1) & 1]);
     __syncthreads();
   }
+  acc += (MODEL == FM_GAUSS1 ? 2.0 : 1.0) * lr.value();  // (2 / p) log R
+  if (MODEL == FM_T) acc = fma(1.0 + 0.5 * fm.nu, lt.value(), acc);
   acc = wave_sum(acc);
   if (lane == 0) atomicAdd(out + b, acc / (double)T);
 }
@@ -769,18 +836,46 @@ static inline FastModel make_fast_model(int fmodel, double mparam, int me, int f
   } while (0)
 
 // `part` must hold the scratch of ilrma_api.hip's basis_part_bytes() (used only when items are split)
+// loss_out: nullptr, or B zeroed doubles that receive the data term of the loss of the state at entry
 int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, double *basis, const double *act,
                                int B, int F, int T, int K, int floor_kind, double eps,
-                               double *part, int fmodel, double mparam, int me, hipStream_t st) {
+                               double *part, int fmodel, double mparam, int me, double *loss_out,
+                               hipStream_t st) {
   const TailPlan plan = make_tail_plan(B, (F + 63) / 64, (T + 15) / 16);
   const FastModel fm = make_fast_model(fmodel, mparam, me);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
-  SSSPY_FAST_LAUNCH2(k_basis_fast, W != nullptr, (const c128 *)X, (const c128 *)W,
-                     basis, act, F, T, K, floor_kind, eps, plan, part, fm);
+#define SSSPY_BASIS_LAUNCH(HW, M, L)                                                              \
+  hipLaunchKernelGGL((k_basis_fast<HW, M, L>), grid, block, 0, st, (const c128 *)X,               \
+                     (const c128 *)W, basis, act, F, T, K, floor_kind, eps, plan, part, fm, loss_out)
+#define SSSPY_BASIS_LAUNCH_M(HW, L)                   \
+  switch (fmodel) {                                   \
+    case FM_T: SSSPY_BASIS_LAUNCH(HW, FM_T, false); break; /* no by-product for the t model */ \
+    case FM_GGD: SSSPY_BASIS_LAUNCH(HW, FM_GGD, L); break; \
+    case FM_GAUSS1: SSSPY_BASIS_LAUNCH(HW, FM_GAUSS1, L); break; \
+    default: SSSPY_BASIS_LAUNCH(HW, FM_GAUSS, L); break; \
+  }
+  if (W != nullptr) {
+    if (loss_out) {
+      SSSPY_BASIS_LAUNCH_M(true, true)
+    } else {
+      SSSPY_BASIS_LAUNCH_M(true, false)
+    }
+  } else {
+    if (loss_out) {
+      SSSPY_BASIS_LAUNCH_M(false, true)
+    } else {
+      SSSPY_BASIS_LAUNCH_M(false, false)
+    }
+  }
+#undef SSSPY_BASIS_LAUNCH_M
+#undef SSSPY_BASIS_LAUNCH
   int rc = check_launch("k_basis_fast");
   if (rc || plan.tail == 0) return rc;
+  // split items' share of the loss by-product (never requested for the t model)
+  const double loss_scale = (fmodel == FM_GGD ? 2.0 / fm.beta : 1.0) / (double)T;
   hipLaunchKernelGGL(k_basis_finalize, dim3(N * 64 * 16 / 256, plan.tail), block, 0, st, basis,
-                     part, F, K, plan, floor_kind, eps, fm.expo);
+                     part, F, K, plan, floor_kind, eps, fm.expo,
+                     fmodel != FM_T ? loss_out : (double *)nullptr, loss_scale);
   return check_launch("k_basis_finalize");
 }
 
