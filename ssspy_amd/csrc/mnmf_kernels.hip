@@ -536,15 +536,23 @@ template <int M>
 struct XTileM {
   c128 x[M][4];
 };
+// Through a buffer descriptor of the mixture's tensor: one 32-bit lane offset per tile, channel
+// stride in the scalar offset, the four frames in the immediate (flat loads cost ~5 VALU
+// instructions of 64-bit address arithmetic each, 80 per tile, in kernels that are issue-bound).
+// Frames beyond T are not clamped: they read the next row (finite data, zeros past the end of the
+// tensor) and every consumer masks them with `valid`.  Needs M * F * T * 16 < 2^32.
 template <int M>
-__device__ __forceinline__ void xtile_load(XTileM<M> &xt, const c128 *__restrict__ Xb, int F, int T,
+__device__ __forceinline__ void xtile_load(XTileM<M> &xt, __amdgpu_buffer_rsrc_t xr, int F, int T,
                                            int bin, int j0, int q) {
-  const int j = j0 + 4 * q;
+  const unsigned voff = ((unsigned)bin * (unsigned)T + (unsigned)(j0 + 4 * q)) * 16u;
 #pragma unroll
   for (int m = 0; m < M; ++m) {
-    const c128 *row = Xb + ((long long)m * F + bin) * T;
+    const unsigned soff = (unsigned)m * (unsigned)F * (unsigned)T * 16u;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xt.x[m][r] = row[min(j + r, T - 1)];
+    for (int r = 0; r < 4; ++r) {
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xr, voff + 16u * r, soff, 0);
+      xt.x[m][r] = cmake(__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2]));
+    }
   }
 }
 
@@ -579,7 +587,8 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
   const int i0 = work.group * 64 + wave * 16;
   const int bin = min(i0 + c, F - 1);
   const int ksteps = (K + 3) >> 2;
-  const c128 *Xb = X + (long long)b * M * F * T;
+  const __amdgpu_buffer_rsrc_t xr =
+      make_rsrc(X + (long long)b * M * F * T, (unsigned)M * (unsigned)F * (unsigned)T * 16u);
   const double *act_b = act + (long long)b * N * K * T;
   c128 Qb[M][M];
   double Db[N][M];
@@ -625,14 +634,16 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
   VStage st;
   XTileM<M> cur, nxt;
   vstage_load(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
-  xtile_load<M>(cur, Xb, F, T, bin, min(jt_begin, ntiles - 1) * 16, q);
+  xtile_load<M>(cur, xr, F, T, bin, min(jt_begin, ntiles - 1) * 16, q);
   vstage_store(st, vs[0]);
   __syncthreads();
-  for (int jt = jt_begin; jt < jt_end; ++jt) {
+  // one tile of the walk: compute on `xc`, prefetch the next tile into `xn`.  The walk calls it with
+  // the two register sets swapping roles (no 64-register copy per tile).
+  auto tile = [&](const XTileM<M> &xc, XTileM<M> &xn, const int jt) __attribute__((always_inline)) {
     const int j0 = jt * 16;
     const int jn = min(jt + 1, jt_end - 1) * 16;
     vstage_load(st, act_b, K, T, jn);
-    xtile_load<M>(nxt, Xb, F, T, bin, jn, q);
+    xtile_load<M>(xn, xr, F, T, bin, jn, q);
     const double *vcur = vs[(jt - jt_begin) & 1];
     double4_t lamR[N];
 #pragma unroll
@@ -643,7 +654,7 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
       const bool valid = j0 + 4 * q + r < T;
       c128 x[M];
 #pragma unroll
-      for (int m = 0; m < M; ++m) x[m] = cur.x[m][r];
+      for (int m = 0; m < M; ++m) x[m] = xc.x[m][r];
       double lam[N], qx2[M], rc[M];
 #pragma unroll
       for (int n = 0; n < N; ++n) lam[n] = lamR[n][r];
@@ -704,7 +715,10 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
     }
     vstage_store(st, vs[(jt - jt_begin + 1) & 1]);
     __syncthreads();
-    cur = nxt;
+  };
+  for (int jt = jt_begin; jt < jt_end; jt += 2) {
+    tile(cur, nxt, jt);
+    if (jt + 1 < jt_end) tile(nxt, cur, jt + 1);
   }
   const long long slot = (long long)work.tail_idx * nchunks + work.chunk;
   double *tp = tailpart + slot * mnmf_tail_doubles<M>();
@@ -914,7 +928,8 @@ __global__ __launch_bounds__(256) void k_mnmf_activation_fast(const c128 *__rest
   const int jf = j0 + c;
   const bool fvalid = jf < T;
   const int jc = fvalid ? jf : T - 1;
-  const c128 *Xb = X + (long long)b * M * F * T;
+  const __amdgpu_buffer_rsrc_t xsrc =
+      make_rsrc(X + (long long)b * M * F * T, (unsigned)M * (unsigned)F * (unsigned)T * 16u);
   const double *basis_b = basis + (long long)b * N * F * K;
   const c128 *Q_b = Q + (long long)b * F * M * M;
   const double *D_b = Dsp + (long long)b * F * N * M;
@@ -943,12 +958,18 @@ __global__ __launch_bounds__(256) void k_mnmf_activation_fast(const c128 *__rest
   for (int it = t_begin; it < t_end; ++it) {
     const int i0 = it * 16;
     const int in = min(it + 1, t_end - 1) * 16;
+    // x through the mixture's buffer descriptor: one lane offset per tile, (channel, bin row) in the
+    // scalar offset.  Bins beyond F read the next channel's rows (zeros past the tensor) and are masked.
     c128 x[M][4];
+    const unsigned voff = ((unsigned)(i0 + q) * (unsigned)T + (unsigned)jc) * 16u;
 #pragma unroll
     for (int m = 0; m < M; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        x[m][r] = Xb[((long long)m * F + min(i0 + q + 4 * r, F - 1)) * T + jc];
+      for (int r = 0; r < 4; ++r) {
+        const unsigned soff = ((unsigned)m * (unsigned)F + 4u * r) * (unsigned)T * 16u;
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xsrc, voff, soff, 0);
+        x[m][r] = cmake(__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2]));
+      }
     tstage_load<M>(st, basis_b, Q_b, D_b, F, K, in);
     const int pb = (it - t_begin) & 1;
     const double *tcur = ts[pb];
@@ -961,6 +982,7 @@ __global__ __launch_bounds__(256) void k_mnmf_activation_fast(const c128 *__rest
         if (ks < ksteps) R = mfma_f64(tcur[(n * 16 + c) * TROW + 4 * ks + q], vb[n][ks], R);
       lamR[n] = R;
     }
+    double a[N][4], bq[N][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int bl = q + 4 * r;
@@ -981,7 +1003,6 @@ __global__ __launch_bounds__(256) void k_mnmf_activation_fast(const c128 *__rest
         g[m] = rcp_nr(rc[m]);
         h[m] = qx2[m] * g[m] * g[m];
       }
-      // GEMM2 issued frame row by frame row (the (a, b) factors of a whole tile would cost 64 VGPRs)
 #pragma unroll
       for (int n = 0; n < N; ++n) {
         double sa = 0.0, sb = 0.0;
@@ -990,11 +1011,18 @@ __global__ __launch_bounds__(256) void k_mnmf_activation_fast(const c128 *__rest
           sa = fma(Db[n][m], h[m], sa);
           sb = fma(Db[n][m], g[m], sb);
         }
-        const double ta = tcur[(n * 16 + bl) * TROW + c];
-        numv[n] = mfma_f64(ta, valid ? sa : 0.0, numv[n]);
-        denv[n] = mfma_f64(ta, valid ? sb : 0.0, denv[n]);
+        a[n][r] = valid ? sa : 0.0;
+        bq[n][r] = valid ? sb : 0.0;
       }
     }
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double ta = tcur[(n * 16 + q + 4 * r) * TROW + c];
+        numv[n] = mfma_f64(ta, a[n][r], numv[n]);
+        denv[n] = mfma_f64(ta, bq[n][r], denv[n]);
+      }
     tstage_store<M>(st, ts[pb ^ 1], ql[pb ^ 1], dl[pb ^ 1]);
     __syncthreads();
   }
@@ -1243,7 +1271,8 @@ constexpr int cov_lds_mm() {
 // workgroups unsplit, the remainder (or a small batch) split along the frames.
 static inline bool mnmf_fast_ok(int B, int F, int T, int K) {
   static const bool disabled = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;
-  return !disabled && K <= 16;
+  // one mixture must fit a 32-bit buffer descriptor (up to 4 channels of complex128)
+  return !disabled && K <= 16 && (long long)4 * F * T * 16 < (1ll << 32);
 }
 static inline TailPlan mnmf_plan(int B, int F, int T) {
   // these kernels hold one workgroup per CU (x prefetch in registers, > 256 VGPR + AGPR)
@@ -1288,8 +1317,7 @@ int LAUNCHER(mnmf_activation)(const void *X, const void *Q, const double *Dsp, c
   const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
   const int ktiles = kt_count(K);
   dim3 grid((T + 63) / 64, nchunks, B * ktiles), block(256);
-  static const bool no_fast = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;
-  if (!no_fast && K <= 16) {
+  if (mnmf_fast_ok(B, F, T, K)) {
     MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_activation_fast<MM>), grid, block, 0, st,
                                           (const c128 *)X, (const c128 *)Q, Dsp, basis, act, part, F,
                                           T, K, tiles_per_chunk, nchunks));
