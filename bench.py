@@ -55,6 +55,8 @@ def parse_args():
                     help="only the headline (skip the loss / AuxIVA / other-config legs)")
     ap.add_argument("--other-batch", type=int, default=32,
                     help="mixtures in the batched configs[2] / configs[3] legs")
+    ap.add_argument("--mnmf-batch", type=int, default=128,
+                    help="mixtures in the second batched configs[3] leg (the headline's shard size)")
     return ap.parse_args()
 
 
@@ -210,10 +212,14 @@ def other_configs(args, dev, x0_host, pins, cpu_configs1):
 
     # ---- configs[3]: FastGaussMNMF-IP1, N=M=4, F=1025, T=512, n_basis=8 (4 passes)
     M, F, T, K = 4, 1025, 512, 8
-    Xh = nmf_mixture_batch(4000, Bo, M, F, T)
+    Bm = max(Bo, args.mnmf_batch)
+    Xh = nmf_mixture_batch(4000, Bm, M, F, T)
     sha_ok = sha256_of(Xh[0]) == pins["configs3_seed4000_N4_F1025_T512"]["sha256"]
     ent = {"input_sha256_ok": sha_ok}
-    for tag, nb, iters in (("single", 1, 100), ("batch", Bo, 20)):
+    legs = [("single", 1, 100), ("batch", Bo, 20)]
+    if Bm > Bo:
+        legs.append(("batch{}".format(Bm), Bm, 10))
+    for tag, nb, iters in legs:
         m = FastGaussMNMF(n_basis=K, record_loss=False, rng=np.random.default_rng(0))
         m._bind_input(torch.from_numpy(Xh[:nb]).to(dev))
         m._reset()

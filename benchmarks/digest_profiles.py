@@ -15,7 +15,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 
@@ -75,6 +75,7 @@ for k, label in KERNELS.items():
                     "tallies 128-B requests as 64 B)".format(B),
         }
 if traffic:
+    traffic["_round"] = tag
     json.dump(traffic, open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
 oc = os.path.join(src, "other_configs.txt")
 if os.path.exists(oc):

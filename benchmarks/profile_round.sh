@@ -6,7 +6,7 @@
 # traffic of the three pass kernels), other_configs.txt.  benchmarks/digest_profiles.py turns these
 # into the tracked files under profiles/.
 set -u
-tag=${1:-r01}
+tag=${1:-r02}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/$tag
 mkdir -p $out
