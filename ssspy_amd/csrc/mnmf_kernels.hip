@@ -1153,6 +1153,7 @@ __global__ __launch_bounds__(64) void k_mnmf_qinv(const c128 *__restrict__ Q, c1
 // s = Q~^H R^-1 x, R = to_psd(sum_m R~_m q~_m q~_m^H) (eigenvalues floored).
 template <int M>
 __global__ __launch_bounds__(256) void k_mnmf_separate(const c128 *__restrict__ X,
+                                                       const c128 *__restrict__ Q,
                                                        const c128 *__restrict__ Qinv,
                                                        const double *__restrict__ Dsp,
                                                        const double *__restrict__ basis,
@@ -1162,10 +1163,21 @@ __global__ __launch_bounds__(256) void k_mnmf_separate(const c128 *__restrict__ 
   const int i = blockIdx.x, b = blockIdx.y;
   const int F = d.F, T = d.T, K = d.K;
   __shared__ c128 qt[M * M];
+  __shared__ c128 qsrc[M * M];
   __shared__ double dd[N * M];
-  if (threadIdx.x < M * M) qt[threadIdx.x] = Qinv[((long long)b * F + i) * (M * M) + threadIdx.x];
+  if (threadIdx.x < M * M) {
+    qt[threadIdx.x] = Qinv[((long long)b * F + i) * (M * M) + threadIdx.x];
+    qsrc[threadIdx.x] = Q[((long long)b * F + i) * (M * M) + threadIdx.x];
+  }
   if (threadIdx.x < N * M) dd[threadIdx.x] = Dsp[((long long)b * F + i) * (N * M) + threadIdx.x];
   __syncthreads();
+  // ||Q||_F^2 of the bin: R = Q~ diag(rc) Q~^H with Q~ = Q^-1 has lambda_min(R) >= min_m rc_m / ||Q||_2^2
+  // >= min_m rc_m / ||Q||_F^2, so when that bound clears the eigenvalue floor, to_psd leaves R
+  // untouched and R^-1 = Q^H diag(1 / rc) Q in closed form -- no eigen-decomposition
+  // (add-flooring shifts every eigenvalue and always takes the general path).
+  double qf2 = 0.0;
+#pragma unroll
+  for (int e = 0; e < M * M; ++e) qf2 += cabs2(qsrc[e]);
   for (int j = threadIdx.x; j < T; j += blockDim.x) {
     double lam[N];
 #pragma unroll
@@ -1177,12 +1189,41 @@ __global__ __launch_bounds__(256) void k_mnmf_separate(const c128 *__restrict__ 
       lam[n] = r;
     }
     double rc[M];
+    double rcmin = 0.0;
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       double r = 0.0;
 #pragma unroll
       for (int n = 0; n < N; ++n) r = fma(lam[n], dd[n * M + m], r);
       rc[m] = r;
+      rcmin = m == 0 ? r : (r < rcmin ? r : rcmin);
+    }
+    c128 x[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] = X[(((long long)b * M + m) * F + i) * T + j];
+    if (floor_kind != SSSPY_FLOOR_ADD && rcmin > eps * qf2 * 1.0000001) {
+      // s_m = (Q x)_m / rc_m ;  Y_n = sum_m lam_n d_nm q~[ref][m] s_m
+      c128 sm[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        c128 y = cmake(0.0, 0.0);
+#pragma unroll
+        for (int a = 0; a < M; ++a) cfma(y, qsrc[m * M + a], x[a]);
+        const double g = 1.0 / rc[m];
+        sm[m] = cmul(qt[ref * M + m], cmake(y.x * g, y.y * g));
+      }
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        c128 y = cmake(0.0, 0.0);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const double wgt = lam[n] * dd[n * M + m];
+          y.x = fma(wgt, sm[m].x, y.x);
+          y.y = fma(wgt, sm[m].y, y.y);
+        }
+        Y[(((long long)b * N + n) * F + i) * T + j] = y;
+      }
+      continue;
     }
     // R = sum_m rc[m] q~_m q~_m^H  (q~_m = column m of Q^-1), Hermitian by construction
     c128 A[M][M], P[M][M];
@@ -1202,9 +1243,6 @@ __global__ __launch_bounds__(256) void k_mnmf_separate(const c128 *__restrict__ 
         A[c2][a] = cconj(s);
       }
     jacobi_eigh<M>(A, P);
-    c128 x[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) x[m] = X[(((long long)b * M + m) * F + i) * T + j];
     // z = P diag(1/floor(lam)) P^H x
     c128 z[M];
 #pragma unroll
@@ -1430,7 +1468,8 @@ int LAUNCHER(mnmf_separate)(const void *X, const void *Q, void *Qinv, const doub
     hipLaunchKernelGGL((k_mnmf_qinv<MM>), dim3((unsigned)((nbins + 63) / 64)), dim3(64), 0, st,
                        (const c128 *)Q, (c128 *)Qinv, nbins, info);
     hipLaunchKernelGGL((k_mnmf_separate<MM>), dim3(F, B), dim3(256), 0, st, (const c128 *)X,
-                       (const c128 *)Qinv, Dsp, basis, act, (c128 *)Y, d, ref, floor_kind, eps);
+                       (const c128 *)Q, (const c128 *)Qinv, Dsp, basis, act, (c128 *)Y, d, ref,
+                       floor_kind, eps);
   });
   return check_launch("k_mnmf_separate");
 }
