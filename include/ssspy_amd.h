@@ -280,7 +280,8 @@ int ssspy_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis,
  * (n_basis > 16, n_sources > 4, fractional domains), which have no such by-product.
  * replaces: ssspy/bss/base.py:68-77 around ssspy/bss/ilrma.py:900-922 and :1946-1965. */
 /* 1 when ssspy_ilrma_ip1_update_deferred_loss has the by-product for this shape and model, else 0. */
-int ssspy_ilrma_deferred_loss_supported(int N, int T, int K, double domain, int source_model);
+int ssspy_ilrma_deferred_loss_supported(int N, int F, int T, int K, double domain,
+                                        int source_model);
 int ssspy_ilrma_ip1_update_deferred_loss(const void *X, const void *C, void *W, double *basis,
                                          double *activation, void *U, int B, int N, int F, int T,
                                          int K, double domain, int source_model, double model_param,

@@ -63,7 +63,7 @@ PROTOTYPES = {
     "ssspy_ilrma_loss_data": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p]),
     "ssspy_ilrma_ip1_update": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _i, _i, _d,
                                     _p, _z, _p, _p]),
-    "ssspy_ilrma_deferred_loss_supported": (_i, [_i, _i, _i, _d, _i]),
+    "ssspy_ilrma_deferred_loss_supported": (_i, [_i, _i, _i, _i, _d, _i]),
     "ssspy_ilrma_ip1_update_deferred_loss": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i,
                                                   _d, _i, _i, _d, _p, _z, _p, _p, _p, _p]),
     "ssspy_ilrma_partition_expand": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

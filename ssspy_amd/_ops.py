@@ -300,8 +300,8 @@ def ilrma_ip1_update(X, C, W, basis, activation, U, domain, normalize, flooring,
     )
 
 
-def ilrma_deferred_loss_supported(N, T, K, domain, model=GAUSS):
-    return bool(_L().ssspy_ilrma_deferred_loss_supported(N, T, K, domain, model[0]))
+def ilrma_deferred_loss_supported(N, F, T, K, domain, model=GAUSS):
+    return bool(_L().ssspy_ilrma_deferred_loss_supported(N, F, T, K, domain, model[0]))
 
 
 def ilrma_ip1_update_deferred_loss(X, C, W, basis, activation, U, domain, normalize, flooring, ws,

@@ -330,7 +330,7 @@ class _MMILRMA(ILRMABase):
             return False
         B, N, F, T = self._X.shape
         dev = self._X.device
-        if not _ops.ilrma_deferred_loss_supported(N, T, self.n_basis, float(self.domain), self._model):
+        if not _ops.ilrma_deferred_loss_supported(N, F, T, self.n_basis, float(self.domain), self._model):
             return False  # shapes / models outside the tuned kernels have no such by-product
         if self._U is None:
             self._U = dv.empty((B, F, N, N, N), dv.c128, dev)

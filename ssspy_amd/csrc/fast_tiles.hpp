@@ -79,24 +79,54 @@ __device__ __forceinline__ void xtile_load_binmajor(XTile<NC> &xt, const c128 *_
   }
 }
 
-// The same loads through a buffer descriptor of the mixture's tensor (base in SGPRs): the per-lane
-// address state is ONE 32-bit offset per tile -- channel stride in the scalar offset, the four
-// frames in the instruction's immediate -- where the flat form keeps a 64-bit address per load.
-// Frames beyond T are not clamped: they read the next row (finite data; zeros past the end of the
-// tensor) and the caller masks them.  Needs NC * F * T * 16 < 2^32.
+// ---- the same tiles through buffer descriptors (one per channel row block, base in SGPRs): the
+// per-lane address state is ONE 32-bit offset per tile -- the four frames (or bin rows) of a lane go
+// into the instruction's immediate or a scalar offset -- where the flat form costs ~5 VALU
+// instructions of 64-bit address arithmetic per load (80 per tile in kernels that are issue-bound).
+// Out-of-range frames / bins are not clamped: they read a neighbouring row of the same channel
+// (finite data) or, past the end of the channel, the zeros the bounds check returns; every consumer
+// masks them.  Needs F * T * 16 < 2^32 per channel (the launchers check).
 template <int NC>
-__device__ __forceinline__ void xtile_load_binmajor_buf(XTile<NC> &xt, __amdgpu_buffer_rsrc_t xr,
-                                                        int F, int T, int bin, int j0, int q) {
+struct XSrc {
+  __amdgpu_buffer_rsrc_t ch[NC];
+};
+
+template <int NC>
+__device__ __forceinline__ XSrc<NC> make_xsrc(const c128 *Xb, int F, int T) {
+  XSrc<NC> s;
+#pragma unroll
+  for (int m = 0; m < NC; ++m)
+    s.ch[m] = make_rsrc(Xb + (long long)m * F * T, (unsigned)F * (unsigned)T * 16u);
+  return s;
+}
+
+__device__ __forceinline__ c128 c128_from(u32x4_t v) {
+  return cmake(__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2]));
+}
+
+// bin-major: frames j0 + q + 4r of bin `bin`
+template <int NC>
+__device__ __forceinline__ void xtile_load_binmajor(XTile<NC> &xt, const XSrc<NC> &src, int T,
+                                                    int bin, int j0, int q) {
   const unsigned voff = ((unsigned)bin * (unsigned)T + (unsigned)(j0 + q)) * 16u;
 #pragma unroll
-  for (int m = 0; m < NC; ++m) {
-    const unsigned soff = (unsigned)m * (unsigned)F * (unsigned)T * 16u;
+  for (int m = 0; m < NC; ++m)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xr, voff + 64u * r, soff, 0);
-      xt.x[m][r] = cmake(__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2]));
-    }
-  }
+    for (int r = 0; r < 4; ++r)
+      xt.x[m][r] = c128_from(__builtin_amdgcn_raw_buffer_load_b128(src.ch[m], voff + 64u * r, 0, 0));
+}
+
+// frame-major: frame jc of bins i0 + q + 4r
+template <int NC>
+__device__ __forceinline__ void xtile_load_framemajor(XTile<NC> &xt, const XSrc<NC> &src, int T,
+                                                      int i0, int jc, int q) {
+  const unsigned voff = ((unsigned)(i0 + q) * (unsigned)T + (unsigned)jc) * 16u;
+#pragma unroll
+  for (int m = 0; m < NC; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      xt.x[m][r] = c128_from(
+          __builtin_amdgcn_raw_buffer_load_b128(src.ch[m], voff, 4u * r * (unsigned)T * 16u, 0));
 }
 
 // The same tile, fetched with coalesced addresses and transposed through a wave-private LDS
@@ -111,6 +141,9 @@ __device__ __forceinline__ void xtile_load_binmajor_buf(XTile<NC> &xt, __amdgpu_
 constexpr int XPATCH = 2 * 16 * 17;  // c128 slots per wave
 
 template <int NC>
+__device__ __forceinline__ void xtile_transpose(XTile<NC> &xt, int c, int q, c128 *patch);
+
+template <int NC>
 __device__ __forceinline__ void xtile_load_transposed(XTile<NC> &xt, const c128 *__restrict__ Xb,
                                                       int F, int T, int i0, int j0, int c, int q,
                                                       c128 *patch) {
@@ -120,6 +153,26 @@ __device__ __forceinline__ void xtile_load_transposed(XTile<NC> &xt, const c128 
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
       xt.x[m][rr] = Xb[((long long)m * F + min(i0 + 4 * rr + q, F - 1)) * T + jf];
+  xtile_transpose<NC>(xt, c, q, patch);
+}
+
+// buffer-descriptor form of the coalesced fetch (frame j0 + c of bins i0 + q + 4 rr)
+template <int NC>
+__device__ __forceinline__ void xtile_load_transposed(XTile<NC> &xt, const XSrc<NC> &src, int T,
+                                                      int i0, int j0, int c, int q, c128 *patch) {
+  const unsigned voff = ((unsigned)(i0 + q) * (unsigned)T + (unsigned)min(j0 + c, T - 1)) * 16u;
+#pragma unroll
+  for (int m = 0; m < NC; ++m)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+      xt.x[m][rr] = c128_from(
+          __builtin_amdgcn_raw_buffer_load_b128(src.ch[m], voff, 4u * rr * (unsigned)T * 16u, 0));
+  xtile_transpose<NC>(xt, c, q, patch);
+}
+
+// (lane = frame, register = bin) -> (lane = bin, register = frame) through the wave's LDS patch
+template <int NC>
+__device__ __forceinline__ void xtile_transpose(XTile<NC> &xt, int c, int q, c128 *patch) {
 #pragma unroll
   for (int m0 = 0; m0 < NC; m0 += 2) {
     // The patch is reused by every pass and every tile, and the exchange is between LANES: nothing

@@ -55,10 +55,12 @@ static inline int fast_model_id(double domain, int source_model) {
   if (domain == 1.0 && base == SSSPY_SOURCE_GAUSS && !me) return 3;
   return -1;
 }
-static inline bool fast_path(int N, int T, int K, double domain, int source_model = SSSPY_SOURCE_GAUSS) {
+// (one channel of a mixture must fit the 32-bit offset of a buffer descriptor: F T 16 bytes < 4 GiB)
+static inline bool fast_path(int N, int F, int T, int K, double domain,
+                             int source_model = SSSPY_SOURCE_GAUSS) {
   static const bool disabled = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;
-  (void)T;
-  return !disabled && fast_model_id(domain, source_model) >= 0 && N >= 2 && N <= 4 && K <= 16;
+  return !disabled && fast_model_id(domain, source_model) >= 0 && N >= 2 && N <= 4 && K <= 16 &&
+         (long long)F * T * 16 < (1ll << 32);
 }
 static inline int is_me(int source_model) { return (source_model & SSSPY_SOURCE_ME) ? 1 : 0; }
 
@@ -457,7 +459,7 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
   char *ws = (char *)workspace;
   hipStream_t st = as_stream(stream);
   if (loss_done) *loss_done = false;
-  if (fast_path(N, T, K, domain, source_model)) {
+  if (fast_path(N, F, T, K, domain, source_model)) {
     if (loss_done) *loss_done = loss_out != nullptr;
     ILRMA_FAST_DISPATCH(N, ilrma_fast_basis, X, W, basis, activation, B, F, T, K, floor_kind,
                         floor_eps, (double *)(ws + w.bpart), fast_model_id(domain, source_model),
@@ -502,7 +504,7 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
   hipStream_t st = as_stream(stream);
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   auto run = [&]() -> int {
-    if (fast_path(N, T, K, domain, source_model)) {
+    if (fast_path(N, F, T, K, domain, source_model)) {
       ILRMA_FAST_DISPATCH(N, ilrma_fast_activation, X, W, basis, activation, part, chunks, B, F, T,
                           K, fast_model_id(domain, source_model), model_param, st);
     }
@@ -519,7 +521,7 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
 // U[b,i,n] for every model; `upart` is the fast path's scratch for split blocks
 static int wcov_into(const void *X, const void *W, const double *basis, const double *activation,
                      void *U, int N, const IlrmaDims &d, void *upart, hipStream_t st) {
-  if (fast_path(N, d.T, d.K, d.p, d.model) && (d.model == SSSPY_SOURCE_GAUSS || W)) {
+  if (fast_path(N, d.F, d.T, d.K, d.p, d.model) && (d.model == SSSPY_SOURCE_GAUSS || W)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, W, basis, activation, U, d.B, d.F, d.T, d.K, upart,
                         fast_model_id(d.p, d.model), d.mparam, d.floor_kind, d.floor_eps, st);
   }
@@ -613,7 +615,7 @@ int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
   hipStream_t st = as_stream(stream);
   hipError_t e = hipMemsetAsync(out, 0, (size_t)B * sizeof(double), st);
   if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
-  if (fast_path(N, T, K, domain, source_model)) {
+  if (fast_path(N, F, T, K, domain, source_model)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_loss, X, W, basis, activation, out, B, F, T, K,
                         fast_model_id(domain, source_model), model_param, st);
   }
@@ -637,7 +639,7 @@ static int ip1_update_impl(const void *X, const void *C, void *W, double *basis,
   int rc;
   if (loss_data) {
     // (the Student-t data term is not linear in the pass's accumulators; no by-product there)
-    if (!ssspy_ilrma_deferred_loss_supported(N, T, K, domain, source_model))
+    if (!ssspy_ilrma_deferred_loss_supported(N, F, T, K, domain, source_model))
       return fail(SSSPY_ERR_UNSUPPORTED,
                   "ilrma_ip1_update_deferred_loss: this shape takes the generic kernels, which have "
                   "no loss by-product (use ssspy_ilrma_loss_data + ssspy_ilrma_ip1_update)");
@@ -678,8 +680,9 @@ int ssspy_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis,
                          info, nullptr, nullptr, stream);
 }
 
-int ssspy_ilrma_deferred_loss_supported(int N, int T, int K, double domain, int source_model) {
-  return fast_path(N, T, K, domain, source_model) && fast_model_id(domain, source_model) != 1;
+int ssspy_ilrma_deferred_loss_supported(int N, int F, int T, int K, double domain,
+                                        int source_model) {
+  return fast_path(N, F, T, K, domain, source_model) && fast_model_id(domain, source_model) != 1;
 }
 
 int ssspy_ilrma_ip1_update_deferred_loss(const void *X, const void *C, void *W, double *basis,
