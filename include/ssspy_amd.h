@@ -378,6 +378,13 @@ int ssspy_fastmnmf_diagonalizer_covariance(const void *X, const double *D, const
                                            const double *activation, void *U, int B, int N, int M,
                                            int F, int T, int K, void *stream);
 
+/* weights[b,m,i,j] = 1 / R~_ijm, R~ = sum_n lambda_nij d_inm (B,M,F,T): the per-channel weights of the
+ * diagonaliser covariance, U = ssspy_weighted_covariance(X, weights, SSSPY_WEIGHT_BIN_FRAME, S = M).
+ * Any n_sources <= 8, n_channels in [2, 8].  replaces: ssspy/bss/mnmf.py:1489-1512 (the weight part). */
+int ssspy_fastmnmf_weights(const void *X, const void *Q, const double *D, const double *basis,
+                           const double *activation, double *weights, int B, int N, int M, int F,
+                           int T, int K, void *stream);
+
 /* out[b] = sum_i mean_j sum_m ( |q x|^2 / R~ + log R~ ) (zeroed by the call); caller adds
  * -2 sum logdet Q.   replaces: ssspy/bss/mnmf.py:1240-1258. */
 int ssspy_fastmnmf_loss_data(const void *X, const void *Q, const double *D, const double *basis,

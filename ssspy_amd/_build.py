@@ -50,6 +50,7 @@ def _units():
         ("ipa_kernels.hip", "ipa_kernels.o", []),
         ("stft_kernels.hip", "stft_kernels.o", []),
         ("hermitian_ops.hip", "hermitian_ops.o", []),
+        ("fmnmf_generic.hip", "fmnmf_generic.o", []),
     ]
     units.append(("mnmf_api.hip", "mnmf_api.o", []))
     for n in MNMF_N:

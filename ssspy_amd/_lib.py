@@ -91,6 +91,7 @@ PROTOTYPES = {
                                    _z, _p, _p]),
     "ssspy_fastmnmf_diagonalizer_covariance": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ssspy_fastmnmf_loss_data": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "ssspy_fastmnmf_weights": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ssspy_fastmnmf_separate": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p,
                                      _z, _p, _p]),
 }

@@ -418,6 +418,20 @@ def fastmnmf_diagonalizer_covariance(X, D, basis, activation, out=None):
     return out
 
 
+def fastmnmf_weights(X, Q, D, basis, activation, out=None):
+    """1 / R~ per (channel, bin, frame), (B, M, F, T): the weights of the diagonaliser covariance."""
+    B, M, F, T = X.shape
+    N, K = basis.shape[1], basis.shape[-1]
+    if out is None:
+        out = dv.empty((B, M, F, T), dv.f64, X.device)
+    _lib.check(
+        _L().ssspy_fastmnmf_weights(ptr(X), ptr(Q), ptr(D), ptr(basis), ptr(activation), ptr(out), B,
+                                    N, M, F, T, K, _st()),
+        "fastmnmf_weights",
+    )
+    return out
+
+
 def fastmnmf_loss_data(X, Q, D, basis, activation, out=None):
     B, M, F, T = X.shape
     N, K = basis.shape[1], basis.shape[-1]

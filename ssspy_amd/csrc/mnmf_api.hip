@@ -35,6 +35,26 @@ int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, i
                    int floor_kind, double floor_eps, int *info, hipStream_t st);
 int row_power(const void *W, const void *C, double *qbuf, int B, int F, int N, hipStream_t st);
 
+// general shapes (n_sources or n_channels above 4): the point-wise path of fmnmf_generic.hip
+size_t fmnmf_generic_workspace_doubles(int B, int N, int M, int F, int T);
+int fmnmf_generic_update(const void *X, const void *C, void *Q, double *D, double *basis,
+                         double *activation, int B, int N, int M, int F, int T, int K, int steps,
+                         int floor_kind, double floor_eps, double *gws, void *U, double *qbuf,
+                         int *info, hipStream_t st);
+int fmnmf_generic_weights(const void *X, const void *Q, const double *D, const double *basis,
+                          const double *act, double *Wt, int B, int N, int M, int F, int T, int K,
+                          hipStream_t st);
+int fmnmf_generic_loss(const void *X, const void *Q, const double *D, const double *basis,
+                       const double *act, double *out, int B, int N, int M, int F, int T, int K,
+                       hipStream_t st);
+int fmnmf_generic_separate(const void *X, const void *Q, void *Qinv, const double *D,
+                           const double *basis, const double *act, void *Y, int B, int N, int M,
+                           int F, int T, int K, int ref, int floor_kind, double eps, int *info,
+                           hipStream_t st);
+
+// the MFMA-tile kernels (mnmf_kernels.hip) are compiled for 2..4 sources and channels
+static inline bool mnmf_tiled(int N, int M) { return N >= 2 && N <= 4 && M >= 2 && M <= 4; }
+
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static inline int mnmf_chunks(int B, int F, int T, int K) {
@@ -48,7 +68,7 @@ static inline int mnmf_chunks(int B, int F, int T, int K) {
 }
 
 struct MnmfWs {
-  size_t part, btmp, U, qbuf, qinv, tail, total;
+  size_t part, btmp, U, qbuf, qinv, tail, generic, total;
 };
 
 // partial sums of the split work items of the bin-major kernels' last scheduling round
@@ -74,6 +94,8 @@ static inline MnmfWs mnmf_ws(int B, int N, int M, int F, int T, int K) {
   off += al((size_t)B * F * M * M * 2 * sizeof(double));
   w.tail = off;
   off += al(mnmf_tail_bytes(N, M));
+  w.generic = off;
+  if (!mnmf_tiled(N, M)) off += al(fmnmf_generic_workspace_doubles(B, N, M, F, T) * sizeof(double));
   w.total = off;
   return w;
 }
@@ -154,6 +176,10 @@ int ssspy_fastmnmf_update(const void *X, const void *C, void *Q, double *D, doub
   hipStream_t st = as_stream(stream);
   char *ws = (char *)workspace;
   int rc = SSSPY_OK;
+  if (!mnmf_tiled(N, M))
+    return fmnmf_generic_update(X, C, Q, D, basis, activation, B, N, M, F, T, K, steps, floor_kind,
+                                floor_eps, (double *)(ws + w.generic), ws + w.U,
+                                (double *)(ws + w.qbuf), info, st);
   if (steps & SSSPY_MNMF_BASIS) {
     rc = step_basis(X, Q, D, basis, activation, B, N, M, F, T, K, floor_kind, floor_eps, ws, w, st);
     if (rc) return rc;
@@ -204,9 +230,22 @@ int ssspy_fastmnmf_diagonalizer_covariance(const void *X, const double *D, const
                                            int F, int T, int K, void *stream) {
   SSSPY_REQUIRE(X && D && basis && activation && U && B > 0, "fastmnmf_diagonalizer_covariance: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_diagonalizer_covariance: bad n_basis");
+  if (!mnmf_tiled(N, M))
+    return fail(SSSPY_ERR_UNSUPPORTED,
+                "fastmnmf_diagonalizer_covariance: beyond 4 sources / channels use "
+                "ssspy_fastmnmf_weights + ssspy_weighted_covariance");
   // no workspace at this entry point: the generic (unsplit) covariance kernel
   MNMF_DISPATCH(N, mnmf_wcov, X, D, basis, activation, U, B, M, F, T, K, (double *)nullptr,
                 as_stream(stream));
+}
+
+int ssspy_fastmnmf_weights(const void *X, const void *Q, const double *D, const double *basis,
+                           const double *activation, double *weights, int B, int N, int M, int F,
+                           int T, int K, void *stream) {
+  SSSPY_REQUIRE(X && Q && D && basis && activation && weights && B > 0, "fastmnmf_weights: bad argument");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_weights: bad n_basis");
+  return fmnmf_generic_weights(X, Q, D, basis, activation, weights, B, N, M, F, T, K,
+                               as_stream(stream));
 }
 
 int ssspy_fastmnmf_loss_data(const void *X, const void *Q, const double *D, const double *basis,
@@ -217,6 +256,8 @@ int ssspy_fastmnmf_loss_data(const void *X, const void *Q, const double *D, cons
   hipStream_t st = as_stream(stream);
   hipError_t e = hipMemsetAsync(out, 0, (size_t)B * sizeof(double), st);
   if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+  if (!mnmf_tiled(N, M))
+    return fmnmf_generic_loss(X, Q, D, basis, activation, out, B, N, M, F, T, K, st);
   MNMF_DISPATCH(N, mnmf_loss, X, Q, D, basis, activation, out, B, M, F, T, K, st);
 }
 
@@ -229,6 +270,9 @@ int ssspy_fastmnmf_separate(const void *X, const void *Q, const double *D, const
   const MnmfWs w = mnmf_ws(B, N, M, F, T, K);
   SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "fastmnmf_separate: workspace too small");
   void *Qinv = (char *)workspace + w.qinv;
+  if (!mnmf_tiled(N, M))
+    return fmnmf_generic_separate(X, Q, Qinv, D, basis, activation, Y, B, N, M, F, T, K,
+                                  reference_id, floor_kind, floor_eps, info, as_stream(stream));
   MNMF_DISPATCH(N, mnmf_separate, X, Q, Qinv, D, basis, activation, Y, B, M, F, T, K, reference_id,
                 floor_kind, floor_eps, info, as_stream(stream));
 }

@@ -415,6 +415,10 @@ def main():
     run_mnmf("fmnmf_ip1_m4", M=4, F=21, T=36, K=8, seed=5, gen=gen_mixture)
     run_mnmf("fmnmf_ip1_m3_n2", M=3, F=16, T=30, K=3, seed=6, n_sources=2)
     run_mnmf("fmnmf_ip1_m2_nonorm", M=2, F=16, T=30, K=3, seed=7, normalization=False)
+    # shapes beyond 4 sources / channels (the general point-wise path of the device build)
+    run_mnmf("fmnmf_ip1_m6_n3", M=6, F=12, T=40, K=4, seed=8, n_sources=3, gen=gen_mixture)
+    run_mnmf("fmnmf_ip1_m5", M=5, F=10, T=36, K=3, seed=9)
+    run_mnmf("fmnmf_ip1_m8_n2", M=8, F=8, T=48, K=2, seed=11, n_sources=2)
     # --- GaussMNMF (full-rank spatial covariance) ---
     run_gmnmf("gmnmf_m2", M=2, F=12, T=20, K=2, seed=80)
     run_gmnmf("gmnmf_m3", M=3, F=10, T=24, K=3, seed=81, gen=gen_mixture, spatial_init=True)

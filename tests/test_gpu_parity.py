@@ -517,7 +517,8 @@ def test_aux_iva_iss_config3_shape_against_oracle():
 
 
 # ------------------------------------------------------------------------------- FastGaussMNMF
-MNMF_CASES = ["fmnmf_ip1_m3", "fmnmf_ip1_m4", "fmnmf_ip1_m3_n2", "fmnmf_ip1_m2_nonorm"]
+MNMF_CASES = ["fmnmf_ip1_m3", "fmnmf_ip1_m4", "fmnmf_ip1_m3_n2", "fmnmf_ip1_m2_nonorm",
+              "fmnmf_ip1_m6_n3", "fmnmf_ip1_m5", "fmnmf_ip1_m8_n2"]
 
 
 @pytest.mark.parametrize("case", MNMF_CASES)
@@ -1229,3 +1230,52 @@ def test_deferred_loss_batched_and_large_batch_path():
         ref = GaussILRMAOracle(n_basis=K)
         ref.run(X[b], n_iter=3, basis=basis[b], activation=act[b])
         np.testing.assert_allclose(loss[:, b], ref.loss, rtol=LOSS_RTOL)
+
+
+# ------------------------------------------------------------------------------- FastMNMF, general shapes
+@pytest.mark.parametrize("M,N,algo", [(5, 5, "IP"), (6, 2, "IP"), (8, 8, "IP"), (3, 1, "IP"),
+                                      (6, 3, "IP2"), (4, 6, "IP")])
+def test_fast_gauss_mnmf_general_shapes_against_oracle(M, N, algo):
+    """More than 4 channels or sources (and a single source): the point-wise general path of
+    fmnmf_generic.hip -- every parameter, the loss list and the Wiener-filter output against the
+    oracle; batch of two equals the single runs; the step methods equal the fused update.
+    ref: ssspy/bss/mnmf.py:1278-1303, :1174-1217."""
+    from oracle.mnmf import FastGaussMNMFOracle
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    F, T, K = 9, 70, 3
+    rng = np.random.default_rng(100 * M + N)
+    Xs = np.stack([nmf_mixture(900 + M + b, M, F, T) for b in range(2)])
+    kw = dict(basis=rng.random((2, N, F, K)), activation=rng.random((2, N, K, T)),
+              spatial=rng.random((2, F, N, M)))
+    mb = FastGaussMNMF(n_basis=K, n_sources=N, diagonalizer_algorithm=algo)
+    Yb = mb(Xs, n_iter=4, **kw)
+    for b in range(2):
+        one = {k: v[b] for k, v in kw.items()}
+        if algo == "IP":
+            ref = FastGaussMNMFOracle(n_basis=K, n_sources=N)
+            Yr = ref.run(Xs[b], n_iter=4, **{k: v.copy() for k, v in one.items()})
+            np.testing.assert_allclose(np.asarray(mb.loss)[:, b], ref.loss, rtol=1e-8)
+            for name in ("diagonalizer", "spatial", "basis", "activation"):
+                assert rel_err(getattr(mb, name)[b], getattr(ref, name)) < 1e-7, name
+            assert rel_err(Yb[b], Yr) < 1e-6
+        m1 = FastGaussMNMF(n_basis=K, n_sources=N, diagonalizer_algorithm=algo)
+        Y1 = m1(Xs[b], n_iter=4, **one)
+        assert rel_err(Yb[b], Y1) < 1e-11
+        np.testing.assert_allclose(np.asarray(mb.loss)[:, b], m1.loss, rtol=1e-11)
+    # step methods one by one == the fused update
+    ms = FastGaussMNMF(n_basis=K, n_sources=N, diagonalizer_algorithm=algo)
+    ms._bind_input(Xs[0])
+    ms._reset(**{k: v[0] for k, v in kw.items()})
+    mf = FastGaussMNMF(n_basis=K, n_sources=N, diagonalizer_algorithm=algo)
+    mf._bind_input(Xs[0])
+    mf._reset(**{k: v[0] for k, v in kw.items()})
+    mf.update_once()
+    ms.update_basis()
+    ms.update_activation()
+    ms.update_diagonalizer()
+    ms.update_spatial()
+    ms.normalize()
+    for name in ("diagonalizer", "spatial", "basis", "activation"):
+        assert rel_err(getattr(ms, name), getattr(mf, name)) < 1e-12, name

@@ -41,7 +41,8 @@ IVA_CASES = [
     "auxgauss_iss2_n3", "auxlap_ipa_n3", "auxgauss_ipa_n2", "auxlap_mdp_ip1_n3",
     "auxlap_mdp_iss1_n2",
 ]
-MNMF_CASES = ["fmnmf_ip1_m3", "fmnmf_ip1_m4", "fmnmf_ip1_m3_n2", "fmnmf_ip1_m2_nonorm"]
+MNMF_CASES = ["fmnmf_ip1_m3", "fmnmf_ip1_m4", "fmnmf_ip1_m3_n2", "fmnmf_ip1_m2_nonorm",
+              "fmnmf_ip1_m6_n3", "fmnmf_ip1_m5", "fmnmf_ip1_m8_n2"]
 
 
 def _floor(g):
