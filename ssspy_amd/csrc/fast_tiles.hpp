@@ -24,35 +24,36 @@ __device__ __forceinline__ double rcp_nr(double x) {
 
 __device__ __forceinline__ int tile_pi(int rho) { return 4 * (rho & 3) + (rho >> 2); }
 
-// ---- stage the activation tile V[b, n, 0:16, j0:j0+16] of every source into LDS rows of VROW
-// doubles (zero beyond K rows / T frames).  256 threads, NS*16 rows * 8 double2 chunks.
-template <int NS>
+// ---- stage the activation tile V[b, n, 0:KR, j0:j0+16] of every source into LDS rows of VROW
+// doubles (zero beyond K rows / T frames).  256 threads, NS*KR rows * 8 double2 chunks; KR = 16
+// (n_basis <= 16) or 32.
+template <int NS, int KR = 16>
 struct VStage {
-  double2 v[(NS * 16 * 8 + 255) / 256];
+  double2 v[(NS * KR * 8 + 255) / 256];
 };
 
-template <int NS>
-__device__ __forceinline__ void vstage_load(VStage<NS> &st, const double *__restrict__ act_b, int K,
-                                            int T, int j0) {
+template <int NS, int KR = 16>
+__device__ __forceinline__ void vstage_load(VStage<NS, KR> &st, const double *__restrict__ act_b,
+                                            int K, int T, int j0) {
 #pragma unroll
-  for (int u = 0; u < (NS * 16 * 8 + 255) / 256; ++u) {
+  for (int u = 0; u < (NS * KR * 8 + 255) / 256; ++u) {
     const int idx = threadIdx.x + 256 * u;
-    const int row = idx >> 3, chunk = idx & 7;  // row = n*16 + k
-    const int n = row >> 4, k = row & 15;
+    const int row = idx >> 3, chunk = idx & 7;  // row = n*KR + k
+    const int n = row / KR, k = row % KR;
     const int j = j0 + 2 * chunk;
     double2 val = make_double2(0.0, 0.0);
-    if (idx < NS * 16 * 8 && k < K) val = load_pair_in_row(act_b + ((long long)n * K + k) * T, j, T);
+    if (idx < NS * KR * 8 && k < K) val = load_pair_in_row(act_b + ((long long)n * K + k) * T, j, T);
     st.v[u] = val;
   }
 }
 
-template <int NS>
-__device__ __forceinline__ void vstage_store(const VStage<NS> &st, double *buf) {
+template <int NS, int KR = 16>
+__device__ __forceinline__ void vstage_store(const VStage<NS, KR> &st, double *buf) {
 #pragma unroll
-  for (int u = 0; u < (NS * 16 * 8 + 255) / 256; ++u) {
+  for (int u = 0; u < (NS * KR * 8 + 255) / 256; ++u) {
     const int idx = threadIdx.x + 256 * u;
     const int row = idx >> 3, chunk = idx & 7;
-    if (idx < NS * 16 * 8) {  // frame f of the tile lives in slot tile_pi(f)
+    if (idx < NS * KR * 8) {  // frame f of the tile lives in slot tile_pi(f)
       buf[row * VROW + tile_pi(2 * chunk)] = st.v[u].x;
       buf[row * VROW + tile_pi(2 * chunk + 1)] = st.v[u].y;
     }
@@ -201,12 +202,13 @@ __device__ __forceinline__ void xtile_transpose(XTile<NC> &xt, int c, int q, c12
 // GEMM1 of the bin-major tile from the staged V: R[bin c, frame j0+q+4r] in register r
 // (D row q+4r reads slot tile_pi(q+4r) = 4q+r, which holds frame tile_pi(4q+r) = q+4r)
 // ksteps = ceil(K / 4): k-slabs beyond n_basis are zero on both sides and are skipped
-__device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const double (&tb)[4], int c,
+template <int KS>
+__device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const double (&tb)[KS], int c,
                                                  int q, int ksteps) {
   double4_t R = {0.0, 0.0, 0.0, 0.0};
   const int col = tile_pi(c);
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
+  for (int ks = 0; ks < KS; ++ks)
     if (ks < ksteps) R = mfma_f64(vs_n[(4 * ks + q) * VROW + col], tb[ks], R);
   return R;
 }

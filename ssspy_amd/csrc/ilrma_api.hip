@@ -20,11 +20,12 @@ namespace ssspy {
 DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
 #undef DECL_N
 
-// throughput variants (ilrma_fast.hip): n_basis <= 16, n_sources <= 4, models of fast_model_id()
+// throughput variants (ilrma_fast.hip): n_basis <= 32 (two k tiles above 16), n_sources <= 4, models
+// of fast_model_id()
 #define DECL_FAST(n)                                                                           \
-  int ilrma_fast_basis_n##n(const void *, const void *, double *, const double *, int, int, int, \
-                            int, int, double, double *, int, double, int, double *,            \
-                            hipStream_t);                                                      \
+  int ilrma_fast_basis_n##n(const void *, const void *, const double *, double *, const double *, \
+                            int, int, int, int, int, double, double *, int, double, int,        \
+                            double *, hipStream_t);                                             \
   int ilrma_fast_activation_n##n(const void *, const void *, const double *, const double *,   \
                                  double *, int, int, int, int, int, int, double, hipStream_t); \
   int ilrma_fast_wcov_n##n(const void *, const void *, const double *, const double *, void *, \
@@ -59,7 +60,7 @@ static inline int fast_model_id(double domain, int source_model) {
 static inline bool fast_path(int N, int F, int T, int K, double domain,
                              int source_model = SSSPY_SOURCE_GAUSS) {
   static const bool disabled = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;
-  return !disabled && fast_model_id(domain, source_model) >= 0 && N >= 2 && N <= 4 && K <= 16 &&
+  return !disabled && fast_model_id(domain, source_model) >= 0 && N >= 2 && N <= 4 && K <= 32 &&
          (long long)F * T * 16 < (1ll << 32);
 }
 static inline int is_me(int source_model) { return (source_model & SSSPY_SOURCE_ME) ? 1 : 0; }
@@ -450,7 +451,7 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
                              size_t workspace_bytes, double *loss_out, bool *loss_done,
                              void *stream) {
   SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0, "update_basis: bad argument");
-  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_basis: n_basis must be in [1, 64]");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_basis: n_basis must be in [1, 256]");
   SSSPY_REQUIRE(domain > 0.0 && domain <= 2.0, "update_basis: domain must be in (0, 2]");
   int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
@@ -459,15 +460,19 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
   char *ws = (char *)workspace;
   hipStream_t st = as_stream(stream);
   if (loss_done) *loss_done = false;
-  if (fast_path(N, F, T, K, domain, source_model)) {
-    if (loss_done) *loss_done = loss_out != nullptr;
-    ILRMA_FAST_DISPATCH(N, ilrma_fast_basis, X, W, basis, activation, B, F, T, K, floor_kind,
-                        floor_eps, (double *)(ws + w.bpart), fast_model_id(domain, source_model),
-                        model_param, is_me(source_model), loss_out, st);
-  }
-  const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
+  // above 16 bases the update cannot be in place (several items per bin group read the old basis)
   double *out = K > 16 ? (double *)(ws + w.btmp) : basis;
-  auto run = [&]() -> int { ILRMA_DISPATCH(N, ilrma_basis, X, W, basis, out, activation, d, st); };
+  auto run = [&]() -> int {
+    if (fast_path(N, F, T, K, domain, source_model)) {
+      if (loss_done) *loss_done = loss_out != nullptr && K <= 16;
+      ILRMA_FAST_DISPATCH(N, ilrma_fast_basis, X, W, basis, out, activation, B, F, T, K, floor_kind,
+                          floor_eps, (double *)(ws + w.bpart), fast_model_id(domain, source_model),
+                          model_param, is_me(source_model), K <= 16 ? loss_out : nullptr, st);
+    }
+    const IlrmaDims d =
+        make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
+    ILRMA_DISPATCH(N, ilrma_basis, X, W, basis, out, activation, d, st);
+  };
   rc = run();
   if (rc) return rc;
   if (out != basis) {
@@ -494,7 +499,7 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
                                   size_t workspace_bytes, void *stream) {
   SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0,
                 "update_activation: bad argument");
-  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_activation: n_basis must be in [1, 64]");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_activation: n_basis must be in [1, 256]");
   int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
   const IlrmaWs w = ilrma_ws(B, N, F, T, K);
@@ -615,7 +620,7 @@ int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
   hipStream_t st = as_stream(stream);
   hipError_t e = hipMemsetAsync(out, 0, (size_t)B * sizeof(double), st);
   if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
-  if (fast_path(N, F, T, K, domain, source_model)) {
+  if (K <= 16 && fast_path(N, F, T, K, domain, source_model)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_loss, X, W, basis, activation, out, B, F, T, K,
                         fast_model_id(domain, source_model), model_param, st);
   }
@@ -682,7 +687,8 @@ int ssspy_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis,
 
 int ssspy_ilrma_deferred_loss_supported(int N, int F, int T, int K, double domain,
                                         int source_model) {
-  return fast_path(N, F, T, K, domain, source_model) && fast_model_id(domain, source_model) != 1;
+  return K <= 16 && fast_path(N, F, T, K, domain, source_model) &&
+         fast_model_id(domain, source_model) != 1;
 }
 
 int ssspy_ilrma_ip1_update_deferred_loss(const void *X, const void *C, void *W, double *basis,
@@ -717,7 +723,7 @@ int ssspy_ilrma_partition_update(const void *X, const void *W, double *basis, do
   SSSPY_REQUIRE(X && basis && activation && latent && Teff && Vrep && B > 0 && F > 0 && T > 0,
                 "partition_update: bad argument");
   SSSPY_REQUIRE(N >= 1 && N <= SSSPY_MAX_SOURCES, "partition_update: n_sources must be in [1, 8]");
-  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "partition_update: n_basis must be in [1, 64]");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "partition_update: n_basis must be in [1, 256]");
   SSSPY_REQUIRE(domain > 0.0 && domain <= 2.0, "partition_update: domain must be in (0, 2]");
   int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;

@@ -142,23 +142,35 @@ __device__ __forceinline__ double mm_num_factor<FM_GAUSS1>(double pw, double, do
 // term is not linear in the accumulators), into loss_out[b]: the pass already forms |y|^2 and R
 // under the current (W, T, V), so the loss of iteration t comes out of the basis pass of iteration
 // t + 1 instead of a fourth pass over X (ref: ssspy/bss/ilrma.py:1946-1965).
-template <bool HAS_W, int MODEL, bool LOSS>
-__global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ X,
-                                                       const c128 *__restrict__ W, double *basis,
+// KS = 4: n_basis <= 16, one work item per (mixture, bin group), updated in place.
+// KS = 8: n_basis <= 32: the k-range is two 16-wide tiles and a work item is (mixture, bin group,
+// k tile): both items of a group run the whole walk (GEMM1 over all 32 k) and keep the accumulators
+// of their own tile, so the pass costs about twice the n_basis <= 16 one -- against 6x for the generic
+// kernels.  Its 64-register basis operand only fits because |y|^2 of all sources is formed first
+// (the x tile is dead before GEMM1's operands go live); results go to `basis_out` (the sibling
+// item still reads the old basis), which the launcher copies back.
+template <bool HAS_W, int MODEL, bool LOSS, int KS>
+__global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 *__restrict__ X,
+                                                       const c128 *__restrict__ W,
+                                                       const double *basis, double *basis_out,
                                                        const double *__restrict__ act, int F,
                                                        int T, int K, int floor_kind, double eps,
                                                        TailPlan plan, double *__restrict__ part,
                                                        FastModel fm, double *__restrict__ loss_out) {
-  __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
+  constexpr int KR = 4 * KS;  // staged activation rows per source
+  __shared__ __attribute__((aligned(16))) double vs[2][N * KR * VROW];
   constexpr int WSTRIDE = N * N + 1;  // 16-byte slots per bin: odd, so 16 bins never share a bank
   __shared__ __attribute__((aligned(16))) c128 wl[4][16 * WSTRIDE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
   const BlockWork work = block_work(plan);
   const int b = work.b, nchunks = work.nchunks;
-  const int i0 = work.group * 64 + wave * 16;
+  const int group = KS == 8 ? work.group >> 1 : work.group;
+  const int kt = KS == 8 ? work.group & 1 : 0;  // the 16-wide k tile this item accumulates
+  const int i0 = group * 64 + wave * 16;
   const int bin = min(i0 + c, F - 1);
   const bool bin_valid = i0 + c < F;
+  const int ksteps = (K + 3) >> 2;
   double lacc = 0.0;
   LogSum lr;  // log R of everything this lane visits
   lr.clear();
@@ -173,11 +185,11 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
                                      : cmake((rem / N) == (rem % N) ? 1.0 : 0.0, 0.0);
   }
   const c128 *wmine = wl[wave] + c * WSTRIDE;
-  double tb[N][4];
+  double tb[N][KS];
 #pragma unroll
   for (int n = 0; n < N; ++n)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const int kk = 4 * ks + q;
       tb[n][ks] = kk < K ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
     }
@@ -191,74 +203,106 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
   const int ntiles = (T + 15) >> 4;
   const int tpc = (ntiles + nchunks - 1) / nchunks;
   const int jt_begin = work.chunk * tpc, jt_end = min(ntiles, jt_begin + tpc);
-  VStage st;
+  fast::VStage<N, KR> st;
   XTile cur;
-  fast::vstage_load<N>(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
-  fast::vstage_store<N>(st, vs[0]);
+  fast::vstage_load<N, KR>(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
+  fast::vstage_store<N, KR>(st, vs[0]);
   __syncthreads();
 
   for (int jt = jt_begin; jt < jt_end; ++jt) {
     const int j0 = jt * 16;
     const int jn = min(jt + 1, jt_end - 1) * 16;  // last iteration re-fetches its own tile
     fast::xtile_load_binmajor<N>(cur, xsrc, T, bin, j0, q);
-    fast::vstage_load<N>(st, act_b, K, T, jn);
+    if (KS != 8) fast::vstage_load<N, KR>(st, act_b, K, T, jn);
     const double *vcur = vs[(jt - jt_begin) & 1];
+    double pwall[KS == 8 ? N : 1][4];
+    if (KS == 8) {
+      // |y|^2 of every source first: the x tile dies here.  One demixing coefficient at a time and
+      // the next activation tile requested only afterwards keep this phase inside the budget.
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        c128 y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = HAS_W ? cmake(0.0, 0.0) : cur.x[n][r];
+        if (HAS_W) {
+#pragma unroll
+          for (int m = 0; m < N; ++m) {
+            const c128 w = wmine[n * N + m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cfma(y[r], w, cur.x[m][r]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pwall[n][r] = cabs2(y[r]);
+      }
+      fast::vstage_load<N, KR>(st, act_b, K, T, jn);
+    }
 #pragma unroll
     for (int n = 0; n < N; ++n) {
-      const double *vn = vcur + n * 16 * VROW;
-      const double4_t R = rt_from_lds(vn, tb[n], c, q, (K + 3) >> 2);
-      const double2 vb01 = *reinterpret_cast<const double2 *>(vn + c * VROW + 4 * q);
-      const double2 vb23 = *reinterpret_cast<const double2 *>(vn + c * VROW + 4 * q + 2);
+      const double *vn = vcur + n * KR * VROW;
+      const double4_t R = rt_from_lds<KS>(vn, tb[n], c, q, ksteps);
+      // GEMM2 B operand: V[n, k = 16 kt + c, frame q + 4r] (slots 4q .. 4q+3 of the permuted row)
+      const double *vrow = vn + (16 * kt + c) * VROW + 4 * q;
+      const double2 vb01 = *reinterpret_cast<const double2 *>(vrow);
+      const double2 vb23 = *reinterpret_cast<const double2 *>(vrow + 2);
       const double vb[4] = {vb01.x, vb01.y, vb23.x, vb23.y};
       c128 wr[N];
+      if (KS != 8) {
 #pragma unroll
-      for (int m = 0; m < N; ++m) wr[m] = wmine[n * N + m];
+        for (int m = 0; m < N; ++m) wr[m] = wmine[n * N + m];
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        c128 y = cur.x[n][r];
-        if (HAS_W) {
-          y = cmake(0.0, 0.0);
+        double pw;
+        if (KS == 8) {
+          pw = pwall[n][r];
+        } else {
+          c128 y = cur.x[n][r];
+          if (HAS_W) {
+            y = cmake(0.0, 0.0);
 #pragma unroll
-          for (int m = 0; m < N; ++m) cfma(y, wr[m], cur.x[m][r]);
+            for (int m = 0; m < N; ++m) cfma(y, wr[m], cur.x[m][r]);
+          }
+          pw = cabs2(y);
         }
         const bool valid = j0 + q + 4 * r < T;
         const double rinv = rcp_nr(R[r]);
         const double bb = valid ? rinv : 0.0;
-        const double pw = cabs2(y);
         const double aa = valid ? mm_num_factor<MODEL>(pw, R[r], rinv, fm) : 0.0;
         num[n] = mfma_f64(aa, vb[r], num[n]);
         den[n] = mfma_f64(bb, vb[r], den[n]);
         if (LOSS) {
-          // log R of every element (and the t model's log(1 + (2/nu) P/R)): LogSum, no log here.
-          // The P/R part of the other models needs nothing per element: see the epilogue.
+          // log R of every element: LogSum, no log here.  The P/R part needs nothing per element:
+          // see the epilogue.
           const bool lv = valid && bin_valid;
           lr.mul(lv ? R[r] : 1.0);
         }
       }
     }
     if (LOSS) lr.renorm();
-    fast::vstage_store<N>(st, vs[(jt - jt_begin + 1) & 1]);
+    fast::vstage_store<N, KR>(st, vs[(jt - jt_begin + 1) & 1]);
     __syncthreads();
   }
-  // D: col = basis index c, row = q + 4r -> bin i0 + q + 4r
+  // D: col = basis index 16 kt + c, row = q + 4r -> bin i0 + q + 4r
   // Loss by-product: sum_j a_nij R_nij = sum_k t_nik num_nik with the basis the pass started from, and
   // a R is the model's data term up to a constant (Gauss P/R, domain 1 P/R^2, GGD (beta/2)(P/R)^(beta/2)):
   // it falls out of the finished accumulators (the split items' share is added by k_basis_finalize).
+  const int kout = 16 * kt + c;
 #pragma unroll
   for (int n = 0; n < N; ++n)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ob = i0 + q + 4 * r;
-      if (ob < F && c < K) {
+      if (ob < F && kout < K) {
         if (nchunks == 1) {
-          double *dst = basis + (((long long)b * N + n) * F + ob) * K + c;
-          const double told = *dst;
+          const long long o = (((long long)b * N + n) * F + ob) * K + kout;
+          const double told = basis[o];
           if (LOSS) lacc = fma(told, num[n][r], lacc);
           const double ratio = num[n][r] / den[n][r];
-          *dst = apply_floor(ratio_pow(ratio, fm.expo) * told, floor_kind, eps);
+          basis_out[o] = apply_floor(ratio_pow(ratio, fm.expo) * told, floor_kind, eps);
         } else {
           const long long slot = (long long)work.tail_idx * nchunks + work.chunk;
-          double *dst = part + (((slot * N + n) * 64 + (ob - work.group * 64)) * 16 + c) * 2;
+          double *dst = part + (((slot * N + n) * 64 + (ob - group * 64)) * 16 + c) * 2;
           dst[0] = num[n][r];
           dst[1] = den[n][r];
         }
@@ -266,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
     }
   if (LOSS) {
     if (MODEL == FM_GGD) lacc *= 2.0 / fm.beta;
-    lacc += (MODEL == FM_GAUSS1 ? 2.0 : 1.0) * lr.value();  // (2 / p) log R
+    if (kt == 0) lacc += (MODEL == FM_GAUSS1 ? 2.0 : 1.0) * lr.value();  // (2 / p) log R, once
     lacc = wave_sum(lacc);
     if (lane == 0) atomicAdd(loss_out + b, lacc / (double)T);
   }
@@ -274,18 +318,20 @@ __global__ __launch_bounds__(256, 2) void k_basis_fast(const c128 *__restrict__ 
 
 // basis <- floor(basis * sqrt(sum_chunks num / sum_chunks den)) for the split (tail) items;
 // grid: (N*64*16/256, tail items); one thread per (n, local bin, k)
+// ktiles: 1 (n_basis <= 16) or 2 (the item index also carries the k tile, see k_basis_fast<.., 8>)
 // loss_out / loss_scale: the split items' share of the loss by-product sum_k t num (see k_basis_fast)
-__global__ __launch_bounds__(256) void k_basis_finalize(double *basis,
+__global__ __launch_bounds__(256) void k_basis_finalize(const double *basis, double *basis_out,
                                                         const double *__restrict__ part, int F,
-                                                        int K, TailPlan plan, int floor_kind,
-                                                        double eps, double expo,
+                                                        int K, TailPlan plan, int ktiles,
+                                                        int floor_kind, double eps, double expo,
                                                         double *__restrict__ loss_out,
                                                         double loss_scale) {
   const int tail_idx = blockIdx.y;
   const int item = plan.full + tail_idx;
-  const int b = item / plan.groups, group = item - b * plan.groups;
+  const int b = item / plan.groups, g2 = item - b * plan.groups;
+  const int group = ktiles == 2 ? g2 >> 1 : g2, kt = ktiles == 2 ? g2 & 1 : 0;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (n, local bin, k16)
-  const int k = e & 15, lb = (e >> 4) & 63, n = e >> 10;
+  const int k = 16 * kt + (e & 15), lb = (e >> 4) & 63, n = e >> 10;
   const int bin = group * 64 + lb;
   double contrib = 0.0;
   if (n < N && k < K && bin < F) {
@@ -296,11 +342,11 @@ __global__ __launch_bounds__(256) void k_basis_finalize(double *basis,
       sn += src[0];
       sd += src[1];
     }
-    double *dst = basis + (((long long)b * N + n) * F + bin) * K + k;
-    const double told = *dst;
+    const long long o = (((long long)b * N + n) * F + bin) * K + k;
+    const double told = basis[o];
     contrib = told * sn;
     const double ratio = sn / sd;
-    *dst = apply_floor(ratio_pow(ratio, expo) * told, floor_kind, eps);
+    basis_out[o] = apply_floor(ratio_pow(ratio, expo) * told, floor_kind, eps);
   }
   if (loss_out) {  // uniform per launch
     contrib = wave_sum(contrib);
@@ -422,7 +468,9 @@ constexpr int WC_BINS = 16 * WC_WB;              // bins per workgroup
 // grid: 1-D, see TailPlan.  Unsplit blocks store U directly; split blocks store their partial sums
 // (already scaled by 1/T) to `upart` ([tail item][chunk][WC_BINS][N][N][N]) for k_wcov_fold.
 // t and GGD models: varphi depends on |w_n^H x|^2, so the wave also needs its bins' demixing rows
-template <int MODEL>
+// KS: k-steps of GEMM1 compiled in (4: n_basis <= 16, 8: n_basis <= 32; no k tiles here, the pass has
+// no second GEMM)
+template <int MODEL, int KS>
 __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X,
                                                       const c128 *__restrict__ W,
                                                       const double *__restrict__ basis,
@@ -445,11 +493,11 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
   const int bin = min(i0 + c, F - 1);
   const fast::XSrc<N> xsrc = fast::make_xsrc<N>(X + (long long)b * N * F * T, F, T);
   const double *act_b = act + (long long)b * N * K * T;
-  double tb[SG][4];
+  double tb[SG][KS];
 #pragma unroll
   for (int s = 0; s < SG; ++s)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const int kk = 4 * ks + q, n = min(s0 + s, N - 1);
       tb[s][ks] = kk < K ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
     }
@@ -471,12 +519,12 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
     const int j0 = jt * 16;
     // GEMM1 A operand straight from global memory: V[n, 4ks+q, j0+c] (the activation of a mixture
     // is 0.26 MB, shared by all its items on this XCD: L2 hits), 128-byte runs per (ks, q)
-    double va[SG][4];
+    double va[SG][KS];
     const int jv = j0 + c;
 #pragma unroll
     for (int s = 0; s < SG; ++s)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         const int kk = 4 * ks + q, n = min(s0 + s, N - 1);
         va[s][ks] = (kk < K && jv < T) ? act_b[((long long)n * K + kk) * T + jv] : 0.0;
       }
@@ -486,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
     for (int s = 0; s < SG; ++s) {
       R[s] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < KS; ++ks)
         if (ks < ((K + 3) >> 2)) R[s] = mfma_f64(va[s][ks], tb[s][ks], R[s]);
     }
 #pragma unroll
@@ -644,20 +692,29 @@ __global__ __launch_bounds__(256) void k_wcov_fold(c128 *__restrict__ U,
 // ========================================================================= activation (pass 2)
 // grid: (ceil(T/64), chunks, B); wave w owns frames [64*bx + 16w, +16) and walks the bin tiles
 // of its chunk; the basis tile (all sources) and the 16 demixing matrices are staged in LDS.
+template <int KS>
 struct TStage {
-  double t[(N * 16 * 16 + 255) / 256];
+  double t[(N * 16 * 4 * KS + 255) / 256];
   c128 w;
 };
 
-__device__ __forceinline__ void tstage_load(TStage &st, const double *__restrict__ basis_b,
+// staged basis rows: [n][bin 16][k < 4 KS] with one slot of padding per row
+template <int KS>
+constexpr int trow() {
+  return 4 * KS + 1;
+}
+
+template <int KS>
+__device__ __forceinline__ void tstage_load(TStage<KS> &st, const double *__restrict__ basis_b,
                                             const c128 *__restrict__ W_b, int F, int K, int i0) {
+  constexpr int KR = 4 * KS;
 #pragma unroll
-  for (int u = 0; u < (N * 16 * 16 + 255) / 256; ++u) {
+  for (int u = 0; u < (N * 16 * KR + 255) / 256; ++u) {
     const int idx = threadIdx.x + 256 * u;  // (n, bin, k)
-    const int k = idx & 15, bl = (idx >> 4) & 15, n = idx >> 8;
+    const int k = idx % KR, bl = (idx / KR) & 15, n = idx / (16 * KR);
     const int bi = i0 + bl;
     double v = 0.0;
-    if (idx < N * 256 && k < K && bi < F) v = basis_b[((long long)n * F + bi) * K + k];
+    if (idx < N * 16 * KR && k < K && bi < F) v = basis_b[((long long)n * F + bi) * K + k];
     st.t[u] = v;
   }
   {
@@ -671,15 +728,16 @@ __device__ __forceinline__ void tstage_load(TStage &st, const double *__restrict
   }
 }
 
-constexpr int TROW = 17;  // doubles per staged basis row (16 + 1 pad)
 constexpr int AWSTRIDE = N * N + 1;  // 16-byte slots per staged demixing matrix
 
-__device__ __forceinline__ void tstage_store(const TStage &st, double *tbuf, c128 *wbuf) {
+template <int KS>
+__device__ __forceinline__ void tstage_store(const TStage<KS> &st, double *tbuf, c128 *wbuf) {
+  constexpr int KR = 4 * KS;
 #pragma unroll
-  for (int u = 0; u < (N * 16 * 16 + 255) / 256; ++u) {
+  for (int u = 0; u < (N * 16 * KR + 255) / 256; ++u) {
     const int idx = threadIdx.x + 256 * u;
-    const int k = idx & 15, row = idx >> 4;  // row = n*16 + bin
-    if (idx < N * 256) tbuf[row * TROW + k] = st.t[u];
+    const int k = idx % KR, row = idx / KR;  // row = n*16 + bin
+    if (idx < N * 16 * KR) tbuf[row * trow<KS>() + k] = st.t[u];
   }
   // one 16-byte slot of padding per bin: lanes of different q read different bins at once, and an
   // unpadded N*N-slot stride (256 B at N = 4) would put them all on the same banks
@@ -688,22 +746,24 @@ __device__ __forceinline__ void tstage_store(const TStage &st, double *tbuf, c12
 }
 
 // HAS_W = false: the ISS / IPA state passes the separated spectrogram itself (y = x_n, no filter)
-template <bool HAS_W, int MODEL>
-__global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restrict__ X,
-                                                         const c128 *__restrict__ W,
-                                                         const double *__restrict__ basis,
-                                                         const double *__restrict__ act,
-                                                         double *__restrict__ part, int F, int T,
-                                                         int K, int tiles_per_chunk, int nchunks,
-                                                         FastModel fm) {
+// KS = 8 (16 < n_basis <= 32): grid.y carries (bin chunk, k tile); both k-tile items run GEMM1 over all
+// 32 k and keep the sums of their own 16 (see k_basis_fast); one wave per SIMD.
+template <bool HAS_W, int MODEL, int KS>
+__global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_activation_fast(
+    const c128 *__restrict__ X, const c128 *__restrict__ W, const double *__restrict__ basis,
+    const double *__restrict__ act, double *__restrict__ part, int F, int T, int K,
+    int tiles_per_chunk, int nchunks, FastModel fm) {
+  constexpr int TROW = trow<KS>();
   __shared__ __attribute__((aligned(16))) double ts[2][N * 16 * TROW];
   __shared__ __attribute__((aligned(16))) c128 ws[2][16 * AWSTRIDE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
-  // (frame group, bin chunk, mixture) from the XCD-contiguous item: the frame groups of one
-  // (mixture, chunk) share the staged basis tiles and demixing matrices
+  // (frame group, bin chunk [x k tile], mixture) from the XCD-contiguous item: the frame groups of
+  // one (mixture, chunk) share the staged basis tiles and demixing matrices
   const GridItem gi = xcd_contiguous_grid();
-  const int chunk = gi.y, b = gi.z;
+  const int chunk = KS == 8 ? gi.y >> 1 : gi.y, b = gi.z;
+  const int kt = KS == 8 ? gi.y & 1 : 0;
+  const int ksteps = (K + 3) >> 2;
   const int j0 = (gi.x * 4 + wave) * 16;
   const int jf = j0 + c;
   const bool fvalid = jf < T;
@@ -712,11 +772,11 @@ __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restri
   const double *basis_b = basis + (long long)b * N * F * K;
   const c128 *W_b = W ? W + (long long)b * F * N * N : nullptr;
 
-  double vb[N][4];  // GEMM1 B operand V[n, 4ks+q, frame]
+  double vb[N][KS];  // GEMM1 B operand V[n, 4ks+q, frame]
 #pragma unroll
   for (int n = 0; n < N; ++n)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const int kk = 4 * ks + q;
       vb[n][ks] = (kk < K && fvalid) ? act[(((long long)b * N + n) * K + kk) * T + jc] : 0.0;
     }
@@ -729,16 +789,16 @@ __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restri
   const int ntiles = (F + 15) >> 4;
   const int t_begin = chunk * tiles_per_chunk;
   const int t_end = min(ntiles, t_begin + tiles_per_chunk);
-  TStage st;
+  TStage<KS> st;
   XTile cur;
-  tstage_load(st, basis_b, W_b, F, K, t_begin * 16);
-  tstage_store(st, ts[0], ws[0]);
+  tstage_load<KS>(st, basis_b, W_b, F, K, t_begin * 16);
+  tstage_store<KS>(st, ts[0], ws[0]);
   __syncthreads();
   for (int it = t_begin; it < t_end; ++it) {
     const int i0 = it * 16;
     const int in = min(it + 1, t_end - 1) * 16;
     fast::xtile_load_framemajor<N>(cur, xsrc, T, i0, jc, q);
-    tstage_load(st, basis_b, W_b, F, K, in);
+    tstage_load<KS>(st, basis_b, W_b, F, K, in);
     const int pb = (it - t_begin) & 1;
     const double *tcur = ts[pb];
     const c128 *wcur = ws[pb];
@@ -748,8 +808,8 @@ __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restri
       // GEMM1: A[row = c -> bin i0+c][kk = q] = T[n, i0+c, 4ks+q]
       double4_t R = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        if (ks < ((K + 3) >> 2)) R = mfma_f64(tn[c * TROW + 4 * ks + q], vb[n][ks], R);
+      for (int ks = 0; ks < KS; ++ks)
+        if (ks < ksteps) R = mfma_f64(tn[c * TROW + 4 * ks + q], vb[n][ks], R);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int bl = q + 4 * r;
@@ -765,20 +825,21 @@ __global__ __launch_bounds__(256, 2) void k_activation_fast(const c128 *__restri
         const double bb = valid ? rinv : 0.0;
         const double pw = cabs2(y);
         const double aa = valid ? mm_num_factor<MODEL>(pw, R[r], rinv, fm) : 0.0;
-        // GEMM2: A[row = c -> basis index c][kk = q] = T[n, bin i0+q+4r, c] (zero-staged pads)
-        const double ta = tn[bl * TROW + c];
+        // GEMM2: A[row = c -> basis index 16 kt + c][kk = q] = T[n, bin i0+q+4r, 16 kt + c]
+        // (zero-staged pads)
+        const double ta = tn[bl * TROW + 16 * kt + c];
         numv[n] = mfma_f64(ta, aa, numv[n]);
         denv[n] = mfma_f64(ta, bb, denv[n]);
       }
     }
-    tstage_store(st, ts[pb ^ 1], ws[pb ^ 1]);
+    tstage_store<KS>(st, ts[pb ^ 1], ws[pb ^ 1]);
     __syncthreads();
   }
 #pragma unroll
   for (int n = 0; n < N; ++n)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int ok = q + 4 * r;
+      const int ok = 16 * kt + q + 4 * r;
       if (ok < K && fvalid) {
         const long long base = ((((long long)b * nchunks + chunk) * N + n) * 2) * K;
         part[(base + ok) * T + jf] = numv[n][r];
@@ -825,46 +886,58 @@ static inline FastModel make_fast_model(int fmodel, double mparam, int me, int f
   } while (0)
 
 // `part` must hold the scratch of ilrma_api.hip's basis_part_bytes() (used only when items are split)
-// loss_out: nullptr, or B zeroed doubles that receive the data term of the loss of the state at entry
-int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, double *basis, const double *act,
-                               int B, int F, int T, int K, int floor_kind, double eps,
-                               double *part, int fmodel, double mparam, int me, double *loss_out,
-                               hipStream_t st) {
-  const TailPlan plan = make_tail_plan(B, (F + 63) / 64, (T + 15) / 16);
+// loss_out: nullptr, or B zeroed doubles that receive the data term of the loss of the state at entry.
+// K <= 16: basis_out == basis (in place); 16 < K <= 32: basis_out must be a separate (B,N,F,K) buffer
+// (two k-tile items per bin group read the old basis) and the caller copies it back.
+int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis, double *basis_out,
+                               const double *act, int B, int F, int T, int K, int floor_kind,
+                               double eps, double *part, int fmodel, double mparam, int me,
+                               double *loss_out, hipStream_t st) {
+  const int ktiles = K > 16 ? 2 : 1;
+  // (the wide variant holds one workgroup per CU)
+  const TailPlan plan =
+      make_tail_plan(B, ((F + 63) / 64) * ktiles, (T + 15) / 16, ktiles == 2 ? 256 : SLOTS);
   const FastModel fm = make_fast_model(fmodel, mparam, me);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
-#define SSSPY_BASIS_LAUNCH(HW, M, L)                                                              \
-  hipLaunchKernelGGL((k_basis_fast<HW, M, L>), grid, block, 0, st, (const c128 *)X,               \
-                     (const c128 *)W, basis, act, F, T, K, floor_kind, eps, plan, part, fm, loss_out)
-#define SSSPY_BASIS_LAUNCH_M(HW, L)                   \
-  switch (fmodel) {                                   \
-    case FM_T: SSSPY_BASIS_LAUNCH(HW, FM_T, false); break; /* no by-product for the t model */ \
-    case FM_GGD: SSSPY_BASIS_LAUNCH(HW, FM_GGD, L); break; \
-    case FM_GAUSS1: SSSPY_BASIS_LAUNCH(HW, FM_GAUSS1, L); break; \
-    default: SSSPY_BASIS_LAUNCH(HW, FM_GAUSS, L); break; \
+#define SSSPY_BASIS_LAUNCH(HW, M, L, KS_)                                                          \
+  hipLaunchKernelGGL((k_basis_fast<HW, M, L, KS_>), grid, block, 0, st, (const c128 *)X,           \
+                     (const c128 *)W, basis, basis_out, act, F, T, K, floor_kind, eps, plan, part, \
+                     fm, loss_out)
+#define SSSPY_BASIS_LAUNCH_M(HW, L, KS_)                                  \
+  switch (fmodel) {                                                       \
+    case FM_T: SSSPY_BASIS_LAUNCH(HW, FM_T, false, KS_); break; /* no by-product for the t model */ \
+    case FM_GGD: SSSPY_BASIS_LAUNCH(HW, FM_GGD, L, KS_); break;           \
+    case FM_GAUSS1: SSSPY_BASIS_LAUNCH(HW, FM_GAUSS1, L, KS_); break;     \
+    default: SSSPY_BASIS_LAUNCH(HW, FM_GAUSS, L, KS_); break;             \
   }
-  if (W != nullptr) {
-    if (loss_out) {
-      SSSPY_BASIS_LAUNCH_M(true, true)
+  if (ktiles == 2) {  // the wide variant carries no loss by-product (register budget)
+    if (W != nullptr) {
+      SSSPY_BASIS_LAUNCH_M(true, false, 8)
     } else {
-      SSSPY_BASIS_LAUNCH_M(true, false)
+      SSSPY_BASIS_LAUNCH_M(false, false, 8)
+    }
+  } else if (W != nullptr) {
+    if (loss_out) {
+      SSSPY_BASIS_LAUNCH_M(true, true, 4)
+    } else {
+      SSSPY_BASIS_LAUNCH_M(true, false, 4)
     }
   } else {
     if (loss_out) {
-      SSSPY_BASIS_LAUNCH_M(false, true)
+      SSSPY_BASIS_LAUNCH_M(false, true, 4)
     } else {
-      SSSPY_BASIS_LAUNCH_M(false, false)
+      SSSPY_BASIS_LAUNCH_M(false, false, 4)
     }
   }
 #undef SSSPY_BASIS_LAUNCH_M
 #undef SSSPY_BASIS_LAUNCH
   int rc = check_launch("k_basis_fast");
   if (rc || plan.tail == 0) return rc;
-  // split items' share of the loss by-product (never requested for the t model)
+  // split items' share of the loss by-product (never requested for the t model or the wide variant)
   const double loss_scale = (fmodel == FM_GGD ? 2.0 / fm.beta : 1.0) / (double)T;
   hipLaunchKernelGGL(k_basis_finalize, dim3(N * 64 * 16 / 256, plan.tail), block, 0, st, basis,
-                     part, F, K, plan, floor_kind, eps, fm.expo,
-                     fmodel != FM_T ? loss_out : (double *)nullptr, loss_scale);
+                     basis_out, part, F, K, plan, ktiles, floor_kind, eps, fm.expo,
+                     (fmodel != FM_T && ktiles == 1) ? loss_out : (double *)nullptr, loss_scale);
   return check_launch("k_basis_finalize");
 }
 
@@ -874,9 +947,31 @@ int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *
   const int ntiles = (F + 15) / 16;
   const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
   const FastModel fm = make_fast_model(fmodel, mparam, 0);
-  dim3 grid((T + 63) / 64, nchunks, B), block(256);
-  SSSPY_FAST_LAUNCH2(k_activation_fast, W != nullptr, (const c128 *)X,
-                     (const c128 *)W, basis, act, part, F, T, K, tiles_per_chunk, nchunks, fm);
+  const int ktiles = K > 16 ? 2 : 1;
+  dim3 grid((T + 63) / 64, nchunks * ktiles, B), block(256);
+#define SSSPY_ACT_LAUNCH(HW, M, KS_)                                                             \
+  hipLaunchKernelGGL((k_activation_fast<HW, M, KS_>), grid, block, 0, st, (const c128 *)X,        \
+                     (const c128 *)W, basis, act, part, F, T, K, tiles_per_chunk, nchunks, fm)
+#define SSSPY_ACT_LAUNCH_M(HW, KS_)                        \
+  switch (fmodel) {                                        \
+    case FM_T: SSSPY_ACT_LAUNCH(HW, FM_T, KS_); break;     \
+    case FM_GGD: SSSPY_ACT_LAUNCH(HW, FM_GGD, KS_); break; \
+    case FM_GAUSS1: SSSPY_ACT_LAUNCH(HW, FM_GAUSS1, KS_); break; \
+    default: SSSPY_ACT_LAUNCH(HW, FM_GAUSS, KS_); break;   \
+  }
+  if (ktiles == 2) {
+    if (W != nullptr) {
+      SSSPY_ACT_LAUNCH_M(true, 8)
+    } else {
+      SSSPY_ACT_LAUNCH_M(false, 8)
+    }
+  } else if (W != nullptr) {
+    SSSPY_ACT_LAUNCH_M(true, 4)
+  } else {
+    SSSPY_ACT_LAUNCH_M(false, 4)
+  }
+#undef SSSPY_ACT_LAUNCH_M
+#undef SSSPY_ACT_LAUNCH
   return check_launch("k_activation_fast");
 }
 
@@ -900,15 +995,22 @@ int LAUNCHER(ilrma_fast_wcov)(const void *X, const void *W, const double *basis,
   const TailPlan plan = make_tail_plan(B, (F + WC_BINS - 1) / WC_BINS, (T + 15) / 16);
   const FastModel fm = make_fast_model(fmodel, mparam, 0, floor_kind, floor_eps);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
-#define SSSPY_WCOV_LAUNCH(M)                                                                     \
-  hipLaunchKernelGGL(k_wcov_fast<M>, grid, block, 0, st, (const c128 *)X, (const c128 *)W, basis, \
-                     act, (c128 *)U, F, T, K, plan, (c128 *)upart, fm)
-  switch (fmodel) {
-    case FM_T: SSSPY_WCOV_LAUNCH(FM_T); break;
-    case FM_GGD: SSSPY_WCOV_LAUNCH(FM_GGD); break;
-    case FM_GAUSS1: SSSPY_WCOV_LAUNCH(FM_GAUSS1); break;
-    default: SSSPY_WCOV_LAUNCH(FM_GAUSS); break;
+#define SSSPY_WCOV_LAUNCH(M, KS_)                                                                 \
+  hipLaunchKernelGGL((k_wcov_fast<M, KS_>), grid, block, 0, st, (const c128 *)X, (const c128 *)W,  \
+                     basis, act, (c128 *)U, F, T, K, plan, (c128 *)upart, fm)
+#define SSSPY_WCOV_LAUNCH_M(KS_)                       \
+  switch (fmodel) {                                    \
+    case FM_T: SSSPY_WCOV_LAUNCH(FM_T, KS_); break;    \
+    case FM_GGD: SSSPY_WCOV_LAUNCH(FM_GGD, KS_); break; \
+    case FM_GAUSS1: SSSPY_WCOV_LAUNCH(FM_GAUSS1, KS_); break; \
+    default: SSSPY_WCOV_LAUNCH(FM_GAUSS, KS_); break;  \
   }
+  if (K > 16) {
+    SSSPY_WCOV_LAUNCH_M(8)
+  } else {
+    SSSPY_WCOV_LAUNCH_M(4)
+  }
+#undef SSSPY_WCOV_LAUNCH_M
 #undef SSSPY_WCOV_LAUNCH
   int rc = check_launch("k_wcov_fast");
   if (rc || plan.tail == 0) return rc;

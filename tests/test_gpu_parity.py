@@ -364,7 +364,7 @@ def test_heavy_tailed_ilrma_constructor_contract():
     assert "dof=3" in repr(TILRMA(n_basis=2, dof=3)) and repr(TILRMA(2, 3)).startswith("TILRMA(")
 
 
-@pytest.mark.parametrize("K", [1, 7, 16, 17, 40])
+@pytest.mark.parametrize("K", [1, 7, 16, 17, 24, 32, 33, 40, 100])
 def test_gauss_ilrma_n_basis_sweep_against_oracle(K):
     """n_basis off the 16-wide MFMA tile (1, 7), on it (16), and in the K>16 path (17, 40)."""
     from oracle.ilrma import GaussILRMAOracle
@@ -1279,3 +1279,98 @@ def test_fast_gauss_mnmf_general_shapes_against_oracle(M, N, algo):
     ms.normalize()
     for name in ("diagonalizer", "spatial", "basis", "activation"):
         assert rel_err(getattr(ms, name), getattr(mf, name)) < 1e-12, name
+
+
+def test_large_n_basis_partitioned_and_mnmf():
+    """n_basis above 64 (the former limit of the partitioning kernels' LDS tables): partitioned
+    GaussILRMA, FastGaussMNMF and GaussMNMF with 100 bases against the oracle."""
+    from oracle.gmnmf import GaussMNMFOracle
+    from oracle.ilrma import GaussILRMAOracle
+    from oracle.mnmf import FastGaussMNMFOracle
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.bss.mnmf import FastGaussMNMF, GaussMNMF
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    N, F, T, K = 3, 10, 40, 100
+    X = nmf_mixture(31, N, F, T)
+    rng = np.random.default_rng(7)
+    basis, act = rng.random((F, K)), rng.random((K, T))
+    latent = rng.random((N, K))
+    latent /= latent.sum(axis=0)
+    m = GaussILRMA(n_basis=K, partitioning=True)
+    Y = m(X, n_iter=3, basis=basis, activation=act, latent=latent)
+    ref = GaussILRMAOracle(n_basis=K, partitioning=True)
+    Yr = ref.run(X, n_iter=3, basis=basis, activation=act, latent=latent)
+    assert rel_err(Y, Yr) < TOL
+    np.testing.assert_allclose(m.loss, ref.loss, rtol=LOSS_RTOL)
+    b3, a3 = rng.random((N, F, K)), rng.random((N, K, T))
+    sp0 = rng.random((F, N, N))
+    mf = FastGaussMNMF(n_basis=K)
+    Yf = mf(X, n_iter=2, basis=b3, activation=a3, spatial=sp0)
+    rf = FastGaussMNMFOracle(n_basis=K)
+    Yfr = rf.run(X, n_iter=2, basis=b3, activation=a3, spatial=sp0.copy())
+    np.testing.assert_allclose(mf.loss, rf.loss, rtol=1e-8)
+    assert rel_err(Yf, Yfr) < 1e-6
+    mg = GaussMNMF(n_basis=K)
+    Yg = mg(X, n_iter=2, basis=b3, activation=a3)
+    rg = GaussMNMFOracle(n_basis=K)
+    Ygr = rg.run(X, n_iter=2, basis=b3, activation=a3)
+    np.testing.assert_allclose(mg.loss, rg.loss, rtol=1e-7)
+    assert rel_err(Yg, Ygr) < 1e-6
+
+
+@pytest.mark.parametrize("model,domain,algo,src", [(("gauss", None), 2, "IP", "MM"), (("gauss", None), 1, "IP", "MM"),
+                                                   (("t", 4.0), 2, "IP", "MM"), (("ggd", 1.3), 2, "IP", "MM"),
+                                                   (("gauss", None), 2, "ISS", "MM"), (("gauss", None), 2, "IP", "ME"),
+                                                   (("t", 4.0), 2, "IP2", "MM")])
+@pytest.mark.parametrize("K,T", [(20, 50), (32, 33)])
+def test_ilrma_wide_basis_tuned_path_against_oracle(model, domain, algo, src, K, T):
+    """16 < n_basis <= 32 on the tuned kernels (two k-tile work items per bin group; basis written out
+    of place): every source model, filter and ISS states, odd frame counts, a batch that mixes whole
+    rounds and split tail items."""
+    from oracle.ilrma import GaussILRMAOracle
+
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    N, F, B = 3, 70, 2
+    rng = np.random.default_rng(K + T)
+    X = np.stack([nmf_mixture(500 + b, N, F, T) for b in range(B)])
+    basis, act = rng.random((B, N, F, K)), rng.random((B, N, K, T))
+    cls = _ilrma_class(model)
+    kw = dict(n_basis=K, spatial_algorithm=algo, domain=domain, source_algorithm=src)
+    if model[0] == "t":
+        kw["dof"] = model[1]
+    elif model[0] == "ggd":
+        kw["beta"] = model[1]
+    m = cls(**kw)
+    Y = m(X, n_iter=3, basis=basis, activation=act)
+    for b in range(B):
+        ref = GaussILRMAOracle(n_basis=K, spatial_algorithm=algo, domain=domain, model=model,
+                               source_algorithm=src)
+        Yr = ref.run(X[b], n_iter=3, basis=basis[b], activation=act[b])
+        np.testing.assert_allclose(np.asarray(m.loss)[:, b], ref.loss, rtol=LOSS_RTOL)
+        assert rel_err(m.basis[b], ref.basis) < TOL and rel_err(m.activation[b], ref.activation) < TOL
+        if algo == "IP2":
+            assert rel_err(Y[b], Yr) < 1e-7
+        else:
+            assert rel_err(Y[b], Yr) < TOL
+
+
+def test_ilrma_wide_basis_large_batch():
+    """n_basis = 24 with 300 tiny mixtures: more work items than resident workgroups, so the launch
+    has whole rounds and a split tail; first / middle / last mixture against the oracle."""
+    from oracle.ilrma import GaussILRMAOracle
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    B, N, F, T, K = 300, 4, 70, 40, 24
+    rng = np.random.default_rng(9)
+    X = np.stack([nmf_mixture(9000 + b, N, F, T) for b in range(B)])
+    basis, act = rng.random((B, N, F, K)), rng.random((B, N, K, T))
+    m = GaussILRMA(n_basis=K)
+    Y = m(X, n_iter=2, basis=basis, activation=act)
+    for b in (0, 150, B - 1):
+        ref = GaussILRMAOracle(n_basis=K)
+        Yr = ref.run(X[b], n_iter=2, basis=basis[b], activation=act[b])
+        assert rel_err(Y[b], Yr) < TOL
+        np.testing.assert_allclose(np.asarray(m.loss)[:, b], ref.loss, rtol=LOSS_RTOL)
