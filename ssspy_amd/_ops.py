@@ -13,8 +13,41 @@ def _L():
     return _lib.load()
 
 
-def _st():
-    return dv.stream_handle()
+# ---- workspace allocation.  With SSSPY_AMD_WS_CANARY=1 (the GPU tests set it) every workspace gets
+# a guard band behind it, filled with a pattern that check_workspace_canaries() verifies: a kernel
+# that writes past the size the C ABI asked for is caught instead of corrupting a neighbour.
+import os as _os
+
+_CANARY_DOUBLES = 4096 if _os.environ.get("SSSPY_AMD_WS_CANARY") else 0
+_CANARY_VALUE = -7.25e300
+_canaries = []
+
+
+def _workspace(nbytes, dev):
+    n = (int(nbytes) + 7) // 8
+    buf = dv.empty((n + _CANARY_DOUBLES,), dv.f64, dev)
+    if not _CANARY_DOUBLES:
+        return buf, int(nbytes)
+    import weakref
+
+    buf[n:].fill_(_CANARY_VALUE)
+    view = buf[:n]
+    view._guard = buf[n:]  # keeps the band addressable for as long as the workspace lives
+    _canaries.append((weakref.ref(view), n))
+    return view, int(nbytes)
+
+
+def check_workspace_canaries():
+    """Raise if anything wrote behind a live workspace (only active with SSSPY_AMD_WS_CANARY=1)."""
+    alive = []
+    for ref, n in _canaries:
+        view = ref()
+        if view is None:
+            continue
+        alive.append((ref, n))
+        if not bool((view._guard == _CANARY_VALUE).all().item()):
+            raise RuntimeError("a kernel wrote past the end of a {}-byte workspace".format(8 * n))
+    _canaries[:] = alive
 
 
 def separate(X, W, out=None):
@@ -196,8 +229,7 @@ def sum_logdet(W, out=None):
 
 # ----------------------------------------------------------------------------- ILRMA
 def ilrma_workspace(B, N, F, T, K, dev):
-    nbytes = int(_L().ssspy_ilrma_workspace_bytes(B, N, F, T, K))
-    return dv.empty(((nbytes + 7) // 8,), dv.f64, dev), nbytes
+    return _workspace(_L().ssspy_ilrma_workspace_bytes(B, N, F, T, K), dev)
 
 
 GAUSS = (_lib.SOURCE_GAUSS, 0.0)  # source model as (SSSPY_SOURCE_*, model_param); see include/ssspy_amd.h
@@ -390,8 +422,7 @@ def iva_loss_data(r2, variance, n_bins, contrast, out=None):
 
 # ----------------------------------------------------------------------------- FastMNMF
 def fastmnmf_workspace(B, N, M, F, T, K, dev):
-    nbytes = int(_L().ssspy_fastmnmf_workspace_bytes(B, N, M, F, T, K))
-    return dv.empty(((nbytes + 7) // 8,), dv.f64, dev), nbytes
+    return _workspace(_L().ssspy_fastmnmf_workspace_bytes(B, N, M, F, T, K), dev)
 
 
 def fastmnmf_update(X, C, Q, D, basis, activation, steps, flooring, ws, ws_bytes, info):
@@ -462,8 +493,7 @@ def fastmnmf_separate(X, Q, D, basis, activation, reference_id, flooring, ws, ws
 
 # ------------------------------------------------------------------------- GaussMNMF
 def gmnmf_workspace(B, N, M, F, T, K, dev):
-    nbytes = int(_L().ssspy_gmnmf_workspace_bytes(B, N, M, F, T, K))
-    return dv.empty(((nbytes + 7) // 8,), dv.f64, dev), nbytes
+    return _workspace(_L().ssspy_gmnmf_workspace_bytes(B, N, M, F, T, K), dev)
 
 
 def gmnmf_update(X, basis, activation, spatial, steps, flooring, ws, ws_bytes, latent=None):

@@ -185,6 +185,9 @@ class DeviceStateMixin:
         return info
 
     def _check_device_errors(self):
+        from .. import _ops
+
+        _ops.check_workspace_canaries()  # no-op unless SSSPY_AMD_WS_CANARY is set
         info = self.__dict__.get("_info")
         if info is not None:
             count = int(info.item())  # synchronises

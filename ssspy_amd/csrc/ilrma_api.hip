@@ -65,6 +65,18 @@ static inline bool fast_path(int N, int F, int T, int K, double domain,
 }
 static inline int is_me(int source_model) { return (source_model & SSSPY_SOURCE_ME) ? 1 : 0; }
 
+// More than 4 sources on the tuned NMF passes: the multiplicative updates of source n need only
+// |y_n|^2 and (T_n, V_n), and (B, N, ...) tensors are (B N / G, G, ...) tensors in memory, so a wide
+// mixture is walked as N / G "mixtures" of G sources over the separated spectrogram y = W x (formed
+// once by ssspy_separate; the ISS / IPA state is y already).  Returns the group size G (4, 3 or 2)
+// or 0 when the shape has none (N <= 4, N = 5 or 7, or the model / n_basis is off the tuned path).
+static inline int source_group(int N, int F, int T, int K, double domain, int source_model) {
+  if (N <= 4) return 0;
+  for (int G = 4; G >= 2; --G)
+    if (N % G == 0 && fast_path(G, F, T, K, domain, source_model)) return G;
+  return 0;
+}
+
 static inline int check_model(int source_model, double param, double domain = 2.0) {
   const int model = source_model & 0xff;
   const bool me = (source_model & SSSPY_SOURCE_ME) != 0;
@@ -120,8 +132,10 @@ int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, i
 
 // scratch of the bin-major fast kernels (basis, covariance): partial sums of the at most 512
 // split blocks of the last scheduling round (TailPlan in ilrma_fast.hip)
+// (wide mixtures run them in groups of at most 4 sources, see source_group())
 static inline size_t basis_part_bytes(int N) {
-  return N <= 4 ? align256((size_t)512 * N * 64 * 16 * 2 * sizeof(double)) : 0;
+  const int G = N < 4 ? N : 4;
+  return align256((size_t)512 * G * 64 * 16 * 2 * sizeof(double));
 }
 static inline size_t u_part_bytes(int N) {
   return N <= 4 ? align256((size_t)512 * 64 * N * N * N * 2 * sizeof(double)) : 0;
@@ -407,7 +421,7 @@ extern "C" {
 
 // One scratch layout for every ILRMA entry point: callers pass the same buffer everywhere.
 struct IlrmaWs {
-  size_t act_part, btmp, qbuf, psi, bpart, upart, praw, total;
+  size_t act_part, btmp, qbuf, psi, bpart, upart, praw, ybuf, total;
 };
 static inline IlrmaWs ilrma_ws(int B, int N, int F, int T, int K) {
   IlrmaWs w;
@@ -426,6 +440,8 @@ static inline IlrmaWs ilrma_ws(int B, int N, int F, int T, int K) {
   off += u_part_bytes(N);
   w.praw = off;  // (num, den) basis sums of the partitioned updates
   off += align256((size_t)B * N * F * K * 2 * sizeof(double));
+  w.ybuf = off;  // y = W x of a wide mixture (more than 4 sources), see source_group()
+  off += N > 4 ? align256((size_t)B * N * F * T * 2 * sizeof(double)) : 0;
   w.total = off;
   return w;
 }
@@ -463,6 +479,18 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
   // above 16 bases the update cannot be in place (several items per bin group read the old basis)
   double *out = K > 16 ? (double *)(ws + w.btmp) : basis;
   auto run = [&]() -> int {
+    if (const int G = source_group(N, F, T, K, domain, source_model)) {
+      const void *Y = X;
+      if (W) {
+        int r = ssspy_separate(X, W, ws + w.ybuf, B, N, F, T, stream);
+        if (r) return r;
+        Y = ws + w.ybuf;
+      }
+      ILRMA_FAST_DISPATCH(G, ilrma_fast_basis, Y, nullptr, basis, out, activation, B * (N / G), F, T,
+                          K, floor_kind, floor_eps, (double *)(ws + w.bpart),
+                          fast_model_id(domain, source_model), model_param, is_me(source_model),
+                          nullptr, st);
+    }
     if (fast_path(N, F, T, K, domain, source_model)) {
       if (loss_done) *loss_done = loss_out != nullptr && K <= 16;
       ILRMA_FAST_DISPATCH(N, ilrma_fast_basis, X, W, basis, out, activation, B, F, T, K, floor_kind,
@@ -509,6 +537,18 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
   hipStream_t st = as_stream(stream);
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   auto run = [&]() -> int {
+    if (const int G = source_group(N, F, T, K, domain, source_model)) {
+      // (the partial sums keep their (mixture, chunk, source) layout: B N / G mixtures of G sources
+      // with the same chunk count are the same array)
+      const void *Y = X;
+      if (W) {
+        int r = ssspy_separate(X, W, (char *)workspace + w.ybuf, B, N, F, T, stream);
+        if (r) return r;
+        Y = (char *)workspace + w.ybuf;
+      }
+      ILRMA_FAST_DISPATCH(G, ilrma_fast_activation, Y, nullptr, basis, activation, part, chunks,
+                          B * (N / G), F, T, K, fast_model_id(domain, source_model), model_param, st);
+    }
     if (fast_path(N, F, T, K, domain, source_model)) {
       ILRMA_FAST_DISPATCH(N, ilrma_fast_activation, X, W, basis, activation, part, chunks, B, F, T,
                           K, fast_model_id(domain, source_model), model_param, st);
@@ -517,9 +557,13 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
   };
   rc = run();
   if (rc) return rc;
-  dim3 g2((unsigned)(((long long)K * T + 255) / 256), N, B);
+  // fold the chunks in the layout the kernel wrote: (mixture, chunk, source) of the regrouped batch
+  // when the wide-mixture path ran
+  const int G = source_group(N, F, T, K, domain, source_model);
+  const int Nf = G ? G : N, Bf = G ? B * (N / G) : B;
+  dim3 g2((unsigned)(((long long)K * T + 255) / 256), Nf, Bf);
   hipLaunchKernelGGL(k_ilrma_activation_finalize, g2, dim3(256), 0, st, activation,
-                     (const double *)part, N, K, T, chunks, d);
+                     (const double *)part, Nf, K, T, chunks, d);
   return check_launch("k_ilrma_activation_finalize");
 }
 
@@ -656,12 +700,21 @@ static int ip1_update_impl(const void *X, const void *C, void *W, double *basis,
     if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
   }
   bool loss_done = false;
-  rc = update_basis_impl(X, W, basis, activation, B, N, F, T, K, domain, source_model, model_param,
-                         floor_kind, floor_eps, workspace, workspace_bytes, loss_data, &loss_done,
-                         stream);
+  // wide mixture on the grouped path: y = W x once for both NMF passes (they then see the ISS-style
+  // state: the spectrogram itself, no filter)
+  const void *Xs = X, *Ws = W;
+  if (source_group(N, F, T, K, domain, source_model)) {
+    rc = ssspy_separate(X, W, ws + w.ybuf, B, N, F, T, stream);
+    if (rc) return rc;
+    Xs = ws + w.ybuf;
+    Ws = nullptr;
+  }
+  rc = update_basis_impl(Xs, Ws, basis, activation, B, N, F, T, K, domain, source_model,
+                         model_param, floor_kind, floor_eps, workspace, workspace_bytes, loss_data,
+                         &loss_done, stream);
   if (rc) return rc;
   if (loss_data && !loss_done) return fail(SSSPY_ERR_UNSUPPORTED, "ilrma_ip1_update: no loss by-product");
-  rc = ssspy_ilrma_update_activation(X, W, basis, activation, B, N, F, T, K, domain, source_model,
+  rc = ssspy_ilrma_update_activation(Xs, Ws, basis, activation, B, N, F, T, K, domain, source_model,
                                      model_param, floor_kind, floor_eps, workspace, workspace_bytes,
                                      stream);
   if (rc) return rc;

@@ -4,6 +4,9 @@ import sys
 import numpy as np
 import pytest
 
+# guard bands behind every device workspace, verified whenever a separator syncs with the host
+os.environ.setdefault("SSSPY_AMD_WS_CANARY", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1374,3 +1374,47 @@ def test_ilrma_wide_basis_large_batch():
         Yr = ref.run(X[b], n_iter=2, basis=basis[b], activation=act[b])
         assert rel_err(Y[b], Yr) < TOL
         np.testing.assert_allclose(np.asarray(m.loss)[:, b], ref.loss, rtol=LOSS_RTOL)
+
+
+@pytest.mark.parametrize("model,N,algo,K", [(("gauss", None), 6, "IP", 5), (("gauss", None), 8, "IP", 16),
+                                            (("gauss", None), 8, "ISS", 7), (("t", 5.0), 8, "IP", 4),
+                                            (("ggd", 1.4), 6, "IP2", 6), (("gauss", None), 8, "IP", 24)])
+def test_ilrma_wide_mixture_grouped_sources_against_oracle(model, N, algo, K):
+    """6 or 8 sources: the NMF passes walk the separated spectrogram as N / G groups of G <= 4 sources
+    through the tuned kernels (y = W x formed once per iteration).  Batch of two against the oracle;
+    the step methods against the fused update."""
+    from oracle.ilrma import GaussILRMAOracle
+
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    F, T, B = 40, 60, 2
+    rng = np.random.default_rng(N * 10 + K)
+    X = np.stack([nmf_mixture(600 + b, N, F, T) for b in range(B)])
+    basis, act = rng.random((B, N, F, K)), rng.random((B, N, K, T))
+    cls = _ilrma_class(model)
+    kw = dict(n_basis=K, spatial_algorithm=algo)
+    if model[0] == "t":
+        kw["dof"] = model[1]
+    elif model[0] == "ggd":
+        kw["beta"] = model[1]
+    m = cls(**kw)
+    Y = m(X, n_iter=3, basis=basis, activation=act)
+    for b in range(B):
+        ref = GaussILRMAOracle(n_basis=K, spatial_algorithm=algo, model=model)
+        Yr = ref.run(X[b], n_iter=3, basis=basis[b], activation=act[b])
+        np.testing.assert_allclose(np.asarray(m.loss)[:, b], ref.loss, rtol=LOSS_RTOL)
+        assert rel_err(m.basis[b], ref.basis) < TOL and rel_err(m.activation[b], ref.activation) < TOL
+        assert rel_err(Y[b], Yr) < (1e-7 if algo == "IP2" else TOL)
+    if algo == "IP":
+        ms = cls(**kw)
+        ms._bind_input(X)
+        ms._reset(flooring_fn=ms.flooring_fn, basis=basis, activation=act)
+        mf = cls(**kw)
+        mf._bind_input(X)
+        mf._reset(flooring_fn=mf.flooring_fn, basis=basis, activation=act)
+        mf.update_once()
+        ms.update_source_model()
+        ms.update_spatial_model()
+        ms.normalize()
+        for name in ("demix_filter", "basis", "activation"):
+            assert rel_err(getattr(ms, name), getattr(mf, name)) < 1e-12, name
