@@ -50,6 +50,10 @@ def check_workspace_canaries():
     _canaries[:] = alive
 
 
+def _st():
+    return dv.stream_handle()
+
+
 def separate(X, W, out=None):
     B, N, F, T = X.shape
     if out is None:
