@@ -71,3 +71,46 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "oracle/" not in src and "oracle." not in src.replace("the oracle.", ""), f
+
+
+def test_host_modules_have_no_undefined_names():
+    """Every global name the host-side wrappers refer to exists (the device paths cannot run in the
+    CPU suite, so a helper dropped by an edit would otherwise surface only on the GPU box)."""
+    import ast
+    import builtins
+    import importlib
+    import pkgutil
+
+    import ssspy_amd
+
+    def bound_names(fn):
+        names = {a.arg for a in ast.walk(fn) if isinstance(a, ast.arg)}
+        for node in ast.walk(fn):
+            if isinstance(node, ast.Name) and isinstance(node.ctx, ast.Store):
+                names.add(node.id)
+            elif isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+                names.add(node.name)
+            elif isinstance(node, (ast.Import, ast.ImportFrom)):
+                names.update((a.asname or a.name).split(".")[0] for a in node.names)
+            elif isinstance(node, ast.ExceptHandler) and node.name:
+                names.add(node.name)
+        return names
+
+    def visit(node, enclosing, scope, where):
+        for child in ast.iter_child_nodes(node):
+            if isinstance(child, (ast.FunctionDef, ast.Lambda)):
+                visible = enclosing | bound_names(child)
+                for sub in ast.walk(child):
+                    if isinstance(sub, ast.Name) and isinstance(sub.ctx, ast.Load):
+                        assert sub.id in visible or sub.id in scope, \
+                            "{}: undefined name {!r} (line {})".format(where, sub.id, sub.lineno)
+                visit(child, visible, scope, where)
+            else:
+                visit(child, enclosing, scope, where)
+
+    for info in pkgutil.walk_packages(ssspy_amd.__path__, "ssspy_amd."):
+        if info.name.endswith("_build"):
+            continue
+        mod = importlib.import_module(info.name)
+        tree = ast.parse(open(mod.__file__).read())
+        visit(tree, set(), set(dir(mod)) | set(dir(builtins)), info.name)
