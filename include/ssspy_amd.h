@@ -371,6 +371,23 @@ int ssspy_fastmnmf_update(const void *X, const void *C, void *Q, double *D, doub
                           int floor_kind, double floor_eps, void *workspace, size_t workspace_bytes,
                           int *info, void *stream);
 
+/* The same steps with the |(Q x)_m|^2 hand-over: the reference recomputes Q x in every one of
+ * update_basis / update_activation / update_spatial (mnmf.py:1329-1331, :1386-1388, :1659-1661);
+ * here the spatial pass stores |Q x|^2 and the next iteration's basis and activation passes read
+ * it (half the bytes of x, no M x M products).  `handover`: ssspy_fastmnmf_handover_doubles()
+ * doubles owned by the caller -- |Q x|^2 (B,M,F,T) followed by a per-(mixture, channel) scale
+ * (B,M) that absorbs the power normalisation.  *handover_valid (host): on entry, whether the
+ * buffer matches the Q and X passed in (0 on the first call or after the caller changed Q or X:
+ * it is then rebuilt when a step needs it); on return, whether it matches Q on exit.
+ * ssspy_fastmnmf_handover_doubles() is 0 for shapes without the hand-over (use
+ * ssspy_fastmnmf_update). */
+size_t ssspy_fastmnmf_handover_doubles(int B, int N, int M, int F, int T, int K);
+int ssspy_fastmnmf_update_handover(const void *X, const void *C, void *Q, double *D, double *basis,
+                                   double *activation, int B, int N, int M, int F, int T, int K,
+                                   int steps, int floor_kind, double floor_eps, void *workspace,
+                                   size_t workspace_bytes, int *info, double *handover,
+                                   int *handover_valid, void *stream);
+
 /* U[b,i,m] = (1/T) sum_j x x^H / R~_ijm  -> (B,F,M,M,M): the covariances the diagonaliser update
  * (IP1 inside ssspy_fastmnmf_update, or ssspy_update_by_ip2 for diagonalizer_algorithm="IP2") needs.
  * replaces: ssspy/bss/mnmf.py:1504-1512, :1621-1629. */

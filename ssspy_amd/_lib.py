@@ -89,6 +89,9 @@ PROTOTYPES = {
     "ssspy_fastmnmf_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "ssspy_fastmnmf_update": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p,
                                    _z, _p, _p]),
+    "ssspy_fastmnmf_handover_doubles": (_z, [_i, _i, _i, _i, _i, _i]),
+    "ssspy_fastmnmf_update_handover": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d,
+                                            _p, _z, _p, _p, _p, _p]),
     "ssspy_fastmnmf_diagonalizer_covariance": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ssspy_fastmnmf_loss_data": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ssspy_fastmnmf_weights": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

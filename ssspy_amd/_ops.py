@@ -440,6 +440,32 @@ def fastmnmf_update(X, C, Q, D, basis, activation, steps, flooring, ws, ws_bytes
     )
 
 
+def fastmnmf_handover(B, N, M, F, T, K, dev):
+    """The |Q x|^2 hand-over buffer of ssspy_fastmnmf_update_handover, or None for shapes without it."""
+    n = _L().ssspy_fastmnmf_handover_doubles(B, N, M, F, T, K)
+    if not n or _os.environ.get("SSSPY_AMD_NO_HANDOVER"):
+        return None
+    return _workspace(8 * n, dev)[0]
+
+
+def fastmnmf_update_handover(X, C, Q, D, basis, activation, steps, flooring, ws, ws_bytes, info,
+                             handover, valid):
+    """`valid`: whether `handover` matches (Q, X); returns whether it does afterwards."""
+    import ctypes
+
+    B, M, F, T = X.shape
+    N, K = basis.shape[1], basis.shape[-1]
+    flag = ctypes.c_int(1 if valid else 0)
+    _lib.check(
+        _L().ssspy_fastmnmf_update_handover(
+            ptr(X), ptr(C), ptr(Q), ptr(D), ptr(basis), ptr(activation), B, N, M, F, T, K, steps,
+            flooring[0], flooring[1], ptr(ws), ws_bytes, ptr(info), ptr(handover),
+            ctypes.cast(ctypes.pointer(flag), ctypes.c_void_p), _st()),
+        "fastmnmf_update_handover",
+    )
+    return bool(flag.value)
+
+
 def fastmnmf_diagonalizer_covariance(X, D, basis, activation, out=None):
     B, M, F, T = X.shape
     N, K = basis.shape[1], basis.shape[-1]

@@ -150,6 +150,10 @@ class FastMNMFBase(MNMFBase):
         self._init_spatial(flooring_fn=flooring_fn, rng=self.rng)
         self._ws, self._ws_bytes = _ops.fastmnmf_workspace(B, N, M, F, T, self.n_basis,
                                                            self._X.device)
+        # |Q x|^2 handed from the spatial pass to the next basis / activation passes (None for
+        # shapes without it); valid while neither the diagonaliser nor the input moved under it
+        self._handover = _ops.fastmnmf_handover(B, N, M, F, T, self.n_basis, self._X.device)
+        self._handover_key = None
         self._separate_dev()
 
     def _init_diagonalizer(self, rng=None) -> None:
@@ -179,13 +183,22 @@ class FastMNMFBase(MNMFBase):
 
     def _update(self, steps, flooring_fn="self") -> None:
         need_c = bool(steps & _lib.MNMF_NORMALIZE)
-        _ops.fastmnmf_update(
+        args = (
             self._X, self._C() if need_c else None, self._state_dev("diagonalizer"),
             self._state_dev("spatial"), self._state_dev("basis"), self._state_dev("activation"),
             steps, self._resolve_floor(flooring_fn), self._ws, self._ws_bytes, self._info_tensor(),
         )
+        handover = getattr(self, "_handover", None)
+        if handover is None:
+            _ops.fastmnmf_update(*args)
+            valid = False
+        else:
+            key = (self._state_rev("diagonalizer"), self._X.data_ptr())
+            valid = _ops.fastmnmf_update_handover(*args, handover, self._handover_key == key)
         for name in ("diagonalizer", "spatial", "basis", "activation"):
             self._state_touch(name)
+        self._handover_key = (
+            (self._state_rev("diagonalizer"), self._X.data_ptr()) if valid else None)
 
     def normalize(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/mnmf.py:602-630."""

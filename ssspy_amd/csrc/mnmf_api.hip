@@ -4,19 +4,23 @@
 namespace ssspy {
 
 #define DECL_N(n)                                                                                \
+  int mnmf_handover_ok_n##n(int, int, int, int);                                                \
+  int mnmf_qx2_n##n(const void *, const void *, double *, double *, int, int, int, int,         \
+                    hipStream_t);                                                               \
   int mnmf_basis_n##n(const void *, const void *, const double *, const double *, double *,     \
                       const double *, int, int, int, int, int, int, double, double *,           \
-                      hipStream_t);                                                             \
+                      const double *, const double *, hipStream_t);                             \
   int mnmf_activation_n##n(const void *, const void *, const double *, const double *,          \
-                           const double *, double *, int, int, int, int, int, int, hipStream_t); \
+                           const double *, double *, int, int, int, int, int, int,              \
+                           const double *, const double *, hipStream_t);                        \
   int mnmf_wcov_n##n(const void *, const double *, const double *, const double *, void *, int, \
                      int, int, int, int, double *, hipStream_t);                                \
   int mnmf_spatial_n##n(const void *, const void *, double *, const double *, const double *,   \
-                        int, int, int, int, int, double *, hipStream_t);                        \
+                        int, int, int, int, int, double *, double *, double *, hipStream_t);    \
   int mnmf_loss_n##n(const void *, const void *, const double *, const double *, const double *, \
                      double *, int, int, int, int, int, hipStream_t);                           \
   int mnmf_norm_scale_n##n(void *, double *, const double *, int, int, int, int, double,        \
-                           hipStream_t);                                                        \
+                           double *, hipStream_t);                                              \
   int mnmf_separate_n##n(const void *, const void *, void *, const double *, const double *,    \
                          const double *, void *, int, int, int, int, int, int, int, double,     \
                          int *, hipStream_t);
@@ -118,13 +122,15 @@ __global__ __launch_bounds__(256) void k_mnmf_activation_finalize(double *act,
   *dst = apply_floor((*dst) * sqrt(sn / sd), floor_kind, eps);
 }
 
+// P / pscale: the |Q x|^2 hand-over (nullptr: the pass reads x and Q)
 static int step_basis(const void *X, const void *Q, const double *D, double *basis,
                       const double *act, int B, int N, int M, int F, int T, int K, int fk,
-                      double eps, char *ws, const MnmfWs &w, hipStream_t st) {
+                      double eps, char *ws, const MnmfWs &w, const double *P,
+                      const double *pscale, hipStream_t st) {
   double *out = K > 16 ? (double *)(ws + w.btmp) : basis;
   auto run = [&]() -> int {
     MNMF_DISPATCH(N, mnmf_basis, X, Q, D, basis, out, act, B, M, F, T, K, fk, eps,
-                  (double *)(ws + w.tail), st);
+                  (double *)(ws + w.tail), P, pscale, st);
   };
   int rc = run();
   if (rc) return rc;
@@ -138,11 +144,13 @@ static int step_basis(const void *X, const void *Q, const double *D, double *bas
 
 static int step_activation(const void *X, const void *Q, const double *D, const double *basis,
                            double *act, int B, int N, int M, int F, int T, int K, int fk,
-                           double eps, char *ws, const MnmfWs &w, hipStream_t st) {
+                           double eps, char *ws, const MnmfWs &w, const double *P,
+                           const double *pscale, hipStream_t st) {
   const int chunks = mnmf_chunks(B, F, T, K);
   double *part = (double *)(ws + w.part);
   auto run = [&]() -> int {
-    MNMF_DISPATCH(N, mnmf_activation, X, Q, D, basis, act, part, chunks, B, M, F, T, K, st);
+    MNMF_DISPATCH(N, mnmf_activation, X, Q, D, basis, act, part, chunks, B, M, F, T, K, P, pscale,
+                  st);
   };
   int rc = run();
   if (rc) return rc;
@@ -150,6 +158,100 @@ static int step_activation(const void *X, const void *Q, const double *D, const 
   hipLaunchKernelGGL(k_mnmf_activation_finalize, g2, dim3(256), 0, st, act, part, N, K, T, chunks,
                      fk, eps);
   return check_launch("k_mnmf_activation_finalize");
+}
+
+static int handover_ok(int B, int N, int M, int F, int T, int K) {
+  if (!mnmf_tiled(N, M)) return 0;
+  MNMF_DISPATCH(N, mnmf_handover_ok, B, F, T, K);
+}
+static int handover_fill(const void *X, const void *Q, double *P, double *pscale, int B, int N,
+                         int M, int F, int T, hipStream_t st) {
+  MNMF_DISPATCH(N, mnmf_qx2, X, Q, P, pscale, B, M, F, T, st);
+}
+
+// One iteration (or a subset of its steps).  `handover` (optional): |Q x|^2 (B, M, F, T) followed
+// by its per-(mixture, channel) scale (B, M); *valid says whether it matches Q and x on entry and,
+// on return, on exit.
+static int fastmnmf_update_impl(const void *X, const void *C, void *Q, double *D, double *basis,
+                                double *activation, int B, int N, int M, int F, int T, int K,
+                                int steps, int floor_kind, double floor_eps, void *workspace,
+                                size_t workspace_bytes, int *info, double *handover, int *valid,
+                                hipStream_t st) {
+  SSSPY_REQUIRE(X && Q && D && basis && activation && B > 0 && F > 0 && T > 0,
+                "fastmnmf_update: bad argument");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_update: n_basis must be in [1, 256]");
+  const MnmfWs w = mnmf_ws(B, N, M, F, T, K);
+  SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "fastmnmf_update: workspace too small");
+  SSSPY_REQUIRE(!(steps & SSSPY_MNMF_NORMALIZE) || C, "fastmnmf_update: normalisation needs C");
+  char *ws = (char *)workspace;
+  int rc = SSSPY_OK;
+  if (!mnmf_tiled(N, M)) {
+    SSSPY_REQUIRE(!handover, "fastmnmf_update: no hand-over for this shape");
+    return fmnmf_generic_update(X, C, Q, D, basis, activation, B, N, M, F, T, K, steps, floor_kind,
+                                floor_eps, (double *)(ws + w.generic), ws + w.U,
+                                (double *)(ws + w.qbuf), info, st);
+  }
+  double *P = handover, *pscale = handover ? handover + (size_t)B * M * F * T : nullptr;
+  if (handover) {
+    SSSPY_REQUIRE(valid, "fastmnmf_update: hand-over without its validity flag");
+    SSSPY_REQUIRE(handover_ok(B, N, M, F, T, K) == 1, "fastmnmf_update: no hand-over for this shape");
+  }
+  bool have_p = handover && *valid;
+  if (handover && !have_p && (steps & (SSSPY_MNMF_BASIS | SSSPY_MNMF_ACTIVATION))) {
+    rc = handover_fill(X, Q, P, pscale, B, N, M, F, T, st);
+    if (rc) return rc;
+    have_p = true;
+  }
+  if (valid) *valid = 0;  // until the call is through
+  if (steps & SSSPY_MNMF_BASIS) {
+    rc = step_basis(X, Q, D, basis, activation, B, N, M, F, T, K, floor_kind, floor_eps, ws, w,
+                    have_p ? P : nullptr, pscale, st);
+    if (rc) return rc;
+  }
+  if (steps & SSSPY_MNMF_ACTIVATION) {
+    rc = step_activation(X, Q, D, basis, activation, B, N, M, F, T, K, floor_kind, floor_eps, ws, w,
+                         have_p ? P : nullptr, pscale, st);
+    if (rc) return rc;
+  }
+  double *qbuf = (double *)(ws + w.qbuf);
+  bool have_q = false;
+  if (steps & SSSPY_MNMF_DIAGONALIZER) {
+    void *U = ws + w.U;
+    auto run = [&]() -> int {
+      MNMF_DISPATCH(N, mnmf_wcov, X, D, basis, activation, U, B, M, F, T, K,
+                    (double *)(ws + w.tail), st);
+    };
+    rc = run();
+    if (rc) return rc;
+    // IP1 on the M x M diagonaliser with M weighted covariances per bin
+    rc = ip1_with_power(Q, U, C, C ? qbuf : nullptr, B, F, M, floor_kind, floor_eps, info, st);
+    if (rc) return rc;
+    have_q = C != nullptr;
+    have_p = false;  // Q moved
+  }
+  if (steps & SSSPY_MNMF_SPATIAL) {
+    auto run = [&]() -> int {
+      MNMF_DISPATCH(N, mnmf_spatial, X, Q, D, basis, activation, B, M, F, T, K,
+                    (double *)(ws + w.tail), P, pscale, st);
+    };
+    rc = run();
+    if (rc) return rc;
+    have_p = handover != nullptr;  // written with the Q of this pass, scale 1
+  }
+  if (steps & SSSPY_MNMF_NORMALIZE) {
+    if (!have_q) {
+      rc = row_power(Q, C, qbuf, B, F, M, st);
+      if (rc) return rc;
+    }
+    auto run = [&]() -> int {
+      MNMF_DISPATCH(N, mnmf_norm_scale, Q, D, qbuf, B, M, F, floor_kind, floor_eps,
+                    have_p ? pscale : nullptr, st);
+    };
+    rc = run();
+    if (rc) return rc;
+  }
+  if (valid) *valid = have_p ? 1 : 0;
+  return rc;
 }
 
 }  // namespace ssspy
@@ -167,62 +269,26 @@ int ssspy_fastmnmf_update(const void *X, const void *C, void *Q, double *D, doub
                           double *activation, int B, int N, int M, int F, int T, int K, int steps,
                           int floor_kind, double floor_eps, void *workspace, size_t workspace_bytes,
                           int *info, void *stream) {
-  SSSPY_REQUIRE(X && Q && D && basis && activation && B > 0 && F > 0 && T > 0,
-                "fastmnmf_update: bad argument");
-  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_update: n_basis must be in [1, 256]");
-  const MnmfWs w = mnmf_ws(B, N, M, F, T, K);
-  SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "fastmnmf_update: workspace too small");
-  SSSPY_REQUIRE(!(steps & SSSPY_MNMF_NORMALIZE) || C, "fastmnmf_update: normalisation needs C");
-  hipStream_t st = as_stream(stream);
-  char *ws = (char *)workspace;
-  int rc = SSSPY_OK;
-  if (!mnmf_tiled(N, M))
-    return fmnmf_generic_update(X, C, Q, D, basis, activation, B, N, M, F, T, K, steps, floor_kind,
-                                floor_eps, (double *)(ws + w.generic), ws + w.U,
-                                (double *)(ws + w.qbuf), info, st);
-  if (steps & SSSPY_MNMF_BASIS) {
-    rc = step_basis(X, Q, D, basis, activation, B, N, M, F, T, K, floor_kind, floor_eps, ws, w, st);
-    if (rc) return rc;
-  }
-  if (steps & SSSPY_MNMF_ACTIVATION) {
-    rc = step_activation(X, Q, D, basis, activation, B, N, M, F, T, K, floor_kind, floor_eps, ws, w,
-                         st);
-    if (rc) return rc;
-  }
-  double *qbuf = (double *)(ws + w.qbuf);
-  bool have_q = false;
-  if (steps & SSSPY_MNMF_DIAGONALIZER) {
-    void *U = ws + w.U;
-    auto run = [&]() -> int {
-      MNMF_DISPATCH(N, mnmf_wcov, X, D, basis, activation, U, B, M, F, T, K,
-                    (double *)(ws + w.tail), st);
-    };
-    rc = run();
-    if (rc) return rc;
-    // IP1 on the M x M diagonaliser with M weighted covariances per bin
-    rc = ip1_with_power(Q, U, C, C ? qbuf : nullptr, B, F, M, floor_kind, floor_eps, info, st);
-    if (rc) return rc;
-    have_q = C != nullptr;
-  }
-  if (steps & SSSPY_MNMF_SPATIAL) {
-    auto run = [&]() -> int {
-      MNMF_DISPATCH(N, mnmf_spatial, X, Q, D, basis, activation, B, M, F, T, K,
-                    (double *)(ws + w.tail), st);
-    };
-    rc = run();
-    if (rc) return rc;
-  }
-  if (steps & SSSPY_MNMF_NORMALIZE) {
-    if (!have_q) {
-      rc = row_power(Q, C, qbuf, B, F, M, st);
-      if (rc) return rc;
-    }
-    auto run = [&]() -> int {
-      MNMF_DISPATCH(N, mnmf_norm_scale, Q, D, qbuf, B, M, F, floor_kind, floor_eps, st);
-    };
-    rc = run();
-  }
-  return rc;
+  return fastmnmf_update_impl(X, C, Q, D, basis, activation, B, N, M, F, T, K, steps, floor_kind,
+                              floor_eps, workspace, workspace_bytes, info, nullptr, nullptr,
+                              as_stream(stream));
+}
+
+size_t ssspy_fastmnmf_handover_doubles(int B, int N, int M, int F, int T, int K) {
+  if (B <= 0 || N <= 0 || M <= 0 || F <= 0 || T <= 0 || K <= 0) return 0;
+  if (handover_ok(B, N, M, F, T, K) != 1) return 0;
+  return (size_t)B * M * F * T + (size_t)B * M;
+}
+
+int ssspy_fastmnmf_update_handover(const void *X, const void *C, void *Q, double *D, double *basis,
+                                   double *activation, int B, int N, int M, int F, int T, int K,
+                                   int steps, int floor_kind, double floor_eps, void *workspace,
+                                   size_t workspace_bytes, int *info, double *handover,
+                                   int *handover_valid, void *stream) {
+  SSSPY_REQUIRE(handover && handover_valid, "fastmnmf_update_handover: bad argument");
+  return fastmnmf_update_impl(X, C, Q, D, basis, activation, B, N, M, F, T, K, steps, floor_kind,
+                              floor_eps, workspace, workspace_bytes, info, handover, handover_valid,
+                              as_stream(stream));
 }
 
 int ssspy_fastmnmf_diagonalizer_covariance(const void *X, const double *D, const double *basis,

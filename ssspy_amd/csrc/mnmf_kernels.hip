@@ -10,6 +10,7 @@
 //   frame-major tile : activation update
 // Compiled once per N (-DSSSPY_N=2..4); M (channels) is a template parameter dispatched at launch.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 #include "cov_core.hpp"
@@ -46,6 +47,19 @@ __device__ __forceinline__ void frame_terms(const c128 (&Q)[M][M], const double 
 #pragma unroll
     for (int a = 0; a < M; ++a) cfma(y, Q[m][a], x[a]);
     qx2[m] = cabs2(y);
+    double r = 0.0;
+#pragma unroll
+    for (int n = 0; n < N; ++n) r = fma(lam[n], D[n][m], r);
+    rc[m] = r;
+  }
+}
+
+// R~_m alone (|(Q x)_m|^2 comes from the handed-over tensor, see k_mnmf_binmajor_fast)
+template <int M>
+__device__ __forceinline__ void rc_terms(const double (&D)[N][M], const double (&lam)[N],
+                                         double (&rc)[M]) {
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
     double r = 0.0;
 #pragma unroll
     for (int n = 0; n < N; ++n) r = fma(lam[n], D[n][m], r);
@@ -556,8 +570,37 @@ __device__ __forceinline__ void xtile_load(XTileM<M> &xt, __amdgpu_buffer_rsrc_t
   }
 }
 
+// |(Q x)_m|^2 handed over from the spatial pass (B, M, F, T) f64: the same walk as xtile_load at
+// half the bytes and without the M x M complex products.  Needs M * F * T * 8 < 2^32 and an even
+// T (16-byte aligned rows; odd T keeps the x path).
+template <int M>
+struct PTileM {
+  double p[M][4];
+};
+template <int M>
+__device__ __forceinline__ void ptile_load(PTileM<M> &pt, __amdgpu_buffer_rsrc_t pr, int F, int T,
+                                           int bin, int j0, int q) {
+  const unsigned voff = ((unsigned)bin * (unsigned)T + (unsigned)(j0 + 4 * q)) * 8u;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const unsigned soff = (unsigned)m * (unsigned)F * (unsigned)T * 8u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(pr, voff + 16u * h, soff, 0);
+      pt.p[m][2 * h] = __hiloint2double((int)v[1], (int)v[0]);
+      pt.p[m][2 * h + 1] = __hiloint2double((int)v[3], (int)v[2]);
+    }
+  }
+}
+
 // which of the three bin-major passes a kernel instance performs
 enum { MODE_BASIS = 0, MODE_WCOV = 1, MODE_SPATIAL = 2 };
+// the |Q x|^2 hand-over: none, read it instead of x (basis pass), write it (spatial pass)
+enum { P_NONE = 0, P_READ = 1, P_WRITE = 2 };
+#ifndef SSSPY_MNMF_PBASIS_WAVES
+#define SSSPY_MNMF_PBASIS_WAVES 2
+#endif
+constexpr int PBASIS_WAVES = SSSPY_MNMF_PBASIS_WAVES;  // waves per SIMD of the P_READ basis pass
 
 // grid: 1-D, see TailPlan (tail_plan.hpp): a work item is (mixture, 64-bin group), wave w owns bins
 // [64 group + 16 w, +16).  Unsplit items finish their bins in place; the split items of the last
@@ -570,15 +613,15 @@ constexpr int mnmf_tail_doubles() {
   return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
-template <int M, int MODE>
-__global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restrict__ X,
-                                                               const c128 *__restrict__ Q,
-                                                               double *Dsp, double *basis,
-                                                               const double *__restrict__ act,
-                                                               c128 *__restrict__ U, int F, int T,
-                                                               int K, int floor_kind, double eps,
-                                                               TailPlan plan,
-                                                               double *__restrict__ tailpart) {
+template <int M, int MODE, int PMODE = P_NONE>
+__global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnmf_binmajor_fast(
+    const c128 *__restrict__ X, const c128 *__restrict__ Q, double *Dsp, double *basis,
+    const double *__restrict__ act, c128 *__restrict__ U, int F, int T, int K, int floor_kind,
+    double eps, TailPlan plan, double *__restrict__ tailpart, double *__restrict__ P,
+    const double *__restrict__ pscale) {
+  static_assert(PMODE == P_NONE || (PMODE == P_READ && MODE == MODE_BASIS) ||
+                    (PMODE == P_WRITE && MODE == MODE_SPATIAL),
+                "the basis pass reads the hand-over, the spatial pass writes it");
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
@@ -587,17 +630,24 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
   const int i0 = work.group * 64 + wave * 16;
   const int bin = min(i0 + c, F - 1);
   const int ksteps = (K + 3) >> 2;
+  // PMODE == P_READ: the descriptor of the mixture's |Q x|^2 slab instead of x
   const __amdgpu_buffer_rsrc_t xr =
-      make_rsrc(X + (long long)b * M * F * T, (unsigned)M * (unsigned)F * (unsigned)T * 16u);
+      PMODE == P_READ
+          ? make_rsrc(P + (long long)b * M * F * T, (unsigned)M * (unsigned)F * (unsigned)T * 8u)
+          : make_rsrc(X + (long long)b * M * F * T, (unsigned)M * (unsigned)F * (unsigned)T * 16u);
   const double *act_b = act + (long long)b * N * K * T;
   c128 Qb[M][M];
   double Db[N][M];
+  double ps[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) ps[m] = PMODE == P_READ ? pscale[b * M + m] : 1.0;
 #pragma unroll
   for (int m = 0; m < M; ++m)
 #pragma unroll
     for (int a2 = 0; a2 < M; ++a2)
-      Qb[m][a2] = (MODE != MODE_WCOV) ? Q[((long long)b * F + bin) * (M * M) + m * M + a2]
-                                      : cmake(0.0, 0.0);  // the covariance pass does not need Q
+      Qb[m][a2] = (MODE != MODE_WCOV && PMODE != P_READ)
+                      ? Q[((long long)b * F + bin) * (M * M) + m * M + a2]
+                      : cmake(0.0, 0.0);  // neither the covariance pass nor the hand-over needs Q
 #pragma unroll
   for (int n = 0; n < N; ++n)
 #pragma unroll
@@ -632,30 +682,41 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
   const int tpc = (ntiles + nchunks - 1) / nchunks;
   const int jt_begin = work.chunk * tpc, jt_end = min(ntiles, jt_begin + tpc);
   VStage st;
-  XTileM<M> cur, nxt;
+  using Tile = typename std::conditional<PMODE == P_READ, PTileM<M>, XTileM<M>>::type;
+  Tile cur, nxt;
+  auto load_tile = [&](Tile &t, const int j0) __attribute__((always_inline)) {
+    if constexpr (PMODE == P_READ) ptile_load<M>(t, xr, F, T, bin, j0, q);
+    else xtile_load<M>(t, xr, F, T, bin, j0, q);
+  };
   vstage_load(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
-  xtile_load<M>(cur, xr, F, T, bin, min(jt_begin, ntiles - 1) * 16, q);
+  load_tile(cur, min(jt_begin, ntiles - 1) * 16);
   vstage_store(st, vs[0]);
   __syncthreads();
   // one tile of the walk: compute on `xc`, prefetch the next tile into `xn`.  The walk calls it with
   // the two register sets swapping roles (no 64-register copy per tile).
-  auto tile = [&](const XTileM<M> &xc, XTileM<M> &xn, const int jt) __attribute__((always_inline)) {
+  auto tile = [&](const Tile &xc, Tile &xn, const int jt) __attribute__((always_inline)) {
     const int j0 = jt * 16;
     const int jn = min(jt + 1, jt_end - 1) * 16;
     vstage_load(st, act_b, K, T, jn);
-    xtile_load<M>(xn, xr, F, T, bin, jn, q);
+    load_tile(xn, jn);
     const double *vcur = vs[(jt - jt_begin) & 1];
     double4_t lamR[N];
 #pragma unroll
     for (int n = 0; n < N; ++n) lamR[n] = rt_from_lds(vcur + n * 16 * VROW, tb[n], c, q, ksteps);
     double a[N][4], bq[N][4];
+    double pw[M][4];  // P_WRITE: this tile's |Q x|^2
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool valid = j0 + 4 * q + r < T;
       c128 x[M];
-#pragma unroll
-      for (int m = 0; m < M; ++m) x[m] = xc.x[m][r];
       double lam[N], qx2[M], rc[M];
+      if constexpr (PMODE == P_READ) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) qx2[m] = xc.p[m][r] * ps[m];
+      } else {
+#pragma unroll
+        for (int m = 0; m < M; ++m) x[m] = xc.x[m][r];
+      }
 #pragma unroll
       for (int n = 0; n < N; ++n) lam[n] = lamR[n][r];
       if (MODE == MODE_WCOV) {
@@ -669,7 +730,12 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
         }
         acc.add(x, phi);
       } else {
-        frame_terms<M>(Qb, Db, x, lam, qx2, rc);
+        if constexpr (PMODE == P_READ) rc_terms<M>(Db, lam, rc);
+        else frame_terms<M>(Qb, Db, x, lam, qx2, rc);
+        if constexpr (PMODE == P_WRITE) {
+#pragma unroll
+          for (int m = 0; m < M; ++m) pw[m][r] = qx2[m];
+        }
         double g[M], h[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) {
@@ -685,8 +751,15 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
               sa = fma(Db[n][m], h[m], sa);
               sb = fma(Db[n][m], g[m], sb);
             }
-            a[n][r] = valid ? sa : 0.0;
-            bq[n][r] = valid ? sb : 0.0;
+            if constexpr (PMODE == P_READ) {
+              // straight into the contraction over frames (no 32-register a / bq tile to hold)
+              const double vbr = vcur[(n * 16 + c) * VROW + 4 * q + r];
+              num[n] = mfma_f64(valid ? sa : 0.0, vbr, num[n]);
+              den[n] = mfma_f64(valid ? sb : 0.0, vbr, den[n]);
+            } else {
+              a[n][r] = valid ? sa : 0.0;
+              bq[n][r] = valid ? sb : 0.0;
+            }
           }
         } else {
 #pragma unroll
@@ -699,7 +772,7 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
         }
       }
     }
-    if (MODE == MODE_BASIS) {
+    if (MODE == MODE_BASIS && PMODE != P_READ) {
 #pragma unroll
       for (int n = 0; n < N; ++n) {
         const double *vn = vcur + n * 16 * VROW;
@@ -710,6 +783,22 @@ __global__ __launch_bounds__(256) void k_mnmf_binmajor_fast(const c128 *__restri
         for (int r = 0; r < 4; ++r) {
           num[n] = mfma_f64(a[n][r], vb[r], num[n]);
           den[n] = mfma_f64(bq[n][r], vb[r], den[n]);
+        }
+      }
+    }
+    if constexpr (PMODE == P_WRITE) {
+      if (i0 + c < F) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          double *dst = P + (((long long)b * M + m) * F + bin) * T + j0 + 4 * q;
+          if (j0 + 4 * q + 3 < T) {
+            *reinterpret_cast<double2 *>(dst) = make_double2(pw[m][0], pw[m][1]);
+            *reinterpret_cast<double2 *>(dst + 2) = make_double2(pw[m][2], pw[m][3]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (j0 + 4 * q + r < T) dst[r] = pw[m][r];
+          }
         }
       }
     }
@@ -873,7 +962,7 @@ struct TStageM {
   double dv;
 };
 
-template <int M>
+template <int M, bool WITHQ = true>
 __device__ __forceinline__ void tstage_load(TStageM<M> &st, const double *__restrict__ basis_b,
                                             const c128 *__restrict__ Q_b,
                                             const double *__restrict__ D_b, int F, int K, int i0) {
@@ -889,13 +978,14 @@ __device__ __forceinline__ void tstage_load(TStageM<M> &st, const double *__rest
   {
     const int idx = threadIdx.x;
     const int bi = min(i0 + idx / (M * M), F - 1);
-    st.qv = idx < 16 * M * M ? Q_b[(long long)bi * (M * M) + idx % (M * M)] : cmake(0.0, 0.0);
+    st.qv = (WITHQ && idx < 16 * M * M) ? Q_b[(long long)bi * (M * M) + idx % (M * M)]
+                                        : cmake(0.0, 0.0);
     const int bj = min(i0 + idx / (N * M), F - 1);
     st.dv = idx < 16 * N * M ? D_b[(long long)bj * (N * M) + idx % (N * M)] : 0.0;
   }
 }
 
-template <int M>
+template <int M, bool WITHQ = true>
 __device__ __forceinline__ void tstage_store(const TStageM<M> &st, double *tbuf, c128 *qbuf,
                                              double *dbuf) {
 #pragma unroll
@@ -904,19 +994,18 @@ __device__ __forceinline__ void tstage_store(const TStageM<M> &st, double *tbuf,
     const int k = idx & 15, row = idx >> 4;
     if (idx < N * 256) tbuf[row * TROW + k] = st.t[u];
   }
-  if (threadIdx.x < 16 * M * M) qbuf[threadIdx.x] = st.qv;
+  if (WITHQ && threadIdx.x < 16 * M * M) qbuf[threadIdx.x] = st.qv;
   if (threadIdx.x < 16 * N * M) dbuf[threadIdx.x] = st.dv;
 }
 
-template <int M>
-__global__ __launch_bounds__(256) void k_mnmf_activation_fast(const c128 *__restrict__ X,
-                                                              const c128 *__restrict__ Q,
-                                                              const double *__restrict__ Dsp,
-                                                              const double *__restrict__ basis,
-                                                              const double *__restrict__ act,
-                                                              double *__restrict__ part, int F,
-                                                              int T, int K, int tiles_per_chunk,
-                                                              int nchunks) {
+// USEP: |(Q x)_m|^2 comes from the hand-over tensor P (B, M, F, T) times pscale (B, M) instead of
+// x and Q (half the bytes, no M x M complex products).
+template <int M, bool USEP>
+__global__ __launch_bounds__(256, USEP ? 2 : 1) void k_mnmf_activation_fast(
+    const c128 *__restrict__ X, const c128 *__restrict__ Q, const double *__restrict__ Dsp,
+    const double *__restrict__ basis, const double *__restrict__ act, double *__restrict__ part,
+    int F, int T, int K, int tiles_per_chunk, int nchunks, const double *__restrict__ P,
+    const double *__restrict__ pscale) {
   __shared__ __attribute__((aligned(16))) double ts[2][N * 16 * TROW];
   __shared__ __attribute__((aligned(16))) c128 ql[2][16 * M * M];
   __shared__ __attribute__((aligned(16))) double dl[2][16 * N * M];
@@ -929,7 +1018,11 @@ __global__ __launch_bounds__(256) void k_mnmf_activation_fast(const c128 *__rest
   const bool fvalid = jf < T;
   const int jc = fvalid ? jf : T - 1;
   const __amdgpu_buffer_rsrc_t xsrc =
-      make_rsrc(X + (long long)b * M * F * T, (unsigned)M * (unsigned)F * (unsigned)T * 16u);
+      USEP ? make_rsrc(P + (long long)b * M * F * T, (unsigned)M * (unsigned)F * (unsigned)T * 8u)
+           : make_rsrc(X + (long long)b * M * F * T, (unsigned)M * (unsigned)F * (unsigned)T * 16u);
+  double ps[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) ps[m] = USEP ? pscale[b * M + m] : 1.0;
   const double *basis_b = basis + (long long)b * N * F * K;
   const c128 *Q_b = Q + (long long)b * F * M * M;
   const double *D_b = Dsp + (long long)b * F * N * M;
@@ -952,8 +1045,8 @@ __global__ __launch_bounds__(256) void k_mnmf_activation_fast(const c128 *__rest
   const int t_end = min(ntiles, t_begin + tiles_per_chunk);
   const int ksteps = (K + 3) >> 2;  // k-slabs beyond n_basis are zero on both sides
   TStageM<M> st;
-  tstage_load<M>(st, basis_b, Q_b, D_b, F, K, t_begin * 16);
-  tstage_store<M>(st, ts[0], ql[0], dl[0]);
+  tstage_load<M, !USEP>(st, basis_b, Q_b, D_b, F, K, t_begin * 16);
+  tstage_store<M, !USEP>(st, ts[0], ql[0], dl[0]);
   __syncthreads();
   for (int it = t_begin; it < t_end; ++it) {
     const int i0 = it * 16;
@@ -961,16 +1054,30 @@ __global__ __launch_bounds__(256) void k_mnmf_activation_fast(const c128 *__rest
     // x through the mixture's buffer descriptor: one lane offset per tile, (channel, bin row) in the
     // scalar offset.  Bins beyond F read the next channel's rows (zeros past the tensor) and are masked.
     c128 x[M][4];
-    const unsigned voff = ((unsigned)(i0 + q) * (unsigned)T + (unsigned)jc) * 16u;
+    double pv[M][4];
+    if constexpr (USEP) {
+      const unsigned voff = ((unsigned)(i0 + q) * (unsigned)T + (unsigned)jc) * 8u;
 #pragma unroll
-    for (int m = 0; m < M; ++m)
+      for (int m = 0; m < M; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const unsigned soff = ((unsigned)m * (unsigned)F + 4u * r) * (unsigned)T * 16u;
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xsrc, voff, soff, 0);
-        x[m][r] = cmake(__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2]));
-      }
-    tstage_load<M>(st, basis_b, Q_b, D_b, F, K, in);
+        for (int r = 0; r < 4; ++r) {
+          const unsigned soff = ((unsigned)m * (unsigned)F + 4u * r) * (unsigned)T * 8u;
+          const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(xsrc, voff, soff, 0);
+          pv[m][r] = __hiloint2double((int)v[1], (int)v[0]);
+        }
+    } else {
+      const unsigned voff = ((unsigned)(i0 + q) * (unsigned)T + (unsigned)jc) * 16u;
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned soff = ((unsigned)m * (unsigned)F + 4u * r) * (unsigned)T * 16u;
+          const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xsrc, voff, soff, 0);
+          x[m][r] =
+              cmake(__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2]));
+        }
+    }
+    tstage_load<M, !USEP>(st, basis_b, Q_b, D_b, F, K, in);
     const int pb = (it - t_begin) & 1;
     const double *tcur = ts[pb];
     double4_t lamR[N];
@@ -990,13 +1097,19 @@ __global__ __launch_bounds__(256) void k_mnmf_activation_fast(const c128 *__rest
       c128 Qb[M][M];
       double Db[N][M];
       load_bin<M>(Qb, Db, ql[pb] + bl * M * M, dl[pb] + bl * N * M);
-      c128 xr[M];
-#pragma unroll
-      for (int m = 0; m < M; ++m) xr[m] = x[m][r];
       double lam[N], qx2[M], rc[M];
 #pragma unroll
       for (int n = 0; n < N; ++n) lam[n] = lamR[n][r];
-      frame_terms<M>(Qb, Db, xr, lam, qx2, rc);
+      if constexpr (USEP) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) qx2[m] = pv[m][r] * ps[m];
+        rc_terms<M>(Db, lam, rc);
+      } else {
+        c128 xr[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) xr[m] = x[m][r];
+        frame_terms<M>(Qb, Db, xr, lam, qx2, rc);
+      }
       double g[M], h[M];
 #pragma unroll
       for (int m = 0; m < M; ++m) {
@@ -1023,7 +1136,7 @@ __global__ __launch_bounds__(256) void k_mnmf_activation_fast(const c128 *__rest
         numv[n] = mfma_f64(ta, a[n][r], numv[n]);
         denv[n] = mfma_f64(ta, bq[n][r], denv[n]);
       }
-    tstage_store<M>(st, ts[pb ^ 1], ql[pb ^ 1], dl[pb ^ 1]);
+    tstage_store<M, !USEP>(st, ts[pb ^ 1], ql[pb ^ 1], dl[pb ^ 1]);
     __syncthreads();
   }
 #pragma unroll
@@ -1101,10 +1214,41 @@ __global__ __launch_bounds__(256) void k_mnmf_loss(const c128 *__restrict__ X,
 
 // ================================================================ normalisation of Q rows and D
 // psi_m = floor(sqrt(mean_i q[i][m])); Q[:,m,:] /= psi_m; D[:,:,m] /= psi_m^2. grid (ceil(F/64), B)
+// |Q x|^2 of one mixture straight from x and Q (the hand-over tensor when nothing valid is at hand:
+// first iteration, or Q / x changed by the caller) and pscale <- 1.  grid: (ceil(T/256), F, B)
+template <int M>
+__global__ __launch_bounds__(256) void k_mnmf_qx2(const c128 *__restrict__ X,
+                                                  const c128 *__restrict__ Q,
+                                                  double *__restrict__ P, double *pscale, int F,
+                                                  int T) {
+  const int b = blockIdx.z, bin = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0 && bin == 0 && threadIdx.x < M) pscale[b * M + threadIdx.x] = 1.0;
+  if (j >= T) return;
+  const c128 *Qb = Q + ((long long)b * F + bin) * (M * M);
+  c128 x[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) x[m] = X[(((long long)b * M + m) * F + bin) * T + j];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    c128 y = cmake(0.0, 0.0);
+#pragma unroll
+    for (int a = 0; a < M; ++a) cfma(y, Qb[m * M + a], x[a]);
+    P[(((long long)b * M + m) * F + bin) * T + j] = cabs2(y);
+  }
+}
+
+__global__ void k_mnmf_fill_ones(double *p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 1.0;
+}
+
+// pscale (B, M), when given, takes the same 1 / psi_m^2 as D: |(Q x)_m|^2 = P * pscale stays true
 template <int M>
 __global__ __launch_bounds__(256) void k_mnmf_norm_scale(c128 *Q, double *Dsp,
                                                          const double *__restrict__ qbuf, int F,
-                                                         int floor_kind, double eps) {
+                                                         int floor_kind, double eps,
+                                                         double *pscale) {
   __shared__ double scratch[4];
   __shared__ double psi[M];
   const int b = blockIdx.y;
@@ -1120,6 +1264,8 @@ __global__ __launch_bounds__(256) void k_mnmf_norm_scale(c128 *Q, double *Dsp,
     }
   }
   __syncthreads();
+  if (pscale && blockIdx.x == 0 && threadIdx.x < M)
+    pscale[b * M + threadIdx.x] /= psi[threadIdx.x] * psi[threadIdx.x];
   const int i0 = blockIdx.x * 64;
   const int nb = min(64, F - i0);
   c128 *Qb = Q + ((long long)b * F + i0) * M * M;
@@ -1317,17 +1463,40 @@ static inline TailPlan mnmf_plan(int B, int F, int T) {
   return make_tail_plan(B, (F + 63) / 64, (T + 15) / 16, 256);
 }
 
+// whether the |Q x|^2 hand-over (P, pscale) is taken by the passes of this shape
+int LAUNCHER(mnmf_handover_ok)(int B, int F, int T, int K) {
+  return (mnmf_fast_ok(B, F, T, K) && T % 2 == 0) ? 1 : 0;
+}
+
+int LAUNCHER(mnmf_qx2)(const void *X, const void *Q, double *P, double *pscale, int B, int M,
+                       int F, int T, hipStream_t st) {
+  dim3 grid((T + 255) / 256, F, B);
+  MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_qx2<MM>), grid, dim3(256), 0, st, (const c128 *)X,
+                                        (const c128 *)Q, P, pscale, F, T));
+  return check_launch("k_mnmf_qx2");
+}
+
 int LAUNCHER(mnmf_basis)(const void *X, const void *Q, const double *Dsp, const double *basis,
                          double *basis_out, const double *act, int B, int M, int F, int T, int K,
-                         int floor_kind, double eps, double *tailpart, hipStream_t st) {
+                         int floor_kind, double eps, double *tailpart, const double *P,
+                         const double *pscale, hipStream_t st) {
   Dims d{B, F, T, K};
   if (mnmf_fast_ok(B, F, T, K) && basis_out == basis) {
-    const TailPlan plan = mnmf_plan(B, F, T);
+    // two workgroups per CU with the hand-over (no x tiles, no Q in registers)
+    const TailPlan plan = P ? make_tail_plan(B, (F + 63) / 64, (T + 15) / 16, 256 * PBASIS_WAVES)
+                            : mnmf_plan(B, F, T);
     dim3 fgrid(plan.full + plan.tail * plan.split);
     MNMF_DISPATCH_M(M, {
+      if (P)
+        hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_BASIS, P_READ>), fgrid, dim3(256), 0, st,
+                           (const c128 *)X, (const c128 *)Q, (double *)Dsp, basis_out, act,
+                           (c128 *)nullptr, F, T, K, floor_kind, eps, plan, tailpart,
+                           const_cast<double *>(P), pscale);
+      else
       hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_BASIS>), fgrid, dim3(256), 0, st,
                          (const c128 *)X, (const c128 *)Q, (double *)Dsp, basis_out, act,
-                         (c128 *)nullptr, F, T, K, floor_kind, eps, plan, tailpart);
+                         (c128 *)nullptr, F, T, K, floor_kind, eps, plan, tailpart,
+                         (double *)nullptr, (const double *)nullptr);
       if (plan.tail > 0)
         hipLaunchKernelGGL((k_mnmf_basis_finalize<MM>), dim3(N * 64 * 16 / 256, plan.tail), dim3(256),
                            0, st, basis_out, tailpart, F, K, plan, floor_kind, eps);
@@ -1349,16 +1518,25 @@ int LAUNCHER(mnmf_basis)(const void *X, const void *Q, const double *Dsp, const 
 
 int LAUNCHER(mnmf_activation)(const void *X, const void *Q, const double *Dsp, const double *basis,
                               const double *act, double *part, int nchunks, int B, int M, int F,
-                              int T, int K, hipStream_t st) {
+                              int T, int K, const double *P, const double *pscale,
+                              hipStream_t st) {
   Dims d{B, F, T, K};
   const int ntiles = (F + 15) / 16;
   const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
   const int ktiles = kt_count(K);
   dim3 grid((T + 63) / 64, nchunks, B * ktiles), block(256);
   if (mnmf_fast_ok(B, F, T, K)) {
-    MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_activation_fast<MM>), grid, block, 0, st,
-                                          (const c128 *)X, (const c128 *)Q, Dsp, basis, act, part, F,
-                                          T, K, tiles_per_chunk, nchunks));
+    MNMF_DISPATCH_M(M, {
+      if (P)
+        hipLaunchKernelGGL((k_mnmf_activation_fast<MM, true>), grid, block, 0, st, (const c128 *)X,
+                           (const c128 *)Q, Dsp, basis, act, part, F, T, K, tiles_per_chunk, nchunks,
+                           P, pscale);
+      else
+        hipLaunchKernelGGL((k_mnmf_activation_fast<MM, false>), grid, block, 0, st,
+                           (const c128 *)X, (const c128 *)Q, Dsp, basis, act, part, F, T, K,
+                           tiles_per_chunk, nchunks, (const double *)nullptr,
+                           (const double *)nullptr);
+    });
     return check_launch("k_mnmf_activation_fast");
   }
   MNMF_DISPATCH_M(M, {
@@ -1384,7 +1562,8 @@ int LAUNCHER(mnmf_wcov)(const void *X, const double *Dsp, const double *basis, c
     MNMF_DISPATCH_M(M, {
       hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_WCOV>), fgrid, dim3(256), 0, st,
                          (const c128 *)X, (const c128 *)nullptr, (double *)Dsp, (double *)basis, act,
-                         (c128 *)U, F, T, K, 0, 0.0, plan, tailpart);
+                         (c128 *)U, F, T, K, 0, 0.0, plan, tailpart, (double *)nullptr,
+                         (const double *)nullptr);
       if (plan.tail > 0)
         hipLaunchKernelGGL((k_mnmf_wcov_fold<MM>), dim3((64 * MM * MM * MM + 255) / 256, plan.tail),
                            dim3(256), 0, st, (c128 *)U, tailpart, F, plan);
@@ -1404,17 +1583,28 @@ int LAUNCHER(mnmf_wcov)(const void *X, const double *Dsp, const double *basis, c
   return check_launch("k_mnmf_wcov");
 }
 
+// P / pscale (optional): the pass also writes |Q x|^2 for the next basis and activation passes
 int LAUNCHER(mnmf_spatial)(const void *X, const void *Q, double *Dsp, const double *basis,
                            const double *act, int B, int M, int F, int T, int K, double *tailpart,
-                           hipStream_t st) {
+                           double *P, double *pscale, hipStream_t st) {
   Dims d{B, F, T, K};
   if (mnmf_fast_ok(B, F, T, K)) {
     const TailPlan plan = mnmf_plan(B, F, T);
     dim3 fgrid(plan.full + plan.tail * plan.split);
+    if (P)
+      hipLaunchKernelGGL(k_mnmf_fill_ones, dim3((B * M + 255) / 256), dim3(256), 0, st, pscale,
+                         B * M);
     MNMF_DISPATCH_M(M, {
+      if (P)
+        hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_SPATIAL, P_WRITE>), fgrid, dim3(256), 0,
+                           st, (const c128 *)X, (const c128 *)Q, Dsp, (double *)basis, act,
+                           (c128 *)nullptr, F, T, K, 0, 0.0, plan, tailpart, P,
+                           (const double *)nullptr);
+      else
       hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_SPATIAL>), fgrid, dim3(256), 0, st,
                          (const c128 *)X, (const c128 *)Q, Dsp, (double *)basis, act,
-                         (c128 *)nullptr, F, T, K, 0, 0.0, plan, tailpart);
+                         (c128 *)nullptr, F, T, K, 0, 0.0, plan, tailpart, (double *)nullptr,
+                         (const double *)nullptr);
       if (plan.tail > 0)
         hipLaunchKernelGGL((k_mnmf_spatial_finalize<MM>), dim3((64 * N * MM + 255) / 256, plan.tail),
                            dim3(256), 0, st, Dsp, tailpart, F, plan);
@@ -1451,10 +1641,10 @@ int LAUNCHER(mnmf_loss)(const void *X, const void *Q, const double *Dsp, const d
 }
 
 int LAUNCHER(mnmf_norm_scale)(void *Q, double *Dsp, const double *qbuf, int B, int M, int F,
-                              int floor_kind, double eps, hipStream_t st) {
+                              int floor_kind, double eps, double *pscale, hipStream_t st) {
   dim3 grid((F + 63) / 64, B), block(256);
   MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_norm_scale<MM>), grid, block, 0, st, (c128 *)Q, Dsp,
-                                        qbuf, F, floor_kind, eps));
+                                        qbuf, F, floor_kind, eps, pscale));
   return check_launch("k_mnmf_norm_scale");
 }
 

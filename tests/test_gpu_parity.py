@@ -669,6 +669,79 @@ def test_fast_gauss_mnmf_config4_shape_against_oracle():
     assert rel_err(Y, Yr) < 1e-7
 
 
+def _fastmnmf_states(m):
+    return [np.array(v) for v in (m.diagonalizer, m.spatial, m.basis, m.activation, m.output)]
+
+
+@pytest.mark.parametrize("M,F,T,K", [(4, 70, 96, 8), (3, 33, 50, 5), (2, 17, 130, 16), (4, 20, 37, 3)])
+def test_fast_gauss_mnmf_handover_matches_plain_path_and_oracle(M, F, T, K, monkeypatch):
+    """The |Q x|^2 hand-over (spatial pass -> next basis / activation passes) against the passes
+    that read x and Q, and against the oracle.  Odd T has no hand-over (8-byte aligned rows)."""
+    from oracle.mnmf import FastGaussMNMFOracle
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    X = nmf_mixture(77, M, F, T)
+    kw = dict(basis=np.random.default_rng(1).random((M, F, K)),
+              activation=np.random.default_rng(2).random((M, K, T)),
+              spatial=np.random.default_rng(4).random((F, M, M)))
+    m1 = FastGaussMNMF(n_basis=K)
+    m1(X, n_iter=4, **{k: v.copy() for k, v in kw.items()})
+    assert (m1._handover is not None) == (T % 2 == 0)
+    monkeypatch.setenv("SSSPY_AMD_NO_HANDOVER", "1")
+    m2 = FastGaussMNMF(n_basis=K)
+    m2(X, n_iter=4, **{k: v.copy() for k, v in kw.items()})
+    assert m2._handover is None
+    for a, b in zip(_fastmnmf_states(m1), _fastmnmf_states(m2)):
+        assert rel_err(a, b) < 1e-11
+    np.testing.assert_allclose(m1.loss, m2.loss, rtol=1e-11)
+    ref = FastGaussMNMFOracle(n_basis=K)
+    Yr = ref.run(X, n_iter=4, **{k: v.copy() for k, v in kw.items()})
+    np.testing.assert_allclose(m1.loss, ref.loss, rtol=LOSS_RTOL)
+    assert rel_err(m1.diagonalizer, ref.diagonalizer) < TOL
+    assert rel_err(m1.output, Yr) < 1e-7
+
+
+def test_fast_gauss_mnmf_handover_follows_state_changes(monkeypatch):
+    """The hand-over is dropped whenever the diagonaliser moves outside the spatial pass: caller
+    assignment, single steps out of order, IP2; a batch keeps one scale per (mixture, channel)."""
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    B, M, F, T, K = 3, 4, 40, 64, 6
+    X = np.stack([nmf_mixture(90 + b, M, F, T) for b in range(B)])
+    kw = dict(basis=np.random.default_rng(1).random((B, M, F, K)),
+              activation=np.random.default_rng(2).random((B, M, K, T)),
+              spatial=np.random.default_rng(4).random((B, F, M, M)))
+
+    def scenario(algo):
+        m = FastGaussMNMF(n_basis=K, diagonalizer_algorithm=algo)
+        m(X, n_iter=2, **{k: v.copy() for k, v in kw.items()})
+        m.diagonalizer = np.array(m.diagonalizer) * (1.0 + 0.25j)      # caller moves Q
+        m.update_once()
+        m.update_once()
+        m.update_basis()
+        m.update_diagonalizer()                                        # Q moves, no spatial pass
+        m.update_activation()
+        m.update_spatial()
+        m.normalize()
+        m.update_basis()
+        m.update_activation()
+        m.spatial = np.array(m.spatial) * 1.5                          # D alone: hand-over stays
+        m.update_once()
+        return m, _fastmnmf_states(m)[:4]
+
+    for algo in ("IP1", "IP2"):
+        m1, with_handover = scenario(algo)
+        assert m1._handover is not None
+        with monkeypatch.context() as mp:
+            mp.setenv("SSSPY_AMD_NO_HANDOVER", "1")
+            m2, plain = scenario(algo)
+            assert m2._handover is None
+        for a, b in zip(with_handover, plain):
+            assert rel_err(a, b) < 1e-9  # nine iterations of rounding-level differences
+
+
 def test_wiener_filter_floors_small_eigenvalues():
     """to_psd inside separate(): with a huge floor every eigenvalue is clamped, so R = eps I and the
     output is x-independent of the spatial model's conditioning: Y_n = R_n[ref,:] x / eps."""
