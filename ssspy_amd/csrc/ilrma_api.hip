@@ -77,6 +77,41 @@ static inline int source_group(int N, int F, int T, int K, double domain, int so
   return 0;
 }
 
+// The general form (any source count above 4, e.g. 5 or 7): the B N sources of the batch, in memory
+// order, are cut into at most three runs of `count` groups of G sources each -- groups of 4 and one
+// or two closing groups of 3 / 2 sources -- and every run is one launch of the tuned kernels on its
+// slice of y, T and V.  Returns the number of runs (0: not on the grouped path).
+struct SourceRun {
+  long long first;  // first source of the run in the flat (B N) order
+  int count, G;     // `count` groups of G sources
+};
+static inline int source_runs(int B, int N, int F, int T, int K, double domain, int source_model,
+                              SourceRun (&run)[3]) {
+  if (N <= 4) return 0;
+  if (const int G = source_group(N, F, T, K, domain, source_model)) {
+    run[0] = SourceRun{0, B * (N / G), G};
+    return 1;
+  }
+  for (int G = 2; G <= 4; ++G)
+    if (!fast_path(G, F, T, K, domain, source_model)) return 0;
+  const long long S = (long long)B * N;  // >= 5
+  const int r = (int)(S % 4);
+  const int tail = r == 0 ? 0 : (r == 1 ? 5 : r);  // 5 = 3 + 2
+  int n = 0;
+  if (S - tail > 0) run[n++] = SourceRun{0, (int)((S - tail) / 4), 4};
+  if (tail == 5) {
+    run[n++] = SourceRun{S - 5, 1, 3};
+    run[n++] = SourceRun{S - 2, 1, 2};
+  } else if (tail) {
+    run[n++] = SourceRun{S - tail, 1, tail};
+  }
+  return n;
+}
+static inline bool grouped_path(int B, int N, int F, int T, int K, double domain, int source_model) {
+  SourceRun run[3];
+  return source_runs(B, N, F, T, K, domain, source_model, run) > 0;
+}
+
 static inline int check_model(int source_model, double param, double domain = 2.0) {
   const int model = source_model & 0xff;
   const bool me = (source_model & SSSPY_SOURCE_ME) != 0;
@@ -479,17 +514,28 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
   // above 16 bases the update cannot be in place (several items per bin group read the old basis)
   double *out = K > 16 ? (double *)(ws + w.btmp) : basis;
   auto run = [&]() -> int {
-    if (const int G = source_group(N, F, T, K, domain, source_model)) {
-      const void *Y = X;
+    SourceRun runs[3];
+    if (const int nruns = source_runs(B, N, F, T, K, domain, source_model, runs)) {
+      const c128 *Y = (const c128 *)X;
       if (W) {
         int r = ssspy_separate(X, W, ws + w.ybuf, B, N, F, T, stream);
         if (r) return r;
-        Y = ws + w.ybuf;
+        Y = (const c128 *)(ws + w.ybuf);
       }
-      ILRMA_FAST_DISPATCH(G, ilrma_fast_basis, Y, nullptr, basis, out, activation, B * (N / G), F, T,
-                          K, floor_kind, floor_eps, (double *)(ws + w.bpart),
-                          fast_model_id(domain, source_model), model_param, is_me(source_model),
-                          nullptr, st);
+      for (int i = 0; i < nruns; ++i) {
+        const SourceRun &sr = runs[i];
+        auto one = [&]() -> int {
+          ILRMA_FAST_DISPATCH(sr.G, ilrma_fast_basis, Y + sr.first * F * T, nullptr,
+                              basis + sr.first * F * K, out + sr.first * F * K,
+                              activation + sr.first * K * T, sr.count, F, T, K, floor_kind,
+                              floor_eps, (double *)(ws + w.bpart),
+                              fast_model_id(domain, source_model), model_param,
+                              is_me(source_model), nullptr, st);
+        };
+        const int r = one();
+        if (r) return r;
+      }
+      return SSSPY_OK;
     }
     if (fast_path(N, F, T, K, domain, source_model)) {
       if (loss_done) *loss_done = loss_out != nullptr && K <= 16;
@@ -536,18 +582,31 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
   const int chunks = act_chunks(B, N, F, T, K);
   hipStream_t st = as_stream(stream);
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
+  SourceRun runs[3];
+  const int nruns = source_runs(B, N, F, T, K, domain, source_model, runs);
+  // (the partial sums of a run keep the (group, chunk, source) layout at the run's offset: every
+  // source owns `chunks` slabs of 2 K T doubles wherever its group starts)
+  const size_t part_per_source = (size_t)chunks * 2 * K * T;
   auto run = [&]() -> int {
-    if (const int G = source_group(N, F, T, K, domain, source_model)) {
-      // (the partial sums keep their (mixture, chunk, source) layout: B N / G mixtures of G sources
-      // with the same chunk count are the same array)
-      const void *Y = X;
+    if (nruns) {
+      const c128 *Y = (const c128 *)X;
       if (W) {
         int r = ssspy_separate(X, W, (char *)workspace + w.ybuf, B, N, F, T, stream);
         if (r) return r;
-        Y = (char *)workspace + w.ybuf;
+        Y = (const c128 *)((char *)workspace + w.ybuf);
       }
-      ILRMA_FAST_DISPATCH(G, ilrma_fast_activation, Y, nullptr, basis, activation, part, chunks,
-                          B * (N / G), F, T, K, fast_model_id(domain, source_model), model_param, st);
+      for (int i = 0; i < nruns; ++i) {
+        const SourceRun &sr = runs[i];
+        auto one = [&]() -> int {
+          ILRMA_FAST_DISPATCH(sr.G, ilrma_fast_activation, Y + sr.first * F * T, nullptr,
+                              basis + sr.first * F * K, activation + sr.first * K * T,
+                              part + sr.first * part_per_source, chunks, sr.count, F, T, K,
+                              fast_model_id(domain, source_model), model_param, st);
+        };
+        const int r = one();
+        if (r) return r;
+      }
+      return SSSPY_OK;
     }
     if (fast_path(N, F, T, K, domain, source_model)) {
       ILRMA_FAST_DISPATCH(N, ilrma_fast_activation, X, W, basis, activation, part, chunks, B, F, T,
@@ -559,11 +618,19 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
   if (rc) return rc;
   // fold the chunks in the layout the kernel wrote: (mixture, chunk, source) of the regrouped batch
   // when the wide-mixture path ran
-  const int G = source_group(N, F, T, K, domain, source_model);
-  const int Nf = G ? G : N, Bf = G ? B * (N / G) : B;
-  dim3 g2((unsigned)(((long long)K * T + 255) / 256), Nf, Bf);
-  hipLaunchKernelGGL(k_ilrma_activation_finalize, g2, dim3(256), 0, st, activation,
-                     (const double *)part, Nf, K, T, chunks, d);
+  if (!nruns) {
+    dim3 g2((unsigned)(((long long)K * T + 255) / 256), N, B);
+    hipLaunchKernelGGL(k_ilrma_activation_finalize, g2, dim3(256), 0, st, activation,
+                       (const double *)part, N, K, T, chunks, d);
+    return check_launch("k_ilrma_activation_finalize");
+  }
+  for (int i = 0; i < nruns; ++i) {
+    const SourceRun &sr = runs[i];
+    dim3 g2((unsigned)(((long long)K * T + 255) / 256), sr.G, sr.count);
+    hipLaunchKernelGGL(k_ilrma_activation_finalize, g2, dim3(256), 0, st,
+                       activation + sr.first * K * T,
+                       (const double *)(part + sr.first * part_per_source), sr.G, K, T, chunks, d);
+  }
   return check_launch("k_ilrma_activation_finalize");
 }
 
@@ -703,7 +770,7 @@ static int ip1_update_impl(const void *X, const void *C, void *W, double *basis,
   // wide mixture on the grouped path: y = W x once for both NMF passes (they then see the ISS-style
   // state: the spectrogram itself, no filter)
   const void *Xs = X, *Ws = W;
-  if (source_group(N, F, T, K, domain, source_model)) {
+  if (grouped_path(B, N, F, T, K, domain, source_model)) {
     rc = ssspy_separate(X, W, ws + w.ybuf, B, N, F, T, stream);
     if (rc) return rc;
     Xs = ws + w.ybuf;

@@ -1491,3 +1491,40 @@ def test_ilrma_wide_mixture_grouped_sources_against_oracle(model, N, algo, K):
         ms.normalize()
         for name in ("demix_filter", "basis", "activation"):
             assert rel_err(getattr(ms, name), getattr(mf, name)) < 1e-12, name
+
+
+@pytest.mark.parametrize("model,N,B,algo,K", [
+    (("gauss", None), 5, 1, "IP", 4),     # 5 sources: one group of 3 and one of 2
+    (("gauss", None), 5, 2, "IP", 16),    # 10: two groups of 4, one of 2
+    (("gauss", None), 7, 1, "ISS", 6),    # 7: 4 + 3
+    (("t", 5.0), 7, 3, "IP", 3),          # 21: four groups of 4, then 3 + 2
+    (("ggd", 1.4), 5, 3, "IP2", 5),       # 15: three groups of 4, one of 3
+    (("gauss", None), 7, 2, "IP", 24),    # 14 with two k-tile work items per bin group
+])
+def test_ilrma_five_and_seven_sources_against_oracle(model, N, B, algo, K):
+    """Source counts without a divisor in {2, 3, 4}: the B N sources are cut into runs of groups of
+    4 with closing groups of 3 / 2, one tuned launch per run (ilrma_api.hip: source_runs)."""
+    from oracle.ilrma import GaussILRMAOracle
+
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    F, T = 40, 60
+    rng = np.random.default_rng(N * 10 + K + B)
+    X = np.stack([nmf_mixture(700 + b, N, F, T) for b in range(B)])
+    basis, act = rng.random((B, N, F, K)), rng.random((B, N, K, T))
+    cls = _ilrma_class(model)
+    kw = dict(n_basis=K, spatial_algorithm=algo)
+    if model[0] == "t":
+        kw["dof"] = model[1]
+    elif model[0] == "ggd":
+        kw["beta"] = model[1]
+    m = cls(**kw)
+    Y = m(X, n_iter=3, basis=basis, activation=act)
+    for b in range(B):
+        ref = GaussILRMAOracle(n_basis=K, spatial_algorithm=algo, model=model)
+        Yr = ref.run(X[b], n_iter=3, basis=basis[b], activation=act[b])
+        # (IP2: eigenvectors of nearly degenerate pairs; the loss is a difference of large terms)
+        np.testing.assert_allclose(np.asarray(m.loss)[:, b], ref.loss,
+                                   rtol=1e-7 if algo == "IP2" else LOSS_RTOL)
+        assert rel_err(m.basis[b], ref.basis) < TOL and rel_err(m.activation[b], ref.activation) < TOL
+        assert rel_err(Y[b], Yr) < (1e-7 if algo == "IP2" else TOL)
