@@ -51,6 +51,7 @@ def _units():
         ("stft_kernels.hip", "stft_kernels.o", []),
         ("hermitian_ops.hip", "hermitian_ops.o", []),
         ("fmnmf_generic.hip", "fmnmf_generic.o", []),
+        ("wide_cov.hip", "wide_cov.o", []),
     ]
     units.append(("mnmf_api.hip", "mnmf_api.o", []))
     for n in MNMF_N:

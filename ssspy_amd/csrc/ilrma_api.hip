@@ -164,6 +164,10 @@ static inline size_t qbuf_bytes(int B, int N, int F) {
 
 int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, int F, int N,
                    int floor_kind, double floor_eps, int *info, hipStream_t st);
+// wide_cov.hip: weighted covariance of 5..8 channels on the matrix cores
+bool wide_weighted_cov_ok(int N, int S, int F, int T, int kind);
+int wide_weighted_cov(const void *A, const double *weight, int kind, void *U, int B, int N, int S,
+                      int F, int T, hipStream_t st);
 
 // scratch of the bin-major fast kernels (basis, covariance): partial sums of the at most 512
 // split blocks of the last scheduling round (TailPlan in ilrma_fast.hip)
@@ -456,7 +460,7 @@ extern "C" {
 
 // One scratch layout for every ILRMA entry point: callers pass the same buffer everywhere.
 struct IlrmaWs {
-  size_t act_part, btmp, qbuf, psi, bpart, upart, praw, ybuf, total;
+  size_t act_part, btmp, qbuf, psi, bpart, upart, praw, ybuf, wbuf, total;
 };
 static inline IlrmaWs ilrma_ws(int B, int N, int F, int T, int K) {
   IlrmaWs w;
@@ -477,6 +481,8 @@ static inline IlrmaWs ilrma_ws(int B, int N, int F, int T, int K) {
   off += align256((size_t)B * N * F * K * 2 * sizeof(double));
   w.ybuf = off;  // y = W x of a wide mixture (more than 4 sources), see source_group()
   off += N > 4 ? align256((size_t)B * N * F * T * 2 * sizeof(double)) : 0;
+  w.wbuf = off;  // varphi (B, N, F, T) of a wide mixture's covariance pass (wide_cov.hip)
+  off += N > 4 ? align256((size_t)B * N * F * T * sizeof(double)) : 0;
   w.total = off;
   return w;
 }
@@ -634,9 +640,22 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
   return check_launch("k_ilrma_activation_finalize");
 }
 
-// U[b,i,n] for every model; `upart` is the fast path's scratch for split blocks
+// U[b,i,n] for every model; `upart` is the fast path's scratch for split blocks.  Wide mixtures
+// (5..8 sources) go through the weights varphi = 1 / R~ (`wbuf`, (B, N, F, T)) and the matrix-core
+// covariance of wide_cov.hip; the heavy-tailed models need the separated spectrogram for that
+// (`Ysep`, or X itself when W is NULL) and keep the generic kernel without it.
 static int wcov_into(const void *X, const void *W, const double *basis, const double *activation,
-                     void *U, int N, const IlrmaDims &d, void *upart, hipStream_t st) {
+                     void *U, int N, const IlrmaDims &d, void *upart, double *wbuf,
+                     const void *Ysep, hipStream_t st) {
+  if (N > 4 && wbuf && wide_weighted_cov_ok(N, N, d.F, d.T, SSSPY_WEIGHT_BIN_FRAME)) {
+    const void *Y = Ysep ? Ysep : (W ? nullptr : X);
+    if (d.model == SSSPY_SOURCE_GAUSS || Y) {
+      dim3 grid((d.F + ISSW_BINS - 1) / ISSW_BINS, N, d.B), block(256);
+      hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, st, (const c128 *)Y, basis, activation,
+                         wbuf, N, d);
+      return wide_weighted_cov(X, wbuf, SSSPY_WEIGHT_BIN_FRAME, U, d.B, N, N, d.F, d.T, st);
+    }
+  }
   if (fast_path(N, d.F, d.T, d.K, d.p, d.model) && (d.model == SSSPY_SOURCE_GAUSS || W)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, W, basis, activation, U, d.B, d.F, d.T, d.K, upart,
                         fast_model_id(d.p, d.model), d.mparam, d.floor_kind, d.floor_eps, st);
@@ -659,7 +678,8 @@ int ssspy_ilrma_weighted_covariance(const void *X, const void *W, const double *
                 "ilrma_weighted_covariance: workspace too small");
   hipStream_t st = as_stream(stream);
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
-  return wcov_into(X, W, basis, activation, U, N, d, (char *)workspace + w.upart, st);
+  return wcov_into(X, W, basis, activation, U, N, d, (char *)workspace + w.upart,
+                   N > 4 ? (double *)((char *)workspace + w.wbuf) : nullptr, nullptr, st);
 }
 
 static int launch_norm_scale(void *W, double *basis, const double *qbuf, int B, int N, int F, int K,
@@ -786,7 +806,8 @@ static int ip1_update_impl(const void *X, const void *C, void *W, double *basis,
                                      stream);
   if (rc) return rc;
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
-  rc = wcov_into(X, W, basis, activation, U, N, d, ws + w.upart, st);
+  rc = wcov_into(X, W, basis, activation, U, N, d, ws + w.upart,
+                 N > 4 ? (double *)(ws + w.wbuf) : nullptr, Ws ? nullptr : Xs, st);
   if (rc) return rc;
   double *qbuf = (double *)(ws + w.qbuf);
   rc = ip1_with_power(W, U, normalize ? C : nullptr, normalize ? qbuf : nullptr, B, F, N,

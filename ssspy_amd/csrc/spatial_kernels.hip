@@ -10,30 +10,48 @@ int ilrma_fast_wcov_frame_n2(const void *, const double *, void *, int, int, int
 int ilrma_fast_wcov_frame_n3(const void *, const double *, void *, int, int, int, hipStream_t);
 int ilrma_fast_wcov_frame_n4(const void *, const double *, void *, int, int, int, hipStream_t);
 
+// wide_cov.hip: 5..8 channels on the matrix cores
+bool wide_weighted_cov_ok(int N, int S, int F, int T, int kind);
+int wide_weighted_cov(const void *A, const double *weight, int kind, void *U, int B, int N, int S,
+                      int F, int T, hipStream_t st);
+
 thread_local char g_last_error[512] = "";
 
 // ---------------------------------------------------------------------------------- separate
 // One block per (bin, mixture); lanes run along frames so every channel row is read and
-// every source row written as contiguous 16-byte elements.  W_i is wave-uniform.
+// every source row written as contiguous 16-byte elements.  W_i is block-uniform: its rows are read
+// through scalar loads (the index depends on blockIdx and loop counters only) and enter the FMAs as
+// SGPR operands -- an LDS copy costs one ds_read per complex product, which bound the kernel at
+// 8 sources (0.59 ms for 16 mixtures of N = 8, F = 1025, T = 512: 0.9 TB/s).
 template <int N>
 __global__ __launch_bounds__(256) void k_separate(const c128 *__restrict__ X,
                                                   const c128 *__restrict__ W, c128 *Y, int F,
                                                   int T) {
   const int i = blockIdx.x, b = blockIdx.y;
-  __shared__ c128 w[N * N];
-  if (threadIdx.x < N * N) w[threadIdx.x] = W[((long long)b * F + i) * (N * N) + threadIdx.x];
-  __syncthreads();
+  const c128 *__restrict__ w = W + ((long long)b * F + i) * (N * N);
   const long long row0 = ((long long)b * N) * F + i;
-  for (int j = threadIdx.x; j < T; j += blockDim.x) {
-    c128 x[N];
+  // two frames per thread and pass; the loop over sources stays rolled so that one row of W (2 N
+  // scalars) is live at a time instead of the whole matrix spilling out of the SGPR file
+  for (int j0 = 0; j0 < T; j0 += 2 * blockDim.x) {
+    const int ja = j0 + threadIdx.x, jb = ja + blockDim.x;
+    const bool va = ja < T, vb = jb < T;
+    c128 xa[N], xb[N];
 #pragma unroll
-    for (int m = 0; m < N; ++m) x[m] = X[(row0 + (long long)m * F) * T + j];
-#pragma unroll
+    for (int m = 0; m < N; ++m) {
+      xa[m] = va ? X[(row0 + (long long)m * F) * T + ja] : cmake(0.0, 0.0);
+      xb[m] = vb ? X[(row0 + (long long)m * F) * T + jb] : cmake(0.0, 0.0);
+    }
+#pragma unroll 1
     for (int n = 0; n < N; ++n) {
-      c128 y = cmake(0.0, 0.0);
+      c128 ya = cmake(0.0, 0.0), yb = cmake(0.0, 0.0);
 #pragma unroll
-      for (int m = 0; m < N; ++m) cfma(y, w[n * N + m], x[m]);
-      Y[(row0 + (long long)n * F) * T + j] = y;
+      for (int m = 0; m < N; ++m) {
+        const c128 wv = w[n * N + m];
+        cfma(ya, wv, xa[m]);
+        cfma(yb, wv, xb[m]);
+      }
+      if (va) Y[(row0 + (long long)n * F) * T + ja] = ya;
+      if (vb) Y[(row0 + (long long)n * F) * T + jb] = yb;
     }
   }
 }
@@ -535,6 +553,8 @@ int ssspy_weighted_covariance(const void *A, const double *weight, int weight_ki
     if (N == 4) rc = ilrma_fast_wcov_frame_n4(A, weight, U, B, F, T, as_stream(stream));
     if (rc >= 0) return rc;
   }
+  if (wide_weighted_cov_ok(N, S, F, T, weight_kind))
+    return wide_weighted_cov(A, weight, weight_kind, U, B, N, S, F, T, as_stream(stream));
   DISPATCH_N(N, return dispatch_weighted_cov<NN>((const c128 *)A, weight, weight_kind, (c128 *)U,
                                                  B, S, F, T, as_stream(stream)));
   return SSSPY_OK;
