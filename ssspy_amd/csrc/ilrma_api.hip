@@ -403,11 +403,13 @@ __global__ __launch_bounds__(256) void k_partition_normalize(double *basis, doub
 }
 
 // ------------------------------------------------------------------------------ ISS weight
-// grid: (ceil(F / ISSW_BINS), N, B).  A thread owns a frame and ISSW_BINS bins: each activation
-// value is loaded once per ISSW_BINS outputs and the basis entries are wave-uniform (scalar loads),
-// so the kernel is bound by the varphi write (one block per bin re-read the whole K x T activation
-// from L2 for every row: 0.82 ms at 32 mixtures of configs[1], against 0.54 GB of output).
-constexpr int ISSW_BINS = 16;
+// varphi[b, n, i, j] = spatial_weight(|y|^2, (T V)_nij) (the 1 / R~ of the ISS sweep and of the wide
+// covariance pass).  A wave owns 16 bins of one source and walks the frames 16 at a time: the tile of
+// T V is ceil(K / 4) f64 MFMAs (basis rows in registers for K <= 16, the activation slab one 8-byte
+// load per lane and k-step), and the D layout puts 16 consecutive frames of one bin in 16 lanes, so
+// the writes are 128-byte rows.  grid: ceil(F / 64) x N x B, wave w owns bins [64 x + 16 w, +16).
+// (The previous thread-per-frame version fetched the basis entries one scalar load at a time:
+// 0.31 ms for 0.54 GB of output.)
 __global__ __launch_bounds__(256) void k_ilrma_iss_weight(const c128 *__restrict__ Y,
                                                           const double *__restrict__ basis,
                                                           const double *__restrict__ act,
@@ -415,26 +417,47 @@ __global__ __launch_bounds__(256) void k_ilrma_iss_weight(const c128 *__restrict
                                                           IlrmaDims d) {
   const int n = blockIdx.y, b = blockIdx.z;
   const int F = d.F, T = d.T, K = d.K;
-  const int i0 = blockIdx.x * ISSW_BINS;
-  const int nb = min(ISSW_BINS, F - i0);
-  const double *tr = basis + (((long long)b * N + n) * F + i0) * K;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int i0 = blockIdx.x * 64 + wave * 16;
+  if (i0 >= F) return;
+  const double *Tn = basis + (((long long)b * N + n) * F) * K;
   const double *Vn = act + ((long long)b * N + n) * K * T;
-  const long long row0 = (((long long)b * N + n) * F + i0) * T;
-  for (int j = threadIdx.x; j < T; j += blockDim.x) {
-    double r[ISSW_BINS];
+  const long long row0 = ((long long)b * N + n) * F;
+  const int ksteps = (K + 3) >> 2;
+  // A operand: basis[bin i0 + c][4 ks + q]
+  const int abin = min(i0 + c, F - 1);
+  double ta[4];
 #pragma unroll
-    for (int ib = 0; ib < ISSW_BINS; ++ib) r[ib] = 0.0;
-    for (int k = 0; k < K; ++k) {
-      const double v = Vn[(long long)k * T + j];
+  for (int ks = 0; ks < 4; ++ks) {
+    const int kk = 4 * ks + q;
+    ta[ks] = kk < K ? Tn[(long long)abin * K + kk] : 0.0;
+  }
+  const bool need_y = d.model != SSSPY_SOURCE_GAUSS;
+  for (int j0 = 0; j0 < T; j0 += 16) {
+    const int jc = min(j0 + c, T - 1);
+    double4_t R = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int ib = 0; ib < ISSW_BINS; ++ib) r[ib] = fma(tr[min(ib, nb - 1) * K + k], v, r[ib]);
+    for (int ks = 0; ks < 4; ++ks)
+      if (ks < ksteps) {
+        const int kk = 4 * ks + q;
+        const double vb = kk < K ? Vn[(long long)kk * T + jc] : 0.0;
+        R = mfma_f64(ta[ks], vb, R);
+      }
+    for (int ks = 4; ks < ksteps; ++ks) {  // n_basis above 16: both operands from memory
+      const int kk = 4 * ks + q;
+      const double av = kk < K ? Tn[(long long)abin * K + kk] : 0.0;
+      const double vb = kk < K ? Vn[(long long)kk * T + jc] : 0.0;
+      R = mfma_f64(av, vb, R);
     }
+    // D: bin i0 + q + 4 r, frame j0 + c
 #pragma unroll
-    for (int ib = 0; ib < ISSW_BINS; ++ib) {
-      if (ib < nb) {
-        const long long e = row0 + (long long)ib * T + j;
-        const double P = (d.model != SSSPY_SOURCE_GAUSS) ? cabs2(Y[e]) : 0.0;
-        varphi[e] = spatial_weight(P, r[ib], d);
+    for (int r = 0; r < 4; ++r) {
+      const int bin = i0 + q + 4 * r;
+      if (bin < F && j0 + c < T) {
+        const long long e = (row0 + bin) * T + j0 + c;
+        const double P = need_y ? cabs2(Y[e]) : 0.0;
+        varphi[e] = spatial_weight(P, R[r], d);
       }
     }
   }
@@ -650,7 +673,7 @@ static int wcov_into(const void *X, const void *W, const double *basis, const do
   if (N > 4 && wbuf && wide_weighted_cov_ok(N, N, d.F, d.T, SSSPY_WEIGHT_BIN_FRAME)) {
     const void *Y = Ysep ? Ysep : (W ? nullptr : X);
     if (d.model == SSSPY_SOURCE_GAUSS || Y) {
-      dim3 grid((d.F + ISSW_BINS - 1) / ISSW_BINS, N, d.B), block(256);
+      dim3 grid((d.F + 63) / 64, N, d.B), block(256);
       hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, st, (const c128 *)Y, basis, activation,
                          wbuf, N, d);
       return wide_weighted_cov(X, wbuf, SSSPY_WEIGHT_BIN_FRAME, U, d.B, N, N, d.F, d.T, st);
@@ -735,7 +758,7 @@ int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *act
   int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
-  dim3 grid((F + ISSW_BINS - 1) / ISSW_BINS, N, B), block(256);
+  dim3 grid((F + 63) / 64, N, B), block(256);
   hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, as_stream(stream), (const c128 *)Y, basis,
                      activation, varphi, N, d);
   return check_launch("k_ilrma_iss_weight");

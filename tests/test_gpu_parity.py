@@ -1527,7 +1527,8 @@ def test_ilrma_five_and_seven_sources_against_oracle(model, N, B, algo, K):
         Yr = ref.run(X[b], n_iter=3, basis=basis[b], activation=act[b])
         # (IP2: eigenvectors of nearly degenerate pairs; the loss is a difference of large terms)
         np.testing.assert_allclose(np.asarray(m.loss)[:, b], ref.loss,
-                                   rtol=1e-7 if algo == "IP2" else LOSS_RTOL)
-        tol = 1e-7 if algo == "IP2" else TOL
+                                   rtol=1e-6 if algo == "IP2" else LOSS_RTOL)
+        # (IP2 on GGD sources: near-degenerate eigen pairs amplify rounding; north_star asks 1e-4)
+        tol = 1e-6 if algo == "IP2" else TOL
         assert rel_err(m.basis[b], ref.basis) < tol and rel_err(m.activation[b], ref.activation) < tol
         assert rel_err(Y[b], Yr) < tol
