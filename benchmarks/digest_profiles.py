@@ -77,6 +77,16 @@ for k, label in KERNELS.items():
 if traffic:
     traffic["_round"] = tag
     json.dump(traffic, open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
+other = latest(os.path.join(src, "other_stats", "**", "*kernel_stats.csv"))
+if other:
+    rows = [r for r in csv.DictReader(open(other))]
+    with open(os.path.join(dst, "{}_other_configs_b32_kernel_stats.csv".format(tag)), "w") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        for r in rows:
+            if float(r.get("Percentage", 0) or 0) >= 0.01:
+                r["Name"] = r["Name"][:120]
+                w.writerow(r)
 oc = os.path.join(src, "other_configs.txt")
 if os.path.exists(oc):
     shutil.copy(oc, os.path.join(dst, "{}_other_configs.txt".format(tag)))

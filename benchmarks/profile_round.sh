@@ -3,7 +3,8 @@
 #   benchmarks/profile_round.sh <tag>
 # Writes under gpurun_out/<tag>/: bench.json (default bench.py run), stats/ (rocprofv3
 # --kernel-trace --stats of a short bench run), fetch/ and write/ (separate --pmc passes for the HBM
-# traffic of the three pass kernels), other_configs.txt.  benchmarks/digest_profiles.py turns these
+# traffic of the three pass kernels), other_configs.txt, other_stats/ (rocprofv3 statistics of
+# configs[2] and configs[3] at 32 mixtures).  benchmarks/digest_profiles.py turns these
 # into the tracked files under profiles/.
 set -u
 tag=${1:-r02}
@@ -21,4 +22,9 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- \
   python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-single > $out/write.log 2>&1
 python benchmarks/other_configs.py > $out/other_configs.txt 2>&1
 python benchmarks/other_configs.py --batch 32 >> $out/other_configs.txt 2>&1
+python benchmarks/other_configs.py --batch 128 --only fastmnmf --iters 10 >> $out/other_configs.txt 2>&1
+python benchmarks/wide_mixtures.py >> $out/other_configs.txt 2>&1
+# per-kernel statistics of configs[2] / configs[3] at 32 mixtures
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/other_stats -- \
+  python benchmarks/other_configs.py --batch 32 --only iva_iss,fastmnmf --iters 10 > $out/other_stats.log 2>&1
 tail -c 600 $out/bench.json
