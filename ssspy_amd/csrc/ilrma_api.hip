@@ -407,20 +407,25 @@ __global__ __launch_bounds__(256) void k_partition_normalize(double *basis, doub
 // covariance pass).  A wave owns 16 bins of one source and walks the frames 16 at a time: the tile of
 // T V is ceil(K / 4) f64 MFMAs (basis rows in registers for K <= 16, the activation slab one 8-byte
 // load per lane and k-step), and the D layout puts 16 consecutive frames of one bin in 16 lanes, so
-// the writes are 128-byte rows.  grid: ceil(F / 64) x N x B, wave w owns bins [64 x + 16 w, +16).
+// the writes are 128-byte rows.  grid: (ceil(F / 64) * nchunks) x N x B, wave w of block (g, chunk)
+// owns bins [64 g + 16 w, +16) and the chunk's frame tiles (small batches split the frames so that
+// the launch still has a few thousand waves: iss_weight_chunks()).
 // (The previous thread-per-frame version fetched the basis entries one scalar load at a time:
 // 0.31 ms for 0.54 GB of output.)
 __global__ __launch_bounds__(256) void k_ilrma_iss_weight(const c128 *__restrict__ Y,
                                                           const double *__restrict__ basis,
                                                           const double *__restrict__ act,
                                                           double *__restrict__ varphi, int N,
-                                                          IlrmaDims d) {
+                                                          IlrmaDims d, int nchunks) {
   const int n = blockIdx.y, b = blockIdx.z;
   const int F = d.F, T = d.T, K = d.K;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int i0 = blockIdx.x * 64 + wave * 16;
+  const int group = blockIdx.x / nchunks, chunk = blockIdx.x - group * nchunks;
+  const int i0 = group * 64 + wave * 16;
   if (i0 >= F) return;
+  const int ntiles = (T + 15) >> 4, tpc = (ntiles + nchunks - 1) / nchunks;
+  const int j_begin = chunk * tpc * 16, j_end = min(T, (chunk + 1) * tpc * 16);
   const double *Tn = basis + (((long long)b * N + n) * F) * K;
   const double *Vn = act + ((long long)b * N + n) * K * T;
   const long long row0 = ((long long)b * N + n) * F;
@@ -434,33 +439,55 @@ __global__ __launch_bounds__(256) void k_ilrma_iss_weight(const c128 *__restrict
     ta[ks] = kk < K ? Tn[(long long)abin * K + kk] : 0.0;
   }
   const bool need_y = d.model != SSSPY_SOURCE_GAUSS;
-  for (int j0 = 0; j0 < T; j0 += 16) {
-    const int jc = min(j0 + c, T - 1);
-    double4_t R = {0.0, 0.0, 0.0, 0.0};
+  // two frame tiles per pass: their loads and MFMA chains are independent
+  for (int j0 = j_begin; j0 < j_end; j0 += 32) {
+    int jc[2];
+    double4_t R[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      jc[u] = min(j0 + 16 * u + c, T - 1);
+      R[u] = double4_t{0.0, 0.0, 0.0, 0.0};
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
       if (ks < ksteps) {
         const int kk = 4 * ks + q;
-        const double vb = kk < K ? Vn[(long long)kk * T + jc] : 0.0;
-        R = mfma_f64(ta[ks], vb, R);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const double vb = kk < K ? Vn[(long long)kk * T + jc[u]] : 0.0;
+          R[u] = mfma_f64(ta[ks], vb, R[u]);
+        }
       }
     for (int ks = 4; ks < ksteps; ++ks) {  // n_basis above 16: both operands from memory
       const int kk = 4 * ks + q;
       const double av = kk < K ? Tn[(long long)abin * K + kk] : 0.0;
-      const double vb = kk < K ? Vn[(long long)kk * T + jc] : 0.0;
-      R = mfma_f64(av, vb, R);
-    }
-    // D: bin i0 + q + 4 r, frame j0 + c
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int bin = i0 + q + 4 * r;
-      if (bin < F && j0 + c < T) {
-        const long long e = (row0 + bin) * T + j0 + c;
-        const double P = need_y ? cabs2(Y[e]) : 0.0;
-        varphi[e] = spatial_weight(P, R[r], d);
+      for (int u = 0; u < 2; ++u) {
+        const double vb = kk < K ? Vn[(long long)kk * T + jc[u]] : 0.0;
+        R[u] = mfma_f64(av, vb, R[u]);
       }
     }
+    // D: bin i0 + q + 4 r, frame j0 + 16 u + c
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int bin = i0 + q + 4 * r, jf = j0 + 16 * u + c;
+        if (bin < F && jf < j_end) {
+          const long long e = (row0 + bin) * T + jf;
+          const double P = need_y ? cabs2(Y[e]) : 0.0;
+          varphi[e] = spatial_weight(P, R[u][r], d);
+        }
+      }
   }
+}
+
+static inline int iss_weight_chunks(int B, int N, int F, int T) {
+  const long long waves = (long long)B * N * ((F + 15) / 16);
+  long long want = (4096 + waves - 1) / waves;
+  const int ntiles = (T + 15) / 16;
+  if (want > ntiles) want = ntiles;
+  return want < 1 ? 1 : (int)want;
 }
 
 // acc[b, n] = sum_j frame_power[b, n, j]; grid: (N, B)
@@ -673,9 +700,10 @@ static int wcov_into(const void *X, const void *W, const double *basis, const do
   if (N > 4 && wbuf && wide_weighted_cov_ok(N, N, d.F, d.T, SSSPY_WEIGHT_BIN_FRAME)) {
     const void *Y = Ysep ? Ysep : (W ? nullptr : X);
     if (d.model == SSSPY_SOURCE_GAUSS || Y) {
-      dim3 grid((d.F + 63) / 64, N, d.B), block(256);
+      const int chunks = iss_weight_chunks(d.B, N, d.F, d.T);
+      dim3 grid(((d.F + 63) / 64) * chunks, N, d.B), block(256);
       hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, st, (const c128 *)Y, basis, activation,
-                         wbuf, N, d);
+                         wbuf, N, d, chunks);
       return wide_weighted_cov(X, wbuf, SSSPY_WEIGHT_BIN_FRAME, U, d.B, N, N, d.F, d.T, st);
     }
   }
@@ -758,9 +786,10 @@ int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *act
   int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
-  dim3 grid((F + 63) / 64, N, B), block(256);
+  const int chunks = iss_weight_chunks(B, N, F, T);
+  dim3 grid(((F + 63) / 64) * chunks, N, B), block(256);
   hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, as_stream(stream), (const c128 *)Y, basis,
-                     activation, varphi, N, d);
+                     activation, varphi, N, d, chunks);
   return check_launch("k_ilrma_iss_weight");
 }
 
