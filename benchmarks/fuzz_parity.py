@@ -45,7 +45,7 @@ def main():
         if kind == "fmnmf" and rng.random() < 0.3:
             B, F, T = 300, int(rng.choice([65, 70, 129])), int(rng.choice([31, 32, 48]))  # bin-split kernels
         if kind == "gmnmf":
-            N = min(N, 4)  # GaussMNMF: up to 4 channels
+            N = min(N, 5)  # (above 4 channels the kernels run from scratch memory: keep it short)
             F, T, B = min(F, 33), min(T, 47), min(B, 2)  # the oracle holds (N,F,T,M,M) temporaries
         if N > 4:
             F, T = min(F, 70), min(T, 100)  # keep the oracle's share of the run short

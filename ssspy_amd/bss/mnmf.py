@@ -427,7 +427,8 @@ class GaussMNMF(MNMF):
 
     Args as the reference: ``n_basis``, ``n_sources`` (default: number of channels),
     ``partitioning`` (False on the device path), ``flooring_fn``, ``callbacks``,
-    ``normalization``, ``record_loss``, ``reference_id``, ``rng``.  n_channels in [2, 4].
+    ``normalization``, ``record_loss``, ``reference_id``, ``rng``.  n_channels in [2, 8] (tuned for up to 4;
+    above that the per-lane M x M kernels run out of registers and are an order of magnitude slower).
     """
 
     def __init__(

@@ -658,14 +658,18 @@ static inline size_t bin_smem(int N, int M, int K) {
     case 2: { constexpr int MM = 2; CALL; } break;                                           \
     case 3: { constexpr int MM = 3; CALL; } break;                                           \
     case 4: { constexpr int MM = 4; CALL; } break;                                           \
-    default: return fail(SSSPY_ERR_UNSUPPORTED, "GaussMNMF: n_channels must be in [2, 4]");  \
+    case 5: { constexpr int MM = 5; CALL; } break;                                           \
+    case 6: { constexpr int MM = 6; CALL; } break;                                           \
+    case 7: { constexpr int MM = 7; CALL; } break;                                           \
+    case 8: { constexpr int MM = 8; CALL; } break;                                           \
+    default: return fail(SSSPY_ERR_UNSUPPORTED, "GaussMNMF: n_channels must be in [2, 8]");  \
   }
 
 static int check_dims(int B, int N, int M, int F, int T, int K) {
   SSSPY_REQUIRE(B > 0 && F > 0 && T > 0, "GaussMNMF: bad shape");
   SSSPY_REQUIRE(N >= 1 && N <= SSSPY_MAX_SOURCES, "GaussMNMF: n_sources must be in [1, 8]");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "GaussMNMF: n_basis must be in [1, 256]");
-  if (M < 2 || M > 4) return fail(SSSPY_ERR_UNSUPPORTED, "GaussMNMF: n_channels must be in [2, 4]");
+  if (M < 2 || M > 8) return fail(SSSPY_ERR_UNSUPPORTED, "GaussMNMF: n_channels must be in [2, 8]");
   return SSSPY_OK;
 }
 
@@ -772,9 +776,16 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
     rc = refresh();
     if (rc) return rc;
     const size_t smem = bin_smem(N, M, K) + (size_t)GM_PB * (2 * M * M + GM_NMAX) * sizeof(double);
-    GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_spatial_acc<MM>), dim3(F, B), dim3(GM_PB), smem, st,
-                                        (const c128 *)X, Tn, Vn, (const c128 *)spatial, PQ, N, F,
-                                        T, K, floor_kind, floor_eps));
+    GM_DISPATCH_M(M, {
+      if (smem > 48 * 1024) {  // 8 channels: 64 points x 136 doubles; gfx950 has 160 KB per CU
+        hipError_t e = hipFuncSetAttribute((const void *)k_gmnmf_spatial_acc<MM>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+      }
+      hipLaunchKernelGGL((k_gmnmf_spatial_acc<MM>), dim3(F, B), dim3(GM_PB), smem, st,
+                         (const c128 *)X, Tn, Vn, (const c128 *)spatial, PQ, N, F, T, K,
+                         floor_kind, floor_eps);
+    });
     rc = check_launch("k_gmnmf_spatial_acc");
     if (rc) return rc;
     const long long count = (long long)B * N * F;

@@ -428,6 +428,10 @@ def main():
     run_gmnmf("gmnmf_part_m3", M=3, F=10, T=24, K=5, seed=84, gen=gen_mixture, spatial_init=True,
               partitioning=True)
     run_gmnmf("gmnmf_part_m2_n3", M=2, F=11, T=20, K=4, seed=85, n_sources=3, partitioning=True)
+    # above 4 channels (the per-lane M x M kernels spill, but run)
+    run_gmnmf("gmnmf_m5", M=5, F=9, T=26, K=3, seed=86, gen=gen_mixture, spatial_init=True, n_iter=6)
+    run_gmnmf("gmnmf_m6_n3", M=6, F=7, T=30, K=2, seed=87, n_sources=3, n_iter=6)
+    run_gmnmf("gmnmf_m8", M=8, F=5, T=36, K=2, seed=88, gen=gen_mixture, n_iter=4)
     # --- IPA (iterative projection with adjustment, LQPQM solver) ---
     run_ipa_operators()
     run_ilrma("gilrma_ipa_n3", N=3, F=18, T=40, K=4, algo="IPA", seed=100, gen=gen_mixture)

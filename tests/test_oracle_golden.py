@@ -190,7 +190,7 @@ def test_fast_gauss_mnmf(case):
 
 
 GMNMF_CASES = ["gmnmf_m2", "gmnmf_m3", "gmnmf_m4_n3", "gmnmf_m2_nonorm_add", "gmnmf_part_m3",
-               "gmnmf_part_m2_n3"]
+               "gmnmf_part_m2_n3", "gmnmf_m5", "gmnmf_m6_n3", "gmnmf_m8"]
 
 
 @pytest.mark.parametrize("case", GMNMF_CASES)
