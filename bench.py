@@ -418,6 +418,20 @@ def main():
             "AuxLaplaceIVA-IP1, same batch ({} x N={} F={} T={}), {} iterations".format(B, N, F, T, ni),
             dti, B, 2 * 16.0 * N * F * T)
         del iva
+        # ... and with ISS (the fused sweep kernel: one read and one write of the separated batch)
+        iva = AuxLaplaceIVA(spatial_algorithm="ISS", record_loss=False)
+        iva._contrast = _device_contrast(iva.contrast_fn, iva.d_contrast_fn)
+        iva._bind_input(X)
+        iva._reset()
+        for _ in range(3):
+            iva.update_once()
+        dts = time_loop(iva.update_once, ni)
+        iva._check_device_errors()
+        out["auxiva_iss"] = rate_entry(
+            "AuxLaplaceIVA-ISS, same batch ({} x N={} F={} T={}), {} iterations".format(B, N, F, T, ni),
+            dts, B, 2 * 16.0 * N * F * T)
+        del iva
+        torch.cuda.empty_cache()
 
     # ---- CPU baseline of the headline: the NumPy oracle (reference expression structure)
     if not args.no_cpu_baseline and n_gpus == 1:

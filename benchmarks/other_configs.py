@@ -35,7 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--only", default="", help="comma-separated subset of iva_iss,iva_ip,ilrma_iss,ilrma_models,fastmnmf,gmnmf")
+    ap.add_argument("--only", default="", help="comma-separated subset of iva_iss,iva_ip,iva_iss4,ilrma_iss,ilrma_models,fastmnmf,gmnmf")
     args = ap.parse_args()
     only = [t for t in args.only.split(",") if t]
 
@@ -80,6 +80,25 @@ def main():
             m.update_once()
         dt = timed(m.update_once, args.iters)
         print(json.dumps({"config": "AuxLaplaceIVA-IP N=4 F=1025 T=512 batch={}".format(B),
+                          "ms_per_iter": round(dt * 1e3, 3), "mixture_iterations_per_s": round(B / dt, 2),
+                          "algorithmic_GBs": round(2 * 16 * N * F * T * B / dt / 1e9, 1)}))
+        del m
+        torch.cuda.empty_cache()
+
+    if want("iva_iss4"):
+        # the metric's AuxIVA leg with ISS: configs[1] shape
+        N, F, T = 4, 1025, 512
+        X = nmf_mixture(1000, N, F, T)
+        if args.batch > 1:
+            X = np.stack([X] * args.batch)
+        m = AuxLaplaceIVA(spatial_algorithm="ISS", record_loss=False)
+        m._contrast = 0
+        m._bind_input(X)
+        m._reset()
+        for _ in range(3):
+            m.update_once()
+        dt = timed(m.update_once, args.iters)
+        print(json.dumps({"config": "AuxLaplaceIVA-ISS N=4 F=1025 T=512 batch={}".format(B),
                           "ms_per_iter": round(dt * 1e3, 3), "mixture_iterations_per_s": round(B / dt, 2),
                           "algorithmic_GBs": round(2 * 16 * N * F * T * B / dt / 1e9, 1)}))
         del m
