@@ -1,5 +1,7 @@
 // Shared per-bin operators: separate, (weighted / cross) covariance, IP1, ISS1 transform,
 // projection back, log-determinant.  See include/ssspy_amd.h for the contract of each entry.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "cov_core.hpp"
 #include "smallmat.hpp"
@@ -296,6 +298,127 @@ __global__ __launch_bounds__(64) void k_ip1_wide(c128 *W, const c128 *__restrict
   }
 }
 
+// The same update with a bin spread over G lanes (G = 8 for 5..8 sources): lane r owns row r of the
+// filter and of the product A = W U_n.  The LU solve of A w = e_n is row-distributed -- the pivot
+// (largest |re| + |im| among the rows not yet used, the lowest row on ties: LAPACK's choice) is found
+// by three exchange steps, its lane broadcasts the row, the other unused rows eliminate; the back
+// substitution broadcasts one unknown per step -- so every lane ends with the whole w, the arithmetic
+// of a row is the one of lu_forward / lu_backward, and no lane ever holds an N x N matrix (the
+// one-lane-per-bin kernels above: 900 resp. 325 spilled registers at N = 8, 0.56 ms for 16 x 1025
+// bins; this one 0.26 ms).  The covariance entries are read where they are used: the G lanes of a bin
+// ask for the same address (one request).  (Four lanes per bin for N <= 4 at one mixture was tried
+// for latency: 115.5 -> 114.3 us per iteration, not kept.)
+template <int N, int G>
+__global__ __launch_bounds__(256) void k_ip1_rows(c128 *W, const c128 *__restrict__ U,
+                                                  long long nbins, int floor_kind, double eps,
+                                                  int *info, const c128 *__restrict__ C,
+                                                  double *qbuf) {
+  static_assert(G == 4 || G == 8, "group of 4 or 8 lanes");
+  static_assert(N <= G, "one lane per row");
+  const int r = threadIdx.x % G;  // my row
+  const long long idx = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const bool live = idx < nbins;
+  const long long id = live ? idx : nbins - 1;  // idle groups shadow the last bin, never store
+  const bool row = r < N;
+  const int rr = row ? r : N - 1;
+  c128 Wr[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c) Wr[c] = W[id * (N * N) + rr * N + c];
+  bool ok = true;
+#pragma unroll 1
+  for (int n = 0; n < N; ++n) {
+    const c128 *Un = U + (id * N + n) * (N * N);
+    c128 a[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) a[c] = cmake(0.0, 0.0);
+#pragma unroll
+    for (int m = 0; m < N; ++m)
+#pragma unroll
+      for (int c = 0; c < N; ++c) cfma(a[c], Wr[m], Un[m * N + c]);
+    c128 rhs = cmake(r == n ? 1.0 : 0.0, 0.0);
+    int order = row ? -1 : N;  // elimination step at which my row became the pivot row
+    int plane[N];              // lane of the group that owns pivot k (uniform within the group)
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const bool cand = order < 0;
+      double bv = cand ? cabs1(a[k]) : -1.0;
+      int bl = r;
+#pragma unroll
+      for (int m = 1; m < G; m <<= 1) {
+        const double ov = __shfl_xor(bv, m, G);
+        const int ol = __shfl_xor(bl, m, G);
+        const bool take = ov > bv || (ov == bv && ol < bl);
+        bv = take ? ov : bv;
+        bl = take ? ol : bl;
+      }
+      plane[k] = bl;
+      if (r == bl) order = k;
+      c128 prow[N];
+#pragma unroll
+      for (int c = k; c < N; ++c)
+        prow[c] = cmake(__shfl(a[c].x, bl, G), __shfl(a[c].y, bl, G));
+      const c128 prhs = cmake(__shfl(rhs.x, bl, G), __shfl(rhs.y, bl, G));
+      const c128 piv = prow[k];
+      ok = ok && (piv.x != 0.0 || piv.y != 0.0);
+      const c128 inv = crecip(piv);
+      if (order < 0) {  // still unused: eliminate column k
+        const c128 f = cmul(a[k], inv);
+#pragma unroll
+        for (int c = k + 1; c < N; ++c) cfms(a[c], f, prow[c]);
+        cfms(rhs, f, prhs);
+      }
+    }
+    c128 w[N];
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) {
+      // the owner of pivot k has folded the unknowns above k into its right-hand side already
+      const c128 mine = cmul(rhs, crecip(a[k]));
+      w[k] = cmake(__shfl(mine.x, plane[k], G), __shfl(mine.y, plane[k], G));
+      if (order < k) cfms(rhs, a[k], w[k]);
+    }
+    // Re(w^H U_n w): lane r takes row r
+    c128 t = cmake(0.0, 0.0);
+#pragma unroll
+    for (int b2 = 0; b2 < N; ++b2) cfma(t, Un[rr * N + b2], w[b2]);
+    double q = 0.0;
+#pragma unroll
+    for (int c = 0; c < N; ++c)
+      if (c == rr) q = w[c].x * t.x + w[c].y * t.y;
+    q = row ? q : 0.0;
+    // (summed in row order on every lane, like quad_form: a tree would round differently)
+    double qf = 0.0;
+#pragma unroll
+    for (int c = 0; c < N; ++c) qf += __shfl(q, c, G);
+    qf = qf < 0.0 ? 0.0 : qf;  // np.maximum(., 0): NaN propagates
+    const double d = apply_floor(sqrt(qf), floor_kind, eps);
+    if (r == n) {
+#pragma unroll
+      for (int c = 0; c < N; ++c) Wr[c] = cmake(w[c].x / d, -w[c].y / d);
+    }
+  }
+  if (live && row) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) W[idx * (N * N) + r * N + c] = Wr[c];
+    if (!ok && info && r == 0) atomicAdd(info, 1);
+    if (C && qbuf) {
+      // y_r = sum_m W[r][m] x_m  =>  E|y_r|^2 = conj(v)^H C conj(v) with v = row r of W
+      const c128 *Cm = C + idx * (N * N);
+      c128 v[N];
+#pragma unroll
+      for (int m = 0; m < N; ++m) v[m] = cconj(Wr[m]);
+      double q = 0.0;
+#pragma unroll
+      for (int a2 = 0; a2 < N; ++a2) {
+        c128 t = cmake(0.0, 0.0);
+#pragma unroll
+        for (int b2 = 0; b2 < N; ++b2) cfma(t, Cm[a2 * N + b2], v[b2]);
+        q += v[a2].x * t.x + v[a2].y * t.y;
+      }
+      qbuf[idx * N + r] = q;
+    }
+  }
+}
+
 // qbuf[bin][n] = Re(w_n C w_n^H) for the current W (stand-alone power statistic)
 template <int N>
 __global__ __launch_bounds__(64) void k_row_power(const c128 *__restrict__ W,
@@ -502,6 +625,18 @@ int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, i
                    int floor_kind, double floor_eps, int *info, hipStream_t st) {
   const long long nbins = (long long)B * F;
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
+  static const bool one_lane = std::getenv("SSSPY_AMD_IP1_ONE_LANE") != nullptr;  // A/B switch
+  if (N > 4 && !one_lane) {  // a bin on 8 lanes, one per row
+    dim3 g8((unsigned)((nbins * 8 + 255) / 256)), b8(256);
+    switch (N) {
+      case 5: hipLaunchKernelGGL((k_ip1_rows<5, 8>), g8, b8, 0, st, (c128 *)W, (const c128 *)U, nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf); break;
+      case 6: hipLaunchKernelGGL((k_ip1_rows<6, 8>), g8, b8, 0, st, (c128 *)W, (const c128 *)U, nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf); break;
+      case 7: hipLaunchKernelGGL((k_ip1_rows<7, 8>), g8, b8, 0, st, (c128 *)W, (const c128 *)U, nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf); break;
+      case 8: hipLaunchKernelGGL((k_ip1_rows<8, 8>), g8, b8, 0, st, (c128 *)W, (const c128 *)U, nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf); break;
+      default: return fail(SSSPY_ERR_UNSUPPORTED, "n_sources must be in [1, 8]");
+    }
+    return check_launch("k_ip1_rows");
+  }
   if (N > 4) {  // the register-resident kernel spills heavily beyond 4 x 4 (see k_ip1_wide)
     switch (N) {
       case 5: hipLaunchKernelGGL((k_ip1_wide<5>), grid, block, 0, st, (c128 *)W, (const c128 *)U, nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf); break;
