@@ -220,92 +220,14 @@ __global__ __launch_bounds__(64) void k_ip1(c128 *W, const c128 *__restrict__ U,
   }
 }
 
-// The same update for N > 4.  An 8 x 8 complex matrix is 256 VGPRs: with the filter, the covariance and
-// the product in registers the kernel above spills ~900 registers per lane (1.1 ms for 16 x 1025
-// bins).  Here only the product A = W U_n lives in registers; the lane's filter sits in LDS
-// ([element][lane]: conflict-free), the covariance rows are streamed from global memory where they are
-// used.  Same operation order as k_ip1 (bit-identical results).
-template <int N>
-__global__ __launch_bounds__(64) void k_ip1_wide(c128 *W, const c128 *__restrict__ U,
-                                                 long long nbins, int floor_kind, double eps,
-                                                 int *info, const c128 *__restrict__ C,
-                                                 double *qbuf) {
-  __shared__ c128 wl[N * N * 64];
-  const int lane = threadIdx.x;
-  const long long idx = (long long)blockIdx.x * blockDim.x + lane;
-  const long long id = idx < nbins ? idx : nbins - 1;  // idle lanes shadow the last bin, never store
-#pragma unroll
-  for (int e = 0; e < N * N; ++e) wl[e * 64 + lane] = W[id * (N * N) + e];
-  bool ok = true;
-#pragma unroll 1
-  for (int n = 0; n < N; ++n) {
-    const c128 *Un = U + (id * N + n) * (N * N);
-    Mat<N> A;
-#pragma unroll
-    for (int r = 0; r < N; ++r)
-#pragma unroll
-      for (int c = 0; c < N; ++c) A.a[r][c] = cmake(0.0, 0.0);
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      c128 urow[N];
-#pragma unroll
-      for (int c = 0; c < N; ++c) urow[c] = Un[k * N + c];
-#pragma unroll
-      for (int r = 0; r < N; ++r) {
-        const c128 w = wl[(r * N + k) * 64 + lane];
-#pragma unroll
-        for (int c = 0; c < N; ++c) cfma(A.a[r][c], w, urow[c]);
-      }
-    }
-    c128 w[N];
-    ok = solve_unit<N>(A, n, w) && ok;
-    double qf = 0.0;  // Re(w^H U_n w), rows of U_n streamed
-#pragma unroll
-    for (int a = 0; a < N; ++a) {
-      c128 t = cmake(0.0, 0.0);
-#pragma unroll
-      for (int b2 = 0; b2 < N; ++b2) cfma(t, Un[a * N + b2], w[b2]);
-      qf += w[a].x * t.x + w[a].y * t.y;
-    }
-    qf = qf < 0.0 ? 0.0 : qf;  // np.maximum(., 0): NaN propagates
-    const double d = apply_floor(sqrt(qf), floor_kind, eps);
-#pragma unroll
-    for (int c = 0; c < N; ++c) wl[(n * N + c) * 64 + lane] = cmake(w[c].x / d, -w[c].y / d);
-  }
-  if (idx < nbins) {
-#pragma unroll
-    for (int e = 0; e < N * N; ++e) W[idx * (N * N) + e] = wl[e * 64 + lane];
-    if (!ok && info) atomicAdd(info, 1);
-    if (C && qbuf) {
-      const c128 *Cm = C + idx * (N * N);
-#pragma unroll 1
-      for (int n = 0; n < N; ++n) {
-        // y_n = sum_m W[n][m] x_m  =>  E|y_n|^2 = conj(v)^H C conj(v) with v = row n of W
-        c128 v[N];
-#pragma unroll
-        for (int m = 0; m < N; ++m) v[m] = cconj(wl[(n * N + m) * 64 + lane]);
-        double q = 0.0;
-#pragma unroll
-        for (int a = 0; a < N; ++a) {
-          c128 t = cmake(0.0, 0.0);
-#pragma unroll
-          for (int b2 = 0; b2 < N; ++b2) cfma(t, Cm[a * N + b2], v[b2]);
-          q += v[a].x * t.x + v[a].y * t.y;
-        }
-        qbuf[idx * N + n] = q;
-      }
-    }
-  }
-}
-
 // The same update with a bin spread over G lanes (G = 8 for 5..8 sources): lane r owns row r of the
 // filter and of the product A = W U_n.  The LU solve of A w = e_n is row-distributed -- the pivot
 // (largest |re| + |im| among the rows not yet used, the lowest row on ties: LAPACK's choice) is found
 // by three exchange steps, its lane broadcasts the row, the other unused rows eliminate; the back
 // substitution broadcasts one unknown per step -- so every lane ends with the whole w, the arithmetic
 // of a row is the one of lu_forward / lu_backward, and no lane ever holds an N x N matrix (the
-// one-lane-per-bin kernels above: 900 resp. 325 spilled registers at N = 8, 0.56 ms for 16 x 1025
-// bins; this one 0.26 ms).  The covariance entries are read where they are used: the G lanes of a bin
+// one-lane-per-bin kernel above spills 900 registers at N = 8, and a version with the filter in LDS
+// and the covariance streamed still 325: 1.1 resp. 0.56 ms for 16 x 1025 bins; this one 0.26 ms).  The covariance entries are read where they are used: the G lanes of a bin
 // ask for the same address (one request).  (Four lanes per bin for N <= 4 at one mixture was tried
 // for latency: 115.5 -> 114.3 us per iteration, not kept.)
 template <int N, int G>
@@ -625,8 +547,7 @@ int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, i
                    int floor_kind, double floor_eps, int *info, hipStream_t st) {
   const long long nbins = (long long)B * F;
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
-  static const bool one_lane = std::getenv("SSSPY_AMD_IP1_ONE_LANE") != nullptr;  // A/B switch
-  if (N > 4 && !one_lane) {  // a bin on 8 lanes, one per row
+  if (N > 4) {  // a bin on 8 lanes, one per row
     dim3 g8((unsigned)((nbins * 8 + 255) / 256)), b8(256);
     switch (N) {
       case 5: hipLaunchKernelGGL((k_ip1_rows<5, 8>), g8, b8, 0, st, (c128 *)W, (const c128 *)U, nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf); break;
@@ -636,16 +557,6 @@ int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, i
       default: return fail(SSSPY_ERR_UNSUPPORTED, "n_sources must be in [1, 8]");
     }
     return check_launch("k_ip1_rows");
-  }
-  if (N > 4) {  // the register-resident kernel spills heavily beyond 4 x 4 (see k_ip1_wide)
-    switch (N) {
-      case 5: hipLaunchKernelGGL((k_ip1_wide<5>), grid, block, 0, st, (c128 *)W, (const c128 *)U, nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf); break;
-      case 6: hipLaunchKernelGGL((k_ip1_wide<6>), grid, block, 0, st, (c128 *)W, (const c128 *)U, nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf); break;
-      case 7: hipLaunchKernelGGL((k_ip1_wide<7>), grid, block, 0, st, (c128 *)W, (const c128 *)U, nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf); break;
-      case 8: hipLaunchKernelGGL((k_ip1_wide<8>), grid, block, 0, st, (c128 *)W, (const c128 *)U, nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf); break;
-      default: return fail(SSSPY_ERR_UNSUPPORTED, "n_sources must be in [1, 8]");
-    }
-    return check_launch("k_ip1_wide");
   }
   DISPATCH_N(N, hipLaunchKernelGGL((k_ip1<NN>), grid, block, 0, st, (c128 *)W, (const c128 *)U,
                                    nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf));
