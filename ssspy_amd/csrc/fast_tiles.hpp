@@ -101,6 +101,48 @@ __device__ __forceinline__ XSrc<NC> make_xsrc(const c128 *Xb, int F, int T) {
   return s;
 }
 
+// |y|^2 instead of y (the grouped passes of a wide mixture read the power of the separated
+// spectrogram, (B, N, F, T) f64: half the bytes): per-channel descriptors over 8-byte elements and
+// the two tile fetches on them.
+template <int NC>
+struct PTile {
+  double p[NC][4];
+};
+template <int NC>
+__device__ __forceinline__ XSrc<NC> make_psrc(const double *Pb, int F, int T) {
+  XSrc<NC> s;
+#pragma unroll
+  for (int m = 0; m < NC; ++m)
+    s.ch[m] = make_rsrc(Pb + (long long)m * F * T, (unsigned)F * (unsigned)T * 8u);
+  return s;
+}
+__device__ __forceinline__ double f64_from(u32x2_t v) {
+  return __hiloint2double((int)v[1], (int)v[0]);
+}
+// bin-major: frames j0 + q + 4r of bin `bin`
+template <int NC>
+__device__ __forceinline__ void ptile_load_binmajor(PTile<NC> &pt, const XSrc<NC> &src, int T,
+                                                    int bin, int j0, int q) {
+  const unsigned voff = ((unsigned)bin * (unsigned)T + (unsigned)(j0 + q)) * 8u;
+#pragma unroll
+  for (int m = 0; m < NC; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      pt.p[m][r] = f64_from(__builtin_amdgcn_raw_buffer_load_b64(src.ch[m], voff + 32u * r, 0, 0));
+}
+// frame-major: frame jc of bins i0 + q + 4r
+template <int NC>
+__device__ __forceinline__ void ptile_load_framemajor(PTile<NC> &pt, const XSrc<NC> &src, int T,
+                                                      int i0, int jc, int q) {
+  const unsigned voff = ((unsigned)(i0 + q) * (unsigned)T + (unsigned)jc) * 8u;
+#pragma unroll
+  for (int m = 0; m < NC; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      pt.p[m][r] = f64_from(
+          __builtin_amdgcn_raw_buffer_load_b64(src.ch[m], voff, 4u * r * (unsigned)T * 8u, 0));
+}
+
 __device__ __forceinline__ c128 c128_from(u32x4_t v) {
   return cmake(__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2]));
 }

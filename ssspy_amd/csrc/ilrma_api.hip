@@ -25,9 +25,10 @@ DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
 #define DECL_FAST(n)                                                                           \
   int ilrma_fast_basis_n##n(const void *, const void *, const double *, double *, const double *, \
                             int, int, int, int, int, double, double *, int, double, int,        \
-                            double *, hipStream_t);                                             \
+                            double *, int, hipStream_t);                                        \
   int ilrma_fast_activation_n##n(const void *, const void *, const double *, const double *,   \
-                                 double *, int, int, int, int, int, int, double, hipStream_t); \
+                                 double *, int, int, int, int, int, int, double, int,           \
+                                 hipStream_t);                                                  \
   int ilrma_fast_wcov_n##n(const void *, const void *, const double *, const double *, void *, \
                            int, int, int, int, void *, int, double, int, double, hipStream_t); \
   int ilrma_fast_loss_n##n(const void *, const void *, const double *, const double *, double *, \
@@ -164,6 +165,8 @@ static inline size_t qbuf_bytes(int B, int N, int F) {
 
 int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, int F, int N,
                    int floor_kind, double floor_eps, int *info, hipStream_t st);
+int separate_power(const void *X, const void *W, double *P, int B, int N, int F, int T,
+                   hipStream_t st);
 // wide_cov.hip: weighted covariance of 5..8 channels on the matrix cores
 bool wide_weighted_cov_ok(int N, int S, int F, int T, int kind);
 int wide_weighted_cov(const void *A, const double *weight, int kind, void *U, int B, int N, int S,
@@ -412,7 +415,9 @@ __global__ __launch_bounds__(256) void k_partition_normalize(double *basis, doub
 // the launch still has a few thousand waves: iss_weight_chunks()).
 // (The previous thread-per-frame version fetched the basis entries one scalar load at a time:
 // 0.31 ms for 0.54 GB of output.)
+// (Ypow: |y|^2 handed in instead of y)
 __global__ __launch_bounds__(256) void k_ilrma_iss_weight(const c128 *__restrict__ Y,
+                                                          const double *__restrict__ Ypow,
                                                           const double *__restrict__ basis,
                                                           const double *__restrict__ act,
                                                           double *__restrict__ varphi, int N,
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(256) void k_ilrma_iss_weight(const c128 *__restrict
         const int bin = i0 + q + 4 * r, jf = j0 + 16 * u + c;
         if (bin < F && jf < j_end) {
           const long long e = (row0 + bin) * T + jf;
-          const double P = need_y ? cabs2(Y[e]) : 0.0;
+          const double P = need_y ? (Ypow ? Ypow[e] : cabs2(Y[e])) : 0.0;
           varphi[e] = spatial_weight(P, R[u][r], d);
         }
       }
@@ -556,7 +561,8 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
                              int B, int N, int F, int T, int K, double domain, int source_model,
                              double model_param, int floor_kind, double floor_eps, void *workspace,
                              size_t workspace_bytes, double *loss_out, bool *loss_done,
-                             void *stream) {
+                             void *stream, bool x_is_power = false) {
+  // x_is_power (grouped path of a wide mixture only, W == NULL): X holds |y|^2 (B, N, F, T) f64
   SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0, "update_basis: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_basis: n_basis must be in [1, 256]");
   SSSPY_REQUIRE(domain > 0.0 && domain <= 2.0, "update_basis: domain must be in (0, 2]");
@@ -567,26 +573,33 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
   char *ws = (char *)workspace;
   hipStream_t st = as_stream(stream);
   if (loss_done) *loss_done = false;
+  SSSPY_REQUIRE(!x_is_power || (!W && grouped_path(B, N, F, T, K, domain, source_model)),
+                "update_basis: power input off the grouped path");
   // above 16 bases the update cannot be in place (several items per bin group read the old basis)
   double *out = K > 16 ? (double *)(ws + w.btmp) : basis;
   auto run = [&]() -> int {
     SourceRun runs[3];
     if (const int nruns = source_runs(B, N, F, T, K, domain, source_model, runs)) {
-      const c128 *Y = (const c128 *)X;
+      // what the tuned kernels read: the separated spectrogram handed in (ISS / IPA state), or the
+      // power |W x|^2 formed here (half the bytes of y)
+      const char *Y = (const char *)X;
+      bool power = x_is_power;
       if (W) {
-        int r = ssspy_separate(X, W, ws + w.ybuf, B, N, F, T, stream);
+        int r = separate_power(X, W, (double *)(ws + w.ybuf), B, N, F, T, st);
         if (r) return r;
-        Y = (const c128 *)(ws + w.ybuf);
+        Y = ws + w.ybuf;
+        power = true;
       }
+      const size_t elem = power ? sizeof(double) : sizeof(c128);
       for (int i = 0; i < nruns; ++i) {
         const SourceRun &sr = runs[i];
         auto one = [&]() -> int {
-          ILRMA_FAST_DISPATCH(sr.G, ilrma_fast_basis, Y + sr.first * F * T, nullptr,
+          ILRMA_FAST_DISPATCH(sr.G, ilrma_fast_basis, Y + (size_t)sr.first * F * T * elem, nullptr,
                               basis + sr.first * F * K, out + sr.first * F * K,
                               activation + sr.first * K * T, sr.count, F, T, K, floor_kind,
                               floor_eps, (double *)(ws + w.bpart),
                               fast_model_id(domain, source_model), model_param,
-                              is_me(source_model), nullptr, st);
+                              is_me(source_model), nullptr, power ? 1 : 0, st);
         };
         const int r = one();
         if (r) return r;
@@ -597,7 +610,7 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
       if (loss_done) *loss_done = loss_out != nullptr && K <= 16;
       ILRMA_FAST_DISPATCH(N, ilrma_fast_basis, X, W, basis, out, activation, B, F, T, K, floor_kind,
                           floor_eps, (double *)(ws + w.bpart), fast_model_id(domain, source_model),
-                          model_param, is_me(source_model), K <= 16 ? loss_out : nullptr, st);
+                          model_param, is_me(source_model), K <= 16 ? loss_out : nullptr, 0, st);
     }
     const IlrmaDims d =
         make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
@@ -622,11 +635,11 @@ int ssspy_ilrma_update_basis(const void *X, const void *W, double *basis, const 
                            stream);
 }
 
-int ssspy_ilrma_update_activation(const void *X, const void *W, const double *basis,
+static int update_activation_impl(const void *X, const void *W, const double *basis,
                                   double *activation, int B, int N, int F, int T, int K,
                                   double domain, int source_model, double model_param,
                                   int floor_kind, double floor_eps, void *workspace,
-                                  size_t workspace_bytes, void *stream) {
+                                  size_t workspace_bytes, void *stream, bool x_is_power) {
   SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0,
                 "update_activation: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_activation: n_basis must be in [1, 256]");
@@ -640,24 +653,28 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   SourceRun runs[3];
   const int nruns = source_runs(B, N, F, T, K, domain, source_model, runs);
+  SSSPY_REQUIRE(!x_is_power || (nruns && !W), "update_activation: power input off the grouped path");
   // (the partial sums of a run keep the (group, chunk, source) layout at the run's offset: every
   // source owns `chunks` slabs of 2 K T doubles wherever its group starts)
   const size_t part_per_source = (size_t)chunks * 2 * K * T;
   auto run = [&]() -> int {
     if (nruns) {
-      const c128 *Y = (const c128 *)X;
+      const char *Y = (const char *)X;
+      bool power = x_is_power;
       if (W) {
-        int r = ssspy_separate(X, W, (char *)workspace + w.ybuf, B, N, F, T, stream);
+        int r = separate_power(X, W, (double *)((char *)workspace + w.ybuf), B, N, F, T, st);
         if (r) return r;
-        Y = (const c128 *)((char *)workspace + w.ybuf);
+        Y = (const char *)workspace + w.ybuf;
+        power = true;
       }
+      const size_t elem = power ? sizeof(double) : sizeof(c128);
       for (int i = 0; i < nruns; ++i) {
         const SourceRun &sr = runs[i];
         auto one = [&]() -> int {
-          ILRMA_FAST_DISPATCH(sr.G, ilrma_fast_activation, Y + sr.first * F * T, nullptr,
-                              basis + sr.first * F * K, activation + sr.first * K * T,
+          ILRMA_FAST_DISPATCH(sr.G, ilrma_fast_activation, Y + (size_t)sr.first * F * T * elem,
+                              nullptr, basis + sr.first * F * K, activation + sr.first * K * T,
                               part + sr.first * part_per_source, chunks, sr.count, F, T, K,
-                              fast_model_id(domain, source_model), model_param, st);
+                              fast_model_id(domain, source_model), model_param, power ? 1 : 0, st);
         };
         const int r = one();
         if (r) return r;
@@ -666,7 +683,7 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
     }
     if (fast_path(N, F, T, K, domain, source_model)) {
       ILRMA_FAST_DISPATCH(N, ilrma_fast_activation, X, W, basis, activation, part, chunks, B, F, T,
-                          K, fast_model_id(domain, source_model), model_param, st);
+                          K, fast_model_id(domain, source_model), model_param, 0, st);
     }
     ILRMA_DISPATCH(N, ilrma_activation, X, W, basis, activation, part, chunks, d, st);
   };
@@ -690,20 +707,31 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
   return check_launch("k_ilrma_activation_finalize");
 }
 
+int ssspy_ilrma_update_activation(const void *X, const void *W, const double *basis,
+                                  double *activation, int B, int N, int F, int T, int K,
+                                  double domain, int source_model, double model_param,
+                                  int floor_kind, double floor_eps, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+  return update_activation_impl(X, W, basis, activation, B, N, F, T, K, domain, source_model,
+                                model_param, floor_kind, floor_eps, workspace, workspace_bytes,
+                                stream, false);
+}
+
 // U[b,i,n] for every model; `upart` is the fast path's scratch for split blocks.  Wide mixtures
 // (5..8 sources) go through the weights varphi = 1 / R~ (`wbuf`, (B, N, F, T)) and the matrix-core
 // covariance of wide_cov.hip; the heavy-tailed models need the separated spectrogram for that
 // (`Ysep`, or X itself when W is NULL) and keep the generic kernel without it.
 static int wcov_into(const void *X, const void *W, const double *basis, const double *activation,
                      void *U, int N, const IlrmaDims &d, void *upart, double *wbuf,
-                     const void *Ysep, hipStream_t st) {
+                     const void *Ysep, bool ysep_is_power, hipStream_t st) {
   if (N > 4 && wbuf && wide_weighted_cov_ok(N, N, d.F, d.T, SSSPY_WEIGHT_BIN_FRAME)) {
     const void *Y = Ysep ? Ysep : (W ? nullptr : X);
+    const bool ypow = Ysep && ysep_is_power;
     if (d.model == SSSPY_SOURCE_GAUSS || Y) {
       const int chunks = iss_weight_chunks(d.B, N, d.F, d.T);
       dim3 grid(((d.F + 63) / 64) * chunks, N, d.B), block(256);
-      hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, st, (const c128 *)Y, basis, activation,
-                         wbuf, N, d, chunks);
+      hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, st, ypow ? nullptr : (const c128 *)Y,
+                         ypow ? (const double *)Y : nullptr, basis, activation, wbuf, N, d, chunks);
       return wide_weighted_cov(X, wbuf, SSSPY_WEIGHT_BIN_FRAME, U, d.B, N, N, d.F, d.T, st);
     }
   }
@@ -730,7 +758,7 @@ int ssspy_ilrma_weighted_covariance(const void *X, const void *W, const double *
   hipStream_t st = as_stream(stream);
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   return wcov_into(X, W, basis, activation, U, N, d, (char *)workspace + w.upart,
-                   N > 4 ? (double *)((char *)workspace + w.wbuf) : nullptr, nullptr, st);
+                   N > 4 ? (double *)((char *)workspace + w.wbuf) : nullptr, nullptr, false, st);
 }
 
 static int launch_norm_scale(void *W, double *basis, const double *qbuf, int B, int N, int F, int K,
@@ -788,8 +816,8 @@ int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *act
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   const int chunks = iss_weight_chunks(B, N, F, T);
   dim3 grid(((F + 63) / 64) * chunks, N, B), block(256);
-  hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, as_stream(stream), (const c128 *)Y, basis,
-                     activation, varphi, N, d, chunks);
+  hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, as_stream(stream), (const c128 *)Y,
+                     (const double *)nullptr, basis, activation, varphi, N, d, chunks);
   return check_launch("k_ilrma_iss_weight");
 }
 
@@ -842,24 +870,28 @@ static int ip1_update_impl(const void *X, const void *C, void *W, double *basis,
   // wide mixture on the grouped path: y = W x once for both NMF passes (they then see the ISS-style
   // state: the spectrogram itself, no filter)
   const void *Xs = X, *Ws = W;
+  bool xs_is_power = false;
   if (grouped_path(B, N, F, T, K, domain, source_model)) {
-    rc = ssspy_separate(X, W, ws + w.ybuf, B, N, F, T, stream);
+    // (the passes that follow need |y|^2 only: the NMF passes, and the weights of a heavy-tailed
+    // covariance pass)
+    rc = separate_power(X, W, (double *)(ws + w.ybuf), B, N, F, T, st);
     if (rc) return rc;
     Xs = ws + w.ybuf;
     Ws = nullptr;
+    xs_is_power = true;
   }
   rc = update_basis_impl(Xs, Ws, basis, activation, B, N, F, T, K, domain, source_model,
                          model_param, floor_kind, floor_eps, workspace, workspace_bytes, loss_data,
-                         &loss_done, stream);
+                         &loss_done, stream, xs_is_power);
   if (rc) return rc;
   if (loss_data && !loss_done) return fail(SSSPY_ERR_UNSUPPORTED, "ilrma_ip1_update: no loss by-product");
-  rc = ssspy_ilrma_update_activation(Xs, Ws, basis, activation, B, N, F, T, K, domain, source_model,
-                                     model_param, floor_kind, floor_eps, workspace, workspace_bytes,
-                                     stream);
+  rc = update_activation_impl(Xs, Ws, basis, activation, B, N, F, T, K, domain, source_model,
+                              model_param, floor_kind, floor_eps, workspace, workspace_bytes, stream,
+                              xs_is_power);
   if (rc) return rc;
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   rc = wcov_into(X, W, basis, activation, U, N, d, ws + w.upart,
-                 N > 4 ? (double *)(ws + w.wbuf) : nullptr, Ws ? nullptr : Xs, st);
+                 N > 4 ? (double *)(ws + w.wbuf) : nullptr, Ws ? nullptr : Xs, xs_is_power, st);
   if (rc) return rc;
   double *qbuf = (double *)(ws + w.qbuf);
   rc = ip1_with_power(W, U, normalize ? C : nullptr, normalize ? qbuf : nullptr, B, F, N,

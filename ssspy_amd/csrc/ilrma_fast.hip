@@ -149,7 +149,10 @@ __device__ __forceinline__ double mm_num_factor<FM_GAUSS1>(double pw, double, do
 // kernels.  Its 64-register basis operand only fits because |y|^2 of all sources is formed first
 // (the x tile is dead before GEMM1's operands go live); results go to `basis_out` (the sibling
 // item still reads the old basis), which the launcher copies back.
-template <bool HAS_W, int MODEL, bool LOSS, int KS>
+// IN: what X holds -- IN_X the mixture (filter applied here), IN_Y the separated spectrogram, IN_P its
+// power |y|^2 as (B, N, F, T) f64 (the grouped passes of a wide mixture: half the bytes).
+enum { IN_Y = 0, IN_X = 1, IN_P = 2 };
+template <int IN, int MODEL, bool LOSS, int KS>
 __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 *__restrict__ X,
                                                        const c128 *__restrict__ W,
                                                        const double *basis, double *basis_out,
@@ -157,6 +160,7 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 
                                                        int T, int K, int floor_kind, double eps,
                                                        TailPlan plan, double *__restrict__ part,
                                                        FastModel fm, double *__restrict__ loss_out) {
+  constexpr bool HAS_W = IN == IN_X, PIN = IN == IN_P;
   constexpr int KR = 4 * KS;  // staged activation rows per source
   __shared__ __attribute__((aligned(16))) double vs[2][N * KR * VROW];
   constexpr int WSTRIDE = N * N + 1;  // 16-byte slots per bin: odd, so 16 bins never share a bank
@@ -174,7 +178,9 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 
   double lacc = 0.0;
   LogSum lr;  // log R of everything this lane visits
   lr.clear();
-  const fast::XSrc<N> xsrc = fast::make_xsrc<N>(X + (long long)b * N * F * T, F, T);
+  const fast::XSrc<N> xsrc =
+      PIN ? fast::make_psrc<N>(reinterpret_cast<const double *>(X) + (long long)b * N * F * T, F, T)
+          : fast::make_xsrc<N>(X + (long long)b * N * F * T, F, T);
   const double *act_b = act + (long long)b * N * K * T;
 
   // demixing matrices of the wave's 16 bins -> LDS (wave-private region, filled by the wave)
@@ -205,6 +211,7 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 
   const int jt_begin = work.chunk * tpc, jt_end = min(ntiles, jt_begin + tpc);
   fast::VStage<N, KR> st;
   XTile cur;
+  fast::PTile<N> pcur;
   fast::vstage_load<N, KR>(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
   fast::vstage_store<N, KR>(st, vs[0]);
   __syncthreads();
@@ -212,7 +219,8 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 
   for (int jt = jt_begin; jt < jt_end; ++jt) {
     const int j0 = jt * 16;
     const int jn = min(jt + 1, jt_end - 1) * 16;  // last iteration re-fetches its own tile
-    fast::xtile_load_binmajor<N>(cur, xsrc, T, bin, j0, q);
+    if constexpr (PIN) fast::ptile_load_binmajor<N>(pcur, xsrc, T, bin, j0, q);
+    else fast::xtile_load_binmajor<N>(cur, xsrc, T, bin, j0, q);
     if (KS != 8) fast::vstage_load<N, KR>(st, act_b, K, T, jn);
     const double *vcur = vs[(jt - jt_begin) & 1];
     double pwall[KS == 8 ? N : 1][4];
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 
           }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pwall[n][r] = cabs2(y[r]);
+        for (int r = 0; r < 4; ++r) pwall[n][r] = PIN ? pcur.p[n][r] : cabs2(y[r]);
       }
       fast::vstage_load<N, KR>(st, act_b, K, T, jn);
     }
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 
 #pragma unroll
             for (int m = 0; m < N; ++m) cfma(y, wr[m], cur.x[m][r]);
           }
-          pw = cabs2(y);
+          pw = PIN ? pcur.p[n][r] : cabs2(y);
         }
         const bool valid = j0 + q + 4 * r < T;
         const double rinv = rcp_nr(R[r]);
@@ -748,11 +756,12 @@ __device__ __forceinline__ void tstage_store(const TStage<KS> &st, double *tbuf,
 // HAS_W = false: the ISS / IPA state passes the separated spectrogram itself (y = x_n, no filter)
 // KS = 8 (16 < n_basis <= 32): grid.y carries (bin chunk, k tile); both k-tile items run GEMM1 over all
 // 32 k and keep the sums of their own 16 (see k_basis_fast); one wave per SIMD.
-template <bool HAS_W, int MODEL, int KS>
+template <int IN, int MODEL, int KS>
 __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_activation_fast(
     const c128 *__restrict__ X, const c128 *__restrict__ W, const double *__restrict__ basis,
     const double *__restrict__ act, double *__restrict__ part, int F, int T, int K,
     int tiles_per_chunk, int nchunks, FastModel fm) {
+  constexpr bool HAS_W = IN == IN_X, PIN = IN == IN_P;
   constexpr int TROW = trow<KS>();
   __shared__ __attribute__((aligned(16))) double ts[2][N * 16 * TROW];
   __shared__ __attribute__((aligned(16))) c128 ws[2][16 * AWSTRIDE];
@@ -768,7 +777,9 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_activation_fast(
   const int jf = j0 + c;
   const bool fvalid = jf < T;
   const int jc = fvalid ? jf : T - 1;
-  const fast::XSrc<N> xsrc = fast::make_xsrc<N>(X + (long long)b * N * F * T, F, T);
+  const fast::XSrc<N> xsrc =
+      PIN ? fast::make_psrc<N>(reinterpret_cast<const double *>(X) + (long long)b * N * F * T, F, T)
+          : fast::make_xsrc<N>(X + (long long)b * N * F * T, F, T);
   const double *basis_b = basis + (long long)b * N * F * K;
   const c128 *W_b = W ? W + (long long)b * F * N * N : nullptr;
 
@@ -791,13 +802,15 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_activation_fast(
   const int t_end = min(ntiles, t_begin + tiles_per_chunk);
   TStage<KS> st;
   XTile cur;
+  fast::PTile<N> pcur;
   tstage_load<KS>(st, basis_b, W_b, F, K, t_begin * 16);
   tstage_store<KS>(st, ts[0], ws[0]);
   __syncthreads();
   for (int it = t_begin; it < t_end; ++it) {
     const int i0 = it * 16;
     const int in = min(it + 1, t_end - 1) * 16;
-    fast::xtile_load_framemajor<N>(cur, xsrc, T, i0, jc, q);
+    if constexpr (PIN) fast::ptile_load_framemajor<N>(pcur, xsrc, T, i0, jc, q);
+    else fast::xtile_load_framemajor<N>(cur, xsrc, T, i0, jc, q);
     tstage_load<KS>(st, basis_b, W_b, F, K, in);
     const int pb = (it - t_begin) & 1;
     const double *tcur = ts[pb];
@@ -823,7 +836,7 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_activation_fast(
         const bool valid = fvalid && (i0 + bl < F);
         const double rinv = rcp_nr(R[r]);
         const double bb = valid ? rinv : 0.0;
-        const double pw = cabs2(y);
+        const double pw = PIN ? pcur.p[n][r] : cabs2(y);
         const double aa = valid ? mm_num_factor<MODEL>(pw, R[r], rinv, fm) : 0.0;
         // GEMM2: A[row = c -> basis index 16 kt + c][kk = q] = T[n, bin i0+q+4r, 16 kt + c]
         // (zero-staged pads)
@@ -889,10 +902,13 @@ static inline FastModel make_fast_model(int fmodel, double mparam, int me, int f
 // loss_out: nullptr, or B zeroed doubles that receive the data term of the loss of the state at entry.
 // K <= 16: basis_out == basis (in place); 16 < K <= 32: basis_out must be a separate (B,N,F,K) buffer
 // (two k-tile items per bin group read the old basis) and the caller copies it back.
+// power_in (only with W == nullptr and loss_out == nullptr): X holds |y|^2 as (B, N, F, T) f64.
 int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis, double *basis_out,
                                const double *act, int B, int F, int T, int K, int floor_kind,
                                double eps, double *part, int fmodel, double mparam, int me,
-                               double *loss_out, hipStream_t st) {
+                               double *loss_out, int power_in, hipStream_t st) {
+  if (power_in && (W != nullptr || loss_out != nullptr))
+    return fail(SSSPY_ERR_BADARG, "ilrma_fast_basis: power input excludes a filter and the loss");
   const int ktiles = K > 16 ? 2 : 1;
   // (the wide variant holds one workgroup per CU)
   const TailPlan plan =
@@ -910,7 +926,13 @@ int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis
     case FM_GAUSS1: SSSPY_BASIS_LAUNCH(HW, FM_GAUSS1, L, KS_); break;     \
     default: SSSPY_BASIS_LAUNCH(HW, FM_GAUSS, L, KS_); break;             \
   }
-  if (ktiles == 2) {  // the wide variant carries no loss by-product (register budget)
+  if (power_in) {
+    if (ktiles == 2) {
+      SSSPY_BASIS_LAUNCH_M(IN_P, false, 8)
+    } else {
+      SSSPY_BASIS_LAUNCH_M(IN_P, false, 4)
+    }
+  } else if (ktiles == 2) {  // the wide variant carries no loss by-product (register budget)
     if (W != nullptr) {
       SSSPY_BASIS_LAUNCH_M(true, false, 8)
     } else {
@@ -943,7 +965,10 @@ int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis
 
 int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *basis,
                                     const double *act, double *part, int nchunks, int B, int F,
-                                    int T, int K, int fmodel, double mparam, hipStream_t st) {
+                                    int T, int K, int fmodel, double mparam, int power_in,
+                                    hipStream_t st) {
+  if (power_in && W != nullptr)
+    return fail(SSSPY_ERR_BADARG, "ilrma_fast_activation: power input excludes a filter");
   const int ntiles = (F + 15) / 16;
   const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
   const FastModel fm = make_fast_model(fmodel, mparam, 0);
@@ -959,7 +984,13 @@ int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *
     case FM_GAUSS1: SSSPY_ACT_LAUNCH(HW, FM_GAUSS1, KS_); break; \
     default: SSSPY_ACT_LAUNCH(HW, FM_GAUSS, KS_); break;   \
   }
-  if (ktiles == 2) {
+  if (power_in) {
+    if (ktiles == 2) {
+      SSSPY_ACT_LAUNCH_M(IN_P, 8)
+    } else {
+      SSSPY_ACT_LAUNCH_M(IN_P, 4)
+    }
+  } else if (ktiles == 2) {
     if (W != nullptr) {
       SSSPY_ACT_LAUNCH_M(true, 8)
     } else {

@@ -25,7 +25,9 @@ thread_local char g_last_error[512] = "";
 // through scalar loads (the index depends on blockIdx and loop counters only) and enter the FMAs as
 // SGPR operands -- an LDS copy costs one ds_read per complex product, which bound the kernel at
 // 8 sources (0.59 ms for 16 mixtures of N = 8, F = 1025, T = 512: 0.9 TB/s).
-template <int N>
+// POWER: write |y|^2 as (B, N, F, T) f64 into `Y` instead of y (the grouped NMF passes of a wide
+// mixture read nothing else of y: half the bytes written here and read there).
+template <int N, bool POWER = false>
 __global__ __launch_bounds__(256) void k_separate(const c128 *__restrict__ X,
                                                   const c128 *__restrict__ W, c128 *Y, int F,
                                                   int T) {
@@ -52,8 +54,14 @@ __global__ __launch_bounds__(256) void k_separate(const c128 *__restrict__ X,
         cfma(ya, wv, xa[m]);
         cfma(yb, wv, xb[m]);
       }
-      if (va) Y[(row0 + (long long)n * F) * T + ja] = ya;
-      if (vb) Y[(row0 + (long long)n * F) * T + jb] = yb;
+      if constexpr (POWER) {
+        double *P = reinterpret_cast<double *>(Y);
+        if (va) P[(row0 + (long long)n * F) * T + ja] = cabs2(ya);
+        if (vb) P[(row0 + (long long)n * F) * T + jb] = cabs2(yb);
+      } else {
+        if (va) Y[(row0 + (long long)n * F) * T + ja] = ya;
+        if (vb) Y[(row0 + (long long)n * F) * T + jb] = yb;
+      }
     }
   }
 }
@@ -561,6 +569,15 @@ int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, i
   DISPATCH_N(N, hipLaunchKernelGGL((k_ip1<NN>), grid, block, 0, st, (c128 *)W, (const c128 *)U,
                                    nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf));
   return check_launch("k_ip1");
+}
+
+// P[b, n, i, j] = |(W_i x_ij)_n|^2
+int separate_power(const void *X, const void *W, double *P, int B, int N, int F, int T,
+                   hipStream_t st) {
+  dim3 grid(F, B), block(256);
+  DISPATCH_N(N, hipLaunchKernelGGL((k_separate<NN, true>), grid, block, 0, st, (const c128 *)X,
+                                   (const c128 *)W, (c128 *)P, F, T));
+  return check_launch("k_separate_power");
 }
 
 int row_power(const void *W, const void *C, double *qbuf, int B, int F, int N, hipStream_t st) {
