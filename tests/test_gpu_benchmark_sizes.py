@@ -140,6 +140,50 @@ def test_configs3_full_size_against_oracle():
     assert rel_err(Y, ref.separate(ref.input)) < 1e-7
 
 
+def test_configs3_batch_of_32_equals_single_mixture_runs():
+    """configs[3] at the batch bench.py and the profiles quote (32 full-size mixtures, seeds
+    4000..4031): three iterations of the batched update_once() -- whole rounds plus a split tail of
+    work items, the |Qx|^2 hand-over read by the two-waves-per-SIMD basis / activation passes from
+    the second iteration on -- against the single-mixture runs of mixtures 0, 17 and 31 (all-split
+    schedule), and the batch without the hand-over."""
+    import torch
+
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+    from ssspy_amd.utils.dataset import nmf_mixture_batch, sha256_of
+
+    B, M, F, T, K = 32, 4, 1025, 512, 8
+    pins = json.load(open(os.path.join(HERE, "golden", "input_sha256.json")))
+    Xh = nmf_mixture_batch(4000, B, M, F, T)
+    assert sha256_of(Xh[0]) == pins["configs3_seed4000_N4_F1025_T512"]["sha256"]
+    rng = np.random.default_rng(4100)
+    kw = dict(basis=rng.random((B, M, F, K)), activation=rng.random((B, M, K, T)),
+              spatial=rng.random((B, F, M, M)))
+    names = ("diagonalizer", "spatial", "basis", "activation")
+
+    def run(X, sel=None):
+        m = FastGaussMNMF(n_basis=K)
+        init = {k: (v if sel is None else v[sel]).copy() for k, v in kw.items()}
+        Y = m(X, n_iter=3, **init)
+        return m, [np.array(getattr(m, k)) for k in names] + [np.array(Y)], np.asarray(m.loss)
+
+    mb, batch, lossb = run(torch.from_numpy(Xh).to("cuda"))
+    assert mb._handover is not None and lossb.shape == (4, B)
+    for b in (0, 17, 31):
+        _, single, loss1 = run(Xh[b], b)
+        for name, a, ref in zip(names + ("output",), batch, single):
+            assert rel_err(a[b], ref) < 1e-10, (b, name)
+        np.testing.assert_allclose(lossb[:, b], loss1, rtol=1e-10)
+    os.environ["SSSPY_AMD_NO_HANDOVER"] = "1"
+    try:
+        mp, plain, lossp = run(torch.from_numpy(Xh).to("cuda"))
+    finally:
+        del os.environ["SSSPY_AMD_NO_HANDOVER"]
+    assert mp._handover is None
+    for name, a, ref in zip(names + ("output",), batch, plain):
+        assert rel_err(a, ref) < 1e-10, name
+    np.testing.assert_allclose(lossb, lossp, rtol=1e-10)
+
+
 def test_bench_two_rank_control_flow_on_one_device():
     """bench.py's N > 1 path (rank/world from the environment, barrier, max over ranks, rank 0
     prints) dry-run with two gloo ranks sharing the one GPU of this box, so the multi-rank control
