@@ -50,7 +50,7 @@ def main():
         if N > 4:
             F, T = min(F, 70), min(T, 100)  # keep the oracle's share of the run short
         X = np.stack([nmf_mixture(int(rng.integers(1 << 30)), N, F, T) for _ in range(B)])
-        tag = (kind, algo, N, F, T, K, B)
+        tag = (case, kind, algo, N, F, T, K, B)
         # pairwise updates solve 2 x 2 generalised eigenproblems whose conditioning amplifies
         # rounding differences (and which are degenerate when the sources share one basis vector)
         tol = 1e-5 if algo in ("IP2", "ISS2") else 1e-7
