@@ -231,6 +231,17 @@ def other_configs(args, dev, x0_host, pins, cpu_configs1):
                               4 * 16.0 * M * F * T)
         ent[tag]["wiener_separate_ms"] = round(1e3 * time_loop(m._separate_dev, 3), 3)
         m._check_device_errors()
+        if tag == "batch":
+            # the separator's own record_loss=True loop (the reference's default): loss terms from the
+            # |Qx|^2 hand-over, kept in HBM until the end of the run
+            m.record_loss, m.loss = True, []
+            t0 = time.perf_counter()
+            assert m._iterate_with_resident_loss(iters, True)
+            torch.cuda.synchronize()
+            dtl = (time.perf_counter() - t0) / iters
+            ent["batch_with_record_loss"] = {
+                "ms_per_step": round(1e3 * dtl, 4), "iterations_per_s": round(nb / dtl, 2),
+                "note": "{} iterations + the initial loss, {} mixtures".format(iters, nb)}
         del m
         torch.cuda.empty_cache()
     if cpu:

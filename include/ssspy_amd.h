@@ -388,6 +388,15 @@ int ssspy_fastmnmf_update_handover(const void *X, const void *C, void *Q, double
                                    size_t workspace_bytes, int *info, double *handover,
                                    int *handover_valid, void *stream);
 
+/* The data term of the loss (as ssspy_fastmnmf_loss_data) from a VALID hand-over buffer instead of
+ * X and Q: half the bytes, no M x M products.  The caller guarantees that the buffer matches the
+ * current Q and X (ssspy_fastmnmf_update_handover returned *handover_valid = 1 and neither moved
+ * since).  out: B doubles.  replaces: ssspy/bss/mnmf.py:1240-1258. */
+int ssspy_fastmnmf_loss_data_handover(const double *D, const double *basis,
+                                      const double *activation, const double *handover,
+                                      double *out, int B, int N, int M, int F, int T, int K,
+                                      void *stream);
+
 /* U[b,i,m] = (1/T) sum_j x x^H / R~_ijm  -> (B,F,M,M,M): the covariances the diagonaliser update
  * (IP1 inside ssspy_fastmnmf_update, or ssspy_update_by_ip2 for diagonalizer_algorithm="IP2") needs.
  * replaces: ssspy/bss/mnmf.py:1504-1512, :1621-1629. */

@@ -92,6 +92,7 @@ PROTOTYPES = {
     "ssspy_fastmnmf_handover_doubles": (_z, [_i, _i, _i, _i, _i, _i]),
     "ssspy_fastmnmf_update_handover": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d,
                                             _p, _z, _p, _p, _p, _p]),
+    "ssspy_fastmnmf_loss_data_handover": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ssspy_fastmnmf_diagonalizer_covariance": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ssspy_fastmnmf_loss_data": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ssspy_fastmnmf_weights": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -506,6 +506,19 @@ def fastmnmf_loss_data(X, Q, D, basis, activation, out=None):
     return out
 
 
+def fastmnmf_loss_data_handover(D, basis, activation, handover, n_channels, n_frames, out=None):
+    """Data term of the loss from a valid |Q x|^2 hand-over (see fastmnmf_update_handover)."""
+    B, N, F, K = basis.shape
+    if out is None:
+        out = dv.empty((B,), dv.f64, basis.device)
+    _lib.check(
+        _L().ssspy_fastmnmf_loss_data_handover(ptr(D), ptr(basis), ptr(activation), ptr(handover),
+                                               ptr(out), B, N, n_channels, F, n_frames, K, _st()),
+        "fastmnmf_loss_data_handover",
+    )
+    return out
+
+
 def fastmnmf_separate(X, Q, D, basis, activation, reference_id, flooring, ws, ws_bytes, info,
                       out=None):
     B, M, F, T = X.shape

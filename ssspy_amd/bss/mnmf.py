@@ -72,7 +72,9 @@ class MNMFBase(DeviceStateMixin, IterativeMethodBase):
         """Separate a frequency-domain multichannel mixture (ref: ssspy/bss/mnmf.py:90-118)."""
         self._bind_input(input)
         self._reset(**kwargs)
-        IterativeMethodBase.__call__(self, n_iter=n_iter, initial_call=initial_call)
+        resident = getattr(self, "_iterate_with_resident_loss", None)
+        if resident is None or not resident(int(n_iter), initial_call):
+            IterativeMethodBase.__call__(self, n_iter=n_iter, initial_call=initial_call)
         self._separate_dev()
         return self._final_output()
 
@@ -291,15 +293,67 @@ class FastGaussMNMF(FastMNMFBase):
         out = dv.to_host(Y)
         return out if batched else out[0]
 
+    def _handover_valid(self) -> bool:
+        return (getattr(self, "_handover", None) is not None and self._handover_key ==
+                (self._state_rev("diagonalizer"), self._X.data_ptr()))
+
+    def _loss_terms(self, data_out=None, logdet_out=None):
+        """(data term, sum of log|det Q|) on the device; the data term from the |Q x|^2 hand-over
+        while it is valid (half the bytes of the pass over X)."""
+        Q = self._state_dev("diagonalizer")
+        D, Tb, Vb = (self._state_dev(k) for k in ("spatial", "basis", "activation"))
+        if self._handover_valid():
+            data = _ops.fastmnmf_loss_data_handover(D, Tb, Vb, self._handover, self.n_channels,
+                                                    self.n_frames, out=data_out)
+        else:
+            data = _ops.fastmnmf_loss_data(self._X, Q, D, Tb, Vb, out=data_out)
+        return data, _ops.sum_logdet(Q, out=logdet_out)
+
     def compute_loss(self) -> float:
         """ref: ssspy/bss/mnmf.py:1219-1261."""
-        Q = self._state_dev("diagonalizer")
-        data = _ops.fastmnmf_loss_data(self._X, Q, self._state_dev("spatial"),
-                                       self._state_dev("basis"), self._state_dev("activation"))
-        logdet = _ops.sum_logdet(Q)
+        data, logdet = self._loss_terms()
         self._check_device_errors()
         values = dv.to_host(data) - 2.0 * dv.to_host(logdet)
         return values.copy() if self._batched else values[0].item()
+
+    def _stock_ip1_iteration(self) -> bool:
+        """update_once() is the one fused C-ABI call (stock step methods, IP1, power normalisation)."""
+        cls = type(self)
+        stock = all(
+            getattr(cls, name) is getattr(FastGaussMNMF, name)
+            for name in ("update_basis", "update_activation", "update_diagonalizer",
+                         "update_spatial", "normalize", "normalize_by_power")
+        )
+        return stock and self.diagonalizer_algorithm in ["IP", "IP1"] and (
+            not self.normalization or type(self.normalization) is bool
+            or self.normalization == "power")
+
+    def _iterate_with_resident_loss(self, n_iter: int, initial_call: bool) -> bool:
+        """``record_loss=True`` (the reference's default) without a host round trip per iteration:
+        the loss terms of every iteration stay in HBM and the list is assembled from one download
+        at the end -- taken only when nothing can look at ``self.loss`` in between (no callbacks,
+        stock ``update_once`` / ``compute_loss``); otherwise (returns False) the reference's loop
+        runs unchanged.  ref: ssspy/bss/base.py:68-77, ssspy/bss/mnmf.py:1219-1261."""
+        cls = type(self)
+        if not (self.record_loss and not self.callbacks and n_iter > 0
+                and self._stock_ip1_iteration()
+                and cls.update_once is FastGaussMNMF.update_once
+                and cls.compute_loss is FastGaussMNMF.compute_loss):
+            return False
+        B, dev = self._X.shape[0], self._X.device
+        data = dv.zeros((n_iter + 1, B), dv.f64, dev)
+        logdet = dv.zeros((n_iter + 1, B), dv.f64, dev)
+        if initial_call:
+            self._loss_terms(data[0], logdet[0])
+        for t in range(n_iter):
+            self.update_once()
+            self._loss_terms(data[t + 1], logdet[t + 1])
+        self._check_device_errors()
+        values = dv.to_host(data) - 2.0 * dv.to_host(logdet)
+        if not initial_call:
+            values = values[1:]
+        self.loss.extend(v.copy() if self._batched else v[0].item() for v in values)
+        return True
 
     def compute_logdet(self, diagonalizer: np.ndarray) -> np.ndarray:
         """log|det Q_i| per bin (ref: ssspy/bss/mnmf.py:1263-1276); host-side convenience."""
@@ -307,15 +361,7 @@ class FastGaussMNMF(FastMNMFBase):
 
     def update_once(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/mnmf.py:1278-1303; one C-ABI call for the whole iteration."""
-        cls = type(self)
-        stock = all(
-            getattr(cls, name) is getattr(FastGaussMNMF, name)
-            for name in ("update_basis", "update_activation", "update_diagonalizer",
-                         "update_spatial", "normalize", "normalize_by_power")
-        )
-        if stock and self.diagonalizer_algorithm in ["IP", "IP1"] and (
-                not self.normalization or type(self.normalization) is bool
-                or self.normalization == "power"):
+        if self._stock_ip1_iteration():
             steps = _lib.MNMF_ALL if self.normalization else _lib.MNMF_ALL & ~_lib.MNMF_NORMALIZE
             self._update(steps, flooring_fn)
             return

@@ -5,6 +5,8 @@ namespace ssspy {
 
 #define DECL_N(n)                                                                                \
   int mnmf_handover_ok_n##n(int, int, int, int);                                                \
+  int mnmf_loss_handover_n##n(const double *, const double *, const double *, const double *,   \
+                              const double *, double *, int, int, int, int, int, hipStream_t);  \
   int mnmf_qx2_n##n(const void *, const void *, double *, double *, int, int, int, int,         \
                     hipStream_t);                                                               \
   int mnmf_basis_n##n(const void *, const void *, const double *, const double *, double *,     \
@@ -325,6 +327,23 @@ int ssspy_fastmnmf_loss_data(const void *X, const void *Q, const double *D, cons
   if (!mnmf_tiled(N, M))
     return fmnmf_generic_loss(X, Q, D, basis, activation, out, B, N, M, F, T, K, st);
   MNMF_DISPATCH(N, mnmf_loss, X, Q, D, basis, activation, out, B, M, F, T, K, st);
+}
+
+int ssspy_fastmnmf_loss_data_handover(const double *D, const double *basis,
+                                      const double *activation, const double *handover,
+                                      double *out, int B, int N, int M, int F, int T, int K,
+                                      void *stream) {
+  SSSPY_REQUIRE(D && basis && activation && handover && out && B > 0,
+                "fastmnmf_loss_data_handover: bad argument");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_loss_data_handover: bad n_basis");
+  if (handover_ok(B, N, M, F, T, K) != 1)
+    return fail(SSSPY_ERR_UNSUPPORTED, "fastmnmf_loss_data_handover: no hand-over for this shape");
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)B * sizeof(double), st);
+  if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+  const double *pscale = handover + (size_t)B * M * F * T;
+  MNMF_DISPATCH(N, mnmf_loss_handover, D, basis, activation, handover, pscale, out, B, M, F, T, K,
+                st);
 }
 
 int ssspy_fastmnmf_separate(const void *X, const void *Q, const double *D, const double *basis,

@@ -593,8 +593,31 @@ __device__ __forceinline__ void ptile_load(PTileM<M> &pt, __amdgpu_buffer_rsrc_t
   }
 }
 
-// which of the three bin-major passes a kernel instance performs
-enum { MODE_BASIS = 0, MODE_WCOV = 1, MODE_SPATIAL = 2 };
+// which of the bin-major passes a kernel instance performs (MODE_LOSS: the data term of the
+// negative log-likelihood from the |Q x|^2 hand-over, P_READ only)
+enum { MODE_BASIS = 0, MODE_WCOV = 1, MODE_SPATIAL = 2, MODE_LOSS = 3 };
+
+// sum of logs as a running product of mantissas plus a sum of exponents (v_frexp_*; one log at the
+// end): 2 VALU instructions per value instead of an fp64 log (same device as ilrma_fast.hip's)
+struct LogSumM {
+  double mant;
+  int expo;
+  __device__ __forceinline__ void clear() {
+    mant = 1.0;
+    expo = 0;
+  }
+  __device__ __forceinline__ void mul(double x) {
+    mant *= __builtin_amdgcn_frexp_mant(x);
+    expo += __builtin_amdgcn_frexp_exp(x);
+  }
+  __device__ __forceinline__ void renorm() {
+    expo += __builtin_amdgcn_frexp_exp(mant);
+    mant = __builtin_amdgcn_frexp_mant(mant);
+  }
+  __device__ __forceinline__ double value() const {
+    return log(mant) + 0.6931471805599453094 * (double)expo;
+  }
+};
 // the |Q x|^2 hand-over: none, read it instead of x (basis pass), write it (spatial pass)
 enum { P_NONE = 0, P_READ = 1, P_WRITE = 2 };
 #ifndef SSSPY_MNMF_PBASIS_WAVES
@@ -619,9 +642,10 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
     const double *__restrict__ act, c128 *__restrict__ U, int F, int T, int K, int floor_kind,
     double eps, TailPlan plan, double *__restrict__ tailpart, double *__restrict__ P,
     const double *__restrict__ pscale) {
-  static_assert(PMODE == P_NONE || (PMODE == P_READ && MODE == MODE_BASIS) ||
+  static_assert((PMODE == P_NONE && MODE != MODE_LOSS) ||
+                    (PMODE == P_READ && (MODE == MODE_BASIS || MODE == MODE_LOSS)) ||
                     (PMODE == P_WRITE && MODE == MODE_SPATIAL),
-                "the basis pass reads the hand-over, the spatial pass writes it");
+                "the basis and loss passes read the hand-over, the spatial pass writes it");
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
@@ -678,6 +702,10 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
 #pragma unroll
       for (int m = 0; m < M; ++m) sn[n][m] = sd[n][m] = 0.0;
   }
+  double lacc = 0.0;  // MODE_LOSS: sum of |Q x|^2 / R~ over this lane's (bin, frame, channel)
+  LogSumM lr;         // ... and of log R~
+  lr.clear();
+  const bool bin_valid = i0 + c < F;
   const int ntiles = (T + 15) >> 4;
   const int tpc = (ntiles + nchunks - 1) / nchunks;
   const int jt_begin = work.chunk * tpc, jt_end = min(ntiles, jt_begin + tpc);
@@ -742,7 +770,14 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
           g[m] = rcp_nr(rc[m]);
           h[m] = qx2[m] * g[m] * g[m];
         }
-        if (MODE == MODE_BASIS) {
+        if (MODE == MODE_LOSS) {
+          const bool lv = valid && bin_valid;
+#pragma unroll
+          for (int m = 0; m < M; ++m) {
+            lacc += lv ? qx2[m] * g[m] : 0.0;  // (select the product: g is inf on padded frames)
+            lr.mul(lv ? rc[m] : 1.0);
+          }
+        } else if (MODE == MODE_BASIS) {
 #pragma unroll
           for (int n = 0; n < N; ++n) {
             double sa = 0.0, sb = 0.0;
@@ -761,7 +796,7 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
               bq[n][r] = valid ? sb : 0.0;
             }
           }
-        } else {
+        } else if (MODE == MODE_SPATIAL) {
 #pragma unroll
           for (int m = 0; m < M; ++m)
 #pragma unroll
@@ -772,6 +807,7 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
         }
       }
     }
+    if (MODE == MODE_LOSS) lr.renorm();
     if (MODE == MODE_BASIS && PMODE != P_READ) {
 #pragma unroll
       for (int n = 0; n < N; ++n) {
@@ -808,6 +844,12 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
   for (int jt = jt_begin; jt < jt_end; jt += 2) {
     tile(cur, nxt, jt);
     if (jt + 1 < jt_end) tile(nxt, cur, jt + 1);
+  }
+  if (MODE == MODE_LOSS) {  // `tailpart` is the per-mixture output here (B zeroed doubles)
+    lacc += lr.value();
+    lacc = wave_sum(lacc);
+    if (lane == 0) atomicAdd(tailpart + b, lacc / (double)T);
+    return;
   }
   const long long slot = (long long)work.tail_idx * nchunks + work.chunk;
   double *tp = tailpart + slot * mnmf_tail_doubles<M>();
@@ -1638,6 +1680,22 @@ int LAUNCHER(mnmf_loss)(const void *X, const void *Q, const double *Dsp, const d
                          (const c128 *)Q, Dsp, basis, act, out, d);
   });
   return check_launch("k_mnmf_loss");
+}
+
+// out[b] += the data term of the loss from the hand-over (out zeroed by the caller)
+int LAUNCHER(mnmf_loss_handover)(const double *Dsp, const double *basis, const double *act,
+                                 const double *P, const double *pscale, double *out, int B, int M,
+                                 int F, int T, int K, hipStream_t st) {
+  if (!mnmf_fast_ok(B, F, T, K) || T % 2 != 0)
+    return fail(SSSPY_ERR_UNSUPPORTED, "fastmnmf_loss_data_handover: no hand-over for this shape");
+  const TailPlan plan = make_tail_plan(B, (F + 63) / 64, (T + 15) / 16, 256 * PBASIS_WAVES);
+  dim3 fgrid(plan.full + plan.tail * plan.split);
+  MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_LOSS, P_READ>), fgrid,
+                                        dim3(256), 0, st, (const c128 *)nullptr,
+                                        (const c128 *)nullptr, (double *)Dsp, (double *)basis, act,
+                                        (c128 *)nullptr, F, T, K, 0, 0.0, plan, out,
+                                        const_cast<double *>(P), pscale));
+  return check_launch("k_mnmf_loss_handover");
 }
 
 int LAUNCHER(mnmf_norm_scale)(void *Q, double *Dsp, const double *qbuf, int B, int M, int F,

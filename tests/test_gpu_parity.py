@@ -703,6 +703,30 @@ def test_fast_gauss_mnmf_handover_matches_plain_path_and_oracle(M, F, T, K, monk
     assert rel_err(m1.output, Yr) < 1e-7
 
 
+def test_fast_gauss_mnmf_resident_loss_loop_equals_reference_loop():
+    """record_loss=True without callbacks keeps the loss terms in HBM until the end of __call__;
+    with a callback the reference's loop (compute_loss() and a download per iteration) runs.  Same
+    list, same state; initial_call=False drops the first entry in both."""
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    B, M, F, T, K = 2, 4, 40, 64, 5
+    X = np.stack([nmf_mixture(300 + b, M, F, T) for b in range(B)])
+    kw = dict(basis=np.random.default_rng(1).random((B, M, F, K)),
+              activation=np.random.default_rng(2).random((B, M, K, T)),
+              spatial=np.random.default_rng(4).random((B, F, M, M)))
+    for initial_call in (True, False):
+        seen = []
+        m1 = FastGaussMNMF(n_basis=K)
+        Y1 = m1(X, n_iter=4, initial_call=initial_call, **{k: v.copy() for k, v in kw.items()})
+        m2 = FastGaussMNMF(n_basis=K, callbacks=lambda method: seen.append(len(method.loss)))
+        Y2 = m2(X, n_iter=4, initial_call=initial_call, **{k: v.copy() for k, v in kw.items()})
+        assert len(m1.loss) == len(m2.loss) == (5 if initial_call else 4)
+        assert seen == list(range(1, len(m2.loss) + 1)) if initial_call else len(seen) == 4
+        np.testing.assert_allclose(np.asarray(m1.loss), np.asarray(m2.loss), rtol=1e-12)
+        assert rel_err(Y1, Y2) < 1e-13 and rel_err(m1.diagonalizer, m2.diagonalizer) < 1e-13
+
+
 def test_fast_gauss_mnmf_handover_follows_state_changes(monkeypatch):
     """The hand-over is dropped whenever the diagonaliser moves outside the spatial pass: caller
     assignment, single steps out of order, IP2; a batch keeps one scale per (mixture, channel)."""
