@@ -261,12 +261,54 @@ class AuxIVA(AuxIVABase):
         self._contrast = _device_contrast(self.contrast_fn, self.d_contrast_fn)
         self._bind_input(input)
         self._reset(**kwargs)
-        IterativeMethodBase.__call__(self, n_iter=n_iter, initial_call=initial_call)
+        if not self._iterate_with_resident_loss(int(n_iter), initial_call):
+            IterativeMethodBase.__call__(self, n_iter=n_iter, initial_call=initial_call)
         if self.scale_restoration:
             self.restore_scale()
         if self._uses_filter():
             self._state_set_dev("output", _ops.separate(self._X, self._state_dev("demix_filter")))
         return self._final_output()
+
+    def _iterate_with_resident_loss(self, n_iter: int, initial_call: bool) -> bool:
+        """IP1 with ``record_loss=True`` (the reference's default) at the cost of ``record_loss=False``.
+
+        ``compute_loss()`` needs the frame powers of the current estimate -- a pass over the mixture
+        -- and so does the next ``update_once()``: here the loss of the state after iteration t is
+        taken from the frame powers iteration t + 1 forms anyway, all loss terms stay in HBM, and
+        the list is assembled from one download at the end.  Only when nothing can look at
+        ``self.loss`` in between (no callbacks, stock methods, a contrast that runs on the device
+        and keeps no variance state); otherwise (returns False) the reference's loop runs unchanged.
+        ref: ssspy/bss/base.py:68-77, ssspy/bss/iva.py:200-222, :1736-1793."""
+        cls = type(self)
+        if not (self.record_loss and not self.callbacks and n_iter > 0
+                and self.spatial_algorithm in _IP1 and self._contrast is not None
+                and self._variance_tensor() is None
+                and cls.update_once is AuxIVA.update_once
+                and cls.update_once_ip1 is AuxIVA.update_once_ip1
+                and cls.compute_loss is AuxIVA.compute_loss):
+            return False
+        B, dev, N = self._X.shape[0], self._X.device, self.n_sources
+        data = dv.zeros((n_iter + 1, B), dv.f64, dev)
+        logdet = dv.zeros((n_iter + 1, B), dv.f64, dev)
+        W = self._state_dev("demix_filter")
+        floor = self._resolve_floor("self")
+        for t in range(n_iter + 1):
+            r2 = _ops.iva_frame_power(self._X, W)
+            if t > 0 or initial_call:
+                _ops.iva_loss_data(r2, None, self.n_bins, self._contrast, out=data[t])
+                _ops.sum_logdet(W, out=logdet[t])
+            if t == n_iter:
+                break
+            weight = _ops.iva_weight(r2, self.n_bins, self._contrast, floor, variance=None)
+            U = _ops.weighted_covariance(self._X, weight, _lib.WEIGHT_FRAME, N)
+            _ops.update_by_ip1(W, U, floor, self._info_tensor())
+        self._state_touch("demix_filter")
+        self._check_device_errors()
+        values = dv.to_host(data) - 2.0 * dv.to_host(logdet)
+        if not initial_call:
+            values = values[1:]
+        self.loss.extend(v.copy() if self._batched else v[0].item() for v in values)
+        return True
 
     def __repr__(self) -> str:
         s = "AuxIVA(spatial_algorithm={}, scale_restoration={}, record_loss={}".format(

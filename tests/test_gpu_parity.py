@@ -703,6 +703,28 @@ def test_fast_gauss_mnmf_handover_matches_plain_path_and_oracle(M, F, T, K, monk
     assert rel_err(m1.output, Yr) < 1e-7
 
 
+def test_aux_iva_ip1_resident_loss_loop_equals_reference_loop():
+    """AuxLaplaceIVA-IP1, record_loss=True without callbacks: the loss of every state comes from the
+    frame powers the next iteration forms anyway and the list from one download; with a callback the
+    reference's loop runs (compute_loss() per iteration).  Same list, same filters."""
+    from ssspy_amd.bss.iva import AuxLaplaceIVA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    B, N, F, T = 3, 4, 33, 70
+    X = np.stack([nmf_mixture(800 + b, N, F, T) for b in range(B)])
+    for algo in ("IP", "IP1"):
+        for initial_call in (True, False):
+            m1 = AuxLaplaceIVA(spatial_algorithm=algo)
+            Y1 = m1(X, n_iter=5, initial_call=initial_call)
+            m2 = AuxLaplaceIVA(spatial_algorithm=algo, callbacks=lambda method: None)
+            Y2 = m2(X, n_iter=5, initial_call=initial_call)
+            assert len(m1.loss) == len(m2.loss) == (6 if initial_call else 5)
+            # (the frame powers are summed with atomics: runs differ in the last bits)
+            np.testing.assert_allclose(np.asarray(m1.loss), np.asarray(m2.loss), rtol=1e-11)
+            assert rel_err(Y1, Y2) < 1e-10
+            assert rel_err(m1.demix_filter, m2.demix_filter) < 1e-10
+
+
 def test_fast_gauss_mnmf_resident_loss_loop_equals_reference_loop():
     """record_loss=True without callbacks keeps the loss terms in HBM until the end of __call__;
     with a callback the reference's loop (compute_loss() and a download per iteration) runs.  Same
