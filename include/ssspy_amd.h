@@ -133,6 +133,15 @@ int ssspy_iss1_fused_max_frames(int N);
 int ssspy_iss1_fused(void *Y, const double *weight, int weight_kind, double *r2_next, int B, int N,
                      int F, int T, int floor_kind, double floor_eps, void *stream);
 
+/* The same sweep set, also tracking the log-determinant of the demixing filter the ISS state never
+ * forms: the sweep of source n multiplies W_i by (I - v e_n^T), det = d_in^(-1/2), so
+ * logdet[b] += -1/2 sum_i sum_n log d_in (logdet: B doubles holding sum_i log|det W_i| of the Y
+ * passed in; NOT zeroed by the call).  Lets compute_loss() (ssspy/bss/iva.py:2177-2192) skip the
+ * reconstruction of W from Y X^H -- two more passes per recorded loss. */
+int ssspy_iss1_fused_tracked(void *Y, const double *weight, int weight_kind, double *r2_next, int B,
+                             int N, int F, int T, int floor_kind, double floor_eps, double *logdet,
+                             void *stream);
+
 /* W <- W * (W^-1)[ref,:]^T.  W (B,F,N,N) in place.  G (B,F,N,N), optional: receives
  * diag((W^-1)[ref, :]), the scales (projection-back normalisation needs them for the basis).
  * replaces: ssspy/algorithm/projection_back.py:87-99. */

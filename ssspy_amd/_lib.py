@@ -39,6 +39,7 @@ PROTOTYPES = {
     "ssspy_iss2_transform": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
     "ssspy_iss1_fused_max_frames": (_i, [_i]),
     "ssspy_iss1_fused": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p]),
+    "ssspy_iss1_fused_tracked": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
     "ssspy_projection_back_filter": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "ssspy_mdp_scale": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "ssspy_ilrma_scale_basis": (_i, [_p, _p, _i, _i, _i, _i, _d, _p]),

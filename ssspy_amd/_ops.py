@@ -164,9 +164,17 @@ def iss1_fused_max_frames(n_sources):
     return int(_L().ssspy_iss1_fused_max_frames(n_sources))
 
 
-def iss1_fused(Y, weight, kind, flooring, r2_next=None):
-    """In-place fused ISS1 on Y; optionally accumulates the next iteration's frame powers."""
+def iss1_fused(Y, weight, kind, flooring, r2_next=None, logdet=None):
+    """In-place fused ISS1 on Y; optionally accumulates the next iteration's frame powers, and moves
+    `logdet` (B,) = sum_i log|det W_i| of the implied demixing filters along with the sweeps."""
     B, N, F, T = Y.shape
+    if logdet is not None:
+        _lib.check(
+            _L().ssspy_iss1_fused_tracked(ptr(Y), ptr(weight), kind, ptr(r2_next), B, N, F, T,
+                                          flooring[0], flooring[1], ptr(logdet), _st()),
+            "iss1_fused_tracked",
+        )
+        return Y
     _lib.check(
         _L().ssspy_iss1_fused(ptr(Y), ptr(weight), kind, ptr(r2_next), B, N, F, T, flooring[0],
                               flooring[1], _st()),

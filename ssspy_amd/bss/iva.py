@@ -321,7 +321,13 @@ class AuxIVA(AuxIVABase):
     def _reset(self, **kwargs) -> None:
         """ref: ssspy/bss/iva.py:1687-1697."""
         super()._reset(**kwargs)
+        self._logdet_cache = None
         if self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"]:
+            # sum_i log|det W_i| of the filters the ISS state stops carrying, as (tensor, revision of
+            # `output` it describes): the fused sweep kernel moves it along (each sweep multiplies
+            # det W_i by d_in^(-1/2)), so compute_loss() need not rebuild W from Y X^H
+            self._logdet_cache = (_ops.sum_logdet(self._state_dev("demix_filter")),
+                                  self._state_rev("output"))
             self.demix_filter = None
         # frame powers of the output (ISS state) as (tensor, revision of `output` they describe): any
         # later write to the output -- a kernel, scale restoration, an assignment by a callback --
@@ -436,29 +442,46 @@ class AuxIVA(AuxIVABase):
         if self.n_frames <= _ops.iss1_fused_max_frames(N):
             # one read + one write of Y; the kernel also leaves the next iteration's frame powers
             r2_next = dv.empty(tuple(weight.shape), dv.f64, Y.device)
-            _ops.iss1_fused(Y, weight, _lib.WEIGHT_FRAME, floor, r2_next)
+            tracked = self._tracked_logdet()
+            _ops.iss1_fused(Y, weight, _lib.WEIGHT_FRAME, floor, r2_next, logdet=tracked)
             self._state_touch("output")
             self._r2_cache = (r2_next, self._state_rev("output"))
+            self._logdet_cache = None if tracked is None else (tracked, self._state_rev("output"))
         else:
             Vc = _ops.weighted_covariance(Y, weight, _lib.WEIGHT_FRAME, N)
             G = _ops.iss1_transform(Vc, floor)
             _ops.separate(Y, G, out=Y)
             self._state_touch("output")
 
-    def compute_loss(self) -> float:
-        """ref: ssspy/bss/iva.py:200-222 (filter state), :2177-2192 (ISS state)."""
+    def _tracked_logdet(self):
+        """The tracked sum_i log|det W_i| if it describes the current output, else None."""
+        cache = getattr(self, "_logdet_cache", None)
+        if cache is not None and cache[1] == self._state_rev("output"):
+            return cache[0]
+        return None
+
+    def _logdet_sum(self):
+        """sum_i log|det W_i| (B,) on the device, and the filters if they had to be formed."""
         if self._uses_filter():
             W = self._state_dev("demix_filter")
-        else:
-            W = _ops.demix_from_covariance(_ops.cross_covariance(self._state_dev("output"), self._X),
-                                           self._C(), self._info_tensor())
+            return _ops.sum_logdet(W), W
+        tracked = self._tracked_logdet()
+        if tracked is not None:
+            return tracked, None
+        W = _ops.demix_from_covariance(_ops.cross_covariance(self._state_dev("output"), self._X),
+                                       self._C(), self._info_tensor())
+        return _ops.sum_logdet(W), W
+
+    def compute_loss(self) -> float:
+        """ref: ssspy/bss/iva.py:200-222 (filter state), :2177-2192 (ISS state)."""
+        logdet, W = self._logdet_sum()
         if self._contrast is None:
-            return self._host_contrast_loss(W)
+            return self._host_contrast_loss(W, logdet)
         r2 = self._frame_power()
         data = _ops.iva_loss_data(r2, self._variance_tensor(), self.n_bins, self._contrast)
-        return self._host_loss(data, _ops.sum_logdet(W))
+        return self._host_loss(data, logdet)
 
-    def _host_contrast_loss(self, W):
+    def _host_contrast_loss(self, W, logdet_dev):
         """Loss with a user ``contrast_fn``: the closure takes the whole separated spectrogram
         (ssspy/bss/iva.py:216, :2181), so the estimate crosses PCIe once per recorded loss -- the
         price of an opaque Python callable, paid only with ``record_loss=True``."""
@@ -469,7 +492,7 @@ class AuxIVA(AuxIVABase):
         else:
             Y = dv.to_host(self._state_dev("output"))
         self._check_device_errors()
-        logdet = dv.to_host(_ops.sum_logdet(W))
+        logdet = dv.to_host(logdet_dev)
         values = np.array([np.sum(np.mean(self.contrast_fn(Yb), axis=1), axis=0) for Yb in Y])
         values = values - 2.0 * logdet
         return values.copy() if self._batched else values[0].item()

@@ -94,10 +94,13 @@ struct IssShape {
 // The N sequential rank-1 sweeps of one bin on the register-resident slab y[n][f] (thread-owned
 // frames), weights phi[n][f]; `part` is the two-buffer LDS scratch of the block reduction (one
 // barrier per sweep), `parity` its state.  ref: ssspy/bss/_update_spatial_model.py:146-194.
-template <int N, int FPT>
+// TRACK: lane n also sums log d_n over the sweeps into `ld`.  The sweep of source n multiplies the
+// demixing matrix by (I - v e_n^T), whose determinant is 1 - v_n = d_n^(-1/2): the log-determinant of
+// the (never formed) filter moves by -1/2 log d_n, which is all compute_loss() needs of it.
+template <int N, int FPT, bool TRACK = false>
 __device__ __forceinline__ void iss_sweeps(c128 (&y)[N][FPT], const double (&phi)[N][FPT],
                                            double *part, int &parity, double invT, int floor_kind,
-                                           double eps) {
+                                           double eps, double *ld = nullptr) {
   using S = IssShape<N>;
   constexpr int SGR = S::SGR, NG = S::NG, NVP = S::NVP;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -148,6 +151,7 @@ __device__ __forceinline__ void iss_sweeps(c128 (&y)[N][FPT], const double (&phi
       }
     }
     const double den = apply_floor(t2 * invT, floor_kind, eps);
+    if (TRACK && lane == n) *ld += log(den);
     const double vx = lane == n ? 1.0 - 1.0 / sqrt(den) : t0 * invT / den;
     const double vy = lane == n ? 0.0 : t1 * invT / den;
     c128 v[N];
@@ -164,11 +168,12 @@ __device__ __forceinline__ void iss_sweeps(c128 (&y)[N][FPT], const double (&phi
 
 // grid: (ceil(F / bins_per_block), B); 256 threads; thread t owns frames t + 256 f, f < FPT.
 // weight: (B, N, T) when !PER_BIN, (B, N, F, T) when PER_BIN.
-template <int N, int FPT, bool PER_BIN>
+// TRACK: logdet_delta[b] += sum over this block's bins of -1/2 sum_n log d_n (see iss_sweeps)
+template <int N, int FPT, bool PER_BIN, bool TRACK = false>
 __global__ __launch_bounds__(256, 2) void k_iss1_fused(c128 *Y, const double *__restrict__ weight,
                                                        double *r2_next, int F, int T,
                                                        int bins_per_block, int floor_kind,
-                                                       double eps) {
+                                                       double eps, double *logdet_delta) {
   __shared__ double part[2 * IssShape<N>::PART];
   __shared__ double r2s[N * FPT * 256];  // [n][f][thread]: thread-private slots, no barrier needed
   const int b = blockIdx.y;
@@ -196,6 +201,7 @@ __global__ __launch_bounds__(256, 2) void k_iss1_fused(c128 *Y, const double *__
       phi[n][f] = fv[f] ? wv : 0.0;
     }
   int parity = 0;
+  double ld = 0.0;
   for (int i = i_begin; i < i_end; ++i) {
     c128 y[N][FPT];
 #pragma unroll
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void k_iss1_fused(c128 *Y, const double *__
         }
       }
     }
-    iss_sweeps<N, FPT>(y, phi, part, parity, invT, floor_kind, eps);
+    iss_sweeps<N, FPT, TRACK>(y, phi, part, parity, invT, floor_kind, eps, &ld);
 #pragma unroll
     for (int n = 0; n < N; ++n) {
       const long long row = (((long long)b * N + n) * F + i) * T;
@@ -224,6 +230,14 @@ __global__ __launch_bounds__(256, 2) void k_iss1_fused(c128 *Y, const double *__
         if (fv[f]) buffer_store_c128(yr, jj[f] * 16u, y[n][f]);
         r2s[(n * FPT + f) * 256 + threadIdx.x] += cabs2(y[n][f]);
       }
+    }
+  }
+  if (TRACK) {
+    // every wave holds the same sums in its lanes 0..N-1: wave 0 reports
+    double v = (threadIdx.x < N) ? ld : 0.0;
+    if (threadIdx.x < 64) {
+      v = wave_sum(v);
+      if (threadIdx.x == 0) atomicAdd(logdet_delta + b, -0.5 * v);
     }
   }
   if (r2_next) {
@@ -243,32 +257,40 @@ constexpr int iss_max_fpt() {
 
 template <int N, int FPT>
 static int launch_iss(void *Y, const double *weight, bool per_bin, double *r2_next, int B, int F,
-                      int T, int floor_kind, double eps, hipStream_t st) {
+                      int T, int floor_kind, double eps, double *logdet_delta, hipStream_t st) {
   // a few bins per block amortise the weight loads and the r2 atomics; keep >= ~4 blocks per CU
   long long want_blocks = 1024;
   int bpb = (int)(((long long)B * F + want_blocks - 1) / want_blocks);
   if (bpb < 1) bpb = 1;
   if (bpb > 8) bpb = 8;
   dim3 grid((F + bpb - 1) / bpb, B), block(256);
-  if (per_bin)
+  if (logdet_delta) {  // tracked variants (a separate instantiation: the untracked hot kernels keep
+                       // their register allocation)
+    if (per_bin)
+      hipLaunchKernelGGL((k_iss1_fused<N, FPT, true, true>), grid, block, 0, st, (c128 *)Y, weight,
+                         r2_next, F, T, bpb, floor_kind, eps, logdet_delta);
+    else
+      hipLaunchKernelGGL((k_iss1_fused<N, FPT, false, true>), grid, block, 0, st, (c128 *)Y, weight,
+                         r2_next, F, T, bpb, floor_kind, eps, logdet_delta);
+  } else if (per_bin)
     hipLaunchKernelGGL((k_iss1_fused<N, FPT, true>), grid, block, 0, st, (c128 *)Y, weight, r2_next,
-                       F, T, bpb, floor_kind, eps);
+                       F, T, bpb, floor_kind, eps, (double *)nullptr);
   else
     hipLaunchKernelGGL((k_iss1_fused<N, FPT, false>), grid, block, 0, st, (c128 *)Y, weight, r2_next,
-                       F, T, bpb, floor_kind, eps);
+                       F, T, bpb, floor_kind, eps, (double *)nullptr);
   return check_launch("k_iss1_fused");
 }
 
 template <int N>
 static int dispatch_iss(void *Y, const double *weight, bool per_bin, double *r2_next, int B, int F,
-                        int T, int floor_kind, double eps, hipStream_t st) {
+                        int T, int floor_kind, double eps, double *ld, hipStream_t st) {
   const int fpt = (T + 255) / 256;
-  if (fpt <= 1) return launch_iss<N, 1>(Y, weight, per_bin, r2_next, B, F, T, floor_kind, eps, st);
-  if (fpt <= 2) return launch_iss<N, 2>(Y, weight, per_bin, r2_next, B, F, T, floor_kind, eps, st);
-  if (fpt <= 4) return launch_iss<N, 4>(Y, weight, per_bin, r2_next, B, F, T, floor_kind, eps, st);
+  if (fpt <= 1) return launch_iss<N, 1>(Y, weight, per_bin, r2_next, B, F, T, floor_kind, eps, ld, st);
+  if (fpt <= 2) return launch_iss<N, 2>(Y, weight, per_bin, r2_next, B, F, T, floor_kind, eps, ld, st);
+  if (fpt <= 4) return launch_iss<N, 4>(Y, weight, per_bin, r2_next, B, F, T, floor_kind, eps, ld, st);
   if (iss_max_fpt<N>() >= 8 && fpt <= 8)
     return launch_iss<N, (iss_max_fpt<N>() >= 8 ? 8 : 4)>(Y, weight, per_bin, r2_next, B, F, T,
-                                                          floor_kind, eps, st);
+                                                          floor_kind, eps, ld, st);
   return fail(SSSPY_ERR_UNSUPPORTED, "iss1_fused: n_frames too large for the register-resident slab");
 }
 
@@ -283,8 +305,9 @@ int ssspy_iss1_fused_max_frames(int N) {
   return 256 * (N <= 4 ? 8 : 4);
 }
 
-int ssspy_iss1_fused(void *Y, const double *weight, int weight_kind, double *r2_next, int B, int N,
-                     int F, int T, int floor_kind, double floor_eps, void *stream) {
+static int iss1_fused_impl(void *Y, const double *weight, int weight_kind, double *r2_next, int B,
+                           int N, int F, int T, int floor_kind, double floor_eps,
+                           double *logdet_delta, void *stream) {
   SSSPY_REQUIRE(Y && weight && B > 0 && F > 0 && T > 0, "iss1_fused: bad argument");
   SSSPY_REQUIRE(weight_kind == SSSPY_WEIGHT_FRAME || weight_kind == SSSPY_WEIGHT_BIN_FRAME,
                 "iss1_fused: weight_kind must be FRAME or BIN_FRAME");
@@ -295,8 +318,22 @@ int ssspy_iss1_fused(void *Y, const double *weight, int weight_kind, double *r2_
     if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
   }
   DISPATCH_N(N, return dispatch_iss<NN>(Y, weight, per_bin, r2_next, B, F, T, floor_kind, floor_eps,
-                                        as_stream(stream)));
+                                        logdet_delta, as_stream(stream)));
   return SSSPY_OK;
+}
+
+int ssspy_iss1_fused(void *Y, const double *weight, int weight_kind, double *r2_next, int B, int N,
+                     int F, int T, int floor_kind, double floor_eps, void *stream) {
+  return iss1_fused_impl(Y, weight, weight_kind, r2_next, B, N, F, T, floor_kind, floor_eps, nullptr,
+                         stream);
+}
+
+int ssspy_iss1_fused_tracked(void *Y, const double *weight, int weight_kind, double *r2_next, int B,
+                             int N, int F, int T, int floor_kind, double floor_eps,
+                             double *logdet, void *stream) {
+  SSSPY_REQUIRE(logdet, "iss1_fused_tracked: bad argument");
+  return iss1_fused_impl(Y, weight, weight_kind, r2_next, B, N, F, T, floor_kind, floor_eps, logdet,
+                         stream);
 }
 
 }  // extern "C"

@@ -725,6 +725,32 @@ def test_aux_iva_ip1_resident_loss_loop_equals_reference_loop():
             assert rel_err(m1.demix_filter, m2.demix_filter) < 1e-10
 
 
+@pytest.mark.parametrize("N,T", [(2, 40), (4, 300), (8, 70)])
+def test_aux_iva_iss_tracked_logdet_equals_rebuilt_filters(N, T):
+    """ISS keeps no filters; compute_loss() needs sum_i log|det W_i|.  The fused sweep kernel tracks
+    it (each sweep multiplies det W_i by d_in^(-1/2)); without the tracker W is rebuilt from Y X^H
+    for every recorded loss.  Same loss lists, also from a non-identity initial filter."""
+    from ssspy_amd.bss.iva import AuxGaussIVA, AuxLaplaceIVA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    B, F = 2, 33
+    X = np.stack([nmf_mixture(850 + b, N, F, T) for b in range(B)])
+    rng = np.random.default_rng(N)
+    W0 = np.eye(N) + 0.2 * (rng.standard_normal((B, F, N, N)) + 1j * rng.standard_normal((B, F, N, N)))
+    for cls in (AuxLaplaceIVA, AuxGaussIVA):
+        class Untracked(cls):
+            def _tracked_logdet(self):
+                return None
+
+        for kw in ({}, {"demix_filter": W0}):
+            m1 = cls(spatial_algorithm="ISS")
+            m1(X, n_iter=4, **{k: v.copy() for k, v in kw.items()})
+            assert m1._tracked_logdet() is None  # retired by the scale restoration at the end
+            m2 = Untracked(spatial_algorithm="ISS")
+            m2(X, n_iter=4, **{k: v.copy() for k, v in kw.items()})
+            np.testing.assert_allclose(np.asarray(m1.loss), np.asarray(m2.loss), rtol=1e-10)
+
+
 def test_fast_gauss_mnmf_resident_loss_loop_equals_reference_loop():
     """record_loss=True without callbacks keeps the loss terms in HBM until the end of __call__;
     with a callback the reference's loop (compute_loss() and a download per iteration) runs.  Same
