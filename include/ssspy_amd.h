@@ -254,6 +254,13 @@ int ssspy_ilrma_normalize_output(void *Y, double *basis, const double *frame_pow
                                  double floor_eps, void *workspace, size_t workspace_bytes,
                                  void *stream);
 
+/* The same, also moving the tracked sum_i log|det W_i| of the ISS state (ssspy_iss1_fused_tracked):
+ * dividing source n by psi_n divides row n of every implied filter, logdet[b] -= F sum_n log psi_n. */
+int ssspy_ilrma_normalize_output_tracked(void *Y, double *basis, const double *frame_power, int B,
+                                         int N, int F, int T, int K, double domain, int floor_kind,
+                                         double floor_eps, void *workspace, size_t workspace_bytes,
+                                         double *logdet, void *stream);
+
 /* varphi[b,n,i,j] (B,N,F,T) doubles for the ISS paths; Y (the separated spectrogram) is read only
  * by the heavy-tailed models.
  * replaces: ssspy/bss/ilrma.py:1690-1694, :3125-3143, :4202-4220. */

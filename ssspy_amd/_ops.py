@@ -294,10 +294,19 @@ def ilrma_normalize_filter(W, C, basis, domain, flooring, ws, ws_bytes):
     )
 
 
-def ilrma_normalize_output(Y, basis, domain, flooring, ws, ws_bytes, frame_power=None):
-    """frame_power (B,N,T): sum over bins of |Y|^2 of the current Y when the caller already has it."""
+def ilrma_normalize_output(Y, basis, domain, flooring, ws, ws_bytes, frame_power=None, logdet=None):
+    """frame_power (B,N,T): sum over bins of |Y|^2 of the current Y when the caller already has it.
+    logdet (B,): the tracked sum_i log|det W_i| of the ISS state, moved along with the scaling."""
     B, N, F, T = Y.shape
     K = basis.shape[-1]
+    if logdet is not None:
+        _lib.check(
+            _L().ssspy_ilrma_normalize_output_tracked(
+                ptr(Y), ptr(basis), ptr(frame_power), B, N, F, T, K, domain, flooring[0],
+                flooring[1], ptr(ws), ws_bytes, ptr(logdet), _st()),
+            "ilrma_normalize_output_tracked",
+        )
+        return
     _lib.check(
         _L().ssspy_ilrma_normalize_output(ptr(Y), ptr(basis), ptr(frame_power), B, N, F, T, K,
                                           domain, flooring[0], flooring[1], ptr(ws), ws_bytes,

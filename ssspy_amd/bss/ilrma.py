@@ -303,8 +303,24 @@ class _MMILRMA(ILRMABase):
         """ref: ssspy/bss/ilrma.py:875-898."""
         flooring_fn = choose_flooring_fn(flooring_fn, method=self)
         super()._reset(flooring_fn=flooring_fn, **kwargs)
+        self._logdet_cache = None
         if self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"]:
+            # sum_i log|det W_i| of the filters the ISS state stops carrying, as (tensor, revision of
+            # `output` it describes); the fused sweep and the power normalisation move it along, so
+            # compute_loss() need not rebuild W from Y X^H (see AuxIVA._reset)
+            self._logdet_cache = (_ops.sum_logdet(self._state_dev("demix_filter")),
+                                  self._state_rev("output"))
             self.demix_filter = None
+
+    def _tracked_logdet(self):
+        """The tracked sum_i log|det W_i| if it describes the current output, else None."""
+        cache = getattr(self, "_logdet_cache", None)
+        if cache is not None and cache[1] == self._state_rev("output"):
+            return cache[0]
+        return None
+
+    def _restamp_logdet(self, tracked) -> None:
+        self._logdet_cache = None if tracked is None else (tracked, self._state_rev("output"))
 
     # -- the loop with the loss as a by-product ----------------------------------------------
     def _fused_ip1(self) -> bool:
@@ -569,13 +585,17 @@ class _MMILRMA(ILRMABase):
             # the sweep also leaves sum_i |y_nij|^2 of the new Y: the power normalisation that
             # follows in update_once() reads it instead of making its own pass over Y
             frame_power = dv.empty((Y.shape[0], N, Y.shape[-1]), dv.f64, Y.device)
-            _ops.iss1_fused(Y, varphi, _lib.WEIGHT_BIN_FRAME, floor, r2_next=frame_power)
+            tracked = self._tracked_logdet()
+            _ops.iss1_fused(Y, varphi, _lib.WEIGHT_BIN_FRAME, floor, r2_next=frame_power,
+                            logdet=tracked)
         else:
+            tracked = None
             Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
             G = _ops.iss1_transform(Vc, floor)
             _ops.separate(Y, G, out=Y)
         self._state_touch("output")
         self._iss_frame_power = (frame_power, self._state_rev("output"))
+        self._restamp_logdet(tracked)
 
     def normalize(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/ilrma.py:333-363."""
@@ -636,9 +656,12 @@ class _MMILRMA(ILRMABase):
             frame_power, rev = getattr(self, "_iss_frame_power", (None, None))
             if rev != self._state_rev("output"):
                 frame_power = None  # Y was replaced or rewritten since the sweep
+            tracked = self._tracked_logdet()
             _ops.ilrma_normalize_output(Y, self._state_dev("basis"), float(self.domain), floor,
-                                        self._ws, self._ws_bytes, frame_power=frame_power)
+                                        self._ws, self._ws_bytes, frame_power=frame_power,
+                                        logdet=tracked)
             self._state_touch("output")
+            self._restamp_logdet(tracked)
         self._state_touch("basis")
 
     def compute_loss(self) -> float:
@@ -649,9 +672,12 @@ class _MMILRMA(ILRMABase):
             data = _ops.ilrma_loss_data(self._X, W, T, V, float(self.domain), model=self._model)
         else:
             Y = self._state_dev("output")
+            data = _ops.ilrma_loss_data(Y, None, T, V, float(self.domain), model=self._model)
+            tracked = self._tracked_logdet()
+            if tracked is not None:  # moved along by the sweeps and the normalisation
+                return self._host_loss(data, tracked)
             W = _ops.demix_from_covariance(_ops.cross_covariance(Y, self._X), self._C(),
                                            self._info_tensor())
-            data = _ops.ilrma_loss_data(Y, None, T, V, float(self.domain), model=self._model)
         return self._host_loss(data, _ops.sum_logdet(W))
 
 

@@ -277,11 +277,14 @@ __global__ __launch_bounds__(256) void k_ilrma_normalize_output(c128 *Y, double 
                                                                 const double *__restrict__ acc,
                                                                 int N, int F, int T, int K,
                                                                 double p, int floor_kind,
-                                                                double eps, double *psi_out) {
+                                                                double eps, double *psi_out,
+                                                                double *logdet) {
   const int i = blockIdx.x, n = blockIdx.y, b = blockIdx.z;
   double v = acc[b * N + n] / ((double)F * (double)T);
   const double psi = apply_floor(sqrt(v), floor_kind, eps);
   if (psi_out && i == 0 && threadIdx.x == 0) psi_out[b * N + n] = psi;
+  // (row n of every implied demixing matrix is divided by psi: sum_i log|det W_i| moves by -F log psi)
+  if (logdet && i == 0 && threadIdx.x == 0) atomicAdd(logdet + b, -(double)F * log(psi));
   c128 *row = Y + (((long long)b * N + n) * F + i) * T;
   for (int j = threadIdx.x; j < T; j += blockDim.x) {
     c128 y = row[j];
@@ -782,10 +785,10 @@ int ssspy_ilrma_normalize_filter(void *W, const void *C, double *basis, int B, i
   return launch_norm_scale(W, basis, qbuf, B, N, F, K, domain, floor_kind, floor_eps, st);
 }
 
-int ssspy_ilrma_normalize_output(void *Y, double *basis, const double *frame_power, int B, int N,
+static int normalize_output_impl(void *Y, double *basis, const double *frame_power, int B, int N,
                                  int F, int T, int K, double domain, int floor_kind,
                                  double floor_eps, void *workspace, size_t workspace_bytes,
-                                 void *stream) {
+                                 double *logdet, void *stream) {
   SSSPY_REQUIRE(Y && basis && B > 0 && N >= 1, "normalize_output: bad argument");
   SSSPY_REQUIRE(workspace && workspace_bytes >= (size_t)B * N * sizeof(double),
                 "normalize_output: workspace too small");
@@ -801,8 +804,25 @@ int ssspy_ilrma_normalize_output(void *Y, double *basis, const double *frame_pow
                        N, F, T);
   }
   hipLaunchKernelGGL(k_ilrma_normalize_output, grid, block, 0, st, (c128 *)Y, basis, acc, N, F, T,
-                     K, domain, floor_kind, floor_eps, (double *)nullptr);
+                     K, domain, floor_kind, floor_eps, (double *)nullptr, logdet);
   return check_launch("k_ilrma_normalize_output");
+}
+
+int ssspy_ilrma_normalize_output(void *Y, double *basis, const double *frame_power, int B, int N,
+                                 int F, int T, int K, double domain, int floor_kind,
+                                 double floor_eps, void *workspace, size_t workspace_bytes,
+                                 void *stream) {
+  return normalize_output_impl(Y, basis, frame_power, B, N, F, T, K, domain, floor_kind, floor_eps,
+                               workspace, workspace_bytes, nullptr, stream);
+}
+
+int ssspy_ilrma_normalize_output_tracked(void *Y, double *basis, const double *frame_power, int B,
+                                         int N, int F, int T, int K, double domain, int floor_kind,
+                                         double floor_eps, void *workspace, size_t workspace_bytes,
+                                         double *logdet, void *stream) {
+  SSSPY_REQUIRE(logdet, "normalize_output_tracked: bad argument");
+  return normalize_output_impl(Y, basis, frame_power, B, N, F, T, K, domain, floor_kind, floor_eps,
+                               workspace, workspace_bytes, logdet, stream);
 }
 
 int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *activation,
@@ -1027,7 +1047,8 @@ int ssspy_ilrma_partition_normalize(void *W, const void *C, void *Y, double *bas
     hipLaunchKernelGGL(k_output_power, dim3((F + 15) / 16, N, B), block, 0, st, (const c128 *)Y, qbuf,
                        N, F, T);
     hipLaunchKernelGGL(k_ilrma_normalize_output, grid, block, 0, st, (c128 *)Y, (double *)nullptr,
-                       (const double *)qbuf, N, F, T, K, domain, floor_kind, floor_eps, psi);
+                       (const double *)qbuf, N, F, T, K, domain, floor_kind, floor_eps, psi,
+                       (double *)nullptr);
     int rc = check_launch("k_ilrma_normalize_output");
     if (rc) return rc;
   }

@@ -751,6 +751,32 @@ def test_aux_iva_iss_tracked_logdet_equals_rebuilt_filters(N, T):
             np.testing.assert_allclose(np.asarray(m1.loss), np.asarray(m2.loss), rtol=1e-10)
 
 
+@pytest.mark.parametrize("N,norm", [(2, True), (4, True), (4, False), (8, True), (3, "projection_back")])
+def test_ilrma_iss_tracked_logdet_equals_rebuilt_filters(N, norm):
+    """ILRMA on the ISS state: the sweeps and the power normalisation move the tracked
+    sum_i log|det W_i| along; without it (and with the projection-back normalisation, which retires
+    it) compute_loss() rebuilds W from Y X^H.  Same loss lists."""
+    from ssspy_amd.bss.ilrma import GaussILRMA, TILRMA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    B, F, T, K = 2, 33, 70, 4
+    X = np.stack([nmf_mixture(870 + b, N, F, T) for b in range(B)])
+    rng = np.random.default_rng(N)
+    init = dict(basis=rng.random((B, N, F, K)), activation=rng.random((B, N, K, T)))
+    for cls, extra in ((GaussILRMA, {}), (TILRMA, {"dof": 5.0})):
+        class Untracked(cls):
+            def _tracked_logdet(self):
+                return None
+
+        kw = dict(n_basis=K, spatial_algorithm="ISS", normalization=norm, **extra)
+        m1 = cls(**kw)
+        m1(X, n_iter=4, **{k: v.copy() for k, v in init.items()})
+        m2 = Untracked(**kw)
+        m2(X, n_iter=4, **{k: v.copy() for k, v in init.items()})
+        np.testing.assert_allclose(np.asarray(m1.loss), np.asarray(m2.loss), rtol=1e-10)
+        assert rel_err(m1.output, m2.output) < 1e-12
+
+
 def test_fast_gauss_mnmf_resident_loss_loop_equals_reference_loop():
     """record_loss=True without callbacks keeps the loss terms in HBM until the end of __call__;
     with a callback the reference's loop (compute_loss() and a download per iteration) runs.  Same
