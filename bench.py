@@ -179,6 +179,22 @@ def other_configs(args, dev, x0_host, pins, cpu_configs1):
         ent["cpu_baseline"] = cpu_configs1  # same oracle on the same mixture as the headline's
     out["configs1_single"] = ent
     del sep1
+    # ... and the metric's AuxIVA leg on the same single mixture (IP1: two passes over X; ISS: one
+    # read + one write of the separated spectrogram)
+    for key, algo in (("auxiva_ip_single", "IP"), ("auxiva_iss_single", "ISS")):
+        iva = AuxLaplaceIVA(spatial_algorithm=algo, record_loss=False)
+        iva._contrast = _device_contrast(iva.contrast_fn, iva.d_contrast_fn)
+        iva._bind_input(torch.from_numpy(x0_host[None]).to(dev))
+        iva._reset()
+        if algo == "IP":
+            iva._C()
+        for _ in range(20):
+            iva.update_once()
+        dt = time_loop(iva.update_once, 300)
+        iva._check_device_errors()
+        out[key] = rate_entry("AuxLaplaceIVA-{} N=4 F=1025 T=512, 1 mixture, 300 iterations".format(
+            "IP1" if algo == "IP" else "ISS"), dt, 1, 2 * 16.0 * N * F * T)
+        del iva
 
     # ---- configs[2]: AuxLaplaceIVA-ISS, N=8, F=2049, T=1024 (2 passes: read Y, write Y)
     N, F, T = 8, 2049, 1024
