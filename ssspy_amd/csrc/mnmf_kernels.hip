@@ -537,12 +537,13 @@ __device__ __forceinline__ void vstage_store(const VStage &st, double *buf) {
   }
 }
 // ksteps = ceil(K / 4): k-slabs beyond n_basis are zero on both sides and are skipped
-__device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const double (&tb)[4], int c,
+template <int KQ>
+__device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const double (&tb)[KQ], int c,
                                                  int q, int ksteps) {
   double4_t R = {0.0, 0.0, 0.0, 0.0};
   const int col = tile_pi(c);
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
+  for (int ks = 0; ks < KQ; ++ks)
     if (ks < ksteps) R = mfma_f64(vs_n[(4 * ks + q) * VROW + col], tb[ks], R);
   return R;
 }
@@ -636,7 +637,8 @@ constexpr int mnmf_tail_doubles() {
   return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
-template <int M, int MODE, int PMODE = P_NONE>
+// KQ: k-slabs of 4 the instance carries (4: n_basis <= 16; 2: n_basis <= 8, half the basis registers)
+template <int M, int MODE, int PMODE = P_NONE, int KQ = 4>
 __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnmf_binmajor_fast(
     const c128 *__restrict__ X, const c128 *__restrict__ Q, double *Dsp, double *basis,
     const double *__restrict__ act, c128 *__restrict__ U, int F, int T, int K, int floor_kind,
@@ -676,11 +678,11 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
   for (int n = 0; n < N; ++n)
 #pragma unroll
     for (int m = 0; m < M; ++m) Db[n][m] = Dsp[((long long)b * F + bin) * (N * M) + n * M + m];
-  double tb[N][4];
+  double tb[N][KQ];
 #pragma unroll
   for (int n = 0; n < N; ++n)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KQ; ++ks) {
       const int kk = 4 * ks + q;
       tb[n][ks] = kk < K ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
     }
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
     const double *vcur = vs[(jt - jt_begin) & 1];
     double4_t lamR[N];
 #pragma unroll
-    for (int n = 0; n < N; ++n) lamR[n] = rt_from_lds(vcur + n * 16 * VROW, tb[n], c, q, ksteps);
+    for (int n = 0; n < N; ++n) lamR[n] = rt_from_lds<KQ>(vcur + n * 16 * VROW, tb[n], c, q, ksteps);
     double a[N][4], bq[N][4];
     double pw[M][4];  // P_WRITE: this tile's |Q x|^2
 #pragma unroll
@@ -1529,7 +1531,12 @@ int LAUNCHER(mnmf_basis)(const void *X, const void *Q, const double *Dsp, const 
                             : mnmf_plan(B, F, T);
     dim3 fgrid(plan.full + plan.tail * plan.split);
     MNMF_DISPATCH_M(M, {
-      if (P)
+      if (P && K <= 8)
+        hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_BASIS, P_READ, 2>), fgrid, dim3(256), 0,
+                           st, (const c128 *)X, (const c128 *)Q, (double *)Dsp, basis_out, act,
+                           (c128 *)nullptr, F, T, K, floor_kind, eps, plan, tailpart,
+                           const_cast<double *>(P), pscale);
+      else if (P)
         hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_BASIS, P_READ>), fgrid, dim3(256), 0, st,
                            (const c128 *)X, (const c128 *)Q, (double *)Dsp, basis_out, act,
                            (c128 *)nullptr, F, T, K, floor_kind, eps, plan, tailpart,
