@@ -774,7 +774,7 @@ def test_ilrma_iss_tracked_logdet_equals_rebuilt_filters(N, norm):
         m2 = Untracked(**kw)
         m2(X, n_iter=4, **{k: v.copy() for k, v in init.items()})
         np.testing.assert_allclose(np.asarray(m1.loss), np.asarray(m2.loss), rtol=1e-10)
-        assert rel_err(m1.output, m2.output) < 1e-12
+        assert rel_err(m1.output, m2.output) < 1e-9  # (frame powers are summed with atomics)
 
 
 def test_fast_gauss_mnmf_resident_loss_loop_equals_reference_loop():
@@ -797,8 +797,8 @@ def test_fast_gauss_mnmf_resident_loss_loop_equals_reference_loop():
         Y2 = m2(X, n_iter=4, initial_call=initial_call, **{k: v.copy() for k, v in kw.items()})
         assert len(m1.loss) == len(m2.loss) == (5 if initial_call else 4)
         assert seen == list(range(1, len(m2.loss) + 1)) if initial_call else len(seen) == 4
-        np.testing.assert_allclose(np.asarray(m1.loss), np.asarray(m2.loss), rtol=1e-12)
-        assert rel_err(Y1, Y2) < 1e-13 and rel_err(m1.diagonalizer, m2.diagonalizer) < 1e-13
+        np.testing.assert_allclose(np.asarray(m1.loss), np.asarray(m2.loss), rtol=1e-11)
+        assert rel_err(Y1, Y2) < 1e-11 and rel_err(m1.diagonalizer, m2.diagonalizer) < 1e-11
 
 
 def test_fast_gauss_mnmf_handover_follows_state_changes(monkeypatch):
