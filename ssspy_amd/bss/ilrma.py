@@ -304,7 +304,9 @@ class _MMILRMA(ILRMABase):
         flooring_fn = choose_flooring_fn(flooring_fn, method=self)
         super()._reset(flooring_fn=flooring_fn, **kwargs)
         self._logdet_cache = None
-        if self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"]:
+        if self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"] and not self.record_loss:
+            self.demix_filter = None  # (nothing reads the log-determinant: no tracker)
+        elif self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"]:
             # sum_i log|det W_i| of the filters the ISS state stops carrying, as (tensor, revision of
             # `output` it describes); the fused sweep and the power normalisation move it along, so
             # compute_loss() need not rebuild W from Y X^H (see AuxIVA._reset)

@@ -322,7 +322,9 @@ class AuxIVA(AuxIVABase):
         """ref: ssspy/bss/iva.py:1687-1697."""
         super()._reset(**kwargs)
         self._logdet_cache = None
-        if self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"]:
+        if self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"] and not self.record_loss:
+            self.demix_filter = None  # (nothing reads the log-determinant: no tracker)
+        elif self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"]:
             # sum_i log|det W_i| of the filters the ISS state stops carrying, as (tensor, revision of
             # `output` it describes): the fused sweep kernel moves it along (each sweep multiplies
             # det W_i by d_in^(-1/2)), so compute_loss() need not rebuild W from Y X^H

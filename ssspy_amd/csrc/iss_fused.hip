@@ -97,10 +97,17 @@ struct IssShape {
 // TRACK: lane n also sums log d_n over the sweeps into `ld`.  The sweep of source n multiplies the
 // demixing matrix by (I - v e_n^T), whose determinant is 1 - v_n = d_n^(-1/2): the log-determinant of
 // the (never formed) filter moves by -1/2 log d_n, which is all compute_loss() needs of it.
+// (kept as a product of mantissas and a sum of exponents -- three registers, four instructions per
+// sweep -- with one log per workgroup at the end: an fp64 log inside the sweeps cost the N = 8 slab
+// kernel, which sits at the register cap, a third of its speed)
+struct LogProd {
+  double mant;
+  int expo;
+};
 template <int N, int FPT, bool TRACK = false>
 __device__ __forceinline__ void iss_sweeps(c128 (&y)[N][FPT], const double (&phi)[N][FPT],
                                            double *part, int &parity, double invT, int floor_kind,
-                                           double eps, double *ld = nullptr) {
+                                           double eps, LogProd *ld = nullptr) {
   using S = IssShape<N>;
   constexpr int SGR = S::SGR, NG = S::NG, NVP = S::NVP;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -151,7 +158,11 @@ __device__ __forceinline__ void iss_sweeps(c128 (&y)[N][FPT], const double (&phi
       }
     }
     const double den = apply_floor(t2 * invT, floor_kind, eps);
-    if (TRACK && lane == n) *ld += log(den);
+    if (TRACK) {  // lane n keeps d_n; the others multiply by one
+      const double f = lane == n ? den : 1.0;
+      ld->mant *= __builtin_amdgcn_frexp_mant(f);
+      ld->expo += __builtin_amdgcn_frexp_exp(f);
+    }
     const double vx = lane == n ? 1.0 - 1.0 / sqrt(den) : t0 * invT / den;
     const double vy = lane == n ? 0.0 : t1 * invT / den;
     c128 v[N];
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void k_iss1_fused(c128 *Y, const double *__
       phi[n][f] = fv[f] ? wv : 0.0;
     }
   int parity = 0;
-  double ld = 0.0;
+  LogProd ld{1.0, 0};
   for (int i = i_begin; i < i_end; ++i) {
     c128 y[N][FPT];
 #pragma unroll
@@ -234,7 +245,8 @@ __global__ __launch_bounds__(256, 2) void k_iss1_fused(c128 *Y, const double *__
   }
   if (TRACK) {
     // every wave holds the same sums in its lanes 0..N-1: wave 0 reports
-    double v = (threadIdx.x < N) ? ld : 0.0;
+    // (at most 8 bins x 8 sweeps of factors in [1/2, 1): the mantissa product cannot underflow)
+    double v = (threadIdx.x < N) ? log(ld.mant) + 0.6931471805599453094 * (double)ld.expo : 0.0;
     if (threadIdx.x < 64) {
       v = wave_sum(v);
       if (threadIdx.x == 0) atomicAdd(logdet_delta + b, -0.5 * v);
