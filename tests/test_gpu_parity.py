@@ -777,6 +777,28 @@ def test_ilrma_iss_tracked_logdet_equals_rebuilt_filters(N, norm):
         assert rel_err(m1.output, m2.output) < 1e-9  # (frame powers are summed with atomics)
 
 
+def test_iss_logdet_tracker_only_with_record_loss():
+    """The tracked sweep kernel is a separate, slightly slower instantiation (the N = 8 slab kernel
+    sits at the register cap): it must run only when the loss is recorded."""
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.bss.iva import AuxLaplaceIVA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    X = nmf_mixture(5, 3, 17, 40)
+    for record_loss in (False, True):
+        for m in (AuxLaplaceIVA(spatial_algorithm="ISS", record_loss=record_loss),
+                  GaussILRMA(n_basis=2, spatial_algorithm="ISS", record_loss=record_loss)):
+            m._bind_input(X)
+            if isinstance(m, AuxLaplaceIVA):
+                from ssspy_amd.bss.iva import _device_contrast
+                m._contrast = _device_contrast(m.contrast_fn, m.d_contrast_fn)
+                m._reset()
+            else:
+                m._reset(flooring_fn=m.flooring_fn)
+            m.update_once()
+            assert (m._tracked_logdet() is not None) == record_loss
+
+
 def test_fast_gauss_mnmf_resident_loss_loop_equals_reference_loop():
     """record_loss=True without callbacks keeps the loss terms in HBM until the end of __call__;
     with a callback the reference's loop (compute_loss() and a download per iteration) runs.  Same
