@@ -360,6 +360,11 @@ def main():
             tj = json.load(open(tpath))
             traffic = tj.get("k_ilrma_" + dominant, {}).get("hbm_bytes_per_launch_batch{}".format(B))
             traffic_source = "profiles/roofline_traffic.json ({})".format(tj.get("_round", "r01"))
+            from ssspy_amd.utils.dataset import kernel_sources_sha256
+            if tj.get("_kernel_sources_sha256") not in (None, kernel_sources_sha256()):
+                # the counters were collected on other kernel sources: do not quote them
+                traffic = None
+                traffic_source += " -- stale: the pass kernels changed since it was collected"
         except Exception:
             traffic = None
     roofline = {

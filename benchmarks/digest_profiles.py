@@ -76,6 +76,9 @@ for k, label in KERNELS.items():
         }
 if traffic:
     traffic["_round"] = tag
+    sys.path.insert(0, ROOT)
+    from ssspy_amd.utils.dataset import kernel_sources_sha256
+    traffic["_kernel_sources_sha256"] = kernel_sources_sha256()  # bench.py: stale after a kernel change
     json.dump(traffic, open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
 other = latest(os.path.join(src, "other_stats", "**", "*kernel_stats.csv"))
 if other:

@@ -73,3 +73,17 @@ def nmf_mixture_batch(first_seed, n_mixtures, n_sources, n_bins, n_frames, worke
 def sha256_of(array):
     """SHA-256 of the C-contiguous bytes of an array."""
     return hashlib.sha256(np.ascontiguousarray(array).tobytes()).hexdigest()
+
+
+def kernel_sources_sha256():
+    """SHA-256 over the sources of the three ILRMA pass kernels (the kernels the committed PMC traffic
+    figures describe): lets bench.py see when `profiles/roofline_traffic.json` predates a change."""
+    import hashlib
+    import os
+
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+    h = hashlib.sha256()
+    for name in ("ilrma_fast.hip", "fast_tiles.hpp", "tail_plan.hpp", "common.hpp"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
