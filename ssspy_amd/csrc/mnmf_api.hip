@@ -25,7 +25,7 @@ namespace ssspy {
                            double *, hipStream_t);                                              \
   int mnmf_separate_n##n(const void *, const void *, void *, const double *, const double *,    \
                          const double *, void *, int, int, int, int, int, int, int, double,     \
-                         int *, hipStream_t);
+                         int *, int *, hipStream_t);
 DECL_N(2) DECL_N(3) DECL_N(4)
 #undef DECL_N
 
@@ -358,8 +358,9 @@ int ssspy_fastmnmf_separate(const void *X, const void *Q, const double *D, const
   if (!mnmf_tiled(N, M))
     return fmnmf_generic_separate(X, Q, Qinv, D, basis, activation, Y, B, N, M, F, T, K,
                                   reference_id, floor_kind, floor_eps, info, as_stream(stream));
+  // (the per-bin row powers' scratch is idle here: B F ints of it flag the bins for the general kernel)
   MNMF_DISPATCH(N, mnmf_separate, X, Q, Qinv, D, basis, activation, Y, B, M, F, T, K, reference_id,
-                floor_kind, floor_eps, info, as_stream(stream));
+                floor_kind, floor_eps, info, (int *)((char *)workspace + w.qbuf), as_stream(stream));
 }
 
 }  // extern "C"

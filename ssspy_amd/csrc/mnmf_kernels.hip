@@ -1339,6 +1339,169 @@ __global__ __launch_bounds__(64) void k_mnmf_qinv(const c128 *__restrict__ Q, c1
   if (!ok && info) atomicAdd(info, 1);
 }
 
+// The closed form alone (see k_mnmf_separate below for the bound): when min_m R~_m clears the
+// eigenvalue floor at every frame of a bin -- the normal case with the default floor of 1e-10 --
+// the bin is finished here, by a kernel that carries no eigen-decomposition and so runs at full
+// occupancy; otherwise redo[b, i] is set and the general kernel recomputes the bin.
+// grid: (F, B); lanes along frames.
+template <int M>
+__global__ __launch_bounds__(256) void k_mnmf_separate_closed(
+    const c128 *__restrict__ X, const c128 *__restrict__ Q, const c128 *__restrict__ Qinv,
+    const double *__restrict__ Dsp, const double *__restrict__ basis,
+    const double *__restrict__ act, c128 *Y, Dims d, int ref, int floor_kind, double eps,
+    int *__restrict__ redo) {
+  const int i = blockIdx.x, b = blockIdx.y;
+  const int F = d.F, T = d.T, K = d.K;
+  __shared__ c128 qref[M];
+  __shared__ c128 qsrc[M * M];
+  __shared__ double dd[N * M];
+  if (threadIdx.x < M) qref[threadIdx.x] = Qinv[((long long)b * F + i) * (M * M) + ref * M + threadIdx.x];
+  if (threadIdx.x < M * M) qsrc[threadIdx.x] = Q[((long long)b * F + i) * (M * M) + threadIdx.x];
+  if (threadIdx.x < N * M) dd[threadIdx.x] = Dsp[((long long)b * F + i) * (N * M) + threadIdx.x];
+  __syncthreads();
+  if (floor_kind == SSSPY_FLOOR_ADD) {  // add-flooring shifts every eigenvalue: general path
+    if (threadIdx.x == 0) redo[(long long)b * F + i] = 1;
+    return;
+  }
+  double qf2 = 0.0;
+#pragma unroll
+  for (int e = 0; e < M * M; ++e) qf2 += cabs2(qsrc[e]);
+  bool bad = false;
+  for (int j = threadIdx.x; j < T; j += blockDim.x) {
+    double lam[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const double *tr = basis + (((long long)b * N + n) * F + i) * K;
+      const double *Vn = act + ((long long)b * N + n) * K * T;
+      double r = 0.0;
+      for (int k = 0; k < K; ++k) r = fma(tr[k], Vn[(long long)k * T + j], r);
+      lam[n] = r;
+    }
+    double rc[M];
+    double rcmin = 0.0;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      double r = 0.0;
+#pragma unroll
+      for (int n = 0; n < N; ++n) r = fma(lam[n], dd[n * M + m], r);
+      rc[m] = r;
+      rcmin = m == 0 ? r : (r < rcmin ? r : rcmin);
+    }
+    if (!(rcmin > eps * qf2 * 1.0000001)) {
+      bad = true;
+      continue;
+    }
+    c128 x[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] = X[(((long long)b * M + m) * F + i) * T + j];
+    // s_m = (Q x)_m / rc_m ;  Y_n = sum_m lam_n d_nm q~[ref][m] s_m  (the operations of the general
+    // kernel's closed branch, in its order)
+    c128 sm[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      c128 y = cmake(0.0, 0.0);
+#pragma unroll
+      for (int a = 0; a < M; ++a) cfma(y, qsrc[m * M + a], x[a]);
+      const double g = 1.0 / rc[m];
+      sm[m] = cmul(qref[m], cmake(y.x * g, y.y * g));
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      c128 y = cmake(0.0, 0.0);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const double wgt = lam[n] * dd[n * M + m];
+        y.x = fma(wgt, sm[m].x, y.x);
+        y.y = fma(wgt, sm[m].y, y.y);
+      }
+      Y[(((long long)b * N + n) * F + i) * T + j] = y;
+    }
+  }
+  if (bad) redo[(long long)b * F + i] = 1;
+}
+
+// The same for n_basis <= 16 with a thread owning ONE frame of SEP_BINS consecutive bins: the
+// activations of its frame stay in registers across the bins (the per-bin kernel above fetches
+// N K values per point, 4 GB of L2 traffic at 32 mixtures), and everything per-bin -- basis rows, Q,
+// row `ref` of Q^-1, D -- is block-uniform and arrives through scalar loads, so there is no LDS and
+// no barrier.  grid: (ceil(F / SEP_BINS), ceil(T / 256), B).
+constexpr int SEP_BINS = 16;
+template <int M>
+__global__ __launch_bounds__(256) void k_mnmf_separate_closed_rows(
+    const c128 *__restrict__ X, const c128 *__restrict__ Q, const c128 *__restrict__ Qinv,
+    const double *__restrict__ Dsp, const double *__restrict__ basis,
+    const double *__restrict__ act, c128 *Y, Dims d, int ref, double eps,
+    int *__restrict__ redo) {
+  const int b = blockIdx.z;
+  const int F = d.F, T = d.T, K = d.K;
+  const int j = blockIdx.y * 256 + threadIdx.x;
+  const bool fvalid = j < T;
+  const int jc = fvalid ? j : T - 1;
+  double v[N][16];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      v[n][k] = k < K ? act[(((long long)b * N + n) * K + k) * T + jc] : 0.0;
+  const int i_end = min(F, (int)(blockIdx.x + 1) * SEP_BINS);
+  for (int i = blockIdx.x * SEP_BINS; i < i_end; ++i) {
+    const c128 *__restrict__ qsrc = Q + ((long long)b * F + i) * (M * M);
+    const c128 *__restrict__ qref = Qinv + ((long long)b * F + i) * (M * M) + ref * M;
+    const double *__restrict__ dd = Dsp + ((long long)b * F + i) * (N * M);
+    double qf2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < M * M; ++e) qf2 += cabs2(qsrc[e]);
+    double lam[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const double *__restrict__ tr = basis + (((long long)b * N + n) * F + i) * K;
+      double r = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (k < K) r = fma(tr[k], v[n][k], r);
+      lam[n] = r;
+    }
+    double rc[M];
+    double rcmin = 0.0;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      double r = 0.0;
+#pragma unroll
+      for (int n = 0; n < N; ++n) r = fma(lam[n], dd[n * M + m], r);
+      rc[m] = r;
+      rcmin = m == 0 ? r : (r < rcmin ? r : rcmin);
+    }
+    if (!fvalid) continue;
+    if (!(rcmin > eps * qf2 * 1.0000001)) {
+      redo[(long long)b * F + i] = 1;
+      continue;
+    }
+    c128 x[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] = X[(((long long)b * M + m) * F + i) * T + j];
+    c128 sm[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      c128 y = cmake(0.0, 0.0);
+#pragma unroll
+      for (int a = 0; a < M; ++a) cfma(y, qsrc[m * M + a], x[a]);
+      const double g = 1.0 / rc[m];
+      sm[m] = cmul(qref[m], cmake(y.x * g, y.y * g));
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      c128 y = cmake(0.0, 0.0);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const double wgt = lam[n] * dd[n * M + m];
+        y.x = fma(wgt, sm[m].x, y.x);
+        y.y = fma(wgt, sm[m].y, y.y);
+      }
+      Y[(((long long)b * N + n) * F + i) * T + j] = y;
+    }
+  }
+}
+
 // grid: (F, B); lanes along frames.  Y_n = sum_m lam_n d_nm q~[ref][m] s_m,
 // s = Q~^H R^-1 x, R = to_psd(sum_m R~_m q~_m q~_m^H) (eigenvalues floored).
 template <int M>
@@ -1349,9 +1512,11 @@ __global__ __launch_bounds__(256) void k_mnmf_separate(const c128 *__restrict__ 
                                                        const double *__restrict__ basis,
                                                        const double *__restrict__ act, c128 *Y,
                                                        Dims d, int ref, int floor_kind,
-                                                       double eps) {
+                                                       double eps, const int *__restrict__ redo) {
   const int i = blockIdx.x, b = blockIdx.y;
   const int F = d.F, T = d.T, K = d.K;
+  // (redo: only the bins the closed-form kernel below could not finish)
+  if (redo && redo[(long long)b * F + i] == 0) return;
   __shared__ c128 qt[M * M];
   __shared__ c128 qsrc[M * M];
   __shared__ double dd[N * M];
@@ -1713,18 +1878,30 @@ int LAUNCHER(mnmf_norm_scale)(void *Q, double *Dsp, const double *qbuf, int B, i
   return check_launch("k_mnmf_norm_scale");
 }
 
+// redo: B F ints of scratch (bins the closed-form kernel hands to the general one)
 int LAUNCHER(mnmf_separate)(const void *X, const void *Q, void *Qinv, const double *Dsp,
                             const double *basis, const double *act, void *Y, int B, int M, int F,
                             int T, int K, int ref, int floor_kind, double eps, int *info,
-                            hipStream_t st) {
+                            int *redo, hipStream_t st) {
   Dims d{B, F, T, K};
   const long long nbins = (long long)B * F;
+  hipError_t e = hipMemsetAsync(redo, 0, (size_t)nbins * sizeof(int), st);
+  if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
   MNMF_DISPATCH_M(M, {
     hipLaunchKernelGGL((k_mnmf_qinv<MM>), dim3((unsigned)((nbins + 63) / 64)), dim3(64), 0, st,
                        (const c128 *)Q, (c128 *)Qinv, nbins, info);
+    if (K <= 16 && floor_kind != SSSPY_FLOOR_ADD)
+      hipLaunchKernelGGL((k_mnmf_separate_closed_rows<MM>),
+                         dim3((F + SEP_BINS - 1) / SEP_BINS, (T + 255) / 256, B), dim3(256), 0, st,
+                         (const c128 *)X, (const c128 *)Q, (const c128 *)Qinv, Dsp, basis, act,
+                         (c128 *)Y, d, ref, eps, redo);
+    else
+      hipLaunchKernelGGL((k_mnmf_separate_closed<MM>), dim3(F, B), dim3(256), 0, st,
+                         (const c128 *)X, (const c128 *)Q, (const c128 *)Qinv, Dsp, basis, act,
+                         (c128 *)Y, d, ref, floor_kind, eps, redo);
     hipLaunchKernelGGL((k_mnmf_separate<MM>), dim3(F, B), dim3(256), 0, st, (const c128 *)X,
                        (const c128 *)Q, (const c128 *)Qinv, Dsp, basis, act, (c128 *)Y, d, ref,
-                       floor_kind, eps);
+                       floor_kind, eps, (const int *)redo);
   });
   return check_launch("k_mnmf_separate");
 }
