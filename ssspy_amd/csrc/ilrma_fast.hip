@@ -69,7 +69,9 @@ struct FastModel {
 
 // x^e for x >= 0 through exp2 / log2 (about 1e-14 relative over the dynamic range met here, and
 // less than half the instructions of the correctly rounded pow)
+// (e is uniform: beta = 1, the Laplace-like GGD, needs nothing but square roots)
 __device__ __forceinline__ double pow_nonneg(double x, double e) {
+  if (e == 0.5) return sqrt(x);
   return x > 0.0 ? exp2(e * log2(x)) : 0.0;
 }
 
