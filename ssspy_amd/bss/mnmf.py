@@ -71,7 +71,13 @@ class MNMFBase(DeviceStateMixin, IterativeMethodBase):
     ) -> np.ndarray:
         """Separate a frequency-domain multichannel mixture (ref: ssspy/bss/mnmf.py:90-118)."""
         self._bind_input(input)
-        self._reset(**kwargs)
+        # the reference fills `output` at reset (ssspy/bss/mnmf.py:540); only a callback can read it
+        # before the Wiener filter of the final state below replaces it
+        self._skip_reset_output = not self.callbacks
+        try:
+            self._reset(**kwargs)
+        finally:
+            self._skip_reset_output = False
         resident = getattr(self, "_iterate_with_resident_loss", None)
         if resident is None or not resident(int(n_iter), initial_call):
             IterativeMethodBase.__call__(self, n_iter=n_iter, initial_call=initial_call)
@@ -156,7 +162,8 @@ class FastMNMFBase(MNMFBase):
         # shapes without it); valid while neither the diagonaliser nor the input moved under it
         self._handover = _ops.fastmnmf_handover(B, N, M, F, T, self.n_basis, self._X.device)
         self._handover_key = None
-        self._separate_dev()
+        if not getattr(self, "_skip_reset_output", False):
+            self._separate_dev()
 
     def _init_diagonalizer(self, rng=None) -> None:
         """ref: ssspy/bss/mnmf.py:542-564."""
@@ -431,7 +438,8 @@ class MNMF(MNMFBase):
         self._floor = device_flooring(self.flooring_fn)
         self._init_nmf(rng=self.rng)
         self._ws, self._ws_bytes = _ops.gmnmf_workspace(B, N, M, F, T, self.n_basis, self._X.device)
-        self._separate_dev()
+        if not getattr(self, "_skip_reset_output", False):
+            self._separate_dev()
 
     def _init_nmf(self, rng=None) -> None:
         """NMF parameters, then H = I / M per source and bin.  ref: ssspy/bss/mnmf.py:327-353."""
