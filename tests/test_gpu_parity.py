@@ -777,6 +777,20 @@ def test_ilrma_iss_tracked_logdet_equals_rebuilt_filters(N, norm):
         assert rel_err(m1.output, m2.output) < 1e-9  # (frame powers are summed with atomics)
 
 
+def test_stream_handle_follows_the_current_stream():
+    """The raw-handle fast path must name the stream torch would launch on, also inside a
+    `torch.cuda.stream(...)` context (kernels enqueue on it; a wrong handle would race)."""
+    import torch
+    from ssspy_amd import _device as dv
+
+    assert dv.stream_handle() == torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert dv.stream_handle() == side.cuda_stream
+        assert dv.stream_handle() == torch.cuda.current_stream().cuda_stream
+    assert dv.stream_handle() == torch.cuda.current_stream().cuda_stream
+
+
 def test_iss_logdet_tracker_only_with_record_loss():
     """The tracked sweep kernel is a separate, slightly slower instantiation (the N = 8 slab kernel
     sits at the register cap): it must run only when the loss is recorded."""
