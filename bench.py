@@ -412,58 +412,66 @@ def main():
     # ---- the same batch with record_loss=True semantics (SURVEY 8d asks for both): the separator's
     # own loop, update_once() then the loss bookkeeping of IterativeMethodBase
     if extra:
-        nl = max(3, args.steps)
-        sep.record_loss, sep.loss = True, []
-        assert sep._iterate_with_deferred_loss(2, True)  # warm-up of the loss variants
-        sep.loss = []
-        torch.cuda.synchronize()
-        tl = time.perf_counter()
-        ok = sep._iterate_with_deferred_loss(nl, True)  # the loop __call__ runs with record_loss=True
-        torch.cuda.synchronize()
-        dtl = (time.perf_counter() - tl) / nl
-        assert ok and len(sep.loss) == nl + 1
-        sep.record_loss, sep.loss = False, None
-        out["with_record_loss"] = {
-            "workload": "same batch, the separator's record_loss=True loop ({} iterations + the "
-                        "initial and final loss): loss of iteration t as a by-product of the basis "
-                        "pass of iteration t+1, one dedicated loss pass at the end".format(nl),
-            "ms_per_step": round(1e3 * dtl, 4), "iterations_per_s": round(B / dtl, 2),
-            "frac": round(3 * pass_bytes / dtl / 1e9 / HBM_PEAK_GBS, 4),
-        }
+        try:
+            nl = max(3, args.steps)
+            sep.record_loss, sep.loss = True, []
+            assert sep._iterate_with_deferred_loss(2, True)  # warm-up of the loss variants
+            sep.loss = []
+            torch.cuda.synchronize()
+            tl = time.perf_counter()
+            ok = sep._iterate_with_deferred_loss(nl, True)  # the loop __call__ runs with record_loss=True
+            torch.cuda.synchronize()
+            dtl = (time.perf_counter() - tl) / nl
+            assert ok and len(sep.loss) == nl + 1
+            sep.record_loss, sep.loss = False, None
+            out["with_record_loss"] = {
+                "workload": "same batch, the separator's record_loss=True loop ({} iterations + the "
+                            "initial and final loss): loss of iteration t as a by-product of the basis "
+                            "pass of iteration t+1, one dedicated loss pass at the end".format(nl),
+                "ms_per_step": round(1e3 * dtl, 4), "iterations_per_s": round(B / dtl, 2),
+                "frac": round(3 * pass_bytes / dtl / 1e9 / HBM_PEAK_GBS, 4),
+            }
+        except Exception as exc:  # an extra leg must never cost the headline line
+            out['with_record_loss'] = {"error": "{}: {}".format(type(exc).__name__, str(exc)[:300])}
+            torch.cuda.empty_cache()
 
     # ---- the metric's AuxIVA leg: AuxLaplaceIVA (IP1) on the same resident batch, two passes over X
     # per iteration (frame powers, weighted covariance)
     if extra:
-        from ssspy_amd.bss.iva import AuxLaplaceIVA, _device_contrast
+        try:
+            from ssspy_amd.bss.iva import AuxLaplaceIVA, _device_contrast
 
-        iva = AuxLaplaceIVA(spatial_algorithm="IP", record_loss=False)
-        iva._contrast = _device_contrast(iva.contrast_fn, iva.d_contrast_fn)
-        iva._bind_input(X)
-        iva._reset()
-        iva._C()
-        for _ in range(3):
-            iva.update_once()
-        ni = max(5, args.steps)
-        dti = time_loop(iva.update_once, ni)
-        iva._check_device_errors()
-        out["auxiva_ip"] = rate_entry(
-            "AuxLaplaceIVA-IP1, same batch ({} x N={} F={} T={}), {} iterations".format(B, N, F, T, ni),
-            dti, B, 2 * 16.0 * N * F * T)
-        del iva
-        # ... and with ISS (the fused sweep kernel: one read and one write of the separated batch)
-        iva = AuxLaplaceIVA(spatial_algorithm="ISS", record_loss=False)
-        iva._contrast = _device_contrast(iva.contrast_fn, iva.d_contrast_fn)
-        iva._bind_input(X)
-        iva._reset()
-        for _ in range(3):
-            iva.update_once()
-        dts = time_loop(iva.update_once, ni)
-        iva._check_device_errors()
-        out["auxiva_iss"] = rate_entry(
-            "AuxLaplaceIVA-ISS, same batch ({} x N={} F={} T={}), {} iterations".format(B, N, F, T, ni),
-            dts, B, 2 * 16.0 * N * F * T)
-        del iva
-        torch.cuda.empty_cache()
+            iva = AuxLaplaceIVA(spatial_algorithm="IP", record_loss=False)
+            iva._contrast = _device_contrast(iva.contrast_fn, iva.d_contrast_fn)
+            iva._bind_input(X)
+            iva._reset()
+            iva._C()
+            for _ in range(3):
+                iva.update_once()
+            ni = max(5, args.steps)
+            dti = time_loop(iva.update_once, ni)
+            iva._check_device_errors()
+            out["auxiva_ip"] = rate_entry(
+                "AuxLaplaceIVA-IP1, same batch ({} x N={} F={} T={}), {} iterations".format(B, N, F, T, ni),
+                dti, B, 2 * 16.0 * N * F * T)
+            del iva
+            # ... and with ISS (the fused sweep kernel: one read and one write of the separated batch)
+            iva = AuxLaplaceIVA(spatial_algorithm="ISS", record_loss=False)
+            iva._contrast = _device_contrast(iva.contrast_fn, iva.d_contrast_fn)
+            iva._bind_input(X)
+            iva._reset()
+            for _ in range(3):
+                iva.update_once()
+            dts = time_loop(iva.update_once, ni)
+            iva._check_device_errors()
+            out["auxiva_iss"] = rate_entry(
+                "AuxLaplaceIVA-ISS, same batch ({} x N={} F={} T={}), {} iterations".format(B, N, F, T, ni),
+                dts, B, 2 * 16.0 * N * F * T)
+            del iva
+            torch.cuda.empty_cache()
+        except Exception as exc:  # an extra leg must never cost the headline line
+            out['auxiva'] = {"error": "{}: {}".format(type(exc).__name__, str(exc)[:300])}
+            torch.cuda.empty_cache()
 
     # ---- CPU baseline of the headline: the NumPy oracle (reference expression structure)
     if not args.no_cpu_baseline and n_gpus == 1:
@@ -484,7 +492,10 @@ def main():
     if extra:
         del sep, X
         torch.cuda.empty_cache()
-        out["configs"] = other_configs(args, dev, x0_host, pins, out.get("cpu_baseline"))
+        try:
+            out["configs"] = other_configs(args, dev, x0_host, pins, out.get("cpu_baseline"))
+        except Exception as exc:  # an extra leg must never cost the headline line
+            out["configs"] = {"error": "{}: {}".format(type(exc).__name__, str(exc)[:300])}
 
     print(json.dumps(out))
     if distributed:
