@@ -255,7 +255,8 @@ int ssspy_ilrma_normalize_output(void *Y, double *basis, const double *frame_pow
                                  void *stream);
 
 /* The same, also moving the tracked sum_i log|det W_i| of the ISS state (ssspy_iss1_fused_tracked):
- * dividing source n by psi_n divides row n of every implied filter, logdet[b] -= F sum_n log psi_n. */
+ * dividing source n by psi_n divides row n of every implied filter, logdet[b] -= F sum_n log psi_n.
+ * replaces: ssspy/bss/ilrma.py:365-444 (normalize_by_power) + the filter rebuild of :1946-1965. */
 int ssspy_ilrma_normalize_output_tracked(void *Y, double *basis, const double *frame_power, int B,
                                          int N, int F, int T, int K, double domain, int floor_kind,
                                          double floor_eps, void *workspace, size_t workspace_bytes,
