@@ -19,6 +19,7 @@ After the timed region, on rank 0 at N=1 (none of it is part of ``value``):
     every one with its own CPU baseline (the matching oracle class on this box's host cores).
 
     python bench.py                       # 1 GPU, 128 mixtures, finishes in ~2-3 min
+    python bench.py --gpus 8              # starts 8 ranks itself (torch.distributed.run, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
 """
@@ -275,9 +276,31 @@ def other_configs(args, dev, x0_host, pins, cpu_configs1):
     return out
 
 
+def launch_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: start N ranks of this script (one process per
+    GPU, RCCL) through torch.distributed.run on the loopback address and hand back its exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus {} but WORLD_SIZE={} (launch one rank per GPU, or run "
+                         "`python bench.py --gpus N` and let it start them)".format(args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1

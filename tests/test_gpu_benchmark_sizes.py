@@ -204,3 +204,39 @@ def test_bench_two_rank_control_flow_on_one_device():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
     assert out["config"]["global_batch"] == 8 and out["scaling"] == "weak"
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """The driver's command form is plain ``python bench.py --gpus N ...`` (no launcher): bench.py
+    must start the N ranks itself and report ``n_gpus == N``.  Dry run on this one-GPU box: both
+    ranks on device 0, gloo for the barrier and the timing max (RCCL refuses two ranks on one
+    device); on a node the same command runs one RCCL rank per GPU."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SSSPY_BENCH_ONE_DEVICE="1", SSSPY_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--batch", "4"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["value"] > 0
+
+
+def test_bench_rejects_world_size_mismatch():
+    """``--gpus`` is read: a launcher world size that disagrees with it is an error, not a silent
+    one-rank run."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+                          "--warmup", "0", "--batch", "2", "--no-extra", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert res.returncode != 0 and "WORLD_SIZE" in (res.stderr + res.stdout)
