@@ -77,6 +77,14 @@ class GaussILRMAOracle:
         self.demix_filter = W
         self.output = sp.separate(self.input, W)
         lead = () if self.partitioning else (N,)
+        if self.partitioning:
+            # the reference draws latent first, then basis, then activation (ilrma.py:230-251)
+            if latent is None:
+                latent = self.rng.random((N, self.n_basis))
+                latent = sp.floor(latent / latent.sum(axis=0), self.flooring)
+            else:
+                latent = latent.copy()
+            self.latent = latent
         if basis is None:
             basis = sp.floor(self.rng.random(lead + (F, self.n_basis)), self.flooring)
         else:
@@ -86,13 +94,6 @@ class GaussILRMAOracle:
         else:
             activation = activation.copy()
         self.basis, self.activation = basis, activation
-        if self.partitioning:
-            if latent is None:
-                latent = self.rng.random((N, self.n_basis))
-                latent = sp.floor(latent / latent.sum(axis=0), self.flooring)
-            else:
-                latent = latent.copy()
-            self.latent = latent
         if not self.uses_filter:
             self.demix_filter = None
 

@@ -17,6 +17,9 @@ DEFAULT_FLOOR = ("max", EPS)
 
 def floor(x, flooring=DEFAULT_FLOOR):
     """ref: ssspy/special/flooring.py:6-18 (identity / max_flooring / add_flooring)."""
+    if callable(flooring):
+        # an arbitrary callable, as the reference accepts (ssspy/bss/ilrma.py:70-89)
+        return flooring(x)
     kind, eps = flooring
     if kind == "max":
         return np.maximum(x, eps)

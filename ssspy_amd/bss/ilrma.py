@@ -109,6 +109,13 @@ class ILRMABase(DeviceStateMixin, IterativeMethodBase):
             rng = np.random.default_rng()
         N, F, T, K = self.n_sources, self.n_bins, self.n_frames, self.n_basis
         src = () if self.partitioning else (N,)
+        if self.partitioning:
+            # draw order of the reference: latent, then basis, then activation (ilrma.py:230-251)
+            if not self._state_has("latent"):
+                Z = rng.random(self._lead() + (N, K))
+                self.latent = flooring_fn(Z / Z.sum(axis=-2, keepdims=True))
+            else:
+                self.latent = np.array(self.latent, dtype=np.float64, copy=True)
         if not self._state_has("basis"):
             self.basis = flooring_fn(rng.random(self._lead() + src + (F, K)))
         else:
@@ -118,11 +125,6 @@ class ILRMABase(DeviceStateMixin, IterativeMethodBase):
         else:
             self.activation = np.array(self.activation, dtype=np.float64, copy=True)
         if self.partitioning:
-            if not self._state_has("latent"):
-                Z = rng.random(self._lead() + (N, K))
-                self.latent = flooring_fn(Z / Z.sum(axis=-2, keepdims=True))
-            else:
-                self.latent = np.array(self.latent, dtype=np.float64, copy=True)
             B = self._X.shape[0]
             self._Teff = dv.empty((B, N, F, K), dv.f64, self._X.device)
             self._Vrep = dv.empty((B, N, K, T), dv.f64, self._X.device)

@@ -84,9 +84,24 @@ def skipped(name):
     return bool(ONLY) and not any(name.startswith(p) for p in ONLY)
 
 
+OUT_DIR = os.environ.get("SSSPY_GOLDEN_OUT", HERE)
+
+
 def save(name, **arrays):
-    path = os.path.join(HERE, name + ".npz")
-    np.savez_compressed(path, **arrays)
+    """An .npz whose bytes depend on the arrays only (fixed member timestamps, sorted keys), so
+    re-running this script reproduces the committed fixtures byte for byte."""
+    import io
+    import zipfile
+
+    path = os.path.join(OUT_DIR, name + ".npz")
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED, compresslevel=6) as zf:
+        for key in sorted(arrays):
+            buf = io.BytesIO()
+            np.lib.format.write_array(buf, np.asanyarray(arrays[key]), allow_pickle=False)
+            info = zipfile.ZipInfo(key + ".npy", date_time=(1980, 1, 1, 0, 0, 0))
+            info.compress_type = zipfile.ZIP_DEFLATED
+            info.external_attr = 0o644 << 16
+            zf.writestr(info, buf.getvalue())
     print("{:40s} {:8.1f} KiB".format(name, os.path.getsize(path) / 1024))
 
 
@@ -231,6 +246,84 @@ def run_gmnmf(name, *, M, F, T, K, seed, n_sources=None, gen=gen_iid, flooring=(
     out.update(meta(kind="gauss_mnmf", n_basis=K, n_sources=N, n_iter=n_iter,
                     partitioning=partitioning,
                     floor_kind=flooring[0], floor_eps=flooring[1], normalization=normalization))
+    save(name, **out)
+
+
+
+# --------------------------------------------------------------------------- rng-drawn initial state
+class InitialAndFinal:
+    """Callback copying the state at the initial call (the rng-drawn parameters) and after the first
+    and the last iteration."""
+
+    def __init__(self, names, n_iter):
+        self.names, self.n_iter = names, n_iter
+        self.count = -1
+        self.store = {}
+
+    def __call__(self, method):
+        self.count += 1
+        if self.count in (0, 1, self.n_iter):
+            for name in self.names:
+                value = getattr(method, name, None)
+                if value is not None:
+                    self.store["it{}_{}".format(self.count, name)] = np.array(value, copy=True)
+
+
+def run_rng_init(name, *, cls, seed, N, F, T, K, n_iter=5, gen=gen_iid, **kwargs):
+    """No injected state: every parameter comes from ``rng=default_rng(seed + 3)`` in the order the
+    reference draws it (ilrma.py:230-266: latent, basis, activation with partitioning; mnmf.py:
+    221-254 basis, activation, latent; mnmf.py:535-538, 595: basis, activation, spatial)."""
+    if skipped(name):
+        return
+    X = gen(seed, N, F, T)
+    names = {"ilrma": ["latent", "basis", "activation", "demix_filter"],
+             "fmnmf": ["basis", "activation", "diagonalizer", "spatial"],
+             "gmnmf": ["basis", "activation", "latent", "spatial"]}[cls]
+    snap = InitialAndFinal(names, n_iter)
+    rng = np.random.default_rng(seed + 3)
+    if cls == "ilrma":
+        model = kwargs.pop("model", ("gauss", None))
+        common = dict(n_basis=K, callbacks=snap, rng=rng, **kwargs)
+        if model[0] == "t":
+            m = TILRMA(dof=model[1], **common)
+        else:
+            m = GaussILRMA(**common)
+        kwargs["model"], kwargs["model_param"] = model[0], (0.0 if model[1] is None else model[1])
+    elif cls == "fmnmf":
+        m = FastGaussMNMF(n_basis=K, callbacks=snap, rng=rng, **kwargs)
+    else:
+        m = GaussMNMF(n_basis=K, callbacks=snap, rng=rng, **kwargs)
+    Y = m(X, n_iter=n_iter)
+    out = dict(X=X, loss=np.array(m.loss), final_output=Y)
+    out.update(snap.store)
+    out.update(meta(kind="rng_init_" + cls, seed=seed, n_basis=K, n_iter=n_iter, **kwargs))
+    save(name, **out)
+
+
+def custom_floor(x):
+    """A flooring callable that is none of the reference's three (ssspy/special/flooring.py)."""
+    return np.maximum(x, 1e-8) + 1e-12
+
+
+def run_custom_floor(name, *, kind, seed, N, F, T, K=4, n_iter=6, gen=gen_mixture, **kwargs):
+    """``flooring_fn`` is an arbitrary callable in the reference (ilrma.py:70-89)."""
+    if skipped(name):
+        return
+    X = gen(seed, N, F, T)
+    rng = np.random.default_rng(seed + 3)
+    if kind == "ilrma":
+        snap = InitialAndFinal(["basis", "activation", "demix_filter", "output"], n_iter)
+        m = GaussILRMA(n_basis=K, flooring_fn=custom_floor, callbacks=snap, rng=rng, **kwargs)
+    elif kind == "iva":
+        snap = InitialAndFinal(["demix_filter", "output"], n_iter)
+        m = AuxLaplaceIVA(flooring_fn=custom_floor, callbacks=snap, **kwargs)
+    else:
+        snap = InitialAndFinal(["basis", "activation", "diagonalizer", "spatial"], n_iter)
+        m = FastGaussMNMF(n_basis=K, flooring_fn=custom_floor, callbacks=snap, rng=rng, **kwargs)
+    Y = m(X, n_iter=n_iter)
+    out = dict(X=X, loss=np.array(m.loss), final_output=Y)
+    out.update(snap.store)
+    out.update(meta(kind="custom_floor_" + kind, seed=seed, n_basis=K, n_iter=n_iter, **kwargs))
     save(name, **out)
 
 
@@ -458,6 +551,29 @@ def main():
     run_generic_auxiva("auxgeneric_iss1_n2", N=2, F=24, T=40, algo="ISS", seed=121)
     run_generic_auxiva("auxgeneric_ip2_n3", N=3, F=18, T=40, algo="IP2", seed=122, gen=gen_mixture)
     run_all_channel_restoration()
+    # --- rng-drawn initial state (nothing injected): pins the draw order of _init_nmf & friends ---
+    run_rng_init("rnginit_gilrma_n3", cls="ilrma", seed=130, N=3, F=14, T=30, K=4,
+                 spatial_algorithm="IP")
+    run_rng_init("rnginit_gilrma_part_n3", cls="ilrma", seed=131, N=3, F=14, T=30, K=5,
+                 spatial_algorithm="IP", partitioning=True)
+    run_rng_init("rnginit_gilrma_part_iss_n2", cls="ilrma", seed=132, N=2, F=15, T=28, K=4,
+                 spatial_algorithm="ISS", partitioning=True)
+    run_rng_init("rnginit_tilrma_part_n2", cls="ilrma", seed=133, N=2, F=13, T=32, K=4,
+                 spatial_algorithm="IP", partitioning=True, model=("t", 5.0))
+    run_rng_init("rnginit_fmnmf_m3", cls="fmnmf", seed=134, N=3, F=12, T=28, K=3)
+    run_rng_init("rnginit_gmnmf_m2", cls="gmnmf", seed=135, N=2, F=9, T=20, K=3)
+    run_rng_init("rnginit_gmnmf_part_m2", cls="gmnmf", seed=136, N=2, F=9, T=20, K=4,
+                 partitioning=True)
+    # --- arbitrary flooring callables ---
+    run_custom_floor("customfloor_gilrma_ip1_n3", kind="ilrma", seed=150, N=3, F=14, T=30,
+                     spatial_algorithm="IP")
+    run_custom_floor("customfloor_gilrma_iss1_n2", kind="ilrma", seed=151, N=2, F=15, T=28,
+                     spatial_algorithm="ISS")
+    run_custom_floor("customfloor_auxlap_ip1_n3", kind="iva", seed=152, N=3, F=14, T=30,
+                     spatial_algorithm="IP")
+    run_custom_floor("customfloor_auxlap_iss1_n2", kind="iva", seed=153, N=2, F=15, T=28,
+                     spatial_algorithm="ISS")
+    run_custom_floor("customfloor_fmnmf_m3", kind="fmnmf", seed=154, N=3, F=12, T=28, K=3)
     # --- operators ---
     run_operators()
 

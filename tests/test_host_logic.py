@@ -128,3 +128,17 @@ def test_callbacks_and_loss_protocol():
     d2 = Dummy(record_loss=False)
     d2(n_iter=1, initial_call=False)
     assert d2.loss is None
+
+
+def test_bench_gpus_flag_is_read():
+    """bench.py --gpus N under a launcher whose WORLD_SIZE disagrees must fail before touching a
+    device (the check sits in front of the HIP-device assertion, so it runs here too)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert res.returncode != 0 and "WORLD_SIZE=1" in res.stderr

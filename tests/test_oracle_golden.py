@@ -250,3 +250,121 @@ def test_ipa_operator(N):
 def test_inv2():
     g = load_golden("operators")
     assert rel_err(sp.inv2(g["inv2_in"]), g["inv2_out"]) < 1e-13
+
+
+# --------------------------------------------------------------------------- rng-drawn initial state
+def _golden_custom_floor(x):
+    """Same function as tests/golden/make_golden.py:custom_floor (a fixture cannot carry code)."""
+    return np.maximum(x, 1e-8) + 1e-12
+
+
+RNG_INIT_CASES = ["rnginit_gilrma_n3", "rnginit_gilrma_part_n3", "rnginit_gilrma_part_iss_n2",
+                  "rnginit_tilrma_part_n2", "rnginit_fmnmf_m3", "rnginit_gmnmf_m2",
+                  "rnginit_gmnmf_part_m2"]
+CUSTOM_FLOOR_CASES = ["customfloor_gilrma_ip1_n3", "customfloor_gilrma_iss1_n2",
+                      "customfloor_auxlap_ip1_n3", "customfloor_auxlap_iss1_n2",
+                      "customfloor_fmnmf_m3"]
+
+
+def _oracle_for(g, flooring=sp.DEFAULT_FLOOR):
+    """Oracle instance for a ``rnginit_*`` / ``customfloor_*`` fixture: constructor arguments from
+    the meta keys, the generator seeded like the reference run, NO injected state."""
+    kind = str(g["meta_kind"]).split("_")[-1]
+    rng = np.random.default_rng(int(g["meta_seed"]) + 3)
+    K = int(g["meta_n_basis"])
+    part = bool(g["meta_partitioning"]) if "meta_partitioning" in g else False
+    if kind == "ilrma":
+        model = (str(g["meta_model"]), float(g["meta_model_param"])) if "meta_model" in g else ("gauss", None)
+        if model[0] == "gauss":
+            model = ("gauss", None)
+        return GaussILRMAOracle(n_basis=K, spatial_algorithm=str(g["meta_spatial_algorithm"]),
+                                partitioning=part, model=model, rng=rng, flooring=flooring), \
+            ["latent", "basis", "activation", "demix_filter", "output"]
+    if kind == "iva":
+        return AuxIVAOracle(spatial_algorithm=str(g["meta_spatial_algorithm"]), contrast="laplace",
+                            flooring=flooring), ["demix_filter", "output"]
+    if kind == "fmnmf":
+        return FastGaussMNMFOracle(n_basis=K, rng=rng, flooring=flooring), \
+            ["basis", "activation", "diagonalizer", "spatial"]
+    return GaussMNMFOracle(n_basis=K, partitioning=part, rng=rng, flooring=flooring), \
+        ["basis", "activation", "latent", "spatial"]
+
+
+def _replay_uninjected(g, m, names, tol):
+    m.reset(g["X"])
+    n_iter = int(g["meta_n_iter"])
+    losses = [m.compute_loss()]
+    for k in range(n_iter + 1):
+        if k > 0:
+            m.update_once()
+            losses.append(m.compute_loss())
+        for name in names:
+            key = "it{}_{}".format(k, name)
+            if key in g and getattr(m, name, None) is not None:
+                if k == 0 and name != "output":
+                    # the drawn state itself: the same generator calls in the same order
+                    np.testing.assert_array_equal(getattr(m, name), g[key], err_msg=key)
+                else:
+                    assert rel_err(getattr(m, name), g[key]) < tol, key
+    np.testing.assert_allclose(losses, g["loss"], rtol=max(1e-10, tol))
+
+
+@pytest.mark.parametrize("case", RNG_INIT_CASES)
+def test_rng_drawn_initial_state(case):
+    """Nothing injected: the parameters are drawn from ``rng`` in the reference's order
+    (ssspy/bss/ilrma.py:230-266 latent -> basis -> activation under partitioning;
+    mnmf.py:221-254 basis -> activation -> latent; mnmf.py:535-538 basis -> activation -> spatial)."""
+    g = load_golden(case)
+    m, names = _oracle_for(g)
+    _replay_uninjected(g, m, names, 1e-8 if "gmnmf" in case else TOL)
+
+
+@pytest.mark.parametrize("case", CUSTOM_FLOOR_CASES)
+def test_custom_flooring_callable(case):
+    """``flooring_fn`` may be any callable in the reference (ssspy/bss/ilrma.py:70-89)."""
+    g = load_golden(case)
+    m, names = _oracle_for(g, flooring=_golden_custom_floor)
+    _replay_uninjected(g, m, names, TOL)
+
+
+def test_fixture_key_sets():
+    """Every fixture carries the keys the current generator writes for its kind (no stale files)."""
+    import glob
+    import os
+
+    from conftest import GOLDEN_DIR
+
+    need = {"gauss_ilrma": {"meta_source_algorithm", "meta_partitioning", "meta_model", "loss", "X"},
+            "aux_iva": {"meta_algo", "meta_contrast", "loss"},
+            "fast_gauss_mnmf": {"meta_n_sources", "loss", "spatial0"},
+            "gauss_mnmf": {"meta_partitioning", "loss"}}
+    seen = 0
+    for path in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
+        g = load_golden(os.path.basename(path)[:-4])
+        kind = str(g["meta_kind"]) if "meta_kind" in g else None
+        if kind in need:
+            seen += 1
+            assert need[kind] <= set(g), (path, need[kind] - set(g))
+    assert seen >= 60
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/ssspy"),
+                    reason="needs the reference checkout (build container only)")
+def test_generator_reproduces_committed_fixtures(tmp_path):
+    """tests/golden/make_golden.py writes deterministic archives: regenerating a sample of fixtures
+    from the reference gives the committed bytes."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+
+    from conftest import GOLDEN_DIR
+
+    sample = ["gilrma_ip1_n4", "rnginit_gilrma_part_n3", "fmnmf_ip1_m4", "auxlap_iss1_n8", "operators"]
+    env = dict(os.environ, SSSPY_GOLDEN_OUT=str(tmp_path))
+    subprocess.run([sys.executable, os.path.join(GOLDEN_DIR, "make_golden.py")] + sample, env=env,
+                   check=True, capture_output=True, timeout=600)
+    for name in sample:
+        a = hashlib.sha256(open(os.path.join(GOLDEN_DIR, name + ".npz"), "rb").read()).hexdigest()
+        b = hashlib.sha256(open(os.path.join(str(tmp_path), name + ".npz"), "rb").read()).hexdigest()
+        assert a == b, name
