@@ -39,6 +39,7 @@ enum {
   SSSPY_ERR_BADARG = 1,      /* shape / enum outside what the kernels support */
   SSSPY_ERR_HIP = 2,         /* a HIP runtime call failed */
   SSSPY_ERR_UNSUPPORTED = 3, /* valid reference configuration not built here */
+  SSSPY_ERR_INTERNAL = 4,    /* an invariant of the library itself was violated (a bug) */
 };
 
 enum { SSSPY_FLOOR_NONE = 0, SSSPY_FLOOR_MAX = 1, SSSPY_FLOOR_ADD = 2 };
@@ -293,8 +294,10 @@ int ssspy_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis,
  * is a by-product of the basis pass (which forms |y|^2 and R under the same parameters), so a loop
  * with record_loss=True costs three passes over X per iteration, not four: the loss after iteration t
  * comes out of iteration t + 1, and only the last one needs ssspy_ilrma_loss_data.  Returns
- * SSSPY_ERR_UNSUPPORTED (before touching any state) for shapes outside the tuned kernels
- * (n_basis > 16, n_sources > 4, fractional domains), which have no such by-product.
+ * SSSPY_ERR_UNSUPPORTED (before touching any state) where the tuned kernels have no such
+ * by-product: n_basis > 16, n_sources > 4, domains other than 1 and 2 (and domain 1 with a model
+ * other than Gauss / MM), the Student-t model (its data term is not linear in the pass's
+ * accumulators), and mixtures with n_bins * n_frames * 16 bytes >= 4 GiB.
  * replaces: ssspy/bss/base.py:68-77 around ssspy/bss/ilrma.py:900-922 and :1946-1965. */
 /* 1 when ssspy_ilrma_ip1_update_deferred_loss has the by-product for this shape and model, else 0. */
 int ssspy_ilrma_deferred_loss_supported(int N, int F, int T, int K, double domain,

@@ -12,7 +12,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libssspy_amd.so")
 
-OK, ERR_BADARG, ERR_HIP, ERR_UNSUPPORTED = 0, 1, 2, 3
+OK, ERR_BADARG, ERR_HIP, ERR_UNSUPPORTED, ERR_INTERNAL = 0, 1, 2, 3, 4
 FLOOR_NONE, FLOOR_MAX, FLOOR_ADD = 0, 1, 2
 WEIGHT_UNIT, WEIGHT_FRAME, WEIGHT_BIN_FRAME = 0, 1, 2
 SOURCE_GAUSS, SOURCE_T, SOURCE_GGD = 0, 1, 2

@@ -16,6 +16,39 @@ from .. import _device as dv
 from .. import _lib
 
 
+class HostSnapshot(np.ndarray):
+    """Read-only host copy of a device-resident state variable.
+
+    The device buffer stays the truth, so writing into the snapshot (``m.basis[0] = 1``) raises
+    instead of being lost.  Augmented assignment on the attribute still works as in the
+    reference: ``m.basis *= 2`` evaluates getter -> ``__imul__`` -> setter, and the in-place
+    operators here compute out of place and hand a fresh plain array to the setter, which
+    uploads it.  Every other result (ufuncs, slices of results) is a plain ``numpy.ndarray``."""
+
+    def __array_wrap__(self, array, context=None, return_scalar=False):
+        if return_scalar:
+            return array[()]
+        return np.asarray(array).view(np.ndarray)
+
+
+def _out_of_place(ufunc):
+    def op(self, other):
+        return ufunc(np.asarray(self).view(np.ndarray), other)
+    return op
+
+
+for _name, _ufunc in (("__iadd__", np.add), ("__isub__", np.subtract), ("__imul__", np.multiply),
+                      ("__itruediv__", np.true_divide), ("__ipow__", np.power),
+                      ("__ifloordiv__", np.floor_divide), ("__imatmul__", np.matmul)):
+    setattr(HostSnapshot, _name, _out_of_place(_ufunc))
+
+
+def _snapshot(host):
+    view = host.view(HostSnapshot)
+    view.flags.writeable = False
+    return view
+
+
 class Synced:
     """Descriptor: NumPy view of a device-resident state variable."""
 
@@ -104,9 +137,7 @@ class DeviceStateMixin:
             # a snapshot of the device buffer, which stays the truth: writing into the snapshot
             # would be lost silently, so it is read-only -- state is changed by assigning the
             # attribute (``m.basis = new``), which uploads
-            view = host.view()
-            view.flags.writeable = False
-            ent["host"], ent["host_rw"] = view, host
+            ent["host"], ent["host_rw"] = _snapshot(host), host
         return ent["host"]
 
     def _final_output(self):
@@ -171,9 +202,7 @@ class DeviceStateMixin:
             # from here on the device copy is what the kernels see: hand out the host value
             # read-only so that an in-place edit cannot be lost silently (see _state_get)
             if isinstance(ent["host"], np.ndarray):
-                view = ent["host"].view()
-                view.flags.writeable = False
-                ent["host"] = view
+                ent["host"] = _snapshot(ent["host"])
         return ent["dev"]
 
     # -- singular-matrix reporting ------------------------------------------------------

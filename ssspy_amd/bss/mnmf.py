@@ -73,7 +73,14 @@ class MNMFBase(DeviceStateMixin, IterativeMethodBase):
         self._bind_input(input)
         # the reference fills `output` at reset (ssspy/bss/mnmf.py:540); only a callback can read it
         # before the Wiener filter of the final state below replaces it
-        self._skip_reset_output = not self.callbacks
+        # (or a subclass's own update_once / compute_loss: then the reset-time filter is kept)
+        cls = type(self)
+        bases = [base for base in (FastGaussMNMF, GaussMNMF) if isinstance(self, base)]
+        stock = bool(bases) and all(getattr(cls, name) is getattr(base, name)
+                                    for base in bases for name in ("update_once", "compute_loss"))
+        self._skip_reset_output = not self.callbacks and stock
+        if self._skip_reset_output:
+            self._state().pop("output", None)  # no stale estimate of an earlier call to be read
         try:
             self._reset(**kwargs)
         finally:

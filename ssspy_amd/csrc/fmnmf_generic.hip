@@ -432,6 +432,8 @@ template <int MODE>
 static int launch_points(const void *X, const void *Q, const double *D, const double *basis,
                          const double *act, double *out0, double *out1, int B, int N, int M, int F,
                          int T, int K, hipStream_t st) {
+  // point_terms keeps lam[NMAX]: more sources would silently drop out of R~
+  if (N < 1 || N > NMAX) return fail(SSSPY_ERR_UNSUPPORTED, "FastMNMF: n_sources must be in [1, 8]");
   dim3 grid((T + 127) / 128, F, B), block(128);
   const size_t smem = bin_smem(N, M, K);
   FMG_DISPATCH_M(M, hipLaunchKernelGGL((k_points<MM, MODE>), grid, block, smem, st, (const c128 *)X,
@@ -453,8 +455,8 @@ int fmnmf_generic_update(const void *X, const void *C, void *Q, double *D, doubl
                          int floor_kind, double floor_eps, double *gws, void *U, double *qbuf,
                          int *info, hipStream_t st) {
   using namespace fmg;
-  SSSPY_REQUIRE(N >= 1 && N <= NMAX, "FastMNMF: n_sources must be in [1, 8]");
-  SSSPY_REQUIRE(M >= 2 && M <= 8, "FastMNMF: n_channels must be in [2, 8]");
+  if (N < 1 || N > NMAX) return fail(SSSPY_ERR_UNSUPPORTED, "FastMNMF: n_sources must be in [1, 8]");
+  if (M < 2 || M > 8) return fail(SSSPY_ERR_UNSUPPORTED, "FastMNMF: n_channels must be in [2, 8]");
   const size_t pts = (size_t)B * F * T;
   double *A = gws, *Bt = gws + pts * N, *Wt = gws + pts * 2 * N;
   int rc = SSSPY_OK;
@@ -523,6 +525,7 @@ int fmnmf_generic_separate(const void *X, const void *Q, void *Qinv, const doubl
                            int F, int T, int K, int ref, int floor_kind, double eps, int *info,
                            hipStream_t st) {
   using namespace fmg;
+  if (N < 1 || N > NMAX) return fail(SSSPY_ERR_UNSUPPORTED, "FastMNMF: n_sources must be in [1, 8]");
   const long long nbins = (long long)B * F;
   FMG_DISPATCH_M(M, {
     hipLaunchKernelGGL((k_qinv<MM>), dim3((unsigned)((nbins + 63) / 64)), dim3(64), 0, st,

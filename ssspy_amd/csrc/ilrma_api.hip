@@ -904,7 +904,10 @@ static int ip1_update_impl(const void *X, const void *C, void *W, double *basis,
                          model_param, floor_kind, floor_eps, workspace, workspace_bytes, loss_data,
                          &loss_done, stream, xs_is_power);
   if (rc) return rc;
-  if (loss_data && !loss_done) return fail(SSSPY_ERR_UNSUPPORTED, "ilrma_ip1_update: no loss by-product");
+  // (unreachable: ssspy_ilrma_deferred_loss_supported above admits exactly the shapes whose basis
+  // pass leaves the data term; kept as an internal error because the basis is already rewritten)
+  if (loss_data && !loss_done)
+    return fail(SSSPY_ERR_INTERNAL, "ilrma_ip1_update: basis pass left no loss by-product");
   rc = update_activation_impl(Xs, Ws, basis, activation, B, N, F, T, K, domain, source_model,
                               model_param, floor_kind, floor_eps, workspace, workspace_bytes, stream,
                               xs_is_power);

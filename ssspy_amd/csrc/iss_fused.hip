@@ -222,9 +222,11 @@ __global__ __launch_bounds__(256, 2) void k_iss1_fused(c128 *Y, const double *__
       const __amdgpu_buffer_rsrc_t wr = make_rsrc(weight + (PER_BIN ? row : 0), (unsigned)T * 8u);
 #pragma unroll
       for (int f = 0; f < FPT; ++f) {
-        // frames beyond T re-read frame T-1 (finite data) with weight 0: they add nothing to the
-        // sums and are never stored, and the loads stay unconditional
-        y[n][f] = buffer_load_c128(yr, jj[f] * 16u);
+        // frames beyond T re-read frame T-1 with weight 0 and are zeroed (0 * Inf of a non-finite
+        // sample must not reach the sums): they add nothing, are never stored, and the loads stay
+        // unconditional
+        const c128 yv = buffer_load_c128(yr, jj[f] * 16u);
+        y[n][f] = fv[f] ? yv : c128{0.0, 0.0};
         if (PER_BIN) {
           const double wv = buffer_load_f64(wr, jj[f] * 8u);
           phi[n][f] = fv[f] ? wv : 0.0;

@@ -95,10 +95,12 @@ __global__ __launch_bounds__(256, SSSPY_WIDE_COV_WAVES) void k_wide_cov(const c1
     // lane (a, h, k) holds frame t1 + h of channel a; the tile rows are [Re ; Im] of ONE frame
     const double sent = h ? sl.z.x : sl.z.y;
     const double got = partner8(sent);
-    const double v1 = h ? got : sl.z.x;  // row a + 8 h of frame t1 = 8 s + 2 k
-    const double v2 = h ? sl.z.y : got;  // ... of frame t1 + 1
     const int t1 = 8 * s + 2 * k;
     const bool ok1 = !TAIL || t1 < T, ok2 = !TAIL || t1 + 1 < T;
+    // frames past T were loaded from whatever follows the row: zero the samples themselves, not
+    // only their weights (0 * Inf would put a NaN of a neighbouring row into this bin)
+    const double v1 = ok1 ? (h ? got : sl.z.x) : 0.0;  // row a + 8 h of frame t1 = 8 s + 2 k
+    const double v2 = ok2 ? (h ? sl.z.y : got) : 0.0;  // ... of frame t1 + 1
     // (the two updates of one accumulator are NS MFMAs apart)
 #pragma unroll
     for (int n = 0; n < NS; ++n) {

@@ -140,6 +140,50 @@ def test_configs3_full_size_against_oracle():
     assert rel_err(Y, ref.separate(ref.input)) < 1e-7
 
 
+def test_configs2_full_size_100_iterations_against_oracle():
+    """BASELINE configs[2] literally: AuxLaplaceIVA-ISS, N=8, F=2049, T=1024, 100 iterations,
+    against 100 oracle iterations on the host (ssspy/bss/iva.py:1917-1966,
+    _update_spatial_model.py:146-194).  Loss list 1e-9; spectrograms 1e-6 (100 sweeps of 8
+    sources amplify rounding), as for configs[1]."""
+    from oracle.iva import AuxIVAOracle
+    from ssspy_amd.bss.iva import AuxLaplaceIVA
+
+    X = _pinned_mixture("configs2_seed3000_N8_F2049_T1024")
+    m = AuxLaplaceIVA(spatial_algorithm="ISS")
+    Y = m(X, n_iter=100)
+    ref = AuxIVAOracle(spatial_algorithm="ISS", contrast="laplace")
+    Yr = ref.run(X, n_iter=100)
+    assert len(m.loss) == 101
+    np.testing.assert_allclose(m.loss, ref.loss, rtol=LOSS_RTOL)
+    assert rel_err(Y, Yr) < 1e-6
+
+
+def test_configs3_full_size_100_iterations_against_oracle():
+    """BASELINE configs[3] literally: FastGaussMNMF (IP1), N=M=4, F=1025, T=512, n_basis=8, 100
+    iterations against 100 oracle iterations (ssspy/bss/mnmf.py:1278-1303): loss list 1e-9, every
+    parameter and the Wiener-filter output 1e-6."""
+    from oracle.mnmf import FastGaussMNMFOracle
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+
+    M, F, T, K = 4, 1025, 512, 8
+    X = _pinned_mixture("configs3_seed4000_N4_F1025_T512")
+    kw = dict(basis=np.random.default_rng(1).random((M, F, K)),
+              activation=np.random.default_rng(2).random((M, K, T)),
+              spatial=np.random.default_rng(4).random((F, M, M)))
+    m = FastGaussMNMF(n_basis=K)
+    Y = m(X, n_iter=100, **kw)
+    ref = FastGaussMNMFOracle(n_basis=K, record_loss=True)
+    ref.reset(X, **{k: v.copy() for k, v in kw.items()})
+    ref_loss = [ref.compute_loss()]
+    for _ in range(100):
+        ref.update_once()
+        ref_loss.append(ref.compute_loss())
+    np.testing.assert_allclose(m.loss, ref_loss, rtol=LOSS_RTOL)
+    for name in ("diagonalizer", "spatial", "basis", "activation"):
+        assert rel_err(getattr(m, name), getattr(ref, name)) < 1e-6, name
+    assert rel_err(Y, ref.separate(ref.input)) < 1e-6
+
+
 def test_configs3_batch_of_32_equals_single_mixture_runs():
     """configs[3] at the batch bench.py and the profiles quote (32 full-size mixtures, seeds
     4000..4031): three iterations of the batched update_once() -- whole rounds plus a split tail of

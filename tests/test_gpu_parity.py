@@ -1668,3 +1668,76 @@ def test_ilrma_five_and_seven_sources_against_oracle(model, N, B, algo, K):
         tol = 1e-6 if algo == "IP2" else TOL
         assert rel_err(m.basis[b], ref.basis) < tol and rel_err(m.activation[b], ref.activation) < tol
         assert rel_err(Y[b], Yr) < tol
+
+
+# ------------------------------------------------------------------------------- rng-drawn state
+class _Snap0:
+    """Callback that keeps the state at the initial call, after iteration 1 and after the last."""
+
+    def __init__(self, names, n_iter):
+        self.names, self.n_iter, self.count, self.store = names, n_iter, -1, {}
+
+    def __call__(self, m):
+        self.count += 1
+        if self.count in (0, 1, self.n_iter):
+            for name in self.names:
+                v = getattr(m, name, None)
+                if v is not None:
+                    self.store["it{}_{}".format(self.count, name)] = np.array(v, copy=True)
+
+
+def _separator_for(g, snap, flooring_fn="default"):
+    """Product separator for a ``rnginit_*`` / ``customfloor_*`` fixture, seeded like the reference
+    run that made it; nothing is injected."""
+    from ssspy_amd.bss.ilrma import TILRMA, GaussILRMA
+    from ssspy_amd.bss.iva import AuxLaplaceIVA
+    from ssspy_amd.bss.mnmf import FastGaussMNMF, GaussMNMF
+
+    kind = str(g["meta_kind"]).split("_")[-1]
+    rng = np.random.default_rng(int(g["meta_seed"]) + 3)
+    K = int(g["meta_n_basis"])
+    kw = {} if type(flooring_fn) is str else {"flooring_fn": flooring_fn}
+    part = bool(g["meta_partitioning"]) if "meta_partitioning" in g else False
+    if kind == "ilrma":
+        common = dict(n_basis=K, spatial_algorithm=str(g["meta_spatial_algorithm"]),
+                      partitioning=part, callbacks=snap, rng=rng, **kw)
+        if "meta_model" in g and str(g["meta_model"]) == "t":
+            return TILRMA(dof=float(g["meta_model_param"]), **common)
+        return GaussILRMA(**common)
+    if kind == "iva":
+        return AuxLaplaceIVA(spatial_algorithm=str(g["meta_spatial_algorithm"]), callbacks=snap, **kw)
+    if kind == "fmnmf":
+        return FastGaussMNMF(n_basis=K, callbacks=snap, rng=rng, **kw)
+    return GaussMNMF(n_basis=K, partitioning=part, callbacks=snap, rng=rng, **kw)
+
+
+_STATE_NAMES = ["latent", "basis", "activation", "demix_filter", "diagonalizer", "spatial", "output"]
+
+
+def _replay_uninjected(g, flooring_fn="default", tol=TOL):
+    n_iter = int(g["meta_n_iter"])
+    snap = _Snap0(_STATE_NAMES, n_iter)
+    m = _separator_for(g, snap, flooring_fn)
+    Y = m(g["X"], n_iter=n_iter)
+    checked = 0
+    for key, value in snap.store.items():
+        if key not in g:
+            continue
+        if key.startswith("it0_") and not key.endswith("output"):
+            np.testing.assert_array_equal(value, g[key], err_msg=key)  # the draws themselves
+        else:
+            assert rel_err(value, g[key]) < tol, key
+        checked += 1
+    assert checked >= 4
+    np.testing.assert_allclose(m.loss, g["loss"], rtol=max(LOSS_RTOL, tol * 0.1))
+    assert rel_err(Y, g["final_output"]) < tol
+
+
+@pytest.mark.parametrize("case", ["rnginit_gilrma_n3", "rnginit_gilrma_part_n3",
+                                  "rnginit_gilrma_part_iss_n2", "rnginit_tilrma_part_n2",
+                                  "rnginit_fmnmf_m3", "rnginit_gmnmf_m2", "rnginit_gmnmf_part_m2"])
+def test_rng_drawn_initial_state_against_golden(case):
+    """Only ``rng=default_rng(s)`` is given: the separator must draw its parameters in the
+    reference's order (ssspy/bss/ilrma.py:230-266, mnmf.py:221-254, :535-538, :595) and then
+    follow the reference run."""
+    _replay_uninjected(load_golden(case), tol=1e-7 if "gmnmf" in case else TOL)
