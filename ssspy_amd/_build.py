@@ -60,6 +60,7 @@ def _units():
         units.append(("ilrma_kernels.hip", "ilrma_kernels_n{}.o".format(n), ["-DSSSPY_N={}".format(n)]))
     for n in ILRMA_FAST_N:
         units.append(("ilrma_fast.hip", "ilrma_fast_n{}.o".format(n), ["-DSSSPY_N={}".format(n)]))
+        units.append(("ilrma_small.hip", "ilrma_small_n{}.o".format(n), ["-DSSSPY_N={}".format(n)]))
     return units
 
 

@@ -30,11 +30,25 @@ DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
                                  double *, int, int, int, int, int, int, double, int,           \
                                  hipStream_t);                                                  \
   int ilrma_fast_wcov_n##n(const void *, const void *, const double *, const double *, void *, \
-                           int, int, int, int, void *, int, double, int, double, hipStream_t); \
+                           int, int, int, int, void *, int, double, int, double, hipStream_t,  \
+                           int *, int *);                                                      \
   int ilrma_fast_loss_n##n(const void *, const void *, const double *, const double *, double *, \
                            int, int, int, int, int, double, hipStream_t);
 DECL_FAST(2) DECL_FAST(3) DECL_FAST(4)
 #undef DECL_FAST
+
+// latency variants for a handful of mixtures (ilrma_small.hip): n_basis <= 16, n_sources <= 4
+#define DECL_SMALL(n)                                                                           \
+  size_t ilrma_small_scratch_n##n(int, int, int, int);                                            \
+  int ilrma_small_activation_n##n(const void *, const void *, const double *, double *, int, int, \
+                                  int, int, int, double, double *, int, double, int,              \
+                                  hipStream_t);                                                   \
+  int ilrma_small_ip1_n##n(const void *, int, int, const void *, void *, int, int, int, double,   \
+                           double *, int *, hipStream_t);                                         \
+  int ilrma_small_norm_n##n(void *, double *, const double *, int, int, int, double, int, double, \
+                            hipStream_t);
+DECL_SMALL(2) DECL_SMALL(3) DECL_SMALL(4)
+#undef DECL_SMALL
 
 #define ILRMA_FAST_DISPATCH(N_, fn, ...)             \
   switch (N_) {                                      \
@@ -65,6 +79,27 @@ static inline bool fast_path(int N, int F, int T, int K, double domain,
          (long long)F * T * 16 < (1ll << 32);
 }
 static inline int is_me(int source_model) { return (source_model & SSSPY_SOURCE_ME) ? 1 : 0; }
+
+// The latency kernels (ilrma_small.hip) serve batches whose bin tiles do not fill the chip with the
+// throughput kernels' 64-bin work items: B * ceil(F / 16) <= SSSPY_AMD_SMALL_MAX_ITEMS (default 640:
+// up to 9 mixtures of 1025 bins; 0 switches the path off).
+static inline bool small_path(int B, int N, int F, int T, int K, double domain,
+                              int source_model = SSSPY_SOURCE_GAUSS) {
+  static const long long max_items = [] {
+    const char *e = std::getenv("SSSPY_AMD_SMALL_MAX_ITEMS");
+    return e ? std::atoll(e) : 640ll;
+  }();
+  return K <= 16 && fast_path(N, F, T, K, domain, source_model) &&
+         (long long)B * ((F + 15) / 16) <= max_items;
+}
+static inline size_t small_scratch(int B, int N, int F, int T, int K) {
+  switch (N) {
+    case 2: return ilrma_small_scratch_n2(B, F, T, K);
+    case 3: return ilrma_small_scratch_n3(B, F, T, K);
+    case 4: return ilrma_small_scratch_n4(B, F, T, K);
+    default: return 0;
+  }
+}
 
 // More than 4 sources on the tuned NMF passes: the multiplicative updates of source n need only
 // |y_n|^2 and (T_n, V_n), and (B, N, ...) tensors are (B N / G, G, ...) tensors in memory, so a wide
@@ -153,8 +188,12 @@ static inline int act_chunks(int B, int N, int F, int T, int K) {
   return (int)want;
 }
 
+// (the latency kernel's partials when the shape can take it: the workspace is sized without knowing
+// the source model, so Gauss at domain 2 stands for "any model of the tuned path")
 static inline size_t act_part_bytes(int B, int N, int F, int T, int K) {
-  return align256((size_t)B * act_chunks(B, N, F, T, K) * N * 2 * K * T * sizeof(double));
+  const size_t ap = (N >= 2 && N <= 4 && small_path(B, N, F, T, K, 2.0)) ? small_scratch(B, N, F, T, K) : 0;
+  const size_t base = (size_t)B * act_chunks(B, N, F, T, K) * N * 2 * K * T * sizeof(double);
+  return align256(base > ap ? base : ap);
 }
 static inline size_t basis_tmp_bytes(int B, int N, int F, int K) {
   return K > 16 ? align256((size_t)B * N * F * K * sizeof(double)) : 0;
@@ -657,6 +696,12 @@ static int update_activation_impl(const void *X, const void *W, const double *ba
   SourceRun runs[3];
   const int nruns = source_runs(B, N, F, T, K, domain, source_model, runs);
   SSSPY_REQUIRE(!x_is_power || (nruns && !W), "update_activation: power input off the grouped path");
+  if (!nruns && small_path(B, N, F, T, K, domain, source_model)) {
+    // a handful of mixtures: the latency kernel and its own fold (in place)
+    ILRMA_FAST_DISPATCH(N, ilrma_small_activation, X, W, basis, activation, B, F, T, K, floor_kind,
+                        floor_eps, part, fast_model_id(domain, source_model), model_param,
+                        is_me(source_model), st);
+  }
   // (the partial sums of a run keep the (group, chunk, source) layout at the run's offset: every
   // source owns `chunks` slabs of 2 K T doubles wherever its group starts)
   const size_t part_per_source = (size_t)chunks * 2 * K * T;
@@ -740,7 +785,8 @@ static int wcov_into(const void *X, const void *W, const double *basis, const do
   }
   if (fast_path(N, d.F, d.T, d.K, d.p, d.model) && (d.model == SSSPY_SOURCE_GAUSS || W)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, W, basis, activation, U, d.B, d.F, d.T, d.K, upart,
-                        fast_model_id(d.p, d.model), d.mparam, d.floor_kind, d.floor_eps, st);
+                        fast_model_id(d.p, d.model), d.mparam, d.floor_kind, d.floor_eps, st,
+                        nullptr, nullptr);
   }
   ILRMA_DISPATCH(N, ilrma_wcov, X, W, basis, activation, U, d, st);
 }
@@ -912,11 +958,32 @@ static int ip1_update_impl(const void *X, const void *C, void *W, double *basis,
                               model_param, floor_kind, floor_eps, workspace, workspace_bytes, stream,
                               xs_is_power);
   if (rc) return rc;
+  double *qbuf = (double *)(ws + w.qbuf);
+  if (small_path(B, N, F, T, K, domain, source_model)) {
+    // a handful of mixtures: the covariance pass leaves its split items' records, and one kernel
+    // folds them, runs IP1 and forms the output power; U is materialised only if no item was split
+    int split = 0, rbins = 0;
+    auto cov = [&]() -> int {
+      ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, W, basis, activation, U, B, F, T, K, ws + w.upart,
+                          fast_model_id(domain, source_model), model_param, floor_kind, floor_eps,
+                          st, &split, &rbins);
+    };
+    rc = cov();
+    if (rc) return rc;
+    auto ip1 = [&]() -> int {
+      ILRMA_FAST_DISPATCH(N, ilrma_small_ip1, split ? (const void *)(ws + w.upart) : (const void *)U,
+                          split, rbins, normalize ? C : nullptr, W, B, F, floor_kind, floor_eps,
+                          qbuf, info, st);
+    };
+    rc = ip1();
+    if (rc || !normalize) return rc;
+    ILRMA_FAST_DISPATCH(N, ilrma_small_norm, W, basis, qbuf, B, F, K, domain, floor_kind, floor_eps,
+                        st);
+  }
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   rc = wcov_into(X, W, basis, activation, U, N, d, ws + w.upart,
                  N > 4 ? (double *)(ws + w.wbuf) : nullptr, Ws ? nullptr : Xs, xs_is_power, st);
   if (rc) return rc;
-  double *qbuf = (double *)(ws + w.qbuf);
   rc = ip1_with_power(W, U, normalize ? C : nullptr, normalize ? qbuf : nullptr, B, F, N,
                       floor_kind, floor_eps, info, st);
   if (rc || !normalize) return rc;

@@ -26,6 +26,7 @@
 
 #include "common.hpp"
 #include "cov_core.hpp"
+#include "fast_model.hpp"
 #include "fast_tiles.hpp"
 #include "tail_plan.hpp"
 
@@ -45,91 +46,21 @@ namespace SSSPY_CAT(ilrma_fast_n, SSSPY_N) {
 
 constexpr int N = SSSPY_N;
 using fast::rcp_nr;
+using fast::FastModel;
+using fast::FM_GAUSS;
+using fast::FM_GAUSS1;
+using fast::FM_GGD;
+using fast::FM_T;
+using fast::LogSum;
+using fast::mm_num_factor;
+using fast::pow_nonneg;
+using fast::ratio_pow;
 using fast::rt_from_lds;
 using fast::tile_pi;
 using fast::VROW;
 using fast::XPATCH;
 typedef fast::VStage<N> VStage;
 typedef fast::XTile<N> XTile;
-
-// Source models of the tuned kernels (R = (T V)_nij, P = |y_nij|^2; ref: ssspy/bss/ilrma.py):
-//   FM_GAUSS  domain 2: a = P / R^2,           varphi = 1 / R                        (:1116-1125, :1494-1498)
-//   FM_T      domain 2: a = P / (R~ R), varphi = 1 / R~, R~ = w R + (1 - w) P, w = nu / (nu + 2)
-//                                                                              (:2505-2518, :2915-2935)
-//   FM_GGD    domain 2: a = (beta / 2) (P / R)^(beta/2) / R,
-//                       varphi = 1 / ((2 / beta) floor(P^((2 - beta)/2)) R^(beta/2))  (:3810-3821, :3987-4011)
-//   FM_GAUSS1 domain 1: a = P / R^3,           varphi = 1 / R^2
-// `expo`: exponent of the (num / den) ratio: p / (p + 2), 1 for the ME updates, p / (beta + p) for GGD.
-constexpr int FM_GAUSS = 0, FM_T = 1, FM_GGD = 2, FM_GAUSS1 = 3;
-struct FastModel {
-  double w, w1, nu, beta, expo;
-  int floor_kind;
-  double floor_eps;
-};
-
-// x^e for x >= 0 through exp2 / log2 (about 1e-14 relative over the dynamic range met here, and
-// less than half the instructions of the correctly rounded pow)
-// (e is uniform: beta = 1, the Laplace-like GGD, needs nothing but square roots)
-__device__ __forceinline__ double pow_nonneg(double x, double e) {
-  if (e == 0.5) return sqrt(x);
-  return x > 0.0 ? exp2(e * log2(x)) : 0.0;
-}
-
-__device__ __forceinline__ double ratio_pow(double ratio, double expo) {
-  if (expo == 0.5) return sqrt(ratio);
-  if (expo == 1.0) return ratio;
-  return pow(ratio, expo);
-}
-
-// sum of log(x_i) without a log per value: the running product of the mantissas (each in [0.5, 1))
-// and the integer sum of the exponents; the mantissa product is renormalised before it can
-// underflow (every 16 factors is ample: >= 2^-16), one log at the very end.  2 VALU instructions per
-// value instead of the ~40 of an fp64 log; the rounding of the product adds ~1e-16 per factor to a
-// sum of logs of magnitude >= 1.
-struct LogSum {
-  double mant;
-  int expo;
-  __device__ __forceinline__ void clear() {
-    mant = 1.0;
-    expo = 0;
-  }
-  __device__ __forceinline__ void mul(double x) {
-    mant *= __builtin_amdgcn_frexp_mant(x);
-    expo += __builtin_amdgcn_frexp_exp(x);
-  }
-  __device__ __forceinline__ void renorm() {
-    expo += __builtin_amdgcn_frexp_exp(mant);
-    mant = __builtin_amdgcn_frexp_mant(mant);
-  }
-  __device__ __forceinline__ double value() const {
-    return log(mant) + 0.6931471805599453094 * (double)expo;
-  }
-};
-
-// numerator factor a of the multiplicative updates (rinv = 1 / R)
-template <int MODEL>
-__device__ __forceinline__ double mm_num_factor(double pw, double R, double rinv,
-                                                const FastModel &fm);
-template <>
-__device__ __forceinline__ double mm_num_factor<FM_GAUSS>(double pw, double, double rinv,
-                                                          const FastModel &) {
-  return pw * rinv * rinv;
-}
-template <>
-__device__ __forceinline__ double mm_num_factor<FM_T>(double pw, double R, double rinv,
-                                                      const FastModel &fm) {
-  return pw * rcp_nr(fma(fm.w, R, fm.w1 * pw)) * rinv;
-}
-template <>
-__device__ __forceinline__ double mm_num_factor<FM_GGD>(double pw, double, double rinv,
-                                                        const FastModel &fm) {
-  return 0.5 * fm.beta * pow_nonneg(pw * rinv, 0.5 * fm.beta) * rinv;
-}
-template <>
-__device__ __forceinline__ double mm_num_factor<FM_GAUSS1>(double pw, double, double rinv,
-                                                           const FastModel &) {
-  return pw * rinv * rinv * rinv;
-}
 
 // =============================================================================== basis (pass 1)
 // grid: (ceil(F/64), 1, B); 256 threads; wave w owns bins [64*bx + 16w, +16).
@@ -865,22 +796,7 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_activation_fast(
 
 }  // namespace ilrma_fast_n<N>
 using namespace SSSPY_CAT(ilrma_fast_n, SSSPY_N);
-
-// fmodel: FM_*; mparam: dof (t) / beta (GGD); me: exponent 1 instead of p / (p + 2)
-static inline FastModel make_fast_model(int fmodel, double mparam, int me, int floor_kind = 0,
-                                        double floor_eps = 0.0) {
-  FastModel fm;
-  const bool t = fmodel == FM_T;
-  fm.nu = t ? mparam : 1.0;
-  fm.w = t ? mparam / (mparam + 2.0) : 1.0;
-  fm.w1 = 1.0 - fm.w;
-  fm.beta = fmodel == FM_GGD ? mparam : 2.0;
-  const double p = fmodel == FM_GAUSS1 ? 1.0 : 2.0;
-  fm.expo = me ? 1.0 : (fmodel == FM_GGD ? p / (fm.beta + p) : p / (p + 2.0));
-  fm.floor_kind = floor_kind;
-  fm.floor_eps = floor_eps;
-  return fm;
-}
+using fast::make_fast_model;
 
 #define SSSPY_FAST_LAUNCH_M(kernel, HW, ...)                                              \
   switch (fmodel) {                                                                       \
@@ -1022,9 +938,15 @@ int LAUNCHER(ilrma_fast_loss)(const void *X, const void *W, const double *basis,
 
 // `upart` must hold u_part_bytes() of ilrma_api.hip (used only when some items are split);
 // W is read by the t and GGD models only; the floor is GGD's (on |y|^(2 - beta))
+// split_out (optional): the caller folds the split items' records itself (k_ip1_small): no
+// k_wcov_fold here; *split_out = chunks per item, *rbins_out = bins per record -- only when EVERY
+// item is split (a handful of mixtures); otherwise *split_out = 0 and U is complete on return.
 int LAUNCHER(ilrma_fast_wcov)(const void *X, const void *W, const double *basis, const double *act,
                               void *U, int B, int F, int T, int K, void *upart, int fmodel,
-                              double mparam, int floor_kind, double floor_eps, hipStream_t st) {
+                              double mparam, int floor_kind, double floor_eps, hipStream_t st,
+                              int *split_out = nullptr, int *rbins_out = nullptr) {
+  if (split_out) *split_out = 0;
+  if (rbins_out) *rbins_out = WC_BINS;
   const TailPlan plan = make_tail_plan(B, (F + WC_BINS - 1) / WC_BINS, (T + 15) / 16);
   const FastModel fm = make_fast_model(fmodel, mparam, 0, floor_kind, floor_eps);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
@@ -1047,6 +969,10 @@ int LAUNCHER(ilrma_fast_wcov)(const void *X, const void *W, const double *basis,
 #undef SSSPY_WCOV_LAUNCH
   int rc = check_launch("k_wcov_fast");
   if (rc || plan.tail == 0) return rc;
+  if (split_out && plan.full == 0) {
+    *split_out = plan.split;
+    return rc;
+  }
   hipLaunchKernelGGL(k_wcov_fold, dim3((WC_BINS * N * N * N + 255) / 256, plan.tail), block, 0, st,
                      (c128 *)U, (const c128 *)upart, F, plan);
   return check_launch("k_wcov_fold");

@@ -551,9 +551,29 @@ __global__ __launch_bounds__(256) void k_sum_logdet(const c128 *__restrict__ W, 
 using namespace ssspy;
 
 namespace ssspy {
+// ilrma_small.hip: the latency form (16-bin workgroups, four lanes per bin, operands in LDS)
+#define DECL_SMALL_IP1(n)                                                                          \
+  int ilrma_small_ip1_n##n(const void *, int, int, const void *, void *, int, int, int, double,    \
+                           double *, int *, hipStream_t);
+DECL_SMALL_IP1(2) DECL_SMALL_IP1(3) DECL_SMALL_IP1(4)
+#undef DECL_SMALL_IP1
+
 int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, int F, int N,
                    int floor_kind, double floor_eps, int *info, hipStream_t st) {
   const long long nbins = (long long)B * F;
+  // a handful of mixtures: one lane per bin would leave the chip to 17 waves running a chain of
+  // ~5000 dependent fp64 instructions each (17 us at 1025 bins); four lanes per bin take 12
+  static const bool small_off = [] {
+    const char *e = std::getenv("SSSPY_AMD_SMALL_MAX_ITEMS");
+    return e && std::atoll(e) == 0;
+  }();
+  if (!small_off && N >= 2 && N <= 4 && nbins <= 16384) {
+    switch (N) {
+      case 2: return ilrma_small_ip1_n2(U, 0, 0, C, W, B, F, floor_kind, floor_eps, qbuf, info, st);
+      case 3: return ilrma_small_ip1_n3(U, 0, 0, C, W, B, F, floor_kind, floor_eps, qbuf, info, st);
+      default: return ilrma_small_ip1_n4(U, 0, 0, C, W, B, F, floor_kind, floor_eps, qbuf, info, st);
+    }
+  }
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
   if (N > 4) {  // a bin on 8 lanes, one per row
     dim3 g8((unsigned)((nbins * 8 + 255) / 256)), b8(256);
