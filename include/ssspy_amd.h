@@ -128,11 +128,16 @@ int ssspy_iss1_fused_max_frames(int N);
 /* One whole update_by_iss1 sweep set, in place on Y (B,N,F,T): a bin's N x T slab stays in the
  * registers of one workgroup through the N rank-1 steps (one read + one write of Y).
  * weight: (B,N,T) for SSSPY_WEIGHT_FRAME, (B,N,F,T) for SSSPY_WEIGHT_BIN_FRAME.
- * r2_next (B,N,T), optional: receives sum_i |y_new|^2 (zeroed by the call) -- the frame powers the
- * next AuxIVA iteration needs, saving its separate pass.
+ * r2_next (B,N,T), optional: receives sum_i |y_new|^2 -- the frame powers the next AuxIVA iteration
+ * needs, saving its separate pass.  They are summed without atomics (every block leaves its bins' sums
+ * in `workspace`, a second kernel adds them in block order), so the result -- and with it the
+ * trajectory -- is the same on every run; `workspace` (ssspy_iss1_fused_workspace_bytes) is needed only
+ * with r2_next.
  * replaces: ssspy/bss/_update_spatial_model.py:146-194 (update_by_iss1). */
+size_t ssspy_iss1_fused_workspace_bytes(int B, int N, int F, int T);
 int ssspy_iss1_fused(void *Y, const double *weight, int weight_kind, double *r2_next, int B, int N,
-                     int F, int T, int floor_kind, double floor_eps, void *stream);
+                     int F, int T, int floor_kind, double floor_eps, void *workspace,
+                     size_t workspace_bytes, void *stream);
 
 /* The same sweep set, also tracking the log-determinant of the demixing filter the ISS state never
  * forms: the sweep of source n multiplies W_i by (I - v e_n^T), det = d_in^(-1/2), so
@@ -141,7 +146,7 @@ int ssspy_iss1_fused(void *Y, const double *weight, int weight_kind, double *r2_
  * reconstruction of W from Y X^H -- two more passes per recorded loss. */
 int ssspy_iss1_fused_tracked(void *Y, const double *weight, int weight_kind, double *r2_next, int B,
                              int N, int F, int T, int floor_kind, double floor_eps, double *logdet,
-                             void *stream);
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* W <- W * (W^-1)[ref,:]^T.  W (B,F,N,N) in place.  G (B,F,N,N), optional: receives
  * diag((W^-1)[ref, :]), the scales (projection-back normalisation needs them for the basis).
@@ -248,7 +253,9 @@ int ssspy_ilrma_normalize_filter(void *W, const void *C, double *basis, int B, i
 
 /* same for the ISS state: psi from |Y|^2 directly, Y /= psi, basis /= psi^p.
  * frame_power (B,N,T), optional: sum_i |y_nij|^2 of the CURRENT Y, as ssspy_iss1_fused leaves it in
- * r2_next -- saves the pass over Y that computes the power; NULL: computed here.
+ * r2_next -- saves the pass over Y that computes the power; NULL: computed here (one partial sum
+ * per 16 bin rows, added in order: no atomics).  workspace: B * N * ceil(F / 16) doubles (B * N with
+ * frame_power); the buffer of ssspy_ilrma_workspace_bytes is large enough.
  * replaces: ssspy/bss/ilrma.py:365-444 (normalize_by_power, demix_filter is None branch). */
 int ssspy_ilrma_normalize_output(void *Y, double *basis, const double *frame_power, int B, int N,
                                  int F, int T, int K, double domain, int floor_kind,
@@ -352,9 +359,12 @@ int ssspy_ilrma_partition_normalize(void *W, const void *C, void *Y, double *bas
 /* ------------------------------------------------------------------ AuxIVA (IP1/ISS1) */
 
 /* r2[b,n,j] = sum_i |y_nij|^2 with y = W x (or y = X when W == NULL).   r2 (B,N,T).
+ * Summed without atomics (bin chunks leave partial sums in `workspace`, folded in chunk order): the
+ * same bits on every run.  workspace: ssspy_iva_frame_power_workspace_bytes (0 for large batches).
  * replaces: np.linalg.norm(Y, axis=1) at ssspy/bss/iva.py:1787,1962 (squared). */
+size_t ssspy_iva_frame_power_workspace_bytes(int B, int N, int F, int T);
 int ssspy_iva_frame_power(const void *X, const void *W, double *r2, int B, int N, int F, int T,
-                          void *stream);
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* weight[b,n,j] = G'(r)/floor(2 r), r = sqrt(r2); Gauss also refreshes variance = r2 / F.
  * replaces: ssspy/bss/iva.py:1788-1789, :1963-1964, :3105-3115, :3273-3289, :3465-3473. */

@@ -38,8 +38,9 @@ PROTOTYPES = {
     "ssspy_ipa_transform": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _d, _p, _p]),
     "ssspy_iss2_transform": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
     "ssspy_iss1_fused_max_frames": (_i, [_i]),
-    "ssspy_iss1_fused": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p]),
-    "ssspy_iss1_fused_tracked": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
+    "ssspy_iss1_fused_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "ssspy_iss1_fused": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p, _z, _p]),
+    "ssspy_iss1_fused_tracked": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p, _p, _z, _p]),
     "ssspy_projection_back_filter": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "ssspy_mdp_scale": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "ssspy_ilrma_scale_basis": (_i, [_p, _p, _i, _i, _i, _i, _d, _p]),
@@ -74,7 +75,8 @@ PROTOTYPES = {
                                           _i, _i, _d, _p, _z, _p]),
     "ssspy_ilrma_partition_normalize": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p,
                                              _z, _p]),
-    "ssspy_iva_frame_power": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "ssspy_iva_frame_power_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "ssspy_iva_frame_power": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
     "ssspy_iva_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _d, _p]),
     "ssspy_iva_loss_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ssspy_gmnmf_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),

@@ -54,6 +54,24 @@ def _st():
     return dv.stream_handle()
 
 
+# ---- transient scratch of single operators (partial sums folded inside the same C-ABI call): one
+# growing buffer per device; every call runs on the caller's stream, in order, so it is never needed
+# by two operators at once
+_scratch_bufs = {}
+
+
+def _scratch(nbytes, dev):
+    nbytes = int(nbytes)
+    if nbytes == 0:
+        return None, 0
+    key = str(dev)
+    ent = _scratch_bufs.get(key)
+    if ent is None or ent[1] < nbytes:
+        ent = _workspace(nbytes, dev)
+        _scratch_bufs[key] = ent
+    return ent
+
+
 def separate(X, W, out=None):
     B, N, F, T = X.shape
     if out is None:
@@ -165,19 +183,24 @@ def iss1_fused_max_frames(n_sources):
 
 
 def iss1_fused(Y, weight, kind, flooring, r2_next=None, logdet=None):
-    """In-place fused ISS1 on Y; optionally accumulates the next iteration's frame powers, and moves
-    `logdet` (B,) = sum_i log|det W_i| of the implied demixing filters along with the sweeps."""
+    """In-place fused ISS1 on Y; optionally leaves the next iteration's frame powers (summed without
+    atomics: blocks' partial sums in a scratch buffer, folded in order), and moves `logdet` (B,) =
+    sum_i log|det W_i| of the implied demixing filters along with the sweeps."""
     B, N, F, T = Y.shape
+    ws, ws_bytes = (None, 0)
+    if r2_next is not None:
+        ws, ws_bytes = _scratch(_L().ssspy_iss1_fused_workspace_bytes(B, N, F, T), Y.device)
     if logdet is not None:
         _lib.check(
             _L().ssspy_iss1_fused_tracked(ptr(Y), ptr(weight), kind, ptr(r2_next), B, N, F, T,
-                                          flooring[0], flooring[1], ptr(logdet), _st()),
+                                          flooring[0], flooring[1], ptr(logdet), ptr(ws), ws_bytes,
+                                          _st()),
             "iss1_fused_tracked",
         )
         return Y
     _lib.check(
         _L().ssspy_iss1_fused(ptr(Y), ptr(weight), kind, ptr(r2_next), B, N, F, T, flooring[0],
-                              flooring[1], _st()),
+                              flooring[1], ptr(ws), ws_bytes, _st()),
         "iss1_fused",
     )
     return Y
@@ -413,8 +436,9 @@ def iva_frame_power(X, W, out=None):
     B, N, F, T = X.shape
     if out is None:
         out = dv.empty((B, N, T), dv.f64, X.device)
-    _lib.check(_L().ssspy_iva_frame_power(ptr(X), ptr(W), ptr(out), B, N, F, T, _st()),
-               "iva_frame_power")
+    ws, ws_bytes = _scratch(_L().ssspy_iva_frame_power_workspace_bytes(B, N, F, T), X.device)
+    _lib.check(_L().ssspy_iva_frame_power(ptr(X), ptr(W), ptr(out), B, N, F, T, ptr(ws), ws_bytes,
+                                          _st()), "iva_frame_power")
     return out
 
 

@@ -320,10 +320,10 @@ __global__ __launch_bounds__(256) void k_gm_part_latent(const double *__restrict
   }
 }
 
-// Activation sums: acc[b,n,0,k,j] += sum_{i in chunk} T A, acc[b,n,1,k,j] += sum T Bt.
-// grid: (ceil(T/64), bin chunks of 4*GM_ACT_BINS, N*B); wave w walks its own GM_ACT_BINS bins,
-// lanes are frames, the four waves fold through LDS and one atomic add per (k, frame) leaves.
-constexpr int GM_ACT_BINS = 32;
+// Activation sums: acc[b,n,0,k,j] = sum_i T A, acc[b,n,1,k,j] = sum_i T Bt.
+// grid: (ceil(T/64), 1, N*B); wave w walks its quarter of the bins, lanes are frames, the four
+// waves fold through LDS in wave order and the sum is STORED: no fp64 atomics, so the activation --
+// and with it the whole trajectory -- is the same on every run.
 
 __global__ __launch_bounds__(256) void k_gmnmf_activation_sums(const double *__restrict__ basis,
                                                                const double *__restrict__ A,
@@ -334,8 +334,9 @@ __global__ __launch_bounds__(256) void k_gmnmf_activation_sums(const double *__r
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + lane;
   const int n = blockIdx.z % N, b = blockIdx.z / N;
-  const int i_begin = (blockIdx.y * 4 + wave) * GM_ACT_BINS;
-  const int i_end = min(F, i_begin + GM_ACT_BINS);
+  const int per_wave = (F + 3) >> 2;
+  const int i_begin = wave * per_wave;
+  const int i_end = min(F, i_begin + per_wave);
   const int jc = min(j, T - 1);
   double sn[8], sd[8];
 #pragma unroll
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256) void k_gmnmf_activation_sums(const double *__r
     const int jj = blockIdx.x * 64 + ln;
     if (jj < T && k0 + kk < K) {
       const double v = fold[0][row][ln] + fold[1][row][ln] + fold[2][row][ln] + fold[3][row][ln];
-      atomicAdd(acc + ((((long long)b * N + n) * 2 + nd) * K + k0 + kk) * T + jj, v);
+      acc[((((long long)b * N + n) * 2 + nd) * K + k0 + kk) * T + jj] = v;
     }
   }
 }
@@ -750,11 +751,8 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
     rc = launch_traces(X, Tn, Vn, spatial, A, Bt, B, N, M, F, T, K, floor_kind, floor_eps, st);
     if (rc) return rc;
     const long long count = (long long)B * N * K * T;
-    hipError_t e = hipMemsetAsync(vacc, 0, (size_t)count * 2 * sizeof(double), st);
-    if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
-    const int chunks = (F + 4 * GM_ACT_BINS - 1) / (4 * GM_ACT_BINS);
     for (int k0 = 0; k0 < K; k0 += 8) {
-      hipLaunchKernelGGL(k_gmnmf_activation_sums, dim3((T + 63) / 64, chunks, N * B), dim3(256), 0,
+      hipLaunchKernelGGL(k_gmnmf_activation_sums, dim3((T + 63) / 64, 1, N * B), dim3(256), 0,
                          st, Tn, (const double *)A, (const double *)Bt, vacc, N, F, T, K, k0);
       rc = check_launch("k_gmnmf_activation_sums");
       if (rc) return rc;

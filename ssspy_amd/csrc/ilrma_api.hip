@@ -298,6 +298,8 @@ __global__ __launch_bounds__(256) void k_norm_scale(c128 *W, double *basis,
 }
 
 // ------------------------------------------------------------------ power normalisation (output)
+// acc[b][n][blk] = sum of |y|^2 over 16 bin rows: one slot per block, no fp64 atomics (the
+// normalised state is the same on every run); the consumer adds the slots in order
 __global__ __launch_bounds__(256) void k_output_power(const c128 *__restrict__ Y, double *acc,
                                                       int N, int F, int T) {
   // grid: (ceil(F / 16), N, B): 16 consecutive bin rows (one contiguous run) per block
@@ -309,21 +311,35 @@ __global__ __launch_bounds__(256) void k_output_power(const c128 *__restrict__ Y
   double local = 0.0;
   for (long long e = threadIdx.x; e < len; e += blockDim.x) local += cabs2(run[e]);
   const double total = block_sum(local, scratch);
-  if (threadIdx.x == 0) atomicAdd(acc + b * N + n, total);
+  if (threadIdx.x == 0) acc[((long long)b * N + n) * gridDim.x + blockIdx.x] = total;
+}
+
+// psi of source n from the `slots` partial powers of (b, n), every thread the same sum
+__device__ __forceinline__ double psi_from_slots(const double *__restrict__ acc, int slots, int F,
+                                                 int T, int floor_kind, double eps) {
+  double v = 0.0;
+  for (int k = 0; k < slots; ++k) v += acc[k];
+  v = v / ((double)F * (double)T);
+  return apply_floor(sqrt(v), floor_kind, eps);
 }
 
 __global__ __launch_bounds__(256) void k_ilrma_normalize_output(c128 *Y, double *basis,
                                                                 const double *__restrict__ acc,
-                                                                int N, int F, int T, int K,
-                                                                double p, int floor_kind,
+                                                                int slots, int N, int F, int T,
+                                                                int K, double p, int floor_kind,
                                                                 double eps, double *psi_out,
                                                                 double *logdet) {
   const int i = blockIdx.x, n = blockIdx.y, b = blockIdx.z;
-  double v = acc[b * N + n] / ((double)F * (double)T);
-  const double psi = apply_floor(sqrt(v), floor_kind, eps);
+  const double psi = psi_from_slots(acc + ((long long)b * N + n) * slots, slots, F, T, floor_kind, eps);
   if (psi_out && i == 0 && threadIdx.x == 0) psi_out[b * N + n] = psi;
-  // (row n of every implied demixing matrix is divided by psi: sum_i log|det W_i| moves by -F log psi)
-  if (logdet && i == 0 && threadIdx.x == 0) atomicAdd(logdet + b, -(double)F * log(psi));
+  // (row n of every implied demixing matrix is divided by psi: sum_i log|det W_i| moves by
+  // -F sum_n log psi_n; ONE thread per mixture adds all N terms, in source order)
+  if (logdet && i == 0 && n == 0 && threadIdx.x == 0) {
+    double delta = 0.0;
+    for (int m = 0; m < N; ++m)
+      delta += log(psi_from_slots(acc + ((long long)b * N + m) * slots, slots, F, T, floor_kind, eps));
+    logdet[b] -= (double)F * delta;
+  }
   c128 *row = Y + (((long long)b * N + n) * F + i) * T;
   for (int j = threadIdx.x; j < T; j += blockDim.x) {
     c128 y = row[j];
@@ -836,7 +852,9 @@ static int normalize_output_impl(void *Y, double *basis, const double *frame_pow
                                  double floor_eps, void *workspace, size_t workspace_bytes,
                                  double *logdet, void *stream) {
   SSSPY_REQUIRE(Y && basis && B > 0 && N >= 1, "normalize_output: bad argument");
-  SSSPY_REQUIRE(workspace && workspace_bytes >= (size_t)B * N * sizeof(double),
+  // frame powers given: one slot per (mixture, source); else one per block of 16 bin rows
+  const int slots = frame_power ? 1 : (F + 15) / 16;
+  SSSPY_REQUIRE(workspace && workspace_bytes >= (size_t)B * N * slots * sizeof(double),
                 "normalize_output: workspace too small");
   hipStream_t st = as_stream(stream);
   double *acc = (double *)workspace;
@@ -844,13 +862,11 @@ static int normalize_output_impl(void *Y, double *basis, const double *frame_pow
   if (frame_power) {
     hipLaunchKernelGGL(k_power_from_frames, dim3(N, B), block, 0, st, frame_power, acc, N, T);
   } else {
-    hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * N * sizeof(double), st);
-    if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
-    hipLaunchKernelGGL(k_output_power, dim3((F + 15) / 16, N, B), block, 0, st, (const c128 *)Y, acc,
-                       N, F, T);
+    hipLaunchKernelGGL(k_output_power, dim3(slots, N, B), block, 0, st, (const c128 *)Y, acc, N, F,
+                       T);
   }
-  hipLaunchKernelGGL(k_ilrma_normalize_output, grid, block, 0, st, (c128 *)Y, basis, acc, N, F, T,
-                     K, domain, floor_kind, floor_eps, (double *)nullptr, logdet);
+  hipLaunchKernelGGL(k_ilrma_normalize_output, grid, block, 0, st, (c128 *)Y, basis, acc, slots, N,
+                     F, T, K, domain, floor_kind, floor_eps, (double *)nullptr, logdet);
   return check_launch("k_ilrma_normalize_output");
 }
 
@@ -1111,13 +1127,13 @@ int ssspy_ilrma_partition_normalize(void *W, const void *C, void *Y, double *bas
     rc = check_launch("k_norm_scale");
     if (rc) return rc;
   } else {
-    hipError_t e = hipMemsetAsync(qbuf, 0, (size_t)B * N * sizeof(double), st);
-    if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+    // (qbuf holds B F N doubles: room for the B N ceil(F / 16) power slots)
+    const int slots = (F + 15) / 16;
     dim3 grid(F, N, B), block(256);
-    hipLaunchKernelGGL(k_output_power, dim3((F + 15) / 16, N, B), block, 0, st, (const c128 *)Y, qbuf,
-                       N, F, T);
+    hipLaunchKernelGGL(k_output_power, dim3(slots, N, B), block, 0, st, (const c128 *)Y, qbuf, N, F,
+                       T);
     hipLaunchKernelGGL(k_ilrma_normalize_output, grid, block, 0, st, (c128 *)Y, (double *)nullptr,
-                       (const double *)qbuf, N, F, T, K, domain, floor_kind, floor_eps, psi,
+                       (const double *)qbuf, slots, N, F, T, K, domain, floor_kind, floor_eps, psi,
                        (double *)nullptr);
     int rc = check_launch("k_ilrma_normalize_output");
     if (rc) return rc;

@@ -255,13 +255,31 @@ __global__ __launch_bounds__(256, 2) void k_iss1_fused(c128 *Y, const double *__
     }
   }
   if (r2_next) {
+    // the block's sums over its bins, to its own slab r2_next[block][b][n][j]; k_iss1_r2_fold adds the
+    // slabs in block order (no fp64 atomics: the next iteration's weights are the same on every run)
+    double *slab = r2_next + ((long long)blockIdx.x * gridDim.y + b) * N * T;
 #pragma unroll
     for (int n = 0; n < N; ++n)
 #pragma unroll
       for (int f = 0; f < FPT; ++f)
-        if (fv[f])
-          atomicAdd(r2_next + ((long long)b * N + n) * T + jj[f], r2s[(n * FPT + f) * 256 + threadIdx.x]);
+        if (fv[f]) slab[(long long)n * T + jj[f]] = r2s[(n * FPT + f) * 256 + threadIdx.x];
   }
+}
+
+// r2[e] = sum over the blocks' slabs, in block order; e over B * N * T
+__global__ __launch_bounds__(256) void k_iss1_r2_fold(const double *__restrict__ part, double *r2,
+                                                      long long total, int nblocks) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  double s = 0.0;
+  for (int k0 = 0; k0 < nblocks; k0 += 8) {  // eight loads in flight per round trip
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(long long)min(k0 + u, nblocks - 1) * total + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += k0 + u < nblocks ? v[u] : 0.0;
+  }
+  r2[e] = s;
 }
 
 template <int N>
@@ -269,14 +287,21 @@ constexpr int iss_max_fpt() {
   return N <= 2 ? 8 : (N <= 4 ? 8 : 4);
 }
 
+// bins per block: a few bins amortise the weight loads and the frame-power slab a block leaves
+// (N T doubles against N T complex per bin in and out: 1/(4 bpb) of the pass's traffic); keep >= ~4
+// blocks per CU.  With frame powers requested large batches take up to 32 bins per block (1.5 %).
+static int iss_bins_per_block(int B, int F, bool with_r2) {
+  const long long want_blocks = 1024;
+  int bpb = (int)(((long long)B * F + want_blocks - 1) / want_blocks);
+  if (bpb < 1) bpb = 1;
+  const int cap = with_r2 ? 32 : 8;
+  return bpb > cap ? cap : bpb;
+}
+
 template <int N, int FPT>
 static int launch_iss(void *Y, const double *weight, bool per_bin, double *r2_next, int B, int F,
                       int T, int floor_kind, double eps, double *logdet_delta, hipStream_t st) {
-  // a few bins per block amortise the weight loads and the r2 atomics; keep >= ~4 blocks per CU
-  long long want_blocks = 1024;
-  int bpb = (int)(((long long)B * F + want_blocks - 1) / want_blocks);
-  if (bpb < 1) bpb = 1;
-  if (bpb > 8) bpb = 8;
+  const int bpb = iss_bins_per_block(B, F, r2_next != nullptr);
   dim3 grid((F + bpb - 1) / bpb, B), block(256);
   if (logdet_delta) {  // tracked variants (a separate instantiation: the untracked hot kernels keep
                        // their register allocation)
@@ -319,35 +344,51 @@ int ssspy_iss1_fused_max_frames(int N) {
   return 256 * (N <= 4 ? 8 : 4);
 }
 
+size_t ssspy_iss1_fused_workspace_bytes(int B, int N, int F, int T) {
+  if (B <= 0 || N <= 0 || F <= 0 || T <= 0) return 0;
+  const int bpb = iss_bins_per_block(B, F, true);
+  return (size_t)((F + bpb - 1) / bpb) * B * N * T * sizeof(double);
+}
+
 static int iss1_fused_impl(void *Y, const double *weight, int weight_kind, double *r2_next, int B,
                            int N, int F, int T, int floor_kind, double floor_eps,
-                           double *logdet_delta, void *stream) {
+                           double *logdet_delta, void *workspace, size_t workspace_bytes,
+                           void *stream) {
   SSSPY_REQUIRE(Y && weight && B > 0 && F > 0 && T > 0, "iss1_fused: bad argument");
   SSSPY_REQUIRE(weight_kind == SSSPY_WEIGHT_FRAME || weight_kind == SSSPY_WEIGHT_BIN_FRAME,
                 "iss1_fused: weight_kind must be FRAME or BIN_FRAME");
   SSSPY_REQUIRE(T <= ssspy_iss1_fused_max_frames(N), "iss1_fused: n_frames above the fused limit");
+  SSSPY_REQUIRE(!r2_next || (workspace &&
+                             workspace_bytes >= ssspy_iss1_fused_workspace_bytes(B, N, F, T)),
+                "iss1_fused: frame powers need the workspace of ssspy_iss1_fused_workspace_bytes");
   const bool per_bin = weight_kind == SSSPY_WEIGHT_BIN_FRAME;
-  if (r2_next) {
-    hipError_t e = hipMemsetAsync(r2_next, 0, (size_t)B * N * T * sizeof(double), as_stream(stream));
-    if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
-  }
-  DISPATCH_N(N, return dispatch_iss<NN>(Y, weight, per_bin, r2_next, B, F, T, floor_kind, floor_eps,
-                                        logdet_delta, as_stream(stream)));
-  return SSSPY_OK;
+  hipStream_t st = as_stream(stream);
+  double *slabs = r2_next ? (double *)workspace : nullptr;
+  int rc = SSSPY_OK;
+  DISPATCH_N(N, rc = dispatch_iss<NN>(Y, weight, per_bin, slabs, B, F, T, floor_kind, floor_eps,
+                                      logdet_delta, st));
+  if (rc || !r2_next) return rc;
+  const int bpb = iss_bins_per_block(B, F, true);
+  const long long total = (long long)B * N * T;
+  hipLaunchKernelGGL(k_iss1_r2_fold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                     (const double *)slabs, r2_next, total, (F + bpb - 1) / bpb);
+  return check_launch("k_iss1_r2_fold");
 }
 
 int ssspy_iss1_fused(void *Y, const double *weight, int weight_kind, double *r2_next, int B, int N,
-                     int F, int T, int floor_kind, double floor_eps, void *stream) {
+                     int F, int T, int floor_kind, double floor_eps, void *workspace,
+                     size_t workspace_bytes, void *stream) {
   return iss1_fused_impl(Y, weight, weight_kind, r2_next, B, N, F, T, floor_kind, floor_eps, nullptr,
-                         stream);
+                         workspace, workspace_bytes, stream);
 }
 
 int ssspy_iss1_fused_tracked(void *Y, const double *weight, int weight_kind, double *r2_next, int B,
                              int N, int F, int T, int floor_kind, double floor_eps,
-                             double *logdet, void *stream) {
+                             double *logdet, void *workspace, size_t workspace_bytes,
+                             void *stream) {
   SSSPY_REQUIRE(logdet, "iss1_fused_tracked: bad argument");
   return iss1_fused_impl(Y, weight, weight_kind, r2_next, B, N, F, T, floor_kind, floor_eps, logdet,
-                         stream);
+                         workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

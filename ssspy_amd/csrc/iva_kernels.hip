@@ -6,7 +6,9 @@
 namespace ssspy {
 
 // lanes along frames (coalesced rows), block walks a chunk of bins; W_i is wave-uniform.
-// grid: (ceil(T/256), bin chunks, B); r2 must be zeroed before the launch.
+// grid: (ceil(T/256), bin chunks, B).  One chunk: r2 is stored directly; several: every chunk stores
+// its sums to part[chunk][b][n][j] and k_iva_frame_power_fold adds them in chunk order -- no fp64
+// atomics: the weights of the next iteration, hence the whole trajectory, are the same on every run.
 template <int N>
 __global__ __launch_bounds__(256) void k_iva_frame_power(const c128 *__restrict__ X,
                                                          const c128 *__restrict__ W, double *r2,
@@ -37,8 +39,27 @@ __global__ __launch_bounds__(256) void k_iva_frame_power(const c128 *__restrict_
       for (int n = 0; n < N; ++n) acc[n] += cabs2(x[n]);
     }
   }
+  // (r2 is the output itself with one chunk, else the chunk's slab of the partial buffer)
+  double *dst = r2 + (long long)blockIdx.y * gridDim.z * N * T;
 #pragma unroll
-  for (int n = 0; n < N; ++n) atomicAdd(r2 + ((long long)b * N + n) * T + j, acc[n]);
+  for (int n = 0; n < N; ++n) dst[((long long)b * N + n) * T + j] = acc[n];
+}
+
+// r2[e] = sum over chunks, in chunk order; e over B * N * T
+__global__ __launch_bounds__(256) void k_iva_frame_power_fold(const double *__restrict__ part,
+                                                              double *r2, long long total,
+                                                              int chunks) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  double s = 0.0;
+  for (int ch0 = 0; ch0 < chunks; ch0 += 8) {  // eight loads in flight per round trip
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(long long)min(ch0 + u, chunks - 1) * total + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += ch0 + u < chunks ? v[u] : 0.0;
+  }
+  r2[e] = s;
 }
 
 __global__ __launch_bounds__(256) void k_iva_weight(const double *__restrict__ r2, double *weight,
@@ -88,23 +109,42 @@ using namespace ssspy;
 
 extern "C" {
 
-int ssspy_iva_frame_power(const void *X, const void *W, double *r2, int B, int N, int F, int T,
-                          void *stream) {
-  SSSPY_REQUIRE(X && r2 && B > 0 && F > 0 && T > 0, "iva_frame_power: bad argument");
-  hipStream_t st = as_stream(stream);
-  hipError_t e = hipMemsetAsync(r2, 0, (size_t)B * N * T * sizeof(double), st);
-  if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+// bin chunks of the frame-power pass: enough blocks to fill the chip
+static int frame_power_chunks(int B, int F, int T, int *bins_per_chunk) {
   const int gx = (T + 255) / 256;
-  // enough blocks to fill the chip, at most one atomic per (chunk, source, frame)
   long long want = 2048 / ((long long)gx * B);
   if (want < 1) want = 1;
   if (want > F) want = F;
-  const int bins_per_chunk = (int)((F + want - 1) / want);
-  const int chunks = (F + bins_per_chunk - 1) / bins_per_chunk;
-  dim3 grid(gx, chunks, B), block(256);
+  *bins_per_chunk = (int)((F + want - 1) / want);
+  return (F + *bins_per_chunk - 1) / *bins_per_chunk;
+}
+
+size_t ssspy_iva_frame_power_workspace_bytes(int B, int N, int F, int T) {
+  if (B <= 0 || N <= 0 || F <= 0 || T <= 0) return 0;
+  int bpc;
+  const int chunks = frame_power_chunks(B, F, T, &bpc);
+  return chunks > 1 ? (size_t)chunks * B * N * T * sizeof(double) : 0;
+}
+
+int ssspy_iva_frame_power(const void *X, const void *W, double *r2, int B, int N, int F, int T,
+                          void *workspace, size_t workspace_bytes, void *stream) {
+  SSSPY_REQUIRE(X && r2 && B > 0 && F > 0 && T > 0, "iva_frame_power: bad argument");
+  hipStream_t st = as_stream(stream);
+  int bins_per_chunk;
+  const int chunks = frame_power_chunks(B, F, T, &bins_per_chunk);
+  const size_t need = ssspy_iva_frame_power_workspace_bytes(B, N, F, T);
+  SSSPY_REQUIRE(need == 0 || (workspace && workspace_bytes >= need),
+                "iva_frame_power: workspace too small");
+  double *dst = chunks > 1 ? (double *)workspace : r2;
+  dim3 grid((T + 255) / 256, chunks, B), block(256);
   DISPATCH_N(N, hipLaunchKernelGGL((k_iva_frame_power<NN>), grid, block, 0, st, (const c128 *)X,
-                                   (const c128 *)W, r2, F, T, bins_per_chunk));
-  return check_launch("k_iva_frame_power");
+                                   (const c128 *)W, dst, F, T, bins_per_chunk));
+  int rc = check_launch("k_iva_frame_power");
+  if (rc || chunks == 1) return rc;
+  const long long total = (long long)B * N * T;
+  hipLaunchKernelGGL(k_iva_frame_power_fold, dim3((unsigned)((total + 255) / 256)), block, 0, st,
+                     (const double *)workspace, r2, total, chunks);
+  return check_launch("k_iva_frame_power_fold");
 }
 
 int ssspy_iva_weight(const double *r2, double *weight, double *variance, int B, int N, int F, int T,
