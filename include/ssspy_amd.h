@@ -320,11 +320,17 @@ int ssspy_ilrma_ip1_update_deferred_loss(const void *X, const void *C, void *W, 
  * the current separated spectrogram, Vc (B,F,N,N,N) = ssspy_weighted_covariance(Y, weight), the
  * update matrix G (B,F,N,N) of source `source_idx`; the caller then applies ssspy_separate(Y, G)
  * and repeats for the next source.  n_sources in [2, 8].
+ * newton_ws: B 64-bit words of scratch.  The reference's Newton loop runs over all bins of a mixture
+ * at once and stops at the first step at which every bin has converged (linalg/lqpqm.py:196-213);
+ * with the scratch a probe pass finds that step count per mixture and the update makes exactly as
+ * many steps (max_iter <= 62); with NULL every bin makes max_iter steps.  not_converged (optional):
+ * incremented once per mixture whose bins had not all converged after max_iter steps (the
+ * reference's UserWarning).
  * replaces: ssspy/bss/_update_spatial_model.py:398-513 (update_by_ipa body), linalg/lqpqm.py:13-352
- * (lqpqm2 with `max_iter` Newton steps per bin). */
+ * (lqpqm2, solve_equation). */
 int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int B, int F, int N,
                         int normalization, int max_iter, int floor_kind, double floor_eps,
-                        int *info, void *stream);
+                        int *info, void *newton_ws, int *not_converged, void *stream);
 
 /* ---- partitioning (latent variables): basis (B,F,K), activation (B,K,T), latent (B,N,K) with
  * R_nij = sum_k z_nk t_ik v_kj (ssspy/bss/ilrma.py:297-327).  Every entry point above that takes
@@ -510,10 +516,13 @@ int ssspy_sqrtmh(const void *X, void *out, long long n, int M, int inverse, int 
 int ssspy_gmeanmh(const void *A, const void *Bm, void *G, long long n, int M, int type,
                   void *stream);
 /* y = argmin of the log-quadratically penalised quadratic (type 2): H (n, L, L) Hermitian, v (n, L),
- * z (n) -> y (n, L), L in [1, 7], `max_iter` Newton steps per problem.
+ * z (n) -> y (n, L), L in [1, 7].  newton_ws (one 64-bit word of scratch) / not_converged: as for
+ * ssspy_ipa_transform, the n problems forming one group (the reference's loop stops when all of them
+ * have converged); NULL: max_iter Newton steps per problem.
  * replaces: ssspy/linalg/lqpqm.py:13-352 (lqpqm2 with singular_fn = "x < flooring_fn(0)"). */
 int ssspy_lqpqm2(const void *H, const void *v, const double *z, void *y, long long n, int L,
-                 int max_iter, int floor_kind, double floor_eps, void *stream);
+                 int max_iter, int floor_kind, double floor_eps, void *newton_ws,
+                 int *not_converged, void *stream);
 
 /* ------------------------------------------------------------------ STFT / ISTFT
  * The transforms the reference's workflow takes from SciPy either side of a separator

@@ -4,15 +4,16 @@ TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
 
 Restates ``update_by_ipa`` (ssspy/bss/_update_spatial_model.py:398-513) and ``lqpqm2`` /
 ``solve_equation`` / ``_find_largest_root`` (ssspy/linalg/lqpqm.py:13-352, linalg/cubic.py) one
-frequency bin at a time -- the unit the device kernel works on.  Two deliberate simplifications
-against the reference, both exact unless noted:
-
-* the Newton loop of ``solve_equation`` runs ``max_iter`` steps for every bin; the reference stops
-  early only when ALL bins have converged at once (lqpqm.py:165-169), which changes results by at
-  most the convergence threshold;
-* the degenerate branch ``||v|| < floor(0)`` of ``lqpqm2`` returns a scaled eigenvector whose
-  phase is LAPACK's (lqpqm.py:78-92); it is restated, but no parity is claimed for it.
+frequency bin at a time -- the unit the device kernel works on -- except for the Newton loop of
+``solve_equation``, which runs over all (non-singular) bins of the call at once and stops at the
+first step at which every one of them has converged (lqpqm.py:196-213), warning when they have not
+after ``max_iter`` steps.  One caveat: the degenerate branch ``||v|| < floor(0)`` of ``lqpqm2``
+returns a scaled eigenvector whose phase is LAPACK's (lqpqm.py:78-92); it is restated, but no parity
+is claimed for it.
 """
+
+import warnings
+
 
 import numpy as np
 
@@ -50,11 +51,9 @@ def largest_cubic_root(A, B, C):
     return max(roots) - A / 3
 
 
-def solve_equation(phi, v, z, flooring, max_iter):
-    """Largest root lambda of  lambda^2 sum_l phi_l |v_l|^2 / (lambda - phi_l)^2 - lambda + z = 0.
-
-    ref: ssspy/linalg/lqpqm.py:112-200 (normalization=True).
-    """
+def _secular_setup(phi, v, z, flooring):
+    """Masked, normalised coefficients and the Cardano start value of one bin.
+    ref: ssspy/linalg/lqpqm.py:157-194 (normalization=True)."""
     f0 = floor0(flooring)
     mask = phi * np.abs(v) ** 2 >= f0
     phi = mask * phi
@@ -70,31 +69,61 @@ def solve_equation(phi, v, z, flooring, max_iter):
     if not lamb > 1:
         lamb = 1 + f0
     lamb = max(lamb, z)
+    return dict(phi=phi, w2=np.abs(v) ** 2, z=z, lamb=lamb, phi_max=phi_max)
+
+
+def solve_equations(problems, flooring, max_iter):
+    """Largest roots lambda_i of  lambda^2 sum_l phi_l |v_l|^2 / (lambda - phi_l)^2 - lambda + z = 0
+    for a list of (phi, v, z): Newton steps on ALL of them until every |f_i| <= floor(0) at the same
+    step, at most ``max_iter``; UserWarning when they have not converged by then.
+    ref: ssspy/linalg/lqpqm.py:112-216."""
+    f0 = floor0(flooring)
+    st = [_secular_setup(phi, v, z, flooring) for phi, v, z in problems]
+    if not st:
+        return []
+
+    def fn(s):
+        return s["lamb"] ** 2 * np.sum(s["phi"] * s["w2"] / (s["lamb"] - s["phi"]) ** 2) - s["lamb"] + s["z"]
+
+    broke = False
     for _ in range(max_iter):
-        f = lamb**2 * np.sum(phi * np.abs(v) ** 2 / (lamb - phi) ** 2) - lamb + z
-        df = -2 * lamb * np.sum((phi * np.abs(v)) ** 2 / (lamb - phi) ** 3) - 1
-        mu = lamb - f / df
-        lamb = mu if mu > 1 else (1 + lamb) / 2
-    return lamb * phi_max
+        f = [fn(s) for s in st]
+        if all(abs(fi) <= f0 for fi in f):
+            broke = True
+            break
+        for s, fi in zip(st, f):
+            df = -2 * s["lamb"] * np.sum(s["phi"] ** 2 * s["w2"] / (s["lamb"] - s["phi"]) ** 3) - 1
+            mu = s["lamb"] - fi / df
+            s["lamb"] = mu if mu > 1 else (1 + s["lamb"]) / 2
+    if not broke and max_iter > 0 and not all(abs(fn(s)) <= f0 for s in st):
+        warnings.warn("Newton-Raphson method did not converge in {} iterations.".format(max_iter),
+                      UserWarning)
+    return [s["lamb"] * s["phi_max"] for s in st]
 
 
 def lqpqm2(H, v, z, flooring, max_iter):
-    """argmin of the log-quadratically penalised quadratic (type 2).  ref: lqpqm.py:13-110."""
-    phi, sigma = np.linalg.eigh(H)
-    if np.linalg.norm(v) < floor0(flooring):
-        lamb = max(z, phi[-1])
-        return np.sqrt(max((lamb - z) / phi[-1], 0.0)) * sigma[:, -1]
-    v_t = sigma.conj().T @ v
-    lamb = solve_equation(phi, v_t, z, flooring, max_iter)
-    return sigma @ (phi * v_t / (lamb - phi))
+    """argmin of the log-quadratically penalised quadratic (type 2), a batch: H (n, L, L), v (n, L),
+    z (n,) -> y (n, L).  ref: lqpqm.py:13-110."""
+    n = len(H)
+    y = [None] * n
+    todo, problems = [], []
+    for i in range(n):
+        phi, sigma = np.linalg.eigh(H[i])
+        if np.linalg.norm(v[i]) < floor0(flooring):
+            lamb = max(z[i], phi[-1])
+            y[i] = np.sqrt(max((lamb - z[i]) / phi[-1], 0.0)) * sigma[:, -1]
+            continue
+        v_t = sigma.conj().T @ v[i]
+        todo.append((i, phi, sigma, v_t))
+        problems.append((phi, v_t, z[i]))
+    for (i, phi, sigma, v_t), lamb in zip(todo, solve_equations(problems, flooring, max_iter)):
+        y[i] = sigma @ (phi * v_t / (lamb - phi))
+    return np.stack(y)
 
 
-def ipa_transform_bin(U, s, flooring, normalization, max_iter):
-    """The N x N update matrix of one bin for source ``s``: y <- G y.
-
-    U (N, N, N): U[n] = mean_j varphi_nj y_j y_j^H (not yet PSD-floored).
-    ref: ssspy/bss/_update_spatial_model.py:425-511.
-    """
+def _ipa_prepare_bin(U, s, flooring, normalization):
+    """Everything of one bin up to the LQPQM problem (H, v, z).  U (N, N, N): U[n] = mean_j varphi_nj
+    y_j y_j^H (not yet PSD-floored).  ref: ssspy/bss/_update_spatial_model.py:425-486."""
     N = U.shape[0]
     U = sp.to_psd(U, flooring)
     rest = [m for m in range(N) if m != s]
@@ -114,17 +143,30 @@ def ipa_transform_bin(U, s, flooring, normalization, max_iter):
     if normalization:
         tr = np.real(np.trace(H))
         H, zz = H / tr, zz / tr
-    q = lqpqm2(H, v, zz, flooring, max_iter) / a_sqrt - b / a
+    return dict(H=H, v=v, z=zz, a=a, b=b, a_sqrt=a_sqrt, U_s=U_s, rest=rest, N=N, s=s)
+
+
+def _ipa_finish_bin(st, q_check, flooring):
+    """The N x N update matrix of one bin from the LQPQM solution: y <- G y.  ref: :487-511."""
+    N, s, rest = st["N"], st["s"], st["rest"]
+    q = q_check / st["a_sqrt"] - st["b"] / st["a"]
     q_tilde = np.zeros(N, dtype=np.complex128)
     q_tilde[s] = 1.0
     q_tilde[rest] = -q.conj()
-    Uq = np.linalg.solve(U_s, q_tilde)
+    Uq = np.linalg.solve(st["U_s"], q_tilde)
     den = sp.floor(np.sqrt(max(np.real(np.vdot(q_tilde, Uq)), 0.0)), flooring)
     p = Uq / den
     G = np.eye(N, dtype=np.complex128)
     G[s, :] = p.conj()
     G[rest, s] = q.conj()
     return G
+
+
+def ipa_transforms(U, s, flooring, normalization, max_iter):
+    """Update matrices (F, N, N) of all bins for source ``s``; U (F, N, N, N)."""
+    st = [_ipa_prepare_bin(U[i], s, flooring, normalization) for i in range(len(U))]
+    y = lqpqm2([b["H"] for b in st], [b["v"] for b in st], [b["z"] for b in st], flooring, max_iter)
+    return np.stack([_ipa_finish_bin(b, y[i], flooring) for i, b in enumerate(st)])
 
 
 def update_by_ipa(Y, varphi, flooring=sp.DEFAULT_FLOOR, normalization=True, max_iter=1):
@@ -134,7 +176,6 @@ def update_by_ipa(Y, varphi, flooring=sp.DEFAULT_FLOOR, normalization=True, max_
     for s in range(N):
         YY = Y[:, None] * Y[None, :].conj()  # (a, b, F, T)
         U = np.mean(varphi[:, None, None] * YY, axis=-1).transpose(3, 0, 1, 2)  # (F, n, a, b)
-        G = np.stack([ipa_transform_bin(U[i], s, flooring, normalization, max_iter)
-                      for i in range(F)])
+        G = ipa_transforms(U, s, flooring, normalization, max_iter)
         Y = sp.separate(Y, G)
     return Y

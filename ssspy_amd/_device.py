@@ -62,3 +62,4 @@ def stream_handle():
 c128 = torch.complex128
 f64 = torch.float64
 i32 = torch.int32
+i64 = torch.int64

@@ -35,7 +35,7 @@ PROTOTYPES = {
     "ssspy_update_by_ip1": (_i, [_p, _p, _i, _i, _i, _i, _d, _p, _p]),
     "ssspy_iss1_transform": (_i, [_p, _p, _i, _i, _i, _i, _d, _p]),
     "ssspy_update_by_ip2": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
-    "ssspy_ipa_transform": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _d, _p, _p]),
+    "ssspy_ipa_transform": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p]),
     "ssspy_iss2_transform": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
     "ssspy_iss1_fused_max_frames": (_i, [_i]),
     "ssspy_iss1_fused_workspace_bytes": (_z, [_i, _i, _i, _i]),
@@ -86,7 +86,7 @@ PROTOTYPES = {
     "ssspy_eigh_general": (_i, [_p, _p, _p, _p, _q, _i, _i, _p, _p]),
     "ssspy_sqrtmh": (_i, [_p, _p, _q, _i, _i, _i, _d, _p]),
     "ssspy_gmeanmh": (_i, [_p, _p, _p, _q, _i, _i, _p]),
-    "ssspy_lqpqm2": (_i, [_p, _p, _p, _p, _q, _i, _i, _i, _d, _p]),
+    "ssspy_lqpqm2": (_i, [_p, _p, _p, _p, _q, _i, _i, _i, _d, _p, _p, _p]),
     "ssspy_stft_frames": (_i, [_q, _i, _i]),
     "ssspy_stft": (_i, [_p, _p, _p, _d, _i, _i, _q, _i, _i, _p]),
     "ssspy_istft_samples": (_q, [_i, _i, _i]),

@@ -153,27 +153,33 @@ def iss2_transform(Vc, pairs, flooring, info=None, out=None):
     return out
 
 
-def ipa_transform(Vc, source_idx, normalization, max_iter, flooring, info=None, out=None):
+def ipa_transform(Vc, source_idx, normalization, max_iter, flooring, info=None, out=None,
+                  newton_ws=None, not_converged=None):
+    """newton_ws (B int64 words of scratch): the Newton loop makes the reference's number of steps
+    (it stops when every bin of a mixture has converged); not_converged (int32 counter): mixtures
+    whose bins had not all converged after max_iter steps."""
     B, F, N = Vc.shape[0], Vc.shape[1], Vc.shape[-1]
     if out is None:
         out = dv.empty((B, F, N, N), dv.c128, Vc.device)
     _lib.check(
         _L().ssspy_ipa_transform(ptr(Vc), ptr(out), int(source_idx), B, F, N,
                                  int(bool(normalization)), int(max_iter), flooring[0], flooring[1],
-                                 ptr(info), _st()),
+                                 ptr(info), ptr(newton_ws), ptr(not_converged), _st()),
         "ipa_transform",
     )
     return out
 
 
-def update_by_ipa(Y, weight, kind, normalization, max_iter, flooring, info=None):
+def update_by_ipa(Y, weight, kind, normalization, max_iter, flooring, info=None, not_converged=None):
     """One IPA sweep in place on the device spectrogram Y (B, N, F, T): per source, weighted
     covariance of the current Y -> update matrix -> Y <- G Y."""
-    N = Y.shape[1]
+    B, N = Y.shape[0], Y.shape[1]
     Vc = G = None
+    newton_ws = dv.empty((B,), dv.i64, Y.device)
     for s in range(N):
         Vc = weighted_covariance(Y, weight, kind, N, out=Vc)
-        G = ipa_transform(Vc, s, normalization, max_iter, flooring, info, out=G)
+        G = ipa_transform(Vc, s, normalization, max_iter, flooring, info, out=G,
+                          newton_ws=newton_ws, not_converged=not_converged)
         separate(Y, G, out=Y)
     return Y
 

@@ -205,13 +205,18 @@ class DeviceStateMixin:
                 ent["host"] = _snapshot(ent["host"])
         return ent["dev"]
 
-    # -- singular-matrix reporting ------------------------------------------------------
+    # -- singular-matrix / non-convergence reporting
     def _info_tensor(self):
+        """Device counters the kernels bump: [0] singular per-bin systems (the reference raises
+        LinAlgError), [1] mixtures whose IPA Newton iteration had not converged (it warns)."""
         info = self.__dict__.get("_info")
         if info is None:
-            info = dv.zeros((1,), dv.i32)
+            info = dv.zeros((2,), dv.i32)
             self.__dict__["_info"] = info
         return info
+
+    def _newton_counter(self):
+        return self._info_tensor()[1:]
 
     def _check_device_errors(self):
         from .. import _ops
@@ -219,7 +224,14 @@ class DeviceStateMixin:
         _ops.check_workspace_canaries()  # no-op unless SSSPY_AMD_WS_CANARY is set
         info = self.__dict__.get("_info")
         if info is not None:
-            count = int(info.item())  # synchronises
-            if count:
+            singular, not_converged = (int(v) for v in info.tolist())  # synchronises
+            if singular or not_converged:
                 info.zero_()
-                _lib.raise_if_singular(count, type(self).__name__)
+            if not_converged:
+                import warnings
+
+                warnings.warn(
+                    "Newton-Raphson method did not converge in {} iterations.".format(
+                        getattr(self, "newton_iter", "the given")), UserWarning)
+            if singular:
+                _lib.raise_if_singular(singular, type(self).__name__)

@@ -168,8 +168,14 @@ def update_by_ipa(
     else:
         w = dv.to_device(np.broadcast_to(wt, (B, N, F, T)), dtype=np.float64)
         kind = _lib.WEIGHT_BIN_FRAME
-    info = dv.zeros((1,), dv.i32)
-    _ops.update_by_ipa(Y, w, kind, normalization, max_iter, floor, info)
+    info = dv.zeros((2,), dv.i32)  # [singular systems, mixtures whose Newton loop did not converge]
+    _ops.update_by_ipa(Y, w, kind, normalization, max_iter, floor, info, not_converged=info[1:])
     out = dv.to_host(Y)[0]
-    _lib.raise_if_singular(int(info.item()), "update_by_ipa")
+    singular, not_converged = (int(v) for v in info.tolist())
+    if not_converged:
+        import warnings
+
+        warnings.warn("Newton-Raphson method did not converge in {} iterations.".format(max_iter),
+                      UserWarning)
+    _lib.raise_if_singular(singular, "update_by_ipa")
     return out

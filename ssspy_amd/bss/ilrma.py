@@ -535,7 +535,8 @@ class _MMILRMA(ILRMABase):
                                        model=self._model,
                                        flooring=self._resolve_floor(flooring_fn))
         _ops.update_by_ipa(Y, varphi, _lib.WEIGHT_BIN_FRAME, self.lqpqm_normalization,
-                           self.newton_iter, self._resolve_floor(flooring_fn), self._info_tensor())
+                           self.newton_iter, self._resolve_floor(flooring_fn), self._info_tensor(),
+                           not_converged=self._newton_counter())
         self._state_touch("output")
 
     def update_spatial_model_ip2(self, flooring_fn="self") -> None:

@@ -393,7 +393,8 @@ class AuxIVA(AuxIVABase):
         Y = self._state_dev("output")
         weight = self._weights(flooring_fn)
         _ops.update_by_ipa(Y, weight, _lib.WEIGHT_FRAME, self.lqpqm_normalization,
-                           self.newton_iter, self._resolve_floor(flooring_fn), self._info_tensor())
+                           self.newton_iter, self._resolve_floor(flooring_fn), self._info_tensor(),
+                           not_converged=self._newton_counter())
         self._state_touch("output")
 
     def _pair_weight_contrast(self):

@@ -11,9 +11,17 @@
 // replaces: ssspy/bss/_update_spatial_model.py:398-513 (update_by_ipa), :611-645 (_psd_inv),
 //           ssspy/linalg/lqpqm.py:13-352 (lqpqm2, solve_equation, _find_largest_root),
 //           ssspy/linalg/cubic.py (polar complex cube root).
-// Two differences from the reference: every bin runs `max_iter` Newton steps (the reference stops
-// early only when all bins have converged at once); the ||v|| ~ 0 branch returns a scaled
-// eigenvector whose phase is the decomposition's.
+// The Newton loop of the reference runs over all bins of a mixture at once and stops at the first
+// step at which EVERY (non-singular) bin has converged (lqpqm.py:196-213) -- a reduction across bins
+// in the middle of a per-bin computation.  Every bin's trajectory is independent of the others for
+// as long as the loop runs, so the step count is found by a PROBE pass: the same kernel up to the
+// Newton loop, run for all max_iter steps, each bin leaving the bit mask "converged at step k" (and
+// after the last step) AND-ed into one 64-bit word per mixture; k_newton_steps turns the word into
+// the number of steps the reference would have made (and counts the mixtures that never converged:
+// the reference's UserWarning); the real pass then makes exactly that many steps.  Without the word
+// (newton_ws == NULL, or max_iter > 62) every bin runs max_iter steps.
+// One difference from the reference remains: the ||v|| ~ 0 branch returns a scaled eigenvector whose
+// phase is the decomposition's.
 #include "common.hpp"
 #include "hermitian.hpp"
 #include "smallmat.hpp"
@@ -65,9 +73,13 @@ __device__ __forceinline__ double largest_cubic_root(double A, double B, double 
 }
 
 // y = argmin of the LQPQM (type 2) with H = sigma diag(phi) sigma^H.  ref: lqpqm.py:13-110
+// mode: NEWTON_FIXED max_iter steps; NEWTON_PROBE max_iter steps, convergence bits AND-ed into *word
+// (nothing else is produced); NEWTON_APPLY the number of steps found in *word by k_newton_steps
+enum { NEWTON_FIXED = 0, NEWTON_PROBE = 1, NEWTON_APPLY = 2 };
 template <int L>
 __device__ __forceinline__ void lqpqm2(c128 (&H)[L][L], const c128 (&v)[L], double z,
-                                       int floor_kind, double eps, int max_iter, c128 (&y)[L]) {
+                                       int floor_kind, double eps, int max_iter, c128 (&y)[L],
+                                       int mode = NEWTON_FIXED, unsigned long long *word = nullptr) {
   c128 sigma[L][L];
   jacobi_eigh<L>(H, sigma);
   double phi[L];
@@ -138,7 +150,9 @@ __device__ __forceinline__ void lqpqm2(c128 (&H)[L][L], const c128 (&v)[L], doub
   double lamb = largest_cubic_root(A, Bc, Cc);
   if (!(lamb > 1.0)) lamb = 1.0 + f0;
   lamb = fmax(lamb, zn);
-  for (int it = 0; it < max_iter; ++it) {
+  const int steps = mode == NEWTON_APPLY ? (int)*word : max_iter;
+  unsigned long long bits = 0ull;
+  for (int it = 0; it <= steps; ++it) {
     double s2 = 0.0, s3 = 0.0;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -147,9 +161,15 @@ __device__ __forceinline__ void lqpqm2(c128 (&H)[L][L], const c128 (&v)[L], doub
       s3 += ph[l] * ph[l] * w2[l] / (dl * dl * dl);
     }
     const double f = lamb * lamb * s2 - lamb + zn;
+    if (fabs(f) <= f0) bits |= 1ull << it;  // (bit `steps`: the state after the last step)
+    if (it == steps) break;
     const double df = -2.0 * lamb * s3 - 1.0;
     const double mu = lamb - f / df;
     lamb = mu > 1.0 ? mu : 0.5 * (1.0 + lamb);
+  }
+  if (mode == NEWTON_PROBE) {
+    atomicAnd(word, bits);
+    return;
   }
   lamb *= pm;
   // y = sigma (phi * vt / (lamb - phi)) with the unmasked phi, vt
@@ -173,14 +193,16 @@ __device__ __forceinline__ constexpr int rest_index(int m) {
 // Vc: (nbins, N, N, N) weighted covariances; G: (nbins, N, N).  One lane per bin.
 // (one wave per SIMD: the N x N working set of the larger source counts wants the whole 512-entry
 // register file; the grid has only B*F lanes anyway)
-template <int N, int S>
+template <int N, int S, int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ipa_transform(const c128 *__restrict__ Vc,
                                                       c128 *__restrict__ G, long long nbins,
-                                                      int normalization, int max_iter,
-                                                      int floor_kind, double eps, int *info) {
+                                                      int F, int normalization, int max_iter,
+                                                      int floor_kind, double eps, int *info,
+                                                      unsigned long long *newton_ws) {
   constexpr int L = N - 1;
   const long long bin = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (bin >= nbins) return;
+  unsigned long long *word = MODE == NEWTON_FIXED ? nullptr : newton_ws + bin / F;
   const c128 *Ub = Vc + bin * (long long)(N * N * N);
   c128 M[N][N], P[N][N];
   double lam[N];
@@ -233,7 +255,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   }
   const bool ok = lu_forward<L, 1>(C, rhs);
   lu_backward<L, 1>(C, rhs);
-  if (!ok && info) atomicAdd(info, 1);
+  if (MODE != NEWTON_PROBE && !ok && info) atomicAdd(info, 1);
   double dCd = 0.0;
 #pragma unroll
   for (int r = 0; r < L; ++r) dCd += d[r].x * rhs[r][0].x + d[r].y * rhs[r][0].y;
@@ -264,7 +286,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   }
   hermitize<L>(H);
   c128 qc[L];
-  lqpqm2<L>(H, v, z, floor_kind, eps, max_iter, qc);
+  lqpqm2<L>(H, v, z, floor_kind, eps, max_iter, qc, MODE, word);
+  if (MODE == NEWTON_PROBE) return;
   // q = q_check / a_sqrt - b / a ; q~ = e_S - E conj(q)
   c128 q[L], qt[N];
 #pragma unroll
@@ -303,10 +326,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 }
 
 // standalone LQPQM2 (ssspy.linalg.lqpqm2): H (n, L, L), v (n, L), z (n) -> y (n, L)
-template <int L>
+// word <- the number of Newton steps the reference makes: the first step at which every problem of
+// the group had converged (it stops BEFORE that step's update), else max_iter; groups that had not
+// converged after the last step either are counted in *not_converged.  grid: 1 block, thread = group
+__global__ void k_newton_steps(unsigned long long *words, int ngroups, int max_iter,
+                               int *not_converged) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ngroups) return;
+  const unsigned long long w = words[g];
+  int steps = max_iter;
+  for (int k = 0; k < max_iter; ++k)
+    if ((w >> k) & 1ull) {
+      steps = k;
+      break;
+    }
+  if (steps == max_iter && !((w >> max_iter) & 1ull) && not_converged) atomicAdd(not_converged, 1);
+  words[g] = (unsigned long long)steps;
+}
+
+template <int L, int MODE>
 __global__ __launch_bounds__(64) void k_lqpqm2(const c128 *__restrict__ H, const c128 *__restrict__ v,
                                                const double *__restrict__ z, c128 *y, long long n,
-                                               int max_iter, int floor_kind, double eps) {
+                                               int max_iter, int floor_kind, double eps,
+                                               unsigned long long *newton_ws) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
   c128 Hm[L][L], vv[L], yy[L];
@@ -317,17 +359,47 @@ __global__ __launch_bounds__(64) void k_lqpqm2(const c128 *__restrict__ H, const
     for (int c = 0; c < L; ++c) Hm[r][c] = H[(idx * L + r) * L + c];
   }
   hermitize<L>(Hm);
-  lqpqm2<L>(Hm, vv, z[idx], floor_kind, eps, max_iter, yy);
+  lqpqm2<L>(Hm, vv, z[idx], floor_kind, eps, max_iter, yy, MODE, newton_ws);
+  if (MODE == NEWTON_PROBE) return;
 #pragma unroll
   for (int r = 0; r < L; ++r) y[idx * L + r] = yy[r];
 }
 
+// all-ones words, probe pass, words -> step counts
+static int newton_prepare(unsigned long long *ws, int ngroups, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(ws, 0xFF, (size_t)ngroups * sizeof(unsigned long long), st);
+  return e == hipSuccess ? SSSPY_OK : fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+}
+static int newton_finish(unsigned long long *ws, int ngroups, int max_iter, int *not_converged,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(k_newton_steps, dim3((ngroups + 255) / 256), dim3(256), 0, st, ws, ngroups,
+                     max_iter, not_converged);
+  return check_launch("k_newton_steps");
+}
+
 template <int N, int S>
-static int launch_one(const void *Vc, void *G, long long nbins, int normalization, int max_iter,
-                      int floor_kind, double eps, int *info, hipStream_t st) {
+static int launch_one(const void *Vc, void *G, long long nbins, int B, int F, int normalization,
+                      int max_iter, int floor_kind, double eps, int *info,
+                      unsigned long long *newton_ws, int *not_converged, hipStream_t st) {
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
-  hipLaunchKernelGGL((k_ipa_transform<N, S>), grid, block, 0, st, (const c128 *)Vc, (c128 *)G,
-                     nbins, normalization, max_iter, floor_kind, eps, info);
+  if (!newton_ws || max_iter > 62 || max_iter == 0) {
+    hipLaunchKernelGGL((k_ipa_transform<N, S, NEWTON_FIXED>), grid, block, 0, st, (const c128 *)Vc,
+                       (c128 *)G, nbins, F, normalization, max_iter, floor_kind, eps, info,
+                       (unsigned long long *)nullptr);
+    return check_launch("k_ipa_transform");
+  }
+  int rc = newton_prepare(newton_ws, B, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_ipa_transform<N, S, NEWTON_PROBE>), grid, block, 0, st, (const c128 *)Vc,
+                     (c128 *)G, nbins, F, normalization, max_iter, floor_kind, eps, info,
+                     newton_ws);
+  rc = check_launch("k_ipa_transform (probe)");
+  if (rc) return rc;
+  rc = newton_finish(newton_ws, B, max_iter, not_converged, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_ipa_transform<N, S, NEWTON_APPLY>), grid, block, 0, st, (const c128 *)Vc,
+                     (c128 *)G, nbins, F, normalization, max_iter, floor_kind, eps, info,
+                     newton_ws);
   return check_launch("k_ipa_transform");
 }
 
@@ -337,7 +409,8 @@ using namespace ssspy;
 
 extern "C" int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int B, int F, int N,
                                    int normalization, int max_iter, int floor_kind,
-                                   double floor_eps, int *info, void *stream) {
+                                   double floor_eps, int *info, void *newton_ws,
+                                   int *not_converged, void *stream) {
   SSSPY_REQUIRE(Vc && G && B > 0 && F > 0, "ipa_transform: bad argument");
   SSSPY_REQUIRE(source_idx >= 0 && source_idx < N, "ipa_transform: bad source index");
   SSSPY_REQUIRE(max_iter >= 0, "ipa_transform: max_iter must be non-negative");
@@ -347,8 +420,9 @@ extern "C" int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int 
   hipStream_t st = as_stream(stream);
 #define IPA_CASE(N_, S_)                                                                     \
   if (N == N_ && source_idx == S_)                                                           \
-    return launch_one<N_, S_>(Vc, G, nbins, normalization, max_iter, floor_kind, floor_eps, \
-                              info, st);
+    return launch_one<N_, S_>(Vc, G, nbins, B, F, normalization, max_iter, floor_kind,     \
+                              floor_eps, info, (unsigned long long *)newton_ws, not_converged, \
+                              st);
   IPA_CASE(2, 0) IPA_CASE(2, 1)
   IPA_CASE(3, 0) IPA_CASE(3, 1) IPA_CASE(3, 2)
   IPA_CASE(4, 0) IPA_CASE(4, 1) IPA_CASE(4, 2) IPA_CASE(4, 3)
@@ -363,18 +437,35 @@ extern "C" int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int 
 }
 
 extern "C" int ssspy_lqpqm2(const void *H, const void *v, const double *z, void *y, long long n,
-                            int L, int max_iter, int floor_kind, double floor_eps, void *stream) {
+                            int L, int max_iter, int floor_kind, double floor_eps, void *newton_ws,
+                            int *not_converged, void *stream) {
   SSSPY_REQUIRE(H && v && z && y && n > 0 && max_iter >= 0, "lqpqm2: bad argument");
   if (L < 1 || L > 7) return fail(SSSPY_ERR_UNSUPPORTED, "lqpqm2: dimension must be in [1, 7]");
   dim3 grid((unsigned)((n + 63) / 64)), block(64);
   hipStream_t st = as_stream(stream);
-#define LQ_CASE(L_)                                                                          \
-  if (L == L_) {                                                                             \
-    hipLaunchKernelGGL((k_lqpqm2<L_>), grid, block, 0, st, (const c128 *)H, (const c128 *)v, z, \
-                       (c128 *)y, n, max_iter, floor_kind, floor_eps);                       \
-    return check_launch("k_lqpqm2");                                                         \
+  unsigned long long *ws = (unsigned long long *)newton_ws;
+  const bool exact = ws && max_iter >= 1 && max_iter <= 62;
+#define LQ_LAUNCH(L_, MODE_)                                                                     \
+  hipLaunchKernelGGL((k_lqpqm2<L_, MODE_>), grid, block, 0, st, (const c128 *)H, (const c128 *)v, \
+                     z, (c128 *)y, n, max_iter, floor_kind, floor_eps, ws)
+#define LQ_CASE(L_)                                                                              \
+  if (L == L_) {                                                                                 \
+    if (!exact) {                                                                                \
+      LQ_LAUNCH(L_, NEWTON_FIXED);                                                               \
+      return check_launch("k_lqpqm2");                                                           \
+    }                                                                                            \
+    int rc = newton_prepare(ws, 1, st);                                                          \
+    if (rc) return rc;                                                                           \
+    LQ_LAUNCH(L_, NEWTON_PROBE);                                                                 \
+    rc = check_launch("k_lqpqm2 (probe)");                                                       \
+    if (rc) return rc;                                                                           \
+    rc = newton_finish(ws, 1, max_iter, not_converged, st);                                      \
+    if (rc) return rc;                                                                           \
+    LQ_LAUNCH(L_, NEWTON_APPLY);                                                                 \
+    return check_launch("k_lqpqm2");                                                             \
   }
   LQ_CASE(1) LQ_CASE(2) LQ_CASE(3) LQ_CASE(4) LQ_CASE(5) LQ_CASE(6) LQ_CASE(7)
 #undef LQ_CASE
+#undef LQ_LAUNCH
   return SSSPY_ERR_UNSUPPORTED;
 }

@@ -181,8 +181,9 @@ def lqpqm2(H: np.ndarray, v: np.ndarray, z: np.ndarray, flooring_fn="default",
            singular_fn="flooring", max_iter: int = 10) -> np.ndarray:
     """Log-quadratically penalised quadratic minimisation, type 2 (ref: ssspy/linalg/lqpqm.py:13-110).
 
-    H (n_bins, L, L) Hermitian, v (n_bins, L), z (n_bins,) -> y (n_bins, L).  Every problem runs
-    ``max_iter`` Newton steps; ``singular_fn`` must be the reference's default ("flooring").
+    H (n_bins, L, L) Hermitian, v (n_bins, L), z (n_bins,) -> y (n_bins, L).  The Newton loop stops
+    when every problem has converged and warns when they have not after ``max_iter`` steps, like
+    the reference (lqpqm.py:196-213); ``singular_fn`` must be the reference's default ("flooring").
     """
     import functools
 
@@ -200,6 +201,15 @@ def lqpqm2(H: np.ndarray, v: np.ndarray, z: np.ndarray, flooring_fn="default",
     dvv = dv.to_device(np.ascontiguousarray(v, dtype=np.complex128))
     dz = dv.to_device(np.ascontiguousarray(z))
     y = dv.empty((n, L), dv.c128, dH.device)
+    newton_ws = dv.empty((1,), dv.i64, dH.device)
+    not_converged = dv.zeros((1,), dv.i32, dH.device)
     _lib.check(_lib.load().ssspy_lqpqm2(ptr(dH), ptr(dvv), ptr(dz), ptr(y), n, L, int(max_iter),
-                                        floor[0], floor[1], dv.stream_handle()), "lqpqm2")
-    return dv.to_host(y)
+                                        floor[0], floor[1], ptr(newton_ws), ptr(not_converged),
+                                        dv.stream_handle()), "lqpqm2")
+    out = dv.to_host(y)
+    if int(not_converged.item()):
+        import warnings
+
+        warnings.warn("Newton-Raphson method did not converge in {} iterations.".format(max_iter),
+                      UserWarning)
+    return out

@@ -112,7 +112,7 @@ def meta(**kw):
 # --------------------------------------------------------------------------- ILRMA
 def run_ilrma(name, *, N, F, T, K, algo, seed, gen=gen_iid, domain=2, flooring=("max", 1e-10),
               normalization=True, scale_restoration=True, n_iter=10, model=("gauss", None),
-              source_algorithm="MM", partitioning=False):
+              source_algorithm="MM", partitioning=False, **ipa_kwargs):
     if skipped(name):
         return
     X = gen(seed, N, F, T)
@@ -135,7 +135,7 @@ def run_ilrma(name, *, N, F, T, K, algo, seed, gen=gen_iid, domain=2, flooring=(
     elif model[0] == "ggd":
         m = GGDILRMA(n_basis=K, beta=model[1], **common)
     else:
-        m = GaussILRMA(n_basis=K, **common)
+        m = GaussILRMA(n_basis=K, **common, **ipa_kwargs)
     Y = m(X, n_iter=n_iter, basis=basis, activation=activation,
           **{k: v.copy() for k, v in init.items()})
     out = dict(X=X, basis0=basis, activation0=activation, loss=np.array(m.loss), final_output=Y,
@@ -150,7 +150,8 @@ def run_ilrma(name, *, N, F, T, K, algo, seed, gen=gen_iid, domain=2, flooring=(
                     model=model[0], model_param=(0.0 if model[1] is None else model[1]),
                     source_algorithm=source_algorithm, partitioning=partitioning,
                     floor_kind=flooring[0], floor_eps=flooring[1], normalization=normalization,
-                    scale_restoration=scale_restoration))
+                    scale_restoration=scale_restoration,
+                    newton_iter=ipa_kwargs.get("newton_iter", 1)))
     save(name, **out)
 
 
@@ -344,6 +345,22 @@ def run_ipa_operators():
                                                             max_iter=3)
         out["n{}_out_bcast_add".format(N)] = update_by_ipa(
             Y.copy(), varphi[:, :1, :], flooring_fn=functools.partial(add_flooring, eps=1e-4))
+        # enough Newton steps for the loop to stop early (all bins converged): lqpqm.py:196-213
+        out["n{}_out_it12".format(N)] = update_by_ipa(Y.copy(), varphi, max_iter=12)
+    # the LQPQM solver itself, 10 Newton steps at most (its default)
+    from ssspy.linalg import lqpqm2
+
+    rng = np.random.default_rng(149)
+    for L in (1, 2, 3, 5):
+        n = 21
+        A = rng.standard_normal((n, L, 9)) + 1j * rng.standard_normal((n, L, 9))
+        H = A @ A.swapaxes(-2, -1).conj()
+        H = H / np.real(np.trace(H, axis1=-2, axis2=-1))[:, None, None]
+        v = rng.standard_normal((n, L)) + 1j * rng.standard_normal((n, L))
+        z = rng.random(n) * 2.0
+        out["lq{}_H".format(L)], out["lq{}_v".format(L)], out["lq{}_z".format(L)] = H, v, z
+        out["lq{}_y".format(L)] = lqpqm2(H, v, z)
+        out["lq{}_y_it2".format(L)] = lqpqm2(H, v, z, max_iter=2)
     save("ipa_operators", **out)
 
 
@@ -531,6 +548,8 @@ def main():
     run_ilrma("gilrma_ipa_n2_p1", N=2, F=17, T=34, K=3, algo="IPA", seed=101, domain=1)
     run_ilrma("gilrma_ipa_part_n4", N=4, F=12, T=44, K=6, algo="IPA", seed=102, gen=gen_mixture,
               partitioning=True)
+    run_ilrma("gilrma_ipa_newton8_n3", N=3, F=16, T=40, K=4, algo="IPA", seed=105, gen=gen_mixture,
+              newton_iter=8)
     run_iva("auxlap_ipa_n3", N=3, F=20, T=44, algo="IPA", contrast="laplace", seed=103, gen=gen_mixture)
     run_iva("auxgauss_ipa_n2", N=2, F=24, T=40, algo="IPA", contrast="gauss", seed=104)
     # --- scale restoration by the minimal distortion principle, projection-back normalisation ---

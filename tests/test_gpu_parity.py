@@ -27,6 +27,7 @@ ILRMA_CASES = [
     "ggdilrma_iss2_n3_p1", "gilrma_me_ip1_n3", "tilrma_me_iss1_n2", "gilrma_part_ip1_n3",
     "gilrma_part_iss1_n2_p1", "gilrma_part_me_ip2_n3", "tilrma_part_ip1_n2", "ggdilrma_part_iss1_n3",
     "tilrma_part_me_nonorm_n2", "gilrma_ipa_n3", "gilrma_ipa_n2_p1", "gilrma_ipa_part_n4",
+    "gilrma_ipa_newton8_n3",
     "gilrma_mdp_ip1_n3", "gilrma_mdp_iss1_n2", "gilrma_pbnorm_ip1_n3", "gilrma_pbnorm_iss1_n2_p1",
 ]
 IVA_CASES = [
@@ -116,6 +117,8 @@ def test_ipa_operator_against_golden(N):
                    g["n{}_out_nonorm_it3".format(N)]) < 1e-10
     out = update_by_ipa(Y, varphi[:, :1, :], flooring_fn=functools.partial(add_flooring, eps=1e-4))
     assert rel_err(out, g["n{}_out_bcast_add".format(N)]) < 1e-10
+    # twelve steps allowed: the loop stops as soon as every bin of the call has converged
+    assert rel_err(update_by_ipa(Y, varphi, max_iter=12), g["n{}_out_it12".format(N)]) < 1e-10
 
 
 def test_ipa_eight_sources_against_oracle():
@@ -164,6 +167,7 @@ def test_gauss_ilrma_against_golden(case):
         normalization=_option(g["meta_normalization"]),
         scale_restoration=_option(g["meta_scale_restoration"]),
         source_algorithm=str(g["meta_source_algorithm"]) if "meta_source_algorithm" in g else "MM",
+        **({"newton_iter": int(g["meta_newton_iter"])} if str(g["meta_algo"]) == "IPA" else {}),
     )
     b0, a0 = g["basis0"].copy(), g["activation0"].copy()
     extra = {"latent": g["latent0"].copy()} if partitioning else {}
@@ -1255,8 +1259,29 @@ def test_lqpqm2_against_oracle(L):
     z = rng.random(n) * 2.0
     for max_iter in (1, 10):
         y = lqpqm2(H, v, z, max_iter=max_iter)
-        yr = np.stack([oracle_lqpqm2(H[i], v[i], z[i], ("max", 1e-10), max_iter) for i in range(n)])
+        yr = oracle_lqpqm2(H, v, z, ("max", 1e-10), max_iter)
         assert rel_err(y, yr) < 1e-10
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 5])
+def test_lqpqm2_against_golden(L):
+    """ssspy.linalg.lqpqm2 of the reference: the loop stops when every problem has converged (no
+    warning at its default of ten steps) and warns when two steps are not enough."""
+    import warnings
+
+    from ssspy_amd.linalg import lqpqm2
+
+    g = load_golden("ipa_operators")
+    H, v, z = (g["lq{}_{}".format(L, k)] for k in "Hvz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert rel_err(lqpqm2(H, v, z), g["lq{}_y".format(L)]) < 1e-10
+    if L > 1:
+        with pytest.warns(UserWarning, match="did not converge in 2 iterations"):
+            y2 = lqpqm2(H, v, z, max_iter=2)
+    else:
+        y2 = lqpqm2(H, v, z, max_iter=2)
+    assert rel_err(y2, g["lq{}_y_it2".format(L)]) < 1e-10
 
 
 # ------------------------------------------------------------------------------- boundary (round 2)

@@ -28,6 +28,7 @@ ILRMA_CASES = [
     "gilrma_me_ip1_n3", "tilrma_me_iss1_n2", "gilrma_part_ip1_n3", "gilrma_part_iss1_n2_p1",
     "gilrma_part_me_ip2_n3", "tilrma_part_ip1_n2", "ggdilrma_part_iss1_n3",
     "tilrma_part_me_nonorm_n2", "gilrma_ipa_n3", "gilrma_ipa_n2_p1", "gilrma_ipa_part_n4",
+    "gilrma_ipa_newton8_n3",
     "gilrma_mdp_ip1_n3", "gilrma_mdp_iss1_n2", "gilrma_pbnorm_ip1_n3", "gilrma_pbnorm_iss1_n2_p1",
 ]
 
@@ -73,6 +74,7 @@ def test_gauss_ilrma(case):
         source_algorithm=str(g["meta_source_algorithm"]) if "meta_source_algorithm" in g else "MM",
         partitioning=bool(g["meta_partitioning"]) if "meta_partitioning" in g else False,
     )
+    m.newton_iter = int(g["meta_newton_iter"])
     init = dict(basis=g["basis0"], activation=g["activation0"])
     if m.partitioning:
         init["latent"] = g["latent0"]
@@ -245,6 +247,24 @@ def test_ipa_operator(N):
                    g["n{}_out_nonorm_it3".format(N)]) < 1e-11
     assert rel_err(update_by_ipa(Y, varphi[:, :1, :], flooring=("add", 1e-4)),
                    g["n{}_out_bcast_add".format(N)]) < 1e-11
+    # twelve steps allowed: the reference's loop stops as soon as every bin has converged
+    assert rel_err(update_by_ipa(Y, varphi, max_iter=12), g["n{}_out_it12".format(N)]) < 1e-11
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 5])
+def test_lqpqm2_operator(L):
+    """ssspy.linalg.lqpqm2 on a batch: the Newton loop stops when ALL problems have converged
+    (lqpqm.py:196-213) and warns when they have not."""
+    import warnings
+
+    from oracle.ipa import lqpqm2
+
+    g = load_golden("ipa_operators")
+    H, v, z = (g["lq{}_{}".format(L, k)] for k in "Hvz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # ten steps: converged, no warning
+        assert rel_err(lqpqm2(H, v, z, ("max", 1e-10), 10), g["lq{}_y".format(L)]) < 1e-10
+    assert rel_err(lqpqm2(H, v, z, ("max", 1e-10), 2), g["lq{}_y_it2".format(L)]) < 1e-10
 
 
 def test_inv2():
