@@ -99,6 +99,16 @@ int ssspy_cross_covariance(const void *A, const void *Bm, void *C, int B, int N,
 int ssspy_update_by_ip1(void *W, const void *U, int B, int F, int N, int floor_kind,
                         double floor_eps, int *info, void *stream);
 
+/* The same sweep one source at a time, for a flooring_fn that is an arbitrary Python callable (the
+ * reference accepts any, ssspy/bss/ilrma.py:70-89) and so cannot run in a kernel: the solve of source
+ * `source_idx` leaves the unnormalised row conj(w) in W and denom (B,F) = sqrt(max(Re(w^H U_n w), 0));
+ * the caller applies its callable to denom and divides the row by the result.
+ * replaces: ssspy/bss/_update_spatial_model.py:63-76 (one iteration of the source loop). */
+int ssspy_ip1_source_solve(void *W, const void *U, double *denom, int source_idx, int B, int F,
+                           int N, int *info, void *stream);
+int ssspy_scale_filter_row(void *W, const double *denom, int source_idx, int B, int F, int N,
+                           void *stream);
+
 /* One iterative-source-steering sweep expressed on per-bin statistics:
  * given Vc[b,i,s] = (1/T) sum_j varphi_s y y^H (B,F,N,N,N) it runs the N rank-1
  * steps of the reference on the N x N matrices and returns the accumulated

@@ -33,6 +33,8 @@ PROTOTYPES = {
     "ssspy_weighted_covariance": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "ssspy_cross_covariance": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "ssspy_update_by_ip1": (_i, [_p, _p, _i, _i, _i, _i, _d, _p, _p]),
+    "ssspy_ip1_source_solve": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "ssspy_scale_filter_row": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "ssspy_iss1_transform": (_i, [_p, _p, _i, _i, _i, _i, _d, _p]),
     "ssspy_update_by_ip2": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
     "ssspy_ipa_transform": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p]),

@@ -100,13 +100,61 @@ def cross_covariance(A, Bm, out=None):
     return out
 
 
+def _apply_host(fn, dev_tensor):
+    """fn on the host copy of a device tensor, one mixture (leading axis) at a time: the shapes the
+    callable sees are the reference's."""
+    import numpy as np
+
+    host = dv.to_host(dev_tensor)
+    out = np.stack([np.asarray(fn(h), dtype=host.dtype) for h in host])
+    if out.shape != host.shape:
+        raise ValueError("flooring_fn must return an array of the shape it was given")
+    return out
+
+
 def update_by_ip1(W, U, flooring, info=None):
     B, F, N, _ = W.shape
+    host = getattr(flooring, "host", None)
+    if host is not None:
+        # an arbitrary flooring callable: one source at a time, the denominators d (B, F) come down,
+        # are floored on the host and go back up (ssspy/bss/_update_spatial_model.py:63-76)
+        denom = dv.empty((B, F), dv.f64, W.device)
+        for n in range(N):
+            _lib.check(_L().ssspy_ip1_source_solve(ptr(W), ptr(U), ptr(denom), n, B, F, N,
+                                                   ptr(info), _st()), "ip1_source_solve")
+            denom.copy_(dv.to_device(_apply_host(host, denom), dev=W.device))
+            _lib.check(_L().ssspy_scale_filter_row(ptr(W), ptr(denom), n, B, F, N, _st()),
+                       "scale_filter_row")
+        return W
     _lib.check(
         _L().ssspy_update_by_ip1(ptr(W), ptr(U), B, F, N, flooring[0], flooring[1], ptr(info), _st()),
         "update_by_ip1",
     )
     return W
+
+
+def update_by_iss1_host_floor(Y, weight, kind, host):
+    """ISS1 with an arbitrary flooring callable: per source one covariance pass and one pass that
+    applies the steering step; the N x F denominators are floored on the host in between.
+    ref: ssspy/bss/_update_spatial_model.py:178-192."""
+    import numpy as np
+
+    B, N, F, T = Y.shape
+    Vc = None
+    eye = np.eye(N, dtype=np.complex128)
+    for n in range(N):
+        Vc = weighted_covariance(Y, weight, kind, N, out=Vc)  # (B, F, m, a, b) = mean varphi_m y y^H
+        V = dv.to_host(Vc)
+        num = V[:, :, np.arange(N), np.arange(N), n]          # (B, F, m): mean varphi_m y_m conj(y_n)
+        den = np.real(V[:, :, :, n, n])                       # (B, F, m): mean varphi_m |y_n|^2
+        # the callable sees (n_sources, n_bins) as in the reference
+        den = np.stack([np.asarray(host(d.T), dtype=np.float64).T for d in den])
+        v = num / den
+        v[:, :, n] = 1.0 - 1.0 / np.sqrt(den[:, :, n])
+        G = np.broadcast_to(eye, (B, F, N, N)).copy()
+        G[:, :, :, n] -= v                                     # y <- y - v y_n
+        separate(Y, dv.to_device(G, dev=Y.device), out=Y)
+    return Y
 
 
 def iss1_transform(Vc, flooring, out=None):

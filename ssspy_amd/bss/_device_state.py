@@ -205,6 +205,20 @@ class DeviceStateMixin:
                 ent["host"] = _snapshot(ent["host"])
         return ent["dev"]
 
+    def _host_floor_state(self, name, floor) -> None:
+        """``state = flooring_fn(state)`` on the host for a flooring callable the kernels cannot run
+        (utils.flooring.DeviceFloor.host); one mixture at a time, so the callable sees the
+        reference's shapes.  A no-op for the three built-in floors (applied inside the kernels)."""
+        host = getattr(floor, "host", None)
+        if host is None:
+            return
+        value = np.asarray(getattr(self, name))
+        if self._batched:
+            value = np.stack([np.asarray(host(v)) for v in value])
+        else:
+            value = np.asarray(host(value))
+        setattr(self, name, value)
+
     # -- singular-matrix / non-convergence reporting
     def _info_tensor(self):
         """Device counters the kernels bump: [0] singular per-bin systems (the reference raises

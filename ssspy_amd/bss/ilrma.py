@@ -22,7 +22,7 @@ import numpy as np
 from .. import _device as dv
 from .. import _lib, _ops
 from ..special.flooring import identity, max_flooring
-from ..utils.flooring import choose_flooring_fn, device_flooring
+from ..utils.flooring import choose_flooring_fn, device_flooring, host_floor, require_device_floor
 from ..utils.select_pair import resolve_pairs, sequential_pair_selector
 from ._device_state import DeviceStateMixin, Synced
 from .base import IterativeMethodBase
@@ -258,8 +258,7 @@ class _MMILRMA(ILRMABase):
                 self.pair_selector = sequential_pair_selector
         else:
             self.pair_selector = pair_selector
-        # fails early (before any upload) when the floor cannot run on the device
-        device_flooring(self.flooring_fn)
+        device_flooring(self.flooring_fn)  # (translation errors, if any, surface before any upload)
 
     def __call__(
         self, input: np.ndarray, n_iter: int = 100, initial_call: bool = True, **kwargs
@@ -345,6 +344,7 @@ class _MMILRMA(ILRMABase):
         ref: ssspy/bss/base.py:68-77, ssspy/bss/ilrma.py:1910-1967."""
         cls = type(self)
         if not (self.record_loss and not self.callbacks and n_iter > 0 and self._fused_ip1()
+                and host_floor(self._floor) is None
                 and cls.update_once is _MMILRMA.update_once
                 and cls.compute_loss is _MMILRMA.compute_loss):
             return False
@@ -396,8 +396,8 @@ class _MMILRMA(ILRMABase):
         ref: ssspy/bss/ilrma.py:900-922.  With the stock methods and the IP1 path the whole
         iteration is one C-ABI call (five kernel launches on the current stream).
         """
-        if self._fused_ip1():
-            floor = self._resolve_floor(flooring_fn)
+        floor = self._resolve_floor(flooring_fn)
+        if self._fused_ip1() and host_floor(floor) is None:
             B, N, F, T = self._X.shape
             if self._U is None:
                 self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
@@ -461,6 +461,7 @@ class _MMILRMA(ILRMABase):
         self.update_activation_mm(flooring_fn=flooring_fn)
 
     def _partition_update(self, steps, flooring_fn="self") -> None:
+        require_device_floor(self._resolve_floor(flooring_fn), "The partitioning function")
         src, W = self._source_and_filter()
         _ops.ilrma_partition_update(src, W, self._state_dev("basis"), self._state_dev("activation"),
                                     self._state_dev("latent"), self._Teff, self._Vrep,
@@ -493,10 +494,12 @@ class _MMILRMA(ILRMABase):
             self._state_touch("basis")
             return
         src, W = self._source_and_filter()
+        floor = self._resolve_floor(flooring_fn)
         _ops.ilrma_update_basis(src, W, self._state_dev("basis"), self._state_dev("activation"),
-                                float(self.domain), self._resolve_floor(flooring_fn), self._ws,
-                                self._ws_bytes, model=self._model)
+                                float(self.domain), floor, self._ws, self._ws_bytes,
+                                model=self._model)
         self._state_touch("basis")
+        self._host_floor_state("basis", floor)  # (an arbitrary callable: T = flooring_fn(T) on the host)
 
     def update_activation_mm(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/ilrma.py:1130-1204."""
@@ -505,11 +508,12 @@ class _MMILRMA(ILRMABase):
             self._state_touch("activation")
             return
         src, W = self._source_and_filter()
+        floor = self._resolve_floor(flooring_fn)
         _ops.ilrma_update_activation(src, W, self._state_dev("basis"),
-                                     self._state_dev("activation"), float(self.domain),
-                                     self._resolve_floor(flooring_fn), self._ws, self._ws_bytes,
-                                     model=self._model)
+                                     self._state_dev("activation"), float(self.domain), floor,
+                                     self._ws, self._ws_bytes, model=self._model)
         self._state_touch("activation")
+        self._host_floor_state("activation", floor)
 
     def update_spatial_model(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/ilrma.py:1403-1438."""
@@ -530,6 +534,7 @@ class _MMILRMA(ILRMABase):
         """Iterative projection with adjustment on per-bin statistics: per source, weighted
         covariance of the current output, LQPQM update matrix, Y <- G Y.
         ref: ssspy/bss/ilrma.py:1794-1908."""
+        require_device_floor(self._resolve_floor(flooring_fn), "IPA")
         Y = self._state_dev("output")
         varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y,
                                        model=self._model,
@@ -541,6 +546,7 @@ class _MMILRMA(ILRMABase):
 
     def update_spatial_model_ip2(self, flooring_fn="self") -> None:
         """Weighted covariance + pairwise iterative projection.  ref: ssspy/bss/ilrma.py:1509-1633."""
+        require_device_floor(self._resolve_floor(flooring_fn), "IP2")
         B, N, F, T = self._X.shape
         if self._U is None:
             self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
@@ -555,6 +561,7 @@ class _MMILRMA(ILRMABase):
 
     def update_spatial_model_iss2(self, flooring_fn="self") -> None:
         """Pairwise iterative source steering on per-bin statistics.  ref: ilrma.py:1698-1792."""
+        require_device_floor(self._resolve_floor(flooring_fn), "ISS2")
         Y = self._state_dev("output")
         N = Y.shape[1]
         varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y, model=self._model,
@@ -567,6 +574,8 @@ class _MMILRMA(ILRMABase):
 
     def update_spatial_model_ip1(self, flooring_fn="self") -> None:
         """Weighted covariance + iterative projection.  ref: ssspy/bss/ilrma.py:1440-1507."""
+        if self._base_model[0] == _lib.SOURCE_GGD:  # (its weights floor |y|^(2 - beta) per element)
+            require_device_floor(self._resolve_floor(flooring_fn), "GGD-ILRMA")
         B, N, F, T = self._X.shape
         if self._U is None:
             self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
@@ -586,7 +595,12 @@ class _MMILRMA(ILRMABase):
                                        flooring=self._resolve_floor(flooring_fn))
         floor = self._resolve_floor(flooring_fn)
         frame_power = None
-        if Y.shape[-1] <= _ops.iss1_fused_max_frames(N):
+        if host_floor(floor) is not None:
+            if self._base_model[0] == _lib.SOURCE_GGD:
+                require_device_floor(floor, "GGD-ILRMA")
+            tracked = None
+            _ops.update_by_iss1_host_floor(Y, varphi, _lib.WEIGHT_BIN_FRAME, floor.host)
+        elif Y.shape[-1] <= _ops.iss1_fused_max_frames(N):
             # the sweep also leaves sum_i |y_nij|^2 of the new Y: the power normalisation that
             # follows in update_once() reads it instead of making its own pass over Y
             frame_power = dv.empty((Y.shape[0], N, Y.shape[-1]), dv.f64, Y.device)
@@ -641,6 +655,8 @@ class _MMILRMA(ILRMABase):
     def normalize_by_power(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/ilrma.py:365-444 (no partitioning)."""
         floor = self._resolve_floor(flooring_fn)
+        if host_floor(floor) is not None:
+            return self._normalize_by_power_host_floor(floor)
         if self.partitioning:
             filt = self._uses_filter()
             _ops.ilrma_partition_normalize(
@@ -668,6 +684,31 @@ class _MMILRMA(ILRMABase):
             self._state_touch("output")
             self._restamp_logdet(tracked)
         self._state_touch("basis")
+
+    def _normalize_by_power_host_floor(self, floor) -> None:
+        """psi = flooring_fn(sqrt(mean |y|^2)) with an arbitrary callable: the frame powers come from
+        one device pass, the N scales are floored on the host, W (or Y) and the basis are rescaled.
+        ref: ssspy/bss/ilrma.py:412-444."""
+        require_device_floor(floor, "The partitioning function") if self.partitioning else None
+        B, N, F, T = self._X.shape
+        p = float(self.domain)
+        filt = self._uses_filter()
+        src = self._X if filt else self._state_dev("output")
+        r2 = dv.to_host(_ops.iva_frame_power(src, self._state_dev("demix_filter") if filt else None))
+        psi = np.stack([np.asarray(floor.host(np.sqrt(r.sum(axis=-1) / (F * T))), dtype=np.float64)
+                        for r in r2])  # (B, N)
+        lead = (slice(None),) if self._batched else (0,)
+        psi_v = psi[lead]
+        self.basis = np.asarray(self.basis) / (psi_v[..., :, None, None] ** p)
+        if filt:
+            self.demix_filter = np.asarray(self.demix_filter) / psi_v[..., None, :, None]
+        else:
+            G = np.zeros((B, F, N, N), dtype=np.complex128)
+            G[:, :, np.arange(N), np.arange(N)] = 1.0 / psi[:, None, :]
+            Y = self._state_dev("output")
+            _ops.separate(Y, dv.to_device(G, dev=Y.device), out=Y)
+            self._state_touch("output")
+            self._restamp_logdet(None)
 
     def compute_loss(self) -> float:
         """Negative log-likelihood (ref: ssspy/bss/ilrma.py:1910-1967)."""

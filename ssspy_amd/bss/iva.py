@@ -21,7 +21,7 @@ import numpy as np
 from .. import _device as dv
 from .. import _lib, _ops
 from ..special.flooring import identity, max_flooring
-from ..utils.flooring import choose_flooring_fn, device_flooring
+from ..utils.flooring import choose_flooring_fn, device_flooring, host_floor, require_device_floor
 from ..utils.select_pair import resolve_pairs, sequential_pair_selector
 from ._device_state import DeviceStateMixin, Synced
 from .base import IterativeMethodBase
@@ -282,6 +282,7 @@ class AuxIVA(AuxIVABase):
         cls = type(self)
         if not (self.record_loss and not self.callbacks and n_iter > 0
                 and self.spatial_algorithm in _IP1 and self._contrast is not None
+                and host_floor(self._floor) is None
                 and self._variance_tensor() is None
                 and cls.update_once is AuxIVA.update_once
                 and cls.update_once_ip1 is AuxIVA.update_once_ip1
@@ -344,7 +345,12 @@ class AuxIVA(AuxIVABase):
         return self._weights_from_power(self._frame_power(), self._contrast, flooring_fn)
 
     def _weights_from_power(self, r2, contrast, flooring_fn):
-        if contrast is None:
+        floor = self._resolve_floor(flooring_fn)
+        if contrast is None or host_floor(floor) is not None:
+            # a user closure, or a flooring callable the kernels cannot run: on the host, on the
+            # (n_sources, n_frames) norms
+            if self._variance_tensor() is not None:
+                require_device_floor(floor, "AuxGaussIVA")
             return self._host_weights(r2, flooring_fn)
         return _ops.iva_weight(r2, self.n_bins, contrast, self._resolve_floor(flooring_fn),
                                variance=self._variance_tensor())
@@ -390,6 +396,7 @@ class AuxIVA(AuxIVABase):
 
     def update_once_ipa(self, flooring_fn="self") -> None:
         """Iterative projection with adjustment.  ref: ssspy/bss/iva.py:2068-2175."""
+        require_device_floor(self._resolve_floor(flooring_fn), "IPA")
         Y = self._state_dev("output")
         weight = self._weights(flooring_fn)
         _ops.update_by_ipa(Y, weight, _lib.WEIGHT_FRAME, self.lqpqm_normalization,
@@ -406,6 +413,7 @@ class AuxIVA(AuxIVABase):
         the current filters.  ref: ssspy/bss/iva.py:1795-1915."""
         N = self.n_sources
         floor = self._resolve_floor(flooring_fn)
+        require_device_floor(floor, "IP2")
         W = self._state_dev("demix_filter")
         for m, n in resolve_pairs(getattr(self, "pair_selector", None), N):
             r2 = _ops.iva_frame_power(self._X, W)
@@ -419,8 +427,9 @@ class AuxIVA(AuxIVABase):
         """Pairwise iterative source steering.  ref: ssspy/bss/iva.py:1968-2066."""
         N = self.n_sources
         Y = self._state_dev("output")
-        weight = self._weights(flooring_fn)
         floor = self._resolve_floor(flooring_fn)
+        require_device_floor(floor, "ISS2")
+        weight = self._weights(flooring_fn)
         Vc = _ops.weighted_covariance(Y, weight, _lib.WEIGHT_FRAME, N)
         G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N), floor,
                                 self._info_tensor())
@@ -442,7 +451,11 @@ class AuxIVA(AuxIVABase):
         Y = self._state_dev("output")
         weight = self._weights(flooring_fn)
         floor = self._resolve_floor(flooring_fn)
-        if self.n_frames <= _ops.iss1_fused_max_frames(N):
+        if host_floor(floor) is not None:
+            _ops.update_by_iss1_host_floor(Y, weight, _lib.WEIGHT_FRAME, floor.host)
+            self._state_touch("output")
+            self._logdet_cache = None
+        elif self.n_frames <= _ops.iss1_fused_max_frames(N):
             # one read + one write of Y; the kernel also leaves the next iteration's frame powers
             r2_next = dv.empty(tuple(weight.shape), dv.f64, Y.device)
             tracked = self._tracked_logdet()

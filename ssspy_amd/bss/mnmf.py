@@ -23,7 +23,7 @@ import numpy as np
 from .. import _device as dv
 from .. import _lib, _ops
 from ..special.flooring import identity, max_flooring
-from ..utils.flooring import choose_flooring_fn, device_flooring
+from ..utils.flooring import choose_flooring_fn, device_flooring, require_device_floor
 from ..utils.select_pair import resolve_pairs, sequential_pair_selector
 from ._device_state import DeviceStateMixin, Synced
 from .base import IterativeMethodBase
@@ -160,6 +160,8 @@ class FastMNMFBase(MNMFBase):
         self.n_sources, self.n_channels = N, M
         self.n_bins, self.n_frames = F, T
         self._floor = device_flooring(flooring_fn)
+        # (every MNMF step floors inside one fused call: the three built-in floors only)
+        require_device_floor(self._floor, "FastMNMF")
         self._init_nmf(flooring_fn=flooring_fn, rng=self.rng)
         self._init_diagonalizer(rng=self.rng)
         self._init_spatial(flooring_fn=flooring_fn, rng=self.rng)
@@ -443,6 +445,7 @@ class MNMF(MNMFBase):
         self.n_sources, self.n_channels = N, M
         self.n_bins, self.n_frames = F, T
         self._floor = device_flooring(self.flooring_fn)
+        require_device_floor(self._floor, "GaussMNMF")
         self._init_nmf(rng=self.rng)
         self._ws, self._ws_bytes = _ops.gmnmf_workspace(B, N, M, F, T, self.n_basis, self._X.device)
         if not getattr(self, "_skip_reset_output", False):

@@ -228,6 +228,41 @@ __global__ __launch_bounds__(64) void k_ip1(c128 *W, const c128 *__restrict__ U,
   }
 }
 
+// ---- IP1 one source at a time, for flooring functions that cannot run in a kernel: the solve of
+// source n writes the UNNORMALISED row conj(w) and d = sqrt(max(Re(w^H U_n w), 0)) per bin, the host
+// applies its callable to d (B x F doubles), k_scale_filter_row divides the row.
+// ref: ssspy/bss/_update_spatial_model.py:63-76.
+template <int N>
+__global__ __launch_bounds__(64) void k_ip1_source_solve(c128 *W, const c128 *__restrict__ U,
+                                                         double *__restrict__ denom,
+                                                         long long nbins, int n, int *info) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nbins) return;
+  Mat<N> Wm, Un, A;
+  load_mat<N>(Wm, W + idx * (N * N));
+  load_mat<N>(Un, U + (idx * N + n) * (N * N));
+  matmul<N>(A, Wm, Un);
+  c128 w[N];
+  const bool ok = solve_unit<N>(A, n, w);
+  double qf = quad_form<N>(w, Un);
+  qf = qf < 0.0 ? 0.0 : qf;  // np.maximum(., 0): NaN propagates
+  denom[idx] = sqrt(qf);
+#pragma unroll
+  for (int c = 0; c < N; ++c) W[idx * (N * N) + n * N + c] = cconj(w[c]);
+  if (!ok && info) atomicAdd(info, 1);
+}
+
+__global__ __launch_bounds__(256) void k_scale_filter_row(c128 *W, const double *__restrict__ denom,
+                                                          long long nbins, int N, int n) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (bin, column)
+  if (e >= nbins * N) return;
+  const long long idx = e / N;
+  const int c = (int)(e - idx * N);
+  const double d = denom[idx];
+  c128 *p = W + idx * (N * N) + n * N + c;
+  *p = cmake(p->x / d, p->y / d);
+}
+
 // The same update with a bin spread over G lanes (G = 8 for 5..8 sources): lane r owns row r of the
 // filter and of the product A = W U_n.  The LU solve of A w = e_n is row-distributed -- the pivot
 // (largest |re| + |im| among the rows not yet used, the lowest row on ties: LAPACK's choice) is found
@@ -661,6 +696,28 @@ int ssspy_update_by_ip1(void *W, const void *U, int B, int F, int N, int floor_k
                                    (const c128 *)U, nbins, floor_kind, floor_eps, info,
                                    (const c128 *)nullptr, (double *)nullptr));
   return check_launch("k_ip1");
+}
+
+int ssspy_ip1_source_solve(void *W, const void *U, double *denom, int source_idx, int B, int F,
+                           int N, int *info, void *stream) {
+  SSSPY_REQUIRE(W && U && denom && B > 0 && F > 0, "ip1_source_solve: bad argument");
+  SSSPY_REQUIRE(source_idx >= 0 && source_idx < N, "ip1_source_solve: bad source index");
+  const long long nbins = (long long)B * F;
+  dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
+  DISPATCH_N(N, hipLaunchKernelGGL((k_ip1_source_solve<NN>), grid, block, 0, as_stream(stream),
+                                   (c128 *)W, (const c128 *)U, denom, nbins, source_idx, info));
+  return check_launch("k_ip1_source_solve");
+}
+
+int ssspy_scale_filter_row(void *W, const double *denom, int source_idx, int B, int F, int N,
+                           void *stream) {
+  SSSPY_REQUIRE(W && denom && B > 0 && F > 0 && N >= 1 && N <= SSSPY_MAX_SOURCES,
+                "scale_filter_row: bad argument");
+  SSSPY_REQUIRE(source_idx >= 0 && source_idx < N, "scale_filter_row: bad source index");
+  const long long nbins = (long long)B * F;
+  hipLaunchKernelGGL(k_scale_filter_row, dim3((unsigned)((nbins * N + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), (c128 *)W, denom, nbins, N, source_idx);
+  return check_launch("k_scale_filter_row");
 }
 
 int ssspy_iss1_transform(const void *Vc, void *G, int B, int F, int N, int floor_kind,

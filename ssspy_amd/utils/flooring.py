@@ -24,6 +24,20 @@ def choose_flooring_fn(flooring_fn="self", method=None):
     return flooring_fn
 
 
+class DeviceFloor(tuple):
+    """``(kind, eps)`` as the kernels take it, plus ``host``: the flooring callable itself when it
+    is none of the reference's three and therefore cannot run inside a kernel.  The kernels are
+    then launched without a floor (``FLOOR_NONE``) and the callable is applied on the host to the
+    small arrays the reference applies it to -- basis, activation, per-bin denominators, the
+    normalisation scales -- between the device passes (ssspy/bss/ilrma.py:1126, :1202, :420;
+    _update_spatial_model.py:74, :188; iva.py:1788)."""
+
+    def __new__(cls, kind, eps, host=None):
+        obj = tuple.__new__(cls, (kind, eps))
+        obj.host = host
+        return obj
+
+
 def _default_eps(fn):
     try:
         param = inspect.signature(fn).parameters.get("eps")
@@ -40,10 +54,11 @@ def device_flooring(flooring_fn):
     Recognised: ``None`` / ``identity`` -> NONE, ``max_flooring`` -> MAX, ``add_flooring`` ->
     ADD, each possibly wrapped in ``functools.partial(..., eps=...)``; functions are matched
     by name so the reference's own ``ssspy.special.flooring`` functions work too.  Any other
-    callable cannot run inside a kernel: NotImplementedError (there is no CPU fallback).
+    callable comes back as ``DeviceFloor(NONE, 0, host=callable)``: it is evaluated on the host on
+    the small arrays it acts on (see DeviceFloor); the passes over the spectrograms stay on the device.
     """
     if flooring_fn is None:
-        return (_lib.FLOOR_NONE, 0.0)
+        return DeviceFloor(_lib.FLOOR_NONE, 0.0)
     fn, eps = flooring_fn, None
     while isinstance(fn, functools.partial):
         if fn.args:
@@ -57,13 +72,23 @@ def device_flooring(flooring_fn):
     name = getattr(fn, "__name__", None)
     if not isinstance(fn, functools.partial):
         if name == "identity":
-            return (_lib.FLOOR_NONE, 0.0)
+            return DeviceFloor(_lib.FLOOR_NONE, 0.0)
         if name == "max_flooring":
-            return (_lib.FLOOR_MAX, _default_eps(fn) if eps is None else eps)
+            return DeviceFloor(_lib.FLOOR_MAX, _default_eps(fn) if eps is None else eps)
         if name == "add_flooring":
-            return (_lib.FLOOR_ADD, _default_eps(fn) if eps is None else eps)
-    raise NotImplementedError(
-        "flooring_fn={!r} is not one of identity / max_flooring / add_flooring "
-        "(optionally functools.partial(..., eps=...)); arbitrary Python callables cannot be "
-        "evaluated inside the HIP kernels".format(flooring_fn)
-    )
+            return DeviceFloor(_lib.FLOOR_ADD, _default_eps(fn) if eps is None else eps)
+    return DeviceFloor(_lib.FLOOR_NONE, 0.0, host=flooring_fn)
+
+
+def host_floor(floor):
+    """The host callable of a resolved floor, or None when the kernels apply it themselves."""
+    return getattr(floor, "host", None)
+
+
+def require_device_floor(floor, what):
+    """For the steps whose floors sit in the middle of a per-element computation on the
+    spectrograms (no small array to take to the host)."""
+    if host_floor(floor) is not None:
+        raise NotImplementedError(
+            "{} is built for identity / max_flooring / add_flooring only (the floor acts inside a "
+            "pass over the spectrograms); got flooring_fn={!r}".format(what, floor.host))

@@ -20,8 +20,11 @@ def test_device_flooring_mapping():
     assert device_flooring(max_flooring) == (_lib.FLOOR_MAX, 1e-10)
     assert device_flooring(functools.partial(max_flooring, eps=1e-5)) == (_lib.FLOOR_MAX, 1e-5)
     assert device_flooring(functools.partial(add_flooring, eps=1e-3)) == (_lib.FLOOR_ADD, 1e-3)
-    with pytest.raises(NotImplementedError):
-        device_flooring(lambda x: x + 1)
+    # any other callable is kept for the host (evaluated on the small arrays it floors)
+    fn = lambda x: x + 1  # noqa: E731
+    floor = device_flooring(fn)
+    assert floor == (_lib.FLOOR_NONE, 0.0) and floor.host is fn
+    assert device_flooring(max_flooring).host is None
 
 
 def test_choose_flooring_fn():
@@ -61,8 +64,7 @@ def test_constructor_argument_checks():
     with pytest.raises(AssertionError):
         GaussILRMA(n_basis=2, spatial_algorithm="IPA", bogus=1)
     assert AuxLaplaceIVA(spatial_algorithm="IPA").newton_iter == 1
-    with pytest.raises(NotImplementedError):
-        GaussILRMA(n_basis=2, flooring_fn=lambda x: x)
+    GaussILRMA(n_basis=2, flooring_fn=lambda x: x)  # any callable is accepted, as in the reference
     with pytest.raises(ValueError):
         GaussILRMA(n_basis=2, reference_id=None)
     with pytest.raises(AssertionError):
