@@ -16,10 +16,13 @@ namespace fast {
 //   FM_GGD    domain 2: a = (beta / 2) (P / R)^(beta/2) / R,
 //                       varphi = 1 / ((2 / beta) floor(P^((2 - beta)/2)) R^(beta/2))  (:3810-3821, :3987-4011)
 //   FM_GAUSS1 domain 1: a = P / R^3,           varphi = 1 / R^2
+//   FM_GAUSSP domain p: a = P / R^((p+2)/p),   varphi = 1 / R^(2/p)   (any 0 < p <= 2; powers as
+//                       exp2(e log2 R): ~1e-14 relative, a third of the instructions of pow)
 // `expo`: exponent of the (num / den) ratio: p / (p + 2), 1 for the ME updates, p / (beta + p) for GGD.
-constexpr int FM_GAUSS = 0, FM_T = 1, FM_GGD = 2, FM_GAUSS1 = 3;
+constexpr int FM_GAUSS = 0, FM_T = 1, FM_GGD = 2, FM_GAUSS1 = 3, FM_GAUSSP = 4;
 struct FastModel {
   double w, w1, nu, beta, expo;
+  double pinv2, e_num;  // FM_GAUSSP: 2 / p and -(p + 2) / p
   int floor_kind;
   double floor_eps;
 };
@@ -87,6 +90,11 @@ __device__ __forceinline__ double mm_num_factor<FM_GAUSS1>(double pw, double, do
                                                            const FastModel &) {
   return pw * rinv * rinv * rinv;
 }
+template <>
+__device__ __forceinline__ double mm_num_factor<FM_GAUSSP>(double pw, double R, double,
+                                                           const FastModel &fm) {
+  return pw * pow_nonneg(R, fm.e_num);
+}
 
 // fmodel: FM_*; mparam: dof (t) / beta (GGD); me: exponent 1 instead of p / (p + 2)
 static inline FastModel make_fast_model(int fmodel, double mparam, int me, int floor_kind = 0,
@@ -97,7 +105,10 @@ static inline FastModel make_fast_model(int fmodel, double mparam, int me, int f
   fm.w = t ? mparam / (mparam + 2.0) : 1.0;
   fm.w1 = 1.0 - fm.w;
   fm.beta = fmodel == FM_GGD ? mparam : 2.0;
-  const double p = fmodel == FM_GAUSS1 ? 1.0 : 2.0;
+  // (FM_GAUSSP: the domain travels in mparam)
+  const double p = fmodel == FM_GAUSS1 ? 1.0 : (fmodel == FM_GAUSSP ? mparam : 2.0);
+  fm.pinv2 = 2.0 / p;
+  fm.e_num = -(p + 2.0) / p;
   fm.expo = me ? 1.0 : (fmodel == FM_GGD ? p / (fm.beta + p) : p / (p + 2.0));
   fm.floor_kind = floor_kind;
   fm.floor_eps = floor_eps;

@@ -58,7 +58,8 @@ DECL_SMALL(2) DECL_SMALL(3) DECL_SMALL(4)
   }
 
 // the tuned kernels: n_sources <= 4, n_basis <= 16 and one of the models ilrma_fast.hip carries
-// (its FM_* ids): Gauss at domain 2 (MM or ME) or 1, Student-t and GGD at domain 2;
+// (its FM_* ids): Gauss at domain 2 (MM or ME), 1 or any other value in (0, 2), Student-t and GGD
+// at domain 2;
 // `source_model` may carry the SSSPY_SOURCE_ME flag.  -1: generic kernels.
 static inline int fast_model_id(double domain, int source_model) {
   const int base = source_model & 0xff;
@@ -69,7 +70,13 @@ static inline int fast_model_id(double domain, int source_model) {
     if (base == SSSPY_SOURCE_GGD) return 2;
   }
   if (domain == 1.0 && base == SSSPY_SOURCE_GAUSS && !me) return 3;
+  // Gauss at any other domain in (0, 2): the powers R^((p+2)/p), R^(2/p) as exp2(e log2 R)
+  if (base == SSSPY_SOURCE_GAUSS && !me && domain > 0.0 && domain < 2.0) return 4;
   return -1;
+}
+// what the tuned kernels take as their model parameter: dof (t), beta (GGD), the domain (id 4)
+static inline double fast_model_param(double domain, int source_model, double model_param) {
+  return fast_model_id(domain, source_model) == 4 ? domain : model_param;
 }
 // (one channel of a mixture must fit the 32-bit offset of a buffer descriptor: F T 16 bytes < 4 GiB)
 static inline bool fast_path(int N, int F, int T, int K, double domain,
@@ -656,7 +663,7 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
                               basis + sr.first * F * K, out + sr.first * F * K,
                               activation + sr.first * K * T, sr.count, F, T, K, floor_kind,
                               floor_eps, (double *)(ws + w.bpart),
-                              fast_model_id(domain, source_model), model_param,
+                              fast_model_id(domain, source_model), fast_model_param(domain, source_model, model_param),
                               is_me(source_model), nullptr, power ? 1 : 0, st);
         };
         const int r = one();
@@ -668,7 +675,7 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
       if (loss_done) *loss_done = loss_out != nullptr && K <= 16;
       ILRMA_FAST_DISPATCH(N, ilrma_fast_basis, X, W, basis, out, activation, B, F, T, K, floor_kind,
                           floor_eps, (double *)(ws + w.bpart), fast_model_id(domain, source_model),
-                          model_param, is_me(source_model), K <= 16 ? loss_out : nullptr, 0, st);
+                          fast_model_param(domain, source_model, model_param), is_me(source_model), K <= 16 ? loss_out : nullptr, 0, st);
     }
     const IlrmaDims d =
         make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
@@ -715,7 +722,7 @@ static int update_activation_impl(const void *X, const void *W, const double *ba
   if (!nruns && small_path(B, N, F, T, K, domain, source_model)) {
     // a handful of mixtures: the latency kernel and its own fold (in place)
     ILRMA_FAST_DISPATCH(N, ilrma_small_activation, X, W, basis, activation, B, F, T, K, floor_kind,
-                        floor_eps, part, fast_model_id(domain, source_model), model_param,
+                        floor_eps, part, fast_model_id(domain, source_model), fast_model_param(domain, source_model, model_param),
                         is_me(source_model), st);
   }
   // (the partial sums of a run keep the (group, chunk, source) layout at the run's offset: every
@@ -738,7 +745,7 @@ static int update_activation_impl(const void *X, const void *W, const double *ba
           ILRMA_FAST_DISPATCH(sr.G, ilrma_fast_activation, Y + (size_t)sr.first * F * T * elem,
                               nullptr, basis + sr.first * F * K, activation + sr.first * K * T,
                               part + sr.first * part_per_source, chunks, sr.count, F, T, K,
-                              fast_model_id(domain, source_model), model_param, power ? 1 : 0, st);
+                              fast_model_id(domain, source_model), fast_model_param(domain, source_model, model_param), power ? 1 : 0, st);
         };
         const int r = one();
         if (r) return r;
@@ -747,7 +754,7 @@ static int update_activation_impl(const void *X, const void *W, const double *ba
     }
     if (fast_path(N, F, T, K, domain, source_model)) {
       ILRMA_FAST_DISPATCH(N, ilrma_fast_activation, X, W, basis, activation, part, chunks, B, F, T,
-                          K, fast_model_id(domain, source_model), model_param, 0, st);
+                          K, fast_model_id(domain, source_model), fast_model_param(domain, source_model, model_param), 0, st);
     }
     ILRMA_DISPATCH(N, ilrma_activation, X, W, basis, activation, part, chunks, d, st);
   };
@@ -801,7 +808,7 @@ static int wcov_into(const void *X, const void *W, const double *basis, const do
   }
   if (fast_path(N, d.F, d.T, d.K, d.p, d.model) && (d.model == SSSPY_SOURCE_GAUSS || W)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, W, basis, activation, U, d.B, d.F, d.T, d.K, upart,
-                        fast_model_id(d.p, d.model), d.mparam, d.floor_kind, d.floor_eps, st,
+                        fast_model_id(d.p, d.model), fast_model_param(d.p, d.model, d.mparam), d.floor_kind, d.floor_eps, st,
                         nullptr, nullptr);
   }
   ILRMA_DISPATCH(N, ilrma_wcov, X, W, basis, activation, U, d, st);
@@ -915,7 +922,7 @@ int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
   if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
   if (K <= 16 && fast_path(N, F, T, K, domain, source_model)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_loss, X, W, basis, activation, out, B, F, T, K,
-                        fast_model_id(domain, source_model), model_param, st);
+                        fast_model_id(domain, source_model), fast_model_param(domain, source_model, model_param), st);
   }
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, SSSPY_FLOOR_NONE, 0.0);
   ILRMA_DISPATCH(N, ilrma_loss, X, W, basis, activation, out, d, st);
@@ -981,7 +988,7 @@ static int ip1_update_impl(const void *X, const void *C, void *W, double *basis,
     int split = 0, rbins = 0;
     auto cov = [&]() -> int {
       ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, W, basis, activation, U, B, F, T, K, ws + w.upart,
-                          fast_model_id(domain, source_model), model_param, floor_kind, floor_eps,
+                          fast_model_id(domain, source_model), fast_model_param(domain, source_model, model_param), floor_kind, floor_eps,
                           st, &split, &rbins);
     };
     rc = cov();

@@ -49,6 +49,7 @@ using fast::rcp_nr;
 using fast::FastModel;
 using fast::FM_GAUSS;
 using fast::FM_GAUSS1;
+using fast::FM_GAUSSP;
 using fast::FM_GGD;
 using fast::FM_T;
 using fast::LogSum;
@@ -251,7 +252,8 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 
     }
   if (LOSS) {
     if (MODEL == FM_GGD) lacc *= 2.0 / fm.beta;
-    if (kt == 0) lacc += (MODEL == FM_GAUSS1 ? 2.0 : 1.0) * lr.value();  // (2 / p) log R, once
+    if (kt == 0)  // (2 / p) log R, once
+      lacc += (MODEL == FM_GAUSS1 ? 2.0 : (MODEL == FM_GAUSSP ? fm.pinv2 : 1.0)) * lr.value();
     lacc = wave_sum(lacc);
     if (lane == 0) atomicAdd(loss_out + b, lacc / (double)T);
   }
@@ -376,6 +378,8 @@ __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X
           acc += pow_nonneg(pr, 0.5 * fm.beta);  // (P / R)^(beta/2), ilrma.py:4377-4381
         else if (MODEL == FM_GAUSS1)
           acc += pr * ri;                        // P / R^2
+        else if (MODEL == FM_GAUSSP)
+          acc += (valid ? cabs2(y) : 0.0) * pow_nonneg(rr, -fm.pinv2);  // P / R^(2/p)
         else
           acc += pr;
         lr.mul(rr);
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X
     fast::vstage_store<N>(st, vs[(jt - jt_begin + 1) & 1]);
     __syncthreads();
   }
-  acc += (MODEL == FM_GAUSS1 ? 2.0 : 1.0) * lr.value();  // (2 / p) log R
+  acc += (MODEL == FM_GAUSS1 ? 2.0 : (MODEL == FM_GAUSSP ? fm.pinv2 : 1.0)) * lr.value();  // (2 / p) log R
   if (MODEL == FM_T) acc = fma(1.0 + 0.5 * fm.nu, lt.value(), acc);
   acc = wave_sum(acc);
   if (lane == 0) atomicAdd(out + b, acc / (double)T);
@@ -502,7 +506,8 @@ __global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X
           }
         }
         if (MODEL == FM_GAUSS1) den = den * den;  // R^(2/p), p = 1
-        phi[s] = (valid && s0 + s < N) ? rcp_nr(den) : 0.0;
+        const double ph = MODEL == FM_GAUSSP ? pow_nonneg(den, -fm.pinv2) : rcp_nr(den);
+        phi[s] = (valid && s0 + s < N) ? ph : 0.0;
       }
       acc.add(x, phi);
     }
@@ -805,6 +810,9 @@ using fast::make_fast_model;
     case FM_GAUSS1:                                                                       \
       hipLaunchKernelGGL((kernel<HW, FM_GAUSS1>), grid, block, 0, st, __VA_ARGS__);       \
       break;                                                                              \
+    case FM_GAUSSP:                                                                       \
+      hipLaunchKernelGGL((kernel<HW, FM_GAUSSP>), grid, block, 0, st, __VA_ARGS__);       \
+      break;                                                                              \
     default: hipLaunchKernelGGL((kernel<HW, FM_GAUSS>), grid, block, 0, st, __VA_ARGS__); break;   \
   }
 #define SSSPY_FAST_LAUNCH2(kernel, A, ...)                  \
@@ -842,6 +850,7 @@ int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis
     case FM_T: SSSPY_BASIS_LAUNCH(HW, FM_T, false, KS_); break; /* no by-product for the t model */ \
     case FM_GGD: SSSPY_BASIS_LAUNCH(HW, FM_GGD, L, KS_); break;           \
     case FM_GAUSS1: SSSPY_BASIS_LAUNCH(HW, FM_GAUSS1, L, KS_); break;     \
+    case FM_GAUSSP: SSSPY_BASIS_LAUNCH(HW, FM_GAUSSP, L, KS_); break;     \
     default: SSSPY_BASIS_LAUNCH(HW, FM_GAUSS, L, KS_); break;             \
   }
   if (power_in) {
@@ -900,6 +909,7 @@ int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *
     case FM_T: SSSPY_ACT_LAUNCH(HW, FM_T, KS_); break;     \
     case FM_GGD: SSSPY_ACT_LAUNCH(HW, FM_GGD, KS_); break; \
     case FM_GAUSS1: SSSPY_ACT_LAUNCH(HW, FM_GAUSS1, KS_); break; \
+    case FM_GAUSSP: SSSPY_ACT_LAUNCH(HW, FM_GAUSSP, KS_); break; \
     default: SSSPY_ACT_LAUNCH(HW, FM_GAUSS, KS_); break;   \
   }
   if (power_in) {
@@ -958,6 +968,7 @@ int LAUNCHER(ilrma_fast_wcov)(const void *X, const void *W, const double *basis,
     case FM_T: SSSPY_WCOV_LAUNCH(FM_T, KS_); break;    \
     case FM_GGD: SSSPY_WCOV_LAUNCH(FM_GGD, KS_); break; \
     case FM_GAUSS1: SSSPY_WCOV_LAUNCH(FM_GAUSS1, KS_); break; \
+    case FM_GAUSSP: SSSPY_WCOV_LAUNCH(FM_GAUSSP, KS_); break; \
     default: SSSPY_WCOV_LAUNCH(FM_GAUSS, KS_); break;  \
   }
   if (K > 16) {

@@ -50,6 +50,7 @@ constexpr int N = SSSPY_N;
 using fast::FastModel;
 using fast::FM_GAUSS;
 using fast::FM_GAUSS1;
+using fast::FM_GAUSSP;
 using fast::FM_GGD;
 using fast::FM_T;
 using fast::mm_num_factor;
@@ -633,6 +634,9 @@ size_t LAUNCHER(ilrma_small_scratch)(int B, int F, int T, int K) {
     case FM_GGD: hipLaunchKernelGGL((kernel<HW, FM_GGD>), grid, block, 0, st, __VA_ARGS__); break; \
     case FM_GAUSS1:                                                                               \
       hipLaunchKernelGGL((kernel<HW, FM_GAUSS1>), grid, block, 0, st, __VA_ARGS__);               \
+      break;                                                                                      \
+    case FM_GAUSSP:                                                                               \
+      hipLaunchKernelGGL((kernel<HW, FM_GAUSSP>), grid, block, 0, st, __VA_ARGS__);               \
       break;                                                                                      \
     default: hipLaunchKernelGGL((kernel<HW, FM_GAUSS>), grid, block, 0, st, __VA_ARGS__); break;   \
   }

@@ -258,11 +258,13 @@ def test_heavy_tailed_ilrma_sweep_against_oracle(model, N, K, algo, domain):
 
 @pytest.mark.parametrize("algo", ["IP", "ISS", "IP2"])
 @pytest.mark.parametrize("N,K,F,T,domain", [(4, 16, 70, 130, 1), (3, 5, 33, 47, 1), (2, 16, 20, 64, 1),
-                                            (4, 7, 33, 48, 1.5), (4, 16, 70, 130, 2)])
+                                            (4, 7, 33, 48, 1.5), (4, 16, 70, 130, 2),
+                                            (3, 16, 70, 130, 0.6), (4, 12, 40, 100, 1.7)])
 def test_gauss_ilrma_domain_sweep_against_oracle(algo, N, K, F, T, domain):
-    """Amplitude-domain (domain = 1) Gauss-ILRMA runs on the tuned kernels (R^3 / R^2 instead of
-    powers, cube-root update), other domains on the generic ones; several frame tiles, ragged
-    edges, split and unsplit work items."""
+    """Gauss-ILRMA off the power domain on the tuned kernels: domain 1 with R^3 / R^2 instead of
+    powers and a cube-root update, any other domain in (0, 2) with the powers as exp2(e log2 R)
+    (round 3; the generic kernels before); several frame tiles, ragged edges, split and unsplit
+    work items."""
     from oracle.ilrma import GaussILRMAOracle
     from ssspy_amd.bss.ilrma import GaussILRMA
     from ssspy_amd.utils.dataset import nmf_mixture
