@@ -167,6 +167,100 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
   return total;
 }
 
+
+// ---------------------------------------------------------------- deterministic cross-block sums
+// Sums that cross workgroups without fp64 atomics (whose order, and so whose low bits, change from
+// run to run): every producer block stores its partial sums to its own slab, and k_fold_slabs adds
+// the slabs of a reduction set IN SLAB ORDER.  A set can have hundreds of slabs (a single-mixture
+// ISS sweep: 513 blocks), so the fold has two levels inside one launch: block (x, g) adds the <= 32
+// slabs of group g for 256 outputs, and the block that draws the last ticket of column x adds the
+// groups' results -- whoever is last, the order (and the bits) are the same.  (Tried first: the
+// ticket and the fold inside the producing kernel -- one agent-scope release per producer block cost
+// the fused ISS sweep 2x at 128 mixtures; in the fold kernel it is one per 32 slabs.)
+// Visibility follows the release / acquire recipe of cdna_hip_programming.md (split-K reduction):
+// plain stores -> s_waitcnt vmcnt(0) -> barrier -> lane 0: agent-scope release, s_waitcnt vmcnt(0)
+// (restated in asm: hipcc may drop it), relaxed agent-scope ticket; the last block: agent-scope
+// acquire -> barrier -> plain loads.  The counters are zeroed by the host before every launch.
+constexpr int FOLD_GROUP = 32;
+
+// true (in every thread) in the block that drew the last of `members` tickets.  `flag`: one LDS word.
+// Every thread of the block must call it.
+__device__ __forceinline__ bool last_arriver(unsigned *counter, unsigned members, int *flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket =
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = ticket == members - 1u;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *flag = last ? 1 : 0;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+
+// sum of count values src[k * stride], k in order, eight loads in flight per round trip
+__device__ __forceinline__ double ordered_sum(const double *src, long long stride, int count) {
+  double s = 0.0;
+  for (int k0 = 0; k0 < count; k0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(long long)min(k0 + u, count - 1) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += k0 + u < count ? v[u] : 0.0;
+  }
+  return s;
+}
+
+__host__ __device__ inline int fold_groups(int nslabs) {
+  return (nslabs + FOLD_GROUP - 1) / FOLD_GROUP;
+}
+
+// out[e] = sum_k slabs[k * total + e] (k < nslabs, in order), e < total.
+// grid: (ceil(total / 256), fold_groups(nslabs)); gslabs: groups * total doubles of scratch;
+// counters: gridDim.x zeroed words.
+static __global__ __launch_bounds__(256) void k_fold_slabs(const double *__restrict__ slabs,
+                                                    double *gslabs, unsigned *counters,
+                                                    double *out, long long total, int nslabs) {
+  __shared__ int flag;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = e < total;
+  const int ng = gridDim.y, g = blockIdx.y;
+  const int members = min(FOLD_GROUP, nslabs - g * FOLD_GROUP);
+  const double s = live ? ordered_sum(slabs + (long long)g * FOLD_GROUP * total + e, total, members)
+                        : 0.0;
+  if (ng == 1) {
+    if (live) out[e] = s;
+    return;
+  }
+  if (live) gslabs[(long long)g * total + e] = s;
+  if (!last_arriver(counters + blockIdx.x, (unsigned)ng, &flag)) return;
+  if (live) out[e] = ordered_sum(gslabs + e, total, ng);
+}
+
+// host side: scratch behind the slabs and the launch.  `scratch` holds fold_scratch_bytes(...).
+static inline size_t fold_scratch_bytes(long long total, int nslabs) {
+  const int ng = fold_groups(nslabs);
+  if (ng <= 1) return 0;
+  return (size_t)ng * total * sizeof(double) + (size_t)((total + 255) / 256) * sizeof(unsigned);
+}
+static inline int launch_fold_slabs(const double *slabs, void *scratch, double *out, long long total,
+                             int nslabs, hipStream_t st) {
+  const int ng = fold_groups(nslabs);
+  const unsigned gx = (unsigned)((total + 255) / 256);
+  double *gslabs = (double *)scratch;
+  unsigned *counters = ng > 1 ? (unsigned *)(gslabs + (size_t)ng * total) : nullptr;
+  if (ng > 1) {
+    hipError_t e = hipMemsetAsync(counters, 0, (size_t)gx * sizeof(unsigned), st);
+    if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(k_fold_slabs, dim3(gx, ng), dim3(256), 0, st, slabs, gslabs, counters, out,
+                     total, nslabs);
+  return check_launch("k_fold_slabs");
+}
+
 __device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c) {
   // v_mfma_f64_16x16x4_f64: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
   // C/D: col = lane&15, row = (lane>>4) + 4*reg
@@ -190,6 +284,12 @@ __device__ __forceinline__ c128 buffer_load_c128(__amdgpu_buffer_rsrc_t r, unsig
 __device__ __forceinline__ double buffer_load_f64(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
   const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
   return __hiloint2double((int)v[1], (int)v[0]);
+}
+__device__ __forceinline__ void buffer_store_f64(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double x) {
+  u32x2_t v;
+  v[0] = (unsigned)__double2loint(x);
+  v[1] = (unsigned)__double2hiint(x);
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, 0);
 }
 __device__ __forceinline__ void buffer_store_c128(__amdgpu_buffer_rsrc_t r, unsigned byte_off, c128 z) {
   u32x4_t v;

@@ -23,7 +23,7 @@
 // Tried and dropped in round 1 (profiles/r01_other_configs.txt): 512-thread workgroups that prefetch
 // the next bin's slab with LDS-direct loads (128 KB of LDS) -- the cross-lane work doubled per SIMD.
 // While the updated slab is written back, |y|^2 is accumulated per (source, frame) over the bins of
-// the block and added atomically to r2_next: the frame powers r_nj^2 of the NEXT iteration's
+// the block and summed over the blocks (tree_fold) into r2_next: the frame powers r_nj^2 of the NEXT iteration's
 // auxiliary weights, which would otherwise need their own pass over Y (2 passes).
 #include "common.hpp"
 
@@ -182,7 +182,7 @@ __device__ __forceinline__ void iss_sweeps(c128 (&y)[N][FPT], const double (&phi
 // TRACK: logdet_delta[b] += sum over this block's bins of -1/2 sum_n log d_n (see iss_sweeps)
 template <int N, int FPT, bool PER_BIN, bool TRACK = false>
 __global__ __launch_bounds__(256, 2) void k_iss1_fused(c128 *Y, const double *__restrict__ weight,
-                                                       double *r2_next, int F, int T,
+                                                       double *r2_slabs, int F, int T,
                                                        int bins_per_block, int floor_kind,
                                                        double eps, double *logdet_delta) {
   __shared__ double part[2 * IssShape<N>::PART];
@@ -254,32 +254,22 @@ __global__ __launch_bounds__(256, 2) void k_iss1_fused(c128 *Y, const double *__
       if (threadIdx.x == 0) atomicAdd(logdet_delta + b, -0.5 * v);
     }
   }
-  if (r2_next) {
-    // the block's sums over its bins, to its own slab r2_next[block][b][n][j]; k_iss1_r2_fold adds the
-    // slabs in block order (no fp64 atomics: the next iteration's weights are the same on every run)
-    double *slab = r2_next + ((long long)blockIdx.x * gridDim.y + b) * N * T;
+  if (r2_slabs) {
+    // the block's sums over its bins go to its own slab r2_slabs[block][b][n][j]; k_fold_slabs adds
+    // the slabs in block order: no fp64 atomics -- the next iteration's weights, and with them the
+    // whole trajectory, are the same on every run
+    // (through a buffer descriptor: one 32-bit lane offset instead of N FPT 64-bit addresses)
+    const int len = N * T;
+    const __amdgpu_buffer_rsrc_t sr = make_rsrc(
+        r2_slabs + ((long long)blockIdx.x * gridDim.y + b) * len, (unsigned)len * 8u);
 #pragma unroll
     for (int n = 0; n < N; ++n)
 #pragma unroll
       for (int f = 0; f < FPT; ++f)
-        if (fv[f]) slab[(long long)n * T + jj[f]] = r2s[(n * FPT + f) * 256 + threadIdx.x];
+        if (fv[f])
+          buffer_store_f64(sr, ((unsigned)n * (unsigned)T + jj[f]) * 8u,
+                           r2s[(n * FPT + f) * 256 + threadIdx.x]);
   }
-}
-
-// r2[e] = sum over the blocks' slabs, in block order; e over B * N * T
-__global__ __launch_bounds__(256) void k_iss1_r2_fold(const double *__restrict__ part, double *r2,
-                                                      long long total, int nblocks) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  double s = 0.0;
-  for (int k0 = 0; k0 < nblocks; k0 += 8) {  // eight loads in flight per round trip
-    double v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = part[(long long)min(k0 + u, nblocks - 1) * total + e];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += k0 + u < nblocks ? v[u] : 0.0;
-  }
-  r2[e] = s;
 }
 
 template <int N>
@@ -288,48 +278,49 @@ constexpr int iss_max_fpt() {
 }
 
 // bins per block: a few bins amortise the weight loads and the frame-power slab a block leaves
-// (N T doubles against N T complex per bin in and out: 1/(4 bpb) of the pass's traffic); keep >= ~4
-// blocks per CU.  With frame powers requested large batches take up to 32 bins per block (1.5 %).
+// (N T doubles against N T complex per bin in and out: 1/(4 bpb) of the pass's traffic, and as much
+// again when the slabs are added up); keep >= ~4 blocks per CU.  With frame powers requested large
+// batches take up to 16 bins per block (3 %).
 static int iss_bins_per_block(int B, int F, bool with_r2) {
   const long long want_blocks = 1024;
   int bpb = (int)(((long long)B * F + want_blocks - 1) / want_blocks);
   if (bpb < 1) bpb = 1;
-  const int cap = with_r2 ? 32 : 8;
+  const int cap = with_r2 ? 16 : 8;
   return bpb > cap ? cap : bpb;
 }
 
 template <int N, int FPT>
-static int launch_iss(void *Y, const double *weight, bool per_bin, double *r2_next, int B, int F,
+static int launch_iss(void *Y, const double *weight, bool per_bin, double *r2_slabs, int B, int F,
                       int T, int floor_kind, double eps, double *logdet_delta, hipStream_t st) {
-  const int bpb = iss_bins_per_block(B, F, r2_next != nullptr);
+  const int bpb = iss_bins_per_block(B, F, r2_slabs != nullptr);
   dim3 grid((F + bpb - 1) / bpb, B), block(256);
   if (logdet_delta) {  // tracked variants (a separate instantiation: the untracked hot kernels keep
                        // their register allocation)
     if (per_bin)
       hipLaunchKernelGGL((k_iss1_fused<N, FPT, true, true>), grid, block, 0, st, (c128 *)Y, weight,
-                         r2_next, F, T, bpb, floor_kind, eps, logdet_delta);
+                         r2_slabs, F, T, bpb, floor_kind, eps, logdet_delta);
     else
       hipLaunchKernelGGL((k_iss1_fused<N, FPT, false, true>), grid, block, 0, st, (c128 *)Y, weight,
-                         r2_next, F, T, bpb, floor_kind, eps, logdet_delta);
+                         r2_slabs, F, T, bpb, floor_kind, eps, logdet_delta);
   } else if (per_bin)
-    hipLaunchKernelGGL((k_iss1_fused<N, FPT, true>), grid, block, 0, st, (c128 *)Y, weight, r2_next,
+    hipLaunchKernelGGL((k_iss1_fused<N, FPT, true>), grid, block, 0, st, (c128 *)Y, weight, r2_slabs,
                        F, T, bpb, floor_kind, eps, (double *)nullptr);
   else
-    hipLaunchKernelGGL((k_iss1_fused<N, FPT, false>), grid, block, 0, st, (c128 *)Y, weight, r2_next,
+    hipLaunchKernelGGL((k_iss1_fused<N, FPT, false>), grid, block, 0, st, (c128 *)Y, weight, r2_slabs,
                        F, T, bpb, floor_kind, eps, (double *)nullptr);
   return check_launch("k_iss1_fused");
 }
 
 template <int N>
-static int dispatch_iss(void *Y, const double *weight, bool per_bin, double *r2_next, int B, int F,
-                        int T, int floor_kind, double eps, double *ld, hipStream_t st) {
+static int dispatch_iss(void *Y, const double *weight, bool per_bin, double *r2_slabs, int B,
+                        int F, int T, int floor_kind, double eps, double *ld, hipStream_t st) {
   const int fpt = (T + 255) / 256;
-  if (fpt <= 1) return launch_iss<N, 1>(Y, weight, per_bin, r2_next, B, F, T, floor_kind, eps, ld, st);
-  if (fpt <= 2) return launch_iss<N, 2>(Y, weight, per_bin, r2_next, B, F, T, floor_kind, eps, ld, st);
-  if (fpt <= 4) return launch_iss<N, 4>(Y, weight, per_bin, r2_next, B, F, T, floor_kind, eps, ld, st);
+  if (fpt <= 1) return launch_iss<N, 1>(Y, weight, per_bin, r2_slabs, B, F, T, floor_kind, eps, ld, st);
+  if (fpt <= 2) return launch_iss<N, 2>(Y, weight, per_bin, r2_slabs, B, F, T, floor_kind, eps, ld, st);
+  if (fpt <= 4) return launch_iss<N, 4>(Y, weight, per_bin, r2_slabs, B, F, T, floor_kind, eps, ld, st);
   if (iss_max_fpt<N>() >= 8 && fpt <= 8)
-    return launch_iss<N, (iss_max_fpt<N>() >= 8 ? 8 : 4)>(Y, weight, per_bin, r2_next, B, F, T,
-                                                          floor_kind, eps, ld, st);
+    return launch_iss<N, (iss_max_fpt<N>() >= 8 ? 8 : 4)>(Y, weight, per_bin, r2_slabs, B, F,
+                                                          T, floor_kind, eps, ld, st);
   return fail(SSSPY_ERR_UNSUPPORTED, "iss1_fused: n_frames too large for the register-resident slab");
 }
 
@@ -344,10 +335,19 @@ int ssspy_iss1_fused_max_frames(int N) {
   return 256 * (N <= 4 ? 8 : 4);
 }
 
+// slabs [block][b][N T], then the scratch of the fold
+static size_t iss_r2_layout(int B, int N, int F, int T, size_t *scratch_off) {
+  const int bpb = iss_bins_per_block(B, F, true);
+  const int nblk = (F + bpb - 1) / bpb;
+  const long long total = (long long)B * N * T;
+  const size_t slabs = (size_t)nblk * total * sizeof(double);
+  if (scratch_off) *scratch_off = slabs;
+  return slabs + fold_scratch_bytes(total, nblk);
+}
+
 size_t ssspy_iss1_fused_workspace_bytes(int B, int N, int F, int T) {
   if (B <= 0 || N <= 0 || F <= 0 || T <= 0) return 0;
-  const int bpb = iss_bins_per_block(B, F, true);
-  return (size_t)((F + bpb - 1) / bpb) * B * N * T * sizeof(double);
+  return iss_r2_layout(B, N, F, T, nullptr);
 }
 
 static int iss1_fused_impl(void *Y, const double *weight, int weight_kind, double *r2_next, int B,
@@ -358,8 +358,9 @@ static int iss1_fused_impl(void *Y, const double *weight, int weight_kind, doubl
   SSSPY_REQUIRE(weight_kind == SSSPY_WEIGHT_FRAME || weight_kind == SSSPY_WEIGHT_BIN_FRAME,
                 "iss1_fused: weight_kind must be FRAME or BIN_FRAME");
   SSSPY_REQUIRE(T <= ssspy_iss1_fused_max_frames(N), "iss1_fused: n_frames above the fused limit");
-  SSSPY_REQUIRE(!r2_next || (workspace &&
-                             workspace_bytes >= ssspy_iss1_fused_workspace_bytes(B, N, F, T)),
+  size_t scratch_off = 0;
+  const size_t need = iss_r2_layout(B, N, F, T, &scratch_off);
+  SSSPY_REQUIRE(!r2_next || (workspace && workspace_bytes >= need),
                 "iss1_fused: frame powers need the workspace of ssspy_iss1_fused_workspace_bytes");
   const bool per_bin = weight_kind == SSSPY_WEIGHT_BIN_FRAME;
   hipStream_t st = as_stream(stream);
@@ -369,10 +370,8 @@ static int iss1_fused_impl(void *Y, const double *weight, int weight_kind, doubl
                                       logdet_delta, st));
   if (rc || !r2_next) return rc;
   const int bpb = iss_bins_per_block(B, F, true);
-  const long long total = (long long)B * N * T;
-  hipLaunchKernelGGL(k_iss1_r2_fold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                     (const double *)slabs, r2_next, total, (F + bpb - 1) / bpb);
-  return check_launch("k_iss1_r2_fold");
+  return launch_fold_slabs(slabs, (char *)workspace + scratch_off, r2_next, (long long)B * N * T,
+                           (F + bpb - 1) / bpb, st);
 }
 
 int ssspy_iss1_fused(void *Y, const double *weight, int weight_kind, double *r2_next, int B, int N,

@@ -5,14 +5,70 @@
 
 namespace ssspy {
 
-// lanes along frames (coalesced rows), block walks a chunk of bins; W_i is wave-uniform.
-// grid: (ceil(T/256), bin chunks, B).  One chunk: r2 is stored directly; several: every chunk stores
-// its sums to part[chunk][b][n][j] and k_iva_frame_power_fold adds them in chunk order -- no fp64
-// atomics: the weights of the next iteration, hence the whole trajectory, are the same on every run.
+// lanes along frames (coalesced 1 KB rows), W_i is wave-uniform.  grid: (ceil(T/64), bin chunks, B);
+// the four waves of a block take a quarter of the chunk's bins each and fold through LDS in wave
+// order.  One chunk: r2 is stored directly; several: every chunk stores its sums to its slab
+// part[chunk][b][n][j] and k_fold_slabs (common.hpp) adds them in chunk order -- no fp64 atomics: the
+// weights of the next iteration, hence the whole trajectory, are the same on every run.
 template <int N>
 __global__ __launch_bounds__(256) void k_iva_frame_power(const c128 *__restrict__ X,
                                                          const c128 *__restrict__ W, double *r2,
                                                          int F, int T, int bins_per_chunk) {
+  __shared__ double fold[4][N][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const int b = blockIdx.z;
+  const int c_begin = blockIdx.y * bins_per_chunk;
+  const int c_end = min(F, c_begin + bins_per_chunk);
+  const int per_wave = (c_end - c_begin + 3) >> 2;
+  const int i_begin = c_begin + wave * per_wave;
+  const int i_end = min(c_end, i_begin + per_wave);
+  const int jc = min(j, T - 1);
+  double acc[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) acc[n] = 0.0;
+#pragma unroll 2
+  for (int i = i_begin; i < i_end; ++i) {
+    c128 x[N];
+#pragma unroll
+    for (int m = 0; m < N; ++m) x[m] = X[(((long long)b * N + m) * F + i) * T + jc];
+    if (W) {
+      const c128 *Wi = W + ((long long)b * F + i) * (N * N);
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        c128 y = cmake(0.0, 0.0);
+#pragma unroll
+        for (int m = 0; m < N; ++m) cfma(y, Wi[n * N + m], x[m]);
+        acc[n] += cabs2(y);
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < N; ++n) acc[n] += cabs2(x[n]);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n) fold[wave][n][lane] = acc[n];
+  __syncthreads();
+  // (r2 is the output itself with one chunk, else the chunk's slab of the partial buffer)
+  double *dst = r2 + (long long)blockIdx.y * gridDim.z * N * T;
+  for (int e = threadIdx.x; e < N * 64; e += 256) {
+    const int n = e >> 6, ln = e & 63;
+    const int jj = blockIdx.x * 64 + ln;
+    if (jj < T)
+      dst[((long long)b * N + n) * T + jj] =
+          ((fold[0][n][ln] + fold[1][n][ln]) + fold[2][n][ln]) + fold[3][n][ln];
+  }
+}
+
+// The same sums with a thread per frame (256 frames per block, no fold): the shape for large batches,
+// where (T / 256) B blocks per bin chunk already fill the chip (128 mixtures: 2.03 -> 1.8 ms per
+// AuxIVA-IP iteration against the 64-frame form above, which wins below ~64 mixtures).
+// grid: (ceil(T/256), bin chunks, B)
+template <int N>
+__global__ __launch_bounds__(256) void k_iva_frame_power_wide(const c128 *__restrict__ X,
+                                                              const c128 *__restrict__ W,
+                                                              double *r2, int F, int T,
+                                                              int bins_per_chunk) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.z;
   const int i_begin = blockIdx.y * bins_per_chunk;
@@ -39,27 +95,9 @@ __global__ __launch_bounds__(256) void k_iva_frame_power(const c128 *__restrict_
       for (int n = 0; n < N; ++n) acc[n] += cabs2(x[n]);
     }
   }
-  // (r2 is the output itself with one chunk, else the chunk's slab of the partial buffer)
   double *dst = r2 + (long long)blockIdx.y * gridDim.z * N * T;
 #pragma unroll
   for (int n = 0; n < N; ++n) dst[((long long)b * N + n) * T + j] = acc[n];
-}
-
-// r2[e] = sum over chunks, in chunk order; e over B * N * T
-__global__ __launch_bounds__(256) void k_iva_frame_power_fold(const double *__restrict__ part,
-                                                              double *r2, long long total,
-                                                              int chunks) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  double s = 0.0;
-  for (int ch0 = 0; ch0 < chunks; ch0 += 8) {  // eight loads in flight per round trip
-    double v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = part[(long long)min(ch0 + u, chunks - 1) * total + e];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += ch0 + u < chunks ? v[u] : 0.0;
-  }
-  r2[e] = s;
 }
 
 __global__ __launch_bounds__(256) void k_iva_weight(const double *__restrict__ r2, double *weight,
@@ -109,42 +147,57 @@ using namespace ssspy;
 
 extern "C" {
 
-// bin chunks of the frame-power pass: enough blocks to fill the chip
-static int frame_power_chunks(int B, int F, int T, int *bins_per_chunk) {
-  const int gx = (T + 255) / 256;
-  long long want = 2048 / ((long long)gx * B);
+// Shape of the frame-power pass: frames per block (256: a thread per frame, large batches; 64: four
+// waves share the bins, a handful of mixtures) and bin chunks -- enough blocks to fill the chip, at
+// most 128 slabs for the fold.
+struct FramePowerPlan {
+  int frames_per_block, bins_per_chunk, chunks;
+};
+static FramePowerPlan frame_power_plan(int B, int F, int T) {
+  FramePowerPlan p;
+  p.frames_per_block = (long long)((T + 255) / 256) * B >= 128 ? 256 : 64;
+  const int gx = (T + p.frames_per_block - 1) / p.frames_per_block;
+  long long want = (p.frames_per_block == 256 ? 2048 : 1024) / ((long long)gx * B);
   if (want < 1) want = 1;
+  if (want > 128) want = 128;
   if (want > F) want = F;
-  *bins_per_chunk = (int)((F + want - 1) / want);
-  return (F + *bins_per_chunk - 1) / *bins_per_chunk;
+  p.bins_per_chunk = (int)((F + want - 1) / want);
+  p.chunks = (F + p.bins_per_chunk - 1) / p.bins_per_chunk;
+  return p;
 }
 
 size_t ssspy_iva_frame_power_workspace_bytes(int B, int N, int F, int T) {
   if (B <= 0 || N <= 0 || F <= 0 || T <= 0) return 0;
-  int bpc;
-  const int chunks = frame_power_chunks(B, F, T, &bpc);
-  return chunks > 1 ? (size_t)chunks * B * N * T * sizeof(double) : 0;
+  const FramePowerPlan p = frame_power_plan(B, F, T);
+  if (p.chunks <= 1) return 0;
+  const long long total = (long long)B * N * T;
+  return (size_t)p.chunks * total * sizeof(double) + fold_scratch_bytes(total, p.chunks);
 }
 
 int ssspy_iva_frame_power(const void *X, const void *W, double *r2, int B, int N, int F, int T,
                           void *workspace, size_t workspace_bytes, void *stream) {
   SSSPY_REQUIRE(X && r2 && B > 0 && F > 0 && T > 0, "iva_frame_power: bad argument");
   hipStream_t st = as_stream(stream);
-  int bins_per_chunk;
-  const int chunks = frame_power_chunks(B, F, T, &bins_per_chunk);
+  const FramePowerPlan p = frame_power_plan(B, F, T);
   const size_t need = ssspy_iva_frame_power_workspace_bytes(B, N, F, T);
   SSSPY_REQUIRE(need == 0 || (workspace && workspace_bytes >= need),
                 "iva_frame_power: workspace too small");
-  double *dst = chunks > 1 ? (double *)workspace : r2;
-  dim3 grid((T + 255) / 256, chunks, B), block(256);
-  DISPATCH_N(N, hipLaunchKernelGGL((k_iva_frame_power<NN>), grid, block, 0, st, (const c128 *)X,
-                                   (const c128 *)W, dst, F, T, bins_per_chunk));
+  double *dst = p.chunks > 1 ? (double *)workspace : r2;
+  dim3 grid((T + p.frames_per_block - 1) / p.frames_per_block, p.chunks, B), block(256);
+  if (p.frames_per_block == 256) {
+    DISPATCH_N(N, hipLaunchKernelGGL((k_iva_frame_power_wide<NN>), grid, block, 0, st,
+                                     (const c128 *)X, (const c128 *)W, dst, F, T,
+                                     p.bins_per_chunk));
+  } else {
+    DISPATCH_N(N, hipLaunchKernelGGL((k_iva_frame_power<NN>), grid, block, 0, st, (const c128 *)X,
+                                     (const c128 *)W, dst, F, T, p.bins_per_chunk));
+  }
   int rc = check_launch("k_iva_frame_power");
-  if (rc || chunks == 1) return rc;
+  if (rc || p.chunks == 1) return rc;
   const long long total = (long long)B * N * T;
-  hipLaunchKernelGGL(k_iva_frame_power_fold, dim3((unsigned)((total + 255) / 256)), block, 0, st,
-                     (const double *)workspace, r2, total, chunks);
-  return check_launch("k_iva_frame_power_fold");
+  return launch_fold_slabs((const double *)workspace,
+                           (char *)workspace + (size_t)p.chunks * total * sizeof(double), r2, total,
+                           p.chunks, st);
 }
 
 int ssspy_iva_weight(const double *r2, double *weight, double *variance, int B, int N, int F, int T,
