@@ -25,6 +25,7 @@ After the timed region, on rank 0 at N=1 (none of it is part of ``value``):
 """
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -73,7 +74,17 @@ def make_separator(X, K, seed, record_loss=False):
     return sep
 
 
+def settle_host():
+    """A full collection of CPython's oldest generation walks every object torch and NumPy created at
+    import (42 ms here) and lands in whichever short loop crosses the allocation threshold
+    (benchmarks/tools/iter_times.py: iteration 21 of a 160 us loop took 42 ms).  Collect now and move
+    the survivors to the permanent generation; the collector stays enabled in the timed loops."""
+    gc.collect()
+    gc.freeze()
+
+
 def time_loop(fn, n):
+    settle_host()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
@@ -350,6 +361,7 @@ def main():
     # ---- the timed region: exactly `steps` update_once() calls (one fused C-ABI call each)
     for _ in range(args.warmup):
         sep.update_once()
+    settle_host()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -93,4 +93,8 @@ if other:
 oc = os.path.join(src, "other_configs.txt")
 if os.path.exists(oc):
     shutil.copy(oc, os.path.join(dst, "{}_other_configs.txt".format(tag)))
+single = os.path.join(src, "single.txt")
+if os.path.exists(single):  # single-mixture timelines (benchmarks/single_trace.py) + the AuxIVA lines
+    keep = [ln for ln in open(single) if "amdgpu.ids" not in ln]
+    open(os.path.join(dst, "{}_single_mixture.txt".format(tag)), "w").writelines(keep)
 print(json.dumps({"bench_value": bench["value"], "roofline": bench["roofline"], "traffic": traffic}, indent=1))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """AuxLaplaceIVA lines of bench.py in isolation: N=4 F=1025 T=512 (IP / ISS, 1 and 128 mixtures),
 configs[2] N=8 F=2049 T=1024 (ISS, 1 and 32 mixtures).  ms per update_once()."""
+import gc
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +14,7 @@ def run(X, algo, iters):
     m._bind_input(X); m._reset()
     if algo == "IP": m._C()
     for _ in range(5): m.update_once()
+    gc.collect(); gc.freeze()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(iters): m.update_once()
     torch.cuda.synchronize()

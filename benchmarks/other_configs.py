@@ -9,6 +9,7 @@ algorithmic-bytes rate of SURVEY.md 8d, and the one-off costs outside the loop.
 """
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -23,6 +24,8 @@ from ssspy_amd.utils.dataset import nmf_mixture  # noqa: E402
 
 
 def timed(fn, n):
+    gc.collect()   # a full collection (42 ms with torch imported) must not land in a 20-iteration loop
+    gc.freeze()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):

@@ -7,7 +7,7 @@
 # configs[2] and configs[3] at 32 mixtures).  benchmarks/digest_profiles.py turns these
 # into the tracked files under profiles/.
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/$tag
 mkdir -p $out
@@ -27,4 +27,12 @@ python benchmarks/wide_mixtures.py >> $out/other_configs.txt 2>&1
 # per-kernel statistics of configs[2] / configs[3] at 32 mixtures
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/other_stats -- \
   python benchmarks/other_configs.py --batch 32 --only iva_iss,fastmnmf --iters 10 > $out/other_stats.log 2>&1
+# single-mixture timelines (configs[1] / configs[3] literally) and the AuxIVA lines
+python benchmarks/single_mixture.py 300 > $out/single.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out/single_trace -- python benchmarks/single_mixture.py 60 > /dev/null 2>&1
+python benchmarks/single_trace.py $out/single_trace >> $out/single.txt 2>&1
+python benchmarks/single_mnmf.py 300 >> $out/single.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out/single_mnmf_trace -- python benchmarks/single_mnmf.py 60 > /dev/null 2>&1
+python benchmarks/single_trace.py $out/single_mnmf_trace >> $out/single.txt 2>&1
+python benchmarks/iva_lines.py >> $out/single.txt 2>&1
 tail -c 600 $out/bench.json

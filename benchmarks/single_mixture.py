@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """configs[1] literally: ONE GaussILRMA-IP1 mixture (N=4, F=1025, T=512, K=16), update_once loop."""
-import os, sys, time
+import gc, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ssspy_amd.bss.ilrma import GaussILRMA
@@ -11,6 +11,7 @@ X = nmf_mixture(1000, 4, 1025, 512)
 sep = GaussILRMA(n_basis=16, record_loss=False, rng=np.random.default_rng(0))
 sep._bind_input(X); sep._reset(flooring_fn=sep.flooring_fn); sep._C()
 for _ in range(10): sep.update_once()
+gc.collect(); gc.freeze()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(n): sep.update_once()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0

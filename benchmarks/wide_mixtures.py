@@ -6,6 +6,7 @@
 One JSON object per source count, with the time per iteration and the time per (source, bin, frame)
 relative to nothing -- compare the ns_per_point column across N (N = 4 is the tuned path).
 """
+import gc
 import argparse
 import json
 import os
@@ -36,6 +37,7 @@ def main():
         for _ in range(2):
             sep.update_once()
         torch.cuda.synchronize()
+        gc.collect(); gc.freeze()
         t0 = time.perf_counter()
         for _ in range(args.iters):
             sep.update_once()

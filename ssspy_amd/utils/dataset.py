@@ -83,7 +83,7 @@ def kernel_sources_sha256():
 
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
     h = hashlib.sha256()
-    for name in ("ilrma_fast.hip", "fast_tiles.hpp", "tail_plan.hpp", "common.hpp"):
+    for name in ("ilrma_fast.hip", "fast_model.hpp", "fast_tiles.hpp", "tail_plan.hpp", "common.hpp"):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
