@@ -201,15 +201,18 @@ __device__ __forceinline__ bool last_arriver(unsigned *counter, unsigned members
   return *flag != 0;
 }
 
-// sum of count values src[k * stride], k in order, eight loads in flight per round trip
-__device__ __forceinline__ double ordered_sum(const double *src, long long stride, int count) {
-  double s = 0.0;
+// sum of count values src[k * stride], k in order, eight loads in flight per round trip.
+// V: double (one output per thread) or double2 (two; 16-byte loads, stride in units of V)
+template <typename V>
+__device__ __forceinline__ V ordered_sum(const V *src, long long stride, int count) {
+  V s = V{};
   for (int k0 = 0; k0 < count; k0 += 8) {
-    double v[8];
+    V v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = src[(long long)min(k0 + u, count - 1) * stride];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += k0 + u < count ? v[u] : 0.0;
+    for (int u = 0; u < 8; ++u)
+      if (k0 + u < count) s += v[u];  // count is uniform: a scalar branch, not a select per lane
   }
   return s;
 }
@@ -218,19 +221,19 @@ __host__ __device__ inline int fold_groups(int nslabs) {
   return (nslabs + FOLD_GROUP - 1) / FOLD_GROUP;
 }
 
-// out[e] = sum_k slabs[k * total + e] (k < nslabs, in order), e < total.
-// grid: (ceil(total / 256), fold_groups(nslabs)); gslabs: groups * total doubles of scratch;
+// out[e] = sum_k slabs[k * total + e] (k < nslabs, in order), e < total (in units of V).
+// grid: (ceil(total / 256), fold_groups(nslabs)); gslabs: groups * total V of scratch;
 // counters: gridDim.x zeroed words.
-static __global__ __launch_bounds__(256) void k_fold_slabs(const double *__restrict__ slabs,
-                                                    double *gslabs, unsigned *counters,
-                                                    double *out, long long total, int nslabs) {
+template <typename V>
+static __global__ __launch_bounds__(256) void k_fold_slabs(const V *__restrict__ slabs, V *gslabs,
+                                                           unsigned *counters, V *out,
+                                                           long long total, int nslabs) {
   __shared__ int flag;
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   const bool live = e < total;
   const int ng = gridDim.y, g = blockIdx.y;
   const int members = min(FOLD_GROUP, nslabs - g * FOLD_GROUP);
-  const double s = live ? ordered_sum(slabs + (long long)g * FOLD_GROUP * total + e, total, members)
-                        : 0.0;
+  const V s = live ? ordered_sum(slabs + (long long)g * FOLD_GROUP * total + e, total, members) : V{};
   if (ng == 1) {
     if (live) out[e] = s;
     return;
@@ -249,15 +252,23 @@ static inline size_t fold_scratch_bytes(long long total, int nslabs) {
 static inline int launch_fold_slabs(const double *slabs, void *scratch, double *out, long long total,
                              int nslabs, hipStream_t st) {
   const int ng = fold_groups(nslabs);
-  const unsigned gx = (unsigned)((total + 255) / 256);
   double *gslabs = (double *)scratch;
   unsigned *counters = ng > 1 ? (unsigned *)(gslabs + (size_t)ng * total) : nullptr;
+  // two outputs per thread through 16-byte loads when the layout allows (same sums, same order)
+  const bool pairs = total % 2 == 0 &&
+                     (((uintptr_t)slabs | (uintptr_t)gslabs | (uintptr_t)out) & 15u) == 0;
+  const long long units = pairs ? total / 2 : total;
+  const unsigned gx = (unsigned)((units + 255) / 256);
   if (ng > 1) {
     hipError_t e = hipMemsetAsync(counters, 0, (size_t)gx * sizeof(unsigned), st);
     if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(k_fold_slabs, dim3(gx, ng), dim3(256), 0, st, slabs, gslabs, counters, out,
-                     total, nslabs);
+  if (pairs)
+    hipLaunchKernelGGL(k_fold_slabs<double2>, dim3(gx, ng), dim3(256), 0, st, (const double2 *)slabs,
+                       (double2 *)gslabs, counters, (double2 *)out, units, nslabs);
+  else
+    hipLaunchKernelGGL(k_fold_slabs<double>, dim3(gx, ng), dim3(256), 0, st, slabs, gslabs, counters,
+                       out, units, nslabs);
   return check_launch("k_fold_slabs");
 }
 

@@ -43,8 +43,8 @@ DECL_FAST(2) DECL_FAST(3) DECL_FAST(4)
   int ilrma_small_activation_n##n(const void *, const void *, const double *, double *, int, int, \
                                   int, int, int, double, double *, int, double, int,              \
                                   hipStream_t);                                                   \
-  int ilrma_small_ip1_n##n(const void *, int, int, const void *, void *, int, int, int, double,   \
-                           double *, int *, hipStream_t);                                         \
+  int ilrma_small_ip1_n##n(const void *, int, int, long long, const void *, void *, int, int, int, \
+                           double, double *, int *, hipStream_t);                                 \
   int ilrma_small_norm_n##n(void *, double *, const double *, int, int, int, double, int, double, \
                             hipStream_t);
 DECL_SMALL(2) DECL_SMALL(3) DECL_SMALL(4)
@@ -995,7 +995,7 @@ static int ip1_update_impl(const void *X, const void *C, void *W, double *basis,
     if (rc) return rc;
     auto ip1 = [&]() -> int {
       ILRMA_FAST_DISPATCH(N, ilrma_small_ip1, split ? (const void *)(ws + w.upart) : (const void *)U,
-                          split, rbins, normalize ? C : nullptr, W, B, F, floor_kind, floor_eps,
+                          split, rbins, 0ll, normalize ? C : nullptr, W, B, F, floor_kind, floor_eps,
                           qbuf, info, st);
     };
     rc = ip1();

@@ -278,15 +278,13 @@ __global__ __launch_bounds__(256) void k_basis_finalize(const double *basis, dou
   const int bin = group * 64 + lb;
   double contrib = 0.0;
   if (n < N && k < K && bin < F) {
-    double sn = 0.0, sd = 0.0;
-    for (int ch = 0; ch < plan.split; ++ch) {
-      const double *src =
-          part + ((((long long)tail_idx * plan.split + ch) * N + n) * 1024 + (e & 1023)) * 2;
-      sn += src[0];
-      sd += src[1];
-    }
     const long long o = (((long long)b * N + n) * F + bin) * K + k;
     const double told = basis[o];
+    // chunks in order, eight loads per round trip (ordered_sum, common.hpp)
+    const double2 s2 = ordered_sum(reinterpret_cast<const double2 *>(part) +
+                                       (((long long)tail_idx * plan.split) * N + n) * 1024 + (e & 1023),
+                                   (long long)N * 1024, plan.split);
+    const double sn = s2.x, sd = s2.y;
     contrib = told * sn;
     const double ratio = sn / sd;
     basis_out[o] = apply_floor(ratio_pow(ratio, expo) * told, floor_kind, eps);
@@ -626,13 +624,9 @@ __global__ __launch_bounds__(256) void k_wcov_fold(c128 *__restrict__ U,
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int lb = e / (N * N * N);
   if (e >= PER || group * WC_BINS + lb >= F) return;
-  double re = 0.0, im = 0.0;
-  for (int ch = 0; ch < plan.split; ++ch) {
-    const c128 v = upart[((long long)tail_idx * plan.split + ch) * PER + e];
-    re += v.x;
-    im += v.y;
-  }
-  U[((long long)b * F + group * WC_BINS) * (long long)(N * N * N) + e] = cmake(re, im);
+  const c128 s2 = ordered_sum(upart + (long long)tail_idx * plan.split * PER + e, (long long)PER,
+                              plan.split);  // chunks in order, eight loads per round trip
+  U[((long long)b * F + group * WC_BINS) * (long long)(N * N * N) + e] = s2;
 }
 
 // ========================================================================= activation (pass 2)

@@ -363,10 +363,12 @@ __device__ __forceinline__ c128 crecip_nr(c128 a) {
 // Input: the finished covariance U (B, F, N, N, N) (nchunks == 0), or the partial records of the
 // split items of k_wcov_fast, upart[(b * groups + group) * nchunks + ch][rbins][N^3] (TailPlan with
 // no unsplit item: a handful of mixtures), which are summed here instead of by k_wcov_fold.
+// rec: c128 between consecutive records (rbins N^3 for k_wcov_fast; FastMNMF's records share a
+// wider scratch slot, mnmf_tail_doubles()).
 __global__ __launch_bounds__(256) void k_ip1_small(c128 *W, const c128 *__restrict__ Usrc,
                                                    const c128 *__restrict__ C, double *qbuf, int F,
-                                                   int nchunks, int rbins, int floor_kind,
-                                                   double eps, int *info) {
+                                                   int nchunks, int rbins, long long rec,
+                                                   int floor_kind, double eps, int *info) {
   constexpr int NN = N * N, G = 4;
   __shared__ __attribute__((aligned(16))) c128 Us[16][N][NN + 1];
   __shared__ __attribute__((aligned(16))) c128 Ws[16][NN + 1];
@@ -390,7 +392,6 @@ __global__ __launch_bounds__(256) void k_ip1_small(c128 *W, const c128 *__restri
         }
       } else {
         const int groups = (F + rbins - 1) / rbins, group = bin / rbins;
-        const long long rec = (long long)rbins * (N * NN);  // c128 per record
         const c128 *src = Usrc + ((long long)b * groups + group) * nchunks * rec +
                           (long long)(bin - group * rbins) * (N * NN) + e;
 #pragma unroll
@@ -666,12 +667,14 @@ int LAUNCHER(ilrma_small_activation)(const void *X, const void *W, const double 
 // IP1 (+ output power q[bin][n] = Re(w_n C w_n^H) when C and qbuf are given) from the finished
 // covariance (nchunks == 0: `Usrc` is U) or from the partial records k_wcov_fast left for its fold
 // (nchunks of them per group of `rbins` bins).
-int LAUNCHER(ilrma_small_ip1)(const void *Usrc, int nchunks, int rbins, const void *C, void *W, int B,
-                              int F, int floor_kind, double eps, double *qbuf, int *info,
-                              hipStream_t st) {
+// rec_stride: c128 between records, 0 = packed (rbins N^3).
+int LAUNCHER(ilrma_small_ip1)(const void *Usrc, int nchunks, int rbins, long long rec_stride,
+                              const void *C, void *W, int B, int F, int floor_kind, double eps,
+                              double *qbuf, int *info, hipStream_t st) {
+  const long long rec = rec_stride > 0 ? rec_stride : (long long)rbins * (N * N * N);
   hipLaunchKernelGGL(k_ip1_small, dim3((F + 15) / 16, B), dim3(256), 0, st, (c128 *)W,
                      (const c128 *)Usrc, (const c128 *)C, C ? qbuf : (double *)nullptr, F, nchunks,
-                     rbins, floor_kind, eps, info);
+                     rbins, rec, floor_kind, eps, info);
   return check_launch("k_ip1_small");
 }
 

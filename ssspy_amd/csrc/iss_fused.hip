@@ -25,6 +25,8 @@
 // While the updated slab is written back, |y|^2 is accumulated per (source, frame) over the bins of
 // the block and summed over the blocks (tree_fold) into r2_next: the frame powers r_nj^2 of the NEXT iteration's
 // auxiliary weights, which would otherwise need their own pass over Y (2 passes).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace ssspy {
@@ -282,6 +284,11 @@ constexpr int iss_max_fpt() {
 // again when the slabs are added up); keep >= ~4 blocks per CU.  With frame powers requested large
 // batches take up to 16 bins per block (3 %).
 static int iss_bins_per_block(int B, int F, bool with_r2) {
+  static const int forced = [] {
+    const char *e = getenv("SSSPY_AMD_ISS_BPB");  // experiments only
+    return e ? atoi(e) : 0;
+  }();
+  if (forced > 0 && with_r2) return forced;
   const long long want_blocks = 1024;
   int bpb = (int)(((long long)B * F + want_blocks - 1) / want_blocks);
   if (bpb < 1) bpb = 1;

@@ -16,13 +16,14 @@ namespace ssspy {
                            const double *, double *, int, int, int, int, int, int,              \
                            const double *, const double *, hipStream_t);                        \
   int mnmf_wcov_n##n(const void *, const double *, const double *, const double *, void *, int, \
-                     int, int, int, int, double *, hipStream_t);                                \
+                     int, int, int, int, double *, int *, long long *, hipStream_t);            \
   int mnmf_spatial_n##n(const void *, const void *, double *, const double *, const double *,   \
-                        int, int, int, int, int, double *, double *, double *, hipStream_t);    \
+                        int, int, int, int, int, double *, double *, double *, int,             \
+                        hipStream_t);                                                           \
   int mnmf_loss_n##n(const void *, const void *, const double *, const double *, const double *, \
                      double *, int, int, int, int, int, hipStream_t);                           \
   int mnmf_norm_scale_n##n(void *, double *, const double *, int, int, int, int, double,        \
-                           double *, hipStream_t);                                              \
+                           double *, int, hipStream_t);                                         \
   int mnmf_separate_n##n(const void *, const void *, void *, const double *, const double *,    \
                          const double *, void *, int, int, int, int, int, int, int, double,     \
                          int *, int *, hipStream_t);
@@ -40,6 +41,10 @@ DECL_N(2) DECL_N(3) DECL_N(4)
 int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, int F, int N,
                    int floor_kind, double floor_eps, int *info, hipStream_t st);
 int row_power(const void *W, const void *C, double *qbuf, int B, int F, int N, hipStream_t st);
+bool ip1_small_shape(int B, int F, int N);
+int ip1_from_records(void *W, const void *records, int nchunks, int rbins, long long rec_stride,
+                     const void *C, double *qbuf, int B, int F, int N, int floor_kind,
+                     double floor_eps, int *info, hipStream_t st);
 
 // general shapes (n_sources or n_channels above 4): the point-wise path of fmnmf_generic.hip
 size_t fmnmf_generic_workspace_doubles(int B, int N, int M, int F, int T);
@@ -114,14 +119,14 @@ __global__ __launch_bounds__(256) void k_mnmf_activation_finalize(double *act,
   const int b = blockIdx.z, n = blockIdx.y;
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long long)K * T) return;
-  double sn = 0.0, sd = 0.0;
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const long long base = ((((long long)b * nchunks + ch) * N + n) * 2) * K * T;
-    sn += part[base + e];
-    sd += part[base + (long long)K * T + e];
-  }
+  // chunks in order, eight loads per round trip (ordered_sum, common.hpp)
   double *dst = act + ((long long)b * N + n) * K * T + e;
-  *dst = apply_floor((*dst) * sqrt(sn / sd), floor_kind, eps);
+  const double vold = *dst;
+  const double *src = part + ((((long long)b * nchunks) * N + n) * 2) * K * T + e;
+  const long long stride = (long long)N * 2 * K * T;
+  const double sn = ordered_sum(src, stride, nchunks);
+  const double sd = ordered_sum(src + (long long)K * T, stride, nchunks);
+  *dst = apply_floor(vold * sqrt(sn / sd), floor_kind, eps);
 }
 
 // P / pscale: the |Q x|^2 hand-over (nullptr: the pass reads x and Q)
@@ -219,22 +224,33 @@ static int fastmnmf_update_impl(const void *X, const void *C, void *Q, double *D
   bool have_q = false;
   if (steps & SSSPY_MNMF_DIAGONALIZER) {
     void *U = ws + w.U;
+    // a handful of mixtures: every item of the pass is split, and IP1's latency form folds the
+    // partial records itself (no fold kernel, U is not materialised)
+    int split = 0;
+    long long rec = 0;
+    const bool small = ip1_small_shape(B, F, M);
     auto run = [&]() -> int {
       MNMF_DISPATCH(N, mnmf_wcov, X, D, basis, activation, U, B, M, F, T, K,
-                    (double *)(ws + w.tail), st);
+                    (double *)(ws + w.tail), small ? &split : nullptr, &rec, st);
     };
     rc = run();
     if (rc) return rc;
     // IP1 on the M x M diagonaliser with M weighted covariances per bin
-    rc = ip1_with_power(Q, U, C, C ? qbuf : nullptr, B, F, M, floor_kind, floor_eps, info, st);
+    if (split)
+      rc = ip1_from_records(Q, ws + w.tail, split, 64, rec, C, C ? qbuf : nullptr, B, F, M,
+                            floor_kind, floor_eps, info, st);
+    else
+      rc = ip1_with_power(Q, U, C, C ? qbuf : nullptr, B, F, M, floor_kind, floor_eps, info, st);
     if (rc) return rc;
     have_q = C != nullptr;
     have_p = false;  // Q moved
   }
+  bool fresh_scale = false;  // P written below and its scale left to the normalisation
   if (steps & SSSPY_MNMF_SPATIAL) {
+    fresh_scale = handover != nullptr && (steps & SSSPY_MNMF_NORMALIZE) != 0;
     auto run = [&]() -> int {
       MNMF_DISPATCH(N, mnmf_spatial, X, Q, D, basis, activation, B, M, F, T, K,
-                    (double *)(ws + w.tail), P, pscale, st);
+                    (double *)(ws + w.tail), P, pscale, fresh_scale ? 1 : 0, st);
     };
     rc = run();
     if (rc) return rc;
@@ -247,7 +263,7 @@ static int fastmnmf_update_impl(const void *X, const void *C, void *Q, double *D
     }
     auto run = [&]() -> int {
       MNMF_DISPATCH(N, mnmf_norm_scale, Q, D, qbuf, B, M, F, floor_kind, floor_eps,
-                    have_p ? pscale : nullptr, st);
+                    have_p ? pscale : nullptr, fresh_scale ? 1 : 0, st);
     };
     rc = run();
     if (rc) return rc;
@@ -304,7 +320,7 @@ int ssspy_fastmnmf_diagonalizer_covariance(const void *X, const double *D, const
                 "ssspy_fastmnmf_weights + ssspy_weighted_covariance");
   // no workspace at this entry point: the generic (unsplit) covariance kernel
   MNMF_DISPATCH(N, mnmf_wcov, X, D, basis, activation, U, B, M, F, T, K, (double *)nullptr,
-                as_stream(stream));
+                (int *)nullptr, (long long *)nullptr, as_stream(stream));
 }
 
 int ssspy_fastmnmf_weights(const void *X, const void *Q, const double *D, const double *basis,

@@ -937,15 +937,14 @@ __global__ __launch_bounds__(256) void k_mnmf_basis_finalize(double *basis,
   const int k = e & 15, lb = (e >> 4) & 63, n = e >> 10;
   const int bin = group * 64 + lb;
   if (n >= N || k >= K || bin >= F) return;
-  double sn = 0.0, sd = 0.0;
-  for (int ch = 0; ch < plan.split; ++ch) {
-    const double *src = tailpart + ((long long)tail_idx * plan.split + ch) * mnmf_tail_doubles<M>() +
-                        (long long)e * 2;
-    sn += src[0];
-    sd += src[1];
-  }
+  // (chunks in order, eight loads per round trip: ordered_sum, common.hpp)
   double *dst = basis + (((long long)b * N + n) * F + bin) * K + k;
-  *dst = apply_floor((*dst) * sqrt(sn / sd), floor_kind, eps);
+  const double told = *dst;
+  const double2 s = ordered_sum(
+      reinterpret_cast<const double2 *>(tailpart + (long long)tail_idx * plan.split *
+                                                       mnmf_tail_doubles<M>()) + e,
+      (long long)(mnmf_tail_doubles<M>() / 2), plan.split);
+  *dst = apply_floor(told * sqrt(s.x / s.y), floor_kind, eps);
 }
 
 // U[tail items] = sum of their chunks; grid: (64*M^3/256 rounded up, tail)
@@ -960,14 +959,11 @@ __global__ __launch_bounds__(256) void k_mnmf_wcov_fold(c128 *__restrict__ U,
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int lb = e / (M * M * M);
   if (e >= PER || group * 64 + lb >= F) return;
-  double re = 0.0, im = 0.0;
-  for (int ch = 0; ch < plan.split; ++ch) {
-    const c128 v = reinterpret_cast<const c128 *>(
-        tailpart + ((long long)tail_idx * plan.split + ch) * mnmf_tail_doubles<M>())[e];
-    re += v.x;
-    im += v.y;
-  }
-  U[((long long)b * F + group * 64) * (long long)(M * M * M) + e] = cmake(re, im);
+  const double2 s = ordered_sum(
+      reinterpret_cast<const double2 *>(tailpart + (long long)tail_idx * plan.split *
+                                                       mnmf_tail_doubles<M>()) + e,
+      (long long)(mnmf_tail_doubles<M>() / 2), plan.split);
+  U[((long long)b * F + group * 64) * (long long)(M * M * M) + e] = cmake(s.x, s.y);
 }
 
 // d <- d * sqrt(sum a / sum b); grid: (64*N*M/256 rounded up, tail)
@@ -982,15 +978,13 @@ __global__ __launch_bounds__(256) void k_mnmf_spatial_finalize(double *Dsp,
   const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (local bin, n, m)
   const int lb = e / (N * M);
   if (e >= PER || group * 64 + lb >= F) return;
-  double a = 0.0, bb = 0.0;
-  for (int ch = 0; ch < plan.split; ++ch) {
-    const double *src = tailpart + ((long long)tail_idx * plan.split + ch) * mnmf_tail_doubles<M>() +
-                        (long long)e * 2;
-    a += src[0];
-    bb += src[1];
-  }
   double *dst = Dsp + ((long long)b * F + group * 64) * (N * M) + e;
-  *dst = sqrt(a / bb) * (*dst);
+  const double dold = *dst;
+  const double2 s = ordered_sum(
+      reinterpret_cast<const double2 *>(tailpart + (long long)tail_idx * plan.split *
+                                                       mnmf_tail_doubles<M>()) + e,
+      (long long)(mnmf_tail_doubles<M>() / 2), plan.split);
+  *dst = sqrt(s.x / s.y) * dold;
 }
 
 // ------------------------------------------------------------ activation, frame-major fast variant
@@ -1287,41 +1281,86 @@ __global__ void k_mnmf_fill_ones(double *p, int n) {
   if (i < n) p[i] = 1.0;
 }
 
-// pscale (B, M), when given, takes the same 1 / psi_m^2 as D: |(Q x)_m|^2 = P * pscale stays true
+// pscale (B, M), when given, takes the same 1 / psi_m^2 as D: |(Q x)_m|^2 = P * pscale stays true.
+// pscale_fresh: P was written by the spatial pass of this very call (scale 1): store 1 / psi^2
+// instead of dividing -- the pass then need not reset the scale first.
+// grid: (ceil(F / 64), B).  Every block folds q over all bins (fixed order), but asks for its 64
+// diagonalisers and spatial rows BEFORE the reduction: one round trip instead of three.
 template <int M>
 __global__ __launch_bounds__(256) void k_mnmf_norm_scale(c128 *Q, double *Dsp,
                                                          const double *__restrict__ qbuf, int F,
                                                          int floor_kind, double eps,
-                                                         double *pscale) {
-  __shared__ double scratch[4];
+                                                         double *pscale, int pscale_fresh) {
+  __shared__ double wsum[4][M];
   __shared__ double psi[M];
   const int b = blockIdx.y;
+  const int i0 = blockIdx.x * 64;
+  const int nb = min(64, F - i0);
+  constexpr int QPT = (64 * M * M + 255) / 256, DPT = (64 * N * M + 255) / 256;
+  c128 *Qb = Q + ((long long)b * F + i0) * M * M;
+  double *Db = Dsp + ((long long)b * F + i0) * N * M;
+  c128 qv[QPT];
+  double dv[DPT];
+#pragma unroll
+  for (int u = 0; u < QPT; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    qv[u] = Qb[min(e, nb * M * M - 1)];
+  }
+#pragma unroll
+  for (int u = 0; u < DPT; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    dv[u] = Db[min(e, nb * N * M - 1)];
+  }
   const double *qb = qbuf + (long long)b * F * M;
-  for (int m = 0; m < M; ++m) {
+  {
+    const int m = threadIdx.x % M;
+    const int stride = (256 / M) * M;  // thread t sums entries t, t + stride, ...: all of channel m
     double local = 0.0;
-    for (int i = threadIdx.x; i < F; i += blockDim.x) local += qb[(long long)i * M + m];
-    const double total = block_sum(local, scratch);
-    if (threadIdx.x == 0) {
-      double v = total / (double)F;
+    if ((int)threadIdx.x < stride) {
+      const int total = F * M;
+      for (int e0 = threadIdx.x; e0 < total; e0 += 8 * stride) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = qb[min(e0 + u * stride, total - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) local += e0 + u * stride < total ? v[u] : 0.0;
+      }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int m2 = 0; m2 < M; ++m2) {
+      const double tot = wave_sum(m == m2 ? local : 0.0);
+      if (lane == 0) wsum[wave][m2] = tot;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < M) {
+      double v = 0.0;
+      for (int w = 0; w < 4; ++w) v += wsum[w][threadIdx.x];
+      v = v / (double)F;
       v = v < 0.0 ? 0.0 : v;
-      psi[m] = apply_floor(sqrt(v), floor_kind, eps);
+      psi[threadIdx.x] = apply_floor(sqrt(v), floor_kind, eps);
     }
   }
   __syncthreads();
-  if (pscale && blockIdx.x == 0 && threadIdx.x < M)
-    pscale[b * M + threadIdx.x] /= psi[threadIdx.x] * psi[threadIdx.x];
-  const int i0 = blockIdx.x * 64;
-  const int nb = min(64, F - i0);
-  c128 *Qb = Q + ((long long)b * F + i0) * M * M;
-  for (int e = threadIdx.x; e < nb * M * M; e += blockDim.x) {
-    const int m = (e / M) % M;
-    const c128 v = Qb[e];
-    Qb[e] = cmake(v.x / psi[m], v.y / psi[m]);
+  if (pscale && blockIdx.x == 0 && threadIdx.x < M) {
+    const double p2 = psi[threadIdx.x] * psi[threadIdx.x];
+    pscale[b * M + threadIdx.x] = (pscale_fresh ? 1.0 : pscale[b * M + threadIdx.x]) / p2;
   }
-  double *Db = Dsp + ((long long)b * F + i0) * N * M;
-  for (int e = threadIdx.x; e < nb * N * M; e += blockDim.x) {
-    const int m = e % M;
-    Db[e] = Db[e] / (psi[m] * psi[m]);
+#pragma unroll
+  for (int u = 0; u < QPT; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    if (e < nb * M * M) {
+      const int m = (e / M) % M;
+      Qb[e] = cmake(qv[u].x / psi[m], qv[u].y / psi[m]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < DPT; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    if (e < nb * N * M) {
+      const int m = e % M;
+      Db[e] = dv[u] / (psi[m] * psi[m]);
+    }
   }
 }
 
@@ -1766,21 +1805,31 @@ int LAUNCHER(mnmf_activation)(const void *X, const void *Q, const double *Dsp, c
   return check_launch("k_mnmf_activation");
 }
 
+// split_out / rec_out (optional, a caller that can fold the partial records itself -- IP1's latency
+// form): when every item was split the fold is skipped, *split_out = chunks per item (else 0) and
+// *rec_out = c128 between records; the records sit in tailpart as [(b groups + group) split + ch],
+// 64 bins x M^3 each.
 int LAUNCHER(mnmf_wcov)(const void *X, const double *Dsp, const double *basis, const double *act,
                         void *U, int B, int M, int F, int T, int K, double *tailpart,
-                        hipStream_t st) {
+                        int *split_out, long long *rec_out, hipStream_t st) {
   Dims d{B, F, T, K};
+  if (split_out) *split_out = 0;
   if (mnmf_fast_ok(B, F, T, K) && tailpart) {
     const TailPlan plan = mnmf_plan(B, F, T);
     dim3 fgrid(plan.full + plan.tail * plan.split);
+    const bool records = split_out && rec_out && plan.full == 0 && plan.tail > 0;
     MNMF_DISPATCH_M(M, {
       hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_WCOV>), fgrid, dim3(256), 0, st,
                          (const c128 *)X, (const c128 *)nullptr, (double *)Dsp, (double *)basis, act,
                          (c128 *)U, F, T, K, 0, 0.0, plan, tailpart, (double *)nullptr,
                          (const double *)nullptr);
-      if (plan.tail > 0)
+      if (records) {
+        *split_out = plan.split;
+        *rec_out = mnmf_tail_doubles<MM>() / 2;
+      } else if (plan.tail > 0) {
         hipLaunchKernelGGL((k_mnmf_wcov_fold<MM>), dim3((64 * MM * MM * MM + 255) / 256, plan.tail),
                            dim3(256), 0, st, (c128 *)U, tailpart, F, plan);
+      }
     });
     return check_launch("k_mnmf_wcov_fast");
   }
@@ -1797,15 +1846,17 @@ int LAUNCHER(mnmf_wcov)(const void *X, const double *Dsp, const double *basis, c
   return check_launch("k_mnmf_wcov");
 }
 
-// P / pscale (optional): the pass also writes |Q x|^2 for the next basis and activation passes
+// P / pscale (optional): the pass also writes |Q x|^2 for the next basis and activation passes.
+// scale_follows: the caller normalises next and lets k_mnmf_norm_scale store the scale
+// (pscale_fresh), so it is not reset to 1 here.
 int LAUNCHER(mnmf_spatial)(const void *X, const void *Q, double *Dsp, const double *basis,
                            const double *act, int B, int M, int F, int T, int K, double *tailpart,
-                           double *P, double *pscale, hipStream_t st) {
+                           double *P, double *pscale, int scale_follows, hipStream_t st) {
   Dims d{B, F, T, K};
   if (mnmf_fast_ok(B, F, T, K)) {
     const TailPlan plan = mnmf_plan(B, F, T);
     dim3 fgrid(plan.full + plan.tail * plan.split);
-    if (P)
+    if (P && !scale_follows)
       hipLaunchKernelGGL(k_mnmf_fill_ones, dim3((B * M + 255) / 256), dim3(256), 0, st, pscale,
                          B * M);
     MNMF_DISPATCH_M(M, {
@@ -1871,10 +1922,11 @@ int LAUNCHER(mnmf_loss_handover)(const double *Dsp, const double *basis, const d
 }
 
 int LAUNCHER(mnmf_norm_scale)(void *Q, double *Dsp, const double *qbuf, int B, int M, int F,
-                              int floor_kind, double eps, double *pscale, hipStream_t st) {
+                              int floor_kind, double eps, double *pscale, int pscale_fresh,
+                              hipStream_t st) {
   dim3 grid((F + 63) / 64, B), block(256);
   MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_norm_scale<MM>), grid, block, 0, st, (c128 *)Q, Dsp,
-                                        qbuf, F, floor_kind, eps, pscale));
+                                        qbuf, F, floor_kind, eps, pscale, pscale_fresh));
   return check_launch("k_mnmf_norm_scale");
 }
 

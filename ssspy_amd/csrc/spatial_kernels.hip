@@ -588,27 +588,46 @@ using namespace ssspy;
 namespace ssspy {
 // ilrma_small.hip: the latency form (16-bin workgroups, four lanes per bin, operands in LDS)
 #define DECL_SMALL_IP1(n)                                                                          \
-  int ilrma_small_ip1_n##n(const void *, int, int, const void *, void *, int, int, int, double,    \
-                           double *, int *, hipStream_t);
+  int ilrma_small_ip1_n##n(const void *, int, int, long long, const void *, void *, int, int, int, \
+                           double, double *, int *, hipStream_t);
 DECL_SMALL_IP1(2) DECL_SMALL_IP1(3) DECL_SMALL_IP1(4)
 #undef DECL_SMALL_IP1
+
+static bool small_ip1_off() {
+  static const bool off = [] {
+    const char *e = std::getenv("SSSPY_AMD_SMALL_MAX_ITEMS");
+    return e && std::atoll(e) == 0;
+  }();
+  return off;
+}
+
+// Does the latency form of IP1 (ilrma_small.hip) serve this shape?  It also folds the partial
+// records a split covariance pass leaves (ip1_from_records), so callers ask before they fold.
+bool ip1_small_shape(int B, int F, int N) {
+  return !small_ip1_off() && N >= 2 && N <= 4 && (long long)B * F <= 16384;
+}
+
+// IP1 (+ output power) straight from the partial covariance records of a pass whose every item was
+// split: records[(b * groups + group) * nchunks + ch] hold rbins bins x N^3 complex each, rec_stride
+// c128 apart.  Only for ip1_small_shape().
+int ip1_from_records(void *W, const void *records, int nchunks, int rbins, long long rec_stride,
+                     const void *C, double *qbuf, int B, int F, int N, int floor_kind,
+                     double floor_eps, int *info, hipStream_t st) {
+  switch (N) {
+    case 2: return ilrma_small_ip1_n2(records, nchunks, rbins, rec_stride, C, W, B, F, floor_kind, floor_eps, qbuf, info, st);
+    case 3: return ilrma_small_ip1_n3(records, nchunks, rbins, rec_stride, C, W, B, F, floor_kind, floor_eps, qbuf, info, st);
+    case 4: return ilrma_small_ip1_n4(records, nchunks, rbins, rec_stride, C, W, B, F, floor_kind, floor_eps, qbuf, info, st);
+    default: return fail(SSSPY_ERR_INTERNAL, "ip1_from_records: shape off the small path");
+  }
+}
 
 int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, int F, int N,
                    int floor_kind, double floor_eps, int *info, hipStream_t st) {
   const long long nbins = (long long)B * F;
   // a handful of mixtures: one lane per bin would leave the chip to 17 waves running a chain of
   // ~5000 dependent fp64 instructions each (17 us at 1025 bins); four lanes per bin take 12
-  static const bool small_off = [] {
-    const char *e = std::getenv("SSSPY_AMD_SMALL_MAX_ITEMS");
-    return e && std::atoll(e) == 0;
-  }();
-  if (!small_off && N >= 2 && N <= 4 && nbins <= 16384) {
-    switch (N) {
-      case 2: return ilrma_small_ip1_n2(U, 0, 0, C, W, B, F, floor_kind, floor_eps, qbuf, info, st);
-      case 3: return ilrma_small_ip1_n3(U, 0, 0, C, W, B, F, floor_kind, floor_eps, qbuf, info, st);
-      default: return ilrma_small_ip1_n4(U, 0, 0, C, W, B, F, floor_kind, floor_eps, qbuf, info, st);
-    }
-  }
+  if (ip1_small_shape(B, F, N))
+    return ip1_from_records(W, U, 0, 0, 0, C, qbuf, B, F, N, floor_kind, floor_eps, info, st);
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
   if (N > 4) {  // a bin on 8 lanes, one per row
     dim3 g8((unsigned)((nbins * 8 + 255) / 256)), b8(256);
