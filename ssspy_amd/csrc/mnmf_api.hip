@@ -18,12 +18,12 @@ namespace ssspy {
   int mnmf_wcov_n##n(const void *, const double *, const double *, const double *, void *, int, \
                      int, int, int, int, double *, int *, long long *, hipStream_t);            \
   int mnmf_spatial_n##n(const void *, const void *, double *, const double *, const double *,   \
-                        int, int, int, int, int, double *, double *, double *, int,             \
+                        int, int, int, int, int, double *, double *, double *, int, int *,      \
                         hipStream_t);                                                           \
   int mnmf_loss_n##n(const void *, const void *, const double *, const double *, const double *, \
                      double *, int, int, int, int, int, hipStream_t);                           \
   int mnmf_norm_scale_n##n(void *, double *, const double *, int, int, int, int, double,        \
-                           double *, int, hipStream_t);                                         \
+                           double *, int, const double *, int, hipStream_t);                    \
   int mnmf_separate_n##n(const void *, const void *, void *, const double *, const double *,    \
                          const double *, void *, int, int, int, int, int, int, int, double,     \
                          int *, int *, hipStream_t);
@@ -246,11 +246,14 @@ static int fastmnmf_update_impl(const void *X, const void *C, void *Q, double *D
     have_p = false;  // Q moved
   }
   bool fresh_scale = false;  // P written below and its scale left to the normalisation
+  int spatial_split = 0;     // > 0: the fold of the spatial pass is left to the normalisation too
   if (steps & SSSPY_MNMF_SPATIAL) {
-    fresh_scale = handover != nullptr && (steps & SSSPY_MNMF_NORMALIZE) != 0;
+    const bool norm_next = (steps & SSSPY_MNMF_NORMALIZE) != 0;
+    fresh_scale = handover != nullptr && norm_next;
     auto run = [&]() -> int {
       MNMF_DISPATCH(N, mnmf_spatial, X, Q, D, basis, activation, B, M, F, T, K,
-                    (double *)(ws + w.tail), P, pscale, fresh_scale ? 1 : 0, st);
+                    (double *)(ws + w.tail), P, pscale, fresh_scale ? 1 : 0,
+                    norm_next ? &spatial_split : (int *)nullptr, st);
     };
     rc = run();
     if (rc) return rc;
@@ -263,7 +266,8 @@ static int fastmnmf_update_impl(const void *X, const void *C, void *Q, double *D
     }
     auto run = [&]() -> int {
       MNMF_DISPATCH(N, mnmf_norm_scale, Q, D, qbuf, B, M, F, floor_kind, floor_eps,
-                    have_p ? pscale : nullptr, fresh_scale ? 1 : 0, st);
+                    have_p ? pscale : nullptr, fresh_scale ? 1 : 0,
+                    (const double *)(ws + w.tail), spatial_split, st);
     };
     rc = run();
     if (rc) return rc;

@@ -1290,7 +1290,9 @@ template <int M>
 __global__ __launch_bounds__(256) void k_mnmf_norm_scale(c128 *Q, double *Dsp,
                                                          const double *__restrict__ qbuf, int F,
                                                          int floor_kind, double eps,
-                                                         double *pscale, int pscale_fresh) {
+                                                         double *pscale, int pscale_fresh,
+                                                         const double *__restrict__ tailpart,
+                                                         int split) {
   __shared__ double wsum[4][M];
   __shared__ double psi[M];
   const int b = blockIdx.y;
@@ -1310,6 +1312,19 @@ __global__ __launch_bounds__(256) void k_mnmf_norm_scale(c128 *Q, double *Dsp,
   for (int u = 0; u < DPT; ++u) {
     const int e = threadIdx.x + 256 * u;
     dv[u] = Db[min(e, nb * N * M - 1)];
+  }
+  if (tailpart) {
+    // the spatial pass of this call left the (a, b) sums of this bin group as `split` partial
+    // records (every item split: a handful of mixtures); its fold d <- d sqrt(sum a / sum b)
+    // (k_mnmf_spatial_finalize) happens here, on the way
+    const double2 *rec = reinterpret_cast<const double2 *>(
+        tailpart + ((long long)b * gridDim.x + blockIdx.x) * split * mnmf_tail_doubles<M>());
+#pragma unroll
+    for (int u = 0; u < DPT; ++u) {
+      const int e = min((int)threadIdx.x + 256 * u, nb * N * M - 1);
+      const double2 s = ordered_sum(rec + e, (long long)(mnmf_tail_doubles<M>() / 2), split);
+      dv[u] = sqrt(s.x / s.y) * dv[u];
+    }
   }
   const double *qb = qbuf + (long long)b * F * M;
   {
@@ -1849,9 +1864,14 @@ int LAUNCHER(mnmf_wcov)(const void *X, const double *Dsp, const double *basis, c
 // P / pscale (optional): the pass also writes |Q x|^2 for the next basis and activation passes.
 // scale_follows: the caller normalises next and lets k_mnmf_norm_scale store the scale
 // (pscale_fresh), so it is not reset to 1 here.
+// split_out (optional; only a caller that runs mnmf_norm_scale next may pass it): when every item
+// was split, the fold of the partial records is left to that kernel and *split_out = chunks per
+// item (else 0).
 int LAUNCHER(mnmf_spatial)(const void *X, const void *Q, double *Dsp, const double *basis,
                            const double *act, int B, int M, int F, int T, int K, double *tailpart,
-                           double *P, double *pscale, int scale_follows, hipStream_t st) {
+                           double *P, double *pscale, int scale_follows, int *split_out,
+                           hipStream_t st) {
+  if (split_out) *split_out = 0;
   Dims d{B, F, T, K};
   if (mnmf_fast_ok(B, F, T, K)) {
     const TailPlan plan = mnmf_plan(B, F, T);
@@ -1870,7 +1890,9 @@ int LAUNCHER(mnmf_spatial)(const void *X, const void *Q, double *Dsp, const doub
                          (const c128 *)X, (const c128 *)Q, Dsp, (double *)basis, act,
                          (c128 *)nullptr, F, T, K, 0, 0.0, plan, tailpart, (double *)nullptr,
                          (const double *)nullptr);
-      if (plan.tail > 0)
+      if (split_out && plan.full == 0 && plan.tail > 0)
+        *split_out = plan.split;
+      else if (plan.tail > 0)
         hipLaunchKernelGGL((k_mnmf_spatial_finalize<MM>), dim3((64 * N * MM + 255) / 256, plan.tail),
                            dim3(256), 0, st, Dsp, tailpart, F, plan);
     });
@@ -1923,10 +1945,13 @@ int LAUNCHER(mnmf_loss_handover)(const double *Dsp, const double *basis, const d
 
 int LAUNCHER(mnmf_norm_scale)(void *Q, double *Dsp, const double *qbuf, int B, int M, int F,
                               int floor_kind, double eps, double *pscale, int pscale_fresh,
-                              hipStream_t st) {
+                              const double *spatial_records, int spatial_split, hipStream_t st) {
+  // spatial_records / spatial_split: see mnmf_spatial's split_out
   dim3 grid((F + 63) / 64, B), block(256);
   MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_norm_scale<MM>), grid, block, 0, st, (c128 *)Q, Dsp,
-                                        qbuf, F, floor_kind, eps, pscale, pscale_fresh));
+                                        qbuf, F, floor_kind, eps, pscale, pscale_fresh,
+                                        spatial_split ? spatial_records : (const double *)nullptr,
+                                        spatial_split));
   return check_launch("k_mnmf_norm_scale");
 }
 
