@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libssspy_amd.so")
+# SSSPY_AMD_LIB: another build of the same library (A / B runs of kernel experiments)
+LIB_PATH = os.environ.get("SSSPY_AMD_LIB") or os.path.join(_PKG, "lib", "libssspy_amd.so")
 
 OK, ERR_BADARG, ERR_HIP, ERR_UNSUPPORTED, ERR_INTERNAL = 0, 1, 2, 3, 4
 FLOOR_NONE, FLOOR_MAX, FLOOR_ADD = 0, 1, 2
