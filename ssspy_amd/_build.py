@@ -54,12 +54,21 @@ def _units():
         ("wide_cov.hip", "wide_cov.o", []),
     ]
     units.append(("mnmf_api.hip", "mnmf_api.o", []))
+    # Scheduling strategy per unit (measured A / B on one box, benchmarks/tools/ab_lib.sh): hipcc's
+    # max-ilp strategy gains 3.6 % on the ILRMA basis pass and 4.6 % on the FastMNMF iteration, loses
+    # 6 % on the ILRMA activation pass and 26 % on the fused ISS sweep -- so it is set for exactly the
+    # units that gain (the basis pass is its own unit for this: SSSPY_FAST_PART).
+    max_ilp = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
     for n in MNMF_N:
-        units.append(("mnmf_kernels.hip", "mnmf_kernels_n{}.o".format(n), ["-DSSSPY_N={}".format(n)]))
+        units.append(("mnmf_kernels.hip", "mnmf_kernels_n{}.o".format(n),
+                      ["-DSSSPY_N={}".format(n)] + max_ilp))
     for n in ILRMA_N:
         units.append(("ilrma_kernels.hip", "ilrma_kernels_n{}.o".format(n), ["-DSSSPY_N={}".format(n)]))
     for n in ILRMA_FAST_N:
-        units.append(("ilrma_fast.hip", "ilrma_fast_n{}.o".format(n), ["-DSSSPY_N={}".format(n)]))
+        units.append(("ilrma_fast.hip", "ilrma_fast_basis_n{}.o".format(n),
+                      ["-DSSSPY_N={}".format(n), "-DSSSPY_FAST_PART=1"] + max_ilp))
+        units.append(("ilrma_fast.hip", "ilrma_fast_n{}.o".format(n),
+                      ["-DSSSPY_N={}".format(n), "-DSSSPY_FAST_PART=2"]))
         units.append(("ilrma_small.hip", "ilrma_small_n{}.o".format(n), ["-DSSSPY_N={}".format(n)]))
     return units
 

@@ -63,6 +63,17 @@ using fast::XPATCH;
 typedef fast::VStage<N> VStage;
 typedef fast::XTile<N> XTile;
 
+#ifndef SSSPY_FAST_PART
+#define SSSPY_FAST_PART 0  // 0: the whole file; 1: the basis pass only; 2: everything else
+#endif
+// (the build compiles the basis pass as its own unit: it alone gains from the max-ilp scheduling
+//  strategy -- 1.140 -> 1.099 ms at 128 mixtures, the activation pass loses 6 % with it; _build.py)
+
+// IN: what X holds -- IN_X the mixture (filter applied here), IN_Y the separated spectrogram, IN_P its
+// power |y|^2 as (B, N, F, T) f64 (the grouped passes of a wide mixture: half the bytes).
+enum { IN_Y = 0, IN_X = 1, IN_P = 2 };
+
+#if SSSPY_FAST_PART != 2
 // =============================================================================== basis (pass 1)
 // grid: (ceil(F/64), 1, B); 256 threads; wave w owns bins [64*bx + 16w, +16).
 // Register diet for 2 waves per SIMD (<= 256 VGPR+AGPR): the demixing rows live in LDS and are
@@ -83,9 +94,6 @@ typedef fast::XTile<N> XTile;
 // kernels.  Its 64-register basis operand only fits because |y|^2 of all sources is formed first
 // (the x tile is dead before GEMM1's operands go live); results go to `basis_out` (the sibling
 // item still reads the old basis), which the launcher copies back.
-// IN: what X holds -- IN_X the mixture (filter applied here), IN_Y the separated spectrogram, IN_P its
-// power |y|^2 as (B, N, F, T) f64 (the grouped passes of a wide mixture: half the bytes).
-enum { IN_Y = 0, IN_X = 1, IN_P = 2 };
 template <int IN, int MODEL, bool LOSS, int KS>
 __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 *__restrict__ X,
                                                        const c128 *__restrict__ W,
@@ -295,6 +303,9 @@ __global__ __launch_bounds__(256) void k_basis_finalize(const double *basis, dou
   }
 }
 
+#endif  // basis part
+
+#if SSSPY_FAST_PART != 1
 // ================================================================================ loss data
 // out[b] += sum_{n,i} mean_j ( |y|^2 / R + log R ), the data term of compute_loss().  Same walk as
 // the basis pass without its second GEMM; the logarithms are summed as a mantissa product and an
@@ -793,6 +804,7 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_activation_fast(
     }
 }
 
+#endif  // other passes
 }  // namespace ilrma_fast_n<N>
 using namespace SSSPY_CAT(ilrma_fast_n, SSSPY_N);
 using fast::make_fast_model;
@@ -818,6 +830,7 @@ using fast::make_fast_model;
     }                                                       \
   } while (0)
 
+#if SSSPY_FAST_PART != 2
 // `part` must hold the scratch of ilrma_api.hip's basis_part_bytes() (used only when items are split)
 // loss_out: nullptr, or B zeroed doubles that receive the data term of the loss of the state at entry.
 // K <= 16: basis_out == basis (in place); 16 < K <= 32: basis_out must be a separate (B,N,F,K) buffer
@@ -884,6 +897,9 @@ int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis
   return check_launch("k_basis_finalize");
 }
 
+#endif
+
+#if SSSPY_FAST_PART != 1
 int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *basis,
                                     const double *act, double *part, int nchunks, int B, int F,
                                     int T, int K, int fmodel, double mparam, int power_in,
@@ -996,6 +1012,8 @@ int LAUNCHER(ilrma_fast_wcov_frame)(const void *X, const double *weight, void *U
                      weight, (c128 *)U, F, T, groups);
   return check_launch("k_wcov_frame_fast");
 }
+
+#endif
 
 #undef SSSPY_FAST_LAUNCH2
 #undef SSSPY_FAST_LAUNCH_M
