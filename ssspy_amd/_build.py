@@ -70,6 +70,13 @@ def _units():
         units.append(("ilrma_fast.hip", "ilrma_fast_n{}.o".format(n),
                       ["-DSSSPY_N={}".format(n), "-DSSSPY_FAST_PART=2"]))
         units.append(("ilrma_small.hip", "ilrma_small_n{}.o".format(n), ["-DSSSPY_N={}".format(n)]))
+    # experiments: SSSPY_AMD_UNIT_FLAGS="ilrma_fast_n=-mllvm -x=y;iss_fused=-O2" appends flags to the
+    # units whose object name starts with the given prefix (benchmarks/tools/build_variant.sh)
+    spec = os.environ.get("SSSPY_AMD_UNIT_FLAGS", "")
+    for item in [t for t in spec.split(";") if "=" in t]:
+        prefix, flags = item.split("=", 1)
+        units = [(s, o, e + flags.split()) if o.startswith(prefix.strip()) else (s, o, e)
+                 for s, o, e in units]
     return units
 
 
