@@ -413,6 +413,18 @@ __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X
 // x x^H products it needs; the x loads of the two group-waves hit the same L1 lines.
 // fp64 MFMA and fp64 VALU do not overlap on gfx950 (benchmarks/micro/f64_rates.hip), so what the
 // second resident wave per SIMD hides is LDS / HBM latency, not arithmetic.
+// Round 3 built the alternative -- a wave owning its bin tile for ALL four sources (no duplicate
+// x x^H products: -28 % VALU instructions; one fetch of the x tile: half the requests) -- three
+// ways and measured each at 128 mixtures against this kernel's 0.92 ms: (i) two waves per SIMD
+// with the x tile fetched by LDS-direct loads (buffer_load_dwordx4 ... lds, bank-conflict-free
+// through a swizzle on the source side, no staging registers): 1.86 ms -- at the 256-register
+// budget hipcc parks the GEMM1 operand in scratch and reloads it before every MFMA behind a full
+// s_waitcnt; (ii) one wave per SIMD (no spills), LDS-direct loads double-buffered one tile ahead:
+// 1.97 ms; (iii) one wave per SIMD with the next tile prefetched into a second register set:
+// 2.00 ms, of which 1.45 ms remain with the x loads removed altogether -- a single wave per SIMD
+// exposes the latency of every dependent fp64 chain (reciprocal + Newton steps, accumulator
+// round trips through AGPRs, the per-frame LDS reads), which the second wave of the split form
+// hides.  Correct in all three forms (parity suite), not kept.
 constexpr int WC_SG = N >= 4 ? 2 : N;            // sources per wave
 constexpr int WC_NG = (N + WC_SG - 1) / WC_SG;   // source groups
 constexpr int WC_WB = 4 / WC_NG;                 // bin tiles per workgroup
