@@ -141,8 +141,8 @@ int ssspy_iss1_fused_max_frames(int N);
  * r2_next (B,N,T), optional: receives sum_i |y_new|^2 -- the frame powers the next AuxIVA iteration
  * needs, saving its separate pass.  They are summed without atomics (every block leaves its bins' sums
  * in `workspace`, a second kernel adds them in block order), so the result -- and with it the
- * trajectory -- is the same on every run; `workspace` (ssspy_iss1_fused_workspace_bytes) is needed only
- * with r2_next.
+ * trajectory -- is the same on every run; `workspace` (ssspy_iss1_fused_workspace_bytes) is needed
+ * with r2_next (and by the tracked form below).
  * replaces: ssspy/bss/_update_spatial_model.py:146-194 (update_by_iss1). */
 size_t ssspy_iss1_fused_workspace_bytes(int B, int N, int F, int T);
 int ssspy_iss1_fused(void *Y, const double *weight, int weight_kind, double *r2_next, int B, int N,
@@ -152,7 +152,8 @@ int ssspy_iss1_fused(void *Y, const double *weight, int weight_kind, double *r2_
 /* The same sweep set, also tracking the log-determinant of the demixing filter the ISS state never
  * forms: the sweep of source n multiplies W_i by (I - v e_n^T), det = d_in^(-1/2), so
  * logdet[b] += -1/2 sum_i sum_n log d_in (logdet: B doubles holding sum_i log|det W_i| of the Y
- * passed in; NOT zeroed by the call).  Lets compute_loss() (ssspy/bss/iva.py:2177-2192) skip the
+ * passed in; NOT zeroed by the call; the blocks' shares go through `workspace` and are added in
+ * block order: no atomics).  Lets compute_loss() (ssspy/bss/iva.py:2177-2192) skip the
  * reconstruction of W from Y X^H -- two more passes per recorded loss. */
 int ssspy_iss1_fused_tracked(void *Y, const double *weight, int weight_kind, double *r2_next, int B,
                              int N, int F, int T, int floor_kind, double floor_eps, double *logdet,
@@ -289,11 +290,16 @@ int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *act
                            void *stream);
 
 /* out[b] = sum_{n,i} mean_j ( data term of the model + (2/p) log R ), y = W x (or x when
- * W == NULL); `out` (B doubles) is zeroed by the call.  The caller adds -2 * ssspy_sum_logdet.
+ * W == NULL); `out` (B doubles) is overwritten.  The caller adds -2 * ssspy_sum_logdet.
+ * The per-workgroup shares are parked in `workspace` (ssspy_ilrma_loss_workspace_bytes; the
+ * workspace of ssspy_ilrma_workspace_bytes is large enough too) and added up in a fixed order:
+ * no fp64 atomics, the same bits on every run.
  * replaces: ssspy/bss/ilrma.py:1946-1965, :3291-3310, :4367-4386. */
+size_t ssspy_ilrma_loss_workspace_bytes(int B, int N, int F);
 int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
                           const double *activation, double *out, int B, int N, int F, int T, int K,
-                          double domain, int source_model, double model_param, void *stream);
+                          double domain, int source_model, double model_param, void *workspace,
+                          size_t workspace_bytes, void *stream);
 
 /* One whole update_once() of an ILRMA with spatial_algorithm="IP1", source_algorithm="MM": basis,
  * activation, weighted covariance, IP1, power normalisation -- the launches the host would otherwise
@@ -306,7 +312,7 @@ int ssspy_ilrma_ip1_update(const void *X, const void *C, void *W, double *basis,
                            void *stream);
 
 /* The same update_once(), which also leaves the negative log-likelihood of the state AT ENTRY:
- * loss_data[b] (B doubles, zeroed by the call) = the data term ssspy_ilrma_loss_data would give,
+ * loss_data[b] (B doubles, overwritten) = the data term ssspy_ilrma_loss_data would give,
  * logdet[b] = ssspy_sum_logdet(W) before W is rewritten; loss = loss_data - 2 logdet.  The data term
  * is a by-product of the basis pass (which forms |y|^2 and R under the same parameters), so a loop
  * with record_loss=True costs three passes over X per iteration, not four: the loss after iteration t

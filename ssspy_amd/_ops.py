@@ -242,7 +242,7 @@ def iss1_fused(Y, weight, kind, flooring, r2_next=None, logdet=None):
     sum_i log|det W_i| of the implied demixing filters along with the sweeps."""
     B, N, F, T = Y.shape
     ws, ws_bytes = (None, 0)
-    if r2_next is not None:
+    if r2_next is not None or logdet is not None:
         ws, ws_bytes = _scratch(_L().ssspy_iss1_fused_workspace_bytes(B, N, F, T), Y.device)
     if logdet is not None:
         _lib.check(
@@ -410,9 +410,10 @@ def ilrma_loss_data(X, W, basis, activation, domain, out=None, model=GAUSS):
     K = basis.shape[-1]
     if out is None:
         out = dv.empty((B,), dv.f64, X.device)
+    ws, ws_bytes = _scratch(_L().ssspy_ilrma_loss_workspace_bytes(B, N, F), X.device)
     _lib.check(
         _L().ssspy_ilrma_loss_data(ptr(X), ptr(W), ptr(basis), ptr(activation), ptr(out), B, N, F,
-                                   T, K, domain, model[0], model[1], _st()),
+                                   T, K, domain, model[0], model[1], ptr(ws), ws_bytes, _st()),
         "ilrma_loss_data",
     )
     return out

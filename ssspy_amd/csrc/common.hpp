@@ -224,10 +224,12 @@ __host__ __device__ inline int fold_groups(int nslabs) {
 // out[e] = sum_k slabs[k * total + e] (k < nslabs, in order), e < total (in units of V).
 // grid: (ceil(total / 256), fold_groups(nslabs)); gslabs: groups * total V of scratch;
 // counters: gridDim.x zeroed words.
+// accumulate: out[e] += the sum (one writer per element: still the same bits on every run)
 template <typename V>
 static __global__ __launch_bounds__(256) void k_fold_slabs(const V *__restrict__ slabs, V *gslabs,
                                                            unsigned *counters, V *out,
-                                                           long long total, int nslabs) {
+                                                           long long total, int nslabs,
+                                                           int accumulate) {
   __shared__ int flag;
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   const bool live = e < total;
@@ -235,12 +237,20 @@ static __global__ __launch_bounds__(256) void k_fold_slabs(const V *__restrict__
   const int members = min(FOLD_GROUP, nslabs - g * FOLD_GROUP);
   const V s = live ? ordered_sum(slabs + (long long)g * FOLD_GROUP * total + e, total, members) : V{};
   if (ng == 1) {
-    if (live) out[e] = s;
+    if (live) {
+      V r = s;
+      if (accumulate) r += out[e];
+      out[e] = r;
+    }
     return;
   }
   if (live) gslabs[(long long)g * total + e] = s;
   if (!last_arriver(counters + blockIdx.x, (unsigned)ng, &flag)) return;
-  if (live) out[e] = ordered_sum(gslabs + e, total, ng);
+  if (live) {
+    V r = ordered_sum(gslabs + e, total, ng);
+    if (accumulate) r += out[e];
+    out[e] = r;
+  }
 }
 
 // host side: scratch behind the slabs and the launch.  `scratch` holds fold_scratch_bytes(...).
@@ -250,7 +260,7 @@ static inline size_t fold_scratch_bytes(long long total, int nslabs) {
   return (size_t)ng * total * sizeof(double) + (size_t)((total + 255) / 256) * sizeof(unsigned);
 }
 static inline int launch_fold_slabs(const double *slabs, void *scratch, double *out, long long total,
-                             int nslabs, hipStream_t st) {
+                             int nslabs, hipStream_t st, int accumulate = 0) {
   const int ng = fold_groups(nslabs);
   double *gslabs = (double *)scratch;
   unsigned *counters = ng > 1 ? (unsigned *)(gslabs + (size_t)ng * total) : nullptr;
@@ -265,11 +275,29 @@ static inline int launch_fold_slabs(const double *slabs, void *scratch, double *
   }
   if (pairs)
     hipLaunchKernelGGL(k_fold_slabs<double2>, dim3(gx, ng), dim3(256), 0, st, (const double2 *)slabs,
-                       (double2 *)gslabs, counters, (double2 *)out, units, nslabs);
+                       (double2 *)gslabs, counters, (double2 *)out, units, nslabs, accumulate);
   else
     hipLaunchKernelGGL(k_fold_slabs<double>, dim3(gx, ng), dim3(256), 0, st, slabs, gslabs, counters,
-                       out, units, nslabs);
+                       out, units, nslabs, accumulate);
   return check_launch("k_fold_slabs");
+}
+
+// ---- per-mixture scalars (loss terms) without atomics: contributor `slot` of mixture b stores its
+// share to slots[slot * B + b] (every contributor its own slot; slots nobody writes stay zero), the
+// launcher zeroes the slots first and folds them in slot order afterwards.
+static inline size_t scalar_slots_bytes(int B, int nslots) {
+  const size_t a = ((size_t)nslots * B * sizeof(double) + 255) & ~(size_t)255;
+  return a + ((fold_scratch_bytes(B, nslots) + 255) & ~(size_t)255);
+}
+static inline int scalar_slots_begin(void *ws, int B, int nslots, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(ws, 0, (size_t)nslots * B * sizeof(double), st);
+  return e == hipSuccess ? SSSPY_OK : fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+}
+// out[b] (+)= sum over slots
+static inline int scalar_slots_fold(void *ws, int B, int nslots, double *out, int accumulate,
+                                    hipStream_t st) {
+  const size_t a = ((size_t)nslots * B * sizeof(double) + 255) & ~(size_t)255;
+  return launch_fold_slabs((const double *)ws, (char *)ws + a, out, B, nslots, st, accumulate);
 }
 
 __device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c) {

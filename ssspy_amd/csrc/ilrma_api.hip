@@ -15,8 +15,9 @@ namespace ssspy {
                             int, IlrmaDims, hipStream_t);                                      \
   int ilrma_wcov_n##n(const void *, const void *, const double *, const double *, void *,       \
                       IlrmaDims, hipStream_t);                                                 \
+  size_t ilrma_loss_ws_bytes_n##n(int, int);                                                   \
   int ilrma_loss_n##n(const void *, const void *, const double *, const double *, double *,     \
-                      IlrmaDims, hipStream_t);
+                      void *, IlrmaDims, hipStream_t);
 DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
 #undef DECL_N
 
@@ -25,7 +26,8 @@ DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
 #define DECL_FAST(n)                                                                           \
   int ilrma_fast_basis_n##n(const void *, const void *, const double *, double *, const double *, \
                             int, int, int, int, int, double, double *, int, double, int,        \
-                            double *, int, hipStream_t);                                        \
+                            double *, void *, int, hipStream_t);                                \
+  size_t ilrma_fast_loss_ws_bytes_n##n(int, int);                                               \
   int ilrma_fast_activation_n##n(const void *, const void *, const double *, const double *,   \
                                  double *, int, int, int, int, int, int, double, int,           \
                                  hipStream_t);                                                  \
@@ -33,7 +35,7 @@ DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
                            int, int, int, int, void *, int, double, int, double, hipStream_t,  \
                            int *, int *);                                                      \
   int ilrma_fast_loss_n##n(const void *, const void *, const double *, const double *, double *, \
-                           int, int, int, int, int, double, hipStream_t);
+                           void *, int, int, int, int, int, double, hipStream_t);
 DECL_FAST(2) DECL_FAST(3) DECL_FAST(4)
 #undef DECL_FAST
 
@@ -224,6 +226,32 @@ int wide_weighted_cov(const void *A, const double *weight, int kind, void *U, in
 static inline size_t basis_part_bytes(int N) {
   const int G = N < 4 ? N : 4;
   return align256((size_t)512 * G * 64 * 16 * 2 * sizeof(double));
+}
+// scratch of the deterministic loss sums: the larger of what the tuned kernels (by-product of the
+// basis pass, loss pass) and the generic loss kernel need
+static inline size_t loss_slots_bytes(int B, int N, int F) {
+  auto generic = [&]() -> size_t {
+    switch (N) {
+      case 2: return ilrma_loss_ws_bytes_n2(B, F);
+      case 3: return ilrma_loss_ws_bytes_n3(B, F);
+      case 4: return ilrma_loss_ws_bytes_n4(B, F);
+      case 5: return ilrma_loss_ws_bytes_n5(B, F);
+      case 6: return ilrma_loss_ws_bytes_n6(B, F);
+      case 7: return ilrma_loss_ws_bytes_n7(B, F);
+      case 8: return ilrma_loss_ws_bytes_n8(B, F);
+      default: return 0;
+    }
+  };
+  auto tuned = [&]() -> size_t {
+    switch (N) {
+      case 2: return ilrma_fast_loss_ws_bytes_n2(B, F);
+      case 3: return ilrma_fast_loss_ws_bytes_n3(B, F);
+      case 4: return ilrma_fast_loss_ws_bytes_n4(B, F);
+      default: return 0;
+    }
+  };
+  const size_t a = generic(), b = tuned();
+  return align256(a > b ? a : b);
 }
 static inline size_t u_part_bytes(int N) {
   return N <= 4 ? align256((size_t)512 * 64 * N * N * N * 2 * sizeof(double)) : 0;
@@ -580,7 +608,7 @@ extern "C" {
 
 // One scratch layout for every ILRMA entry point: callers pass the same buffer everywhere.
 struct IlrmaWs {
-  size_t act_part, btmp, qbuf, psi, bpart, upart, praw, ybuf, wbuf, total;
+  size_t act_part, btmp, qbuf, psi, lslots, bpart, upart, praw, ybuf, wbuf, total;
 };
 static inline IlrmaWs ilrma_ws(int B, int N, int F, int T, int K) {
   IlrmaWs w;
@@ -593,6 +621,8 @@ static inline IlrmaWs ilrma_ws(int B, int N, int F, int T, int K) {
   off += qbuf_bytes(B, N, F);
   w.psi = off;
   off += align256((size_t)B * N * sizeof(double));
+  w.lslots = off;  // per-wave shares of a loss, folded in a fixed order (no fp64 atomics)
+  off += loss_slots_bytes(B, N, F);
   w.bpart = off;
   off += basis_part_bytes(N);
   w.upart = off;
@@ -664,7 +694,7 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
                               activation + sr.first * K * T, sr.count, F, T, K, floor_kind,
                               floor_eps, (double *)(ws + w.bpart),
                               fast_model_id(domain, source_model), fast_model_param(domain, source_model, model_param),
-                              is_me(source_model), nullptr, power ? 1 : 0, st);
+                              is_me(source_model), nullptr, nullptr, power ? 1 : 0, st);
         };
         const int r = one();
         if (r) return r;
@@ -675,7 +705,8 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
       if (loss_done) *loss_done = loss_out != nullptr && K <= 16;
       ILRMA_FAST_DISPATCH(N, ilrma_fast_basis, X, W, basis, out, activation, B, F, T, K, floor_kind,
                           floor_eps, (double *)(ws + w.bpart), fast_model_id(domain, source_model),
-                          fast_model_param(domain, source_model, model_param), is_me(source_model), K <= 16 ? loss_out : nullptr, 0, st);
+                          fast_model_param(domain, source_model, model_param), is_me(source_model),
+                          K <= 16 ? loss_out : nullptr, ws + w.lslots, 0, st);
     }
     const IlrmaDims d =
         make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
@@ -910,22 +941,29 @@ int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *act
   return check_launch("k_ilrma_iss_weight");
 }
 
+size_t ssspy_ilrma_loss_workspace_bytes(int B, int N, int F) {
+  if (B <= 0 || N <= 0 || F <= 0) return 0;
+  return loss_slots_bytes(B, N, F);
+}
+
 int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
                           const double *activation, double *out, int B, int N, int F, int T, int K,
-                          double domain, int source_model, double model_param, void *stream) {
+                          double domain, int source_model, double model_param, void *workspace,
+                          size_t workspace_bytes, void *stream) {
   SSSPY_REQUIRE(X && basis && activation && out && B > 0, "ilrma_loss_data: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "ilrma_loss_data: bad n_basis");
+  SSSPY_REQUIRE(N >= 2 && N <= SSSPY_MAX_SOURCES, "ilrma_loss_data: n_sources must be in [2, 8]");
+  SSSPY_REQUIRE(workspace && workspace_bytes >= loss_slots_bytes(B, N, F),
+                "ilrma_loss_data: workspace too small (ssspy_ilrma_loss_workspace_bytes)");
   int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
   hipStream_t st = as_stream(stream);
-  hipError_t e = hipMemsetAsync(out, 0, (size_t)B * sizeof(double), st);
-  if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
   if (K <= 16 && fast_path(N, F, T, K, domain, source_model)) {
-    ILRMA_FAST_DISPATCH(N, ilrma_fast_loss, X, W, basis, activation, out, B, F, T, K,
+    ILRMA_FAST_DISPATCH(N, ilrma_fast_loss, X, W, basis, activation, out, workspace, B, F, T, K,
                         fast_model_id(domain, source_model), fast_model_param(domain, source_model, model_param), st);
   }
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, SSSPY_FLOOR_NONE, 0.0);
-  ILRMA_DISPATCH(N, ilrma_loss, X, W, basis, activation, out, d, st);
+  ILRMA_DISPATCH(N, ilrma_loss, X, W, basis, activation, out, workspace, d, st);
 }
 
 static int ip1_update_impl(const void *X, const void *C, void *W, double *basis, double *activation,
@@ -952,8 +990,7 @@ static int ip1_update_impl(const void *X, const void *C, void *W, double *basis,
     // by-product of the basis pass
     rc = ssspy_sum_logdet(W, logdet, B, F, N, stream);
     if (rc) return rc;
-    hipError_t e = hipMemsetAsync(loss_data, 0, (size_t)B * sizeof(double), st);
-    if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+    // (loss_data is stored, not accumulated: the basis pass folds its per-wave shares into it)
   }
   bool loss_done = false;
   // wide mixture on the grouped path: y = W x once for both NMF passes (they then see the ISS-style

@@ -84,7 +84,7 @@ enum { IN_Y = 0, IN_X = 1, IN_P = 2 };
 // HAS_W = false: the ISS / IPA state passes the separated spectrogram itself (y = x_n, no filter)
 // LOSS: also accumulate the data term of the negative log-likelihood of the state the pass sees,
 // sum_{n,i} mean_j (|y|^2 / R + log R) (model variants as in k_loss_fast; not the t model, whose
-// term is not linear in the accumulators), into loss_out[b]: the pass already forms |y|^2 and R
+// term is not linear in the accumulators), into its loss slot: the pass already forms |y|^2 and R
 // under the current (W, T, V), so the loss of iteration t comes out of the basis pass of iteration
 // t + 1 instead of a fourth pass over X (ref: ssspy/bss/ilrma.py:1946-1965).
 // KS = 4: n_basis <= 16, one work item per (mixture, bin group), updated in place.
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 
                                                        const double *__restrict__ act, int F,
                                                        int T, int K, int floor_kind, double eps,
                                                        TailPlan plan, double *__restrict__ part,
-                                                       FastModel fm, double *__restrict__ loss_out) {
+                                                       FastModel fm, double *__restrict__ loss_slots,
+                                                       int B) {
   constexpr bool HAS_W = IN == IN_X, PIN = IN == IN_P;
   constexpr int KR = 4 * KS;  // staged activation rows per source
   __shared__ __attribute__((aligned(16))) double vs[2][N * KR * VROW];
@@ -263,20 +264,24 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 
     if (kt == 0)  // (2 / p) log R, once
       lacc += (MODEL == FM_GAUSS1 ? 2.0 : (MODEL == FM_GAUSSP ? fm.pinv2 : 1.0)) * lr.value();
     lacc = wave_sum(lacc);
-    if (lane == 0) atomicAdd(loss_out + b, lacc / (double)T);
+    // no atomics: every (bin group, chunk, wave) of a mixture owns a slot (loss_slot_count())
+    const int maxsplit = plan.split > 1 ? plan.split : 1;
+    if (lane == 0)
+      loss_slots[(long long)((work.group * maxsplit + work.chunk) * 4 + wave) * B + b] =
+          lacc / (double)T;
   }
 }
 
 // basis <- floor(basis * sqrt(sum_chunks num / sum_chunks den)) for the split (tail) items;
 // grid: (N*64*16/256, tail items); one thread per (n, local bin, k)
 // ktiles: 1 (n_basis <= 16) or 2 (the item index also carries the k tile, see k_basis_fast<.., 8>)
-// loss_out / loss_scale: the split items' share of the loss by-product sum_k t num (see k_basis_fast)
+// loss_slots / loss_scale: the split items' share of the loss by-product sum_k t num (see k_basis_fast)
 __global__ __launch_bounds__(256) void k_basis_finalize(const double *basis, double *basis_out,
                                                         const double *__restrict__ part, int F,
                                                         int K, TailPlan plan, int ktiles,
                                                         int floor_kind, double eps, double expo,
-                                                        double *__restrict__ loss_out,
-                                                        double loss_scale) {
+                                                        double *__restrict__ loss_slots,
+                                                        double loss_scale, int B, int slot0) {
   const int tail_idx = blockIdx.y;
   const int item = plan.full + tail_idx;
   const int b = item / plan.groups, g2 = item - b * plan.groups;
@@ -297,9 +302,11 @@ __global__ __launch_bounds__(256) void k_basis_finalize(const double *basis, dou
     const double ratio = sn / sd;
     basis_out[o] = apply_floor(ratio_pow(ratio, expo) * told, floor_kind, eps);
   }
-  if (loss_out) {  // uniform per launch
+  if (loss_slots) {  // uniform per launch; slots behind those of k_basis_fast
     contrib = wave_sum(contrib);
-    if ((threadIdx.x & 63) == 0) atomicAdd(loss_out + b, contrib * loss_scale);
+    if ((threadIdx.x & 63) == 0)
+      loss_slots[(long long)(slot0 + (g2 * (int)gridDim.x + (int)blockIdx.x) * 4 +
+                             (int)(threadIdx.x >> 6)) * B + b] = contrib * loss_scale;
   }
 }
 
@@ -307,7 +314,8 @@ __global__ __launch_bounds__(256) void k_basis_finalize(const double *basis, dou
 
 #if SSSPY_FAST_PART != 1
 // ================================================================================ loss data
-// out[b] += sum_{n,i} mean_j ( |y|^2 / R + log R ), the data term of compute_loss().  Same walk as
+// sum_{n,i} mean_j ( |y|^2 / R + log R ), the data term of compute_loss(), as one slot per wave (the
+// launcher folds them into out[b] in a fixed order).  Same walk as
 // the basis pass without its second GEMM; the logarithms are summed as a mantissa product and an
 // exponent sum (LogSum): no fp64 log in the walk at all.
 // HAS_W = false: the ISS / IPA state passes the separated spectrogram itself (y = x_n, no filter)
@@ -316,8 +324,8 @@ __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X
                                                       const c128 *__restrict__ W,
                                                       const double *__restrict__ basis,
                                                       const double *__restrict__ act,
-                                                      double *__restrict__ out, int F, int T, int K,
-                                                      TailPlan plan, FastModel fm) {
+                                                      double *__restrict__ slots, int F, int T,
+                                                      int K, TailPlan plan, FastModel fm, int B) {
   __shared__ __attribute__((aligned(16))) double vs[2][N * 16 * VROW];
   constexpr int WSTRIDE = N * N + 1;
   __shared__ __attribute__((aligned(16))) c128 wl[4][16 * WSTRIDE];
@@ -402,7 +410,10 @@ __global__ __launch_bounds__(256, 2) void k_loss_fast(const c128 *__restrict__ X
   acc += (MODEL == FM_GAUSS1 ? 2.0 : (MODEL == FM_GAUSSP ? fm.pinv2 : 1.0)) * lr.value();  // (2 / p) log R
   if (MODEL == FM_T) acc = fma(1.0 + 0.5 * fm.nu, lt.value(), acc);
   acc = wave_sum(acc);
-  if (lane == 0) atomicAdd(out + b, acc / (double)T);
+  // no atomics: one slot per (bin group, chunk, wave) of the mixture, folded in order afterwards
+  const int maxsplit = plan.split > 1 ? plan.split : 1;
+  if (lane == 0)
+    slots[(long long)((work.group * maxsplit + work.chunk) * 4 + wave) * B + b] = acc / (double)T;
 }
 
 // ================================================================== weighted covariance (pass 3)
@@ -851,19 +862,34 @@ using fast::make_fast_model;
 int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis, double *basis_out,
                                const double *act, int B, int F, int T, int K, int floor_kind,
                                double eps, double *part, int fmodel, double mparam, int me,
-                               double *loss_out, int power_in, hipStream_t st) {
+                               double *loss_out, void *loss_ws, int power_in, hipStream_t st) {
+  // loss_ws: LAUNCHER(ilrma_fast_loss_ws_bytes)() of scratch behind loss_out (the per-wave shares
+  // are stored there and added up in a fixed order: no atomics)
   if (power_in && (W != nullptr || loss_out != nullptr))
     return fail(SSSPY_ERR_BADARG, "ilrma_fast_basis: power input excludes a filter and the loss");
+  if (loss_out && !loss_ws) return fail(SSSPY_ERR_BADARG, "ilrma_fast_basis: loss without scratch");
   const int ktiles = K > 16 ? 2 : 1;
   // (the wide variant holds one workgroup per CU)
   const TailPlan plan =
       make_tail_plan(B, ((F + 63) / 64) * ktiles, (T + 15) / 16, ktiles == 2 ? 256 : SLOTS);
   const FastModel fm = make_fast_model(fmodel, mparam, me);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
+  // loss slots per mixture: (bin group, chunk, wave) of the pass, then (bin group, block, wave) of
+  // the fold of the split items
+  const int maxsplit = plan.split > 1 ? plan.split : 1;
+  const int nbx = N * 64 * 16 / 256;
+  const int slots_pass = plan.groups * maxsplit * 4;
+  const int nslots = slots_pass + plan.groups * nbx * 4;
+  const bool with_loss = loss_out != nullptr && ktiles == 1 && fmodel != FM_T;
+  double *loss_slots = with_loss ? (double *)loss_ws : nullptr;
+  if (with_loss) {
+    const int rc0 = scalar_slots_begin(loss_ws, B, nslots, st);
+    if (rc0) return rc0;
+  }
 #define SSSPY_BASIS_LAUNCH(HW, M, L, KS_)                                                          \
   hipLaunchKernelGGL((k_basis_fast<HW, M, L, KS_>), grid, block, 0, st, (const c128 *)X,           \
                      (const c128 *)W, basis, basis_out, act, F, T, K, floor_kind, eps, plan, part, \
-                     fm, loss_out)
+                     fm, loss_slots, B)
 #define SSSPY_BASIS_LAUNCH_M(HW, L, KS_)                                  \
   switch (fmodel) {                                                       \
     case FM_T: SSSPY_BASIS_LAUNCH(HW, FM_T, false, KS_); break; /* no by-product for the t model */ \
@@ -885,13 +911,13 @@ int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis
       SSSPY_BASIS_LAUNCH_M(false, false, 8)
     }
   } else if (W != nullptr) {
-    if (loss_out) {
+    if (with_loss) {
       SSSPY_BASIS_LAUNCH_M(true, true, 4)
     } else {
       SSSPY_BASIS_LAUNCH_M(true, false, 4)
     }
   } else {
-    if (loss_out) {
+    if (with_loss) {
       SSSPY_BASIS_LAUNCH_M(false, true, 4)
     } else {
       SSSPY_BASIS_LAUNCH_M(false, false, 4)
@@ -900,13 +926,23 @@ int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis
 #undef SSSPY_BASIS_LAUNCH_M
 #undef SSSPY_BASIS_LAUNCH
   int rc = check_launch("k_basis_fast");
-  if (rc || plan.tail == 0) return rc;
-  // split items' share of the loss by-product (never requested for the t model or the wide variant)
-  const double loss_scale = (fmodel == FM_GGD ? 2.0 / fm.beta : 1.0) / (double)T;
-  hipLaunchKernelGGL(k_basis_finalize, dim3(N * 64 * 16 / 256, plan.tail), block, 0, st, basis,
-                     basis_out, part, F, K, plan, ktiles, floor_kind, eps, fm.expo,
-                     (fmodel != FM_T && ktiles == 1) ? loss_out : (double *)nullptr, loss_scale);
-  return check_launch("k_basis_finalize");
+  if (rc) return rc;
+  if (plan.tail > 0) {
+    // split items' share of the loss by-product (never requested for the t model or the wide variant)
+    const double loss_scale = (fmodel == FM_GGD ? 2.0 / fm.beta : 1.0) / (double)T;
+    hipLaunchKernelGGL(k_basis_finalize, dim3(nbx, plan.tail), block, 0, st, basis, basis_out, part,
+                       F, K, plan, ktiles, floor_kind, eps, fm.expo, loss_slots, loss_scale, B,
+                       slots_pass);
+    rc = check_launch("k_basis_finalize");
+    if (rc) return rc;
+  }
+  return with_loss ? scalar_slots_fold(loss_ws, B, nslots, loss_out, 0, st) : rc;
+}
+
+// scratch of the deterministic loss sums (both the by-product of the basis pass and the loss pass)
+size_t LAUNCHER(ilrma_fast_loss_ws_bytes)(int B, int F) {
+  const int groups = (F + 63) / 64;
+  return scalar_slots_bytes(B, groups * 4 * (16 + N * 64 * 16 / 256));
 }
 
 #endif
@@ -956,16 +992,21 @@ int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *
   return check_launch("k_activation_fast");
 }
 
-// `out` (B doubles) must be zeroed by the caller
+// out[b] = the data term; loss_ws: LAUNCHER(ilrma_fast_loss_ws_bytes)() of scratch
 int LAUNCHER(ilrma_fast_loss)(const void *X, const void *W, const double *basis, const double *act,
-                              double *out, int B, int F, int T, int K, int fmodel, double mparam,
-                              hipStream_t st) {
+                              double *out, void *loss_ws, int B, int F, int T, int K, int fmodel,
+                              double mparam, hipStream_t st) {
   const TailPlan plan = make_tail_plan(B, (F + 63) / 64, (T + 15) / 16);
   const FastModel fm = make_fast_model(fmodel, mparam, 0);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
+  const int nslots = plan.groups * (plan.split > 1 ? plan.split : 1) * 4;
+  int rc = scalar_slots_begin(loss_ws, B, nslots, st);
+  if (rc) return rc;
+  double *slots = (double *)loss_ws;
   SSSPY_FAST_LAUNCH2(k_loss_fast, W != nullptr, (const c128 *)X, (const c128 *)W,
-                     basis, act, out, F, T, K, plan, fm);
-  return check_launch("k_loss_fast");
+                     basis, act, slots, F, T, K, plan, fm, B);
+  rc = check_launch("k_loss_fast");
+  return rc ? rc : scalar_slots_fold(loss_ws, B, nslots, out, 0, st);
 }
 
 // `upart` must hold u_part_bytes() of ilrma_api.hip (used only when some items are split);

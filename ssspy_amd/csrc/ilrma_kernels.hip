@@ -394,8 +394,8 @@ template <bool KSMALL>
 __global__ __launch_bounds__(256) void k_ilrma_loss(const c128 *__restrict__ X,
                                                     const c128 *__restrict__ W,
                                                     const double *__restrict__ basis,
-                                                    const double *__restrict__ act, double *out,
-                                                    IlrmaDims d) {
+                                                    const double *__restrict__ act,
+                                                    double *slots, IlrmaDims d) {
   constexpr int N = NSRC, SG = SGRP;
   __shared__ double scratch[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -451,7 +451,9 @@ __global__ __launch_bounds__(256) void k_ilrma_loss(const c128 *__restrict__ X,
     }
   }
   const double total = block_sum(local, scratch);
-  if (threadIdx.x == 0) atomicAdd(out + b, total / (double)T);
+  // one slot per (bin tile, source group) of the mixture; the launcher adds them up in order
+  if (threadIdx.x == 0)
+    slots[(long long)(blockIdx.x * NGROUPS + g) * d.B + b] = total / (double)T;
 }
 
 // ----------------------------------------------------------------------- host-side launchers
@@ -504,16 +506,25 @@ int LAUNCHER(ilrma_wcov)(const void *X, const void *W, const double *basis, cons
   return check_launch("k_ilrma_wcov");
 }
 
+// out[b] = the data term of the loss; loss_ws: ilrma_loss_ws_bytes() of scratch (per-block shares,
+// added up in a fixed order: no atomics)
+size_t LAUNCHER(ilrma_loss_ws_bytes)(int B, int F) {
+  return scalar_slots_bytes(B, ((F + 15) / 16) * NGROUPS);
+}
 int LAUNCHER(ilrma_loss)(const void *X, const void *W, const double *basis, const double *act,
-                         double *out, IlrmaDims d, hipStream_t st) {
+                         double *out, void *loss_ws, IlrmaDims d, hipStream_t st) {
   dim3 grid((d.F + 15) / 16, 1, d.B * NGROUPS), block(256);
+  const int nslots = (int)grid.x * NGROUPS;
+  int rc = scalar_slots_begin(loss_ws, d.B, nslots, st);
+  if (rc) return rc;
   if (d.K <= 16)
     hipLaunchKernelGGL((k_ilrma_loss<true>), grid, block, 0, st, (const c128 *)X, (const c128 *)W,
-                       basis, act, out, d);
+                       basis, act, (double *)loss_ws, d);
   else
     hipLaunchKernelGGL((k_ilrma_loss<false>), grid, block, 0, st, (const c128 *)X,
-                       (const c128 *)W, basis, act, out, d);
-  return check_launch("k_ilrma_loss");
+                       (const c128 *)W, basis, act, (double *)loss_ws, d);
+  rc = check_launch("k_ilrma_loss");
+  return rc ? rc : scalar_slots_fold(loss_ws, d.B, nslots, out, 0, st);
 }
 
 }  // namespace ssspy

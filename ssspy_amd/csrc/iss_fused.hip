@@ -253,7 +253,9 @@ __global__ __launch_bounds__(256, 2) void k_iss1_fused(c128 *Y, const double *__
     double v = (threadIdx.x < N) ? log(ld.mant) + 0.6931471805599453094 * (double)ld.expo : 0.0;
     if (threadIdx.x < 64) {
       v = wave_sum(v);
-      if (threadIdx.x == 0) atomicAdd(logdet_delta + b, -0.5 * v);
+      // the block's share goes to its own slot [block][b]; the launcher adds the slots to the
+      // caller's running log-determinant in block order (no atomics)
+      if (threadIdx.x == 0) logdet_delta[(long long)blockIdx.x * gridDim.y + b] = -0.5 * v;
     }
   }
   if (r2_slabs) {
@@ -349,12 +351,14 @@ static size_t iss_r2_layout(int B, int N, int F, int T, size_t *scratch_off) {
   const long long total = (long long)B * N * T;
   const size_t slabs = (size_t)nblk * total * sizeof(double);
   if (scratch_off) *scratch_off = slabs;
-  return slabs + fold_scratch_bytes(total, nblk);
+  return (slabs + fold_scratch_bytes(total, nblk) + 255) & ~(size_t)255;
 }
+// behind it: the per-block shares of the tracked log-determinant (at most one block per bin)
+static size_t iss_logdet_slots_bytes(int B, int F) { return scalar_slots_bytes(B, F); }
 
 size_t ssspy_iss1_fused_workspace_bytes(int B, int N, int F, int T) {
   if (B <= 0 || N <= 0 || F <= 0 || T <= 0) return 0;
-  return iss_r2_layout(B, N, F, T, nullptr);
+  return iss_r2_layout(B, N, F, T, nullptr) + iss_logdet_slots_bytes(B, F);
 }
 
 static int iss1_fused_impl(void *Y, const double *weight, int weight_kind, double *r2_next, int B,
@@ -366,19 +370,28 @@ static int iss1_fused_impl(void *Y, const double *weight, int weight_kind, doubl
                 "iss1_fused: weight_kind must be FRAME or BIN_FRAME");
   SSSPY_REQUIRE(T <= ssspy_iss1_fused_max_frames(N), "iss1_fused: n_frames above the fused limit");
   size_t scratch_off = 0;
-  const size_t need = iss_r2_layout(B, N, F, T, &scratch_off);
-  SSSPY_REQUIRE(!r2_next || (workspace && workspace_bytes >= need),
-                "iss1_fused: frame powers need the workspace of ssspy_iss1_fused_workspace_bytes");
+  const size_t r2_bytes = iss_r2_layout(B, N, F, T, &scratch_off);
+  const size_t need = r2_bytes + iss_logdet_slots_bytes(B, F);
+  SSSPY_REQUIRE((!r2_next && !logdet_delta) || (workspace && workspace_bytes >= need),
+                "iss1_fused: frame powers / the tracked log-determinant need the workspace of "
+                "ssspy_iss1_fused_workspace_bytes");
   const bool per_bin = weight_kind == SSSPY_WEIGHT_BIN_FRAME;
   hipStream_t st = as_stream(stream);
   double *slabs = r2_next ? (double *)workspace : nullptr;
+  void *ld_ws = logdet_delta ? (char *)workspace + r2_bytes : nullptr;  // slots [block][b]
   int rc = SSSPY_OK;
   DISPATCH_N(N, rc = dispatch_iss<NN>(Y, weight, per_bin, slabs, B, F, T, floor_kind, floor_eps,
-                                      logdet_delta, st));
-  if (rc || !r2_next) return rc;
-  const int bpb = iss_bins_per_block(B, F, true);
+                                      (double *)ld_ws, st));
+  if (rc) return rc;
+  const int bpb = iss_bins_per_block(B, F, r2_next != nullptr);
+  const int nblk = (F + bpb - 1) / bpb;
+  if (logdet_delta) {  // every block wrote its slot: logdet[b] += the blocks' shares, in block order
+    rc = scalar_slots_fold(ld_ws, B, nblk, logdet_delta, 1, st);
+    if (rc) return rc;
+  }
+  if (!r2_next) return rc;
   return launch_fold_slabs(slabs, (char *)workspace + scratch_off, r2_next, (long long)B * N * T,
-                           (F + bpb - 1) / bpb, st);
+                           nblk, st);
 }
 
 int ssspy_iss1_fused(void *Y, const double *weight, int weight_kind, double *r2_next, int B, int N,

@@ -1774,8 +1774,9 @@ def test_rng_drawn_initial_state_against_golden(case):
 @pytest.mark.parametrize("kind", ["auxiva_ip", "auxiva_iss", "ilrma_iss", "ilrma_ip", "gmnmf"])
 def test_state_is_bitwise_reproducible(kind):
     """No fp64 atomics on anything the state depends on (frame powers of AuxIVA and of the fused ISS
-    sweep, output power of the ISS normalisation, GaussMNMF's activation sums): two runs from the
-    same input give the same bits, for a single mixture and for a batch."""
+    sweep, output power of the ISS normalisation, GaussMNMF's activation sums) nor on the ILRMA /
+    AuxIVA loss terms: two runs from the same input give the same bits, for a single mixture and
+    for a batch."""
     from ssspy_amd.bss.ilrma import GaussILRMA
     from ssspy_amd.bss.iva import AuxLaplaceIVA
     from ssspy_amd.bss.mnmf import GaussMNMF
@@ -1788,17 +1789,21 @@ def test_state_is_bitwise_reproducible(kind):
         def run():
             if kind.startswith("auxiva"):
                 m = AuxLaplaceIVA(spatial_algorithm="IP" if kind.endswith("ip") else "ISS",
-                                  record_loss=False)
-                return m(X, n_iter=6)
+                                  record_loss=True)
+                return m(X, n_iter=6), np.asarray(m.loss)
             if kind == "gmnmf":
                 m = GaussMNMF(n_basis=K, record_loss=False, rng=np.random.default_rng(3))
-                return m(X, n_iter=3)
+                return m(X, n_iter=3), None
             m = GaussILRMA(n_basis=K, spatial_algorithm="ISS" if kind.endswith("iss") else "IP",
-                           record_loss=False, rng=np.random.default_rng(3))
-            return m(X, n_iter=6)
+                           record_loss=True, rng=np.random.default_rng(3))
+            return m(X, n_iter=6), np.asarray(m.loss)
 
-        Y1, Y2 = run(), run()
+        (Y1, L1), (Y2, L2) = run(), run()
         assert np.array_equal(Y1, Y2), (kind, B)
+        # the recorded losses too (ILRMA: per-wave shares folded in order, both as the by-product of
+        # the basis pass and from the loss pass; ISS: the tracked log-determinant)
+        if L1 is not None:
+            assert np.array_equal(L1, L2), (kind, B)
 
 
 # ------------------------------------------------------------------------------- arbitrary floors
