@@ -443,11 +443,13 @@ int ssspy_fastmnmf_update_handover(const void *X, const void *C, void *Q, double
 /* The data term of the loss (as ssspy_fastmnmf_loss_data) from a VALID hand-over buffer instead of
  * X and Q: half the bytes, no M x M products.  The caller guarantees that the buffer matches the
  * current Q and X (ssspy_fastmnmf_update_handover returned *handover_valid = 1 and neither moved
- * since).  out: B doubles.  replaces: ssspy/bss/mnmf.py:1240-1258. */
+ * since).  out: B doubles, overwritten; workspace: ssspy_fastmnmf_loss_workspace_bytes (the
+ * per-wave shares, added up in a fixed order: no fp64 atomics).
+ * replaces: ssspy/bss/mnmf.py:1240-1258. */
 int ssspy_fastmnmf_loss_data_handover(const double *D, const double *basis,
                                       const double *activation, const double *handover,
                                       double *out, int B, int N, int M, int F, int T, int K,
-                                      void *stream);
+                                      void *workspace, size_t workspace_bytes, void *stream);
 
 /* U[b,i,m] = (1/T) sum_j x x^H / R~_ijm  -> (B,F,M,M,M): the covariances the diagonaliser update
  * (IP1 inside ssspy_fastmnmf_update, or ssspy_update_by_ip2 for diagonalizer_algorithm="IP2") needs.
@@ -463,11 +465,14 @@ int ssspy_fastmnmf_weights(const void *X, const void *Q, const double *D, const 
                            const double *activation, double *weights, int B, int N, int M, int F,
                            int T, int K, void *stream);
 
-/* out[b] = sum_i mean_j sum_m ( |q x|^2 / R~ + log R~ ) (zeroed by the call); caller adds
- * -2 sum logdet Q.   replaces: ssspy/bss/mnmf.py:1240-1258. */
+/* out[b] = sum_i mean_j sum_m ( |q x|^2 / R~ + log R~ ) (overwritten); caller adds
+ * -2 sum logdet Q.  The per-block shares go through `workspace`
+ * (ssspy_fastmnmf_loss_workspace_bytes) and are added up in a fixed order: no fp64 atomics, the
+ * same bits on every run.   replaces: ssspy/bss/mnmf.py:1240-1258. */
+size_t ssspy_fastmnmf_loss_workspace_bytes(int B, int N, int M, int F, int T);
 int ssspy_fastmnmf_loss_data(const void *X, const void *Q, const double *D, const double *basis,
                              const double *activation, double *out, int B, int N, int M, int F,
-                             int T, int K, void *stream);
+                             int T, int K, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Multichannel Wiener filter output Y (B,N,F,T) for reference channel `reference_id`:
  * per (bin, frame) an M x M Hermitian eigen-decomposition (Jacobi) with floored eigenvalues.
@@ -507,11 +512,15 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
                        int floor_kind, double floor_eps, void *workspace, size_t workspace_bytes,
                        void *stream);
 
-/* out[b] = sum_i mean_j ( tr(R^-1 XX) + log det R ); `out` (B doubles) is zeroed by the call.
+/* out[b] = sum_i mean_j ( tr(R^-1 XX) + log det R ); `out` (B doubles) is overwritten; the
+ * per-block shares go through `workspace` (ssspy_gmnmf_loss_workspace_bytes) and are added up in
+ * a fixed order (no fp64 atomics).
  * replaces: ssspy/bss/mnmf.py:765-804. */
+size_t ssspy_gmnmf_loss_workspace_bytes(int B, int F, int T);
 int ssspy_gmnmf_loss(const void *X, const double *basis, const double *activation,
                      const void *spatial, double *out, int B, int N, int M, int F, int T, int K,
-                     int floor_kind, double floor_eps, void *stream);
+                     int floor_kind, double floor_eps, void *workspace, size_t workspace_bytes,
+                     void *stream);
 
 /* multichannel Wiener filter: Y[b,n,i,j] = (lambda_nij H_ni R_ij^-1 x_ij)[reference_id]
  * -> Y (B,N,F,T) c128.  replaces: ssspy/bss/mnmf.py:729-763. */

@@ -85,7 +85,8 @@ PROTOTYPES = {
     "ssspy_iva_loss_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ssspy_gmnmf_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "ssspy_gmnmf_update": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p, _z, _p]),
-    "ssspy_gmnmf_loss": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _d, _p]),
+    "ssspy_gmnmf_loss_workspace_bytes": (_z, [_i, _i, _i]),
+    "ssspy_gmnmf_loss": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _d, _p, _z, _p]),
     "ssspy_gmnmf_separate": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p]),
     "ssspy_eigh_general": (_i, [_p, _p, _p, _p, _q, _i, _i, _p, _p]),
     "ssspy_sqrtmh": (_i, [_p, _p, _q, _i, _i, _i, _d, _p]),
@@ -101,9 +102,11 @@ PROTOTYPES = {
     "ssspy_fastmnmf_handover_doubles": (_z, [_i, _i, _i, _i, _i, _i]),
     "ssspy_fastmnmf_update_handover": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d,
                                             _p, _z, _p, _p, _p, _p]),
-    "ssspy_fastmnmf_loss_data_handover": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "ssspy_fastmnmf_loss_data_handover": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z,
+                                               _p]),
+    "ssspy_fastmnmf_loss_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "ssspy_fastmnmf_diagonalizer_covariance": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "ssspy_fastmnmf_loss_data": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "ssspy_fastmnmf_loss_data": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "ssspy_fastmnmf_weights": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ssspy_fastmnmf_separate": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p,
                                      _z, _p, _p]),

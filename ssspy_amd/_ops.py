@@ -594,9 +594,10 @@ def fastmnmf_loss_data(X, Q, D, basis, activation, out=None):
     N, K = basis.shape[1], basis.shape[-1]
     if out is None:
         out = dv.empty((B,), dv.f64, X.device)
+    ws, ws_bytes = _scratch(_L().ssspy_fastmnmf_loss_workspace_bytes(B, N, M, F, T), X.device)
     _lib.check(
         _L().ssspy_fastmnmf_loss_data(ptr(X), ptr(Q), ptr(D), ptr(basis), ptr(activation), ptr(out),
-                                      B, N, M, F, T, K, _st()),
+                                      B, N, M, F, T, K, ptr(ws), ws_bytes, _st()),
         "fastmnmf_loss_data",
     )
     return out
@@ -607,9 +608,12 @@ def fastmnmf_loss_data_handover(D, basis, activation, handover, n_channels, n_fr
     B, N, F, K = basis.shape
     if out is None:
         out = dv.empty((B,), dv.f64, basis.device)
+    ws, ws_bytes = _scratch(
+        _L().ssspy_fastmnmf_loss_workspace_bytes(B, N, n_channels, F, n_frames), basis.device)
     _lib.check(
         _L().ssspy_fastmnmf_loss_data_handover(ptr(D), ptr(basis), ptr(activation), ptr(handover),
-                                               ptr(out), B, N, n_channels, F, n_frames, K, _st()),
+                                               ptr(out), B, N, n_channels, F, n_frames, K, ptr(ws),
+                                               ws_bytes, _st()),
         "fastmnmf_loss_data_handover",
     )
     return out
@@ -651,9 +655,10 @@ def gmnmf_loss(X, basis, activation, spatial, flooring, out=None):
     N, K = basis.shape[1], basis.shape[-1]
     if out is None:
         out = dv.empty((B,), dv.f64, X.device)
+    ws, ws_bytes = _scratch(_L().ssspy_gmnmf_loss_workspace_bytes(B, F, T), X.device)
     _lib.check(
         _L().ssspy_gmnmf_loss(ptr(X), ptr(basis), ptr(activation), ptr(spatial), ptr(out), B, N, M,
-                              F, T, K, flooring[0], flooring[1], _st()),
+                              F, T, K, flooring[0], flooring[1], ptr(ws), ws_bytes, _st()),
         "gmnmf_loss",
     )
     return out

@@ -132,7 +132,10 @@ __global__ __launch_bounds__(128) void k_points(const c128 *__restrict__ X,
     term = wave_sum(valid ? term : 0.0);
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = term;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out0 + b, (scratch[0] + scratch[1]) / (double)T);
+    // one slot per (frame block, bin) of the mixture, [slot][B]; fmnmf_generic_loss folds them
+    if (threadIdx.x == 0)
+      out0[((long long)blockIdx.y * gridDim.x + blockIdx.x) * gridDim.z + b] =
+          (scratch[0] + scratch[1]) / (double)T;
   }
 }
 
@@ -514,10 +517,16 @@ int fmnmf_generic_weights(const void *X, const void *Q, const double *D, const d
   return fmg::launch_points<fmg::MODE_WEIGHTS>(X, Q, D, basis, act, Wt, nullptr, B, N, M, F, T, K, st);
 }
 
+size_t fmnmf_generic_loss_ws_bytes(int B, int F, int T) {
+  return scalar_slots_bytes(B, ((T + 127) / 128) * F);
+}
+// out[b] = the data term; loss_ws: fmnmf_generic_loss_ws_bytes() (every block writes its slot)
 int fmnmf_generic_loss(const void *X, const void *Q, const double *D, const double *basis,
-                       const double *act, double *out, int B, int N, int M, int F, int T, int K,
-                       hipStream_t st) {
-  return fmg::launch_points<fmg::MODE_LOSS>(X, Q, D, basis, act, out, nullptr, B, N, M, F, T, K, st);
+                       const double *act, double *out, void *loss_ws, int B, int N, int M, int F,
+                       int T, int K, hipStream_t st) {
+  const int rc = fmg::launch_points<fmg::MODE_LOSS>(X, Q, D, basis, act, (double *)loss_ws, nullptr,
+                                                    B, N, M, F, T, K, st);
+  return rc ? rc : scalar_slots_fold(loss_ws, B, ((T + 127) / 128) * F, out, 0, st);
 }
 
 int fmnmf_generic_separate(const void *X, const void *Q, void *Qinv, const double *D,

@@ -593,7 +593,9 @@ __global__ __launch_bounds__(128) void k_gmnmf_loss(const c128 *__restrict__ X,
     term = fma(c1, xu, c0 * trR) + pt.logdet;
   }
   const double total = block_sum(term, red);
-  if (threadIdx.x == 0) atomicAdd(out + b, total / (double)T);
+  // one slot per (frame block, bin) of the mixture, [slot][B]; ssspy_gmnmf_loss folds them in order
+  if (threadIdx.x == 0)
+    out[((long long)blockIdx.y * gridDim.x + blockIdx.x) * gridDim.z + b] = total / (double)T;
 }
 
 // --------------------------------------------------------------------------- Wiener filter
@@ -812,20 +814,28 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
   return SSSPY_OK;
 }
 
+size_t ssspy_gmnmf_loss_workspace_bytes(int B, int F, int T) {
+  if (B <= 0 || F <= 0 || T <= 0) return 0;
+  return scalar_slots_bytes(B, ((T + 127) / 128) * F);
+}
+
 int ssspy_gmnmf_loss(const void *X, const double *basis, const double *activation,
                      const void *spatial, double *out, int B, int N, int M, int F, int T, int K,
-                     int floor_kind, double floor_eps, void *stream) {
+                     int floor_kind, double floor_eps, void *workspace, size_t workspace_bytes,
+                     void *stream) {
   SSSPY_REQUIRE(X && basis && activation && spatial && out, "gmnmf_loss: null argument");
   int rc = check_dims(B, N, M, F, T, K);
   if (rc) return rc;
+  SSSPY_REQUIRE(workspace && workspace_bytes >= ssspy_gmnmf_loss_workspace_bytes(B, F, T),
+                "gmnmf_loss: workspace too small (ssspy_gmnmf_loss_workspace_bytes)");
   hipStream_t st = as_stream(stream);
-  hipError_t e = hipMemsetAsync(out, 0, (size_t)B * sizeof(double), st);
-  if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
   dim3 grid((T + 127) / 128, F, B), block(128);
+  // (every block writes its slot; the fold stores out[b])
   GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_loss<MM>), grid, block, bin_smem(N, M, K), st,
                                       (const c128 *)X, basis, activation, (const c128 *)spatial,
-                                      out, N, F, T, K, floor_kind, floor_eps));
-  return check_launch("k_gmnmf_loss");
+                                      (double *)workspace, N, F, T, K, floor_kind, floor_eps));
+  rc = check_launch("k_gmnmf_loss");
+  return rc ? rc : scalar_slots_fold(workspace, B, (int)grid.x * F, out, 0, st);
 }
 
 int ssspy_gmnmf_separate(const void *X, const double *basis, const double *activation,

@@ -6,7 +6,9 @@ namespace ssspy {
 #define DECL_N(n)                                                                                \
   int mnmf_handover_ok_n##n(int, int, int, int);                                                \
   int mnmf_loss_handover_n##n(const double *, const double *, const double *, const double *,   \
-                              const double *, double *, int, int, int, int, int, hipStream_t);  \
+                              const double *, double *, void *, int, int, int, int, int,        \
+                              hipStream_t);                                                     \
+  size_t mnmf_loss_ws_bytes_n##n(int, int);                                                     \
   int mnmf_qx2_n##n(const void *, const void *, double *, double *, int, int, int, int,         \
                     hipStream_t);                                                               \
   int mnmf_basis_n##n(const void *, const void *, const double *, const double *, double *,     \
@@ -21,7 +23,7 @@ namespace ssspy {
                         int, int, int, int, int, double *, double *, double *, int, int *,      \
                         hipStream_t);                                                           \
   int mnmf_loss_n##n(const void *, const void *, const double *, const double *, const double *, \
-                     double *, int, int, int, int, int, hipStream_t);                           \
+                     double *, void *, int, int, int, int, int, hipStream_t);                   \
   int mnmf_norm_scale_n##n(void *, double *, const double *, int, int, int, int, double,        \
                            double *, int, const double *, int, hipStream_t);                    \
   int mnmf_separate_n##n(const void *, const void *, void *, const double *, const double *,    \
@@ -55,9 +57,10 @@ int fmnmf_generic_update(const void *X, const void *C, void *Q, double *D, doubl
 int fmnmf_generic_weights(const void *X, const void *Q, const double *D, const double *basis,
                           const double *act, double *Wt, int B, int N, int M, int F, int T, int K,
                           hipStream_t st);
+size_t fmnmf_generic_loss_ws_bytes(int B, int F, int T);
 int fmnmf_generic_loss(const void *X, const void *Q, const double *D, const double *basis,
-                       const double *act, double *out, int B, int N, int M, int F, int T, int K,
-                       hipStream_t st);
+                       const double *act, double *out, void *loss_ws, int B, int N, int M, int F,
+                       int T, int K, hipStream_t st);
 int fmnmf_generic_separate(const void *X, const void *Q, void *Qinv, const double *D,
                            const double *basis, const double *act, void *Y, int B, int N, int M,
                            int F, int T, int K, int ref, int floor_kind, double eps, int *info,
@@ -336,34 +339,52 @@ int ssspy_fastmnmf_weights(const void *X, const void *Q, const double *D, const 
                                as_stream(stream));
 }
 
+// scratch of the loss entry points (per-block / per-wave shares, added up in a fixed order)
+static size_t fastmnmf_loss_ws(int B, int N, int M, int F, int T) {
+  if (!mnmf_tiled(N, M)) return fmnmf_generic_loss_ws_bytes(B, F, T);
+  switch (N) {
+    case 2: return mnmf_loss_ws_bytes_n2(B, F);
+    case 3: return mnmf_loss_ws_bytes_n3(B, F);
+    default: return mnmf_loss_ws_bytes_n4(B, F);
+  }
+}
+
+size_t ssspy_fastmnmf_loss_workspace_bytes(int B, int N, int M, int F, int T) {
+  if (B <= 0 || N <= 0 || M <= 0 || F <= 0 || T <= 0) return 0;
+  return fastmnmf_loss_ws(B, N, M, F, T);
+}
+
 int ssspy_fastmnmf_loss_data(const void *X, const void *Q, const double *D, const double *basis,
                              const double *activation, double *out, int B, int N, int M, int F,
-                             int T, int K, void *stream) {
+                             int T, int K, void *workspace, size_t workspace_bytes, void *stream) {
   SSSPY_REQUIRE(X && Q && D && basis && activation && out && B > 0, "fastmnmf_loss_data: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_loss_data: bad n_basis");
+  SSSPY_REQUIRE(N >= 1 && N <= SSSPY_MAX_SOURCES && M >= 2 && M <= 8,
+                "fastmnmf_loss_data: n_sources in [1, 8], n_channels in [2, 8]");
+  SSSPY_REQUIRE(workspace && workspace_bytes >= fastmnmf_loss_ws(B, N, M, F, T),
+                "fastmnmf_loss_data: workspace too small (ssspy_fastmnmf_loss_workspace_bytes)");
   hipStream_t st = as_stream(stream);
-  hipError_t e = hipMemsetAsync(out, 0, (size_t)B * sizeof(double), st);
-  if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
   if (!mnmf_tiled(N, M))
-    return fmnmf_generic_loss(X, Q, D, basis, activation, out, B, N, M, F, T, K, st);
-  MNMF_DISPATCH(N, mnmf_loss, X, Q, D, basis, activation, out, B, M, F, T, K, st);
+    return fmnmf_generic_loss(X, Q, D, basis, activation, out, workspace, B, N, M, F, T, K, st);
+  MNMF_DISPATCH(N, mnmf_loss, X, Q, D, basis, activation, out, workspace, B, M, F, T, K, st);
 }
 
 int ssspy_fastmnmf_loss_data_handover(const double *D, const double *basis,
                                       const double *activation, const double *handover,
                                       double *out, int B, int N, int M, int F, int T, int K,
-                                      void *stream) {
+                                      void *workspace, size_t workspace_bytes, void *stream) {
   SSSPY_REQUIRE(D && basis && activation && handover && out && B > 0,
                 "fastmnmf_loss_data_handover: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_loss_data_handover: bad n_basis");
   if (handover_ok(B, N, M, F, T, K) != 1)
     return fail(SSSPY_ERR_UNSUPPORTED, "fastmnmf_loss_data_handover: no hand-over for this shape");
+  SSSPY_REQUIRE(workspace && workspace_bytes >= fastmnmf_loss_ws(B, N, M, F, T),
+                "fastmnmf_loss_data_handover: workspace too small "
+                "(ssspy_fastmnmf_loss_workspace_bytes)");
   hipStream_t st = as_stream(stream);
-  hipError_t e = hipMemsetAsync(out, 0, (size_t)B * sizeof(double), st);
-  if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
   const double *pscale = handover + (size_t)B * M * F * T;
-  MNMF_DISPATCH(N, mnmf_loss_handover, D, basis, activation, handover, pscale, out, B, M, F, T, K,
-                st);
+  MNMF_DISPATCH(N, mnmf_loss_handover, D, basis, activation, handover, pscale, out, workspace, B, M,
+                F, T, K, st);
 }
 
 int ssspy_fastmnmf_separate(const void *X, const void *Q, const double *D, const double *basis,

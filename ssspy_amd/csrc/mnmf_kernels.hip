@@ -847,10 +847,15 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
     tile(cur, nxt, jt);
     if (jt + 1 < jt_end) tile(nxt, cur, jt + 1);
   }
-  if (MODE == MODE_LOSS) {  // `tailpart` is the per-mixture output here (B zeroed doubles)
+  if (MODE == MODE_LOSS) {
+    // `tailpart` holds the loss slots here, [slot][B] with one slot per (bin group, chunk, wave) of
+    // the mixture; this mode has no floor, and the launcher passes B in `floor_kind`
     lacc += lr.value();
     lacc = wave_sum(lacc);
-    if (lane == 0) atomicAdd(tailpart + b, lacc / (double)T);
+    const int maxsplit = plan.split > 1 ? plan.split : 1;
+    if (lane == 0)
+      tailpart[(long long)((work.group * maxsplit + work.chunk) * 4 + wave) * floor_kind + b] =
+          lacc / (double)T;
     return;
   }
   const long long slot = (long long)work.tail_idx * nchunks + work.chunk;
@@ -1247,7 +1252,8 @@ __global__ __launch_bounds__(256) void k_mnmf_loss(const c128 *__restrict__ X,
     }
   }
   const double total = block_sum(local, scratch);
-  if (threadIdx.x == 0) atomicAdd(out + b, total / (double)T);
+  // one slot per bin tile of the mixture ([slot][B]); the launcher adds them in order
+  if (threadIdx.x == 0) out[(long long)blockIdx.x * d.B + b] = total / (double)T;
 }
 
 // ================================================================ normalisation of Q rows and D
@@ -1911,36 +1917,50 @@ int LAUNCHER(mnmf_spatial)(const void *X, const void *Q, double *Dsp, const doub
   return check_launch("k_mnmf_spatial");
 }
 
+// scratch of the deterministic loss sums (per-block / per-wave shares, folded in a fixed order)
+size_t LAUNCHER(mnmf_loss_ws_bytes)(int B, int F) {
+  const int a = (F + 15) / 16, b = ((F + 63) / 64) * 16 * 4;
+  return scalar_slots_bytes(B, a > b ? a : b);
+}
+
+// out[b] = the data term of the loss; loss_ws: mnmf_loss_ws_bytes()
 int LAUNCHER(mnmf_loss)(const void *X, const void *Q, const double *Dsp, const double *basis,
-                        const double *act, double *out, int B, int M, int F, int T, int K,
-                        hipStream_t st) {
+                        const double *act, double *out, void *loss_ws, int B, int M, int F, int T,
+                        int K, hipStream_t st) {
   Dims d{B, F, T, K};
   dim3 grid((F + 15) / 16, 1, B), block(256);
+  // (every block writes its slot: no reset needed)
   MNMF_DISPATCH_M(M, {
     if (K <= 16)
       hipLaunchKernelGGL((k_mnmf_loss<MM, true>), grid, block, 0, st, (const c128 *)X,
-                         (const c128 *)Q, Dsp, basis, act, out, d);
+                         (const c128 *)Q, Dsp, basis, act, (double *)loss_ws, d);
     else
       hipLaunchKernelGGL((k_mnmf_loss<MM, false>), grid, block, 0, st, (const c128 *)X,
-                         (const c128 *)Q, Dsp, basis, act, out, d);
+                         (const c128 *)Q, Dsp, basis, act, (double *)loss_ws, d);
   });
-  return check_launch("k_mnmf_loss");
+  const int rc = check_launch("k_mnmf_loss");
+  return rc ? rc : scalar_slots_fold(loss_ws, B, (int)grid.x, out, 0, st);
 }
 
-// out[b] += the data term of the loss from the hand-over (out zeroed by the caller)
+// out[b] = the data term of the loss from the hand-over; loss_ws: mnmf_loss_ws_bytes()
 int LAUNCHER(mnmf_loss_handover)(const double *Dsp, const double *basis, const double *act,
-                                 const double *P, const double *pscale, double *out, int B, int M,
-                                 int F, int T, int K, hipStream_t st) {
+                                 const double *P, const double *pscale, double *out, void *loss_ws,
+                                 int B, int M, int F, int T, int K, hipStream_t st) {
   if (!mnmf_fast_ok(B, F, T, K) || T % 2 != 0)
     return fail(SSSPY_ERR_UNSUPPORTED, "fastmnmf_loss_data_handover: no hand-over for this shape");
   const TailPlan plan = make_tail_plan(B, (F + 63) / 64, (T + 15) / 16, 256 * PBASIS_WAVES);
   dim3 fgrid(plan.full + plan.tail * plan.split);
+  const int nslots = plan.groups * (plan.split > 1 ? plan.split : 1) * 4;
+  int rc = scalar_slots_begin(loss_ws, B, nslots, st);
+  if (rc) return rc;
+  // (MODE_LOSS: `tailpart` = the slots, `floor_kind` = B, see the kernel)
   MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_LOSS, P_READ>), fgrid,
                                         dim3(256), 0, st, (const c128 *)nullptr,
                                         (const c128 *)nullptr, (double *)Dsp, (double *)basis, act,
-                                        (c128 *)nullptr, F, T, K, 0, 0.0, plan, out,
+                                        (c128 *)nullptr, F, T, K, B, 0.0, plan, (double *)loss_ws,
                                         const_cast<double *>(P), pscale));
-  return check_launch("k_mnmf_loss_handover");
+  rc = check_launch("k_mnmf_loss_handover");
+  return rc ? rc : scalar_slots_fold(loss_ws, B, nslots, out, 0, st);
 }
 
 int LAUNCHER(mnmf_norm_scale)(void *Q, double *Dsp, const double *qbuf, int B, int M, int F,

@@ -1771,7 +1771,8 @@ def test_rng_drawn_initial_state_against_golden(case):
 
 
 # ------------------------------------------------------------------------------- determinism
-@pytest.mark.parametrize("kind", ["auxiva_ip", "auxiva_iss", "ilrma_iss", "ilrma_ip", "gmnmf"])
+@pytest.mark.parametrize("kind", ["auxiva_ip", "auxiva_iss", "ilrma_iss", "ilrma_ip", "gmnmf",
+                                  "fmnmf", "fmnmf_wide"])
 def test_state_is_bitwise_reproducible(kind):
     """No fp64 atomics on anything the state depends on (frame powers of AuxIVA and of the fused ISS
     sweep, output power of the ISS normalisation, GaussMNMF's activation sums) nor on the ILRMA /
@@ -1779,10 +1780,12 @@ def test_state_is_bitwise_reproducible(kind):
     for a batch."""
     from ssspy_amd.bss.ilrma import GaussILRMA
     from ssspy_amd.bss.iva import AuxLaplaceIVA
-    from ssspy_amd.bss.mnmf import GaussMNMF
+    from ssspy_amd.bss.mnmf import FastGaussMNMF, GaussMNMF
     from ssspy_amd.utils.dataset import nmf_mixture
 
     N, F, T, K = (2, 24, 40, 3) if kind == "gmnmf" else (4, 257, 300, 6)
+    if kind == "fmnmf_wide":  # the point-wise path above 4 channels
+        N, F, T, K = 5, 33, 64, 3
     for B in (1, 5):
         X = np.stack([nmf_mixture(950 + b, N, F, T) for b in range(B)])
 
@@ -1792,18 +1795,21 @@ def test_state_is_bitwise_reproducible(kind):
                                   record_loss=True)
                 return m(X, n_iter=6), np.asarray(m.loss)
             if kind == "gmnmf":
-                m = GaussMNMF(n_basis=K, record_loss=False, rng=np.random.default_rng(3))
-                return m(X, n_iter=3), None
+                m = GaussMNMF(n_basis=K, record_loss=True, rng=np.random.default_rng(3))
+                return m(X, n_iter=3), np.asarray(m.loss)
+            if kind.startswith("fmnmf"):
+                m = FastGaussMNMF(n_basis=K, record_loss=True, rng=np.random.default_rng(3))
+                return m(X, n_iter=4), np.asarray(m.loss)
             m = GaussILRMA(n_basis=K, spatial_algorithm="ISS" if kind.endswith("iss") else "IP",
                            record_loss=True, rng=np.random.default_rng(3))
             return m(X, n_iter=6), np.asarray(m.loss)
 
         (Y1, L1), (Y2, L2) = run(), run()
         assert np.array_equal(Y1, Y2), (kind, B)
-        # the recorded losses too (ILRMA: per-wave shares folded in order, both as the by-product of
-        # the basis pass and from the loss pass; ISS: the tracked log-determinant)
-        if L1 is not None:
-            assert np.array_equal(L1, L2), (kind, B)
+        # the recorded losses too (per-wave / per-block shares folded in a fixed order: ILRMA both as
+        # the by-product of the basis pass and from the loss pass, ISS with the tracked
+        # log-determinant, FastMNMF from the hand-over and from x, GaussMNMF)
+        assert np.array_equal(L1, L2), (kind, B)
 
 
 # ------------------------------------------------------------------------------- arbitrary floors
