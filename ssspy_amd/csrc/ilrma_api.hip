@@ -21,7 +21,7 @@ namespace ssspy {
 DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
 #undef DECL_N
 
-// throughput variants (ilrma_fast.hip): n_basis <= 32 (two k tiles above 16), n_sources <= 4, models
+// throughput variants (ilrma_fast.hip): n_basis <= 64 (two / four k tiles above 16 / 32), n_sources <= 4, models
 // of fast_model_id()
 #define DECL_FAST(n)                                                                           \
   int ilrma_fast_basis_n##n(const void *, const void *, const double *, double *, const double *, \
@@ -84,7 +84,7 @@ static inline double fast_model_param(double domain, int source_model, double mo
 static inline bool fast_path(int N, int F, int T, int K, double domain,
                              int source_model = SSSPY_SOURCE_GAUSS) {
   static const bool disabled = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;
-  return !disabled && fast_model_id(domain, source_model) >= 0 && N >= 2 && N <= 4 && K <= 32 &&
+  return !disabled && fast_model_id(domain, source_model) >= 0 && N >= 2 && N <= 4 && K <= 64 &&
          (long long)F * T * 16 < (1ll << 32);
 }
 static inline int is_me(int source_model) { return (source_model & SSSPY_SOURCE_ME) ? 1 : 0; }

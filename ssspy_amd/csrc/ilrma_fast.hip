@@ -95,7 +95,7 @@ enum { IN_Y = 0, IN_X = 1, IN_P = 2 };
 // (the x tile is dead before GEMM1's operands go live); results go to `basis_out` (the sibling
 // item still reads the old basis), which the launcher copies back.
 template <int IN, int MODEL, bool LOSS, int KS>
-__global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 *__restrict__ X,
+__global__ __launch_bounds__(256, KS >= 8 ? 1 : 2) void k_basis_fast(const c128 *__restrict__ X,
                                                        const c128 *__restrict__ W,
                                                        const double *basis, double *basis_out,
                                                        const double *__restrict__ act, int F,
@@ -112,8 +112,9 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 
   const int c = lane & 15, q = lane >> 4;
   const BlockWork work = block_work(plan);
   const int b = work.b, nchunks = work.nchunks;
-  const int group = KS == 8 ? work.group >> 1 : work.group;
-  const int kt = KS == 8 ? work.group & 1 : 0;  // the 16-wide k tile this item accumulates
+  constexpr int KT = KS / 4;  // k tiles (= items per bin group): 1, 2 or 4
+  const int group = work.group / KT;
+  const int kt = work.group % KT;  // the 16-wide k tile this item accumulates
   const int i0 = group * 64 + wave * 16;
   const int bin = min(i0 + c, F - 1);
   const bool bin_valid = i0 + c < F;
@@ -164,10 +165,10 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 
     const int jn = min(jt + 1, jt_end - 1) * 16;  // last iteration re-fetches its own tile
     if constexpr (PIN) fast::ptile_load_binmajor<N>(pcur, xsrc, T, bin, j0, q);
     else fast::xtile_load_binmajor<N>(cur, xsrc, T, bin, j0, q);
-    if (KS != 8) fast::vstage_load<N, KR>(st, act_b, K, T, jn);
+    if (KS < 8) fast::vstage_load<N, KR>(st, act_b, K, T, jn);
     const double *vcur = vs[(jt - jt_begin) & 1];
-    double pwall[KS == 8 ? N : 1][4];
-    if (KS == 8) {
+    double pwall[KS >= 8 ? N : 1][4];
+    if (KS >= 8) {
       // |y|^2 of every source first: the x tile dies here.  One demixing coefficient at a time and
       // the next activation tile requested only afterwards keep this phase inside the budget.
 #pragma unroll
@@ -198,14 +199,14 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 
       const double2 vb23 = *reinterpret_cast<const double2 *>(vrow + 2);
       const double vb[4] = {vb01.x, vb01.y, vb23.x, vb23.y};
       c128 wr[N];
-      if (KS != 8) {
+      if (KS < 8) {
 #pragma unroll
         for (int m = 0; m < N; ++m) wr[m] = wmine[n * N + m];
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double pw;
-        if (KS == 8) {
+        if (KS >= 8) {
           pw = pwall[n][r];
         } else {
           c128 y = cur.x[n][r];
@@ -274,7 +275,8 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_basis_fast(const c128 
 
 // basis <- floor(basis * sqrt(sum_chunks num / sum_chunks den)) for the split (tail) items;
 // grid: (N*64*16/256, tail items); one thread per (n, local bin, k)
-// ktiles: 1 (n_basis <= 16) or 2 (the item index also carries the k tile, see k_basis_fast<.., 8>)
+// ktiles: 1 (n_basis <= 16), 2 (<= 32) or 4 (<= 64): the item index also carries the k tile, see
+// k_basis_fast<.., 8 | 16>
 // loss_slots / loss_scale: the split items' share of the loss by-product sum_k t num (see k_basis_fast)
 __global__ __launch_bounds__(256) void k_basis_finalize(const double *basis, double *basis_out,
                                                         const double *__restrict__ part, int F,
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) void k_basis_finalize(const double *basis, dou
   const int tail_idx = blockIdx.y;
   const int item = plan.full + tail_idx;
   const int b = item / plan.groups, g2 = item - b * plan.groups;
-  const int group = ktiles == 2 ? g2 >> 1 : g2, kt = ktiles == 2 ? g2 & 1 : 0;
+  const int group = g2 / ktiles, kt = g2 % ktiles;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (n, local bin, k16)
   const int k = 16 * kt + (e & 15), lb = (e >> 4) & 63, n = e >> 10;
   const int bin = group * 64 + lb;
@@ -448,7 +450,7 @@ constexpr int WC_BINS = 16 * WC_WB;              // bins per workgroup
 // KS: k-steps of GEMM1 compiled in (4: n_basis <= 16, 8: n_basis <= 32; no k tiles here, the pass has
 // no second GEMM)
 template <int MODEL, int KS>
-__global__ __launch_bounds__(256, 2) void k_wcov_fast(const c128 *__restrict__ X,
+__global__ __launch_bounds__(256, KS >= 16 ? 1 : 2) void k_wcov_fast(const c128 *__restrict__ X,
                                                       const c128 *__restrict__ W,
                                                       const double *__restrict__ basis,
                                                       const double *__restrict__ act,
@@ -720,10 +722,10 @@ __device__ __forceinline__ void tstage_store(const TStage<KS> &st, double *tbuf,
 }
 
 // HAS_W = false: the ISS / IPA state passes the separated spectrogram itself (y = x_n, no filter)
-// KS = 8 (16 < n_basis <= 32): grid.y carries (bin chunk, k tile); both k-tile items run GEMM1 over all
-// 32 k and keep the sums of their own 16 (see k_basis_fast); one wave per SIMD.
+// KS = 8 / 16 (16 < n_basis <= 32 / 64): grid.y carries (bin chunk, k tile); every k-tile item runs
+// GEMM1 over all k and keeps the sums of its own 16 (see k_basis_fast); one wave per SIMD.
 template <int IN, int MODEL, int KS>
-__global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_activation_fast(
+__global__ __launch_bounds__(256, KS >= 8 ? 1 : 2) void k_activation_fast(
     const c128 *__restrict__ X, const c128 *__restrict__ W, const double *__restrict__ basis,
     const double *__restrict__ act, double *__restrict__ part, int F, int T, int K,
     int tiles_per_chunk, int nchunks, FastModel fm) {
@@ -736,8 +738,9 @@ __global__ __launch_bounds__(256, KS == 8 ? 1 : 2) void k_activation_fast(
   // (frame group, bin chunk [x k tile], mixture) from the XCD-contiguous item: the frame groups of
   // one (mixture, chunk) share the staged basis tiles and demixing matrices
   const GridItem gi = xcd_contiguous_grid();
-  const int chunk = KS == 8 ? gi.y >> 1 : gi.y, b = gi.z;
-  const int kt = KS == 8 ? gi.y & 1 : 0;
+  constexpr int KT = KS / 4;  // k tiles: grid.y = chunks x KT
+  const int chunk = gi.y / KT, b = gi.z;
+  const int kt = gi.y % KT;
   const int ksteps = (K + 3) >> 2;
   const int j0 = (gi.x * 4 + wave) * 16;
   const int jf = j0 + c;
@@ -868,10 +871,10 @@ int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis
   if (power_in && (W != nullptr || loss_out != nullptr))
     return fail(SSSPY_ERR_BADARG, "ilrma_fast_basis: power input excludes a filter and the loss");
   if (loss_out && !loss_ws) return fail(SSSPY_ERR_BADARG, "ilrma_fast_basis: loss without scratch");
-  const int ktiles = K > 16 ? 2 : 1;
-  // (the wide variant holds one workgroup per CU)
+  const int ktiles = K > 32 ? 4 : (K > 16 ? 2 : 1);
+  // (the wide variants hold one workgroup per CU)
   const TailPlan plan =
-      make_tail_plan(B, ((F + 63) / 64) * ktiles, (T + 15) / 16, ktiles == 2 ? 256 : SLOTS);
+      make_tail_plan(B, ((F + 63) / 64) * ktiles, (T + 15) / 16, ktiles >= 2 ? 256 : SLOTS);
   const FastModel fm = make_fast_model(fmodel, mparam, me);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
   // loss slots per mixture: (bin group, chunk, wave) of the pass, then (bin group, block, wave) of
@@ -899,12 +902,20 @@ int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis
     default: SSSPY_BASIS_LAUNCH(HW, FM_GAUSS, L, KS_); break;             \
   }
   if (power_in) {
-    if (ktiles == 2) {
+    if (ktiles == 4) {
+      SSSPY_BASIS_LAUNCH_M(IN_P, false, 16)
+    } else if (ktiles == 2) {
       SSSPY_BASIS_LAUNCH_M(IN_P, false, 8)
     } else {
       SSSPY_BASIS_LAUNCH_M(IN_P, false, 4)
     }
-  } else if (ktiles == 2) {  // the wide variant carries no loss by-product (register budget)
+  } else if (ktiles == 4) {  // the wide variants carry no loss by-product (register budget)
+    if (W != nullptr) {
+      SSSPY_BASIS_LAUNCH_M(true, false, 16)
+    } else {
+      SSSPY_BASIS_LAUNCH_M(false, false, 16)
+    }
+  } else if (ktiles == 2) {
     if (W != nullptr) {
       SSSPY_BASIS_LAUNCH_M(true, false, 8)
     } else {
@@ -957,7 +968,7 @@ int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *
   const int ntiles = (F + 15) / 16;
   const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
   const FastModel fm = make_fast_model(fmodel, mparam, 0);
-  const int ktiles = K > 16 ? 2 : 1;
+  const int ktiles = K > 32 ? 4 : (K > 16 ? 2 : 1);
   dim3 grid((T + 63) / 64, nchunks * ktiles, B), block(256);
 #define SSSPY_ACT_LAUNCH(HW, M, KS_)                                                             \
   hipLaunchKernelGGL((k_activation_fast<HW, M, KS_>), grid, block, 0, st, (const c128 *)X,        \
@@ -971,10 +982,18 @@ int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *
     default: SSSPY_ACT_LAUNCH(HW, FM_GAUSS, KS_); break;   \
   }
   if (power_in) {
-    if (ktiles == 2) {
+    if (ktiles == 4) {
+      SSSPY_ACT_LAUNCH_M(IN_P, 16)
+    } else if (ktiles == 2) {
       SSSPY_ACT_LAUNCH_M(IN_P, 8)
     } else {
       SSSPY_ACT_LAUNCH_M(IN_P, 4)
+    }
+  } else if (ktiles == 4) {
+    if (W != nullptr) {
+      SSSPY_ACT_LAUNCH_M(true, 16)
+    } else {
+      SSSPY_ACT_LAUNCH_M(false, 16)
     }
   } else if (ktiles == 2) {
     if (W != nullptr) {
@@ -1020,7 +1039,8 @@ int LAUNCHER(ilrma_fast_wcov)(const void *X, const void *W, const double *basis,
                               int *split_out = nullptr, int *rbins_out = nullptr) {
   if (split_out) *split_out = 0;
   if (rbins_out) *rbins_out = WC_BINS;
-  const TailPlan plan = make_tail_plan(B, (F + WC_BINS - 1) / WC_BINS, (T + 15) / 16);
+  const TailPlan plan =
+      make_tail_plan(B, (F + WC_BINS - 1) / WC_BINS, (T + 15) / 16, K > 32 ? 256 : SLOTS);
   const FastModel fm = make_fast_model(fmodel, mparam, 0, floor_kind, floor_eps);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
 #define SSSPY_WCOV_LAUNCH(M, KS_)                                                                 \
@@ -1034,7 +1054,9 @@ int LAUNCHER(ilrma_fast_wcov)(const void *X, const void *W, const double *basis,
     case FM_GAUSSP: SSSPY_WCOV_LAUNCH(FM_GAUSSP, KS_); break; \
     default: SSSPY_WCOV_LAUNCH(FM_GAUSS, KS_); break;  \
   }
-  if (K > 16) {
+  if (K > 32) {  // (one workgroup per CU: the 64-row GEMM1 operands take the whole register file)
+    SSSPY_WCOV_LAUNCH_M(16)
+  } else if (K > 16) {
     SSSPY_WCOV_LAUNCH_M(8)
   } else {
     SSSPY_WCOV_LAUNCH_M(4)

@@ -370,9 +370,10 @@ def test_heavy_tailed_ilrma_constructor_contract():
     assert "dof=3" in repr(TILRMA(n_basis=2, dof=3)) and repr(TILRMA(2, 3)).startswith("TILRMA(")
 
 
-@pytest.mark.parametrize("K", [1, 7, 16, 17, 24, 32, 33, 40, 100])
+@pytest.mark.parametrize("K", [1, 7, 16, 17, 24, 32, 33, 40, 48, 64, 65, 100])
 def test_gauss_ilrma_n_basis_sweep_against_oracle(K):
-    """n_basis off the 16-wide MFMA tile (1, 7), on it (16), and in the K>16 path (17, 40)."""
+    """n_basis off the 16-wide MFMA tile (1, 7), on it (16), on the two- and four-k-tile variants of
+    the tuned kernels (17..32, 33..64) and beyond them (65, 100: generic kernels)."""
     from oracle.ilrma import GaussILRMAOracle
     from ssspy_amd.bss.ilrma import GaussILRMA
     from ssspy_amd.utils.dataset import nmf_mixture
@@ -388,6 +389,30 @@ def test_gauss_ilrma_n_basis_sweep_against_oracle(K):
     assert rel_err(Y, Yr) < TOL
     assert rel_err(m.basis, ref.basis) < TOL and rel_err(m.activation, ref.activation) < TOL
     np.testing.assert_allclose(m.loss, ref.loss, rtol=LOSS_RTOL)
+
+
+@pytest.mark.parametrize("K,algo", [(40, "IP"), (64, "IP"), (48, "ISS")])
+def test_gauss_ilrma_wide_basis_batch_equals_single_and_oracle(K, algo):
+    """33 <= n_basis <= 64 on a batch large enough for unsplit and split work items (four k-tile
+    items per bin group): elements equal their single-mixture runs, element 0 the oracle."""
+    from oracle.ilrma import GaussILRMAOracle
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    B, N, F, T = 70, 4, 70, 50
+    X = np.stack([nmf_mixture(400 + b, N, F, T) for b in range(B)])
+    rng = np.random.default_rng(K)
+    basis, act = rng.random((B, N, F, K)), rng.random((B, N, K, T))
+    m = GaussILRMA(n_basis=K, spatial_algorithm=algo)
+    Y = m(X, n_iter=3, basis=basis, activation=act)
+    for b in (0, 33, 69):
+        s1 = GaussILRMA(n_basis=K, spatial_algorithm=algo)
+        Yb = s1(X[b], n_iter=3, basis=basis[b], activation=act[b])
+        assert rel_err(Y[b], Yb) < 1e-11, b
+        assert rel_err(m.basis[b], s1.basis) < 1e-11 and rel_err(m.activation[b], s1.activation) < 1e-11
+    ref = GaussILRMAOracle(n_basis=K, spatial_algorithm=algo)
+    Yr = ref.run(X[0], n_iter=3, basis=basis[0], activation=act[0])
+    assert rel_err(Y[0], Yr) < TOL
 
 
 @pytest.mark.parametrize("N,algo", [(2, "IP"), (5, "IP"), (6, "ISS"), (8, "IP")])
