@@ -24,6 +24,7 @@ python benchmarks/other_configs.py > $out/other_configs.txt 2>&1
 python benchmarks/other_configs.py --batch 32 >> $out/other_configs.txt 2>&1
 python benchmarks/other_configs.py --batch 128 --only fastmnmf --iters 10 >> $out/other_configs.txt 2>&1
 python benchmarks/wide_mixtures.py >> $out/other_configs.txt 2>&1
+python benchmarks/wide_basis.py >> $out/other_configs.txt 2>&1
 # per-kernel statistics of configs[2] / configs[3] at 32 mixtures
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/other_stats -- \
   python benchmarks/other_configs.py --batch 32 --only iva_iss,fastmnmf --iters 10 > $out/other_stats.log 2>&1
