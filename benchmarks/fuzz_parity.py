@@ -35,7 +35,7 @@ def main():
         N = int(rng.choice([2, 3, 4, 4, 5, 6, 7, 8]))  # above 4: grouped NMF passes, wide covariance
         F = int(rng.choice([1, 3, 15, 16, 17, 31, 33, 63, 64, 65, 70, 129]))
         T = int(rng.choice([2, 5, 15, 16, 17, 31, 32, 33, 47, 64, 65, 100, 130]))
-        K = int(rng.choice([1, 2, 3, 4, 7, 8, 15, 16, 17, 24, 32]))  # 17..32: the two-k-tile variants
+        K = int(rng.choice([1, 2, 3, 4, 7, 8, 15, 16, 17, 24, 32, 33, 48, 64, 70]))  # 17..32 / 33..64: the two- / four-k-tile variants
         B = int(rng.choice([1, 1, 1, 2, 5, 40]))
         algo = str(rng.choice(["IP", "ISS", "IP2", "ISS2"]))
         if T < 2 * N:
