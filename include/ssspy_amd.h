@@ -66,7 +66,7 @@ enum { SSSPY_SOURCE_GAUSS = 0, SSSPY_SOURCE_T = 1, SSSPY_SOURCE_GGD = 2 };
 enum { SSSPY_SOURCE_ME = 0x100 };
 
 #define SSSPY_MAX_SOURCES 8
-#define SSSPY_MAX_BASIS 256
+#define SSSPY_MAX_BASIS 1024 /* ILRMA; the MNMF entry points take n_basis <= 256 */
 #define SSSPY_MAX_PAIRS 32
 
 const char *ssspy_amd_version(void);

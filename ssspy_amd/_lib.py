@@ -21,7 +21,7 @@ PARTITION_LATENT, PARTITION_BASIS, PARTITION_ACTIVATION = 1, 2, 4
 SOURCE_ME = 0x100  # OR-ed into the model: source_algorithm="ME"
 CONTRAST_LAPLACE, CONTRAST_GAUSS, CONTRAST_GAUSS_FIXED = 0, 1, 2
 MAX_PAIRS = 32
-MAX_SOURCES, MAX_BASIS = 8, 256
+MAX_SOURCES, MAX_BASIS = 8, 1024
 
 _p, _i, _d, _z = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
 _q = ctypes.c_longlong

@@ -659,7 +659,7 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
                              void *stream, bool x_is_power = false) {
   // x_is_power (grouped path of a wide mixture only, W == NULL): X holds |y|^2 (B, N, F, T) f64
   SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0, "update_basis: bad argument");
-  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_basis: n_basis must be in [1, 256]");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_basis: n_basis must be in [1, 1024]");
   SSSPY_REQUIRE(domain > 0.0 && domain <= 2.0, "update_basis: domain must be in (0, 2]");
   int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
@@ -738,7 +738,7 @@ static int update_activation_impl(const void *X, const void *W, const double *ba
                                   size_t workspace_bytes, void *stream, bool x_is_power) {
   SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0,
                 "update_activation: bad argument");
-  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_activation: n_basis must be in [1, 256]");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_activation: n_basis must be in [1, 1024]");
   int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
   const IlrmaWs w = ilrma_ws(B, N, F, T, K);
@@ -1098,7 +1098,7 @@ int ssspy_ilrma_partition_update(const void *X, const void *W, double *basis, do
   SSSPY_REQUIRE(X && basis && activation && latent && Teff && Vrep && B > 0 && F > 0 && T > 0,
                 "partition_update: bad argument");
   SSSPY_REQUIRE(N >= 1 && N <= SSSPY_MAX_SOURCES, "partition_update: n_sources must be in [1, 8]");
-  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "partition_update: n_basis must be in [1, 256]");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "partition_update: n_basis must be in [1, 1024]");
   SSSPY_REQUIRE(domain > 0.0 && domain <= 2.0, "partition_update: domain must be in (0, 2]");
   int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;

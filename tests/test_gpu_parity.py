@@ -356,6 +356,29 @@ def test_partitioned_ilrma_batch_against_oracle(model, algo, src):
         np.testing.assert_allclose(np.asarray(m.loss)[:, b], ref.loss, rtol=LOSS_RTOL)
 
 
+def test_partitioned_ilrma_many_bases_against_oracle():
+    """partitioning=True with n_basis = 300 (the latent variables of all sources sit in LDS of one
+    workgroup: sized for n_basis <= 1024) and n_basis beyond the limit refused loudly."""
+    from oracle.ilrma import GaussILRMAOracle
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    N, F, T, K = 3, 12, 30, 300
+    X = nmf_mixture(44, N, F, T)
+    rng = np.random.default_rng(12)
+    basis, act = rng.random((F, K)), rng.random((K, T))
+    lat = rng.random((N, K))
+    lat = lat / lat.sum(axis=0, keepdims=True)
+    m = GaussILRMA(n_basis=K, partitioning=True)
+    Y = m(X, n_iter=3, basis=basis, activation=act, latent=lat)
+    ref = GaussILRMAOracle(n_basis=K, partitioning=True)
+    Yr = ref.run(X, n_iter=3, basis=basis, activation=act, latent=lat)
+    assert rel_err(Y, Yr) < TOL and rel_err(m.latent, ref.latent) < TOL
+    np.testing.assert_allclose(m.loss, ref.loss, rtol=LOSS_RTOL)
+    with pytest.raises((NotImplementedError, ValueError)):
+        GaussILRMA(n_basis=1025)(X, n_iter=1)
+
+
 def test_heavy_tailed_ilrma_constructor_contract():
     from ssspy_amd.bss.ilrma import GGDILRMA, TILRMA
 
@@ -370,7 +393,7 @@ def test_heavy_tailed_ilrma_constructor_contract():
     assert "dof=3" in repr(TILRMA(n_basis=2, dof=3)) and repr(TILRMA(2, 3)).startswith("TILRMA(")
 
 
-@pytest.mark.parametrize("K", [1, 7, 16, 17, 24, 32, 33, 40, 48, 64, 65, 100])
+@pytest.mark.parametrize("K", [1, 7, 16, 17, 24, 32, 33, 40, 48, 64, 65, 100, 300])
 def test_gauss_ilrma_n_basis_sweep_against_oracle(K):
     """n_basis off the 16-wide MFMA tile (1, 7), on it (16), on the two- and four-k-tile variants of
     the tuned kernels (17..32, 33..64) and beyond them (65, 100: generic kernels)."""
