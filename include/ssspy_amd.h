@@ -553,7 +553,7 @@ int ssspy_lqpqm2(const void *H, const void *v, const double *z, void *y, long lo
  * The transforms the reference's workflow takes from SciPy either side of a separator
  * (tests/package/bss/test_ilrma.py, test_iva.py, test_mnmf.py: scipy.signal.stft(x, window="hann",
  * nperseg=n_fft, noverlap=n_fft - hop) and scipy.signal.istft), with SciPy's defaults:
- * boundary="zeros", padded=True, one-sided, scaling="spectrum".  n_fft a power of two <= 4096.
+ * boundary="zeros", padded=True, one-sided, scaling="spectrum".  n_fft a power of two <= 8192.
  * x (B, C, n_samples) f64 -> Z (B, C, n_fft/2+1, ssspy_stft_frames(...)) c128; `window` (n_fft) f64
  * on the device, `window_sum` its sum. */
 int ssspy_stft_frames(long long n_samples, int n_fft, int hop);

@@ -9,7 +9,7 @@
 // (where it exceeds 1e-10), boundary removed.
 //
 // One workgroup transforms one segment in LDS: bit-reversed load, log2(n) radix-2 passes, twiddles
-// from sincospi.  n_fft is a power of two up to 4096 (64 KB of complex128).
+// from sincospi.  n_fft is a power of two up to 8192 (128 KB of complex128 in LDS).
 #include "common.hpp"
 #include "ssspy_amd.h"
 
@@ -120,6 +120,17 @@ using namespace ssspy;
 
 extern "C" {
 
+// the segment sits in LDS: 16 bytes x n_fft, 128 KB of the CU's 160 at 8192 (above the 64 KB a
+// launch gets by default: raise the kernel's limit first)
+constexpr int STFT_MAX_NFFT = 8192;
+static int allow_lds(const void *kernel, int n_fft) {
+  const size_t bytes = (size_t)n_fft * sizeof(c128);
+  if (bytes <= 64 * 1024) return SSSPY_OK;
+  hipError_t e =
+      hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return e == hipSuccess ? SSSPY_OK : fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+}
+
 int ssspy_stft_frames(long long n_samples, int n_fft, int hop) {
   if (n_samples <= 0 || n_fft <= 0 || hop <= 0) return 0;
   long long Lp = n_samples + 2LL * (n_fft / 2);
@@ -135,8 +146,10 @@ int ssspy_stft(const double *x, void *Z, const double *window, double window_sum
                     window_sum != 0.0,
                 "stft: bad argument");
   const int lg = ilog2_exact(n_fft);
-  if (lg < 1 || n_fft > 4096)
-    return fail(SSSPY_ERR_UNSUPPORTED, "stft: n_fft must be a power of two in [2, 4096]");
+  if (lg < 1 || n_fft > STFT_MAX_NFFT)
+    return fail(SSSPY_ERR_UNSUPPORTED, "stft: n_fft must be a power of two in [2, 8192]");
+  int rc0 = allow_lds((const void *)k_stft, n_fft);
+  if (rc0) return rc0;
   const int n_frames = ssspy_stft_frames(n_samples, n_fft, hop);
   hipLaunchKernelGGL(k_stft, dim3(n_frames, C, B), dim3(256), (size_t)n_fft * sizeof(c128),
                      as_stream(stream), x, (c128 *)Z, n_samples, n_fft, lg, hop, n_frames, window,
@@ -155,8 +168,10 @@ int ssspy_istft(const void *Z, double *x, const double *window, double window_su
                     hop <= n_fft,
                 "istft: bad argument");
   const int lg = ilog2_exact(n_fft);
-  if (lg < 1 || n_fft > 4096)
-    return fail(SSSPY_ERR_UNSUPPORTED, "istft: n_fft must be a power of two in [2, 4096]");
+  if (lg < 1 || n_fft > STFT_MAX_NFFT)
+    return fail(SSSPY_ERR_UNSUPPORTED, "istft: n_fft must be a power of two in [2, 8192]");
+  int rc0 = allow_lds((const void *)k_istft_segments, n_fft);
+  if (rc0) return rc0;
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(k_istft_segments, dim3(n_frames, C, B), dim3(256),
                      (size_t)n_fft * sizeof(c128), st, (const c128 *)Z, segments, n_fft, lg,

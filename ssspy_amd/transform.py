@@ -8,7 +8,7 @@ reference's workflow uses either side of a separator (``window="hann"``, ``bound
 
 Both take NumPy arrays or device tensors; with ``device_output=True`` the result stays in HBM, so
 a separator can consume the spectrogram (``_bind_input`` accepts device tensors) and hand its
-output to ``istft`` without the spectrogram crossing PCIe.  ``n_fft`` is a power of two <= 4096.
+output to ``istft`` without the spectrogram crossing PCIe.  ``n_fft`` is a power of two <= 8192.
 """
 
 from typing import Optional, Union

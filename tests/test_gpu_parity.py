@@ -1179,7 +1179,7 @@ def test_large_batch_paths_against_oracle(T):
 
 # ------------------------------------------------------------------------------- STFT / ISTFT
 @pytest.mark.parametrize("n_fft,hop,L", [(64, 16, 1000), (256, 128, 4097), (1024, 256, 9000),
-                                         (4096, 1024, 20000), (128, 128, 777)])
+                                         (4096, 1024, 20000), (128, 128, 777), (8192, 2048, 40000)])
 def test_stft_istft_against_scipy(n_fft, hop, L):
     """The transforms the reference's workflow takes from scipy.signal, with SciPy's defaults."""
     import scipy.signal as ss
