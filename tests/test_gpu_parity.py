@@ -1876,6 +1876,41 @@ def test_arbitrary_flooring_callable_against_golden(case):
     _replay_uninjected(load_golden(case), flooring_fn=_golden_custom_floor)
 
 
+@pytest.mark.parametrize("kind", ["ilrma_ip", "ilrma_iss", "tilrma_ip", "auxiva_ip", "auxiva_iss"])
+def test_host_evaluated_floor_equals_the_kernel_floor(kind):
+    """A callable the kernels do not recognise but that computes max(x, eps) takes the host path
+    (split steps, floor on the small arrays); the recognised ``max_flooring`` runs inside the
+    kernels.  Same mathematics, different code on both sides of the boundary: the results agree
+    to rounding, on a batch and at a size the goldens do not reach."""
+    import functools
+
+    from ssspy_amd.bss.ilrma import TILRMA, GaussILRMA
+    from ssspy_amd.bss.iva import AuxLaplaceIVA
+    from ssspy_amd.special.flooring import max_flooring
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    eps = 1e-9
+    B, N, F, T = 3, 4, 129, 150
+    X = np.stack([nmf_mixture(620 + b, N, F, T) for b in range(B)])
+
+    def make(floor):
+        rng = np.random.default_rng(8)
+        if kind == "ilrma_ip":
+            return GaussILRMA(n_basis=6, flooring_fn=floor, rng=rng)
+        if kind == "ilrma_iss":
+            return GaussILRMA(n_basis=6, spatial_algorithm="ISS", flooring_fn=floor, rng=rng)
+        if kind == "tilrma_ip":
+            return TILRMA(n_basis=6, dof=4.0, flooring_fn=floor, rng=rng)
+        return AuxLaplaceIVA(spatial_algorithm="IP" if kind.endswith("ip") else "ISS",
+                             flooring_fn=floor)
+
+    dev = make(functools.partial(max_flooring, eps=eps))
+    host = make(lambda x: np.maximum(x, eps))
+    Yd, Yh = dev(X, n_iter=5), host(X, n_iter=5)
+    assert rel_err(Yh, Yd) < 1e-10
+    np.testing.assert_allclose(np.asarray(host.loss), np.asarray(dev.loss), rtol=1e-10)
+
+
 def test_arbitrary_flooring_callable_unsupported_paths_fail_loudly():
     from ssspy_amd.bss.ilrma import GaussILRMA
     from ssspy_amd.bss.mnmf import FastGaussMNMF
