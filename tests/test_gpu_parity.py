@@ -121,6 +121,35 @@ def test_ipa_operator_against_golden(N):
     assert rel_err(update_by_ipa(Y, varphi, max_iter=12), g["n{}_out_it12".format(N)]) < 1e-10
 
 
+@pytest.mark.parametrize("newton_iter", [1, 6, 40])
+def test_ipa_newton_step_count_is_per_mixture(newton_iter):
+    """The reference stops its joint Newton loop when every bin of THE mixture has converged
+    (ssspy/linalg/lqpqm.py:196-213): in a batch each mixture keeps its own step count, so every
+    element equals its single-mixture run, and element 0 the oracle."""
+    import warnings
+
+    from oracle.ilrma import GaussILRMAOracle
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    B, N, F, T, K = 4, 3, 33, 60, 4
+    X = np.stack([nmf_mixture(810 + 7 * b, N, F, T) for b in range(B)])
+    rng = np.random.default_rng(21)
+    basis, act = rng.random((B, N, F, K)), rng.random((B, N, K, T))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # (the reference's "did not converge" at small step counts)
+        m = GaussILRMA(n_basis=K, spatial_algorithm="IPA", newton_iter=newton_iter)
+        Y = m(X, n_iter=3, basis=basis, activation=act)
+        for b in range(B):
+            s1 = GaussILRMA(n_basis=K, spatial_algorithm="IPA", newton_iter=newton_iter)
+            Yb = s1(X[b], n_iter=3, basis=basis[b], activation=act[b])
+            assert rel_err(Y[b], Yb) < 1e-12, b
+        ref = GaussILRMAOracle(n_basis=K, spatial_algorithm="IPA")
+        ref.newton_iter = newton_iter
+        Yr = ref.run(X[0], n_iter=3, basis=basis[0], activation=act[0])
+    assert rel_err(Y[0], Yr) < TOL
+
+
 def test_ipa_eight_sources_against_oracle():
     from oracle.ipa import update_by_ipa as oracle_ipa
     from ssspy_amd.bss._update_spatial_model import update_by_ipa
