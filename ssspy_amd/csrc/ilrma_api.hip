@@ -223,9 +223,11 @@ int wide_weighted_cov(const void *A, const double *weight, int kind, void *U, in
 // scratch of the bin-major fast kernels (basis, covariance): partial sums of the at most 512
 // split blocks of the last scheduling round (TailPlan in ilrma_fast.hip)
 // (wide mixtures run them in groups of at most 4 sources, see source_group())
+// (the wide variants, 16 < n_basis <= 64: at most 256 split blocks, each leaving one 16-k record per
+//  k tile it accumulates -- up to 4)
 static inline size_t basis_part_bytes(int N) {
   const int G = N < 4 ? N : 4;
-  return align256((size_t)512 * G * 64 * 16 * 2 * sizeof(double));
+  return align256((size_t)1024 * G * 64 * 16 * 2 * sizeof(double));
 }
 // scratch of the deterministic loss sums: the larger of what the tuned kernels (by-product of the
 // basis pass, loss pass) and the generic loss kernel need

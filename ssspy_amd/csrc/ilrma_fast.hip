@@ -112,9 +112,20 @@ __global__ __launch_bounds__(256, KS >= 8 ? 1 : 2) void k_basis_fast(const c128 
   const int c = lane & 15, q = lane >> 4;
   const BlockWork work = block_work(plan);
   const int b = work.b, nchunks = work.nchunks;
-  constexpr int KT = KS / 4;  // k tiles (= items per bin group): 1, 2 or 4
-  const int group = work.group / KT;
-  const int kt = work.group % KT;  // the 16-wide k tile this item accumulates
+  constexpr int KT = KS / 4;  // 16-wide k tiles of the n_basis range: 1, 2 or 4
+  // KTI: k tiles ONE item accumulates.  16 < n_basis <= 32: both (GEMM1 over the 32 k once per tile,
+  // GEMM2 for both tiles, their accumulators in the one-wave register file); n_basis above 32: one
+  // (four items per bin group, each repeating GEMM1).  -DSSSPY_KTILE_ITEMS: KTI = 1, the round-2 scheme of one item
+  // per k tile, each repeating GEMM1.
+#ifdef SSSPY_KTILE_ITEMS
+  constexpr int KTI = 1;
+#else
+  // (KS = 16: the 128-register GEMM1 operand leaves no room -- two tiles per item spill 74 VGPRs,
+  //  four 252 -- so n_basis above 32 keeps one tile per item)
+  constexpr int KTI = KS == 8 ? 2 : 1;
+#endif
+  const int group = work.group / (KT / KTI);
+  const int kt0 = (work.group % (KT / KTI)) * KTI;  // first k tile of this item
   const int i0 = group * 64 + wave * 16;
   const int bin = min(i0 + c, F - 1);
   const bool bin_valid = i0 + c < F;
@@ -143,12 +154,14 @@ __global__ __launch_bounds__(256, KS >= 8 ? 1 : 2) void k_basis_fast(const c128 
       const int kk = 4 * ks + q;
       tb[n][ks] = kk < K ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
     }
-  double4_t num[N], den[N];
+  double4_t num[N][KTI], den[N][KTI];
 #pragma unroll
-  for (int n = 0; n < N; ++n) {
-    num[n] = double4_t{0.0, 0.0, 0.0, 0.0};
-    den[n] = double4_t{0.0, 0.0, 0.0, 0.0};
-  }
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int ti = 0; ti < KTI; ++ti) {
+      num[n][ti] = double4_t{0.0, 0.0, 0.0, 0.0};
+      den[n][ti] = double4_t{0.0, 0.0, 0.0, 0.0};
+    }
 
   const int ntiles = (T + 15) >> 4;
   const int tpc = (ntiles + nchunks - 1) / nchunks;
@@ -194,10 +207,17 @@ __global__ __launch_bounds__(256, KS >= 8 ? 1 : 2) void k_basis_fast(const c128 
       const double *vn = vcur + n * KR * VROW;
       const double4_t R = rt_from_lds<KS>(vn, tb[n], c, q, ksteps);
       // GEMM2 B operand: V[n, k = 16 kt + c, frame q + 4r] (slots 4q .. 4q+3 of the permuted row)
-      const double *vrow = vn + (16 * kt + c) * VROW + 4 * q;
-      const double2 vb01 = *reinterpret_cast<const double2 *>(vrow);
-      const double2 vb23 = *reinterpret_cast<const double2 *>(vrow + 2);
-      const double vb[4] = {vb01.x, vb01.y, vb23.x, vb23.y};
+      double vb[KTI][4];
+#pragma unroll
+      for (int ti = 0; ti < KTI; ++ti) {
+        const double *vrow = vn + (16 * (kt0 + ti) + c) * VROW + 4 * q;
+        const double2 vb01 = *reinterpret_cast<const double2 *>(vrow);
+        const double2 vb23 = *reinterpret_cast<const double2 *>(vrow + 2);
+        vb[ti][0] = vb01.x;
+        vb[ti][1] = vb01.y;
+        vb[ti][2] = vb23.x;
+        vb[ti][3] = vb23.y;
+      }
       c128 wr[N];
       if (KS < 8) {
 #pragma unroll
@@ -221,8 +241,11 @@ __global__ __launch_bounds__(256, KS >= 8 ? 1 : 2) void k_basis_fast(const c128 
         const double rinv = rcp_nr(R[r]);
         const double bb = valid ? rinv : 0.0;
         const double aa = valid ? mm_num_factor<MODEL>(pw, R[r], rinv, fm) : 0.0;
-        num[n] = mfma_f64(aa, vb[r], num[n]);
-        den[n] = mfma_f64(bb, vb[r], den[n]);
+#pragma unroll
+        for (int ti = 0; ti < KTI; ++ti) {
+          num[n][ti] = mfma_f64(aa, vb[ti][r], num[n][ti]);
+          den[n][ti] = mfma_f64(bb, vb[ti][r], den[n][ti]);
+        }
         if (LOSS) {
           // log R of every element: LogSum, no log here.  The P/R part needs nothing per element:
           // see the epilogue.
@@ -239,30 +262,34 @@ __global__ __launch_bounds__(256, KS >= 8 ? 1 : 2) void k_basis_fast(const c128 
   // Loss by-product: sum_j a_nij R_nij = sum_k t_nik num_nik with the basis the pass started from, and
   // a R is the model's data term up to a constant (Gauss P/R, domain 1 P/R^2, GGD (beta/2)(P/R)^(beta/2)):
   // it falls out of the finished accumulators (the split items' share is added by k_basis_finalize).
-  const int kout = 16 * kt + c;
 #pragma unroll
-  for (int n = 0; n < N; ++n)
+  for (int ti = 0; ti < KTI; ++ti) {
+    const int kout = 16 * (kt0 + ti) + c;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ob = i0 + q + 4 * r;
-      if (ob < F && kout < K) {
-        if (nchunks == 1) {
-          const long long o = (((long long)b * N + n) * F + ob) * K + kout;
-          const double told = basis[o];
-          if (LOSS) lacc = fma(told, num[n][r], lacc);
-          const double ratio = num[n][r] / den[n][r];
-          basis_out[o] = apply_floor(ratio_pow(ratio, fm.expo) * told, floor_kind, eps);
-        } else {
-          const long long slot = (long long)work.tail_idx * nchunks + work.chunk;
-          double *dst = part + (((slot * N + n) * 64 + (ob - group * 64)) * 16 + c) * 2;
-          dst[0] = num[n][r];
-          dst[1] = den[n][r];
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ob = i0 + q + 4 * r;
+        if (ob < F && kout < K) {
+          if (nchunks == 1) {
+            const long long o = (((long long)b * N + n) * F + ob) * K + kout;
+            const double told = basis[o];
+            if (LOSS) lacc = fma(told, num[n][ti][r], lacc);
+            const double ratio = num[n][ti][r] / den[n][ti][r];
+            basis_out[o] = apply_floor(ratio_pow(ratio, fm.expo) * told, floor_kind, eps);
+          } else {
+            // partial sums of a split item: one 16-k record per (item, chunk, k tile of the item)
+            const long long slot = ((long long)work.tail_idx * nchunks + work.chunk) * KTI + ti;
+            double *dst = part + (((slot * N + n) * 64 + (ob - group * 64)) * 16 + c) * 2;
+            dst[0] = num[n][ti][r];
+            dst[1] = den[n][ti][r];
+          }
         }
       }
-    }
+  }
   if (LOSS) {
     if (MODEL == FM_GGD) lacc *= 2.0 / fm.beta;
-    if (kt == 0)  // (2 / p) log R, once
+    if (kt0 == 0)  // (2 / p) log R, once
       lacc += (MODEL == FM_GAUSS1 ? 2.0 : (MODEL == FM_GAUSSP ? fm.pinv2 : 1.0)) * lr.value();
     lacc = wave_sum(lacc);
     // no atomics: every (bin group, chunk, wave) of a mixture owns a slot (loss_slot_count())
@@ -287,7 +314,12 @@ __global__ __launch_bounds__(256) void k_basis_finalize(const double *basis, dou
   const int tail_idx = blockIdx.y;
   const int item = plan.full + tail_idx;
   const int b = item / plan.groups, g2 = item - b * plan.groups;
-  const int group = g2 / ktiles, kt = g2 % ktiles;
+  // ktiles > 0: the item index carries the k tile (one record per item and chunk);
+  // ktiles < 0: |ktiles| tiles inside every item, this launch's blockIdx.z picks one
+  const int kti = ktiles < 0 ? -ktiles : 1;
+  const int group = ktiles < 0 ? g2 : g2 / ktiles;
+  const int kt = ktiles < 0 ? (int)blockIdx.z : g2 % ktiles;
+  const int ti = ktiles < 0 ? (int)blockIdx.z : 0;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (n, local bin, k16)
   const int k = 16 * kt + (e & 15), lb = (e >> 4) & 63, n = e >> 10;
   const int bin = group * 64 + lb;
@@ -297,8 +329,9 @@ __global__ __launch_bounds__(256) void k_basis_finalize(const double *basis, dou
     const double told = basis[o];
     // chunks in order, eight loads per round trip (ordered_sum, common.hpp)
     const double2 s2 = ordered_sum(reinterpret_cast<const double2 *>(part) +
-                                       (((long long)tail_idx * plan.split) * N + n) * 1024 + (e & 1023),
-                                   (long long)N * 1024, plan.split);
+                                       ((((long long)tail_idx * plan.split) * kti + ti) * N + n) * 1024 +
+                                       (e & 1023),
+                                   (long long)kti * N * 1024, plan.split);
     const double sn = s2.x, sd = s2.y;
     contrib = told * sn;
     const double ratio = sn / sd;
@@ -738,9 +771,16 @@ __global__ __launch_bounds__(256, KS >= 8 ? 1 : 2) void k_activation_fast(
   // (frame group, bin chunk [x k tile], mixture) from the XCD-contiguous item: the frame groups of
   // one (mixture, chunk) share the staged basis tiles and demixing matrices
   const GridItem gi = xcd_contiguous_grid();
-  constexpr int KT = KS / 4;  // k tiles: grid.y = chunks x KT
-  const int chunk = gi.y / KT, b = gi.z;
-  const int kt = gi.y % KT;
+  constexpr int KT = KS / 4;  // k tiles of the n_basis range
+  // k tiles one item accumulates: both at 16 < n_basis <= 32, one above (see k_basis_fast);
+  // grid.y = chunks x (KT / KTI)
+#ifdef SSSPY_KTILE_ITEMS
+  constexpr int KTI = 1;
+#else
+  constexpr int KTI = KS == 8 ? 2 : 1;
+#endif
+  const int chunk = gi.y / (KT / KTI), b = gi.z;
+  const int kt0 = (gi.y % (KT / KTI)) * KTI;
   const int ksteps = (K + 3) >> 2;
   const int j0 = (gi.x * 4 + wave) * 16;
   const int jf = j0 + c;
@@ -760,12 +800,14 @@ __global__ __launch_bounds__(256, KS >= 8 ? 1 : 2) void k_activation_fast(
       const int kk = 4 * ks + q;
       vb[n][ks] = (kk < K && fvalid) ? act[(((long long)b * N + n) * K + kk) * T + jc] : 0.0;
     }
-  double4_t numv[N], denv[N];
+  double4_t numv[N][KTI], denv[N][KTI];
 #pragma unroll
-  for (int n = 0; n < N; ++n) {
-    numv[n] = double4_t{0.0, 0.0, 0.0, 0.0};
-    denv[n] = double4_t{0.0, 0.0, 0.0, 0.0};
-  }
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int ti = 0; ti < KTI; ++ti) {
+      numv[n][ti] = double4_t{0.0, 0.0, 0.0, 0.0};
+      denv[n][ti] = double4_t{0.0, 0.0, 0.0, 0.0};
+    }
   const int ntiles = (F + 15) >> 4;
   const int t_begin = chunk * tiles_per_chunk;
   const int t_end = min(ntiles, t_begin + tiles_per_chunk);
@@ -809,25 +851,30 @@ __global__ __launch_bounds__(256, KS >= 8 ? 1 : 2) void k_activation_fast(
         const double aa = valid ? mm_num_factor<MODEL>(pw, R[r], rinv, fm) : 0.0;
         // GEMM2: A[row = c -> basis index 16 kt + c][kk = q] = T[n, bin i0+q+4r, 16 kt + c]
         // (zero-staged pads)
-        const double ta = tn[bl * TROW + 16 * kt + c];
-        numv[n] = mfma_f64(ta, aa, numv[n]);
-        denv[n] = mfma_f64(ta, bb, denv[n]);
+#pragma unroll
+        for (int ti = 0; ti < KTI; ++ti) {
+          const double ta = tn[bl * TROW + 16 * (kt0 + ti) + c];
+          numv[n][ti] = mfma_f64(ta, aa, numv[n][ti]);
+          denv[n][ti] = mfma_f64(ta, bb, denv[n][ti]);
+        }
       }
     }
     tstage_store<KS>(st, ts[pb ^ 1], ws[pb ^ 1]);
     __syncthreads();
   }
 #pragma unroll
-  for (int n = 0; n < N; ++n)
+  for (int ti = 0; ti < KTI; ++ti)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ok = 16 * kt + q + 4 * r;
-      if (ok < K && fvalid) {
-        const long long base = ((((long long)b * nchunks + chunk) * N + n) * 2) * K;
-        part[(base + ok) * T + jf] = numv[n][r];
-        part[(base + K + ok) * T + jf] = denv[n][r];
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ok = 16 * (kt0 + ti) + q + 4 * r;
+        if (ok < K && fvalid) {
+          const long long base = ((((long long)b * nchunks + chunk) * N + n) * 2) * K;
+          part[(base + ok) * T + jf] = numv[n][ti][r];
+          part[(base + K + ok) * T + jf] = denv[n][ti][r];
+        }
       }
-    }
 }
 
 #endif  // other passes
@@ -872,9 +919,14 @@ int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis
     return fail(SSSPY_ERR_BADARG, "ilrma_fast_basis: power input excludes a filter and the loss");
   if (loss_out && !loss_ws) return fail(SSSPY_ERR_BADARG, "ilrma_fast_basis: loss without scratch");
   const int ktiles = K > 32 ? 4 : (K > 16 ? 2 : 1);
+#ifdef SSSPY_KTILE_ITEMS
+  const int item_tiles = ktiles;  // one item per (bin group, k tile)
+#else
+  const int item_tiles = ktiles == 2 ? 1 : ktiles;  // n_basis <= 32: both k tiles inside the item
+#endif
   // (the wide variants hold one workgroup per CU)
   const TailPlan plan =
-      make_tail_plan(B, ((F + 63) / 64) * ktiles, (T + 15) / 16, ktiles >= 2 ? 256 : SLOTS);
+      make_tail_plan(B, ((F + 63) / 64) * item_tiles, (T + 15) / 16, ktiles >= 2 ? 256 : SLOTS);
   const FastModel fm = make_fast_model(fmodel, mparam, me);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
   // loss slots per mixture: (bin group, chunk, wave) of the pass, then (bin group, block, wave) of
@@ -941,9 +993,10 @@ int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis
   if (plan.tail > 0) {
     // split items' share of the loss by-product (never requested for the t model or the wide variant)
     const double loss_scale = (fmodel == FM_GGD ? 2.0 / fm.beta : 1.0) / (double)T;
-    hipLaunchKernelGGL(k_basis_finalize, dim3(nbx, plan.tail), block, 0, st, basis, basis_out, part,
-                       F, K, plan, ktiles, floor_kind, eps, fm.expo, loss_slots, loss_scale, B,
-                       slots_pass);
+    const int inner = ktiles / item_tiles;  // k tiles inside an item
+    hipLaunchKernelGGL(k_basis_finalize, dim3(nbx, plan.tail, inner), block, 0, st, basis,
+                       basis_out, part, F, K, plan, inner > 1 ? -inner : item_tiles, floor_kind, eps,
+                       fm.expo, loss_slots, loss_scale, B, slots_pass);
     rc = check_launch("k_basis_finalize");
     if (rc) return rc;
   }
@@ -969,7 +1022,12 @@ int LAUNCHER(ilrma_fast_activation)(const void *X, const void *W, const double *
   const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
   const FastModel fm = make_fast_model(fmodel, mparam, 0);
   const int ktiles = K > 32 ? 4 : (K > 16 ? 2 : 1);
-  dim3 grid((T + 63) / 64, nchunks * ktiles, B), block(256);
+#ifdef SSSPY_KTILE_ITEMS
+  const int item_tiles = ktiles;
+#else
+  const int item_tiles = ktiles == 2 ? 1 : ktiles;  // n_basis <= 32: both k tiles inside the item
+#endif
+  dim3 grid((T + 63) / 64, nchunks * item_tiles, B), block(256);
 #define SSSPY_ACT_LAUNCH(HW, M, KS_)                                                             \
   hipLaunchKernelGGL((k_activation_fast<HW, M, KS_>), grid, block, 0, st, (const c128 *)X,        \
                      (const c128 *)W, basis, act, part, F, T, K, tiles_per_chunk, nchunks, fm)
