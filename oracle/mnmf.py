@@ -1,4 +1,4 @@
-"""Oracle: FastGaussMNMF with the IP1 diagonaliser update.
+"""Oracle: FastGaussMNMF with the IP1 and the pairwise (IP2) diagonaliser update.
 
 TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
 
@@ -25,7 +25,14 @@ class FastGaussMNMFOracle:
         record_loss=True,
         reference_id=0,
         rng=None,
+        diagonalizer_algorithm="IP",
+        pairs=None,
     ):
+        # ref: ssspy/bss/mnmf.py:1140-1153 -- "IP" / "IP1" / "IP2"; `pairs` is the list the
+        # reference's pair_selector(n_channels) yields (None: sequential_pair_selector)
+        assert diagonalizer_algorithm in ("IP", "IP1", "IP2")
+        self.diagonalizer_algorithm = diagonalizer_algorithm
+        self.pairs = pairs
         self.n_basis = n_basis
         self.n_sources = n_sources
         self.flooring = flooring
@@ -105,14 +112,19 @@ class FastGaussMNMFOracle:
         self.activation = sp.floor(V * np.sqrt(num / den), self.flooring)
 
     def update_diagonalizer(self):
-        """ref: ssspy/bss/mnmf.py:1449-1514 (IP1)."""
+        """ref: ssspy/bss/mnmf.py:1419-1447 (dispatch), :1449-1514 (IP1), :1516-1633 (IP2: the same
+        weighted covariances, then the pairwise projection of _update_spatial_model.py:81-143)."""
         X = self.input
         Lamb = self._lamb().transpose(1, 0, 2)  # (F, N, T)
         LambD = np.sum(Lamb[:, :, None, :] * self.spatial[:, :, :, None], axis=1)  # (F, M, T)
         varphi = 1 / LambD
         XX = (X[:, None, :, :] * X[None, :, :, :].conj()).transpose(2, 0, 1, 3)  # (F, M, M, T)
         U = np.mean(varphi[:, :, None, None, :] * XX[:, None, :, :, :], axis=-1)
-        self.diagonalizer = sp.update_by_ip1(self.diagonalizer, U, self.flooring)
+        if self.diagonalizer_algorithm == "IP2":
+            self.diagonalizer = sp.update_by_ip2(self.diagonalizer, U, self.flooring,
+                                                 pairs=self.pairs)
+        else:
+            self.diagonalizer = sp.update_by_ip1(self.diagonalizer, U, self.flooring)
 
     def update_spatial(self):
         """ref: ssspy/bss/mnmf.py:1635-1675 (no flooring)."""

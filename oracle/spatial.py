@@ -180,6 +180,11 @@ def sequential_pairs(n_sources, stop=None, step=1):
     return [(m % n_sources, (m + 1) % n_sources) for m in range(0, stop, step)]
 
 
+def combination_pairs(n_sources):
+    """ref: ssspy/utils/select_pair.py:47-78."""
+    return [(m, n) for m in range(n_sources) for n in range(m + 1, n_sources)]
+
+
 def update_by_ip2_one_pair(W, U_pair, pair, flooring=DEFAULT_FLOOR):
     """Pairwise iterative projection for sources (m, n).  ref: _update_spatial_model.py:317-395.
 

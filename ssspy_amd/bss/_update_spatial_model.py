@@ -37,7 +37,7 @@ def update_by_ip1(
     Raises:
         numpy.linalg.LinAlgError: if a bin's system ``W U_n`` is singular.
     """
-    floor = device_flooring(flooring_fn)
+    floor = device_flooring(flooring_fn, allow_host=True)  # _ops.update_by_ip1 floors on the host
     batched = demix_filter.ndim == 4
     W = dv.to_device(demix_filter if batched else demix_filter[None], dtype=np.complex128)
     U = dv.to_device(weighted_covariance if batched else weighted_covariance[None],
@@ -67,7 +67,7 @@ def update_by_iss1(
     Returns:
         New array with the updated spectrograms.
     """
-    floor = device_flooring(flooring_fn)
+    floor = device_flooring(flooring_fn, allow_host=True)
     batched = separated.ndim == 4
     Y = dv.to_device(separated if batched else separated[None], dtype=np.complex128)
     wt = weight if batched else weight[None]
@@ -78,7 +78,9 @@ def update_by_iss1(
     else:
         w = dv.to_device(np.broadcast_to(wt, (B, N, F, T)), dtype=np.float64)
         kind = _lib.WEIGHT_BIN_FRAME
-    if T <= _ops.iss1_fused_max_frames(N):
+    if floor.host is not None:  # an arbitrary callable: the N x F denominators go to the host
+        out = dv.to_host(_ops.update_by_iss1_host_floor(Y, w, kind, floor.host))
+    elif T <= _ops.iss1_fused_max_frames(N):
         out = dv.to_host(_ops.iss1_fused(Y, w, kind, floor))  # Y is a private device copy
     else:
         Vc = _ops.weighted_covariance(Y, w, kind, N)
@@ -99,7 +101,7 @@ def update_by_ip2(
     The two rows of a pair come out with the arbitrary phase of a 2 x 2 eigenvector (as in the
     reference, where it is LAPACK's); scale restoration removes it.
     """
-    floor = device_flooring(flooring_fn)
+    floor = device_flooring(flooring_fn, what="update_by_ip2")
     N = demix_filter.shape[-2]
     W = dv.to_device(demix_filter[None], dtype=np.complex128)
     U = dv.to_device(weighted_covariance[None], dtype=np.complex128)
@@ -123,7 +125,7 @@ def update_by_iss2(
 
     Default pairs: (0,1), (2,3), ... as in the reference (sequential selector with step 2).
     """
-    floor = device_flooring(flooring_fn)
+    floor = device_flooring(flooring_fn, what="update_by_iss2")
     Y = dv.to_device(separated[None], dtype=np.complex128)
     B, N, F, T = Y.shape
     if pair_selector is None:
@@ -158,7 +160,7 @@ def update_by_ipa(
         normalization: unit-trace normalisation of the LQPQM problem.
         max_iter: Newton steps of the LQPQM solver (every bin runs all of them).
     """
-    floor = device_flooring(flooring_fn)
+    floor = device_flooring(flooring_fn, what="update_by_ipa")
     Y = dv.to_device(separated[None], dtype=np.complex128)
     B, N, F, T = Y.shape
     wt = weight[None]

@@ -96,7 +96,7 @@ class ILRMABase(DeviceStateMixin, IterativeMethodBase):
             raise ValueError("demix_filter=None cannot be given at reset.")
         self._state_set_dev("output", _ops.separate(self._X, self._state_dev("demix_filter")))
         self._init_nmf(flooring_fn=flooring_fn, rng=self.rng)
-        self._floor = device_flooring(flooring_fn)
+        self._floor = device_flooring(flooring_fn, allow_host=True)
         K = self.n_basis
         self._ws, self._ws_bytes = _ops.ilrma_workspace(B, N, F, T, K, self._X.device)
         self._U = None
@@ -156,7 +156,7 @@ class ILRMABase(DeviceStateMixin, IterativeMethodBase):
     def _resolve_floor(self, flooring_fn):
         if type(flooring_fn) is str and flooring_fn == "self":
             return self._floor
-        return device_flooring(choose_flooring_fn(flooring_fn, method=self))
+        return device_flooring(choose_flooring_fn(flooring_fn, method=self), allow_host=True)
 
     def _uses_filter(self) -> bool:
         return not self._state_is_none("demix_filter")
@@ -258,7 +258,7 @@ class _MMILRMA(ILRMABase):
                 self.pair_selector = sequential_pair_selector
         else:
             self.pair_selector = pair_selector
-        device_flooring(self.flooring_fn)  # (translation errors, if any, surface before any upload)
+        device_flooring(self.flooring_fn, allow_host=True)  # (translation errors, if any, surface before any upload)
 
     def __call__(
         self, input: np.ndarray, n_iter: int = 100, initial_call: bool = True, **kwargs

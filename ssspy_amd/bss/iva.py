@@ -79,7 +79,7 @@ class IVABase(DeviceStateMixin, IterativeMethodBase):
         if self._state_is_none("demix_filter"):
             raise ValueError("demix_filter=None cannot be given at reset.")
         self._state_set_dev("output", _ops.separate(self._X, self._state_dev("demix_filter")))
-        self._floor = device_flooring(self.flooring_fn)
+        self._floor = device_flooring(self.flooring_fn, allow_host=True)
 
     def separate(self, input: np.ndarray, demix_filter: np.ndarray) -> np.ndarray:
         """y_ij = W_i x_ij (ref: ssspy/bss/iva.py:171-194); NumPy in, NumPy out."""
@@ -95,7 +95,7 @@ class IVABase(DeviceStateMixin, IterativeMethodBase):
     def _resolve_floor(self, flooring_fn):
         if type(flooring_fn) is str and flooring_fn == "self":
             return self._floor
-        return device_flooring(choose_flooring_fn(flooring_fn, method=self))
+        return device_flooring(choose_flooring_fn(flooring_fn, method=self), allow_host=True)
 
     def _host_loss(self, data, logdet_sum):
         self._check_device_errors()
@@ -252,7 +252,7 @@ class AuxIVA(AuxIVABase):
         for key in valid_keys:
             if not hasattr(self, key):
                 setattr(self, key, self._default_kwargs[key])
-        device_flooring(self.flooring_fn)
+        device_flooring(self.flooring_fn, allow_host=True)
 
     def __call__(
         self, input: np.ndarray, n_iter: int = 100, initial_call: bool = True, **kwargs

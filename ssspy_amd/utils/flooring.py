@@ -37,6 +37,9 @@ class DeviceFloor(tuple):
         obj.host = host
         return obj
 
+    def __reduce__(self):  # copy.deepcopy / pickle of a separator that keeps its resolved floor
+        return (DeviceFloor, (self[0], self[1], self.host))
+
 
 def _default_eps(fn):
     try:
@@ -48,14 +51,16 @@ def _default_eps(fn):
     return float(param.default)
 
 
-def device_flooring(flooring_fn):
+def device_flooring(flooring_fn, allow_host=False, what="this operation"):
     """Map a flooring callable to the ``(kind, eps)`` pair the HIP kernels take.
 
     Recognised: ``None`` / ``identity`` -> NONE, ``max_flooring`` -> MAX, ``add_flooring`` ->
     ADD, each possibly wrapped in ``functools.partial(..., eps=...)``; functions are matched
     by name so the reference's own ``ssspy.special.flooring`` functions work too.  Any other
-    callable comes back as ``DeviceFloor(NONE, 0, host=callable)``: it is evaluated on the host on
-    the small arrays it acts on (see DeviceFloor); the passes over the spectrograms stay on the device.
+    callable: with ``allow_host=True`` -- the caller has a host-evaluation path and reads
+    ``.host`` -- it comes back as ``DeviceFloor(NONE, 0, host=callable)`` and is evaluated on the
+    host on the small arrays it acts on (see DeviceFloor) while the passes over the spectrograms
+    stay on the device; otherwise ``NotImplementedError`` (never a silently unfloored run).
     """
     if flooring_fn is None:
         return DeviceFloor(_lib.FLOOR_NONE, 0.0)
@@ -77,7 +82,10 @@ def device_flooring(flooring_fn):
             return DeviceFloor(_lib.FLOOR_MAX, _default_eps(fn) if eps is None else eps)
         if name == "add_flooring":
             return DeviceFloor(_lib.FLOOR_ADD, _default_eps(fn) if eps is None else eps)
-    return DeviceFloor(_lib.FLOOR_NONE, 0.0, host=flooring_fn)
+    floor = DeviceFloor(_lib.FLOOR_NONE, 0.0, host=flooring_fn)
+    if not allow_host:
+        require_device_floor(floor, what)
+    return floor
 
 
 def host_floor(floor):

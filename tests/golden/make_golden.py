@@ -23,13 +23,15 @@ REFERENCE = os.environ.get("SSSPY_REFERENCE", "/root/reference")
 sys.path.insert(0, REFERENCE)
 
 from ssspy.algorithm import minimal_distortion_principle, projection_back  # noqa: E402
-from ssspy.bss._update_spatial_model import update_by_ip1, update_by_ipa, update_by_iss1  # noqa: E402
+from ssspy.bss._update_spatial_model import (  # noqa: E402
+    update_by_ip1, update_by_ip2, update_by_ipa, update_by_iss1, update_by_iss2)
 from ssspy.bss.ilrma import GGDILRMA, TILRMA, GaussILRMA  # noqa: E402
 from ssspy.bss.iva import AuxGaussIVA, AuxIVA, AuxLaplaceIVA  # noqa: E402
 from ssspy.bss.mnmf import FastGaussMNMF, GaussMNMF  # noqa: E402
 from ssspy.linalg import eigh2, inv2  # noqa: E402
 from ssspy.special.flooring import add_flooring, max_flooring  # noqa: E402
 from ssspy.special.psd import to_psd  # noqa: E402
+from ssspy.utils.select_pair import combination_pair_selector  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SNAP_ITERS = (1, 2, 10)
@@ -185,7 +187,7 @@ def run_iva(name, *, N, F, T, algo, contrast, seed, gen=gen_iid, flooring=("max"
 
 # --------------------------------------------------------------------------- MNMF
 def run_mnmf(name, *, M, F, T, K, seed, n_sources=None, gen=gen_iid, flooring=("max", 1e-10),
-             normalization=True, n_iter=10):
+             normalization=True, n_iter=10, diag_algo="IP", pairs="sequential"):
     if skipped(name):
         return
     N = M if n_sources is None else n_sources
@@ -194,9 +196,14 @@ def run_mnmf(name, *, M, F, T, K, seed, n_sources=None, gen=gen_iid, flooring=("
     activation = np.random.default_rng(seed + 2).random((N, K, T))
     spatial = np.random.default_rng(seed + 4).random((F, N, M))
     snap = Snapshots(["diagonalizer", "spatial", "basis", "activation"])
+    extra = {}
+    if diag_algo != "IP":  # the IP1 fixtures keep their bytes: no new constructor arguments for them
+        extra["diagonalizer_algorithm"] = diag_algo
+        if pairs == "combination":
+            extra["pair_selector"] = combination_pair_selector
     m = FastGaussMNMF(n_basis=K, n_sources=n_sources, flooring_fn=flooring_of(flooring),
                       callbacks=snap, normalization=normalization,
-                      rng=np.random.default_rng(seed + 3))
+                      rng=np.random.default_rng(seed + 3), **extra)
     Y = m(X, n_iter=n_iter, basis=basis, activation=activation, spatial=spatial.copy())
     out = dict(X=X, basis0=basis, activation0=activation, spatial0=spatial,
                loss=np.array(m.loss), final_output=Y, final_basis=m.basis,
@@ -205,6 +212,8 @@ def run_mnmf(name, *, M, F, T, K, seed, n_sources=None, gen=gen_iid, flooring=("
     out.update(snap.store)
     out.update(meta(kind="fast_gauss_mnmf", n_basis=K, n_sources=N, n_iter=n_iter,
                     floor_kind=flooring[0], floor_eps=flooring[1], normalization=normalization))
+    if diag_algo != "IP":
+        out.update(meta(diag_algo=diag_algo, pairs=pairs))
     save(name, **out)
 
 
@@ -457,6 +466,44 @@ def run_operators():
     save("operators", **out)
 
 
+def run_pairwise_operators():
+    """update_by_ip2 / update_by_iss2 on random operands (ssspy/bss/_update_spatial_model.py:81-143,
+    197-314): default (sequential) pairs, every combination, an explicit list with negative and
+    descending indices (:241-251), broadcast weights, add-flooring."""
+    if skipped("pairwise_operators"):
+        return
+    out = {}
+    add = functools.partial(add_flooring, eps=1e-3)
+    for N in (2, 3, 4, 5, 8):
+        rng = np.random.default_rng(170 + N)
+        F, T = 9, 34
+        X = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+        W = rng.standard_normal((F, N, N)) + 1j * rng.standard_normal((F, N, N))
+        varphi = 1 / (rng.random((N, F, T)) + 0.1)
+        XX = (X[:, None] * X[None].conj()).transpose(2, 0, 1, 3)
+        U = np.mean(varphi.transpose(1, 0, 2)[:, :, None, None, :] * XX[:, None], axis=-1)
+        Y = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+        p = "n{}_".format(N)
+        out[p + "W"], out[p + "U"], out[p + "Y"], out[p + "varphi"] = W, U, Y, varphi
+        out[p + "ip2_out"] = update_by_ip2(W.copy(), U)
+        out[p + "ip2_out_comb"] = update_by_ip2(W.copy(), U, pair_selector=combination_pair_selector)
+        out[p + "ip2_out_add"] = update_by_ip2(W.copy(), U, flooring_fn=add)
+        explicit = [(N - 1, 0), (0, N - 1)] if N > 2 else [(1, 0)]
+        out[p + "ip2_pairs"] = np.array(explicit)
+        out[p + "ip2_out_pairs"] = update_by_ip2(W.copy(), U, pair_selector=lambda n: explicit)
+        W_keep = W.copy()
+        out[p + "ip2_out_copy"] = update_by_ip2(W_keep, U, overwrite=False)
+        assert np.array_equal(W_keep, W)
+        out[p + "iss2_out"] = update_by_iss2(Y.copy(), varphi)
+        out[p + "iss2_out_comb"] = update_by_iss2(Y.copy(), varphi,
+                                                  pair_selector=combination_pair_selector)
+        out[p + "iss2_out_bcast_add"] = update_by_iss2(Y.copy(), varphi[:, :1, :], flooring_fn=add)
+        neg = [(-1, 0), (1, -N)] if N > 2 else [(-1, 0)]  # negative and descending indices
+        out[p + "iss2_pairs"] = np.array(neg)
+        out[p + "iss2_out_pairs"] = update_by_iss2(Y.copy(), varphi, pair_selector=lambda n: neg)
+    save("pairwise_operators", **out)
+
+
 def main():
     # --- GaussILRMA, IP1 ---
     run_ilrma("gilrma_ip1_n2", N=2, F=17, T=32, K=2, algo="IP", seed=0)            # KAT-1 of SURVEY 8c
@@ -525,6 +572,14 @@ def main():
     run_mnmf("fmnmf_ip1_m4", M=4, F=21, T=36, K=8, seed=5, gen=gen_mixture)
     run_mnmf("fmnmf_ip1_m3_n2", M=3, F=16, T=30, K=3, seed=6, n_sources=2)
     run_mnmf("fmnmf_ip1_m2_nonorm", M=2, F=16, T=30, K=3, seed=7, normalization=False)
+    # --- FastGaussMNMF with the pairwise diagonaliser update (mnmf.py:1516-1633) ---
+    run_mnmf("fmnmf_ip2_m2", M=2, F=16, T=30, K=3, seed=12, diag_algo="IP2")
+    run_mnmf("fmnmf_ip2_m3", M=3, F=17, T=40, K=4, seed=13, gen=gen_mixture, diag_algo="IP2")
+    run_mnmf("fmnmf_ip2_m4", M=4, F=15, T=36, K=5, seed=14, gen=gen_mixture, diag_algo="IP2")
+    run_mnmf("fmnmf_ip2_m3_n2", M=3, F=16, T=32, K=3, seed=15, n_sources=2, diag_algo="IP2")
+    run_mnmf("fmnmf_ip2_m4_comb", M=4, F=14, T=34, K=3, seed=16, diag_algo="IP2",
+             pairs="combination")
+    run_mnmf("fmnmf_ip2_m5", M=5, F=10, T=36, K=3, seed=17, diag_algo="IP2", n_iter=6)
     # shapes beyond 4 sources / channels (the general point-wise path of the device build)
     run_mnmf("fmnmf_ip1_m6_n3", M=6, F=12, T=40, K=4, seed=8, n_sources=3, gen=gen_mixture)
     run_mnmf("fmnmf_ip1_m5", M=5, F=10, T=36, K=3, seed=9)
@@ -595,6 +650,7 @@ def main():
     run_custom_floor("customfloor_fmnmf_m3", kind="fmnmf", seed=154, N=3, F=12, T=28, K=3)
     # --- operators ---
     run_operators()
+    run_pairwise_operators()
 
 
 if __name__ == "__main__":

@@ -22,9 +22,20 @@ def test_device_flooring_mapping():
     assert device_flooring(functools.partial(add_flooring, eps=1e-3)) == (_lib.FLOOR_ADD, 1e-3)
     # any other callable is kept for the host (evaluated on the small arrays it floors)
     fn = lambda x: x + 1  # noqa: E731
-    floor = device_flooring(fn)
+    floor = device_flooring(fn, allow_host=True)
     assert floor == (_lib.FLOOR_NONE, 0.0) and floor.host is fn
     assert device_flooring(max_flooring).host is None
+    # ... only where the caller has a host-evaluation path; elsewhere it fails loudly instead of
+    # running unfloored (round-3 advisor finding)
+    with pytest.raises(NotImplementedError, match="to_psd"):
+        device_flooring(fn, what="to_psd")
+    # a separator keeps its resolved floor: deepcopy / pickle must keep the callable
+    import copy
+    import pickle
+
+    assert copy.deepcopy(floor).host is fn
+    kept = pickle.loads(pickle.dumps(device_flooring(abs, allow_host=True)))
+    assert kept == (_lib.FLOOR_NONE, 0.0) and kept.host is abs
 
 
 def test_choose_flooring_fn():

@@ -172,23 +172,73 @@ def test_aux_iva_config1_kat(case, algo):
     assert np.sum(np.abs(Y) ** 2) == pytest.approx(float(g["kat_energy"]), rel=1e-10)
 
 
-@pytest.mark.parametrize("case", MNMF_CASES)
+MNMF_IP2_CASES = ["fmnmf_ip2_m2", "fmnmf_ip2_m3", "fmnmf_ip2_m4", "fmnmf_ip2_m3_n2",
+                  "fmnmf_ip2_m4_comb", "fmnmf_ip2_m5"]
+
+
+def mnmf_pairs(g):
+    """The pair list of a FastGaussMNMF-IP2 fixture (None: the reference's sequential default)."""
+    if "meta_pairs" in g and str(g["meta_pairs"]) == "combination":
+        return sp.combination_pairs(g["X"].shape[0])
+    return None
+
+
+@pytest.mark.parametrize("case", MNMF_CASES + MNMF_IP2_CASES)
 def test_fast_gauss_mnmf(case):
+    """IP1 and IP2 (ssspy/bss/mnmf.py:1449-1633) diagonaliser updates.  With IP2 the rows of Q carry
+    the arbitrary phase of the 2x2 generalised eigenvectors, so Q is compared up to one phase per
+    (bin, row); everything else -- D, T, V, the loss, the Wiener-filter output -- is phase-free."""
     g = load_golden(case)
     n_sources = int(g["meta_n_sources"])
+    ip2 = "meta_diag_algo" in g and str(g["meta_diag_algo"]) == "IP2"
     m = FastGaussMNMFOracle(
         n_basis=int(g["meta_n_basis"]), n_sources=n_sources, flooring=_floor(g),
         normalization=_option(g["meta_normalization"]),
+        diagonalizer_algorithm="IP2" if ip2 else "IP", pairs=mnmf_pairs(g),
     )
     m.reset(g["X"], basis=g["basis0"], activation=g["activation0"], spatial=g["spatial0"].copy())
     losses = [m.compute_loss()]
     for k in range(1, int(g["meta_n_iter"]) + 1):
         m.update_once()
         losses.append(m.compute_loss())
-        _check_snapshots(g, k, m, ["diagonalizer", "spatial", "basis", "activation"])
+        if ip2:
+            key = "it{}_diagonalizer".format(k)
+            if key in g:
+                assert rel_err_up_to_phase(m.diagonalizer, g[key], "demix_filter") < 1e-9, key
+            _check_snapshots(g, k, m, ["spatial", "basis", "activation"])
+        else:
+            _check_snapshots(g, k, m, ["diagonalizer", "spatial", "basis", "activation"])
     np.testing.assert_allclose(losses, g["loss"], rtol=1e-10)
     Y = m.separate(m.input)
     assert rel_err(Y, g["final_output"]) < 1e-9
+
+
+@pytest.mark.parametrize("N", [2, 3, 4, 5, 8])
+def test_pairwise_operators(N):
+    """update_by_ip2 / update_by_iss2 against the reference's outputs
+    (ssspy/bss/_update_spatial_model.py:81-143, 197-314), up to the eigenvector phase per (bin, row)
+    resp. (bin, source)."""
+    g = load_golden("pairwise_operators")
+    p = lambda s: g["n{}_".format(N) + s]  # noqa: E731
+    W, U, Y, varphi = p("W"), p("U"), p("Y"), p("varphi")
+    tol = 1e-10
+    assert rel_err_up_to_phase(sp.update_by_ip2(W, U), p("ip2_out"), "demix_filter") < tol
+    assert rel_err_up_to_phase(sp.update_by_ip2(W, U, pairs=sp.combination_pairs(N)),
+                               p("ip2_out_comb"), "demix_filter") < tol
+    assert rel_err_up_to_phase(sp.update_by_ip2(W, U, ("add", 1e-3)), p("ip2_out_add"),
+                               "demix_filter") < tol
+    pairs = [tuple(int(v) for v in pr) for pr in p("ip2_pairs")]
+    assert rel_err_up_to_phase(sp.update_by_ip2(W, U, pairs=pairs), p("ip2_out_pairs"),
+                               "demix_filter") < tol
+    assert np.array_equal(p("ip2_out_copy"), p("ip2_out"))
+    assert rel_err_up_to_phase(sp.update_by_iss2(Y, varphi), p("iss2_out"), "output") < tol
+    assert rel_err_up_to_phase(sp.update_by_iss2(Y, varphi, pairs=sp.combination_pairs(N)),
+                               p("iss2_out_comb"), "output") < tol
+    assert rel_err_up_to_phase(sp.update_by_iss2(Y, varphi[:, :1, :], ("add", 1e-3)),
+                               p("iss2_out_bcast_add"), "output") < tol
+    pairs = [tuple(int(v) for v in pr) for pr in p("iss2_pairs")]
+    assert rel_err_up_to_phase(sp.update_by_iss2(Y, varphi, pairs=pairs), p("iss2_out_pairs"),
+                               "output") < tol
 
 
 GMNMF_CASES = ["gmnmf_m2", "gmnmf_m3", "gmnmf_m4_n3", "gmnmf_m2_nonorm_add", "gmnmf_part_m3",
