@@ -102,6 +102,19 @@ class DeviceStateMixin:
             self._X = dv.to_device(X4, dtype=np.complex128)
         self._static_cov = None
 
+    def call_on_device(self, input, n_iter: int = 100, initial_call: bool = True, **kwargs):
+        """``__call__`` for callers that keep their spectrograms in HBM (extension over the
+        reference): ``input`` is a complex128 tensor on the HIP device (or a NumPy array, uploaded as
+        usual) and the separated spectrograms come back as a device tensor of the same shape -- no
+        download, nothing synchronises.  Everything else (kwarg injection, loss list, callbacks) is
+        ``__call__``'s.  Used by ``parallel.separate_pipelined`` to overlap the transfers of one
+        sub-batch with the iterations of another."""
+        self._return_device = True
+        try:
+            return self(input, n_iter=n_iter, initial_call=initial_call, **kwargs)
+        finally:
+            self._return_device = False
+
     def _lead(self):
         return (self._X.shape[0],) if self._batched else ()
 
@@ -143,6 +156,9 @@ class DeviceStateMixin:
     def _final_output(self):
         """What ``__call__`` returns: the host copy of ``output``.  The iteration is over, so the
         array is handed out writable like the reference's (which returns ``self.output`` itself)."""
+        if getattr(self, "_return_device", False):  # call_on_device(): no download
+            out_dev = self._state_dev("output")
+            return out_dev if self._batched else out_dev[0]
         out = self.output
         ent = self._state().get("output", {})
         if ent.get("host") is out and ent.get("host_rw") is not None:

@@ -197,7 +197,7 @@ class FastMNMFBase(MNMFBase):
     def _resolve_floor(self, flooring_fn):
         if type(flooring_fn) is str and flooring_fn == "self":
             return self._floor
-        return device_flooring(choose_flooring_fn(flooring_fn, method=self), what="MNMF")
+        return device_flooring(choose_flooring_fn(flooring_fn, method=self), what="FastMNMF")
 
     def _update(self, steps, flooring_fn="self") -> None:
         need_c = bool(steps & _lib.MNMF_NORMALIZE)
@@ -274,7 +274,7 @@ class FastGaussMNMF(FastMNMFBase):
                 self.pair_selector = sequential_pair_selector
         else:
             self.pair_selector = pair_selector
-        device_flooring(self.flooring_fn, what="MNMF")
+        device_flooring(self.flooring_fn, what="FastMNMF")
 
     def __repr__(self) -> str:
         s = "FastGaussMNMF(n_basis={}".format(self.n_basis)
@@ -444,7 +444,7 @@ class MNMF(MNMFBase):
         N = M if self.n_sources is None else self.n_sources
         self.n_sources, self.n_channels = N, M
         self.n_bins, self.n_frames = F, T
-        self._floor = device_flooring(self.flooring_fn, what="MNMF")
+        self._floor = device_flooring(self.flooring_fn, what="GaussMNMF")
         require_device_floor(self._floor, "GaussMNMF")
         self._init_nmf(rng=self.rng)
         self._ws, self._ws_bytes = _ops.gmnmf_workspace(B, N, M, F, T, self.n_basis, self._X.device)
@@ -520,7 +520,7 @@ class GaussMNMF(MNMF):
             reference_id=reference_id,
             rng=rng,
         )
-        device_flooring(self.flooring_fn, what="MNMF")
+        device_flooring(self.flooring_fn, what="GaussMNMF")
 
     def __repr__(self) -> str:
         s = "GaussMNMF(n_basis={}".format(self.n_basis)
@@ -536,7 +536,7 @@ class GaussMNMF(MNMF):
     def _resolve_floor(self, flooring_fn):
         if type(flooring_fn) is str and flooring_fn == "self":
             return self._floor
-        return device_flooring(choose_flooring_fn(flooring_fn, method=self), what="MNMF")
+        return device_flooring(choose_flooring_fn(flooring_fn, method=self), what="GaussMNMF")
 
     def _update(self, steps, flooring_fn="self") -> None:
         latent = self._state_dev("latent") if self.partitioning else None

@@ -42,7 +42,14 @@ __device__ __forceinline__ void vstage_load(VStage<NS, KR> &st, const double *__
     const int n = row / KR, k = row % KR;
     const int j = j0 + 2 * chunk;
     double2 val = make_double2(0.0, 0.0);
+#ifdef SSSPY_ASSUME_FULL
+    {
+      const double2_a8 v = *reinterpret_cast<const double2_a8 *>(act_b + ((long long)n * K + k) * T + j);
+      val = make_double2(v.x, v.y);
+    }
+#else
     if (idx < NS * KR * 8 && k < K) val = load_pair_in_row(act_b + ((long long)n * K + k) * T, j, T);
+#endif
     st.v[u] = val;
   }
 }
@@ -64,6 +71,31 @@ template <int NC>
 struct XTile {
   c128 x[NC][4];
 };
+
+// Order pin for a register-neutral prefetch: returns v unchanged, but through an opaque asm that
+// reads every power -- so all of them (the last uses of the x tile) are computed BEFORE the asm and
+// whatever is addressed with the result (the re-load of the x registers) comes AFTER it.  Pure
+// arithmetic carries no ordering against loads in LLVM IR: without the pin the IR-level sinking moves
+// the |y|^2 arithmetic below the loads and both tiles are live at once (240 bytes of spills measured).
+template <int NS>
+__device__ __forceinline__ int pin_after_powers(const double (&pw)[NS][4], int v) {
+  static_assert(NS >= 1 && NS <= 4, "pin_after_powers: 1..4 sources");
+  if constexpr (NS == 4)
+    asm volatile("" : "+v"(v) : "v"(pw[0][0]), "v"(pw[0][1]), "v"(pw[0][2]), "v"(pw[0][3]),
+                 "v"(pw[1][0]), "v"(pw[1][1]), "v"(pw[1][2]), "v"(pw[1][3]), "v"(pw[2][0]),
+                 "v"(pw[2][1]), "v"(pw[2][2]), "v"(pw[2][3]), "v"(pw[3][0]), "v"(pw[3][1]),
+                 "v"(pw[3][2]), "v"(pw[3][3]));
+  else if constexpr (NS == 3)
+    asm volatile("" : "+v"(v) : "v"(pw[0][0]), "v"(pw[0][1]), "v"(pw[0][2]), "v"(pw[0][3]),
+                 "v"(pw[1][0]), "v"(pw[1][1]), "v"(pw[1][2]), "v"(pw[1][3]), "v"(pw[2][0]),
+                 "v"(pw[2][1]), "v"(pw[2][2]), "v"(pw[2][3]));
+  else if constexpr (NS == 2)
+    asm volatile("" : "+v"(v) : "v"(pw[0][0]), "v"(pw[0][1]), "v"(pw[0][2]), "v"(pw[0][3]),
+                 "v"(pw[1][0]), "v"(pw[1][1]), "v"(pw[1][2]), "v"(pw[1][3]));
+  else
+    asm volatile("" : "+v"(v) : "v"(pw[0][0]), "v"(pw[0][1]), "v"(pw[0][2]), "v"(pw[0][3]));
+  return v;
+}
 
 // bin-major x tile: lane (c, q) reads frames j0+q+4r of bin `bin`, so one load instruction
 // (fixed r) takes 64 contiguous bytes per bin from the 4 q-lanes: 16 half cache lines instead of the
@@ -251,7 +283,11 @@ __device__ __forceinline__ double4_t rt_from_lds(const double *vs_n, const doubl
   const int col = tile_pi(c);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
+#ifdef SSSPY_ASSUME_FULL
+    R = mfma_f64(vs_n[(4 * ks + q) * VROW + col], tb[ks], R);
+#else
     if (ks < ksteps) R = mfma_f64(vs_n[(4 * ks + q) * VROW + col], tb[ks], R);
+#endif
   return R;
 }
 

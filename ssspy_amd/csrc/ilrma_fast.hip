@@ -105,6 +105,20 @@ __global__ __launch_bounds__(256, KS >= 8 ? 1 : 2) void k_basis_fast(const c128 
                                                        int B) {
   constexpr bool HAS_W = IN == IN_X, PIN = IN == IN_P;
   constexpr int KR = 4 * KS;  // staged activation rows per source
+  // Round-4 experiment, off by default (-DSSSPY_BASIS_PREFETCH builds it): spill-free at 210 VGPRs, two
+  // waves per SIMD, the x loads fully hidden -- and not faster (1.103 against 1.078 ms at 128
+  // mixtures): the pass runs at the 1400 W package cap (profiles/r04_power_cap.md), where the
+  // rate is set by the energy of a tile, not by its stalls.
+#ifdef SSSPY_BASIS_PREFETCH
+  constexpr bool PREFETCH = KS < 8;
+#else
+  constexpr bool PREFETCH = false;
+#endif
+  constexpr bool PWF = KS >= 8 || PREFETCH;  // powers first
+  // with PREFETCH the GEMM1 basis operand is read from LDS per use (wave-private rows, 8 KB per wave)
+  // instead of living in 32 registers: the budget goes to the powers
+  constexpr bool TB_LDS = PREFETCH;
+  __shared__ __attribute__((aligned(16))) double tls[TB_LDS ? 4 : 1][TB_LDS ? N * 256 : 1];
   __shared__ __attribute__((aligned(16))) double vs[2][N * KR * VROW];
   constexpr int WSTRIDE = N * N + 1;  // 16-byte slots per bin: odd, so 16 bins never share a bank
   __shared__ __attribute__((aligned(16))) c128 wl[4][16 * WSTRIDE];
@@ -147,13 +161,17 @@ __global__ __launch_bounds__(256, KS >= 8 ? 1 : 2) void k_basis_fast(const c128 
   }
   const c128 *wmine = wl[wave] + c * WSTRIDE;
   double tb[N][KS];
+  if (TB_LDS) {
+    fast::stage_basis_rows<N>(tls[wave], basis + (long long)b * N * F * K, F, K, i0, lane);
+  } else {
 #pragma unroll
-  for (int n = 0; n < N; ++n)
+    for (int n = 0; n < N; ++n)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int kk = 4 * ks + q;
-      tb[n][ks] = kk < K ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
-    }
+      for (int ks = 0; ks < KS; ++ks) {
+        const int kk = 4 * ks + q;
+        tb[n][ks] = kk < K ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
+      }
+  }
   double4_t num[N][KTI], den[N][KTI];
 #pragma unroll
   for (int n = 0; n < N; ++n)
@@ -173,17 +191,29 @@ __global__ __launch_bounds__(256, KS >= 8 ? 1 : 2) void k_basis_fast(const c128 
   fast::vstage_store<N, KR>(st, vs[0]);
   __syncthreads();
 
+  // PREFETCH (n_basis <= 16): |y|^2 of every source is formed FIRST, which is the last use of the x
+  // tile, and the same registers are re-loaded with the NEXT tile right away: its 16 loads have the
+  // two GEMMs of this tile to land instead of being waited for at the top of the next trip (the
+  // register price is the 16 powers kept live through the GEMM phase; the x tile is dead there;
+  // fast::pin_after_powers keeps LLVM from sinking the power arithmetic below the re-load).
+  if (PREFETCH) {
+    if constexpr (PIN) fast::ptile_load_binmajor<N>(pcur, xsrc, T, bin, jt_begin * 16, q);
+    else fast::xtile_load_binmajor<N>(cur, xsrc, T, bin, jt_begin * 16, q);
+  }
   for (int jt = jt_begin; jt < jt_end; ++jt) {
     const int j0 = jt * 16;
     const int jn = min(jt + 1, jt_end - 1) * 16;  // last iteration re-fetches its own tile
-    if constexpr (PIN) fast::ptile_load_binmajor<N>(pcur, xsrc, T, bin, j0, q);
-    else fast::xtile_load_binmajor<N>(cur, xsrc, T, bin, j0, q);
+    if (!PREFETCH) {
+      if constexpr (PIN) fast::ptile_load_binmajor<N>(pcur, xsrc, T, bin, j0, q);
+      else fast::xtile_load_binmajor<N>(cur, xsrc, T, bin, j0, q);
+    }
     if (KS < 8) fast::vstage_load<N, KR>(st, act_b, K, T, jn);
     const double *vcur = vs[(jt - jt_begin) & 1];
-    double pwall[KS >= 8 ? N : 1][4];
-    if (KS >= 8) {
+    double pwall[PWF ? N : 1][4];
+    if (PWF) {
       // |y|^2 of every source first: the x tile dies here.  One demixing coefficient at a time and
-      // the next activation tile requested only afterwards keep this phase inside the budget.
+      // (wide variants) the next activation tile requested only afterwards keep this phase inside
+      // the budget.
 #pragma unroll
       for (int n = 0; n < N; ++n) {
         c128 y[4];
@@ -200,12 +230,18 @@ __global__ __launch_bounds__(256, KS >= 8 ? 1 : 2) void k_basis_fast(const c128 
 #pragma unroll
         for (int r = 0; r < 4; ++r) pwall[n][r] = PIN ? pcur.p[n][r] : cabs2(y[r]);
       }
-      fast::vstage_load<N, KR>(st, act_b, K, T, jn);
+      if (KS >= 8) fast::vstage_load<N, KR>(st, act_b, K, T, jn);
+      if constexpr (PREFETCH) {
+        const int jnp = fast::pin_after_powers<N>(pwall, jn);
+        if constexpr (PIN) fast::ptile_load_binmajor<N>(pcur, xsrc, T, bin, jnp, q);
+        else fast::xtile_load_binmajor<N>(cur, xsrc, T, bin, jnp, q);
+      }
     }
 #pragma unroll
     for (int n = 0; n < N; ++n) {
       const double *vn = vcur + n * KR * VROW;
-      const double4_t R = rt_from_lds<KS>(vn, tb[n], c, q, ksteps);
+      const double4_t R = TB_LDS ? rt_from_lds(vn, tls[wave] + n * 256, c, q, ksteps)
+                                 : rt_from_lds<KS>(vn, tb[n], c, q, ksteps);
       // GEMM2 B operand: V[n, k = 16 kt + c, frame q + 4r] (slots 4q .. 4q+3 of the permuted row)
       double vb[KTI][4];
 #pragma unroll
@@ -219,14 +255,14 @@ __global__ __launch_bounds__(256, KS >= 8 ? 1 : 2) void k_basis_fast(const c128 
         vb[ti][3] = vb23.y;
       }
       c128 wr[N];
-      if (KS < 8) {
+      if (!PWF) {
 #pragma unroll
         for (int m = 0; m < N; ++m) wr[m] = wmine[n * N + m];
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double pw;
-        if (KS >= 8) {
+        if (PWF) {
           pw = pwall[n][r];
         } else {
           c128 y = cur.x[n][r];
@@ -237,7 +273,11 @@ __global__ __launch_bounds__(256, KS >= 8 ? 1 : 2) void k_basis_fast(const c128 
           }
           pw = PIN ? pcur.p[n][r] : cabs2(y);
         }
+#ifdef SSSPY_ASSUME_FULL
+        const bool valid = true;
+#else
         const bool valid = j0 + q + 4 * r < T;
+#endif
         const double rinv = rcp_nr(R[r]);
         const double bb = valid ? rinv : 0.0;
         const double aa = valid ? mm_num_factor<MODEL>(pw, R[r], rinv, fm) : 0.0;

@@ -86,3 +86,91 @@ def max_over_ranks(seconds: float, device: Optional[torch.device] = None) -> flo
 def barrier() -> None:
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
+
+
+def separate_pipelined(make_separator: Callable[[], object], X, sub_batch: int, n_iter: int = 100,
+                       out: Optional[np.ndarray] = None, **call_kwargs) -> np.ndarray:
+    """Separate a HOST-resident batch ``X`` (n_mixtures, n_channels, n_bins, n_frames) complex128
+    in sub-batches of ``sub_batch`` mixtures, overlapping the PCIe transfers with the iterations:
+    while the separator iterates on sub-batch k (torch's current stream), a copy stream uploads
+    sub-batch k + 1 and a second one downloads the result of k - 1.  Mixtures are independent, so
+    the result equals ``make_separator()(X, n_iter)`` element for element.
+
+    ``make_separator()`` returns a fresh separator (``GaussILRMA`` ...) per sub-batch.  Transfers are
+    asynchronous only from / to page-locked memory: a pinned ``X`` (e.g. the ``.numpy()`` view of
+    ``torch.empty(..., pin_memory=True)``) is uploaded in place, anything else is staged through two
+    pinned buffers of one sub-batch each (one extra host copy).  The result is written to ``out``
+    (allocated pinned when None) and returned as a NumPy array.
+    """
+    Xt = X if isinstance(X, torch.Tensor) else torch.from_numpy(X)
+    if Xt.dtype != torch.complex128 or Xt.dim() != 4:
+        raise ValueError("separate_pipelined: X must be (n_mixtures, n_channels, n_bins, n_frames) complex128")
+    B = Xt.shape[0]
+    sub_batch = max(1, min(int(sub_batch), B))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    compute = torch.cuda.current_stream()
+    up, down = torch.cuda.Stream(), torch.cuda.Stream()
+    if out is None:
+        out_t = torch.empty(tuple(Xt.shape), dtype=torch.complex128, pin_memory=True)
+    else:
+        out_t = out if isinstance(out, torch.Tensor) else torch.from_numpy(out)
+    direct_in, direct_out = Xt.is_pinned(), out_t.is_pinned()
+    shape1 = (sub_batch,) + tuple(Xt.shape[1:])
+    stage_in = None if direct_in else [torch.empty(shape1, dtype=torch.complex128, pin_memory=True)
+                                       for _ in range(2)]
+    stage_out = None if direct_out else [torch.empty(shape1, dtype=torch.complex128, pin_memory=True)
+                                         for _ in range(2)]
+    blocks = [(lo, min(lo + sub_batch, B)) for lo in range(0, B, sub_batch)]
+
+    slot_read = [None, None]  # per input staging slot: the event of the upload that last read it
+
+    def upload(k):
+        lo, hi = blocks[k]
+        src = Xt[lo:hi]
+        if not direct_in:
+            if slot_read[k % 2] is not None:
+                slot_read[k % 2].synchronize()  # upload k - 2 has left the slot
+            stage_in[k % 2][: hi - lo].copy_(src)  # host copy
+            src = stage_in[k % 2][: hi - lo]
+        with torch.cuda.stream(up):
+            xd = src.to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(up)
+        slot_read[k % 2] = ev
+        return xd, ev
+
+    pending = []  # (block index, device result, download-finished event, staging slot or None)
+
+    def retire(entry):
+        k, yd, ev, slot = entry
+        ev.synchronize()
+        if slot is not None:
+            lo, hi = blocks[k]
+            out_t[lo:hi].copy_(stage_out[slot][: hi - lo])
+
+    nxt = upload(0)
+    for k, (lo, hi) in enumerate(blocks):
+        xd, ev_up = nxt
+        if k + 1 < len(blocks):
+            nxt = upload(k + 1)
+        compute.wait_event(ev_up)
+        sep = make_separator()
+        yd = sep.call_on_device(xd, n_iter=n_iter, **call_kwargs)
+        done = torch.cuda.Event()
+        done.record(compute)
+        # the staging slot of download k was last used by download k - 2: retire it first
+        while len(pending) >= 2:
+            retire(pending.pop(0))
+        with torch.cuda.stream(down):
+            down.wait_event(done)
+            slot = None if direct_out else k % 2
+            dst = out_t[lo:hi] if direct_out else stage_out[slot][: hi - lo]
+            dst.copy_(yd, non_blocking=True)
+            ev_dn = torch.cuda.Event()
+            ev_dn.record(down)
+        yd.record_stream(down)
+        xd.record_stream(compute)
+        pending.append((k, yd, ev_dn, slot))
+    for entry in pending:
+        retire(entry)
+    return out_t.numpy()

@@ -66,3 +66,73 @@ def test_kernel_families_agree(tmp_path):
                 np.testing.assert_allclose(other[key], base[key], rtol=tol, err_msg=name + ":" + key)
             else:
                 assert _rel(other[key], base[key]) < tol, (name, key)
+
+
+def test_two_ranks_real_separators_share_one_device(tmp_path):
+    """Multi-GPU readiness without a node (round-3 verdict item 9): two gloo ranks, both on HIP device
+    0, run the REAL GaussILRMA separator on an uneven shard (5 mixtures = 3 + 2) through
+    parallel.run_sharded; the gathered filters and loss lists must equal the serial batched run of
+    all 5.  (tests/test_parallel_gloo.py covers the same control flow on CPU with the oracle as the
+    per-shard stand-in.)  Mixtures are independent, but the split of a mixture's frame range into
+    chunks depends on how many work items the launch has, so a 3-mixture launch and a 5-mixture
+    launch may add the same partial sums in a different order: 1e-12, not bit for bit."""
+    out = tmp_path / "device_ranks.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(ROOT, "tests", "_gloo_device_worker.py"), str(out)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    got = np.load(out)
+    assert int(got["world"]) == 2 and float(got["slowest"]) == 2.0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _gloo_device_worker as w
+
+    serial = w.process(0, w.N_MIX)
+    assert got["full"].shape == serial.shape == (5, w.F * w.N * w.N + w.N_ITER + 1)
+    assert _rel(got["full"], serial) < 1e-12
+    # the shards themselves are reproducible bit for bit: rank 0's block again, in this process
+    assert np.array_equal(got["full"][:3], w.process(0, 3))
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_separate_pipelined_equals_batched_call(pinned):
+    """parallel.separate_pipelined (upload of sub-batch k + 1 and download of k - 1 overlapping the
+    iterations of k, three streams) against one batched __call__ of the same separator: 7 mixtures
+    in sub-batches of 3 (3 + 3 + 1), pinned input (uploaded in place) and pageable input (staged)."""
+    import torch
+
+    from ssspy_amd import parallel
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    B, N, F, T, K = 7, 3, 65, 80, 5
+    X = np.stack([nmf_mixture(300 + b, N, F, T) for b in range(B)])
+
+    def make():
+        return GaussILRMA(n_basis=K, record_loss=False, rng=np.random.default_rng(11))
+
+    # per-mixture initial state must not depend on the sub-batch a mixture lands in: inject it
+    basis = np.random.default_rng(1).random((B, N, F, K))
+    act = np.random.default_rng(2).random((B, N, K, T))
+    ref = GaussILRMA(n_basis=K, record_loss=False)(X, n_iter=5, basis=basis, activation=act)
+    Xin = X
+    if pinned:
+        Xp = torch.empty(X.shape, dtype=torch.complex128, pin_memory=True)
+        Xp.copy_(torch.from_numpy(X))
+        Xin = Xp.numpy()
+    outs = []
+    for lo in range(0, B, 3):  # the same sub-batches through the pipelined runner, state injected
+        hi = min(lo + 3, B)
+        outs.append(parallel.separate_pipelined(
+            lambda: GaussILRMA(n_basis=K, record_loss=False), Xin[lo:hi], 3, n_iter=5,
+            basis=basis[lo:hi], activation=act[lo:hi]))
+    assert _rel(np.concatenate(outs), ref) < 1e-10
+    # rng-drawn state, several sub-batches in flight: every sub-batch equals its own __call__
+    Y = parallel.separate_pipelined(make, Xin, 3, n_iter=4)
+    assert Y.shape == X.shape
+    for lo in range(0, B, 3):
+        hi = min(lo + 3, B)
+        assert np.array_equal(Y[lo:hi], make()(X[lo:hi], n_iter=4)), lo
+    assert np.array_equal(Xin, X)  # the input is never written
