@@ -1,12 +1,14 @@
-"""Oracle: Gauss-ILRMA (IP1 / ISS1 spatial update, MM source update).
+"""Oracle: ILRMA (Gauss, Student-t and GGD source models).
 
 TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
 
-Restates ``GaussILRMA`` of the reference for ``source_algorithm="MM"``, no
-partitioning, ``spatial_algorithm in {"IP","IP1","ISS","ISS1"}``, power
-normalisation and projection-back scale restoration — the configuration on
-the north-star path.  The per-iteration order
-is Appendix A of SURVEY.md: basis, activation, spatial, normalise.
+Restates ``GaussILRMA`` / ``TILRMA`` / ``GGDILRMA`` of the reference (ssspy/bss/ilrma.py) in its own
+expression structure: ``source_algorithm`` "MM" and "ME", with and without ``partitioning`` (latent
+variables), every ``spatial_algorithm`` (IP1 / IP2 / ISS1 / ISS2 through ``oracle/spatial.py``, IPA
+through ``oracle/ipa.py``), power and projection-back normalisation, projection-back and
+minimal-distortion scale restoration.  The
+per-iteration order is Appendix A of SURVEY.md: basis, activation, spatial, normalise.  Pinned by
+tests/test_oracle_golden.py against fixtures the reference generated.
 """
 
 import numpy as np

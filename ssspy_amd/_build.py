@@ -22,7 +22,7 @@ OBJ_DIR = os.path.join(ROOT, "build", "obj")
 LIB_PATH = os.path.join(PKG, "lib", "libssspy_amd.so")
 
 ARCH = "gfx950"
-CXXFLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-munsafe-fp-atomics",
+CXXFLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC",
             "-I" + INCLUDE, "-I" + CSRC] + os.environ.get("SSSPY_AMD_EXTRA_CXXFLAGS", "").split()
 
 ILRMA_N = list(range(2, 9))

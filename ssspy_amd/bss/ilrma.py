@@ -4,10 +4,10 @@ Drop-in separator classes for the reference's ``ssspy.bss.ilrma`` hot path
 (ssspy/bss/ilrma.py): same constructor arguments, ``__call__`` / ``update_once`` /
 ``compute_loss`` protocol and state attributes, with every per-iteration computation done
 by the HIP kernels of ``libssspy_amd.so``.  Built here: ``GaussILRMA``, ``TILRMA`` and
-``GGDILRMA`` with ``spatial_algorithm in {"IP", "IP1", "IP2", "ISS", "ISS1", "ISS2"}``,
-``source_algorithm="MM"``, no partitioning, power normalisation, projection-back scale
-restoration.  Configurations of
-the reference that are not built yet raise ``NotImplementedError`` (never a CPU fallback).
+``GGDILRMA`` with ``spatial_algorithm in {"IP", "IP1", "IP2", "ISS", "ISS1", "ISS2", "IPA"}``,
+``source_algorithm in {"MM", "ME"}``, with and without ``partitioning``, power and projection-back
+normalisation, projection-back and minimal-distortion scale restoration.  What is not built
+raises ``NotImplementedError`` naming the step (never a CPU fallback).
 
 Extension over the reference: ``input`` may be 4-D ``(n_mixtures, n_channels, n_bins,
 n_frames)``; the mixtures are independent and every attribute then carries the same

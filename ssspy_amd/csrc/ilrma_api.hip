@@ -5,6 +5,7 @@
 
 #include "common.hpp"
 #include "ilrma_params.hpp"
+#include "tail_plan.hpp"
 
 namespace ssspy {
 
@@ -190,11 +191,11 @@ static inline int ngroups_of(int N) { return N <= 4 ? 1 : (N + 1) / 2; }
 static inline int act_chunks(int B, int N, int F, int T, int K) {
   const long long blocks0 = (long long)B * ngroups_of(N) * ((T + 63) / 64) * ((K + 15) / 16);
   const int ntiles = (F + 15) / 16;
-  long long want = (512 + blocks0 - 1) / blocks0;
-  if (want < 1) want = 1;
-  if (want > 16) want = 16;
-  if (want > ntiles) want = ntiles;
-  return (int)want;
+  // (round 4: chunk count by the cost search of tail_plan.hpp instead of "just fill one round";
+  //  24 mixtures of the configs[1] shape: 5 chunks in two short rounds instead of 3 in two long ones)
+  const int want = best_split(blocks0, ntiles, 512, 16, 2048);
+  // a single chunk finishes in place (no partial sums): keep it whenever the batch fills the chip
+  return blocks0 >= 2048 ? 1 : want;
 }
 
 // (the latency kernel's partials when the shape can take it: the workspace is sized without knowing
@@ -220,8 +221,8 @@ bool wide_weighted_cov_ok(int N, int S, int F, int T, int kind);
 int wide_weighted_cov(const void *A, const double *weight, int kind, void *U, int B, int N, int S,
                       int F, int T, hipStream_t st);
 
-// scratch of the bin-major fast kernels (basis, covariance): partial sums of the at most 512
-// split blocks of the last scheduling round (TailPlan in ilrma_fast.hip)
+// scratch of the bin-major fast kernels (basis, covariance): partial sums of the at most 1024
+// split blocks of the closing scheduling rounds (TailPlan in ilrma_fast.hip)
 // (wide mixtures run them in groups of at most 4 sources, see source_group())
 // (the wide variants, 16 < n_basis <= 64: at most 256 split blocks, each leaving one 16-k record per
 //  k tile it accumulates -- up to 4)
@@ -256,7 +257,7 @@ static inline size_t loss_slots_bytes(int B, int N, int F) {
   return align256(a > b ? a : b);
 }
 static inline size_t u_part_bytes(int N) {
-  return N <= 4 ? align256((size_t)512 * 64 * N * N * N * 2 * sizeof(double)) : 0;
+  return N <= 4 ? align256((size_t)1024 * 64 * N * N * N * 2 * sizeof(double)) : 0;
 }
 int row_power(const void *W, const void *C, double *qbuf, int B, int F, int N, hipStream_t st);
 

@@ -966,7 +966,8 @@ int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis
 #endif
   // (the wide variants hold one workgroup per CU)
   const TailPlan plan =
-      make_tail_plan(B, ((F + 63) / 64) * item_tiles, (T + 15) / 16, ktiles >= 2 ? 256 : SLOTS);
+      make_tail_plan(B, ((F + 63) / 64) * item_tiles, (T + 15) / 16, ktiles >= 2 ? 256 : SLOTS,
+                     ktiles >= 2 ? 256 : 1024);  // (basis_part_bytes(): 1024 records)
   const FastModel fm = make_fast_model(fmodel, mparam, me);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
   // loss slots per mixture: (bin group, chunk, wave) of the pass, then (bin group, block, wave) of
@@ -1138,7 +1139,8 @@ int LAUNCHER(ilrma_fast_wcov)(const void *X, const void *W, const double *basis,
   if (split_out) *split_out = 0;
   if (rbins_out) *rbins_out = WC_BINS;
   const TailPlan plan =
-      make_tail_plan(B, (F + WC_BINS - 1) / WC_BINS, (T + 15) / 16, K > 32 ? 256 : SLOTS);
+      make_tail_plan(B, (F + WC_BINS - 1) / WC_BINS, (T + 15) / 16, K > 32 ? 256 : SLOTS,
+                     K > 32 ? 256 : 1024);  // (u_part_bytes(): 1024 records)
   const FastModel fm = make_fast_model(fmodel, mparam, 0, floor_kind, floor_eps);
   dim3 grid(plan.full + plan.tail * plan.split), block(256);
 #define SSSPY_WCOV_LAUNCH(M, KS_)                                                                 \

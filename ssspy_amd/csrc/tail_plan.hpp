@@ -17,25 +17,46 @@ struct TailPlan {
   int full, tail, split, groups;  // blocks = full + tail * split; groups = bin groups per mixture
 };
 
+// Pick the number of chunks `s` (1 .. max_split, no empty chunks) an item of `ntiles` tiles is cut
+// into when `items` of them are scheduled on `slots` concurrent workgroups: equal-size blocks run in
+// ceil(items * s / slots) rounds of ceil(ntiles / s) tiles each plus a fixed cost per block (its
+// prologue and the partial-sum record it leaves, ~2 tiles) and per chunk of the fold.  Round 4
+// (benchmarks/batch_sweep.py): the old rule -- the largest s that still fits ONE round, none if two
+// items do not fit -- left 47 % of the slots idle at 16 mixtures of the configs[1] shape (272 items,
+// s = 1) where three chunks in two short rounds take 25 tile times instead of 33.5.
+static inline int best_split(long long items, int ntiles, int slots, int max_split,
+                             long long max_blocks) {
+  if (items <= 0 || ntiles <= 1) return 1;
+  const double ovh = 2.0, fold = 0.15;
+  int best = 1;
+  double best_cost = (double)((items + slots - 1) / slots) * (ntiles + ovh);
+  if (max_split > ntiles) max_split = ntiles;
+  for (int s = 2; s <= max_split; ++s) {
+    const int tpc = (ntiles + s - 1) / s;
+    const int se = (ntiles + tpc - 1) / tpc;  // chunks that are not empty
+    if (se != s) continue;                    // the same cut as a smaller s
+    const long long blocks = items * se;
+    if (blocks > max_blocks) break;
+    const double cost = (double)((blocks + slots - 1) / slots) * (tpc + ovh) + fold * se;
+    if (cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best = se;
+    }
+  }
+  return best;
+}
+
 // slots: workgroups the chip holds at once for the kernel (512 at two workgroups per CU, 256 for
-// a kernel whose register use allows one)
-static inline TailPlan make_tail_plan(int B, int groups, int ntiles, int slots = SLOTS) {
+// a kernel whose register use allows one); max_blocks: split blocks the caller's partial-sum
+// scratch has room for (default: one round, the pre-round-4 behaviour)
+static inline TailPlan make_tail_plan(int B, int groups, int ntiles, int slots = SLOTS,
+                                      int max_blocks = 0) {
   TailPlan p;
   const long long items = (long long)B * groups;
   p.groups = groups;
   p.full = (int)(items / slots) * slots;
   p.tail = (int)(items - p.full);
-  p.split = 1;
-  if (p.tail > 0) {
-    int s = slots / p.tail;
-    s = s > 16 ? 16 : s;
-    s = s > ntiles ? ntiles : s;
-    if (s > 1) {
-      const int tpc = (ntiles + s - 1) / s;
-      s = (ntiles + tpc - 1) / tpc;  // no empty chunks
-    }
-    p.split = s < 1 ? 1 : s;
-  }
+  p.split = p.tail > 0 ? best_split(p.tail, ntiles, slots, 16, max_blocks > 0 ? max_blocks : slots) : 1;
   if (p.split == 1) {
     p.full += p.tail;
     p.tail = 0;
