@@ -548,23 +548,35 @@ int ssspy_gmeanmh(const void *A, const void *Bm, void *G, long long n, int M, in
 int ssspy_lqpqm2(const void *H, const void *v, const double *z, void *y, long long n, int L,
                  int max_iter, int floor_kind, double floor_eps, void *newton_ws,
                  int *not_converged, void *stream);
+/* The same with the reference's `singular_fn` evaluated by the caller: singular (n ints, device) is
+ * singular_fn(||v||) per problem -- None: ||v|| == 0, or any callable (the norms are n numbers the
+ * host forms from its own v); problems flagged singular take the "v = 0" branch and stay out of the
+ * joint convergence test.  replaces: ssspy/linalg/lqpqm.py:61-78 (singular_fn), :80-110. */
+int ssspy_lqpqm2_masked(const void *H, const void *v, const double *z, void *y, long long n, int L,
+                        int max_iter, int floor_kind, double floor_eps, void *newton_ws,
+                        int *not_converged, const int *singular, void *stream);
 
 /* ------------------------------------------------------------------ STFT / ISTFT
  * The transforms the reference's workflow takes from SciPy either side of a separator
  * (tests/package/bss/test_ilrma.py, test_iva.py, test_mnmf.py: scipy.signal.stft(x, window="hann",
  * nperseg=n_fft, noverlap=n_fft - hop) and scipy.signal.istft), with SciPy's defaults:
- * boundary="zeros", padded=True, one-sided, scaling="spectrum".  n_fft a power of two <= 8192.
+ * boundary="zeros", padded=True, one-sided, scaling="spectrum".  n_fft: a power of two <= 8192
+ * (radix-2 in LDS) or ANY length in [2, 4096], even or odd, as SciPy's nperseg (Bluestein's chirp-z
+ * on two radix-2 transforms; `workspace` = ssspy_stft_workspace_bytes(n_fft) bytes on the device for
+ * the chirp's spectrum, 0 / NULL for a power of two).
  * x (B, C, n_samples) f64 -> Z (B, C, n_fft/2+1, ssspy_stft_frames(...)) c128; `window` (n_fft) f64
  * on the device, `window_sum` its sum. */
 int ssspy_stft_frames(long long n_samples, int n_fft, int hop);
+size_t ssspy_stft_workspace_bytes(int n_fft);
 int ssspy_stft(const double *x, void *Z, const double *window, double window_sum, int B, int C,
-               long long n_samples, int n_fft, int hop, void *stream);
+               long long n_samples, int n_fft, int hop, void *workspace, void *stream);
 
 /* Z (B, C, n_fft/2+1, n_frames) -> x (B, C, ssspy_istft_samples(...)); `segments` is scratch of
- * B*C*n_frames*n_fft doubles. */
+ * B*C*n_frames*n_fft doubles, `workspace` as for ssspy_stft. */
 long long ssspy_istft_samples(int n_frames, int n_fft, int hop);
 int ssspy_istft(const void *Z, double *x, const double *window, double window_sum,
-                double *segments, int B, int C, int n_frames, int n_fft, int hop, void *stream);
+                double *segments, int B, int C, int n_frames, int n_fft, int hop, void *workspace,
+                void *stream);
 
 #ifdef __cplusplus
 }

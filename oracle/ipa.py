@@ -101,17 +101,27 @@ def solve_equations(problems, flooring, max_iter):
     return [s["lamb"] * s["phi_max"] for s in st]
 
 
-def lqpqm2(H, v, z, flooring, max_iter):
+def lqpqm2(H, v, z, flooring, max_iter, singular_fn="flooring"):
     """argmin of the log-quadratically penalised quadratic (type 2), a batch: H (n, L, L), v (n, L),
-    z (n,) -> y (n, L).  ref: lqpqm.py:13-110."""
+    z (n,) -> y (n, L).  ref: lqpqm.py:13-110.  singular_fn: "flooring" (||v|| < floor(0)), None
+    (||v|| == 0) or a callable on the norms (lqpqm.py:61-78)."""
     n = len(H)
     y = [None] * n
     todo, problems = [], []
+    norms = np.linalg.norm(np.asarray(v), axis=-1)
+    if singular_fn is None:
+        singular = norms == 0
+    elif isinstance(singular_fn, str):
+        singular = norms < floor0(flooring)
+    else:
+        singular = np.asarray(singular_fn(norms), dtype=bool)
     for i in range(n):
         phi, sigma = np.linalg.eigh(H[i])
-        if np.linalg.norm(v[i]) < floor0(flooring):
+        if singular[i]:
             lamb = max(z[i], phi[-1])
-            y[i] = np.sqrt(max((lamb - z[i]) / phi[-1], 0.0)) * sigma[:, -1]
+            # the reference indexes the (n_bins, L, L) eigenvector array with [:, -1] (lqpqm.py:87):
+            # the LAST ROW of the eigenvector matrix, not the top eigenvector -- restated as is
+            y[i] = np.sqrt(max((lamb - z[i]) / phi[-1], 0.0)) * sigma[-1, :]
             continue
         v_t = sigma.conj().T @ v[i]
         todo.append((i, phi, sigma, v_t))

@@ -92,10 +92,12 @@ PROTOTYPES = {
     "ssspy_sqrtmh": (_i, [_p, _p, _q, _i, _i, _i, _d, _p]),
     "ssspy_gmeanmh": (_i, [_p, _p, _p, _q, _i, _i, _p]),
     "ssspy_lqpqm2": (_i, [_p, _p, _p, _p, _q, _i, _i, _i, _d, _p, _p, _p]),
+    "ssspy_lqpqm2_masked": (_i, [_p, _p, _p, _p, _q, _i, _i, _i, _d, _p, _p, _p, _p]),
     "ssspy_stft_frames": (_i, [_q, _i, _i]),
-    "ssspy_stft": (_i, [_p, _p, _p, _d, _i, _i, _q, _i, _i, _p]),
+    "ssspy_stft_workspace_bytes": (_z, [_i]),
+    "ssspy_stft": (_i, [_p, _p, _p, _d, _i, _i, _q, _i, _i, _p, _p]),
     "ssspy_istft_samples": (_q, [_i, _i, _i]),
-    "ssspy_istft": (_i, [_p, _p, _p, _d, _p, _i, _i, _i, _i, _i, _p]),
+    "ssspy_istft": (_i, [_p, _p, _p, _d, _p, _i, _i, _i, _i, _i, _p, _p]),
     "ssspy_fastmnmf_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "ssspy_fastmnmf_update": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p,
                                    _z, _p, _p]),

@@ -91,13 +91,15 @@ static inline bool fast_path(int N, int F, int T, int K, double domain,
 static inline int is_me(int source_model) { return (source_model & SSSPY_SOURCE_ME) ? 1 : 0; }
 
 // The latency kernels (ilrma_small.hip) serve batches whose bin tiles do not fill the chip with the
-// throughput kernels' 64-bin work items: B * ceil(F / 16) <= SSSPY_AMD_SMALL_MAX_ITEMS (default 640:
+// throughput kernels' 64-bin work items: B * ceil(F / 16) <= SSSPY_AMD_SMALL_MAX_ITEMS (default 350, i.e. up to 5 mixtures of 1025 bins --
+// round 4: with the cost-based tail plan the throughput kernels win from 6 mixtures on, 29.7 k
+// against 27.4 k mixture-iterations/s at 9, benchmarks/batch_sweep.py; it was 640:
 // up to 9 mixtures of 1025 bins; 0 switches the path off).
 static inline bool small_path(int B, int N, int F, int T, int K, double domain,
                               int source_model = SSSPY_SOURCE_GAUSS) {
   static const long long max_items = [] {
     const char *e = std::getenv("SSSPY_AMD_SMALL_MAX_ITEMS");
-    return e ? std::atoll(e) : 640ll;
+    return e ? std::atoll(e) : 350ll;
   }();
   return K <= 16 && fast_path(N, F, T, K, domain, source_model) &&
          (long long)B * ((F + 15) / 16) <= max_items;

@@ -79,7 +79,8 @@ enum { NEWTON_FIXED = 0, NEWTON_PROBE = 1, NEWTON_APPLY = 2 };
 template <int L>
 __device__ __forceinline__ void lqpqm2(c128 (&H)[L][L], const c128 (&v)[L], double z,
                                        int floor_kind, double eps, int max_iter, c128 (&y)[L],
-                                       int mode = NEWTON_FIXED, unsigned long long *word = nullptr) {
+                                       int mode = NEWTON_FIXED, unsigned long long *word = nullptr,
+                                       int singular_override = -1) {
   c128 sigma[L][L];
   jacobi_eigh<L>(H, sigma);
   double phi[L];
@@ -89,25 +90,31 @@ __device__ __forceinline__ void lqpqm2(c128 (&H)[L][L], const c128 (&v)[L], doub
   double vnorm2 = 0.0;
 #pragma unroll
   for (int l = 0; l < L; ++l) vnorm2 += cabs2(v[l]);
-  if (sqrt(vnorm2) < f0) {
-    // v = 0: a scaled top eigenvector
+  // singular_override: the caller evaluated the reference's singular_fn on ||v|| itself (None:
+  // x == 0, or any callable; lqpqm.py:61-78); -1: the default "x < flooring_fn(0)"
+  const bool is_singular = singular_override < 0 ? sqrt(vnorm2) < f0 : singular_override != 0;
+  if (is_singular) {
+    // v = 0.  The reference returns scale * sigma[:, -1] taken on the (n_bins, L, L) eigenvector
+    // array (lqpqm.py:84-93), i.e. the LAST ROW of each eigenvector matrix in ascending-eigenvalue
+    // column order, not its last column: component a is the last entry of the eigenvector of the
+    // a-th smallest eigenvalue (every entry with that eigenvector's arbitrary phase).  Followed
+    // literally -- the moduli are what parity can pin.
     double pmax = phi[0];
-    int arg = 0;
 #pragma unroll
-    for (int l = 1; l < L; ++l)
-      if (phi[l] > pmax) {
-        pmax = phi[l];
-        arg = l;
-      }
+    for (int l = 1; l < L; ++l) pmax = fmax(pmax, phi[l]);
     const double lamb = fmax(z, pmax);
     const double scale = sqrt(fmax((lamb - z) / pmax, 0.0));
 #pragma unroll
-    for (int a = 0; a < L; ++a) {
-      c128 col = cmake(0.0, 0.0);
+    for (int a = 0; a < L; ++a) y[a] = cmake(0.0, 0.0);
 #pragma unroll
-      for (int l = 0; l < L; ++l)
-        if (l == arg) col = sigma[a][l];
-      y[a] = cscale(col, scale);
+    for (int l = 0; l < L; ++l) {
+      int rank = 0;  // position of phi[l] in ascending order (ties by index)
+#pragma unroll
+      for (int m = 0; m < L; ++m) rank += (phi[m] < phi[l] || (phi[m] == phi[l] && m < l)) ? 1 : 0;
+      const c128 val = cscale(sigma[L - 1][l], scale);
+#pragma unroll
+      for (int a = 0; a < L; ++a)
+        if (a == rank) y[a] = val;
     }
     return;
   }
@@ -348,7 +355,8 @@ template <int L, int MODE>
 __global__ __launch_bounds__(64) void k_lqpqm2(const c128 *__restrict__ H, const c128 *__restrict__ v,
                                                const double *__restrict__ z, c128 *y, long long n,
                                                int max_iter, int floor_kind, double eps,
-                                               unsigned long long *newton_ws) {
+                                               unsigned long long *newton_ws,
+                                               const int *__restrict__ singular) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
   c128 Hm[L][L], vv[L], yy[L];
@@ -359,7 +367,8 @@ __global__ __launch_bounds__(64) void k_lqpqm2(const c128 *__restrict__ H, const
     for (int c = 0; c < L; ++c) Hm[r][c] = H[(idx * L + r) * L + c];
   }
   hermitize<L>(Hm);
-  lqpqm2<L>(Hm, vv, z[idx], floor_kind, eps, max_iter, yy, MODE, newton_ws);
+  lqpqm2<L>(Hm, vv, z[idx], floor_kind, eps, max_iter, yy, MODE, newton_ws,
+            singular ? singular[idx] : -1);
   if (MODE == NEWTON_PROBE) return;
 #pragma unroll
   for (int r = 0; r < L; ++r) y[idx * L + r] = yy[r];
@@ -436,9 +445,9 @@ extern "C" int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int 
   return fail(SSSPY_ERR_UNSUPPORTED, "ipa_transform: unsupported (n_sources, source) pair");
 }
 
-extern "C" int ssspy_lqpqm2(const void *H, const void *v, const double *z, void *y, long long n,
-                            int L, int max_iter, int floor_kind, double floor_eps, void *newton_ws,
-                            int *not_converged, void *stream) {
+static int lqpqm2_launch(const void *H, const void *v, const double *z, void *y, long long n, int L,
+                         int max_iter, int floor_kind, double floor_eps, void *newton_ws,
+                         int *not_converged, const int *singular, void *stream) {
   SSSPY_REQUIRE(H && v && z && y && n > 0 && max_iter >= 0, "lqpqm2: bad argument");
   if (L < 1 || L > 7) return fail(SSSPY_ERR_UNSUPPORTED, "lqpqm2: dimension must be in [1, 7]");
   dim3 grid((unsigned)((n + 63) / 64)), block(64);
@@ -447,7 +456,7 @@ extern "C" int ssspy_lqpqm2(const void *H, const void *v, const double *z, void 
   const bool exact = ws && max_iter >= 1 && max_iter <= 62;
 #define LQ_LAUNCH(L_, MODE_)                                                                     \
   hipLaunchKernelGGL((k_lqpqm2<L_, MODE_>), grid, block, 0, st, (const c128 *)H, (const c128 *)v, \
-                     z, (c128 *)y, n, max_iter, floor_kind, floor_eps, ws)
+                     z, (c128 *)y, n, max_iter, floor_kind, floor_eps, ws, singular)
 #define LQ_CASE(L_)                                                                              \
   if (L == L_) {                                                                                 \
     if (!exact) {                                                                                \
@@ -468,4 +477,20 @@ extern "C" int ssspy_lqpqm2(const void *H, const void *v, const double *z, void 
 #undef LQ_CASE
 #undef LQ_LAUNCH
   return SSSPY_ERR_UNSUPPORTED;
+}
+
+extern "C" int ssspy_lqpqm2(const void *H, const void *v, const double *z, void *y, long long n,
+                            int L, int max_iter, int floor_kind, double floor_eps, void *newton_ws,
+                            int *not_converged, void *stream) {
+  return lqpqm2_launch(H, v, z, y, n, L, max_iter, floor_kind, floor_eps, newton_ws, not_converged,
+                       nullptr, stream);
+}
+
+extern "C" int ssspy_lqpqm2_masked(const void *H, const void *v, const double *z, void *y,
+                                   long long n, int L, int max_iter, int floor_kind,
+                                   double floor_eps, void *newton_ws, int *not_converged,
+                                   const int *singular, void *stream) {
+  SSSPY_REQUIRE(singular, "lqpqm2_masked: the singular mask is required");
+  return lqpqm2_launch(H, v, z, y, n, L, max_iter, floor_kind, floor_eps, newton_ws, not_converged,
+                       singular, stream);
 }

@@ -9,7 +9,11 @@
 // (where it exceeds 1e-10), boundary removed.
 //
 // One workgroup transforms one segment in LDS: bit-reversed load, log2(n) radix-2 passes, twiddles
-// from sincospi.  n_fft is a power of two up to 8192 (128 KB of complex128 in LDS).
+// from sincospi.  A power-of-two n_fft up to 8192 (128 KB of complex128 in LDS) is transformed
+// directly; any other n_fft up to 4096 (SciPy takes any nperseg) goes through Bluestein's chirp-z
+// identity inside the same workgroup: x_t e^{-+ i pi t^2 / n} convolved with the chirp e^{+- i pi j^2 / n}
+// by two radix-2 transforms of length m = the power of two >= 2 n - 1, the chirp's spectrum computed
+// once per call into a caller-provided workspace (ssspy_stft_workspace_bytes).
 #include "common.hpp"
 #include "ssspy_amd.h"
 
@@ -33,10 +37,72 @@ __device__ __forceinline__ void fft_inplace(c128 *buf, int n, int log2n, double 
   __syncthreads();
 }
 
+// e^{sign * i pi t^2 / n}; t^2 is reduced mod 2 n in integers first (the phase has period 2 n)
+__device__ __forceinline__ c128 chirp(long long t, int n, double sign) {
+  const long long r = (t * t) % (2ll * n);
+  double sn, cs;
+  sincospi(sign * (double)r / (double)n, &sn, &cs);
+  return cmake(cs, sn);
+}
+
+__device__ __forceinline__ void bitrev_permute(c128 *buf, int m, int log2m) {
+  __syncthreads();
+  for (int i = threadIdx.x; i < m; i += blockDim.x) {
+    const int j = (int)(__brev((unsigned)i) >> (32 - log2m));
+    if (i < j) {
+      const c128 a = buf[i], b = buf[j];
+      buf[i] = b;
+      buf[j] = a;
+    }
+  }
+  __syncthreads();
+}
+
+// Spectrum of the Bluestein chirp b_j = e^{-sign * i pi j^2 / n}, j = -(n-1) .. n-1 at index j mod m
+// (the DFT with exponent sign `sign` convolves with the chirp of the opposite sign).  One workgroup.
+__global__ __launch_bounds__(256) void k_bluestein_chirp(c128 *__restrict__ bhat, int n, int m,
+                                                         int log2m, double sign) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  c128 *buf = reinterpret_cast<c128 *>(smem);
+  for (int i = threadIdx.x; i < m; i += blockDim.x) {
+    c128 v = cmake(0.0, 0.0);
+    if (i < n) v = chirp(i, n, -sign);
+    else if (i > m - n) v = chirp(m - i, n, -sign);
+    buf[__brev((unsigned)i) >> (32 - log2m)] = v;
+  }
+  fft_inplace(buf, m, log2m, -1.0);
+  for (int i = threadIdx.x; i < m; i += blockDim.x) bhat[i] = buf[i];
+}
+
+// DFT of length n (any n) of the sequence already in buf[0 .. n) in NATURAL order, exponent sign
+// `sign`, result in buf[0 .. n) (unnormalised).  m > 0: Bluestein with the chirp spectrum `bhat`;
+// m == 0: n is a power of two and buf is transformed directly.
+__device__ __forceinline__ void dft_any(c128 *buf, int n, int log2n, int m, int log2m,
+                                        const c128 *__restrict__ bhat, double sign) {
+  if (m == 0) {
+    bitrev_permute(buf, n, log2n);
+    fft_inplace(buf, n, log2n, sign);
+    return;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < m; t += blockDim.x)
+    buf[t] = t < n ? cmul(buf[t], chirp(t, n, sign)) : cmake(0.0, 0.0);
+  bitrev_permute(buf, m, log2m);
+  fft_inplace(buf, m, log2m, -1.0);
+  for (int k = threadIdx.x; k < m; k += blockDim.x) buf[k] = cmul(buf[k], bhat[k]);
+  bitrev_permute(buf, m, log2m);
+  fft_inplace(buf, m, log2m, 1.0);
+  const double inv = 1.0 / (double)m;
+  for (int k = threadIdx.x; k < n; k += blockDim.x)
+    buf[k] = cscale(cmul(buf[k], chirp(k, n, sign)), inv);
+  __syncthreads();
+}
+
 // grid: (n_frames, C, B).  x (B, C, L) real -> Z (B, C, n/2+1, n_frames) complex
 __global__ __launch_bounds__(256) void k_stft(const double *__restrict__ x, c128 *__restrict__ Z,
                                               long long L, int n, int log2n, int hop, int n_frames,
-                                              const double *__restrict__ window, double scale) {
+                                              const double *__restrict__ window, double scale, int m,
+                                              int log2m, const c128 *__restrict__ bhat) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   c128 *buf = reinterpret_cast<c128 *>(smem);
   const int frame = blockIdx.x, ch = blockIdx.y, b = blockIdx.z;
@@ -46,9 +112,9 @@ __global__ __launch_bounds__(256) void k_stft(const double *__restrict__ x, c128
   for (int t = threadIdx.x; t < n; t += blockDim.x) {
     const long long sidx = start + t;
     const double v = (sidx >= 0 && sidx < L) ? xs[sidx] * window[t] : 0.0;
-    buf[__brev((unsigned)t) >> (32 - log2n)] = cmake(v, 0.0);
+    buf[t] = cmake(v, 0.0);
   }
-  fft_inplace(buf, n, log2n, -1.0);
+  dft_any(buf, n, log2n, m, log2m, bhat, -1.0);
   const int F = n / 2 + 1;
   c128 *out = Z + ((long long)b * C + ch) * F * n_frames + frame;
   for (int k = threadIdx.x; k < F; k += blockDim.x)
@@ -61,7 +127,8 @@ __global__ __launch_bounds__(256) void k_istft_segments(const c128 *__restrict__
                                                         double *__restrict__ seg, int n, int log2n,
                                                         int n_frames,
                                                         const double *__restrict__ window,
-                                                        double gain) {
+                                                        double gain, int m, int log2m,
+                                                        const c128 *__restrict__ bhat) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   c128 *buf = reinterpret_cast<c128 *>(smem);
   const int frame = blockIdx.x, ch = blockIdx.y, b = blockIdx.z;
@@ -71,13 +138,14 @@ __global__ __launch_bounds__(256) void k_istft_segments(const c128 *__restrict__
     c128 v;
     if (k < F) {
       v = in[(long long)k * n_frames];
-      if (k == 0 || k == n / 2) v.y = 0.0;  // irfft ignores the imaginary part of DC / Nyquist
+      // irfft ignores the imaginary part of DC and (even n) of Nyquist
+      if (k == 0 || (2 * k == n)) v.y = 0.0;
     } else {
       v = cconj(in[(long long)(n - k) * n_frames]);
     }
-    buf[__brev((unsigned)k) >> (32 - log2n)] = v;
+    buf[k] = v;
   }
-  fft_inplace(buf, n, log2n, 1.0);
+  dft_any(buf, n, log2n, m, log2m, bhat, 1.0);
   double *out = seg + (((long long)b * C + ch) * n_frames + frame) * n;
   const double g = gain / (double)n;
   for (int t = threadIdx.x; t < n; t += blockDim.x) out[t] = buf[t].x * g * window[t];
@@ -120,15 +188,55 @@ using namespace ssspy;
 
 extern "C" {
 
-// the segment sits in LDS: 16 bytes x n_fft, 128 KB of the CU's 160 at 8192 (above the 64 KB a
-// launch gets by default: raise the kernel's limit first)
-constexpr int STFT_MAX_NFFT = 8192;
-static int allow_lds(const void *kernel, int n_fft) {
-  const size_t bytes = (size_t)n_fft * sizeof(c128);
+// the segment sits in LDS: 16 bytes x the transform length, 128 KB of the CU's 160 at 8192 (above
+// the 64 KB a launch gets by default: raise the kernel's limit first)
+constexpr int STFT_MAX_LEN = 8192;
+static int allow_lds(const void *kernel, int len) {
+  const size_t bytes = (size_t)len * sizeof(c128);
   if (bytes <= 64 * 1024) return SSSPY_OK;
   hipError_t e =
       hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   return e == hipSuccess ? SSSPY_OK : fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+}
+
+// transform plan of a segment length: direct radix-2 (m = 0) or Bluestein of length m
+struct FftPlan {
+  int log2n, m, log2m, lds_len;
+  bool ok;
+};
+static FftPlan fft_plan(int n) {
+  FftPlan p = {ilog2_exact(n), 0, 0, n, false};
+  if (n < 2) return p;
+  if (p.log2n >= 1) {
+    p.ok = n <= STFT_MAX_LEN;
+    return p;
+  }
+  int m = 1, lg = 0;
+  while (m < 2 * n - 1) {
+    m <<= 1;
+    ++lg;
+  }
+  p.log2n = 0;
+  p.m = m;
+  p.log2m = lg;
+  p.lds_len = m;
+  p.ok = m <= STFT_MAX_LEN;
+  return p;
+}
+
+size_t ssspy_stft_workspace_bytes(int n_fft) {
+  const FftPlan p = fft_plan(n_fft);
+  return p.ok && p.m ? (size_t)p.m * sizeof(c128) : 0;
+}
+
+static int prepare_chirp(const FftPlan &p, int n, double sign, void *workspace, hipStream_t st) {
+  if (!p.m) return SSSPY_OK;
+  SSSPY_REQUIRE(workspace, "stft: this n_fft needs ssspy_stft_workspace_bytes() of workspace");
+  int rc = allow_lds((const void *)k_bluestein_chirp, p.m);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_bluestein_chirp, dim3(1), dim3(256), (size_t)p.m * sizeof(c128), st,
+                     (c128 *)workspace, n, p.m, p.log2m, sign);
+  return check_launch("k_bluestein_chirp");
 }
 
 int ssspy_stft_frames(long long n_samples, int n_fft, int hop) {
@@ -141,19 +249,23 @@ int ssspy_stft_frames(long long n_samples, int n_fft, int hop) {
 }
 
 int ssspy_stft(const double *x, void *Z, const double *window, double window_sum, int B, int C,
-               long long n_samples, int n_fft, int hop, void *stream) {
+               long long n_samples, int n_fft, int hop, void *workspace, void *stream) {
   SSSPY_REQUIRE(x && Z && window && B > 0 && C > 0 && n_samples > 0 && hop > 0 && hop <= n_fft &&
                     window_sum != 0.0,
                 "stft: bad argument");
-  const int lg = ilog2_exact(n_fft);
-  if (lg < 1 || n_fft > STFT_MAX_NFFT)
-    return fail(SSSPY_ERR_UNSUPPORTED, "stft: n_fft must be a power of two in [2, 8192]");
-  int rc0 = allow_lds((const void *)k_stft, n_fft);
+  const FftPlan p = fft_plan(n_fft);
+  if (!p.ok)
+    return fail(SSSPY_ERR_UNSUPPORTED,
+                "stft: n_fft must be a power of two <= 8192 or any length in [2, 4096]");
+  hipStream_t st = as_stream(stream);
+  int rc0 = prepare_chirp(p, n_fft, -1.0, workspace, st);
+  if (rc0) return rc0;
+  rc0 = allow_lds((const void *)k_stft, p.lds_len);
   if (rc0) return rc0;
   const int n_frames = ssspy_stft_frames(n_samples, n_fft, hop);
-  hipLaunchKernelGGL(k_stft, dim3(n_frames, C, B), dim3(256), (size_t)n_fft * sizeof(c128),
-                     as_stream(stream), x, (c128 *)Z, n_samples, n_fft, lg, hop, n_frames, window,
-                     1.0 / window_sum);
+  hipLaunchKernelGGL(k_stft, dim3(n_frames, C, B), dim3(256), (size_t)p.lds_len * sizeof(c128), st,
+                     x, (c128 *)Z, n_samples, n_fft, p.log2n, hop, n_frames, window,
+                     1.0 / window_sum, p.m, p.log2m, (const c128 *)workspace);
   return check_launch("k_stft");
 }
 
@@ -163,19 +275,23 @@ long long ssspy_istft_samples(int n_frames, int n_fft, int hop) {
 }
 
 int ssspy_istft(const void *Z, double *x, const double *window, double window_sum,
-                double *segments, int B, int C, int n_frames, int n_fft, int hop, void *stream) {
+                double *segments, int B, int C, int n_frames, int n_fft, int hop, void *workspace,
+                void *stream) {
   SSSPY_REQUIRE(Z && x && window && segments && B > 0 && C > 0 && n_frames > 0 && hop > 0 &&
                     hop <= n_fft,
                 "istft: bad argument");
-  const int lg = ilog2_exact(n_fft);
-  if (lg < 1 || n_fft > STFT_MAX_NFFT)
-    return fail(SSSPY_ERR_UNSUPPORTED, "istft: n_fft must be a power of two in [2, 8192]");
-  int rc0 = allow_lds((const void *)k_istft_segments, n_fft);
-  if (rc0) return rc0;
+  const FftPlan p = fft_plan(n_fft);
+  if (!p.ok)
+    return fail(SSSPY_ERR_UNSUPPORTED,
+                "istft: n_fft must be a power of two <= 8192 or any length in [2, 4096]");
   hipStream_t st = as_stream(stream);
+  int rc0 = prepare_chirp(p, n_fft, 1.0, workspace, st);
+  if (rc0) return rc0;
+  rc0 = allow_lds((const void *)k_istft_segments, p.lds_len);
+  if (rc0) return rc0;
   hipLaunchKernelGGL(k_istft_segments, dim3(n_frames, C, B), dim3(256),
-                     (size_t)n_fft * sizeof(c128), st, (const c128 *)Z, segments, n_fft, lg,
-                     n_frames, window, window_sum);
+                     (size_t)p.lds_len * sizeof(c128), st, (const c128 *)Z, segments, n_fft, p.log2n,
+                     n_frames, window, window_sum, p.m, p.log2m, (const c128 *)workspace);
   int rc = check_launch("k_istft_segments");
   if (rc) return rc;
   const long long L_out = ssspy_istft_samples(n_frames, n_fft, hop);

@@ -183,18 +183,27 @@ def lqpqm2(H: np.ndarray, v: np.ndarray, z: np.ndarray, flooring_fn="default",
 
     H (n_bins, L, L) Hermitian, v (n_bins, L), z (n_bins,) -> y (n_bins, L).  The Newton loop stops
     when every problem has converged and warns when they have not after ``max_iter`` steps, like
-    the reference (lqpqm.py:196-213); ``singular_fn`` must be the reference's default ("flooring").
+    the reference (lqpqm.py:196-213).  ``singular_fn``: "flooring" (default), None or a callable on the
+    norms of ``v``, as in the reference (lqpqm.py:61-78); the solution of a singular problem is a
+    scaled top eigenvector of ``H`` and carries that eigenvector's arbitrary phase.
     """
     import functools
 
     from ..special.flooring import max_flooring
     from ..utils.flooring import device_flooring
 
-    if singular_fn != "flooring":
-        raise NotImplementedError("singular_fn other than 'flooring' is not built for the device path.")
     if isinstance(flooring_fn, str) and flooring_fn == "default":
         flooring_fn = functools.partial(max_flooring, eps=1e-10)
-    floor = device_flooring(flooring_fn)
+    floor = device_flooring(flooring_fn, what="lqpqm2")
+    # singular_fn (lqpqm.py:61-78): "flooring" -> ||v|| < flooring_fn(0), decided in the kernel; None
+    # -> ||v|| == 0; a callable -> its verdict on the (n_bins,) norms.  The last two are evaluated here
+    # on the host (n numbers from the caller's own v) and handed to the kernel as a mask.
+    mask = None
+    if singular_fn is None:
+        mask = np.linalg.norm(np.asarray(v), axis=-1) == 0
+    elif not (isinstance(singular_fn, str) and singular_fn == "flooring"):
+        assert callable(singular_fn), "singular_fn should be callable."
+        mask = np.asarray(singular_fn(np.linalg.norm(np.asarray(v), axis=-1)), dtype=bool)
     H, v, z = np.asarray(H), np.asarray(v), np.asarray(z, dtype=np.float64)
     n, L = v.shape
     dH = dv.to_device(np.ascontiguousarray(H, dtype=np.complex128))
@@ -203,9 +212,17 @@ def lqpqm2(H: np.ndarray, v: np.ndarray, z: np.ndarray, flooring_fn="default",
     y = dv.empty((n, L), dv.c128, dH.device)
     newton_ws = dv.empty((1,), dv.i64, dH.device)
     not_converged = dv.zeros((1,), dv.i32, dH.device)
-    _lib.check(_lib.load().ssspy_lqpqm2(ptr(dH), ptr(dvv), ptr(dz), ptr(y), n, L, int(max_iter),
-                                        floor[0], floor[1], ptr(newton_ws), ptr(not_converged),
-                                        dv.stream_handle()), "lqpqm2")
+    if mask is None:
+        _lib.check(_lib.load().ssspy_lqpqm2(ptr(dH), ptr(dvv), ptr(dz), ptr(y), n, L, int(max_iter),
+                                            floor[0], floor[1], ptr(newton_ws), ptr(not_converged),
+                                            dv.stream_handle()), "lqpqm2")
+    else:
+        if mask.shape != (n,):
+            raise ValueError("singular_fn must return one flag per problem, got shape {}".format(mask.shape))
+        dmask = dv.to_device(mask.astype(np.int32))
+        _lib.check(_lib.load().ssspy_lqpqm2_masked(
+            ptr(dH), ptr(dvv), ptr(dz), ptr(y), n, L, int(max_iter), floor[0], floor[1],
+            ptr(newton_ws), ptr(not_converged), ptr(dmask), dv.stream_handle()), "lqpqm2")
     out = dv.to_host(y)
     if int(not_converged.item()):
         import warnings

@@ -466,6 +466,40 @@ def run_operators():
     save("operators", **out)
 
 
+def singular_below_half(x):
+    """A singular_fn that is neither of the reference's two built-ins (ssspy/linalg/lqpqm.py:61-78)."""
+    return x < 0.5
+
+
+def run_lqpqm_singular():
+    """lqpqm2 with singular_fn=None (||v|| == 0), a callable, and the default, on problems some of
+    which have v exactly zero / tiny / small (ssspy/linalg/lqpqm.py:61-110)."""
+    if skipped("lqpqm_singular"):
+        return
+    from ssspy.linalg import lqpqm2
+
+    out = {}
+    rng = np.random.default_rng(180)
+    for L in (1, 2, 3, 5):
+        n = 24
+        A = rng.standard_normal((n, L, 7)) + 1j * rng.standard_normal((n, L, 7))
+        H = A @ A.swapaxes(-2, -1).conj()
+        H = H / np.real(np.trace(H, axis1=-2, axis2=-1))[:, None, None]
+        v = rng.standard_normal((n, L)) + 1j * rng.standard_normal((n, L))
+        v[::4] = 0.0                      # exactly zero: singular for every rule
+        v[1::4] *= 1e-13                  # below the default floor (1e-10), not zero
+        v[2::4] *= 0.2 / np.linalg.norm(v[2::4], axis=-1, keepdims=True)  # norm 0.2 < 0.5
+        z = rng.random(n) * 2.0
+        p = "l{}_".format(L)
+        out[p + "H"], out[p + "v"], out[p + "z"] = H, v, z
+        out[p + "y_default"] = lqpqm2(H, v, z)
+        out[p + "y_none"] = lqpqm2(H, v, z, singular_fn=None)
+        out[p + "y_callable"] = lqpqm2(H, v, z, singular_fn=singular_below_half)
+        out[p + "y_none_nofloor_it3"] = lqpqm2(H, v, z, flooring_fn=None, singular_fn=None,
+                                               max_iter=3)
+    save("lqpqm_singular", **out)
+
+
 def run_pairwise_operators():
     """update_by_ip2 / update_by_iss2 on random operands (ssspy/bss/_update_spatial_model.py:81-143,
     197-314): default (sequential) pairs, every combination, an explicit list with negative and
@@ -651,6 +685,7 @@ def main():
     # --- operators ---
     run_operators()
     run_pairwise_operators()
+    run_lqpqm_singular()
 
 
 if __name__ == "__main__":

@@ -1286,6 +1286,38 @@ def test_stft_istft_against_scipy(n_fft, hop, L):
         assert rel_err(y[:, :L], x) < 1e-12
 
 
+@pytest.mark.parametrize("n_fft,hop,window", [
+    (1000, 250, "hann"), (1536, 384, "hamming"), (300, 75, ("kaiser", 8.6)), (4096 - 2, 1000, "blackman"),
+    (441, 147, "hann"), (25, 5, ("tukey", 0.5)), (2, 1, "boxcar"), (3000, 1000, "bartlett")])
+def test_stft_any_length_and_named_windows_against_scipy(n_fft, hop, window):
+    """SciPy takes any nperseg (even or odd) and any of its named windows; here lengths that are not a
+    power of two go through Bluestein's chirp-z on two radix-2 transforms in LDS."""
+    import scipy.signal as ss
+
+    from ssspy_amd.transform import istft, stft
+
+    rng = np.random.default_rng(n_fft)
+    L = 7 * n_fft + 13
+    x = rng.standard_normal((2, L))
+    _, _, Zr = ss.stft(x, window=window, nperseg=n_fft, noverlap=n_fft - hop)
+    Z = stft(x, n_fft=n_fft, hop_length=hop, window=window)
+    assert Z.shape == Zr.shape
+    assert rel_err(Z, Zr) < 1e-11
+    _, yr = ss.istft(Zr, window=window, nperseg=n_fft, noverlap=n_fft - hop)
+    y = istft(Zr, n_fft=n_fft, hop_length=hop, window=window)
+    assert y.shape == yr.shape
+    assert rel_err(y, yr) < 1e-11
+
+
+def test_stft_rejects_what_it_cannot_hold():
+    from ssspy_amd.transform import stft
+
+    with pytest.raises(NotImplementedError):
+        stft(np.zeros((1, 20000)), n_fft=5000)  # Bluestein needs 16384 points: beyond the 128 KB of LDS
+    with pytest.raises(ValueError, match="Unknown window"):
+        stft(np.zeros((1, 2000)), n_fft=64, window="no_such_window")
+
+
 def test_waveform_to_waveform_stays_on_device():
     """stft -> separator -> istft with device tensors between the stages == the SciPy / NumPy path."""
     import scipy.signal as ss
@@ -1418,6 +1450,37 @@ def test_lqpqm2_against_golden(L):
     else:
         y2 = lqpqm2(H, v, z, max_iter=2)
     assert rel_err(y2, g["lq{}_y_it2".format(L)]) < 1e-10
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 5])
+def test_lqpqm2_singular_fn_against_golden(L):
+    """singular_fn = "flooring" (default), None and a callable, on problems whose v is exactly zero,
+    below the floor, and small (ssspy/linalg/lqpqm.py:61-110).  Non-singular problems: equal to the
+    reference.  Singular ones: the reference returns scale * (the last row of LAPACK's eigenvector
+    matrix), every entry with the arbitrary phase of a different eigenvector -- the moduli are what
+    is defined, and they are compared."""
+    import warnings
+
+    from test_oracle_golden import lqpqm_singular_check
+
+    from ssspy_amd.linalg import lqpqm2
+
+    g = load_golden("lqpqm_singular")
+    H, v, z = (g["l{}_{}".format(L, k)] for k in ("H", "v", "z"))
+    norms = np.linalg.norm(v, axis=-1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # (convergence warnings are pinned by the test above)
+        lqpqm_singular_check(lqpqm2(H, v, z), g["l{}_y_default".format(L)], norms < 1e-10)
+        lqpqm_singular_check(lqpqm2(H, v, z, singular_fn=None), g["l{}_y_none".format(L)], norms == 0)
+        lqpqm_singular_check(lqpqm2(H, v, z, singular_fn=lambda x: x < 0.5),
+                             g["l{}_y_callable".format(L)], norms < 0.5)
+        # no floor, three steps: the reference's NaNs (v = 1e-13-ish with singular_fn=None, L = 1) are
+        # NaNs here too
+        ref = g["l{}_y_none_nofloor_it3".format(L)]
+        y = lqpqm2(H, v, z, flooring_fn=None, singular_fn=None, max_iter=3)
+        ok = np.isfinite(ref).all(axis=-1)
+        lqpqm_singular_check(y[ok], ref[ok], (norms == 0)[ok], tol=1e-9)
+        assert not np.isfinite(y[~ok]).any()
 
 
 # ------------------------------------------------------------------------------- boundary (round 2)

@@ -155,3 +155,20 @@ def test_bench_gpus_flag_is_read():
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"],
                          env=env, capture_output=True, text=True, timeout=300, cwd=root)
     assert res.returncode != 0 and "WORLD_SIZE=1" in res.stderr
+
+
+def test_named_windows_equal_scipy():
+    """ssspy_amd.transform.get_window restates SciPy's periodic windows (a host-side table of n_fft
+    samples); the reference's workflow passes the name straight to scipy.signal.stft."""
+    import scipy.signal as ss
+
+    from ssspy_amd.transform import get_window
+
+    names = ["hann", "hamming", "blackman", "blackmanharris", "nuttall", "flattop", "boxcar",
+             "bartlett", "triang", "cosine", "bohman", "parzen", ("kaiser", 8.6), ("gaussian", 7.0),
+             ("tukey", 0.3), ("general_hamming", 0.6)]
+    for n in (2, 9, 64, 441, 1000):
+        for w in names:
+            assert np.allclose(get_window(w, n), ss.get_window(w, n), rtol=0, atol=1e-13), (n, w)
+    with pytest.raises(ValueError):
+        get_window("nope", 16)

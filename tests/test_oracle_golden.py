@@ -317,6 +317,32 @@ def test_lqpqm2_operator(L):
     assert rel_err(lqpqm2(H, v, z, ("max", 1e-10), 2), g["lq{}_y_it2".format(L)]) < 1e-10
 
 
+def lqpqm_singular_check(y, ref, singular, tol=1e-10):
+    """Non-singular problems: equal.  Singular ones: the reference returns scale * (last row of the
+    eigenvector matrix), each entry carrying the arbitrary phase of a different eigenvector
+    (lqpqm.py:84-93) -- only the moduli are defined."""
+    assert rel_err(y[~singular], ref[~singular]) < tol
+    if singular.any():
+        assert rel_err(np.abs(y[singular]), np.abs(ref[singular])) < tol
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 5])
+def test_lqpqm2_singular_fn(L):
+    """singular_fn = default / None / a callable (ssspy/linalg/lqpqm.py:61-78) on problems with v
+    exactly zero, below the floor, and small."""
+    from oracle import ipa
+
+    g = load_golden("lqpqm_singular")
+    H, v, z = (g["l{}_{}".format(L, k)] for k in ("H", "v", "z"))
+    norms = np.linalg.norm(v, axis=-1)
+    for key, kw, singular in (("y_default", {}, norms < 1e-10),
+                              ("y_none", dict(singular_fn=None), norms == 0),
+                              ("y_callable", dict(singular_fn=lambda x: x < 0.5), norms < 0.5)):
+        ref = g["l{}_{}".format(L, key)]
+        y = ipa.lqpqm2(H, v, z, ("max", 1e-10), 10, **kw)
+        lqpqm_singular_check(y, ref, singular)
+
+
 def test_inv2():
     g = load_golden("operators")
     assert rel_err(sp.inv2(g["inv2_in"]), g["inv2_out"]) < 1e-13
