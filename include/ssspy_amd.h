@@ -65,7 +65,12 @@ enum { SSSPY_SOURCE_GAUSS = 0, SSSPY_SOURCE_T = 1, SSSPY_SOURCE_GGD = 2 };
  * exponent 1 (domain must be 2; Gauss and t models; ssspy/bss/ilrma.py:1249-1401, :2659-2830) */
 enum { SSSPY_SOURCE_ME = 0x100 };
 
-#define SSSPY_MAX_SOURCES 8
+#define SSSPY_MAX_SOURCES 8 /* kernels compiled per source count (everything in registers) */
+/* Above that, up to SSSPY_RT_MAX_SOURCES, the shared operators, the AuxIVA entry points and the ILRMA
+ * iteration on the Gauss model's tuned passes run with the source count at run time (wide_n.hip:
+ * correct, not tuned; the reference has no limit: ssspy/bss/ilrma.py:180, iva.py:152).  IP2 / ISS2 /
+ * IPA, the MNMF entry points and the Hermitian operators stay at SSSPY_MAX_SOURCES. */
+#define SSSPY_RT_MAX_SOURCES 16
 #define SSSPY_MAX_BASIS 1024 /* ILRMA; the MNMF entry points take n_basis <= 256 */
 #define SSSPY_MAX_PAIRS 32
 

@@ -6,6 +6,7 @@
 #include "common.hpp"
 #include "ilrma_params.hpp"
 #include "tail_plan.hpp"
+#include "wide_n.hpp"
 
 namespace ssspy {
 
@@ -256,7 +257,8 @@ static inline size_t loss_slots_bytes(int B, int N, int F) {
     }
   };
   const size_t a = generic(), b = tuned();
-  return align256(a > b ? a : b);
+  const size_t c = rt_sources_ok(N) ? rt_ilrma_loss_ws_bytes(B, N, F) : 0;
+  return align256(a > b ? (a > c ? a : c) : (b > c ? b : c));
 }
 static inline size_t u_part_bytes(int N) {
   return N <= 4 ? align256((size_t)1024 * 64 * N * N * N * 2 * sizeof(double)) : 0;
@@ -292,8 +294,8 @@ __global__ __launch_bounds__(256) void k_norm_scale(c128 *W, double *basis,
                                                     const double *__restrict__ qbuf, int N, int F,
                                                     int K, double p, int floor_kind, double eps,
                                                     double *psi_out) {
-  __shared__ double wsum[4][SSSPY_MAX_SOURCES];
-  __shared__ double psi[SSSPY_MAX_SOURCES];
+  __shared__ double wsum[4][SSSPY_RT_MAX_SOURCES];
+  __shared__ double psi[SSSPY_RT_MAX_SOURCES];
   const int b = blockIdx.y;
   const double *qb = qbuf + (long long)b * F * N;
   // thread t walks the flat (bin, n) array with a stride that keeps its source index fixed
@@ -831,6 +833,23 @@ int ssspy_ilrma_update_activation(const void *X, const void *W, const double *ba
 static int wcov_into(const void *X, const void *W, const double *basis, const double *activation,
                      void *U, int N, const IlrmaDims &d, void *upart, double *wbuf,
                      const void *Ysep, bool ysep_is_power, hipStream_t st) {
+  if (rt_sources_ok(N)) {
+    // more than 8 sources: varphi = 1 / R^(2/p) by the ISS weight kernel (run-time N), then the
+    // run-time covariance of wide_n.hip.  Gauss model, or any model with y at hand
+    const void *Y = Ysep ? Ysep : (W ? nullptr : X);
+    const bool ypow = Ysep && ysep_is_power;
+    if (!wbuf || !(d.model == SSSPY_SOURCE_GAUSS || Y))
+      return fail(SSSPY_ERR_UNSUPPORTED,
+                  "ILRMA above 8 sources: covariance weights need the Gauss model or the separated "
+                  "spectrogram");
+    const int chunks = iss_weight_chunks(d.B, N, d.F, d.T);
+    dim3 grid(((d.F + 63) / 64) * chunks, N, d.B), block(256);
+    hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, st, ypow ? nullptr : (const c128 *)Y,
+                       ypow ? (const double *)Y : nullptr, basis, activation, wbuf, N, d, chunks);
+    int rc = check_launch("k_ilrma_iss_weight");
+    if (rc) return rc;
+    return rt_covariance(X, X, wbuf, SSSPY_WEIGHT_BIN_FRAME, U, d.B, N, N, d.F, d.T, st);
+  }
   if (N > 4 && wbuf && wide_weighted_cov_ok(N, N, d.F, d.T, SSSPY_WEIGHT_BIN_FRAME)) {
     const void *Y = Ysep ? Ysep : (W ? nullptr : X);
     const bool ypow = Ysep && ysep_is_power;
@@ -879,7 +898,7 @@ static int launch_norm_scale(void *W, double *basis, const double *qbuf, int B, 
 int ssspy_ilrma_normalize_filter(void *W, const void *C, double *basis, int B, int N, int F, int K,
                                  double domain, int floor_kind, double floor_eps, void *workspace,
                                  size_t workspace_bytes, void *stream) {
-  SSSPY_REQUIRE(W && C && basis && B > 0 && N >= 1 && N <= SSSPY_MAX_SOURCES,
+  SSSPY_REQUIRE(W && C && basis && B > 0 && N >= 1 && N <= SSSPY_RT_MAX_SOURCES,
                 "normalize_filter: bad argument");
   hipStream_t st = as_stream(stream);
   SSSPY_REQUIRE(workspace && workspace_bytes >= qbuf_bytes(B, N, F),
@@ -957,12 +976,17 @@ int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
                           size_t workspace_bytes, void *stream) {
   SSSPY_REQUIRE(X && basis && activation && out && B > 0, "ilrma_loss_data: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "ilrma_loss_data: bad n_basis");
-  SSSPY_REQUIRE(N >= 2 && N <= SSSPY_MAX_SOURCES, "ilrma_loss_data: n_sources must be in [2, 8]");
+  SSSPY_REQUIRE(N >= 2 && N <= SSSPY_RT_MAX_SOURCES, "ilrma_loss_data: n_sources must be in [2, 16]");
   SSSPY_REQUIRE(workspace && workspace_bytes >= loss_slots_bytes(B, N, F),
                 "ilrma_loss_data: workspace too small (ssspy_ilrma_loss_workspace_bytes)");
   int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
   hipStream_t st = as_stream(stream);
+  if (rt_sources_ok(N)) {
+    if ((source_model & 0xff) != SSSPY_SOURCE_GAUSS)
+      return fail(SSSPY_ERR_UNSUPPORTED, "ILRMA above 8 sources: the loss is built for the Gauss model");
+    return rt_ilrma_loss(X, W, basis, activation, out, workspace, B, N, F, T, K, domain, st);
+  }
   if (K <= 16 && fast_path(N, F, T, K, domain, source_model)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_loss, X, W, basis, activation, out, workspace, B, F, T, K,
                         fast_model_id(domain, source_model), fast_model_param(domain, source_model, model_param), st);

@@ -2,6 +2,7 @@
 // contrast part of the loss.  The covariance / IP1 / ISS1 steps are the shared operators of
 // spatial_kernels.hip.
 #include "common.hpp"
+#include "wide_n.hpp"
 
 namespace ssspy {
 
@@ -184,6 +185,14 @@ int ssspy_iva_frame_power(const void *X, const void *W, double *r2, int B, int N
                 "iva_frame_power: workspace too small");
   double *dst = p.chunks > 1 ? (double *)workspace : r2;
   dim3 grid((T + p.frames_per_block - 1) / p.frames_per_block, p.chunks, B), block(256);
+  if (rt_sources_ok(N)) {  // a thread per frame, whatever the plan's block shape (same slab layout)
+    int rc = rt_frame_power(X, W, dst, B, N, F, T, p.bins_per_chunk, p.chunks, st);
+    if (rc || p.chunks == 1) return rc;
+    const long long total = (long long)B * N * T;
+    return launch_fold_slabs((const double *)workspace,
+                             (char *)workspace + (size_t)p.chunks * total * sizeof(double), r2,
+                             total, p.chunks, st);
+  }
   if (p.frames_per_block == 256) {
     DISPATCH_N(N, hipLaunchKernelGGL((k_iva_frame_power_wide<NN>), grid, block, 0, st,
                                      (const c128 *)X, (const c128 *)W, dst, F, T,

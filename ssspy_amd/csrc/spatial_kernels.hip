@@ -5,6 +5,7 @@
 #include "common.hpp"
 #include "cov_core.hpp"
 #include "smallmat.hpp"
+#include "wide_n.hpp"
 
 namespace ssspy {
 // ilrma_fast.hip (one translation unit per N)
@@ -624,6 +625,7 @@ int ip1_from_records(void *W, const void *records, int nchunks, int rbins, long 
 int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, int F, int N,
                    int floor_kind, double floor_eps, int *info, hipStream_t st) {
   const long long nbins = (long long)B * F;
+  if (rt_sources_ok(N)) return rt_ip1(W, U, C, qbuf, B, F, N, floor_kind, floor_eps, info, st);
   // a handful of mixtures: one lane per bin would leave the chip to 17 waves running a chain of
   // ~5000 dependent fp64 instructions each (17 us at 1025 bins); four lanes per bin take 12
   if (ip1_small_shape(B, F, N))
@@ -648,6 +650,7 @@ int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, i
 // P[b, n, i, j] = |(W_i x_ij)_n|^2
 int separate_power(const void *X, const void *W, double *P, int B, int N, int F, int T,
                    hipStream_t st) {
+  if (rt_sources_ok(N)) return rt_separate(X, W, P, B, N, F, T, true, st);
   dim3 grid(F, B), block(256);
   DISPATCH_N(N, hipLaunchKernelGGL((k_separate<NN, true>), grid, block, 0, st, (const c128 *)X,
                                    (const c128 *)W, (c128 *)P, F, T));
@@ -655,6 +658,7 @@ int separate_power(const void *X, const void *W, double *P, int B, int N, int F,
 }
 
 int row_power(const void *W, const void *C, double *qbuf, int B, int F, int N, hipStream_t st) {
+  if (rt_sources_ok(N)) return rt_row_power(W, C, qbuf, B, F, N, st);
   const long long nbins = (long long)B * F;
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
   DISPATCH_N(N, hipLaunchKernelGGL((k_row_power<NN>), grid, block, 0, st, (const c128 *)W,
@@ -671,6 +675,7 @@ const char *ssspy_last_error(void) { return g_last_error; }
 int ssspy_separate(const void *X, const void *W, void *Y, int B, int N, int F, int T,
                    void *stream) {
   SSSPY_REQUIRE(X && W && Y && B > 0 && F > 0 && T > 0, "separate: bad argument");
+  if (rt_sources_ok(N)) return rt_separate(X, W, Y, B, N, F, T, false, as_stream(stream));
   dim3 grid(F, B), block(256);
   DISPATCH_N(N, hipLaunchKernelGGL((k_separate<NN>), grid, block, 0, as_stream(stream),
                                    (const c128 *)X, (const c128 *)W, (c128 *)Y, F, T));
@@ -682,6 +687,8 @@ int ssspy_weighted_covariance(const void *A, const double *weight, int weight_ki
   SSSPY_REQUIRE(A && U && B > 0 && F > 0 && T > 0 && S > 0, "weighted_covariance: bad argument");
   SSSPY_REQUIRE(weight_kind == SSSPY_WEIGHT_UNIT || weight, "weighted_covariance: weight is NULL");
   SSSPY_REQUIRE(weight_kind != SSSPY_WEIGHT_UNIT || S == 1, "weighted_covariance: UNIT needs S=1");
+  if (rt_sources_ok(N))
+    return rt_covariance(A, A, weight, weight_kind, U, B, N, S, F, T, as_stream(stream));
   if (weight_kind == SSSPY_WEIGHT_FRAME && S == N && N >= 2 && N <= 4) {
     // AuxIVA's per-iteration pass: the tuned tile walk when the batch fills the chip
     int rc = -1;
@@ -700,6 +707,8 @@ int ssspy_weighted_covariance(const void *A, const double *weight, int weight_ki
 int ssspy_cross_covariance(const void *A, const void *Bm, void *C, int B, int N, int F, int T,
                            void *stream) {
   SSSPY_REQUIRE(A && Bm && C && B > 0 && F > 0 && T > 0, "cross_covariance: bad argument");
+  if (rt_sources_ok(N))
+    return rt_covariance(A, Bm, nullptr, SSSPY_WEIGHT_UNIT, C, B, N, 1, F, T, as_stream(stream));
   dim3 grid(F, B), block(256);
   DISPATCH_N(N, hipLaunchKernelGGL((k_cross_cov<NN, NN>), grid, block, 0, as_stream(stream),
                                    (const c128 *)A, (const c128 *)Bm, (c128 *)C, F, T));
@@ -709,6 +718,8 @@ int ssspy_cross_covariance(const void *A, const void *Bm, void *C, int B, int N,
 int ssspy_update_by_ip1(void *W, const void *U, int B, int F, int N, int floor_kind,
                         double floor_eps, int *info, void *stream) {
   SSSPY_REQUIRE(W && U && B > 0 && F > 0, "update_by_ip1: bad argument");
+  if (rt_sources_ok(N))
+    return rt_ip1(W, U, nullptr, nullptr, B, F, N, floor_kind, floor_eps, info, as_stream(stream));
   const long long nbins = (long long)B * F;
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
   DISPATCH_N(N, hipLaunchKernelGGL((k_ip1<NN>), grid, block, 0, as_stream(stream), (c128 *)W,
@@ -730,7 +741,7 @@ int ssspy_ip1_source_solve(void *W, const void *U, double *denom, int source_idx
 
 int ssspy_scale_filter_row(void *W, const double *denom, int source_idx, int B, int F, int N,
                            void *stream) {
-  SSSPY_REQUIRE(W && denom && B > 0 && F > 0 && N >= 1 && N <= SSSPY_MAX_SOURCES,
+  SSSPY_REQUIRE(W && denom && B > 0 && F > 0 && N >= 1 && N <= SSSPY_RT_MAX_SOURCES,
                 "scale_filter_row: bad argument");
   SSSPY_REQUIRE(source_idx >= 0 && source_idx < N, "scale_filter_row: bad source index");
   const long long nbins = (long long)B * F;
@@ -742,6 +753,8 @@ int ssspy_scale_filter_row(void *W, const double *denom, int source_idx, int B, 
 int ssspy_iss1_transform(const void *Vc, void *G, int B, int F, int N, int floor_kind,
                          double floor_eps, void *stream) {
   SSSPY_REQUIRE(Vc && G && B > 0 && F > 0, "iss1_transform: bad argument");
+  if (rt_sources_ok(N))
+    return rt_iss1_transform(Vc, G, B, F, N, floor_kind, floor_eps, as_stream(stream));
   const long long nbins = (long long)B * F;
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
   DISPATCH_N(N, hipLaunchKernelGGL((k_iss1_transform<NN>), grid, block, 0, as_stream(stream),
@@ -753,6 +766,7 @@ int ssspy_projection_back_filter(void *W, void *G, int B, int F, int N, int refe
                                  void *stream) {
   SSSPY_REQUIRE(W && B > 0 && F > 0 && reference_id >= 0 && reference_id < N,
                 "projection_back_filter: bad argument");
+  if (rt_sources_ok(N)) return rt_pb_filter(W, G, B, F, N, reference_id, info, as_stream(stream));
   const long long nbins = (long long)B * F;
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
   DISPATCH_N(N, hipLaunchKernelGGL((k_pb_filter<NN>), grid, block, 0, as_stream(stream),
@@ -784,6 +798,8 @@ int ssspy_projection_back_scale(const void *XY, const void *YY, void *G, int B, 
                                 int reference_id, int *info, void *stream) {
   SSSPY_REQUIRE(XY && YY && G && B > 0 && F > 0 && reference_id >= 0 && reference_id < N,
                 "projection_back_scale: bad argument");
+  if (rt_sources_ok(N))
+    return rt_pb_scale(XY, YY, G, B, F, N, reference_id, info, as_stream(stream));
   const long long nbins = (long long)B * F;
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
   DISPATCH_N(N, hipLaunchKernelGGL((k_pb_scale<NN>), grid, block, 0, as_stream(stream),
@@ -795,6 +811,7 @@ int ssspy_projection_back_scale(const void *XY, const void *YY, void *G, int B, 
 int ssspy_demix_from_covariance(const void *YX, const void *XX, void *W, int B, int F, int N,
                                 int *info, void *stream) {
   SSSPY_REQUIRE(YX && XX && W && B > 0 && F > 0, "demix_from_covariance: bad argument");
+  if (rt_sources_ok(N)) return rt_demix_from_cov(YX, XX, W, B, F, N, info, as_stream(stream));
   const long long nbins = (long long)B * F;
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
   DISPATCH_N(N, hipLaunchKernelGGL((k_demix_from_cov<NN>), grid, block, 0, as_stream(stream),
@@ -804,6 +821,7 @@ int ssspy_demix_from_covariance(const void *YX, const void *XX, void *W, int B, 
 
 int ssspy_sum_logdet(const void *W, double *out, int B, int F, int N, void *stream) {
   SSSPY_REQUIRE(W && out && B > 0 && F > 0, "sum_logdet: bad argument");
+  if (rt_sources_ok(N)) return rt_sum_logdet(W, out, B, F, N, as_stream(stream));
   dim3 grid(B), block(256);
   DISPATCH_N(N, hipLaunchKernelGGL((k_sum_logdet<NN>), grid, block, 0, as_stream(stream),
                                    (const c128 *)W, out, F));

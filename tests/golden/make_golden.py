@@ -682,6 +682,14 @@ def main():
     run_custom_floor("customfloor_auxlap_iss1_n2", kind="iva", seed=153, N=2, F=15, T=28,
                      spatial_algorithm="ISS")
     run_custom_floor("customfloor_fmnmf_m3", kind="fmnmf", seed=154, N=3, F=12, T=28, K=3)
+    # --- more than 8 sources (the reference takes n_sources from input.shape without a limit) ---
+    run_ilrma("gilrma_ip1_n10", N=10, F=12, T=80, K=3, algo="IP", seed=160, gen=gen_mixture, n_iter=6)
+    run_ilrma("gilrma_iss1_n9_p1", N=9, F=10, T=72, K=2, algo="ISS", seed=161, domain=1, n_iter=6)
+    run_iva("auxlap_iss1_n12", N=12, F=8, T=96, algo="ISS", contrast="laplace", seed=162,
+            gen=gen_mixture, n_iter=6)
+    run_iva("auxlap_ip1_n9", N=9, F=10, T=80, algo="IP", contrast="laplace", seed=163, n_iter=6)
+    run_iva("auxgauss_ip1_n16_mdp", N=16, F=6, T=128, algo="IP", contrast="gauss", seed=164,
+            gen=gen_mixture, n_iter=4, scale_restoration="minimal_distortion_principle")
     # --- operators ---
     run_operators()
     run_pairwise_operators()
