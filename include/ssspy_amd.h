@@ -137,6 +137,17 @@ int ssspy_update_by_ip2(void *W, const void *U, int pair_only, const int *pairs,
 int ssspy_iss2_transform(const void *Vc, void *G, const int *pairs, int n_pairs, int B, int F,
                          int N, int floor_kind, double floor_eps, int *info, void *stream);
 
+/* The pairwise updates for a flooring callable that cannot run in a kernel (the reference takes any
+ * callable: ssspy/bss/_update_spatial_model.py:81-143, :197-314).  ONE pair per call, rows left
+ * UNNORMALISED, denom (B, F, 2) f64 <- sqrt(max(h^H G h, 0)) of the pair's two members; the caller
+ * applies its callable to each (n_bins,) slice on the host and divides the rows with
+ * ssspy_scale_filter_row (IP2: rows pair[0], pair[1] of W; ISS2: the same rows of the transform G,
+ * which `accumulate` continues from its current value instead of the identity). */
+int ssspy_update_by_ip2_deferred(void *W, const void *U, int pair_only, const int *pair, int B,
+                                 int F, int N, double *denom, int *info, void *stream);
+int ssspy_iss2_transform_deferred(const void *Vc, void *G, const int *pair, int accumulate, int B,
+                                  int F, int N, double *denom, int *info, void *stream);
+
 /* Largest n_frames the fused ISS kernel holds in registers for N sources (0 if N unsupported). */
 int ssspy_iss1_fused_max_frames(int N);
 

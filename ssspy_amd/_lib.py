@@ -40,6 +40,8 @@ PROTOTYPES = {
     "ssspy_update_by_ip2": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
     "ssspy_ipa_transform": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p]),
     "ssspy_iss2_transform": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
+    "ssspy_update_by_ip2_deferred": (_i, [_p, _p, _i, _p, _i, _i, _i, _p, _p, _p]),
+    "ssspy_iss2_transform_deferred": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "ssspy_iss1_fused_max_frames": (_i, [_i]),
     "ssspy_iss1_fused_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "ssspy_iss1_fused": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p, _z, _p]),

@@ -179,6 +179,26 @@ def update_by_ip2(W, U, pairs, flooring, info=None, pair_only=False):
     """Pairwise iterative projection in place on W; U (B,F,N,N,N), or with pair_only the pair's own
     two covariances (B,F,2,N,N)."""
     B, F, N, _ = W.shape
+    host = getattr(flooring, "host", None)
+    if host is not None:
+        # an arbitrary flooring callable: pair by pair, the two denominators (B, F) floored on the
+        # host between the projection and the division (ref: _update_spatial_model.py:381-388)
+        import numpy as np
+
+        denom = dv.empty((B, F, 2), dv.f64, W.device)
+        for pair in pairs:
+            arr, _ = _pair_array([pair])
+            _lib.check(_L().ssspy_update_by_ip2_deferred(ptr(W), ptr(U), int(bool(pair_only)), arr,
+                                                         B, F, N, ptr(denom), ptr(info), _st()),
+                       "update_by_ip2 (deferred)")
+            d = dv.to_host(denom)
+            for k, row in enumerate(pair):
+                # (the callable sees (n_bins, 1), as in the reference)
+                dk = np.stack([np.asarray(host(d[b, :, k][:, None]), dtype=np.float64).reshape(F)
+                               for b in range(B)])
+                _lib.check(_L().ssspy_scale_filter_row(ptr(W), ptr(dv.to_device(dk, dev=W.device)),
+                                                       int(row), B, F, N, _st()), "scale_filter_row")
+        return W
     arr, n_pairs = _pair_array(pairs)
     _lib.check(
         _L().ssspy_update_by_ip2(ptr(W), ptr(U), int(bool(pair_only)), arr, n_pairs, B, F, N,
@@ -192,6 +212,26 @@ def iss2_transform(Vc, pairs, flooring, info=None, out=None):
     B, F, N = Vc.shape[0], Vc.shape[1], Vc.shape[-1]
     if out is None:
         out = dv.empty((B, F, N, N), dv.c128, Vc.device)
+    host = getattr(flooring, "host", None)
+    if host is not None:
+        # an arbitrary flooring callable: pair by pair on the accumulated transform, the two
+        # denominators floored on the host (ref: _update_spatial_model.py:300-312)
+        import numpy as np
+
+        denom = dv.empty((B, F, 2), dv.f64, Vc.device)
+        for p, pair in enumerate(pairs):
+            arr, _ = _pair_array([pair])
+            _lib.check(_L().ssspy_iss2_transform_deferred(ptr(Vc), ptr(out), arr, int(p > 0), B, F,
+                                                          N, ptr(denom), ptr(info), _st()),
+                       "iss2_transform (deferred)")
+            d = dv.to_host(denom)
+            # (the callable sees both members at once, (2, n_bins), as in the reference)
+            fl = np.stack([np.asarray(host(d[b].T), dtype=np.float64).reshape(2, F) for b in range(B)])
+            for k, row in enumerate(pair):
+                dk = np.ascontiguousarray(fl[:, k, :])
+                _lib.check(_L().ssspy_scale_filter_row(ptr(out), ptr(dv.to_device(dk, dev=Vc.device)),
+                                                       int(row), B, F, N, _st()), "scale_filter_row")
+        return out
     arr, n_pairs = _pair_array(pairs)
     _lib.check(
         _L().ssspy_iss2_transform(ptr(Vc), ptr(out), arr, n_pairs, B, F, N, flooring[0],

@@ -461,7 +461,10 @@ class _MMILRMA(ILRMABase):
         self.update_activation_mm(flooring_fn=flooring_fn)
 
     def _partition_update(self, steps, flooring_fn="self") -> None:
-        require_device_floor(self._resolve_floor(flooring_fn), "The partitioning function")
+        # (with a flooring callable the kernels cannot run the step runs unfloored -- the resolved
+        # floor is then (NONE, 0) -- and the callers floor the small array on the host afterwards)
+        if self._base_model[0] != _lib.SOURCE_GAUSS:
+            require_device_floor(self._resolve_floor(flooring_fn), "Partitioning with a heavy-tailed model")
         src, W = self._source_and_filter()
         _ops.ilrma_partition_update(src, W, self._state_dev("basis"), self._state_dev("activation"),
                                     self._state_dev("latent"), self._Teff, self._Vrep,
@@ -492,6 +495,7 @@ class _MMILRMA(ILRMABase):
         if self.partitioning:
             self._partition_update(_lib.PARTITION_BASIS, flooring_fn)
             self._state_touch("basis")
+            self._host_floor_state("basis", self._resolve_floor(flooring_fn))
             return
         src, W = self._source_and_filter()
         floor = self._resolve_floor(flooring_fn)
@@ -506,6 +510,7 @@ class _MMILRMA(ILRMABase):
         if self.partitioning:
             self._partition_update(_lib.PARTITION_ACTIVATION, flooring_fn)
             self._state_touch("activation")
+            self._host_floor_state("activation", self._resolve_floor(flooring_fn))
             return
         src, W = self._source_and_filter()
         floor = self._resolve_floor(flooring_fn)
@@ -546,7 +551,8 @@ class _MMILRMA(ILRMABase):
 
     def update_spatial_model_ip2(self, flooring_fn="self") -> None:
         """Weighted covariance + pairwise iterative projection.  ref: ssspy/bss/ilrma.py:1509-1633."""
-        require_device_floor(self._resolve_floor(flooring_fn), "IP2")
+        if self._base_model[0] != _lib.SOURCE_GAUSS:  # (t / GGD weights floor per element)
+            require_device_floor(self._resolve_floor(flooring_fn), "IP2 with a heavy-tailed model")
         B, N, F, T = self._X.shape
         if self._U is None:
             self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
@@ -561,7 +567,8 @@ class _MMILRMA(ILRMABase):
 
     def update_spatial_model_iss2(self, flooring_fn="self") -> None:
         """Pairwise iterative source steering on per-bin statistics.  ref: ilrma.py:1698-1792."""
-        require_device_floor(self._resolve_floor(flooring_fn), "ISS2")
+        if self._base_model[0] != _lib.SOURCE_GAUSS:  # (t / GGD weights floor per element)
+            require_device_floor(self._resolve_floor(flooring_fn), "ISS2 with a heavy-tailed model")
         Y = self._state_dev("output")
         N = Y.shape[1]
         varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y, model=self._model,
@@ -689,7 +696,6 @@ class _MMILRMA(ILRMABase):
         """psi = flooring_fn(sqrt(mean |y|^2)) with an arbitrary callable: the frame powers come from
         one device pass, the N scales are floored on the host, W (or Y) and the basis are rescaled.
         ref: ssspy/bss/ilrma.py:412-444."""
-        require_device_floor(floor, "The partitioning function") if self.partitioning else None
         B, N, F, T = self._X.shape
         p = float(self.domain)
         filt = self._uses_filter()
@@ -699,7 +705,13 @@ class _MMILRMA(ILRMABase):
                         for r in r2])  # (B, N)
         lead = (slice(None),) if self._batched else (0,)
         psi_v = psi[lead]
-        self.basis = np.asarray(self.basis) / (psi_v[..., :, None, None] ** p)
+        if self.partitioning:  # ref: ssspy/bss/ilrma.py:422-430 (small arrays: (N, K), (F, K))
+            Z_psi = np.asarray(self.latent) / (psi_v[..., :, None] ** p)
+            scale = np.sum(Z_psi, axis=-2)
+            self.basis = np.asarray(self.basis) * scale[..., None, :]
+            self.latent = Z_psi / scale[..., None, :]
+        else:
+            self.basis = np.asarray(self.basis) / (psi_v[..., :, None, None] ** p)
         if filt:
             self.demix_filter = np.asarray(self.demix_filter) / psi_v[..., None, :, None]
         else:

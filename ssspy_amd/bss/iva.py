@@ -350,7 +350,7 @@ class AuxIVA(AuxIVABase):
             # a user closure, or a flooring callable the kernels cannot run: on the host, on the
             # (n_sources, n_frames) norms
             if self._variance_tensor() is not None:
-                require_device_floor(floor, "AuxGaussIVA")
+                return self._host_weights_gauss(r2, contrast, flooring_fn)
             return self._host_weights(r2, flooring_fn)
         return _ops.iva_weight(r2, self.n_bins, contrast, self._resolve_floor(flooring_fn),
                                variance=self._variance_tensor())
@@ -367,6 +367,27 @@ class AuxIVA(AuxIVABase):
                            for rb in r])
         if weight.shape != r.shape:
             raise ValueError("d_contrast_fn must map (n_sources, n_frames) to the same shape.")
+        return dv.to_device(weight, dtype=np.float64, dev=r2.device)
+
+    def _host_weights_gauss(self, r2, contrast, flooring_fn):
+        """AuxGaussIVA with a flooring callable the kernels cannot run: the variance refresh
+        alpha = r^2 / n_bins (ssspy/bss/iva.py:3465-3473) unless the pair loop of IP2 keeps it fixed,
+        then varphi = (2 r / alpha) / flooring_fn(2 r) on the (n_sources, n_frames) norms
+        (:3273-3288, :1787-1789) -- host arithmetic on B N T numbers, as for user closures."""
+        flooring_fn = choose_flooring_fn(self.flooring_fn if (type(flooring_fn) is str and
+                                                              flooring_fn == "self") else flooring_fn,
+                                         method=self)
+        self._check_device_errors()
+        r2h = dv.to_host(r2)  # (B, N, T)
+        var_dev = self._variance_tensor()
+        if contrast == _lib.CONTRAST_GAUSS_FIXED:
+            var = dv.to_host(var_dev)
+        else:
+            var = r2h / float(self.n_bins)
+            var_dev.copy_(dv.to_device(var, dtype=np.float64, dev=r2.device))
+        r = np.sqrt(r2h)
+        weight = np.stack([np.asarray((2 * rb / vb) / flooring_fn(2 * rb), dtype=np.float64)
+                           for rb, vb in zip(r, var)])
         return dv.to_device(weight, dtype=np.float64, dev=r2.device)
 
     def _frame_power(self):
@@ -413,7 +434,6 @@ class AuxIVA(AuxIVABase):
         the current filters.  ref: ssspy/bss/iva.py:1795-1915."""
         N = self.n_sources
         floor = self._resolve_floor(flooring_fn)
-        require_device_floor(floor, "IP2")
         W = self._state_dev("demix_filter")
         for m, n in resolve_pairs(getattr(self, "pair_selector", None), N):
             r2 = _ops.iva_frame_power(self._X, W)
@@ -428,7 +448,6 @@ class AuxIVA(AuxIVABase):
         N = self.n_sources
         Y = self._state_dev("output")
         floor = self._resolve_floor(flooring_fn)
-        require_device_floor(floor, "ISS2")
         weight = self._weights(flooring_fn)
         Vc = _ops.weighted_covariance(Y, weight, _lib.WEIGHT_FRAME, N)
         G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N), floor,
@@ -622,8 +641,12 @@ class AuxGaussIVA(AuxIVA):
 
     def update_source_model(self) -> None:
         """alpha_nj = mean_i |y_nij|^2 (ref: ssspy/bss/iva.py:3465-3473)."""
-        _ops.iva_weight(self._frame_power(), self.n_bins, _lib.CONTRAST_GAUSS, self._floor,
-                        variance=self._variance_tensor())
+        if host_floor(self._floor) is not None:  # (no floor acts on the variance itself)
+            var = dv.to_host(self._frame_power()) / float(self.n_bins)
+            self._variance_tensor().copy_(dv.to_device(var, dtype=np.float64))
+        else:
+            _ops.iva_weight(self._frame_power(), self.n_bins, _lib.CONTRAST_GAUSS, self._floor,
+                            variance=self._variance_tensor())
         self._state_touch("variance")
 
     def _pair_weight_contrast(self):

@@ -77,7 +77,7 @@ __device__ __forceinline__ bool ip2_half(const Mat<N> &Wm, const Mat<N> &Um, int
 template <int N>
 __global__ __launch_bounds__(64) void k_ip2(c128 *W, const c128 *__restrict__ U, long long nbins,
                                             int pair_only, PairList pairs, int floor_kind,
-                                            double eps, int *info) {
+                                            double eps, int *info, double *denom) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nbins) return;
   Mat<N> Wm;
@@ -101,8 +101,14 @@ __global__ __launch_bounds__(64) void k_ip2(c128 *W, const c128 *__restrict__ U,
     double qm = quad2(hm, Gm), qn = quad2(hn, Gn);
     qm = qm < 0.0 ? 0.0 : qm;
     qn = qn < 0.0 ? 0.0 : qn;
-    const double dm = apply_floor(sqrt(qm), floor_kind, eps);
-    const double dn = apply_floor(sqrt(qn), floor_kind, eps);
+    // denom (one pair per launch): the flooring callable runs on the host -- leave the rows
+    // unnormalised, hand out sqrt(max(q, 0)) of both members, ssspy_scale_filter_row divides later
+    const double dm = denom ? 1.0 : apply_floor(sqrt(qm), floor_kind, eps);
+    const double dn = denom ? 1.0 : apply_floor(sqrt(qn), floor_kind, eps);
+    if (denom) {
+      denom[idx * 2 + 0] = sqrt(qm);
+      denom[idx * 2 + 1] = sqrt(qn);
+    }
     c128 wm[N], wn[N];
 #pragma unroll
     for (int r = 0; r < N; ++r) {
@@ -127,11 +133,13 @@ __global__ __launch_bounds__(64) void k_ip2(c128 *W, const c128 *__restrict__ U,
 template <int N>
 __global__ __launch_bounds__(64) void k_iss2_transform(const c128 *__restrict__ Vc, c128 *G,
                                                        long long nbins, PairList pairs,
-                                                       int floor_kind, double eps, int *info) {
+                                                       int floor_kind, double eps, int *info,
+                                                       double *denom, int accumulate) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nbins) return;
   Mat<N> Gm;
-  set_identity<N>(Gm);
+  if (accumulate) load_mat<N>(Gm, G + idx * (N * N));  // continue from the transform so far
+  else set_identity<N>(Gm);
   const c128 *V0 = Vc + idx * (long long)(N * N * N);
   bool ok = true;
 #pragma unroll 1
@@ -208,7 +216,9 @@ __global__ __launch_bounds__(64) void k_iss2_transform(const c128 *__restrict__ 
       const c128 h[2] = {z[0][k], z[1][k]};
       double q = (k == 0) ? quad2(h, Gmain[0]) : quad2(h, Gmain[1]);
       q = q < 0.0 ? 0.0 : q;
-      const double dk = apply_floor(sqrt(q), floor_kind, eps);
+      // (denom: host-side flooring callable, see k_ip2)
+      const double dk = denom ? 1.0 : apply_floor(sqrt(q), floor_kind, eps);
+      if (denom) denom[idx * 2 + k] = sqrt(q);
       c128 row[N];
 #pragma unroll
       for (int c = 0; c < N; ++c) {
@@ -255,8 +265,23 @@ int ssspy_update_by_ip2(void *W, const void *U, int pair_only, const int *pairs,
   const long long nbins = (long long)B * F;
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
   DISPATCH_N(N, hipLaunchKernelGGL((k_ip2<NN>), grid, block, 0, as_stream(stream), (c128 *)W,
-                                   (const c128 *)U, nbins, pair_only, pl, floor_kind, floor_eps, info));
+                                   (const c128 *)U, nbins, pair_only, pl, floor_kind, floor_eps, info,
+                                   (double *)nullptr));
   return check_launch("k_ip2");
+}
+
+int ssspy_update_by_ip2_deferred(void *W, const void *U, int pair_only, const int *pair, int B,
+                                 int F, int N, double *denom, int *info, void *stream) {
+  SSSPY_REQUIRE(W && U && pair && denom && B > 0 && F > 0, "update_by_ip2_deferred: bad argument");
+  PairList pl;
+  int rc = fill_pairs(pl, pair, 1, N);
+  if (rc) return rc;
+  const long long nbins = (long long)B * F;
+  dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
+  DISPATCH_N(N, hipLaunchKernelGGL((k_ip2<NN>), grid, block, 0, as_stream(stream), (c128 *)W,
+                                   (const c128 *)U, nbins, pair_only, pl, SSSPY_FLOOR_NONE, 0.0, info,
+                                   denom));
+  return check_launch("k_ip2 (deferred)");
 }
 
 int ssspy_iss2_transform(const void *Vc, void *G, const int *pairs, int n_pairs, int B, int F,
@@ -269,8 +294,22 @@ int ssspy_iss2_transform(const void *Vc, void *G, const int *pairs, int n_pairs,
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
   DISPATCH_N(N, hipLaunchKernelGGL((k_iss2_transform<NN>), grid, block, 0, as_stream(stream),
                                    (const c128 *)Vc, (c128 *)G, nbins, pl, floor_kind, floor_eps,
-                                   info));
+                                   info, (double *)nullptr, 0));
   return check_launch("k_iss2_transform");
+}
+
+int ssspy_iss2_transform_deferred(const void *Vc, void *G, const int *pair, int accumulate, int B,
+                                  int F, int N, double *denom, int *info, void *stream) {
+  SSSPY_REQUIRE(Vc && G && pair && denom && B > 0 && F > 0, "iss2_transform_deferred: bad argument");
+  PairList pl;
+  int rc = fill_pairs(pl, pair, 1, N);
+  if (rc) return rc;
+  const long long nbins = (long long)B * F;
+  dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
+  DISPATCH_N(N, hipLaunchKernelGGL((k_iss2_transform<NN>), grid, block, 0, as_stream(stream),
+                                   (const c128 *)Vc, (c128 *)G, nbins, pl, SSSPY_FLOOR_NONE, 0.0,
+                                   info, denom, accumulate ? 1 : 0));
+  return check_launch("k_iss2_transform (deferred)");
 }
 
 }  // extern "C"

@@ -327,6 +327,9 @@ def run_custom_floor(name, *, kind, seed, N, F, T, K=4, n_iter=6, gen=gen_mixtur
     elif kind == "iva":
         snap = InitialAndFinal(["demix_filter", "output"], n_iter)
         m = AuxLaplaceIVA(flooring_fn=custom_floor, callbacks=snap, **kwargs)
+    elif kind == "gaussiva":
+        snap = InitialAndFinal(["demix_filter", "output", "variance"], n_iter)
+        m = AuxGaussIVA(flooring_fn=custom_floor, callbacks=snap, **kwargs)
     else:
         snap = InitialAndFinal(["basis", "activation", "diagonalizer", "spatial"], n_iter)
         m = FastGaussMNMF(n_basis=K, flooring_fn=custom_floor, callbacks=snap, rng=rng, **kwargs)
@@ -682,6 +685,25 @@ def main():
     run_custom_floor("customfloor_auxlap_iss1_n2", kind="iva", seed=153, N=2, F=15, T=28,
                      spatial_algorithm="ISS")
     run_custom_floor("customfloor_fmnmf_m3", kind="fmnmf", seed=154, N=3, F=12, T=28, K=3)
+    # ... on the pairwise updates (two denominators per pair), under partitioning, AuxGaussIVA
+    run_custom_floor("customfloor_gilrma_ip2_n3", kind="ilrma", seed=155, N=3, F=14, T=30,
+                     spatial_algorithm="IP2")
+    run_custom_floor("customfloor_gilrma_iss2_n4", kind="ilrma", seed=156, N=4, F=12, T=32,
+                     spatial_algorithm="ISS2")
+    run_custom_floor("customfloor_gilrma_part_ip1_n3", kind="ilrma", seed=157, N=3, F=14, T=30, K=5,
+                     spatial_algorithm="IP", partitioning=True)
+    run_custom_floor("customfloor_gilrma_part_iss1_n2", kind="ilrma", seed=158, N=2, F=15, T=28, K=4,
+                     spatial_algorithm="ISS", partitioning=True)
+    run_custom_floor("customfloor_auxlap_ip2_n3", kind="iva", seed=159, N=3, F=14, T=30,
+                     spatial_algorithm="IP2")
+    run_custom_floor("customfloor_auxlap_iss2_n3", kind="iva", seed=165, N=3, F=14, T=30,
+                     spatial_algorithm="ISS2")
+    run_custom_floor("customfloor_auxgauss_ip1_n3", kind="gaussiva", seed=166, N=3, F=14, T=30,
+                     spatial_algorithm="IP")
+    run_custom_floor("customfloor_auxgauss_iss1_n2", kind="gaussiva", seed=167, N=2, F=15, T=28,
+                     spatial_algorithm="ISS")
+    run_custom_floor("customfloor_auxgauss_ip2_n3", kind="gaussiva", seed=168, N=3, F=14, T=30,
+                     spatial_algorithm="IP2")
     # --- more than 8 sources (the reference takes n_sources from input.shape without a limit) ---
     run_ilrma("gilrma_ip1_n10", N=10, F=12, T=80, K=3, algo="IP", seed=160, gen=gen_mixture, n_iter=6)
     run_ilrma("gilrma_iss1_n9_p1", N=9, F=10, T=72, K=2, algo="ISS", seed=161, domain=1, n_iter=6)
