@@ -99,6 +99,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=6.0)
     ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--no-others", action="store_true", help="skip the configs[2] / configs[3] legs")
     args = ap.parse_args()
     import bench
     from ssspy_amd import _device as dv
@@ -153,6 +154,54 @@ def main():
         rec["hbm_TBs"] = round(passes * 16.0 * N * F * T * B / (ms * 1e-3) / 1e12, 3)
         out[name] = rec
     sep._check_device_errors()
+    del sep, X, Xr
+    torch.cuda.empty_cache()
+    if not args.no_others:
+        from ssspy_amd.bss.iva import AuxLaplaceIVA, _device_contrast
+        from ssspy_amd.bss.mnmf import FastGaussMNMF
+
+        def leg(name, m, bytes_per_step):
+            for _ in range(3):
+                m.update_once()
+            torch.cuda.synchronize()
+            n = 0
+            with sampler:
+                t0 = time.perf_counter()
+                while time.perf_counter() - t0 < args.seconds:
+                    for _ in range(10):
+                        m.update_once()
+                    n += 10
+                    torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            rec = sampler.summary(0.5, card)
+            rec["ms_per_step"] = round(1e3 * dt / n, 4)
+            rec["hbm_TBs"] = round(bytes_per_step / (dt / n) / 1e12, 3)
+            out[name] = rec
+            m._check_device_errors()
+
+        N2, F2, T2, B2 = 8, 2049, 1024, 32
+        X2 = torch.from_numpy(nmf_mixture_batch(3000, B2, N2, F2, T2)).to("cuda:0")
+        m = AuxLaplaceIVA(spatial_algorithm="ISS", record_loss=False)
+        m._contrast = _device_contrast(m.contrast_fn, m.d_contrast_fn)
+        m._bind_input(X2)
+        m._reset()
+        leg("configs2_iss_b32", m, 2 * 16.0 * N2 * F2 * T2 * B2)
+        del m, X2
+        torch.cuda.empty_cache()
+        B3 = 128
+        X3 = torch.from_numpy(nmf_mixture_batch(4000, B3, 4, 1025, 512)).to("cuda:0")
+        m = FastGaussMNMF(n_basis=8, record_loss=False, rng=np.random.default_rng(0))
+        m._bind_input(X3)
+        m._reset()
+        leg("configs3_fmnmf_b128", m, 4 * 16.0 * 4 * 1025 * 512 * B3)
+        m = AuxLaplaceIVA(spatial_algorithm="IP", record_loss=False)
+        m._contrast = _device_contrast(m.contrast_fn, m.d_contrast_fn)
+        m._bind_input(X3)
+        m._reset()
+        m._C()
+        leg("auxiva_ip_b128", m, 2 * 16.0 * 4 * 1025 * 512 * B3)
+        del m, X3
+        torch.cuda.empty_cache()
     time.sleep(5.0)  # the hwmon power value is a moving average: let the load drain out of it
     with sampler:
         time.sleep(1.0)

@@ -165,8 +165,34 @@ __device__ __forceinline__ void iss_sweeps(c128 (&y)[N][FPT], const double (&phi
       ld->mant *= __builtin_amdgcn_frexp_mant(f);
       ld->expo += __builtin_amdgcn_frexp_exp(f);
     }
+#ifdef SSSPY_ISS_IEEE_DIV
     const double vx = lane == n ? 1.0 - 1.0 / sqrt(den) : t0 * invT / den;
     const double vy = lane == n ? 0.0 : t1 * invT / den;
+#else
+    // The coefficient lane is the serial section of a sweep (every thread waits for it at the
+    // readlanes below): v_rcp_f64 / v_rsq_f64 + two Newton steps (~1 ulp, benchmarks/micro/
+    // rcp_precision.hip) instead of two IEEE divides and a square root (~90 dependent instructions).
+    double rd = __builtin_amdgcn_rcp(den);
+    double e1 = fma(-den, rd, 1.0);
+    rd = fma(rd, e1, rd);
+    e1 = fma(-den, rd, 1.0);
+    rd = fma(rd, e1, rd);
+    double rs = __builtin_amdgcn_rsq(den);
+    double h = 0.5 * den * rs;
+    double e2 = fma(-h, rs, 0.5);
+    rs = fma(rs, e2, rs);
+    h = 0.5 * den * rs;
+    e2 = fma(-h, rs, 0.5);
+    rs = fma(rs, e2, rs);
+    // (den = 0, Inf or NaN: keep what the divide and the square root return)
+    const bool special = !(den > 0.0) || !(den < 1.7976931348623157e308);
+    if (special) {
+      rd = 1.0 / den;
+      rs = 1.0 / sqrt(den);
+    }
+    const double vx = lane == n ? 1.0 - rs : t0 * invT * rd;
+    const double vy = lane == n ? 0.0 : t1 * invT * rd;
+#endif
     c128 v[N];
 #pragma unroll
     for (int s = 0; s < N; ++s) v[s] = cmake(readlane_f64(vx, s), readlane_f64(vy, s));
