@@ -55,8 +55,9 @@ def _st():
 
 
 # ---- transient scratch of single operators (partial sums folded inside the same C-ABI call): one
-# growing buffer per device; every call runs on the caller's stream, in order, so it is never needed
-# by two operators at once
+# growing buffer per (device, stream): calls on one stream run in order, so the buffer is never
+# needed by two operators at once; separators driven on different streams of one device (threads,
+# parallel.separate_pipelined callers) get their own (round-3 advisor finding)
 _scratch_bufs = {}
 
 
@@ -64,7 +65,7 @@ def _scratch(nbytes, dev):
     nbytes = int(nbytes)
     if nbytes == 0:
         return None, 0
-    key = str(dev)
+    key = (str(dev), _st())
     ent = _scratch_bufs.get(key)
     if ent is None or ent[1] < nbytes:
         ent = _workspace(nbytes, dev)

@@ -31,8 +31,16 @@ class HostSnapshot(np.ndarray):
         return np.asarray(array).view(np.ndarray)
 
 
-def _out_of_place(ufunc):
+def _snapshot_inplace(name, ufunc):
+    """Augmented assignment: out of place on the read-only snapshot itself (the result goes to the
+    attribute's setter, which uploads it), but TRUE in-place ndarray semantics on anything derived
+    from it that the user owns -- ``c = m.basis.copy(); d = c; c += 1`` must change ``d`` too
+    (round-3 advisor finding: copies, slices and pickles of a snapshot keep the subclass)."""
+    base = getattr(np.ndarray, name)
+
     def op(self, other):
+        if self.flags.writeable:
+            return base(self, other)
         return ufunc(np.asarray(self).view(np.ndarray), other)
     return op
 
@@ -40,7 +48,7 @@ def _out_of_place(ufunc):
 for _name, _ufunc in (("__iadd__", np.add), ("__isub__", np.subtract), ("__imul__", np.multiply),
                       ("__itruediv__", np.true_divide), ("__ipow__", np.power),
                       ("__ifloordiv__", np.floor_divide), ("__imatmul__", np.matmul)):
-    setattr(HostSnapshot, _name, _out_of_place(_ufunc))
+    setattr(HostSnapshot, _name, _snapshot_inplace(_name, _ufunc))
 
 
 def _snapshot(host):

@@ -329,14 +329,22 @@ __global__ __launch_bounds__(256) void k_gmnmf_activation_sums(const double *__r
                                                                const double *__restrict__ A,
                                                                const double *__restrict__ Bt,
                                                                double *__restrict__ acc, int N,
-                                                               int F, int T, int K, int k0) {
+                                                               int F, int T, int K, int k0,
+                                                               int bins_per_chunk,
+                                                               long long slab_stride) {
+  // grid.y = bin chunks (round 4: a handful of mixtures left the chip to (T / 64) N B blocks walking
+  // all bins); chunk c stores its sums to slab c (acc + c * slab_stride), k_fold_slabs adds the
+  // slabs in chunk order -- one chunk stores straight to the sums
   __shared__ double fold[4][16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + lane;
   const int n = blockIdx.z % N, b = blockIdx.z / N;
-  const int per_wave = (F + 3) >> 2;
-  const int i_begin = wave * per_wave;
-  const int i_end = min(F, i_begin + per_wave);
+  const int c_begin = blockIdx.y * bins_per_chunk;
+  const int c_end = min(F, c_begin + bins_per_chunk);
+  const int per_wave = (c_end - c_begin + 3) >> 2;
+  const int i_begin = c_begin + wave * per_wave;
+  const int i_end = min(c_end, i_begin + per_wave);
+  acc += (long long)blockIdx.y * slab_stride;
   const int jc = min(j, T - 1);
   double sn[8], sd[8];
 #pragma unroll
@@ -629,8 +637,16 @@ __global__ __launch_bounds__(128) void k_gmnmf_separate(const c128 *__restrict__
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct GmnmfWs {
-  size_t a, bt, pq, vacc, teff, vrep, raw, total;
+  size_t a, bt, pq, vacc, teff, vrep, raw, vslabs, total;
 };
+// bin chunks of the activation sums: enough blocks for the chip at small batches, at most 16
+static inline int gm_act_chunks(int B, int N, int F, int T) {
+  const long long blocks0 = (long long)((T + 63) / 64) * N * B;
+  long long want = (1024 + blocks0 - 1) / blocks0;
+  if (want > 16) want = 16;
+  if (want > (F + 7) / 8) want = (F + 7) / 8;  // at least 8 bins per chunk
+  return want < 1 ? 1 : (int)want;
+}
 static inline GmnmfWs gmnmf_ws(int B, int N, int M, int F, int T, int K) {
   GmnmfWs w;
   size_t off = 0;
@@ -648,6 +664,14 @@ static inline GmnmfWs gmnmf_ws(int B, int N, int M, int F, int T, int K) {
   off += align256((size_t)B * N * K * T * sizeof(double));
   w.raw = off;
   off += align256((size_t)B * N * F * K * 2 * sizeof(double));
+  w.vslabs = off;  // per-chunk slabs of the activation sums + the scratch of their fold
+  {
+    const int chunks = gm_act_chunks(B, N, F, T);
+    const long long vtotal = 2ll * B * N * K * T;
+    off += chunks > 1 ? align256((size_t)chunks * vtotal * sizeof(double) +
+                                 fold_scratch_bytes(vtotal, chunks))
+                      : 0;
+  }
   w.total = off;
   return w;
 }
@@ -753,10 +777,20 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
     rc = launch_traces(X, Tn, Vn, spatial, A, Bt, B, N, M, F, T, K, floor_kind, floor_eps, st);
     if (rc) return rc;
     const long long count = (long long)B * N * K * T;
+    const int chunks = gm_act_chunks(B, N, F, T);
+    const int bpc = (F + chunks - 1) / chunks;
+    const long long vtotal = 2 * count;  // (num, den) sums
+    double *slabs = chunks > 1 ? (double *)(ws + w.vslabs) : vacc;
     for (int k0 = 0; k0 < K; k0 += 8) {
-      hipLaunchKernelGGL(k_gmnmf_activation_sums, dim3((T + 63) / 64, 1, N * B), dim3(256), 0,
-                         st, Tn, (const double *)A, (const double *)Bt, vacc, N, F, T, K, k0);
+      hipLaunchKernelGGL(k_gmnmf_activation_sums, dim3((T + 63) / 64, chunks, N * B), dim3(256), 0,
+                         st, Tn, (const double *)A, (const double *)Bt, slabs, N, F, T, K, k0, bpc,
+                         vtotal);
       rc = check_launch("k_gmnmf_activation_sums");
+      if (rc) return rc;
+    }
+    if (chunks > 1) {
+      rc = launch_fold_slabs(slabs, (char *)slabs + (size_t)chunks * vtotal * sizeof(double), vacc,
+                             vtotal, chunks, st);
       if (rc) return rc;
     }
     if (part) {

@@ -2092,3 +2092,88 @@ def test_arbitrary_flooring_callable_unsupported_paths_fail_loudly():
                flooring_fn=_golden_custom_floor)(X, n_iter=1)
     with pytest.raises(NotImplementedError, match="FastMNMF"):
         FastGaussMNMF(n_basis=2, flooring_fn=_golden_custom_floor)(X, n_iter=1)
+
+
+# ------------------------------------------------------------------------------- non-finite inputs
+def _same_nonfinite(out, ref, tol=1e-9):
+    """The reference propagates NaN / Inf silently (e.g. num / denom with a zero denominator,
+    ssspy/bss/ilrma.py:1125): the same elements must be non-finite, the finite ones equal."""
+    fo, fr = np.isfinite(out), np.isfinite(ref)
+    assert np.array_equal(fo, fr), "non-finite pattern differs: {} vs {} elements".format(
+        int((~fo).sum()), int((~fr).sum()))
+    assert (~fr).any() and fr.any()
+    assert rel_err(out[fr], ref[fr]) < tol
+
+
+@pytest.mark.parametrize("N,T", [(2, 70), (4, 300), (8, 1000), (8, 257)])
+def test_fused_iss_propagates_non_finite_samples_like_the_reference(N, T):
+    """NaN / Inf samples in a few bins, frame counts that leave padding lanes in the register slab
+    (T not a multiple of 256; round 2's advisor found a 0 * Inf there): exactly the bins the
+    reference turns non-finite are non-finite, every other bin is untouched."""
+    from oracle import spatial as sp
+    from ssspy_amd.bss._update_spatial_model import update_by_iss1
+
+    rng = np.random.default_rng(N * 1000 + T)
+    F = 9
+    Y = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+    varphi = 1 / (rng.random((N, 1, T)) + 0.1)
+    Y[0, 1, T - 1] = np.inf          # the last valid frame: next to the padding
+    Y[N - 1, 4, 0] = np.nan
+    Y[1 % N, 7, T // 2] = -np.inf + 1j
+    with np.errstate(all="ignore"):
+        ref = sp.update_by_iss1(Y, varphi)
+    out = update_by_iss1(Y, varphi)
+    _same_nonfinite(out, ref)
+    bad_bins = sorted(set(np.where(~np.isfinite(ref))[1].tolist()))
+    assert bad_bins == [1, 4, 7]
+
+
+@pytest.mark.parametrize("N", [6, 8])
+def test_wide_covariance_propagates_non_finite_samples_like_the_reference(N):
+    """The matrix-core covariance of 6..8 channels (wide_cov.hip): frames beyond T are clamped loads
+    with weight 0; a non-finite sample must poison its own bin only."""
+    from ssspy_amd import _device as dv
+    from ssspy_amd import _lib, _ops
+
+    rng = np.random.default_rng(N)
+    F, T = 10, 77  # 77 = 9 slabs of 8 frames + 5: padding lanes in the last slab
+    X = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+    w = 1 / (rng.random((N, F, T)) + 0.1)
+    X[2, 3, T - 1] = np.inf
+    X[0, 8, 5] = np.nan
+    with np.errstate(all="ignore"):
+        XX = X[:, None] * X[None].conj()                       # (a, c, F, T)
+        ref = np.mean(w[:, None, None] * XX[None], axis=-1).transpose(3, 0, 1, 2)  # (F, s, a, c)
+    U = dv.to_host(_ops.weighted_covariance(dv.to_device(X[None]), dv.to_device(w[None]),
+                                            _lib.WEIGHT_BIN_FRAME, N))[0]
+    fo, fr = np.isfinite(U), np.isfinite(ref)
+    bad_out = sorted(set(np.where(~fo)[0].tolist()))
+    assert bad_out == sorted(set(np.where(~fr)[0].tolist())) == [3, 8]
+    good = [i for i in range(F) if i not in (3, 8)]
+    assert rel_err(U[good], ref[good]) < 1e-11
+
+
+def test_zero_denominators_propagate_like_the_reference():
+    """An all-zero activation row makes num = den = 0 in the basis update: the reference computes
+    0 / 0 = NaN without a word (ssspy/bss/ilrma.py:1125, flooring_fn=None keeps it); so does the
+    device pass, in the same elements."""
+    from oracle.ilrma import GaussILRMAOracle
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    N, F, T, K = 3, 20, 40, 4
+    X = nmf_mixture(77, N, F, T)
+    basis = np.random.default_rng(1).random((N, F, K))
+    act = np.random.default_rng(2).random((N, K, T))
+    act[1, 2, :] = 0.0
+    ref = GaussILRMAOracle(n_basis=K, flooring=("none", 0.0), normalization=False, record_loss=False)
+    ref.reset(X, basis=basis, activation=act)
+    with np.errstate(all="ignore"):
+        ref.update_basis()
+    m = GaussILRMA(n_basis=K, flooring_fn=None, normalization=False, record_loss=False)
+    m._bind_input(X)
+    m._reset(flooring_fn=None, basis=basis, activation=act)
+    m.update_basis_mm(flooring_fn=None)
+    out = np.asarray(m.basis)
+    _same_nonfinite(out, ref.basis, tol=1e-11)
+    assert np.isnan(out[1, :, 2]).all() and np.isfinite(out[0]).all()
