@@ -71,7 +71,7 @@ enum { SSSPY_SOURCE_ME = 0x100 };
  * correct, not tuned; the reference has no limit: ssspy/bss/ilrma.py:180, iva.py:152).  IP2 / ISS2 /
  * IPA, the MNMF entry points and the Hermitian operators stay at SSSPY_MAX_SOURCES. */
 #define SSSPY_RT_MAX_SOURCES 16
-#define SSSPY_MAX_BASIS 1024 /* ILRMA; the MNMF entry points take n_basis <= 256 */
+#define SSSPY_MAX_BASIS 1024
 #define SSSPY_MAX_PAIRS 32
 
 const char *ssspy_amd_version(void);

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_gm_part_activation(const double *__rest
 __global__ __launch_bounds__(256) void k_gm_part_latent(const double *__restrict__ raw,
                                                         const double *__restrict__ basis,
                                                         double *latent, int N, int F, int K) {
-  __shared__ double znew[SSSPY_MAX_SOURCES * 256];  // (GaussMNMF: n_basis <= 256)
+  extern __shared__ __attribute__((aligned(16))) double znew[];  // N K doubles (<= 64 KB)
   const int b = blockIdx.x;
   for (int e = threadIdx.x; e < N * K; e += blockDim.x) {
     const int n = e / K, k = e % K;
@@ -695,7 +695,7 @@ static inline size_t bin_smem(int N, int M, int K) {
 static int check_dims(int B, int N, int M, int F, int T, int K) {
   SSSPY_REQUIRE(B > 0 && F > 0 && T > 0, "GaussMNMF: bad shape");
   SSSPY_REQUIRE(N >= 1 && N <= SSSPY_MAX_SOURCES, "GaussMNMF: n_sources must be in [1, 8]");
-  SSSPY_REQUIRE(K >= 1 && K <= 256, "GaussMNMF: n_basis must be in [1, 256]");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "GaussMNMF: n_basis must be in [1, 1024]");
   if (M < 2 || M > 8) return fail(SSSPY_ERR_UNSUPPORTED, "GaussMNMF: n_channels must be in [2, 8]");
   return SSSPY_OK;
 }
@@ -840,7 +840,8 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
   if (steps & SSSPY_GMNMF_LATENT) {
     rc = basis_sums(raw);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gm_part_latent, dim3(B), dim3(256), 0, st, (const double *)raw,
+    hipLaunchKernelGGL(k_gm_part_latent, dim3(B), dim3(256), (size_t)N * K * sizeof(double), st,
+                       (const double *)raw,
                        (const double *)basis, latent, N, F, K);
     rc = check_launch("k_gm_part_latent");
     if (rc) return rc;

@@ -189,7 +189,7 @@ static int fastmnmf_update_impl(const void *X, const void *C, void *Q, double *D
                                 hipStream_t st) {
   SSSPY_REQUIRE(X && Q && D && basis && activation && B > 0 && F > 0 && T > 0,
                 "fastmnmf_update: bad argument");
-  SSSPY_REQUIRE(K >= 1 && K <= 256, "fastmnmf_update: n_basis must be in [1, 256]");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_update: n_basis must be in [1, 1024]");
   const MnmfWs w = mnmf_ws(B, N, M, F, T, K);
   SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "fastmnmf_update: workspace too small");
   SSSPY_REQUIRE(!(steps & SSSPY_MNMF_NORMALIZE) || C, "fastmnmf_update: normalisation needs C");
@@ -320,7 +320,7 @@ int ssspy_fastmnmf_diagonalizer_covariance(const void *X, const double *D, const
                                            const double *activation, void *U, int B, int N, int M,
                                            int F, int T, int K, void *stream) {
   SSSPY_REQUIRE(X && D && basis && activation && U && B > 0, "fastmnmf_diagonalizer_covariance: bad argument");
-  SSSPY_REQUIRE(K >= 1 && K <= 256, "fastmnmf_diagonalizer_covariance: bad n_basis");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_diagonalizer_covariance: bad n_basis");
   if (!mnmf_tiled(N, M))
     return fail(SSSPY_ERR_UNSUPPORTED,
                 "fastmnmf_diagonalizer_covariance: beyond 4 sources / channels use "
@@ -334,7 +334,7 @@ int ssspy_fastmnmf_weights(const void *X, const void *Q, const double *D, const 
                            const double *activation, double *weights, int B, int N, int M, int F,
                            int T, int K, void *stream) {
   SSSPY_REQUIRE(X && Q && D && basis && activation && weights && B > 0, "fastmnmf_weights: bad argument");
-  SSSPY_REQUIRE(K >= 1 && K <= 256, "fastmnmf_weights: bad n_basis");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_weights: bad n_basis");
   return fmnmf_generic_weights(X, Q, D, basis, activation, weights, B, N, M, F, T, K,
                                as_stream(stream));
 }
@@ -358,7 +358,7 @@ int ssspy_fastmnmf_loss_data(const void *X, const void *Q, const double *D, cons
                              const double *activation, double *out, int B, int N, int M, int F,
                              int T, int K, void *workspace, size_t workspace_bytes, void *stream) {
   SSSPY_REQUIRE(X && Q && D && basis && activation && out && B > 0, "fastmnmf_loss_data: bad argument");
-  SSSPY_REQUIRE(K >= 1 && K <= 256, "fastmnmf_loss_data: bad n_basis");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_loss_data: bad n_basis");
   SSSPY_REQUIRE(N >= 1 && N <= SSSPY_MAX_SOURCES && M >= 2 && M <= 8,
                 "fastmnmf_loss_data: n_sources in [1, 8], n_channels in [2, 8]");
   SSSPY_REQUIRE(workspace && workspace_bytes >= fastmnmf_loss_ws(B, N, M, F, T),
@@ -375,7 +375,7 @@ int ssspy_fastmnmf_loss_data_handover(const double *D, const double *basis,
                                       void *workspace, size_t workspace_bytes, void *stream) {
   SSSPY_REQUIRE(D && basis && activation && handover && out && B > 0,
                 "fastmnmf_loss_data_handover: bad argument");
-  SSSPY_REQUIRE(K >= 1 && K <= 256, "fastmnmf_loss_data_handover: bad n_basis");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_loss_data_handover: bad n_basis");
   if (handover_ok(B, N, M, F, T, K) != 1)
     return fail(SSSPY_ERR_UNSUPPORTED, "fastmnmf_loss_data_handover: no hand-over for this shape");
   SSSPY_REQUIRE(workspace && workspace_bytes >= fastmnmf_loss_ws(B, N, M, F, T),

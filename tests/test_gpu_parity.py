@@ -2172,8 +2172,43 @@ def test_zero_denominators_propagate_like_the_reference():
         ref.update_basis()
     m = GaussILRMA(n_basis=K, flooring_fn=None, normalization=False, record_loss=False)
     m._bind_input(X)
-    m._reset(flooring_fn=None, basis=basis, activation=act)
-    m.update_basis_mm(flooring_fn=None)
+    m._reset(flooring_fn=m.flooring_fn, basis=basis, activation=act)
+    m.update_basis_mm()
     out = np.asarray(m.basis)
     _same_nonfinite(out, ref.basis, tol=1e-11)
     assert np.isnan(out[1, :, 2]).all() and np.isfinite(out[0]).all()
+
+
+@pytest.mark.parametrize("cls,K", [("fast", 17), ("fast", 300), ("fast", 1024), ("gauss", 300),
+                                   ("gauss_part", 520)])
+def test_mnmf_n_basis_beyond_256_against_oracle(cls, K):
+    """The reference puts no bound on n_basis (ssspy/bss/mnmf.py:1112-1153, :681-763); the MNMF entry
+    points stopped at 256 until round 4 (now 1024, like ILRMA)."""
+    from oracle.gmnmf import GaussMNMFOracle
+    from oracle.mnmf import FastGaussMNMFOracle
+    from ssspy_amd.bss.mnmf import FastGaussMNMF, GaussMNMF
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    M, F, T = 3, 9, 24
+    X = nmf_mixture(88, M, F, T)
+    rng = np.random.default_rng(K)
+    if cls == "fast":
+        kw = dict(basis=rng.random((M, F, K)), activation=rng.random((M, K, T)),
+                  spatial=rng.random((F, M, M)))
+        ref = FastGaussMNMFOracle(n_basis=K)
+        m = FastGaussMNMF(n_basis=K)
+    elif cls == "gauss":
+        kw = dict(basis=rng.random((M, F, K)), activation=rng.random((M, K, T)))
+        ref = GaussMNMFOracle(n_basis=K, rng=np.random.default_rng(1))
+        m = GaussMNMF(n_basis=K, rng=np.random.default_rng(1))
+    else:
+        latent = rng.random((M, K))
+        kw = dict(basis=rng.random((F, K)), activation=rng.random((K, T)),
+                  latent=latent / latent.sum(axis=0))
+        ref = GaussMNMFOracle(n_basis=K, partitioning=True, rng=np.random.default_rng(1))
+        m = GaussMNMF(n_basis=K, partitioning=True, rng=np.random.default_rng(1))
+    Yr = ref.run(X, n_iter=3, **{k: v.copy() for k, v in kw.items()})
+    Y = m(X, n_iter=3, **kw)
+    np.testing.assert_allclose(m.loss, ref.loss, rtol=1e-8)
+    assert rel_err(m.basis, ref.basis) < 1e-7 and rel_err(m.activation, ref.activation) < 1e-7
+    assert rel_err(Y, Yr) < 1e-6
