@@ -53,6 +53,7 @@ def _units():
         ("fmnmf_generic.hip", "fmnmf_generic.o", []),
         ("wide_cov.hip", "wide_cov.o", []),
         ("wide_n.hip", "wide_n.o", []),
+        ("wide_basis.hip", "wide_basis.o", []),
     ]
     units.append(("mnmf_api.hip", "mnmf_api.o", []))
     # Scheduling strategy per unit (measured A / B on one box, benchmarks/tools/ab_lib.sh): hipcc's

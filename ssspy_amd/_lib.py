@@ -137,7 +137,7 @@ def load():
             "(there is no CPU fallback for the device path)".format(LIB_PATH)
         )
     try:
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH, mode=os.RTLD_NOW)  # unresolved symbols fail here, not at first call
     except OSError as e:  # e.g. libamdhip64 missing
         raise HipLibraryError("cannot load {}: {}".format(LIB_PATH, e)) from e
     for name, (restype, argtypes) in PROTOTYPES.items():

@@ -521,7 +521,10 @@ __global__ __launch_bounds__(256) void k_ilrma_iss_weight(const c128 *__restrict
                                                           const double *__restrict__ basis,
                                                           const double *__restrict__ act,
                                                           double *__restrict__ varphi, int N,
-                                                          IlrmaDims d, int nchunks) {
+                                                          IlrmaDims d, int nchunks,
+                                                          double *__restrict__ bout = nullptr) {
+  // bout: the (a, b) mode of the wide-basis path (wide_basis.hip): varphi <- the numerator factor a
+  // of the MM update, bout <- b = 1 / R (mm_weights) instead of the spatial weight
   const int n = blockIdx.y, b = blockIdx.z;
   const int F = d.F, T = d.T, K = d.K;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(256) void k_ilrma_iss_weight(const c128 *__restrict
     const int kk = 4 * ks + q;
     ta[ks] = kk < K ? Tn[(long long)abin * K + kk] : 0.0;
   }
-  const bool need_y = d.model != SSSPY_SOURCE_GAUSS;
+  const bool need_y = d.model != SSSPY_SOURCE_GAUSS || bout != nullptr;
   // two frame tiles per pass: their loads and MFMA chains are independent
   for (int j0 = j_begin; j0 < j_end; j0 += 32) {
     int jc[2];
@@ -581,7 +584,14 @@ __global__ __launch_bounds__(256) void k_ilrma_iss_weight(const c128 *__restrict
         if (bin < F && jf < j_end) {
           const long long e = (row0 + bin) * T + jf;
           const double P = need_y ? (Ypow ? Ypow[e] : cabs2(Y[e])) : 0.0;
-          varphi[e] = spatial_weight(P, R[u][r], d);
+          if (bout) {
+            double wa, wb;
+            mm_weights(P, R[u][r], d, true, wa, wb);
+            varphi[e] = wa;
+            bout[e] = wb;
+          } else {
+            varphi[e] = spatial_weight(P, R[u][r], d);
+          }
         }
       }
   }
@@ -615,8 +625,11 @@ extern "C" {
 
 // One scratch layout for every ILRMA entry point: callers pass the same buffer everywhere.
 struct IlrmaWs {
-  size_t act_part, btmp, qbuf, psi, lslots, bpart, upart, praw, ybuf, wbuf, total;
+  size_t act_part, btmp, qbuf, psi, lslots, bpart, upart, praw, ybuf, wbuf, gb, gnd, total;
 };
+// shapes that may take the wide-basis path of wide_basis.hip (its buffers are sized for them; the
+// source model, which the workspace query does not know, decides at the call)
+static inline bool wide_basis_shape(int N, int K) { return K > 64 || N > SSSPY_MAX_SOURCES; }
 static inline IlrmaWs ilrma_ws(int B, int N, int F, int T, int K) {
   IlrmaWs w;
   size_t off = 0;
@@ -636,10 +649,15 @@ static inline IlrmaWs ilrma_ws(int B, int N, int F, int T, int K) {
   off += u_part_bytes(N);
   w.praw = off;  // (num, den) basis sums of the partitioned updates
   off += align256((size_t)B * N * F * K * 2 * sizeof(double));
+  const bool wb = wide_basis_shape(N, K);
   w.ybuf = off;  // y = W x of a wide mixture (more than 4 sources), see source_group()
-  off += N > 4 ? align256((size_t)B * N * F * T * 2 * sizeof(double)) : 0;
-  w.wbuf = off;  // varphi (B, N, F, T) of a wide mixture's covariance pass (wide_cov.hip)
-  off += N > 4 ? align256((size_t)B * N * F * T * sizeof(double)) : 0;
+  off += (N > 4 || wb) ? align256((size_t)B * N * F * T * 2 * sizeof(double)) : 0;
+  w.wbuf = off;  // varphi (B, N, F, T) of a wide mixture's covariance pass (wide_cov.hip); a of wide_basis
+  off += (N > 4 || wb) ? align256((size_t)B * N * F * T * sizeof(double)) : 0;
+  w.gb = off;    // wide-basis path: b = 1 / R (B, N, F, T)
+  off += wb ? align256((size_t)B * N * F * T * sizeof(double)) : 0;
+  w.gnd = off;   // wide-basis path: (num, den) of the products
+  off += wb ? align256((size_t)2 * B * N * (F > T ? F : T) * K * sizeof(double)) : 0;
   w.total = off;
   return w;
 }
@@ -649,10 +667,47 @@ size_t ssspy_ilrma_workspace_bytes(int B, int N, int F, int T, int K) {
   return ilrma_ws(B, N, F, T, K).total;
 }
 
+extern "C++" {
+namespace ssspy {  // wide_basis.hip
+int wb_update_basis(const double *a, const double *b, double *basis, const double *activation,
+                    double *nd, int BN, int F, int T, int K, const IlrmaDims &d, hipStream_t st);
+int wb_update_activation(const double *a, const double *b, const double *basis, double *activation,
+                         double *nd, int BN, int F, int T, int K, const IlrmaDims &d,
+                         hipStream_t st);
+}  // namespace ssspy
+}  // extern "C++"
+
+// a = numerator factor, b = 1 / R of the MM updates for the wide-basis path: |y|^2 from the filter
+// (ybuf), from a power input, or from y itself; the weight kernel's (a, b) mode writes wbuf / gb
+static int wb_weights(const void *X, const void *W, bool x_is_power, const double *basis,
+                      const double *activation, int N, const IlrmaDims &d, char *ws, size_t ybuf,
+                      size_t wbuf, size_t gb, hipStream_t st);
+
 static IlrmaDims make_dims(int B, int F, int T, int K, double domain, int model, double mparam,
                            int floor_kind, double floor_eps) {
   return IlrmaDims{B, F, T, K, domain, model & 0xff, (model & SSSPY_SOURCE_ME) ? 1 : 0, mparam,
                    floor_kind, floor_eps, 0};
+}
+
+static int wb_weights(const void *X, const void *W, bool x_is_power, const double *basis,
+                      const double *activation, int N, const IlrmaDims &d, char *ws, size_t ybuf,
+                      size_t wbuf, size_t gb, hipStream_t st) {
+  const c128 *Y = nullptr;
+  const double *Ypow = nullptr;
+  if (W) {
+    int r = separate_power(X, W, (double *)(ws + ybuf), d.B, N, d.F, d.T, st);
+    if (r) return r;
+    Ypow = (const double *)(ws + ybuf);
+  } else if (x_is_power) {
+    Ypow = (const double *)X;
+  } else {
+    Y = (const c128 *)X;
+  }
+  const int chunks = iss_weight_chunks(d.B, N, d.F, d.T);
+  dim3 grid(((d.F + 63) / 64) * chunks, N, d.B), block(256);
+  hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, st, Y, Ypow, basis, activation,
+                     (double *)(ws + wbuf), N, d, chunks, (double *)(ws + gb));
+  return check_launch("k_ilrma_iss_weight (a, b)");
 }
 
 // Basis update; with loss_out (B zeroed doubles) the tuned kernel also leaves the data term of the loss
@@ -679,6 +734,7 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
                 "update_basis: power input off the grouped path");
   // above 16 bases the update cannot be in place (several items per bin group read the old basis)
   double *out = K > 16 ? (double *)(ws + w.btmp) : basis;
+  bool in_place = false;
   auto run = [&]() -> int {
     SourceRun runs[3];
     if (const int nruns = source_runs(B, N, F, T, K, domain, source_model, runs)) {
@@ -717,11 +773,19 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
     }
     const IlrmaDims d =
         make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
+    if (wide_basis_shape(N, K)) {
+      // n_basis above 64 (or more than 8 sources off the grouped path): dense products, in place
+      int r = wb_weights(X, W, x_is_power, basis, activation, N, d, ws, w.ybuf, w.wbuf, w.gb, st);
+      if (r) return r;
+      in_place = true;
+      return wb_update_basis((const double *)(ws + w.wbuf), (const double *)(ws + w.gb), basis,
+                             activation, (double *)(ws + w.gnd), B * N, F, T, K, d, st);
+    }
     ILRMA_DISPATCH(N, ilrma_basis, X, W, basis, out, activation, d, st);
   };
   rc = run();
   if (rc) return rc;
-  if (out != basis) {
+  if (out != basis && !in_place) {
     hipError_t e = hipMemcpyAsync(basis, out, (size_t)B * N * F * K * sizeof(double),
                                   hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
@@ -762,6 +826,14 @@ static int update_activation_impl(const void *X, const void *W, const double *ba
     ILRMA_FAST_DISPATCH(N, ilrma_small_activation, X, W, basis, activation, B, F, T, K, floor_kind,
                         floor_eps, part, fast_model_id(domain, source_model), fast_model_param(domain, source_model, model_param),
                         is_me(source_model), st);
+  }
+  if (!nruns && !fast_path(N, F, T, K, domain, source_model) && wide_basis_shape(N, K)) {
+    // n_basis above 64 (or more than 8 sources off the grouped path): dense products (wide_basis.hip)
+    char *ws = (char *)workspace;
+    rc = wb_weights(X, W, x_is_power, basis, activation, N, d, ws, w.ybuf, w.wbuf, w.gb, st);
+    if (rc) return rc;
+    return wb_update_activation((const double *)(ws + w.wbuf), (const double *)(ws + w.gb), basis,
+                                activation, (double *)(ws + w.gnd), B * N, F, T, K, d, st);
   }
   // (the partial sums of a run keep the (group, chunk, source) layout at the run's offset: every
   // source owns `chunks` slabs of 2 K T doubles wherever its group starts)
@@ -861,6 +933,19 @@ static int wcov_into(const void *X, const void *W, const double *basis, const do
       return wide_weighted_cov(X, wbuf, SSSPY_WEIGHT_BIN_FRAME, U, d.B, N, N, d.F, d.T, st);
     }
   }
+  if (wbuf && d.K > 64 && (d.model == SSSPY_SOURCE_GAUSS || Ysep || !W)) {
+    // n_basis above 64: the weight kernel walks any n_basis on the matrix cores; the covariance is
+    // then the shared weighted-covariance operator (no T V inside it)
+    const void *Y = Ysep ? Ysep : (W ? nullptr : X);
+    const bool ypow = Ysep && ysep_is_power;
+    const int chunks = iss_weight_chunks(d.B, N, d.F, d.T);
+    dim3 grid(((d.F + 63) / 64) * chunks, N, d.B), block(256);
+    hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, st, ypow ? nullptr : (const c128 *)Y,
+                       ypow ? (const double *)Y : nullptr, basis, activation, wbuf, N, d, chunks);
+    int rc = check_launch("k_ilrma_iss_weight");
+    if (rc) return rc;
+    return ssspy_weighted_covariance(X, wbuf, SSSPY_WEIGHT_BIN_FRAME, U, d.B, N, N, d.F, d.T, st);
+  }
   if (fast_path(N, d.F, d.T, d.K, d.p, d.model) && (d.model == SSSPY_SOURCE_GAUSS || W)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, W, basis, activation, U, d.B, d.F, d.T, d.K, upart,
                         fast_model_id(d.p, d.model), fast_model_param(d.p, d.model, d.mparam), d.floor_kind, d.floor_eps, st,
@@ -885,7 +970,8 @@ int ssspy_ilrma_weighted_covariance(const void *X, const void *W, const double *
   hipStream_t st = as_stream(stream);
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   return wcov_into(X, W, basis, activation, U, N, d, (char *)workspace + w.upart,
-                   N > 4 ? (double *)((char *)workspace + w.wbuf) : nullptr, nullptr, false, st);
+                   (N > 4 || wide_basis_shape(N, K)) ? (double *)((char *)workspace + w.wbuf) : nullptr,
+                   nullptr, false, st);
 }
 
 static int launch_norm_scale(void *W, double *basis, const double *qbuf, int B, int N, int F, int K,
@@ -1071,7 +1157,8 @@ static int ip1_update_impl(const void *X, const void *C, void *W, double *basis,
   }
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   rc = wcov_into(X, W, basis, activation, U, N, d, ws + w.upart,
-                 N > 4 ? (double *)(ws + w.wbuf) : nullptr, Ws ? nullptr : Xs, xs_is_power, st);
+                 (N > 4 || wide_basis_shape(N, K)) ? (double *)(ws + w.wbuf) : nullptr,
+                 Ws ? nullptr : Xs, xs_is_power, st);
   if (rc) return rc;
   rc = ip1_with_power(W, U, normalize ? C : nullptr, normalize ? qbuf : nullptr, B, F, N,
                       floor_kind, floor_eps, info, st);
