@@ -629,7 +629,17 @@ struct IlrmaWs {
 };
 // shapes that may take the wide-basis path of wide_basis.hip (its buffers are sized for them; the
 // source model, which the workspace query does not know, decides at the call)
-static inline bool wide_basis_shape(int N, int K) { return K > 64 || N > SSSPY_MAX_SOURCES; }
+// The register-tiled passes win up to 32 bases (16: 1.0 ms, 32: 1.6 ms per iteration at 32 mixtures of
+// the configs[1] shape); from 33 on their four-k-tile form (4.1-4.7 ms) loses to the dense products
+// (3.1-3.2 ms; 80: 4.1, 128: 4.6, 256: 7.1, 1024: 22.8 -- benchmarks/wide_basis.py, round 4).
+// SSSPY_AMD_WIDE_BASIS_MIN_K (development): smallest n_basis on the wide-basis path
+static inline bool wide_basis_shape(int N, int K) {
+  static const int min_k = [] {
+    const char *e = std::getenv("SSSPY_AMD_WIDE_BASIS_MIN_K");
+    return e ? std::atoi(e) : 33;
+  }();
+  return K >= min_k || N > SSSPY_MAX_SOURCES;
+}
 static inline IlrmaWs ilrma_ws(int B, int N, int F, int T, int K) {
   IlrmaWs w;
   size_t off = 0;
@@ -674,6 +684,9 @@ int wb_update_basis(const double *a, const double *b, double *basis, const doubl
 int wb_update_activation(const double *a, const double *b, const double *basis, double *activation,
                          double *nd, int BN, int F, int T, int K, const IlrmaDims &d,
                          hipStream_t st);
+int wb_tv_weights(int mode, const double *basis, const double *activation, const double *ypow,
+                  const void *y, double *out0, double *out1, int BN, int F, int T, int K,
+                  const IlrmaDims &d, hipStream_t st);
 }  // namespace ssspy
 }  // extern "C++"
 
@@ -703,11 +716,10 @@ static int wb_weights(const void *X, const void *W, bool x_is_power, const doubl
   } else {
     Y = (const c128 *)X;
   }
-  const int chunks = iss_weight_chunks(d.B, N, d.F, d.T);
-  dim3 grid(((d.F + 63) / 64) * chunks, N, d.B), block(256);
-  hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, st, Y, Ypow, basis, activation,
-                     (double *)(ws + wbuf), N, d, chunks, (double *)(ws + gb));
-  return check_launch("k_ilrma_iss_weight (a, b)");
+  // (T V as a tiled GEMM with the (a, b) map in its epilogue: the weight kernel's own walk fetches
+  //  both operands from memory at every k-step -- 1.75 ms against 0.45 at n_basis 128, 32 mixtures)
+  return wb_tv_weights(1, basis, activation, Ypow, Y, (double *)(ws + wbuf), (double *)(ws + gb),
+                       d.B * N, d.F, d.T, d.K, d, st);
 }
 
 // Basis update; with loss_out (B zeroed doubles) the tuned kernel also leaves the data term of the loss
@@ -764,7 +776,7 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
       }
       return SSSPY_OK;
     }
-    if (fast_path(N, F, T, K, domain, source_model)) {
+    if (fast_path(N, F, T, K, domain, source_model) && !(K > 32 && wide_basis_shape(N, K))) {
       if (loss_done) *loss_done = loss_out != nullptr && K <= 16;
       ILRMA_FAST_DISPATCH(N, ilrma_fast_basis, X, W, basis, out, activation, B, F, T, K, floor_kind,
                           floor_eps, (double *)(ws + w.bpart), fast_model_id(domain, source_model),
@@ -827,7 +839,8 @@ static int update_activation_impl(const void *X, const void *W, const double *ba
                         floor_eps, part, fast_model_id(domain, source_model), fast_model_param(domain, source_model, model_param),
                         is_me(source_model), st);
   }
-  if (!nruns && !fast_path(N, F, T, K, domain, source_model) && wide_basis_shape(N, K)) {
+  if (!nruns && wide_basis_shape(N, K) &&
+      !(fast_path(N, F, T, K, domain, source_model) && K <= 32)) {
     // n_basis above 64 (or more than 8 sources off the grouped path): dense products (wide_basis.hip)
     char *ws = (char *)workspace;
     rc = wb_weights(X, W, x_is_power, basis, activation, N, d, ws, w.ybuf, w.wbuf, w.gb, st);
@@ -933,16 +946,14 @@ static int wcov_into(const void *X, const void *W, const double *basis, const do
       return wide_weighted_cov(X, wbuf, SSSPY_WEIGHT_BIN_FRAME, U, d.B, N, N, d.F, d.T, st);
     }
   }
-  if (wbuf && d.K > 64 && (d.model == SSSPY_SOURCE_GAUSS || Ysep || !W)) {
+  if (wbuf && d.K > 32 && wide_basis_shape(N, d.K) &&
+      (d.model == SSSPY_SOURCE_GAUSS || Ysep || !W)) {
     // n_basis above 64: the weight kernel walks any n_basis on the matrix cores; the covariance is
     // then the shared weighted-covariance operator (no T V inside it)
     const void *Y = Ysep ? Ysep : (W ? nullptr : X);
     const bool ypow = Ysep && ysep_is_power;
-    const int chunks = iss_weight_chunks(d.B, N, d.F, d.T);
-    dim3 grid(((d.F + 63) / 64) * chunks, N, d.B), block(256);
-    hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, st, ypow ? nullptr : (const c128 *)Y,
-                       ypow ? (const double *)Y : nullptr, basis, activation, wbuf, N, d, chunks);
-    int rc = check_launch("k_ilrma_iss_weight");
+    int rc = wb_tv_weights(2, basis, activation, ypow ? (const double *)Y : nullptr,
+                           ypow ? nullptr : Y, wbuf, nullptr, d.B * N, d.F, d.T, d.K, d, st);
     if (rc) return rc;
     return ssspy_weighted_covariance(X, wbuf, SSSPY_WEIGHT_BIN_FRAME, U, d.B, N, N, d.F, d.T, st);
   }

@@ -3,8 +3,8 @@
 // grouped path.  Round 3 left these to the first-generation kernels (n_basis 80: 25 ms per iteration
 // at 32 mixtures of the configs[1] shape against 4.7 ms at 64).  Here the update is what it is on
 // paper -- three dense products per source and a few element-wise maps:
-//   R  = T V                      (F x T)    k_ilrma_iss_weight in its (a, b) mode forms it tile by
-//   a  = mm numerator factor, b = 1 / R      tile on the matrix cores and writes a and b
+//   R  = T V                      (F x T)    a batched GEMM whose epilogue maps R (and |y|^2) to
+//   a  = mm numerator factor, b = 1 / R      a and b (or to the covariance pass's weight 1 / R~)
 //   basis:      num = a V^T,  den = b V^T    (F x K)   one batched GEMM, both right-hand sides
 //   activation: num = T^T a,  den = T^T b    (K x T)   one batched GEMM
 //   state <- floor(state * (num / den)^e)              k_mu_update
@@ -71,10 +71,21 @@ __device__ __forceinline__ void gemm_stage_store(const double (&reg)[4], double 
   }
 }
 
+// Epilogues: EPI_STORE C = the product; EPI_AB the product is R = (T V) of one source: with P = |y|^2
+// (ypow, or |y|^2 of y) C0 <- the numerator factor a, C1 <- b = 1 / R of the MM update (mm_weights);
+// EPI_PHI C0 <- the spatial weight 1 / R~ of the covariance pass (spatial_weight).
+enum { EPI_STORE = 0, EPI_AB = 1, EPI_PHI = 2 };
+struct GemmEpi {
+  const double *ypow;  // (batches, M, N) f64, or NULL
+  const c128 *y;       // (batches, M, N) complex when ypow is NULL (may be NULL for EPI_PHI / Gauss)
+  IlrmaDims d;
+};
+
 // grid: (ceil(M / 64), ceil(N / 64), batches)
+template <int EPI>
 __global__ __launch_bounds__(256) void k_gemm_f64(GemmSide A, GemmSide Bm, double *C0, double *C1,
                                                   long long c_batch, int M, int N, int Kd,
-                                                  int dual) {
+                                                  int dual, GemmEpi epi) {
   __shared__ double As[2][GK * GLD], Bs[2][GK * GLD];
   const int g = blockIdx.z;
   const int set = dual ? (g & 1) : 0;
@@ -128,7 +139,24 @@ __global__ __launch_bounds__(256) void k_gemm_f64(GemmSide A, GemmSide Bm, doubl
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm + 16 * i + q + 4 * r, col = n0 + wn + 16 * j + c;
-        if (row < M && col < N) Cb[(long long)row * N + col] = acc[i][j][r];
+        if (row < M && col < N) {
+          const long long e = (long long)row * N + col;
+          if (EPI == EPI_STORE) {
+            Cb[e] = acc[i][j][r];
+          } else {
+            const long long ge = bi * c_batch + e;
+            const bool need = EPI == EPI_AB || epi.d.model != SSSPY_SOURCE_GAUSS;
+            const double P = need ? (epi.ypow ? epi.ypow[ge] : cabs2(epi.y[ge])) : 0.0;
+            if (EPI == EPI_AB) {
+              double wa, wb;
+              mm_weights(P, acc[i][j][r], epi.d, true, wa, wb);
+              C0[ge] = wa;
+              C1[ge] = wb;
+            } else {
+              C0[ge] = spatial_weight(P, acc[i][j][r], epi.d);
+            }
+          }
+        }
       }
 }
 
@@ -136,8 +164,27 @@ static int launch_gemm(const GemmSide &A, const GemmSide &Bm, double *C0, double
                        long long c_batch, int M, int N, int Kd, int batches, int dual,
                        hipStream_t st) {
   dim3 grid((M + GT - 1) / GT, (N + GT - 1) / GT, dual ? 2 * batches : batches);
-  hipLaunchKernelGGL(k_gemm_f64, grid, dim3(256), 0, st, A, Bm, C0, C1, c_batch, M, N, Kd, dual);
+  hipLaunchKernelGGL(k_gemm_f64<EPI_STORE>, grid, dim3(256), 0, st, A, Bm, C0, C1, c_batch, M, N,
+                     Kd, dual, GemmEpi{});
   return check_launch("k_gemm_f64");
+}
+
+// R = T V per source (F x T, n_basis deep) with the element-wise map in the epilogue:
+// mode EPI_AB -> out0 = a, out1 = b; EPI_PHI -> out0 = varphi.  ypow / y: |y|^2 or y, (B N, F, T).
+int wb_tv_weights(int mode, const double *basis, const double *activation, const double *ypow,
+                  const void *y, double *out0, double *out1, int BN, int F, int T, int K,
+                  const IlrmaDims &d, hipStream_t st) {
+  const GemmSide A{basis, basis, (long long)F * K, (long long)K, 1};        // T[i][k]
+  const GemmSide Bm{activation, activation, (long long)K * T, (long long)T, 1};  // V[k][j]
+  dim3 grid((F + GT - 1) / GT, (T + GT - 1) / GT, BN);
+  const GemmEpi epi{ypow, (const c128 *)y, d};
+  if (mode == EPI_AB)
+    hipLaunchKernelGGL(k_gemm_f64<EPI_AB>, grid, dim3(256), 0, st, A, Bm, out0, out1,
+                       (long long)F * T, F, T, K, 0, epi);
+  else
+    hipLaunchKernelGGL(k_gemm_f64<EPI_PHI>, grid, dim3(256), 0, st, A, Bm, out0, out1,
+                       (long long)F * T, F, T, K, 0, epi);
+  return check_launch("k_gemm_f64 (T V epilogue)");
 }
 
 // state <- floor(state * (num / den)^e), element-wise.  ref: ssspy/bss/ilrma.py:1126-1128, :1202-1204
