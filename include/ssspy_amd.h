@@ -311,7 +311,7 @@ int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *act
  * workspace of ssspy_ilrma_workspace_bytes is large enough too) and added up in a fixed order:
  * no fp64 atomics, the same bits on every run.
  * replaces: ssspy/bss/ilrma.py:1946-1965, :3291-3310, :4367-4386. */
-size_t ssspy_ilrma_loss_workspace_bytes(int B, int N, int F);
+size_t ssspy_ilrma_loss_workspace_bytes(int B, int N, int F, int T);
 int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
                           const double *activation, double *out, int B, int N, int F, int T, int K,
                           double domain, int source_model, double model_param, void *workspace,

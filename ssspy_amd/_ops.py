@@ -451,7 +451,7 @@ def ilrma_loss_data(X, W, basis, activation, domain, out=None, model=GAUSS):
     K = basis.shape[-1]
     if out is None:
         out = dv.empty((B,), dv.f64, X.device)
-    ws, ws_bytes = _scratch(_L().ssspy_ilrma_loss_workspace_bytes(B, N, F), X.device)
+    ws, ws_bytes = _scratch(_L().ssspy_ilrma_loss_workspace_bytes(B, N, F, T), X.device)
     _lib.check(
         _L().ssspy_ilrma_loss_data(ptr(X), ptr(W), ptr(basis), ptr(activation), ptr(out), B, N, F,
                                    T, K, domain, model[0], model[1], ptr(ws), ws_bytes, _st()),

@@ -235,7 +235,8 @@ static inline size_t basis_part_bytes(int N) {
 }
 // scratch of the deterministic loss sums: the larger of what the tuned kernels (by-product of the
 // basis pass, loss pass) and the generic loss kernel need
-static inline size_t loss_slots_bytes(int B, int N, int F) {
+size_t wb_loss_ws_bytes(int B, int N, int F, int T);  // wide_basis.hip
+static inline size_t loss_slots_bytes(int B, int N, int F, int T) {
   auto generic = [&]() -> size_t {
     switch (N) {
       case 2: return ilrma_loss_ws_bytes_n2(B, F);
@@ -257,7 +258,11 @@ static inline size_t loss_slots_bytes(int B, int N, int F) {
     }
   };
   const size_t a = generic(), b = tuned();
-  const size_t c = rt_sources_ok(N) ? rt_ilrma_loss_ws_bytes(B, N, F) : 0;
+  size_t c = rt_sources_ok(N) ? rt_ilrma_loss_ws_bytes(B, N, F) : 0;
+  // (the wide-basis loss: one slot per 64 x 64 tile of every source; a y = W x buffer when a filter
+  //  is given)
+  const size_t g = align256(wb_loss_ws_bytes(B, N, F, T)) + align256((size_t)B * N * F * T * sizeof(double));
+  c = c > g ? c : g;
   return align256(a > b ? (a > c ? a : c) : (b > c ? b : c));
 }
 static inline size_t u_part_bytes(int N) {
@@ -652,7 +657,7 @@ static inline IlrmaWs ilrma_ws(int B, int N, int F, int T, int K) {
   w.psi = off;
   off += align256((size_t)B * N * sizeof(double));
   w.lslots = off;  // per-wave shares of a loss, folded in a fixed order (no fp64 atomics)
-  off += loss_slots_bytes(B, N, F);
+  off += loss_slots_bytes(B, N, F, T);
   w.bpart = off;
   off += basis_part_bytes(N);
   w.upart = off;
@@ -687,6 +692,9 @@ int wb_update_activation(const double *a, const double *b, const double *basis, 
 int wb_tv_weights(int mode, const double *basis, const double *activation, const double *ypow,
                   const void *y, double *out0, double *out1, int BN, int F, int T, int K,
                   const IlrmaDims &d, hipStream_t st);
+int wb_loss_data(const double *basis, const double *activation, const double *ypow, const void *y,
+                 double *out, void *ws, int B, int N, int F, int T, int K, const IlrmaDims &d,
+                 hipStream_t st);
 }  // namespace ssspy
 }  // extern "C++"
 
@@ -1062,9 +1070,9 @@ int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *act
   return check_launch("k_ilrma_iss_weight");
 }
 
-size_t ssspy_ilrma_loss_workspace_bytes(int B, int N, int F) {
-  if (B <= 0 || N <= 0 || F <= 0) return 0;
-  return loss_slots_bytes(B, N, F);
+size_t ssspy_ilrma_loss_workspace_bytes(int B, int N, int F, int T) {
+  if (B <= 0 || N <= 0 || F <= 0 || T <= 0) return 0;
+  return loss_slots_bytes(B, N, F, T);
 }
 
 int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
@@ -1074,19 +1082,31 @@ int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
   SSSPY_REQUIRE(X && basis && activation && out && B > 0, "ilrma_loss_data: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "ilrma_loss_data: bad n_basis");
   SSSPY_REQUIRE(N >= 2 && N <= SSSPY_RT_MAX_SOURCES, "ilrma_loss_data: n_sources must be in [2, 16]");
-  SSSPY_REQUIRE(workspace && workspace_bytes >= loss_slots_bytes(B, N, F),
+  SSSPY_REQUIRE(workspace && workspace_bytes >= loss_slots_bytes(B, N, F, T),
                 "ilrma_loss_data: workspace too small (ssspy_ilrma_loss_workspace_bytes)");
   int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
   hipStream_t st = as_stream(stream);
-  if (rt_sources_ok(N)) {
-    if ((source_model & 0xff) != SSSPY_SOURCE_GAUSS)
-      return fail(SSSPY_ERR_UNSUPPORTED, "ILRMA above 8 sources: the loss is built for the Gauss model");
-    return rt_ilrma_loss(X, W, basis, activation, out, workspace, B, N, F, T, K, domain, st);
-  }
   if (K <= 16 && fast_path(N, F, T, K, domain, source_model)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_loss, X, W, basis, activation, out, workspace, B, F, T, K,
                         fast_model_id(domain, source_model), fast_model_param(domain, source_model, model_param), st);
+  }
+  if (K > 16 || rt_sources_ok(N)) {
+    // n_basis above 16 (or more than 8 sources): T V on the matrix cores, the terms summed in the
+    // product's epilogue (wide_basis.hip) -- the per-N loss kernels took 1.7 / 2.8 / 5.0 ms at
+    // n_basis 32 / 64 / 128 (32 mixtures), as much as the iteration they follow
+    const IlrmaDims dl = make_dims(B, F, T, K, domain, source_model, model_param, SSSPY_FLOOR_NONE, 0.0);
+    char *wsb = (char *)workspace;
+    const size_t slots = align256(wb_loss_ws_bytes(B, N, F, T));
+    const double *ypow = nullptr;
+    const void *y = X;
+    if (W) {
+      rc = separate_power(X, W, (double *)(wsb + slots), B, N, F, T, st);
+      if (rc) return rc;
+      ypow = (const double *)(wsb + slots);
+      y = nullptr;
+    }
+    return wb_loss_data(basis, activation, ypow, y, out, workspace, B, N, F, T, K, dl, st);
   }
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, SSSPY_FLOOR_NONE, 0.0);
   ILRMA_DISPATCH(N, ilrma_loss, X, W, basis, activation, out, workspace, d, st);

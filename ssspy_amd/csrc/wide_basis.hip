@@ -74,7 +74,9 @@ __device__ __forceinline__ void gemm_stage_store(const double (&reg)[4], double 
 // Epilogues: EPI_STORE C = the product; EPI_AB the product is R = (T V) of one source: with P = |y|^2
 // (ypow, or |y|^2 of y) C0 <- the numerator factor a, C1 <- b = 1 / R of the MM update (mm_weights);
 // EPI_PHI C0 <- the spatial weight 1 / R~ of the covariance pass (spatial_weight).
-enum { EPI_STORE = 0, EPI_AB = 1, EPI_PHI = 2 };
+// EPI_LOSS: the workgroup's sum of loss_term(P, R) over its tile goes to C0[batch][tile] (one slot per
+// workgroup, no atomics; wb_loss_data adds a mixture's slots in a fixed order).
+enum { EPI_STORE = 0, EPI_AB = 1, EPI_PHI = 2, EPI_LOSS = 3 };
 struct GemmEpi {
   const double *ypow;  // (batches, M, N) f64, or NULL
   const c128 *y;       // (batches, M, N) complex when ypow is NULL (may be NULL for EPI_PHI / Gauss)
@@ -131,6 +133,27 @@ __global__ __launch_bounds__(256) void k_gemm_f64(GemmSide A, GemmSide Bm, doubl
     }
     __syncthreads();
   }
+  if (EPI == EPI_LOSS) {
+    __shared__ double red[4];
+    double local = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm + 16 * i + q + 4 * r, col = n0 + wn + 16 * j + c;
+          if (row < M && col < N) {
+            const long long ge = bi * c_batch + (long long)row * N + col;
+            const double P = epi.ypow ? epi.ypow[ge] : cabs2(epi.y[ge]);
+            local += loss_term(P, acc[i][j][r], epi.d);
+          }
+        }
+    const double total = block_sum(local, red);
+    if (threadIdx.x == 0)
+      C0[((long long)bi * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y] = total;
+    return;
+  }
   // D: row = q + 4 r, col = c of each 16 x 16 tile; C is row-major (N contiguous)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -167,6 +190,41 @@ static int launch_gemm(const GemmSide &A, const GemmSide &Bm, double *C0, double
   hipLaunchKernelGGL(k_gemm_f64<EPI_STORE>, grid, dim3(256), 0, st, A, Bm, C0, C1, c_batch, M, N,
                      Kd, dual, GemmEpi{});
   return check_launch("k_gemm_f64");
+}
+
+// out[b] = scale * (sum of the mixture's `count` slots), one block per mixture, fixed order
+__global__ __launch_bounds__(256) void k_wb_sum_slots(const double *__restrict__ slots, double *out,
+                                                      long long count, double scale) {
+  __shared__ double scratch[4];
+  const int b = blockIdx.x;
+  double s = 0.0;
+  for (long long e = threadIdx.x; e < count; e += blockDim.x) s += slots[b * count + e];
+  const double total = block_sum(s, scratch);
+  if (threadIdx.x == 0) out[b] = total * scale;
+}
+
+size_t wb_loss_ws_bytes(int B, int N, int F, int T) {
+  return (size_t)B * N * ((F + GT - 1) / GT) * ((T + GT - 1) / GT) * sizeof(double);
+}
+
+// Data term of the negative log-likelihood, out[b] = sum_{n,i} mean_j loss_term(|y|^2, (T V)_nij), any
+// n_basis / source count / model: T V tile by tile on the matrix cores, the terms summed per
+// workgroup in the epilogue.  ypow / y: |y|^2 or y (B N, F, T); ws: wb_loss_ws_bytes().
+// ref: ssspy/bss/ilrma.py:1946-1965 (Gauss), :3301-3305 (t), :4377-4381 (GGD).
+int wb_loss_data(const double *basis, const double *activation, const double *ypow, const void *y,
+                 double *out, void *ws, int B, int N, int F, int T, int K, const IlrmaDims &d,
+                 hipStream_t st) {
+  const GemmSide A{basis, basis, (long long)F * K, (long long)K, 1};
+  const GemmSide Bm{activation, activation, (long long)K * T, (long long)T, 1};
+  dim3 grid((F + GT - 1) / GT, (T + GT - 1) / GT, B * N);
+  const GemmEpi epi{ypow, (const c128 *)y, d};
+  hipLaunchKernelGGL(k_gemm_f64<EPI_LOSS>, grid, dim3(256), 0, st, A, Bm, (double *)ws,
+                     (double *)nullptr, (long long)F * T, F, T, K, 0, epi);
+  int rc = check_launch("k_gemm_f64 (loss)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_wb_sum_slots, dim3(B), dim3(256), 0, st, (const double *)ws, out,
+                     (long long)N * grid.x * grid.y, 1.0 / (double)T);
+  return check_launch("k_wb_sum_slots");
 }
 
 // R = T V per source (F x T, n_basis deep) with the element-wise map in the epilogue:
