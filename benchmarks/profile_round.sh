@@ -7,7 +7,7 @@
 # configs[2] and configs[3] at 32 mixtures).  benchmarks/digest_profiles.py turns these
 # into the tracked files under profiles/.
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/$tag
 mkdir -p $out
@@ -24,7 +24,9 @@ python benchmarks/other_configs.py > $out/other_configs.txt 2>&1
 python benchmarks/other_configs.py --batch 32 >> $out/other_configs.txt 2>&1
 python benchmarks/other_configs.py --batch 128 --only fastmnmf --iters 10 >> $out/other_configs.txt 2>&1
 python benchmarks/wide_mixtures.py >> $out/other_configs.txt 2>&1
-python benchmarks/wide_basis.py >> $out/other_configs.txt 2>&1
+python benchmarks/wide_basis.py 16 32 33 40 64 80 128 256 1024 >> $out/other_configs.txt 2>&1
+python benchmarks/batch_sweep.py > $out/batch_sweep.txt 2>&1
+python benchmarks/power_profile.py --seconds 5 > $out/power_profile.json 2> /dev/null
 # per-kernel statistics of configs[2] / configs[3] at 32 mixtures
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/other_stats -- \
   python benchmarks/other_configs.py --batch 32 --only iva_iss,fastmnmf --iters 10 > $out/other_stats.log 2>&1
