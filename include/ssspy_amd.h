@@ -72,7 +72,7 @@ enum { SSSPY_SOURCE_ME = 0x100 };
  * IPA, the MNMF entry points and the Hermitian operators stay at SSSPY_MAX_SOURCES. */
 #define SSSPY_RT_MAX_SOURCES 16
 #define SSSPY_MAX_BASIS 1024
-#define SSSPY_MAX_PAIRS 32
+#define SSSPY_MAX_PAIRS 128 /* every pair of 16 sources: 120 */
 
 const char *ssspy_amd_version(void);
 const char *ssspy_last_error(void);

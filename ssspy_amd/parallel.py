@@ -89,7 +89,8 @@ def barrier() -> None:
 
 
 def separate_pipelined(make_separator: Callable[[], object], X, sub_batch: int, n_iter: int = 100,
-                       out: Optional[np.ndarray] = None, **call_kwargs) -> np.ndarray:
+                       out: Optional[np.ndarray] = None, ramp: bool = True,
+                       **call_kwargs) -> np.ndarray:
     """Separate a HOST-resident batch ``X`` (n_mixtures, n_channels, n_bins, n_frames) complex128
     in sub-batches of ``sub_batch`` mixtures, overlapping the PCIe transfers with the iterations:
     while the separator iterates on sub-batch k (torch's current stream), a copy stream uploads
@@ -115,12 +116,24 @@ def separate_pipelined(make_separator: Callable[[], object], X, sub_batch: int, 
     else:
         out_t = out if isinstance(out, torch.Tensor) else torch.from_numpy(out)
     direct_in, direct_out = Xt.is_pinned(), out_t.is_pinned()
-    shape1 = (sub_batch,) + tuple(Xt.shape[1:])
+    shape1 = (sub_batch,) + tuple(Xt.shape[1:])  # (edge blocks are smaller: they fit)
     stage_in = None if direct_in else [torch.empty(shape1, dtype=torch.complex128, pin_memory=True)
                                        for _ in range(2)]
     stage_out = None if direct_out else [torch.empty(shape1, dtype=torch.complex128, pin_memory=True)
                                          for _ in range(2)]
-    blocks = [(lo, min(lo + sub_batch, B)) for lo in range(0, B, sub_batch)]
+    # The first upload and the last download have nothing to hide behind: a short leading and a
+    # short trailing sub-batch (a quarter of the others) keep that exposed transfer small.
+    edge = max(1, sub_batch // 4) if ramp and B > 2 * sub_batch else 0
+    blocks, lo = [], 0
+    if edge:
+        blocks.append((0, edge))
+        lo = edge
+    stop = B - edge if edge else B
+    while lo < stop:
+        blocks.append((lo, min(lo + sub_batch, stop)))
+        lo = blocks[-1][1]
+    if edge:
+        blocks.append((stop, B))
 
     slot_read = [None, None]  # per input staging slot: the event of the upload that last read it
 

@@ -712,6 +712,11 @@ def main():
     run_iva("auxlap_ip1_n9", N=9, F=10, T=80, algo="IP", contrast="laplace", seed=163, n_iter=6)
     run_iva("auxgauss_ip1_n16_mdp", N=16, F=6, T=128, algo="IP", contrast="gauss", seed=164,
             gen=gen_mixture, n_iter=4, scale_restoration="minimal_distortion_principle")
+    run_ilrma("gilrma_ip2_n9", N=9, F=8, T=72, K=2, algo="IP2", seed=169, gen=gen_mixture, n_iter=4)
+    run_ilrma("gilrma_iss2_n10", N=10, F=8, T=80, K=3, algo="ISS2", seed=170, n_iter=4)
+    run_iva("auxlap_ip2_n9", N=9, F=8, T=72, algo="IP2", contrast="laplace", seed=171, n_iter=4)
+    run_iva("auxlap_iss2_n12", N=12, F=6, T=96, algo="ISS2", contrast="laplace", seed=172,
+            gen=gen_mixture, n_iter=4)
     # --- operators ---
     run_operators()
     run_pairwise_operators()
