@@ -68,8 +68,8 @@ enum { SSSPY_SOURCE_ME = 0x100 };
 #define SSSPY_MAX_SOURCES 8 /* kernels compiled per source count (everything in registers) */
 /* Above that, up to SSSPY_RT_MAX_SOURCES, the shared operators, the AuxIVA entry points and the ILRMA
  * iteration on the Gauss model's tuned passes run with the source count at run time (wide_n.hip:
- * correct, not tuned; the reference has no limit: ssspy/bss/ilrma.py:180, iva.py:152).  IP2 / ISS2 /
- * IPA, the MNMF entry points and the Hermitian operators stay at SSSPY_MAX_SOURCES. */
+ * correct, not tuned; the reference has no limit: ssspy/bss/ilrma.py:180, iva.py:152).  IPA, the MNMF
+ * entry points and the Hermitian operators stay at SSSPY_MAX_SOURCES. */
 #define SSSPY_RT_MAX_SOURCES 16
 #define SSSPY_MAX_BASIS 1024
 #define SSSPY_MAX_PAIRS 128 /* every pair of 16 sources: 120 */
@@ -225,6 +225,12 @@ int ssspy_eigh(const void *A, double *lamb, void *V, long long n, int M, void *s
 /* Hermitise, floor the eigenvalues, rebuild, Hermitise.  replaces: ssspy/special/psd.py:11-71. */
 int ssspy_to_psd(const void *A, void *out, long long n, int M, int floor_kind, double floor_eps,
                  void *stream);
+/* out = P diag(w) P^H, Hermitised when `hermitise`: the rebuild half of to_psd / invsqrtmh for an
+ * eigenvalue map the kernels cannot run (any flooring callable: ssspy_eigh -> the callable on the
+ * (n, M) eigenvalues on the host -> this).  P (n, M, M) c128, w (n, M) f64, any M.
+ * replaces: ssspy/special/psd.py:54-69, ssspy/linalg/sqrtm.py:58-64. */
+int ssspy_herm_rebuild(const void *P, const double *w, void *out, long long n, int M, int hermitise,
+                       void *stream);
 
 /* generalised 2x2 Hermitian eigenproblem via Cholesky of B; type 1: A z = l B z, 2: A B z = l z,
  * 3: B A z = l z.  lamb (n,2) ascending, Z (n,2,2).  `info` counts non-positive-definite B.

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "ssspy_inv2": (_i, [_p, _p, _q, _p]),
     "ssspy_eigh": (_i, [_p, _p, _p, _q, _i, _p]),
     "ssspy_to_psd": (_i, [_p, _p, _q, _i, _i, _d, _p]),
+    "ssspy_herm_rebuild": (_i, [_p, _p, _p, _q, _i, _i, _p]),
     "ssspy_eigh2": (_i, [_p, _p, _p, _p, _q, _i, _p, _p]),
     "ssspy_ilrma_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "ssspy_ilrma_update_basis": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _i, _d, _p, _z,

@@ -168,11 +168,41 @@ __global__ __launch_bounds__(256) void k_eigh2(const c128 *__restrict__ A, const
   Z[idx * 4 + 3] = z1[1];
 }
 
+// out = P diag(w) P^H (optionally Hermitised), dimension at run time: one thread per entry.
+// The second half of to_psd / invsqrtmh when the eigenvalue map is a host callable
+// (ref: ssspy/special/psd.py:54-69, ssspy/linalg/sqrtm.py:58-64).
+__global__ __launch_bounds__(256) void k_herm_rebuild(const c128 *__restrict__ P,
+                                                      const double *__restrict__ w, c128 *out,
+                                                      long long n, int M, int hermitise) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * M * M) return;
+  const long long idx = e / (M * M);
+  const int a = (int)(e % (M * M)) / M, c = (int)(e % M);
+  const c128 *Pm = P + idx * M * M;
+  const double *wm = w + idx * M;
+  c128 ac = cmake(0.0, 0.0), ca = cmake(0.0, 0.0);
+  for (int k = 0; k < M; ++k) {
+    const c128 pa = cscale(Pm[a * M + k], wm[k]), pc = cscale(Pm[c * M + k], wm[k]);
+    ac = cadd(ac, cmulc(pa, Pm[c * M + k]));  // P[a][k] w[k] conj(P[c][k])
+    ca = cadd(ca, cmulc(pc, Pm[a * M + k]));
+  }
+  out[e] = hermitise ? cmake(0.5 * (ac.x + ca.x), 0.5 * (ac.y - ca.y)) : ac;
+}
+
 }  // namespace ssspy
 
 using namespace ssspy;
 
 extern "C" {
+
+int ssspy_herm_rebuild(const void *P, const double *w, void *out, long long n, int M, int hermitise,
+                       void *stream) {
+  SSSPY_REQUIRE(P && w && out && n > 0 && M >= 1, "herm_rebuild: bad argument");
+  const long long total = n * M * M;
+  hipLaunchKernelGGL(k_herm_rebuild, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), (const c128 *)P, w, (c128 *)out, n, M, hermitise);
+  return check_launch("k_herm_rebuild");
+}
 
 int ssspy_solve(const void *A, const void *Bm, void *X, long long n, int N, int nrhs, int *info,
                 void *stream) {

@@ -135,8 +135,27 @@ def eigh2(A: np.ndarray, B: Optional[np.ndarray] = None, type: int = 1
     return dv.to_host(lamb).reshape(lead + (2,)), (z if complex_in else z.real)
 
 
+def herm_rebuild(P: np.ndarray, w: np.ndarray, hermitise: bool = False) -> np.ndarray:
+    """``P diag(w) P^H`` on the device (optionally Hermitised): the rebuild half of ``to_psd`` /
+    ``invsqrtmh`` when the eigenvalue map is a host callable."""
+    P, w = np.asarray(P), np.asarray(w, dtype=np.float64)
+    lead, n, Pf = _flat(P, 2)
+    M = Pf.shape[-1]
+    dP = dv.to_device(Pf, dtype=np.complex128)
+    dw = dv.to_device(w.reshape(n, M))
+    out = dv.empty((n, M, M), dv.c128, dP.device)
+    _lib.check(_lib.load().ssspy_herm_rebuild(ptr(dP), ptr(dw), ptr(out), n, M, int(bool(hermitise)),
+                                              dv.stream_handle()), "herm_rebuild")
+    res = dv.to_host(out).reshape(lead + (M, M))
+    return res if np.iscomplexobj(P) else res.real
+
+
 def _hermitian_fn(X, inverse, flooring):
     X = np.asarray(X)
+    host = getattr(flooring, "host", None)
+    if host is not None:  # invsqrtmh with an arbitrary callable: eigh -> host map -> rebuild
+        lamb, P = eigh(X)
+        return herm_rebuild(P, 1.0 / np.asarray(host(np.sqrt(lamb)), dtype=np.float64))
     lead, n, Xf = _flat(X, 2)
     M = Xf.shape[-1]
     dX = dv.to_device(Xf)
@@ -156,7 +175,7 @@ def invsqrtmh(X: np.ndarray, flooring_fn=None) -> np.ndarray:
     """Inverse square root, ``P diag(1 / flooring_fn(sqrt(lamb))) P^H`` (ref: sqrtm.py:27-64)."""
     from ..utils.flooring import device_flooring
 
-    return _hermitian_fn(X, True, device_flooring(flooring_fn))
+    return _hermitian_fn(X, True, device_flooring(flooring_fn, allow_host=True))
 
 
 def gmeanmh(A: np.ndarray, B: np.ndarray, type: int = 1) -> np.ndarray:

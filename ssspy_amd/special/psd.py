@@ -32,7 +32,15 @@ def to_psd(
     axis1 = nd + axis1 if axis1 < 0 else axis1
     axis2 = nd + axis2 if axis2 < 0 else axis2
     assert axis1 == nd - 2 and axis2 == nd - 1, "axis1 == -2 and axis2 == -1"
-    floor = device_flooring(flooring_fn)
+    floor = device_flooring(flooring_fn, allow_host=True)
+    if floor.host is not None:
+        # an arbitrary callable: Hermitise, eigh on the device, the callable on the eigenvalues on the
+        # host (it sees the reference's (..., M) array), rebuild + Hermitise on the device
+        from ..linalg import eigh, herm_rebuild
+
+        Xh = (X + X.swapaxes(-2, -1).conj()) / 2 if np.iscomplexobj(X) else (X + X.swapaxes(-2, -1)) / 2
+        lamb, P = eigh(Xh)
+        return herm_rebuild(P, np.asarray(floor.host(lamb), dtype=np.float64), hermitise=True)
     lead = X.shape[:-2]
     n = int(np.prod(lead, dtype=np.int64)) if lead else 1
     M = X.shape[-1]

@@ -503,6 +503,26 @@ def run_lqpqm_singular():
     save("lqpqm_singular", **out)
 
 
+def run_psd_custom_floor():
+    """to_psd and invsqrtmh with a flooring callable that is none of the reference's three
+    (ssspy/special/psd.py:11-71, ssspy/linalg/sqrtm.py:27-64)."""
+    if skipped("psd_custom_floor"):
+        return
+    from ssspy.linalg import invsqrtmh
+
+    out = {}
+    for M in (2, 3, 4, 6):
+        rng = np.random.default_rng(190 + M)
+        A = rng.standard_normal((5, 7, M, M)) + 1j * rng.standard_normal((5, 7, M, M))
+        H = A @ A.swapaxes(-2, -1).conj() - 0.5 * np.eye(M)      # indefinite Hermitian
+        Hp = A @ A.swapaxes(-2, -1).conj() + 1e-9 * np.eye(M)    # positive definite, some tiny eigenvalues
+        Hp[0, 0] = 1e-20 * np.eye(M)
+        out["m{}_H".format(M)], out["m{}_Hp".format(M)] = H, Hp
+        out["m{}_psd".format(M)] = to_psd(H, flooring_fn=custom_floor)
+        out["m{}_invsqrt".format(M)] = invsqrtmh(Hp, flooring_fn=custom_floor)
+    save("psd_custom_floor", **out)
+
+
 def run_pairwise_operators():
     """update_by_ip2 / update_by_iss2 on random operands (ssspy/bss/_update_spatial_model.py:81-143,
     197-314): default (sequential) pairs, every combination, an explicit list with negative and
@@ -721,6 +741,7 @@ def main():
     run_operators()
     run_pairwise_operators()
     run_lqpqm_singular()
+    run_psd_custom_floor()
 
 
 if __name__ == "__main__":

@@ -2214,3 +2214,19 @@ def test_mnmf_n_basis_beyond_256_against_oracle(cls, K):
     np.testing.assert_allclose(m.loss, ref.loss, rtol=1e-8)
     assert rel_err(m.basis, ref.basis) < 1e-7 and rel_err(m.activation, ref.activation) < 1e-7
     assert rel_err(Y, Yr) < 1e-6
+
+
+@pytest.mark.parametrize("M", [2, 3, 4, 6])
+def test_to_psd_and_invsqrtmh_with_a_custom_floor_against_golden(M):
+    """A flooring callable the kernels cannot run: eigen-decomposition on the device, the callable on
+    the (..., M) eigenvalues on the host, P diag(.) P^H back on the device (ssspy_herm_rebuild).
+    ref: ssspy/special/psd.py:11-71, ssspy/linalg/sqrtm.py:27-64."""
+    from ssspy_amd.linalg import invsqrtmh
+    from ssspy_amd.special import to_psd
+
+    g = load_golden("psd_custom_floor")
+    out = to_psd(g["m{}_H".format(M)], flooring_fn=_golden_custom_floor)
+    assert rel_err(out, g["m{}_psd".format(M)]) < 1e-10
+    assert np.all(np.linalg.eigvalsh(out) > 0)
+    out = invsqrtmh(g["m{}_Hp".format(M)], flooring_fn=_golden_custom_floor)
+    assert rel_err(out, g["m{}_invsqrt".format(M)]) < 1e-9
