@@ -126,6 +126,19 @@ static inline int source_group(int N, int F, int T, int K, double domain, int so
   return 0;
 }
 
+// shapes that may take the wide-basis path of wide_basis.hip (its buffers are sized for them; the
+// source model, which the workspace query does not know, decides at the call)
+// The register-tiled passes win up to 32 bases (16: 1.0 ms, 32: 1.6 ms per iteration at 32 mixtures of
+// the configs[1] shape); from 33 on their four-k-tile form (4.1-4.7 ms) loses to the dense products
+// (3.1-3.2 ms; 80: 4.1, 128: 4.6, 256: 7.1, 1024: 22.8 -- benchmarks/wide_basis.py, round 4).
+// SSSPY_AMD_WIDE_BASIS_MIN_K (development): smallest n_basis on the wide-basis path
+static inline bool wide_basis_shape(int N, int K) {
+  static const int min_k = [] {
+    const char *e = std::getenv("SSSPY_AMD_WIDE_BASIS_MIN_K");
+    return e ? std::atoi(e) : 33;
+  }();
+  return K >= min_k || N > SSSPY_MAX_SOURCES;
+}
 // The general form (any source count above 4, e.g. 5 or 7): the B N sources of the batch, in memory
 // order, are cut into at most three runs of `count` groups of G sources each -- groups of 4 and one
 // or two closing groups of 3 / 2 sources -- and every run is one launch of the tuned kernels on its
@@ -137,6 +150,7 @@ struct SourceRun {
 static inline int source_runs(int B, int N, int F, int T, int K, double domain, int source_model,
                               SourceRun (&run)[3]) {
   if (N <= 4) return 0;
+  if (K > 32 && wide_basis_shape(N, K)) return 0;  // the dense products win from 33 bases on
   if (const int G = source_group(N, F, T, K, domain, source_model)) {
     run[0] = SourceRun{0, B * (N / G), G};
     return 1;
@@ -632,19 +646,6 @@ extern "C" {
 struct IlrmaWs {
   size_t act_part, btmp, qbuf, psi, lslots, bpart, upart, praw, ybuf, wbuf, gb, gnd, total;
 };
-// shapes that may take the wide-basis path of wide_basis.hip (its buffers are sized for them; the
-// source model, which the workspace query does not know, decides at the call)
-// The register-tiled passes win up to 32 bases (16: 1.0 ms, 32: 1.6 ms per iteration at 32 mixtures of
-// the configs[1] shape); from 33 on their four-k-tile form (4.1-4.7 ms) loses to the dense products
-// (3.1-3.2 ms; 80: 4.1, 128: 4.6, 256: 7.1, 1024: 22.8 -- benchmarks/wide_basis.py, round 4).
-// SSSPY_AMD_WIDE_BASIS_MIN_K (development): smallest n_basis on the wide-basis path
-static inline bool wide_basis_shape(int N, int K) {
-  static const int min_k = [] {
-    const char *e = std::getenv("SSSPY_AMD_WIDE_BASIS_MIN_K");
-    return e ? std::atoi(e) : 33;
-  }();
-  return K >= min_k || N > SSSPY_MAX_SOURCES;
-}
 static inline IlrmaWs ilrma_ws(int B, int N, int F, int T, int K) {
   IlrmaWs w;
   size_t off = 0;
@@ -750,8 +751,9 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
   char *ws = (char *)workspace;
   hipStream_t st = as_stream(stream);
   if (loss_done) *loss_done = false;
-  SSSPY_REQUIRE(!x_is_power || (!W && grouped_path(B, N, F, T, K, domain, source_model)),
-                "update_basis: power input off the grouped path");
+  SSSPY_REQUIRE(!x_is_power || (!W && (grouped_path(B, N, F, T, K, domain, source_model) ||
+                                       wide_basis_shape(N, K))),
+                "update_basis: power input off the grouped / wide-basis path");
   // above 16 bases the update cannot be in place (several items per bin group read the old basis)
   double *out = K > 16 ? (double *)(ws + w.btmp) : basis;
   bool in_place = false;
@@ -840,7 +842,8 @@ static int update_activation_impl(const void *X, const void *W, const double *ba
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   SourceRun runs[3];
   const int nruns = source_runs(B, N, F, T, K, domain, source_model, runs);
-  SSSPY_REQUIRE(!x_is_power || (nruns && !W), "update_activation: power input off the grouped path");
+  SSSPY_REQUIRE(!x_is_power || (!W && (nruns || wide_basis_shape(N, K))),
+                "update_activation: power input off the grouped / wide-basis path");
   if (!nruns && small_path(B, N, F, T, K, domain, source_model)) {
     // a handful of mixtures: the latency kernel and its own fold (in place)
     ILRMA_FAST_DISPATCH(N, ilrma_small_activation, X, W, basis, activation, B, F, T, K, floor_kind,
@@ -943,17 +946,6 @@ static int wcov_into(const void *X, const void *W, const double *basis, const do
     if (rc) return rc;
     return rt_covariance(X, X, wbuf, SSSPY_WEIGHT_BIN_FRAME, U, d.B, N, N, d.F, d.T, st);
   }
-  if (N > 4 && wbuf && wide_weighted_cov_ok(N, N, d.F, d.T, SSSPY_WEIGHT_BIN_FRAME)) {
-    const void *Y = Ysep ? Ysep : (W ? nullptr : X);
-    const bool ypow = Ysep && ysep_is_power;
-    if (d.model == SSSPY_SOURCE_GAUSS || Y) {
-      const int chunks = iss_weight_chunks(d.B, N, d.F, d.T);
-      dim3 grid(((d.F + 63) / 64) * chunks, N, d.B), block(256);
-      hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, st, ypow ? nullptr : (const c128 *)Y,
-                         ypow ? (const double *)Y : nullptr, basis, activation, wbuf, N, d, chunks);
-      return wide_weighted_cov(X, wbuf, SSSPY_WEIGHT_BIN_FRAME, U, d.B, N, N, d.F, d.T, st);
-    }
-  }
   if (wbuf && d.K > 32 && wide_basis_shape(N, d.K) &&
       (d.model == SSSPY_SOURCE_GAUSS || Ysep || !W)) {
     // n_basis above 64: the weight kernel walks any n_basis on the matrix cores; the covariance is
@@ -964,6 +956,17 @@ static int wcov_into(const void *X, const void *W, const double *basis, const do
                            ypow ? nullptr : Y, wbuf, nullptr, d.B * N, d.F, d.T, d.K, d, st);
     if (rc) return rc;
     return ssspy_weighted_covariance(X, wbuf, SSSPY_WEIGHT_BIN_FRAME, U, d.B, N, N, d.F, d.T, st);
+  }
+  if (N > 4 && wbuf && wide_weighted_cov_ok(N, N, d.F, d.T, SSSPY_WEIGHT_BIN_FRAME)) {
+    const void *Y = Ysep ? Ysep : (W ? nullptr : X);
+    const bool ypow = Ysep && ysep_is_power;
+    if (d.model == SSSPY_SOURCE_GAUSS || Y) {
+      const int chunks = iss_weight_chunks(d.B, N, d.F, d.T);
+      dim3 grid(((d.F + 63) / 64) * chunks, N, d.B), block(256);
+      hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, st, ypow ? nullptr : (const c128 *)Y,
+                         ypow ? (const double *)Y : nullptr, basis, activation, wbuf, N, d, chunks);
+      return wide_weighted_cov(X, wbuf, SSSPY_WEIGHT_BIN_FRAME, U, d.B, N, N, d.F, d.T, st);
+    }
   }
   if (fast_path(N, d.F, d.T, d.K, d.p, d.model) && (d.model == SSSPY_SOURCE_GAUSS || W)) {
     ILRMA_FAST_DISPATCH(N, ilrma_fast_wcov, X, W, basis, activation, U, d.B, d.F, d.T, d.K, upart,
@@ -1146,6 +1149,13 @@ static int ip1_update_impl(const void *X, const void *C, void *W, double *basis,
   if (grouped_path(B, N, F, T, K, domain, source_model)) {
     // (the passes that follow need |y|^2 only: the NMF passes, and the weights of a heavy-tailed
     // covariance pass)
+    rc = separate_power(X, W, (double *)(ws + w.ybuf), B, N, F, T, st);
+    if (rc) return rc;
+    Xs = ws + w.ybuf;
+    Ws = nullptr;
+    xs_is_power = true;
+  } else if (wide_basis_shape(N, K) && !(K <= 32 && fast_path(N, F, T, K, domain, source_model))) {
+    // dense-product path (wide_basis.hip): |W x|^2 once for both source updates and the weights
     rc = separate_power(X, W, (double *)(ws + w.ybuf), B, N, F, T, st);
     if (rc) return rc;
     Xs = ws + w.ybuf;
