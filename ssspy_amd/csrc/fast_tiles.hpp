@@ -245,6 +245,42 @@ __device__ __forceinline__ void xtile_load_transposed(XTile<NC> &xt, const XSrc<
   xtile_transpose<NC>(xt, c, q, patch);
 }
 
+// The tile shared by the NG waves that work on the same 16 bins (one per source group): wave g
+// fetches channels g*NC/NG ... only, all of them write one patch (NC * 16 rows of 17 slots) and
+// every wave reads the whole tile back transposed.  Two workgroup barriers per tile -- the patch of
+// the previous tile has been read by everyone / the writes of this one have landed -- so EVERY wave
+// of the workgroup must walk the same tiles.  Halves (NG = 2) the global loads and the LDS writes
+// of the private form; the waves of a bin tile no longer fetch the same lines twice.
+template <int NC, int NG>
+__device__ __forceinline__ void xtile_load_shared(XTile<NC> &xt, const XSrc<NC> &src, int T, int i0,
+                                                  int j0, int c, int q, int g, c128 *patch) {
+  static_assert(NC % NG == 0, "channels split evenly over the source groups");
+  constexpr int PER = NC / NG;
+  const unsigned voff = ((unsigned)(i0 + q) * (unsigned)T + (unsigned)min(j0 + c, T - 1)) * 16u;
+  u32x4_t ld[PER][4];
+#pragma unroll
+  for (int gg = 0; gg < NG; ++gg)
+    if (gg == g) {  // wave-uniform: the descriptor stays in scalar registers
+#pragma unroll
+      for (int mm = 0; mm < PER; ++mm)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          ld[mm][rr] = __builtin_amdgcn_raw_buffer_load_b128(src.ch[gg * PER + mm], voff,
+                                                             4u * rr * (unsigned)T * 16u, 0);
+    }
+  __syncthreads();  // the previous tile has been read out of the patch by every wave
+#pragma unroll
+  for (int mm = 0; mm < PER; ++mm)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+      patch[((g * PER + mm) * 16 + 4 * rr + q) * 17 + c] = c128_from(ld[mm][rr]);
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < NC; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xt.x[m][r] = patch[(m * 16 + c) * 17 + q + 4 * r];
+}
+
 // (lane = frame, register = bin) -> (lane = bin, register = frame) through the wave's LDS patch
 template <int NC>
 __device__ __forceinline__ void xtile_transpose(XTile<NC> &xt, int c, int q, c128 *patch) {

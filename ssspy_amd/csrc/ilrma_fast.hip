@@ -516,6 +516,13 @@ constexpr int WC_NG = (N + WC_SG - 1) / WC_SG;   // source groups
 constexpr int WC_WB = 4 / WC_NG;                 // bin tiles per workgroup
 
 constexpr int WC_BINS = 16 * WC_WB;              // bins per workgroup
+// two source groups (4 channels): the waves of a bin tile share its x tile (xtile_load_shared)
+#ifdef SSSPY_WCOV_PRIVATE_TILE
+constexpr bool WC_SHARE = false;
+#else
+constexpr bool WC_SHARE = WC_NG == 2 && N == 4;
+#endif
+static_assert(!WC_SHARE || WC_WB * N * 16 * 17 <= 4 * XPATCH, "shared x patches fit the array");
 
 // grid: 1-D, see TailPlan.  Unsplit blocks store U directly; split blocks store their partial sums
 // (already scaled by 1/T) to `upart` ([tail item][chunk][WC_BINS][N][N][N]) for k_wcov_fold.
@@ -544,6 +551,7 @@ __global__ __launch_bounds__(256, KS >= 16 ? 1 : 2) void k_wcov_fast(const c128 
   const int i0 = (work.group * WC_WB + wb) * 16;
   const int bin = min(i0 + c, F - 1);
   const fast::XSrc<N> xsrc = fast::make_xsrc<N>(X + (long long)b * N * F * T, F, T);
+  c128 *xshare = &xpatch[0][0] + wb * (N * 16 * 17);  // WC_SHARE: one patch per bin tile
   const double *act_b = act + (long long)b * N * K * T;
   double tb[SG][KS];
 #pragma unroll
@@ -580,7 +588,14 @@ __global__ __launch_bounds__(256, KS >= 16 ? 1 : 2) void k_wcov_fast(const c128 
         const int kk = 4 * ks + q, n = min(s0 + s, N - 1);
         va[s][ks] = (kk < K && jv < T) ? act_b[((long long)n * K + kk) * T + jv] : 0.0;
       }
-    fast::xtile_load_transposed<N>(cur, xsrc, T, i0, j0, c, q, xpatch[wave]);
+    if constexpr (WC_SHARE) {
+      // the two source-group waves of a bin tile fetch HALF of its channels each and exchange them
+      // through the tile's LDS patch: every byte of x enters the CU once
+      fast::xtile_load_shared<N, WC_NG>(cur, xsrc, T, i0, j0, c, q,
+                                         __builtin_amdgcn_readfirstlane(g), xshare);
+    } else {
+      fast::xtile_load_transposed<N>(cur, xsrc, T, i0, j0, c, q, xpatch[wave]);
+    }
     double4_t R[SG];
 #pragma unroll
     for (int s = 0; s < SG; ++s) {
@@ -671,6 +686,8 @@ __global__ __launch_bounds__(256, 2) void k_wcov_frame_fast(const c128 *__restri
   const int s0 = g * SG;
   const int i0 = (group * WC_WB + wb) * 16;
   const c128 *Xb = X + (long long)b * N * F * T;  // flat loads: measured faster here (A/B, round 2)
+  const fast::XSrc<N> xsrc = fast::make_xsrc<N>(Xb, F, T);
+  c128 *xshare = &xpatch[0][0] + wb * (N * 16 * 17);  // WC_SHARE: one patch per bin tile
   const double *wgt = weight + (long long)b * N * T;
   CovAcc<N, SG> acc;
   acc.clear();
@@ -678,7 +695,12 @@ __global__ __launch_bounds__(256, 2) void k_wcov_frame_fast(const c128 *__restri
   XTile cur;
   for (int jt = 0; jt < ntiles; ++jt) {
     const int j0 = jt * 16;
-    fast::xtile_load_transposed<N>(cur, Xb, F, T, i0, j0, c, q, xpatch[wave]);
+    if constexpr (WC_SHARE) {
+      fast::xtile_load_shared<N, WC_NG>(cur, xsrc, T, i0, j0, c, q,
+                                         __builtin_amdgcn_readfirstlane(g), xshare);
+    } else {
+      fast::xtile_load_transposed<N>(cur, Xb, F, T, i0, j0, c, q, xpatch[wave]);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int j = j0 + q + 4 * r;

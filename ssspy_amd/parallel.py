@@ -13,6 +13,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import _device as dv
+
 
 def rank_world() -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
@@ -168,7 +170,10 @@ def separate_pipelined(make_separator: Callable[[], object], X, sub_batch: int, 
             nxt = upload(k + 1)
         compute.wait_event(ev_up)
         sep = make_separator()
-        yd = sep.call_on_device(xd, n_iter=n_iter, **call_kwargs)
+        # the separator's initial state (random basis / activation: host work) is uploaded without
+        # waiting for the previous sub-batch, so the host prepares k + 1 while the device iterates on k
+        with dv.staged_uploads():
+            yd = sep.call_on_device(xd, n_iter=n_iter, **call_kwargs)
         done = torch.cuda.Event()
         done.record(compute)
         # the staging slot of download k was last used by download k - 2: retire it first
