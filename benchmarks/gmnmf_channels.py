@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""GaussMNMF per-iteration time against the number of channels (M = N), F = 513, T = 256, K = 8,
+`batch` mixtures; and the states after 3 iterations of the packed per-point kernels against the
+full-storage ones (SSSPY_AMD_GMNMF_FULL=1 in a child process).
+
+    python benchmarks/gmnmf_channels.py [batch] [M ...]
+"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ssspy_amd.bss.mnmf import GaussMNMF  # noqa: E402
+from ssspy_amd.utils.dataset import nmf_mixture  # noqa: E402
+
+F, T, K = 513, 256, 8
+
+
+def run(B, M, iters=6):
+    X = np.stack([nmf_mixture(4000 + b, M, F, T) for b in range(B)])
+    m = GaussMNMF(n_basis=K, record_loss=True, rng=np.random.default_rng(0))
+    m._bind_input(X)
+    m._reset()
+    for _ in range(3):
+        m.update_once()
+    loss3 = np.asarray(m.compute_loss())
+    state = {k: np.asarray(getattr(m, k)).copy() for k in ("basis", "activation", "spatial")}
+    state["loss"] = loss3
+    state["output"] = np.asarray(m.separate(m.input))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        m.update_once()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / iters, state
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        B, M, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+        ms, state = run(B, M)
+        np.savez(out, ms=ms, **state)
+        sys.exit(0)
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    Ms = [int(a) for a in sys.argv[2:]] or [2, 3, 4, 5, 6, 7, 8]
+    base = None
+    for M in Ms:
+        ms, state = run(B, M)
+        tmp = "/tmp/gmnmf_full_%d.npz" % M
+        env = dict(os.environ, SSSPY_AMD_GMNMF_FULL="1")
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", str(B), str(M),
+                               tmp], env=env)
+        ref = np.load(tmp)
+        dev = {k: float(np.max(np.abs(state[k] - ref[k])) / max(np.max(np.abs(ref[k])), 1e-300))
+               for k in state}
+        if M == 4:
+            base = ms
+        print(json.dumps({"channels": M, "batch": B, "ms_per_iter": round(ms, 3),
+                          "full_storage_ms_per_iter": round(float(ref["ms"]), 3),
+                          "speedup": round(float(ref["ms"]) / ms, 2),
+                          "vs_4_channels": round(ms / base, 2) if base else None,
+                          "max_rel_dev_after_3_iterations": {k: float("%.2e" % v)
+                                                             for k, v in dev.items()}}))

@@ -11,8 +11,11 @@
 //   tr(R^-1 XX R^-1 H_n) = c1 u^H H_n u + c0 tr(R^-1 H_n R^-1),   tr(R^-1 H_n).
 //
 // replaces: ssspy/bss/mnmf.py:681-1073 (GaussMNMF), :300-414 (MNMF), special/psd.py, linalg/mean.py.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "hermitian.hpp"
+#include "herm_packed.hpp"
 #include "ssspy_amd.h"
 
 namespace ssspy {
@@ -149,7 +152,9 @@ __global__ __launch_bounds__(128) void k_gmnmf_traces(const c128 *__restrict__ X
                                                       const c128 *__restrict__ H,
                                                       double *__restrict__ A,
                                                       double *__restrict__ Bt, int N, int F, int T,
-                                                      int K, int floor_kind, double eps) {
+                                                      int K, int floor_kind, double eps,
+                                                      const int *__restrict__ flags) {
+  if (flags && !flags[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   c128 *Hs = reinterpret_cast<c128 *>(smem);
   double *Ts = reinterpret_cast<double *>(Hs + N * M * M);
@@ -206,18 +211,22 @@ __global__ __launch_bounds__(128) void k_gmnmf_traces(const c128 *__restrict__ X
   }
 }
 
-// basis[b,n,i,k] <- floor(basis * sqrt(sum_j V A / sum_j V Bt)).  grid: (F, N, B), 256 threads;
-// wave w takes k = w, w+4, ...
+// basis[b,n,i,k] <- floor(basis * sqrt(sum_j V A / sum_j V Bt)).  grid: (ceil(F/4), N, B), 256
+// threads: wave w takes bin 4 bx + w and walks the basis index (one wave per (source, bin) row of
+// A / Bt, which stays in L1 over the walk; a block per row and a wave per basis index left the
+// launch at 16 k tiny workgroups, dispatch-bound).  The sum of a (row, k) is taken lane-strided over
+// the frames and folded by wave_sum, the same order whatever the grid.
 // raw != NULL (partitioning): the (num, den) pairs go to raw[b,n,i,k,2] instead
 __global__ __launch_bounds__(256) void k_gmnmf_basis(double *basis, const double *__restrict__ act,
                                                      const double *__restrict__ A,
                                                      const double *__restrict__ Bt, int N, int F,
                                                      int T, int K, int floor_kind, double eps,
                                                      double *raw) {
-  const int i = blockIdx.x, n = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wave, n = blockIdx.y, b = blockIdx.z;
+  if (i >= F) return;
   const long long row = (((long long)b * N + n) * F + i) * T;
-  for (int k = wave; k < K; k += 4) {
+  for (int k = 0; k < K; ++k) {
     const double *v = act + (((long long)b * N + n) * K + k) * T;
     double sn = 0.0, sd = 0.0;
     for (int j = lane; j < T; j += 64) {
@@ -435,7 +444,9 @@ __global__ __launch_bounds__(GM_PB) void k_gmnmf_spatial_acc(const c128 *__restr
                                                            const c128 *__restrict__ H,
                                                            double *__restrict__ PQacc, int N, int F,
                                                            int T, int K, int floor_kind,
-                                                           double eps) {
+                                                           double eps,
+                                                           const int *__restrict__ flags) {
+  if (flags && !flags[blockIdx.y * gridDim.x + blockIdx.x]) return;
   constexpr int E = 2 * M * M;     // packed doubles per point: R^-1 then R^-1 XX R^-1
   constexpr int ROW = E + GM_NMAX;  // doubles per point in LDS
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -508,7 +519,9 @@ template <int M>
 __global__ __launch_bounds__(64) void k_gmnmf_spatial_update(c128 *H,
                                                              const double *__restrict__ PQacc,
                                                              long long count, int floor_kind,
-                                                             double eps) {
+                                                             double eps,
+                                                             const int *__restrict__ flags) {
+  if (flags && !flags[blockIdx.x]) return;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= count) return;
   c128 Hm[M][M], Qm[M][M], Tm[M][M], C[M][M], Pv[M][M];
@@ -575,7 +588,8 @@ __global__ __launch_bounds__(128) void k_gmnmf_loss(const c128 *__restrict__ X,
                                                     const double *__restrict__ act,
                                                     const c128 *__restrict__ H, double *out, int N,
                                                     int F, int T, int K, int floor_kind,
-                                                    double eps) {
+                                                    double eps, const int *__restrict__ flags) {
+  if (flags && !flags[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double red[2];
   c128 *Hs = reinterpret_cast<c128 *>(smem);
@@ -615,14 +629,22 @@ __global__ __launch_bounds__(128) void k_gmnmf_separate(const c128 *__restrict__
                                                         const c128 *__restrict__ H,
                                                         c128 *__restrict__ Y, int N, int F, int T,
                                                         int K, int ref, int floor_kind,
-                                                        double eps) {
+                                                        double eps, int only_marked) {
+  const int i = blockIdx.y, b = blockIdx.z;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  // only_marked: k_gmnmf_separate_p ran first and left NaN in the first source of the points it
+  // could not finish (a NaN the data itself produced is recomputed to the same NaN)
+  bool mine = j < T;
+  if (only_marked && mine) {
+    const double probe = Y[(((long long)b * N) * F + i) * T + j].x;
+    mine = probe != probe;
+  }
+  if (only_marked && !__syncthreads_or(mine ? 1 : 0)) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   c128 *Hs = reinterpret_cast<c128 *>(smem);
   double *Ts = reinterpret_cast<double *>(Hs + N * M * M);
-  const int i = blockIdx.y, b = blockIdx.z;
   stage_bin<M>(Hs, Ts, H, basis, b, N, F, K, i);
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= T) return;
+  if (!mine) return;
   Point<M> pt;
   point_setup<M>(pt, X + (long long)b * M * F * T, act + (long long)b * N * K * T, Hs, Ts, N, F, T,
                  K, i, j, floor_kind, eps);
@@ -634,10 +656,671 @@ __global__ __launch_bounds__(128) void k_gmnmf_separate(const c128 *__restrict__
   }
 }
 
+// ===================================================================== packed per-point path
+// The kernels above keep R, its Cholesky factor, R^-1 and R^-2 as four full M x M complex matrices
+// per lane: 1 000-1 300 spilled registers at 8 channels, and every spatial matrix entry is an LDS
+// read all lanes make at the same address (the LDS return path, not the FMAs, sets their pace).
+// The *_p kernels below are the same computations on ONE packed Hermitian matrix per lane, inverted
+// in place (herm_packed.hpp), with the spatial matrices and the basis row of the block's bin read
+// through the scalar cache (they are wave-uniform: s_load, operands in SGPRs, no LDS at all):
+//   R = sum_n lambda_n (H_n + H_n^H) / 2   (what hermitize() leaves of sum_n lambda_n H_n),
+//   tr(R^-1 H), tr(E H) for Hermitian R^-1, E: sum_a A_aa Re H_aa + sum_{a<c} [ Re A_ac (Re H_ac +
+//   Re H_ca) + Im A_ac (Im H_ac - Im H_ca) ]  -- exact for any H, Hermitian or not.
+// They take the fast route of psd_inverse() only (Cholesky, no eigenvalue below the floor); a block
+// in which any point leaves it raises flags[block], and the full-storage kernel of the same name
+// then recomputes exactly the flagged blocks (launched after every *_p kernel; `flags == nullptr`
+// means "all blocks").
+template <int M>
+struct PointP {
+  double lam[GM_NMAX];
+  HermP<M> Rinv;
+  double logdet;
+  c128 x[M], u[M];
+  bool ok;
+};
+
+// R^-1, log det, x, u from the accumulated R (shared tail of the two point_setup_p forms)
+template <int M>
+__device__ __forceinline__ void point_finish_p(PointP<M> &pt, const c128 *__restrict__ Xb, int F,
+                                               int T, int i, int j, int floor_kind, double eps) {
+  if (floor_kind == SSSPY_FLOOR_ADD) {
+#pragma unroll
+    for (int a = 0; a < M; ++a) pt.Rinv.d[a] += eps;
+  }
+  bool ok = hp_chol_inverse<M>(pt.Rinv, pt.logdet);
+  if (floor_kind == SSSPY_FLOOR_MAX) ok = ok && (hp_fro2<M>(pt.Rinv) * eps * eps < 1.0);
+  pt.ok = ok;
+#pragma unroll
+  for (int m = 0; m < M; ++m) pt.x[m] = Xb[((long long)m * F + i) * T + j];
+  hp_matvec<M>(pt.Rinv, pt.x, pt.u);
+}
+
+// Hb: spatial matrices of this (mixture, bin), source n at Hb + n * hstride (hstride = F M M);
+// Tb: basis rows of this (mixture, bin), source n at Tb + n * tstride (tstride = F K); both uniform
+// over the block
+template <int M>
+__device__ __forceinline__ void point_setup_p(PointP<M> &pt, const c128 *__restrict__ Xb,
+                                              const double *__restrict__ act_b,
+                                              const c128 *__restrict__ Hb, long long hstride,
+                                              const double *__restrict__ Tb, long long tstride,
+                                              int N, int F, int T, int K, int i, int j,
+                                              int floor_kind, double eps) {
+  hp_clear<M>(pt.Rinv);
+#pragma unroll
+  for (int n = 0; n < GM_NMAX; ++n) {
+    double l = 0.0;
+    if (n < N) {
+      for (int k = 0; k < K; ++k)
+        l = fma(Tb[n * tstride + k], act_b[((long long)n * K + k) * T + j], l);
+      const c128 *Hn = Hb + n * hstride;
+      const double hl = 0.5 * l;
+#pragma unroll
+      for (int a = 0; a < M; ++a) {
+        pt.Rinv.d[a] = fma(l, Hn[a * M + a].x, pt.Rinv.d[a]);
+#pragma unroll
+        for (int c = a + 1; c < M; ++c) {
+          const c128 hu = Hn[a * M + c], hd = Hn[c * M + a];
+          c128 &r = pt.Rinv.o[tri<M>(a, c)];
+          r.x = fma(hl, hu.x + hd.x, r.x);
+          r.y = fma(hl, hu.y - hd.y, r.y);
+        }
+      }
+    }
+    pt.lam[n] = l;
+  }
+  point_finish_p<M>(pt, Xb, F, T, i, j, floor_kind, eps);
+}
+
+// The same from the packed symmetric parts k_gm_pack_spatial leaves per (mixture, bin):
+// Hq[n * M * M + ...] = diagonal Re H_aa, then per upper entry (Re H_ac + Re H_ca, Im H_ac - Im H_ca);
+// sources n >= N hold zeros.  One scalar operand per FMA, no additions, no branches.
+template <int M>
+__device__ __forceinline__ void point_setup_q(PointP<M> &pt, const c128 *__restrict__ Xb,
+                                              const double *__restrict__ act_b,
+                                              const double *__restrict__ Hq,
+                                              const double *__restrict__ Tb, long long tstride,
+                                              int N, int F, int T, int K, int i, int j,
+                                              int floor_kind, double eps) {
+  hp_clear<M>(pt.Rinv);
+#pragma unroll
+  for (int n = 0; n < GM_NMAX; ++n) {
+    double l = 0.0;
+    if (n < N) {
+      for (int k = 0; k < K; ++k)
+        l = fma(Tb[n * tstride + k], act_b[((long long)n * K + k) * T + j], l);
+      const double *Hn = Hq + n * (M * M);
+      const double hl = 0.5 * l;
+#pragma unroll
+      for (int a = 0; a < M; ++a) pt.Rinv.d[a] = fma(l, Hn[a], pt.Rinv.d[a]);
+#pragma unroll
+      for (int e = 0; e < (M * (M - 1)) / 2; ++e) {
+        pt.Rinv.o[e].x = fma(hl, Hn[M + 2 * e], pt.Rinv.o[e].x);
+        pt.Rinv.o[e].y = fma(hl, Hn[M + 2 * e + 1], pt.Rinv.o[e].y);
+      }
+    }
+    pt.lam[n] = l;
+  }
+  point_finish_p<M>(pt, Xb, F, T, i, j, floor_kind, eps);
+}
+
+// Hq[b, i, n < 8, M M] from H[b, n, i, M, M]; one thread per (b, i, n, slot)
+template <int M>
+__global__ __launch_bounds__(256) void k_gm_pack_spatial(const c128 *__restrict__ H,
+                                                         double *__restrict__ Hq, int N, int F,
+                                                         long long count) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  const int slot = (int)(e % (M * M));
+  const int n = (int)((e / (M * M)) % GM_NMAX);
+  const long long bi = e / ((long long)M * M * GM_NMAX);
+  const int i = (int)(bi % F);
+  const long long b = bi / F;
+  double v = 0.0;
+  if (n < N) {
+    const c128 *Hn = H + ((b * N + n) * F + i) * (M * M);
+    if (slot < M) {
+      v = Hn[slot * M + slot].x;
+    } else {
+      // slot M + 2 t (+ 1): upper entry t in row-major order
+      const int t = (slot - M) >> 1;
+      int a = 0, rem = t;
+      while (rem >= M - 1 - a) {
+        rem -= M - 1 - a;
+        ++a;
+      }
+      const int c = a + 1 + rem;
+      const c128 hu = Hn[a * M + c], hd = Hn[c * M + a];
+      v = ((slot - M) & 1) ? hu.y - hd.y : hu.x + hd.x;
+    }
+  }
+  Hq[e] = v;
+}
+
+// raise the block's flag when any of its points left the fast route (every thread calls this)
+__device__ __forceinline__ void flag_block(bool ok, int *__restrict__ flags, int block) {
+  const int bad = __syncthreads_or(ok ? 0 : 1);
+  if (threadIdx.x == 0) flags[block] = bad;
+}
+
+__device__ __forceinline__ int flat_block() {
+  return (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+}
+
+// A, Bt as k_gmnmf_traces, from the packed symmetric parts Hq (k_gm_pack_spatial).
+// NP = 4 or 8: sources compiled in (the padding sources of Hq are zero).  grid: (ceil(T/128), F, B)
+template <int M, int NP>
+__global__ __launch_bounds__(128) void k_gmnmf_traces_p(const c128 *__restrict__ X,
+                                                        const double *__restrict__ basis,
+                                                        const double *__restrict__ act,
+                                                        const double *__restrict__ Hq,
+                                                        double *__restrict__ A,
+                                                        double *__restrict__ Bt, int N, int F,
+                                                        int T, int K, int floor_kind, double eps,
+                                                        int *__restrict__ flags) {
+  const int i = blockIdx.y, b = blockIdx.z;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = j < T;
+  const int jc = live ? j : T - 1;
+  const double *Hb = Hq + ((long long)b * F + i) * (GM_NMAX * M * M);
+  PointP<M> pt;
+  point_setup_q<M>(pt, X + (long long)b * M * F * T, act + (long long)b * N * K * T, Hb,
+                   basis + ((long long)b * N * F + i) * K, (long long)F * K, N, F, T, K, i, jc,
+                   floor_kind, eps);
+  double s = 0.0;
+#pragma unroll
+  for (int m = 0; m < M; ++m) s += cabs2(pt.x[m]);
+  double c1, c0;
+  xx_floor_coeffs(s, floor_kind, eps, c1, c0);
+  double accA[NP], accB[NP];
+#pragma unroll
+  for (int n = 0; n < NP; ++n) accA[n] = accB[n] = 0.0;
+  // entry by entry: E = c1 u u^H + c0 R^-2 and G = R^-1, both Hermitian; the entry is formed once
+  // and met with the sources' spatial entries (scalar operands)
+#pragma unroll
+  for (int a = 0; a < M; ++a) {
+    const double r2 = c0 != 0.0 ? hp_square_entry<M>(pt.Rinv, a, a).x : 0.0;
+    const double e = fma(c1, cabs2(pt.u[a]), c0 * r2), g = pt.Rinv.d[a];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+      const double h = Hb[n * (M * M) + a];
+      accA[n] = fma(h, e, accA[n]);
+      accB[n] = fma(h, g, accB[n]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < M; ++a)
+#pragma unroll
+    for (int c = a + 1; c < M; ++c) {
+      c128 r2 = cmake(0.0, 0.0);
+      if (c0 != 0.0) r2 = hp_square_entry<M>(pt.Rinv, a, c);
+      const c128 uu = cmulc(pt.u[a], pt.u[c]);  // u_a conj(u_c)
+      const double ex = fma(c1, uu.x, c0 * r2.x), ey = fma(c1, uu.y, c0 * r2.y);
+      const c128 g = pt.Rinv.o[tri<M>(a, c)];
+      const int slot = M + 2 * tri<M>(a, c);
+#pragma unroll
+      for (int n = 0; n < NP; ++n) {
+        const double hs = Hb[n * (M * M) + slot], hm = Hb[n * (M * M) + slot + 1];
+        accA[n] = fma(ex, hs, accA[n]);
+        accA[n] = fma(ey, hm, accA[n]);
+        accB[n] = fma(g.x, hs, accB[n]);
+        accB[n] = fma(g.y, hm, accB[n]);
+      }
+    }
+  if (live) {
+#pragma unroll
+    for (int n = 0; n < NP; ++n)
+      if (n < N) {
+        const long long o = (((long long)b * N + n) * F + i) * T + j;
+        A[o] = accA[n];
+        Bt[o] = accB[n];
+      }
+  }
+  flag_block(pt.ok || !live, flags, flat_block());
+}
+
+// loss slots as k_gmnmf_loss.  grid: (ceil(T/128), F, B)
+template <int M>
+__global__ __launch_bounds__(128) void k_gmnmf_loss_p(const c128 *__restrict__ X,
+                                                      const double *__restrict__ basis,
+                                                      const double *__restrict__ act,
+                                                      const c128 *__restrict__ H, double *out,
+                                                      int N, int F, int T, int K, int floor_kind,
+                                                      double eps, int *__restrict__ flags) {
+  __shared__ double red[2];
+  const int i = blockIdx.y, b = blockIdx.z;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = j < T;
+  const int jc = live ? j : T - 1;
+  PointP<M> pt;
+  point_setup_p<M>(pt, X + (long long)b * M * F * T, act + (long long)b * N * K * T,
+                   H + ((long long)b * N * F + i) * (M * M), (long long)F * (M * M),
+                   basis + ((long long)b * N * F + i) * K, (long long)F * K, N, F, T, K, i, jc,
+                   floor_kind, eps);
+  double s = 0.0, xu = 0.0, trR = 0.0;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    s += cabs2(pt.x[m]);
+    xu = fma(pt.x[m].x, pt.u[m].x, xu);
+    xu = fma(pt.x[m].y, pt.u[m].y, xu);
+    trR += pt.Rinv.d[m];
+  }
+  double c1, c0;
+  xx_floor_coeffs(s, floor_kind, eps, c1, c0);
+  const double term = live ? fma(c1, xu, c0 * trR) + pt.logdet : 0.0;
+  const double total = block_sum(term, red);
+  if (threadIdx.x == 0)
+    out[((long long)blockIdx.y * gridDim.x + blockIdx.x) * gridDim.z + b] = total / (double)T;
+  flag_block(pt.ok || !live, flags, flat_block());
+}
+
+// Y as k_gmnmf_separate; a point that leaves the fast route stores NaN in its first source, which
+// the full-storage kernel (launched next with `only_marked`) recomputes.  grid: (ceil(T/128), F, B)
+template <int M>
+__global__ __launch_bounds__(128) void k_gmnmf_separate_p(const c128 *__restrict__ X,
+                                                          const double *__restrict__ basis,
+                                                          const double *__restrict__ act,
+                                                          const c128 *__restrict__ H,
+                                                          c128 *__restrict__ Y, int N, int F,
+                                                          int T, int K, int ref, int floor_kind,
+                                                          double eps) {
+  const int i = blockIdx.y, b = blockIdx.z;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= T) return;
+  const long long hstride = (long long)F * (M * M);
+  const c128 *Hb = H + ((long long)b * N * F + i) * (M * M);
+  PointP<M> pt;
+  point_setup_p<M>(pt, X + (long long)b * M * F * T, act + (long long)b * N * K * T, Hb, hstride,
+                   basis + ((long long)b * N * F + i) * K, (long long)F * K, N, F, T, K, i, j,
+                   floor_kind, eps);
+  const double nan = __builtin_nan("");
+#pragma unroll
+  for (int n = 0; n < GM_NMAX; ++n)
+    if (n < N) {
+      c128 y = cmake(0.0, 0.0);
+#pragma unroll
+      for (int c = 0; c < M; ++c) cfma(y, Hb[n * hstride + ref * M + c], pt.u[c]);
+      y = cscale(y, pt.lam[n]);
+      if (n == 0 && !pt.ok) y = cmake(nan, nan);
+      Y[(((long long)b * N + n) * F + i) * T + j] = y;
+    }
+}
+
+// PQacc as k_gmnmf_spatial_acc.  grid: (F, B), one wave: lanes take frames; per chunk of 64 frames
+// the packed matrices of the points go through LDS and are folded with the N weights in register
+// tiles: thread (eg, ng) owns the value pair 2 eg, 2 eg + 1 for NPT sources, so a point costs it
+// one pair read + NPT weight reads for 2 NPT FMAs (the slot-per-thread fold of the full-storage
+// kernel reads two values per FMA, and its 70 KB of LDS at 8 channels leave half the SIMDs idle).
+// From 6 channels on the two matrices of a point (R^-1, then R^-1 XX R^-1) take turns in the rows:
+// 37 KB per workgroup at 8 channels, one workgroup per SIMD.
+constexpr int gm_pow2_floor(int v) { return v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1)); }
+
+template <int EW>  // value slots per row (even); the N weights follow at EW .. EW + 7
+struct GmFold {
+  static constexpr int EG = EW / 2;
+  static constexpr int NG = gm_pow2_floor(64 / EG);
+  static constexpr int NPT = GM_NMAX / NG;
+  static constexpr int ROW = EW + GM_NMAX + 1;  // odd: rows of neighbouring lanes on distinct banks
+};
+
+template <int EW>
+__device__ __forceinline__ void gm_fold_chunk(const double *pts,
+                                              double (&acc)[GmFold<EW>::NPT][2]) {
+  using S = GmFold<EW>;
+  const int eg = threadIdx.x % S::EG, ng = threadIdx.x / S::EG;
+  if (ng >= S::NG) return;
+  const double *v = pts + 2 * eg, *l = pts + EW + ng * S::NPT;
+  for (int p = 0; p < GM_PB; ++p) {
+    const double v0 = v[p * S::ROW], v1 = v[p * S::ROW + 1];
+#pragma unroll
+    for (int q = 0; q < S::NPT; ++q) {
+      const double lq = l[p * S::ROW + q];
+      acc[q][0] = fma(lq, v0, acc[q][0]);
+      acc[q][1] = fma(lq, v1, acc[q][1]);
+    }
+  }
+}
+
+template <int EW>
+__device__ __forceinline__ void gm_fold_store(const double (&acc)[GmFold<EW>::NPT][2],
+                                              double *__restrict__ dst, int N, int limit,
+                                              long long nstride) {
+  using S = GmFold<EW>;
+  const int eg = threadIdx.x % S::EG, ng = threadIdx.x / S::EG;
+  if (ng >= S::NG) return;
+#pragma unroll
+  for (int q = 0; q < S::NPT; ++q) {
+    const int n = ng * S::NPT + q;
+    if (n < N) {
+      if (2 * eg < limit) dst[n * nstride + 2 * eg] = acc[q][0];
+      if (2 * eg + 1 < limit) dst[n * nstride + 2 * eg + 1] = acc[q][1];
+    }
+  }
+}
+
+template <int M>
+__global__ __launch_bounds__(GM_PB) void k_gmnmf_spatial_acc_p(const c128 *__restrict__ X,
+                                                             const double *__restrict__ basis,
+                                                             const double *__restrict__ act,
+                                                             const double *__restrict__ Hq,
+                                                             double *__restrict__ PQacc, int N,
+                                                             int F, int T, int K, int floor_kind,
+                                                             double eps, int *__restrict__ flags) {
+  constexpr bool SPLIT = M >= 6;
+  constexpr int MM2 = M * M;
+  constexpr int EW = SPLIT ? ((MM2 + 1) & ~1) : 2 * MM2;  // value slots per row
+  using S = GmFold<EW>;
+  constexpr int ROW = S::ROW;
+  constexpr int PASSES = SPLIT ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *pts = reinterpret_cast<double *>(smem);  // [GM_PB][ROW]
+  const int i = blockIdx.x, b = blockIdx.y;
+  const c128 *Xb = X + (long long)b * M * F * T;
+  const double *act_b = act + (long long)b * N * K * T;
+  const double *Hb = Hq + ((long long)b * F + i) * (GM_NMAX * M * M);
+  const double *Tb = basis + ((long long)b * N * F + i) * K;
+  double acc[PASSES][S::NPT][2];
+#pragma unroll
+  for (int h = 0; h < PASSES; ++h)
+#pragma unroll
+    for (int q = 0; q < S::NPT; ++q) acc[h][q][0] = acc[h][q][1] = 0.0;
+  bool all_ok = true;
+  double *mine = pts + threadIdx.x * ROW;
+  for (int j0 = 0; j0 < T; j0 += GM_PB) {
+    const int j = j0 + threadIdx.x;
+    const bool live = j < T;
+    PointP<M> pt;
+    point_setup_q<M>(pt, Xb, act_b, Hb, Tb, (long long)F * K, N, F, T, K, i, live ? j : T - 1,
+                     floor_kind, eps);
+    all_ok = all_ok && (pt.ok || !live);
+    double s = 0.0;
+#pragma unroll
+    for (int m = 0; m < M; ++m) s += cabs2(pt.x[m]);
+    double c1, c0;
+    xx_floor_coeffs(s, floor_kind, eps, c1, c0);
+    // packed R^-1 (diagonal first, then re / im of the upper triangle, as pack_hermitian), weights
+#pragma unroll
+    for (int a = 0; a < M; ++a) mine[a] = pt.Rinv.d[a];
+#pragma unroll
+    for (int e = 0; e < (M * (M - 1)) / 2; ++e) {
+      mine[M + 2 * e] = pt.Rinv.o[e].x;
+      mine[M + 2 * e + 1] = pt.Rinv.o[e].y;
+    }
+    if (SPLIT && (MM2 & 1)) mine[MM2] = 0.0;
+#pragma unroll
+    for (int n = 0; n < GM_NMAX; ++n) mine[EW + n] = live ? pt.lam[n] : 0.0;
+    constexpr int QOFF = SPLIT ? 0 : MM2;  // where packed Q = c1 u u^H + c0 R^-2 goes
+    if (SPLIT) {
+      __syncthreads();
+      gm_fold_chunk<EW>(pts, acc[0]);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+      const double r2 = c0 != 0.0 ? hp_square_entry<M>(pt.Rinv, a, a).x : 0.0;
+      mine[QOFF + a] = fma(c1, cabs2(pt.u[a]), c0 * r2);
+    }
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+      for (int c = a + 1; c < M; ++c) {
+        const int e = M + 2 * tri<M>(a, c);
+        c128 r2 = cmake(0.0, 0.0);
+        if (c0 != 0.0) r2 = hp_square_entry<M>(pt.Rinv, a, c);
+        const c128 uu = cmulc(pt.u[a], pt.u[c]);
+        mine[QOFF + e] = fma(c1, uu.x, c0 * r2.x);
+        mine[QOFF + e + 1] = fma(c1, uu.y, c0 * r2.y);
+      }
+    __syncthreads();
+    gm_fold_chunk<EW>(pts, acc[PASSES - 1]);
+    __syncthreads();
+  }
+  double *dst = PQacc + ((long long)b * N * F + i) * (2 * MM2);
+  const long long nstride = (long long)F * (2 * MM2);
+  if (SPLIT) {
+    gm_fold_store<EW>(acc[0], dst, N, MM2, nstride);
+    gm_fold_store<EW>(acc[PASSES - 1], dst + MM2, N, MM2, nstride);
+  } else {
+    gm_fold_store<EW>(acc[0], dst, N, 2 * MM2, nstride);
+  }
+  flag_block(all_ok, flags, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+// H <- to_psd(P^-1 # to_psd(H Q H)) as k_gmnmf_spatial_update, on its fast route: while no eigenvalue
+// floor acts (every to_psd is the identity, or "+ eps I" for the add floor) the geometric mean
+//   P^-1 # B = V (V^-1 B V^-H)^(1/2) V^H   for ANY factor P^-1 = V V^H
+// (G P G = B has one positive definite solution), and with P = U^H U (Cholesky), V = U^-1 this needs
+// ONE eigen-decomposition -- of U B U^H -- where the literal route takes four, on packed matrices
+// that fit the register file.  "No floor acts" is checked, not assumed: B, P and the result must
+// have every eigenvalue above eps (sufficient bounds: 1 / ||A^-1||_F > eps; for P the cheaper
+// ||U^-1||_F^2 < 1 / eps); a block of 64 matrices with any failure stores nothing, raises its flag
+// and is redone by the literal kernel.  One lane per (b, n, i); the block's H matrices are staged
+// in LDS ([entry][lane], coalesced both ways) and the region then parks U^-1 during the sweeps.
+constexpr int GSU_LD = 65;  // lanes per staged entry + 1: the transposing copies hit distinct banks
+// c128 entries of the region per lane: the M x M matrix, or (two turns) the rows of the first turn
+// followed by the parked S0 (M^2 doubles)
+template <int M>
+constexpr int gsu_park_at() {
+  return M >= 7 ? 4 * M : 0;
+}
+template <int M>
+constexpr int gsu_entries() {
+  constexpr int need = (M + 1) / 2 + (M * (M - 1)) / 2;
+  return M >= 7 && gsu_park_at<M>() + need > M * M ? gsu_park_at<M>() + need : M * M;
+}
+
+// One turn of the eigenvector accumulation of k_gmnmf_spatial_update_p: rows TURN * NRH ... of
+// W = V J (V = U^-1 from the packed P at `pq`, formed here; J diagonalises S0) into the region,
+// w = sqrt(max(eigenvalues, 0)).  S0 is consumed; with two turns the first parks it behind its rows
+// and the second picks it up there.
+template <int M, int TURN>
+__device__ __forceinline__ void gsu_turn(HermP<M> &S0, double (&w)[M], c128 *park,
+                                         const double *__restrict__ pq, int floor_kind,
+                                         double eps) {
+  constexpr int NRH = M >= 7 ? 4 : M;  // rows per turn
+  constexpr int TURNS = (M + NRH - 1) / NRH;
+  constexpr int AT = gsu_park_at<M>();
+  if (TURNS > 1 && TURN == 0) {
+#pragma unroll
+    for (int a = 0; a + 1 < M; a += 2) park[(AT + a / 2) * GSU_LD] = cmake(S0.d[a], S0.d[a + 1]);
+    if (M & 1) park[(AT + M / 2) * GSU_LD] = cmake(S0.d[M - 1], 0.0);
+#pragma unroll
+    for (int e = 0; e < (M * (M - 1)) / 2; ++e) park[(AT + (M + 1) / 2 + e) * GSU_LD] = S0.o[e];
+  }
+  if (TURN > 0) {
+#pragma unroll
+    for (int a = 0; a + 1 < M; a += 2) {
+      const c128 z = park[(AT + a / 2) * GSU_LD];
+      S0.d[a] = z.x;
+      S0.d[a + 1] = z.y;
+    }
+    if (M & 1) S0.d[M - 1] = park[(AT + M / 2) * GSU_LD].x;
+#pragma unroll
+    for (int e = 0; e < (M * (M - 1)) / 2; ++e) S0.o[e] = park[(AT + (M + 1) / 2 + e) * GSU_LD];
+  }
+  c128 W[NRH][M];
+  {
+    HermP<M> Vm;
+#pragma unroll
+    for (int a = 0; a < M; ++a) Vm.d[a] = pq[a] + (floor_kind == SSSPY_FLOOR_ADD ? eps : 0.0);
+#pragma unroll
+    for (int e = 0; e < (M * (M - 1)) / 2; ++e) Vm.o[e] = cmake(pq[M + 2 * e], pq[M + 2 * e + 1]);
+    double dinv[M], ld;
+    hp_chol_upper<M>(Vm, dinv, ld);
+    hp_trtri_upper<M>(Vm, dinv);
+#pragma unroll
+    for (int r = 0; r < NRH; ++r) {
+      constexpr int row0 = TURN * NRH;
+#pragma unroll
+      for (int c = 0; c < M; ++c) {
+        const int row = row0 + r;
+        W[r][c] = (row < M && c > row) ? Vm.o[tri<M>(row < M - 1 ? row : 0, c > row ? c : row + 1)]
+                                       : cmake(0.0, 0.0);
+        if (row < M && c == row) W[r][c] = cmake(Vm.d[row], 0.0);
+      }
+    }
+  }
+  hp_jacobi_rows<M, NRH>(S0, W);
+#pragma unroll
+  for (int k = 0; k < M; ++k) w[k] = sqrt(fmax(S0.d[k], 0.0));
+#pragma unroll
+  for (int r = 0; r < NRH; ++r) {
+    const int row = TURN * NRH + r;
+    if (row < M) {
+#pragma unroll
+      for (int c = 0; c < M; ++c) park[(row * M + c) * GSU_LD] = W[r][c];
+    }
+  }
+}
+
+template <int M>
+__global__ __launch_bounds__(64) void k_gmnmf_spatial_update_p(c128 *H,
+                                                               const double *__restrict__ PQacc,
+                                                               long long count, int floor_kind,
+                                                               double eps, int *__restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  c128 *Hs = reinterpret_cast<c128 *>(smem);  // [gsu_entries<M>()][GSU_LD]
+  const int t = threadIdx.x;
+  const long long idx0 = (long long)blockIdx.x * 64, idx = idx0 + t;
+  const bool live = idx < count;
+  const long long idc = live ? idx : count - 1;
+  for (int g = t; g < 64 * M * M; g += 64) {
+    const int tl = g / (M * M), e = g % (M * M);
+    const long long src = idx0 * (M * M) + g;
+    Hs[e * GSU_LD + tl] = src < count * (M * M) ? H[src] : cmake(0.0, 0.0);
+  }
+  __syncthreads();
+  const c128 *Hme = Hs + (live ? t : (int)(idc - idx0));  // entry e at Hme[e * GSU_LD]
+  bool ok = true;
+  double ld;
+  HermP<M> Bm;
+  {  // B = ((H Q) H + its adjoint) / 2
+    HermP<M> Qm;
+    const double *src = PQacc + idc * (2 * M * M) + M * M;
+#pragma unroll
+    for (int a = 0; a < M; ++a) Qm.d[a] = src[a];
+#pragma unroll
+    for (int e = 0; e < (M * (M - 1)) / 2; ++e) Qm.o[e] = cmake(src[M + 2 * e], src[M + 2 * e + 1]);
+    hp_clear<M>(Bm);
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+      c128 ta[M];  // row a of H Q
+#pragma unroll
+      for (int k = 0; k < M; ++k) ta[k] = cmake(0.0, 0.0);
+#pragma unroll
+      for (int l = 0; l < M; ++l) {
+        const c128 hal = Hme[(a * M + l) * GSU_LD];
+#pragma unroll
+        for (int k = 0; k < M; ++k) cfma(ta[k], hal, hp_get<M>(Qm, l, k));
+      }
+      c128 za[M];  // row a of (H Q) H
+#pragma unroll
+      for (int c = 0; c < M; ++c) za[c] = cmake(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < M; ++k)
+#pragma unroll
+        for (int c = 0; c < M; ++c) cfma(za[c], ta[k], Hme[(k * M + c) * GSU_LD]);
+#pragma unroll
+      for (int c = 0; c < M; ++c) {
+        if (c == a) {
+          Bm.d[a] += za[c].x;
+        } else if (c > a) {
+          Bm.o[tri<M>(a, c)].x = fma(0.5, za[c].x, Bm.o[tri<M>(a, c)].x);
+          Bm.o[tri<M>(a, c)].y = fma(0.5, za[c].y, Bm.o[tri<M>(a, c)].y);
+        } else {
+          Bm.o[tri<M>(c, a)].x = fma(0.5, za[c].x, Bm.o[tri<M>(c, a)].x);
+          Bm.o[tri<M>(c, a)].y = fma(-0.5, za[c].y, Bm.o[tri<M>(c, a)].y);
+        }
+      }
+    }
+    if (floor_kind == SSSPY_FLOOR_ADD) {
+#pragma unroll
+      for (int a = 0; a < M; ++a) Bm.d[a] += eps;
+    }
+    HermP<M> tmp = Bm;
+    ok = hp_chol_inverse<M>(tmp, ld) && ok;
+    if (floor_kind == SSSPY_FLOOR_MAX) ok = ok && (hp_fro2<M>(tmp) * eps * eps < 1.0);
+  }
+  HermP<M> S0;
+  {  // P = U^H U; S0 = U B U^H; V = U^-1 parked in LDS
+    HermP<M> Um;
+    const double *src = PQacc + idc * (2 * M * M);
+#pragma unroll
+    for (int a = 0; a < M; ++a) Um.d[a] = src[a] + (floor_kind == SSSPY_FLOOR_ADD ? eps : 0.0);
+#pragma unroll
+    for (int e = 0; e < (M * (M - 1)) / 2; ++e) Um.o[e] = cmake(src[M + 2 * e], src[M + 2 * e + 1]);
+    double dinv[M];
+    ok = hp_chol_upper<M>(Um, dinv, ld) && ok;
+    hp_congruence_upper<M>(Um, Bm, S0);
+    hp_trtri_upper<M>(Um, dinv);
+    if (floor_kind == SSSPY_FLOOR_MAX) ok = ok && (hp_fro2_upper<M>(Um) * eps < 1.0);
+  }
+  __syncthreads();  // every lane is done with the staged H: the region now holds W and parks S0
+  // W = V J, J the eigenvectors of S0 (S0 = J diag(lam) J^H): G = V S0^(1/2) V^H = W diag(sqrt lam) W^H.
+  // From 7 channels on W (128 doubles) does not fit beside the working copy of S0: its rows go in
+  // two turns of 4, each through the whole rotation sequence; S0 waits in the second half of the
+  // region meanwhile, V is formed again for the second turn (one Cholesky + triangular inverse).
+  c128 *park = Hs + t;  // entry e at park[e * GSU_LD]
+  double w[M];
+  gsu_turn<M, 0>(S0, w, park, PQacc + idc * (2 * M * M), floor_kind, eps);
+  if constexpr (M >= 7) gsu_turn<M, 1>(S0, w, park, PQacc + idc * (2 * M * M), floor_kind, eps);
+  HermP<M> Gm;
+#pragma unroll
+  for (int a = 0; a < M; ++a) {
+    c128 ra[M];  // w_k W_ak
+#pragma unroll
+    for (int k = 0; k < M; ++k) ra[k] = cscale(park[(a * M + k) * GSU_LD], w[k]);
+    double dd = 0.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      const c128 wk = park[(a * M + k) * GSU_LD];
+      dd = fma(ra[k].x, wk.x, dd);
+      dd = fma(ra[k].y, wk.y, dd);
+    }
+    Gm.d[a] = dd;
+#pragma unroll
+    for (int c = a + 1; c < M; ++c) {
+      c128 s2 = cmake(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < M; ++k) {  // ra[k] conj(W_ck)
+        const c128 wc = park[(c * M + k) * GSU_LD];
+        s2.x = fma(ra[k].x, wc.x, s2.x);
+        s2.x = fma(ra[k].y, wc.y, s2.x);
+        s2.y = fma(ra[k].y, wc.x, s2.y);
+        s2.y = fma(-ra[k].x, wc.y, s2.y);
+      }
+      Gm.o[tri<M>(a, c)] = s2;
+    }
+  }
+  if (floor_kind == SSSPY_FLOOR_ADD) {
+#pragma unroll
+    for (int a = 0; a < M; ++a) Gm.d[a] += eps;
+  }
+  if (floor_kind == SSSPY_FLOOR_MAX) {
+    HermP<M> tmp = Gm;
+    ok = hp_chol_inverse<M>(tmp, ld) && ok;
+    ok = ok && (hp_fro2<M>(tmp) * eps * eps < 1.0);
+  }
+  const int bad = __syncthreads_or((ok || !live) ? 0 : 1);
+  if (t == 0) flags[blockIdx.x] = bad;
+  if (bad) return;
+  // coalesced store through the staging region
+  c128 *mine = Hs + t;
+#pragma unroll
+  for (int a = 0; a < M; ++a)
+#pragma unroll
+    for (int c = 0; c < M; ++c) mine[(a * M + c) * GSU_LD] = hp_get<M>(Gm, a, c);
+  __syncthreads();
+  for (int g = t; g < 64 * M * M; g += 64) {
+    const int tl = g / (M * M), e = g % (M * M);
+    const long long dst = idx0 * (M * M) + g;
+    if (dst < count * (M * M)) H[dst] = Hs[e * GSU_LD + tl];
+  }
+}
+
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct GmnmfWs {
-  size_t a, bt, pq, vacc, teff, vrep, raw, vslabs, total;
+  size_t a, bt, pq, vacc, teff, vrep, raw, vslabs, flags, hq, total;
 };
 // bin chunks of the activation sums: enough blocks for the chip at small batches, at most 16
 static inline int gm_act_chunks(int B, int N, int F, int T) {
@@ -672,6 +1355,10 @@ static inline GmnmfWs gmnmf_ws(int B, int N, int M, int F, int T, int K) {
                                  fold_scratch_bytes(vtotal, chunks))
                       : 0;
   }
+  w.flags = off;  // one int per block of the per-point kernels: left the fast route (packed path)
+  off += align256((size_t)((T + 127) / 128) * F * B * sizeof(int));
+  w.hq = off;  // packed symmetric parts of the spatial matrices, [b][i][8][M M] (packed path)
+  off += align256((size_t)B * F * GM_NMAX * M * M * sizeof(double));
   w.total = off;
   return w;
 }
@@ -700,13 +1387,50 @@ static int check_dims(int B, int N, int M, int F, int T, int K) {
   return SSSPY_OK;
 }
 
+// SSSPY_AMD_GMNMF_FULL=1: the full-storage kernels only (A / B, debugging)
+// (2 and 3 channels keep the full-storage kernels: nothing spills there and the packed route's
+// extra launches -- packing, the flag-gated repair kernels -- cost 10 % of a 0.15-0.25 ms iteration)
+static bool packed_points(int M) {
+  static const bool off = std::getenv("SSSPY_AMD_GMNMF_FULL") != nullptr;
+  return !off && M >= 4;
+}
+
+static int launch_pack_spatial(const void *H, double *Hq, int B, int N, int M, int F,
+                               hipStream_t st) {
+  const long long count = (long long)B * F * GM_NMAX * M * M;
+  GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gm_pack_spatial<MM>),
+                                      dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                                      (const c128 *)H, Hq, N, F, count));
+  return check_launch("k_gm_pack_spatial");
+}
+
+// flags, Hq: workspace of the packed path (both or neither)
 static int launch_traces(const void *X, const double *basis, const double *act, const void *H,
                          double *A, double *Bt, int B, int N, int M, int F, int T, int K,
-                         int floor_kind, double eps, hipStream_t st) {
+                         int floor_kind, double eps, int *flags, double *Hq, bool *hq_valid,
+                         hipStream_t st) {
   dim3 grid((T + 127) / 128, F, B), block(128);
+  const bool packed = packed_points(M) && flags != nullptr && Hq != nullptr;
+  if (packed) {
+    int rc = SSSPY_OK;
+    if (!*hq_valid) rc = launch_pack_spatial(H, Hq, B, N, M, F, st);
+    if (rc) return rc;
+    *hq_valid = true;
+    if (N <= 4) {
+      GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_traces_p<MM, 4>), grid, block, 0, st,
+                                          (const c128 *)X, basis, act, (const double *)Hq, A, Bt,
+                                          N, F, T, K, floor_kind, eps, flags));
+    } else {
+      GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_traces_p<MM, 8>), grid, block, 0, st,
+                                          (const c128 *)X, basis, act, (const double *)Hq, A, Bt,
+                                          N, F, T, K, floor_kind, eps, flags));
+    }
+    rc = check_launch("k_gmnmf_traces_p");
+    if (rc) return rc;
+  }
   GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_traces<MM>), grid, block, bin_smem(N, M, K), st,
                                       (const c128 *)X, basis, act, (const c128 *)H, A, Bt, N, F, T,
-                                      K, floor_kind, eps));
+                                      K, floor_kind, eps, packed ? (const int *)flags : nullptr));
   return check_launch("k_gmnmf_traces");
 }
 
@@ -736,6 +1460,9 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
   double *PQ = (double *)(ws + w.pq), *vacc = (double *)(ws + w.vacc);
   double *Teff = (double *)(ws + w.teff), *Vrep = (double *)(ws + w.vrep);
   double *raw = (double *)(ws + w.raw);
+  int *flags = (int *)(ws + w.flags);
+  double *Hq = (double *)(ws + w.hq);
+  bool hq_valid = false;  // Hq holds the packed form of the CURRENT spatial matrices (this call only)
   hipStream_t st = as_stream(stream);
   const bool part = latent != nullptr;
   // the per-source (basis, activation) pair every kernel takes: the state itself, or the expansion
@@ -753,9 +1480,9 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
   auto basis_sums = [&](double *raw_out) -> int {
     int r = refresh();
     if (r) return r;
-    r = launch_traces(X, Tn, Vn, spatial, A, Bt, B, N, M, F, T, K, floor_kind, floor_eps, st);
+    r = launch_traces(X, Tn, Vn, spatial, A, Bt, B, N, M, F, T, K, floor_kind, floor_eps, flags, Hq, &hq_valid, st);
     if (r) return r;
-    hipLaunchKernelGGL(k_gmnmf_basis, dim3(F, N, B), dim3(256), 0, st, basis, Vn,
+    hipLaunchKernelGGL(k_gmnmf_basis, dim3((F + 3) / 4, N, B), dim3(256), 0, st, basis, Vn,
                        (const double *)A, (const double *)Bt, N, F, T, K, floor_kind, floor_eps,
                        raw_out);
     return check_launch("k_gmnmf_basis");
@@ -774,7 +1501,7 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
   if (steps & SSSPY_GMNMF_ACTIVATION) {
     rc = refresh();
     if (rc) return rc;
-    rc = launch_traces(X, Tn, Vn, spatial, A, Bt, B, N, M, F, T, K, floor_kind, floor_eps, st);
+    rc = launch_traces(X, Tn, Vn, spatial, A, Bt, B, N, M, F, T, K, floor_kind, floor_eps, flags, Hq, &hq_valid, st);
     if (rc) return rc;
     const long long count = (long long)B * N * K * T;
     const int chunks = gm_act_chunks(B, N, F, T);
@@ -816,19 +1543,54 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
       }
+      const bool packed = packed_points(M);
+      if (packed) {
+        const int ew_p = MM >= 6 ? ((MM * MM + 1) & ~1) : 2 * MM * MM;
+        const size_t smem_p = (size_t)GM_PB * (ew_p + GM_NMAX + 1) * sizeof(double);
+        if (smem_p > 48 * 1024) {
+          hipError_t e = hipFuncSetAttribute((const void *)k_gmnmf_spatial_acc_p<MM>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)smem_p);
+          if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+        }
+        if (!hq_valid) rc = launch_pack_spatial(spatial, Hq, B, N, M, F, st);
+        if (rc) return rc;
+        hq_valid = true;
+        hipLaunchKernelGGL((k_gmnmf_spatial_acc_p<MM>), dim3(F, B), dim3(GM_PB), smem_p, st,
+                           (const c128 *)X, Tn, Vn, (const double *)Hq, PQ, N, F, T, K,
+                           floor_kind, floor_eps, flags);
+      }
       hipLaunchKernelGGL((k_gmnmf_spatial_acc<MM>), dim3(F, B), dim3(GM_PB), smem, st,
                          (const c128 *)X, Tn, Vn, (const c128 *)spatial, PQ, N, F, T, K,
-                         floor_kind, floor_eps);
+                         floor_kind, floor_eps, packed ? (const int *)flags : nullptr);
     });
     rc = check_launch("k_gmnmf_spatial_acc");
     if (rc) return rc;
     const long long count = (long long)B * N * F;
+    const bool packed_su = packed_points(M);
+    if (packed_su) {
+      GM_DISPATCH_M(M, {
+        const size_t smem_su = (size_t)gsu_entries<MM>() * GSU_LD * sizeof(c128);
+        if (smem_su > 48 * 1024) {
+          hipError_t e = hipFuncSetAttribute((const void *)k_gmnmf_spatial_update_p<MM>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)smem_su);
+          if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL((k_gmnmf_spatial_update_p<MM>), dim3((unsigned)((count + 63) / 64)),
+                           dim3(64), smem_su, st, (c128 *)spatial, (const double *)PQ, count,
+                           floor_kind, floor_eps, flags);
+      });
+      rc = check_launch("k_gmnmf_spatial_update_p");
+      if (rc) return rc;
+    }
     GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_spatial_update<MM>),
                                         dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st,
                                         (c128 *)spatial, (const double *)PQ, count, floor_kind,
-                                        floor_eps));
+                                        floor_eps, packed_su ? (const int *)flags : nullptr));
     rc = check_launch("k_gmnmf_spatial_update");
     if (rc) return rc;
+    hq_valid = false;
   }
   if (steps & SSSPY_GMNMF_NORMALIZE) {
     const long long count = (long long)B * N * F;
@@ -836,6 +1598,7 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
                        (c128 *)spatial, part ? (double *)nullptr : basis, count, M, K);
     rc = check_launch("k_gmnmf_normalize");
     if (rc) return rc;
+    hq_valid = false;
   }
   if (steps & SSSPY_GMNMF_LATENT) {
     rc = basis_sums(raw);
@@ -851,7 +1614,9 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
 
 size_t ssspy_gmnmf_loss_workspace_bytes(int B, int F, int T) {
   if (B <= 0 || F <= 0 || T <= 0) return 0;
-  return scalar_slots_bytes(B, ((T + 127) / 128) * F);
+  // the loss slots, then one flag per block (packed path)
+  return align256(scalar_slots_bytes(B, ((T + 127) / 128) * F)) +
+         align256((size_t)((T + 127) / 128) * F * B * sizeof(int));
 }
 
 int ssspy_gmnmf_loss(const void *X, const double *basis, const double *activation,
@@ -866,9 +1631,20 @@ int ssspy_gmnmf_loss(const void *X, const double *basis, const double *activatio
   hipStream_t st = as_stream(stream);
   dim3 grid((T + 127) / 128, F, B), block(128);
   // (every block writes its slot; the fold stores out[b])
+  int *flags = (int *)((char *)workspace + align256(scalar_slots_bytes(B, (int)grid.x * F)));
+  const bool packed = packed_points(M);
+  if (packed) {
+    GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_loss_p<MM>), grid, block, 0, st, (const c128 *)X,
+                                        basis, activation, (const c128 *)spatial,
+                                        (double *)workspace, N, F, T, K, floor_kind, floor_eps,
+                                        flags));
+    rc = check_launch("k_gmnmf_loss_p");
+    if (rc) return rc;
+  }
   GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_loss<MM>), grid, block, bin_smem(N, M, K), st,
                                       (const c128 *)X, basis, activation, (const c128 *)spatial,
-                                      (double *)workspace, N, F, T, K, floor_kind, floor_eps));
+                                      (double *)workspace, N, F, T, K, floor_kind, floor_eps,
+                                      packed ? (const int *)flags : nullptr));
   rc = check_launch("k_gmnmf_loss");
   return rc ? rc : scalar_slots_fold(workspace, B, (int)grid.x * F, out, 0, st);
 }
@@ -881,10 +1657,19 @@ int ssspy_gmnmf_separate(const void *X, const double *basis, const double *activ
   if (rc) return rc;
   SSSPY_REQUIRE(reference_id >= 0 && reference_id < M, "gmnmf_separate: bad reference_id");
   dim3 grid((T + 127) / 128, F, B), block(128);
+  const bool packed = packed_points(M);
+  if (packed) {
+    GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_separate_p<MM>), grid, block, 0,
+                                        as_stream(stream), (const c128 *)X, basis, activation,
+                                        (const c128 *)spatial, (c128 *)Y, N, F, T, K,
+                                        reference_id, floor_kind, floor_eps));
+    rc = check_launch("k_gmnmf_separate_p");
+    if (rc) return rc;
+  }
   GM_DISPATCH_M(M, hipLaunchKernelGGL((k_gmnmf_separate<MM>), grid, block, bin_smem(N, M, K),
                                       as_stream(stream), (const c128 *)X, basis, activation,
                                       (const c128 *)spatial, (c128 *)Y, N, F, T, K, reference_id,
-                                      floor_kind, floor_eps));
+                                      floor_kind, floor_eps, packed ? 1 : 0));
   return check_launch("k_gmnmf_separate");
 }
 
