@@ -2230,3 +2230,33 @@ def test_to_psd_and_invsqrtmh_with_a_custom_floor_against_golden(M):
     assert np.all(np.linalg.eigvalsh(out) > 0)
     out = invsqrtmh(g["m{}_Hp".format(M)], flooring_fn=_golden_custom_floor)
     assert rel_err(out, g["m{}_invsqrt".format(M)]) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,floor", [(4, 4, "max"), (5, 3, "max"), (6, 6, "add"), (7, 7, "none"),
+                                       (8, 8, "max"), (8, 5, "tiny"), (5, 5, "tiny")])
+def test_gauss_mnmf_packed_route_equals_full_storage_route(M, N, floor, tmp_path):
+    """The packed per-point kernels (in-place Cholesky inverse, one eigen-decomposition per spatial
+    update, flag-gated repair) against the full-storage kernels they replace -- the literal
+    restatement of ssspy/bss/mnmf.py:838-1073 that the goldens pin -- on the same inputs, in two
+    processes (the route is a per-process setting).  "tiny": silent frames and a rank-deficient
+    bin, where the eigenvalue floor acts and the repair kernels must take over."""
+    import os
+    import subprocess
+    import sys
+
+    worker = os.path.join(os.path.dirname(__file__), "_gmnmf_route_worker.py")
+    outs = []
+    for tag, extra in (("packed", {}), ("full", {"SSSPY_AMD_GMNMF_FULL": "1"})):
+        out = str(tmp_path / (tag + ".npz"))
+        env = {k: v for k, v in os.environ.items() if k != "SSSPY_AMD_GMNMF_FULL"}
+        env.update(extra)
+        subprocess.check_call([sys.executable, worker, str(M), str(N), "33", "40", "3", floor, out],
+                              env=env)
+        outs.append(np.load(out))
+    packed, full = outs
+    for key in ("basis", "activation", "spatial", "Y", "loss"):
+        a, b = packed[key], full[key]
+        assert np.isfinite(b).all(), key
+        scale = max(np.max(np.abs(b)), 1e-300)
+        assert np.max(np.abs(a - b)) <= 1e-8 * scale, (key, np.max(np.abs(a - b)) / scale)
