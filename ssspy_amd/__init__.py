@@ -10,15 +10,15 @@ __version__ = "0.1.0"
 
 import os as _os
 
-# The ROCm runtime sizes a queue's scratch (register-spill) memory by the first kernel that needs
-# any; a later kernel that needs more than HSA_SCRATCH_SINGLE_LIMIT (140 MB by default -- 280 bytes
-# per lane on 256 CUs) then gets "use once" scratch, allocated and released around EVERY dispatch:
-# measured 4.7 ms per GaussMNMF iteration at 8 channels when a 4-channel separator had run before
-# it in the process (7.9 against 3.2 ms; profiles/r04_gmnmf_channels.txt).  The kernels concerned
-# are the one-matrix-per-lane fallbacks for 5-8 channels (GaussMNMF, IP2, IPA, eigh: up to 7 KB per
-# lane).  Raising the limit lets the queue keep the larger allocation (<= 3.7 GB).  Read by the
-# runtime when HIP initialises, i.e. effective when this package is imported before the first
-# torch.cuda call; a value already in the environment is left alone.
+# Kernels that spill (the one-matrix-per-lane fallbacks for 5-8 channels: up to 7 KB of scratch per
+# lane) can run into the ROCm runtime's scratch policy: measured on GaussMNMF, a separator of 8
+# channels that followed one of 4 or 7 channels in the same process ran its first iterations at
+# 6.9-7.9 ms instead of 3.2 (benchmarks/gmnmf_channels.py, profiles/r04_gmnmf_channels.txt); with
+# HSA_SCRATCH_SINGLE_LIMIT (default 140 MB per queue, above which scratch is handed out for one
+# dispatch at a time) raised the same sequence ran at 3.2 ms.  The mechanism was not pinned down
+# further -- a plain update_once() loop does not show it.  The limit is read when HIP initialises,
+# so this only acts when the package is imported before the first torch.cuda call; a value already
+# in the environment is left alone.
 _os.environ.setdefault("HSA_SCRATCH_SINGLE_LIMIT", str(8 << 30))
 
 from . import bss  # noqa: F401,E402

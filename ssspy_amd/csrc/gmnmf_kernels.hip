@@ -1112,7 +1112,9 @@ constexpr int gsu_entries() {
 // W = V J (V = U^-1 from the packed P at `pq`, formed here; J diagonalises S0) into the region,
 // w = sqrt(max(eigenvalues, 0)).  S0 is consumed; with two turns the first parks it behind its rows
 // and the second picks it up there.
-template <int M, int TURN>
+// IDENT: the rows start from the identity instead (W = J: the eigenvectors themselves, for the
+// eigenvalue floor of to_psd) and `ev` returns the raw eigenvalues.
+template <int M, int TURN, bool IDENT>
 __device__ __forceinline__ void gsu_turn(HermP<M> &S0, double (&w)[M], c128 *park,
                                          const double *__restrict__ pq, int floor_kind,
                                          double eps) {
@@ -1138,7 +1140,12 @@ __device__ __forceinline__ void gsu_turn(HermP<M> &S0, double (&w)[M], c128 *par
     for (int e = 0; e < (M * (M - 1)) / 2; ++e) S0.o[e] = park[(AT + (M + 1) / 2 + e) * GSU_LD];
   }
   c128 W[NRH][M];
-  {
+  if (IDENT) {
+#pragma unroll
+    for (int r = 0; r < NRH; ++r)
+#pragma unroll
+      for (int c = 0; c < M; ++c) W[r][c] = cmake(TURN * NRH + r == c ? 1.0 : 0.0, 0.0);
+  } else {
     HermP<M> Vm;
 #pragma unroll
     for (int a = 0; a < M; ++a) Vm.d[a] = pq[a] + (floor_kind == SSSPY_FLOOR_ADD ? eps : 0.0);
@@ -1161,7 +1168,7 @@ __device__ __forceinline__ void gsu_turn(HermP<M> &S0, double (&w)[M], c128 *par
   }
   hp_jacobi_rows<M, NRH>(S0, W);
 #pragma unroll
-  for (int k = 0; k < M; ++k) w[k] = sqrt(fmax(S0.d[k], 0.0));
+  for (int k = 0; k < M; ++k) w[k] = IDENT ? S0.d[k] : sqrt(fmax(S0.d[k], 0.0));
 #pragma unroll
   for (int r = 0; r < NRH; ++r) {
     const int row = TURN * NRH + r;
@@ -1170,6 +1177,60 @@ __device__ __forceinline__ void gsu_turn(HermP<M> &S0, double (&w)[M], c128 *par
       for (int c = 0; c < M; ++c) park[(row * M + c) * GSU_LD] = W[r][c];
     }
   }
+}
+
+// Out = W diag(w) W^H from the rows the turns left in the region
+template <int M>
+__device__ __forceinline__ void gsu_rebuild(const c128 *park, const double (&w)[M], HermP<M> &Out) {
+#pragma unroll
+  for (int a = 0; a < M; ++a) {
+    c128 ra[M];  // w_k W_ak
+#pragma unroll
+    for (int k = 0; k < M; ++k) ra[k] = cscale(park[(a * M + k) * GSU_LD], w[k]);
+    double dd = 0.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      const c128 wk = park[(a * M + k) * GSU_LD];
+      dd = fma(ra[k].x, wk.x, dd);
+      dd = fma(ra[k].y, wk.y, dd);
+    }
+    Out.d[a] = dd;
+#pragma unroll
+    for (int c = a + 1; c < M; ++c) {
+      c128 s2 = cmake(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < M; ++k) {  // ra[k] conj(W_ck)
+        const c128 wc = park[(c * M + k) * GSU_LD];
+        s2.x = fma(ra[k].x, wc.x, s2.x);
+        s2.x = fma(ra[k].y, wc.y, s2.x);
+        s2.y = fma(ra[k].y, wc.x, s2.y);
+        s2.y = fma(-ra[k].x, wc.y, s2.y);
+      }
+      Out.o[tri<M>(a, c)] = s2;
+    }
+  }
+}
+
+// A <- to_psd(A) for the max floor: nothing when every eigenvalue is provably above eps in every
+// lane of the wave (1 / ||A^-1||_F > eps); else the whole wave eigen-decomposes, floors and rebuilds
+// (as the spatial matrices converge towards rank one this becomes the common case: from iteration
+// 40 of an 8-channel run every block has such matrices)
+template <int M>
+__device__ __forceinline__ void gsu_floor_max(HermP<M> &A, c128 *park, double eps) {
+  bool above;
+  {
+    HermP<M> tmp = A;
+    double ld;
+    above = hp_chol_inverse<M>(tmp, ld);
+    above = above && (hp_fro2<M>(tmp) * eps * eps < 1.0);
+  }
+  if (__all(above)) return;
+  double ev[M];
+  gsu_turn<M, 0, true>(A, ev, park, nullptr, SSSPY_FLOOR_MAX, eps);
+  if constexpr (M >= 7) gsu_turn<M, 1, true>(A, ev, park, nullptr, SSSPY_FLOOR_MAX, eps);
+#pragma unroll
+  for (int k = 0; k < M; ++k) ev[k] = fmax(ev[k], eps);
+  gsu_rebuild<M>(park, ev, A);
 }
 
 template <int M>
@@ -1236,10 +1297,10 @@ __global__ __launch_bounds__(64) void k_gmnmf_spatial_update_p(c128 *H,
 #pragma unroll
       for (int a = 0; a < M; ++a) Bm.d[a] += eps;
     }
-    HermP<M> tmp = Bm;
-    ok = hp_chol_inverse<M>(tmp, ld) && ok;
-    if (floor_kind == SSSPY_FLOOR_MAX) ok = ok && (hp_fro2<M>(tmp) * eps * eps < 1.0);
   }
+  __syncthreads();  // every lane is done with the staged H: the region now serves the turns
+  c128 *park = Hs + t;  // entry e at park[e * GSU_LD]
+  if (floor_kind == SSSPY_FLOOR_MAX) gsu_floor_max<M>(Bm, park, eps);
   HermP<M> S0;
   {  // P = U^H U; S0 = U B U^H; V = U^-1 parked in LDS
     HermP<M> Um;
@@ -1254,52 +1315,21 @@ __global__ __launch_bounds__(64) void k_gmnmf_spatial_update_p(c128 *H,
     hp_trtri_upper<M>(Um, dinv);
     if (floor_kind == SSSPY_FLOOR_MAX) ok = ok && (hp_fro2_upper<M>(Um) * eps < 1.0);
   }
-  __syncthreads();  // every lane is done with the staged H: the region now holds W and parks S0
   // W = V J, J the eigenvectors of S0 (S0 = J diag(lam) J^H): G = V S0^(1/2) V^H = W diag(sqrt lam) W^H.
   // From 7 channels on W (128 doubles) does not fit beside the working copy of S0: its rows go in
   // two turns of 4, each through the whole rotation sequence; S0 waits in the second half of the
   // region meanwhile, V is formed again for the second turn (one Cholesky + triangular inverse).
-  c128 *park = Hs + t;  // entry e at park[e * GSU_LD]
   double w[M];
-  gsu_turn<M, 0>(S0, w, park, PQacc + idc * (2 * M * M), floor_kind, eps);
-  if constexpr (M >= 7) gsu_turn<M, 1>(S0, w, park, PQacc + idc * (2 * M * M), floor_kind, eps);
+  gsu_turn<M, 0, false>(S0, w, park, PQacc + idc * (2 * M * M), floor_kind, eps);
+  if constexpr (M >= 7)
+    gsu_turn<M, 1, false>(S0, w, park, PQacc + idc * (2 * M * M), floor_kind, eps);
   HermP<M> Gm;
-#pragma unroll
-  for (int a = 0; a < M; ++a) {
-    c128 ra[M];  // w_k W_ak
-#pragma unroll
-    for (int k = 0; k < M; ++k) ra[k] = cscale(park[(a * M + k) * GSU_LD], w[k]);
-    double dd = 0.0;
-#pragma unroll
-    for (int k = 0; k < M; ++k) {
-      const c128 wk = park[(a * M + k) * GSU_LD];
-      dd = fma(ra[k].x, wk.x, dd);
-      dd = fma(ra[k].y, wk.y, dd);
-    }
-    Gm.d[a] = dd;
-#pragma unroll
-    for (int c = a + 1; c < M; ++c) {
-      c128 s2 = cmake(0.0, 0.0);
-#pragma unroll
-      for (int k = 0; k < M; ++k) {  // ra[k] conj(W_ck)
-        const c128 wc = park[(c * M + k) * GSU_LD];
-        s2.x = fma(ra[k].x, wc.x, s2.x);
-        s2.x = fma(ra[k].y, wc.y, s2.x);
-        s2.y = fma(ra[k].y, wc.x, s2.y);
-        s2.y = fma(-ra[k].x, wc.y, s2.y);
-      }
-      Gm.o[tri<M>(a, c)] = s2;
-    }
-  }
+  gsu_rebuild<M>(park, w, Gm);
   if (floor_kind == SSSPY_FLOOR_ADD) {
 #pragma unroll
     for (int a = 0; a < M; ++a) Gm.d[a] += eps;
   }
-  if (floor_kind == SSSPY_FLOOR_MAX) {
-    HermP<M> tmp = Gm;
-    ok = hp_chol_inverse<M>(tmp, ld) && ok;
-    ok = ok && (hp_fro2<M>(tmp) * eps * eps < 1.0);
-  }
+  if (floor_kind == SSSPY_FLOOR_MAX) gsu_floor_max<M>(Gm, park, eps);
   const int bad = __syncthreads_or((ok || !live) ? 0 : 1);
   if (t == 0) flags[blockIdx.x] = bad;
   if (bad) return;

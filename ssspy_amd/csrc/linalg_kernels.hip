@@ -1,7 +1,10 @@
 // Batched small dense linear algebra (one matrix per lane): solve, inv2, Hermitian eigh,
 // generalised 2x2 eigh, PSD projection.  Device counterparts of ssspy.linalg / ssspy.special.psd.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "hermitian.hpp"
+#include "herm_packed.hpp"
 #include "smallmat.hpp"
 
 namespace ssspy {
@@ -89,6 +92,109 @@ __global__ __launch_bounds__(64) void k_eigh(const c128 *__restrict__ A, double 
     for (int r = 0; r < M; ++r)
 #pragma unroll
       for (int c = 0; c < M; ++c) V[(idx * M + r) * M + c] = R[r][c];
+  }
+}
+
+// The same for 6-8 x 6-8 on packed storage (herm_packed.hpp): the matrix being diagonalised takes M^2
+// registers and the eigenvector rows ride the rotations in turns of 4 (from 7 on; each turn repeats
+// the rotation sequence on a fresh copy), so nothing spills where k_eigh<8> parks 3 266 registers
+// in scratch.  Same rotations in the same order as jacobi_eigh: the same eigen-pairs.
+// mode 1 (to_psd) collects the rows in LDS ([entry][lane]) for the rebuild.
+constexpr int EIGH_LD = 65;
+
+template <int M>
+__device__ __forceinline__ void eigh_load_packed(HermP<M> &Ap, const c128 *__restrict__ src) {
+#pragma unroll
+  for (int a = 0; a < M; ++a) {
+    Ap.d[a] = src[a * M + a].x;
+#pragma unroll
+    for (int c = a + 1; c < M; ++c) {
+      const c128 u = src[a * M + c], l = src[c * M + a];
+      Ap.o[tri<M>(a, c)] = cmake(0.5 * (u.x + l.x), 0.5 * (u.y - l.y));
+    }
+  }
+}
+
+template <int M, int TURN>
+__device__ __forceinline__ void eigh_turn(const c128 *__restrict__ src, double *lamb, c128 *V,
+                                          long long idx, bool live, int mode, double (&ev)[M],
+                                          c128 *park) {
+  constexpr int NRH = M >= 7 ? 4 : M;
+  HermP<M> Aw;
+  eigh_load_packed<M>(Aw, src);
+  c128 W[NRH][M];
+#pragma unroll
+  for (int r = 0; r < NRH; ++r)
+#pragma unroll
+    for (int c = 0; c < M; ++c) W[r][c] = cmake(TURN * NRH + r == c ? 1.0 : 0.0, 0.0);
+  hp_jacobi_rows<M, NRH>(Aw, W);
+#pragma unroll
+  for (int k = 0; k < M; ++k) ev[k] = Aw.d[k];
+  if (mode == 0) {
+    if (!live) return;
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      int rank = 0;
+#pragma unroll
+      for (int j = 0; j < M; ++j)
+        rank += (ev[j] < ev[k] || (ev[j] == ev[k] && j < k)) ? 1 : 0;
+      if (TURN == 0) lamb[idx * M + rank] = ev[k];
+#pragma unroll
+      for (int r = 0; r < NRH; ++r) {
+        const int row = TURN * NRH + r;
+        if (row < M) V[(idx * M + row) * M + rank] = W[r][k];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < NRH; ++r) {
+      const int row = TURN * NRH + r;
+      if (row < M) {
+#pragma unroll
+        for (int c = 0; c < M; ++c) park[(row * M + c) * EIGH_LD] = W[r][c];
+      }
+    }
+  }
+}
+
+template <int M>
+__global__ __launch_bounds__(64) void k_eigh_p(const c128 *__restrict__ A, double *lamb, c128 *V,
+                                               long long n, int mode, int floor_kind, double eps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  c128 *park = reinterpret_cast<c128 *>(smem) + threadIdx.x;  // mode 1 only
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = idx < n;
+  const c128 *src = A + (live ? idx : n - 1) * (M * M);
+  double ev[M];
+  eigh_turn<M, 0>(src, lamb, V, idx, live, mode, ev, park);
+  if constexpr (M >= 7) eigh_turn<M, 1>(src, lamb, V, idx, live, mode, ev, park);
+  if (mode == 0 || !live) return;
+  // (every lane reads only the rows it parked itself: no barrier)
+#pragma unroll
+  for (int k = 0; k < M; ++k) ev[k] = apply_floor(ev[k], floor_kind, eps);
+#pragma unroll
+  for (int a = 0; a < M; ++a) {
+    c128 ra[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) ra[k] = cscale(park[(a * M + k) * EIGH_LD], ev[k]);
+#pragma unroll
+    for (int c = a; c < M; ++c) {
+      c128 s2 = cmake(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < M; ++k) {  // ra[k] conj(P_ck)
+        const c128 pc = park[(c * M + k) * EIGH_LD];
+        s2.x = fma(ra[k].x, pc.x, s2.x);
+        s2.x = fma(ra[k].y, pc.y, s2.x);
+        s2.y = fma(ra[k].y, pc.x, s2.y);
+        s2.y = fma(-ra[k].x, pc.y, s2.y);
+      }
+      if (c == a) {
+        V[(idx * M + a) * M + a] = cmake(s2.x, 0.0);
+      } else {
+        V[(idx * M + a) * M + c] = s2;
+        V[(idx * M + c) * M + a] = cconj(s2);
+      }
+    }
   }
 }
 
@@ -223,6 +329,18 @@ int ssspy_inv2(const void *A, void *out, long long n, void *stream) {
 int ssspy_eigh(const void *A, double *lamb, void *V, long long n, int M, void *stream) {
   SSSPY_REQUIRE(A && lamb && V && n > 0, "eigh: bad argument");
   dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  static const bool full_eigh = std::getenv("SSSPY_AMD_EIGH_FULL") != nullptr;  // A / B
+  if (M >= 6 && M <= 8 && !full_eigh) {  // packed storage
+    switch (M) {
+      case 6: hipLaunchKernelGGL((k_eigh_p<6>), grid, block, 0, as_stream(stream), (const c128 *)A,
+                                 lamb, (c128 *)V, n, 0, 0, 0.0); break;
+      case 7: hipLaunchKernelGGL((k_eigh_p<7>), grid, block, 0, as_stream(stream), (const c128 *)A,
+                                 lamb, (c128 *)V, n, 0, 0, 0.0); break;
+      default: hipLaunchKernelGGL((k_eigh_p<8>), grid, block, 0, as_stream(stream), (const c128 *)A,
+                                  lamb, (c128 *)V, n, 0, 0, 0.0); break;
+    }
+    return check_launch("k_eigh_p");
+  }
   DISPATCH_N(M, hipLaunchKernelGGL((k_eigh<NN>), grid, block, 0, as_stream(stream), (const c128 *)A,
                                    lamb, (c128 *)V, n, 0, 0, 0.0));
   return check_launch("k_eigh");
@@ -232,6 +350,27 @@ int ssspy_to_psd(const void *A, void *out, long long n, int M, int floor_kind, d
                  void *stream) {
   SSSPY_REQUIRE(A && out && n > 0, "to_psd: bad argument");
   dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  static const bool full_eigh = std::getenv("SSSPY_AMD_EIGH_FULL") != nullptr;
+  if (M >= 6 && M <= 8 && !full_eigh) {
+    const size_t smem = (size_t)M * M * EIGH_LD * sizeof(c128);
+#define SSSPY_TO_PSD_P(MM_)                                                                          \
+  {                                                                                                  \
+    if (smem > 48 * 1024) {                                                                          \
+      hipError_t e = hipFuncSetAttribute((const void *)k_eigh_p<MM_>,                                \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);     \
+      if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));                         \
+    }                                                                                                \
+    hipLaunchKernelGGL((k_eigh_p<MM_>), grid, block, smem, as_stream(stream), (const c128 *)A,        \
+                       (double *)nullptr, (c128 *)out, n, 1, floor_kind, floor_eps);                  \
+  }
+    switch (M) {
+      case 6: SSSPY_TO_PSD_P(6) break;
+      case 7: SSSPY_TO_PSD_P(7) break;
+      default: SSSPY_TO_PSD_P(8) break;
+    }
+#undef SSSPY_TO_PSD_P
+    return check_launch("k_to_psd_p");
+  }
   DISPATCH_N(M, hipLaunchKernelGGL((k_eigh<NN>), grid, block, 0, as_stream(stream), (const c128 *)A,
                                    (double *)nullptr, (c128 *)out, n, 1, floor_kind, floor_eps));
   return check_launch("k_to_psd");
