@@ -10,9 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ssspy_amd.bss.mnmf import GaussMNMF  # noqa: E402
 
 
-def main():
-    M, N, F, T, K, floor, out = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]),
-                                 int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], sys.argv[7])
+def one(M, N, F, T, K, floor, out):
     rng = np.random.default_rng(7)
     B = 3
     X = rng.standard_normal((B, M, F, T)) + 1j * rng.standard_normal((B, M, F, T))
@@ -27,6 +25,14 @@ def main():
     Y = m(X, n_iter=4)
     np.savez(out, Y=Y, basis=m.basis, activation=m.activation, spatial=m.spatial,
              loss=np.asarray(m.loss))
+
+
+def main():
+    # argv: out_pattern (with {}), then cases "M,N,F,T,K,floor"
+    pattern = sys.argv[1]
+    for spec in sys.argv[2:]:
+        M, N, F, T, K, floor = spec.split(",")
+        one(int(M), int(N), int(F), int(T), int(K), floor, pattern.format(spec.replace(",", "_")))
 
 
 if __name__ == "__main__":

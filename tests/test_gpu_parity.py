@@ -2232,29 +2232,41 @@ def test_to_psd_and_invsqrtmh_with_a_custom_floor_against_golden(M):
     assert rel_err(out, g["m{}_invsqrt".format(M)]) < 1e-9
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("M,N,floor", [(4, 4, "max"), (5, 3, "max"), (6, 6, "add"), (7, 7, "none"),
-                                       (8, 8, "max"), (8, 5, "tiny"), (5, 5, "tiny")])
-def test_gauss_mnmf_packed_route_equals_full_storage_route(M, N, floor, tmp_path):
-    """The packed per-point kernels (in-place Cholesky inverse, one eigen-decomposition per spatial
-    update, flag-gated repair) against the full-storage kernels they replace -- the literal
-    restatement of ssspy/bss/mnmf.py:838-1073 that the goldens pin -- on the same inputs, in two
-    processes (the route is a per-process setting).  "tiny": silent frames and a rank-deficient
-    bin, where the eigenvalue floor acts and the repair kernels must take over."""
+_ROUTE_CASES = [(4, 4, "max"), (5, 3, "max"), (6, 6, "add"), (7, 7, "none"), (8, 8, "max"),
+                (8, 5, "tiny"), (5, 5, "tiny")]
+_ROUTE_CACHE = {}
+
+
+def _gmnmf_route_outputs(tmp_root):
+    """Both routes on every case: one child process per route (the route is a per-process setting)."""
+    if _ROUTE_CACHE:
+        return _ROUTE_CACHE
     import os
     import subprocess
     import sys
 
     worker = os.path.join(os.path.dirname(__file__), "_gmnmf_route_worker.py")
-    outs = []
+    specs = ["{},{},33,40,3,{}".format(M, N, floor) for M, N, floor in _ROUTE_CASES]
     for tag, extra in (("packed", {}), ("full", {"SSSPY_AMD_GMNMF_FULL": "1"})):
-        out = str(tmp_path / (tag + ".npz"))
+        pattern = os.path.join(str(tmp_root), tag + "_{}.npz")
         env = {k: v for k, v in os.environ.items() if k != "SSSPY_AMD_GMNMF_FULL"}
         env.update(extra)
-        subprocess.check_call([sys.executable, worker, str(M), str(N), "33", "40", "3", floor, out],
-                              env=env)
-        outs.append(np.load(out))
-    packed, full = outs
+        subprocess.check_call([sys.executable, worker, pattern] + specs, env=env)
+        for (M, N, floor), spec in zip(_ROUTE_CASES, specs):
+            _ROUTE_CACHE[(tag, M, N, floor)] = dict(np.load(pattern.format(spec.replace(",", "_"))))
+    return _ROUTE_CACHE
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,floor", _ROUTE_CASES)
+def test_gauss_mnmf_packed_route_equals_full_storage_route(M, N, floor, tmp_path_factory):
+    """The packed per-point kernels (in-place Cholesky inverse, one eigen-decomposition per spatial
+    update, floors applied in the kernel, flag-gated repair) against the full-storage kernels they
+    replace -- the literal restatement of ssspy/bss/mnmf.py:838-1073 that the goldens pin -- on the
+    same inputs, in two processes.  "tiny": silent frames and a rank-deficient bin, where the
+    eigenvalue floor acts."""
+    outs = _gmnmf_route_outputs(tmp_path_factory.mktemp("gmnmf_routes"))
+    packed, full = outs[("packed", M, N, floor)], outs[("full", M, N, floor)]
     for key in ("basis", "activation", "spatial", "Y", "loss"):
         a, b = packed[key], full[key]
         assert np.isfinite(b).all(), key
