@@ -506,8 +506,10 @@ int ssspy_fastmnmf_separate(const void *X, const void *Q, const double *D, const
 
 /* ------------------------------------------------------------------ GaussMNMF (full-rank SCM)
  * State: basis (B,N,F,K) f64, activation (B,N,K,T) f64, spatial (B,N,F,M,M) c128 Hermitian PSD
- * (the reference's `spatial` (N,F,M,M) with a batch axis).  n_channels M in [2, 8] (the per-lane
- * M x M kernels are sized for M <= 4; above that they run from scratch memory), no partitioning.
+ * (the reference's `spatial` (N,F,M,M) with a batch axis).  n_channels M in [2, 8]: one lane per
+ * (bin, frame) point or per spatial matrix; from 4 channels on the point lives in one packed
+ * Hermitian matrix inverted in place (herm_packed.hpp) and the full-storage kernels only redo the
+ * blocks whose points leave the fast route of to_psd (flags in the workspace).
  * R_ij = to_psd(sum_n lambda_nij H_ni); the instantaneous covariance to_psd(x x^H) of
  * MNMFBase._init_instant_covariance (ssspy/bss/mnmf.py:167-188) is applied in closed form. */
 enum {
