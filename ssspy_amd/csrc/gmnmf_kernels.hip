@@ -211,38 +211,115 @@ __global__ __launch_bounds__(128) void k_gmnmf_traces(const c128 *__restrict__ X
   }
 }
 
-// basis[b,n,i,k] <- floor(basis * sqrt(sum_j V A / sum_j V Bt)).  grid: (ceil(F/4), N, B), 256
-// threads: wave w takes bin 4 bx + w and walks the basis index (one wave per (source, bin) row of
-// A / Bt, which stays in L1 over the walk; a block per row and a wave per basis index left the
-// launch at 16 k tiny workgroups, dispatch-bound).  The sum of a (row, k) is taken lane-strided over
-// the frames and folded by wave_sum, the same order whatever the grid.
+// basis[b,n,i,k] <- floor(basis * sqrt(sum_j V A / sum_j V Bt)).  grid: (ceil(F / (4 bpw)), N, B), 256
+// threads: the workgroup stages the activation rows of its (mixture, source) in LDS, as many basis
+// indices at a time as fit, and wave w walks bpw bins against them with the bin's rows of A / Bt in
+// registers (T <= 512).  Three shapes of this kernel were timed at 8 mixtures of 4 / 8 channels
+// (F = 513, T = 256, K = 8): a workgroup per row with a wave per basis index 59 / 115 us, a wave per
+// row re-reading everything 59 / 113 us, this one 55 / 102 us -- 67 / 134 MB of compulsory traffic,
+// so none of them is near a roof and what paces them is not identified (profiles/
+// r04_gmnmf_m*_b8_kernel_stats.csv).  The sum of a (bin, k) is taken lane-strided over the frames
+// and folded by wave_sum: the same order whatever the grid.
 // raw != NULL (partitioning): the (num, den) pairs go to raw[b,n,i,k,2] instead
+constexpr int GMB_LDS = 4096;     // staged activation values (32 KB)
+// bins per wave: up to 16, fewer while that leaves the launch under ~2048 workgroups
+static inline int gmb_bins_per_wave(int B, int N, int F) {
+  const long long rows = (long long)B * N * F;
+  long long bpw = rows / (4 * 2048);
+  if (bpw < 1) bpw = 1;
+  if (bpw > 16) bpw = 16;
+  return (int)bpw;
+}
+
 __global__ __launch_bounds__(256) void k_gmnmf_basis(double *basis, const double *__restrict__ act,
                                                      const double *__restrict__ A,
                                                      const double *__restrict__ Bt, int N, int F,
                                                      int T, int K, int floor_kind, double eps,
-                                                     double *raw) {
+                                                     double *raw, int bpw) {
+  __shared__ double vs[GMB_LDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * 4 + wave, n = blockIdx.y, b = blockIdx.z;
-  if (i >= F) return;
-  const long long row = (((long long)b * N + n) * F + i) * T;
-  for (int k = 0; k < K; ++k) {
-    const double *v = act + (((long long)b * N + n) * K + k) * T;
-    double sn = 0.0, sd = 0.0;
-    for (int j = lane; j < T; j += 64) {
-      const double vv = v[j];
-      sn = fma(vv, A[row + j], sn);
-      sd = fma(vv, Bt[row + j], sd);
+  const int n = blockIdx.y, b = blockIdx.z;
+  const int i_begin = (blockIdx.x * 4 + wave) * bpw;
+  const int i_end = min(F, i_begin + bpw);
+  const double *vbase = act + ((long long)b * N + n) * K * T;
+  // frames in slices that fit the LDS tile with at least one basis index; basis indices in chunks
+  const int tslice = T <= GMB_LDS ? T : GMB_LDS;  // frames staged at a time
+  const int kc = max(1, GMB_LDS / tslice);         // basis indices staged at a time
+  if (tslice == T) {
+    for (int k0 = 0; k0 < K; k0 += kc) {
+      const int kn = min(kc, K - k0);
+      __syncthreads();
+      for (int e = threadIdx.x; e < kn * T; e += 256) vs[e] = vbase[(long long)k0 * T + e];
+      __syncthreads();
+      for (int i = i_begin; i < i_end; ++i) {
+        const long long row = (((long long)b * N + n) * F + i) * T;
+        // the row's traces stay in registers over the basis walk while they fit (T <= 512)
+        constexpr int MT = 8;
+        double ar[MT], br[MT];
+        const bool in_regs = T <= 64 * MT;
+        if (in_regs) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const int j = lane + 64 * m;
+            ar[m] = j < T ? A[row + j] : 0.0;
+            br[m] = j < T ? Bt[row + j] : 0.0;
+          }
+        }
+        for (int kk = 0; kk < kn; ++kk) {
+          double sn = 0.0, sd = 0.0;
+          if (in_regs) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              const int j = lane + 64 * m;
+              if (j < T) {  // (same frames in the same order as the loop below)
+                const double vv = vs[kk * T + j];
+                sn = fma(vv, ar[m], sn);
+                sd = fma(vv, br[m], sd);
+              }
+            }
+          } else {
+            for (int j = lane; j < T; j += 64) {
+              const double vv = vs[kk * T + j];
+              sn = fma(vv, A[row + j], sn);
+              sd = fma(vv, Bt[row + j], sd);
+            }
+          }
+          sn = wave_sum(sn);
+          sd = wave_sum(sd);
+          if (lane == 0) {
+            const long long o = (((long long)b * N + n) * F + i) * K + k0 + kk;
+            if (raw) {
+              raw[2 * o] = sn;
+              raw[2 * o + 1] = sd;
+            } else {
+              basis[o] = apply_floor(basis[o] * sqrt(sn / sd), floor_kind, eps);
+            }
+          }
+        }
+      }
     }
-    sn = wave_sum(sn);
-    sd = wave_sum(sd);
-    if (lane == 0) {
-      const long long o = (((long long)b * N + n) * F + i) * K + k;
-      if (raw) {
-        raw[2 * o] = sn;
-        raw[2 * o + 1] = sd;
-      } else {
-        basis[o] = apply_floor(basis[o] * sqrt(sn / sd), floor_kind, eps);
+  } else {  // more frames than the tile holds: the activation straight from memory
+    for (int i = i_begin; i < i_end; ++i) {
+      const long long row = (((long long)b * N + n) * F + i) * T;
+      for (int k = 0; k < K; ++k) {
+        const double *v = vbase + (long long)k * T;
+        double sn = 0.0, sd = 0.0;
+        for (int j = lane; j < T; j += 64) {
+          const double vv = v[j];
+          sn = fma(vv, A[row + j], sn);
+          sd = fma(vv, Bt[row + j], sd);
+        }
+        sn = wave_sum(sn);
+        sd = wave_sum(sd);
+        if (lane == 0) {
+          const long long o = (((long long)b * N + n) * F + i) * K + k;
+          if (raw) {
+            raw[2 * o] = sn;
+            raw[2 * o + 1] = sd;
+          } else {
+            basis[o] = apply_floor(basis[o] * sqrt(sn / sd), floor_kind, eps);
+          }
+        }
       }
     }
   }
@@ -1512,9 +1589,13 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
     if (r) return r;
     r = launch_traces(X, Tn, Vn, spatial, A, Bt, B, N, M, F, T, K, floor_kind, floor_eps, flags, Hq, &hq_valid, st);
     if (r) return r;
-    hipLaunchKernelGGL(k_gmnmf_basis, dim3((F + 3) / 4, N, B), dim3(256), 0, st, basis, Vn,
+    {
+      const int bpw = gmb_bins_per_wave(B, N, F);
+      hipLaunchKernelGGL(k_gmnmf_basis, dim3((F + 4 * bpw - 1) / (4 * bpw), N, B), dim3(256), 0, st,
+                       basis, Vn,
                        (const double *)A, (const double *)Bt, N, F, T, K, floor_kind, floor_eps,
-                       raw_out);
+                       raw_out, bpw);
+    }
     return check_launch("k_gmnmf_basis");
   };
   if (steps & SSSPY_GMNMF_BASIS) {
