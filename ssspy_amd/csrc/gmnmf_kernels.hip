@@ -216,11 +216,59 @@ __global__ __launch_bounds__(128) void k_gmnmf_traces(const c128 *__restrict__ X
 // indices at a time as fit, and wave w walks bpw bins against them with the bin's rows of A / Bt in
 // registers (T <= 512).  Three shapes of this kernel were timed at 8 mixtures of 4 / 8 channels
 // (F = 513, T = 256, K = 8): a workgroup per row with a wave per basis index 59 / 115 us, a wave per
-// row re-reading everything 59 / 113 us, this one 55 / 102 us -- 67 / 134 MB of compulsory traffic,
-// so none of them is near a roof and what paces them is not identified (profiles/
-// r04_gmnmf_m*_b8_kernel_stats.csv).  The sum of a (bin, k) is taken lane-strided over the frames
-// and folded by wave_sum: the same order whatever the grid.
+// row re-reading everything 59 / 113 us, this one 55 / 102 us, and with the sums on the DPP path
+// (wave_sum_dpp) 45 / 84 us -- 67 / 134 MB of compulsory traffic, so still far from a roof; what
+// else paces it is not identified (profiles/r04_gmnmf_m*_b8_kernel_stats.csv).  The sum of a (bin, k) is taken lane-strided over the frames
+// and folded by wave_sum_dpp: the same order whatever the grid.
 // raw != NULL (partitioning): the (num, den) pairs go to raw[b,n,i,k,2] instead
+// Sum over the 64 lanes on the DPP path (row shifts inside the rows of 16, two row broadcasts across
+// them), total in every lane by a read of lane 63.  wave_sum() (common.hpp) goes through six
+// ds_bpermute pairs per value: 12 trips through the LDS crossbar, and this kernel takes 2 K sums
+// per bin.  A fixed order, like wave_sum's.
+__device__ __forceinline__ double dpp_shift_add(double v, int ctrl_tag) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  int slo, shi;
+  switch (ctrl_tag) {  // (the control word must be a compile-time constant)
+    case 1:
+      slo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xF, 0xF, true);  // row_shr:1
+      shi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xF, 0xF, true);
+      break;
+    case 2:
+      slo = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xF, 0xF, true);  // row_shr:2
+      shi = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xF, 0xF, true);
+      break;
+    case 4:
+      slo = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xF, 0xF, true);  // row_shr:4
+      shi = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xF, 0xF, true);
+      break;
+    case 8:
+      slo = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xF, 0xF, true);  // row_shr:8
+      shi = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xF, 0xF, true);
+      break;
+    case 15:
+      slo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, true);  // row_bcast:15 -> rows 1, 3
+      shi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, true);
+      break;
+    default:
+      slo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, true);  // row_bcast:31 -> rows 2, 3
+      shi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, true);
+      break;
+  }
+  return v + __hiloint2double(shi, slo);
+}
+
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v = dpp_shift_add(v, 1);
+  v = dpp_shift_add(v, 2);
+  v = dpp_shift_add(v, 4);
+  v = dpp_shift_add(v, 8);   // lane 15 of every row: the row's sum
+  v = dpp_shift_add(v, 15);  // lanes 31, 63: rows 0 + 1, rows 2 + 3
+  v = dpp_shift_add(v, 31);  // lane 63: everything
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
 constexpr int GMB_LDS = 4096;     // staged activation values (32 KB)
 // bins per wave: up to 16, fewer while that leaves the launch under ~2048 workgroups
 static inline int gmb_bins_per_wave(int B, int N, int F) {
@@ -284,8 +332,8 @@ __global__ __launch_bounds__(256) void k_gmnmf_basis(double *basis, const double
               sd = fma(vv, Bt[row + j], sd);
             }
           }
-          sn = wave_sum(sn);
-          sd = wave_sum(sd);
+          sn = wave_sum_dpp(sn);
+          sd = wave_sum_dpp(sd);
           if (lane == 0) {
             const long long o = (((long long)b * N + n) * F + i) * K + k0 + kk;
             if (raw) {
@@ -309,8 +357,8 @@ __global__ __launch_bounds__(256) void k_gmnmf_basis(double *basis, const double
           sn = fma(vv, A[row + j], sn);
           sd = fma(vv, Bt[row + j], sd);
         }
-        sn = wave_sum(sn);
-        sd = wave_sum(sd);
+        sn = wave_sum_dpp(sn);
+        sd = wave_sum_dpp(sd);
         if (lane == 0) {
           const long long o = (((long long)b * N + n) * F + i) * K + k;
           if (raw) {
