@@ -90,6 +90,27 @@ def barrier() -> None:
         dist.barrier()
 
 
+def pipeline_blocks(n_mixtures: int, sub_batch: int, ramp: bool = True):
+    """The (lo, hi) mixture ranges ``separate_pipelined`` works through, in order.  The first upload
+    and the last download have nothing to hide behind: with ``ramp`` (and more than two sub-batches
+    of work) a short leading and a short trailing block, a quarter of ``sub_batch``, keep that
+    exposed transfer small."""
+    B = int(n_mixtures)
+    sub_batch = max(1, min(int(sub_batch), B))
+    edge = max(1, sub_batch // 4) if ramp and B > 2 * sub_batch else 0
+    blocks, lo = [], 0
+    if edge:
+        blocks.append((0, edge))
+        lo = edge
+    stop = B - edge if edge else B
+    while lo < stop:
+        blocks.append((lo, min(lo + sub_batch, stop)))
+        lo = blocks[-1][1]
+    if edge:
+        blocks.append((stop, B))
+    return blocks
+
+
 def separate_pipelined(make_separator: Callable[[], object], X, sub_batch: int, n_iter: int = 100,
                        out: Optional[np.ndarray] = None, ramp: bool = True,
                        **call_kwargs) -> np.ndarray:
@@ -123,19 +144,7 @@ def separate_pipelined(make_separator: Callable[[], object], X, sub_batch: int, 
                                        for _ in range(2)]
     stage_out = None if direct_out else [torch.empty(shape1, dtype=torch.complex128, pin_memory=True)
                                          for _ in range(2)]
-    # The first upload and the last download have nothing to hide behind: a short leading and a
-    # short trailing sub-batch (a quarter of the others) keep that exposed transfer small.
-    edge = max(1, sub_batch // 4) if ramp and B > 2 * sub_batch else 0
-    blocks, lo = [], 0
-    if edge:
-        blocks.append((0, edge))
-        lo = edge
-    stop = B - edge if edge else B
-    while lo < stop:
-        blocks.append((lo, min(lo + sub_batch, stop)))
-        lo = blocks[-1][1]
-    if edge:
-        blocks.append((stop, B))
+    blocks = pipeline_blocks(B, sub_batch, ramp)
 
     slot_read = [None, None]  # per input staging slot: the event of the upload that last read it
 

@@ -172,3 +172,25 @@ def test_named_windows_equal_scipy():
             assert np.allclose(get_window(w, n), ss.get_window(w, n), rtol=0, atol=1e-13), (n, w)
     with pytest.raises(ValueError):
         get_window("nope", 16)
+
+
+def test_pipeline_blocks_cover_the_batch_in_order():
+    """parallel.pipeline_blocks: contiguous, disjoint, complete; no block above sub_batch; short
+    edge blocks only when there are more than two sub-batches of work."""
+    from ssspy_amd.parallel import pipeline_blocks
+
+    for B in (1, 2, 5, 63, 64, 65, 128, 129, 256, 1000):
+        for sub in (1, 3, 16, 64, 300):
+            for ramp in (False, True):
+                blocks = pipeline_blocks(B, sub, ramp)
+                assert blocks[0][0] == 0 and blocks[-1][1] == B
+                assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+                eff = max(1, min(sub, B))
+                assert all(0 < hi - lo <= eff for lo, hi in blocks)
+                if ramp and B > 2 * eff:
+                    edge = max(1, eff // 4)
+                    assert blocks[0] == (0, edge) and blocks[-1] == (B - edge, B)
+                else:
+                    assert all(hi - lo == eff for lo, hi in blocks[:-1])
+    assert pipeline_blocks(256, 64) == [(0, 16), (16, 80), (80, 144), (144, 208), (208, 240),
+                                        (240, 256)]
