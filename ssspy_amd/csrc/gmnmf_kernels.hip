@@ -1075,8 +1075,9 @@ __global__ __launch_bounds__(128) void k_gmnmf_separate_p(const c128 *__restrict
 // tiles: thread (eg, ng) owns the value pair 2 eg, 2 eg + 1 for NPT sources, so a point costs it
 // one pair read + NPT weight reads for 2 NPT FMAs (the slot-per-thread fold of the full-storage
 // kernel reads two values per FMA, and its 70 KB of LDS at 8 channels leave half the SIMDs idle).
-// From 6 channels on the two matrices of a point (R^-1, then R^-1 XX R^-1) take turns in the rows:
-// 37 KB per workgroup at 8 channels, one workgroup per SIMD.
+// From GM_SPLIT_FROM channels on the two matrices of a point (R^-1, then R^-1 XX R^-1) take turns in
+// the rows: 37 KB per workgroup at 8 channels (one workgroup per SIMD), 13 KB at 4.
+constexpr int GM_SPLIT_FROM = 4;  // channels from which the two matrices take turns in the rows
 constexpr int gm_pow2_floor(int v) { return v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1)); }
 
 template <int EW>  // value slots per row (even); the N weights follow at EW .. EW + 7
@@ -1130,7 +1131,7 @@ __global__ __launch_bounds__(GM_PB) void k_gmnmf_spatial_acc_p(const c128 *__res
                                                              double *__restrict__ PQacc, int N,
                                                              int F, int T, int K, int floor_kind,
                                                              double eps, int *__restrict__ flags) {
-  constexpr bool SPLIT = M >= 6;
+  constexpr bool SPLIT = M >= GM_SPLIT_FROM;
   constexpr int MM2 = M * M;
   constexpr int EW = SPLIT ? ((MM2 + 1) & ~1) : 2 * MM2;  // value slots per row
   using S = GmFold<EW>;
@@ -1704,7 +1705,7 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
       }
       const bool packed = packed_points(M);
       if (packed) {
-        const int ew_p = MM >= 6 ? ((MM * MM + 1) & ~1) : 2 * MM * MM;
+        const int ew_p = MM >= GM_SPLIT_FROM ? ((MM * MM + 1) & ~1) : 2 * MM * MM;
         const size_t smem_p = (size_t)GM_PB * (ew_p + GM_NMAX + 1) * sizeof(double);
         if (smem_p > 48 * 1024) {
           hipError_t e = hipFuncSetAttribute((const void *)k_gmnmf_spatial_acc_p<MM>,
