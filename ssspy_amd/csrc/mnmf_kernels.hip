@@ -928,6 +928,349 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
   }
 }
 
+// ============================================== x-reading passes with an LDS-DMA tile pipeline
+// Round 5.  The covariance and spatial passes above hold one workgroup per CU (Q, D, the statistics
+// and two x tiles in registers) and keep ONE 16 KB tile per wave in flight: 16 MB over the chip,
+// which at the loaded HBM latency is ~3.5 TB/s -- what they measure.  This form takes the tiles out of
+// the register file: `buffer_load_dwordx4 ... lds` writes them straight into a two-slot ring per wave
+// (128 KB of the CU's 160 KB at 4 channels), the activation tiles into a three-slot ring shared by
+// the workgroup (24 KB); the wave copies the landed tile into ONE register set and re-issues the slot
+// at once -- two tiles in flight behind the one being computed, 64 fewer VGPRs.  hipcc does not track
+// LDS-DMA per slot (it waits vmcnt(0) before any LDS read it can see while a DMA is pending, and at
+// __syncthreads()), so inside the walk every LDS read is an asm ds_read, every wait a counted
+// s_waitcnt, the barrier a raw s_barrier, and the number of VMEM instructions per tile is fixed: the
+// |Q x|^2 stores go through a buffer descriptor with an out-of-range offset for lanes that have
+// nothing to store, never through a branch.
+//
+// LDS image of an x tile (16 bins x 16 frames x M channels): instruction u = 4 m + quad is 1 KB in
+// lane order; lane l = 4 c' + p fetches sample r = p ^ (c' >> 2 & 3) of frames j0 + 4 quad + r of bin
+// c' -- four adjacent lanes cover one 64-byte run (the register form fetches 64 scattered samples per
+// instruction) -- and the consumer lane (c, q) finds frame r of channel m at slot
+// 4 c + (r ^ (c >> 2 & 3)) of instruction 4 m + q: each of ds_read_b128's 16-lane groups covers the
+// 16 slots mod 16 once (no bank conflict; tests/test_host_logic.py replays the index maps).
+// Shapes: T % 16 == 0 (whole tiles: no frame masks anywhere), n_basis <= 16, the hand-over buffer
+// present (spatial pass); everything else takes k_mnmf_binmajor_fast.
+#ifndef SSSPY_GLDS_DBG
+#define SSSPY_GLDS_DBG 0  // experiments (benchmarks/tools/build_variant.sh): 1 no arithmetic, 2 no DMA in the walk, 3 no barrier
+#endif
+typedef double d2_t __attribute__((ext_vector_type(2)));
+#define SSSPY_LDS_ADDR(p) ((unsigned)(size_t)((__attribute__((address_space(3))) void *)(p)))
+
+template <int NWAIT>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NWAIT) : "memory");
+}
+__device__ __forceinline__ void glds_b128(__amdgpu_buffer_rsrc_t r, unsigned lds_addr, unsigned voff,
+                                          unsigned soff) {
+  // (no instruction offset: the hardware adds it to the LDS address as well)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(
+      r, (__attribute__((address_space(3))) void *)(size_t)lds_addr, 16, voff, soff, 0, 0);
+}
+// a value the compiler must treat as used and redefined here: pins the compiler's own waits for
+// ordinary loads in front of the first DMA
+__device__ __forceinline__ void pin(double &a) { asm volatile("" : "+v"(a)); }
+
+template <int M>
+struct XRegs {
+  d2_t x[M][4];
+};
+// the tile of this lane out of ring slot `base` (byte address of this lane's frame-0 sample of
+// channel 0, the r-th entry already swizzled), then lgkmcnt(0) tied to every register read
+template <int M>
+__device__ __forceinline__ void xtile_from_lds(XRegs<M> &t, const unsigned (&base)[4]) {
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t.x[m][r]) : "v"(base[r]), "n"(m * 4096));
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(t.x[m][0]), "+v"(t.x[m][1]), "+v"(t.x[m][2]), "+v"(t.x[m][3]));
+}
+// GEMM1 of one source out of the activation ring: A operand V[k = 4 ks + q][frame tile_pi(c)]
+template <int KQ>
+__device__ __forceinline__ void vrow_from_lds(double (&a)[KQ], unsigned addr, int n) {
+#pragma unroll
+  for (int ks = 0; ks < KQ; ++ks)
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[ks]) : "v"(addr + (unsigned)n * 2048u), "n"(ks * 512));
+}
+
+template <int M, int MODE, int KQ>
+__global__ __launch_bounds__(256, 1) void k_mnmf_binmajor_glds(
+    const c128 *__restrict__ X, const c128 *__restrict__ Q, double *Dsp,
+    const double *__restrict__ basis, const double *__restrict__ act, c128 *__restrict__ U, int F,
+    int T, int K, TailPlan plan, double *__restrict__ tailpart, double *__restrict__ P) {
+  static_assert(MODE == MODE_WCOV || MODE == MODE_SPATIAL, "the two passes that read x");
+  static_assert(KQ == 2 || KQ == 4, "k-slabs of 4 carried: n_basis <= 8 or <= 16");
+  constexpr int XI = 4 * M;                                 // DMA instructions per x tile and wave
+  constexpr int NV = KQ / 2;                                // ... per activation tile and wave
+  constexpr int NS = MODE == MODE_SPATIAL ? 2 * M : 0;      // stores per tile and wave
+  constexpr unsigned XSLOT = 4u * XI * 1024u;               // bytes of one x ring slot (4 waves)
+  constexpr unsigned VSLOT = (unsigned)N * 16u * 16u * 8u;  // bytes of one activation ring slot
+  __shared__ __attribute__((aligned(16))) double xring[2 * 4 * XI * 128];
+  __shared__ __attribute__((aligned(16))) double vring[3 * N * 16 * 16];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const BlockWork work = block_work(plan);
+  const int b = work.b, nchunks = work.nchunks;
+  const int i0 = work.group * 64 + wave * 16;
+  const int bin = min(i0 + c, F - 1);
+  const bool bin_valid = i0 + c < F;
+  const __amdgpu_buffer_rsrc_t xr =
+      make_rsrc(X + (long long)b * M * F * T, (unsigned)M * (unsigned)F * (unsigned)T * 16u);
+  const __amdgpu_buffer_rsrc_t vr =
+      make_rsrc(act + (long long)b * N * K * T, (unsigned)N * (unsigned)K * (unsigned)T * 8u);
+  c128 Qb[M][M];
+  double Db[N][M];
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int a2 = 0; a2 < M; ++a2)
+      Qb[m][a2] = MODE == MODE_SPATIAL ? Q[((long long)b * F + bin) * (M * M) + m * M + a2]
+                                       : cmake(0.0, 0.0);
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int m = 0; m < M; ++m) Db[n][m] = Dsp[((long long)b * F + bin) * (N * M) + n * M + m];
+  double tb[N][KQ];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int ks = 0; ks < KQ; ++ks) {
+      const int kk = 4 * ks + q;
+      tb[n][ks] = kk < K ? basis[(((long long)b * N + n) * F + bin) * K + kk] : 0.0;
+    }
+  // every ordinary load has landed before the first DMA is issued (see the header)
+  if (MODE == MODE_SPATIAL) {
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+      for (int a2 = 0; a2 < M; ++a2) {
+        pin(Qb[m][a2].x);
+        pin(Qb[m][a2].y);
+      }
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) pin(Db[n][m]);
+#pragma unroll
+    for (int ks = 0; ks < KQ; ++ks) pin(tb[n][ks]);
+  }
+  wait_vm<0>();
+
+  CovAcc<M, M> acc;
+  double sn[N][M], sd[N][M];
+  if (MODE == MODE_WCOV) acc.clear();
+  if (MODE == MODE_SPATIAL) {
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int m = 0; m < M; ++m) sn[n][m] = sd[n][m] = 0.0;
+  }
+  const int ntiles = (T + 15) >> 4;
+  const int tpc = (ntiles + nchunks - 1) / nchunks;
+  const int jt_begin = work.chunk * tpc, jt_end = min(ntiles, jt_begin + tpc);
+
+  // ---- producer side: which sample of a tile this lane fetches
+  const int cl = lane >> 2, rl = (lane & 3) ^ ((cl >> 2) & 3);
+  const unsigned xvoff = ((unsigned)min(i0 + cl, F - 1) * (unsigned)T + (unsigned)rl) * 16u;
+  const unsigned xlds = SSSPY_LDS_ADDR(xring) + (unsigned)wave * (XI * 1024u);
+  const int nv = wave % N;  // the source whose activation rows this wave fetches
+  const unsigned vlds = SSSPY_LDS_ADDR(vring) + (unsigned)nv * 2048u;
+  unsigned vvoff[NV];
+#pragma unroll
+  for (int h = 0; h < NV; ++h) {
+    const int k = min(8 * h + (lane >> 3), K - 1);
+    vvoff[h] = (((unsigned)nv * (unsigned)K + (unsigned)k) * (unsigned)T + 2u * (lane & 7)) * 8u;
+  }
+  const unsigned chan = (unsigned)F * (unsigned)T * 16u;
+  auto issue = [&](const int jt, const int xslot, const int vslot) __attribute__((always_inline)) {
+    const unsigned j0 = (unsigned)jt * 16u;
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+        glds_b128(xr, xlds + (unsigned)xslot * XSLOT + (unsigned)(4 * m + qd) * 1024u,
+                  xvoff + j0 * 16u, (unsigned)m * chan + (unsigned)qd * 64u);
+#pragma unroll
+    for (int h = 0; h < NV; ++h)
+      glds_b128(vr, vlds + (unsigned)vslot * VSLOT + (unsigned)h * 1024u, vvoff[h] + j0 * 8u, 0u);
+  };
+  // ---- consumer side
+  unsigned xrd[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    xrd[r] = xlds + (unsigned)q * 1024u + (unsigned)c * 64u + 16u * (unsigned)(r ^ ((c >> 2) & 3));
+  const unsigned vrd = SSSPY_LDS_ADDR(vring) + (unsigned)(q * 16 + tile_pi(c)) * 8u;
+  // |Q x|^2 out: lane (c, q) owns frames j0 + 4 q .. + 3 of its bin, 32 bytes per channel
+  const __amdgpu_buffer_rsrc_t pr =
+      make_rsrc(MODE == MODE_SPATIAL ? P + (long long)b * M * F * T : nullptr,
+                MODE == MODE_SPATIAL ? (unsigned)M * (unsigned)F * (unsigned)T * 8u : 0u);
+  const unsigned pvoff = ((unsigned)bin * (unsigned)T + 4u * (unsigned)q) * 8u;
+  const unsigned pchan = (unsigned)F * (unsigned)T * 8u;
+
+  if (jt_begin < jt_end) issue(jt_begin, 0, 0);
+  if (jt_begin + 1 < jt_end) issue(jt_begin + 1, 1, 1);
+  int vslot = 0;  // (t - jt_begin) % 3
+  for (int t = jt_begin; t < jt_end; ++t) {
+    const int i = t - jt_begin;
+    const int j0 = t * 16;
+    const bool more = t + 2 < jt_end;
+    // x(t) and V(t) have landed; what was issued after them may still be in flight: the DMAs of
+    // tile t + 1 and the stores of tiles t - 2 and t - 1 (the first two tiles have fewer stores
+    // behind them, the last two no younger DMAs: vmcnt is an upper bound on what may be pending)
+    if (!more) wait_vm<0>();
+    else if (i >= 2) wait_vm<XI + NV + 2 * NS>();
+    else if (i == 1) wait_vm<XI + NV + NS>();
+    else wait_vm<XI + NV>();
+    XRegs<M> cur;
+    {
+      unsigned base[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) base[r] = xrd[r] + (unsigned)(i & 1) * XSLOT;
+      xtile_from_lds<M>(cur, base);
+    }
+    // every wave's share of V(t) is in LDS, and every wave is done with V(t - 1)
+#if SSSPY_GLDS_DBG != 3
+    __builtin_amdgcn_s_barrier();
+#endif
+#if SSSPY_GLDS_DBG != 2
+    if (more) issue(t + 2, i & 1, vslot == 0 ? 2 : vslot - 1);
+#endif
+    const unsigned vcur = vrd + (unsigned)vslot * VSLOT;
+    double4_t lamR[N];
+    {
+      double va[N][KQ];
+#pragma unroll
+      for (int n = 0; n < N; ++n) vrow_from_lds<KQ>(va[n], vcur, n);
+      // (lgkmcnt(0): scalar loads share the counter and return out of order)
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        if (KQ == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va[n][0]), "+v"(va[n][1]));
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(va[n][0]), "+v"(va[n][1]), "+v"(va[n][KQ - 2]), "+v"(va[n][KQ - 1]));
+        double4_t R = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KQ; ++ks) R = mfma_f64(va[n][ks], tb[n][ks], R);
+        lamR[n] = R;
+      }
+    }
+    double pw[M][4];
+#if SSSPY_GLDS_DBG == 1
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int m = 0; m < M; ++m) pw[m][r] = cur.x[m][r].x + lamR[m % N][r];
+    if (MODE == MODE_WCOV) acc.diag[0][0] += pw[0][0] + pw[M - 1][3];
+#else
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      c128 x[M];
+      double lam[N];
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = cmake(cur.x[m][r].x, cur.x[m][r].y);
+#pragma unroll
+      for (int n = 0; n < N; ++n) lam[n] = lamR[n][r];
+      if (MODE == MODE_WCOV) {
+        double phi[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          double rr = 0.0;
+#pragma unroll
+          for (int n = 0; n < N; ++n) rr = fma(lam[n], Db[n][m], rr);
+          phi[m] = rcp_nr(rr);
+        }
+        acc.add(x, phi);
+      } else {
+        double qx2[M], rc[M];
+        frame_terms<M>(Qb, Db, x, lam, qx2, rc);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          pw[m][r] = qx2[m];
+          const double g = rcp_nr(rc[m]);
+          const double h = qx2[m] * g * g;
+#pragma unroll
+          for (int n = 0; n < N; ++n) {
+            sn[n][m] = fma(lam[n], h, sn[n][m]);
+            sd[n][m] = fma(lam[n], g, sd[n][m]);
+          }
+        }
+      }
+    }
+#endif
+    if (MODE == MODE_SPATIAL) {
+      // (2 M stores whatever the lane holds: see the header)
+      const unsigned off = bin_valid ? pvoff + (unsigned)j0 * 8u : 0x80000000u;
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          u32x4_t v;
+          v[0] = (unsigned)__double2loint(pw[m][2 * h]);
+          v[1] = (unsigned)__double2hiint(pw[m][2 * h]);
+          v[2] = (unsigned)__double2loint(pw[m][2 * h + 1]);
+          v[3] = (unsigned)__double2hiint(pw[m][2 * h + 1]);
+          __builtin_amdgcn_raw_buffer_store_b128(v, pr, off + (unsigned)m * pchan + 16u * h, 0, 0);
+        }
+    }
+    vslot = vslot == 2 ? 0 : vslot + 1;
+  }
+  const long long slot = (long long)work.tail_idx * nchunks + work.chunk;
+  double *tp = tailpart + slot * mnmf_tail_doubles<M>();
+  if (MODE == MODE_WCOV) {
+    acc.fold_q();
+    const double scale = 1.0 / (double)T;
+    const int ob = i0 + c;
+    if (ob < F && q == 0) {
+      c128 *dst = nchunks == 1 ? U + ((long long)b * F + ob) * (long long)(M * M * M)
+                               : reinterpret_cast<c128 *>(tp) +
+                                     (long long)(ob - work.group * 64) * (M * M * M);
+#pragma unroll
+      for (int s = 0; s < M; ++s) {
+        int e = 0;
+#pragma unroll
+        for (int aa = 0; aa < M; ++aa) {
+          dst[(s * M + aa) * M + aa] = cmake(acc.diag[s][aa] * scale, 0.0);
+#pragma unroll
+          for (int bb = aa + 1; bb < M; ++bb) {
+            const c128 z = acc.off[s][e];
+            dst[(s * M + aa) * M + bb] = cmake(z.x * scale, z.y * scale);
+            dst[(s * M + bb) * M + aa] = cmake(z.x * scale, -z.y * scale);
+            ++e;
+          }
+        }
+      }
+    }
+  }
+  if (MODE == MODE_SPATIAL) {
+    const int ob = i0 + c;
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        double v = sn[n][m], w = sd[n][m];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        w += __shfl_xor(w, 16, 64);
+        w += __shfl_xor(w, 32, 64);
+        if (q == 0 && ob < F) {
+          if (nchunks == 1) {
+            double *dst = Dsp + ((long long)b * F + ob) * (N * M) + n * M + m;
+            *dst = sqrt(v / w) * Db[n][m];
+          } else {
+            double *dst = tp + (((ob - work.group * 64) * N + n) * M + m) * 2;
+            dst[0] = v;
+            dst[1] = w;
+          }
+        }
+      }
+  }
+}
+
 // ---- folds of the split (tail) items; grid.y = tail item, one thread per output value
 // basis <- floor(basis * sqrt(sum num / sum den)); grid: (N*64*16/256, tail)
 template <int M>
@@ -1731,6 +2074,12 @@ static inline TailPlan mnmf_plan(int B, int F, int T) {
   // these kernels hold one workgroup per CU (x prefetch in registers, > 256 VGPR + AGPR)
   return make_tail_plan(B, (F + 63) / 64, (T + 15) / 16, 256);
 }
+// the LDS-DMA form of the two x-reading passes (k_mnmf_binmajor_glds): whole tiles of frames
+static inline bool mnmf_glds_ok(int B, int F, int T, int K) {
+  // (read per call: the parity tests switch it inside one process)
+  const bool disabled = std::getenv("SSSPY_AMD_MNMF_NO_GLDS") != nullptr;  // A / B
+  return !disabled && mnmf_fast_ok(B, F, T, K) && T % 16 == 0;
+}
 
 // whether the |Q x|^2 hand-over (P, pscale) is taken by the passes of this shape
 int LAUNCHER(mnmf_handover_ok)(int B, int F, int T, int K) {
@@ -1839,7 +2188,17 @@ int LAUNCHER(mnmf_wcov)(const void *X, const double *Dsp, const double *basis, c
     const TailPlan plan = mnmf_plan(B, F, T);
     dim3 fgrid(plan.full + plan.tail * plan.split);
     const bool records = split_out && rec_out && plan.full == 0 && plan.tail > 0;
+    const bool glds = mnmf_glds_ok(B, F, T, K);
     MNMF_DISPATCH_M(M, {
+      if (glds && K <= 8)
+        hipLaunchKernelGGL((k_mnmf_binmajor_glds<MM, MODE_WCOV, 2>), fgrid, dim3(256), 0, st,
+                           (const c128 *)X, (const c128 *)nullptr, (double *)Dsp, basis, act,
+                           (c128 *)U, F, T, K, plan, tailpart, (double *)nullptr);
+      else if (glds)
+        hipLaunchKernelGGL((k_mnmf_binmajor_glds<MM, MODE_WCOV, 4>), fgrid, dim3(256), 0, st,
+                           (const c128 *)X, (const c128 *)nullptr, (double *)Dsp, basis, act,
+                           (c128 *)U, F, T, K, plan, tailpart, (double *)nullptr);
+      else
       hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_WCOV>), fgrid, dim3(256), 0, st,
                          (const c128 *)X, (const c128 *)nullptr, (double *)Dsp, (double *)basis, act,
                          (c128 *)U, F, T, K, 0, 0.0, plan, tailpart, (double *)nullptr,
@@ -1885,8 +2244,17 @@ int LAUNCHER(mnmf_spatial)(const void *X, const void *Q, double *Dsp, const doub
     if (P && !scale_follows)
       hipLaunchKernelGGL(k_mnmf_fill_ones, dim3((B * M + 255) / 256), dim3(256), 0, st, pscale,
                          B * M);
+    const bool glds = P && mnmf_glds_ok(B, F, T, K);
     MNMF_DISPATCH_M(M, {
-      if (P)
+      if (glds && K <= 8)
+        hipLaunchKernelGGL((k_mnmf_binmajor_glds<MM, MODE_SPATIAL, 2>), fgrid, dim3(256), 0, st,
+                           (const c128 *)X, (const c128 *)Q, Dsp, basis, act, (c128 *)nullptr, F,
+                           T, K, plan, tailpart, P);
+      else if (glds)
+        hipLaunchKernelGGL((k_mnmf_binmajor_glds<MM, MODE_SPATIAL, 4>), fgrid, dim3(256), 0, st,
+                           (const c128 *)X, (const c128 *)Q, Dsp, basis, act, (c128 *)nullptr, F,
+                           T, K, plan, tailpart, P);
+      else if (P)
         hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_SPATIAL, P_WRITE>), fgrid, dim3(256), 0,
                            st, (const c128 *)X, (const c128 *)Q, Dsp, (double *)basis, act,
                            (c128 *)nullptr, F, T, K, 0, 0.0, plan, tailpart, P,

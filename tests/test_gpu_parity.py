@@ -790,6 +790,48 @@ def test_fast_gauss_mnmf_handover_matches_plain_path_and_oracle(M, F, T, K, monk
     assert rel_err(m1.output, Yr) < 1e-7
 
 
+@pytest.mark.parametrize("B,M,N,F,T,K", [(1, 4, 4, 70, 96, 8), (1, 3, 3, 33, 48, 5), (1, 2, 2, 17, 16, 16),
+                                         (1, 4, 4, 130, 32, 3), (3, 4, 4, 65, 160, 12), (2, 3, 2, 64, 64, 9),
+                                         (5, 4, 3, 129, 80, 16), (40, 4, 4, 20, 48, 4)])
+def test_fast_gauss_mnmf_lds_dma_passes_match_register_passes_and_oracle(B, M, N, F, T, K, monkeypatch):
+    """Round 5: the covariance and spatial passes fed by LDS-DMA (k_mnmf_binmajor_glds, T % 16 == 0)
+    against the register-fed passes (SSSPY_AMD_MNMF_NO_GLDS) on every state array, and against the
+    oracle: single tiles, one and several mixtures (whole items and frame-split items), fewer
+    sources than channels, n_basis on both sides of the k-slab variants, bins that end inside a
+    wave's 16 (F = 17, 65, 129) and whole waves without a bin (F = 65: three of four)."""
+    from oracle.mnmf import FastGaussMNMFOracle
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    X = np.stack([nmf_mixture(500 + b, M, F, T) for b in range(B)])
+    rng = np.random.default_rng(3)
+    kw = dict(basis=rng.random((B, N, F, K)), activation=rng.random((B, N, K, T)),
+              spatial=rng.random((B, F, N, M)))
+    if B == 1:
+        X, kw = X[0], {k: v[0] for k, v in kw.items()}
+    m1 = FastGaussMNMF(n_basis=K, n_sources=N)
+    m1(X, n_iter=3, **{k: v.copy() for k, v in kw.items()})
+    assert m1._handover is not None
+    monkeypatch.setenv("SSSPY_AMD_MNMF_NO_GLDS", "1")
+    m2 = FastGaussMNMF(n_basis=K, n_sources=N)
+    m2(X, n_iter=3, **{k: v.copy() for k, v in kw.items()})
+    monkeypatch.delenv("SSSPY_AMD_MNMF_NO_GLDS")
+    for a, b in zip(_fastmnmf_states(m1), _fastmnmf_states(m2)):
+        assert np.isfinite(a).all()
+        assert rel_err(a, b) < 1e-10  # (fused multiply-adds in the spatial sums: 1e-11 .. 1e-12)
+    np.testing.assert_allclose(m1.loss, m2.loss, rtol=1e-10)
+    b0 = 0 if B == 1 else B - 1
+    Xo = X if B == 1 else X[b0]
+    ref = FastGaussMNMFOracle(n_basis=K, n_sources=N)
+    Yr = ref.run(Xo, n_iter=3, **{k: (v if B == 1 else v[b0]).copy() for k, v in kw.items()})
+    loss = np.asarray(m1.loss)
+    np.testing.assert_allclose(loss if B == 1 else loss[:, b0], ref.loss, rtol=LOSS_RTOL)
+    q = np.asarray(m1.diagonalizer)
+    assert rel_err(q if B == 1 else q[b0], ref.diagonalizer) < TOL
+    y = np.asarray(m1.output)
+    assert rel_err(y if B == 1 else y[b0], Yr) < 1e-7
+
+
 def test_aux_iva_ip1_resident_loss_loop_equals_reference_loop():
     """AuxLaplaceIVA-IP1, record_loss=True without callbacks: the loss of every state comes from the
     frame powers the next iteration forms anyway and the list from one download; with a callback the

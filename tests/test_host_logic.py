@@ -194,3 +194,54 @@ def test_pipeline_blocks_cover_the_batch_in_order():
                     assert all(hi - lo == eff for lo, hi in blocks[:-1])
     assert pipeline_blocks(256, 64) == [(0, 16), (16, 80), (80, 144), (144, 208), (208, 240),
                                         (240, 256)]
+
+
+def test_lds_dma_tile_index_maps():
+    """Index maps of k_mnmf_binmajor_glds (mnmf_kernels.hip), replayed on the host: the producer lane
+    of instruction (m, quad) writes 16 bytes at lane * 16 of its 1 KB block; the consumer lane (c, q)
+    must find frame 4 q + r of channel m and bin c, every 16-lane group of ds_read_b128 must touch
+    16 different bank slots, and four adjacent producer lanes must fetch one 64-byte run."""
+    M, T16 = 4, 16
+    tile = np.arange(M * 16 * T16).reshape(M, 16, T16)  # (channel, bin, frame) sample ids
+    lds = np.full(M * 4 * 64, -1)
+    for m in range(M):
+        for quad in range(4):
+            for lane in range(64):
+                cl = lane >> 2
+                rl = (lane & 3) ^ ((cl >> 2) & 3)
+                lds[(4 * m + quad) * 64 + lane] = tile[m, cl, 4 * quad + rl]
+            frames = [[4 * quad + ((l & 3) ^ (((l >> 2) >> 2) & 3)) for l in range(4 * g, 4 * g + 4)]
+                      for g in range(16)]
+            assert all(sorted(f) == list(range(4 * quad, 4 * quad + 4)) for f in frames)
+    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
+              list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
+    groups += [[l + 32 for l in g] for g in groups]
+    assert sorted(sum(groups, [])) == list(range(64))
+    for m in range(M):
+        for r in range(4):
+            slot16 = {}
+            for lane in range(64):
+                c, q = lane & 15, lane >> 4
+                byte = q * 1024 + c * 64 + 16 * (r ^ ((c >> 2) & 3)) + m * 4096
+                assert byte % 16 == 0
+                assert lds[byte // 16] == tile[m, c, 4 * q + r]
+                slot16[lane] = (byte // 16) % 16
+            for g in groups:
+                assert len({slot16[l] for l in g}) == 16
+    # activation ring: instruction (source n, half h) = rows 8 h .. 8 h + 7 of 16 frames (8 bytes each);
+    # GEMM1's A operand of lane (c, q), k-slab ks is V[4 ks + q][tile_pi(c)]
+    V = np.arange(4 * 16 * 16).reshape(4, 16, 16)
+    vl = np.full(4 * 16 * 16, -1)
+    for n in range(4):
+        for h in range(2):
+            for lane in range(64):
+                k, j = 8 * h + (lane >> 3), 2 * (lane & 7)
+                base = (n * 2048 + h * 1024 + lane * 16) // 8
+                vl[base], vl[base + 1] = V[n, k, j], V[n, k, j + 1]
+    for n in range(4):
+        for ks in range(4):
+            for lane in range(64):
+                c, q = lane & 15, lane >> 4
+                pi = 4 * (c & 3) + (c >> 2)
+                byte = (q * 16 + pi) * 8 + n * 2048 + ks * 512
+                assert vl[byte // 8] == V[n, 4 * ks + q, pi]
