@@ -66,6 +66,10 @@ def parse_args():
     ap.add_argument("--cpu-iters", type=int, default=6)
     ap.add_argument("--no-extra", "--no-single", dest="no_extra", action="store_true",
                     help="only the headline (skip the loss / AuxIVA / other-config legs)")
+    ap.add_argument("--no-pairwise", action="store_true",
+                    help="skip the IP2 / ISS2 / IPA legs (`pairwise_ipa`)")
+    ap.add_argument("--only-pairwise", action="store_true",
+                    help="profiling: after the headline, run only the `pairwise_ipa` legs")
     ap.add_argument("--other-batch", type=int, default=32,
                     help="mixtures in the batched configs[2] / configs[3] legs")
     ap.add_argument("--mnmf-batch", type=int, default=128,
@@ -329,6 +333,75 @@ def other_configs(args, dev, x0_host, pins, cpu_configs1):
 
         ent["cpu_baseline"] = cpu_leg(make, 3, "oracle.mnmf.FastGaussMNMFOracle.update_once")
     out["configs3"] = ent
+    return out
+
+
+def pairwise_ipa_legs(args, dev, Xbatch_host):
+    """Round 5 (round-4 verdict item 2): the pairwise and IPA spatial updates had no timing anywhere.
+    update_once() of GaussILRMA (IP2 / ISS2 / IPA), AuxLaplaceIVA (IP2 / ISS2 / IPA) at the configs[1]
+    shape and FastGaussMNMF with the IP2 diagonaliser at the configs[3] shape, on 1 / 32 / 128
+    mixtures of the headline's batch.  `bytes` is the algorithmic traffic per mixture-iteration in
+    passes of A = 16 N F T over the spectrograms (stated per leg; IP1 / ISS1 beside them for scale)."""
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.bss.iva import AuxLaplaceIVA, _device_contrast
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+
+    N, F, T = Xbatch_host.shape[1:]
+    A = 16.0 * N * F * T
+
+    def ilrma(algo):
+        return lambda: GaussILRMA(n_basis=16, spatial_algorithm=algo, record_loss=False,
+                                  rng=np.random.default_rng(2000))
+
+    def iva(algo):
+        def make():
+            m = AuxLaplaceIVA(spatial_algorithm=algo, record_loss=False)
+            m._contrast = _device_contrast(m.contrast_fn, m.d_contrast_fn)
+            return m
+        return make
+
+    def fmnmf(algo):
+        return lambda: FastGaussMNMF(n_basis=8, diagonalizer_algorithm=algo, record_loss=False,
+                                     rng=np.random.default_rng(0))
+
+    legs = [
+        ("ilrma_ip1", ilrma("IP1"), 3, "basis, activation, covariance passes over X"),
+        ("ilrma_ip2", ilrma("IP2"), 3, "basis, activation, covariance passes over X"),
+        ("ilrma_iss1", ilrma("ISS1"), 4, "basis, activation passes over Y; fused sweep: read + write Y"),
+        ("ilrma_iss2", ilrma("ISS2"), 5, "basis, activation, covariance passes over Y; Y <- G Y read + write"),
+        ("ilrma_ipa", ilrma("IPA"), 5, "basis, activation, covariance passes over Y; Y <- G Y read + write"),
+        ("auxiva_ip2", iva("IP2"), 2, "frame powers and covariance passes over X"),
+        ("auxiva_iss2", iva("ISS2"), 4, "frame powers, covariance passes over Y; Y <- G Y read + write"),
+        ("auxiva_ipa", iva("IPA"), 4, "frame powers, covariance passes over Y; Y <- G Y read + write"),
+        ("fmnmf_ip2", fmnmf("IP2"), 4, "basis, activation, covariance, spatial passes (as IP1)"),
+    ]
+    out = {"shape": "N=M={} F={} T={}; ILRMA n_basis=16, FastGaussMNMF n_basis=8".format(N, F, T),
+           "A_bytes": A}
+    batches = [b for b in (1, 32, 128) if b <= Xbatch_host.shape[0]]
+    for nb in batches:
+        X = torch.from_numpy(Xbatch_host[:nb]).to(dev)
+        for key, make, passes, what in legs:
+            try:
+                m = make()
+                m._bind_input(X)
+                m._reset()
+                iters = 40 if nb == 1 else (10 if nb <= 32 else 5)
+                for _ in range(3):
+                    m.update_once()
+                dt = time_loop(m.update_once, iters)
+                m._check_device_errors()
+                ent = out.setdefault(key, {"passes_of_A": passes, "passes": what})
+                ent["b{}".format(nb)] = {
+                    "ms_per_step": round(1e3 * dt, 4), "iterations_per_s": round(nb / dt, 1),
+                    "achieved_GBs": round(passes * A * nb / dt / 1e9, 1),
+                    "frac": round(passes * A * nb / dt / 1e9 / HBM_PEAK_GBS, 4)}
+                del m
+            except Exception as exc:  # an extra leg must never cost the headline line
+                out.setdefault(key, {})["b{}".format(nb)] = {
+                    "error": "{}: {}".format(type(exc).__name__, str(exc)[:200])}
+            torch.cuda.empty_cache()
+        del X
+        torch.cuda.empty_cache()
     return out
 
 
@@ -690,13 +763,21 @@ def main():
     if extra:
         del sep, X
         torch.cuda.empty_cache()
+    if extra and not args.only_pairwise:
         try:
             out["configs"] = other_configs(args, dev, x0_host, pins, out.get("cpu_baseline"))
         except Exception as exc:  # an extra leg must never cost the headline line
             out["configs"] = {"error": "{}: {}".format(type(exc).__name__, str(exc)[:300])}
 
+    # ---- the pairwise and IPA spatial updates (configs[1] / [3] shapes, 1 / 32 / 128 mixtures)
+    if extra and Xh is not None and not args.no_pairwise:
+        try:
+            out["pairwise_ipa"] = pairwise_ipa_legs(args, dev, Xh)
+        except Exception as exc:  # an extra leg must never cost the headline line
+            out["pairwise_ipa"] = {"error": "{}: {}".format(type(exc).__name__, str(exc)[:300])}
+
     # ---- end to end: host NumPy in -> __call__ -> host NumPy out (PCIe inclusive; never `value`)
-    if extra and Xh is not None:
+    if extra and Xh is not None and not args.only_pairwise:
         try:
             cfg = out.get("configs", {}) if isinstance(out.get("configs"), dict) else {}
             cpu = {"configs1": out.get("cpu_baseline"),

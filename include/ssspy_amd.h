@@ -369,6 +369,17 @@ int ssspy_ilrma_ip1_update_deferred_loss(const void *X, const void *C, void *W, 
 int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int B, int F, int N,
                         int normalization, int max_iter, int floor_kind, double floor_eps,
                         int *info, void *newton_ws, int *not_converged, void *stream);
+/* A whole IPA sweep on per-bin statistics (round 5): Vc (B,F,N,N,N) = ssspy_weighted_covariance(Y,
+ * weight) of the spectrogram BEFORE the sweep (overwritten: after source step s it holds
+ * G_s Vc G_s^H, the covariances of the spectrogram the reference would have formed by then); G
+ * (B,F,N,N) <- G_{N-1} ... G_0.  The caller applies ssspy_separate(Y, G) once: three passes over Y per
+ * sweep (weights, covariance, separate) instead of 3 N.  The weights are those of the sweep's start
+ * for every source, as in the reference (_update_spatial_model.py:436-445: varphi is an argument).
+ * Other arguments as ssspy_ipa_transform.
+ * replaces: ssspy/bss/_update_spatial_model.py:398-513 (update_by_ipa, the loop over sources). */
+int ssspy_ipa_sweep(void *Vc, void *G, int B, int F, int N, int normalization, int max_iter,
+                    int floor_kind, double floor_eps, int *info, void *newton_ws,
+                    int *not_converged, void *stream);
 
 /* ---- partitioning (latent variables): basis (B,F,K), activation (B,K,T), latent (B,N,K) with
  * R_nij = sum_k z_nk t_ik v_kj (ssspy/bss/ilrma.py:297-327).  Every entry point above that takes

@@ -259,17 +259,46 @@ def ipa_transform(Vc, source_idx, normalization, max_iter, flooring, info=None, 
     return out
 
 
-def update_by_ipa(Y, weight, kind, normalization, max_iter, flooring, info=None, not_converged=None):
-    """One IPA sweep in place on the device spectrogram Y (B, N, F, T): per source, weighted
-    covariance of the current Y -> update matrix -> Y <- G Y."""
+def ipa_sweep(Vc, normalization, max_iter, flooring, info=None, out=None, newton_ws=None,
+              not_converged=None):
+    """All N source steps of an IPA sweep on the per-bin statistics Vc (overwritten: V_m <- G V_m G^H
+    after each step); returns the accumulated transform G (B, F, N, N)."""
+    B, F, N = Vc.shape[0], Vc.shape[1], Vc.shape[-1]
+    if out is None:
+        out = dv.empty((B, F, N, N), dv.c128, Vc.device)
+    _lib.check(
+        _L().ssspy_ipa_sweep(ptr(Vc), ptr(out), B, F, N, int(bool(normalization)), int(max_iter),
+                             flooring[0], flooring[1], ptr(info), ptr(newton_ws),
+                             ptr(not_converged), _st()),
+        "ipa_sweep",
+    )
+    return out
+
+
+def update_by_ipa(Y, weight, kind, normalization, max_iter, flooring, info=None, not_converged=None,
+                  Vc=None):
+    """One IPA sweep in place on the device spectrogram Y (B, N, F, T).  The weights are fixed over
+    the sweep (ref: _update_spatial_model.py:436-445), so the covariances the reference recomputes
+    from the updated spectrogram before every source step are G V G^H of the previous ones: one
+    weighted covariance, the N steps on the per-bin statistics, one Y <- G Y (round 5; three passes
+    over Y instead of 3 N).  SSSPY_AMD_IPA_PER_SOURCE=1 keeps the literal per-source passes (A / B).
+    Vc: the weighted covariances of Y when the caller has formed them already (then `weight` is not
+    read; overwritten)."""
     B, N = Y.shape[0], Y.shape[1]
-    Vc = G = None
     newton_ws = dv.empty((B,), dv.i64, Y.device)
-    for s in range(N):
-        Vc = weighted_covariance(Y, weight, kind, N, out=Vc)
-        G = ipa_transform(Vc, s, normalization, max_iter, flooring, info, out=G,
-                          newton_ws=newton_ws, not_converged=not_converged)
-        separate(Y, G, out=Y)
+    if Vc is None and _os.environ.get("SSSPY_AMD_IPA_PER_SOURCE"):
+        Vc = G = None
+        for s in range(N):
+            Vc = weighted_covariance(Y, weight, kind, N, out=Vc)
+            G = ipa_transform(Vc, s, normalization, max_iter, flooring, info, out=G,
+                              newton_ws=newton_ws, not_converged=not_converged)
+            separate(Y, G, out=Y)
+        return Y
+    if Vc is None:
+        Vc = weighted_covariance(Y, weight, kind, N)
+    G = ipa_sweep(Vc, normalization, max_iter, flooring, info, newton_ws=newton_ws,
+                  not_converged=not_converged)
+    separate(Y, G, out=Y)
     return Y
 
 

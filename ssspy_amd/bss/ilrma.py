@@ -15,6 +15,7 @@ leading axis (``loss`` entries become arrays of length ``n_mixtures``).
 """
 
 import functools
+import os as _os
 from typing import Callable, Iterable, List, Optional, Tuple, Union
 
 import numpy as np
@@ -541,13 +542,32 @@ class _MMILRMA(ILRMABase):
         ref: ssspy/bss/ilrma.py:1794-1908."""
         require_device_floor(self._resolve_floor(flooring_fn), "IPA")
         Y = self._state_dev("output")
-        varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y,
-                                       model=self._model,
-                                       flooring=self._resolve_floor(flooring_fn))
+        Vc = self._output_statistics(Y, flooring_fn)
+        varphi = None
+        if Vc is None:
+            varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y,
+                                           model=self._model,
+                                           flooring=self._resolve_floor(flooring_fn))
         _ops.update_by_ipa(Y, varphi, _lib.WEIGHT_BIN_FRAME, self.lqpqm_normalization,
                            self.newton_iter, self._resolve_floor(flooring_fn), self._info_tensor(),
-                           not_converged=self._newton_counter())
+                           not_converged=self._newton_counter(), Vc=Vc)
         self._state_touch("output")
+
+    def _output_statistics(self, Y, flooring_fn):
+        """U_n = mean_j varphi_nij y y^H of the separated spectrogram for the ISS2 / IPA steps in ONE
+        pass: the Gauss weights 1 / (T V)^(2/p) do not depend on y, so the covariance pass of the IP
+        updates (weights formed from the NMF tiles on the fly) serves with Y in place of X -- instead
+        of a weight pass (read |y|^2, write (N, F, T) weights) plus the generic weighted covariance
+        (round 5: 0.78 -> 0.3 ms at 32 mixtures of configs[1]).  None: the caller forms weights."""
+        if self._base_model[0] != _lib.SOURCE_GAUSS or _os.environ.get("SSSPY_AMD_ISS_WEIGHT_PASS"):
+            return None
+        B, N, F, T = Y.shape
+        if getattr(self, "_Vc", None) is None or tuple(self._Vc.shape) != (B, F, N, N, N):
+            self._Vc = dv.empty((B, F, N, N, N), dv.c128, Y.device)
+        _ops.ilrma_weighted_covariance(Y, *self._nmf_pair(), float(self.domain), self._ws,
+                                       self._ws_bytes, out=self._Vc, W=None, model=self._model,
+                                       flooring=self._resolve_floor(flooring_fn))
+        return self._Vc
 
     def update_spatial_model_ip2(self, flooring_fn="self") -> None:
         """Weighted covariance + pairwise iterative projection.  ref: ssspy/bss/ilrma.py:1509-1633."""
@@ -571,9 +591,12 @@ class _MMILRMA(ILRMABase):
             require_device_floor(self._resolve_floor(flooring_fn), "ISS2 with a heavy-tailed model")
         Y = self._state_dev("output")
         N = Y.shape[1]
-        varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y, model=self._model,
-                                       flooring=self._resolve_floor(flooring_fn))
-        Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
+        Vc = self._output_statistics(Y, flooring_fn)
+        if Vc is None:
+            varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y,
+                                           model=self._model,
+                                           flooring=self._resolve_floor(flooring_fn))
+            Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
         G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N),
                                 self._resolve_floor(flooring_fn), self._info_tensor())
         _ops.separate(Y, G, out=Y)

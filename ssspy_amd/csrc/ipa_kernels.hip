@@ -6,7 +6,10 @@
 // (Hermitian Jacobi eigen-decomposition, Cardano start value, Newton steps on the secular
 // equation), and writes the N x N matrix G with  y <- G y:
 //   row s of G = p^H,  G[m][s] = conj(q_m) for m != s,  identity elsewhere.
-// The caller runs  weighted_covariance -> this -> separate  once per source.
+// The caller runs  weighted_covariance -> this -> separate  once per source (ssspy_ipa_transform), or
+// -- round 5 -- weighted_covariance once, the N source steps chained on the per-bin statistics
+// (V_m <- G V_m G^H), one separate with the accumulated transform (ssspy_ipa_sweep): 3 passes over the
+// spectrogram per sweep instead of 3 N.
 //
 // replaces: ssspy/bss/_update_spatial_model.py:398-513 (update_by_ipa), :611-645 (_psd_inv),
 //           ssspy/linalg/lqpqm.py:13-352 (lqpqm2, solve_equation, _find_largest_root),
@@ -175,7 +178,23 @@ __device__ __forceinline__ void lqpqm2(c128 (&H)[L][L], const c128 (&v)[L], doub
     lamb = mu > 1.0 ? mu : 0.5 * (1.0 + lamb);
   }
   if (mode == NEWTON_PROBE) {
-    atomicAnd(word, bits);
+    // One atomic per (wave, mixture), not one per bin: 1025 atomics on one word took 130 of the
+    // probe launch's 205 us (32 mixtures of configs[1]; the apply launch: 75 us).  The lanes still
+    // here (singular problems have left: they do not vote) that share a word elect a leader; bit k of
+    // the group is set when no member has it clear.
+    unsigned long long todo = __ballot(1);
+    const unsigned long long mine_word = (unsigned long long)word;
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const unsigned long long lw = __shfl(mine_word, leader, 64);
+      const bool mine = mine_word == lw;
+      const unsigned long long group = __ballot(mine);
+      unsigned long long all = 0ull;
+      for (int it = 0; it <= steps; ++it)
+        if (__ballot(mine && !((bits >> it) & 1ull)) == 0ull) all |= 1ull << it;
+      if ((int)(threadIdx.x & 63) == leader) atomicAnd(word, all);
+      todo &= ~group;
+    }
     return;
   }
   lamb *= pm;
@@ -201,11 +220,12 @@ __device__ __forceinline__ constexpr int rest_index(int m) {
 // (one wave per SIMD: the N x N working set of the larger source counts wants the whole 512-entry
 // register file; the grid has only B*F lanes anyway)
 template <int N, int S, int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ipa_transform(const c128 *__restrict__ Vc,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ipa_transform(const c128 *Vc,
                                                       c128 *__restrict__ G, long long nbins,
                                                       int F, int normalization, int max_iter,
                                                       int floor_kind, double eps, int *info,
-                                                      unsigned long long *newton_ws) {
+                                                      unsigned long long *newton_ws,
+                                                      c128 *Vchain, int chain_first) {
   constexpr int L = N - 1;
   const long long bin = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (bin >= nbins) return;
@@ -320,16 +340,106 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   }
   const double den = apply_floor(sqrt(fmax(quq, 0.0)), floor_kind, eps);
   c128 *Gb = G + bin * (long long)(N * N);
+  if (!Vchain) {
 #pragma unroll
-  for (int r = 0; r < N; ++r)
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        c128 g = cmake(r == c ? 1.0 : 0.0, 0.0);
+        if (r == S) g = cmake(Uq[c].x / den, -Uq[c].y / den);  // conj(p_c)
+        Gb[r * N + c] = g;
+      }
+#pragma unroll
+    for (int r = 0; r < L; ++r) Gb[rest_index<S>(r) * N + S] = cmake(q[r].x, -q[r].y);
+    return;
+  }
+  // ---- chained sweep (ssspy_ipa_sweep): the step's update y <- G_S y is not applied to the
+  // spectrogram; the statistics follow it, V_m <- G_S V_m G_S^H for every weight set m (what the
+  // reference recomputes from the updated spectrogram, _update_spatial_model.py:442-445), and the
+  // accumulated transform G <- G_S G.  G_S = I except row S (= p^H) and column S (= conj(q)):
+  //   (G_S A)[r] = A[r] + g_r A[S] (r != S),  (G_S A)[S] = sum_c conj(p_c) A[c].
+  c128 prow[N], gcol[N];  // row S of G_S; column S of G_S (entry S unused)
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    prow[c] = cmake(Uq[c].x / den, -Uq[c].y / den);
+    gcol[c] = cmake(0.0, 0.0);
+  }
+#pragma unroll
+  for (int r = 0; r < L; ++r) gcol[rest_index<S>(r)] = cmake(q[r].x, -q[r].y);
+  c128 *Vb = Vchain + bin * (long long)(N * N * N);
+  for (int m = 0; m < N; ++m) {  // (rolled: one matrix live)
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c) M[r][c] = Vb[(m * N + r) * N + c];
+    // left: M <- G_S M
+    c128 srow[N];
 #pragma unroll
     for (int c = 0; c < N; ++c) {
-      c128 g = cmake(r == c ? 1.0 : 0.0, 0.0);
-      if (r == S) g = cmake(Uq[c].x / den, -Uq[c].y / den);  // conj(p_c)
-      Gb[r * N + c] = g;
+      c128 acc = cmake(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < N; ++k) cfma(acc, prow[k], M[k][c]);
+      srow[c] = acc;
     }
 #pragma unroll
-  for (int r = 0; r < L; ++r) Gb[rest_index<S>(r) * N + S] = cmake(q[r].x, -q[r].y);
+    for (int r = 0; r < N; ++r)
+      if (r != S) {
+#pragma unroll
+        for (int c = 0; c < N; ++c) cfma(M[r][c], gcol[r], M[S][c]);
+      }
+#pragma unroll
+    for (int c = 0; c < N; ++c) M[S][c] = srow[c];
+    // right: M <- M G_S^H   (G_S^H: column S = conj(row S of G_S) = p, row S = q^T elsewhere)
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      c128 acc = cmake(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < N; ++k) cfma(acc, M[r][k], cconj(prow[k]));
+      const c128 ms = M[r][S];
+#pragma unroll
+      for (int c = 0; c < N; ++c)
+        if (c != S) cfma(M[r][c], ms, cconj(gcol[c]));
+      M[r][S] = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c) Vb[(m * N + r) * N + c] = M[r][c];
+  }
+  // G <- G_S G (the first step: G = G_S)
+  if (chain_first) {
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        c128 g = cmake(r == c ? 1.0 : 0.0, 0.0);
+        if (r == S) g = prow[c];
+        else if (c == S) g = gcol[r];
+        Gb[r * N + c] = g;
+      }
+  } else {
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c) M[r][c] = Gb[r * N + c];
+    c128 srow[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      c128 acc = cmake(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < N; ++k) cfma(acc, prow[k], M[k][c]);
+      srow[c] = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        c128 g = M[r][c];
+        if (r != S) cfma(g, gcol[r], M[S][c]);
+        else g = srow[c];
+        Gb[r * N + c] = g;
+      }
+  }
 }
 
 // standalone LQPQM2 (ssspy.linalg.lqpqm2): H (n, L, L), v (n, L), z (n) -> y (n, L)
@@ -389,26 +499,27 @@ static int newton_finish(unsigned long long *ws, int ngroups, int max_iter, int 
 template <int N, int S>
 static int launch_one(const void *Vc, void *G, long long nbins, int B, int F, int normalization,
                       int max_iter, int floor_kind, double eps, int *info,
-                      unsigned long long *newton_ws, int *not_converged, hipStream_t st) {
+                      unsigned long long *newton_ws, int *not_converged, hipStream_t st,
+                      c128 *Vchain = nullptr, int chain_first = 0) {
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
   if (!newton_ws || max_iter > 62 || max_iter == 0) {
     hipLaunchKernelGGL((k_ipa_transform<N, S, NEWTON_FIXED>), grid, block, 0, st, (const c128 *)Vc,
                        (c128 *)G, nbins, F, normalization, max_iter, floor_kind, eps, info,
-                       (unsigned long long *)nullptr);
+                       (unsigned long long *)nullptr, Vchain, chain_first);
     return check_launch("k_ipa_transform");
   }
   int rc = newton_prepare(newton_ws, B, st);
   if (rc) return rc;
   hipLaunchKernelGGL((k_ipa_transform<N, S, NEWTON_PROBE>), grid, block, 0, st, (const c128 *)Vc,
                      (c128 *)G, nbins, F, normalization, max_iter, floor_kind, eps, info,
-                     newton_ws);
+                     newton_ws, (c128 *)nullptr, 0);
   rc = check_launch("k_ipa_transform (probe)");
   if (rc) return rc;
   rc = newton_finish(newton_ws, B, max_iter, not_converged, st);
   if (rc) return rc;
   hipLaunchKernelGGL((k_ipa_transform<N, S, NEWTON_APPLY>), grid, block, 0, st, (const c128 *)Vc,
                      (c128 *)G, nbins, F, normalization, max_iter, floor_kind, eps, info,
-                     newton_ws);
+                     newton_ws, Vchain, chain_first);
   return check_launch("k_ipa_transform");
 }
 
@@ -416,22 +527,17 @@ static int launch_one(const void *Vc, void *G, long long nbins, int B, int F, in
 
 using namespace ssspy;
 
-extern "C" int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int B, int F, int N,
-                                   int normalization, int max_iter, int floor_kind,
-                                   double floor_eps, int *info, void *newton_ws,
-                                   int *not_converged, void *stream) {
-  SSSPY_REQUIRE(Vc && G && B > 0 && F > 0, "ipa_transform: bad argument");
-  SSSPY_REQUIRE(source_idx >= 0 && source_idx < N, "ipa_transform: bad source index");
-  SSSPY_REQUIRE(max_iter >= 0, "ipa_transform: max_iter must be non-negative");
-  if (N < 2 || N > SSSPY_MAX_SOURCES)
-    return fail(SSSPY_ERR_UNSUPPORTED, "IPA is built for n_sources in [2, 8]");
+// one source step; Vchain != NULL: the chained form (statistics and accumulated transform updated in
+// place, see the kernel)
+static int ipa_step(const void *Vc, void *G, int source_idx, int B, int F, int N, int normalization,
+                    int max_iter, int floor_kind, double floor_eps, int *info, void *newton_ws,
+                    int *not_converged, hipStream_t st, c128 *Vchain, int chain_first) {
   const long long nbins = (long long)B * F;
-  hipStream_t st = as_stream(stream);
 #define IPA_CASE(N_, S_)                                                                     \
   if (N == N_ && source_idx == S_)                                                           \
     return launch_one<N_, S_>(Vc, G, nbins, B, F, normalization, max_iter, floor_kind,     \
                               floor_eps, info, (unsigned long long *)newton_ws, not_converged, \
-                              st);
+                              st, Vchain, chain_first);
   IPA_CASE(2, 0) IPA_CASE(2, 1)
   IPA_CASE(3, 0) IPA_CASE(3, 1) IPA_CASE(3, 2)
   IPA_CASE(4, 0) IPA_CASE(4, 1) IPA_CASE(4, 2) IPA_CASE(4, 3)
@@ -443,6 +549,34 @@ extern "C" int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int 
   IPA_CASE(8, 6) IPA_CASE(8, 7)
 #undef IPA_CASE
   return fail(SSSPY_ERR_UNSUPPORTED, "ipa_transform: unsupported (n_sources, source) pair");
+}
+
+extern "C" int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int B, int F, int N,
+                                   int normalization, int max_iter, int floor_kind,
+                                   double floor_eps, int *info, void *newton_ws,
+                                   int *not_converged, void *stream) {
+  SSSPY_REQUIRE(Vc && G && B > 0 && F > 0, "ipa_transform: bad argument");
+  SSSPY_REQUIRE(source_idx >= 0 && source_idx < N, "ipa_transform: bad source index");
+  SSSPY_REQUIRE(max_iter >= 0, "ipa_transform: max_iter must be non-negative");
+  if (N < 2 || N > SSSPY_MAX_SOURCES)
+    return fail(SSSPY_ERR_UNSUPPORTED, "IPA is built for n_sources in [2, 8]");
+  return ipa_step(Vc, G, source_idx, B, F, N, normalization, max_iter, floor_kind, floor_eps, info,
+                  newton_ws, not_converged, as_stream(stream), nullptr, 0);
+}
+
+extern "C" int ssspy_ipa_sweep(void *Vc, void *G, int B, int F, int N, int normalization,
+                               int max_iter, int floor_kind, double floor_eps, int *info,
+                               void *newton_ws, int *not_converged, void *stream) {
+  SSSPY_REQUIRE(Vc && G && B > 0 && F > 0, "ipa_sweep: bad argument");
+  SSSPY_REQUIRE(max_iter >= 0, "ipa_sweep: max_iter must be non-negative");
+  if (N < 2 || N > SSSPY_MAX_SOURCES)
+    return fail(SSSPY_ERR_UNSUPPORTED, "IPA is built for n_sources in [2, 8]");
+  for (int s = 0; s < N; ++s) {
+    const int rc = ipa_step(Vc, G, s, B, F, N, normalization, max_iter, floor_kind, floor_eps, info,
+                            newton_ws, not_converged, as_stream(stream), (c128 *)Vc, s == 0);
+    if (rc) return rc;
+  }
+  return SSSPY_OK;
 }
 
 static int lqpqm2_launch(const void *H, const void *v, const double *z, void *y, long long n, int L,

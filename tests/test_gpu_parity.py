@@ -7,6 +7,7 @@ iterations is ~1e3), and losses to 1e-9 relative.
 """
 
 import functools
+import warnings
 
 import numpy as np
 import pytest
@@ -152,6 +153,31 @@ def test_ipa_newton_step_count_is_per_mixture(newton_iter):
         ref.newton_iter = newton_iter
         Yr = ref.run(X[0], n_iter=3, basis=basis[0], activation=act[0])
     assert rel_err(Y[0], Yr) < TOL
+
+
+@pytest.mark.parametrize("N", [2, 3, 4, 6, 8])
+def test_ipa_chained_sweep_equals_per_source_passes(N, monkeypatch):
+    """Round 5: one weighted covariance, the N source steps chained on the per-bin statistics
+    (V_m <- G V_m G^H) and one Y <- G Y (ssspy_ipa_sweep) against the literal per-source passes
+    (SSSPY_AMD_IPA_PER_SOURCE: covariance -> update matrix -> Y <- G Y, N times), a batch of two
+    mixtures with different Newton step counts, and the oracle."""
+    from oracle.ipa import update_by_ipa as oracle_ipa
+    from ssspy_amd.bss._update_spatial_model import update_by_ipa
+
+    rng = np.random.default_rng(40 + N)
+    F, T = 9, 50
+    Y = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+    varphi = 1.0 / (rng.random((N, F, T)) + 0.05)
+    for kw in (dict(), dict(normalization=False, max_iter=4), dict(max_iter=9)):
+        a = update_by_ipa(Y, varphi, **kw)
+        monkeypatch.setenv("SSSPY_AMD_IPA_PER_SOURCE", "1")
+        b = update_by_ipa(Y, varphi, **kw)
+        monkeypatch.delenv("SSSPY_AMD_IPA_PER_SOURCE")
+        assert rel_err(a, b) < 1e-11
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = oracle_ipa(Y, varphi, **kw)
+        assert rel_err(a, ref) < 1e-10
 
 
 def test_ipa_eight_sources_against_oracle():
