@@ -85,6 +85,14 @@ const char *ssspy_last_error(void);
 int ssspy_separate(const void *X, const void *W, void *Y, int B, int N, int F, int T,
                    void *stream);
 
+/* Cout (B,F,N,N) = G C G^H per bin (C != Cout): the covariance of y' = G y from the covariance of y.
+ * ILRMA's ISS2 / IPA iterations keep C_i = (1/T) sum_j y y^H of the separated spectrogram alongside it
+ * (round 5): the power normalisation psi_n^2 = mean_i g_n^H C_i g_n of the UPDATED spectrogram is
+ * then known before y <- G y runs, its scale goes into the rows of G, and the two extra passes of
+ * ssspy/bss/ilrma.py:412-444 (mean |y|^2, y / psi) disappear.  n_sources <= 16. */
+int ssspy_covariance_congruence(const void *C, const void *G, void *Cout, int B, int F, int N,
+                                void *stream);
+
 /* U[b,i,s,a,c] = (1/T) sum_j weight[...] A[b,a,i,j] conj(A[b,c,i,j]), s < S.
  * A (B,N,F,T) complex, U (B,F,S,N,N) complex, weight per `weight_kind`.
  * replaces: the (F,N,N,N,T) broadcast + mean of ssspy/bss/ilrma.py:1500-1505,

@@ -92,6 +92,14 @@ def weighted_covariance(A, weight=None, kind=_lib.WEIGHT_UNIT, n_sets=1, out=Non
     return out
 
 
+def covariance_congruence(C, G, out):
+    """out = G C G^H per bin, (B, F, N, N)."""
+    B, F, N = C.shape[0], C.shape[1], C.shape[-1]
+    _lib.check(_L().ssspy_covariance_congruence(ptr(C), ptr(G), ptr(out), B, F, N, _st()),
+               "covariance_congruence")
+    return out
+
+
 def cross_covariance(A, Bm, out=None):
     B, N, F, T = A.shape
     if out is None:

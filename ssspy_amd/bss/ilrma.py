@@ -413,9 +413,73 @@ class _MMILRMA(ILRMABase):
                 self._state_touch(name)
             return
         self.update_source_model(flooring_fn=flooring_fn)
+        if self._folded_output_normalization(floor):
+            self._update_spatial_model_folded(flooring_fn)
+            return
         self.update_spatial_model(flooring_fn=flooring_fn)
         if self.normalization:
             self.normalize(flooring_fn=flooring_fn)
+
+    # -- ISS2 / IPA with the power normalisation folded into the update matrix (round 5) -------
+    def _folded_output_normalization(self, floor) -> bool:
+        cls = type(self)
+        return (self.spatial_algorithm in _ISS2 + _IPA and bool(self.normalization)
+                and self._power_normalization_or_off() and not self.partitioning
+                and not self._uses_filter() and host_floor(floor) is None and self._is_stock()
+                and cls.update_spatial_model_iss2 is _MMILRMA.update_spatial_model_iss2
+                and cls.update_spatial_model_ipa is _MMILRMA.update_spatial_model_ipa
+                and not _os.environ.get("SSSPY_AMD_NO_FOLDED_NORM"))
+
+    def _output_covariance(self, Y):
+        """C_i = (1/T) sum_j y y^H of the separated spectrogram, (B, F, N, N): formed once and moved
+        along by the folded updates (C <- G C G^H); rebuilt when anything else rewrote Y."""
+        cache = getattr(self, "_ycov", None)
+        if cache is not None and cache[1] == self._state_rev("output"):
+            return cache[0]
+        B, N, F, T = Y.shape
+        return _ops.weighted_covariance(Y).reshape(B, F, N, N)
+
+    def _update_spatial_model_folded(self, flooring_fn) -> None:
+        """update_spatial_model() + normalize() of the ISS2 / IPA iterations in three passes over Y.
+        The reference updates y <- G y, measures psi_n^2 = mean |y_n|^2 in a second pass and divides
+        in a third (ilrma.py:1698-1908, :412-444).  The power of the UPDATED spectrogram is
+        mean_i g_n^H C_i g_n with the covariance C_i of the current one, so psi is known before the
+        update runs: rows of G / psi_n, basis / psi_n^p, one y <- G y, and C <- G C G^H for the next
+        iteration.  The tracked log-determinant moves by sum_i log|det G_i|."""
+        floor = self._resolve_floor(flooring_fn)
+        if self.spatial_algorithm in _IPA:
+            require_device_floor(floor, "IPA")
+        Y = self._state_dev("output")
+        B, N, F, T = Y.shape
+        Vc = self._output_statistics(Y, flooring_fn)
+        if Vc is None:
+            if self._base_model[0] != _lib.SOURCE_GAUSS:  # (t / GGD weights floor per element)
+                require_device_floor(floor, "ISS2 / IPA with a heavy-tailed model")
+            varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y,
+                                           model=self._model, flooring=floor)
+            Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
+        if self.spatial_algorithm in _ISS2:
+            G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N),
+                                    floor, self._info_tensor())
+        else:
+            G = _ops.ipa_sweep(Vc, self.lqpqm_normalization, self.newton_iter, floor,
+                               self._info_tensor(), newton_ws=dv.empty((B,), dv.i64, Y.device),
+                               not_converged=self._newton_counter())
+        C = self._output_covariance(Y)
+        _ops.ilrma_normalize_filter(G, C, self._state_dev("basis"), float(self.domain), floor,
+                                    self._ws, self._ws_bytes)
+        spare = getattr(self, "_ycov_spare", None)
+        if spare is None or spare.shape != C.shape or spare.data_ptr() == C.data_ptr():
+            spare = dv.empty(tuple(C.shape), dv.c128, Y.device)
+        _ops.covariance_congruence(C, G, spare)
+        tracked = self._tracked_logdet()
+        if tracked is not None:
+            tracked.add_(_ops.sum_logdet(G))
+        _ops.separate(Y, G, out=Y)
+        self._state_touch("output")
+        self._state_touch("basis")
+        self._ycov, self._ycov_spare = (spare, self._state_rev("output")), C
+        self._restamp_logdet(tracked)
 
     def _power_normalization_or_off(self) -> bool:
         return (not self.normalization) or type(self.normalization) is bool \

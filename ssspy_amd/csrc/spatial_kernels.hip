@@ -67,6 +67,27 @@ __global__ __launch_bounds__(256) void k_separate(const c128 *__restrict__ X,
   }
 }
 
+// ------------------------------------------------------------------------ covariance congruence
+// Cout_i = G_i C_i G_i^H per bin: the covariance of y' = G y from the covariance of y without a pass
+// over the spectrogram.  One thread per output element (any n_sources; N^2 complex products each).
+__global__ __launch_bounds__(256) void k_covariance_congruence(const c128 *__restrict__ C,
+                                                               const c128 *__restrict__ G,
+                                                               c128 *__restrict__ Cout,
+                                                               long long nbins, int N) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nbins * N * N) return;
+  const long long bin = e / (N * N);
+  const int rc = (int)(e - bin * (N * N)), r = rc / N, c = rc - r * N;
+  const c128 *Cb = C + bin * (long long)(N * N), *Gb = G + bin * (long long)(N * N);
+  c128 acc = cmake(0.0, 0.0);
+  for (int k = 0; k < N; ++k) {
+    c128 t = cmake(0.0, 0.0);  // (C G^H)[k][c]
+    for (int l = 0; l < N; ++l) cfma(t, Cb[k * N + l], cconj(Gb[c * N + l]));
+    cfma(acc, Gb[r * N + k], t);
+  }
+  Cout[e] = acc;
+}
+
 // ------------------------------------------------------------------------- weighted covariance
 template <int N, int SG, int MODE>
 __global__ __launch_bounds__(256) void k_weighted_cov(const c128 *__restrict__ A,
@@ -680,6 +701,16 @@ int ssspy_separate(const void *X, const void *W, void *Y, int B, int N, int F, i
   DISPATCH_N(N, hipLaunchKernelGGL((k_separate<NN>), grid, block, 0, as_stream(stream),
                                    (const c128 *)X, (const c128 *)W, (c128 *)Y, F, T));
   return check_launch("k_separate");
+}
+
+int ssspy_covariance_congruence(const void *C, const void *G, void *Cout, int B, int F, int N,
+                                void *stream) {
+  SSSPY_REQUIRE(C && G && Cout && C != Cout && B > 0 && F > 0 && N >= 1 && N <= SSSPY_RT_MAX_SOURCES,
+                "covariance_congruence: bad argument");
+  const long long nbins = (long long)B * F, total = nbins * N * N;
+  hipLaunchKernelGGL(k_covariance_congruence, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), (const c128 *)C, (const c128 *)G, (c128 *)Cout, nbins, N);
+  return check_launch("k_covariance_congruence");
 }
 
 int ssspy_weighted_covariance(const void *A, const double *weight, int weight_kind, void *U, int B,

@@ -180,6 +180,52 @@ def test_ipa_chained_sweep_equals_per_source_passes(N, monkeypatch):
         assert rel_err(a, ref) < 1e-10
 
 
+@pytest.mark.parametrize("algo,N,B", [("ISS2", 4, 1), ("IPA", 3, 1), ("ISS2", 5, 3), ("IPA", 4, 2),
+                                       ("ISS2", 10, 1)])
+def test_ilrma_folded_power_normalization_equals_three_pass_form(algo, N, B, monkeypatch):
+    """Round 5: ISS2 / IPA iterations of GaussILRMA with the power normalisation folded into the
+    update matrix (psi from g^H C g, C <- G C G^H, tracked log-determinant) against the literal
+    update -> mean |y|^2 -> y / psi passes (SSSPY_AMD_NO_FOLDED_NORM), 12 iterations, with the loss
+    recorded, and against the oracle."""
+    from oracle.ilrma import GaussILRMAOracle
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    F, T, K = 19, 48, 3
+    X = np.stack([nmf_mixture(900 + b, N, F, T) for b in range(B)])
+    rng = np.random.default_rng(8)
+    kw = dict(basis=rng.random((B, N, F, K)), activation=rng.random((B, N, K, T)))
+    if B == 1:
+        X, kw = X[0], {k: v[0] for k, v in kw.items()}
+
+    def run():
+        m = GaussILRMA(n_basis=K, spatial_algorithm=algo)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            Y = m(X, n_iter=12, **{k: v.copy() for k, v in kw.items()})
+        return m, Y
+
+    m1, Y1 = run()
+    assert getattr(m1, "_ycov", None) is not None
+    monkeypatch.setenv("SSSPY_AMD_NO_FOLDED_NORM", "1")
+    m2, Y2 = run()
+    monkeypatch.delenv("SSSPY_AMD_NO_FOLDED_NORM")
+    assert getattr(m2, "_ycov", None) is None
+    err = rel_err  # (after projection back: no pairwise phase ambiguity left)
+    assert err(Y1, Y2) < 1e-9
+    np.testing.assert_allclose(m1.loss, m2.loss, rtol=1e-9)
+    assert rel_err(m1.basis, m2.basis) < 1e-9
+    if N <= 8:
+        ref = GaussILRMAOracle(n_basis=K, spatial_algorithm=algo)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            Yr = ref.run(X if B == 1 else X[0], n_iter=12,
+                         **{k: (v if B == 1 else v[0]).copy() for k, v in kw.items()})
+        loss = np.asarray(m1.loss)
+        np.testing.assert_allclose(loss if B == 1 else loss[:, 0], ref.loss, rtol=LOSS_RTOL)
+        assert err(Y1 if B == 1 else Y1[0], Yr) < 1e-7
+
+
 def test_ipa_eight_sources_against_oracle():
     from oracle.ipa import update_by_ipa as oracle_ipa
     from ssspy_amd.bss._update_spatial_model import update_by_ipa
