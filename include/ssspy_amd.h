@@ -321,11 +321,12 @@ int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *act
 
 /* out[b] = sum_{n,i} mean_j ( data term of the model + (2/p) log R ), y = W x (or x when
  * W == NULL); `out` (B doubles) is overwritten.  The caller adds -2 * ssspy_sum_logdet.
- * The per-workgroup shares are parked in `workspace` (ssspy_ilrma_loss_workspace_bytes; the
- * workspace of ssspy_ilrma_workspace_bytes is large enough too) and added up in a fixed order:
+ * The per-workgroup shares are parked in `workspace` (ssspy_ilrma_loss_workspace_bytes for this
+ * n_basis, with_filter = (W != NULL); the workspace of ssspy_ilrma_workspace_bytes is large enough
+ * too) and added up in a fixed order:
  * no fp64 atomics, the same bits on every run.
  * replaces: ssspy/bss/ilrma.py:1946-1965, :3291-3310, :4367-4386. */
-size_t ssspy_ilrma_loss_workspace_bytes(int B, int N, int F, int T);
+size_t ssspy_ilrma_loss_workspace_bytes(int B, int N, int F, int T, int K, int with_filter);
 int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
                           const double *activation, double *out, int B, int N, int F, int T, int K,
                           double domain, int source_model, double model_param, void *workspace,

@@ -4,6 +4,8 @@ PyTorch is used only as an allocator / stream provider / host<->device copier; e
 arithmetic kernel on the hot path is in libssspy_amd.so.
 """
 
+import threading
+
 import numpy as np
 import torch
 
@@ -26,7 +28,7 @@ def device(index=None):
 # arrays go through page-locked staging buffers (torch's caching host allocator keeps a buffer
 # alive until the copy that reads it has run) and the host never waits.  Off by default: for one
 # call the extra host copy costs more than the wait it saves.
-_staged = [0]
+_staged = threading.local()  # (per thread: a runner's context must not change other threads' copies)
 _STAGE_MIN_BYTES = 1 << 16
 
 
@@ -34,11 +36,11 @@ class staged_uploads:
     """Context manager: ``to_device`` copies of 64 KiB and more become asynchronous."""
 
     def __enter__(self):
-        _staged[0] += 1
+        _staged.depth = getattr(_staged, "depth", 0) + 1
         return self
 
     def __exit__(self, *exc):
-        _staged[0] -= 1
+        _staged.depth -= 1
         return False
 
 
@@ -48,7 +50,7 @@ def to_device(array, dtype=None, dev=None):
     if not a.flags.writeable:  # e.g. a view of an .npz member or a broadcast: torch wants writable
         a = a.copy()
     t = torch.from_numpy(a)
-    if _staged[0] and a.nbytes >= _STAGE_MIN_BYTES:
+    if getattr(_staged, "depth", 0) and a.nbytes >= _STAGE_MIN_BYTES:
         pinned = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         pinned.copy_(t)
         return pinned.to(dev or device(), non_blocking=True)

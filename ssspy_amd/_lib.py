@@ -21,7 +21,9 @@ PARTITION_LATENT, PARTITION_BASIS, PARTITION_ACTIVATION = 1, 2, 4
 SOURCE_ME = 0x100  # OR-ed into the model: source_algorithm="ME"
 CONTRAST_LAPLACE, CONTRAST_GAUSS, CONTRAST_GAUSS_FIXED = 0, 1, 2
 MAX_PAIRS = 32
-MAX_SOURCES, MAX_BASIS = 8, 1024
+# SSSPY_MAX_SOURCES (per-N kernels: IPA, both MNMF classes, the Hermitian operators),
+# SSSPY_RT_MAX_SOURCES (run-time-N kernels: the shared operators, ILRMA and AuxIVA), SSSPY_MAX_BASIS
+MAX_SOURCES, RT_MAX_SOURCES, MAX_BASIS = 8, 16, 1024
 
 _p, _i, _d, _z = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
 _q = ctypes.c_longlong
@@ -72,7 +74,7 @@ PROTOTYPES = {
     "ssspy_ilrma_normalize_output_tracked": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p, _z,
                                                   _p, _p]),
     "ssspy_ilrma_iss_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _i, _d, _p]),
-    "ssspy_ilrma_loss_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "ssspy_ilrma_loss_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "ssspy_ilrma_loss_data": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p, _z, _p]),
     "ssspy_ilrma_ip1_update": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _i, _i, _d,
                                     _p, _z, _p, _p]),

@@ -234,8 +234,10 @@ def iss2_transform(Vc, pairs, flooring, info=None, out=None):
                                                           N, ptr(denom), ptr(info), _st()),
                        "iss2_transform (deferred)")
             d = dv.to_host(denom)
-            # (the callable sees both members at once, (2, n_bins), as in the reference)
-            fl = np.stack([np.asarray(host(d[b].T), dtype=np.float64).reshape(2, F) for b in range(B)])
+            # (the callable sees both members at once, (2, n_bins, 1), as in the reference:
+            #  _update_spatial_model.py:300-312 floors the square root with keepdims)
+            fl = np.stack([np.asarray(host(d[b].T[:, :, None]), dtype=np.float64).reshape(2, F)
+                           for b in range(B)])
             for k, row in enumerate(pair):
                 dk = np.ascontiguousarray(fl[:, k, :])
                 _lib.check(_L().ssspy_scale_filter_row(ptr(out), ptr(dv.to_device(dk, dev=Vc.device)),
@@ -488,7 +490,8 @@ def ilrma_loss_data(X, W, basis, activation, domain, out=None, model=GAUSS):
     K = basis.shape[-1]
     if out is None:
         out = dv.empty((B,), dv.f64, X.device)
-    ws, ws_bytes = _scratch(_L().ssspy_ilrma_loss_workspace_bytes(B, N, F, T), X.device)
+    ws, ws_bytes = _scratch(_L().ssspy_ilrma_loss_workspace_bytes(B, N, F, T, K, int(W is not None)),
+                            X.device)
     _lib.check(
         _L().ssspy_ilrma_loss_data(ptr(X), ptr(W), ptr(basis), ptr(activation), ptr(out), B, N, F,
                                    T, K, domain, model[0], model[1], ptr(ws), ws_bytes, _st()),

@@ -101,7 +101,7 @@ def update_by_ip2(
     The two rows of a pair come out with the arbitrary phase of a 2 x 2 eigenvector (as in the
     reference, where it is LAPACK's); scale restoration removes it.
     """
-    floor = device_flooring(flooring_fn, what="update_by_ip2")
+    floor = device_flooring(flooring_fn, what="update_by_ip2", allow_host=True)
     N = demix_filter.shape[-2]
     W = dv.to_device(demix_filter[None], dtype=np.complex128)
     U = dv.to_device(weighted_covariance[None], dtype=np.complex128)
@@ -125,7 +125,7 @@ def update_by_iss2(
 
     Default pairs: (0,1), (2,3), ... as in the reference (sequential selector with step 2).
     """
-    floor = device_flooring(flooring_fn, what="update_by_iss2")
+    floor = device_flooring(flooring_fn, what="update_by_iss2", allow_host=True)
     Y = dv.to_device(separated[None], dtype=np.complex128)
     B, N, F, T = Y.shape
     if pair_selector is None:

@@ -299,7 +299,11 @@ __global__ __launch_bounds__(64) void k_qinv(const c128 *__restrict__ Q, c128 *Q
 // Multichannel Wiener filter (ref: ssspy/bss/mnmf.py:1174-1217): grid (F, B), lanes along frames.
 // R = Q~ diag(rc) Q~^H, Q~ = Q^-1; closed form R^-1 = Q^H diag(1/rc) Q when the eigenvalue floor is
 // provably idle (lambda_min(R) >= min rc / ||Q||_F^2 > eps), else the Jacobi eigen-floor.
-template <int M>
+// Round 5: two launches of it.  REPAIR == false holds the closed form alone (no M x M working set: 5-8
+// channels no longer spill 530-2400 registers per lane on the path every call takes) and flags the
+// bins that have a point where the floor may act; REPAIR == true is the old kernel restricted to the
+// flagged bins (both forms per point, as before).
+template <int M, bool REPAIR>
 __global__ __launch_bounds__(128) void k_separate(const c128 *__restrict__ X,
                                                   const c128 *__restrict__ Q,
                                                   const c128 *__restrict__ Qinv,
@@ -307,8 +311,9 @@ __global__ __launch_bounds__(128) void k_separate(const c128 *__restrict__ X,
                                                   const double *__restrict__ basis,
                                                   const double *__restrict__ act, c128 *Y, int N,
                                                   int F, int T, int K, int ref, int floor_kind,
-                                                  double eps) {
+                                                  double eps, int *redo) {
   const int i = blockIdx.x, b = blockIdx.y;
+  if (REPAIR && !redo[(long long)b * F + i]) return;
   __shared__ c128 qt[M * M];
   __shared__ c128 qsrc[M * M];
   __shared__ double dd[NMAX * M];
@@ -349,7 +354,12 @@ __global__ __launch_bounds__(128) void k_separate(const c128 *__restrict__ X,
 #pragma unroll
     for (int m = 0; m < M; ++m) x[m] = X[(((long long)b * M + m) * F + i) * T + j];
     c128 sm[M];  // s_m = (Q~^H R^-1 x)_m, then scaled by q~[ref][m]
-    if (floor_kind != SSSPY_FLOOR_ADD && rcmin > eps * qf2 * 1.0000001) {
+    const bool closed = floor_kind != SSSPY_FLOOR_ADD && rcmin > eps * qf2 * 1.0000001;
+    if (!REPAIR && !closed) {
+      redo[(long long)b * F + i] = 1;  // (every writer stores the same value)
+      continue;
+    }
+    if (closed) {
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         c128 y = cmake(0.0, 0.0);
@@ -358,7 +368,7 @@ __global__ __launch_bounds__(128) void k_separate(const c128 *__restrict__ X,
         const double g = 1.0 / rc[m];
         sm[m] = cmake(y.x * g, y.y * g);
       }
-    } else {
+    } else if constexpr (REPAIR) {
       c128 A[M][M], P[M][M];
 #pragma unroll
       for (int a = 0; a < M; ++a)
@@ -532,16 +542,22 @@ int fmnmf_generic_loss(const void *X, const void *Q, const double *D, const doub
 int fmnmf_generic_separate(const void *X, const void *Q, void *Qinv, const double *D,
                            const double *basis, const double *act, void *Y, int B, int N, int M,
                            int F, int T, int K, int ref, int floor_kind, double eps, int *info,
-                           hipStream_t st) {
+                           int *redo, hipStream_t st) {
+  // redo: B F ints of scratch (bins the closed-form launch hands to the general one)
   using namespace fmg;
   if (N < 1 || N > NMAX) return fail(SSSPY_ERR_UNSUPPORTED, "FastMNMF: n_sources must be in [1, 8]");
   const long long nbins = (long long)B * F;
+  hipError_t e = hipMemsetAsync(redo, 0, (size_t)nbins * sizeof(int), st);
+  if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
   FMG_DISPATCH_M(M, {
     hipLaunchKernelGGL((k_qinv<MM>), dim3((unsigned)((nbins + 63) / 64)), dim3(64), 0, st,
                        (const c128 *)Q, (c128 *)Qinv, nbins, info);
-    hipLaunchKernelGGL((k_separate<MM>), dim3(F, B), dim3(128), 0, st, (const c128 *)X,
+    hipLaunchKernelGGL((k_separate<MM, false>), dim3(F, B), dim3(128), 0, st, (const c128 *)X,
                        (const c128 *)Q, (const c128 *)Qinv, D, basis, act, (c128 *)Y, N, F, T, K,
-                       ref, floor_kind, eps);
+                       ref, floor_kind, eps, redo);
+    hipLaunchKernelGGL((k_separate<MM, true>), dim3(F, B), dim3(128), 0, st, (const c128 *)X,
+                       (const c128 *)Q, (const c128 *)Qinv, D, basis, act, (c128 *)Y, N, F, T, K,
+                       ref, floor_kind, eps, redo);
   });
   return check_launch("fmnmf_generic separate");
 }

@@ -250,7 +250,10 @@ static inline size_t basis_part_bytes(int N) {
 // scratch of the deterministic loss sums: the larger of what the tuned kernels (by-product of the
 // basis pass, loss pass) and the generic loss kernel need
 size_t wb_loss_ws_bytes(int B, int N, int F, int T);  // wide_basis.hip
-static inline size_t loss_slots_bytes(int B, int N, int F, int T) {
+// K, with_filter: the wide-basis loss (n_basis above 16, or more than 8 sources) parks one slot per
+// 64 x 64 tile of every source and, when a filter is given, |W x|^2 (B N F T doubles) -- only
+// then (round 4 added both terms for every shape: 2.1 GB idle at the headline batch, twice)
+static inline size_t loss_slots_bytes(int B, int N, int F, int T, int K, bool with_filter) {
   auto generic = [&]() -> size_t {
     switch (N) {
       case 2: return ilrma_loss_ws_bytes_n2(B, F);
@@ -275,8 +278,11 @@ static inline size_t loss_slots_bytes(int B, int N, int F, int T) {
   size_t c = rt_sources_ok(N) ? rt_ilrma_loss_ws_bytes(B, N, F) : 0;
   // (the wide-basis loss: one slot per 64 x 64 tile of every source; a y = W x buffer when a filter
   //  is given)
-  const size_t g = align256(wb_loss_ws_bytes(B, N, F, T)) + align256((size_t)B * N * F * T * sizeof(double));
-  c = c > g ? c : g;
+  if (K > 16 || rt_sources_ok(N)) {
+    const size_t g = align256(wb_loss_ws_bytes(B, N, F, T)) +
+                     (with_filter ? align256((size_t)B * N * F * T * sizeof(double)) : 0);
+    c = c > g ? c : g;
+  }
   return align256(a > b ? (a > c ? a : c) : (b > c ? b : c));
 }
 static inline size_t u_part_bytes(int N) {
@@ -658,7 +664,7 @@ static inline IlrmaWs ilrma_ws(int B, int N, int F, int T, int K) {
   w.psi = off;
   off += align256((size_t)B * N * sizeof(double));
   w.lslots = off;  // per-wave shares of a loss, folded in a fixed order (no fp64 atomics)
-  off += loss_slots_bytes(B, N, F, T);
+  off += loss_slots_bytes(B, N, F, T, K, true);
   w.bpart = off;
   off += basis_part_bytes(N);
   w.upart = off;
@@ -1073,9 +1079,9 @@ int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *act
   return check_launch("k_ilrma_iss_weight");
 }
 
-size_t ssspy_ilrma_loss_workspace_bytes(int B, int N, int F, int T) {
-  if (B <= 0 || N <= 0 || F <= 0 || T <= 0) return 0;
-  return loss_slots_bytes(B, N, F, T);
+size_t ssspy_ilrma_loss_workspace_bytes(int B, int N, int F, int T, int K, int with_filter) {
+  if (B <= 0 || N <= 0 || F <= 0 || T <= 0 || K <= 0) return 0;
+  return loss_slots_bytes(B, N, F, T, K, with_filter != 0);
 }
 
 int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
@@ -1085,7 +1091,7 @@ int ssspy_ilrma_loss_data(const void *X, const void *W, const double *basis,
   SSSPY_REQUIRE(X && basis && activation && out && B > 0, "ilrma_loss_data: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "ilrma_loss_data: bad n_basis");
   SSSPY_REQUIRE(N >= 2 && N <= SSSPY_RT_MAX_SOURCES, "ilrma_loss_data: n_sources must be in [2, 16]");
-  SSSPY_REQUIRE(workspace && workspace_bytes >= loss_slots_bytes(B, N, F, T),
+  SSSPY_REQUIRE(workspace && workspace_bytes >= loss_slots_bytes(B, N, F, T, K, W != nullptr),
                 "ilrma_loss_data: workspace too small (ssspy_ilrma_loss_workspace_bytes)");
   int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;

@@ -184,8 +184,9 @@ __device__ __forceinline__ void iss_sweeps(c128 (&y)[N][FPT], const double (&phi
     h = 0.5 * den * rs;
     e2 = fma(-h, rs, 0.5);
     rs = fma(rs, e2, rs);
-    // (den = 0, Inf or NaN: keep what the divide and the square root return)
-    const bool special = !(den > 0.0) || !(den < 1.7976931348623157e308);
+    // (den = 0, Inf or NaN, or so small that 1 / den overflows -- the reciprocal seed is Inf and the
+    //  Newton step turns it into NaN: keep what the divide and the square root return)
+    const bool special = !(den > 8.9e-308) || !(den < 1.7976931348623157e308);
     if (special) {
       rd = 1.0 / den;
       rs = 1.0 / sqrt(den);

@@ -64,7 +64,7 @@ int fmnmf_generic_loss(const void *X, const void *Q, const double *D, const doub
 int fmnmf_generic_separate(const void *X, const void *Q, void *Qinv, const double *D,
                            const double *basis, const double *act, void *Y, int B, int N, int M,
                            int F, int T, int K, int ref, int floor_kind, double eps, int *info,
-                           hipStream_t st);
+                           int *redo, hipStream_t st);
 
 // the MFMA-tile kernels (mnmf_kernels.hip) are compiled for 2..4 sources and channels
 static inline bool mnmf_tiled(int N, int M) { return N >= 2 && N <= 4 && M >= 2 && M <= 4; }
@@ -398,7 +398,8 @@ int ssspy_fastmnmf_separate(const void *X, const void *Q, const double *D, const
   void *Qinv = (char *)workspace + w.qinv;
   if (!mnmf_tiled(N, M))
     return fmnmf_generic_separate(X, Q, Qinv, D, basis, activation, Y, B, N, M, F, T, K,
-                                  reference_id, floor_kind, floor_eps, info, as_stream(stream));
+                                  reference_id, floor_kind, floor_eps, info,
+                                  (int *)((char *)workspace + w.qbuf), as_stream(stream));
   // (the per-bin row powers' scratch is idle here: B F ints of it flag the bins for the general kernel)
   MNMF_DISPATCH(N, mnmf_separate, X, Q, Qinv, D, basis, activation, Y, B, M, F, T, K, reference_id,
                 floor_kind, floor_eps, info, (int *)((char *)workspace + w.qbuf), as_stream(stream));

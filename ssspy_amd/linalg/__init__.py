@@ -203,8 +203,12 @@ def lqpqm2(H: np.ndarray, v: np.ndarray, z: np.ndarray, flooring_fn="default",
     H (n_bins, L, L) Hermitian, v (n_bins, L), z (n_bins,) -> y (n_bins, L).  The Newton loop stops
     when every problem has converged and warns when they have not after ``max_iter`` steps, like
     the reference (lqpqm.py:196-213).  ``singular_fn``: "flooring" (default), None or a callable on the
-    norms of ``v``, as in the reference (lqpqm.py:61-78); the solution of a singular problem is a
-    scaled top eigenvector of ``H`` and carries that eigenvector's arbitrary phase.
+    norms of ``v``, as in the reference (lqpqm.py:61-78).  A singular problem follows the reference's
+    indexing literally (lqpqm.py:84-93: ``scale * sigma[:, -1]`` on the ``(n_bins, L, L)`` eigenvector
+    array): component ``a`` of the solution is the LAST entry of the eigenvector of the ``a``-th
+    smallest eigenvalue of ``H`` -- the last row of the eigenvector matrix, not its last column.
+    Every component carries a different eigenvector's arbitrary phase, so only the moduli are
+    comparable between implementations.
     """
     import functools
 

@@ -118,7 +118,11 @@ def separate_pipelined(make_separator: Callable[[], object], X, sub_batch: int, 
     in sub-batches of ``sub_batch`` mixtures, overlapping the PCIe transfers with the iterations:
     while the separator iterates on sub-batch k (torch's current stream), a copy stream uploads
     sub-batch k + 1 and a second one downloads the result of k - 1.  Mixtures are independent, so
-    the result equals ``make_separator()(X, n_iter)`` element for element.
+    the result equals ``make_separator()(X, n_iter)`` element for element -- PROVIDED the initial
+    state of a mixture does not depend on where it sits in a call: pass it explicitly
+    (``basis=`` / ``activation=`` in ``call_kwargs``, per mixture) or accept that a separator seeded
+    with one ``rng`` draws a (sub_batch, ...) block per sub-batch where the single call draws one
+    (n_mixtures, ...) block, i.e. different random initial values for all but the first block.
 
     ``make_separator()`` returns a fresh separator (``GaussILRMA`` ...) per sub-batch.  Transfers are
     asynchronous only from / to page-locked memory: a pinned ``X`` (e.g. the ``.numpy()`` view of

@@ -112,7 +112,20 @@ def get_window(window, n_fft: int) -> np.ndarray:
         w1 = 0.5 * (1 + np.cos(np.pi * (-1 + 2.0 * n1 / alpha / (m - 1))))
         w3 = 0.5 * (1 + np.cos(np.pi * (-2.0 / alpha + 1 + 2.0 * n3 / alpha / (m - 1))))
         return np.concatenate([w1, np.ones(n2.shape), w3])[:n]
+    if name in _SCIPY_ONLY_WINDOWS:
+        raise NotImplementedError(
+            "window {!r} is a scipy.signal window that is not built here; pass "
+            "scipy.signal.get_window({!r}, n_fft) as an array instead.".format(name, window))
     raise ValueError("Unknown window type {!r}.".format(window))
+
+
+# valid scipy.signal.get_window names that have no closed form here (see get_window)
+_SCIPY_ONLY_WINDOWS = frozenset([
+    "barthann", "brthan", "bth", "lanczos", "sinc", "taylor", "taylorwin", "exponential", "poisson",
+    "chebwin", "cheb", "dpss", "general_gaussian", "general gaussian", "general gauss",
+    "general_gauss", "ggs", "general_cosine", "general cosine", "general_hamming",
+    "general hamming", "kaiser_bessel_derived", "kbd",
+])
 
 
 def _window(window, n_fft: int) -> np.ndarray:
