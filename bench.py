@@ -179,6 +179,42 @@ def power_leg(sep, seconds):
         return {"error": "{}: {}".format(type(exc).__name__, str(exc)[:200])}
 
 
+def joint_power_leg(sep, seconds, rank, fence):
+    """All ranks run update_once() back to back for `seconds` between two barriers while rank 0
+    samples the power sensor and shader clock of EVERY amdgpu card of the node."""
+    try:
+        sampler = None
+        if rank == 0:
+            import importlib.util
+
+            spec = importlib.util.spec_from_file_location(
+                "power_profile", os.path.join(ROOT, "benchmarks", "power_profile.py"))
+            pp = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(pp)
+            sampler = pp.Sampler()
+        fence()
+        if sampler is not None and sampler.cards:
+            sampler.__enter__()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(20):
+                sep.update_once()
+            torch.cuda.synchronize()
+        if sampler is not None and sampler.cards:
+            sampler.__exit__()
+        fence()
+        if rank != 0:
+            return None
+        if not sampler.cards:
+            return {"error": "no amdgpu hwmon power sensor visible"}
+        cards = [sampler.summary(0.5, card=i) for i in range(len(sampler.cards))]
+        return {"cards": cards, "seconds": seconds,
+                "note": "every rank iterating at once; one entry per amdgpu card with a power sensor "
+                        "(sysfs order, not rank order)"}
+    except Exception as exc:  # never cost the headline line
+        return {"error": "{}: {}".format(type(exc).__name__, str(exc)[:200])}
+
+
 def blas_threads():
     try:
         from threadpoolctl import threadpool_info
@@ -571,19 +607,42 @@ def main():
     for _ in range(args.warmup):
         sep.update_once()
     settle_host()
-    regions = []
+    regions, own_regions = [], []
     for _ in range(max(1, args.repeats)):
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             sep.update_once()
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0  # this rank's own work, before it waits for the others
         fence()
         dt = time.perf_counter() - t0
         if distributed:
             dt = parallel.max_over_ranks(dt, dev if backend == "nccl" else None)
         regions.append(dt)
+        own_regions.append(own)
     elapsed = float(np.median(regions))
     sep._check_device_errors()
+
+    # ---- N > 1: what each rank did on its own, and the power of every card while all ranks run
+    # (round-4 verdict item 10: the first real 8-GPU run should show at a glance whether a slow rank
+    # or a shared power budget limits scaling).  After the timed regions; none of it is `value`.
+    per_rank = joint_power = None
+    if distributed:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {"rank": rank, "device": dev_index,
+                                          "own_s": [float(v) for v in own_regions]})
+        joint_power = joint_power_leg(sep, min(args.power_seconds, 1.5), rank, fence)
+        if rank == 0:
+            rates = [B * args.steps / float(np.median(g["own_s"])) for g in gathered]
+            per_rank = {
+                "mixture_iterations_per_s": [round(r, 1) for r in rates],
+                "min": round(min(rates), 1), "median": round(float(np.median(rates)), 1),
+                "max": round(max(rates), 1), "slowest_rank": int(np.argmin(rates)),
+                "sum": round(sum(rates), 1),
+                "note": "each rank's own steps / its own time to drain them (median region), "
+                        "before the closing barrier; `value` divides by the slowest rank's time",
+            }
 
     if rank != 0:
         if distributed:
@@ -646,6 +705,8 @@ def main():
     }
     if n_gpus == 1 and not args.no_extra:
         roofline["power"] = power_leg(sep, args.power_seconds)
+    if joint_power is not None:
+        roofline["power_all_ranks"] = joint_power
     out = {
         "metric": "GaussILRMA-IP1 update_once mixture-iterations/sec (F=1025,T=512,N=4,K=16)",
         "value": round(value, 2),
@@ -662,6 +723,7 @@ def main():
             "note": "each region = exactly `steps` update_once() calls between barrier + synchronize; "
                     "`value` is the median region",
         },
+        "per_rank": per_rank,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

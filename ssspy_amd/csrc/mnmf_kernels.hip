@@ -718,8 +718,11 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
     if constexpr (PMODE == P_READ) ptile_load<M>(t, xr, F, T, bin, j0, q);
     else xtile_load<M>(t, xr, F, T, bin, j0, q);
   };
+  // (round 5) a wave whose 16 bins all lie beyond F fetches no tile and computes nothing: it only
+  // helps staging the activation tiles (F = 1025: three of the four waves of the 17th bin group)
+  const bool active = __builtin_amdgcn_readfirstlane(i0) < F;
   vstage_load(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
-  load_tile(cur, min(jt_begin, ntiles - 1) * 16);
+  if (active) load_tile(cur, min(jt_begin, ntiles - 1) * 16);
   vstage_store(st, vs[0]);
   __syncthreads();
   // one tile of the walk: compute on `xc`, prefetch the next tile into `xn`.  The walk calls it with
@@ -728,8 +731,9 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
     const int j0 = jt * 16;
     const int jn = min(jt + 1, jt_end - 1) * 16;
     vstage_load(st, act_b, K, T, jn);
-    load_tile(xn, jn);
+    if (active) load_tile(xn, jn);
     const double *vcur = vs[(jt - jt_begin) & 1];
+    if (active) {  // (closed before the staging store below)
     double4_t lamR[N];
 #pragma unroll
     for (int n = 0; n < N; ++n) lamR[n] = rt_from_lds<KQ>(vcur + n * 16 * VROW, tb[n], c, q, ksteps);
@@ -840,6 +844,7 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
         }
       }
     }
+    }  // active
     vstage_store(st, vs[(jt - jt_begin + 1) & 1]);
     __syncthreads();
   };
@@ -1087,14 +1092,20 @@ __global__ __launch_bounds__(256, 1) void k_mnmf_binmajor_glds(
     vvoff[h] = (((unsigned)nv * (unsigned)K + (unsigned)k) * (unsigned)T + 2u * (lane & 7)) * 8u;
   }
   const unsigned chan = (unsigned)F * (unsigned)T * 16u;
+  // a wave whose 16 bins all lie beyond F (F = 1025: three of the four waves of every mixture's 17th
+  // bin group) fetches no x, computes and stores nothing -- it only brings its share of the
+  // activation tiles and keeps the barriers (4.4 % of the wave tiles of these shapes)
+  const bool active = i0 < F;
   auto issue = [&](const int jt, const int xslot, const int vslot) __attribute__((always_inline)) {
     const unsigned j0 = (unsigned)jt * 16u;
+    if (active) {
 #pragma unroll
-    for (int m = 0; m < M; ++m)
+      for (int m = 0; m < M; ++m)
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd)
-        glds_b128(xr, xlds + (unsigned)xslot * XSLOT + (unsigned)(4 * m + qd) * 1024u,
-                  xvoff + j0 * 16u, (unsigned)m * chan + (unsigned)qd * 64u);
+        for (int qd = 0; qd < 4; ++qd)
+          glds_b128(xr, xlds + (unsigned)xslot * XSLOT + (unsigned)(4 * m + qd) * 1024u,
+                    xvoff + j0 * 16u, (unsigned)m * chan + (unsigned)qd * 64u);
+    }
 #pragma unroll
     for (int h = 0; h < NV; ++h)
       glds_b128(vr, vlds + (unsigned)vslot * VSLOT + (unsigned)h * 1024u, vvoff[h] + j0 * 8u, 0u);
@@ -1122,12 +1133,12 @@ __global__ __launch_bounds__(256, 1) void k_mnmf_binmajor_glds(
     // x(t) and V(t) have landed; what was issued after them may still be in flight: the DMAs of
     // tile t + 1 and the stores of tiles t - 2 and t - 1 (the first two tiles have fewer stores
     // behind them, the last two no younger DMAs: vmcnt is an upper bound on what may be pending)
-    if (!more) wait_vm<0>();
+    if (!more || !active) wait_vm<0>();
     else if (i >= 2) wait_vm<XI + NV + 2 * NS>();
     else if (i == 1) wait_vm<XI + NV + NS>();
     else wait_vm<XI + NV>();
     XRegs<M> cur;
-    {
+    if (active) {
       unsigned base[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) base[r] = xrd[r] + (unsigned)(i & 1) * XSLOT;
@@ -1141,6 +1152,8 @@ __global__ __launch_bounds__(256, 1) void k_mnmf_binmajor_glds(
     if (more) issue(t + 2, i & 1, vslot == 0 ? 2 : vslot - 1);
 #endif
     const unsigned vcur = vrd + (unsigned)vslot * VSLOT;
+    vslot = vslot == 2 ? 0 : vslot + 1;
+    if (!active) continue;
     double4_t lamR[N];
     {
       double va[N][KQ];
@@ -1217,7 +1230,6 @@ __global__ __launch_bounds__(256, 1) void k_mnmf_binmajor_glds(
           __builtin_amdgcn_raw_buffer_store_b128(v, pr, off + (unsigned)m * pchan + 16u * h, 0, 0);
         }
     }
-    vslot = vslot == 2 ? 0 : vslot + 1;
   }
   const long long slot = (long long)work.tail_idx * nchunks + work.chunk;
   double *tp = tailpart + slot * mnmf_tail_doubles<M>();

@@ -654,6 +654,15 @@ def main():
     run_gmnmf("gmnmf_m5", M=5, F=9, T=26, K=3, seed=86, gen=gen_mixture, spatial_init=True, n_iter=6)
     run_gmnmf("gmnmf_m6_n3", M=6, F=7, T=30, K=2, seed=87, n_sources=3, n_iter=6)
     run_gmnmf("gmnmf_m8", M=8, F=5, T=36, K=2, seed=88, gen=gen_mixture, n_iter=4)
+    # ... with the eigenvalue floor of to_psd ACTIVE (round 5: the packed per-point route of the device
+    # build was pinned only against its own full-storage route there): eps = 0.3 against per-point
+    # eigenvalues of order 1e-2 .. 1 clips most of R_ij, its inverse and the instantaneous covariance
+    run_gmnmf("gmnmf_floor_m5", M=5, F=8, T=24, K=3, seed=140, gen=gen_mixture, spatial_init=True,
+              flooring=("max", 0.3), n_iter=10)
+    run_gmnmf("gmnmf_floor_m6_n3", M=6, F=6, T=28, K=2, seed=141, n_sources=3,
+              flooring=("max", 0.3), n_iter=10)
+    run_gmnmf("gmnmf_floor_m8", M=8, F=4, T=32, K=2, seed=142, gen=gen_mixture,
+              flooring=("max", 0.3), n_iter=10)
     # --- IPA (iterative projection with adjustment, LQPQM solver) ---
     run_ipa_operators()
     run_ilrma("gilrma_ipa_n3", N=3, F=18, T=40, K=4, algo="IPA", seed=100, gen=gen_mixture)

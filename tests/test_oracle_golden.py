@@ -246,7 +246,9 @@ def test_pairwise_operators(N):
 
 
 GMNMF_CASES = ["gmnmf_m2", "gmnmf_m3", "gmnmf_m4_n3", "gmnmf_m2_nonorm_add", "gmnmf_part_m3",
-               "gmnmf_part_m2_n3", "gmnmf_m5", "gmnmf_m6_n3", "gmnmf_m8"]
+               "gmnmf_part_m2_n3", "gmnmf_m5", "gmnmf_m6_n3", "gmnmf_m8",
+               # eigenvalue floor of to_psd active at most points (eps = 0.3), 10 iterations
+               "gmnmf_floor_m5", "gmnmf_floor_m6_n3", "gmnmf_floor_m8"]
 
 
 @pytest.mark.parametrize("case", GMNMF_CASES)
