@@ -363,6 +363,26 @@ int ssspy_ilrma_ip1_update_deferred_loss(const void *X, const void *C, void *W, 
                                          void *workspace, size_t workspace_bytes, int *info,
                                          double *loss_data, double *logdet, void *stream);
 
+/* The same with the by-product left as RAW slots (round 5): slot s of mixture b at
+ * slots[s * slot_stride + b], s < ssspy_ilrma_deferred_loss_slots() (0: no by-product for this shape).
+ * A run of n_iter iterations allocates one zeroed array of slots x (n_iter + 1) B doubles, passes
+ * slots + t B with slot_stride = (n_iter + 1) B in iteration t, and folds all iterations' slots in
+ * slot order with one ssspy_fold_scalar_slots(slots, (n_iter + 1) B, n_slots, out, ...) at the end --
+ * instead of a memset, a counter memset and a fold launch per iteration.  logdet as above. */
+int ssspy_ilrma_deferred_loss_slots(int B, int N, int F, int T, int K, double domain,
+                                    int source_model);
+int ssspy_ilrma_ip1_update_loss_slots(const void *X, const void *C, void *W, double *basis,
+                                      double *activation, void *U, int B, int N, int F, int T,
+                                      int K, double domain, int source_model, double model_param,
+                                      int normalize, int floor_kind, double floor_eps,
+                                      void *workspace, size_t workspace_bytes, int *info,
+                                      double *slots, long long slot_stride, double *logdet,
+                                      void *stream);
+/* out[e] = sum over s < nslots of slots[s * total + e], e < total, in slot order (deterministic) */
+size_t ssspy_fold_scalar_slots_workspace_bytes(long long total, int nslots);
+int ssspy_fold_scalar_slots(const double *slots, long long total, int nslots, double *out,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
 /* IPA (iterative projection with adjustment), one source step: from the weighted covariances of
  * the current separated spectrogram, Vc (B,F,N,N,N) = ssspy_weighted_covariance(Y, weight), the
  * update matrix G (B,F,N,N) of source `source_idx`; the caller then applies ssspy_separate(Y, G)

@@ -81,6 +81,11 @@ PROTOTYPES = {
     "ssspy_ilrma_deferred_loss_supported": (_i, [_i, _i, _i, _i, _d, _i]),
     "ssspy_ilrma_ip1_update_deferred_loss": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i,
                                                   _d, _i, _i, _d, _p, _z, _p, _p, _p, _p]),
+    "ssspy_ilrma_deferred_loss_slots": (_i, [_i, _i, _i, _i, _i, _d, _i]),
+    "ssspy_ilrma_ip1_update_loss_slots": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i,
+                                               _d, _i, _i, _d, _p, _z, _p, _p, _q, _p, _p]),
+    "ssspy_fold_scalar_slots_workspace_bytes": (_z, [_q, _i]),
+    "ssspy_fold_scalar_slots": (_i, [_p, _q, _i, _p, _p, _z, _p]),
     "ssspy_ilrma_partition_expand": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ssspy_ilrma_partition_update": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d,
                                           _i, _i, _d, _p, _z, _p]),

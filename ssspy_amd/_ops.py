@@ -532,6 +532,33 @@ def ilrma_ip1_update_deferred_loss(X, C, W, basis, activation, U, domain, normal
     return True
 
 
+def ilrma_deferred_loss_slots(B, N, F, T, K, domain, model=GAUSS):
+    """Raw loss slots per mixture of ilrma_ip1_update_loss_slots (0: no by-product for this shape)."""
+    return int(_L().ssspy_ilrma_deferred_loss_slots(B, N, F, T, K, domain, model[0]))
+
+
+def ilrma_ip1_update_loss_slots(X, C, W, basis, activation, U, domain, normalize, flooring, ws,
+                                ws_bytes, info, slots, slot_stride, logdet, model=GAUSS):
+    """ilrma_ip1_update_deferred_loss with the data term left as raw slots (slot s of mixture b at
+    slots[s * slot_stride + b]); the caller zeroes the array once and folds it once
+    (fold_scalar_slots) for a whole run."""
+    B, N, F, T = X.shape
+    K = basis.shape[-1]
+    _lib.check(_L().ssspy_ilrma_ip1_update_loss_slots(
+        ptr(X), ptr(C), ptr(W), ptr(basis), ptr(activation), ptr(U), B, N, F, T, K, domain, model[0],
+        model[1], int(bool(normalize)), flooring[0], flooring[1], ptr(ws), ws_bytes, ptr(info),
+        ptr(slots), int(slot_stride), ptr(logdet), _st()), "ilrma_ip1_update_loss_slots")
+
+
+def fold_scalar_slots(slots, total, nslots, out):
+    """out[e] = sum_s slots[s * total + e] in slot order."""
+    ws, ws_bytes = _scratch(_L().ssspy_fold_scalar_slots_workspace_bytes(int(total), int(nslots)),
+                            slots.device)
+    _lib.check(_L().ssspy_fold_scalar_slots(ptr(slots), int(total), int(nslots), ptr(out), ptr(ws),
+                                            ws_bytes, _st()), "fold_scalar_slots")
+    return out
+
+
 def ilrma_partition_expand(basis, activation, latent, Teff, Vrep):
     B, N, F, K = Teff.shape
     T = Vrep.shape[-1]

@@ -361,13 +361,27 @@ class _MMILRMA(ILRMABase):
         W, Tb, Vb = (self._state_dev(k) for k in ("demix_filter", "basis", "activation"))
         args = (self._X, C, W, Tb, Vb, self._U, float(self.domain), bool(self.normalization),
                 self._floor, self._ws, self._ws_bytes, self._info_tensor())
+        # the data terms of all iterations as raw per-wave shares in ONE zeroed array, folded once at
+        # the end (round 5: a memset, a counter memset and a fold launch per iteration before)
+        nslots = _ops.ilrma_deferred_loss_slots(B, N, F, T, self.n_basis, float(self.domain),
+                                                self._model)
+        stride = (n_iter + 1) * B
+        slots = None
+        if nslots and stride < 2 ** 31 and nslots * stride * 8 <= (1 << 28):  # (<= 256 MB)
+            slots = dv.zeros((nslots, stride), dv.f64, dev)
+        flat = slots.reshape(-1) if slots is not None else None
         for t in range(n_iter):
             if t == 0 and not initial_call:
                 # the reference records nothing before the first iteration in this case
                 _ops.ilrma_ip1_update(*args, model=self._model)
+            elif slots is not None:
+                _ops.ilrma_ip1_update_loss_slots(*args, flat[t * B:], stride, logdet[t],
+                                                 model=self._model)
             elif not _ops.ilrma_ip1_update_deferred_loss(*args, data[t], logdet[t],
                                                          model=self._model):
                 raise RuntimeError("deferred loss unavailable although reported as supported")
+        if slots is not None:
+            _ops.fold_scalar_slots(slots, stride, nslots, data.reshape(-1))
         for name in ("demix_filter", "basis", "activation"):
             self._state_touch(name)
         _ops.ilrma_loss_data(self._X, W, Tb, Vb, float(self.domain), out=data[n_iter],

@@ -28,7 +28,8 @@ DECL_N(2) DECL_N(3) DECL_N(4) DECL_N(5) DECL_N(6) DECL_N(7) DECL_N(8)
 #define DECL_FAST(n)                                                                           \
   int ilrma_fast_basis_n##n(const void *, const void *, const double *, double *, const double *, \
                             int, int, int, int, int, double, double *, int, double, int,        \
-                            double *, void *, int, hipStream_t);                                \
+                            double *, void *, int, hipStream_t, long long);                     \
+  int ilrma_fast_basis_loss_slots_n##n(int, int, int);                                          \
   size_t ilrma_fast_loss_ws_bytes_n##n(int, int);                                               \
   int ilrma_fast_activation_n##n(const void *, const void *, const double *, const double *,   \
                                  double *, int, int, int, int, int, int, double, int,           \
@@ -745,7 +746,8 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
                              int B, int N, int F, int T, int K, double domain, int source_model,
                              double model_param, int floor_kind, double floor_eps, void *workspace,
                              size_t workspace_bytes, double *loss_out, bool *loss_done,
-                             void *stream, bool x_is_power = false) {
+                             void *stream, bool x_is_power = false, long long loss_stride = 0) {
+  // loss_stride > 0: loss_out is a raw slot array (see ilrma_fast_basis), tuned path only
   // x_is_power (grouped path of a wide mixture only, W == NULL): X holds |y|^2 (B, N, F, T) f64
   SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0, "update_basis: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_basis: n_basis must be in [1, 1024]");
@@ -785,7 +787,7 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
                               activation + sr.first * K * T, sr.count, F, T, K, floor_kind,
                               floor_eps, (double *)(ws + w.bpart),
                               fast_model_id(domain, source_model), fast_model_param(domain, source_model, model_param),
-                              is_me(source_model), nullptr, nullptr, power ? 1 : 0, st);
+                              is_me(source_model), nullptr, nullptr, power ? 1 : 0, st, 0ll);
         };
         const int r = one();
         if (r) return r;
@@ -797,7 +799,7 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
       ILRMA_FAST_DISPATCH(N, ilrma_fast_basis, X, W, basis, out, activation, B, F, T, K, floor_kind,
                           floor_eps, (double *)(ws + w.bpart), fast_model_id(domain, source_model),
                           fast_model_param(domain, source_model, model_param), is_me(source_model),
-                          K <= 16 ? loss_out : nullptr, ws + w.lslots, 0, st);
+                          K <= 16 ? loss_out : nullptr, ws + w.lslots, 0, st, loss_stride);
     }
     const IlrmaDims d =
         make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
@@ -1125,7 +1127,8 @@ static int ip1_update_impl(const void *X, const void *C, void *W, double *basis,
                            void *U, int B, int N, int F, int T, int K, double domain,
                            int source_model, double model_param, int normalize, int floor_kind,
                            double floor_eps, void *workspace, size_t workspace_bytes, int *info,
-                           double *loss_data, double *logdet, void *stream) {
+                           double *loss_data, double *logdet, void *stream,
+                           long long loss_stride = 0) {
   SSSPY_REQUIRE(X && W && basis && activation && U, "ilrma_ip1_update: bad argument");
   SSSPY_REQUIRE(!normalize || C, "ilrma_ip1_update: normalisation needs C");
   SSSPY_REQUIRE((loss_data == nullptr) == (logdet == nullptr),
@@ -1170,7 +1173,7 @@ static int ip1_update_impl(const void *X, const void *C, void *W, double *basis,
   }
   rc = update_basis_impl(Xs, Ws, basis, activation, B, N, F, T, K, domain, source_model,
                          model_param, floor_kind, floor_eps, workspace, workspace_bytes, loss_data,
-                         &loss_done, stream, xs_is_power);
+                         &loss_done, stream, xs_is_power, loss_stride);
   if (rc) return rc;
   // (unreachable: ssspy_ilrma_deferred_loss_supported above admits exactly the shapes whose basis
   // pass leaves the data term; kept as an internal error because the basis is already rewritten)
@@ -1239,6 +1242,47 @@ int ssspy_ilrma_ip1_update_deferred_loss(const void *X, const void *C, void *W, 
   return ip1_update_impl(X, C, W, basis, activation, U, B, N, F, T, K, domain, source_model,
                          model_param, normalize, floor_kind, floor_eps, workspace, workspace_bytes,
                          info, loss_data, logdet, stream);
+}
+
+// ---- the same with the loss by-product left as raw slots (round 5): a run of n_iter iterations
+// zeroes one array and folds it once instead of a memset, a counter memset and a fold launch per
+// iteration (3 of the 12 launches of a one-mixture iteration, 17 of its 124 us)
+int ssspy_ilrma_deferred_loss_slots(int B, int N, int F, int T, int K, double domain,
+                                    int source_model) {
+  if (!ssspy_ilrma_deferred_loss_supported(N, F, T, K, domain, source_model)) return 0;
+  switch (N) {
+    case 2: return ilrma_fast_basis_loss_slots_n2(B, F, T);
+    case 3: return ilrma_fast_basis_loss_slots_n3(B, F, T);
+    case 4: return ilrma_fast_basis_loss_slots_n4(B, F, T);
+    default: return 0;
+  }
+}
+
+int ssspy_ilrma_ip1_update_loss_slots(const void *X, const void *C, void *W, double *basis,
+                                      double *activation, void *U, int B, int N, int F, int T,
+                                      int K, double domain, int source_model, double model_param,
+                                      int normalize, int floor_kind, double floor_eps,
+                                      void *workspace, size_t workspace_bytes, int *info,
+                                      double *slots, long long slot_stride, double *logdet,
+                                      void *stream) {
+  SSSPY_REQUIRE(slots && logdet && slot_stride >= B && slot_stride < (1ll << 31),
+                "ilrma_ip1_update_loss_slots: bad argument");
+  return ip1_update_impl(X, C, W, basis, activation, U, B, N, F, T, K, domain, source_model,
+                         model_param, normalize, floor_kind, floor_eps, workspace, workspace_bytes,
+                         info, slots, logdet, stream, slot_stride);
+}
+
+size_t ssspy_fold_scalar_slots_workspace_bytes(long long total, int nslots) {
+  if (total <= 0 || nslots <= 0) return 0;
+  return align256(fold_scratch_bytes(total, nslots)) + 256;
+}
+
+int ssspy_fold_scalar_slots(const double *slots, long long total, int nslots, double *out,
+                            void *workspace, size_t workspace_bytes, void *stream) {
+  SSSPY_REQUIRE(slots && out && total > 0 && nslots > 0, "fold_scalar_slots: bad argument");
+  SSSPY_REQUIRE(workspace && workspace_bytes >= ssspy_fold_scalar_slots_workspace_bytes(total, nslots),
+                "fold_scalar_slots: workspace too small");
+  return launch_fold_slabs(slots, workspace, out, total, nslots, as_stream(stream), 0);
 }
 
 int ssspy_ilrma_partition_expand(const double *basis, const double *activation,

@@ -974,9 +974,13 @@ using fast::make_fast_model;
 int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis, double *basis_out,
                                const double *act, int B, int F, int T, int K, int floor_kind,
                                double eps, double *part, int fmodel, double mparam, int me,
-                               double *loss_out, void *loss_ws, int power_in, hipStream_t st) {
+                               double *loss_out, void *loss_ws, int power_in, hipStream_t st,
+                               long long loss_stride) {
   // loss_ws: LAUNCHER(ilrma_fast_loss_ws_bytes)() of scratch behind loss_out (the per-wave shares
   // are stored there and added up in a fixed order: no atomics)
+  // loss_stride > 0 (round 5): loss_out is the caller's raw slot array instead, slot s of mixture b
+  // at loss_out[s * loss_stride + b], zeroed by the caller and folded by it (ssspy_fold_scalar_slots)
+  // once for many iterations: no memset and no fold launch here
   if (power_in && (W != nullptr || loss_out != nullptr))
     return fail(SSSPY_ERR_BADARG, "ilrma_fast_basis: power input excludes a filter and the loss");
   if (loss_out && !loss_ws) return fail(SSSPY_ERR_BADARG, "ilrma_fast_basis: loss without scratch");
@@ -999,15 +1003,17 @@ int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis
   const int slots_pass = plan.groups * maxsplit * 4;
   const int nslots = slots_pass + plan.groups * nbx * 4;
   const bool with_loss = loss_out != nullptr && ktiles == 1 && fmodel != FM_T;
-  double *loss_slots = with_loss ? (double *)loss_ws : nullptr;
-  if (with_loss) {
+  const bool raw = with_loss && loss_stride > 0;
+  double *loss_slots = with_loss ? (raw ? loss_out : (double *)loss_ws) : nullptr;
+  const int slot_stride = raw ? (int)loss_stride : B;
+  if (with_loss && !raw) {
     const int rc0 = scalar_slots_begin(loss_ws, B, nslots, st);
     if (rc0) return rc0;
   }
 #define SSSPY_BASIS_LAUNCH(HW, M, L, KS_)                                                          \
   hipLaunchKernelGGL((k_basis_fast<HW, M, L, KS_>), grid, block, 0, st, (const c128 *)X,           \
                      (const c128 *)W, basis, basis_out, act, F, T, K, floor_kind, eps, plan, part, \
-                     fm, loss_slots, B)
+                     fm, loss_slots, slot_stride)
 #define SSSPY_BASIS_LAUNCH_M(HW, L, KS_)                                  \
   switch (fmodel) {                                                       \
     case FM_T: SSSPY_BASIS_LAUNCH(HW, FM_T, false, KS_); break; /* no by-product for the t model */ \
@@ -1059,11 +1065,18 @@ int LAUNCHER(ilrma_fast_basis)(const void *X, const void *W, const double *basis
     const int inner = ktiles / item_tiles;  // k tiles inside an item
     hipLaunchKernelGGL(k_basis_finalize, dim3(nbx, plan.tail, inner), block, 0, st, basis,
                        basis_out, part, F, K, plan, inner > 1 ? -inner : item_tiles, floor_kind, eps,
-                       fm.expo, loss_slots, loss_scale, B, slots_pass);
+                       fm.expo, loss_slots, loss_scale, slot_stride, slots_pass);
     rc = check_launch("k_basis_finalize");
     if (rc) return rc;
   }
-  return with_loss ? scalar_slots_fold(loss_ws, B, nslots, loss_out, 0, st) : rc;
+  return (with_loss && !raw) ? scalar_slots_fold(loss_ws, B, nslots, loss_out, 0, st) : rc;
+}
+
+// slots per mixture of the loss by-product of LAUNCHER(ilrma_fast_basis) (the raw form's array)
+int LAUNCHER(ilrma_fast_basis_loss_slots)(int B, int F, int T) {
+  const TailPlan plan = make_tail_plan(B, (F + 63) / 64, (T + 15) / 16, SLOTS, 1024);
+  const int maxsplit = plan.split > 1 ? plan.split : 1;
+  return plan.groups * maxsplit * 4 + plan.groups * (N * 64 * 16 / 256) * 4;
 }
 
 // scratch of the deterministic loss sums (both the by-product of the basis pass and the loss pass)

@@ -587,11 +587,13 @@ __global__ __launch_bounds__(64) void k_demix_from_cov(const c128 *__restrict__ 
   if (!ok && info) atomicAdd(info, 1);
 }
 
-// one block per mixture
-template <int N>
-__global__ __launch_bounds__(256) void k_sum_logdet(const c128 *__restrict__ W, double *out,
-                                                    int F) {
-  __shared__ double scratch[4];
+// one block per mixture (256 threads; THREADS = 1024 for a handful of mixtures of up to 4 sources:
+// 1025 bins on 256 threads are five dependent 4 x 4 eliminations per thread, 15.8 us -- a third of
+// the loss bookkeeping of a one-mixture run; one bin per thread: see profiles/r05_call_timeline.txt)
+template <int N, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void k_sum_logdet(const c128 *__restrict__ W, double *out,
+                                                        int F) {
+  __shared__ double scratch[THREADS / 64];
   const int b = blockIdx.x;
   double s = 0.0;
   for (int i = threadIdx.x; i < F; i += blockDim.x) {
@@ -854,6 +856,15 @@ int ssspy_sum_logdet(const void *W, double *out, int B, int F, int N, void *stre
   SSSPY_REQUIRE(W && out && B > 0 && F > 0, "sum_logdet: bad argument");
   if (rt_sources_ok(N)) return rt_sum_logdet(W, out, B, F, N, as_stream(stream));
   dim3 grid(B), block(256);
+  if (N <= 4 && B <= 64 && F > 256) {
+    switch (N) {
+      case 1: hipLaunchKernelGGL((k_sum_logdet<1, 1024>), grid, dim3(1024), 0, as_stream(stream), (const c128 *)W, out, F); break;
+      case 2: hipLaunchKernelGGL((k_sum_logdet<2, 1024>), grid, dim3(1024), 0, as_stream(stream), (const c128 *)W, out, F); break;
+      case 3: hipLaunchKernelGGL((k_sum_logdet<3, 1024>), grid, dim3(1024), 0, as_stream(stream), (const c128 *)W, out, F); break;
+      default: hipLaunchKernelGGL((k_sum_logdet<4, 1024>), grid, dim3(1024), 0, as_stream(stream), (const c128 *)W, out, F); break;
+    }
+    return check_launch("k_sum_logdet");
+  }
   DISPATCH_N(N, hipLaunchKernelGGL((k_sum_logdet<NN>), grid, block, 0, as_stream(stream),
                                    (const c128 *)W, out, F));
   return check_launch("k_sum_logdet");
