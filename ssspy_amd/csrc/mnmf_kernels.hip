@@ -995,26 +995,34 @@ __device__ __forceinline__ void xtile_from_lds(XRegs<M> &t, const unsigned (&bas
 }
 // GEMM1 of one source out of the activation ring: A operand V[k = 4 ks + q][frame tile_pi(c)]
 template <int KQ>
-__device__ __forceinline__ void vrow_from_lds(double (&a)[KQ], unsigned addr, int n) {
+__device__ __forceinline__ void vrow_from_lds(double (&a)[KQ], unsigned addr, int n, unsigned src_bytes) {
 #pragma unroll
   for (int ks = 0; ks < KQ; ++ks)
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[ks]) : "v"(addr + (unsigned)n * 2048u), "n"(ks * 512));
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[ks]) : "v"(addr + (unsigned)n * src_bytes), "n"(ks * 512));
 }
 
-template <int M, int MODE, int KQ>
+// PRIV (n_basis <= 8 only): every wave fetches its OWN copy of the activation tile (two 4 KB slots per
+// wave: with the x ring the whole 160 KB of the CU) and copies it into registers with the x tile, so
+// nothing is shared between the waves any more: no barrier in the walk (it cost 30 of the covariance
+// pass's 250 us at 32 mixtures: every tile all four waves waited for the slowest DMA), and a wave
+// without bins leaves at once.  Costs 4 KB more L2 -> LDS traffic per wave tile (16 KB of x).
+template <int M, int MODE, int KQ, bool PRIV = false>
 __global__ __launch_bounds__(256, 1) void k_mnmf_binmajor_glds(
     const c128 *__restrict__ X, const c128 *__restrict__ Q, double *Dsp,
     const double *__restrict__ basis, const double *__restrict__ act, c128 *__restrict__ U, int F,
     int T, int K, TailPlan plan, double *__restrict__ tailpart, double *__restrict__ P) {
   static_assert(MODE == MODE_WCOV || MODE == MODE_SPATIAL, "the two passes that read x");
   static_assert(KQ == 2 || KQ == 4, "k-slabs of 4 carried: n_basis <= 8 or <= 16");
+  static_assert(!PRIV || KQ == 2, "private activation tiles: n_basis <= 8");
   constexpr int XI = 4 * M;                                 // DMA instructions per x tile and wave
-  constexpr int NV = KQ / 2;                                // ... per activation tile and wave
+  constexpr int NV = PRIV ? N : KQ / 2;                     // ... per activation tile and wave
   constexpr int NS = MODE == MODE_SPATIAL ? 2 * M : 0;      // stores per tile and wave
   constexpr unsigned XSLOT = 4u * XI * 1024u;               // bytes of one x ring slot (4 waves)
-  constexpr unsigned VSLOT = (unsigned)N * 16u * 16u * 8u;  // bytes of one activation ring slot
+  // bytes of one activation ring slot (PRIV: rows 0..7 of every source, per wave)
+  constexpr unsigned VSLOT = PRIV ? (unsigned)N * 8u * 16u * 8u : (unsigned)N * 16u * 16u * 8u;
+  constexpr unsigned VSRC = PRIV ? 1024u : 2048u;           // bytes between two sources in a slot
   __shared__ __attribute__((aligned(16))) double xring[2 * 4 * XI * 128];
-  __shared__ __attribute__((aligned(16))) double vring[3 * N * 16 * 16];
+  __shared__ __attribute__((aligned(16))) double vring[PRIV ? 4 * 2 * N * 8 * 16 : 3 * N * 16 * 16];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, q = lane >> 4;
@@ -1083,19 +1091,24 @@ __global__ __launch_bounds__(256, 1) void k_mnmf_binmajor_glds(
   const int cl = lane >> 2, rl = (lane & 3) ^ ((cl >> 2) & 3);
   const unsigned xvoff = ((unsigned)min(i0 + cl, F - 1) * (unsigned)T + (unsigned)rl) * 16u;
   const unsigned xlds = SSSPY_LDS_ADDR(xring) + (unsigned)wave * (XI * 1024u);
-  const int nv = wave % N;  // the source whose activation rows this wave fetches
-  const unsigned vlds = SSSPY_LDS_ADDR(vring) + (unsigned)nv * 2048u;
+  // shared ring: wave w fetches the rows of source w % N (instruction h: rows 8 h .. 8 h + 7);
+  // PRIV: every wave fetches rows 0 .. 7 of every source (instruction h = source) into its own slots
+  const int nv = wave % N;
+  const unsigned vlds = SSSPY_LDS_ADDR(vring) +
+                        (PRIV ? (unsigned)wave * 2u * VSLOT : (unsigned)nv * 2048u);
   unsigned vvoff[NV];
 #pragma unroll
   for (int h = 0; h < NV; ++h) {
-    const int k = min(8 * h + (lane >> 3), K - 1);
-    vvoff[h] = (((unsigned)nv * (unsigned)K + (unsigned)k) * (unsigned)T + 2u * (lane & 7)) * 8u;
+    const int k = min((PRIV ? 0 : 8 * h) + (lane >> 3), K - 1);
+    vvoff[h] = (((unsigned)(PRIV ? h : nv) * (unsigned)K + (unsigned)k) * (unsigned)T +
+                2u * (lane & 7)) * 8u;
   }
   const unsigned chan = (unsigned)F * (unsigned)T * 16u;
   // a wave whose 16 bins all lie beyond F (F = 1025: three of the four waves of every mixture's 17th
   // bin group) fetches no x, computes and stores nothing -- it only brings its share of the
   // activation tiles and keeps the barriers (4.4 % of the wave tiles of these shapes)
   const bool active = i0 < F;
+  if (PRIV && !active) return;  // (nothing shared: no barrier to keep)
   auto issue = [&](const int jt, const int xslot, const int vslot) __attribute__((always_inline)) {
     const unsigned j0 = (unsigned)jt * 16u;
     if (active) {
@@ -1115,7 +1128,7 @@ __global__ __launch_bounds__(256, 1) void k_mnmf_binmajor_glds(
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     xrd[r] = xlds + (unsigned)q * 1024u + (unsigned)c * 64u + 16u * (unsigned)(r ^ ((c >> 2) & 3));
-  const unsigned vrd = SSSPY_LDS_ADDR(vring) + (unsigned)(q * 16 + tile_pi(c)) * 8u;
+  const unsigned vrd = (PRIV ? vlds : SSSPY_LDS_ADDR(vring)) + (unsigned)(q * 16 + tile_pi(c)) * 8u;
   // |Q x|^2 out: lane (c, q) owns frames j0 + 4 q .. + 3 of its bin, 32 bytes per channel
   const __amdgpu_buffer_rsrc_t pr =
       make_rsrc(MODE == MODE_SPATIAL ? P + (long long)b * M * F * T : nullptr,
@@ -1144,21 +1157,34 @@ __global__ __launch_bounds__(256, 1) void k_mnmf_binmajor_glds(
       for (int r = 0; r < 4; ++r) base[r] = xrd[r] + (unsigned)(i & 1) * XSLOT;
       xtile_from_lds<M>(cur, base);
     }
-    // every wave's share of V(t) is in LDS, and every wave is done with V(t - 1)
+    double va[N][KQ];
+    if constexpr (PRIV) {
+      // the wave's own activation tile goes to registers with the x tile; both slots are free again
+      const unsigned vmine = vrd + (unsigned)(i & 1) * VSLOT;
+#pragma unroll
+      for (int n = 0; n < N; ++n) vrow_from_lds<KQ>(va[n], vmine, n, VSRC);
+      // (landed in registers before the slot is handed to the next DMA)
+#pragma unroll
+      for (int n = 0; n < N; ++n)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va[n][0]), "+v"(va[n][1]));
+    } else {
+      // every wave's share of V(t) is in LDS, and every wave is done with V(t - 1)
 #if SSSPY_GLDS_DBG != 3
-    __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
 #endif
+    }
 #if SSSPY_GLDS_DBG != 2
-    if (more) issue(t + 2, i & 1, vslot == 0 ? 2 : vslot - 1);
+    if (more) issue(t + 2, i & 1, PRIV ? (i & 1) : (vslot == 0 ? 2 : vslot - 1));
 #endif
     const unsigned vcur = vrd + (unsigned)vslot * VSLOT;
     vslot = vslot == 2 ? 0 : vslot + 1;
     if (!active) continue;
     double4_t lamR[N];
     {
-      double va[N][KQ];
+      if constexpr (!PRIV) {
 #pragma unroll
-      for (int n = 0; n < N; ++n) vrow_from_lds<KQ>(va[n], vcur, n);
+        for (int n = 0; n < N; ++n) vrow_from_lds<KQ>(va[n], vcur, n, VSRC);
+      }
       // (lgkmcnt(0): scalar loads share the counter and return out of order)
 #pragma unroll
       for (int n = 0; n < N; ++n) {
@@ -1841,25 +1867,41 @@ __global__ __launch_bounds__(256) void k_mnmf_separate_closed(
 // row `ref` of Q^-1, D -- is block-uniform and arrives through scalar loads, so there is no LDS and
 // no barrier.  grid: (ceil(F / SEP_BINS), ceil(T / 256), B).
 constexpr int SEP_BINS = 16;
-template <int M>
+template <int M, int KMAX>
 __global__ __launch_bounds__(256) void k_mnmf_separate_closed_rows(
     const c128 *__restrict__ X, const c128 *__restrict__ Q, const c128 *__restrict__ Qinv,
     const double *__restrict__ Dsp, const double *__restrict__ basis,
     const double *__restrict__ act, c128 *Y, Dims d, int ref, double eps,
     int *__restrict__ redo) {
+  // KMAX (round 5): 8 for n_basis <= 8 -- half the activation registers of the 16-wide form (224 ->
+  // 130 VGPRs: three waves per SIMD instead of two) and no FMAs on zero padding; the x samples of the
+  // NEXT bin are requested before this bin's arithmetic (the walk waited for four dependent loads
+  // per bin: 2.2 TB/s), and 1 / R~ is v_rcp_f64 + two Newton steps like everywhere else.
   const int b = blockIdx.z;
   const int F = d.F, T = d.T, K = d.K;
   const int j = blockIdx.y * 256 + threadIdx.x;
   const bool fvalid = j < T;
   const int jc = fvalid ? j : T - 1;
-  double v[N][16];
+  double v[N][KMAX];
 #pragma unroll
   for (int n = 0; n < N; ++n)
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
+    for (int k = 0; k < KMAX; ++k)
       v[n][k] = k < K ? act[(((long long)b * N + n) * K + k) * T + jc] : 0.0;
-  const int i_end = min(F, (int)(blockIdx.x + 1) * SEP_BINS);
-  for (int i = blockIdx.x * SEP_BINS; i < i_end; ++i) {
+  const int i_begin = blockIdx.x * SEP_BINS;
+  const int i_end = min(F, i_begin + SEP_BINS);
+  c128 xnext[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) xnext[m] = X[(((long long)b * M + m) * F + i_begin) * T + jc];
+  for (int i = i_begin; i < i_end; ++i) {
+    c128 x[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] = xnext[m];
+    {
+      const int inx = min(i + 1, i_end - 1);
+#pragma unroll
+      for (int m = 0; m < M; ++m) xnext[m] = X[(((long long)b * M + m) * F + inx) * T + jc];
+    }
     const c128 *__restrict__ qsrc = Q + ((long long)b * F + i) * (M * M);
     const c128 *__restrict__ qref = Qinv + ((long long)b * F + i) * (M * M) + ref * M;
     const double *__restrict__ dd = Dsp + ((long long)b * F + i) * (N * M);
@@ -1872,7 +1914,7 @@ __global__ __launch_bounds__(256) void k_mnmf_separate_closed_rows(
       const double *__restrict__ tr = basis + (((long long)b * N + n) * F + i) * K;
       double r = 0.0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k)
+      for (int k = 0; k < KMAX; ++k)
         if (k < K) r = fma(tr[k], v[n][k], r);
       lam[n] = r;
     }
@@ -1891,16 +1933,13 @@ __global__ __launch_bounds__(256) void k_mnmf_separate_closed_rows(
       redo[(long long)b * F + i] = 1;
       continue;
     }
-    c128 x[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) x[m] = X[(((long long)b * M + m) * F + i) * T + j];
     c128 sm[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       c128 y = cmake(0.0, 0.0);
 #pragma unroll
       for (int a = 0; a < M; ++a) cfma(y, qsrc[m * M + a], x[a]);
-      const double g = 1.0 / rc[m];
+      const double g = rcp_nr(rc[m]);
       sm[m] = cmul(qref[m], cmake(y.x * g, y.y * g));
     }
 #pragma unroll
@@ -2086,6 +2125,16 @@ static inline TailPlan mnmf_plan(int B, int F, int T) {
   // these kernels hold one workgroup per CU (x prefetch in registers, > 256 VGPR + AGPR)
   return make_tail_plan(B, (F + 63) / 64, (T + 15) / 16, 256);
 }
+// private activation tiles per wave (n_basis <= 8; the barrier-free form of k_mnmf_binmajor_glds)
+// Measured (benchmarks/tools/mnmf_steps.py, configs[3] shape): the covariance pass gains at every
+// batch (32 mixtures: 267 -> 253 us, 128: 964 -> 908); the spatial pass, bound by its read + write
+// stream, does not (401 -> 400, 1259 -> 1309) -- so only the covariance pass takes it by default.
+// SSSPY_AMD_MNMF_GLDS_PRIVATE_V=0 / 1: neither / both (A / B).
+static inline bool mnmf_glds_private_v(bool spatial) {
+  const char *e = std::getenv("SSSPY_AMD_MNMF_GLDS_PRIVATE_V");
+  if (e) return e[0] != '0';
+  return !spatial;
+}
 // the LDS-DMA form of the two x-reading passes (k_mnmf_binmajor_glds): whole tiles of frames
 static inline bool mnmf_glds_ok(int B, int F, int T, int K) {
   // (read per call: the parity tests switch it inside one process)
@@ -2202,7 +2251,11 @@ int LAUNCHER(mnmf_wcov)(const void *X, const double *Dsp, const double *basis, c
     const bool records = split_out && rec_out && plan.full == 0 && plan.tail > 0;
     const bool glds = mnmf_glds_ok(B, F, T, K);
     MNMF_DISPATCH_M(M, {
-      if (glds && K <= 8)
+      if (glds && K <= 8 && mnmf_glds_private_v(false))
+        hipLaunchKernelGGL((k_mnmf_binmajor_glds<MM, MODE_WCOV, 2, true>), fgrid, dim3(256), 0, st,
+                           (const c128 *)X, (const c128 *)nullptr, (double *)Dsp, basis, act,
+                           (c128 *)U, F, T, K, plan, tailpart, (double *)nullptr);
+      else if (glds && K <= 8)
         hipLaunchKernelGGL((k_mnmf_binmajor_glds<MM, MODE_WCOV, 2>), fgrid, dim3(256), 0, st,
                            (const c128 *)X, (const c128 *)nullptr, (double *)Dsp, basis, act,
                            (c128 *)U, F, T, K, plan, tailpart, (double *)nullptr);
@@ -2258,7 +2311,11 @@ int LAUNCHER(mnmf_spatial)(const void *X, const void *Q, double *Dsp, const doub
                          B * M);
     const bool glds = P && mnmf_glds_ok(B, F, T, K);
     MNMF_DISPATCH_M(M, {
-      if (glds && K <= 8)
+      if (glds && K <= 8 && mnmf_glds_private_v(true))
+        hipLaunchKernelGGL((k_mnmf_binmajor_glds<MM, MODE_SPATIAL, 2, true>), fgrid, dim3(256), 0,
+                           st, (const c128 *)X, (const c128 *)Q, Dsp, basis, act, (c128 *)nullptr,
+                           F, T, K, plan, tailpart, P);
+      else if (glds && K <= 8)
         hipLaunchKernelGGL((k_mnmf_binmajor_glds<MM, MODE_SPATIAL, 2>), fgrid, dim3(256), 0, st,
                            (const c128 *)X, (const c128 *)Q, Dsp, basis, act, (c128 *)nullptr, F,
                            T, K, plan, tailpart, P);
@@ -2367,8 +2424,13 @@ int LAUNCHER(mnmf_separate)(const void *X, const void *Q, void *Qinv, const doub
   MNMF_DISPATCH_M(M, {
     hipLaunchKernelGGL((k_mnmf_qinv<MM>), dim3((unsigned)((nbins + 63) / 64)), dim3(64), 0, st,
                        (const c128 *)Q, (c128 *)Qinv, nbins, info);
-    if (K <= 16 && floor_kind != SSSPY_FLOOR_ADD)
-      hipLaunchKernelGGL((k_mnmf_separate_closed_rows<MM>),
+    if (K <= 8 && floor_kind != SSSPY_FLOOR_ADD)
+      hipLaunchKernelGGL((k_mnmf_separate_closed_rows<MM, 8>),
+                         dim3((F + SEP_BINS - 1) / SEP_BINS, (T + 255) / 256, B), dim3(256), 0, st,
+                         (const c128 *)X, (const c128 *)Q, (const c128 *)Qinv, Dsp, basis, act,
+                         (c128 *)Y, d, ref, eps, redo);
+    else if (K <= 16 && floor_kind != SSSPY_FLOOR_ADD)
+      hipLaunchKernelGGL((k_mnmf_separate_closed_rows<MM, 16>),
                          dim3((F + SEP_BINS - 1) / SEP_BINS, (T + 255) / 256, B), dim3(256), 0, st,
                          (const c128 *)X, (const c128 *)Q, (const c128 *)Qinv, Dsp, basis, act,
                          (c128 *)Y, d, ref, eps, redo);

@@ -867,7 +867,9 @@ def test_fast_gauss_mnmf_handover_matches_plain_path_and_oracle(M, F, T, K, monk
 @pytest.mark.parametrize("B,M,N,F,T,K", [(1, 4, 4, 70, 96, 8), (1, 3, 3, 33, 48, 5), (1, 2, 2, 17, 16, 16),
                                          (1, 4, 4, 130, 32, 3), (3, 4, 4, 65, 160, 12), (2, 3, 2, 64, 64, 9),
                                          (5, 4, 3, 129, 80, 16), (40, 4, 4, 20, 48, 4)])
-def test_fast_gauss_mnmf_lds_dma_passes_match_register_passes_and_oracle(B, M, N, F, T, K, monkeypatch):
+@pytest.mark.parametrize("private_v", ["0", "1"])
+def test_fast_gauss_mnmf_lds_dma_passes_match_register_passes_and_oracle(B, M, N, F, T, K, private_v,
+                                                                         monkeypatch):
     """Round 5: the covariance and spatial passes fed by LDS-DMA (k_mnmf_binmajor_glds, T % 16 == 0)
     against the register-fed passes (SSSPY_AMD_MNMF_NO_GLDS) on every state array, and against the
     oracle: single tiles, one and several mixtures (whole items and frame-split items), fewer
@@ -877,6 +879,9 @@ def test_fast_gauss_mnmf_lds_dma_passes_match_register_passes_and_oracle(B, M, N
     from ssspy_amd.bss.mnmf import FastGaussMNMF
     from ssspy_amd.utils.dataset import nmf_mixture
 
+    # (both passes with the shared activation ring and its barrier, or both with private tiles per
+    #  wave -- n_basis <= 8 only: the default takes the second for the covariance pass alone)
+    monkeypatch.setenv("SSSPY_AMD_MNMF_GLDS_PRIVATE_V", private_v)
     X = np.stack([nmf_mixture(500 + b, M, F, T) for b in range(B)])
     rng = np.random.default_rng(3)
     kw = dict(basis=rng.random((B, N, F, K)), activation=rng.random((B, N, K, T)),
