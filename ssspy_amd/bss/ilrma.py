@@ -416,6 +416,10 @@ class _MMILRMA(ILRMABase):
             B, N, F, T = self._X.shape
             if self._U is None:
                 self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
+            plan = self._subbatch_plan(B, N, F, T)
+            if plan is not None:
+                self._update_once_in_subbatches(floor, *plan)
+                return
             _ops.ilrma_ip1_update(
                 self._X, self._C() if self.normalization else None,
                 self._state_dev("demix_filter"), self._state_dev("basis"),
@@ -433,6 +437,57 @@ class _MMILRMA(ILRMABase):
         self.update_spatial_model(flooring_fn=flooring_fn)
         if self.normalization:
             self.normalize(flooring_fn=flooring_fn)
+
+    # -- the iteration of a large batch in cache-sized sub-batches (round 5 experiment) -----------
+    def _subbatch_plan(self, B, N, F, T):
+        """(mixtures per sub-batch, streams) or None.  Mixtures are independent, so an iteration over
+        B of them may run sub-batch by sub-batch -- all passes over a few mixtures before the next
+        few -- which lets the second and third pass read X out of the 256 MB Infinity Cache instead
+        of HBM (0.025 against 0.083 nJ per byte above idle, profiles/r05_cache_energy.json; the
+        headline runs at the socket power cap).  SSSPY_AMD_SUBBATCH="<mixtures>:<streams>"."""
+        spec = _os.environ.get("SSSPY_AMD_SUBBATCH")
+        if not spec:
+            return None
+        sub, _, streams = spec.partition(":")
+        sub, streams = int(sub), int(streams or 1)
+        if sub <= 0 or sub >= B:
+            return None
+        return sub, max(1, streams)
+
+    def _update_once_in_subbatches(self, floor, sub, n_streams) -> None:
+        import torch
+
+        B, N, F, T = self._X.shape
+        K = self.n_basis
+        state = getattr(self, "_subbatch_state", None)
+        if state is None or state[0] != (B, sub, n_streams):
+            streams = [torch.cuda.Stream() for _ in range(n_streams)]
+            scratch = [_ops.ilrma_workspace(min(sub, B), N, F, T, K, self._X.device)
+                       for _ in range(n_streams)]
+            state = self._subbatch_state = ((B, sub, n_streams), streams, scratch)
+        _, streams, scratch = state
+        C = self._C() if self.normalization else None
+        W, Tb, Vb = (self._state_dev(k) for k in ("demix_filter", "basis", "activation"))
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for st in streams:
+            st.wait_event(ready)
+        for i, lo in enumerate(range(0, B, sub)):
+            hi = min(B, lo + sub)
+            k = i % n_streams
+            ws, ws_bytes = scratch[k]
+            with torch.cuda.stream(streams[k]):
+                _ops.ilrma_ip1_update(
+                    self._X[lo:hi], None if C is None else C[lo:hi], W[lo:hi], Tb[lo:hi], Vb[lo:hi],
+                    self._U[lo:hi], float(self.domain), bool(self.normalization), floor, ws,
+                    ws_bytes, self._info_tensor(), model=self._model)
+        for st in streams:
+            done = torch.cuda.Event()
+            done.record(st)
+            main.wait_event(done)
+        for name in ("demix_filter", "basis", "activation"):
+            self._state_touch(name)
 
     # -- ISS2 / IPA with the power normalisation folded into the update matrix (round 5) -------
     def _folded_output_normalization(self, floor) -> bool:

@@ -718,11 +718,13 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
     if constexpr (PMODE == P_READ) ptile_load<M>(t, xr, F, T, bin, j0, q);
     else xtile_load<M>(t, xr, F, T, bin, j0, q);
   };
-  // (round 5) a wave whose 16 bins all lie beyond F fetches no tile and computes nothing: it only
-  // helps staging the activation tiles (F = 1025: three of the four waves of the 17th bin group)
-  const bool active = __builtin_amdgcn_readfirstlane(i0) < F;
+  // (round 5, tried and dropped: letting a wave whose 16 bins all lie beyond F -- three of the four
+  //  waves of the 17th bin group at F = 1025 -- skip its tile loads and arithmetic.  The branch around
+  //  the tile body costs the scheduler more than the 4.4 % of skipped wave tiles give back: the
+  //  hand-over basis pass 219 -> 227 us, and the ILRMA basis pass 1.112 -> 1.209 ms at 128 mixtures.
+  //  The LDS-DMA kernels below, whose walk is hand-scheduled, keep it.)
   vstage_load(st, act_b, K, T, min(jt_begin, ntiles - 1) * 16);
-  if (active) load_tile(cur, min(jt_begin, ntiles - 1) * 16);
+  load_tile(cur, min(jt_begin, ntiles - 1) * 16);
   vstage_store(st, vs[0]);
   __syncthreads();
   // one tile of the walk: compute on `xc`, prefetch the next tile into `xn`.  The walk calls it with
@@ -731,9 +733,8 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
     const int j0 = jt * 16;
     const int jn = min(jt + 1, jt_end - 1) * 16;
     vstage_load(st, act_b, K, T, jn);
-    if (active) load_tile(xn, jn);
+    load_tile(xn, jn);
     const double *vcur = vs[(jt - jt_begin) & 1];
-    if (active) {  // (closed before the staging store below)
     double4_t lamR[N];
 #pragma unroll
     for (int n = 0; n < N; ++n) lamR[n] = rt_from_lds<KQ>(vcur + n * 16 * VROW, tb[n], c, q, ksteps);
@@ -844,7 +845,6 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
         }
       }
     }
-    }  // active
     vstage_store(st, vs[(jt - jt_begin + 1) & 1]);
     __syncthreads();
   };
