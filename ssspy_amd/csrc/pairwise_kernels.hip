@@ -131,6 +131,167 @@ __global__ __launch_bounds__(64) void k_ip2(c128 *W, const c128 *__restrict__ U,
 // bin); with G the transform accumulated so far the statistics of the updated Y are G Vc[s] G^H,
 // of which a pair step needs the 2x2 block on the pair for every s and, for the other sources, the
 // pair's column against s.  ref: ssspy/bss/_update_spatial_model.py:197-314.
+// ---- the same update with a bin spread over G = 8 lanes, lane r owning row r of W (round 5; the
+// layout of k_ip1_rows, spatial_kernels.hip).  The one-lane kernel above keeps W, two covariances and
+// the LU working set of a bin in one lane's registers: 110 / 402 / 760 / 1438 spilled VGPRs at 5 / 6
+// / 7 / 8 sources and 1.68 ms per launch for 16 x 1025 bins of 8 sources -- 44 % of a GaussILRMA-IP2
+// iteration (profiles/r05_legs8_*).  Here a lane holds ONE row of W and of A = W U; the covariance
+// entries are read where they are used (the lanes of a bin ask for the same address), the LU solve
+// with the two right-hand sides e_m, e_n is row-distributed (pivot search by three exchange steps,
+// the pivot row broadcast, back substitution broadcasting one pair of unknowns per step) and leaves
+// the whole N x 2 solution in every lane; P^H U P is a sum over the rows in row order.
+template <int N, int G>
+__device__ __forceinline__ bool ip2_half_rows(const c128 (&Wr)[N], const c128 *__restrict__ Um,
+                                              int r, int rr, bool row, int m, int n,
+                                              c128 (&P)[N][2], c128 (&PUP)[2][2]) {
+  c128 a[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c) a[c] = cmake(0.0, 0.0);
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+#pragma unroll
+    for (int c = 0; c < N; ++c) cfma(a[c], Wr[k], Um[k * N + c]);
+  c128 rhs[2] = {cmake(r == m ? 1.0 : 0.0, 0.0), cmake(r == n ? 1.0 : 0.0, 0.0)};
+  bool ok = true;
+  int order = row ? -1 : N;  // elimination step at which my row became the pivot row
+  int plane[N];              // lane of the group that owns pivot k (uniform within the group)
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const bool cand = order < 0;
+    double bv = cand ? cabs1(a[k]) : -1.0;
+    int bl = r;
+#pragma unroll
+    for (int s = 1; s < G; s <<= 1) {
+      const double ov = __shfl_xor(bv, s, G);
+      const int ol = __shfl_xor(bl, s, G);
+      const bool take = ov > bv || (ov == bv && ol < bl);
+      bv = take ? ov : bv;
+      bl = take ? ol : bl;
+    }
+    plane[k] = bl;
+    if (r == bl) order = k;
+    c128 prow[N];
+#pragma unroll
+    for (int c = k; c < N; ++c) prow[c] = cmake(__shfl(a[c].x, bl, G), __shfl(a[c].y, bl, G));
+    const c128 prhs0 = cmake(__shfl(rhs[0].x, bl, G), __shfl(rhs[0].y, bl, G));
+    const c128 prhs1 = cmake(__shfl(rhs[1].x, bl, G), __shfl(rhs[1].y, bl, G));
+    const c128 piv = prow[k];
+    ok = ok && (piv.x != 0.0 || piv.y != 0.0);
+    const c128 inv = crecip(piv);
+    if (order < 0) {  // still unused: eliminate column k
+      const c128 f = cmul(a[k], inv);
+#pragma unroll
+      for (int c = k + 1; c < N; ++c) cfms(a[c], f, prow[c]);
+      cfms(rhs[0], f, prhs0);
+      cfms(rhs[1], f, prhs1);
+    }
+  }
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {
+    // the owner of pivot k has folded the unknowns above k into its right-hand sides already
+    const c128 inv = crecip(a[k]);
+    const c128 m0 = cmul(rhs[0], inv), m1 = cmul(rhs[1], inv);
+    P[k][0] = cmake(__shfl(m0.x, plane[k], G), __shfl(m0.y, plane[k], G));
+    P[k][1] = cmake(__shfl(m1.x, plane[k], G), __shfl(m1.y, plane[k], G));
+    if (order < k) {
+      cfms(rhs[0], a[k], P[k][0]);
+      cfms(rhs[1], a[k], P[k][1]);
+    }
+  }
+  // (U P)[row rr], then P^H (U P): lane rr contributes conj(P[rr][j]) (U P)[rr][k], added in row order
+  c128 up[2] = {cmake(0.0, 0.0), cmake(0.0, 0.0)};
+#pragma unroll
+  for (int b = 0; b < N; ++b) {
+    const c128 u = Um[rr * N + b];
+    cfma(up[0], u, P[b][0]);
+    cfma(up[1], u, P[b][1]);
+  }
+  c128 pmine[2] = {cmake(0.0, 0.0), cmake(0.0, 0.0)};
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+    if (c == rr) {
+      pmine[0] = P[c][0];
+      pmine[1] = P[c][1];
+    }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double tx = row ? pmine[j].x * up[k].x + pmine[j].y * up[k].y : 0.0;
+      const double ty = row ? pmine[j].x * up[k].y - pmine[j].y * up[k].x : 0.0;
+      double sx = 0.0, sy = 0.0;
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        sx += __shfl(tx, c, G);
+        sy += __shfl(ty, c, G);
+      }
+      PUP[j][k] = cmake(sx, sy);
+    }
+  return ok;
+}
+
+template <int N, int G>
+__global__ __launch_bounds__(256) void k_ip2_rows(c128 *W, const c128 *__restrict__ U,
+                                                  long long nbins, int pair_only, PairList pairs,
+                                                  int floor_kind, double eps, int *info,
+                                                  double *denom) {
+  static_assert(G == 8 && N <= G, "one lane per row, groups of 8");
+  const int r = threadIdx.x % G;
+  const long long idx = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const bool live = idx < nbins;
+  const long long id = live ? idx : nbins - 1;  // idle groups shadow the last bin, never store
+  const bool row = r < N;
+  const int rr = row ? r : N - 1;
+  c128 Wr[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c) Wr[c] = W[id * (N * N) + rr * N + c];
+  bool ok = true;
+  const int u_sets = pair_only ? 2 : N;
+#pragma unroll 1
+  for (int p = 0; p < pairs.count; ++p) {
+    const int m = pairs.first[p], n = pairs.second[p];
+    const c128 *Um = U + (id * u_sets + (pair_only ? 0 : m)) * (N * N);
+    const c128 *Un = U + (id * u_sets + (pair_only ? 1 : n)) * (N * N);
+    c128 Pm[N][2], Pn[N][2], Gm[2][2], Gn[2][2];
+    ok = ip2_half_rows<N, G>(Wr, Um, r, rr, row, m, n, Pm, Gm) && ok;
+    ok = ip2_half_rows<N, G>(Wr, Un, r, rr, row, m, n, Pn, Gn) && ok;
+    double lamb[2];
+    c128 z[2][2];
+    ok = eigh2_type1(Gm, Gn, lamb, z) && ok;
+    c128 hm[2] = {z[0][1], z[1][1]}, hn[2] = {z[0][0], z[1][0]};
+    double qm = quad2(hm, Gm), qn = quad2(hn, Gn);
+    qm = qm < 0.0 ? 0.0 : qm;
+    qn = qn < 0.0 ? 0.0 : qn;
+    const double dm = denom ? 1.0 : apply_floor(sqrt(qm), floor_kind, eps);
+    const double dn = denom ? 1.0 : apply_floor(sqrt(qn), floor_kind, eps);
+    if (denom && live && r == 0) {
+      denom[idx * 2 + 0] = sqrt(qm);
+      denom[idx * 2 + 1] = sqrt(qn);
+    }
+    // every lane holds both solutions; rows m and n of W take conj(P h) / d
+    if (r == m || r == n) {
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        c128 v;
+        if (r == m) {
+          v = cmul(Pm[c][0], hm[0]);
+          cfma(v, Pm[c][1], hm[1]);
+          Wr[c] = cmake(v.x / dm, -v.y / dm);
+        } else {
+          v = cmul(Pn[c][0], hn[0]);
+          cfma(v, Pn[c][1], hn[1]);
+          Wr[c] = cmake(v.x / dn, -v.y / dn);
+        }
+      }
+    }
+  }
+  if (live && row) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) W[idx * (N * N) + r * N + c] = Wr[c];
+    if (!ok && info && r == 0) atomicAdd(info, 1);
+  }
+}
+
 template <int N>
 __global__ __launch_bounds__(64) void k_iss2_transform(const c128 *__restrict__ Vc, c128 *G,
                                                        long long nbins, PairList pairs,
@@ -396,6 +557,31 @@ __global__ __launch_bounds__(64) void k_iss2_transform_rt(const c128 *__restrict
 
 static bool pair_rt_sources(int N) { return N > SSSPY_MAX_SOURCES && N <= SSSPY_RT_MAX_SOURCES; }
 
+// 5..8 sources: a bin on 8 lanes (k_ip2_rows)
+static int launch_ip2_rows(void *W, const void *U, long long nbins, int N, int pair_only,
+                           const PairList &pl, int floor_kind, double eps, int *info, double *denom,
+                           hipStream_t st) {
+  dim3 grid((unsigned)((nbins * 8 + 255) / 256)), block(256);
+  switch (N) {
+    case 5: hipLaunchKernelGGL((k_ip2_rows<5, 8>), grid, block, 0, st, (c128 *)W, (const c128 *)U, nbins, pair_only, pl, floor_kind, eps, info, denom); break;
+    case 6: hipLaunchKernelGGL((k_ip2_rows<6, 8>), grid, block, 0, st, (c128 *)W, (const c128 *)U, nbins, pair_only, pl, floor_kind, eps, info, denom); break;
+    case 7: hipLaunchKernelGGL((k_ip2_rows<7, 8>), grid, block, 0, st, (c128 *)W, (const c128 *)U, nbins, pair_only, pl, floor_kind, eps, info, denom); break;
+    case 8: hipLaunchKernelGGL((k_ip2_rows<8, 8>), grid, block, 0, st, (c128 *)W, (const c128 *)U, nbins, pair_only, pl, floor_kind, eps, info, denom); break;
+    default: return fail(SSSPY_ERR_INTERNAL, "k_ip2_rows: 5..8 sources");
+  }
+  return check_launch("k_ip2_rows");
+}
+
+// (per-N kernels of up to 4 sources: above, the row-distributed or the run-time-N forms take over)
+#define DISPATCH_N4(N_, CALL)                                                           \
+  switch (N_) {                                                                         \
+    case 1: { constexpr int NN = 1; CALL; } break;                                      \
+    case 2: { constexpr int NN = 2; CALL; } break;                                      \
+    case 3: { constexpr int NN = 3; CALL; } break;                                      \
+    case 4: { constexpr int NN = 4; CALL; } break;                                      \
+    default: return ::ssspy::fail(SSSPY_ERR_UNSUPPORTED, "n_sources must be in [1, 4]"); \
+  }
+
 static int fill_pairs(PairList &pl, const int *pairs, int n_pairs, int N) {
   if (n_pairs < 1 || n_pairs > SSSPY_MAX_PAIRS)
     return fail(SSSPY_ERR_BADARG, "pair list must hold between 1 and SSSPY_MAX_PAIRS pairs");
@@ -431,9 +617,11 @@ int ssspy_update_by_ip2(void *W, const void *U, int pair_only, const int *pairs,
                        N, pair_only, pl, floor_kind, floor_eps, info, (double *)nullptr);
     return check_launch("k_ip2_rt");
   }
-  DISPATCH_N(N, hipLaunchKernelGGL((k_ip2<NN>), grid, block, 0, as_stream(stream), (c128 *)W,
-                                   (const c128 *)U, nbins, pair_only, pl, floor_kind, floor_eps, info,
-                                   (double *)nullptr));
+  if (N > 4) return launch_ip2_rows(W, U, nbins, N, pair_only, pl, floor_kind, floor_eps, info,
+                                    nullptr, as_stream(stream));
+  DISPATCH_N4(N, hipLaunchKernelGGL((k_ip2<NN>), grid, block, 0, as_stream(stream), (c128 *)W,
+                                    (const c128 *)U, nbins, pair_only, pl, floor_kind, floor_eps, info,
+                                    (double *)nullptr));
   return check_launch("k_ip2");
 }
 
@@ -450,9 +638,11 @@ int ssspy_update_by_ip2_deferred(void *W, const void *U, int pair_only, const in
                        N, pair_only, pl, SSSPY_FLOOR_NONE, 0.0, info, denom);
     return check_launch("k_ip2_rt (deferred)");
   }
-  DISPATCH_N(N, hipLaunchKernelGGL((k_ip2<NN>), grid, block, 0, as_stream(stream), (c128 *)W,
-                                   (const c128 *)U, nbins, pair_only, pl, SSSPY_FLOOR_NONE, 0.0, info,
-                                   denom));
+  if (N > 4) return launch_ip2_rows(W, U, nbins, N, pair_only, pl, SSSPY_FLOOR_NONE, 0.0, info, denom,
+                                    as_stream(stream));
+  DISPATCH_N4(N, hipLaunchKernelGGL((k_ip2<NN>), grid, block, 0, as_stream(stream), (c128 *)W,
+                                    (const c128 *)U, nbins, pair_only, pl, SSSPY_FLOOR_NONE, 0.0, info,
+                                    denom));
   return check_launch("k_ip2 (deferred)");
 }
 
