@@ -97,4 +97,34 @@ single = os.path.join(src, "single.txt")
 if os.path.exists(single):  # single-mixture timelines (benchmarks/single_trace.py) + the AuxIVA lines
     keep = [ln for ln in open(single) if "amdgpu.ids" not in ln]
     open(os.path.join(dst, "{}_single_mixture.txt".format(tag)), "w").writelines(keep)
+# round 5 additions (benchmarks/profile_round.sh)
+for name, out_name in (("mnmf_steps.txt", "{}_mnmf_steps.txt"), ("call_timeline.txt", "{}_call_timeline.txt"),
+                       ("cache_energy.json", "{}_cache_energy.json"),
+                       ("subbatch_sweep.txt", "{}_subbatch_sweep.txt"),
+                       ("batch_sweep.txt", "{}_batch_sweep.txt"),
+                       ("power_profile.json", "{}_power_profile.json")):
+    path = os.path.join(src, name)
+    if os.path.exists(path) and os.path.getsize(path):
+        keep = [ln for ln in open(path) if "amdgpu.ids" not in ln]
+        open(os.path.join(dst, out_name.format(tag)), "w").writelines(keep)
+for path in sorted(glob.glob(os.path.join(src, "legs", "*_b32_kernel_stats.csv"))):
+    rows = [r for r in csv.DictReader(open(path))]
+    leg = os.path.basename(path)[: -len("_b32_kernel_stats.csv")]
+    with open(os.path.join(dst, "{}_pairwise_ipa_{}_b32_kernel_stats.csv".format(tag, leg)), "w") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        for r in rows:
+            if float(r.get("Percentage", 0) or 0) >= 0.05:
+                r["Name"] = r["Name"][:120]
+                w.writerow(r)
+call = latest(os.path.join(src, "call_stats", "**", "*kernel_stats.csv"))
+if call:
+    rows = [r for r in csv.DictReader(open(call))]
+    with open(os.path.join(dst, "{}_call_kernel_stats.csv".format(tag)), "w") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        for r in rows:
+            if float(r.get("Percentage", 0) or 0) >= 0.05:
+                r["Name"] = r["Name"][:120]
+                w.writerow(r)
 print(json.dumps({"bench_value": bench["value"], "roofline": bench["roofline"], "traffic": traffic}, indent=1))

@@ -10,7 +10,7 @@ set -u
 tag=${1:-r04}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/$tag
-mkdir -p $out
+mkdir -p $out $out/legs
 cd /tmp && export TMPDIR=/tmp
 cd $root
 python bench.py > $out/bench.json 2> $out/bench.err
@@ -38,4 +38,19 @@ python benchmarks/single_mnmf.py 300 >> $out/single.txt 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $out/single_mnmf_trace -- python benchmarks/single_mnmf.py 60 > /dev/null 2>&1
 python benchmarks/single_trace.py $out/single_mnmf_trace >> $out/single.txt 2>&1
 python benchmarks/iva_lines.py >> $out/single.txt 2>&1
+# ---- round 5: per-step times of configs[3], the pairwise / IPA legs, the __call__ timeline, the
+# energy per byte of the Infinity Cache, the headline in cache-sized sub-batches
+python benchmarks/tools/mnmf_steps.py 32 > $out/mnmf_steps.txt 2>/dev/null
+python benchmarks/tools/mnmf_steps.py 128 >> $out/mnmf_steps.txt 2>/dev/null
+SSSPY_AMD_MNMF_NO_GLDS=1 python benchmarks/tools/mnmf_steps.py 32 2>/dev/null | sed 's/^/register-fed passes (SSSPY_AMD_MNMF_NO_GLDS): /' >> $out/mnmf_steps.txt
+for leg in ilrma_ip2 ilrma_iss2 ilrma_ipa auxiva_ip2 auxiva_iss2 auxiva_ipa fmnmf_ip2; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/legs/$leg -- python benchmarks/tools/leg_run.py $leg 32 10 > $out/legs/$leg.log 2>&1
+  f=$(find $out/legs/$leg -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cp "$f" $out/legs/${leg}_b32_kernel_stats.csv
+  rm -rf $out/legs/$leg
+done
+python benchmarks/tools/call_timeline.py 100 2>/dev/null | grep -v "^$" | head -12 > $out/call_timeline.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/call_stats -- python benchmarks/tools/call_once.py 100 >> $out/call_timeline.txt 2>&1
+python benchmarks/cache_energy.py --seconds 4 > $out/cache_energy.json 2>/dev/null
+python benchmarks/subbatch_sweep.py --seconds 1.0 > $out/subbatch_sweep.txt 2>/dev/null
 tail -c 600 $out/bench.json
