@@ -210,6 +210,30 @@ __device__ __forceinline__ void lqpqm2(c128 (&H)[L][L], const c128 (&v)[L], doub
   }
 }
 
+// lam_min(A) > shift for a Hermitian A, by the pivots of the Cholesky factorisation of A - shift I
+// (W: working copy; A is left intact)
+template <int N>
+__device__ __forceinline__ bool shifted_positive_definite(const c128 (&A)[N][N], c128 (&W)[N][N],
+                                                          double shift) {
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    double d = A[c][c].x - shift;
+#pragma unroll
+    for (int k = 0; k < c; ++k) d -= cabs2(W[c][k]);
+    ok = ok && (d > 0.0);
+    const double il = 1.0 / sqrt(d > 0.0 ? d : 1.0);
+#pragma unroll
+    for (int r = c + 1; r < N; ++r) {
+      c128 sum = A[r][c];
+#pragma unroll
+      for (int k = 0; k < c; ++k) cfms(sum, W[r][k], cconj(W[c][k]));
+      W[r][c] = cscale(sum, il);
+    }
+  }
+  return ok;
+}
+
 // index of the m-th source other than S
 template <int S>
 __device__ __forceinline__ constexpr int rest_index(int m) {
@@ -233,40 +257,77 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   const c128 *Ub = Vc + bin * (long long)(N * N * N);
   c128 M[N][N], P[N][N];
   double lam[N];
+  // Round 5: to_psd without an eigen-decomposition where its floor provably does nothing.  The
+  // reference's to_psd is P diag(floor(lam)) P^H of the Hermitian part A (special/psd.py:54-71): A
+  // itself under the identity floor, A + eps I under the add floor, and A under the max floor
+  // whenever lam_min(A) > eps -- which a Cholesky factorisation of A - eps I decides (positive
+  // pivots <=> positive definite) at a thirtieth of the cost of the Jacobi sweeps.  N + 1 eigen-
+  // decompositions per source step become none in the common case (the LQPQM problem keeps its own);
+  // a lane whose test fails takes the literal route (`literal`).
   // a_m = Re to_psd(U[m])[S][S], b_m = to_psd(U[m])[S][m] for the other sources
   double a[L];
   c128 b[L];
-#pragma unroll
+#pragma unroll 1
   for (int mm = 0; mm < L; ++mm) {
     const int m = rest_index<S>(mm);
 #pragma unroll
     for (int r = 0; r < N; ++r)
 #pragma unroll
       for (int c = 0; c < N; ++c) M[r][c] = Ub[(m * N + r) * N + c];
-    psd_eigen<N>(M, P, lam, floor_kind, eps);
+    hermitize<N>(M);
     double ass = 0.0;
     c128 bsm = cmake(0.0, 0.0);
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-      ass = fma(lam[k], cabs2(P[S][k]), ass);
-      const c128 t = cmulc(P[S][k], P[m][k]);
-      bsm.x = fma(lam[k], t.x, bsm.x);
-      bsm.y = fma(lam[k], t.y, bsm.y);
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        if (r == S && c == S) ass = M[r][c].x;
+        if (r == S && c == m) bsm = M[r][c];
+      }
+    bool idle = floor_kind != SSSPY_FLOOR_MAX;
+    if (floor_kind == SSSPY_FLOOR_ADD) ass += eps;
+    if (floor_kind == SSSPY_FLOOR_MAX) idle = shifted_positive_definite<N>(M, P, eps);
+    if (!idle) {  // (M is intact: the test works on a copy)
+      psd_eigen<N>(M, P, lam, floor_kind, eps);
+      ass = 0.0;
+      bsm = cmake(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        ass = fma(lam[k], cabs2(P[S][k]), ass);
+        const c128 t = cmulc(P[S][k], P[m][k]);
+        bsm.x = fma(lam[k], t.x, bsm.x);
+        bsm.y = fma(lam[k], t.y, bsm.y);
+      }
     }
     a[mm] = ass;
     b[mm] = bsm;
   }
-  // U_S: eigen-decomposition with the floor of to_psd; _psd_inv floors the floored values again
+  // U_S: to_psd, then _psd_inv floors the floored eigenvalues again (identity / max floor idle:
+  // U_S^-1 by Cholesky; add floor: (A + 2 eps I)^-1 here and (A + eps I)^-1 for the final solve)
 #pragma unroll
   for (int r = 0; r < N; ++r)
 #pragma unroll
     for (int c = 0; c < N; ++c) M[r][c] = Ub[(S * N + r) * N + c];
-  psd_eigen<N>(M, P, lam, floor_kind, eps);
-  double w[N];
-#pragma unroll
-  for (int k = 0; k < N; ++k) w[k] = 1.0 / apply_floor(lam[k], floor_kind, eps);
+  hermitize<N>(M);
   c128 Uinv[N][N];
-  herm_rebuild<N>(P, w, Uinv);
+  bool literal = floor_kind == SSSPY_FLOOR_MAX && !shifted_positive_definite<N>(M, P, eps);
+  if (!literal) {
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c)
+        P[r][c] = (r == c && floor_kind == SSSPY_FLOOR_ADD) ? cmake(M[r][c].x + 2.0 * eps, 0.0)
+                                                            : M[r][c];
+    double ld;
+    literal = !chol_inverse<N>(P, Uinv, ld);  // (not positive definite: the eigen route copes)
+  }
+  double w[N];
+  if (literal) {
+    psd_eigen<N>(M, P, lam, floor_kind, eps);
+#pragma unroll
+    for (int k = 0; k < N; ++k) w[k] = 1.0 / apply_floor(lam[k], floor_kind, eps);
+    herm_rebuild<N>(P, w, Uinv);
+  }
   // C = conj(Uinv)[rest][rest], d = conj(Uinv)[rest][S]
   Mat<L> C;
   c128 Cm[L][L], d[L], rhs[L][1];
@@ -325,9 +386,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
   for (int r = 0; r < L; ++r) qt[rest_index<S>(r)] = cmake(-q[r].x, q[r].y);
   // Uq = U_S^-1 q~ (single floor), p = Uq / floor(sqrt(max(q~^H Uq, 0)))
+  if (literal) {
 #pragma unroll
-  for (int k = 0; k < N; ++k) w[k] = 1.0 / lam[k];
-  herm_rebuild<N>(P, w, Uinv);
+    for (int k = 0; k < N; ++k) w[k] = 1.0 / lam[k];
+    herm_rebuild<N>(P, w, Uinv);
+  } else if (floor_kind == SSSPY_FLOOR_ADD) {
+    // (M still holds the Hermitian part of U_S: the singly floored inverse is (A + eps I)^-1)
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c)
+        P[r][c] = r == c ? cmake(M[r][c].x + eps, 0.0) : M[r][c];
+    double ld;
+    if (!chol_inverse<N>(P, Uinv, ld) && info) atomicAdd(info, 1);
+  }  // (identity / idle max floor: Uinv is U_S^-1 already)
   c128 Uq[N];
   double quq = 0.0;
 #pragma unroll
