@@ -37,11 +37,13 @@ def main():
         T = int(rng.choice([2, 5, 15, 16, 17, 31, 32, 33, 47, 64, 65, 100, 130]))
         K = int(rng.choice([1, 2, 3, 4, 7, 8, 15, 16, 17, 24, 32, 33, 48, 64, 70]))  # 17..32 / 33..64: the two- / four-k-tile variants
         B = int(rng.choice([1, 1, 1, 2, 5, 40]))
-        algo = str(rng.choice(["IP", "ISS", "IP2", "ISS2"]))
+        algo = str(rng.choice(["IP", "ISS", "IP2", "ISS2", "IPA"]))
         if T < 2 * N:
             T = 2 * N + 3
         kind = str(rng.choice(["gauss", "gauss", "t", "ggd", "gauss_p1", "iva_lap", "iva_gauss",
                                "fmnmf", "gmnmf", "part"]))
+        if algo == "IPA" and kind in ("t", "ggd"):
+            algo = "ISS2"  # (the reference raises for IPA with the heavy-tailed models)
         if kind == "fmnmf" and rng.random() < 0.3:
             B, F, T = 300, int(rng.choice([65, 70, 129])), int(rng.choice([31, 32, 48]))  # bin-split kernels
         if kind == "gmnmf":
@@ -53,7 +55,7 @@ def main():
         tag = (case, kind, algo, N, F, T, K, B)
         # pairwise updates solve 2 x 2 generalised eigenproblems whose conditioning amplifies
         # rounding differences (and which are degenerate when the sources share one basis vector)
-        tol = 1e-5 if algo in ("IP2", "ISS2") else 1e-7
+        tol = 1e-5 if algo in ("IP2", "ISS2", "IPA") else 1e-7
         try:
             if kind in ("fmnmf", "gmnmf"):
                 basis = rng.random((B, N, F, K)) + 0.05
