@@ -406,7 +406,9 @@ def pairwise_ipa_legs(args, dev, Xbatch_host):
         ("ilrma_iss1", ilrma("ISS1"), 4, "basis, activation passes over Y; fused sweep: read + write Y"),
         ("ilrma_iss2", ilrma("ISS2"), 5, "basis, activation, covariance passes over Y; Y <- G Y read + write"),
         ("ilrma_ipa", ilrma("IPA"), 5, "basis, activation, covariance passes over Y; Y <- G Y read + write"),
-        ("auxiva_ip2", iva("IP2"), 2, "frame powers and covariance passes over X"),
+        ("auxiva_ip2", iva("IP2"), 2 * N, "per pair (N of them: (0,1), (1,2), ... , (N-1,0)) a frame-power and "
+                                          "a covariance pass over X: the weights are recomputed from the "
+                                          "current filters before every pair (ssspy/bss/iva.py:1795-1915)"),
         ("auxiva_iss2", iva("ISS2"), 4, "frame powers, covariance passes over Y; Y <- G Y read + write"),
         ("auxiva_ipa", iva("IPA"), 4, "frame powers, covariance passes over Y; Y <- G Y read + write"),
         ("fmnmf_ip2", fmnmf("IP2"), 4, "basis, activation, covariance, spatial passes (as IP1)"),
