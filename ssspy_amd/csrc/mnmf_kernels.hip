@@ -1006,7 +1006,10 @@ __device__ __forceinline__ void vrow_from_lds(double (&a)[KQ], unsigned addr, in
 // nothing is shared between the waves any more: no barrier in the walk (it cost 30 of the covariance
 // pass's 250 us at 32 mixtures: every tile all four waves waited for the slowest DMA), and a wave
 // without bins leaves at once.  Costs 4 KB more L2 -> LDS traffic per wave tile (16 KB of x).
-template <int M, int MODE, int KQ, bool PRIV = false>
+// TSTORE (spatial pass, shared activation ring): the |Q x|^2 tile of a channel goes through a 2 KB
+// patch per wave (the last 8 KB of the CU's LDS) so that four adjacent lanes store one 64-byte run
+// (lanes are bins: without it an instruction stores 64 scattered 16-byte pieces).
+template <int M, int MODE, int KQ, bool PRIV = false, bool TSTORE = false>
 __global__ __launch_bounds__(256, 1) void k_mnmf_binmajor_glds(
     const c128 *__restrict__ X, const c128 *__restrict__ Q, double *Dsp,
     const double *__restrict__ basis, const double *__restrict__ act, c128 *__restrict__ U, int F,
@@ -1014,6 +1017,7 @@ __global__ __launch_bounds__(256, 1) void k_mnmf_binmajor_glds(
   static_assert(MODE == MODE_WCOV || MODE == MODE_SPATIAL, "the two passes that read x");
   static_assert(KQ == 2 || KQ == 4, "k-slabs of 4 carried: n_basis <= 8 or <= 16");
   static_assert(!PRIV || KQ == 2, "private activation tiles: n_basis <= 8");
+  static_assert(!TSTORE || (MODE == MODE_SPATIAL && !PRIV), "transposed stores: spatial pass, shared ring");
   constexpr int XI = 4 * M;                                 // DMA instructions per x tile and wave
   constexpr int NV = PRIV ? N : KQ / 2;                     // ... per activation tile and wave
   constexpr int NS = MODE == MODE_SPATIAL ? 2 * M : 0;      // stores per tile and wave
@@ -1023,6 +1027,7 @@ __global__ __launch_bounds__(256, 1) void k_mnmf_binmajor_glds(
   constexpr unsigned VSRC = PRIV ? 1024u : 2048u;           // bytes between two sources in a slot
   __shared__ __attribute__((aligned(16))) double xring[2 * 4 * XI * 128];
   __shared__ __attribute__((aligned(16))) double vring[PRIV ? 4 * 2 * N * 8 * 16 : 3 * N * 16 * 16];
+  __shared__ __attribute__((aligned(16))) double ppatch[TSTORE ? 4 * 256 : 2];  // 2 KB per wave
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, q = lane >> 4;
@@ -1241,7 +1246,45 @@ __global__ __launch_bounds__(256, 1) void k_mnmf_binmajor_glds(
       }
     }
 #endif
-    if (MODE == MODE_SPATIAL) {
+    if constexpr (MODE == MODE_SPATIAL && TSTORE) {
+      // channel by channel through the wave's patch: lane (c, q) writes its 32 bytes (logical 16-byte
+      // slots 2 q, 2 q + 1 of bin row c at physical slot ^ (c & 7): conflict-free for the 8-lane write
+      // groups), lane 4 c' + p reads slot 4 s + p of bin row c' back (frames 8 s + 2 p, + 1) and stores
+      // it: LDS operations of a wave complete in order, so the only wait is before the stores
+      const unsigned pbase = SSSPY_LDS_ADDR(ppatch) + (unsigned)wave * 2048u;
+      const unsigned wr0 = pbase + (unsigned)c * 128u + 16u * (unsigned)((2 * q) ^ (c & 7));
+      const unsigned wr1 = pbase + (unsigned)c * 128u + 16u * (unsigned)((2 * q + 1) ^ (c & 7));
+      const int cs = lane >> 2, ps = lane & 3;
+      const unsigned rd0 = pbase + (unsigned)cs * 128u + 16u * (unsigned)(ps ^ (cs & 7));
+      const unsigned rd1 = pbase + (unsigned)cs * 128u + 16u * (unsigned)((4 + ps) ^ (cs & 7));
+      const bool svalid = i0 + cs < F;
+      const unsigned soff = svalid ? ((unsigned)min(i0 + cs, F - 1) * (unsigned)T + (unsigned)j0 +
+                                      2u * (unsigned)ps) * 8u
+                                   : 0x80000000u;
+      d2_t got[M][2];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const d2_t lo = {pw[m][0], pw[m][1]}, hi = {pw[m][2], pw[m][3]};
+        asm volatile("ds_write_b128 %0, %1" : : "v"(wr0), "v"(lo) : "memory");
+        asm volatile("ds_write_b128 %0, %1" : : "v"(wr1), "v"(hi) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(got[m][0]) : "v"(rd0) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(got[m][1]) : "v"(rd1) : "memory");
+      }
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(got[m][0]), "+v"(got[m][1]));
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          u32x4_t v;
+          v[0] = (unsigned)__double2loint(got[m][sx].x);
+          v[1] = (unsigned)__double2hiint(got[m][sx].x);
+          v[2] = (unsigned)__double2loint(got[m][sx].y);
+          v[3] = (unsigned)__double2hiint(got[m][sx].y);
+          __builtin_amdgcn_raw_buffer_store_b128(v, pr, soff + (unsigned)m * pchan + 64u * sx, 0, 0);
+        }
+    } else if (MODE == MODE_SPATIAL) {
       // (2 M stores whatever the lane holds: see the header)
       const unsigned off = bin_valid ? pvoff + (unsigned)j0 * 8u : 0x80000000u;
 #pragma unroll
@@ -2135,6 +2178,10 @@ static inline bool mnmf_glds_private_v(bool spatial) {
   if (e) return e[0] != '0';
   return !spatial;
 }
+// |Q x|^2 stores of the spatial pass transposed through LDS into 64-byte runs (n_basis <= 8)
+static inline bool mnmf_glds_tstore() {
+  return std::getenv("SSSPY_AMD_MNMF_GLDS_TSTORE") != nullptr;  // (experiment)
+}
 // the LDS-DMA form of the two x-reading passes (k_mnmf_binmajor_glds): whole tiles of frames
 static inline bool mnmf_glds_ok(int B, int F, int T, int K) {
   // (read per call: the parity tests switch it inside one process)
@@ -2315,6 +2362,10 @@ int LAUNCHER(mnmf_spatial)(const void *X, const void *Q, double *Dsp, const doub
         hipLaunchKernelGGL((k_mnmf_binmajor_glds<MM, MODE_SPATIAL, 2, true>), fgrid, dim3(256), 0,
                            st, (const c128 *)X, (const c128 *)Q, Dsp, basis, act, (c128 *)nullptr,
                            F, T, K, plan, tailpart, P);
+      else if (glds && K <= 8 && mnmf_glds_tstore())
+        hipLaunchKernelGGL((k_mnmf_binmajor_glds<MM, MODE_SPATIAL, 2, false, true>), fgrid,
+                           dim3(256), 0, st, (const c128 *)X, (const c128 *)Q, Dsp, basis, act,
+                           (c128 *)nullptr, F, T, K, plan, tailpart, P);
       else if (glds && K <= 8)
         hipLaunchKernelGGL((k_mnmf_binmajor_glds<MM, MODE_SPATIAL, 2>), fgrid, dim3(256), 0, st,
                            (const c128 *)X, (const c128 *)Q, Dsp, basis, act, (c128 *)nullptr, F,
