@@ -181,10 +181,11 @@ def power_leg(sep, seconds):
 
 def joint_power_leg(sep, seconds, rank, fence):
     """All ranks run update_once() back to back for `seconds` between two barriers while rank 0
-    samples the power sensor and shader clock of EVERY amdgpu card of the node."""
-    try:
-        sampler = None
-        if rank == 0:
+    samples the power sensor and shader clock of EVERY amdgpu card of the node.  Every rank passes
+    both barriers whatever happens to the sampler (a rank that skipped one would hang the others)."""
+    sampler, err = None, None
+    if rank == 0:
+        try:
             import importlib.util
 
             spec = importlib.util.spec_from_file_location(
@@ -192,26 +193,31 @@ def joint_power_leg(sep, seconds, rank, fence):
             pp = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(pp)
             sampler = pp.Sampler()
-        fence()
-        if sampler is not None and sampler.cards:
-            sampler.__enter__()
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < seconds:
-            for _ in range(20):
-                sep.update_once()
-            torch.cuda.synchronize()
-        if sampler is not None and sampler.cards:
-            sampler.__exit__()
-        fence()
-        if rank != 0:
-            return None
-        if not sampler.cards:
-            return {"error": "no amdgpu hwmon power sensor visible"}
+            if not sampler.cards:
+                sampler, err = None, "no amdgpu hwmon power sensor visible"
+        except Exception as exc:
+            sampler, err = None, "{}: {}".format(type(exc).__name__, str(exc)[:200])
+    fence()
+    if sampler is not None:
+        sampler.__enter__()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            sep.update_once()
+        torch.cuda.synchronize()
+    if sampler is not None:
+        sampler.__exit__()
+    fence()
+    if rank != 0:
+        return None
+    if sampler is None:
+        return {"error": err}
+    try:
         cards = [sampler.summary(0.5, card=i) for i in range(len(sampler.cards))]
         return {"cards": cards, "seconds": seconds,
                 "note": "every rank iterating at once; one entry per amdgpu card with a power sensor "
                         "(sysfs order, not rank order)"}
-    except Exception as exc:  # never cost the headline line
+    except Exception as exc:
         return {"error": "{}: {}".format(type(exc).__name__, str(exc)[:200])}
 
 
@@ -631,12 +637,15 @@ def main():
     # or a shared power budget limits scaling).  After the timed regions; none of it is `value`.
     per_rank = joint_power = None
     if distributed:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, {"rank": rank, "device": dev_index,
-                                          "own_s": [float(v) for v in own_regions]})
+        # (a plain all_gather of one double per rank, on the device for RCCL: the same kind of
+        # collective as the all-reduce of max_over_ranks)
+        mine = torch.tensor([float(np.median(own_regions))], dtype=torch.float64,
+                            device=dev if backend == "nccl" else torch.device("cpu"))
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
         joint_power = joint_power_leg(sep, min(args.power_seconds, 1.5), rank, fence)
         if rank == 0:
-            rates = [B * args.steps / float(np.median(g["own_s"])) for g in gathered]
+            rates = [B * args.steps / float(g.item()) for g in gathered]
             per_rank = {
                 "mixture_iterations_per_s": [round(r, 1) for r in rates],
                 "min": round(min(rates), 1), "median": round(float(np.median(rates)), 1),

@@ -544,6 +544,17 @@ int ssspy_fastmnmf_separate(const void *X, const void *Q, const double *D, const
                             int K, int reference_id, int floor_kind, double floor_eps,
                             void *workspace, size_t workspace_bytes, int *info, void *stream);
 
+/* The same filter split at the eigenvalue floor of to_psd, for a flooring callable the kernels do
+ * not know (round 5): stage 1 leaves the eigenvalues of R_ij in ascending order, lam (B,F,T,M) -- what
+ * numpy.linalg.eigh hands the reference's flooring_fn (special/psd.py:54-62) -- and the eigenvectors
+ * P (B,F,T,M,M); the caller applies the callable to lam on the host; stage 2 (same workspace,
+ * untouched in between: it holds Q^-1) rebuilds R^-1 from them and writes Y.  Any N, M <= 8.
+ * replaces: ssspy/bss/mnmf.py:1174-1217 with an arbitrary flooring_fn. */
+int ssspy_fastmnmf_separate_eig(const void *X, const void *Q, const double *D, const double *basis,
+                                const double *activation, void *Y, int B, int N, int M, int F,
+                                int T, int K, int reference_id, int stage, double *lam, void *P,
+                                void *workspace, size_t workspace_bytes, int *info, void *stream);
+
 /* ------------------------------------------------------------------ GaussMNMF (full-rank SCM)
  * State: basis (B,N,F,K) f64, activation (B,N,K,T) f64, spatial (B,N,F,M,M) c128 Hermitian PSD
  * (the reference's `spatial` (N,F,M,M) with a batch axis).  n_channels M in [2, 8]: one lane per

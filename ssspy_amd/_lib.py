@@ -124,6 +124,8 @@ PROTOTYPES = {
     "ssspy_fastmnmf_weights": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ssspy_fastmnmf_separate": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p,
                                      _z, _p, _p]),
+    "ssspy_fastmnmf_separate_eig": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p,
+                                         _p, _p, _z, _p, _p]),
 }
 GMNMF_BASIS, GMNMF_ACTIVATION, GMNMF_SPATIAL, GMNMF_NORMALIZE, GMNMF_ALL = 1, 2, 4, 8, 15
 GMNMF_LATENT = 16

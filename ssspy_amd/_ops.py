@@ -742,6 +742,30 @@ def fastmnmf_separate(X, Q, D, basis, activation, reference_id, flooring, ws, ws
     return out
 
 
+def fastmnmf_separate_host_floor(X, Q, D, basis, activation, reference_id, host_fn, ws, ws_bytes,
+                                 info, out=None):
+    """The Wiener filter with an arbitrary flooring callable on the eigenvalues of R_ij: stage 1
+    leaves ascending eigenvalues (B, F, T, M) and eigenvectors in HBM, the callable runs on the host
+    on each mixture's (F, T, M) array -- what to_psd hands it in the reference (special/psd.py:54-62)
+    -- and stage 2 finishes from the floored values."""
+    B, M, F, T = X.shape
+    N, K = basis.shape[1], basis.shape[-1]
+    if out is None:
+        out = dv.empty((B, N, F, T), dv.c128, X.device)
+    lam = dv.empty((B, F, T, M), dv.f64, X.device)
+    P = dv.empty((B, F, T, M, M), dv.c128, X.device)
+    for stage in (1, 2):
+        _lib.check(
+            _L().ssspy_fastmnmf_separate_eig(ptr(X), ptr(Q), ptr(D), ptr(basis), ptr(activation),
+                                             ptr(out), B, N, M, F, T, K, reference_id, stage,
+                                             ptr(lam), ptr(P), ptr(ws), ws_bytes, ptr(info), _st()),
+            "fastmnmf_separate_eig",
+        )
+        if stage == 1:
+            lam.copy_(dv.to_device(_apply_host(host_fn, lam), dev=X.device))
+    return out
+
+
 # ------------------------------------------------------------------------- GaussMNMF
 def gmnmf_workspace(B, N, M, F, T, K, dev):
     return _workspace(_L().ssspy_gmnmf_workspace_bytes(B, N, M, F, T, K), dev)

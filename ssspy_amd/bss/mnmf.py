@@ -23,7 +23,7 @@ import numpy as np
 from .. import _device as dv
 from .. import _lib, _ops
 from ..special.flooring import identity, max_flooring
-from ..utils.flooring import choose_flooring_fn, device_flooring, require_device_floor
+from ..utils.flooring import choose_flooring_fn, device_flooring, host_floor, require_device_floor
 from ..utils.select_pair import resolve_pairs, sequential_pair_selector
 from ._device_state import DeviceStateMixin, Synced
 from .base import IterativeMethodBase
@@ -159,9 +159,9 @@ class FastMNMFBase(MNMFBase):
         N = M if self.n_sources is None else self.n_sources
         self.n_sources, self.n_channels = N, M
         self.n_bins, self.n_frames = F, T
-        self._floor = device_flooring(flooring_fn, what="FastMNMF")
-        # (every MNMF step floors inside one fused call: the three built-in floors only)
-        require_device_floor(self._floor, "FastMNMF")
+        # (an arbitrary callable: the steps run one by one with the floor off, the callable on the
+        #  small arrays on the host in between -- round 5, see _update_host_floor)
+        self._floor = device_flooring(flooring_fn, allow_host=True, what="FastMNMF")
         self._init_nmf(flooring_fn=flooring_fn, rng=self.rng)
         self._init_diagonalizer(rng=self.rng)
         self._init_spatial(flooring_fn=flooring_fn, rng=self.rng)
@@ -197,14 +197,62 @@ class FastMNMFBase(MNMFBase):
     def _resolve_floor(self, flooring_fn):
         if type(flooring_fn) is str and flooring_fn == "self":
             return self._floor
-        return device_flooring(choose_flooring_fn(flooring_fn, method=self), what="FastMNMF")
+        return device_flooring(choose_flooring_fn(flooring_fn, method=self), allow_host=True,
+                               what="FastMNMF")
+
+    def _update_host_floor(self, steps, floor) -> None:
+        """The steps of `steps` one by one for a flooring callable the kernels do not know: each pass
+        over X runs with the floor off and the callable is applied on the host to the small array the
+        reference applies it to -- basis (N, F, K) and activation (N, K, T) after their updates
+        (mnmf.py:1358, 1415), the IP1 denominators (F,) per channel (_update_spatial_model.py:63-76),
+        the normalisation scales psi (M,) (mnmf.py:673)."""
+        for flag, name in ((_lib.MNMF_BASIS, "basis"), (_lib.MNMF_ACTIVATION, "activation")):
+            if steps & flag:
+                self._update(flag, identity)
+                dev = self._state_dev(name)
+                dev.copy_(dv.to_device(_ops._apply_host(floor.host, dev), dev=dev.device))
+                self._state_touch(name)
+        if steps & _lib.MNMF_DIAGONALIZER:
+            U = self._diagonalizer_covariance()
+            _ops.update_by_ip1(self._state_dev("diagonalizer"), U, floor, self._info_tensor())
+            self._state_touch("diagonalizer")
+        if steps & _lib.MNMF_SPATIAL:
+            self._update(_lib.MNMF_SPATIAL, identity)
+        if steps & _lib.MNMF_NORMALIZE:
+            # psi_m^2 = mean_ij |q_im^H x_ij|^2 = mean_i q_im^H C_i q_im with the static covariance C:
+            # (F, M, M) arrays on the host, psi floored by the callable, Q rows / psi, D / psi^2
+            Q, D = self._state_dev("diagonalizer"), self._state_dev("spatial")
+            Qh, Dh, Ch = dv.to_host(Q), dv.to_host(D), dv.to_host(self._C())
+            for b in range(Qh.shape[0]):
+                qx2 = np.real(np.einsum("fma,fab,fmb->fm", Qh[b], Ch[b], Qh[b].conj())).mean(axis=0)
+                psi = np.asarray(floor.host(np.sqrt(np.maximum(qx2, 0.0))), dtype=np.float64)
+                Qh[b] /= psi[None, :, None]
+                Dh[b] /= psi ** 2
+            Q.copy_(dv.to_device(Qh, dev=Q.device))
+            D.copy_(dv.to_device(Dh, dev=D.device))
+            self._state_touch("diagonalizer")
+            self._state_touch("spatial")
+
+    def _diagonalizer_covariance(self):
+        """U_m = mean_j x x^H / R~_m (B, F, M, M, M): the weights of the diagonaliser updates."""
+        if self.n_sources <= 4 and self.n_channels <= 4 and self.n_sources >= 2:
+            return _ops.fastmnmf_diagonalizer_covariance(
+                self._X, self._state_dev("spatial"), self._state_dev("basis"),
+                self._state_dev("activation"))
+        weights = _ops.fastmnmf_weights(
+            self._X, self._state_dev("diagonalizer"), self._state_dev("spatial"),
+            self._state_dev("basis"), self._state_dev("activation"))
+        return _ops.weighted_covariance(self._X, weights, _lib.WEIGHT_BIN_FRAME, self.n_channels)
 
     def _update(self, steps, flooring_fn="self") -> None:
+        floor = self._resolve_floor(flooring_fn)
+        if host_floor(floor) is not None:
+            return self._update_host_floor(steps, floor)
         need_c = bool(steps & _lib.MNMF_NORMALIZE)
         args = (
             self._X, self._C() if need_c else None, self._state_dev("diagonalizer"),
             self._state_dev("spatial"), self._state_dev("basis"), self._state_dev("activation"),
-            steps, self._resolve_floor(flooring_fn), self._ws, self._ws_bytes, self._info_tensor(),
+            steps, floor, self._ws, self._ws_bytes, self._info_tensor(),
         )
         handover = getattr(self, "_handover", None)
         if handover is None:
@@ -274,7 +322,7 @@ class FastGaussMNMF(FastMNMFBase):
                 self.pair_selector = sequential_pair_selector
         else:
             self.pair_selector = pair_selector
-        device_flooring(self.flooring_fn, what="FastMNMF")
+        device_flooring(self.flooring_fn, allow_host=True, what="FastMNMF")
 
     def __repr__(self) -> str:
         s = "FastGaussMNMF(n_basis={}".format(self.n_basis)
@@ -287,24 +335,24 @@ class FastGaussMNMF(FastMNMFBase):
         )
         return s
 
+    def _wiener(self, X):
+        args = (X, self._state_dev("diagonalizer"), self._state_dev("spatial"),
+                self._state_dev("basis"), self._state_dev("activation"), self.reference_id)
+        if host_floor(self._floor) is not None:
+            return _ops.fastmnmf_separate_host_floor(*args, self._floor.host, self._ws,
+                                                     self._ws_bytes, self._info_tensor())
+        return _ops.fastmnmf_separate(*args, self._floor, self._ws, self._ws_bytes,
+                                      self._info_tensor())
+
     def _separate_dev(self) -> None:
-        Y = _ops.fastmnmf_separate(
-            self._X, self._state_dev("diagonalizer"), self._state_dev("spatial"),
-            self._state_dev("basis"), self._state_dev("activation"), self.reference_id,
-            self._floor, self._ws, self._ws_bytes, self._info_tensor(),
-        )
-        self._state_set_dev("output", Y)
+        self._state_set_dev("output", self._wiener(self._X))
 
     def separate(self, input: np.ndarray) -> np.ndarray:
         """Multichannel Wiener filter with the current parameters (ref: mnmf.py:1174-1217)."""
         batched = input.ndim == 4
         self._check_separate_input(input)
         X = dv.to_device(input if batched else input[None], dtype=np.complex128)
-        Y = _ops.fastmnmf_separate(
-            X, self._state_dev("diagonalizer"), self._state_dev("spatial"),
-            self._state_dev("basis"), self._state_dev("activation"), self.reference_id,
-            self._floor, self._ws, self._ws_bytes, self._info_tensor(),
-        )
+        Y = self._wiener(X)
         self._check_device_errors()
         out = dv.to_host(Y)
         return out if batched else out[0]

@@ -303,7 +303,11 @@ __global__ __launch_bounds__(64) void k_qinv(const c128 *__restrict__ Q, c128 *Q
 // channels no longer spill 530-2400 registers per lane on the path every call takes) and flags the
 // bins that have a point where the floor may act; REPAIR == true is the old kernel restricted to the
 // flagged bins (both forms per point, as before).
-template <int M, bool REPAIR>
+// EIG (an arbitrary flooring callable, evaluated on the host -- round 5): 1 = every point takes the
+// literal route up to its eigen-decomposition and leaves the eigenvalues (ascending, as numpy.linalg.
+// eigh hands them to the callable: lam_io (B, F, T, M)) and eigenvectors (P_io (B, F, T, M, M)) in HBM;
+// 2 = the same walk from the floored eigenvalues and the stored eigenvectors to Y.
+template <int M, bool REPAIR, int EIG = 0>
 __global__ __launch_bounds__(128) void k_separate(const c128 *__restrict__ X,
                                                   const c128 *__restrict__ Q,
                                                   const c128 *__restrict__ Qinv,
@@ -311,9 +315,10 @@ __global__ __launch_bounds__(128) void k_separate(const c128 *__restrict__ X,
                                                   const double *__restrict__ basis,
                                                   const double *__restrict__ act, c128 *Y, int N,
                                                   int F, int T, int K, int ref, int floor_kind,
-                                                  double eps, int *redo) {
+                                                  double eps, int *redo, double *lam_io = nullptr,
+                                                  c128 *P_io = nullptr) {
   const int i = blockIdx.x, b = blockIdx.y;
-  if (REPAIR && !redo[(long long)b * F + i]) return;
+  if (REPAIR && EIG == 0 && !redo[(long long)b * F + i]) return;
   __shared__ c128 qt[M * M];
   __shared__ c128 qsrc[M * M];
   __shared__ double dd[NMAX * M];
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(128) void k_separate(const c128 *__restrict__ X,
 #pragma unroll
     for (int m = 0; m < M; ++m) x[m] = X[(((long long)b * M + m) * F + i) * T + j];
     c128 sm[M];  // s_m = (Q~^H R^-1 x)_m, then scaled by q~[ref][m]
-    const bool closed = floor_kind != SSSPY_FLOOR_ADD && rcmin > eps * qf2 * 1.0000001;
+    const bool closed = EIG == 0 && floor_kind != SSSPY_FLOOR_ADD && rcmin > eps * qf2 * 1.0000001;
     if (!REPAIR && !closed) {
       redo[(long long)b * F + i] = 1;  // (every writer stores the same value)
       continue;
@@ -385,7 +390,34 @@ __global__ __launch_bounds__(128) void k_separate(const c128 *__restrict__ X,
           A[a][c2] = s;
           A[c2][a] = cconj(s);
         }
-      jacobi_eigh<M>(A, P);
+      double evs[M];
+      const long long point = ((long long)b * F + i) * T + j;
+      if constexpr (EIG == 2) {
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+          evs[k] = lam_io[point * M + k];
+#pragma unroll
+          for (int a = 0; a < M; ++a) P[a][k] = P_io[(point * M + a) * M + k];
+        }
+      } else {
+        jacobi_eigh<M>(A, P);
+#pragma unroll
+        for (int k = 0; k < M; ++k) evs[k] = apply_floor(A[k][k].x, floor_kind, eps);
+      }
+      if constexpr (EIG == 1) {
+        // ascending order without dynamic indexing (rank of every eigenvalue, ties by index)
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+          int rank = 0;
+#pragma unroll
+          for (int l = 0; l < M; ++l)
+            rank += (A[l][l].x < A[k][k].x || (A[l][l].x == A[k][k].x && l < k)) ? 1 : 0;
+          lam_io[point * M + rank] = A[k][k].x;
+#pragma unroll
+          for (int a = 0; a < M; ++a) P_io[(point * M + a) * M + rank] = P[a][k];
+        }
+        continue;
+      }
 #pragma unroll
       for (int a = 0; a < M; ++a) z[a] = cmake(0.0, 0.0);
 #pragma unroll
@@ -397,7 +429,7 @@ __global__ __launch_bounds__(128) void k_separate(const c128 *__restrict__ X,
           proj.x += pk.x * x[a].x + pk.y * x[a].y;
           proj.y += pk.x * x[a].y - pk.y * x[a].x;
         }
-        const double ev = apply_floor(A[k][k].x, floor_kind, eps);
+        const double ev = evs[k];
         proj = cmake(proj.x / ev, proj.y / ev);
 #pragma unroll
         for (int a = 0; a < M; ++a) cfma(z[a], P[a][k], proj);
@@ -560,6 +592,32 @@ int fmnmf_generic_separate(const void *X, const void *Q, void *Qinv, const doubl
                        ref, floor_kind, eps, redo);
   });
   return check_launch("fmnmf_generic separate");
+}
+
+// The Wiener filter split at the eigenvalue floor of to_psd (an arbitrary flooring callable):
+// stage 1 leaves ascending eigenvalues lam (B,F,T,M) and eigenvectors P (B,F,T,M,M); the host floors
+// lam; stage 2 finishes.  Any N, M <= 8.
+int fmnmf_generic_separate_eig(const void *X, const void *Q, void *Qinv, const double *D,
+                               const double *basis, const double *act, void *Y, int B, int N,
+                               int M, int F, int T, int K, int ref, int stage, double *lam,
+                               void *P, int *info, hipStream_t st) {
+  using namespace fmg;
+  if (N < 1 || N > NMAX) return fail(SSSPY_ERR_UNSUPPORTED, "FastMNMF: n_sources must be in [1, 8]");
+  const long long nbins = (long long)B * F;
+  FMG_DISPATCH_M(M, {
+    if (stage == 1) {
+      hipLaunchKernelGGL((k_qinv<MM>), dim3((unsigned)((nbins + 63) / 64)), dim3(64), 0, st,
+                         (const c128 *)Q, (c128 *)Qinv, nbins, info);
+      hipLaunchKernelGGL((k_separate<MM, true, 1>), dim3(F, B), dim3(128), 0, st, (const c128 *)X,
+                         (const c128 *)Q, (const c128 *)Qinv, D, basis, act, (c128 *)Y, N, F, T, K,
+                         ref, SSSPY_FLOOR_NONE, 0.0, (int *)nullptr, lam, (c128 *)P);
+    } else {
+      hipLaunchKernelGGL((k_separate<MM, true, 2>), dim3(F, B), dim3(128), 0, st, (const c128 *)X,
+                         (const c128 *)Q, (const c128 *)Qinv, D, basis, act, (c128 *)Y, N, F, T, K,
+                         ref, SSSPY_FLOOR_NONE, 0.0, (int *)nullptr, lam, (c128 *)P);
+    }
+  });
+  return check_launch("fmnmf_generic separate (eigen stages)");
 }
 
 }  // namespace ssspy

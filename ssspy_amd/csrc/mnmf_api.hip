@@ -65,6 +65,10 @@ int fmnmf_generic_separate(const void *X, const void *Q, void *Qinv, const doubl
                            const double *basis, const double *act, void *Y, int B, int N, int M,
                            int F, int T, int K, int ref, int floor_kind, double eps, int *info,
                            int *redo, hipStream_t st);
+int fmnmf_generic_separate_eig(const void *X, const void *Q, void *Qinv, const double *D,
+                               const double *basis, const double *act, void *Y, int B, int N,
+                               int M, int F, int T, int K, int ref, int stage, double *lam,
+                               void *P, int *info, hipStream_t st);
 
 // the MFMA-tile kernels (mnmf_kernels.hip) are compiled for 2..4 sources and channels
 static inline bool mnmf_tiled(int N, int M) { return N >= 2 && N <= 4 && M >= 2 && M <= 4; }
@@ -403,6 +407,22 @@ int ssspy_fastmnmf_separate(const void *X, const void *Q, const double *D, const
   // (the per-bin row powers' scratch is idle here: B F ints of it flag the bins for the general kernel)
   MNMF_DISPATCH(N, mnmf_separate, X, Q, Qinv, D, basis, activation, Y, B, M, F, T, K, reference_id,
                 floor_kind, floor_eps, info, (int *)((char *)workspace + w.qbuf), as_stream(stream));
+}
+
+int ssspy_fastmnmf_separate_eig(const void *X, const void *Q, const double *D, const double *basis,
+                                const double *activation, void *Y, int B, int N, int M, int F,
+                                int T, int K, int reference_id, int stage, double *lam, void *P,
+                                void *workspace, size_t workspace_bytes, int *info, void *stream) {
+  SSSPY_REQUIRE(X && Q && D && basis && activation && lam && P && B > 0,
+                "fastmnmf_separate_eig: bad argument");
+  SSSPY_REQUIRE((stage == 1 || stage == 2) && (stage == 1 || Y), "fastmnmf_separate_eig: bad stage");
+  SSSPY_REQUIRE(reference_id >= 0 && reference_id < M, "fastmnmf_separate_eig: bad reference_id");
+  const MnmfWs w = mnmf_ws(B, N, M, F, T, K);
+  SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "fastmnmf_separate_eig: workspace too small");
+  // (stage 1 leaves Q^-1 in the workspace; stage 2 reads it: the same workspace, untouched between)
+  return fmnmf_generic_separate_eig(X, Q, (char *)workspace + w.qinv, D, basis, activation, Y, B, N,
+                                    M, F, T, K, reference_id, stage, lam, P, info,
+                                    as_stream(stream));
 }
 
 }  // extern "C"

@@ -2156,7 +2156,7 @@ def _golden_custom_floor(x):
                                   "customfloor_gilrma_part_ip1_n3", "customfloor_gilrma_part_iss1_n2",
                                   "customfloor_auxlap_ip2_n3", "customfloor_auxlap_iss2_n3",
                                   "customfloor_auxgauss_ip1_n3", "customfloor_auxgauss_iss1_n2",
-                                  "customfloor_auxgauss_ip2_n3"])
+                                  "customfloor_auxgauss_ip2_n3", "customfloor_fmnmf_m3"])
 def test_arbitrary_flooring_callable_against_golden(case):
     """``flooring_fn`` may be any callable in the reference (ssspy/bss/ilrma.py:70-89).  One that is
     none of the three built-in floors is evaluated on the host on the small arrays it acts on (basis,
@@ -2213,8 +2213,43 @@ def test_arbitrary_flooring_callable_unsupported_paths_fail_loudly():
     with pytest.raises(NotImplementedError, match="heavy-tailed"):
         TILRMA(n_basis=2, dof=4.0, spatial_algorithm="IP2",
                flooring_fn=_golden_custom_floor)(X, n_iter=1)
-    with pytest.raises(NotImplementedError, match="FastMNMF"):
-        FastGaussMNMF(n_basis=2, flooring_fn=_golden_custom_floor)(X, n_iter=1)
+    from ssspy_amd.bss.mnmf import GaussMNMF
+
+    with pytest.raises(NotImplementedError, match="GaussMNMF"):
+        GaussMNMF(n_basis=2, flooring_fn=_golden_custom_floor)(X, n_iter=1)
+    assert FastGaussMNMF is not None  # (FastGaussMNMF takes any callable since round 5: see below)
+
+
+@pytest.mark.parametrize("algo,N,M,B", [("IP", 3, 3, 1), ("IP", 4, 4, 3), ("IP2", 3, 4, 2), ("IP", 2, 6, 1)])
+def test_fast_gauss_mnmf_host_evaluated_floor_equals_the_kernel_floor(algo, N, M, B):
+    """Round 5: FastGaussMNMF with a flooring callable the kernels do not recognise -- the steps run
+    one by one with the floor off, the callable on basis / activation / IP denominators / psi on the
+    host, and the Wiener filter is split at its eigenvalue floor (stage 1: eigen-decomposition of
+    every R_ij to HBM; the callable on the (F, T, M) eigenvalues; stage 2).  With max(x, eps) as the
+    callable the result must equal the recognised max_flooring inside the kernels, with an eps large
+    enough for the Wiener floor to act (1e-2) and on the point-wise path above 4 channels."""
+    import functools
+
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+    from ssspy_amd.special.flooring import max_flooring
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    F, T, K = 33, 48, 3
+    X = np.stack([nmf_mixture(700 + b, M, F, T) for b in range(B)])
+    if B == 1:
+        X = X[0]
+    for eps in (1e-10, 1e-2):
+        def make(floor):
+            return FastGaussMNMF(n_basis=K, n_sources=N, diagonalizer_algorithm=algo,
+                                 flooring_fn=floor, rng=np.random.default_rng(5))
+
+        dev = make(functools.partial(max_flooring, eps=eps))
+        host = make(lambda x, e=eps: np.maximum(x, e))
+        Yd, Yh = dev(X, n_iter=4), host(X, n_iter=4)
+        assert rel_err(Yh, Yd) < 1e-8
+        np.testing.assert_allclose(np.asarray(host.loss), np.asarray(dev.loss), rtol=1e-9)
+        assert rel_err(host.basis, dev.basis) < 1e-9
+        assert rel_err(host.spatial, dev.spatial) < 1e-9
 
 
 # ------------------------------------------------------------------------------- non-finite inputs
