@@ -492,9 +492,21 @@ class _MMILRMA(ILRMABase):
     # -- ISS2 / IPA with the power normalisation folded into the update matrix (round 5) -------
     def _folded_output_normalization(self, floor) -> bool:
         cls = type(self)
-        return (self.spatial_algorithm in _ISS2 + _IPA and bool(self.normalization)
+        algos = _ISS2 + _IPA
+        # ISS1 on the per-bin statistics with the folded normalisation against the register-resident
+        # sweep + weight pass + scale pass: faster up to 4 sources (the tuned covariance pass), see
+        # DESIGN 4 item 40.  SSSPY_AMD_ISS1_STATISTICS=0 / 1 forces either.
+        iss1 = _os.environ.get("SSSPY_AMD_ISS1_STATISTICS")
+        # (a handful of mixtures: the one fused sweep launch wins, 112 against 125 us for one
+        #  mixture of configs[1]; 32 mixtures 1.80 -> 1.29 ms, 128: 6.82 -> 4.65 ms)
+        if (iss1 != "0" and self._base_model[0] == _lib.SOURCE_GAUSS
+                and (iss1 == "1" or (self._X.shape[1] <= 4
+                                     and self._X.shape[0] * self._X.shape[2] >= 4096))):
+            algos = algos + _ISS1
+        return (self.spatial_algorithm in algos and bool(self.normalization)
                 and self._power_normalization_or_off() and not self.partitioning
                 and not self._uses_filter() and host_floor(floor) is None and self._is_stock()
+                and cls.update_spatial_model_iss1 is _MMILRMA.update_spatial_model_iss1
                 and cls.update_spatial_model_iss2 is _MMILRMA.update_spatial_model_iss2
                 and cls.update_spatial_model_ipa is _MMILRMA.update_spatial_model_ipa
                 and not _os.environ.get("SSSPY_AMD_NO_FOLDED_NORM"))
@@ -527,7 +539,9 @@ class _MMILRMA(ILRMABase):
             varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y,
                                            model=self._model, flooring=floor)
             Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
-        if self.spatial_algorithm in _ISS2:
+        if self.spatial_algorithm in _ISS1:
+            G = _ops.iss1_transform(Vc, floor)
+        elif self.spatial_algorithm in _ISS2:
             G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N),
                                     floor, self._info_tensor())
         else:

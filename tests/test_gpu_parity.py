@@ -181,7 +181,7 @@ def test_ipa_chained_sweep_equals_per_source_passes(N, monkeypatch):
 
 
 @pytest.mark.parametrize("algo,N,B", [("ISS2", 4, 1), ("IPA", 3, 1), ("ISS2", 5, 3), ("IPA", 4, 2),
-                                       ("ISS2", 10, 1)])
+                                       ("ISS2", 10, 1), ("ISS1", 4, 1), ("ISS1", 3, 3), ("ISS1", 2, 1)])
 def test_ilrma_folded_power_normalization_equals_three_pass_form(algo, N, B, monkeypatch):
     """Round 5: ISS2 / IPA iterations of GaussILRMA with the power normalisation folded into the
     update matrix (psi from g^H C g, C <- G C G^H, tracked log-determinant) against the literal
@@ -205,6 +205,8 @@ def test_ilrma_folded_power_normalization_equals_three_pass_form(algo, N, B, mon
             Y = m(X, n_iter=12, **{k: v.copy() for k, v in kw.items()})
         return m, Y
 
+    if algo == "ISS1":  # (small shapes keep the fused sweep by default)
+        monkeypatch.setenv("SSSPY_AMD_ISS1_STATISTICS", "1")
     m1, Y1 = run()
     assert getattr(m1, "_ycov", None) is not None
     monkeypatch.setenv("SSSPY_AMD_NO_FOLDED_NORM", "1")
