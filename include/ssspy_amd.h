@@ -515,10 +515,13 @@ int ssspy_fastmnmf_loss_data_handover(const double *D, const double *basis,
 
 /* U[b,i,m] = (1/T) sum_j x x^H / R~_ijm  -> (B,F,M,M,M): the covariances the diagonaliser update
  * (IP1 inside ssspy_fastmnmf_update, or ssspy_update_by_ip2 for diagonalizer_algorithm="IP2") needs.
+ * workspace: NULL, or ssspy_fastmnmf_workspace_bytes() of scratch -- with it the tuned pass of the
+ * fused update runs (its split work items park partial sums there).
  * replaces: ssspy/bss/mnmf.py:1504-1512, :1621-1629. */
 int ssspy_fastmnmf_diagonalizer_covariance(const void *X, const double *D, const double *basis,
                                            const double *activation, void *U, int B, int N, int M,
-                                           int F, int T, int K, void *stream);
+                                           int F, int T, int K, void *workspace,
+                                           size_t workspace_bytes, void *stream);
 
 /* weights[b,m,i,j] = 1 / R~_ijm, R~ = sum_n lambda_nij d_inm (B,M,F,T): the per-channel weights of the
  * diagonaliser covariance, U = ssspy_weighted_covariance(X, weights, SSSPY_WEIGHT_BIN_FRAME, S = M).

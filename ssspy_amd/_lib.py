@@ -119,7 +119,8 @@ PROTOTYPES = {
     "ssspy_fastmnmf_loss_data_handover": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z,
                                                _p]),
     "ssspy_fastmnmf_loss_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
-    "ssspy_fastmnmf_diagonalizer_covariance": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "ssspy_fastmnmf_diagonalizer_covariance": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p,
+                                                    _z, _p]),
     "ssspy_fastmnmf_loss_data": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "ssspy_fastmnmf_weights": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ssspy_fastmnmf_separate": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p,

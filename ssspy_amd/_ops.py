@@ -670,14 +670,16 @@ def fastmnmf_update_handover(X, C, Q, D, basis, activation, steps, flooring, ws,
     return bool(flag.value)
 
 
-def fastmnmf_diagonalizer_covariance(X, D, basis, activation, out=None):
+def fastmnmf_diagonalizer_covariance(X, D, basis, activation, out=None, ws=None, ws_bytes=0):
+    """ws (the separator's fastmnmf_workspace): the tuned covariance pass instead of the generic one."""
     B, M, F, T = X.shape
     N, K = basis.shape[1], basis.shape[-1]
     if out is None:
         out = dv.empty((B, F, M, M, M), dv.c128, X.device)
     _lib.check(
         _L().ssspy_fastmnmf_diagonalizer_covariance(ptr(X), ptr(D), ptr(basis), ptr(activation),
-                                                    ptr(out), B, N, M, F, T, K, _st()),
+                                                    ptr(out), B, N, M, F, T, K, ptr(ws),
+                                                    int(ws_bytes), _st()),
         "fastmnmf_diagonalizer_covariance",
     )
     return out

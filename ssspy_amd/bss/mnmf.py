@@ -238,7 +238,7 @@ class FastMNMFBase(MNMFBase):
         if self.n_sources <= 4 and self.n_channels <= 4 and self.n_sources >= 2:
             return _ops.fastmnmf_diagonalizer_covariance(
                 self._X, self._state_dev("spatial"), self._state_dev("basis"),
-                self._state_dev("activation"))
+                self._state_dev("activation"), ws=self._ws, ws_bytes=self._ws_bytes)
         weights = _ops.fastmnmf_weights(
             self._X, self._state_dev("diagonalizer"), self._state_dev("spatial"),
             self._state_dev("basis"), self._state_dev("activation"))
@@ -455,15 +455,7 @@ class FastGaussMNMF(FastMNMFBase):
 
     def update_diagonalizer_ip2(self, flooring_fn="self") -> None:
         """Pairwise iterative projection on Q.  ref: ssspy/bss/mnmf.py:1516-1633."""
-        if self.n_sources <= 4 and self.n_channels <= 4 and self.n_sources >= 2:
-            U = _ops.fastmnmf_diagonalizer_covariance(
-                self._X, self._state_dev("spatial"), self._state_dev("basis"),
-                self._state_dev("activation"))
-        else:  # general shapes: per-channel weights, then the generic weighted covariance
-            weights = _ops.fastmnmf_weights(
-                self._X, self._state_dev("diagonalizer"), self._state_dev("spatial"),
-                self._state_dev("basis"), self._state_dev("activation"))
-            U = _ops.weighted_covariance(self._X, weights, _lib.WEIGHT_BIN_FRAME, self.n_channels)
+        U = self._diagonalizer_covariance()
         _ops.update_by_ip2(self._state_dev("diagonalizer"), U,
                            resolve_pairs(getattr(self, "pair_selector", None), self.n_channels),
                            self._resolve_floor(flooring_fn), self._info_tensor())
