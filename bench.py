@@ -409,14 +409,18 @@ def pairwise_ipa_legs(args, dev, Xbatch_host):
     legs = [
         ("ilrma_ip1", ilrma("IP1"), 3, "basis, activation, covariance passes over X"),
         ("ilrma_ip2", ilrma("IP2"), 3, "basis, activation, covariance passes over X"),
-        ("ilrma_iss1", ilrma("ISS1"), 4, "basis, activation passes over Y; fused sweep: read + write Y"),
+        ("ilrma_iss1", ilrma("ISS1"), lambda nb: 4 if nb * F < 4096 else 5,
+         "one mixture: basis, activation passes over Y, fused sweep read + write Y (4); batches: "
+         "basis, activation, covariance passes over Y, Y <- G Y read + write (5)"),
         ("ilrma_iss2", ilrma("ISS2"), 5, "basis, activation, covariance passes over Y; Y <- G Y read + write"),
         ("ilrma_ipa", ilrma("IPA"), 5, "basis, activation, covariance passes over Y; Y <- G Y read + write"),
         ("auxiva_ip2", iva("IP2"), 2 * N, "per pair (N of them: (0,1), (1,2), ... , (N-1,0)) a frame-power and "
                                           "a covariance pass over X: the weights are recomputed from the "
                                           "current filters before every pair (ssspy/bss/iva.py:1795-1915)"),
-        ("auxiva_iss2", iva("ISS2"), 4, "frame powers, covariance passes over Y; Y <- G Y read + write"),
-        ("auxiva_ipa", iva("IPA"), 4, "frame powers, covariance passes over Y; Y <- G Y read + write"),
+        ("auxiva_iss2", iva("ISS2"), 3, "covariance pass over Y; Y <- G Y read + write (the frame powers "
+                                        "of the next weights are a by-product of that walk)"),
+        ("auxiva_ipa", iva("IPA"), 3, "covariance pass over Y; Y <- G Y read + write (the frame powers "
+                                      "of the next weights are a by-product of that walk)"),
         ("fmnmf_ip2", fmnmf("IP2"), 4, "basis, activation, covariance, spatial passes (as IP1)"),
     ]
     out = {"shape": "N=M={} F={} T={}; ILRMA n_basis=16, FastGaussMNMF n_basis=8".format(N, F, T),
@@ -434,11 +438,12 @@ def pairwise_ipa_legs(args, dev, Xbatch_host):
                     m.update_once()
                 dt = time_loop(m.update_once, iters)
                 m._check_device_errors()
-                ent = out.setdefault(key, {"passes_of_A": passes, "passes": what})
+                np_ = passes(nb) if callable(passes) else passes
+                ent = out.setdefault(key, {"passes": what})
                 ent["b{}".format(nb)] = {
                     "ms_per_step": round(1e3 * dt, 4), "iterations_per_s": round(nb / dt, 1),
-                    "achieved_GBs": round(passes * A * nb / dt / 1e9, 1),
-                    "frac": round(passes * A * nb / dt / 1e9 / HBM_PEAK_GBS, 4)}
+                    "passes_of_A": np_, "achieved_GBs": round(np_ * A * nb / dt / 1e9, 1),
+                    "frac": round(np_ * A * nb / dt / 1e9 / HBM_PEAK_GBS, 4)}
                 del m
             except Exception as exc:  # an extra leg must never cost the headline line
                 out.setdefault(key, {})["b{}".format(nb)] = {

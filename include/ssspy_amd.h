@@ -450,6 +450,14 @@ size_t ssspy_iva_frame_power_workspace_bytes(int B, int N, int F, int T);
 int ssspy_iva_frame_power(const void *X, const void *W, double *r2, int B, int N, int F, int T,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/* Y = W X (Y may be X: in place) AND r2[b,n,j] = sum_i |y_nij|^2 of the result in one walk (round 5):
+ * the separate() that ends an AuxIVA ISS2 / IPA step and the frame-power pass of the next iteration's
+ * weights (ssspy/bss/iva.py:1968-2066 followed by :1917-1935).  Workspace as ssspy_iva_frame_power.
+ * n_sources <= 8. */
+int ssspy_separate_frame_power(const void *X, const void *W, void *Y, double *r2, int B, int N,
+                               int F, int T, void *workspace, size_t workspace_bytes,
+                               void *stream);
+
 /* weight[b,n,j] = G'(r)/floor(2 r), r = sqrt(r2); Gauss also refreshes variance = r2 / F.
  * replaces: ssspy/bss/iva.py:1788-1789, :1963-1964, :3105-3115, :3273-3289, :3465-3473. */
 int ssspy_iva_weight(const double *r2, double *weight, double *variance, int B, int N, int F, int T,

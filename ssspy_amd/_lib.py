@@ -93,6 +93,7 @@ PROTOTYPES = {
                                              _z, _p]),
     "ssspy_iva_frame_power_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "ssspy_iva_frame_power": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "ssspy_separate_frame_power": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
     "ssspy_iva_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _d, _p]),
     "ssspy_iva_loss_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ssspy_gmnmf_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),

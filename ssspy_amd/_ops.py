@@ -286,7 +286,7 @@ def ipa_sweep(Vc, normalization, max_iter, flooring, info=None, out=None, newton
 
 
 def update_by_ipa(Y, weight, kind, normalization, max_iter, flooring, info=None, not_converged=None,
-                  Vc=None):
+                  Vc=None, frame_power=False):
     """One IPA sweep in place on the device spectrogram Y (B, N, F, T).  The weights are fixed over
     the sweep (ref: _update_spatial_model.py:436-445), so the covariances the reference recomputes
     from the updated spectrogram before every source step are G V G^H of the previous ones: one
@@ -303,13 +303,17 @@ def update_by_ipa(Y, weight, kind, normalization, max_iter, flooring, info=None,
             G = ipa_transform(Vc, s, normalization, max_iter, flooring, info, out=G,
                               newton_ws=newton_ws, not_converged=not_converged)
             separate(Y, G, out=Y)
-        return Y
+        return None if frame_power else Y
     if Vc is None:
         Vc = weighted_covariance(Y, weight, kind, N)
     G = ipa_sweep(Vc, normalization, max_iter, flooring, info, newton_ws=newton_ws,
                   not_converged=not_converged)
+    if frame_power:  # (AuxIVA: the next iteration's weights want sum_i |y|^2 of the new Y)
+        r2 = separate_frame_power(Y, G)
+        if r2 is not None:
+            return r2
     separate(Y, G, out=Y)
-    return Y
+    return None if frame_power else Y
 
 
 def iss1_fused_max_frames(n_sources):
@@ -603,6 +607,20 @@ def iva_frame_power(X, W, out=None):
     _lib.check(_L().ssspy_iva_frame_power(ptr(X), ptr(W), ptr(out), B, N, F, T, ptr(ws), ws_bytes,
                                           _st()), "iva_frame_power")
     return out
+
+
+def separate_frame_power(Y, G, r2=None):
+    """Y <- G Y in place and the frame powers sum_i |y|^2 (B, N, T) of the result in one walk; None
+    when the shape has no such kernel (more than 8 sources: the caller makes the two passes)."""
+    B, N, F, T = Y.shape
+    if N > _lib.MAX_SOURCES:
+        return None
+    if r2 is None:
+        r2 = dv.empty((B, N, T), dv.f64, Y.device)
+    ws, ws_bytes = _scratch(_L().ssspy_iva_frame_power_workspace_bytes(B, N, F, T), Y.device)
+    _lib.check(_L().ssspy_separate_frame_power(ptr(Y), ptr(G), ptr(Y), ptr(r2), B, N, F, T, ptr(ws),
+                                               ws_bytes, _st()), "separate_frame_power")
+    return r2
 
 
 def iva_weight(r2, n_bins, contrast, flooring, weight=None, variance=None):

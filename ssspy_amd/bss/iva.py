@@ -420,10 +420,12 @@ class AuxIVA(AuxIVABase):
         require_device_floor(self._resolve_floor(flooring_fn), "IPA")
         Y = self._state_dev("output")
         weight = self._weights(flooring_fn)
-        _ops.update_by_ipa(Y, weight, _lib.WEIGHT_FRAME, self.lqpqm_normalization,
-                           self.newton_iter, self._resolve_floor(flooring_fn), self._info_tensor(),
-                           not_converged=self._newton_counter())
+        r2 = _ops.update_by_ipa(Y, weight, _lib.WEIGHT_FRAME, self.lqpqm_normalization,
+                                self.newton_iter, self._resolve_floor(flooring_fn),
+                                self._info_tensor(), not_converged=self._newton_counter(),
+                                frame_power=True)
         self._state_touch("output")
+        self._r2_cache = None if r2 is None else (r2, self._state_rev("output"))
 
     def _pair_weight_contrast(self):
         """Contrast code for the per-pair weights of IP2 (the Gauss model keeps its variance)."""
@@ -459,8 +461,7 @@ class AuxIVA(AuxIVABase):
         Vc = _ops.weighted_covariance(Y, weight, _lib.WEIGHT_FRAME, N)
         G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N), floor,
                                 self._info_tensor())
-        _ops.separate(Y, G, out=Y)
-        self._state_touch("output")
+        self._separate_output(Y, G)
 
     def update_once_ip1(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/iva.py:1736-1793."""
@@ -492,8 +493,16 @@ class AuxIVA(AuxIVABase):
         else:
             Vc = _ops.weighted_covariance(Y, weight, _lib.WEIGHT_FRAME, N)
             G = _ops.iss1_transform(Vc, floor)
+            self._separate_output(Y, G)
+
+    def _separate_output(self, Y, G) -> None:
+        """Y <- G Y in place; the walk also leaves sum_i |y|^2 of the new Y, which the next
+        iteration's weights would otherwise fetch with a pass of their own (round 5)."""
+        r2 = _ops.separate_frame_power(Y, G)
+        if r2 is None:
             _ops.separate(Y, G, out=Y)
-            self._state_touch("output")
+        self._state_touch("output")
+        self._r2_cache = None if r2 is None else (r2, self._state_rev("output"))
 
     def _tracked_logdet(self):
         """The tracked sum_i log|det W_i| if it describes the current output, else None."""

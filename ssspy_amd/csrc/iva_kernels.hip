@@ -12,9 +12,12 @@ namespace ssspy {
 // part[chunk][b][n][j] and k_fold_slabs (common.hpp) adds them in chunk order -- no fp64 atomics: the
 // weights of the next iteration, hence the whole trajectory, are the same on every run.
 template <int N>
-__global__ __launch_bounds__(256) void k_iva_frame_power(const c128 *__restrict__ X,
+__global__ __launch_bounds__(256) void k_iva_frame_power(const c128 *X,
                                                          const c128 *__restrict__ W, double *r2,
-                                                         int F, int T, int bins_per_chunk) {
+                                                         int F, int T, int bins_per_chunk,
+                                                         c128 *Yout = nullptr) {
+  // Yout (round 5, needs W; may be X itself): y = W x is also stored -- the separate() that precedes
+  // the next iteration's weights and their frame-power pass in one walk (ssspy_separate_frame_power)
   __shared__ double fold[4][N][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + lane;
@@ -41,6 +44,7 @@ __global__ __launch_bounds__(256) void k_iva_frame_power(const c128 *__restrict_
 #pragma unroll
         for (int m = 0; m < N; ++m) cfma(y, Wi[n * N + m], x[m]);
         acc[n] += cabs2(y);
+        if (Yout && j < T) Yout[(((long long)b * N + n) * F + i) * T + j] = y;
       }
     } else {
 #pragma unroll
@@ -66,10 +70,11 @@ __global__ __launch_bounds__(256) void k_iva_frame_power(const c128 *__restrict_
 // AuxIVA-IP iteration against the 64-frame form above, which wins below ~64 mixtures).
 // grid: (ceil(T/256), bin chunks, B)
 template <int N>
-__global__ __launch_bounds__(256) void k_iva_frame_power_wide(const c128 *__restrict__ X,
+__global__ __launch_bounds__(256) void k_iva_frame_power_wide(const c128 *X,
                                                               const c128 *__restrict__ W,
                                                               double *r2, int F, int T,
-                                                              int bins_per_chunk) {
+                                                              int bins_per_chunk,
+                                                              c128 *Yout = nullptr) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.z;
   const int i_begin = blockIdx.y * bins_per_chunk;
@@ -90,6 +95,7 @@ __global__ __launch_bounds__(256) void k_iva_frame_power_wide(const c128 *__rest
 #pragma unroll
         for (int m = 0; m < N; ++m) cfma(y, Wi[n * N + m], x[m]);
         acc[n] += cabs2(y);
+        if (Yout) Yout[(((long long)b * N + n) * F + i) * T + j] = y;
       }
     } else {
 #pragma unroll
@@ -175,8 +181,26 @@ size_t ssspy_iva_frame_power_workspace_bytes(int B, int N, int F, int T) {
   return (size_t)p.chunks * total * sizeof(double) + fold_scratch_bytes(total, p.chunks);
 }
 
+static int frame_power_impl(const void *X, const void *W, double *r2, void *Yout, int B, int N,
+                            int F, int T, void *workspace, size_t workspace_bytes, void *stream);
+
 int ssspy_iva_frame_power(const void *X, const void *W, double *r2, int B, int N, int F, int T,
                           void *workspace, size_t workspace_bytes, void *stream) {
+  return frame_power_impl(X, W, r2, nullptr, B, N, F, T, workspace, workspace_bytes, stream);
+}
+
+int ssspy_separate_frame_power(const void *X, const void *W, void *Y, double *r2, int B, int N,
+                               int F, int T, void *workspace, size_t workspace_bytes,
+                               void *stream) {
+  SSSPY_REQUIRE(W && Y, "separate_frame_power: bad argument");
+  if (rt_sources_ok(N))
+    return fail(SSSPY_ERR_UNSUPPORTED, "separate_frame_power: up to 8 sources (use ssspy_separate + "
+                                       "ssspy_iva_frame_power)");
+  return frame_power_impl(X, W, r2, Y, B, N, F, T, workspace, workspace_bytes, stream);
+}
+
+static int frame_power_impl(const void *X, const void *W, double *r2, void *Yout, int B, int N,
+                            int F, int T, void *workspace, size_t workspace_bytes, void *stream) {
   SSSPY_REQUIRE(X && r2 && B > 0 && F > 0 && T > 0, "iva_frame_power: bad argument");
   hipStream_t st = as_stream(stream);
   const FramePowerPlan p = frame_power_plan(B, F, T);
@@ -196,10 +220,11 @@ int ssspy_iva_frame_power(const void *X, const void *W, double *r2, int B, int N
   if (p.frames_per_block == 256) {
     DISPATCH_N(N, hipLaunchKernelGGL((k_iva_frame_power_wide<NN>), grid, block, 0, st,
                                      (const c128 *)X, (const c128 *)W, dst, F, T,
-                                     p.bins_per_chunk));
+                                     p.bins_per_chunk, (c128 *)Yout));
   } else {
     DISPATCH_N(N, hipLaunchKernelGGL((k_iva_frame_power<NN>), grid, block, 0, st, (const c128 *)X,
-                                     (const c128 *)W, dst, F, T, p.bins_per_chunk));
+                                     (const c128 *)W, dst, F, T, p.bins_per_chunk,
+                                     (c128 *)Yout));
   }
   int rc = check_launch("k_iva_frame_power");
   if (rc || p.chunks == 1) return rc;
