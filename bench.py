@@ -409,11 +409,16 @@ def pairwise_ipa_legs(args, dev, Xbatch_host):
     legs = [
         ("ilrma_ip1", ilrma("IP1"), 3, "basis, activation, covariance passes over X"),
         ("ilrma_ip2", ilrma("IP2"), 3, "basis, activation, covariance passes over X"),
-        ("ilrma_iss1", ilrma("ISS1"), lambda nb: 4 if nb * F < 4096 else 5,
+        ("ilrma_iss1", ilrma("ISS1"), lambda nb: 4 if nb * F < 4096 else 3,
          "one mixture: basis, activation passes over Y, fused sweep read + write Y (4); batches: "
-         "basis, activation, covariance passes over Y, Y <- G Y read + write (5)"),
-        ("ilrma_iss2", ilrma("ISS2"), 5, "basis, activation, covariance passes over Y; Y <- G Y read + write"),
-        ("ilrma_ipa", ilrma("IPA"), 5, "basis, activation, covariance passes over Y; Y <- G Y read + write"),
+         "basis, activation, covariance passes over X read through the filters the updates imply, "
+         "W <- G W per bin, Y formed when `output` is read (3)"),
+        ("ilrma_iss2", ilrma("ISS2"), 3, "basis, activation, covariance passes over X read through the "
+                                         "filters the updates imply (W <- G W per bin; Y formed when "
+                                         "`output` is read)"),
+        ("ilrma_ipa", ilrma("IPA"), 3, "basis, activation, covariance passes over X read through the "
+                                       "filters the updates imply (W <- G W per bin; Y formed when "
+                                       "`output` is read)"),
         ("auxiva_ip2", iva("IP2"), 2 * N, "per pair (N of them: (0,1), (1,2), ... , (N-1,0)) a frame-power and "
                                           "a covariance pass over X: the weights are recomputed from the "
                                           "current filters before every pair (ssspy/bss/iva.py:1795-1915)"),

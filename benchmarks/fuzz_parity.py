@@ -4,6 +4,9 @@ fixed cases live in tests/).  Shapes are drawn to cross tile edges (16 / 32 / 64
 frames), the split / unsplit work-item boundary and every option of the ILRMA / AuxIVA classes.
 
     python benchmarks/fuzz_parity.py [n_cases] [seed]
+
+FUZZ_KINDS / FUZZ_ALGOS (comma lists) and FUZZ_MAX_SOURCES narrow the draw, FUZZ_ITER sets the number
+of ILRMA iterations (default 3).
 """
 import os
 import sys
@@ -38,10 +41,15 @@ def main():
         K = int(rng.choice([1, 2, 3, 4, 7, 8, 15, 16, 17, 24, 32, 33, 48, 64, 70]))  # 17..32 / 33..64: the two- / four-k-tile variants
         B = int(rng.choice([1, 1, 1, 2, 5, 40]))
         algo = str(rng.choice(["IP", "ISS", "IP2", "ISS2", "IPA"]))
+        if os.environ.get("FUZZ_ALGOS"):
+            algo = str(rng.choice(os.environ["FUZZ_ALGOS"].split(",")))
+        N = min(N, int(os.environ.get("FUZZ_MAX_SOURCES", "8")))
         if T < 2 * N:
             T = 2 * N + 3
         kind = str(rng.choice(["gauss", "gauss", "t", "ggd", "gauss_p1", "iva_lap", "iva_gauss",
                                "fmnmf", "gmnmf", "part"]))
+        if os.environ.get("FUZZ_KINDS"):
+            kind = str(rng.choice(os.environ["FUZZ_KINDS"].split(",")))
         if algo == "IPA" and kind in ("t", "ggd"):
             algo = "ISS2"  # (the reference raises for IPA with the heavy-tailed models)
         if kind == "fmnmf" and rng.random() < 0.3:
@@ -129,13 +137,16 @@ def main():
                 m = GGDILRMA(beta=model[1], **kw)
             else:
                 m = GaussILRMA(**kw)
-            Y = m(X, n_iter=3, basis=basis, activation=act)
+            n_iter = int(os.environ.get("FUZZ_ITER", "3"))
+            Y = m(X, n_iter=n_iter, basis=basis, activation=act)
             for b in {0, B - 1}:
                 ref = GaussILRMAOracle(model=model, **kw)
-                Yr = ref.run(X[b], n_iter=3, basis=basis[b], activation=act[b])
+                Yr = ref.run(X[b], n_iter=n_iter, basis=basis[b], activation=act[b])
                 e = rel(Y[b], Yr)
                 eb = rel(m.basis[b], ref.basis)
                 el = np.max(np.abs(np.asarray(m.loss)[:, b] / np.asarray(ref.loss) - 1))
+                if os.environ.get("FUZZ_VERBOSE"):
+                    print("case", tag, src, bool(norm), b, "%.2e %.2e %.2e" % (e, eb, el))
                 if not (e < tol and eb < tol and el < 1e-7):
                     bad += 1
                     print("MISMATCH", tag, src, bool(norm), b, e, eb, el)

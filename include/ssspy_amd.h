@@ -93,6 +93,18 @@ int ssspy_separate(const void *X, const void *W, void *Y, int B, int N, int F, i
 int ssspy_covariance_congruence(const void *C, const void *G, void *Cout, int B, int F, int N,
                                 void *stream);
 
+/* The same with S matrices per bin sharing its G: C, Cout (B,F,S,N,N), G (B,F,N,N).  The statistics
+ * of the separated spectrogram from those of the mixture, mean phi y y^H = W (mean phi x x^H) W^H:
+ * the ISS / ISS2 / IPA iterations of ILRMA then read the mixture through the filters they imply
+ * (ssspy_compose_filters) like the IP iterations do, and y <- G y (ssspy/bss/ilrma.py:1635-1908)
+ * is carried out once, when the output is read. */
+int ssspy_covariance_congruence_sets(const void *C, const void *G, void *Cout, int B, int F, int S,
+                                     int N, void *stream);
+
+/* out (B,F,N,N) = G W per bin (out aliases neither): the filters implied by y <- G y with y = W x. */
+int ssspy_compose_filters(const void *G, const void *W, void *out, int B, int F, int N,
+                          void *stream);
+
 /* U[b,i,s,a,c] = (1/T) sum_j weight[...] A[b,a,i,j] conj(A[b,c,i,j]), s < S.
  * A (B,N,F,T) complex, U (B,F,S,N,N) complex, weight per `weight_kind`.
  * replaces: the (F,N,N,N,T) broadcast + mean of ssspy/bss/ilrma.py:1500-1505,

@@ -42,6 +42,8 @@ PROTOTYPES = {
     "ssspy_update_by_ip2": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
     "ssspy_ipa_transform": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p]),
     "ssspy_covariance_congruence": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "ssspy_covariance_congruence_sets": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "ssspy_compose_filters": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "ssspy_ipa_sweep": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p]),
     "ssspy_iss2_transform": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
     "ssspy_update_by_ip2_deferred": (_i, [_p, _p, _i, _p, _i, _i, _i, _p, _p, _p]),

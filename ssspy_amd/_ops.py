@@ -93,10 +93,20 @@ def weighted_covariance(A, weight=None, kind=_lib.WEIGHT_UNIT, n_sets=1, out=Non
 
 
 def covariance_congruence(C, G, out):
-    """out = G C G^H per bin, (B, F, N, N)."""
+    """out = G C G^H per bin: C, out (B, F, N, N) or (B, F, S, N, N) with the S matrices of a bin
+    sharing its G (B, F, N, N)."""
     B, F, N = C.shape[0], C.shape[1], C.shape[-1]
-    _lib.check(_L().ssspy_covariance_congruence(ptr(C), ptr(G), ptr(out), B, F, N, _st()),
+    S = C.shape[2] if C.dim() == 5 else 1
+    _lib.check(_L().ssspy_covariance_congruence_sets(ptr(C), ptr(G), ptr(out), B, F, S, N, _st()),
                "covariance_congruence")
+    return out
+
+
+def compose_filters(G, W, out):
+    """out = G W per bin, (B, F, N, N)."""
+    B, F, N = W.shape[0], W.shape[1], W.shape[-1]
+    _lib.check(_L().ssspy_compose_filters(ptr(G), ptr(W), ptr(out), B, F, N, _st()),
+               "compose_filters")
     return out
 
 

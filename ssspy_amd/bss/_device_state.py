@@ -150,6 +150,7 @@ class DeviceStateMixin:
         ent = st[name]
         if ent["none"]:
             return None
+        self._state_settle(ent)
         if ent["host"] is None:
             self._check_device_errors()
             host = dv.to_host(ent["dev"])
@@ -195,6 +196,23 @@ class DeviceStateMixin:
         ent = self._state()[name]
         ent["host"] = ent["host_rw"] = None
         ent["rev"] = self._next_rev()
+        ent.pop("lazy", None)  # (whoever rewrote it read it through _state_dev, or replaced all of it)
+
+    def _state_defer(self, name, fill):
+        """The value changed but the device buffer was not rewritten: ``fill()`` brings it up to date
+        and runs before the next read (host view or kernel operand), if there is one.  ILRMA's ISS /
+        IPA iterations keep the filters their updates imply and read the mixture through them, so
+        ``output`` is only formed when somebody looks at it."""
+        ent = self._state()[name]
+        ent["host"] = ent["host_rw"] = None
+        ent["rev"] = self._next_rev()
+        ent["lazy"] = fill
+
+    @staticmethod
+    def _state_settle(ent):
+        fill = ent.pop("lazy", None)
+        if fill is not None:
+            fill()
 
     def _next_rev(self):
         self.__dict__["_state_serial"] = self.__dict__.get("_state_serial", 0) + 1
@@ -215,6 +233,7 @@ class DeviceStateMixin:
         ent = self._state()[name]
         if ent["none"]:
             return None
+        self._state_settle(ent)
         if ent["dev"] is None:
             host = np.asarray(ent["host"])
             if not self._batched:

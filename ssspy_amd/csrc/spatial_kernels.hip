@@ -73,12 +73,13 @@ __global__ __launch_bounds__(256) void k_separate(const c128 *__restrict__ X,
 __global__ __launch_bounds__(256) void k_covariance_congruence(const c128 *__restrict__ C,
                                                                const c128 *__restrict__ G,
                                                                c128 *__restrict__ Cout,
-                                                               long long nbins, int N) {
+                                                               long long nbins, int sets, int N) {
+  // C, Cout: (nbins, sets, N, N); G: (nbins, N, N), shared by the sets of its bin
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nbins * N * N) return;
-  const long long bin = e / (N * N);
-  const int rc = (int)(e - bin * (N * N)), r = rc / N, c = rc - r * N;
-  const c128 *Cb = C + bin * (long long)(N * N), *Gb = G + bin * (long long)(N * N);
+  if (e >= nbins * sets * N * N) return;
+  const long long mat = e / (N * N);
+  const int rc = (int)(e - mat * (N * N)), r = rc / N, c = rc - r * N;
+  const c128 *Cb = C + mat * (long long)(N * N), *Gb = G + (mat / sets) * (long long)(N * N);
   c128 acc = cmake(0.0, 0.0);
   for (int k = 0; k < N; ++k) {
     c128 t = cmake(0.0, 0.0);  // (C G^H)[k][c]
@@ -86,6 +87,21 @@ __global__ __launch_bounds__(256) void k_covariance_congruence(const c128 *__res
     cfma(acc, Gb[r * N + k], t);
   }
   Cout[e] = acc;
+}
+
+// out_i = G_i W_i per bin (the demixing filters an output-side update y <- G y implies)
+__global__ __launch_bounds__(256) void k_compose_filters(const c128 *__restrict__ G,
+                                                         const c128 *__restrict__ W,
+                                                         c128 *__restrict__ out, long long nbins,
+                                                         int N) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nbins * N * N) return;
+  const long long bin = e / (N * N);
+  const int rc = (int)(e - bin * (N * N)), r = rc / N, c = rc - r * N;
+  const c128 *Gb = G + bin * (long long)(N * N), *Wb = W + bin * (long long)(N * N);
+  c128 acc = cmake(0.0, 0.0);
+  for (int k = 0; k < N; ++k) cfma(acc, Gb[r * N + k], Wb[k * N + c]);
+  out[e] = acc;
 }
 
 // ------------------------------------------------------------------------- weighted covariance
@@ -705,14 +721,31 @@ int ssspy_separate(const void *X, const void *W, void *Y, int B, int N, int F, i
   return check_launch("k_separate");
 }
 
+int ssspy_covariance_congruence_sets(const void *C, const void *G, void *Cout, int B, int F,
+                                     int S, int N, void *stream) {
+  SSSPY_REQUIRE(C && G && Cout && C != Cout && B > 0 && F > 0 && S >= 1 && N >= 1 &&
+                    N <= SSSPY_RT_MAX_SOURCES,
+                "covariance_congruence: bad argument");
+  const long long nbins = (long long)B * F, total = nbins * S * N * N;
+  hipLaunchKernelGGL(k_covariance_congruence, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), (const c128 *)C, (const c128 *)G, (c128 *)Cout, nbins, S, N);
+  return check_launch("k_covariance_congruence");
+}
+
 int ssspy_covariance_congruence(const void *C, const void *G, void *Cout, int B, int F, int N,
                                 void *stream) {
-  SSSPY_REQUIRE(C && G && Cout && C != Cout && B > 0 && F > 0 && N >= 1 && N <= SSSPY_RT_MAX_SOURCES,
-                "covariance_congruence: bad argument");
+  return ssspy_covariance_congruence_sets(C, G, Cout, B, F, 1, N, stream);
+}
+
+int ssspy_compose_filters(const void *G, const void *W, void *out, int B, int F, int N,
+                          void *stream) {
+  SSSPY_REQUIRE(G && W && out && out != G && out != W && B > 0 && F > 0 && N >= 1 &&
+                    N <= SSSPY_RT_MAX_SOURCES,
+                "compose_filters: bad argument");
   const long long nbins = (long long)B * F, total = nbins * N * N;
-  hipLaunchKernelGGL(k_covariance_congruence, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     as_stream(stream), (const c128 *)C, (const c128 *)G, (c128 *)Cout, nbins, N);
-  return check_launch("k_covariance_congruence");
+  hipLaunchKernelGGL(k_compose_filters, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), (const c128 *)G, (const c128 *)W, (c128 *)out, nbins, N);
+  return check_launch("k_compose_filters");
 }
 
 int ssspy_weighted_covariance(const void *A, const double *weight, int weight_kind, void *U, int B,

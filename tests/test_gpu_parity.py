@@ -183,15 +183,16 @@ def test_ipa_chained_sweep_equals_per_source_passes(N, monkeypatch):
 @pytest.mark.parametrize("algo,N,B", [("ISS2", 4, 1), ("IPA", 3, 1), ("ISS2", 5, 3), ("IPA", 4, 2),
                                        ("ISS2", 10, 1), ("ISS1", 4, 1), ("ISS1", 3, 3), ("ISS1", 2, 1)])
 def test_ilrma_folded_power_normalization_equals_three_pass_form(algo, N, B, monkeypatch):
-    """Round 5: ISS2 / IPA iterations of GaussILRMA with the power normalisation folded into the
-    update matrix (psi from g^H C g, C <- G C G^H, tracked log-determinant) against the literal
-    update -> mean |y|^2 -> y / psi passes (SSSPY_AMD_NO_FOLDED_NORM), 12 iterations, with the loss
-    recorded, and against the oracle."""
+    """Round 5: ISS / ISS2 / IPA iterations of GaussILRMA (i) reading the mixture through the filters
+    their updates imply, Y formed on demand (the default), (ii) on Y with the power normalisation
+    folded into the update matrix (psi from g^H C g, C <- G C G^H, tracked log-determinant;
+    SSSPY_AMD_NO_IMPLIED_FILTER) against (iii) the literal update -> mean |y|^2 -> y / psi passes
+    (SSSPY_AMD_NO_FOLDED_NORM), 12 iterations, with the loss recorded, and against the oracle."""
     from oracle.ilrma import GaussILRMAOracle
     from ssspy_amd.bss.ilrma import GaussILRMA
     from ssspy_amd.utils.dataset import nmf_mixture
 
-    F, T, K = 19, 48, 3
+    F, T, K = 19, 64, 3
     X = np.stack([nmf_mixture(900 + b, N, F, T) for b in range(B)])
     rng = np.random.default_rng(8)
     kw = dict(basis=rng.random((B, N, F, K)), activation=rng.random((B, N, K, T)))
@@ -207,25 +208,85 @@ def test_ilrma_folded_power_normalization_equals_three_pass_form(algo, N, B, mon
 
     if algo == "ISS1":  # (small shapes keep the fused sweep by default)
         monkeypatch.setenv("SSSPY_AMD_ISS1_STATISTICS", "1")
+    m0, Y0 = run()
+    assert (m0._implied_filter() is not None and getattr(m0, "_ycov", None) is None) or N > 4
+    monkeypatch.setenv("SSSPY_AMD_NO_IMPLIED_FILTER", "1")
     m1, Y1 = run()
     assert getattr(m1, "_ycov", None) is not None
     monkeypatch.setenv("SSSPY_AMD_NO_FOLDED_NORM", "1")
     m2, Y2 = run()
     monkeypatch.delenv("SSSPY_AMD_NO_FOLDED_NORM")
+    monkeypatch.delenv("SSSPY_AMD_NO_IMPLIED_FILTER")
     assert getattr(m2, "_ycov", None) is None
     err = rel_err  # (after projection back: no pairwise phase ambiguity left)
-    assert err(Y1, Y2) < 1e-9
-    np.testing.assert_allclose(m1.loss, m2.loss, rtol=1e-9)
-    assert rel_err(m1.basis, m2.basis) < 1e-9
+    for m, Y in ((m0, Y0), (m1, Y1)):
+        assert err(Y, Y2) < 1e-9
+        np.testing.assert_allclose(m.loss, m2.loss, rtol=1e-9)
+        assert rel_err(m.basis, m2.basis) < 1e-9
+        assert rel_err(m.activation, m2.activation) < 1e-9
     if N <= 8:
         ref = GaussILRMAOracle(n_basis=K, spatial_algorithm=algo)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             Yr = ref.run(X if B == 1 else X[0], n_iter=12,
                          **{k: (v if B == 1 else v[0]).copy() for k, v in kw.items()})
-        loss = np.asarray(m1.loss)
-        np.testing.assert_allclose(loss if B == 1 else loss[:, 0], ref.loss, rtol=LOSS_RTOL)
-        assert err(Y1 if B == 1 else Y1[0], Yr) < 1e-7
+        for m, Y in ((m0, Y0), (m1, Y1)):
+            loss = np.asarray(m.loss)
+            np.testing.assert_allclose(loss if B == 1 else loss[:, 0], ref.loss, rtol=LOSS_RTOL)
+            assert err(Y if B == 1 else Y[0], Yr) < 1e-7
+
+
+@pytest.mark.parametrize("model,algo", [(("gauss", None), "ISS1"), (("gauss", None), "IPA"),
+                                        (("gauss", None), "ISS2")])
+def test_ilrma_implied_filter_iterations_mixed_with_single_steps(model, algo, monkeypatch):
+    """The output state read through the implied filters stays coherent with everything that looks
+    at or rewrites ``output`` in between: a callback reading it every iteration, single steps
+    (update_spatial_model + normalize, which rewrite Y and retire the filters), projection back --
+    each against the same sequence with the implied
+    filters switched off (SSSPY_AMD_NO_IMPLIED_FILTER)."""
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    cls, extra = _ilrma_class(model), {}
+    N, F, T, K = 3, 17, 50, 2
+    X = nmf_mixture(77, N, F, T)
+    rng = np.random.default_rng(5)
+    kw = dict(basis=rng.random((N, F, K)), activation=rng.random((N, K, T)))
+
+    if algo == "ISS1":  # (small shapes keep the fused sweep by default)
+        monkeypatch.setenv("SSSPY_AMD_ISS1_STATISTICS", "1")
+
+    def run():
+        seen = []
+        m = cls(n_basis=K, spatial_algorithm=algo, record_loss=True,
+                callbacks=lambda mm: seen.append(np.array(mm.output)), **extra)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m(X, n_iter=3, **{k: v.copy() for k, v in kw.items()})
+            lazy_between = m._implied_filter() is not None
+            m.update_once()
+            m.update_source_model()
+            m.update_spatial_model()      # rewrites Y: the filters are retired
+            m.normalize()
+            m.update_once()
+            loss_mid = m.compute_loss()
+            for _ in range(3):
+                m.update_once()
+            m.restore_scale()
+            Y = np.array(m.output)
+        return m, Y, seen, loss_mid, lazy_between
+
+    m0, Y0, seen0, l0, lazy0 = run()
+    monkeypatch.setenv("SSSPY_AMD_NO_IMPLIED_FILTER", "1")
+    m1, Y1, seen1, l1, lazy1 = run()
+    monkeypatch.delenv("SSSPY_AMD_NO_IMPLIED_FILTER")
+    assert lazy0 and not lazy1
+    assert len(seen0) == len(seen1) > 0
+    for a, b in zip(seen0, seen1):
+        assert rel_err(a, b) < 1e-9
+    assert rel_err(Y0, Y1) < 1e-9
+    np.testing.assert_allclose(m0.loss, m1.loss, rtol=1e-9)
+    np.testing.assert_allclose(l0, l1, rtol=1e-9)
+    assert rel_err(m0.basis, m1.basis) < 1e-9
 
 
 def test_ipa_eight_sources_against_oracle():
