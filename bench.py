@@ -422,10 +422,12 @@ def pairwise_ipa_legs(args, dev, Xbatch_host):
         ("auxiva_ip2", iva("IP2"), 2 * N, "per pair (N of them: (0,1), (1,2), ... , (N-1,0)) a frame-power and "
                                           "a covariance pass over X: the weights are recomputed from the "
                                           "current filters before every pair (ssspy/bss/iva.py:1795-1915)"),
-        ("auxiva_iss2", iva("ISS2"), 3, "covariance pass over Y; Y <- G Y read + write (the frame powers "
-                                        "of the next weights are a by-product of that walk)"),
-        ("auxiva_ipa", iva("IPA"), 3, "covariance pass over Y; Y <- G Y read + write (the frame powers "
-                                      "of the next weights are a by-product of that walk)"),
+        ("auxiva_iss2", iva("ISS2"), 2, "frame-power and covariance passes over X read through the filters "
+                                        "the updates imply (W <- G W per bin; Y formed when `output` is "
+                                        "read)"),
+        ("auxiva_ipa", iva("IPA"), 2, "frame-power and covariance passes over X read through the filters "
+                                      "the updates imply (W <- G W per bin; Y formed when `output` is "
+                                      "read)"),
         ("fmnmf_ip2", fmnmf("IP2"), 4, "basis, activation, covariance, spatial passes (as IP1)"),
     ]
     out = {"shape": "N=M={} F={} T={}; ILRMA n_basis=16, FastGaussMNMF n_basis=8".format(N, F, T),

@@ -14,6 +14,7 @@ The gradient / natural-gradient / Fast / PDS / ADMM IVA variants are out of scop
 """
 
 import functools
+import os as _os
 from typing import Callable, Iterable, List, Optional, Tuple, Union
 
 import numpy as np
@@ -92,6 +93,18 @@ class IVABase(DeviceStateMixin, IterativeMethodBase):
     def _uses_filter(self) -> bool:
         return not self._state_is_none("demix_filter")
 
+    def _implied_filter(self):
+        """W with output = W x while nothing else rewrote ``output`` since, else None (the ISS2 / IPA
+        iterations of AuxIVA keep it, see AuxIVA._update_once_implied)."""
+        kept = getattr(self, "_implied", None)
+        if (kept is None or kept[1] != self._state_rev("output")
+                or _os.environ.get("SSSPY_AMD_NO_IMPLIED_FILTER")):
+            return None
+        return kept[0]
+
+    def _fill_output_from_implied_filter(self) -> None:
+        _ops.separate(self._X, self._implied[0], out=self._state()["output"]["dev"])
+
     def _resolve_floor(self, flooring_fn):
         if type(flooring_fn) is str and flooring_fn == "self":
             return self._floor
@@ -124,6 +137,12 @@ class IVABase(DeviceStateMixin, IterativeMethodBase):
             _ops.projection_back_filter(W, self.reference_id, info)
             self._state_touch("demix_filter")
             self._state_set_dev("output", _ops.separate(self._X, W))
+        elif self._implied_filter() is not None and self.reference_id is not None:
+            # the same scales from the filters the output state implies: one pass instead of four
+            W = self._implied_filter().clone()
+            _ops.projection_back_filter(W, self.reference_id, info)
+            self._state_set_dev("output", _ops.separate(self._X, W))
+            self._implied = (W, self._state_rev("output"))
         else:
             Y = self._state_dev("output")
             XY = _ops.cross_covariance(self._X, Y)
@@ -323,6 +342,14 @@ class AuxIVA(AuxIVABase):
         """ref: ssspy/bss/iva.py:1687-1697."""
         super()._reset(**kwargs)
         self._logdet_cache = None
+        self._implied = None
+        B, N, F, T = self._X.shape
+        if self.spatial_algorithm in _ISS2 + _IPA and N <= 4 and T >= 16 * N:
+            # the filters the output state implies (output = W x): the ISS2 / IPA iterations read the
+            # mixture through them (_update_once_implied).  Up to 4 sources (the tuned covariance
+            # pass) and at least 16 frames per source (W U W^H rounds like eps |W|^2 |U|, the direct
+            # sum over Y like eps |y|^2: next to singular covariances lose digits, see ilrma.py)
+            self._implied = (self._state_dev("demix_filter").clone(), self._state_rev("output"))
         if self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"] and not self.record_loss:
             self.demix_filter = None  # (nothing reads the log-determinant: no tracker)
         elif self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"]:
@@ -396,7 +423,12 @@ class AuxIVA(AuxIVABase):
             return _ops.iva_frame_power(self._X, self._state_dev("demix_filter"))
         cache = self._r2_cache
         if cache is None or cache[1] != self._state_rev("output"):
-            cache = (_ops.iva_frame_power(self._state_dev("output"), None), self._state_rev("output"))
+            W = self._implied_filter()
+            if W is not None:
+                r2 = _ops.iva_frame_power(self._X, W)
+            else:
+                r2 = _ops.iva_frame_power(self._state_dev("output"), None)
+            cache = (r2, self._state_rev("output"))
             self._r2_cache = cache
         return cache[0]
 
@@ -418,6 +450,8 @@ class AuxIVA(AuxIVABase):
     def update_once_ipa(self, flooring_fn="self") -> None:
         """Iterative projection with adjustment.  ref: ssspy/bss/iva.py:2068-2175."""
         require_device_floor(self._resolve_floor(flooring_fn), "IPA")
+        if self._update_once_implied(flooring_fn):
+            return
         Y = self._state_dev("output")
         weight = self._weights(flooring_fn)
         r2 = _ops.update_by_ipa(Y, weight, _lib.WEIGHT_FRAME, self.lqpqm_normalization,
@@ -455,6 +489,8 @@ class AuxIVA(AuxIVABase):
     def update_once_iss2(self, flooring_fn="self") -> None:
         """Pairwise iterative source steering.  ref: ssspy/bss/iva.py:1968-2066."""
         N = self.n_sources
+        if self._update_once_implied(flooring_fn):
+            return
         Y = self._state_dev("output")
         floor = self._resolve_floor(flooring_fn)
         weight = self._weights(flooring_fn)
@@ -462,6 +498,42 @@ class AuxIVA(AuxIVABase):
         G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N), floor,
                                 self._info_tensor())
         self._separate_output(Y, G)
+
+    def _update_once_implied(self, flooring_fn) -> bool:
+        """ISS2 / IPA iteration without touching Y (round 5).  The reference keeps only the separated
+        spectrogram and rewrites it (iva.py:1968-2175): weights from its frame powers, statistics
+        mean phi y y^H, Y <- G Y -- three spectrogram-sized transfers per iteration even with the
+        frame powers taken in the rewrite.  With output = W x the frame powers are |W x|^2 (the IP1
+        pass), the statistics W U W^H with the weighted covariances U of the MIXTURE, the update
+        W <- G W on (F, N, N): two read-only passes, Y formed when ``output`` is read
+        (_state_defer).  False: not applicable, the caller runs the literal form."""
+        W = self._implied_filter()
+        floor = self._resolve_floor(flooring_fn)
+        if W is None or host_floor(floor) is not None or self._contrast is None:
+            return False
+        B, N, F, T = self._X.shape
+        dev = self._X.device
+        weight = self._weights(flooring_fn)  # (frame powers through _frame_power(): |W x|^2)
+        U = _ops.weighted_covariance(self._X, weight, _lib.WEIGHT_FRAME, N)
+        Vc = getattr(self, "_Vc_implied", None)
+        if Vc is None or tuple(Vc.shape) != tuple(U.shape) or Vc.data_ptr() == U.data_ptr():
+            Vc = self._Vc_implied = dv.empty(tuple(U.shape), dv.c128, dev)
+        _ops.covariance_congruence(U, W, Vc)
+        if self.spatial_algorithm in _ISS2:
+            G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N),
+                                    floor, self._info_tensor())
+        else:
+            G = _ops.ipa_sweep(Vc, self.lqpqm_normalization, self.newton_iter, floor,
+                               self._info_tensor(), newton_ws=dv.empty((B,), dv.i64, dev),
+                               not_converged=self._newton_counter())
+        spare = getattr(self, "_implied_spare", None)
+        if spare is None or spare.shape != W.shape or spare.data_ptr() == W.data_ptr():
+            spare = dv.empty(tuple(W.shape), dv.c128, dev)
+        _ops.compose_filters(G, W, spare)
+        self._state_defer("output", self._fill_output_from_implied_filter)
+        self._implied, self._implied_spare = (spare, self._state_rev("output")), W
+        self._r2_cache = None
+        return True
 
     def update_once_ip1(self, flooring_fn="self") -> None:
         """ref: ssspy/bss/iva.py:1736-1793."""
@@ -515,6 +587,9 @@ class AuxIVA(AuxIVABase):
         """sum_i log|det W_i| (B,) on the device, and the filters if they had to be formed."""
         if self._uses_filter():
             W = self._state_dev("demix_filter")
+            return _ops.sum_logdet(W), W
+        W = self._implied_filter()
+        if W is not None:
             return _ops.sum_logdet(W), W
         tracked = self._tracked_logdet()
         if tracked is not None:

@@ -89,6 +89,44 @@ __global__ __launch_bounds__(256) void k_covariance_congruence(const c128 *__res
   Cout[e] = acc;
 }
 
+// The same with one lane per matrix and everything in registers (N <= 4: 16 + 16 loads per lane
+// instead of 24 per output element; 32 mixtures of configs[1]: 62 -> see DESIGN 4 item 44).
+template <int N>
+__global__ __launch_bounds__(256) void k_covariance_congruence_n(const c128 *__restrict__ C,
+                                                                 const c128 *__restrict__ G,
+                                                                 c128 *__restrict__ Cout,
+                                                                 long long nmats, int sets) {
+  const long long mat = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (mat >= nmats) return;
+  const c128 *Cb = C + mat * (N * N), *Gb = G + (mat / sets) * (N * N);
+  c128 g[N][N], c[N][N], t[N][N];
+#pragma unroll
+  for (int r = 0; r < N; ++r)
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      g[r][k] = Gb[r * N + k];
+      c[r][k] = Cb[r * N + k];
+    }
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+#pragma unroll
+    for (int cc = 0; cc < N; ++cc) {  // t = C G^H
+      c128 a = cmake(0.0, 0.0);
+#pragma unroll
+      for (int l = 0; l < N; ++l) cfma(a, c[k][l], cconj(g[cc][l]));
+      t[k][cc] = a;
+    }
+#pragma unroll
+  for (int r = 0; r < N; ++r)
+#pragma unroll
+    for (int cc = 0; cc < N; ++cc) {
+      c128 a = cmake(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < N; ++k) cfma(a, g[r][k], t[k][cc]);
+      Cout[mat * (N * N) + r * N + cc] = a;
+    }
+}
+
 // out_i = G_i W_i per bin (the demixing filters an output-side update y <- G y implies)
 __global__ __launch_bounds__(256) void k_compose_filters(const c128 *__restrict__ G,
                                                          const c128 *__restrict__ W,
@@ -727,6 +765,20 @@ int ssspy_covariance_congruence_sets(const void *C, const void *G, void *Cout, i
                     N <= SSSPY_RT_MAX_SOURCES,
                 "covariance_congruence: bad argument");
   const long long nbins = (long long)B * F, total = nbins * S * N * N;
+  if (N >= 2 && N <= 4) {
+    const long long nmats = nbins * S;
+    const dim3 grid((unsigned)((nmats + 255) / 256)), block(256);
+    if (N == 2)
+      hipLaunchKernelGGL((k_covariance_congruence_n<2>), grid, block, 0, as_stream(stream),
+                         (const c128 *)C, (const c128 *)G, (c128 *)Cout, nmats, S);
+    if (N == 3)
+      hipLaunchKernelGGL((k_covariance_congruence_n<3>), grid, block, 0, as_stream(stream),
+                         (const c128 *)C, (const c128 *)G, (c128 *)Cout, nmats, S);
+    if (N == 4)
+      hipLaunchKernelGGL((k_covariance_congruence_n<4>), grid, block, 0, as_stream(stream),
+                         (const c128 *)C, (const c128 *)G, (c128 *)Cout, nmats, S);
+    return check_launch("k_covariance_congruence_n");
+  }
   hipLaunchKernelGGL(k_covariance_congruence, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      as_stream(stream), (const c128 *)C, (const c128 *)G, (c128 *)Cout, nbins, S, N);
   return check_launch("k_covariance_congruence");

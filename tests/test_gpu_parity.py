@@ -289,6 +289,60 @@ def test_ilrma_implied_filter_iterations_mixed_with_single_steps(model, algo, mo
     assert rel_err(m0.basis, m1.basis) < 1e-9
 
 
+@pytest.mark.parametrize("contrast,algo,N,B", [("laplace", "ISS2", 4, 1), ("laplace", "IPA", 3, 2),
+                                               ("gauss", "ISS2", 3, 1), ("gauss", "IPA", 4, 3),
+                                               ("laplace", "ISS2", 2, 1)])
+def test_auxiva_implied_filter_iterations_equal_the_literal_form(contrast, algo, N, B, monkeypatch):
+    """Round 5: ISS2 / IPA iterations of AuxIVA reading the mixture through the filters their updates
+    imply (frame powers |W x|^2, statistics W U W^H, W <- G W; Y formed on read) against the literal
+    passes over Y (SSSPY_AMD_NO_IMPLIED_FILTER) and the oracle: outputs seen by a callback every
+    iteration, the loss list, the result after projection back; then single steps that rewrite Y."""
+    from oracle.iva import AuxIVAOracle
+    from ssspy_amd.bss.iva import AuxGaussIVA, AuxLaplaceIVA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    F, T = 21, 70
+    X = np.stack([nmf_mixture(300 + b, N, F, T) for b in range(B)])
+    if B == 1:
+        X = X[0]
+    cls = AuxLaplaceIVA if contrast == "laplace" else AuxGaussIVA
+
+    def run(with_callback):
+        seen = []
+        kw = {"callbacks": (lambda mm: seen.append(np.array(mm.output)))} if with_callback else {}
+        m = cls(spatial_algorithm=algo, **kw)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            Y = np.array(m(X, n_iter=6))
+            lazy = m._implied_filter() is not None
+            m.update_once()
+            loss_mid = m.compute_loss()
+            Ymid = np.array(m.output)
+        return m, Y, seen, lazy, loss_mid, Ymid
+
+    a = run(False)
+    b = run(True)
+    monkeypatch.setenv("SSSPY_AMD_NO_IMPLIED_FILTER", "1")
+    c = run(True)
+    monkeypatch.delenv("SSSPY_AMD_NO_IMPLIED_FILTER")
+    assert a[3] and b[3] and not c[3]
+    for r in (a, b):
+        assert rel_err(r[1], c[1]) < 1e-9
+        np.testing.assert_allclose(r[0].loss, c[0].loss, rtol=1e-9)
+        np.testing.assert_allclose(r[4], c[4], rtol=1e-9)
+        assert rel_err(r[5], c[5]) < 1e-9
+    assert len(b[2]) == len(c[2]) == 7
+    for u, v in zip(b[2], c[2]):
+        assert rel_err(u, v) < 1e-9
+    ref = AuxIVAOracle(spatial_algorithm=algo, contrast=contrast)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Yr = ref.run(X if B == 1 else X[0], n_iter=6)
+    loss = np.asarray(a[0].loss)
+    np.testing.assert_allclose(loss if B == 1 else loss[:, 0], ref.loss, rtol=LOSS_RTOL)
+    assert rel_err(a[1] if B == 1 else a[1][0], Yr) < 1e-7
+
+
 def test_ipa_eight_sources_against_oracle():
     from oracle.ipa import update_by_ipa as oracle_ipa
     from ssspy_amd.bss._update_spatial_model import update_by_ipa
