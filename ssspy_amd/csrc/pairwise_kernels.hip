@@ -396,6 +396,139 @@ __global__ __launch_bounds__(64) void k_iss2_transform(const c128 *__restrict__ 
   if (!ok && info) atomicAdd(info, 1);
 }
 
+// ---- ISS2 transform with a bin on GL lanes, lane s = source s = row s of G (round 5).  The lane
+// per bin above runs 513 waves at 32 x 1025 bins -- half a wave per SIMD, every wave a serial walk
+// over N sources per pair with N^2 uncoalesced loads each (88 us at 4 sources; 256 AGPRs + scratch
+// at 8).  Here source s's statistics stay in lane s's registers (N <= 4) or are re-read by it
+// (N > 4), the pair's rows and 2 x 2 blocks travel by lane shuffles, and every lane repeats the
+// 2 x 2 eigenproblem.  Same expressions in the same order as k_iss2_transform: identical results.
+template <int N, int GL, bool HOLD>
+__global__ __launch_bounds__(256) void k_iss2_transform_rows(const c128 *__restrict__ Vc, c128 *G,
+                                                             long long nbins, PairList pairs,
+                                                             int floor_kind, double eps, int *info,
+                                                             double *denom, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int s = lane & (GL - 1), base = lane & ~(GL - 1);
+  const long long idx =
+      ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64 / GL) + lane / GL;
+  const bool live = idx < nbins;
+  const long long bin = live ? idx : nbins - 1;
+  const int sr = s < N ? s : N - 1;  // (idle lanes of a 3-source group shadow the last source)
+  c128 gs[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+    gs[c] = accumulate ? G[bin * (N * N) + sr * N + c] : cmake(c == sr ? 1.0 : 0.0, 0.0);
+  const c128 *Vs = Vc + (bin * N + sr) * (long long)(N * N);
+  c128 Vh[HOLD ? N : 1][HOLD ? N : 1];
+  if (HOLD) {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+#pragma unroll
+      for (int d = 0; d < N; ++d) Vh[HOLD ? a : 0][HOLD ? d : 0] = Vs[a * N + d];
+  }
+  bool ok = true;
+#pragma unroll 1
+  for (int p = 0; p < pairs.count; ++p) {
+    const int p0 = pairs.first[p], p1 = pairs.second[p];
+    c128 g0[N], g1[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      g0[c] = cmake(__shfl(gs[c].x, base + p0), __shfl(gs[c].y, base + p0));
+      g1[c] = cmake(__shfl(gs[c].x, base + p1), __shfl(gs[c].y, base + p1));
+    }
+    c128 t0[N], t1[N], ts[N];
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+      c128 a0 = cmake(0.0, 0.0), a1 = a0, a2 = a0;
+#pragma unroll
+      for (int d = 0; d < N; ++d) {
+        const c128 u = HOLD ? Vh[HOLD ? a : 0][HOLD ? d : 0] : Vs[a * N + d];
+        a0 = cadd(a0, cmulc(u, g0[d]));
+        a1 = cadd(a1, cmulc(u, g1[d]));
+        a2 = cadd(a2, cmulc(u, gs[d]));
+      }
+      t0[a] = a0;
+      t1[a] = a1;
+      ts[a] = a2;
+    }
+    c128 C[2][2], Fv[2];
+    C[0][0] = C[0][1] = C[1][0] = C[1][1] = Fv[0] = Fv[1] = cmake(0.0, 0.0);
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+      cfma(C[0][0], g0[a], t0[a]);
+      cfma(C[0][1], g0[a], t1[a]);
+      cfma(C[1][0], g1[a], t0[a]);
+      cfma(C[1][1], g1[a], t1[a]);
+      cfma(Fv[0], g0[a], ts[a]);
+      cfma(Fv[1], g1[a], ts[a]);
+    }
+    c128 Gmain[2][2][2];  // [k][a][b]: block of source p_k on the pair, from its lane
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        Gmain[0][a][b] = cmake(__shfl(C[a][b].x, base + p0), __shfl(C[a][b].y, base + p0));
+        Gmain[1][a][b] = cmake(__shfl(C[a][b].x, base + p1), __shfl(C[a][b].y, base + p1));
+      }
+    double lamb[2];
+    c128 z[2][2];
+    ok = eigh2_type1(Gmain[0], Gmain[1], lamb, z) && ok;
+    c128 row[N];
+    if (s == p0 || s == p1) {
+      const int k = (s == p0) ? 0 : 1;
+      const c128 h[2] = {k == 0 ? z[0][0] : z[0][1], k == 0 ? z[1][0] : z[1][1]};
+      double q = (k == 0) ? quad2(h, Gmain[0]) : quad2(h, Gmain[1]);
+      q = q < 0.0 ? 0.0 : q;
+      const double dk = denom ? 1.0 : apply_floor(sqrt(q), floor_kind, eps);
+      if (denom && live) denom[idx * 2 + k] = sqrt(q);
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        c128 v = cmul(cconj(h[0]), g0[c]);
+        v = cadd(v, cmul(cconj(h[1]), g1[c]));
+        row[c] = cmake(v.x / dk, v.y / dk);
+      }
+    } else {
+      const c128 det = csub(cmul(C[0][0], C[1][1]), cmul(C[0][1], C[1][0]));
+      const c128 idet = crecip(det);
+      const c128 q0 = cmul(idet, csub(cmul(C[0][1], Fv[1]), cmul(C[1][1], Fv[0])));
+      const c128 q1 = cmul(idet, csub(cmul(C[1][0], Fv[0]), cmul(C[0][0], Fv[1])));
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        c128 v = gs[c];
+        v = cadd(v, cmul(cconj(q0), g0[c]));
+        v = cadd(v, cmul(cconj(q1), g1[c]));
+        row[c] = v;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c) gs[c] = row[c];
+  }
+  if (live && s < N) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) G[idx * (N * N) + s * N + c] = gs[c];
+    if (!ok && info && s == 0) atomicAdd(info, 1);
+  }
+}
+
+template <int N>
+static int launch_iss2_rows(const void *Vc, void *G, long long nbins, const PairList &pl,
+                            int floor_kind, double eps, int *info, double *denom, int accumulate,
+                            hipStream_t st) {
+  constexpr int GL = N <= 2 ? 2 : (N <= 4 ? 4 : 8);
+  constexpr bool HOLD = N <= 4;
+  const long long per_block = 4 * (64 / GL);
+  hipLaunchKernelGGL((k_iss2_transform_rows<N, GL, HOLD>),
+                     dim3((unsigned)((nbins + per_block - 1) / per_block)), dim3(256), 0, st,
+                     (const c128 *)Vc, (c128 *)G, nbins, pl, floor_kind, eps, info, denom,
+                     accumulate);
+  return check_launch("k_iss2_transform_rows");
+}
+
+static bool iss2_rows_enabled() {
+  const char *e = getenv("SSSPY_AMD_ISS2_ONE_LANE");  // (A/B switch: the lane-per-bin kernel)
+  return !(e && e[0] == '1');
+}
+
 // ---- the same two updates with the source count at run time (9 <= N <= SSSPY_RT_MAX_SOURCES):
 // loops instead of unrolled code, the bin's matrices in the lane's private memory (round 4; the
 // reference has no limit on n_sources).  Arithmetic as above.
@@ -659,6 +792,9 @@ int ssspy_iss2_transform(const void *Vc, void *G, const int *pairs, int n_pairs,
                        (c128 *)G, nbins, N, pl, floor_kind, floor_eps, info, (double *)nullptr, 0);
     return check_launch("k_iss2_transform_rt");
   }
+  if (N >= 2 && iss2_rows_enabled())
+    DISPATCH_N(N, return launch_iss2_rows<NN>(Vc, G, nbins, pl, floor_kind, floor_eps, info, nullptr,
+                                              0, as_stream(stream)));
   DISPATCH_N(N, hipLaunchKernelGGL((k_iss2_transform<NN>), grid, block, 0, as_stream(stream),
                                    (const c128 *)Vc, (c128 *)G, nbins, pl, floor_kind, floor_eps,
                                    info, (double *)nullptr, 0));
@@ -679,6 +815,9 @@ int ssspy_iss2_transform_deferred(const void *Vc, void *G, const int *pair, int 
                        accumulate ? 1 : 0);
     return check_launch("k_iss2_transform_rt (deferred)");
   }
+  if (N >= 2 && iss2_rows_enabled())
+    DISPATCH_N(N, return launch_iss2_rows<NN>(Vc, G, nbins, pl, SSSPY_FLOOR_NONE, 0.0, info, denom,
+                                              accumulate ? 1 : 0, as_stream(stream)));
   DISPATCH_N(N, hipLaunchKernelGGL((k_iss2_transform<NN>), grid, block, 0, as_stream(stream),
                                    (const c128 *)Vc, (c128 *)G, nbins, pl, SSSPY_FLOOR_NONE, 0.0,
                                    info, denom, accumulate ? 1 : 0));
