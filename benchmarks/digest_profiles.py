@@ -117,6 +117,20 @@ for path in sorted(glob.glob(os.path.join(src, "legs", "*_b32_kernel_stats.csv")
             if float(r.get("Percentage", 0) or 0) >= 0.05:
                 r["Name"] = r["Name"][:120]
                 w.writerow(r)
+for path in sorted(glob.glob(os.path.join(src, "legs", "*_n8_b16_kernel_stats.csv"))):
+    rows = [r for r in csv.DictReader(open(path))]
+    leg = os.path.basename(path)[: -len("_n8_b16_kernel_stats.csv")]
+    with open(os.path.join(dst, "{}_legs8_{}_b16_kernel_stats.csv".format(tag, leg)), "w") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        for r in rows:
+            if float(r.get("Percentage", 0) or 0) >= 0.05:
+                r["Name"] = r["Name"][:120]
+                w.writerow(r)
+path = os.path.join(src, "legs_ms.txt")
+if os.path.exists(path) and os.path.getsize(path):
+    open(os.path.join(dst, "{}_legs_ms.txt".format(tag)), "w").writelines(
+        ln for ln in open(path) if "amdgpu.ids" not in ln)
 call = latest(os.path.join(src, "call_stats", "**", "*kernel_stats.csv"))
 if call:
     rows = [r for r in csv.DictReader(open(call))]

@@ -43,12 +43,20 @@ python benchmarks/iva_lines.py >> $out/single.txt 2>&1
 python benchmarks/tools/mnmf_steps.py 32 > $out/mnmf_steps.txt 2>/dev/null
 python benchmarks/tools/mnmf_steps.py 128 >> $out/mnmf_steps.txt 2>/dev/null
 SSSPY_AMD_MNMF_NO_GLDS=1 python benchmarks/tools/mnmf_steps.py 32 2>/dev/null | sed 's/^/register-fed passes (SSSPY_AMD_MNMF_NO_GLDS): /' >> $out/mnmf_steps.txt
-for leg in ilrma_ip2 ilrma_iss2 ilrma_ipa auxiva_ip2 auxiva_iss2 auxiva_ipa fmnmf_ip2; do
+for leg in ilrma_ip2 ilrma_iss1 ilrma_iss2 ilrma_ipa auxiva_ip2 auxiva_iss2 auxiva_ipa fmnmf_ip2; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/legs/$leg -- python benchmarks/tools/leg_run.py $leg 32 10 > $out/legs/$leg.log 2>&1
   f=$(find $out/legs/$leg -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" $out/legs/${leg}_b32_kernel_stats.csv
   rm -rf $out/legs/$leg
 done
+# the same legs at 8 sources, 16 mixtures (the source counts above the tuned kernels)
+for leg in ilrma_ip1 ilrma_ip2 ilrma_iss2 ilrma_ipa auxiva_iss2; do
+  LEG_SOURCES=8 rocprofv3 --kernel-trace --stats --output-format csv -d $out/legs/$leg -- python benchmarks/tools/leg_run.py $leg 16 5 > $out/legs/${leg}_n8.log 2>&1
+  f=$(find $out/legs/$leg -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cp "$f" $out/legs/${leg}_n8_b16_kernel_stats.csv
+  rm -rf $out/legs/$leg
+done
+grep -h "ms per iteration" $out/legs/*.log > $out/legs_ms.txt
 python benchmarks/tools/call_timeline.py 100 2>/dev/null | grep -v "^$" | head -12 > $out/call_timeline.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/call_stats -- python benchmarks/tools/call_once.py 100 >> $out/call_timeline.txt 2>&1
 python benchmarks/cache_energy.py --seconds 4 > $out/cache_energy.json 2>/dev/null

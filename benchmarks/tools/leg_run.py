@@ -40,4 +40,4 @@ for _ in range(iters):
     m.update_once()
 e1.record()
 torch.cuda.synchronize()
-print("%s B=%d: %.3f ms per iteration" % (leg, B, e0.elapsed_time(e1) / iters))
+print("%s N=%d B=%d: %.3f ms per iteration (under rocprofv3 when run by profile_round.sh)" % (leg, N, B, e0.elapsed_time(e1) / iters))
