@@ -254,7 +254,11 @@ __global__ __launch_bounds__(256, 2) void k_iss1_fused(c128 *Y, const double *__
         // frames beyond T re-read frame T-1 with weight 0 and are zeroed (0 * Inf of a non-finite
         // sample must not reach the sums): they add nothing, are never stored, and the loads stay
         // unconditional
+#if defined(SSSPY_ISS_DBG) && (SSSPY_ISS_DBG & 2)  // (floor measurement: no slab loads)
+        const c128 yv = cmake(1.0 + 1e-3 * (double)(jj[f] + n), 0.5 + 1e-3 * (double)i);
+#else
         const c128 yv = buffer_load_c128(yr, jj[f] * 16u);
+#endif
         y[n][f] = fv[f] ? yv : c128{0.0, 0.0};
         if (PER_BIN) {
           const double wv = buffer_load_f64(wr, jj[f] * 8u);
@@ -262,14 +266,20 @@ __global__ __launch_bounds__(256, 2) void k_iss1_fused(c128 *Y, const double *__
         }
       }
     }
+#if !(defined(SSSPY_ISS_DBG) && (SSSPY_ISS_DBG & 1))  // (floor measurement: no sweeps)
     iss_sweeps<N, FPT, TRACK>(y, phi, part, parity, invT, floor_kind, eps, &ld);
+#endif
 #pragma unroll
     for (int n = 0; n < N; ++n) {
       const long long row = (((long long)b * N + n) * F + i) * T;
       const __amdgpu_buffer_rsrc_t yr = make_rsrc(Y + row, (unsigned)T * 16u);
 #pragma unroll
       for (int f = 0; f < FPT; ++f) {
+#if defined(SSSPY_ISS_DBG) && (SSSPY_ISS_DBG & 4)  // (floor measurement: no slab stores)
+        if (fv[f] && floor_kind == 12345) buffer_store_c128(yr, jj[f] * 16u, y[n][f]);
+#else
         if (fv[f]) buffer_store_c128(yr, jj[f] * 16u, y[n][f]);
+#endif
         r2s[(n * FPT + f) * 256 + threadIdx.x] += cabs2(y[n][f]);
       }
     }
