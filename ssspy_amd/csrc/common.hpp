@@ -37,6 +37,16 @@ inline int check_launch(const char *what) {
 
 
 // switch on a runtime n_sources to a compile-time NN (1..8)
+// (the same for kernels that only exist up to 4 sources: above, a bin is spread over lanes)
+#define DISPATCH_N4(N_, CALL)                                                           \
+  switch (N_) {                                                                         \
+    case 1: { constexpr int NN = 1; CALL; } break;                                      \
+    case 2: { constexpr int NN = 2; CALL; } break;                                      \
+    case 3: { constexpr int NN = 3; CALL; } break;                                      \
+    case 4: { constexpr int NN = 4; CALL; } break;                                      \
+    default: return ::ssspy::fail(SSSPY_ERR_UNSUPPORTED, "n_sources must be in [1, 4]"); \
+  }
+
 #define DISPATCH_N(N_, CALL)                                                            \
   switch (N_) {                                                                         \
     case 1: { constexpr int NN = 1; CALL; } break;                                      \

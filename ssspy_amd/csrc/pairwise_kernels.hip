@@ -706,15 +706,6 @@ static int launch_ip2_rows(void *W, const void *U, long long nbins, int N, int p
 }
 
 // (per-N kernels of up to 4 sources: above, the row-distributed or the run-time-N forms take over)
-#define DISPATCH_N4(N_, CALL)                                                           \
-  switch (N_) {                                                                         \
-    case 1: { constexpr int NN = 1; CALL; } break;                                      \
-    case 2: { constexpr int NN = 2; CALL; } break;                                      \
-    case 3: { constexpr int NN = 3; CALL; } break;                                      \
-    case 4: { constexpr int NN = 4; CALL; } break;                                      \
-    default: return ::ssspy::fail(SSSPY_ERR_UNSUPPORTED, "n_sources must be in [1, 4]"); \
-  }
-
 static int fill_pairs(PairList &pl, const int *pairs, int n_pairs, int N) {
   if (n_pairs < 1 || n_pairs > SSSPY_MAX_PAIRS)
     return fail(SSSPY_ERR_BADARG, "pair list must hold between 1 and SSSPY_MAX_PAIRS pairs");

@@ -719,8 +719,8 @@ int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, i
     }
     return check_launch("k_ip1_rows");
   }
-  DISPATCH_N(N, hipLaunchKernelGGL((k_ip1<NN>), grid, block, 0, st, (c128 *)W, (const c128 *)U,
-                                   nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf));
+  DISPATCH_N4(N, hipLaunchKernelGGL((k_ip1<NN>), grid, block, 0, st, (c128 *)W, (const c128 *)U,
+                                    nbins, floor_kind, floor_eps, info, (const c128 *)C, qbuf));
   return check_launch("k_ip1");
 }
 
@@ -838,11 +838,16 @@ int ssspy_update_by_ip1(void *W, const void *U, int B, int F, int N, int floor_k
   SSSPY_REQUIRE(W && U && B > 0 && F > 0, "update_by_ip1: bad argument");
   if (rt_sources_ok(N))
     return rt_ip1(W, U, nullptr, nullptr, B, F, N, floor_kind, floor_eps, info, as_stream(stream));
+  // (above 4 sources: a bin on 8 lanes -- the lane-per-bin form spilled 134 / 502 / 888 VGPRs at
+  //  6 / 7 / 8 sources and was what AuxIVA-IP1 and the functional update_by_ip1 ran; round 5)
+  if (N > 4)
+    return ip1_with_power(W, U, nullptr, nullptr, B, F, N, floor_kind, floor_eps, info,
+                          as_stream(stream));
   const long long nbins = (long long)B * F;
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
-  DISPATCH_N(N, hipLaunchKernelGGL((k_ip1<NN>), grid, block, 0, as_stream(stream), (c128 *)W,
-                                   (const c128 *)U, nbins, floor_kind, floor_eps, info,
-                                   (const c128 *)nullptr, (double *)nullptr));
+  DISPATCH_N4(N, hipLaunchKernelGGL((k_ip1<NN>), grid, block, 0, as_stream(stream), (c128 *)W,
+                                    (const c128 *)U, nbins, floor_kind, floor_eps, info,
+                                    (const c128 *)nullptr, (double *)nullptr));
   return check_launch("k_ip1");
 }
 
