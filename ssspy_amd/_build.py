@@ -47,6 +47,7 @@ def _units():
         ("linalg_kernels.hip", "linalg_kernels.o", []),
         ("pairwise_kernels.hip", "pairwise_kernels.o", []),
         ("gmnmf_kernels.hip", "gmnmf_kernels.o", []),
+        ("gmnmf_rows.hip", "gmnmf_rows.o", []),
         ("ipa_kernels.hip", "ipa_kernels.o", []),
         ("stft_kernels.hip", "stft_kernels.o", []),
         ("hermitian_ops.hip", "hermitian_ops.o", []),

@@ -20,6 +20,11 @@
 
 namespace ssspy {
 
+// gmnmf_rows.hip
+bool gmnmf_spatial_update_rows_wanted(int M);
+int gmnmf_spatial_update_rows(void *H, const double *PQ, long long count, int M, int floor_kind,
+                              double eps, int *flags, hipStream_t st);
+
 constexpr int GM_NMAX = SSSPY_MAX_SOURCES;
 
 // coefficients of XX = c1 x x^H + c0 I after the eigenvalue floor
@@ -1728,7 +1733,12 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
     if (rc) return rc;
     const long long count = (long long)B * N * F;
     const bool packed_su = packed_points(M);
-    if (packed_su) {
+    if (packed_su && gmnmf_spatial_update_rows_wanted(M)) {
+      // 7 / 8 channels: a matrix on 8 lanes (gmnmf_rows.hip); same flags, same repair kernel below
+      rc = gmnmf_spatial_update_rows(spatial, (const double *)PQ, count, M, floor_kind, floor_eps,
+                                     flags, st);
+      if (rc) return rc;
+    } else if (packed_su) {
       GM_DISPATCH_M(M, {
         const size_t smem_su = (size_t)gsu_entries<MM>() * GSU_LD * sizeof(c128);
         if (smem_su > 48 * 1024) {
