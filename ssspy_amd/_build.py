@@ -51,6 +51,7 @@ def _units():
         ("ipa_kernels.hip", "ipa_kernels.o", []),
         ("stft_kernels.hip", "stft_kernels.o", []),
         ("hermitian_ops.hip", "hermitian_ops.o", []),
+        ("hermitian_rows.hip", "hermitian_rows.o", []),
         ("fmnmf_generic.hip", "fmnmf_generic.o", []),
         ("wide_cov.hip", "wide_cov.o", []),
         ("wide_n.hip", "wide_n.o", []),

@@ -47,6 +47,18 @@ inline int check_launch(const char *what) {
     default: return ::ssspy::fail(SSSPY_ERR_UNSUPPORTED, "n_sources must be in [1, 4]"); \
   }
 
+// (kernels that exist up to 6 x 6: from 7 x 7 on a matrix is spread over 8 lanes, herm_rows8.hpp)
+#define DISPATCH_N6(N_, CALL)                                                           \
+  switch (N_) {                                                                         \
+    case 1: { constexpr int NN = 1; CALL; } break;                                      \
+    case 2: { constexpr int NN = 2; CALL; } break;                                      \
+    case 3: { constexpr int NN = 3; CALL; } break;                                      \
+    case 4: { constexpr int NN = 4; CALL; } break;                                      \
+    case 5: { constexpr int NN = 5; CALL; } break;                                      \
+    case 6: { constexpr int NN = 6; CALL; } break;                                      \
+    default: return ::ssspy::fail(SSSPY_ERR_UNSUPPORTED, "size must be in [1, 6] here"); \
+  }
+
 #define DISPATCH_N(N_, CALL)                                                            \
   switch (N_) {                                                                         \
     case 1: { constexpr int NN = 1; CALL; } break;                                      \

@@ -1739,18 +1739,28 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
                                      flags, st);
       if (rc) return rc;
     } else if (packed_su) {
-      GM_DISPATCH_M(M, {
-        const size_t smem_su = (size_t)gsu_entries<MM>() * GSU_LD * sizeof(c128);
-        if (smem_su > 48 * 1024) {
-          hipError_t e = hipFuncSetAttribute((const void *)k_gmnmf_spatial_update_p<MM>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)smem_su);
-          if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
-        }
-        hipLaunchKernelGGL((k_gmnmf_spatial_update_p<MM>), dim3((unsigned)((count + 63) / 64)),
-                           dim3(64), smem_su, st, (c128 *)spatial, (const double *)PQ, count,
-                           floor_kind, floor_eps, flags);
-      });
+      // (4-6 channels; the 7 / 8-channel instantiations -- 3 511 spilled VGPRs at 8 -- went with
+      //  round 5's 8-lane kernel)
+      switch (M) {
+#define SSSPY_GSU_P(MM_)                                                                         \
+  case MM_: {                                                                                    \
+    const size_t smem_su = (size_t)gsu_entries<MM_>() * GSU_LD * sizeof(c128);                   \
+    if (smem_su > 48 * 1024) {                                                                   \
+      hipError_t e = hipFuncSetAttribute((const void *)k_gmnmf_spatial_update_p<MM_>,            \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,             \
+                                         (int)smem_su);                                          \
+      if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));                     \
+    }                                                                                            \
+    hipLaunchKernelGGL((k_gmnmf_spatial_update_p<MM_>), dim3((unsigned)((count + 63) / 64)),     \
+                       dim3(64), smem_su, st, (c128 *)spatial, (const double *)PQ, count,        \
+                       floor_kind, floor_eps, flags);                                            \
+  } break;
+        SSSPY_GSU_P(4)
+        SSSPY_GSU_P(5)
+        SSSPY_GSU_P(6)
+#undef SSSPY_GSU_P
+        default: return fail(SSSPY_ERR_INTERNAL, "GaussMNMF: packed spatial update off its range");
+      }
       rc = check_launch("k_gmnmf_spatial_update_p");
       if (rc) return rc;
     }

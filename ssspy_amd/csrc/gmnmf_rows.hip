@@ -181,8 +181,12 @@ __global__ __launch_bounds__(512) void k_gmnmf_spatial_update_rows(c128 *H,
 
 }  // namespace
 
+// 7 and 8 channels always (the lane-per-matrix instantiations are gone); SSSPY_AMD_GMNMF_SU_ROWS=<m>
+// extends it down to m channels for experiments (4-6 keep the packed lane-per-matrix kernel, which
+// does not spill there: 6 channels 0.96 ms per iteration)
 bool gmnmf_spatial_update_rows_wanted(int M) {
-  const char *e = getenv("SSSPY_AMD_GMNMF_SU_ROWS");  // "0": never; "<m>": from m channels on
+  if (M >= 7 && M <= 8) return true;
+  const char *e = getenv("SSSPY_AMD_GMNMF_SU_ROWS");
   const int from = e ? atoi(e) : 7;
   return from > 0 && M >= from && M <= 8;
 }

@@ -9,6 +9,11 @@
 
 namespace ssspy {
 
+// hermitian_rows.hip
+bool hermitian_rows_wanted(int M, int always_from);
+int eigh_rows(const void *A, double *lamb, void *V, long long n, int M, int mode, int floor_kind,
+              double eps, hipStream_t st);
+
 // X = A^-1 B, B (N x nrhs)
 template <int N>
 __global__ __launch_bounds__(64) void k_solve(const c128 *__restrict__ A, const c128 *__restrict__ Bm,
@@ -326,53 +331,54 @@ int ssspy_inv2(const void *A, void *out, long long n, void *stream) {
   return check_launch("k_inv2");
 }
 
+// up to 5 x 5: a lane per matrix; 6 x 6: the same on packed storage (k_eigh_p); 7 x 7 and 8 x 8: a
+// matrix on 8 lanes (hermitian_rows.hip; the lane-per-matrix instantiations there -- 300-3 300
+// spilled VGPRs -- are gone)
+#define SSSPY_DISPATCH_EIGH5(M_, CALL)                                                            \
+  switch (M_) {                                                                                   \
+    case 1: { constexpr int NN = 1; CALL; } break;                                                \
+    case 2: { constexpr int NN = 2; CALL; } break;                                                \
+    case 3: { constexpr int NN = 3; CALL; } break;                                                \
+    case 4: { constexpr int NN = 4; CALL; } break;                                                \
+    case 5: { constexpr int NN = 5; CALL; } break;                                                \
+    default: return ::ssspy::fail(SSSPY_ERR_UNSUPPORTED, "eigh: size must be in [1, 8]");         \
+  }
+
 int ssspy_eigh(const void *A, double *lamb, void *V, long long n, int M, void *stream) {
   SSSPY_REQUIRE(A && lamb && V && n > 0, "eigh: bad argument");
+  if (hermitian_rows_wanted(M, 7))
+    return eigh_rows(A, lamb, V, n, M, 0, 0, 0.0, as_stream(stream));
   dim3 grid((unsigned)((n + 63) / 64)), block(64);
-  static const bool full_eigh = std::getenv("SSSPY_AMD_EIGH_FULL") != nullptr;  // A / B
-  if (M >= 6 && M <= 8 && !full_eigh) {  // packed storage
-    switch (M) {
-      case 6: hipLaunchKernelGGL((k_eigh_p<6>), grid, block, 0, as_stream(stream), (const c128 *)A,
-                                 lamb, (c128 *)V, n, 0, 0, 0.0); break;
-      case 7: hipLaunchKernelGGL((k_eigh_p<7>), grid, block, 0, as_stream(stream), (const c128 *)A,
-                                 lamb, (c128 *)V, n, 0, 0, 0.0); break;
-      default: hipLaunchKernelGGL((k_eigh_p<8>), grid, block, 0, as_stream(stream), (const c128 *)A,
-                                  lamb, (c128 *)V, n, 0, 0, 0.0); break;
-    }
+  if (M == 6) {  // packed storage
+    hipLaunchKernelGGL((k_eigh_p<6>), grid, block, 0, as_stream(stream), (const c128 *)A, lamb,
+                       (c128 *)V, n, 0, 0, 0.0);
     return check_launch("k_eigh_p");
   }
-  DISPATCH_N(M, hipLaunchKernelGGL((k_eigh<NN>), grid, block, 0, as_stream(stream), (const c128 *)A,
-                                   lamb, (c128 *)V, n, 0, 0, 0.0));
+  SSSPY_DISPATCH_EIGH5(M, hipLaunchKernelGGL((k_eigh<NN>), grid, block, 0, as_stream(stream),
+                                             (const c128 *)A, lamb, (c128 *)V, n, 0, 0, 0.0));
   return check_launch("k_eigh");
 }
 
 int ssspy_to_psd(const void *A, void *out, long long n, int M, int floor_kind, double floor_eps,
                  void *stream) {
   SSSPY_REQUIRE(A && out && n > 0, "to_psd: bad argument");
+  if (hermitian_rows_wanted(M, 7))
+    return eigh_rows(A, nullptr, out, n, M, 1, floor_kind, floor_eps, as_stream(stream));
   dim3 grid((unsigned)((n + 63) / 64)), block(64);
-  static const bool full_eigh = std::getenv("SSSPY_AMD_EIGH_FULL") != nullptr;
-  if (M >= 6 && M <= 8 && !full_eigh) {
+  if (M == 6) {
     const size_t smem = (size_t)M * M * EIGH_LD * sizeof(c128);
-#define SSSPY_TO_PSD_P(MM_)                                                                          \
-  {                                                                                                  \
-    if (smem > 48 * 1024) {                                                                          \
-      hipError_t e = hipFuncSetAttribute((const void *)k_eigh_p<MM_>,                                \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);     \
-      if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));                         \
-    }                                                                                                \
-    hipLaunchKernelGGL((k_eigh_p<MM_>), grid, block, smem, as_stream(stream), (const c128 *)A,        \
-                       (double *)nullptr, (c128 *)out, n, 1, floor_kind, floor_eps);                  \
-  }
-    switch (M) {
-      case 6: SSSPY_TO_PSD_P(6) break;
-      case 7: SSSPY_TO_PSD_P(7) break;
-      default: SSSPY_TO_PSD_P(8) break;
+    if (smem > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void *)k_eigh_p<6>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
     }
-#undef SSSPY_TO_PSD_P
+    hipLaunchKernelGGL((k_eigh_p<6>), grid, block, smem, as_stream(stream), (const c128 *)A,
+                       (double *)nullptr, (c128 *)out, n, 1, floor_kind, floor_eps);
     return check_launch("k_to_psd_p");
   }
-  DISPATCH_N(M, hipLaunchKernelGGL((k_eigh<NN>), grid, block, 0, as_stream(stream), (const c128 *)A,
-                                   (double *)nullptr, (c128 *)out, n, 1, floor_kind, floor_eps));
+  SSSPY_DISPATCH_EIGH5(M, hipLaunchKernelGGL((k_eigh<NN>), grid, block, 0, as_stream(stream),
+                                             (const c128 *)A, (double *)nullptr, (c128 *)out, n, 1,
+                                             floor_kind, floor_eps));
   return check_launch("k_to_psd");
 }
 

@@ -1250,7 +1250,7 @@ def test_solve_matches_numpy(N):
         solve(np.zeros((2, N, N), dtype=complex), np.ones((2, N), dtype=complex))
 
 
-@pytest.mark.parametrize("M", [2, 3, 4, 6])
+@pytest.mark.parametrize("M", [2, 3, 4, 6, 7, 8])
 def test_eigh_properties(M):
     """The reference's own property checks (tests/package/linalg/test_eigh.py): A z = lamb z,
     ascending eigenvalues; plus agreement with LAPACK eigenvalues and unitarity."""
@@ -1592,7 +1592,7 @@ def _psd(rng, lead, M, T=32, complex_=True):
     return np.mean(x[..., :, None, :] * x[..., None, :, :].conj(), axis=-1)
 
 
-@pytest.mark.parametrize("M", [3, 4, 6, 8])
+@pytest.mark.parametrize("M", [3, 4, 6, 7, 8])
 @pytest.mark.parametrize("type", [1, 2, 3])
 def test_generalized_eigh(M, type):
     """The reference's property checks for the generalised problem (tests/package/linalg/test_eigh.py),
@@ -1617,7 +1617,7 @@ def test_generalized_eigh(M, type):
     np.testing.assert_allclose(lamb, np.linalg.eigvalsh(C), rtol=1e-11, atol=1e-13)
 
 
-@pytest.mark.parametrize("M", [3, 4])
+@pytest.mark.parametrize("M", [3, 4, 6, 7, 8])
 @pytest.mark.parametrize("is_complex", [True, False])
 def test_sqrtmh_invsqrtmh(M, is_complex):
     """tests/package/linalg/test_sqrtm.py on the device."""
@@ -1654,6 +1654,56 @@ def test_gmeanmh(type):
     else:
         assert np.allclose(G @ np.linalg.inv(A) @ G, np.linalg.inv(B))
     assert rel_err(G, G.swapaxes(-2, -1).conj()) < 1e-13
+
+
+@pytest.mark.parametrize("M", [6, 7, 8])
+def test_hermitian_operators_on_eight_lanes_equal_the_lane_per_matrix_kernels(M, monkeypatch):
+    """Round 5: eigh, to_psd, the generalised eigenproblem, sqrtmh / invsqrtmh and gmeanmh run with a
+    matrix on 8 lanes from 7 x 7 on (hermitian_rows.hip; the lane-per-matrix instantiations of
+    those sizes are gone) and on request from 6 x 6 (SSSPY_AMD_HERM_ROWS=6), where the
+    lane-per-matrix kernels remain to compare with.  Matrix functions agree to rounding,
+    eigenvalues too, eigenvectors up to the phase each decomposition leaves (compared through the
+    projectors z z^H); every size also against LAPACK."""
+    from ssspy_amd.linalg import eigh, gmeanmh, invsqrtmh, sqrtmh
+    from ssspy_amd.special.flooring import max_flooring
+    from ssspy_amd.special.psd import to_psd
+
+    rng = np.random.default_rng(500 + M)
+    lead = (70,)  # (more than two blocks of 32 matrices, a ragged last one)
+    A, B = _psd(rng, lead, M), _psd(rng, lead, M)
+    Hm = rng.standard_normal(lead + (M, M)) + 1j * rng.standard_normal(lead + (M, M))
+    Hm = Hm + Hm.swapaxes(-2, -1).conj()  # indefinite
+    floor = functools.partial(max_flooring, eps=0.5)
+
+    def run():
+        out = {"eigh": eigh(Hm), "psd": to_psd(Hm, flooring_fn=floor), "sqrt": sqrtmh(A),
+               "invsqrt": invsqrtmh(A, flooring_fn=floor)}
+        for t in (1, 2, 3):
+            out["gmean%d" % t] = gmeanmh(A, B, type=t)
+            out["geigh%d" % t] = eigh(A, B, type=t)
+        return out
+
+    monkeypatch.setenv("SSSPY_AMD_HERM_ROWS", "6")  # (by default from 7 x 7)
+    rows = run()
+    monkeypatch.setenv("SSSPY_AMD_HERM_ROWS", "0")
+    lanes = run()
+    monkeypatch.delenv("SSSPY_AMD_HERM_ROWS")
+
+    def projectors(z):
+        return z[..., :, None, :] * z[..., None, :, :].conj()  # [.., r, c, k] = z_rk conj(z_ck)
+
+    for key in ("psd", "sqrt", "invsqrt", "gmean1", "gmean2", "gmean3"):
+        assert rel_err(rows[key], lanes[key]) < 1e-11, key
+    for key in ("eigh", "geigh1", "geigh2", "geigh3"):
+        np.testing.assert_allclose(rows[key][0], lanes[key][0], rtol=1e-11, atol=1e-12, err_msg=key)
+        assert rel_err(projectors(rows[key][1]), projectors(lanes[key][1])) < 1e-9, key
+    # and against LAPACK where NumPy has the function
+    np.testing.assert_allclose(rows["eigh"][0], np.linalg.eigvalsh(Hm), rtol=1e-11, atol=1e-12)
+    lam, V = np.linalg.eigh(Hm)
+    ref_psd = (V * np.maximum(lam, 0.5)[..., None, :]) @ V.swapaxes(-2, -1).conj()
+    assert rel_err(rows["psd"], ref_psd) < 1e-11
+    assert rel_err(rows["sqrt"] @ rows["sqrt"], A) < 1e-11
+    assert rel_err(rows["gmean2"] @ A @ rows["gmean2"], B) < 1e-9
 
 
 @pytest.mark.parametrize("L", [1, 2, 3, 5, 7])
