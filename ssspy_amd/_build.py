@@ -49,6 +49,7 @@ def _units():
         ("gmnmf_kernels.hip", "gmnmf_kernels.o", []),
         ("gmnmf_rows.hip", "gmnmf_rows.o", []),
         ("ipa_kernels.hip", "ipa_kernels.o", []),
+        ("ipa_rows.hip", "ipa_rows.o", []),
         ("stft_kernels.hip", "stft_kernels.o", []),
         ("hermitian_ops.hip", "hermitian_ops.o", []),
         ("hermitian_rows.hip", "hermitian_rows.o", []),

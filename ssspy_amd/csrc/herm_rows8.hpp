@@ -122,7 +122,12 @@ __device__ __forceinline__ bool chol_upper(c128 (&row)[8], int r) {
     const double s = shfl8(row[k].x, k);  // the pivot, from lane k
     const bool pos = s > 0.0;
     ok = ok && pos;
-    const double d = sqrt(pos ? s : 1.0), dinv = 1.0 / d;
+    // (the pivot's square root and reciprocal head every step's dependency chain: v_rsq + Newton
+    //  inside [1e-300, 1e300], the IEEE forms outside)
+    const double sp = pos ? s : 1.0;
+    const bool mid = sp > 1e-300 && sp < 1e300;
+    const double dinv = mid ? rsq2(sp) : 1.0 / sqrt(sp);
+    const double d = sp * dinv;
     c128 uk[8];
 #pragma unroll
     for (int c = k + 1; c < 8; ++c) uk[c] = shfl8(cscale(row[c], dinv), k);  // row k of U
@@ -149,7 +154,8 @@ __device__ __forceinline__ void trtri_col(const c128 *X, int c, c128 (&v)[8]) {
     c128 acc = cmake(0.0, 0.0);
 #pragma unroll
     for (int j = k + 1; j < 8; ++j) cfma(acc, X[k * LD + j], v[j]);  // (v[j] = 0 beyond c)
-    const double inv = 1.0 / X[k * LD + k].x;
+    const double ukk = X[k * LD + k].x;
+    const double inv = (ukk > 1e-300 && ukk < 1e300) ? rcp2(ukk) : 1.0 / ukk;
     asm volatile("" ::: "memory");
     v[k].x = (k == c) ? inv : ((k < c) ? -acc.x * inv : 0.0);
     v[k].y = (k < c) ? -acc.y * inv : 0.0;

@@ -27,58 +27,15 @@
 // phase is the decomposition's.
 #include "common.hpp"
 #include "hermitian.hpp"
+#include "ipa_common.hpp"
 #include "smallmat.hpp"
 #include "ssspy_amd.h"
 
 namespace ssspy {
 
-__device__ __forceinline__ double floor_of_zero(int floor_kind, double eps) {
-  return apply_floor(0.0, floor_kind, eps);
-}
-
-// largest real root of x^3 + A x^2 + B x + C, computed the way the reference does (complex
-// Cardano with the principal polar cube root, whose real part is kept even when it is not the real
-// root: the value only seeds the Newton iteration and is range-checked afterwards)
-__device__ __forceinline__ double largest_cubic_root(double A, double B, double C) {
-  const double P = -(A * A) / 3.0 + B;
-  const double Q = (2.0 * A * A * A) / 27.0 - (A * B) / 3.0 + C;
-  const double disc = (Q * 0.5) * (Q * 0.5) + (P / 3.0) * (P / 3.0) * (P / 3.0);
-  // w = -Q/2 + sqrt(disc) (principal complex square root)
-  const double wr = -0.5 * Q + (disc >= 0.0 ? sqrt(disc) : 0.0);
-  const double wi = disc >= 0.0 ? 0.0 : sqrt(-disc);
-  const double mag = sqrt(wr * wr + wi * wi);
-  double ur, ui, vr, vi, x1;
-  if (mag == 0.0) {
-    ur = 1.0;
-    ui = 0.0;
-    vr = -P / 3.0;
-    vi = 0.0;
-    x1 = cbrt(-Q);
-  } else {
-    const double m3 = cbrt(mag), th = atan2(wi, wr) / 3.0;
-    ur = m3 * cos(th);
-    ui = m3 * sin(th);
-    // V = -P / (3 U)
-    const double den = 3.0 * (ur * ur + ui * ui);
-    vr = -P * ur / den;
-    vi = P * ui / den;
-    x1 = ur + vr;
-  }
-  double root = x1;
-  if (P < 0.0 && !(disc > 0.0)) {
-    const double h = 0.8660254037844386;  // sqrt(3)/2
-    // Re(U w + V conj(w)), Re(U conj(w) + V w), w = (-1 + i sqrt(3)) / 2
-    const double x2 = -0.5 * ur - h * ui - 0.5 * vr + h * vi;
-    const double x3 = -0.5 * ur + h * ui - 0.5 * vr - h * vi;
-    root = fmax(root, fmax(x2, x3));
-  }
-  return root - A / 3.0;
-}
-
 // y = argmin of the LQPQM (type 2) with H = sigma diag(phi) sigma^H.  ref: lqpqm.py:13-110
 // mode: NEWTON_FIXED max_iter steps; NEWTON_PROBE max_iter steps, convergence bits AND-ed into *word
 // (nothing else is produced); NEWTON_APPLY the number of steps found in *word by k_newton_steps
-enum { NEWTON_FIXED = 0, NEWTON_PROBE = 1, NEWTON_APPLY = 2 };
 template <int L>
 __device__ __forceinline__ void lqpqm2(c128 (&H)[L][L], const c128 (&v)[L], double z,
                                        int floor_kind, double eps, int max_iter, c128 (&y)[L],
@@ -595,6 +552,30 @@ static int launch_one(const void *Vc, void *G, long long nbins, int B, int F, in
   return check_launch("k_ipa_transform");
 }
 
+// ipa_rows.hip: the source step with a bin on 8 lanes (5..8 sources; source count and index at run time)
+bool ipa_rows_wanted(int N);
+int ipa_rows_launch(int mode, const void *Vc, void *G, long long nbins, int F, int N, int S,
+                    int normalization, int max_iter, int floor_kind, double eps, int *info,
+                    unsigned long long *newton_ws, void *Vchain, int chain_first, hipStream_t st);
+
+static int launch_rows(const void *Vc, void *G, long long nbins, int B, int F, int N, int S,
+                       int normalization, int max_iter, int floor_kind, double eps, int *info,
+                       unsigned long long *newton_ws, int *not_converged, hipStream_t st,
+                       c128 *Vchain, int chain_first) {
+  if (!newton_ws || max_iter > 62 || max_iter == 0)
+    return ipa_rows_launch(NEWTON_FIXED, Vc, G, nbins, F, N, S, normalization, max_iter, floor_kind,
+                           eps, info, nullptr, Vchain, chain_first, st);
+  int rc = newton_prepare(newton_ws, B, st);
+  if (rc) return rc;
+  rc = ipa_rows_launch(NEWTON_PROBE, Vc, G, nbins, F, N, S, normalization, max_iter, floor_kind, eps,
+                       info, newton_ws, nullptr, 0, st);
+  if (rc) return rc;
+  rc = newton_finish(newton_ws, B, max_iter, not_converged, st);
+  if (rc) return rc;
+  return ipa_rows_launch(NEWTON_APPLY, Vc, G, nbins, F, N, S, normalization, max_iter, floor_kind,
+                         eps, info, newton_ws, Vchain, chain_first, st);
+}
+
 }  // namespace ssspy
 
 using namespace ssspy;
@@ -605,6 +586,10 @@ static int ipa_step(const void *Vc, void *G, int source_idx, int B, int F, int N
                     int max_iter, int floor_kind, double floor_eps, int *info, void *newton_ws,
                     int *not_converged, hipStream_t st, c128 *Vchain, int chain_first) {
   const long long nbins = (long long)B * F;
+  if (ipa_rows_wanted(N))
+    return launch_rows(Vc, G, nbins, B, F, N, source_idx, normalization, max_iter, floor_kind,
+                       floor_eps, info, (unsigned long long *)newton_ws, not_converged, st, Vchain,
+                       chain_first);
 #define IPA_CASE(N_, S_)                                                                     \
   if (N == N_ && source_idx == S_)                                                           \
     return launch_one<N_, S_>(Vc, G, nbins, B, F, normalization, max_iter, floor_kind,     \
@@ -617,8 +602,6 @@ static int ipa_step(const void *Vc, void *G, int source_idx, int B, int F, int N
   IPA_CASE(6, 0) IPA_CASE(6, 1) IPA_CASE(6, 2) IPA_CASE(6, 3) IPA_CASE(6, 4) IPA_CASE(6, 5)
   IPA_CASE(7, 0) IPA_CASE(7, 1) IPA_CASE(7, 2) IPA_CASE(7, 3) IPA_CASE(7, 4) IPA_CASE(7, 5)
   IPA_CASE(7, 6)
-  IPA_CASE(8, 0) IPA_CASE(8, 1) IPA_CASE(8, 2) IPA_CASE(8, 3) IPA_CASE(8, 4) IPA_CASE(8, 5)
-  IPA_CASE(8, 6) IPA_CASE(8, 7)
 #undef IPA_CASE
   return fail(SSSPY_ERR_UNSUPPORTED, "ipa_transform: unsupported (n_sources, source) pair");
 }

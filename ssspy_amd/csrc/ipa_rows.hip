@@ -1,0 +1,484 @@
+// IPA source step for 5..8 sources with a BIN ON 8 LANES (round 5): lane r of an 8-lane group holds
+// row r of every N x N operand (herm_rows8.hpp), the source count and the source index are run-time
+// arguments (padded to 8; rows / columns S and >= N of the reduced problem are zero and the Jacobi
+// rotations that would touch them see a zero off-diagonal).  The lane-per-bin kernel of
+// ipa_kernels.hip is one function per (N, source, mode) -- 72 of them above 4 sources, each with
+// unrolled 7 x 7 / 8 x 8 Jacobi bodies on 1 000-2 000 spilled VGPRs.
+//
+// Same algorithm, statement by statement, as k_ipa_transform (see there for the reference lines:
+// ssspy/bss/_update_spatial_model.py:398-513, :611-645, ssspy/linalg/lqpqm.py:13-352):
+//   a_m, b_m from to_psd(U_m), m != S (Cholesky test of the floor, eigen route when it acts);
+//   U_S^-1 (doubly floored) -> C, d, z;  H, v;  LQPQM2 (Hermitian Jacobi, Cardano start, Newton);
+//   q, q~, p = U_S^-1 q~ / floor(sqrt(q~^H U_S^-1 q~));  G_S;  chained: V_m <- G_S V_m G_S^H, G <- G_S G.
+// Differences in rounding only: C x = d goes through the Cholesky inverse of C (Hermitian positive
+// definite as a principal block of U_S^-1) instead of an LU, column sums run over lanes.
+#include <cstdlib>
+
+#include "herm_rows8.hpp"
+#include "ipa_common.hpp"
+#include "ssspy_amd.h"
+
+namespace ssspy {
+
+using namespace rows8;
+
+namespace {
+
+constexpr int BINS = 32;  // bins per 256-thread block
+
+__device__ __forceinline__ double seld(const double (&a)[8], int i) {
+  double r = a[0];
+#pragma unroll
+  for (int c = 1; c < 8; ++c) r = (i == c) ? a[c] : r;
+  return r;
+}
+__device__ __forceinline__ void putd(double (&a)[8], int i, double v) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) a[c] = (i == c) ? v : a[c];
+}
+
+// row r of the Hermitian part of the N x N matrix at src, zero-padded
+__device__ __forceinline__ void load_herm(const c128 *__restrict__ src, int r, int N, c128 (&row)[8]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    c128 v = cmake(0.0, 0.0);
+    if (r < N && c < N) {
+      const c128 u = src[r * N + c], l = src[c * N + r];
+      v = cmake(0.5 * (u.x + l.x), 0.5 * (u.y - l.y));
+    }
+    row[c] = v;
+  }
+}
+
+// lam_min(A) > shift, by the pivots of the Cholesky factorisation of A - shift I (padding: unit diagonal).
+// First Gershgorin's discs: lam_min >= min_r (a_rr - sum_{c != r} |a_rc|); the statistics of a
+// spectrogram that is already mostly separated are diagonally dominant, and when every matrix of
+// the wave passes, the eight-step factorisation (a chain of dependent pivots) is skipped.
+__device__ __forceinline__ bool shifted_pd(const c128 (&a)[8], int r, int N, double shift) {
+  {
+    double offsum = 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) offsum += sqrt(cabs2(a[c]));
+    const double arr = sel(a, r).x;
+    const bool clear = r >= N || (arr - (offsum - fabs(arr)) > shift);
+    if (__all(clear)) return true;
+  }
+  c128 t[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) t[c] = a[c];
+  put(t, r, r < N ? cmake(sel(a, r).x - shift, 0.0) : cmake(1.0, 0.0));
+  return chol_upper(t, r);
+}
+
+// Inverse of the Hermitian positive definite matrix with row r in `a` (padding: unit diagonal set by
+// the caller): rows of A^-1 = V V^H, V = U^-1.  False when not positive definite.
+__device__ __forceinline__ bool chol_inverse_rows(c128 (&a)[8], c128 *X, int r, c128 (&inv)[8]) {
+  const bool ok = chol_upper(a, r);
+  wsync();
+  store_row(X, r, a);
+  wsync();
+  c128 col[8];
+  trtri_col(X, r, col);
+  wsync();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) X[k * LD + r] = col[k];
+  wsync();
+  c128 vrow[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) vrow[c] = X[r * LD + c];
+  mul_rows_adj(vrow, X, inv);  // sum_k V[r][k] conj(V[c][k])
+  wsync();
+  return ok;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ipa_rows(const c128 *Vc, c128 *__restrict__ G,
+                                                  long long nbins, int F, int N, int S,
+                                                  int normalization, int max_iter, int floor_kind,
+                                                  double eps, int *info,
+                                                  unsigned long long *newton_ws, c128 *Vchain,
+                                                  int chain_first) {
+  __shared__ c128 slots[BINS * SLOT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 7, g = wave * 8 + (lane >> 3);
+  c128 *X = slots + g * SLOT;
+  const long long bin_raw = (long long)blockIdx.x * BINS + g;
+  const bool live = bin_raw < nbins;
+  const long long bin = live ? bin_raw : nbins - 1;  // idle groups shadow the last bin, never store or vote
+  unsigned long long *word = MODE == NEWTON_FIXED ? nullptr : newton_ws + bin / F;
+  const c128 *Ub = Vc + bin * (long long)(N * N * N);
+  const bool rest = r < N && r != S;
+  const double f0 = floor_of_zero(floor_kind, eps);
+
+  // ---- a_m = Re to_psd(U_m)[S][S], b_m = to_psd(U_m)[S][m], m != S (every lane keeps all of them)
+  double a[8];
+  c128 b[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    a[c] = 1.0;
+    b[c] = cmake(0.0, 0.0);
+  }
+#pragma unroll 1
+  for (int m = 0; m < N; ++m) {
+    if (m == S) continue;
+    c128 row[8];
+    load_herm(Ub + m * N * N, r, N, row);
+    double ass = shfl8(sel(row, S).x, S);
+    c128 bsm = shfl8(sel(row, m), S);
+    bool idle = floor_kind != SSSPY_FLOOR_MAX;
+    if (floor_kind == SSSPY_FLOOR_ADD) ass += eps;
+    if (floor_kind == SSSPY_FLOOR_MAX) idle = shifted_pd(row, r, N, eps);
+    if (!idle) {  // the floor may act: the literal route (whole 8-lane groups take it)
+      double lam = sel(row, r).x;
+      c128 p[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) p[c] = cmake(c == r ? 1.0 : 0.0, 0.0);
+      jacobi<true>(row, lam, p, r);
+      const double lf = apply_floor(lam, floor_kind, eps);
+      ass = 0.0;
+      bsm = cmake(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const double lk = shfl8(lf, k);
+        const c128 ps = shfl8(p[k], S), pm = shfl8(p[k], m);
+        if (k < N) {
+          ass = fma(lk, cabs2(ps), ass);
+          const c128 t = cmulc(ps, pm);
+          bsm.x = fma(lk, t.x, bsm.x);
+          bsm.y = fma(lk, t.y, bsm.y);
+        }
+      }
+    }
+    putd(a, m, ass);
+    put(b, m, bsm);
+  }
+
+  // ---- U_S: its Hermitian part `us`; the doubly floored inverse `uinv`
+  c128 us[8], uinv[8], pl[8];  // pl: eigenvectors of the literal route
+  double lamf = 1.0;           // floored eigenvalue r of the literal route
+  load_herm(Ub + S * N * N, r, N, us);
+  bool literal = floor_kind == SSSPY_FLOOR_MAX && !shifted_pd(us, r, N, eps);
+  if (!literal) {
+    c128 t[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) t[c] = us[c];
+    const double shift = floor_kind == SSSPY_FLOOR_ADD ? 2.0 * eps : 0.0;
+    put(t, r, r < N ? cmake(sel(us, r).x + shift, 0.0) : cmake(1.0, 0.0));
+    literal = !chol_inverse_rows(t, X, r, uinv);  // (not positive definite: the eigen route copes)
+  }
+  if (literal) {
+    c128 t[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      t[c] = us[c];
+      pl[c] = cmake(c == r ? 1.0 : 0.0, 0.0);
+    }
+    double lam = sel(us, r).x;
+    jacobi<true>(t, lam, pl, r);
+    lamf = apply_floor(lam, floor_kind, eps);
+    rebuild(pl, r < N ? 1.0 / apply_floor(lamf, floor_kind, eps) : 0.0, X, r, uinv);
+    wsync();
+  }
+
+  // ---- C = conj(Uinv)[rest][rest], d = conj(Uinv)[rest][S];  x = C^-1 d;  z = Uinv[S][S] - d^H x
+  c128 cm[8];  // row r of C embedded in 8 x 8 (zero row / column at S and beyond N)
+#pragma unroll
+  for (int c = 0; c < 8; ++c) cm[c] = (rest && c < N && c != S) ? cconj(uinv[c]) : cmake(0.0, 0.0);
+  const c128 d = rest ? cconj(sel(uinv, S)) : cmake(0.0, 0.0);
+  c128 x;
+  {
+    c128 t[8], cinv[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) t[c] = cm[c];
+    if (!rest) put(t, r, cmake(1.0, 0.0));
+    const bool ok = chol_inverse_rows(t, X, r, cinv);
+    if (MODE != NEWTON_PROBE && !ok && info && live && r == 0) atomicAdd(info, 1);
+    x = cmake(0.0, 0.0);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cfma(x, cinv[c], shfl8(d, c));
+    if (!rest) x = cmake(0.0, 0.0);
+  }
+  const double dCd = sum8(d.x * x.x + d.y * x.y);
+  double z = shfl8(sel(uinv, S).x, S) - dCd;
+  const double as_r = sqrt(seld(a, r));
+  c128 h[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const double sc = 1.0 / (as_r * sqrt(a[c]));
+    h[c] = cscale(cm[c], sc);  // (zero where cm is)
+  }
+  const double tr = sum8(rest ? sel(h, r).x : 0.0);
+  const c128 br = sel(b, r);
+  // v = -b / a_sqrt - a_sqrt * C^-1 d
+  c128 v = rest ? cmake(-br.x / as_r - as_r * x.x, -br.y / as_r - as_r * x.y) : cmake(0.0, 0.0);
+  if (normalization) {
+    const double it = 1.0 / tr;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) h[c] = cscale(h[c], it);
+    z *= it;
+  }
+  // hermitize H (its two triangles come from different lanes)
+  wsync();
+  store_row(X, r, h);
+  wsync();
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const c128 t = X[c * LD + r];
+    h[c] = cmake(0.5 * (h[c].x + t.x), 0.5 * (h[c].y - t.y));
+  }
+  wsync();
+
+  // ---- LQPQM2: H = sigma diag(phi) sigma^H on the rest indices
+  c128 sg[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) sg[c] = cmake(c == r ? 1.0 : 0.0, 0.0);
+  double phi_r = sel(h, r).x;
+  jacobi<true>(h, phi_r, sg, r);
+  double phi[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) phi[l] = shfl8(phi_r, l);
+  const double vnorm2 = sum8(cabs2(v));
+  const bool is_singular = sqrt(vnorm2) < f0;
+  c128 qc = cmake(0.0, 0.0);  // component r of the LQPQM solution
+  if (is_singular) {
+    // v = 0: scale * (last row of the eigenvector matrix in ascending-eigenvalue column order), see
+    // lqpqm2 in ipa_kernels.hip
+    double pmax = -1.7976931348623157e308;
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+      if (l < N && l != S) pmax = fmax(pmax, phi[l]);
+    const double lamb = fmax(z, pmax);
+    const double scale = sqrt(fmax((lamb - z) / pmax, 0.0));
+    const int last = S == N - 1 ? N - 2 : N - 1;
+    const int mypos = r < S ? r : r - 1;  // my position among the rest indices
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      const c128 val = cscale(shfl8(sg[l], last), scale);
+      int rank = 0;
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+        rank += (m < N && m != S && (phi[m] < phi[l] || (phi[m] == phi[l] && m < l))) ? 1 : 0;
+      if (l < N && l != S && rest && rank == mypos) qc = val;
+    }
+  } else {
+    // vt = sigma^H v (column sums over the lanes)
+    c128 vt[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      const c128 t = cmulc(v, sg[l]);  // v_r conj(sigma_rl)
+      vt[l] = cmake(sum8(t.x), sum8(t.y));
+    }
+    // solve_equation (lqpqm.py:112-200), the same arithmetic in every lane
+    double ph[8], w2[8];
+    double pmax = 0.0, v2max = 0.0;
+    bool first = true;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      const bool valid = l < N && l != S;
+      const bool keep = valid && (phi[l] * cabs2(vt[l]) >= f0);
+      ph[l] = keep ? phi[l] : 0.0;
+      w2[l] = keep ? cabs2(vt[l]) : 0.0;
+      if (valid && (first || ph[l] > pmax)) {
+        pmax = ph[l];
+        v2max = w2[l];
+        first = false;
+      }
+    }
+    const double pm = apply_floor(pmax, floor_kind, eps);
+    const double inv = 1.0 / pm;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      ph[l] *= inv;
+      w2[l] *= inv * inv;
+    }
+    const double zn = z * inv;
+    const double A = -(v2max * inv * inv + 2.0 + zn), Bc = 1.0 + 2.0 * zn, Cc = -zn;
+    double lamb = largest_cubic_root(A, Bc, Cc);
+    if (!(lamb > 1.0)) lamb = 1.0 + f0;
+    lamb = fmax(lamb, zn);
+    const int steps = MODE == NEWTON_APPLY ? (int)*word : max_iter;
+    unsigned long long bits = 0ull;
+    for (int it = 0; it <= steps; ++it) {
+      double s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        if (l < N && l != S) {
+          const double dl = lamb - ph[l];
+          s2 += ph[l] * w2[l] / (dl * dl);
+          s3 += ph[l] * ph[l] * w2[l] / (dl * dl * dl);
+        }
+      }
+      const double f = lamb * lamb * s2 - lamb + zn;
+      if (fabs(f) <= f0) bits |= 1ull << it;
+      if (it == steps) break;
+      const double df = -2.0 * lamb * s3 - 1.0;
+      const double mu = lamb - f / df;
+      lamb = mu > 1.0 ? mu : 0.5 * (1.0 + lamb);
+    }
+    if (MODE != NEWTON_PROBE) {
+      lamb *= pm;
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        if (l < N && l != S) {
+          const double gl = phi[l] / (lamb - phi[l]);
+          cfma(qc, sg[l], cscale(vt[l], gl));
+        }
+      }
+    } else {
+      // one vote per bin (lane 0 of the group), one atomic per (wave, mixture): as in lqpqm2
+      const bool voter = live && r == 0;
+      unsigned long long todo = __ballot(voter);
+      const unsigned long long mine_word = (unsigned long long)word;
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned long long lw = __shfl(mine_word, leader, 64);
+        const bool mine = voter && mine_word == lw;
+        const unsigned long long group = __ballot(mine);
+        unsigned long long all = 0ull;
+        for (int it = 0; it <= steps; ++it)
+          if (__ballot(mine && !((bits >> it) & 1ull)) == 0ull) all |= 1ull << it;
+        if ((int)(threadIdx.x & 63) == leader) atomicAnd(word, all);
+        todo &= ~group;
+      }
+    }
+  }
+  if (MODE == NEWTON_PROBE) return;
+
+  // ---- q = q_check / a_sqrt - b / a;  q~ = e_S - E conj(q);  p = U_S^-1 q~ / floor(sqrt(q~^H U_S^-1 q~))
+  const double a_r = seld(a, r);
+  const c128 q = rest ? cmake(qc.x / as_r - br.x / a_r, qc.y / as_r - br.y / a_r) : cmake(0.0, 0.0);
+  const c128 qt = r == S ? cmake(1.0, 0.0) : (rest ? cmake(-q.x, q.y) : cmake(0.0, 0.0));
+  if (literal) {  // singly floored inverse
+    rebuild(pl, r < N ? 1.0 / lamf : 0.0, X, r, uinv);
+    wsync();
+  } else if (floor_kind == SSSPY_FLOOR_ADD) {
+    c128 t[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) t[c] = us[c];
+    put(t, r, r < N ? cmake(sel(us, r).x + eps, 0.0) : cmake(1.0, 0.0));
+    const bool ok = chol_inverse_rows(t, X, r, uinv);
+    if (!ok && info && live && r == 0) atomicAdd(info, 1);
+  }
+  c128 uq = cmake(0.0, 0.0), qtall[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    qtall[c] = shfl8(qt, c);
+    cfma(uq, uinv[c], qtall[c]);
+  }
+  if (r >= N) uq = cmake(0.0, 0.0);
+  const double quq = sum8(qt.x * uq.x + qt.y * uq.y);
+  const double den = apply_floor(sqrt(fmax(quq, 0.0)), floor_kind, eps);
+  c128 prow[8], gcol[8];  // row S of G_S; column S of G_S (entry S unused)
+  const c128 gown = rest ? cmake(q.x, -q.y) : cmake(0.0, 0.0);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const c128 u = shfl8(uq, c);
+    prow[c] = cmake(u.x / den, -u.y / den);
+    gcol[c] = shfl8(gown, c);
+  }
+  c128 *Gb = G + bin * (long long)(N * N);
+  if (!Vchain) {
+    if (live && r < N) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < N) {
+          c128 gv = cmake(r == c ? 1.0 : 0.0, 0.0);
+          if (r == S) gv = prow[c];
+          else if (c == S) gv = gown;
+          Gb[r * N + c] = gv;
+        }
+    }
+    return;
+  }
+  // ---- chained sweep: V_m <- G_S V_m G_S^H for every weight set, G <- G_S G
+  c128 *Vb = Vchain + bin * (long long)(N * N * N);
+#pragma unroll 1
+  for (int m = 0; m <= N; ++m) {  // (m == N: the accumulated transform, left product only)
+    const bool is_g = m == N;
+    if (is_g && chain_first) {
+      if (live && r < N) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c < N) {
+            c128 gv = cmake(r == c ? 1.0 : 0.0, 0.0);
+            if (r == S) gv = prow[c];
+            else if (c == S) gv = gown;
+            Gb[r * N + c] = gv;
+          }
+      }
+      break;
+    }
+    c128 *Mb = is_g ? Gb : Vb + m * N * N;
+    c128 mr[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) mr[c] = (r < N && c < N) ? Mb[r * N + c] : cmake(0.0, 0.0);
+    // left: rows r != S gain g_r M[S]; row S becomes sum_k conj(p_k) M[k]
+    wsync();
+    store_row(X, r, mr);
+    wsync();
+    c128 srow[8];
+    mul_rows(prow, X, srow);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      c128 t = mr[c];
+      cfma(t, gown, X[S * LD + c]);
+      mr[c] = r == S ? srow[c] : t;
+    }
+    wsync();
+    if (!is_g) {
+      // right: M G_S^H (column S = sum_k M[r][k] conj(prow[k]); the others gain M[r][S] conj(g_c))
+      c128 acc = cmake(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) cfma(acc, mr[k], cconj(prow[k]));
+      const c128 ms = sel(mr, S);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        c128 t = mr[c];
+        cfma(t, ms, cconj(gcol[c]));  // (gcol[S] = 0)
+        mr[c] = t;
+      }
+      put(mr, S, acc);
+    }
+    if (live && r < N) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < N) Mb[r * N + c] = mr[c];
+    }
+  }
+}
+
+}  // namespace
+
+// 16 x 1025 bins, us per launch (probe / apply), 8 lanes | a lane per bin: 8 sources 247 / 368 | 285 /
+// 472; an ILRMA-IPA iteration 7.0 | 8.05 ms.  Below 8 sources the padded 8 x 8 loses (6 sources: 4.5 |
+// 2.6 ms per iteration): the kernel is bound by its chains of dependent instructions (pivot ->
+// reciprocal -> broadcast -> update, 56 Jacobi rounds) with two waves per SIMD to interleave.  So:
+// 8 sources always (the 24 lane-per-bin instantiations there, 1 000-2 000 spilled VGPRs each, are
+// gone), and SSSPY_AMD_IPA_ROWS=<n> extends it down to n sources (tests).
+bool ipa_rows_wanted(int N) {
+  if (N == 8) return true;
+  const char *e = getenv("SSSPY_AMD_IPA_ROWS");
+  const int from = e ? atoi(e) : 0;
+  return from > 0 && N >= from && N <= 8;
+}
+
+int ipa_rows_launch(int mode, const void *Vc, void *G, long long nbins, int F, int N, int S,
+                    int normalization, int max_iter, int floor_kind, double eps, int *info,
+                    unsigned long long *newton_ws, void *Vchain, int chain_first, hipStream_t st) {
+  const dim3 grid((unsigned)((nbins + BINS - 1) / BINS)), block(256);
+  if (mode == NEWTON_FIXED)
+    hipLaunchKernelGGL((k_ipa_rows<NEWTON_FIXED>), grid, block, 0, st, (const c128 *)Vc, (c128 *)G,
+                       nbins, F, N, S, normalization, max_iter, floor_kind, eps, info, newton_ws,
+                       (c128 *)Vchain, chain_first);
+  else if (mode == NEWTON_PROBE)
+    hipLaunchKernelGGL((k_ipa_rows<NEWTON_PROBE>), grid, block, 0, st, (const c128 *)Vc, (c128 *)G,
+                       nbins, F, N, S, normalization, max_iter, floor_kind, eps, info, newton_ws,
+                       (c128 *)Vchain, chain_first);
+  else
+    hipLaunchKernelGGL((k_ipa_rows<NEWTON_APPLY>), grid, block, 0, st, (const c128 *)Vc, (c128 *)G,
+                       nbins, F, N, S, normalization, max_iter, floor_kind, eps, info, newton_ws,
+                       (c128 *)Vchain, chain_first);
+  return check_launch("k_ipa_rows");
+}
+
+}  // namespace ssspy
