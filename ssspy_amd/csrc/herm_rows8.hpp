@@ -120,13 +120,13 @@ __device__ __forceinline__ bool chol_upper(c128 (&row)[8], int r) {
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const double s = shfl8(row[k].x, k);  // the pivot, from lane k
-    const bool pos = s > 0.0;
+    // (its reciprocal square root heads every step's dependency chain: v_rsq_f64 + two Newton steps.
+    //  A pivot outside [1e-300, 1e300] counts as "not positive definite": the callers' repair /
+    //  literal routes take such matrices, as they take indefinite ones)
+    const bool pos = s > 1e-300 && s < 1e300;
     ok = ok && pos;
-    // (the pivot's square root and reciprocal head every step's dependency chain: v_rsq + Newton
-    //  inside [1e-300, 1e300], the IEEE forms outside)
     const double sp = pos ? s : 1.0;
-    const bool mid = sp > 1e-300 && sp < 1e300;
-    const double dinv = mid ? rsq2(sp) : 1.0 / sqrt(sp);
+    const double dinv = rsq2(sp);
     const double d = sp * dinv;
     c128 uk[8];
 #pragma unroll
@@ -154,8 +154,7 @@ __device__ __forceinline__ void trtri_col(const c128 *X, int c, c128 (&v)[8]) {
     c128 acc = cmake(0.0, 0.0);
 #pragma unroll
     for (int j = k + 1; j < 8; ++j) cfma(acc, X[k * LD + j], v[j]);  // (v[j] = 0 beyond c)
-    const double ukk = X[k * LD + k].x;
-    const double inv = (ukk > 1e-300 && ukk < 1e300) ? rcp2(ukk) : 1.0 / ukk;
+    const double inv = rcp2(X[k * LD + k].x);  // (a diagonal entry of a factor chol_upper accepted)
     asm volatile("" ::: "memory");
     v[k].x = (k == c) ? inv : ((k < c) ? -acc.x * inv : 0.0);
     v[k].y = (k < c) ? -acc.y * inv : 0.0;

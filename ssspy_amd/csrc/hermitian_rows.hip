@@ -109,7 +109,7 @@ __device__ __forceinline__ void store_rows(c128 *out, long long idx, int M, cons
 }
 
 // mode 0: eigenvalues (n, M) ascending and eigenvectors (n, M, M); mode 1 (to_psd): floor, rebuild
-__global__ __launch_bounds__(256) void k_eigh_rows(const c128 *__restrict__ A, double *lamb, c128 *V,
+__global__ __launch_bounds__(256, 2) void k_eigh_rows(const c128 *__restrict__ A, double *lamb, c128 *V,
                                                    long long n, int M, int mode, int floor_kind,
                                                    double eps) {
   __shared__ c128 slots[MATS * SLOT];
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_eigh_rows(const c128 *__restrict__ A, d
 }
 
 // mode 0: X^(1/2); mode 1: P diag(1 / floor(sqrt(lam))) P^H
-__global__ __launch_bounds__(256) void k_sqrtmh_rows(const c128 *__restrict__ Xin, c128 *out,
+__global__ __launch_bounds__(256, 2) void k_sqrtmh_rows(const c128 *__restrict__ Xin, c128 *out,
                                                      long long n, int M, int mode, int floor_kind,
                                                      double eps) {
   __shared__ c128 slots[MATS * SLOT];
@@ -157,7 +157,7 @@ __device__ __forceinline__ void matmul_rows(const c128 (&left)[8], const c128 (&
 }
 
 // X # Y = X^1/2 (X^-1/2 Y X^-1/2)^1/2 X^1/2;  type 1: A # B, type 2: A^-1 # B, type 3: A # B^-1
-__global__ __launch_bounds__(256) void k_gmeanmh_rows(const c128 *__restrict__ A,
+__global__ __launch_bounds__(256, 2) void k_gmeanmh_rows(const c128 *__restrict__ A,
                                                       const c128 *__restrict__ Bm, c128 *G,
                                                       long long n, int M, int type) {
   __shared__ c128 slots[MATS * SLOT];
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_gmeanmh_rows(const c128 *__restrict__ A
 
 // B = U^H U (L = U^H);  type 1: A z = lamb B z (C = U^-H A U^-1, z = U^-1 y);  type 2: A B z = lamb z
 // (C = U A U^H, z = U^-1 y);  type 3: B A z = lamb z (C = U A U^H, z = U^H y)
-__global__ __launch_bounds__(256) void k_eigh_general_rows(const c128 *__restrict__ A,
+__global__ __launch_bounds__(256, 2) void k_eigh_general_rows(const c128 *__restrict__ A,
                                                            const c128 *__restrict__ Bm, double *lamb,
                                                            c128 *Z, long long n, int M, int type,
                                                            int *info) {

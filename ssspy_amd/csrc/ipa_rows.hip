@@ -92,7 +92,7 @@ __device__ __forceinline__ bool chol_inverse_rows(c128 (&a)[8], c128 *X, int r, 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_ipa_rows(const c128 *Vc, c128 *__restrict__ G,
+__global__ __launch_bounds__(256, 2) void k_ipa_rows(const c128 *Vc, c128 *__restrict__ G,
                                                   long long nbins, int F, int N, int S,
                                                   int normalization, int max_iter, int floor_kind,
                                                   double eps, int *info,
