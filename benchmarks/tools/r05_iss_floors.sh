@@ -1,4 +1,6 @@
 #!/bin/bash
+# Floors of the fused ISS kernel: build the variants first,
+#   for v in 1 2 4 6; do benchmarks/tools/build_variant.sh issdbg$v "iss_fused=-DSSSPY_ISS_DBG=$v"; done
 cd $GRAFT_REPO_ROOT
 for v in "" issdbg1 issdbg2 issdbg4 issdbg6 ""; do
   echo "== ${v:-base}"
