@@ -245,3 +245,81 @@ def test_lds_dma_tile_index_maps():
                 pi = 4 * (c & 3) + (c >> 2)
                 byte = (q * 16 + pi) * 8 + n * 2048 + ks * 512
                 assert vl[byte // 8] == V[n, 4 * ks + q, pi]
+
+
+def test_eight_lane_jacobi_tournament_schedule():
+    """The round-robin order of herm_rows8.hpp replayed on the host.  Every round rotates the pairs
+    of POSITIONS (0,1) (2,3) (4,5) (6,7) and then position m takes the content of position
+    RR_SRC[m] (the constant is read out of the header): seven rounds must meet each of the 28 index
+    pairs exactly once and bring every index back to its place -- the kernels rely on eigenvalue k
+    and column k of the eigenvector matrix being at position k again after every sweep -- and a
+    full sweep of the rotations that schedule prescribes must converge like the cyclic Jacobi method
+    it replaces (a Hermitian 8 x 8 to 1e-14 in under 8 sweeps)."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "ssspy_amd", "csrc", "herm_rows8.hpp")).read()
+    body = re.search(r"constexpr unsigned RR_SRC = (.*?);", text, re.S).group(1)
+    word = 0
+    for term in body.replace("\n", " ").split("|"):
+        term = term.strip().strip("()")
+        if "<<" in term:
+            v, sh = term.split("<<")
+            word |= int(v.strip().rstrip("u"), 0) << int(sh.strip())
+        else:
+            word |= int(term.rstrip("u"), 0)
+    src = [(word >> (4 * m)) & 7 for m in range(8)]
+    assert sorted(src) == list(range(8)) and src[0] == 0
+
+    where = list(range(8))  # index held by each position
+    met = set()
+    for _ in range(7):
+        for k in range(4):
+            met.add(frozenset((where[2 * k], where[2 * k + 1])))
+        where = [where[src[m]] for m in range(8)]
+    assert len(met) == 28
+    assert where == list(range(8))
+
+    # the rotations themselves, as the kernel forms them (rows: J^H (A J), both triangles kept)
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((8, 8)) + 1j * rng.standard_normal((8, 8))
+    A = A + A.conj().T
+    A0 = A.copy()
+    ref = np.linalg.eigvalsh(A)
+    W = np.eye(8, dtype=complex)
+    perm = list(range(8))
+    for sweep in range(8):
+        off = np.linalg.norm(A - np.diag(np.diag(A)))
+        if off <= 1e-15 * np.linalg.norm(np.diag(A)):
+            break
+        for _ in range(7):
+            J = np.eye(8, dtype=complex)
+            for k in range(4):
+                p, q = 2 * k, 2 * k + 1
+                apq, app, aqq = A[p, q], A[p, p].real, A[q, q].real
+                mag = abs(apq)
+                if mag * mag < 1e-300:
+                    continue
+                u = apq / mag
+                tau = (aqq - app) / (2 * mag)
+                t = np.copysign(1.0, tau) / (abs(tau) + np.hypot(1.0, tau))
+                cs = 1 / np.hypot(1.0, t)
+                su = t * cs * u
+                J[p, p] = J[q, q] = cs
+                J[p, q] = su
+                J[q, p] = -np.conj(su)
+            A = J.conj().T @ A @ J
+            W = W @ J
+            P = np.zeros((8, 8))
+            for m in range(8):
+                P[src[m], m] = 1.0  # new position m <- old position src[m]
+            A = P.T @ A @ P
+            W = W @ P
+            perm = [perm[src[m]] for m in range(8)]
+        assert perm == list(range(8))
+    assert sweep < 8
+    lam = np.diag(A).real
+    np.testing.assert_allclose(np.sort(lam), ref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(W @ np.diag(lam) @ W.conj().T, A0, atol=1e-12)  # A0 = W diag(lam) W^H
+    np.testing.assert_allclose(W.conj().T @ W, np.eye(8), atol=1e-13)
