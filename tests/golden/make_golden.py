@@ -340,6 +340,51 @@ def run_custom_floor(name, *, kind, seed, N, F, T, K=4, n_iter=6, gen=gen_mixtur
     save(name, **out)
 
 
+def run_eight_lane_operators():
+    """Round 5: the reference on the sizes the device build runs with a matrix / bin on 8 lanes
+    (herm_rows8.hpp): ssspy.linalg operators at 7 x 7 and 8 x 8, update_by_ipa at 7 and 8 sources."""
+    if skipped("eight_lane_operators"):
+        return
+    from ssspy.linalg import eigh, gmeanmh, invsqrtmh, sqrtmh
+
+    out = {}
+    for M in (7, 8):
+        rng = np.random.default_rng(300 + M)
+        n = 20
+        x = rng.standard_normal((n, M, 2 * M)) + 1j * rng.standard_normal((n, M, 2 * M))
+        y = rng.standard_normal((n, M, 2 * M)) + 1j * rng.standard_normal((n, M, 2 * M))
+        A = x @ x.swapaxes(-2, -1).conj() / (2 * M)
+        B = y @ y.swapaxes(-2, -1).conj() / (2 * M)
+        H = rng.standard_normal((n, M, M)) + 1j * rng.standard_normal((n, M, M))
+        H = H + H.swapaxes(-2, -1).conj()  # indefinite
+        k = "m{}_".format(M)
+        out[k + "A"], out[k + "B"], out[k + "H"] = A, B, H
+        out[k + "sqrtmh"] = sqrtmh(A)
+        out[k + "invsqrtmh"] = invsqrtmh(A)
+        out[k + "invsqrtmh_floor"] = invsqrtmh(A, flooring_fn=functools.partial(max_flooring, eps=0.6))
+        out[k + "to_psd"] = to_psd(H)
+        out[k + "to_psd_floor"] = to_psd(H, flooring_fn=functools.partial(max_flooring, eps=0.5))
+        out[k + "to_psd_add"] = to_psd(H, flooring_fn=functools.partial(add_flooring, eps=0.25))
+        for t in (1, 2, 3):
+            out[k + "gmeanmh{}".format(t)] = gmeanmh(A, B, type=t)
+            lamb, z = eigh(A, B, type=t)
+            out[k + "eigh{}_lamb".format(t)] = lamb
+            out[k + "eigh{}_z".format(t)] = z  # (phase of each column arbitrary)
+    for N in (7, 8):
+        rng = np.random.default_rng(320 + N)
+        F, T = 33, 24  # (33 bins: a full block of 32 of the 8-lane kernel and a ragged one)
+        Y = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+        varphi = 1 / (rng.random((N, F, T)) + 0.1)
+        k = "ipa{}_".format(N)
+        out[k + "Y"], out[k + "varphi"] = Y, varphi
+        out[k + "out"] = update_by_ipa(Y.copy(), varphi)
+        out[k + "out_nonorm_it3"] = update_by_ipa(Y.copy(), varphi, normalization=False, max_iter=3)
+        out[k + "out_bcast_add"] = update_by_ipa(
+            Y.copy(), varphi[:, :1, :], flooring_fn=functools.partial(add_flooring, eps=1e-4))
+        out[k + "out_it12"] = update_by_ipa(Y.copy(), varphi, max_iter=12)
+    save("eight_lane_operators", **out)
+
+
 def run_ipa_operators():
     """update_by_ipa on random spectrograms: per-source-count cases incl. broadcast weights."""
     if skipped("ipa_operators"):
@@ -663,6 +708,8 @@ def main():
               flooring=("max", 0.3), n_iter=10)
     run_gmnmf("gmnmf_floor_m8", M=8, F=4, T=32, K=2, seed=142, gen=gen_mixture,
               flooring=("max", 0.3), n_iter=10)
+    run_gmnmf("gmnmf_m7", M=7, F=5, T=34, K=2, seed=89, gen=gen_mixture, n_iter=4)
+    run_eight_lane_operators()
     # --- IPA (iterative projection with adjustment, LQPQM solver) ---
     run_ipa_operators()
     run_ilrma("gilrma_ipa_n3", N=3, F=18, T=40, K=4, algo="IPA", seed=100, gen=gen_mixture)

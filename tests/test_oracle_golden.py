@@ -246,7 +246,7 @@ def test_pairwise_operators(N):
 
 
 GMNMF_CASES = ["gmnmf_m2", "gmnmf_m3", "gmnmf_m4_n3", "gmnmf_m2_nonorm_add", "gmnmf_part_m3",
-               "gmnmf_part_m2_n3", "gmnmf_m5", "gmnmf_m6_n3", "gmnmf_m8",
+               "gmnmf_part_m2_n3", "gmnmf_m5", "gmnmf_m6_n3", "gmnmf_m7", "gmnmf_m8",
                # eigenvalue floor of to_psd active at most points (eps = 0.3), 10 iterations
                "gmnmf_floor_m5", "gmnmf_floor_m6_n3", "gmnmf_floor_m8"]
 
@@ -305,6 +305,26 @@ def test_ipa_operator(N):
                    g["n{}_out_bcast_add".format(N)]) < 1e-11
     # twelve steps allowed: the reference's loop stops as soon as every bin has converged
     assert rel_err(update_by_ipa(Y, varphi, max_iter=12), g["n{}_out_it12".format(N)]) < 1e-11
+
+
+@pytest.mark.parametrize("N", [7, 8])
+def test_ipa_operator_seven_and_eight_sources(N):
+    """Round 5: update_by_ipa of the reference at the source counts the device build runs with a bin
+    on 8 lanes (fixture eight_lane_operators, generated by tests/golden/make_golden.py)."""
+    import warnings
+
+    from oracle.ipa import update_by_ipa
+
+    g = load_golden("eight_lane_operators")
+    Y, varphi = g["ipa{}_Y".format(N)], g["ipa{}_varphi".format(N)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert rel_err(update_by_ipa(Y, varphi), g["ipa{}_out".format(N)]) < 1e-10
+        assert rel_err(update_by_ipa(Y, varphi, normalization=False, max_iter=3),
+                       g["ipa{}_out_nonorm_it3".format(N)]) < 1e-10
+        assert rel_err(update_by_ipa(Y, varphi[:, :1, :], flooring=("add", 1e-4)),
+                       g["ipa{}_out_bcast_add".format(N)]) < 1e-10
+        assert rel_err(update_by_ipa(Y, varphi, max_iter=12), g["ipa{}_out_it12".format(N)]) < 1e-10
 
 
 @pytest.mark.parametrize("L", [1, 2, 3, 5])
