@@ -341,6 +341,9 @@ class AuxIVA(AuxIVABase):
     def _reset(self, **kwargs) -> None:
         """ref: ssspy/bss/iva.py:1687-1697."""
         super()._reset(**kwargs)
+        # (also here, not only in __call__: update_once() after a manual _bind_input() / _reset() --
+        #  the benchmarks do that, and the reference allows it -- must find the contrast code)
+        self._contrast = _device_contrast(self.contrast_fn, self.d_contrast_fn)
         self._logdet_cache = None
         self._implied = None
         B, N, F, T = self._X.shape
