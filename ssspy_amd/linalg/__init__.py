@@ -2,7 +2,9 @@
 
 Device counterparts of the reference's ``ssspy.linalg`` functions that the demixing hot path
 sits on (ssspy/linalg/_solve.py, inv.py, eigh.py): leading axes are batch axes, the trailing
-two are the matrix; one lane of a wavefront owns one matrix.
+two are the matrix; one lane of a wavefront owns one matrix, and from 7 x 7 on the Hermitian
+functions (eigh, sqrtmh, invsqrtmh, gmeanmh) spread a matrix over 8 lanes, a row per lane
+(csrc/herm_rows8.hpp).
 """
 
 from typing import Optional, Tuple, Union

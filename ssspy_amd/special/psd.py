@@ -23,7 +23,8 @@ def to_psd(
 ) -> np.ndarray:
     """Hermitise, floor the eigenvalues, rebuild, Hermitise (ref: ssspy/special/psd.py:11-71).
 
-    One lane per matrix (cyclic complex Jacobi, M <= 8).  ``flooring_fn`` as for the separators.
+    Complex Jacobi on the device, M <= 8: a lane per matrix up to 6 x 6, a matrix on 8 lanes (a row per
+    lane, csrc/hermitian_rows.hip) at 7 x 7 and 8 x 8.  ``flooring_fn`` as for the separators.
     """
     from ..utils.flooring import device_flooring
 
