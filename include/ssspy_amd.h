@@ -75,6 +75,14 @@ enum { SSSPY_SOURCE_ME = 0x100 };
 #define SSSPY_MAX_PAIRS 128 /* every pair of 16 sources: 120 */
 
 const char *ssspy_amd_version(void);
+
+/* Bumped whenever an entry point changes its argument list (a caller built against another header
+ * would pass a stream where a workspace is expected): the binding compares it with the value of
+ * the header it was written against and refuses to load a library that disagrees.
+ * 2: round 6 (ssspy_covariance_congruence_tracked added; round-5 signatures of
+ *    ssspy_ilrma_loss_workspace_bytes / ssspy_fastmnmf_diagonalizer_covariance). */
+#define SSSPY_ABI_VERSION 2
+int ssspy_abi_version(void);
 const char *ssspy_last_error(void);
 
 /* ------------------------------------------------------------------ shared operators */
@@ -100,6 +108,24 @@ int ssspy_covariance_congruence(const void *C, const void *G, void *Cout, int B,
  * is carried out once, when the output is read. */
 int ssspy_covariance_congruence_sets(const void *C, const void *G, void *Cout, int B, int F, int S,
                                      int N, void *stream);
+
+/* ssspy_covariance_congruence_sets for 2..4 sources that also reports how far the product can round
+ * from the sum over the samples it replaces.  The direct mean phi |y_r|^2 of
+ * ssspy/bss/_update_spatial_model.py:176-194 / :283-395 adds positive terms; the product cancels,
+ * eps * S_rr (S_rr = sum_kl |g_rk| |c_kl| |g_rl|) bounds its error and kappa_r = S_rr / (G C G^H)_rr
+ * is the loss of relative accuracy of that entry (infinite for a non-positive diagonal).  S == N:
+ * set n of a bin holds the statistics under source n's weights, which steer output row n only
+ * (y_n <- y_n - (V_n[n,r] / V_n[r,r]) y_r), so kappa_n = max_r kappa_r of set n weighs with that
+ * row's power p_n = g_n P g_n^H.  power (B,F,N,N): the unweighted covariance of the data G applies
+ * to.  amplification: 2 x (B,2) device doubles, zero before the first launch; the launch with
+ * `phase` adds { sum kappa_n^2 p_n, sum p_n } over bins and sets to amplification[phase & 1][b] and
+ * clears the other half for the next launch (alternate phase).
+ * eps * sqrt([b][0] / [b][1]) estimates the relative Frobenius error the route adds to mixture b's
+ * spectrogram per iteration; the separators poll the slots without waiting and return to the
+ * reference's on-Y iteration past their bound. */
+int ssspy_covariance_congruence_tracked(const void *C, const void *G, void *Cout, int B, int F,
+                                        int S, int N, const void *power, void *amplification,
+                                        int phase, void *stream);
 
 /* out (B,F,N,N) = G W per bin (out aliases neither): the filters implied by y <- G y with y = W x. */
 int ssspy_compose_filters(const void *G, const void *W, void *out, int B, int F, int N,

@@ -24,6 +24,7 @@ MAX_PAIRS = 32
 # SSSPY_MAX_SOURCES (per-N kernels: IPA, both MNMF classes, the Hermitian operators),
 # SSSPY_RT_MAX_SOURCES (run-time-N kernels: the shared operators, ILRMA and AuxIVA), SSSPY_MAX_BASIS
 MAX_SOURCES, RT_MAX_SOURCES, MAX_BASIS = 8, 16, 1024
+ABI_VERSION = 2  # SSSPY_ABI_VERSION of the include/ssspy_amd.h these prototypes mirror
 
 _p, _i, _d, _z = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
 _q = ctypes.c_longlong
@@ -31,6 +32,7 @@ _q = ctypes.c_longlong
 # name -> (restype, argtypes); mirrors include/ssspy_amd.h one to one
 PROTOTYPES = {
     "ssspy_amd_version": (ctypes.c_char_p, []),
+    "ssspy_abi_version": (_i, []),
     "ssspy_last_error": (ctypes.c_char_p, []),
     "ssspy_separate": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "ssspy_weighted_covariance": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
@@ -43,6 +45,7 @@ PROTOTYPES = {
     "ssspy_ipa_transform": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p]),
     "ssspy_covariance_congruence": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "ssspy_covariance_congruence_sets": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "ssspy_covariance_congruence_tracked": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p]),
     "ssspy_compose_filters": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "ssspy_ipa_sweep": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p]),
     "ssspy_iss2_transform": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
@@ -160,6 +163,10 @@ def load():
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes
+    if lib.ssspy_abi_version() != ABI_VERSION:
+        raise HipLibraryError(
+            "{} implements ABI version {}, this binding was written against {}: rebuild it with "
+            "`python -m ssspy_amd._build`".format(LIB_PATH, lib.ssspy_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

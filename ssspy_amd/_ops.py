@@ -92,11 +92,21 @@ def weighted_covariance(A, weight=None, kind=_lib.WEIGHT_UNIT, n_sets=1, out=Non
     return out
 
 
-def covariance_congruence(C, G, out):
+def covariance_congruence(C, G, out, tracked=None):
     """out = G C G^H per bin: C, out (B, F, N, N) or (B, F, S, N, N) with the S matrices of a bin
-    sharing its G (B, F, N, N)."""
+    sharing its G (B, F, N, N).  ``tracked`` = (power (B, F, N, N), slots (2, B, 2) f64, phase): the
+    launch also leaves its power-weighted rounding amplification per mixture in slots[phase & 1]
+    and clears the other half (2..4 sources, see the header)."""
     B, F, N = C.shape[0], C.shape[1], C.shape[-1]
     S = C.shape[2] if C.dim() == 5 else 1
+    if tracked is not None:
+        power, slots, phase = tracked
+        assert tuple(slots.shape) == (2, B, 2) and tuple(power.shape) == (B, F, N, N)
+        _lib.check(_L().ssspy_covariance_congruence_tracked(ptr(C), ptr(G), ptr(out), B, F, S, N,
+                                                            ptr(power), ptr(slots), int(phase),
+                                                            _st()),
+                   "covariance_congruence")
+        return out
     _lib.check(_L().ssspy_covariance_congruence_sets(ptr(C), ptr(G), ptr(out), B, F, S, N, _st()),
                "covariance_congruence")
     return out

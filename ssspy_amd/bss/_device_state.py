@@ -262,6 +262,85 @@ class DeviceStateMixin:
             value = np.asarray(host(value))
         setattr(self, name, value)
 
+    # -- implied-filter route: its rounding bound, watched while it runs (round 6)
+    # The ISS / ISS2 / IPA iterations that read the mixture through the filters their updates imply
+    # form their statistics as W U W^H; ssspy_covariance_congruence_tracked leaves, per mixture, the
+    # power-weighted mean square of kappa = (sum |w||u||w|) / (W U W^H)_rr of every launch in a pair
+    # of device words: eps * kappa_rms estimates the relative error the product adds to the
+    # spectrogram in that iteration, where the reference's sum over the samples adds eps.  Past the
+    # limit the separator forms Y once and goes on with the reference's on-Y iteration.
+    #
+    # The look: behind every launch its words go to a page-locked mirror (asynchronous copy, event);
+    # the NEXT iteration waits for that event before its own launch.  By then the device is past
+    # the spot in a host-bound loop, and in a device-bound one it still has that iteration's source
+    # model passes queued: no bubble either way, and the view is exactly one launch old.
+    #
+    # Calibration (benchmarks/implied_guard.py, tools/kappa_trace.py; profiles/r06_implied_guard.txt):
+    # the route's distance from the oracle after 8-12 iterations is 0.05 .. 0.5 eps * max kappa_rms
+    # where that exceeds the on-Y route's own 1e-13 .. 1e-9.  configs[1]: kappa_rms 1e3 .. 9e3 for
+    # 60 iterations of ILRMA (then 1e5 .. 4e7 as the NMF variances of silent sources reach their
+    # floor), 1e3 .. 6e3 for good with AuxIVA.  Degenerate draws (3 sources on 8 frames, 4 on 11):
+    # 1e3 .. 1e4 for 5-7 iterations, then up to x400 per iteration to 1e12 (2e-6 of the oracle).
+    # With the limit at 1e5 the one launch that can slip through a one-launch-old view stays
+    # below 4e7, i.e. adds less than 1e-8 to the spectrogram; typical runs stay where they add 1e-12.
+    _implied_amp_limit = 1.0e5
+
+    def _amp_reset(self) -> None:
+        self.__dict__["_amp"] = None
+
+    def _amp_slots(self):
+        amp = self.__dict__.get("_amp")
+        if amp is None:
+            B = self._X.shape[0]
+            amp = {"dev": dv.zeros((2, B, 2), dv.f64, self._X.device), "phase": 0, "worst": 0.0,
+                   "host": torch.zeros((2, B, 2), dtype=dv.f64, pin_memory=True),
+                   "event": (torch.cuda.Event(), torch.cuda.Event()), "seen": 0}
+            self.__dict__["_amp"] = amp
+        return amp
+
+    def _amp_tracked(self, power):
+        """The ``tracked`` argument of _ops.covariance_congruence for the next launch."""
+        amp = self._amp_slots()
+        return (power, amp["dev"], amp["phase"])
+
+    def _amp_launched(self) -> None:
+        """Behind a tracked launch: its half of the ring on its way to the mirror."""
+        amp = self._amp_slots()
+        half = amp["phase"] & 1
+        amp["host"][half].copy_(amp["dev"][half], non_blocking=True)
+        amp["event"][half].record()
+        amp["phase"] += 1
+
+    def _amp_kappa_rms(self) -> float:
+        """Largest per-mixture kappa_rms of the launches so far (waits for the last one's copy)."""
+        amp = self.__dict__.get("_amp")
+        if amp is None or amp["phase"] == 0:
+            return 0.0
+        if amp["seen"] < amp["phase"]:
+            half = (amp["phase"] - 1) & 1
+            amp["event"][half].synchronize()
+            h = amp["host"][half].numpy()
+            e2, p = h[:, 0], h[:, 1]
+            with np.errstate(all="ignore"):
+                k2 = e2 / p
+            k2 = k2[p > 0]
+            if k2.size:
+                worst = float("inf") if np.isnan(k2).any() else float(np.sqrt(k2.max()))
+                amp["worst"] = max(amp["worst"], worst)
+            amp["seen"] = amp["phase"]
+        return amp["worst"]
+
+    def _amp_exceeded(self) -> bool:
+        """Asked before an iteration on the route: did the previous launch pass the limit?"""
+        if self.__dict__.get("_amp") is None:
+            return False
+        return not (self._amp_kappa_rms() <= self._implied_amp_limit)
+
+    def _implied_iterations(self) -> int:
+        """Iterations the current call has run on the implied-filter route."""
+        amp = self.__dict__.get("_amp")
+        return 0 if amp is None else amp["phase"]
+
     # -- singular-matrix / non-convergence reporting
     def _info_tensor(self):
         """Device counters the kernels bump: [0] singular per-bin systems (the reference raises

@@ -316,8 +316,8 @@ class _MMILRMA(ILRMABase):
         super()._reset(flooring_fn=flooring_fn, **kwargs)
         self._logdet_cache = None
         self._implied = None
+        self._amp_reset()
         if (self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"] and self._X.shape[1] <= 4
-                and self._X.shape[3] >= 16 * self._X.shape[1]
                 and self._base_model[0] == _lib.SOURCE_GAUSS):
             # the filters the output state implies (output = W x), kept next to it: see
             # _update_spatial_model_implied().  Up to 4 sources, where the passes over (X, W) are
@@ -325,10 +325,10 @@ class _MMILRMA(ILRMABase):
             # only: W U W^H rounds like eps |W|^2 |U| where the direct sum rounds like eps |y|^2, and
             # the t / GGD weights 1 / |y|^(2 - beta) feed that back (the GGD ISS2 golden: 4e-10 on Y,
             # 4e-7 through the filters after 10 iterations -- both started from 1e-15 at iteration 2).
-            # At least 16 frames per source for the same reason: with 11 frames for 4 sources the
-            # covariances of the mixture are next to singular and 8 ISS2 iterations came out at 1e-7
-            # of the oracle through the filters against 1e-10 on Y (fuzz_parity.py; the median ratio
-            # over 112 draws is 1.0, every draw with >= 16 N frames below 1e-11)
+            # How far the product can round is measured by every launch that forms it and the route
+            # is left where that passes its bound (_amp_exceeded; rounds 5's fence of 16 frames per
+            # source is gone: the draw it was fitted to -- 11 frames for 4 sources, 1e-7 of the
+            # oracle after 8 ISS2 iterations through the filters -- now leaves after the second)
             self._implied = (self._state_dev("demix_filter").clone(), self._state_rev("output"))
         if self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"] and not self.record_loss:
             self.demix_filter = None  # (nothing reads the log-determinant: no tracker)
@@ -604,6 +604,14 @@ class _MMILRMA(ILRMABase):
         W = self._implied[0]
         _ops.separate(self._X, W, out=self._state()["output"]["dev"])
 
+    def _leave_implied_route(self) -> None:
+        """Form Y = W x now and go on with the iterations that rewrite it (the reference's)."""
+        W = self._implied[0]
+        self._state_dev("output")  # (runs the deferred fill)
+        if getattr(self, "_logdet_cache", None) is not None:  # (the on-Y updates move it along)
+            self._logdet_cache = (_ops.sum_logdet(W), self._state_rev("output"))
+        self._implied = None
+
     def _update_spatial_model_implied(self, flooring_fn) -> None:
         """update_spatial_model() + normalize() of the ISS / ISS2 / IPA iterations without touching Y.
         The reference keeps only the separated spectrogram and rewrites it, y <- G y
@@ -616,6 +624,9 @@ class _MMILRMA(ILRMABase):
         floor = self._resolve_floor(flooring_fn)
         if self.spatial_algorithm in _IPA:
             require_device_floor(floor, "IPA")
+        if self._amp_exceeded():
+            self._leave_implied_route()
+            return self._update_spatial_model_folded(flooring_fn)
         W = self._implied_filter()
         B, N, F, T = self._X.shape
         dev = self._X.device
@@ -626,7 +637,8 @@ class _MMILRMA(ILRMABase):
         _ops.ilrma_weighted_covariance(self._X, *self._nmf_pair(), float(self.domain), self._ws,
                                        self._ws_bytes, out=self._U, W=W, model=self._model,
                                        flooring=floor)
-        Vc = _ops.covariance_congruence(self._U, W, self._Vc)
+        Vc = _ops.covariance_congruence(self._U, W, self._Vc, tracked=self._amp_tracked(self._C()))
+        self._amp_launched()
         if self.spatial_algorithm in _ISS1:
             G = _ops.iss1_transform(Vc, floor)
         elif self.spatial_algorithm in _ISS2:

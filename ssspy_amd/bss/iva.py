@@ -105,6 +105,15 @@ class IVABase(DeviceStateMixin, IterativeMethodBase):
     def _fill_output_from_implied_filter(self) -> None:
         _ops.separate(self._X, self._implied[0], out=self._state()["output"]["dev"])
 
+    def _leave_implied_route(self) -> None:
+        """Form Y = W x now and go on with the iterations that rewrite it (the reference's)."""
+        W = self._implied[0]
+        self._state_dev("output")  # (runs the deferred fill)
+        if getattr(self, "_logdet_cache", None) is not None:
+            self._logdet_cache = (_ops.sum_logdet(W), self._state_rev("output"))
+        self._implied = None
+        self._r2_cache = None
+
     def _resolve_floor(self, flooring_fn):
         if type(flooring_fn) is str and flooring_fn == "self":
             return self._floor
@@ -347,11 +356,13 @@ class AuxIVA(AuxIVABase):
         self._logdet_cache = None
         self._implied = None
         B, N, F, T = self._X.shape
-        if self.spatial_algorithm in _ISS2 + _IPA and N <= 4 and T >= 16 * N:
+        self._amp_reset()
+        if self.spatial_algorithm in _ISS2 + _IPA and N <= 4:
             # the filters the output state implies (output = W x): the ISS2 / IPA iterations read the
             # mixture through them (_update_once_implied).  Up to 4 sources (the tuned covariance
-            # pass) and at least 16 frames per source (W U W^H rounds like eps |W|^2 |U|, the direct
-            # sum over Y like eps |y|^2: next to singular covariances lose digits, see ilrma.py)
+            # pass).  W U W^H rounds like eps |W|^2 |U|, the direct sum over Y like eps |y|^2: next
+            # to singular covariances lose digits -- every launch measures by how much and the
+            # route is left past the bound (_amp_exceeded, see ilrma.py)
             self._implied = (self._state_dev("demix_filter").clone(), self._state_rev("output"))
         if self.spatial_algorithm in ["ISS", "ISS1", "ISS2", "IPA"] and not self.record_loss:
             self.demix_filter = None  # (nothing reads the log-determinant: no tracker)
@@ -514,6 +525,9 @@ class AuxIVA(AuxIVABase):
         floor = self._resolve_floor(flooring_fn)
         if W is None or host_floor(floor) is not None or self._contrast is None:
             return False
+        if self._amp_exceeded():
+            self._leave_implied_route()
+            return False
         B, N, F, T = self._X.shape
         dev = self._X.device
         weight = self._weights(flooring_fn)  # (frame powers through _frame_power(): |W x|^2)
@@ -521,7 +535,8 @@ class AuxIVA(AuxIVABase):
         Vc = getattr(self, "_Vc_implied", None)
         if Vc is None or tuple(Vc.shape) != tuple(U.shape) or Vc.data_ptr() == U.data_ptr():
             Vc = self._Vc_implied = dv.empty(tuple(U.shape), dv.c128, dev)
-        _ops.covariance_congruence(U, W, Vc)
+        _ops.covariance_congruence(U, W, Vc, tracked=self._amp_tracked(self._C()))
+        self._amp_launched()
         if self.spatial_algorithm in _ISS2:
             G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N),
                                     floor, self._info_tensor())

@@ -91,13 +91,32 @@ __global__ __launch_bounds__(256) void k_covariance_congruence(const c128 *__res
 
 // The same with one lane per matrix and everything in registers (N <= 4: 16 + 16 loads per lane
 // instead of 24 per output element; 32 mixtures of configs[1]: 62 -> see DESIGN 4 item 44).
-template <int N>
-__global__ __launch_bounds__(256) void k_covariance_congruence_n(const c128 *__restrict__ C,
-                                                                 const c128 *__restrict__ G,
-                                                                 c128 *__restrict__ Cout,
-                                                                 long long nmats, int sets) {
-  const long long mat = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (mat >= nmats) return;
+//
+// AMP: also how far the product can round from the sum over the samples it replaces.  The diagonal of
+// the result, (G C G^H)_rr = mean phi |y_r|^2, is a sum of positive terms when taken over the
+// samples; as a product its terms cancel, and eps * S_rr with S_rr = sum_kl |g_rk| |c_kl| |g_rl|
+// bounds the rounding error (off the diagonal: <= eps * sqrt(S_rr S_cc)).  kappa_r = S_rr / (.)_rr
+// is therefore the factor by which row r's statistics -- and through the update the row of the
+// output they steer -- can lose relative accuracy.  A silent source in a loud bin has a large
+// kappa by construction (the filter is there to cancel the loud ones) and no weight in the
+// result, so the launch reports the power-weighted mean square: per mixture
+//   amp[b] = { sum kappa_n^2 p_n, sum p_n }  over bins and sets n (sets == N),
+// kappa_n = max_r kappa_r of set n's matrix -- the statistics under source n's weights, which
+// steer output row n only -- and p_n = g_n P g_n^H the power of that row (P: the unweighted
+// covariance of the data G applies to); a non-positive diagonal counts as infinite.  eps * sqrt(amp[b][0] / amp[b][1]) estimates the relative Frobenius
+// error the route adds to mixture b's spectrogram per iteration.  amp is one half of a ring of
+// two: the launch accumulates into its half (zero on entry) and clears the other for the next.
+template <int N, bool AMP>
+__global__ __launch_bounds__(256) void k_covariance_congruence_n(
+    const c128 *__restrict__ C, const c128 *__restrict__ G, c128 *__restrict__ Cout,
+    long long nmats, int sets, const c128 *__restrict__ P, double *__restrict__ amp,
+    double *__restrict__ amp_next, long long mats_per_mixture, int n_mixtures) {
+  long long mat = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (AMP && blockIdx.x == 0)
+    for (int e = threadIdx.x; e < 2 * n_mixtures; e += blockDim.x) amp_next[e] = 0.0;
+  const bool live = mat < nmats;
+  if (!AMP && !live) return;
+  if (!live) mat = nmats - 1;  // (AMP: the whole wave reaches the shuffles; the copy stores nothing)
   const c128 *Cb = C + mat * (N * N), *Gb = G + (mat / sets) * (N * N);
   c128 g[N][N], c[N][N], t[N][N];
 #pragma unroll
@@ -116,6 +135,7 @@ __global__ __launch_bounds__(256) void k_covariance_congruence_n(const c128 *__r
       for (int l = 0; l < N; ++l) cfma(a, c[k][l], cconj(g[cc][l]));
       t[k][cc] = a;
     }
+  double diag[N];
 #pragma unroll
   for (int r = 0; r < N; ++r)
 #pragma unroll
@@ -123,8 +143,56 @@ __global__ __launch_bounds__(256) void k_covariance_congruence_n(const c128 *__r
       c128 a = cmake(0.0, 0.0);
 #pragma unroll
       for (int k = 0; k < N; ++k) cfma(a, g[r][k], t[k][cc]);
-      Cout[mat * (N * N) + r * N + cc] = a;
+      if (live) Cout[mat * (N * N) + r * N + cc] = a;
+      if (AMP && r == cc) diag[r] = a.x;
     }
+  if (AMP) {
+    // (sets == N: matrix n of a bin holds the statistics under source n's weights, and every entry
+    //  of it steers output row n and no other: y_n <- y_n - (V_n[n,r] / V_n[r,r]) y_r)
+    const c128 *Pb = P + (mat / sets) * (N * N);
+    const int own = (int)(mat % sets);
+    double kmax = 0.0, pown = 0.0;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      double ag[N], s = 0.0;
+      c128 q = cmake(0.0, 0.0);  // g_r P g_r^H
+#pragma unroll
+      for (int k = 0; k < N; ++k) ag[k] = sqrt(cabs2(g[r][k]));
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        double u = 0.0;
+        c128 pg = cmake(0.0, 0.0);
+#pragma unroll
+        for (int l = 0; l < N; ++l) {
+          u = fma(sqrt(cabs2(c[k][l])), ag[l], u);
+          cfma(pg, Pb[k * N + l], cconj(g[r][l]));
+        }
+        s = fma(ag[k], u, s);
+        cfma(q, g[r][k], pg);
+      }
+      const double d = diag[r];
+      kmax = fmax(kmax, d > 0.0 ? s / d : __builtin_huge_val());
+      if (r == own) pown = fmax(q.x, 0.0);
+    }
+    double e2 = kmax * kmax * pown, ptot = pown;
+    if (!live) e2 = ptot = 0.0;
+    const long long b = mat / mats_per_mixture;
+    const long long b0 = __shfl(b, 0);
+    if (__all(b == b0)) {  // (a wave inside one mixture: one pair of atomics)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        e2 += __shfl_xor(e2, o);
+        ptot += __shfl_xor(ptot, o);
+      }
+      if ((threadIdx.x & 63) == 0) {
+        atomicAdd(amp + 2 * b, e2);
+        atomicAdd(amp + 2 * b + 1, ptot);
+      }
+    } else if (live) {
+      atomicAdd(amp + 2 * b, e2);
+      atomicAdd(amp + 2 * b + 1, ptot);
+    }
+  }
 }
 
 // out_i = G_i W_i per bin (the demixing filters an output-side update y <- G y implies)
@@ -746,7 +814,8 @@ int row_power(const void *W, const void *C, double *qbuf, int B, int F, int N, h
 
 extern "C" {
 
-const char *ssspy_amd_version(void) { return "ssspy_amd 0.1.0 (gfx950)"; }
+const char *ssspy_amd_version(void) { return "ssspy_amd 0.2.0 (gfx950)"; }
+int ssspy_abi_version(void) { return SSSPY_ABI_VERSION; }
 const char *ssspy_last_error(void) { return g_last_error; }
 
 int ssspy_separate(const void *X, const void *W, void *Y, int B, int N, int F, int T,
@@ -759,8 +828,8 @@ int ssspy_separate(const void *X, const void *W, void *Y, int B, int N, int F, i
   return check_launch("k_separate");
 }
 
-int ssspy_covariance_congruence_sets(const void *C, const void *G, void *Cout, int B, int F,
-                                     int S, int N, void *stream) {
+static int congruence_sets(const void *C, const void *G, void *Cout, int B, int F, int S, int N,
+                           const void *P, double *amp, int phase, void *stream) {
   SSSPY_REQUIRE(C && G && Cout && C != Cout && B > 0 && F > 0 && S >= 1 && N >= 1 &&
                     N <= SSSPY_RT_MAX_SOURCES,
                 "covariance_congruence: bad argument");
@@ -768,20 +837,41 @@ int ssspy_covariance_congruence_sets(const void *C, const void *G, void *Cout, i
   if (N >= 2 && N <= 4) {
     const long long nmats = nbins * S;
     const dim3 grid((unsigned)((nmats + 255) / 256)), block(256);
-    if (N == 2)
-      hipLaunchKernelGGL((k_covariance_congruence_n<2>), grid, block, 0, as_stream(stream),
-                         (const c128 *)C, (const c128 *)G, (c128 *)Cout, nmats, S);
-    if (N == 3)
-      hipLaunchKernelGGL((k_covariance_congruence_n<3>), grid, block, 0, as_stream(stream),
-                         (const c128 *)C, (const c128 *)G, (c128 *)Cout, nmats, S);
-    if (N == 4)
-      hipLaunchKernelGGL((k_covariance_congruence_n<4>), grid, block, 0, as_stream(stream),
-                         (const c128 *)C, (const c128 *)G, (c128 *)Cout, nmats, S);
+    double *mine = amp ? amp + (size_t)(phase & 1) * 2 * B : nullptr;
+    double *next = amp ? amp + (size_t)(~phase & 1) * 2 * B : nullptr;
+#define SSSPY_CONGRUENCE(NN)                                                                      \
+  if (N == NN) {                                                                                  \
+    if (amp)                                                                                      \
+      hipLaunchKernelGGL((k_covariance_congruence_n<NN, true>), grid, block, 0, as_stream(stream), \
+                         (const c128 *)C, (const c128 *)G, (c128 *)Cout, nmats, S,                \
+                         (const c128 *)P, mine, next, (long long)F * S, B);                       \
+    else                                                                                          \
+      hipLaunchKernelGGL((k_covariance_congruence_n<NN, false>), grid, block, 0,                  \
+                         as_stream(stream), (const c128 *)C, (const c128 *)G, (c128 *)Cout, nmats, \
+                         S, (const c128 *)nullptr, mine, next, (long long)F * S, B);              \
+  }
+    SSSPY_CONGRUENCE(2) SSSPY_CONGRUENCE(3) SSSPY_CONGRUENCE(4)
+#undef SSSPY_CONGRUENCE
     return check_launch("k_covariance_congruence_n");
   }
+  SSSPY_REQUIRE(!amp, "covariance_congruence: the amplification is tracked for 2..4 sources");
   hipLaunchKernelGGL(k_covariance_congruence, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      as_stream(stream), (const c128 *)C, (const c128 *)G, (c128 *)Cout, nbins, S, N);
   return check_launch("k_covariance_congruence");
+}
+
+int ssspy_covariance_congruence_sets(const void *C, const void *G, void *Cout, int B, int F,
+                                     int S, int N, void *stream) {
+  return congruence_sets(C, G, Cout, B, F, S, N, nullptr, nullptr, 0, stream);
+}
+
+int ssspy_covariance_congruence_tracked(const void *C, const void *G, void *Cout, int B, int F,
+                                        int S, int N, const void *power, void *amplification,
+                                        int phase, void *stream) {
+  SSSPY_REQUIRE(amplification && power && S == N,
+                "covariance_congruence_tracked: needs the amplification slots, the power and one "
+                "set per source");
+  return congruence_sets(C, G, Cout, B, F, S, N, power, (double *)amplification, phase, stream);
 }
 
 int ssspy_covariance_congruence(const void *C, const void *G, void *Cout, int B, int F, int N,

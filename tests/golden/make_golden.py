@@ -793,6 +793,19 @@ def main():
     run_iva("auxlap_ip2_n9", N=9, F=8, T=72, algo="IP2", contrast="laplace", seed=171, n_iter=4)
     run_iva("auxlap_iss2_n12", N=12, F=6, T=96, algo="ISS2", contrast="laplace", seed=172,
             gen=gen_mixture, n_iter=4)
+    # --- 3 / 4 sources with at least 16 frames per source (round 6): the device build runs these
+    #     ISS / ISS2 / IPA iterations through the filters the updates imply (W <- G W, statistics
+    #     W U W^H) -- reference vectors for that route, ISS1 on a batch-sized number of bins
+    run_ilrma("gilrma_iss1_n4_t80", N=4, F=33, T=80, K=5, algo="ISS1", seed=180, gen=gen_mixture)
+    run_ilrma("gilrma_iss2_n4_t72", N=4, F=18, T=72, K=4, algo="ISS2", seed=181, gen=gen_mixture)
+    run_ilrma("gilrma_iss2_n3_t64", N=3, F=17, T=64, K=3, algo="ISS2", seed=182)
+    run_ilrma("gilrma_ipa_n3_t56", N=3, F=18, T=56, K=4, algo="IPA", seed=183, gen=gen_mixture)
+    run_ilrma("gilrma_ipa_n4_t72", N=4, F=16, T=72, K=4, algo="IPA", seed=184, gen=gen_mixture)
+    run_iva("auxlap_iss2_n4_t72", N=4, F=20, T=72, algo="ISS2", contrast="laplace", seed=185,
+            gen=gen_mixture)
+    run_iva("auxlap_ipa_n3_t60", N=3, F=20, T=60, algo="IPA", contrast="laplace", seed=186,
+            gen=gen_mixture)
+    run_iva("auxgauss_ipa_n4_t70", N=4, F=16, T=70, algo="IPA", contrast="gauss", seed=187)
     # --- operators ---
     run_operators()
     run_pairwise_operators()

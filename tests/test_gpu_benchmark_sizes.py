@@ -186,6 +186,115 @@ def test_configs3_full_size_100_iterations_against_oracle():
     assert rel_err(Y, ref.separate(ref.input)) < 1e-6
 
 
+# -- the implied-filter route at the shapes bench.py's `pairwise_ipa` legs quote (round 6) ---------
+# Since round 5 the ISS1 / ISS2 / IPA iterations of GaussILRMA (batches; ISS2 / IPA also on one
+# mixture) and the ISS2 / IPA iterations of AuxIVA at up to 4 sources carry the filters the updates
+# imply instead of Y (W <- G W, statistics W U W^H, Y formed on read).  These are the oracle
+# comparisons of exactly that route at N = 4, F = 1025, T = 512: one mixture for 100 iterations and
+# the 32-mixture batch of the bench legs for 20.
+IMPLIED_LEGS = [("ilrma", "ISS1"), ("ilrma", "ISS2"), ("ilrma", "IPA"), ("iva", "ISS2"), ("iva", "IPA")]
+BATCH_PICKS = (0, 17, 31)
+
+
+@pytest.fixture(scope="module")
+def oracle_runs():
+    """Every oracle run of the implied-filter tests, started at once in spawned processes (the 100
+    iteration runs take 1-3 minutes each on the host; the device tests overlap with them)."""
+    import concurrent.futures
+    import multiprocessing
+
+    import _oracle_jobs
+
+    jobs = [(fam, algo, 1000, 100) for fam, algo in IMPLIED_LEGS]
+    jobs += [(fam, algo, 1000 + b, 20) for fam, algo in IMPLIED_LEGS for b in BATCH_PICKS]
+    workers = max(1, min(len(jobs), (os.cpu_count() or 2) // 2))
+    pool = concurrent.futures.ProcessPoolExecutor(workers, mp_context=multiprocessing.get_context("spawn"))
+    futures = {job: pool.submit(_oracle_jobs.run, *job) for job in jobs}
+    yield futures
+    pool.shutdown(wait=False, cancel_futures=True)
+
+
+def _separator(family, algo, **kw):
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.bss.iva import AuxLaplaceIVA
+
+    if family == "ilrma":
+        return GaussILRMA(n_basis=16, spatial_algorithm=algo, **kw)
+    return AuxLaplaceIVA(spatial_algorithm=algo, **kw)
+
+
+@pytest.mark.parametrize("family,algo", IMPLIED_LEGS)
+def test_implied_filter_route_100_iterations_against_oracle(family, algo, oracle_runs):
+    """The pinned configs[1] mixture, 100 iterations of GaussILRMA-ISS1 / ISS2 / IPA and
+    AuxLaplaceIVA-ISS2 / IPA against 100 oracle iterations (ssspy/bss/ilrma.py:1635-1908,
+    ssspy/bss/iva.py:1968-2175): loss list 1e-9, spectrograms after projection back 1e-6.
+    ISS1 on ONE mixture takes the fused sweep on Y by default; it is forced onto the statistics
+    (the batch route) here, and checked on its default below."""
+    import warnings
+
+    import _oracle_jobs
+
+    X = _pinned_mixture("configs1_seed1000_N4_F1025_T512")
+    m = _separator(family, algo)
+    kw = {}
+    if family == "ilrma":
+        kw["basis"], kw["activation"] = _oracle_jobs.initial(1000)
+    forced = family == "ilrma" and algo == "ISS1"
+    if forced:
+        os.environ["SSSPY_AMD_ISS1_STATISTICS"] = "1"
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            Y = m(X, n_iter=100, **kw)
+    finally:
+        if forced:
+            del os.environ["SSSPY_AMD_ISS1_STATISTICS"]
+    # (the NMF variances of silent sources reach their floor after 60-70 iterations of this mixture
+    #  and the route's rounding bound with them: ILRMA then goes on on Y, see _amp_exceeded)
+    assert m._implied_iterations() >= 50, "the run left the implied-filter route early"
+    if family == "iva":
+        assert m._implied is not None
+    loss_ref, Y_ref = oracle_runs[(family, algo, 1000, 100)].result()
+    assert len(m.loss) == 101
+    np.testing.assert_allclose(m.loss, loss_ref, rtol=LOSS_RTOL)
+    assert rel_err(Y, Y_ref) < 1e-6
+
+
+def test_implied_filter_route_batch_of_32_against_oracle(oracle_runs):
+    """The workload of bench.py's `pairwise_ipa.*.b32` legs: the first 32 mixtures of the headline
+    batch (seeds 1000..1031), 20 iterations of the five implied-filter iterations as ONE batch each;
+    mixtures 0, 17 and 31 against 20 oracle iterations (loss 1e-9, spectrograms 1e-7)."""
+    import warnings
+
+    import torch
+
+    import _oracle_jobs
+    from ssspy_amd.utils.dataset import nmf_mixture_batch, sha256_of
+
+    B, N, F, T = 32, 4, 1025, 512
+    pins = json.load(open(os.path.join(HERE, "golden", "input_sha256.json")))
+    Xh = nmf_mixture_batch(1000, B, N, F, T)
+    assert sha256_of(Xh[0]) == pins["configs1_seed1000_N4_F1025_T512"]["sha256"]
+    init = [_oracle_jobs.initial(1000 + b) for b in range(B)]
+    basis, act = np.stack([i[0] for i in init]), np.stack([i[1] for i in init])
+    X = torch.from_numpy(Xh).to("cuda")
+    for family, algo in IMPLIED_LEGS:
+        m = _separator(family, algo)
+        kw = dict(basis=basis, activation=act) if family == "ilrma" else {}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            Y = m(X, n_iter=20, **kw)
+        assert m._implied is not None, (family, algo)
+        loss = np.asarray(m.loss)
+        assert loss.shape == (21, B)
+        for b in BATCH_PICKS:
+            loss_ref, Y_ref = oracle_runs[(family, algo, 1000 + b, 20)].result()
+            np.testing.assert_allclose(loss[:, b], loss_ref, rtol=LOSS_RTOL, err_msg=str((family, algo, b)))
+            assert rel_err(Y[b], Y_ref) < 1e-7, (family, algo, b)
+        del m, Y
+        torch.cuda.empty_cache()
+
+
 def test_configs3_batch_of_32_equals_single_mixture_runs():
     """configs[3] at the batch bench.py and the profiles quote (32 full-size mixtures, seeds
     4000..4031): three iterations of the batched update_once() -- whole rounds plus a split tail of

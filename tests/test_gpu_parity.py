@@ -32,6 +32,9 @@ ILRMA_CASES = [
     "gilrma_mdp_ip1_n3", "gilrma_mdp_iss1_n2", "gilrma_pbnorm_ip1_n3", "gilrma_pbnorm_iss1_n2_p1",
     "gilrma_ip1_n10", "gilrma_iss1_n9_p1",  # above 8 sources: the run-time-N kernels (wide_n.hip)
     "gilrma_ip2_n9", "gilrma_iss2_n10",
+    # 3 / 4 sources, >= 16 frames per source (round 6: the implied-filter route of the device build)
+    "gilrma_iss1_n4_t80", "gilrma_iss2_n4_t72", "gilrma_iss2_n3_t64", "gilrma_ipa_n3_t56",
+    "gilrma_ipa_n4_t72",
 ]
 IVA_CASES = [
     "auxlap_ip1_n2", "auxlap_ip1_n4", "auxlap_iss1_n2", "auxlap_iss1_n8", "auxgauss_ip1_n3",
@@ -40,6 +43,7 @@ IVA_CASES = [
     "auxlap_mdp_iss1_n2",
     "auxlap_iss1_n12", "auxlap_ip1_n9", "auxgauss_ip1_n16_mdp",  # above 8 sources (wide_n.hip)
     "auxlap_ip2_n9", "auxlap_iss2_n12",
+    "auxlap_iss2_n4_t72", "auxlap_ipa_n3_t60", "auxgauss_ipa_n4_t70",  # (round 6, see above)
 ]
 
 
@@ -328,6 +332,74 @@ def test_ilrma_folded_power_normalization_equals_three_pass_form(algo, N, B, mon
             loss = np.asarray(m.loss)
             np.testing.assert_allclose(loss if B == 1 else loss[:, 0], ref.loss, rtol=LOSS_RTOL)
             assert err(Y if B == 1 else Y[0], Yr) < 1e-7
+
+
+@pytest.mark.parametrize("family,algo,N,F,T,seed", [
+    ("ilrma", "ISS2", 3, 33, 8, 0), ("ilrma", "ISS2", 3, 33, 8, 3), ("ilrma", "ISS2", 4, 31, 11, 6),
+    ("ilrma", "IPA", 4, 31, 11, 4), ("iva", "ISS2", 4, 31, 64, "ill"), ("iva", "IPA", 3, 24, 48, "ill")])
+def test_implied_filter_route_is_left_past_its_rounding_bound(family, algo, N, F, T, seed, monkeypatch):
+    """Round 6: the implied-filter route forms its statistics as W U W^H, which can round by
+    eps * kappa where the reference's sum over the samples rounds by eps; every launch measures the
+    power-weighted kappa_rms and the separators return to the on-Y iteration past 1e5
+    (_device_state.py: _amp_exceeded) -- round 5 had a fence of 16 frames per source fitted to a
+    fuzz draw instead.  Badly conditioned draws (3 sources on 8 frames, 4 on 11: through the filters
+    alone they end 1e-6 / 6e-9 from the oracle after 12 / 8 iterations, profiles/r06_implied_guard.txt)
+    and AuxIVA on a mixture with two channels equal to 1e-3 (the advisor's boundary case): the
+    default run must (i) leave the route where the bound is passed, (ii) match the oracle like the
+    on-Y route does; with the guard off the measured kappa_rms is above the limit."""
+    import torch
+
+    from oracle.ilrma import GaussILRMAOracle
+    from oracle.iva import AuxIVAOracle
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.bss.iva import AuxLaplaceIVA
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    K, n_iter = 8, 12
+    if seed == "ill":
+        X = nmf_mixture(7100, N, F, T)
+        X[1] = X[0] + 1e-3 * X[1]
+        rng = np.random.default_rng(0)
+    else:
+        X = nmf_mixture(7000 + seed, N, F, T)
+        rng = np.random.default_rng(seed)
+    kw = dict(basis=rng.random((N, F, K)), activation=rng.random((N, K, T))) if family == "ilrma" else {}
+
+    def run(limit=None, on_y=False):
+        m = (GaussILRMA(n_basis=K, spatial_algorithm=algo) if family == "ilrma"
+             else AuxLaplaceIVA(spatial_algorithm=algo))
+        if limit is not None:
+            m._implied_amp_limit = limit
+        if on_y:
+            monkeypatch.setenv("SSSPY_AMD_NO_IMPLIED_FILTER", "1")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            Y = m(X, n_iter=n_iter, **{k: v.copy() for k, v in kw.items()})
+        if on_y:
+            monkeypatch.delenv("SSSPY_AMD_NO_IMPLIED_FILTER")
+        torch.cuda.synchronize()
+        return m, Y
+
+    ref = (GaussILRMAOracle(n_basis=K, spatial_algorithm=algo) if family == "ilrma"
+           else AuxIVAOracle(spatial_algorithm=algo, contrast="laplace"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Yr = ref.run(X, n_iter=n_iter, **{k: v.copy() for k, v in kw.items()})
+    m_y, Y_y = run(on_y=True)
+    m_g, Y_g = run()
+    m_u, Y_u = run(limit=float("inf"))
+    e_y, e_g = rel_err(Y_y, Yr), rel_err(Y_g, Yr)
+    limit, kappa = type(m_u)._implied_amp_limit, m_u._amp_kappa_rms()
+    print("kappa_rms {:.1e}; from the oracle: on Y {:.1e}, default {:.1e} ({} iterations through the "
+          "filters), guard off {:.1e}".format(kappa, e_y, e_g, m_g._implied_iterations(),
+                                              rel_err(Y_u, Yr)))
+    assert m_u._implied is not None
+    if T <= 8:
+        assert kappa > limit
+    if kappa > limit:
+        assert m_g._implied is None and 0 < m_g._implied_iterations() < n_iter
+    assert e_g < max(10 * e_y, 1e-11), (e_g, e_y, rel_err(Y_u, Yr))
+    np.testing.assert_allclose(m_g.loss, ref.loss, rtol=max(1e3 * e_y, LOSS_RTOL))
 
 
 @pytest.mark.parametrize("model,algo", [(("gauss", None), "ISS1"), (("gauss", None), "IPA"),
