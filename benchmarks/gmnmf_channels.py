@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GaussMNMF per-iteration time against the number of channels (M = N), F = 513, T = 256, K = 8,
 `batch` mixtures; and the states after 3 iterations of the packed per-point kernels against the
-full-storage ones (SSSPY_AMD_GMNMF_FULL=1, one child process run first).
+full-storage ones (rounds 4-5; the switch went in round 6, the column is in profiles/r04_gmnmf_channels.txt).
 GM_WARM=<n>: iterations before the states are compared and the 6 timed iterations start (default 3).
 
     python benchmarks/gmnmf_channels.py [batch] [M ...]
@@ -42,33 +42,14 @@ def run(B, M, iters=6):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--child":
-        B, out = int(sys.argv[2]), sys.argv[3]
-        for M in [int(a) for a in sys.argv[4:]]:
-            ms, state = run(B, M)
-            np.savez(out % M, ms=ms, **state)
-        sys.exit(0)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     Ms = [int(a) for a in sys.argv[2:]] or [2, 3, 4, 5, 6, 7, 8]
-    # the full-storage sweep first, in ONE child process that is gone before this process touches
-    # the device (two processes taking turns on the GPU disturbed the timings of the second)
-    tmp = "/tmp/gmnmf_full_%d.npz"
-    env = dict(os.environ, SSSPY_AMD_GMNMF_FULL="1")
-    subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", str(B), tmp]
-                          + [str(M) for M in Ms], env=env)
     warm = os.environ.get("GM_WARM", "3")
     base = None
     for M in Ms:
         ms, state = run(B, M)
-        ref = np.load(tmp % M)
-        dev = {k: float(np.max(np.abs(state[k] - ref[k])) / max(np.max(np.abs(ref[k])), 1e-300))
-               for k in state}
         if M == 4:
             base = ms
         print(json.dumps({"channels": M, "batch": B, "timed_after_iterations": int(warm),
                           "ms_per_iter": round(ms, 3),
-                          "full_storage_ms_per_iter": round(float(ref["ms"]), 3),
-                          "speedup": round(float(ref["ms"]) / ms, 2),
-                          "vs_4_channels": round(ms / base, 2) if base else None,
-                          "max_rel_dev_of_the_states": {k: float("%.2e" % v)
-                                                        for k, v in dev.items()}}), flush=True)
+                          "vs_4_channels": round(ms / base, 2) if base else None}), flush=True)

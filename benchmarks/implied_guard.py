@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from oracle.ilrma import GaussILRMAOracle  # noqa: E402
 from oracle.iva import AuxIVAOracle  # noqa: E402
+from ssspy_amd import _routes  # noqa: E402
 from ssspy_amd.bss.ilrma import GaussILRMA  # noqa: E402
 from ssspy_amd.bss.iva import AuxLaplaceIVA  # noqa: E402
 from ssspy_amd.utils.dataset import nmf_mixture  # noqa: E402
@@ -61,13 +62,11 @@ def main():
                 kappa = m2._amp_kappa_rms()
                 m3 = make()
                 m3._implied_amp_limit = 0.0  # leaves at the second iteration
-                os.environ["SSSPY_AMD_NO_IMPLIED_FILTER"] = "1"
-                Yy = m3(X, n_iter=n_iter, **{k: v.copy() for k, v in kw.items()})
-                del os.environ["SSSPY_AMD_NO_IMPLIED_FILTER"]
+                with _routes.override(implied_filter=False):
+                    Yy = m3(X, n_iter=n_iter, **{k: v.copy() for k, v in kw.items()})
                 print(family, algo, N, F, T, seed, "| %.1e %s | %.1e %.1e | %.1e" % (
                     rel(Yg, Yr), left, rel(Yu, Yr), kappa, rel(Yy, Yr)), flush=True)
             except Exception as exc:
-                os.environ.pop("SSSPY_AMD_NO_IMPLIED_FILTER", None)
                 print(family, algo, N, F, T, seed, "EXC", type(exc).__name__, str(exc)[:80], flush=True)
     # the benchmark shape, 100 iterations: implied route (guard off) against the on-Y route
     import torch
@@ -82,15 +81,11 @@ def main():
                 m = (GaussILRMA(n_basis=K, spatial_algorithm=algo) if family == "ilrma"
                      else AuxLaplaceIVA(spatial_algorithm=algo))
                 m._implied_amp_limit = float("inf")
-                os.environ["SSSPY_AMD_ISS1_STATISTICS"] = "1"
-                if not implied:
-                    os.environ["SSSPY_AMD_NO_IMPLIED_FILTER"] = "1"
                 trace = []
                 m.callbacks = [lambda mm: trace.append(mm._amp_kappa_rms())]
-                Y = m(X, n_iter=100, **{k: v.copy() for k, v in kw.items()})
+                with _routes.override(iss1_statistics=True, implied_filter=implied):
+                    Y = m(X, n_iter=100, **{k: v.copy() for k, v in kw.items()})
                 torch.cuda.synchronize()
-                os.environ.pop("SSSPY_AMD_NO_IMPLIED_FILTER", None)
-                os.environ.pop("SSSPY_AMD_ISS1_STATISTICS", None)
                 res.append((Y, np.asarray(m.loss), m._amp_kappa_rms(), trace, m._implied_iterations()))
             print("full-size 100 it", family, algo, seed, "implied iterations", res[0][4], "| implied vs on-Y: Y %.1e loss %.1e | kappa_rms %.2e | trace %s" % (
                 rel(res[0][0], res[1][0]), float(np.max(np.abs(res[0][1] / res[1][1] - 1))), res[0][2],

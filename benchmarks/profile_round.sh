@@ -42,7 +42,6 @@ python benchmarks/iva_lines.py >> $out/single.txt 2>&1
 # energy per byte of the Infinity Cache, the headline in cache-sized sub-batches
 python benchmarks/tools/mnmf_steps.py 32 > $out/mnmf_steps.txt 2>/dev/null
 python benchmarks/tools/mnmf_steps.py 128 >> $out/mnmf_steps.txt 2>/dev/null
-SSSPY_AMD_MNMF_NO_GLDS=1 python benchmarks/tools/mnmf_steps.py 32 2>/dev/null | sed 's/^/register-fed passes (SSSPY_AMD_MNMF_NO_GLDS): /' >> $out/mnmf_steps.txt
 for leg in ilrma_ip2 ilrma_iss1 ilrma_iss2 ilrma_ipa auxiva_ip2 auxiva_iss2 auxiva_ipa fmnmf_ip2; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/legs/$leg -- python benchmarks/tools/leg_run.py $leg 32 10 > $out/legs/$leg.log 2>&1
   f=$(find $out/legs/$leg -name '*kernel_stats.csv' | head -1)

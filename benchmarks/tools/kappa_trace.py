@@ -17,6 +17,7 @@ for family, algo, N, F, T, seed, n_iter in [("ilrma", "ISS2", 3, 33, 8, 0, 12), 
     kw = dict(basis=rng.random((N, F, K)), activation=rng.random((N, K, T)))
     m = GaussILRMA(n_basis=K, spatial_algorithm=algo, record_loss=False)
     m._implied_amp_limit = float("inf")
+    m._amp_every_launch = True
     trace = []
     class M(type(m)):
         pass

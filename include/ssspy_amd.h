@@ -442,11 +442,19 @@ int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int B, int F, i
  * (B,F,N,N) <- G_{N-1} ... G_0.  The caller applies ssspy_separate(Y, G) once: three passes over Y per
  * sweep (weights, covariance, separate) instead of 3 N.  The weights are those of the sweep's start
  * for every source, as in the reference (_update_spatial_model.py:436-445: varphi is an argument).
- * Other arguments as ssspy_ipa_transform.
+ * Other arguments as ssspy_ipa_transform, except newton_ws: ssspy_ipa_sweep_newton_words(B, N) words.
  * replaces: ssspy/bss/_update_spatial_model.py:398-513 (update_by_ipa, the loop over sources). */
 int ssspy_ipa_sweep(void *Vc, void *G, int B, int F, int N, int normalization, int max_iter,
                     int floor_kind, double floor_eps, int *info, void *newton_ws,
                     int *not_converged, void *stream);
+/* 64-bit words ssspy_ipa_sweep's newton_ws must hold: a vote word and an arrival counter per
+ * (mixture, source step).  Up to 4 sources the sweep is ONE launch (round 6): a workgroup walks
+ * the N source steps of its 64 bins and meets the mixture's other workgroups at every Newton vote
+ * instead of ending the kernel there (4 launches per source step before). */
+size_t ssspy_ipa_sweep_newton_words(int B, int N);
+/* Development aid: how many of those in-kernel meetings gave up waiting since the library was
+ * loaded (0 unless a launch is broken; synchronises).  -1: the query itself failed. */
+int ssspy_debug_barrier_timeouts(void);
 
 /* ---- partitioning (latent variables): basis (B,F,K), activation (B,K,T), latent (B,N,K) with
  * R_nij = sum_k z_nk t_ik v_kj (ssspy/bss/ilrma.py:297-327).  Every entry point above that takes

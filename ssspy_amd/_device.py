@@ -5,6 +5,7 @@ arithmetic kernel on the hot path is in libssspy_amd.so.
 """
 
 import threading
+import weakref
 
 import numpy as np
 import torch
@@ -62,19 +63,49 @@ def to_device(array, dtype=None, dev=None):
 # goes into a page-locked block instead (25 GB/s) and the NumPy array handed out IS that block:
 # torch's caching host allocator takes it back when the array dies and hands it to the next call,
 # so only the first call pays for the page-locking.
+# Page-locked memory cannot be swapped and the allocator rounds a block up to a power of two, so a
+# caller who keeps every result (``outs = [m(X) for X in dataset]``) would pin up to twice the data
+# (round-5 advisor finding).  The blocks alive in callers' hands are counted (rounded size, released
+# by a finalizer when the array dies) and capped at _PINNED_OUTSTANDING_CAP; past the cap -- i.e.
+# when results are being hoarded rather than consumed -- downloads are ordinary pageable arrays.
 _PINNED_DOWNLOAD_BYTES = (1 << 20, 1 << 28)
+_PINNED_OUTSTANDING_CAP = 1 << 30
+_pinned_lock = threading.Lock()
+_pinned_outstanding = [0]
+
+
+def _pinned_release(nbytes):
+    with _pinned_lock:
+        _pinned_outstanding[0] -= nbytes
+
+
+def pinned_outstanding_bytes():
+    """Page-locked bytes (as the host allocator rounds them) held by arrays ``to_host`` handed out."""
+    return _pinned_outstanding[0]
 
 
 def to_host(tensor):
     t = tensor.detach()
     nbytes = t.numel() * t.element_size()
     if t.is_cuda and _PINNED_DOWNLOAD_BYTES[0] <= nbytes <= _PINNED_DOWNLOAD_BYTES[1]:
+        rounded = 1 << (nbytes - 1).bit_length()
+        with _pinned_lock:
+            fits = _pinned_outstanding[0] + rounded <= _PINNED_OUTSTANDING_CAP
+            if fits:
+                _pinned_outstanding[0] += rounded
+        if not fits:
+            return t.cpu().numpy()
         try:
             host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         except RuntimeError:  # (no page-locked memory left: the plain copy still works)
+            _pinned_release(rounded)
             return t.cpu().numpy()
         host.copy_(t)
-        return host.numpy()
+        out = host.numpy()
+        # (views and snapshots of `out` keep it alive through .base; the block goes back to torch's
+        #  host allocator when the last of them dies)
+        weakref.finalize(out, _pinned_release, rounded)
+        return out
     return t.cpu().numpy()
 
 

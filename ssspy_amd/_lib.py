@@ -48,6 +48,8 @@ PROTOTYPES = {
     "ssspy_covariance_congruence_tracked": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p]),
     "ssspy_compose_filters": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "ssspy_ipa_sweep": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p]),
+    "ssspy_ipa_sweep_newton_words": (_z, [_i, _i]),
+    "ssspy_debug_barrier_timeouts": (_i, []),
     "ssspy_iss2_transform": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
     "ssspy_update_by_ip2_deferred": (_i, [_p, _p, _i, _p, _i, _i, _i, _p, _p, _p]),
     "ssspy_iss2_transform_deferred": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),

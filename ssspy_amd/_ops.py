@@ -5,7 +5,7 @@ synchronises with the device.
 """
 
 from . import _device as dv
-from . import _lib
+from . import _lib, _routes
 from ._device import ptr
 
 
@@ -311,19 +311,11 @@ def update_by_ipa(Y, weight, kind, normalization, max_iter, flooring, info=None,
     the sweep (ref: _update_spatial_model.py:436-445), so the covariances the reference recomputes
     from the updated spectrogram before every source step are G V G^H of the previous ones: one
     weighted covariance, the N steps on the per-bin statistics, one Y <- G Y (round 5; three passes
-    over Y instead of 3 N).  SSSPY_AMD_IPA_PER_SOURCE=1 keeps the literal per-source passes (A / B).
+    over Y instead of 3 N).
     Vc: the weighted covariances of Y when the caller has formed them already (then `weight` is not
     read; overwritten)."""
     B, N = Y.shape[0], Y.shape[1]
-    newton_ws = dv.empty((B,), dv.i64, Y.device)
-    if Vc is None and _os.environ.get("SSSPY_AMD_IPA_PER_SOURCE"):
-        Vc = G = None
-        for s in range(N):
-            Vc = weighted_covariance(Y, weight, kind, N, out=Vc)
-            G = ipa_transform(Vc, s, normalization, max_iter, flooring, info, out=G,
-                              newton_ws=newton_ws, not_converged=not_converged)
-            separate(Y, G, out=Y)
-        return None if frame_power else Y
+    newton_ws = dv.empty((int(_L().ssspy_ipa_sweep_newton_words(B, N)),), dv.i64, Y.device)
     if Vc is None:
         Vc = weighted_covariance(Y, weight, kind, N)
     G = ipa_sweep(Vc, normalization, max_iter, flooring, info, newton_ws=newton_ws,
@@ -685,7 +677,7 @@ def fastmnmf_update(X, C, Q, D, basis, activation, steps, flooring, ws, ws_bytes
 def fastmnmf_handover(B, N, M, F, T, K, dev):
     """The |Q x|^2 hand-over buffer of ssspy_fastmnmf_update_handover, or None for shapes without it."""
     n = _L().ssspy_fastmnmf_handover_doubles(B, N, M, F, T, K)
-    if not n or _os.environ.get("SSSPY_AMD_NO_HANDOVER"):
+    if not n or not _routes.get("handover"):
         return None
     return _workspace(8 * n, dev)[0]
 

@@ -281,9 +281,17 @@ class DeviceStateMixin:
     # 60 iterations of ILRMA (then 1e5 .. 4e7 as the NMF variances of silent sources reach their
     # floor), 1e3 .. 6e3 for good with AuxIVA.  Degenerate draws (3 sources on 8 frames, 4 on 11):
     # 1e3 .. 1e4 for 5-7 iterations, then up to x400 per iteration to 1e12 (2e-6 of the oracle).
-    # With the limit at 1e5 the one launch that can slip through a one-launch-old view stays
-    # below 4e7, i.e. adds less than 1e-8 to the spectrogram; typical runs stay where they add 1e-12.
-    _implied_amp_limit = 1.0e5
+    # Random 4 x 4 mixing alone puts kappa_rms at 1e3 .. 2e4 for nine mixtures in ten and at 1.2e5
+    # for one of the 128 of the bench batch (tools/kappa_batch.py), from the second iteration on and
+    # for good -- with no measurable effect (6e-11 from the oracle after 8 iterations through the
+    # filters against 3e-11 on Y).  The limit is 1e6: what the route adds per iteration stays below
+    # 1e-10 of the spectrogram, and the launch that can slip through a one-launch-old view (x400)
+    # adds 2e-9 .. 2e-8 once.  A batch leaves the route as a whole when one of its mixtures passes.
+    # How often the host looks: after every launch while kappa moves (more than x1.5 between looks)
+    # or is within two decades of the limit, else after every fourth -- the degenerate draws climb
+    # by x1.1, 1.3, 2, 2, 2.5, 7, 14, 60, 300 per iteration, so the quiet phase ends well below it.
+    _implied_amp_limit = 1.0e6
+    _amp_every_launch = False  # (the calibration tools look after every launch)
 
     def _amp_reset(self) -> None:
         self.__dict__["_amp"] = None
@@ -292,54 +300,74 @@ class DeviceStateMixin:
         amp = self.__dict__.get("_amp")
         if amp is None:
             B = self._X.shape[0]
+            host = torch.zeros((2, B, 2), dtype=dv.f64, pin_memory=True)
             amp = {"dev": dv.zeros((2, B, 2), dv.f64, self._X.device), "phase": 0, "worst": 0.0,
-                   "host": torch.zeros((2, B, 2), dtype=dv.f64, pin_memory=True),
-                   "event": (torch.cuda.Event(), torch.cuda.Event()), "seen": 0}
+                   "host": host, "np": host.numpy(), "last": 0.0, "next_look": 1, "pending": None, "launches": 0,
+                   "event": (torch.cuda.Event(), torch.cuda.Event())}
             self.__dict__["_amp"] = amp
         return amp
 
     def _amp_tracked(self, power):
-        """The ``tracked`` argument of _ops.covariance_congruence for the next launch."""
+        """The ``tracked`` argument of _ops.covariance_congruence for the next launch: None between
+        two looks (the plain kernel: no power loads, no atomics)."""
         amp = self._amp_slots()
+        if amp["launches"] + 1 < amp["next_look"]:
+            return None
         return (power, amp["dev"], amp["phase"])
 
-    def _amp_launched(self) -> None:
-        """Behind a tracked launch: its half of the ring on its way to the mirror."""
+    def _amp_launched(self, tracked) -> None:
+        """Behind a launch on the route; a tracked one sends its half of the ring to the mirror."""
         amp = self._amp_slots()
-        half = amp["phase"] & 1
-        amp["host"][half].copy_(amp["dev"][half], non_blocking=True)
-        amp["event"][half].record()
-        amp["phase"] += 1
+        amp["launches"] += 1
+        if tracked is not None:
+            half = amp["phase"] & 1
+            amp["host"][half].copy_(amp["dev"][half], non_blocking=True)
+            amp["event"][half].record()
+            amp["pending"] = half
+            amp["phase"] += 1
 
-    def _amp_kappa_rms(self) -> float:
-        """Largest per-mixture kappa_rms of the launches so far (waits for the last one's copy)."""
-        amp = self.__dict__.get("_amp")
-        if amp is None or amp["phase"] == 0:
-            return 0.0
-        if amp["seen"] < amp["phase"]:
-            half = (amp["phase"] - 1) & 1
-            amp["event"][half].synchronize()
-            h = amp["host"][half].numpy()
+    def _amp_look(self, amp) -> None:
+        half, amp["pending"] = amp["pending"], None
+        amp["event"][half].synchronize()
+        h = amp["np"][half]
+        if h.shape[0] == 1:
+            e2, p = float(h[0, 0]), float(h[0, 1])
+            worst = (e2 / p) ** 0.5 if p > 0 and e2 >= 0 else (0.0 if p <= 0 else float("inf"))
+        else:
             e2, p = h[:, 0], h[:, 1]
             with np.errstate(all="ignore"):
-                k2 = e2 / p
-            k2 = k2[p > 0]
-            if k2.size:
-                worst = float("inf") if np.isnan(k2).any() else float(np.sqrt(k2.max()))
-                amp["worst"] = max(amp["worst"], worst)
-            amp["seen"] = amp["phase"]
+                k2 = (e2 / p)[p > 0]
+            worst = 0.0 if not k2.size else (
+                float("inf") if np.isnan(k2).any() else float(np.sqrt(k2.max())))
+        if worst != worst:
+            worst = float("inf")
+        moving = worst > 1.5 * amp["last"] or worst * 100.0 > self._implied_amp_limit
+        amp["next_look"] = amp["launches"] + (1 if moving or self._amp_every_launch else 4)
+        amp["last"] = worst
+        amp["worst"] = max(amp["worst"], worst)
+
+    def _amp_kappa_rms(self) -> float:
+        """Largest per-mixture kappa_rms among the launches looked at so far."""
+        amp = self.__dict__.get("_amp")
+        if amp is None:
+            return 0.0
+        if amp["pending"] is not None:
+            self._amp_look(amp)
         return amp["worst"]
 
     def _amp_exceeded(self) -> bool:
-        """Asked before an iteration on the route: did the previous launch pass the limit?"""
-        if self.__dict__.get("_amp") is None:
+        """Asked before an iteration on the route: did a launch looked at pass the limit?"""
+        amp = self.__dict__.get("_amp")
+        if amp is None:
             return False
-        return not (self._amp_kappa_rms() <= self._implied_amp_limit)
+        if amp["pending"] is not None:
+            self._amp_look(amp)
+        return not (amp["worst"] <= self._implied_amp_limit)
 
     def _implied_iterations(self) -> int:
         """Iterations the current call has run on the implied-filter route."""
         amp = self.__dict__.get("_amp")
-        return 0 if amp is None else amp["phase"]
+        return 0 if amp is None else amp["launches"]
 
     # -- singular-matrix / non-convergence reporting
     def _info_tensor(self):
@@ -354,6 +382,16 @@ class DeviceStateMixin:
     def _newton_counter(self):
         return self._info_tensor()[1:]
 
+    def _newton_words(self, dev):
+        """Vote words / arrival counters of the IPA sweeps (ssspy_ipa_sweep_newton_words), kept for
+        the call: every sweep prepares them itself."""
+        B, N = self._X.shape[0], self._X.shape[1]
+        words = self.__dict__.get("_newton_ws")
+        need = int(_lib.load().ssspy_ipa_sweep_newton_words(B, N))
+        if words is None or words.numel() < need or words.device != dev:
+            words = self.__dict__["_newton_ws"] = dv.empty((need,), dv.i64, dev)
+        return words
+
     def _check_device_errors(self):
         from .. import _ops
 
@@ -361,6 +399,12 @@ class DeviceStateMixin:
         info = self.__dict__.get("_info")
         if info is not None:
             singular, not_converged = (int(v) for v in info.tolist())  # synchronises
+            if self.__dict__.get("_newton_ws") is not None:
+                timeouts = _lib.load().ssspy_debug_barrier_timeouts()
+                if timeouts:
+                    raise _lib.HipLibraryError(
+                        "an IPA sweep gave up waiting for its mixture's workgroups {} time(s): the "
+                        "results of this process are not to be trusted".format(timeouts))
             if singular or not_converged:
                 info.zero_()
             if not_converged:

@@ -15,13 +15,12 @@ leading axis (``loss`` entries become arrays of length ``n_mixtures``).
 """
 
 import functools
-import os as _os
 from typing import Callable, Iterable, List, Optional, Tuple, Union
 
 import numpy as np
 
 from .. import _device as dv
-from .. import _lib, _ops
+from .. import _lib, _ops, _routes
 from ..special.flooring import identity, max_flooring
 from ..utils.flooring import choose_flooring_fn, device_flooring, host_floor, require_device_floor
 from ..utils.select_pair import resolve_pairs, sequential_pair_selector
@@ -440,10 +439,6 @@ class _MMILRMA(ILRMABase):
             B, N, F, T = self._X.shape
             if self._U is None:
                 self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
-            plan = self._subbatch_plan(B, N, F, T)
-            if plan is not None:
-                self._update_once_in_subbatches(floor, *plan)
-                return
             _ops.ilrma_ip1_update(
                 self._X, self._C() if self.normalization else None,
                 self._state_dev("demix_filter"), self._state_dev("basis"),
@@ -465,70 +460,19 @@ class _MMILRMA(ILRMABase):
         if self.normalization:
             self.normalize(flooring_fn=flooring_fn)
 
-    # -- the iteration of a large batch in cache-sized sub-batches (round 5 experiment) -----------
-    def _subbatch_plan(self, B, N, F, T):
-        """(mixtures per sub-batch, streams) or None.  Mixtures are independent, so an iteration over
-        B of them may run sub-batch by sub-batch -- all passes over a few mixtures before the next
-        few -- which lets the second and third pass read X out of the 256 MB Infinity Cache instead
-        of HBM (0.025 against 0.083 nJ per byte above idle, profiles/r05_cache_energy.json; the
-        headline runs at the socket power cap).  SSSPY_AMD_SUBBATCH="<mixtures>:<streams>"."""
-        spec = _os.environ.get("SSSPY_AMD_SUBBATCH")
-        if not spec:
-            return None
-        sub, _, streams = spec.partition(":")
-        sub, streams = int(sub), int(streams or 1)
-        if sub <= 0 or sub >= B:
-            return None
-        return sub, max(1, streams)
-
-    def _update_once_in_subbatches(self, floor, sub, n_streams) -> None:
-        import torch
-
-        B, N, F, T = self._X.shape
-        K = self.n_basis
-        state = getattr(self, "_subbatch_state", None)
-        if state is None or state[0] != (B, sub, n_streams):
-            streams = [torch.cuda.Stream() for _ in range(n_streams)]
-            scratch = [_ops.ilrma_workspace(min(sub, B), N, F, T, K, self._X.device)
-                       for _ in range(n_streams)]
-            state = self._subbatch_state = ((B, sub, n_streams), streams, scratch)
-        _, streams, scratch = state
-        C = self._C() if self.normalization else None
-        W, Tb, Vb = (self._state_dev(k) for k in ("demix_filter", "basis", "activation"))
-        main = torch.cuda.current_stream()
-        ready = torch.cuda.Event()
-        ready.record(main)
-        for st in streams:
-            st.wait_event(ready)
-        for i, lo in enumerate(range(0, B, sub)):
-            hi = min(B, lo + sub)
-            k = i % n_streams
-            ws, ws_bytes = scratch[k]
-            with torch.cuda.stream(streams[k]):
-                _ops.ilrma_ip1_update(
-                    self._X[lo:hi], None if C is None else C[lo:hi], W[lo:hi], Tb[lo:hi], Vb[lo:hi],
-                    self._U[lo:hi], float(self.domain), bool(self.normalization), floor, ws,
-                    ws_bytes, self._info_tensor(), model=self._model)
-        for st in streams:
-            done = torch.cuda.Event()
-            done.record(st)
-            main.wait_event(done)
-        for name in ("demix_filter", "basis", "activation"):
-            self._state_touch(name)
-
     # -- ISS2 / IPA with the power normalisation folded into the update matrix (round 5) -------
     def _folded_output_normalization(self, floor) -> bool:
         cls = type(self)
         algos = _ISS2 + _IPA
         # ISS1 on the per-bin statistics with the folded normalisation against the register-resident
         # sweep + weight pass + scale pass: faster up to 4 sources (the tuned covariance pass), see
-        # DESIGN 4 item 40.  SSSPY_AMD_ISS1_STATISTICS=0 / 1 forces either.
-        iss1 = _os.environ.get("SSSPY_AMD_ISS1_STATISTICS")
+        # DESIGN 4 item 40 (_routes "iss1_statistics" forces either for the tests).
+        iss1 = _routes.get("iss1_statistics")
         # (a handful of mixtures: the one fused sweep launch wins, 112 against 125 us for one
         #  mixture of configs[1]; 32 mixtures 1.80 -> 1.29 ms, 128: 6.82 -> 4.65 ms)
-        if (iss1 != "0" and self._base_model[0] == _lib.SOURCE_GAUSS
-                and (iss1 == "1" or (self._X.shape[1] <= 4
-                                     and self._X.shape[0] * self._X.shape[2] >= 4096))):
+        if (iss1 is not False and self._base_model[0] == _lib.SOURCE_GAUSS
+                and (iss1 is True or (self._X.shape[1] <= 4
+                                      and self._X.shape[0] * self._X.shape[2] >= 4096))):
             algos = algos + _ISS1
         return (self.spatial_algorithm in algos and bool(self.normalization)
                 and self._power_normalization_or_off() and not self.partitioning
@@ -536,7 +480,7 @@ class _MMILRMA(ILRMABase):
                 and cls.update_spatial_model_iss1 is _MMILRMA.update_spatial_model_iss1
                 and cls.update_spatial_model_iss2 is _MMILRMA.update_spatial_model_iss2
                 and cls.update_spatial_model_ipa is _MMILRMA.update_spatial_model_ipa
-                and not _os.environ.get("SSSPY_AMD_NO_FOLDED_NORM"))
+                and _routes.get("folded_norm"))
 
     def _output_covariance(self, Y):
         """C_i = (1/T) sum_j y y^H of the separated spectrogram, (B, F, N, N): formed once and moved
@@ -573,7 +517,7 @@ class _MMILRMA(ILRMABase):
                                     floor, self._info_tensor())
         else:
             G = _ops.ipa_sweep(Vc, self.lqpqm_normalization, self.newton_iter, floor,
-                               self._info_tensor(), newton_ws=dv.empty((B,), dv.i64, Y.device),
+                               self._info_tensor(), newton_ws=self._newton_words(Y.device),
                                not_converged=self._newton_counter())
         C = self._output_covariance(Y)
         _ops.ilrma_normalize_filter(G, C, self._state_dev("basis"), float(self.domain), floor,
@@ -596,7 +540,7 @@ class _MMILRMA(ILRMABase):
         """W with output = W x while nothing else rewrote ``output`` since, else None."""
         kept = getattr(self, "_implied", None)
         if (kept is None or kept[1] != self._state_rev("output")
-                or _os.environ.get("SSSPY_AMD_NO_IMPLIED_FILTER")):
+                or not _routes.get("implied_filter")):
             return None
         return kept[0]
 
@@ -637,8 +581,9 @@ class _MMILRMA(ILRMABase):
         _ops.ilrma_weighted_covariance(self._X, *self._nmf_pair(), float(self.domain), self._ws,
                                        self._ws_bytes, out=self._U, W=W, model=self._model,
                                        flooring=floor)
-        Vc = _ops.covariance_congruence(self._U, W, self._Vc, tracked=self._amp_tracked(self._C()))
-        self._amp_launched()
+        tracked = self._amp_tracked(self._C())
+        Vc = _ops.covariance_congruence(self._U, W, self._Vc, tracked=tracked)
+        self._amp_launched(tracked)
         if self.spatial_algorithm in _ISS1:
             G = _ops.iss1_transform(Vc, floor)
         elif self.spatial_algorithm in _ISS2:
@@ -646,7 +591,7 @@ class _MMILRMA(ILRMABase):
                                     floor, self._info_tensor())
         else:
             G = _ops.ipa_sweep(Vc, self.lqpqm_normalization, self.newton_iter, floor,
-                               self._info_tensor(), newton_ws=dv.empty((B,), dv.i64, dev),
+                               self._info_tensor(), newton_ws=self._newton_words(dev),
                                not_converged=self._newton_counter())
         spare = getattr(self, "_implied_spare", None)
         if spare is None or spare.shape != W.shape or spare.data_ptr() == W.data_ptr():
@@ -803,7 +748,7 @@ class _MMILRMA(ILRMABase):
         updates (weights formed from the NMF tiles on the fly) serves with Y in place of X -- instead
         of a weight pass (read |y|^2, write (N, F, T) weights) plus the generic weighted covariance
         (round 5: 0.78 -> 0.3 ms at 32 mixtures of configs[1]).  None: the caller forms weights."""
-        if self._base_model[0] != _lib.SOURCE_GAUSS or _os.environ.get("SSSPY_AMD_ISS_WEIGHT_PASS"):
+        if self._base_model[0] != _lib.SOURCE_GAUSS:
             return None
         B, N, F, T = Y.shape
         if getattr(self, "_Vc", None) is None or tuple(self._Vc.shape) != (B, F, N, N, N):

@@ -14,13 +14,12 @@ The gradient / natural-gradient / Fast / PDS / ADMM IVA variants are out of scop
 """
 
 import functools
-import os as _os
 from typing import Callable, Iterable, List, Optional, Tuple, Union
 
 import numpy as np
 
 from .. import _device as dv
-from .. import _lib, _ops
+from .. import _lib, _ops, _routes
 from ..special.flooring import identity, max_flooring
 from ..utils.flooring import choose_flooring_fn, device_flooring, host_floor, require_device_floor
 from ..utils.select_pair import resolve_pairs, sequential_pair_selector
@@ -98,7 +97,7 @@ class IVABase(DeviceStateMixin, IterativeMethodBase):
         iterations of AuxIVA keep it, see AuxIVA._update_once_implied)."""
         kept = getattr(self, "_implied", None)
         if (kept is None or kept[1] != self._state_rev("output")
-                or _os.environ.get("SSSPY_AMD_NO_IMPLIED_FILTER")):
+                or not _routes.get("implied_filter")):
             return None
         return kept[0]
 
@@ -535,14 +534,15 @@ class AuxIVA(AuxIVABase):
         Vc = getattr(self, "_Vc_implied", None)
         if Vc is None or tuple(Vc.shape) != tuple(U.shape) or Vc.data_ptr() == U.data_ptr():
             Vc = self._Vc_implied = dv.empty(tuple(U.shape), dv.c128, dev)
-        _ops.covariance_congruence(U, W, Vc, tracked=self._amp_tracked(self._C()))
-        self._amp_launched()
+        tracked = self._amp_tracked(self._C())
+        _ops.covariance_congruence(U, W, Vc, tracked=tracked)
+        self._amp_launched(tracked)
         if self.spatial_algorithm in _ISS2:
             G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N),
                                     floor, self._info_tensor())
         else:
             G = _ops.ipa_sweep(Vc, self.lqpqm_normalization, self.newton_iter, floor,
-                               self._info_tensor(), newton_ws=dv.empty((B,), dv.i64, dev),
+                               self._info_tensor(), newton_ws=self._newton_words(dev),
                                not_converged=self._newton_counter())
         spare = getattr(self, "_implied_spare", None)
         if spare is None or spare.shape != W.shape or spare.data_ptr() == W.data_ptr():

@@ -1551,10 +1551,7 @@ static int check_dims(int B, int N, int M, int F, int T, int K) {
 // SSSPY_AMD_GMNMF_FULL=1: the full-storage kernels only (A / B, debugging)
 // (2 and 3 channels keep the full-storage kernels: nothing spills there and the packed route's
 // extra launches -- packing, the flag-gated repair kernels -- cost 10 % of a 0.15-0.25 ms iteration)
-static bool packed_points(int M) {
-  static const bool off = std::getenv("SSSPY_AMD_GMNMF_FULL") != nullptr;
-  return !off && M >= 4;
-}
+static bool packed_points(int M) { return M >= 4; }
 
 static int launch_pack_spatial(const void *H, double *Hq, int B, int N, int M, int F,
                                hipStream_t st) {

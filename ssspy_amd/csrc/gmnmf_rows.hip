@@ -181,15 +181,9 @@ __global__ __launch_bounds__(512) void k_gmnmf_spatial_update_rows(c128 *H,
 
 }  // namespace
 
-// 7 and 8 channels always (the lane-per-matrix instantiations are gone); SSSPY_AMD_GMNMF_SU_ROWS=<m>
-// extends it down to m channels for experiments (4-6 keep the packed lane-per-matrix kernel, which
-// does not spill there: 6 channels 0.96 ms per iteration)
-bool gmnmf_spatial_update_rows_wanted(int M) {
-  if (M >= 7 && M <= 8) return true;
-  const char *e = getenv("SSSPY_AMD_GMNMF_SU_ROWS");
-  const int from = e ? atoi(e) : 7;
-  return from > 0 && M >= from && M <= 8;
-}
+// 7 and 8 channels (the lane-per-matrix instantiations are gone); 4-6 keep the packed
+// lane-per-matrix kernel, which does not spill there: 6 channels 0.96 ms per iteration
+bool gmnmf_spatial_update_rows_wanted(int M) { return M >= 7 && M <= 8; }
 
 int gmnmf_spatial_update_rows(void *H, const double *PQ, long long count, int M, int floor_kind,
                               double eps, int *flags, hipStream_t st) {

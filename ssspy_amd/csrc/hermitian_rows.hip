@@ -279,13 +279,8 @@ __global__ __launch_bounds__(256, 2) void k_eigh_general_rows(const c128 *__rest
 // 76 / 214 / 693; sqrtmh 262 | 83 / 341 / 680; gmeanmh 433 | 263 / 841 / 1 749; generalised eigh
 // 232 | 106 / 382 / 872 (the padded 8 x 8 costs the same at every size).  So: always from
 // `always_from` on (the lane-per-matrix instantiations above that are gone: 600-3 800 spilled
-// VGPRs each), and SSSPY_AMD_HERM_ROWS=<m> extends it down to m x m for experiments.
-bool hermitian_rows_wanted(int M, int always_from) {
-  if (M >= always_from && M <= 8) return true;
-  const char *e = getenv("SSSPY_AMD_HERM_ROWS");
-  const int from = e ? atoi(e) : 0;
-  return from > 0 && M >= from && M <= 8;
-}
+// VGPRs each).
+bool hermitian_rows_wanted(int M, int always_from) { return M >= always_from && M <= 8; }
 
 static dim3 rows_grid(long long n) { return dim3((unsigned)((n + MATS - 1) / MATS)); }
 

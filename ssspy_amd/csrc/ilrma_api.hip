@@ -93,16 +93,13 @@ static inline bool fast_path(int N, int F, int T, int K, double domain,
 static inline int is_me(int source_model) { return (source_model & SSSPY_SOURCE_ME) ? 1 : 0; }
 
 // The latency kernels (ilrma_small.hip) serve batches whose bin tiles do not fill the chip with the
-// throughput kernels' 64-bin work items: B * ceil(F / 16) <= SSSPY_AMD_SMALL_MAX_ITEMS (default 350, i.e. up to 5 mixtures of 1025 bins --
+// throughput kernels' 64-bin work items: B * ceil(F / 16) <= 350, i.e. up to 5 mixtures of 1025 bins --
 // round 4: with the cost-based tail plan the throughput kernels win from 6 mixtures on, 29.7 k
 // against 27.4 k mixture-iterations/s at 9, benchmarks/batch_sweep.py; it was 640:
-// up to 9 mixtures of 1025 bins; 0 switches the path off).
+// up to 9 mixtures of 1025 bins).
 static inline bool small_path(int B, int N, int F, int T, int K, double domain,
                               int source_model = SSSPY_SOURCE_GAUSS) {
-  static const long long max_items = [] {
-    const char *e = std::getenv("SSSPY_AMD_SMALL_MAX_ITEMS");
-    return e ? std::atoll(e) : 350ll;
-  }();
+  const long long max_items = 350;
   return K <= 16 && fast_path(N, F, T, K, domain, source_model) &&
          (long long)B * ((F + 15) / 16) <= max_items;
 }
@@ -132,13 +129,8 @@ static inline int source_group(int N, int F, int T, int K, double domain, int so
 // The register-tiled passes win up to 32 bases (16: 1.0 ms, 32: 1.6 ms per iteration at 32 mixtures of
 // the configs[1] shape); from 33 on their four-k-tile form (4.1-4.7 ms) loses to the dense products
 // (3.1-3.2 ms; 80: 4.1, 128: 4.6, 256: 7.1, 1024: 22.8 -- benchmarks/wide_basis.py, round 4).
-// SSSPY_AMD_WIDE_BASIS_MIN_K (development): smallest n_basis on the wide-basis path
 static inline bool wide_basis_shape(int N, int K) {
-  static const int min_k = [] {
-    const char *e = std::getenv("SSSPY_AMD_WIDE_BASIS_MIN_K");
-    return e ? std::atoi(e) : 33;
-  }();
-  return K >= min_k || N > SSSPY_MAX_SOURCES;
+  return K >= 33 || N > SSSPY_MAX_SOURCES;
 }
 // The general form (any source count above 4, e.g. 5 or 7): the B N sources of the batch, in memory
 // order, are cut into at most three runs of `count` groups of G sources each -- groups of 4 and one

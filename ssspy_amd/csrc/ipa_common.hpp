@@ -9,7 +9,7 @@ namespace ssspy {
 // mode of a source step: NEWTON_FIXED max_iter steps; NEWTON_PROBE max_iter steps, convergence bits
 // AND-ed into the mixture's word (nothing else is produced); NEWTON_APPLY the number of steps found
 // in the word by k_newton_steps
-enum { NEWTON_FIXED = 0, NEWTON_PROBE = 1, NEWTON_APPLY = 2 };
+enum { NEWTON_FIXED = 0, NEWTON_PROBE = 1, NEWTON_APPLY = 2, NEWTON_FUSED = 3 };
 
 __device__ __forceinline__ double floor_of_zero(int floor_kind, double eps) {
   return apply_floor(0.0, floor_kind, eps);

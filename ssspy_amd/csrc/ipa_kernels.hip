@@ -36,11 +36,20 @@ namespace ssspy {
 // y = argmin of the LQPQM (type 2) with H = sigma diag(phi) sigma^H.  ref: lqpqm.py:13-110
 // mode: NEWTON_FIXED max_iter steps; NEWTON_PROBE max_iter steps, convergence bits AND-ed into *word
 // (nothing else is produced); NEWTON_APPLY the number of steps found in *word by k_newton_steps
-template <int L>
+// NEWTON_FUSED (round 6): probe and apply in one kernel.  After the max_iter probing steps the lane
+// hands its convergence bits to `vote`, which returns the number of steps the reference makes for
+// the lane's mixture (a reduction over all bins of the mixture: k_ipa_sweep_fused waits for the
+// other workgroups of the mixture there), and the lane repeats that many steps from the start
+// value.  Every lane of the wave must reach the vote: singular problems hand in `false`.
+struct NoVote {
+  __device__ __forceinline__ int operator()(unsigned long long, bool) const { return 0; }
+};
+
+template <int L, class Vote = NoVote>
 __device__ __forceinline__ void lqpqm2(c128 (&H)[L][L], const c128 (&v)[L], double z,
                                        int floor_kind, double eps, int max_iter, c128 (&y)[L],
                                        int mode = NEWTON_FIXED, unsigned long long *word = nullptr,
-                                       int singular_override = -1) {
+                                       int singular_override = -1, Vote vote = Vote()) {
   c128 sigma[L][L];
   jacobi_eigh<L>(H, sigma);
   double phi[L];
@@ -76,6 +85,7 @@ __device__ __forceinline__ void lqpqm2(c128 (&H)[L][L], const c128 (&v)[L], doub
       for (int a = 0; a < L; ++a)
         if (a == rank) y[a] = val;
     }
+    if (mode == NEWTON_FUSED) vote(0ull, false);
     return;
   }
   c128 vt[L];  // sigma^H v
@@ -117,6 +127,7 @@ __device__ __forceinline__ void lqpqm2(c128 (&H)[L][L], const c128 (&v)[L], doub
   double lamb = largest_cubic_root(A, Bc, Cc);
   if (!(lamb > 1.0)) lamb = 1.0 + f0;
   lamb = fmax(lamb, zn);
+  const double lamb0 = lamb;
   const int steps = mode == NEWTON_APPLY ? (int)*word : max_iter;
   unsigned long long bits = 0ull;
   for (int it = 0; it <= steps; ++it) {
@@ -133,6 +144,25 @@ __device__ __forceinline__ void lqpqm2(c128 (&H)[L][L], const c128 (&v)[L], doub
     const double df = -2.0 * lamb * s3 - 1.0;
     const double mu = lamb - f / df;
     lamb = mu > 1.0 ? mu : 0.5 * (1.0 + lamb);
+  }
+  if (mode == NEWTON_FUSED) {
+    const int agreed = vote(bits, true);
+    if (agreed != steps) {  // (the mixture converged early: the reference stopped there)
+      lamb = lamb0;
+      for (int it = 0; it < agreed; ++it) {
+        double s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          const double dl = lamb - ph[l];
+          s2 += ph[l] * w2[l] / (dl * dl);
+          s3 += ph[l] * ph[l] * w2[l] / (dl * dl * dl);
+        }
+        const double f = lamb * lamb * s2 - lamb + zn;
+        const double df = -2.0 * lamb * s3 - 1.0;
+        const double mu = lamb - f / df;
+        lamb = mu > 1.0 ? mu : 0.5 * (1.0 + lamb);
+      }
+    }
   }
   if (mode == NEWTON_PROBE) {
     // One atomic per (wave, mixture), not one per bin: 1025 atomics on one word took 130 of the
@@ -197,20 +227,16 @@ __device__ __forceinline__ constexpr int rest_index(int m) {
   return m < S ? m : m + 1;
 }
 
-// Vc: (nbins, N, N, N) weighted covariances; G: (nbins, N, N).  One lane per bin.
-// (one wave per SIMD: the N x N working set of the larger source counts wants the whole 512-entry
-// register file; the grid has only B*F lanes anyway)
-template <int N, int S, int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ipa_transform(const c128 *Vc,
-                                                      c128 *__restrict__ G, long long nbins,
-                                                      int F, int normalization, int max_iter,
-                                                      int floor_kind, double eps, int *info,
-                                                      unsigned long long *newton_ws,
-                                                      c128 *Vchain, int chain_first) {
+// One source step of a bin (the body of k_ipa_transform and of the fused sweep).
+// `live`: false in the lanes a fused sweep keeps behind the last bin of its mixture (they walk a
+// copy of that bin so that the wave reaches every vote, and store nothing)
+template <int N, int S, int MODE, class Vote = NoVote>
+__device__ __forceinline__ void ipa_source_step(const c128 *Vc, c128 *__restrict__ G,
+                                                long long bin, bool live, int normalization,
+                                                int max_iter, int floor_kind, double eps, int *info,
+                                                unsigned long long *word, c128 *Vchain,
+                                                int chain_first, Vote vote = Vote()) {
   constexpr int L = N - 1;
-  const long long bin = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (bin >= nbins) return;
-  unsigned long long *word = MODE == NEWTON_FIXED ? nullptr : newton_ws + bin / F;
   const c128 *Ub = Vc + bin * (long long)(N * N * N);
   c128 M[N][N], P[N][N];
   double lam[N];
@@ -300,7 +326,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   }
   const bool ok = lu_forward<L, 1>(C, rhs);
   lu_backward<L, 1>(C, rhs);
-  if (MODE != NEWTON_PROBE && !ok && info) atomicAdd(info, 1);
+  if (MODE != NEWTON_PROBE && !ok && info && live) atomicAdd(info, 1);
   double dCd = 0.0;
 #pragma unroll
   for (int r = 0; r < L; ++r) dCd += d[r].x * rhs[r][0].x + d[r].y * rhs[r][0].y;
@@ -331,7 +357,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   }
   hermitize<L>(H);
   c128 qc[L];
-  lqpqm2<L>(H, v, z, floor_kind, eps, max_iter, qc, MODE, word);
+  lqpqm2<L, Vote>(H, v, z, floor_kind, eps, max_iter, qc, MODE, word, -1, vote);
   if (MODE == NEWTON_PROBE) return;
   // q = q_check / a_sqrt - b / a ; q~ = e_S - E conj(q)
   c128 q[L], qt[N];
@@ -355,7 +381,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       for (int c = 0; c < N; ++c)
         P[r][c] = r == c ? cmake(M[r][c].x + eps, 0.0) : M[r][c];
     double ld;
-    if (!chol_inverse<N>(P, Uinv, ld) && info) atomicAdd(info, 1);
+    if (!chol_inverse<N>(P, Uinv, ld) && info && live) atomicAdd(info, 1);
   }  // (identity / idle max floor: Uinv is U_S^-1 already)
   c128 Uq[N];
   double quq = 0.0;
@@ -368,6 +394,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     quq += qt[r].x * s.x + qt[r].y * s.y;
   }
   const double den = apply_floor(sqrt(fmax(quq, 0.0)), floor_kind, eps);
+  if (!live) return;  // (nothing below votes)
   c128 *Gb = G + bin * (long long)(N * N);
   if (!Vchain) {
 #pragma unroll
@@ -469,6 +496,112 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         Gb[r * N + c] = g;
       }
   }
+}
+
+// Vc: (nbins, N, N, N) weighted covariances; G: (nbins, N, N).  One lane per bin.
+// (one wave per SIMD: the N x N working set of the larger source counts wants the whole 512-entry
+// register file; the grid has only B*F lanes anyway)
+template <int N, int S, int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ipa_transform(const c128 *Vc,
+                                                      c128 *__restrict__ G, long long nbins,
+                                                      int F, int normalization, int max_iter,
+                                                      int floor_kind, double eps, int *info,
+                                                      unsigned long long *newton_ws,
+                                                      c128 *Vchain, int chain_first) {
+  const long long bin = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (bin >= nbins) return;
+  unsigned long long *word = MODE == NEWTON_FIXED ? nullptr : newton_ws + bin / F;
+  ipa_source_step<N, S, MODE>(Vc, G, bin, true, normalization, max_iter, floor_kind, eps, info, word,
+                              Vchain, chain_first);
+}
+
+// ---- the whole sweep of up to 4 sources in ONE launch (round 6).  Rounds 4-5 spent four launches
+// per source step: a memset of the vote words, the probe (everything up to the Newton iteration,
+// 50 us at 32 mixtures of configs[1]), the step count, and the apply, which recomputes the probe's
+// state (31 us) -- 16 launches and 0.33 ms per iteration at 4 sources.  Here a workgroup (one wave,
+// 64 bins of ONE mixture) walks the N source steps; at each Newton vote it ANDs its wave's
+// convergence bits into the (mixture, step) word and waits for the mixture's other workgroups
+// (arrival counter, agent-scope release / acquire), then carries on with the state it holds.
+// Forward progress: a mixture's workgroups have consecutive ids, workgroups are dispatched in
+// order, and the chip holds far more than one mixture's ceil(F / 64) of them, so the waiting
+// workgroups of the frontier mixture are always joined by the rest; the wait is bounded anyway
+// (g_ipa_barrier_timeouts, read by ssspy_debug_barrier_timeouts).
+__device__ int g_ipa_barrier_timeouts;
+
+struct SweepVote {
+  unsigned long long *word;  // of this (mixture, source step), all ones before the sweep
+  unsigned *counter;         // its arrival counter, zero before the sweep
+  int nblocks, max_iter, *not_converged;
+  __device__ __forceinline__ int operator()(unsigned long long bits, bool votes) const {
+    unsigned long long all = ~0ull;
+    for (int it = 0; it <= max_iter; ++it)
+      if (__ballot(votes && !((bits >> it) & 1ull)) != 0ull) all &= ~(1ull << it);
+    unsigned long long w = 0ull;
+    if ((threadIdx.x & 63) == 0) {
+      __hip_atomic_fetch_and(word, all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      long long spins = 0;
+      while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
+             (unsigned)nblocks) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1ll << 23)) {  // (seconds: the launch is broken, not slow)
+          atomicAdd(&g_ipa_barrier_timeouts, 1);
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    w = __shfl(w, 0, 64);  // (one wave per workgroup)
+    int steps = max_iter;
+    for (int k = 0; k < max_iter; ++k)
+      if ((w >> k) & 1ull) {
+        steps = k;
+        break;
+      }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && steps == max_iter && !((w >> max_iter) & 1ull) &&
+        not_converged)
+      atomicAdd(not_converged, 1);
+    return steps;
+  }
+};
+
+// ws: B N vote words, then B N arrival counters (64-bit slots); prepared by k_ipa_sweep_prepare
+__global__ void k_ipa_sweep_prepare(unsigned long long *ws, int count) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < count) {
+    ws[e] = ~0ull;
+    ws[count + e] = 0ull;
+  }
+}
+
+template <int N, int S, int MODE>
+__device__ __forceinline__ void ipa_sweep_steps(c128 *Vc, c128 *G, long long bin, bool live,
+                                                int normalization, int max_iter, int floor_kind,
+                                                double eps, int *info, unsigned long long *ws,
+                                                int nblocks, int B, int *not_converged) {
+  if constexpr (S < N) {
+    const int slot = blockIdx.y * N + S;
+    SweepVote vote{ws + slot, (unsigned *)(ws + (long long)B * N + slot), nblocks, max_iter,
+                   not_converged};
+    ipa_source_step<N, S, MODE, SweepVote>(Vc, G, bin, live, normalization, max_iter, floor_kind,
+                                           eps, info, nullptr, Vc, S == 0, vote);
+    ipa_sweep_steps<N, S + 1, MODE>(Vc, G, bin, live, normalization, max_iter, floor_kind, eps,
+                                    info, ws, nblocks, B, not_converged);
+  }
+}
+
+// grid: (ceil(F / 64), B), one wave per workgroup; MODE: NEWTON_FUSED or NEWTON_FIXED (no votes)
+template <int N, int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ipa_sweep_fused(
+    c128 *Vc, c128 *__restrict__ G, int F, int normalization, int max_iter, int floor_kind,
+    double eps, int *info, unsigned long long *ws, int B, int *not_converged) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const bool live = i < F;
+  const long long bin = (long long)blockIdx.y * F + (live ? i : F - 1);
+  ipa_sweep_steps<N, 0, MODE>(Vc, G, bin, live, normalization, max_iter, floor_kind, eps, info, ws,
+                              (int)gridDim.x, B, not_converged);
 }
 
 // standalone LQPQM2 (ssspy.linalg.lqpqm2): H (n, L, L), v (n, L), z (n) -> y (n, L)
@@ -626,12 +759,49 @@ extern "C" int ssspy_ipa_sweep(void *Vc, void *G, int B, int F, int N, int norma
   SSSPY_REQUIRE(max_iter >= 0, "ipa_sweep: max_iter must be non-negative");
   if (N < 2 || N > SSSPY_MAX_SOURCES)
     return fail(SSSPY_ERR_UNSUPPORTED, "IPA is built for n_sources in [2, 8]");
+  if (N <= 4) {  // one launch for the whole sweep (k_ipa_sweep_fused)
+    hipStream_t st = as_stream(stream);
+    const bool votes = newton_ws && max_iter >= 1 && max_iter <= 62;
+    unsigned long long *ws = (unsigned long long *)newton_ws;
+    if (votes) {
+      hipLaunchKernelGGL(k_ipa_sweep_prepare, dim3((B * N + 255) / 256), dim3(256), 0, st, ws, B * N);
+      const int rc = check_launch("k_ipa_sweep_prepare");
+      if (rc) return rc;
+    }
+    const dim3 grid((F + 63) / 64, B), block(64);
+#define IPA_FUSED(N_)                                                                              \
+  if (N == N_) {                                                                                   \
+    if (votes)                                                                                     \
+      hipLaunchKernelGGL((k_ipa_sweep_fused<N_, NEWTON_FUSED>), grid, block, 0, st, (c128 *)Vc,    \
+                         (c128 *)G, F, normalization, max_iter, floor_kind, floor_eps, info, ws, B, \
+                         not_converged);                                                           \
+    else                                                                                           \
+      hipLaunchKernelGGL((k_ipa_sweep_fused<N_, NEWTON_FIXED>), grid, block, 0, st, (c128 *)Vc,    \
+                         (c128 *)G, F, normalization, max_iter, floor_kind, floor_eps, info, ws, B, \
+                         not_converged);                                                           \
+  }
+    IPA_FUSED(2) IPA_FUSED(3) IPA_FUSED(4)
+#undef IPA_FUSED
+    return check_launch("k_ipa_sweep_fused");
+  }
   for (int s = 0; s < N; ++s) {
     const int rc = ipa_step(Vc, G, s, B, F, N, normalization, max_iter, floor_kind, floor_eps, info,
                             newton_ws, not_converged, as_stream(stream), (c128 *)Vc, s == 0);
     if (rc) return rc;
   }
   return SSSPY_OK;
+}
+
+extern "C" size_t ssspy_ipa_sweep_newton_words(int B, int N) {
+  return (B > 0 && N > 0) ? (size_t)2 * B * N : 0;
+}
+
+extern "C" int ssspy_debug_barrier_timeouts(void) {
+  int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ipa_barrier_timeouts), sizeof(int), 0,
+                          hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  return v;
 }
 
 static int lqpqm2_launch(const void *H, const void *v, const double *z, void *y, long long n, int L,

@@ -454,13 +454,9 @@ __global__ __launch_bounds__(256, 2) void k_ipa_rows(const c128 *Vc, c128 *__res
 // 2.6 ms per iteration): the kernel is bound by its chains of dependent instructions (pivot ->
 // reciprocal -> broadcast -> update, 56 Jacobi rounds) with two waves per SIMD to interleave.  So:
 // 8 sources always (the 24 lane-per-bin instantiations there, 1 000-2 000 spilled VGPRs each, are
-// gone), and SSSPY_AMD_IPA_ROWS=<n> extends it down to n sources (tests).
-bool ipa_rows_wanted(int N) {
-  if (N == 8) return true;
-  const char *e = getenv("SSSPY_AMD_IPA_ROWS");
-  const int from = e ? atoi(e) : 0;
-  return from > 0 && N >= from && N <= 8;
-}
+// gone).  5-7 sources keep the lane per bin: a source step there costs 0.13 ms against the 0.24 ms
+// of the padded 8-lane step (8 mixtures of 513 bins, profiles/r05_leg_survey.txt).
+bool ipa_rows_wanted(int N) { return N == 8; }
 
 int ipa_rows_launch(int mode, const void *Vc, void *G, long long nbins, int F, int N, int S,
                     int normalization, int max_iter, int floor_kind, double eps, int *info,

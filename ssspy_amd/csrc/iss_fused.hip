@@ -323,11 +323,6 @@ constexpr int iss_max_fpt() {
 // again when the slabs are added up); keep >= ~4 blocks per CU.  With frame powers requested large
 // batches take up to 16 bins per block (3 %).
 static int iss_bins_per_block(int B, int F, bool with_r2) {
-  static const int forced = [] {
-    const char *e = getenv("SSSPY_AMD_ISS_BPB");  // experiments only
-    return e ? atoi(e) : 0;
-  }();
-  if (forced > 0 && with_r2) return forced;
   const long long want_blocks = 1024;
   int bpb = (int)(((long long)B * F + want_blocks - 1) / want_blocks);
   if (bpb < 1) bpb = 1;

@@ -2171,22 +2171,12 @@ static inline TailPlan mnmf_plan(int B, int F, int T) {
 // private activation tiles per wave (n_basis <= 8; the barrier-free form of k_mnmf_binmajor_glds)
 // Measured (benchmarks/tools/mnmf_steps.py, configs[3] shape): the covariance pass gains at every
 // batch (32 mixtures: 267 -> 253 us, 128: 964 -> 908); the spatial pass, bound by its read + write
-// stream, does not (401 -> 400, 1259 -> 1309) -- so only the covariance pass takes it by default.
-// SSSPY_AMD_MNMF_GLDS_PRIVATE_V=0 / 1: neither / both (A / B).
-static inline bool mnmf_glds_private_v(bool spatial) {
-  const char *e = std::getenv("SSSPY_AMD_MNMF_GLDS_PRIVATE_V");
-  if (e) return e[0] != '0';
-  return !spatial;
-}
-// |Q x|^2 stores of the spatial pass transposed through LDS into 64-byte runs (n_basis <= 8)
-static inline bool mnmf_glds_tstore() {
-  return std::getenv("SSSPY_AMD_MNMF_GLDS_TSTORE") != nullptr;  // (experiment)
-}
+// stream, does not (401 -> 400, 1259 -> 1309) -- so only the covariance pass takes it.  (The A / B
+// switches of round 5 -- private tiles in both passes, |Q x|^2 stores transposed through LDS,
+// register-fed passes at tile-aligned frame counts -- went in round 6 with their instantiations.)
 // the LDS-DMA form of the two x-reading passes (k_mnmf_binmajor_glds): whole tiles of frames
 static inline bool mnmf_glds_ok(int B, int F, int T, int K) {
-  // (read per call: the parity tests switch it inside one process)
-  const bool disabled = std::getenv("SSSPY_AMD_MNMF_NO_GLDS") != nullptr;  // A / B
-  return !disabled && mnmf_fast_ok(B, F, T, K) && T % 16 == 0;
+  return mnmf_fast_ok(B, F, T, K) && T % 16 == 0;
 }
 
 // whether the |Q x|^2 hand-over (P, pscale) is taken by the passes of this shape
@@ -2298,12 +2288,8 @@ int LAUNCHER(mnmf_wcov)(const void *X, const double *Dsp, const double *basis, c
     const bool records = split_out && rec_out && plan.full == 0 && plan.tail > 0;
     const bool glds = mnmf_glds_ok(B, F, T, K);
     MNMF_DISPATCH_M(M, {
-      if (glds && K <= 8 && mnmf_glds_private_v(false))
+      if (glds && K <= 8)
         hipLaunchKernelGGL((k_mnmf_binmajor_glds<MM, MODE_WCOV, 2, true>), fgrid, dim3(256), 0, st,
-                           (const c128 *)X, (const c128 *)nullptr, (double *)Dsp, basis, act,
-                           (c128 *)U, F, T, K, plan, tailpart, (double *)nullptr);
-      else if (glds && K <= 8)
-        hipLaunchKernelGGL((k_mnmf_binmajor_glds<MM, MODE_WCOV, 2>), fgrid, dim3(256), 0, st,
                            (const c128 *)X, (const c128 *)nullptr, (double *)Dsp, basis, act,
                            (c128 *)U, F, T, K, plan, tailpart, (double *)nullptr);
       else if (glds)
@@ -2358,15 +2344,7 @@ int LAUNCHER(mnmf_spatial)(const void *X, const void *Q, double *Dsp, const doub
                          B * M);
     const bool glds = P && mnmf_glds_ok(B, F, T, K);
     MNMF_DISPATCH_M(M, {
-      if (glds && K <= 8 && mnmf_glds_private_v(true))
-        hipLaunchKernelGGL((k_mnmf_binmajor_glds<MM, MODE_SPATIAL, 2, true>), fgrid, dim3(256), 0,
-                           st, (const c128 *)X, (const c128 *)Q, Dsp, basis, act, (c128 *)nullptr,
-                           F, T, K, plan, tailpart, P);
-      else if (glds && K <= 8 && mnmf_glds_tstore())
-        hipLaunchKernelGGL((k_mnmf_binmajor_glds<MM, MODE_SPATIAL, 2, false, true>), fgrid,
-                           dim3(256), 0, st, (const c128 *)X, (const c128 *)Q, Dsp, basis, act,
-                           (c128 *)nullptr, F, T, K, plan, tailpart, P);
-      else if (glds && K <= 8)
+      if (glds && K <= 8)
         hipLaunchKernelGGL((k_mnmf_binmajor_glds<MM, MODE_SPATIAL, 2>), fgrid, dim3(256), 0, st,
                            (const c128 *)X, (const c128 *)Q, Dsp, basis, act, (c128 *)nullptr, F,
                            T, K, plan, tailpart, P);

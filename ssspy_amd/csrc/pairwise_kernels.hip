@@ -292,116 +292,12 @@ __global__ __launch_bounds__(256) void k_ip2_rows(c128 *W, const c128 *__restric
   }
 }
 
-template <int N>
-__global__ __launch_bounds__(64) void k_iss2_transform(const c128 *__restrict__ Vc, c128 *G,
-                                                       long long nbins, PairList pairs,
-                                                       int floor_kind, double eps, int *info,
-                                                       double *denom, int accumulate) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nbins) return;
-  Mat<N> Gm;
-  if (accumulate) load_mat<N>(Gm, G + idx * (N * N));  // continue from the transform so far
-  else set_identity<N>(Gm);
-  const c128 *V0 = Vc + idx * (long long)(N * N * N);
-  bool ok = true;
-#pragma unroll 1
-  for (int p = 0; p < pairs.count; ++p) {
-    const int p0 = pairs.first[p], p1 = pairs.second[p];
-    c128 g0[N], g1[N];
-    get_row<N>(Gm, p0, g0);
-    get_row<N>(Gm, p1, g1);
-    Mat<N> Gnew = Gm;
-    c128 Gmain[2][2][2];  // [k][a][b]: block of source p_k on the pair
-#pragma unroll 1
-    for (int s = 0; s < N; ++s) {
-      const c128 *Vs = V0 + s * N * N;
-      c128 gs[N];
-      get_row<N>(Gm, s, gs);
-      // t_b = Vs g_b^H for b in {p0, p1, s}
-      c128 t0[N], t1[N], ts[N];
-#pragma unroll
-      for (int a = 0; a < N; ++a) {
-        c128 a0 = cmake(0.0, 0.0), a1 = a0, a2 = a0;
-#pragma unroll
-        for (int d = 0; d < N; ++d) {
-          const c128 u = Vs[a * N + d];
-          a0 = cadd(a0, cmulc(u, g0[d]));
-          a1 = cadd(a1, cmulc(u, g1[d]));
-          a2 = cadd(a2, cmulc(u, gs[d]));
-        }
-        t0[a] = a0;
-        t1[a] = a1;
-        ts[a] = a2;
-      }
-      c128 C[2][2], Fv[2];
-      C[0][0] = C[0][1] = C[1][0] = C[1][1] = Fv[0] = Fv[1] = cmake(0.0, 0.0);
-#pragma unroll
-      for (int a = 0; a < N; ++a) {
-        cfma(C[0][0], g0[a], t0[a]);
-        cfma(C[0][1], g0[a], t1[a]);
-        cfma(C[1][0], g1[a], t0[a]);
-        cfma(C[1][1], g1[a], t1[a]);
-        cfma(Fv[0], g0[a], ts[a]);
-        cfma(Fv[1], g1[a], ts[a]);
-      }
-      if (s == p0 || s == p1) {
-        const int k = (s == p0) ? 0 : 1;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            if (k == 0) Gmain[0][a][b] = C[a][b];
-            if (k == 1) Gmain[1][a][b] = C[a][b];
-          }
-      } else {
-        // Q = -inv2(C) Fv ; row_s += conj(Q0) g0 + conj(Q1) g1
-        const c128 det = csub(cmul(C[0][0], C[1][1]), cmul(C[0][1], C[1][0]));
-        const c128 idet = crecip(det);
-        const c128 q0 = cmul(idet, csub(cmul(C[0][1], Fv[1]), cmul(C[1][1], Fv[0])));
-        const c128 q1 = cmul(idet, csub(cmul(C[1][0], Fv[0]), cmul(C[0][0], Fv[1])));
-        c128 row[N];
-#pragma unroll
-        for (int c = 0; c < N; ++c) {
-          c128 v = gs[c];
-          v = cadd(v, cmul(cconj(q0), g0[c]));
-          v = cadd(v, cmul(cconj(q1), g1[c]));
-          row[c] = v;
-        }
-        set_row<N>(Gnew, s, row);
-      }
-    }
-    double lamb[2];
-    c128 z[2][2];
-    ok = eigh2_type1(Gmain[0], Gmain[1], lamb, z) && ok;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const c128 h[2] = {z[0][k], z[1][k]};
-      double q = (k == 0) ? quad2(h, Gmain[0]) : quad2(h, Gmain[1]);
-      q = q < 0.0 ? 0.0 : q;
-      // (denom: host-side flooring callable, see k_ip2)
-      const double dk = denom ? 1.0 : apply_floor(sqrt(q), floor_kind, eps);
-      if (denom) denom[idx * 2 + k] = sqrt(q);
-      c128 row[N];
-#pragma unroll
-      for (int c = 0; c < N; ++c) {
-        c128 v = cmul(cconj(h[0]), g0[c]);
-        v = cadd(v, cmul(cconj(h[1]), g1[c]));
-        row[c] = cmake(v.x / dk, v.y / dk);
-      }
-      set_row<N>(Gnew, k == 0 ? p0 : p1, row);
-    }
-    Gm = Gnew;
-  }
-  store_mat<N>(Gm, G + idx * (N * N));
-  if (!ok && info) atomicAdd(info, 1);
-}
-
-// ---- ISS2 transform with a bin on GL lanes, lane s = source s = row s of G (round 5).  The lane
-// per bin above runs 513 waves at 32 x 1025 bins -- half a wave per SIMD, every wave a serial walk
+// ---- ISS2 transform with a bin on GL lanes, lane s = source s = row s of G (round 5).  A lane
+// per bin (the kernel of rounds 2-5, removed in round 6) ran 513 waves at 32 x 1025 bins -- half a wave per SIMD, every wave a serial walk
 // over N sources per pair with N^2 uncoalesced loads each (88 us at 4 sources; 256 AGPRs + scratch
 // at 8).  Here source s's statistics stay in lane s's registers (N <= 4) or are re-read by it
 // (N > 4), the pair's rows and 2 x 2 blocks travel by lane shuffles, and every lane repeats the
-// 2 x 2 eigenproblem.  Same expressions in the same order as k_iss2_transform: identical results.
+// 2 x 2 eigenproblem.
 template <int N, int GL, bool HOLD>
 __global__ __launch_bounds__(256) void k_iss2_transform_rows(const c128 *__restrict__ Vc, c128 *G,
                                                              long long nbins, PairList pairs,
@@ -524,10 +420,6 @@ static int launch_iss2_rows(const void *Vc, void *G, long long nbins, const Pair
   return check_launch("k_iss2_transform_rows");
 }
 
-static bool iss2_rows_enabled() {
-  const char *e = getenv("SSSPY_AMD_ISS2_ONE_LANE");  // (A/B switch: the lane-per-bin kernel)
-  return !(e && e[0] == '1');
-}
 
 // ---- the same two updates with the source count at run time (9 <= N <= SSSPY_RT_MAX_SOURCES):
 // loops instead of unrolled code, the bin's matrices in the lane's private memory (round 4; the
@@ -783,13 +675,9 @@ int ssspy_iss2_transform(const void *Vc, void *G, const int *pairs, int n_pairs,
                        (c128 *)G, nbins, N, pl, floor_kind, floor_eps, info, (double *)nullptr, 0);
     return check_launch("k_iss2_transform_rt");
   }
-  if (N >= 2 && iss2_rows_enabled())
-    DISPATCH_N(N, return launch_iss2_rows<NN>(Vc, G, nbins, pl, floor_kind, floor_eps, info, nullptr,
-                                              0, as_stream(stream)));
-  DISPATCH_N(N, hipLaunchKernelGGL((k_iss2_transform<NN>), grid, block, 0, as_stream(stream),
-                                   (const c128 *)Vc, (c128 *)G, nbins, pl, floor_kind, floor_eps,
-                                   info, (double *)nullptr, 0));
-  return check_launch("k_iss2_transform");
+  DISPATCH_N(N, return launch_iss2_rows<NN>(Vc, G, nbins, pl, floor_kind, floor_eps, info, nullptr,
+                                            0, as_stream(stream)));
+  return SSSPY_OK;
 }
 
 int ssspy_iss2_transform_deferred(const void *Vc, void *G, const int *pair, int accumulate, int B,
@@ -806,13 +694,9 @@ int ssspy_iss2_transform_deferred(const void *Vc, void *G, const int *pair, int 
                        accumulate ? 1 : 0);
     return check_launch("k_iss2_transform_rt (deferred)");
   }
-  if (N >= 2 && iss2_rows_enabled())
-    DISPATCH_N(N, return launch_iss2_rows<NN>(Vc, G, nbins, pl, SSSPY_FLOOR_NONE, 0.0, info, denom,
-                                              accumulate ? 1 : 0, as_stream(stream)));
-  DISPATCH_N(N, hipLaunchKernelGGL((k_iss2_transform<NN>), grid, block, 0, as_stream(stream),
-                                   (const c128 *)Vc, (c128 *)G, nbins, pl, SSSPY_FLOOR_NONE, 0.0,
-                                   info, denom, accumulate ? 1 : 0));
-  return check_launch("k_iss2_transform (deferred)");
+  DISPATCH_N(N, return launch_iss2_rows<NN>(Vc, G, nbins, pl, SSSPY_FLOOR_NONE, 0.0, info, denom,
+                                            accumulate ? 1 : 0, as_stream(stream)));
+  return SSSPY_OK;
 }
 
 }  // extern "C"

@@ -740,10 +740,7 @@ DECL_SMALL_IP1(2) DECL_SMALL_IP1(3) DECL_SMALL_IP1(4)
 #undef DECL_SMALL_IP1
 
 static bool small_ip1_off() {
-  static const bool off = [] {
-    const char *e = std::getenv("SSSPY_AMD_SMALL_MAX_ITEMS");
-    return e && std::atoll(e) == 0;
-  }();
+  static const bool off = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;  // (with every tuned path)
   return off;
 }
 

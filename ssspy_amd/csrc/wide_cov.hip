@@ -174,9 +174,7 @@ int launch(const c128 *A, const double *weight, int kind, c128 *U, int B, int N,
 bool wide_weighted_cov_ok(int N, int S, int F, int T, int kind) {
   static const bool disabled = std::getenv("SSSPY_AMD_NO_FAST") != nullptr;
   // (5 channels pay for the rows the 16 x 16 tile pads: level with the per-lane kernel, which stays)
-  static const int min_n = std::getenv("SSSPY_AMD_WIDE_COV_MIN_N")
-                               ? std::atoi(std::getenv("SSSPY_AMD_WIDE_COV_MIN_N")) : 6;
-  if (disabled || N < min_n || N < 5 || N > 8 || S < 1 || S > 8) return false;
+  if (disabled || N < 6 || N > 8 || S < 1 || S > 8) return false;
   if ((long long)N * F * T * 16 >= (1ll << 32)) return false;
   if (kind == SSSPY_WEIGHT_UNIT) return S == 1;
   return kind == SSSPY_WEIGHT_FRAME || kind == SSSPY_WEIGHT_BIN_FRAME;

@@ -17,6 +17,8 @@ import pytest
 
 from conftest import rel_err
 
+from ssspy_amd import _routes
+
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-8
@@ -239,16 +241,10 @@ def test_implied_filter_route_100_iterations_against_oracle(family, algo, oracle
     kw = {}
     if family == "ilrma":
         kw["basis"], kw["activation"] = _oracle_jobs.initial(1000)
-    forced = family == "ilrma" and algo == "ISS1"
-    if forced:
-        os.environ["SSSPY_AMD_ISS1_STATISTICS"] = "1"
-    try:
+    with _routes.override(iss1_statistics=True if (family, algo) == ("ilrma", "ISS1") else None):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             Y = m(X, n_iter=100, **kw)
-    finally:
-        if forced:
-            del os.environ["SSSPY_AMD_ISS1_STATISTICS"]
     # (the NMF variances of silent sources reach their floor after 60-70 iterations of this mixture
     #  and the route's rounding bound with them: ILRMA then goes on on Y, see _amp_exceeded)
     assert m._implied_iterations() >= 50, "the run left the implied-filter route early"
@@ -328,11 +324,8 @@ def test_configs3_batch_of_32_equals_single_mixture_runs():
         for name, a, ref in zip(names + ("output",), batch, single):
             assert rel_err(a[b], ref) < 1e-10, (b, name)
         np.testing.assert_allclose(lossb[:, b], loss1, rtol=1e-10)
-    os.environ["SSSPY_AMD_NO_HANDOVER"] = "1"
-    try:
+    with _routes.override(handover=False):
         mp, plain, lossp = run(torch.from_numpy(Xh).to("cuda"))
-    finally:
-        del os.environ["SSSPY_AMD_NO_HANDOVER"]
     assert mp._handover is None
     for name, a, ref in zip(names + ("output",), batch, plain):
         assert rel_err(a, ref) < 1e-10, name

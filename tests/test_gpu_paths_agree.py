@@ -1,7 +1,7 @@
-"""The tuned kernels, the few-mixture kernels and the generic kernels are three implementations of
-the same iteration, chosen by shape.  The development switches (read once per process) force one
-or the other, so each variant runs in its own interpreter and the results are compared here -- at
-sizes where the NumPy oracle would take minutes."""
+"""The tuned kernels and the generic kernels are two implementations of the same iteration, chosen
+by shape.  SSSPY_AMD_NO_FAST (read once per process) forces the generic ones, so each variant runs
+in its own interpreter and the results are compared here -- at sizes where the NumPy oracle would
+take minutes."""
 import os
 import subprocess
 import sys
@@ -55,11 +55,11 @@ def _rel(a, b):
 
 def test_kernel_families_agree(tmp_path):
     base = _run(tmp_path, "default", {})
-    # the few-mixture kernels off: single mixtures take the throughput kernels' split items
-    no_small = _run(tmp_path, "no_small", {"SSSPY_AMD_SMALL_MAX_ITEMS": "0"})
-    # the tuned kernels off: everything on the first-generation generic kernels
+    # the tuned kernels off (and the few-mixture kernels with them): everything on the
+    # first-generation generic kernels.  (Few-mixture against throughput kernels: the batch == single
+    # mixture comparisons of test_gpu_benchmark_sizes.py.)
     generic = _run(tmp_path, "generic", {"SSSPY_AMD_NO_FAST": "1"})
-    for other, name in ((no_small, "no_small"), (generic, "generic")):
+    for other, name in ((generic, "generic"),):
         for key in base.files:
             tol = 1e-9 if key.endswith("_loss") else 1e-8  # summation orders differ; <= 8 iterations
             if key.endswith("_loss"):
