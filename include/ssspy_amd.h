@@ -421,29 +421,22 @@ size_t ssspy_fold_scalar_slots_workspace_bytes(long long total, int nslots);
 int ssspy_fold_scalar_slots(const double *slots, long long total, int nslots, double *out,
                             void *workspace, size_t workspace_bytes, void *stream);
 
-/* IPA (iterative projection with adjustment), one source step: from the weighted covariances of
- * the current separated spectrogram, Vc (B,F,N,N,N) = ssspy_weighted_covariance(Y, weight), the
- * update matrix G (B,F,N,N) of source `source_idx`; the caller then applies ssspy_separate(Y, G)
- * and repeats for the next source.  n_sources in [2, 8].
- * newton_ws: B 64-bit words of scratch.  The reference's Newton loop runs over all bins of a mixture
- * at once and stops at the first step at which every bin has converged (linalg/lqpqm.py:196-213);
- * with the scratch a probe pass finds that step count per mixture and the update makes exactly as
- * many steps (max_iter <= 62); with NULL every bin makes max_iter steps.  not_converged (optional):
- * incremented once per mixture whose bins had not all converged after max_iter steps (the
- * reference's UserWarning).
- * replaces: ssspy/bss/_update_spatial_model.py:398-513 (update_by_ipa body), linalg/lqpqm.py:13-352
- * (lqpqm2, solve_equation). */
-int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int B, int F, int N,
-                        int normalization, int max_iter, int floor_kind, double floor_eps,
-                        int *info, void *newton_ws, int *not_converged, void *stream);
-/* A whole IPA sweep on per-bin statistics (round 5): Vc (B,F,N,N,N) = ssspy_weighted_covariance(Y,
+/* IPA (iterative projection with adjustment): a whole sweep on per-bin statistics (round 5; the
+ * per-source entry point ssspy_ipa_transform of rounds 3-5 went in round 6 with its 81 kernel
+ * instantiations).  n_sources in [2, 8].  Vc (B,F,N,N,N) = ssspy_weighted_covariance(Y,
  * weight) of the spectrogram BEFORE the sweep (overwritten: after source step s it holds
  * G_s Vc G_s^H, the covariances of the spectrogram the reference would have formed by then); G
  * (B,F,N,N) <- G_{N-1} ... G_0.  The caller applies ssspy_separate(Y, G) once: three passes over Y per
  * sweep (weights, covariance, separate) instead of 3 N.  The weights are those of the sweep's start
  * for every source, as in the reference (_update_spatial_model.py:436-445: varphi is an argument).
- * Other arguments as ssspy_ipa_transform, except newton_ws: ssspy_ipa_sweep_newton_words(B, N) words.
- * replaces: ssspy/bss/_update_spatial_model.py:398-513 (update_by_ipa, the loop over sources). */
+ * newton_ws: ssspy_ipa_sweep_newton_words(B, N) 64-bit words of scratch.  The reference's Newton loop
+ * runs over all bins of a mixture at once and stops at the first step at which every bin has
+ * converged (linalg/lqpqm.py:196-213); with the scratch the bins of a mixture vote and make exactly
+ * as many steps (max_iter <= 62); with NULL every bin makes max_iter steps.  not_converged
+ * (optional): incremented once per mixture whose bins had not all converged after max_iter steps
+ * (the reference's UserWarning).  info: incremented per singular per-bin system.
+ * replaces: ssspy/bss/_update_spatial_model.py:398-513 (update_by_ipa), linalg/lqpqm.py:13-352
+ * (lqpqm2, solve_equation). */
 int ssspy_ipa_sweep(void *Vc, void *G, int B, int F, int N, int normalization, int max_iter,
                     int floor_kind, double floor_eps, int *info, void *newton_ws,
                     int *not_converged, void *stream);
@@ -674,7 +667,7 @@ int ssspy_gmeanmh(const void *A, const void *Bm, void *G, long long n, int M, in
                   void *stream);
 /* y = argmin of the log-quadratically penalised quadratic (type 2): H (n, L, L) Hermitian, v (n, L),
  * z (n) -> y (n, L), L in [1, 7].  newton_ws (one 64-bit word of scratch) / not_converged: as for
- * ssspy_ipa_transform, the n problems forming one group (the reference's loop stops when all of them
+ * ssspy_ipa_sweep, the n problems forming one group (the reference's loop stops when all of them
  * have converged); NULL: max_iter Newton steps per problem.
  * replaces: ssspy/linalg/lqpqm.py:13-352 (lqpqm2 with singular_fn = "x < flooring_fn(0)"). */
 int ssspy_lqpqm2(const void *H, const void *v, const double *z, void *y, long long n, int L,

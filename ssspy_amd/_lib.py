@@ -42,7 +42,6 @@ PROTOTYPES = {
     "ssspy_scale_filter_row": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "ssspy_iss1_transform": (_i, [_p, _p, _i, _i, _i, _i, _d, _p]),
     "ssspy_update_by_ip2": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
-    "ssspy_ipa_transform": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p]),
     "ssspy_covariance_congruence": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "ssspy_covariance_congruence_sets": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "ssspy_covariance_congruence_tracked": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p]),

@@ -272,23 +272,6 @@ def iss2_transform(Vc, pairs, flooring, info=None, out=None):
     return out
 
 
-def ipa_transform(Vc, source_idx, normalization, max_iter, flooring, info=None, out=None,
-                  newton_ws=None, not_converged=None):
-    """newton_ws (B int64 words of scratch): the Newton loop makes the reference's number of steps
-    (it stops when every bin of a mixture has converged); not_converged (int32 counter): mixtures
-    whose bins had not all converged after max_iter steps."""
-    B, F, N = Vc.shape[0], Vc.shape[1], Vc.shape[-1]
-    if out is None:
-        out = dv.empty((B, F, N, N), dv.c128, Vc.device)
-    _lib.check(
-        _L().ssspy_ipa_transform(ptr(Vc), ptr(out), int(source_idx), B, F, N,
-                                 int(bool(normalization)), int(max_iter), flooring[0], flooring[1],
-                                 ptr(info), ptr(newton_ws), ptr(not_converged), _st()),
-        "ipa_transform",
-    )
-    return out
-
-
 def ipa_sweep(Vc, normalization, max_iter, flooring, info=None, out=None, newton_ws=None,
               not_converged=None):
     """All N source steps of an IPA sweep on the per-bin statistics Vc (overwritten: V_m <- G V_m G^H

@@ -6,8 +6,8 @@
 // (Hermitian Jacobi eigen-decomposition, Cardano start value, Newton steps on the secular
 // equation), and writes the N x N matrix G with  y <- G y:
 //   row s of G = p^H,  G[m][s] = conj(q_m) for m != s,  identity elsewhere.
-// The caller runs  weighted_covariance -> this -> separate  once per source (ssspy_ipa_transform), or
-// -- round 5 -- weighted_covariance once, the N source steps chained on the per-bin statistics
+// The reference runs  weighted_covariance -> this -> separate  once per source; here -- round 5 --
+// weighted_covariance runs once, the N source steps chained on the per-bin statistics
 // (V_m <- G V_m G^H), one separate with the accumulated transform (ssspy_ipa_sweep): 3 passes over the
 // spectrogram per sweep instead of 3 N.
 //
@@ -227,7 +227,7 @@ __device__ __forceinline__ constexpr int rest_index(int m) {
   return m < S ? m : m + 1;
 }
 
-// One source step of a bin (the body of k_ipa_transform and of the fused sweep).
+// One source step of a bin (the body of the fused sweep).
 // `live`: false in the lanes a fused sweep keeps behind the last bin of its mixture (they walk a
 // copy of that bin so that the wave reaches every vote, and store nothing)
 template <int N, int S, int MODE, class Vote = NoVote>
@@ -498,24 +498,9 @@ __device__ __forceinline__ void ipa_source_step(const c128 *Vc, c128 *__restrict
   }
 }
 
-// Vc: (nbins, N, N, N) weighted covariances; G: (nbins, N, N).  One lane per bin.
-// (one wave per SIMD: the N x N working set of the larger source counts wants the whole 512-entry
-// register file; the grid has only B*F lanes anyway)
-template <int N, int S, int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ipa_transform(const c128 *Vc,
-                                                      c128 *__restrict__ G, long long nbins,
-                                                      int F, int normalization, int max_iter,
-                                                      int floor_kind, double eps, int *info,
-                                                      unsigned long long *newton_ws,
-                                                      c128 *Vchain, int chain_first) {
-  const long long bin = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (bin >= nbins) return;
-  unsigned long long *word = MODE == NEWTON_FIXED ? nullptr : newton_ws + bin / F;
-  ipa_source_step<N, S, MODE>(Vc, G, bin, true, normalization, max_iter, floor_kind, eps, info, word,
-                              Vchain, chain_first);
-}
-
-// ---- the whole sweep of up to 4 sources in ONE launch (round 6).  Rounds 4-5 spent four launches
+// ---- the whole sweep of up to 7 sources in ONE launch (round 6).  One lane per bin; one wave per
+// SIMD (the N x N working set of the larger source counts wants the whole 512-entry register file;
+// the grid has only B F lanes anyway).  Rounds 4-5 spent four launches
 // per source step: a memset of the vote words, the probe (everything up to the Newton iteration,
 // 50 us at 32 mixtures of configs[1]), the step count, and the apply, which recomputes the probe's
 // state (31 us) -- 16 launches and 0.33 ms per iteration at 4 sources.  Here a workgroup (one wave,
@@ -658,99 +643,16 @@ static int newton_finish(unsigned long long *ws, int ngroups, int max_iter, int 
   return check_launch("k_newton_steps");
 }
 
-template <int N, int S>
-static int launch_one(const void *Vc, void *G, long long nbins, int B, int F, int normalization,
-                      int max_iter, int floor_kind, double eps, int *info,
-                      unsigned long long *newton_ws, int *not_converged, hipStream_t st,
-                      c128 *Vchain = nullptr, int chain_first = 0) {
-  dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
-  if (!newton_ws || max_iter > 62 || max_iter == 0) {
-    hipLaunchKernelGGL((k_ipa_transform<N, S, NEWTON_FIXED>), grid, block, 0, st, (const c128 *)Vc,
-                       (c128 *)G, nbins, F, normalization, max_iter, floor_kind, eps, info,
-                       (unsigned long long *)nullptr, Vchain, chain_first);
-    return check_launch("k_ipa_transform");
-  }
-  int rc = newton_prepare(newton_ws, B, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL((k_ipa_transform<N, S, NEWTON_PROBE>), grid, block, 0, st, (const c128 *)Vc,
-                     (c128 *)G, nbins, F, normalization, max_iter, floor_kind, eps, info,
-                     newton_ws, (c128 *)nullptr, 0);
-  rc = check_launch("k_ipa_transform (probe)");
-  if (rc) return rc;
-  rc = newton_finish(newton_ws, B, max_iter, not_converged, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL((k_ipa_transform<N, S, NEWTON_APPLY>), grid, block, 0, st, (const c128 *)Vc,
-                     (c128 *)G, nbins, F, normalization, max_iter, floor_kind, eps, info,
-                     newton_ws, Vchain, chain_first);
-  return check_launch("k_ipa_transform");
-}
-
-// ipa_rows.hip: the source step with a bin on 8 lanes (5..8 sources; source count and index at run time)
+// ipa_rows.hip: the sweep of 8 sources with a bin on 8 lanes
 bool ipa_rows_wanted(int N);
-int ipa_rows_launch(int mode, const void *Vc, void *G, long long nbins, int F, int N, int S,
-                    int normalization, int max_iter, int floor_kind, double eps, int *info,
-                    unsigned long long *newton_ws, void *Vchain, int chain_first, hipStream_t st);
-
-static int launch_rows(const void *Vc, void *G, long long nbins, int B, int F, int N, int S,
-                       int normalization, int max_iter, int floor_kind, double eps, int *info,
-                       unsigned long long *newton_ws, int *not_converged, hipStream_t st,
-                       c128 *Vchain, int chain_first) {
-  if (!newton_ws || max_iter > 62 || max_iter == 0)
-    return ipa_rows_launch(NEWTON_FIXED, Vc, G, nbins, F, N, S, normalization, max_iter, floor_kind,
-                           eps, info, nullptr, Vchain, chain_first, st);
-  int rc = newton_prepare(newton_ws, B, st);
-  if (rc) return rc;
-  rc = ipa_rows_launch(NEWTON_PROBE, Vc, G, nbins, F, N, S, normalization, max_iter, floor_kind, eps,
-                       info, newton_ws, nullptr, 0, st);
-  if (rc) return rc;
-  rc = newton_finish(newton_ws, B, max_iter, not_converged, st);
-  if (rc) return rc;
-  return ipa_rows_launch(NEWTON_APPLY, Vc, G, nbins, F, N, S, normalization, max_iter, floor_kind,
-                         eps, info, newton_ws, Vchain, chain_first, st);
-}
+int ipa_rows_sweep(bool votes, void *Vc, void *G, int B, int F, int N, int normalization,
+                   int max_iter, int floor_kind, double eps, int *info, unsigned long long *ws,
+                   int *not_converged, hipStream_t st);
+int ipa_rows_barrier_timeouts();
 
 }  // namespace ssspy
 
 using namespace ssspy;
-
-// one source step; Vchain != NULL: the chained form (statistics and accumulated transform updated in
-// place, see the kernel)
-static int ipa_step(const void *Vc, void *G, int source_idx, int B, int F, int N, int normalization,
-                    int max_iter, int floor_kind, double floor_eps, int *info, void *newton_ws,
-                    int *not_converged, hipStream_t st, c128 *Vchain, int chain_first) {
-  const long long nbins = (long long)B * F;
-  if (ipa_rows_wanted(N))
-    return launch_rows(Vc, G, nbins, B, F, N, source_idx, normalization, max_iter, floor_kind,
-                       floor_eps, info, (unsigned long long *)newton_ws, not_converged, st, Vchain,
-                       chain_first);
-#define IPA_CASE(N_, S_)                                                                     \
-  if (N == N_ && source_idx == S_)                                                           \
-    return launch_one<N_, S_>(Vc, G, nbins, B, F, normalization, max_iter, floor_kind,     \
-                              floor_eps, info, (unsigned long long *)newton_ws, not_converged, \
-                              st, Vchain, chain_first);
-  IPA_CASE(2, 0) IPA_CASE(2, 1)
-  IPA_CASE(3, 0) IPA_CASE(3, 1) IPA_CASE(3, 2)
-  IPA_CASE(4, 0) IPA_CASE(4, 1) IPA_CASE(4, 2) IPA_CASE(4, 3)
-  IPA_CASE(5, 0) IPA_CASE(5, 1) IPA_CASE(5, 2) IPA_CASE(5, 3) IPA_CASE(5, 4)
-  IPA_CASE(6, 0) IPA_CASE(6, 1) IPA_CASE(6, 2) IPA_CASE(6, 3) IPA_CASE(6, 4) IPA_CASE(6, 5)
-  IPA_CASE(7, 0) IPA_CASE(7, 1) IPA_CASE(7, 2) IPA_CASE(7, 3) IPA_CASE(7, 4) IPA_CASE(7, 5)
-  IPA_CASE(7, 6)
-#undef IPA_CASE
-  return fail(SSSPY_ERR_UNSUPPORTED, "ipa_transform: unsupported (n_sources, source) pair");
-}
-
-extern "C" int ssspy_ipa_transform(const void *Vc, void *G, int source_idx, int B, int F, int N,
-                                   int normalization, int max_iter, int floor_kind,
-                                   double floor_eps, int *info, void *newton_ws,
-                                   int *not_converged, void *stream) {
-  SSSPY_REQUIRE(Vc && G && B > 0 && F > 0, "ipa_transform: bad argument");
-  SSSPY_REQUIRE(source_idx >= 0 && source_idx < N, "ipa_transform: bad source index");
-  SSSPY_REQUIRE(max_iter >= 0, "ipa_transform: max_iter must be non-negative");
-  if (N < 2 || N > SSSPY_MAX_SOURCES)
-    return fail(SSSPY_ERR_UNSUPPORTED, "IPA is built for n_sources in [2, 8]");
-  return ipa_step(Vc, G, source_idx, B, F, N, normalization, max_iter, floor_kind, floor_eps, info,
-                  newton_ws, not_converged, as_stream(stream), nullptr, 0);
-}
 
 extern "C" int ssspy_ipa_sweep(void *Vc, void *G, int B, int F, int N, int normalization,
                                int max_iter, int floor_kind, double floor_eps, int *info,
@@ -759,16 +661,20 @@ extern "C" int ssspy_ipa_sweep(void *Vc, void *G, int B, int F, int N, int norma
   SSSPY_REQUIRE(max_iter >= 0, "ipa_sweep: max_iter must be non-negative");
   if (N < 2 || N > SSSPY_MAX_SOURCES)
     return fail(SSSPY_ERR_UNSUPPORTED, "IPA is built for n_sources in [2, 8]");
-  if (N <= 4) {  // one launch for the whole sweep (k_ipa_sweep_fused)
-    hipStream_t st = as_stream(stream);
-    const bool votes = newton_ws && max_iter >= 1 && max_iter <= 62;
-    unsigned long long *ws = (unsigned long long *)newton_ws;
-    if (votes) {
-      hipLaunchKernelGGL(k_ipa_sweep_prepare, dim3((B * N + 255) / 256), dim3(256), 0, st, ws, B * N);
-      const int rc = check_launch("k_ipa_sweep_prepare");
-      if (rc) return rc;
-    }
-    const dim3 grid((F + 63) / 64, B), block(64);
+  // one launch for the whole sweep: a lane per bin up to 7 sources (k_ipa_sweep_fused), a bin on 8
+  // lanes at 8 (k_ipa_rows)
+  hipStream_t st = as_stream(stream);
+  const bool votes = newton_ws && max_iter >= 1 && max_iter <= 62;
+  unsigned long long *ws = (unsigned long long *)newton_ws;
+  if (votes) {
+    hipLaunchKernelGGL(k_ipa_sweep_prepare, dim3((B * N + 255) / 256), dim3(256), 0, st, ws, B * N);
+    const int rc = check_launch("k_ipa_sweep_prepare");
+    if (rc) return rc;
+  }
+  if (ipa_rows_wanted(N))
+    return ipa_rows_sweep(votes, Vc, G, B, F, N, normalization, max_iter, floor_kind, floor_eps,
+                          info, ws, not_converged, st);
+  const dim3 grid((F + 63) / 64, B), block(64);
 #define IPA_FUSED(N_)                                                                              \
   if (N == N_) {                                                                                   \
     if (votes)                                                                                     \
@@ -780,16 +686,9 @@ extern "C" int ssspy_ipa_sweep(void *Vc, void *G, int B, int F, int N, int norma
                          (c128 *)G, F, normalization, max_iter, floor_kind, floor_eps, info, ws, B, \
                          not_converged);                                                           \
   }
-    IPA_FUSED(2) IPA_FUSED(3) IPA_FUSED(4)
+  IPA_FUSED(2) IPA_FUSED(3) IPA_FUSED(4) IPA_FUSED(5) IPA_FUSED(6) IPA_FUSED(7)
 #undef IPA_FUSED
-    return check_launch("k_ipa_sweep_fused");
-  }
-  for (int s = 0; s < N; ++s) {
-    const int rc = ipa_step(Vc, G, s, B, F, N, normalization, max_iter, floor_kind, floor_eps, info,
-                            newton_ws, not_converged, as_stream(stream), (c128 *)Vc, s == 0);
-    if (rc) return rc;
-  }
-  return SSSPY_OK;
+  return check_launch("k_ipa_sweep_fused");
 }
 
 extern "C" size_t ssspy_ipa_sweep_newton_words(int B, int N) {
@@ -801,7 +700,8 @@ extern "C" int ssspy_debug_barrier_timeouts(void) {
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ipa_barrier_timeouts), sizeof(int), 0,
                           hipMemcpyDeviceToHost) != hipSuccess)
     return -1;
-  return v;
+  const int rows = ipa_rows_barrier_timeouts();
+  return rows < 0 ? -1 : v + rows;
 }
 
 static int lqpqm2_launch(const void *H, const void *v, const double *z, void *y, long long n, int L,

@@ -5,7 +5,7 @@
 // ipa_kernels.hip is one function per (N, source, mode) -- 72 of them above 4 sources, each with
 // unrolled 7 x 7 / 8 x 8 Jacobi bodies on 1 000-2 000 spilled VGPRs.
 //
-// Same algorithm, statement by statement, as k_ipa_transform (see there for the reference lines:
+// Same algorithm, statement by statement, as ipa_source_step of ipa_kernels.hip (see there for the reference lines:
 // ssspy/bss/_update_spatial_model.py:398-513, :611-645, ssspy/linalg/lqpqm.py:13-352):
 //   a_m, b_m from to_psd(U_m), m != S (Cholesky test of the floor, eigen route when it acts);
 //   U_S^-1 (doubly floored) -> C, d, z;  H, v;  LQPQM2 (Hermitian Jacobi, Cardano start, Newton);
@@ -91,24 +91,28 @@ __device__ __forceinline__ bool chol_inverse_rows(c128 (&a)[8], c128 *X, int r, 
   return ok;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void k_ipa_rows(const c128 *Vc, c128 *__restrict__ G,
-                                                  long long nbins, int F, int N, int S,
-                                                  int normalization, int max_iter, int floor_kind,
-                                                  double eps, int *info,
-                                                  unsigned long long *newton_ws, c128 *Vchain,
-                                                  int chain_first) {
-  __shared__ c128 slots[BINS * SLOT];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 7, g = wave * 8 + (lane >> 3);
-  c128 *X = slots + g * SLOT;
-  const long long bin_raw = (long long)blockIdx.x * BINS + g;
-  const bool live = bin_raw < nbins;
-  const long long bin = live ? bin_raw : nbins - 1;  // idle groups shadow the last bin, never store or vote
-  unsigned long long *word = MODE == NEWTON_FIXED ? nullptr : newton_ws + bin / F;
-  const c128 *Ub = Vc + bin * (long long)(N * N * N);
-  const bool rest = r < N && r != S;
+// Round 6: the whole sweep in one launch -- a workgroup walks the N source steps of its 32 bins of
+// ONE mixture and, at every Newton vote, meets the mixture's other workgroups (vote word + arrival
+// counter per (mixture, step) in newton_ws, see k_ipa_sweep_fused in ipa_kernels.hip) instead of
+// ending the kernel: 4 launches per source step before (vote memset, probe, step count, apply --
+// the apply repeating the probe's work).
+enum { ROWS_FUSED_FIXED = 4 };
+__device__ int g_ipa_rows_barrier_timeouts;
+
+// One source step (S at compile time: as a loop variable it costs the register arrays indexed by
+// it their registers -- 86 -> 615 spilled VGPRs -- so the sweep is eight instances in a row).
+template <int MODE, int S>
+__device__ __forceinline__ void ipa_rows_step(const c128 *Ub, c128 *__restrict__ G, c128 *Vchain,
+                                              c128 *X, unsigned long long *vote_word,
+                                              long long bin, bool live, int r, int lane, int N,
+                                              int normalization, int max_iter, int floor_kind,
+                                              double eps, int *info, unsigned long long *newton_ws,
+                                              int B, int *not_converged) {
   const double f0 = floor_of_zero(floor_kind, eps);
+  const int chain_first = S == 0 ? 1 : 0;
+  unsigned long long *word =
+      MODE == NEWTON_FUSED ? newton_ws + (long long)blockIdx.y * N + S : nullptr;
+  const bool rest = r < N && r != S;
 
   // ---- a_m = Re to_psd(U_m)[S][S], b_m = to_psd(U_m)[S][m], m != S (every lane keeps all of them)
   double a[8];
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void k_ipa_rows(const c128 *Vc, c128 *__res
     for (int c = 0; c < 8; ++c) t[c] = cm[c];
     if (!rest) put(t, r, cmake(1.0, 0.0));
     const bool ok = chol_inverse_rows(t, X, r, cinv);
-    if (MODE != NEWTON_PROBE && !ok && info && live && r == 0) atomicAdd(info, 1);
+    if (!ok && info && live && r == 0) atomicAdd(info, 1);
     x = cmake(0.0, 0.0);
 #pragma unroll
     for (int c = 0; c < 8; ++c) cfma(x, cinv[c], shfl8(d, c));
@@ -240,35 +244,19 @@ __global__ __launch_bounds__(256, 2) void k_ipa_rows(const c128 *Vc, c128 *__res
   const double vnorm2 = sum8(cabs2(v));
   const bool is_singular = sqrt(vnorm2) < f0;
   c128 qc = cmake(0.0, 0.0);  // component r of the LQPQM solution
-  if (is_singular) {
-    // v = 0: scale * (last row of the eigenvector matrix in ascending-eigenvalue column order), see
-    // lqpqm2 in ipa_kernels.hip
-    double pmax = -1.7976931348623157e308;
-#pragma unroll
-    for (int l = 0; l < 8; ++l)
-      if (l < N && l != S) pmax = fmax(pmax, phi[l]);
-    const double lamb = fmax(z, pmax);
-    const double scale = sqrt(fmax((lamb - z) / pmax, 0.0));
-    const int last = S == N - 1 ? N - 2 : N - 1;
-    const int mypos = r < S ? r : r - 1;  // my position among the rest indices
-#pragma unroll
-    for (int l = 0; l < 8; ++l) {
-      const c128 val = cscale(shfl8(sg[l], last), scale);
-      int rank = 0;
-#pragma unroll
-      for (int m = 0; m < 8; ++m)
-        rank += (m < N && m != S && (phi[m] < phi[l] || (phi[m] == phi[l] && m < l))) ? 1 : 0;
-      if (l < N && l != S && rest && rank == mypos) qc = val;
-    }
-  } else {
-    // vt = sigma^H v (column sums over the lanes)
-    c128 vt[8];
+  // The Newton iteration of a regular problem (solve_equation, lqpqm.py:112-200; the same
+  // arithmetic in every lane of the group): `steps` steps from the Cardano start value.  solve =
+  // false: the convergence bits of the states before steps 0 .. `steps`; true: component r of the
+  // solution.  A fused sweep runs it twice, around the mixture's vote -- nothing of it stays live
+  // across the wait (keeping vt / phi~ / |v~|^2 there cost 600 spilled VGPRs).
+  unsigned long long bits = 0ull;
+  auto newton = [&](int steps, bool solve) {
+    c128 vt[8];  // sigma^H v (column sums over the lanes)
 #pragma unroll
     for (int l = 0; l < 8; ++l) {
       const c128 t = cmulc(v, sg[l]);  // v_r conj(sigma_rl)
       vt[l] = cmake(sum8(t.x), sum8(t.y));
     }
-    // solve_equation (lqpqm.py:112-200), the same arithmetic in every lane
     double ph[8], w2[8];
     double pmax = 0.0, v2max = 0.0;
     bool first = true;
@@ -296,8 +284,6 @@ __global__ __launch_bounds__(256, 2) void k_ipa_rows(const c128 *Vc, c128 *__res
     double lamb = largest_cubic_root(A, Bc, Cc);
     if (!(lamb > 1.0)) lamb = 1.0 + f0;
     lamb = fmax(lamb, zn);
-    const int steps = MODE == NEWTON_APPLY ? (int)*word : max_iter;
-    unsigned long long bits = 0ull;
     for (int it = 0; it <= steps; ++it) {
       double s2 = 0.0, s3 = 0.0;
 #pragma unroll
@@ -309,13 +295,13 @@ __global__ __launch_bounds__(256, 2) void k_ipa_rows(const c128 *Vc, c128 *__res
         }
       }
       const double f = lamb * lamb * s2 - lamb + zn;
-      if (fabs(f) <= f0) bits |= 1ull << it;
+      if (!solve && fabs(f) <= f0) bits |= 1ull << it;
       if (it == steps) break;
       const double df = -2.0 * lamb * s3 - 1.0;
       const double mu = lamb - f / df;
       lamb = mu > 1.0 ? mu : 0.5 * (1.0 + lamb);
     }
-    if (MODE != NEWTON_PROBE) {
+    if (solve) {
       lamb *= pm;
 #pragma unroll
       for (int l = 0; l < 8; ++l) {
@@ -324,25 +310,69 @@ __global__ __launch_bounds__(256, 2) void k_ipa_rows(const c128 *Vc, c128 *__res
           cfma(qc, sg[l], cscale(vt[l], gl));
         }
       }
-    } else {
-      // one vote per bin (lane 0 of the group), one atomic per (wave, mixture): as in lqpqm2
-      const bool voter = live && r == 0;
-      unsigned long long todo = __ballot(voter);
-      const unsigned long long mine_word = (unsigned long long)word;
-      while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const unsigned long long lw = __shfl(mine_word, leader, 64);
-        const bool mine = voter && mine_word == lw;
-        const unsigned long long group = __ballot(mine);
-        unsigned long long all = 0ull;
-        for (int it = 0; it <= steps; ++it)
-          if (__ballot(mine && !((bits >> it) & 1ull)) == 0ull) all |= 1ull << it;
-        if ((int)(threadIdx.x & 63) == leader) atomicAnd(word, all);
-        todo &= ~group;
-      }
     }
+  };
+  if (is_singular) {
+    // v = 0: scale * (last row of the eigenvector matrix in ascending-eigenvalue column order), see
+    // lqpqm2 in ipa_kernels.hip
+    double pmax = -1.7976931348623157e308;
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+      if (l < N && l != S) pmax = fmax(pmax, phi[l]);
+    const double lamb = fmax(z, pmax);
+    const double scale = sqrt(fmax((lamb - z) / pmax, 0.0));
+    const int last = S == N - 1 ? N - 2 : N - 1;
+    const int mypos = r < S ? r : r - 1;  // my position among the rest indices
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      const c128 val = cscale(shfl8(sg[l], last), scale);
+      int rank = 0;
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+        rank += (m < N && m != S && (phi[m] < phi[l] || (phi[m] == phi[l] && m < l))) ? 1 : 0;
+      if (l < N && l != S && rest && rank == mypos) qc = val;
+    }
+  } else {
+    newton(max_iter, MODE != NEWTON_FUSED);
   }
-  if (MODE == NEWTON_PROBE) return;
+  if (MODE == NEWTON_FUSED) {
+    // the mixture's vote: one AND per wave, then every workgroup of the mixture meets
+    const bool voter = live && r == 0 && !is_singular;
+    unsigned long long all = ~0ull;
+    for (int it = 0; it <= max_iter; ++it)
+      if (__ballot(voter && !((bits >> it) & 1ull)) != 0ull) all &= ~(1ull << it);
+    if (lane == 0) __hip_atomic_fetch_and(word, all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned *counter = (unsigned *)(newton_ws + (long long)B * N + (long long)blockIdx.y * N + S);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      long long spins = 0;
+      while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1ll << 23)) {
+          atomicAdd(&g_ipa_rows_barrier_timeouts, 1);
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      *vote_word = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned long long w = *vote_word;
+    int agreed = max_iter;
+    for (int k = 0; k < max_iter; ++k)
+      if ((w >> k) & 1ull) {
+        agreed = k;
+        break;
+      }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && agreed == max_iter && !((w >> max_iter) & 1ull) &&
+        not_converged)
+      atomicAdd(not_converged, 1);
+    if (!is_singular) newton(agreed, true);
+    __syncthreads();  // (vote_word is rewritten by the next source step)
+  }
 
   // ---- q = q_check / a_sqrt - b / a;  q~ = e_S - E conj(q);  p = U_S^-1 q~ / floor(sqrt(q~^H U_S^-1 q~))
   const double a_r = seld(a, r);
@@ -445,6 +475,36 @@ __global__ __launch_bounds__(256, 2) void k_ipa_rows(const c128 *Vc, c128 *__res
         if (c < N) Mb[r * N + c] = mr[c];
     }
   }
+  // the next source step re-reads what this one stored (other lanes' rows)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wsync();
+}
+
+// MODE NEWTON_FUSED / ROWS_FUSED_FIXED: with / without the mixtures' Newton votes.
+// grid (ceil(F / 32), B), 256 threads = 32 bins x 8 lanes; N == 8 (lanes beyond N would idle)
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_ipa_rows(c128 *Vc, c128 *__restrict__ G, int F, int N,
+                                                     int normalization, int max_iter,
+                                                     int floor_kind, double eps, int *info,
+                                                     unsigned long long *newton_ws, int B,
+                                                     int *not_converged) {
+  __shared__ c128 slots[BINS * SLOT];
+  __shared__ unsigned long long vote_word;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 7, g = wave * 8 + (lane >> 3);
+  c128 *X = slots + g * SLOT;
+  const int local = blockIdx.x * BINS + g;
+  const bool live = local < F;
+  // idle groups shadow the last bin of the mixture, never store or vote
+  const long long bin = (long long)blockIdx.y * F + (live ? local : F - 1);
+  c128 *Ub = Vc + bin * (long long)(N * N * N);
+#define SSSPY_ROWS_STEP(S_)                                                                       \
+  if (S_ < N)                                                                                     \
+    ipa_rows_step<MODE, S_>(Ub, G, Vc, X, &vote_word, bin, live, r, lane, N, normalization,       \
+                            max_iter, floor_kind, eps, info, newton_ws, B, not_converged);
+  SSSPY_ROWS_STEP(0) SSSPY_ROWS_STEP(1) SSSPY_ROWS_STEP(2) SSSPY_ROWS_STEP(3)
+  SSSPY_ROWS_STEP(4) SSSPY_ROWS_STEP(5) SSSPY_ROWS_STEP(6) SSSPY_ROWS_STEP(7)
+#undef SSSPY_ROWS_STEP
 }
 
 }  // namespace
@@ -458,23 +518,27 @@ __global__ __launch_bounds__(256, 2) void k_ipa_rows(const c128 *Vc, c128 *__res
 // of the padded 8-lane step (8 mixtures of 513 bins, profiles/r05_leg_survey.txt).
 bool ipa_rows_wanted(int N) { return N == 8; }
 
-int ipa_rows_launch(int mode, const void *Vc, void *G, long long nbins, int F, int N, int S,
-                    int normalization, int max_iter, int floor_kind, double eps, int *info,
-                    unsigned long long *newton_ws, void *Vchain, int chain_first, hipStream_t st) {
-  const dim3 grid((unsigned)((nbins + BINS - 1) / BINS)), block(256);
-  if (mode == NEWTON_FIXED)
-    hipLaunchKernelGGL((k_ipa_rows<NEWTON_FIXED>), grid, block, 0, st, (const c128 *)Vc, (c128 *)G,
-                       nbins, F, N, S, normalization, max_iter, floor_kind, eps, info, newton_ws,
-                       (c128 *)Vchain, chain_first);
-  else if (mode == NEWTON_PROBE)
-    hipLaunchKernelGGL((k_ipa_rows<NEWTON_PROBE>), grid, block, 0, st, (const c128 *)Vc, (c128 *)G,
-                       nbins, F, N, S, normalization, max_iter, floor_kind, eps, info, newton_ws,
-                       (c128 *)Vchain, chain_first);
+// the whole sweep of 8 sources: votes = the mixtures' Newton votes are held (else max_iter steps
+// everywhere); ws: prepared by the caller (k_ipa_sweep_prepare)
+int ipa_rows_sweep(bool votes, void *Vc, void *G, int B, int F, int N, int normalization,
+                   int max_iter, int floor_kind, double eps, int *info, unsigned long long *ws,
+                   int *not_converged, hipStream_t st) {
+  const dim3 grid((unsigned)((F + BINS - 1) / BINS), (unsigned)B), block(256);
+  if (votes)
+    hipLaunchKernelGGL((k_ipa_rows<NEWTON_FUSED>), grid, block, 0, st, (c128 *)Vc, (c128 *)G, F, N,
+                       normalization, max_iter, floor_kind, eps, info, ws, B, not_converged);
   else
-    hipLaunchKernelGGL((k_ipa_rows<NEWTON_APPLY>), grid, block, 0, st, (const c128 *)Vc, (c128 *)G,
-                       nbins, F, N, S, normalization, max_iter, floor_kind, eps, info, newton_ws,
-                       (c128 *)Vchain, chain_first);
+    hipLaunchKernelGGL((k_ipa_rows<ROWS_FUSED_FIXED>), grid, block, 0, st, (c128 *)Vc, (c128 *)G, F,
+                       N, normalization, max_iter, floor_kind, eps, info, ws, B, not_converged);
   return check_launch("k_ipa_rows");
+}
+
+int ipa_rows_barrier_timeouts() {
+  int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ipa_rows_barrier_timeouts), sizeof(int), 0,
+                          hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  return v;
 }
 
 }  // namespace ssspy
