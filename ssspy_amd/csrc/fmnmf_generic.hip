@@ -9,7 +9,8 @@
 //   loss     sum_m |q_m^H x|^2 / R~_m + log R~_m
 // in HBM; small kernels contract them with the activation (over frames) or the basis (over bins), and
 // the spatial update folds its N x M sums per bin through LDS.  Per iteration that is five passes over
-// X instead of four plus the (N, F, T) traces: a correct general path, not a tuned one.
+// X instead of four plus the (N, F, T) traces.  Round 6: the passes walk runs of bins with the
+// activation column of a frame held in registers (k_walk) instead of re-reading it per bin.
 //
 // replaces: ssspy/bss/mnmf.py:1278-1303 (update_once), :1305-1417, :1449-1514, :1635-1675, :632-678,
 //           :1219-1261 (loss), :1174-1217 (Wiener filter) for shapes outside N, M <= 4.
@@ -29,224 +30,395 @@ namespace fmg {
 constexpr int NMAX = SSSPY_MAX_SOURCES;
 enum { MODE_TRACES = 0, MODE_WEIGHTS = 1, MODE_LOSS = 2 };
 
-// Q, D and basis rows of one bin in LDS: Qs[M*M], Ds[N*M], Ts[N*K]
+// ---- Round 6.  Rounds 3-5 ran one workgroup per (bin, frame block): every point recomputed
+// lambda_n = sum_k t_nik v_nkj from activation rows that all F bins of a mixture re-read -- 64 loads
+// per point, 4.3 GB through the L2 per pass at 8 mixtures of 8 channels (24 TB/s: the passes ran at
+// the L2's rate, 1.5 TB/s of HBM traffic) -- and the two contractions read the traces once per
+// basis index.  Now a workgroup keeps the activation tile of ITS 64 frames in LDS (n_basis <= 8:
+// 32 KB) and each of its waves walks a run of bins with it, the bin's Q, D and basis rows staged in
+// a wave-private LDS patch; wider bases take the column from memory per bin as before.  (The column
+// in 128 registers per lane was tried first: the Wiener-filter mode then spilled 500 of them.)
+constexpr int KT = 8;   // activation rows per source a lane holds
+constexpr int WB = 4;   // waves per workgroup, each walking its own run of bins
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Q, D and the basis rows of one bin, private to a wave
 template <int M>
-__device__ __forceinline__ void stage_bin(c128 *Qs, double *Ds, double *Ts,
-                                          const c128 *__restrict__ Q,
-                                          const double *__restrict__ Dsp,
-                                          const double *__restrict__ basis, int b, int N, int F,
-                                          int K, int i) {
-  for (int e = threadIdx.x; e < M * M; e += blockDim.x) Qs[e] = Q[((long long)b * F + i) * (M * M) + e];
-  for (int e = threadIdx.x; e < N * M; e += blockDim.x) Ds[e] = Dsp[((long long)b * F + i) * (N * M) + e];
-  for (int e = threadIdx.x; e < N * K; e += blockDim.x) {
-    const int n = e / K, k = e % K;
-    Ts[e] = basis[(((long long)b * N + n) * F + i) * K + k];
+struct WaveBin {
+  c128 q[M * M];
+  double d[NMAX * M];   // d[n * M + m], zero beyond N
+  double t[NMAX * KT];  // t[n * KT + k], zero beyond (N, K); unused when K > KT
+};
+
+template <int M>
+__device__ __forceinline__ void stage_wave(WaveBin<M> &s, const c128 *__restrict__ Q,
+                                           const double *__restrict__ Dsp,
+                                           const double *__restrict__ basis, int b, int N, int F,
+                                           int K, int i, int lane) {
+  const long long bin = (long long)b * F + i;
+  wave_lds_sync();  // (the previous bin's reads are done)
+  for (int e = lane; e < M * M; e += 64) s.q[e] = Q[bin * (M * M) + e];
+  for (int e = lane; e < NMAX * M; e += 64) s.d[e] = e < N * M ? Dsp[bin * (N * M) + e] : 0.0;
+  if (K <= KT)
+    for (int e = lane; e < NMAX * KT; e += 64) {
+      const int n = e / KT, k = e % KT;
+      s.t[e] = (n < N && k < K) ? basis[(((long long)b * N + n) * F + i) * K + k] : 0.0;
+    }
+  wave_lds_sync();
+}
+
+// the workgroup's activation tile (n_basis <= KT): vt[n * KT + k][lane] = act[b, n, k, j0 + lane],
+// shared by its four waves (they walk different bins of the same 64 frames); zero beyond (N, K)
+__device__ __forceinline__ void load_tile(double (*vt)[64], const double *__restrict__ act_b, int N,
+                                          int T, int K, int j0) {
+  for (int e = threadIdx.x >> 6; e < NMAX * KT; e += WB) {
+    const int n = e / KT, k = e % KT, lane = threadIdx.x & 63;
+    const int j = min(j0 + lane, T - 1);
+    vt[e][lane] = (n < N && k < K) ? act_b[((long long)n * K + k) * T + j] : 0.0;
   }
   __syncthreads();
 }
 
-static inline size_t bin_smem(int N, int M, int K) {
-  return (size_t)M * M * sizeof(c128) + ((size_t)N * M + (size_t)N * K) * sizeof(double);
+// lam[n] = sum_k t_nik v_nkj of bin i at the lane's frame
+template <int M>
+__device__ __forceinline__ void lambda_terms(double (&lam)[NMAX], const double (*vt)[64],
+                                             const WaveBin<M> &s, const double *__restrict__ act_b,
+                                             const double *__restrict__ basis, int b, int N, int F,
+                                             int T, int K, int i, int j) {
+  if (K <= KT) {
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+      double l = 0.0;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) l = fma(s.t[n * KT + k], vt[n * KT + k][threadIdx.x & 63], l);
+      lam[n] = l;
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+      double l = 0.0;
+      if (n < N) {
+        const double *tr = basis + (((long long)b * N + n) * F + i) * K;
+        for (int k = 0; k < K; ++k) l = fma(tr[k], act_b[((long long)n * K + k) * T + j], l);
+      }
+      lam[n] = l;
+    }
+  }
+  // (scheduling fences between the phases of a point: left alone, hipcc hoists the LDS reads of all
+  //  of them to the top and spills the activation column)
+  __builtin_amdgcn_sched_barrier(0);
 }
 
-// per-point terms: lam[n], qx2[m] = |(Q x)_m|^2, rc[m] = R~_m
+// per-point terms of bin i: lam[n], qx2[m] = |(Q x)_m|^2, rc[m] = R~_m
 template <int M>
 __device__ __forceinline__ void point_terms(double (&lam)[NMAX], double (&qx2)[M], double (&rc)[M],
+                                            const double (*vt)[64], const WaveBin<M> &s,
                                             const c128 *__restrict__ Xb,
-                                            const double *__restrict__ act_b, const c128 *Qs,
-                                            const double *Ds, const double *Ts, int N, int F, int T,
-                                            int K, int i, int j) {
-#pragma unroll
-  for (int n = 0; n < NMAX; ++n) {
-    double l = 0.0;
-    if (n < N)
-      for (int k = 0; k < K; ++k) l = fma(Ts[n * K + k], act_b[((long long)n * K + k) * T + j], l);
-    lam[n] = l;
-  }
+                                            const double *__restrict__ act_b,
+                                            const double *__restrict__ basis, int b, int N, int F,
+                                            int T, int K, int i, int j) {
+  lambda_terms<M>(lam, vt, s, act_b, basis, b, N, F, T, K, i, j);
   c128 x[M];
 #pragma unroll
   for (int m = 0; m < M; ++m) x[m] = Xb[((long long)m * F + i) * T + j];
 #pragma unroll
   for (int m = 0; m < M; ++m) {
-    c128 y = cmake(0.0, 0.0);
+    c128 acc = cmake(0.0, 0.0);
 #pragma unroll
-    for (int a = 0; a < M; ++a) cfma(y, Qs[m * M + a], x[a]);
-    qx2[m] = cabs2(y);
+    for (int a = 0; a < M; ++a) cfma(acc, s.q[m * M + a], x[a]);
+    qx2[m] = cabs2(acc);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
     double r = 0.0;
 #pragma unroll
-    for (int n = 0; n < NMAX; ++n)
-      if (n < N) r = fma(lam[n], Ds[n * M + m], r);
+    for (int n = 0; n < NMAX; ++n) r = fma(lam[n], s.d[n * M + m], r);
     rc[m] = r;
   }
+  __builtin_amdgcn_sched_barrier(0);
 }
 
-// grid: (ceil(T/128), F, B), 128 threads (lanes along frames)
+// bins per wave so that the launch has about 512 workgroups (two rounds of the chip's 256 CUs at
+// one workgroup each, or one at two), at most 16 (the reuse of the activation column)
+struct WalkPlan {
+  int gx, gy, bpw;  // frame tiles, bin groups, bins per wave
+};
+static inline WalkPlan walk_plan(int B, int F, int T) {
+  WalkPlan p;
+  p.gx = (T + 63) / 64;
+  const int most = (F + WB - 1) / WB;  // groups at one bin per wave
+  int gy = (512 + p.gx * B - 1) / (p.gx * B);
+  gy = gy < 1 ? 1 : (gy > most ? most : gy);
+  p.bpw = (F + WB * gy - 1) / (WB * gy);
+  if (p.bpw > 16) p.bpw = 16;
+  p.gy = (F + WB * p.bpw - 1) / (WB * p.bpw);
+  return p;
+}
+
+enum { MODE_SEPARATE = 3, MODE_SPATIAL = 4 };
+constexpr int PROW = NMAX + 2 * 8;  // lam[NMAX], g[M], h[M] of a point (MODE_SPATIAL)
+
+// grid: (frame tiles of 64, bin groups, B), 256 threads: wave w walks bins
+// [(blockIdx.y * WB + w) * bpw, + bpw) for the block's 64 frames (lane = frame).
+//   MODE_TRACES   out0, out1 (B,N,F,T): A_n, Bt_n
+//   MODE_WEIGHTS  out0 (B,M,F,T): 1 / R~_m
+//   MODE_LOSS     out0: one slot per (workgroup, wave), [slot][B]
+//   MODE_SPATIAL  out0: per frame tile the (num, den) sums of the spatial update,
+//                 [tile][b][i][n * M + m][2]
+//   MODE_SEPARATE Yout (B,N,F,T): the Wiener filter's closed form R^-1 = Q^H diag(1 / rc) Q
+//                 (ref: ssspy/bss/mnmf.py:1174-1217) where the eigenvalue floor is provably idle
+//                 (lambda_min(R) >= min rc / ||Q||_F^2 > eps); bins with a point where it may act
+//                 are flagged in `redo` for the repair launch (k_separate<M, true>)
 template <int M, int MODE>
-__global__ __launch_bounds__(128) void k_points(const c128 *__restrict__ X,
-                                                const c128 *__restrict__ Q,
-                                                const double *__restrict__ Dsp,
-                                                const double *__restrict__ basis,
-                                                const double *__restrict__ act,
-                                                double *__restrict__ out0,
-                                                double *__restrict__ out1, int N, int F, int T,
-                                                int K) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  c128 *Qs = reinterpret_cast<c128 *>(smem);
-  double *Ds = reinterpret_cast<double *>(Qs + M * M);
-  double *Ts = Ds + N * M;
-  __shared__ double scratch[2];
-  const int i = blockIdx.y, b = blockIdx.z;
-  stage_bin<M>(Qs, Ds, Ts, Q, Dsp, basis, b, N, F, K, i);
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = j < T;
-  double lam[NMAX], qx2[M], rc[M];
-  point_terms<M>(lam, qx2, rc, X + (long long)b * M * F * T, act + (long long)b * N * K * T, Qs, Ds,
-                 Ts, N, F, T, K, i, valid ? j : T - 1);
-  if (MODE == MODE_TRACES) {
-    if (!valid) return;
-    double g[M], h[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      g[m] = 1.0 / rc[m];
-      h[m] = qx2[m] * g[m] * g[m];
-    }
-    for (int n = 0; n < N; ++n) {
-      double sa = 0.0, sb = 0.0;
+__global__ __launch_bounds__(64 * WB, 2) void k_walk(const c128 *__restrict__ X,
+                                                  const c128 *__restrict__ Q,
+                                                  const c128 *__restrict__ Qinv,
+                                                  const double *__restrict__ Dsp,
+                                                  const double *__restrict__ basis,
+                                                  const double *__restrict__ act,
+                                                  double *__restrict__ out0,
+                                                  double *__restrict__ out1, c128 *__restrict__ Yout,
+                                                  int N, int F, int T, int K, int bpw, int ref,
+                                                  int floor_kind, double eps, int *redo) {
+  __shared__ WaveBin<M> bins[WB];
+  __shared__ double pts[MODE == MODE_SPATIAL ? WB * 64 * PROW : 1];
+  __shared__ c128 qref[MODE == MODE_SEPARATE ? WB * M : 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.z;
+  const int j_raw = blockIdx.x * 64 + lane;
+  const bool valid = j_raw < T;
+  const int j = valid ? j_raw : T - 1;
+  const c128 *Xb = X + (long long)b * M * F * T;
+  const double *act_b = act + (long long)b * N * K * T;
+  WaveBin<M> &s = bins[wave];
+  __shared__ double vt[NMAX * KT][64];
+  if (K <= KT) load_tile(vt, act_b, N, T, K, blockIdx.x * 64);
+  const int i0 = (blockIdx.y * WB + wave) * bpw;
+  double loss = 0.0;
+#pragma unroll 1
+  for (int i = i0; i < min(i0 + bpw, F); ++i) {
+    stage_wave<M>(s, Q, Dsp, basis, b, N, F, K, i, lane);
+    double lam[NMAX], qx2[M], rc[M];
+    if (MODE != MODE_SEPARATE) point_terms<M>(lam, qx2, rc, vt, s, Xb, act_b, basis, b, N, F, T, K, i, j);
+    if (MODE == MODE_TRACES) {
+      double g[M], h[M];
 #pragma unroll
       for (int m = 0; m < M; ++m) {
-        sa = fma(Ds[n * M + m], h[m], sa);
-        sb = fma(Ds[n * M + m], g[m], sb);
+        g[m] = 1.0 / rc[m];
+        h[m] = qx2[m] * g[m] * g[m];
       }
-      const long long o = (((long long)b * N + n) * F + i) * T + j;
-      out0[o] = sa;
-      out1[o] = sb;
+#pragma unroll
+      for (int n = 0; n < NMAX; ++n) {
+        if (n < N && valid) {
+          double sa = 0.0, sb = 0.0;
+#pragma unroll
+          for (int m = 0; m < M; ++m) {
+            sa = fma(s.d[n * M + m], h[m], sa);
+            sb = fma(s.d[n * M + m], g[m], sb);
+          }
+          const long long o = (((long long)b * N + n) * F + i) * T + j;
+          out0[o] = sa;
+          out1[o] = sb;
+        }
+      }
+    } else if (MODE == MODE_WEIGHTS) {
+      if (valid) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) out0[(((long long)b * M + m) * F + i) * T + j] = 1.0 / rc[m];
+      }
+    } else if (MODE == MODE_LOSS) {
+      double term = 0.0;
+#pragma unroll
+      for (int m = 0; m < M; ++m) term += qx2[m] / rc[m] + log(rc[m]);
+      loss += valid ? term : 0.0;
+    } else if (MODE == MODE_SPATIAL) {
+      // d_inm <- d_inm sqrt(sum_j lam_n h_m / sum_j lam_n g_m): the wave's 64 points go through its
+      // LDS patch and lane e = (n, m) folds them (frames beyond T add nothing)
+      double *mine = pts + (wave * 64 + lane) * PROW;
+      wave_lds_sync();
+#pragma unroll
+      for (int n = 0; n < NMAX; ++n) mine[n] = valid ? lam[n] : 0.0;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const double g = 1.0 / rc[m];
+        mine[NMAX + m] = g;
+        mine[NMAX + 8 + m] = qx2[m] * g * g;
+      }
+      wave_lds_sync();
+      if (lane < N * M) {
+        const int n = lane / M, m = lane % M;
+        const double *pw = pts + wave * 64 * PROW;
+        double vn = 0.0, vd = 0.0;
+#pragma unroll 8
+        for (int p = 0; p < 64; ++p) {
+          const double l = pw[p * PROW + n];
+          vn = fma(l, pw[p * PROW + NMAX + 8 + m], vn);
+          vd = fma(l, pw[p * PROW + NMAX + m], vd);
+        }
+        double *dst = out0 + ((((long long)blockIdx.x * gridDim.z + b) * F + i) * (N * M) + lane) * 2;
+        dst[0] = vn;
+        dst[1] = vd;
+      }
+    } else {  // MODE_SEPARATE
+      // One channel m at a time: s_m = q~[ref][m] (Q x)_m / rc_m goes straight into the N outputs
+      // (lam_n d_nm s_m), so neither Q x nor the weights are held (with both, the 8-channel form
+      // wanted 380 registers on top of the activation column).
+      const long long bin = (long long)b * F + i;
+      double qf2 = lane < M * M ? cabs2(s.q[lane]) : 0.0;
+      qf2 = wave_sum(qf2);
+      wave_lds_sync();
+      if (lane < M) qref[wave * M + lane] = Qinv[bin * (M * M) + ref * M + lane];
+      wave_lds_sync();
+      lambda_terms<M>(lam, vt, s, act_b, basis, b, N, F, T, K, i, j);
+      double rcmin = 0.0;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        double r = 0.0;
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) r = fma(lam[n], s.d[n * M + m], r);
+        rc[m] = r;
+        rcmin = m == 0 ? r : (r < rcmin ? r : rcmin);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const bool closed = floor_kind != SSSPY_FLOOR_ADD && rcmin > eps * qf2 * 1.0000001;
+      if (valid && !closed) redo[bin] = 1;  // (every writer stores the same value)
+      c128 x[M], sm[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = Xb[((long long)m * F + i) * T + j];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        c128 acc = cmake(0.0, 0.0);
+#pragma unroll
+        for (int a = 0; a < M; ++a) cfma(acc, s.q[m * M + a], x[a]);
+        const double g = 1.0 / rc[m];
+        sm[m] = cmul(qref[wave * M + m], cmake(acc.x * g, acc.y * g));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (valid && closed) {
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n)
+          if (n < N) {
+            c128 o = cmake(0.0, 0.0);
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+              const double dv = s.d[n * M + m];
+              o.x = fma(dv, sm[m].x, o.x);
+              o.y = fma(dv, sm[m].y, o.y);
+            }
+            Yout[(((long long)b * N + n) * F + i) * T + j] = cmake(lam[n] * o.x, lam[n] * o.y);
+          }
+      }
     }
-  } else if (MODE == MODE_WEIGHTS) {
-    if (!valid) return;
-#pragma unroll
-    for (int m = 0; m < M; ++m) out0[(((long long)b * M + m) * F + i) * T + j] = 1.0 / rc[m];
-  } else {
-    double term = 0.0;
-#pragma unroll
-    for (int m = 0; m < M; ++m) term += qx2[m] / rc[m] + log(rc[m]);
-    term = wave_sum(valid ? term : 0.0);
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = term;
-    __syncthreads();
-    // one slot per (frame block, bin) of the mixture, [slot][B]; fmnmf_generic_loss folds them
-    if (threadIdx.x == 0)
-      out0[((long long)blockIdx.y * gridDim.x + blockIdx.x) * gridDim.z + b] =
-          (scratch[0] + scratch[1]) / (double)T;
+  }
+  if (MODE == MODE_LOSS) {
+    loss = wave_sum(loss);
+    // one slot per (frame tile, bin group, wave) of the mixture, [slot][B]
+    if (lane == 0)
+      out0[(((long long)blockIdx.y * gridDim.x + blockIdx.x) * WB + wave) * gridDim.z + b] =
+          loss / (double)T;
   }
 }
 
-// basis[b,n,i,k] <- floor(basis * sqrt(sum_j V A / sum_j V Bt)).  grid: (F, N, B), 256 threads
+// d_inm <- d_inm sqrt(sum_tiles num / sum_tiles den) (no floor; ssspy/bss/mnmf.py:1650-1675)
+__global__ __launch_bounds__(256) void k_spatial_fold(double *Dsp, const double *__restrict__ part,
+                                                      long long count, int tiles) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  const double2 sums = ordered_sum(reinterpret_cast<const double2 *>(part) + e, count, tiles);
+  Dsp[e] = sqrt(sums.x / sums.y) * Dsp[e];
+}
+
+// basis[b,n,i,k] <- floor(basis * sqrt(sum_j V A / sum_j V Bt)): a wave per (b, n, i) row of the
+// traces, read once per tile of 8 basis indices.  grid: ceil(B N F / 4), 256 threads
 __global__ __launch_bounds__(256) void k_basis(double *basis, const double *__restrict__ act,
                                                const double *__restrict__ A,
-                                               const double *__restrict__ Bt, int N, int F, int T,
-                                               int K, int floor_kind, double eps) {
-  const int i = blockIdx.x, n = blockIdx.y, b = blockIdx.z;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long row = (((long long)b * N + n) * F + i) * T;
-  for (int k = wave; k < K; k += 4) {
-    const double *v = act + (((long long)b * N + n) * K + k) * T;
-    double sn = 0.0, sd = 0.0;
+                                               const double *__restrict__ Bt, long long rows, int N,
+                                               int F, int T, int K, int floor_kind, double eps) {
+  const int lane = threadIdx.x & 63;
+  const long long rowi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b N + n) F + i
+  if (rowi >= rows) return;
+  const long long bn = rowi / F;
+  const double *a = A + rowi * T, *bt = Bt + rowi * T;
+  for (int k0 = 0; k0 < K; k0 += KT) {
+    double sn[KT], sd[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) sn[k] = sd[k] = 0.0;
     for (int j = lane; j < T; j += 64) {
-      const double vv = v[j];
-      sn = fma(vv, A[row + j], sn);
-      sd = fma(vv, Bt[row + j], sd);
-    }
-    sn = wave_sum(sn);
-    sd = wave_sum(sd);
-    if (lane == 0) {
-      const long long o = (((long long)b * N + n) * F + i) * K + k;
-      basis[o] = apply_floor(basis[o] * sqrt(sn / sd), floor_kind, eps);
-    }
-  }
-}
-
-// act[b,n,k,j] <- floor(act * sqrt(sum_i T A / sum_i T Bt)): lanes along frames, each lane walks all
-// bins for its (n, k) -- deterministic, no atomics.  grid: (ceil(T/256), K, N*B)
-__global__ __launch_bounds__(256) void k_activation(const double *__restrict__ basis, double *act,
-                                                    const double *__restrict__ A,
-                                                    const double *__restrict__ Bt, int N, int F,
-                                                    int T, int K, int floor_kind, double eps) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
-  const int n = blockIdx.z % N, b = blockIdx.z / N;
-  if (j >= T) return;
-  const double *tb = basis + ((long long)b * N + n) * F * K + k;
-  const long long base = ((long long)b * N + n) * F * T + j;
-  double sn = 0.0, sd = 0.0;
-  for (int i = 0; i < F; ++i) {
-    const double t = tb[(long long)i * K];
-    sn = fma(t, A[base + (long long)i * T], sn);
-    sd = fma(t, Bt[base + (long long)i * T], sd);
-  }
-  double *dst = act + (((long long)b * N + n) * K + k) * T + j;
-  *dst = apply_floor((*dst) * sqrt(sn / sd), floor_kind, eps);
-}
-
-// d_inm <- d_inm sqrt(sum_j lam_n h_m / sum_j lam_n g_m) (no floor).  grid: (F, B), 64 threads: lanes
-// take frames in chunks of 64, the per-point (lam, g, h) go through LDS and thread e folds the chunk
-// into its (n, m) sums.
-constexpr int PB = 64;
-template <int M>
-__global__ __launch_bounds__(PB) void k_spatial(const c128 *__restrict__ X,
-                                                const c128 *__restrict__ Q, double *Dsp,
-                                                const double *__restrict__ basis,
-                                                const double *__restrict__ act, int N, int F, int T,
-                                                int K) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  c128 *Qs = reinterpret_cast<c128 *>(smem);
-  double *Ds = reinterpret_cast<double *>(Qs + M * M);
-  double *Ts = Ds + N * M;
-  constexpr int ROW = NMAX + 2 * M;  // lam[NMAX], g[M], h[M] per point
-  double *pts = Ts + N * K;          // [PB][ROW]
-  const int i = blockIdx.x, b = blockIdx.y;
-  stage_bin<M>(Qs, Ds, Ts, Q, Dsp, basis, b, N, F, K, i);
-  constexpr int SLOTS = (NMAX * M + PB - 1) / PB;  // (n, m) pairs per thread
-  double an[SLOTS], ad[SLOTS];
+      const double av = a[j], bv = bt[j];
 #pragma unroll
-  for (int s = 0; s < SLOTS; ++s) an[s] = ad[s] = 0.0;
-  for (int j0 = 0; j0 < T; j0 += PB) {
-    const int j = j0 + threadIdx.x;
-    double lam[NMAX], qx2[M], rc[M];
-    point_terms<M>(lam, qx2, rc, X + (long long)b * M * F * T, act + (long long)b * N * K * T, Qs,
-                   Ds, Ts, N, F, T, K, i, j < T ? j : T - 1);
-    double *mine = pts + threadIdx.x * ROW;
-#pragma unroll
-    for (int n = 0; n < NMAX; ++n) mine[n] = j < T ? lam[n] : 0.0;  // frames beyond T add nothing
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const double g = 1.0 / rc[m];
-      mine[NMAX + m] = g;
-      mine[NMAX + M + m] = qx2[m] * g * g;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-      const int idx = threadIdx.x + PB * s;
-      if (idx < N * M) {
-        const int n = idx / M, m = idx % M;
-        double vn = an[s], vd = ad[s];
-        for (int p = 0; p < PB; ++p) {
-          const double l = pts[p * ROW + n];
-          vn = fma(l, pts[p * ROW + NMAX + M + m], vn);
-          vd = fma(l, pts[p * ROW + NMAX + m], vd);
-        }
-        an[s] = vn;
-        ad[s] = vd;
+      for (int k = 0; k < KT; ++k) {
+        const double vv = k0 + k < K ? act[(bn * K + k0 + k) * T + j] : 0.0;
+        sn[k] = fma(vv, av, sn[k]);
+        sd[k] = fma(vv, bv, sd[k]);
       }
     }
-    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      sn[k] = wave_sum(sn[k]);
+      sd[k] = wave_sum(sd[k]);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < KT; ++k)
+        if (k0 + k < K) {
+          const long long o = rowi * K + k0 + k;
+          basis[o] = apply_floor(basis[o] * sqrt(sn[k] / sd[k]), floor_kind, eps);
+        }
+    }
+  }
+}
+
+// act[b,n,k,j] <- floor(act * sqrt(sum_i T A / sum_i T Bt)): lanes along 64 frames, the 8 waves of a
+// workgroup take every eighth bin, their sums meet in LDS in wave order -- deterministic, no atomics,
+// the traces read once per tile of 8 basis indices.  grid: (ceil(T/64), ceil(K/8), N B), 512 threads
+constexpr int AW = 8;
+static_assert(AW == KT, "k_activation finishes basis index `wave` of the tile");
+__global__ __launch_bounds__(64 * AW) void k_activation(const double *__restrict__ basis, double *act,
+                                                        const double *__restrict__ A,
+                                                        const double *__restrict__ Bt, int N, int F,
+                                                        int T, int K, int floor_kind, double eps) {
+  __shared__ double part[AW][2 * KT][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j_raw = blockIdx.x * 64 + lane;
+  const int j = j_raw < T ? j_raw : T - 1;
+  const int k0 = blockIdx.y * KT;
+  const long long bn = blockIdx.z;
+  const double *tb = basis + bn * F * K + k0;
+  const long long base = bn * F * T + j;
+  double sn[KT], sd[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) sn[k] = sd[k] = 0.0;
+  for (int i = wave; i < F; i += AW) {
+    const double av = A[base + (long long)i * T], bv = Bt[base + (long long)i * T];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const double t = k0 + k < K ? tb[(long long)i * K + k] : 0.0;
+      sn[k] = fma(t, av, sn[k]);
+      sd[k] = fma(t, bv, sd[k]);
+    }
   }
 #pragma unroll
-  for (int s = 0; s < SLOTS; ++s) {
-    const int idx = threadIdx.x + PB * s;
-    if (idx < N * M) {
-      double *dst = Dsp + ((long long)b * F + i) * (N * M) + idx;
-      *dst = sqrt(an[s] / ad[s]) * Ds[idx];
+  for (int k = 0; k < KT; ++k) {
+    part[wave][k][lane] = sn[k];
+    part[wave][KT + k][lane] = sd[k];
+  }
+  __syncthreads();
+  // thread (k = wave, frame = lane) finishes one output
+  if (k0 + wave < K && j_raw < T) {
+    double tn = 0.0, td = 0.0;
+#pragma unroll
+    for (int w = 0; w < AW; ++w) {
+      tn += part[w][wave][lane];
+      td += part[w][KT + wave][lane];
     }
+    double *dst = act + (bn * K + k0 + wave) * T + j;
+    *dst = apply_floor((*dst) * sqrt(tn / td), floor_kind, eps);
   }
 }
 
@@ -474,25 +646,31 @@ __global__ __launch_bounds__(128) void k_separate(const c128 *__restrict__ X,
   }
 
 template <int MODE>
-static int launch_points(const void *X, const void *Q, const double *D, const double *basis,
-                         const double *act, double *out0, double *out1, int B, int N, int M, int F,
-                         int T, int K, hipStream_t st) {
+static int launch_walk(const void *X, const void *Q, const void *Qinv, const double *D,
+                       const double *basis, const double *act, double *out0, double *out1, void *Y,
+                       int B, int N, int M, int F, int T, int K, int ref, int floor_kind, double eps,
+                       int *redo, hipStream_t st) {
   // point_terms keeps lam[NMAX]: more sources would silently drop out of R~
   if (N < 1 || N > NMAX) return fail(SSSPY_ERR_UNSUPPORTED, "FastMNMF: n_sources must be in [1, 8]");
-  dim3 grid((T + 127) / 128, F, B), block(128);
-  const size_t smem = bin_smem(N, M, K);
-  FMG_DISPATCH_M(M, hipLaunchKernelGGL((k_points<MM, MODE>), grid, block, smem, st, (const c128 *)X,
-                                       (const c128 *)Q, D, basis, act, out0, out1, N, F, T, K));
-  return check_launch("fmnmf_generic points");
+  const WalkPlan p = walk_plan(B, F, T);
+  dim3 grid(p.gx, p.gy, B), block(64 * WB);
+  FMG_DISPATCH_M(M, hipLaunchKernelGGL((k_walk<MM, MODE>), grid, block, 0, st, (const c128 *)X,
+                                       (const c128 *)Q, (const c128 *)Qinv, D, basis, act, out0,
+                                       out1, (c128 *)Y, N, F, T, K, p.bpw, ref, floor_kind, eps,
+                                       redo));
+  return check_launch("fmnmf_generic walk");
 }
 
 }  // namespace fmg
 
 // ---- entry points used by mnmf_api.hip for shapes outside the MFMA-tile kernels
 size_t fmnmf_generic_workspace_doubles(int B, int N, int M, int F, int T) {
-  // A, Bt (B,N,F,T) each; the (B,M,F,T) weights reuse A's space when M <= N, else their own
+  // A, Bt (B,N,F,T) each -- or, for the spatial update, (num, den) of every (bin, n, m) per frame
+  // tile; the (B,M,F,T) weights behind them
   const size_t pts = (size_t)B * F * T;
-  return pts * (2 * (size_t)N) + pts * (size_t)M;
+  const size_t traces = pts * (2 * (size_t)N);
+  const size_t spatial = (size_t)((T + 63) / 64) * B * F * N * M * 2;
+  return (traces > spatial ? traces : spatial) + pts * (size_t)M;
 }
 
 int fmnmf_generic_update(const void *X, const void *C, void *Q, double *D, double *basis,
@@ -503,28 +681,37 @@ int fmnmf_generic_update(const void *X, const void *C, void *Q, double *D, doubl
   if (N < 1 || N > NMAX) return fail(SSSPY_ERR_UNSUPPORTED, "FastMNMF: n_sources must be in [1, 8]");
   if (M < 2 || M > 8) return fail(SSSPY_ERR_UNSUPPORTED, "FastMNMF: n_channels must be in [2, 8]");
   const size_t pts = (size_t)B * F * T;
-  double *A = gws, *Bt = gws + pts * N, *Wt = gws + pts * 2 * N;
+  const size_t traces = pts * (2 * (size_t)N);
+  const size_t spatial = (size_t)((T + 63) / 64) * B * F * N * M * 2;
+  double *A = gws, *Bt = gws + pts * N, *Wt = gws + (traces > spatial ? traces : spatial);
   int rc = SSSPY_OK;
+  auto traces_pass = [&]() {
+    return launch_walk<MODE_TRACES>(X, Q, nullptr, D, basis, activation, A, Bt, nullptr, B, N, M, F,
+                                    T, K, 0, 0, 0.0, nullptr, st);
+  };
   if (steps & SSSPY_MNMF_BASIS) {
-    rc = launch_points<MODE_TRACES>(X, Q, D, basis, activation, A, Bt, B, N, M, F, T, K, st);
+    rc = traces_pass();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_basis, dim3(F, N, B), dim3(256), 0, st, basis, (const double *)activation,
-                       (const double *)A, (const double *)Bt, N, F, T, K, floor_kind, floor_eps);
+    const long long rows = (long long)B * N * F;
+    hipLaunchKernelGGL(k_basis, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, basis,
+                       (const double *)activation, (const double *)A, (const double *)Bt, rows, N, F,
+                       T, K, floor_kind, floor_eps);
     rc = check_launch("fmnmf_generic basis");
     if (rc) return rc;
   }
   if (steps & SSSPY_MNMF_ACTIVATION) {
-    rc = launch_points<MODE_TRACES>(X, Q, D, basis, activation, A, Bt, B, N, M, F, T, K, st);
+    rc = traces_pass();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_activation, dim3((T + 255) / 256, K, N * B), dim3(256), 0, st,
-                       (const double *)basis, activation, (const double *)A, (const double *)Bt, N,
-                       F, T, K, floor_kind, floor_eps);
+    hipLaunchKernelGGL(k_activation, dim3((T + 63) / 64, (K + KT - 1) / KT, N * B), dim3(64 * AW), 0,
+                       st, (const double *)basis, activation, (const double *)A, (const double *)Bt,
+                       N, F, T, K, floor_kind, floor_eps);
     rc = check_launch("fmnmf_generic activation");
     if (rc) return rc;
   }
   bool have_q = false;
   if (steps & SSSPY_MNMF_DIAGONALIZER) {
-    rc = launch_points<MODE_WEIGHTS>(X, Q, D, basis, activation, Wt, nullptr, B, N, M, F, T, K, st);
+    rc = launch_walk<MODE_WEIGHTS>(X, Q, nullptr, D, basis, activation, Wt, nullptr, nullptr, B, N,
+                                   M, F, T, K, 0, 0, 0.0, nullptr, st);
     if (rc) return rc;
     rc = ssspy_weighted_covariance(X, Wt, SSSPY_WEIGHT_BIN_FRAME, U, B, M, M, F, T, (void *)st);
     if (rc) return rc;
@@ -533,12 +720,13 @@ int fmnmf_generic_update(const void *X, const void *C, void *Q, double *D, doubl
     have_q = C != nullptr;
   }
   if (steps & SSSPY_MNMF_SPATIAL) {
-    const size_t smem = bin_smem(N, M, K) + (size_t)PB * (NMAX + 2 * M) * sizeof(double);
-    FMG_DISPATCH_M(M, hipLaunchKernelGGL((k_spatial<MM>), dim3(F, B), dim3(PB), smem, st,
-                                         (const c128 *)X, (const c128 *)Q, D,
-                                         (const double *)basis, (const double *)activation, N, F, T,
-                                         K));
-    rc = check_launch("fmnmf_generic spatial");
+    rc = launch_walk<MODE_SPATIAL>(X, Q, nullptr, D, basis, activation, gws, nullptr, nullptr, B, N,
+                                   M, F, T, K, 0, 0, 0.0, nullptr, st);
+    if (rc) return rc;
+    const long long count = (long long)B * F * N * M;
+    hipLaunchKernelGGL(k_spatial_fold, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, D,
+                       (const double *)gws, count, (T + 63) / 64);
+    rc = check_launch("fmnmf_generic spatial fold");
     if (rc) return rc;
   }
   if (steps & SSSPY_MNMF_NORMALIZE) {
@@ -556,19 +744,25 @@ int fmnmf_generic_update(const void *X, const void *C, void *Q, double *D, doubl
 int fmnmf_generic_weights(const void *X, const void *Q, const double *D, const double *basis,
                           const double *act, double *Wt, int B, int N, int M, int F, int T, int K,
                           hipStream_t st) {
-  return fmg::launch_points<fmg::MODE_WEIGHTS>(X, Q, D, basis, act, Wt, nullptr, B, N, M, F, T, K, st);
+  return fmg::launch_walk<fmg::MODE_WEIGHTS>(X, Q, nullptr, D, basis, act, Wt, nullptr, nullptr, B, N,
+                                             M, F, T, K, 0, 0, 0.0, nullptr, st);
 }
 
-size_t fmnmf_generic_loss_ws_bytes(int B, int F, int T) {
-  return scalar_slots_bytes(B, ((T + 127) / 128) * F);
+static inline int fmg_loss_slots(int B, int F, int T) {
+  const fmg::WalkPlan p = fmg::walk_plan(B, F, T);
+  return p.gx * p.gy * fmg::WB;
 }
-// out[b] = the data term; loss_ws: fmnmf_generic_loss_ws_bytes() (every block writes its slot)
+size_t fmnmf_generic_loss_ws_bytes(int B, int F, int T) {
+  return scalar_slots_bytes(B, fmg_loss_slots(B, F, T));
+}
+// out[b] = the data term; loss_ws: fmnmf_generic_loss_ws_bytes() (every wave writes its slot)
 int fmnmf_generic_loss(const void *X, const void *Q, const double *D, const double *basis,
                        const double *act, double *out, void *loss_ws, int B, int N, int M, int F,
                        int T, int K, hipStream_t st) {
-  const int rc = fmg::launch_points<fmg::MODE_LOSS>(X, Q, D, basis, act, (double *)loss_ws, nullptr,
-                                                    B, N, M, F, T, K, st);
-  return rc ? rc : scalar_slots_fold(loss_ws, B, ((T + 127) / 128) * F, out, 0, st);
+  const int rc = fmg::launch_walk<fmg::MODE_LOSS>(X, Q, nullptr, D, basis, act, (double *)loss_ws,
+                                                  nullptr, nullptr, B, N, M, F, T, K, 0, 0, 0.0,
+                                                  nullptr, st);
+  return rc ? rc : scalar_slots_fold(loss_ws, B, fmg_loss_slots(B, F, T), out, 0, st);
 }
 
 int fmnmf_generic_separate(const void *X, const void *Q, void *Qinv, const double *D,
@@ -581,16 +775,16 @@ int fmnmf_generic_separate(const void *X, const void *Q, void *Qinv, const doubl
   const long long nbins = (long long)B * F;
   hipError_t e = hipMemsetAsync(redo, 0, (size_t)nbins * sizeof(int), st);
   if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
-  FMG_DISPATCH_M(M, {
-    hipLaunchKernelGGL((k_qinv<MM>), dim3((unsigned)((nbins + 63) / 64)), dim3(64), 0, st,
-                       (const c128 *)Q, (c128 *)Qinv, nbins, info);
-    hipLaunchKernelGGL((k_separate<MM, false>), dim3(F, B), dim3(128), 0, st, (const c128 *)X,
-                       (const c128 *)Q, (const c128 *)Qinv, D, basis, act, (c128 *)Y, N, F, T, K,
-                       ref, floor_kind, eps, redo);
-    hipLaunchKernelGGL((k_separate<MM, true>), dim3(F, B), dim3(128), 0, st, (const c128 *)X,
-                       (const c128 *)Q, (const c128 *)Qinv, D, basis, act, (c128 *)Y, N, F, T, K,
-                       ref, floor_kind, eps, redo);
-  });
+  FMG_DISPATCH_M(M, hipLaunchKernelGGL((k_qinv<MM>), dim3((unsigned)((nbins + 63) / 64)), dim3(64), 0,
+                                       st, (const c128 *)Q, (c128 *)Qinv, nbins, info));
+  int rc = check_launch("fmnmf_generic qinv");
+  if (rc) return rc;
+  rc = launch_walk<MODE_SEPARATE>(X, Q, Qinv, D, basis, act, nullptr, nullptr, Y, B, N, M, F, T, K,
+                                  ref, floor_kind, eps, redo, st);
+  if (rc) return rc;
+  FMG_DISPATCH_M(M, hipLaunchKernelGGL((k_separate<MM, true>), dim3(F, B), dim3(128), 0, st,
+                                       (const c128 *)X, (const c128 *)Q, (const c128 *)Qinv, D, basis,
+                                       act, (c128 *)Y, N, F, T, K, ref, floor_kind, eps, redo));
   return check_launch("fmnmf_generic separate");
 }
 
