@@ -55,20 +55,39 @@ struct WaveBin {
   double t[NMAX * KT];  // t[n * KT + k], zero beyond (N, K); unused when K > KT
 };
 
+// Q, D and the basis rows of bin i in flight to a lane's registers (one element of each per lane:
+// M M, NMAX M and NMAX KT are all <= 64) together with the lane's point of X, and their parking in
+// the wave's patch.  The walk fetches bin i + 1 before it works on bin i: with about two waves per
+// SIMD the bins of a wave were a chain of load latencies (Q -> LDS -> X -> arithmetic -> stores),
+// 78 us for a pass whose arithmetic is 27.
 template <int M>
-__device__ __forceinline__ void stage_wave(WaveBin<M> &s, const c128 *__restrict__ Q,
-                                           const double *__restrict__ Dsp,
-                                           const double *__restrict__ basis, int b, int N, int F,
-                                           int K, int i, int lane) {
+struct BinFetch {
+  c128 x[M];
+  c128 q;
+  double d, t;
+};
+
+template <int M>
+__device__ __forceinline__ void fetch_bin(BinFetch<M> &f, const c128 *__restrict__ Xb,
+                                          const c128 *__restrict__ Q, const double *__restrict__ Dsp,
+                                          const double *__restrict__ basis, int b, int N, int F, int T,
+                                          int K, int i, int j, int lane) {
+  static_assert(M * M <= 64 && NMAX * M <= 64 && NMAX * KT <= 64, "one element per lane");
   const long long bin = (long long)b * F + i;
+  f.q = lane < M * M ? Q[bin * (M * M) + lane] : cmake(0.0, 0.0);
+  f.d = lane < N * M ? Dsp[bin * (N * M) + lane] : 0.0;
+  const int n = lane / KT, k = lane % KT;
+  f.t = (K <= KT && n < N && k < K) ? basis[(((long long)b * N + n) * F + i) * K + k] : 0.0;
+#pragma unroll
+  for (int m = 0; m < M; ++m) f.x[m] = Xb[((long long)m * F + i) * T + j];
+}
+
+template <int M>
+__device__ __forceinline__ void park_bin(WaveBin<M> &s, const BinFetch<M> &f, int lane) {
   wave_lds_sync();  // (the previous bin's reads are done)
-  for (int e = lane; e < M * M; e += 64) s.q[e] = Q[bin * (M * M) + e];
-  for (int e = lane; e < NMAX * M; e += 64) s.d[e] = e < N * M ? Dsp[bin * (N * M) + e] : 0.0;
-  if (K <= KT)
-    for (int e = lane; e < NMAX * KT; e += 64) {
-      const int n = e / KT, k = e % KT;
-      s.t[e] = (n < N && k < K) ? basis[(((long long)b * N + n) * F + i) * K + k] : 0.0;
-    }
+  if (lane < M * M) s.q[lane] = f.q;
+  if (lane < NMAX * M) s.d[lane] = f.d;
+  s.t[lane] = f.t;
   wave_lds_sync();
 }
 
@@ -118,14 +137,11 @@ __device__ __forceinline__ void lambda_terms(double (&lam)[NMAX], const double (
 template <int M>
 __device__ __forceinline__ void point_terms(double (&lam)[NMAX], double (&qx2)[M], double (&rc)[M],
                                             const double (*vt)[64], const WaveBin<M> &s,
-                                            const c128 *__restrict__ Xb,
+                                            const c128 (&x)[M],
                                             const double *__restrict__ act_b,
                                             const double *__restrict__ basis, int b, int N, int F,
                                             int T, int K, int i, int j) {
   lambda_terms<M>(lam, vt, s, act_b, basis, b, N, F, T, K, i, j);
-  c128 x[M];
-#pragma unroll
-  for (int m = 0; m < M; ++m) x[m] = Xb[((long long)m * F + i) * T + j];
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     c128 acc = cmake(0.0, 0.0);
@@ -162,7 +178,11 @@ static inline WalkPlan walk_plan(int B, int F, int T) {
 }
 
 enum { MODE_SEPARATE = 3, MODE_SPATIAL = 4 };
-constexpr int PROW = NMAX + 2 * 8;  // lam[NMAX], g[M], h[M] of a point (MODE_SPATIAL)
+// a point's row in the wave's LDS patch (MODE_SPATIAL): lam[0..8), h[8..16), g[16..24) -- the operands
+// of a 16 x 16 x 4 matrix product over the frames (rows 8..15 of the left operand are zero) -- padded
+// against bank conflicts; the patch holds 32 points, the wave's 64 go through it in two halves (with
+// all 64 the kernel held 110 KB of LDS: one workgroup per CU)
+constexpr int PROW = 26;
 
 // grid: (frame tiles of 64, bin groups, B), 256 threads: wave w walks bins
 // [(blockIdx.y * WB + w) * bpw, + bpw) for the block's 64 frames (lane = frame).
@@ -187,8 +207,9 @@ __global__ __launch_bounds__(64 * WB, 2) void k_walk(const c128 *__restrict__ X,
                                                   int N, int F, int T, int K, int bpw, int ref,
                                                   int floor_kind, double eps, int *redo) {
   __shared__ WaveBin<M> bins[WB];
-  __shared__ double pts[MODE == MODE_SPATIAL ? WB * 64 * PROW : 1];
+  __shared__ double pts[MODE == MODE_SPATIAL ? WB * 32 * PROW : 1];
   __shared__ c128 qref[MODE == MODE_SEPARATE ? WB * M : 1];
+  __shared__ c128 smem_s[MODE == MODE_SEPARATE ? WB * M * 64 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.z;
   const int j_raw = blockIdx.x * 64 + lane;
@@ -201,11 +222,19 @@ __global__ __launch_bounds__(64 * WB, 2) void k_walk(const c128 *__restrict__ X,
   if (K <= KT) load_tile(vt, act_b, N, T, K, blockIdx.x * 64);
   const int i0 = (blockIdx.y * WB + wave) * bpw;
   double loss = 0.0;
+  const int i1 = min(i0 + bpw, F);
+  BinFetch<M> nxt;
+  if (i0 < i1) fetch_bin<M>(nxt, Xb, Q, Dsp, basis, b, N, F, T, K, i0, j, lane);
 #pragma unroll 1
-  for (int i = i0; i < min(i0 + bpw, F); ++i) {
-    stage_wave<M>(s, Q, Dsp, basis, b, N, F, K, i, lane);
+  for (int i = i0; i < i1; ++i) {
+    park_bin<M>(s, nxt, lane);
+    c128 x[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] = nxt.x[m];
+    fetch_bin<M>(nxt, Xb, Q, Dsp, basis, b, N, F, T, K, min(i + 1, i1 - 1), j, lane);
+    __builtin_amdgcn_sched_barrier(0);
     double lam[NMAX], qx2[M], rc[M];
-    if (MODE != MODE_SEPARATE) point_terms<M>(lam, qx2, rc, vt, s, Xb, act_b, basis, b, N, F, T, K, i, j);
+    if (MODE != MODE_SEPARATE) point_terms<M>(lam, qx2, rc, vt, s, x, act_b, basis, b, N, F, T, K, i, j);
     if (MODE == MODE_TRACES) {
       double g[M], h[M];
 #pragma unroll
@@ -238,37 +267,47 @@ __global__ __launch_bounds__(64 * WB, 2) void k_walk(const c128 *__restrict__ X,
       for (int m = 0; m < M; ++m) term += qx2[m] / rc[m] + log(rc[m]);
       loss += valid ? term : 0.0;
     } else if (MODE == MODE_SPATIAL) {
-      // d_inm <- d_inm sqrt(sum_j lam_n h_m / sum_j lam_n g_m): the wave's 64 points go through its
-      // LDS patch and lane e = (n, m) folds them (frames beyond T add nothing)
-      double *mine = pts + (wave * 64 + lane) * PROW;
-      wave_lds_sync();
+      // d_inm <- d_inm sqrt(sum_j lam_n h_m / sum_j lam_n g_m): the sums over the wave's 64 frames
+      // are a (16 x 64) x (64 x 16) product -- rows lam_0..7 (and eight zero rows), columns h_0..7,
+      // g_0..7 -- on the matrix core: the points go through the wave's LDS patch in operand layout,
+      // 32 at a time, 16 v_mfma_f64_16x16x4.  (Rounds 3-5: lane (n, m) walked the 64 points, 192 LDS
+      // reads.)
+      double *pw = pts + wave * 32 * PROW;
+      double *mine = pw + (lane & 31) * PROW;
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+      const int kq = lane >> 4, ic = lane & 15;
 #pragma unroll
-      for (int n = 0; n < NMAX; ++n) mine[n] = valid ? lam[n] : 0.0;
+      for (int half = 0; half < 2; ++half) {
+        wave_lds_sync();
+        if ((lane >> 5) == half) {
 #pragma unroll
-      for (int m = 0; m < M; ++m) {
-        const double g = 1.0 / rc[m];
-        mine[NMAX + m] = g;
-        mine[NMAX + 8 + m] = qx2[m] * g * g;
-      }
-      wave_lds_sync();
-      if (lane < N * M) {
-        const int n = lane / M, m = lane % M;
-        const double *pw = pts + wave * 64 * PROW;
-        double vn = 0.0, vd = 0.0;
-#pragma unroll 8
-        for (int p = 0; p < 64; ++p) {
-          const double l = pw[p * PROW + n];
-          vn = fma(l, pw[p * PROW + NMAX + 8 + m], vn);
-          vd = fma(l, pw[p * PROW + NMAX + m], vd);
+          for (int n = 0; n < NMAX; ++n) mine[n] = valid ? lam[n] : 0.0;  // frames beyond T add nothing
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            const double g = m < M ? 1.0 / rc[m < M ? m : 0] : 0.0;
+            mine[8 + m] = m < M ? qx2[m < M ? m : 0] * g * g : 0.0;
+            mine[16 + m] = g;
+          }
         }
-        double *dst = out0 + ((((long long)blockIdx.x * gridDim.z + b) * F + i) * (N * M) + lane) * 2;
-        dst[0] = vn;
-        dst[1] = vd;
+        wave_lds_sync();
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const double *row = pw + (4 * t + kq) * PROW;
+          const double lamv = row[ic & 7];
+          acc = mfma_f64(ic < 8 ? lamv : 0.0, row[8 + ic], acc);
+        }
+      }
+      // D: column ic, rows kq + 4 reg -> n = kq (reg 0), kq + 4 (reg 1); rows 8..15 are the zero rows
+      const int m = ic & 7;
+      if (m < M) {
+        double *dst = out0 + (((long long)blockIdx.x * gridDim.z + b) * F + i) * (N * M) * 2 + (ic >> 3);
+        if (kq < N) dst[(kq * M + m) * 2] = acc[0];
+        if (kq + 4 < N) dst[((kq + 4) * M + m) * 2] = acc[1];
       }
     } else {  // MODE_SEPARATE
-      // One channel m at a time: s_m = q~[ref][m] (Q x)_m / rc_m goes straight into the N outputs
-      // (lam_n d_nm s_m), so neither Q x nor the weights are held (with both, the 8-channel form
-      // wanted 380 registers on top of the activation column).
+      // s_m = q~[ref][m] (Q x)_m / rc_m one channel at a time in a rolled loop, parked in the wave's
+      // LDS patch; then Y_n = lam_n sum_m d_nm s_m.  (Unrolled, hipcc issues the 64 16-byte reads of
+      // Q ahead of the x loads they wait for: 256 registers, 500 spilled at 8 channels.)
       const long long bin = (long long)b * F + i;
       double qf2 = lane < M * M ? cabs2(s.q[lane]) : 0.0;
       qf2 = wave_sum(qf2);
@@ -276,30 +315,22 @@ __global__ __launch_bounds__(64 * WB, 2) void k_walk(const c128 *__restrict__ X,
       if (lane < M) qref[wave * M + lane] = Qinv[bin * (M * M) + ref * M + lane];
       wave_lds_sync();
       lambda_terms<M>(lam, vt, s, act_b, basis, b, N, F, T, K, i, j);
+      c128 *smw = smem_s + (wave * M) * 64 + lane;  // [m][lane]
       double rcmin = 0.0;
-#pragma unroll
+#pragma unroll 1
       for (int m = 0; m < M; ++m) {
         double r = 0.0;
 #pragma unroll
         for (int n = 0; n < NMAX; ++n) r = fma(lam[n], s.d[n * M + m], r);
-        rc[m] = r;
         rcmin = m == 0 ? r : (r < rcmin ? r : rcmin);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const bool closed = floor_kind != SSSPY_FLOOR_ADD && rcmin > eps * qf2 * 1.0000001;
-      if (valid && !closed) redo[bin] = 1;  // (every writer stores the same value)
-      c128 x[M], sm[M];
-#pragma unroll
-      for (int m = 0; m < M; ++m) x[m] = Xb[((long long)m * F + i) * T + j];
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
         c128 acc = cmake(0.0, 0.0);
 #pragma unroll
         for (int a = 0; a < M; ++a) cfma(acc, s.q[m * M + a], x[a]);
-        const double g = 1.0 / rc[m];
-        sm[m] = cmul(qref[wave * M + m], cmake(acc.x * g, acc.y * g));
+        const double g = 1.0 / r;
+        smw[m * 64] = cmul(qref[wave * M + m], cmake(acc.x * g, acc.y * g));
       }
-      __builtin_amdgcn_sched_barrier(0);
+      const bool closed = floor_kind != SSSPY_FLOOR_ADD && rcmin > eps * qf2 * 1.0000001;
+      if (valid && !closed) redo[bin] = 1;  // (every writer stores the same value)
       if (valid && closed) {
 #pragma unroll
         for (int n = 0; n < NMAX; ++n)
@@ -308,8 +339,9 @@ __global__ __launch_bounds__(64 * WB, 2) void k_walk(const c128 *__restrict__ X,
 #pragma unroll
             for (int m = 0; m < M; ++m) {
               const double dv = s.d[n * M + m];
-              o.x = fma(dv, sm[m].x, o.x);
-              o.y = fma(dv, sm[m].y, o.y);
+              const c128 sv = smw[m * 64];
+              o.x = fma(dv, sv.x, o.x);
+              o.y = fma(dv, sv.y, o.y);
             }
             Yout[(((long long)b * N + n) * F + i) * T + j] = cmake(lam[n] * o.x, lam[n] * o.y);
           }
@@ -334,42 +366,97 @@ __global__ __launch_bounds__(256) void k_spatial_fold(double *Dsp, const double 
   Dsp[e] = sqrt(sums.x / sums.y) * Dsp[e];
 }
 
-// basis[b,n,i,k] <- floor(basis * sqrt(sum_j V A / sum_j V Bt)): a wave per (b, n, i) row of the
-// traces, read once per tile of 8 basis indices.  grid: ceil(B N F / 4), 256 threads
+// basis[b,n,i,k] <- floor(basis * sqrt(sum_j V A / sum_j V Bt)).  A workgroup takes a run of `nb` bins
+// of ONE source and a tile of 8 basis indices, parks the tile's activation rows in LDS (up to
+// BASIS_TMAX frames; beyond, they are read from memory per bin) and each of its four waves walks
+// every fourth bin of the run: the traces are read once, coalesced (lane = frame), the loads of the
+// next 256 frames in flight while the current ones are contracted; the activation rows are read
+// once per workgroup instead of once per bin (through the L2 that was 5x the traces' bytes).  The
+// 16 sums of a (bin, tile) meet by a halving exchange -- at offset 32 a lane keeps eight of its
+// values and trades the other eight, at 16 four, ... -- 19 shuffles instead of the 96 of sixteen
+// wave-wide sums.  grid: (ceil(F / nb), ceil(K / 8), B N), 256 threads
+constexpr int BASIS_TMAX = 1024;
+// one step of the halving exchange: the lanes with bit OFF set keep val[C..2C), the others val[0..C),
+// each adds what its partner at distance OFF held of the same values.  (A template per step: written
+// as one loop over (C, OFF), hipcc left the loop rolled and indexed val[] through 884 v_cndmask --
+// 85 of the kernel's 125 us.)
+template <int C, int OFF>
+__device__ __forceinline__ void halve(double (&val)[2 * KT], int lane) {
+  const bool upper = (lane & OFF) != 0;
+#pragma unroll
+  for (int q = 0; q < C; ++q) {
+    const double send = upper ? val[q] : val[q + C];
+    const double keep = upper ? val[q + C] : val[q];
+    val[q] = keep + __shfl_xor(send, OFF, 64);
+  }
+}
 __global__ __launch_bounds__(256) void k_basis(double *basis, const double *__restrict__ act,
                                                const double *__restrict__ A,
-                                               const double *__restrict__ Bt, long long rows, int N,
-                                               int F, int T, int K, int floor_kind, double eps) {
-  const int lane = threadIdx.x & 63;
-  const long long rowi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b N + n) F + i
-  if (rowi >= rows) return;
-  const long long bn = rowi / F;
-  const double *a = A + rowi * T, *bt = Bt + rowi * T;
-  for (int k0 = 0; k0 < K; k0 += KT) {
-    double sn[KT], sd[KT];
+                                               const double *__restrict__ Bt, int N, int F, int T,
+                                               int K, int nb, int floor_kind, double eps) {
+  extern __shared__ __attribute__((aligned(16))) double vtile[];  // [KT][T] when T <= BASIS_TMAX
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long bn = blockIdx.z;
+  const int k0 = blockIdx.y * KT;
+  const bool tiled = T <= BASIS_TMAX;
+  if (tiled) {
+    for (int k = 0; k < KT; ++k)
+      for (int j = threadIdx.x; j < T; j += blockDim.x)
+        vtile[k * T + j] = k0 + k < K ? act[(bn * K + k0 + k) * T + j] : 0.0;
+    __syncthreads();
+  }
+  const int i_begin = blockIdx.x * nb + wave, i_end = min((int)(blockIdx.x + 1) * nb, F);
+  if (i_begin >= i_end) return;
+  const int chunks = (T + 255) / 256;  // of four runs of 64 frames
+  const double *abase = A + bn * F * T, *btbase = Bt + bn * F * T;
+  double av[4], bv[4];
+  auto fetch = [&](int i, int c, double(&a4)[4], double(&b4)[4]) {
 #pragma unroll
-    for (int k = 0; k < KT; ++k) sn[k] = sd[k] = 0.0;
-    for (int j = lane; j < T; j += 64) {
-      const double av = a[j], bv = bt[j];
+    for (int u = 0; u < 4; ++u) {
+      const int j = c * 256 + 64 * u + lane;
+      const bool in = j < T && i < i_end;
+      a4[u] = in ? abase[(long long)i * T + j] : 0.0;
+      b4[u] = in ? btbase[(long long)i * T + j] : 0.0;
+    }
+  };
+  fetch(i_begin, 0, av, bv);
+  for (int i = i_begin; i < i_end; i += 4) {
+    double val[2 * KT];  // sn[0..8), sd[0..8)
 #pragma unroll
-      for (int k = 0; k < KT; ++k) {
-        const double vv = k0 + k < K ? act[(bn * K + k0 + k) * T + j] : 0.0;
-        sn[k] = fma(vv, av, sn[k]);
-        sd[k] = fma(vv, bv, sd[k]);
+    for (int k = 0; k < 2 * KT; ++k) val[k] = 0.0;
+    for (int c = 0; c < chunks; ++c) {
+      double na[4], nbv[4];
+      const bool last = c + 1 == chunks;
+      fetch(last ? i + 4 : i, last ? 0 : c + 1, na, nbv);  // (zeros past the run's end)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = min(c * 256 + 64 * u + lane, T - 1);  // (beyond T the traces above are zero)
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          const double vv = tiled ? vtile[k * T + j]
+                                  : (k0 + k < K ? act[(bn * K + k0 + k) * T + j] : 0.0);
+          val[k] = fma(vv, av[u], val[k]);
+          val[KT + k] = fma(vv, bv[u], val[KT + k]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = na[u];
+        bv[u] = nbv[u];
       }
     }
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      sn[k] = wave_sum(sn[k]);
-      sd[k] = wave_sum(sd[k]);
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < KT; ++k)
-        if (k0 + k < K) {
-          const long long o = rowi * K + k0 + k;
-          basis[o] = apply_floor(basis[o] * sqrt(sn[k] / sd[k]), floor_kind, eps);
-        }
+    halve<8, 32>(val, lane);
+    halve<4, 16>(val, lane);
+    halve<2, 8>(val, lane);
+    halve<1, 4>(val, lane);
+    double tot = val[0];  // of value (lane >> 2) & 15, summed over the lanes that differ in bits 5..2
+    tot += __shfl_xor(tot, 2, 64);
+    tot += __shfl_xor(tot, 1, 64);
+    const double den = __shfl(tot, (lane + 32) & 63, 64);  // sd[k] sits 32 lanes above sn[k]
+    const int k = lane >> 2;
+    if ((lane & 3) == 0 && k < KT && k0 + k < K) {
+      const long long o = (bn * F + i) * K + k0 + k;
+      basis[o] = apply_floor(basis[o] * sqrt(tot / den), floor_kind, eps);
     }
   }
 }
@@ -692,10 +779,21 @@ int fmnmf_generic_update(const void *X, const void *C, void *Q, double *D, doubl
   if (steps & SSSPY_MNMF_BASIS) {
     rc = traces_pass();
     if (rc) return rc;
-    const long long rows = (long long)B * N * F;
-    hipLaunchKernelGGL(k_basis, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, basis,
-                       (const double *)activation, (const double *)A, (const double *)Bt, rows, N, F,
-                       T, K, floor_kind, floor_eps);
+    const size_t tile = T <= BASIS_TMAX ? (size_t)KT * T * sizeof(double) : 0;
+    if (tile > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void *)k_basis,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile);
+      if (e != hipSuccess) return fail(SSSPY_ERR_HIP, hipGetErrorString(e));
+    }
+    // runs of bins sized for about 768 workgroups (measured: 43 us against 48 at 1536, 58 at 4096),
+    // at least one bin per wave
+    const int ktiles = (K + KT - 1) / KT;
+    int gx = (768 + ktiles * N * B - 1) / (ktiles * N * B);
+    gx = gx > (F + 3) / 4 ? (F + 3) / 4 : gx;
+    const int nb = (F + gx - 1) / gx;
+    hipLaunchKernelGGL(k_basis, dim3((F + nb - 1) / nb, ktiles, N * B), dim3(256), tile, st, basis,
+                       (const double *)activation, (const double *)A, (const double *)Bt, N, F, T, K,
+                       nb, floor_kind, floor_eps);
     rc = check_launch("fmnmf_generic basis");
     if (rc) return rc;
   }
