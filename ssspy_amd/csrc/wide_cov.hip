@@ -14,18 +14,12 @@
 // all weight sets (64 VGPRs at S = 8) and walks the frames eight at a time: one 16-byte load per lane
 // brings 8 channels x 8 frames (whole 128-byte lines), a DPP rotate by 8 inside each row of 16 lanes
 // pairs the real part of one frame with the imaginary part of the same frame held by the partner
-// lane, and 2 S MFMAs consume the slab.  No LDS, no barrier, no cross-wave reduction.
+// lane, and 2 S MFMAs consume the slab.  No barrier, no cross-wave reduction; the weights pass
+// through a wave-private LDS patch (see ZRING / WRING).
 #include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
-
-#ifndef SSSPY_WIDE_COV_WAVES
-#define SSSPY_WIDE_COV_WAVES 2
-#endif
-#ifndef SSSPY_WIDE_COV_RING
-#define SSSPY_WIDE_COV_RING 2
-#endif
 
 namespace ssspy {
 
@@ -39,20 +33,30 @@ __device__ __forceinline__ double partner8(double v) {
   return __hiloint2double(hi, lo);
 }
 
-constexpr int RING = SSSPY_WIDE_COV_RING;  // slabs in flight per wave
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-struct Slab {
-  c128 z;     // channel a, frame 8 s + 2 k + h
-  double2 w[8];  // weights of frames 8 s + 2 k, 8 s + 2 k + 1 per set
-};
+// Loads in flight per wave.  Rounds 4-5 kept two slabs (x and the weights of all sets as 16-byte
+// loads that every lane of a 16-lane row repeated: 36 registers a slab) -- 16 KB in flight per CU,
+// 2 TB/s by Little's law, and 8 channels x 8 mixtures of 513 x 256 took 113 us for 201 MB.  Round 6:
+// the x ring is ZRING slabs deep (4 registers each); the weights of TWO slabs and all sets come as ONE
+// 16-byte load per lane (lane = (set, frame pair): 1 KB without repeats), WRING pairs deep, and reach
+// the lanes that multiply with them through a wave-private 1 KB LDS patch.
+constexpr int ZRING = 8, WRING = 4;
+static_assert(ZRING == 2 * WRING, "a weight load covers two slabs");
 
 // grid: ceil(B F / 4); wave w of a block owns (mixture, bin) item 4 blockIdx.x + w.
 // weight: FRAME (B, S, T), BIN_FRAME (B, S, F, T), UNIT none.  U: (B, F, S, N, N).
 template <int NS, int MODE>
-__global__ __launch_bounds__(256, SSSPY_WIDE_COV_WAVES) void k_wide_cov(const c128 *__restrict__ A,
+__global__ __launch_bounds__(256, 2) void k_wide_cov(const c128 *__restrict__ A,
                                                   const double *__restrict__ weight,
                                                   c128 *__restrict__ U, int N, int F, int T,
                                                   long long nitems) {
+  constexpr bool WEIGHTED = MODE != SSSPY_WEIGHT_UNIT;
+  __shared__ __attribute__((aligned(16))) double2 wpatch[WEIGHTED ? 4 : 1][2][64];  // [set * 8 + pair]
   // (readfirstlane: the compiler cannot see that threadIdx.x >> 6 is wave-uniform, and descriptors
   // built from "divergent" values put every buffer load inside a waterfall loop)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -70,65 +74,78 @@ __global__ __launch_bounds__(256, SSSPY_WIDE_COV_WAVES) void k_wide_cov(const c1
           : make_rsrc(weight + (long long)b * NS * F * T,
                       (unsigned)NS * (unsigned)F * (unsigned)T * 8u);
   const unsigned wrow = MODE == SSSPY_WEIGHT_FRAME ? (unsigned)T : (unsigned)F * (unsigned)T;
-  const unsigned wbase =
-      ((MODE == SSSPY_WEIGHT_FRAME ? 0u : (unsigned)bin * (unsigned)T) + 2u * k) * 8u;
-  auto load = [&](Slab &sl, const int s) __attribute__((always_inline)) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xr, xbase + 128u * s, 0, 0);
-    sl.z = cmake(__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2]));
-    if (MODE != SSSPY_WEIGHT_UNIT) {
-#pragma unroll
-      for (int n = 0; n < NS; ++n) {
-        const u32x4_t p =
-            __builtin_amdgcn_raw_buffer_load_b128(wr, wbase + 64u * s, (unsigned)n * wrow * 8u, 0);
-        sl.w[n] = make_double2(__hiloint2double((int)p[1], (int)p[0]),
-                               __hiloint2double((int)p[3], (int)p[2]));
-      }
-    }
+  // lane (set = lane & 7, pair = lane >> 3) of a weight load: frames 16 sp + 2 pair, + 1 of its set;
+  // sets past NS lie behind the descriptor's range (zeros, never read back)
+  const unsigned wbase = ((MODE == SSSPY_WEIGHT_FRAME ? 0u : (unsigned)bin * (unsigned)T) +
+                          2u * (unsigned)(lane >> 3) + (unsigned)(lane & 7) * wrow) * 8u;
+  const int nslabs = (T + 7) >> 3, npairs = (nslabs + 1) >> 1;
+  auto loadz = [&](u32x4_t &z, const int s) __attribute__((always_inline)) {
+    z = __builtin_amdgcn_raw_buffer_load_b128(xr, xbase + 128u * min(s, nslabs - 1), 0, 0);
+  };
+  auto loadw = [&](u32x4_t &w, const int sp) __attribute__((always_inline)) {
+    if (WEIGHTED) w = __builtin_amdgcn_raw_buffer_load_b128(wr, wbase + 128u * min(sp, npairs - 1), 0, 0);
   };
   double4_t acc[NS];
 #pragma unroll
   for (int n = 0; n < NS; ++n) acc[n] = double4_t{0.0, 0.0, 0.0, 0.0};
-  const int nslabs = (T + 7) >> 3;
   // one slab into the accumulators; TAIL masks the frames past T (the last slab only)
-  auto consume = [&](const Slab &sl, const int s, auto tail) __attribute__((always_inline)) {
+  auto consume = [&](const u32x4_t &zq, const int s, auto tail) __attribute__((always_inline)) {
     constexpr bool TAIL = decltype(tail)::value;
+    const c128 z = cmake(__hiloint2double((int)zq[1], (int)zq[0]), __hiloint2double((int)zq[3], (int)zq[2]));
     // lane (a, h, k) holds frame t1 + h of channel a; the tile rows are [Re ; Im] of ONE frame
-    const double sent = h ? sl.z.x : sl.z.y;
+    const double sent = h ? z.x : z.y;
     const double got = partner8(sent);
     const int t1 = 8 * s + 2 * k;
     const bool ok1 = !TAIL || t1 < T, ok2 = !TAIL || t1 + 1 < T;
     // frames past T were loaded from whatever follows the row: zero the samples themselves, not
     // only their weights (0 * Inf would put a NaN of a neighbouring row into this bin)
-    const double v1 = ok1 ? (h ? got : sl.z.x) : 0.0;  // row a + 8 h of frame t1 = 8 s + 2 k
-    const double v2 = ok2 ? (h ? sl.z.y : got) : 0.0;  // ... of frame t1 + 1
+    const double v1 = ok1 ? (h ? got : z.x) : 0.0;  // row a + 8 h of frame t1 = 8 s + 2 k
+    const double v2 = ok2 ? (h ? z.y : got) : 0.0;  // ... of frame t1 + 1
+    double2 w[NS];
+    if (WEIGHTED) {
+      const double2 *wp = &wpatch[wave][(s >> 1) & 1][4 * (s & 1) + k];
+#pragma unroll
+      for (int n = 0; n < NS; ++n) w[n] = wp[8 * n];
+    }
     // (the two updates of one accumulator are NS MFMAs apart)
 #pragma unroll
     for (int n = 0; n < NS; ++n) {
-      const double p1 = ok1 ? (MODE == SSSPY_WEIGHT_UNIT ? 1.0 : sl.w[n].x) : 0.0;
+      const double p1 = ok1 ? (WEIGHTED ? w[n].x : 1.0) : 0.0;
       acc[n] = mfma_f64(p1 * v1, v1, acc[n]);
     }
 #pragma unroll
     for (int n = 0; n < NS; ++n) {
-      const double p2 = ok2 ? (MODE == SSSPY_WEIGHT_UNIT ? 1.0 : sl.w[n].y) : 0.0;
+      const double p2 = ok2 ? (WEIGHTED ? w[n].y : 1.0) : 0.0;
       acc[n] = mfma_f64(p2 * v2, v2, acc[n]);
     }
   };
-  auto step = [&](Slab &sl, const int s) __attribute__((always_inline)) {
-    // consume slab s, then refill its registers with slab s + RING: RING slabs are in flight per
-    // wave (a slab is ~0.7 us of matrix-core time against ~2 us of HBM latency; measured at N = 8:
-    // 2 waves per SIMD x 2 slabs beats 1 x 3 and 1 x 4 -- 2.53 / 2.73 / 2.67 ms per iteration).
-    // (the refill is unconditional, clamped to the last slab: loads inside branches make the
-    // compiler drain the whole queue at every join)
-    if (8 * s + 8 <= T) consume(sl, s, std::false_type{});
-    else if (s < nslabs) consume(sl, s, std::true_type{});
-    load(sl, min(s + RING, nslabs - 1));
-  };
-  Slab ring[RING];
+  u32x4_t zr[ZRING], wq[WRING];
 #pragma unroll
-  for (int u = 0; u < RING; ++u) load(ring[u], min(u, nslabs - 1));
-  for (int s = 0; s < nslabs; s += RING) {
+  for (int u = 0; u < ZRING; ++u) loadz(zr[u], u);
 #pragma unroll
-    for (int u = 0; u < RING; ++u) step(ring[u], s + u);
+  for (int u = 0; u < WRING; ++u) loadw(wq[u], u);
+  for (int s0 = 0; s0 < nslabs; s0 += ZRING) {
+#pragma unroll
+    for (int pp = 0; pp < WRING; ++pp) {
+      // park the pair's weights (the refills are unconditional, clamped to the last slab / pair:
+      // loads inside branches make the compiler drain the whole queue at every join)
+      const int sp = (s0 >> 1) + pp;
+      if (WEIGHTED) {
+        wave_lds_fence();
+        wpatch[wave][pp & 1][(lane & 7) * 8 + (lane >> 3)] =
+            make_double2(__hiloint2double((int)wq[pp][1], (int)wq[pp][0]),
+                         __hiloint2double((int)wq[pp][3], (int)wq[pp][2]));
+        wave_lds_fence();
+      }
+      loadw(wq[pp], sp + WRING);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int s = s0 + 2 * pp + u;
+        if (8 * s + 8 <= T) consume(zr[2 * pp + u], s, std::false_type{});
+        else if (s < nslabs) consume(zr[2 * pp + u], s, std::true_type{});
+        loadz(zr[2 * pp + u], s + ZRING);
+      }
+    }
   }
   // D[row = k + 4 r][col = lane & 15]: rows / cols 0..7 real parts, 8..15 imaginary parts
   const double scale = 1.0 / (double)T;
