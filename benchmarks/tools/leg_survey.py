@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """ms per iteration of every separator family / spatial algorithm at a given source count (a survey
-for pathological paths): python benchmarks/tools/leg_survey.py <n_sources> [batch] [F] [T]"""
+for pathological paths): python benchmarks/tools/leg_survey.py <n_sources> [batch] [F] [T] [substring of
+the leg names to run]"""
 import os
 import sys
 import time
@@ -34,6 +35,8 @@ if N <= 8:
         legs.append(("FastGaussMNMF-" + algo, lambda a=algo: FastGaussMNMF(n_basis=8, diagonalizer_algorithm=a, record_loss=False, rng=np.random.default_rng(0))))
     legs.append(("GaussMNMF", lambda: GaussMNMF(n_basis=8, record_loss=False, rng=np.random.default_rng(0))))
 pts = N * F * T * B
+if len(sys.argv) > 5:
+    legs = [leg for leg in legs if sys.argv[5] in leg[0]]
 for name, make in legs:
     try:
         m = make()

@@ -117,6 +117,13 @@ def zeros(shape, dtype, dev=None):
     return torch.zeros(tuple(int(s) for s in shape), dtype=dtype, device=dev or device())
 
 
+def eye_filters(B, F, N, dev=None):
+    """(B, F, N, N) identity matrices (plumbing: a torch fill, no arithmetic of the path)."""
+    W = zeros((B, F, N, N), c128, dev)
+    W.diagonal(dim1=-2, dim2=-1).fill_(1.0)
+    return W
+
+
 def ptr(tensor):
     if tensor is None:
         return None

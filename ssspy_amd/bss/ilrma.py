@@ -744,18 +744,30 @@ class _MMILRMA(ILRMABase):
 
     def _output_statistics(self, Y, flooring_fn):
         """U_n = mean_j varphi_nij y y^H of the separated spectrogram for the ISS2 / IPA steps in ONE
-        pass: the Gauss weights 1 / (T V)^(2/p) do not depend on y, so the covariance pass of the IP
-        updates (weights formed from the NMF tiles on the fly) serves with Y in place of X -- instead
-        of a weight pass (read |y|^2, write (N, F, T) weights) plus the generic weighted covariance
-        (round 5: 0.78 -> 0.3 ms at 32 mixtures of configs[1]).  None: the caller forms weights."""
-        if self._base_model[0] != _lib.SOURCE_GAUSS:
+        pass: the covariance pass of the IP updates (weights formed from the NMF tiles on the fly)
+        serves with Y in place of X -- instead of a weight pass (read |y|^2, write (N, F, T) weights)
+        plus the generic weighted covariance (round 5: 0.78 -> 0.3 ms at 32 mixtures of
+        configs[1]).  The Gauss weights 1 / (T V)^(2/p) do not depend on y and the pass takes no
+        filter; the t / GGD weights are functions of |y|^2, which the pass forms as |w_n^H x|^2:
+        up to 4 sources it is handed Y with identity filters (round 6), above that it forms the
+        weights from the spectrogram it is given.  None: the caller forms weights (a host floor on
+        the heavy-tailed weights)."""
+        floor = self._resolve_floor(flooring_fn)
+        gauss = self._base_model[0] == _lib.SOURCE_GAUSS
+        if not gauss and host_floor(floor) is not None:
             return None
         B, N, F, T = Y.shape
+        W = None
+        if not gauss and N <= 4:
+            W = getattr(self, "_eye_filter", None)
+            if W is None or tuple(W.shape) != (B, F, N, N) or W.device != Y.device:
+                W = dv.eye_filters(B, F, N, Y.device)
+                self._eye_filter = W
         if getattr(self, "_Vc", None) is None or tuple(self._Vc.shape) != (B, F, N, N, N):
             self._Vc = dv.empty((B, F, N, N, N), dv.c128, Y.device)
         _ops.ilrma_weighted_covariance(Y, *self._nmf_pair(), float(self.domain), self._ws,
-                                       self._ws_bytes, out=self._Vc, W=None, model=self._model,
-                                       flooring=self._resolve_floor(flooring_fn))
+                                       self._ws_bytes, out=self._Vc, W=W, model=self._model,
+                                       flooring=floor)
         return self._Vc
 
     def update_spatial_model_ip2(self, flooring_fn="self") -> None:

@@ -498,7 +498,7 @@ __device__ __forceinline__ void ipa_source_step(const c128 *Vc, c128 *__restrict
   }
 }
 
-// ---- the whole sweep of up to 7 sources in ONE launch (round 6).  One lane per bin; one wave per
+// ---- the whole sweep of up to 6 sources in ONE launch (round 6).  One lane per bin; one wave per
 // SIMD (the N x N working set of the larger source counts wants the whole 512-entry register file;
 // the grid has only B F lanes anyway).  Rounds 4-5 spent four launches
 // per source step: a memset of the vote words, the probe (everything up to the Newton iteration,
@@ -643,7 +643,7 @@ static int newton_finish(unsigned long long *ws, int ngroups, int max_iter, int 
   return check_launch("k_newton_steps");
 }
 
-// ipa_rows.hip: the sweep of 8 sources with a bin on 8 lanes
+// ipa_rows.hip: the sweep of 7 / 8 sources with a bin on 8 lanes
 bool ipa_rows_wanted(int N);
 int ipa_rows_sweep(bool votes, void *Vc, void *G, int B, int F, int N, int normalization,
                    int max_iter, int floor_kind, double eps, int *info, unsigned long long *ws,
@@ -661,8 +661,8 @@ extern "C" int ssspy_ipa_sweep(void *Vc, void *G, int B, int F, int N, int norma
   SSSPY_REQUIRE(max_iter >= 0, "ipa_sweep: max_iter must be non-negative");
   if (N < 2 || N > SSSPY_MAX_SOURCES)
     return fail(SSSPY_ERR_UNSUPPORTED, "IPA is built for n_sources in [2, 8]");
-  // one launch for the whole sweep: a lane per bin up to 7 sources (k_ipa_sweep_fused), a bin on 8
-  // lanes at 8 (k_ipa_rows)
+  // one launch for the whole sweep: a lane per bin up to 6 sources (k_ipa_sweep_fused), a bin on 8
+  // lanes at 7 and 8 (k_ipa_rows)
   hipStream_t st = as_stream(stream);
   const bool votes = newton_ws && max_iter >= 1 && max_iter <= 62;
   unsigned long long *ws = (unsigned long long *)newton_ws;
@@ -686,7 +686,7 @@ extern "C" int ssspy_ipa_sweep(void *Vc, void *G, int B, int F, int N, int norma
                          (c128 *)G, F, normalization, max_iter, floor_kind, floor_eps, info, ws, B, \
                          not_converged);                                                           \
   }
-  IPA_FUSED(2) IPA_FUSED(3) IPA_FUSED(4) IPA_FUSED(5) IPA_FUSED(6) IPA_FUSED(7)
+  IPA_FUSED(2) IPA_FUSED(3) IPA_FUSED(4) IPA_FUSED(5) IPA_FUSED(6)
 #undef IPA_FUSED
   return check_launch("k_ipa_sweep_fused");
 }

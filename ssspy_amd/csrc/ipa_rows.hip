@@ -509,16 +509,18 @@ __global__ __launch_bounds__(256, 2) void k_ipa_rows(c128 *Vc, c128 *__restrict_
 
 }  // namespace
 
-// 16 x 1025 bins, us per launch (probe / apply), 8 lanes | a lane per bin: 8 sources 247 / 368 | 285 /
-// 472; an ILRMA-IPA iteration 7.0 | 8.05 ms.  Below 8 sources the padded 8 x 8 loses (6 sources: 4.5 |
-// 2.6 ms per iteration): the kernel is bound by its chains of dependent instructions (pivot ->
-// reciprocal -> broadcast -> update, 56 Jacobi rounds) with two waves per SIMD to interleave.  So:
-// 8 sources always (the 24 lane-per-bin instantiations there, 1 000-2 000 spilled VGPRs each, are
-// gone).  5-7 sources keep the lane per bin: a source step there costs 0.13 ms against the 0.24 ms
-// of the padded 8-lane step (8 mixtures of 513 bins, profiles/r05_leg_survey.txt).
-bool ipa_rows_wanted(int N) { return N == 8; }
+// Round 5, 16 x 1025 bins, us per launch (probe / apply), 8 lanes | a lane per bin: 8 sources 247 /
+// 368 | 285 / 472; an ILRMA-IPA iteration 7.0 | 8.05 ms.  The kernel is bound by its chains of
+// dependent instructions (pivot -> reciprocal -> broadcast -> update, 56 Jacobi rounds) with two
+// waves per SIMD to interleave, so the padded 8 x 8 loses where the lane-per-bin form still fits the
+// register file.  Round 6, whole sweep in one launch, 8 mixtures of 513 x 256, GaussILRMA /
+// AuxLaplaceIVA iteration, lane per bin against rows: 5 sources 0.42 / 0.34 against 0.73 / 0.63 ms,
+// 6 sources 0.77 / 0.65 against 0.96 / 0.78, 7 sources 1.45 / 1.30 against 1.26 / 1.04 (the chained
+// lane-per-bin sweep of 7 sources spilled 17 000 VGPRs).  So: 7 and 8 sources here, 5 and 6 a lane
+// per bin.
+bool ipa_rows_wanted(int N) { return N >= 7; }
 
-// the whole sweep of 8 sources: votes = the mixtures' Newton votes are held (else max_iter steps
+// the whole sweep of 7 / 8 sources: votes = the mixtures' Newton votes are held (else max_iter steps
 // everywhere); ws: prepared by the caller (k_ipa_sweep_prepare)
 int ipa_rows_sweep(bool votes, void *Vc, void *G, int B, int F, int N, int normalization,
                    int max_iter, int floor_kind, double eps, int *info, unsigned long long *ws,

@@ -638,6 +638,13 @@ def main():
     run_ilrma("ggdilrma_iss1_n2", N=2, F=17, T=33, K=3, algo="ISS", seed=74, model=("ggd", 1.5))
     run_ilrma("ggdilrma_iss2_n3_p1", N=3, F=16, T=36, K=4, algo="ISS2", seed=75, domain=1, gen=gen_mixture,
               model=("ggd", 0.7))
+    # (round 6: the heavy-tailed ISS2 statistics come from the tuned covariance pass -- up to 4
+    #  sources through identity filters, above that from the spectrogram itself)
+    run_ilrma("tilrma_iss2_n4", N=4, F=17, T=40, K=4, algo="ISS2", seed=76, gen=gen_mixture, model=("t", 6.0))
+    run_ilrma("ggdilrma_iss2_n4", N=4, F=16, T=44, K=3, algo="ISS2", seed=77, gen=gen_mixture,
+              model=("ggd", 1.0))
+    run_ilrma("tilrma_iss2_n6_p1", N=6, F=12, T=48, K=3, algo="ISS2", seed=78, domain=1, gen=gen_mixture,
+              model=("t", 5.0))
     # --- ME source updates and partitioning (latent variables) ---
     run_ilrma("gilrma_me_ip1_n3", N=3, F=18, T=40, K=4, algo="IP", seed=90, gen=gen_mixture,
               source_algorithm="ME")

@@ -27,7 +27,7 @@ ILRMA_CASES = [
     "gilrma_ip1_n2_nofloor", "gilrma_ip1_n3_raw", "gilrma_iss1_n2", "gilrma_iss1_n4",
     "gilrma_iss1_n3_p1", "gilrma_ip2_n3", "gilrma_ip2_n2", "gilrma_iss2_n4", "gilrma_iss2_n3",
     "tilrma_ip1_n3", "tilrma_iss1_n2_p1", "tilrma_ip2_n3", "ggdilrma_ip1_n3", "ggdilrma_iss1_n2",
-    "ggdilrma_iss2_n3_p1", "gilrma_me_ip1_n3", "tilrma_me_iss1_n2", "gilrma_part_ip1_n3",
+    "ggdilrma_iss2_n3_p1", "tilrma_iss2_n4", "ggdilrma_iss2_n4", "tilrma_iss2_n6_p1", "gilrma_me_ip1_n3", "tilrma_me_iss1_n2", "gilrma_part_ip1_n3",
     "gilrma_part_iss1_n2_p1", "gilrma_part_me_ip2_n3", "tilrma_part_ip1_n2", "ggdilrma_part_iss1_n3",
     "tilrma_part_me_nonorm_n2", "gilrma_ipa_n3", "gilrma_ipa_n2_p1", "gilrma_ipa_part_n4",
     "gilrma_ipa_newton8_n3",
