@@ -80,8 +80,10 @@ const char *ssspy_amd_version(void);
  * would pass a stream where a workspace is expected): the binding compares it with the value of
  * the header it was written against and refuses to load a library that disagrees.
  * 2: round 6 (ssspy_covariance_congruence_tracked added; round-5 signatures of
- *    ssspy_ilrma_loss_workspace_bytes / ssspy_fastmnmf_diagonalizer_covariance). */
-#define SSSPY_ABI_VERSION 2
+ *    ssspy_ilrma_loss_workspace_bytes / ssspy_fastmnmf_diagonalizer_covariance).
+ * 3: round 6 (ssspy_ilrma_ip1_update_loss_slots: `logdet` became slots,
+ *    ssspy_ilrma_deferred_logdet_slots added). */
+#define SSSPY_ABI_VERSION 3
 int ssspy_abi_version(void);
 const char *ssspy_last_error(void);
 
@@ -406,9 +408,16 @@ int ssspy_ilrma_ip1_update_deferred_loss(const void *X, const void *C, void *W, 
  * A run of n_iter iterations allocates one zeroed array of slots x (n_iter + 1) B doubles, passes
  * slots + t B with slot_stride = (n_iter + 1) B in iteration t, and folds all iterations' slots in
  * slot order with one ssspy_fold_scalar_slots(slots, (n_iter + 1) B, n_slots, out, ...) at the end --
- * instead of a memset, a counter memset and a fold launch per iteration.  logdet as above. */
+ * instead of a memset, a counter memset and a fold launch per iteration.
+ * logdet (round 6) is laid out the same way: ssspy_ilrma_deferred_logdet_slots() shares per mixture
+ * at logdet[s * slot_stride + b], to be folded in slot order like the data slots -- 1 where the
+ * call leaves the finished sums (logdet[b]), ceil(F / 16) for a handful of mixtures, where the IP1
+ * kernel of the latency path leaves the log-determinants of the filters it reads, per tile of 16
+ * bins, instead of a dedicated one-block launch per iteration (0: no by-product for this shape). */
 int ssspy_ilrma_deferred_loss_slots(int B, int N, int F, int T, int K, double domain,
                                     int source_model);
+int ssspy_ilrma_deferred_logdet_slots(int B, int N, int F, int T, int K, double domain,
+                                      int source_model);
 int ssspy_ilrma_ip1_update_loss_slots(const void *X, const void *C, void *W, double *basis,
                                       double *activation, void *U, int B, int N, int F, int T,
                                       int K, double domain, int source_model, double model_param,

@@ -24,7 +24,7 @@ MAX_PAIRS = 32
 # SSSPY_MAX_SOURCES (per-N kernels: IPA, both MNMF classes, the Hermitian operators),
 # SSSPY_RT_MAX_SOURCES (run-time-N kernels: the shared operators, ILRMA and AuxIVA), SSSPY_MAX_BASIS
 MAX_SOURCES, RT_MAX_SOURCES, MAX_BASIS = 8, 16, 1024
-ABI_VERSION = 2  # SSSPY_ABI_VERSION of the include/ssspy_amd.h these prototypes mirror
+ABI_VERSION = 3  # SSSPY_ABI_VERSION of the include/ssspy_amd.h these prototypes mirror
 
 _p, _i, _d, _z = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
 _q = ctypes.c_longlong
@@ -88,6 +88,7 @@ PROTOTYPES = {
     "ssspy_ilrma_ip1_update_deferred_loss": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i,
                                                   _d, _i, _i, _d, _p, _z, _p, _p, _p, _p]),
     "ssspy_ilrma_deferred_loss_slots": (_i, [_i, _i, _i, _i, _i, _d, _i]),
+    "ssspy_ilrma_deferred_logdet_slots": (_i, [_i, _i, _i, _i, _i, _d, _i]),
     "ssspy_ilrma_ip1_update_loss_slots": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i,
                                                _d, _i, _i, _d, _p, _z, _p, _p, _q, _p, _p]),
     "ssspy_fold_scalar_slots_workspace_bytes": (_z, [_q, _i]),

@@ -531,6 +531,11 @@ def ilrma_ip1_update_deferred_loss(X, C, W, basis, activation, U, domain, normal
     return True
 
 
+def ilrma_deferred_logdet_slots(B, N, F, T, K, domain, model=GAUSS):
+    """Shares per mixture ``ilrma_ip1_update_loss_slots`` leaves in ``logdet`` (0: no by-product)."""
+    return int(_L().ssspy_ilrma_deferred_logdet_slots(B, N, F, T, K, domain, model[0]))
+
+
 def ilrma_deferred_loss_slots(B, N, F, T, K, domain, model=GAUSS):
     """Raw loss slots per mixture of ilrma_ip1_update_loss_slots (0: no by-product for this shape)."""
     return int(_L().ssspy_ilrma_deferred_loss_slots(B, N, F, T, K, domain, model[0]))

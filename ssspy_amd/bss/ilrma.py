@@ -393,18 +393,26 @@ class _MMILRMA(ILRMABase):
         if nslots and stride < 2 ** 31 and nslots * stride * 8 <= (1 << 28):  # (<= 256 MB)
             slots = dv.zeros((nslots, stride), dv.f64, dev)
         flat = slots.reshape(-1) if slots is not None else None
+        # the log-determinants the same way (round 6): one share per mixture (the finished sum) or,
+        # for a handful of mixtures, one per 16-bin tile of the IP1 kernel, folded at the end
+        nld = _ops.ilrma_deferred_logdet_slots(B, N, F, T, self.n_basis, float(self.domain),
+                                               self._model) if slots is not None else 1
+        ld = dv.zeros((nld, stride), dv.f64, dev) if nld > 1 else logdet
+        ld_flat = ld.reshape(-1)
         for t in range(n_iter):
             if t == 0 and not initial_call:
                 # the reference records nothing before the first iteration in this case
                 _ops.ilrma_ip1_update(*args, model=self._model)
             elif slots is not None:
-                _ops.ilrma_ip1_update_loss_slots(*args, flat[t * B:], stride, logdet[t],
+                _ops.ilrma_ip1_update_loss_slots(*args, flat[t * B:], stride, ld_flat[t * B:],
                                                  model=self._model)
             elif not _ops.ilrma_ip1_update_deferred_loss(*args, data[t], logdet[t],
                                                          model=self._model):
                 raise RuntimeError("deferred loss unavailable although reported as supported")
         if slots is not None:
             _ops.fold_scalar_slots(slots, stride, nslots, data.reshape(-1))
+            if nld > 1:
+                _ops.fold_scalar_slots(ld, stride, nld, logdet.reshape(-1))
         for name in ("demix_filter", "basis", "activation"):
             self._state_touch(name)
         _ops.ilrma_loss_data(self._X, W, Tb, Vb, float(self.domain), out=data[n_iter],

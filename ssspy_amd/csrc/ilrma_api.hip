@@ -50,6 +50,9 @@ DECL_FAST(2) DECL_FAST(3) DECL_FAST(4)
                                   hipStream_t);                                                   \
   int ilrma_small_ip1_n##n(const void *, int, int, long long, const void *, void *, int, int, int, \
                            double, double *, int *, hipStream_t);                                 \
+  int ilrma_small_ip1_logdet_n##n(const void *, int, int, long long, const void *, void *, int,   \
+                                  int, int, double, double *, int *, double *, long long,         \
+                                  hipStream_t);                                                   \
   int ilrma_small_norm_n##n(void *, double *, const double *, int, int, int, double, int, double, \
                             hipStream_t);
 DECL_SMALL(2) DECL_SMALL(3) DECL_SMALL(4)
@@ -1136,10 +1139,13 @@ static int ip1_update_impl(const void *X, const void *C, void *W, double *basis,
       return fail(SSSPY_ERR_UNSUPPORTED,
                   "ilrma_ip1_update_deferred_loss: this shape takes the generic kernels, which have "
                   "no loss by-product (use ssspy_ilrma_loss_data + ssspy_ilrma_ip1_update)");
-    // loss of the state at entry: log-determinants now (IP1 rewrites W below), data term as a
-    // by-product of the basis pass
-    rc = ssspy_sum_logdet(W, logdet, B, F, N, stream);
-    if (rc) return rc;
+    // loss of the state at entry: log-determinants now (IP1 rewrites W below) -- or, with slots on
+    // the latency path, as one share per 16-bin tile from the IP1 kernel itself, which reads the
+    // same filters before it rewrites them -- data term as a by-product of the basis pass
+    if (!(loss_stride > 0 && small_path(B, N, F, T, K, domain, source_model))) {
+      rc = ssspy_sum_logdet(W, logdet, B, F, N, stream);
+      if (rc) return rc;
+    }
     // (loss_data is stored, not accumulated: the basis pass folds its per-wave shares into it)
   }
   bool loss_done = false;
@@ -1188,6 +1194,12 @@ static int ip1_update_impl(const void *X, const void *C, void *W, double *basis,
     rc = cov();
     if (rc) return rc;
     auto ip1 = [&]() -> int {
+      if (loss_data && loss_stride > 0) {
+        ILRMA_FAST_DISPATCH(N, ilrma_small_ip1_logdet,
+                            split ? (const void *)(ws + w.upart) : (const void *)U, split, rbins, 0ll,
+                            normalize ? C : nullptr, W, B, F, floor_kind, floor_eps, qbuf, info,
+                            logdet, loss_stride, st);
+      }
       ILRMA_FAST_DISPATCH(N, ilrma_small_ip1, split ? (const void *)(ws + w.upart) : (const void *)U,
                           split, rbins, 0ll, normalize ? C : nullptr, W, B, F, floor_kind, floor_eps,
                           qbuf, info, st);
@@ -1248,6 +1260,12 @@ int ssspy_ilrma_deferred_loss_slots(int B, int N, int F, int T, int K, double do
     case 4: return ilrma_fast_basis_loss_slots_n4(B, F, T);
     default: return 0;
   }
+}
+
+int ssspy_ilrma_deferred_logdet_slots(int B, int N, int F, int T, int K, double domain,
+                                      int source_model) {
+  if (!ssspy_ilrma_deferred_loss_supported(N, F, T, K, domain, source_model)) return 0;
+  return small_path(B, N, F, T, K, domain, source_model) ? (F + 15) / 16 : 1;
 }
 
 int ssspy_ilrma_ip1_update_loss_slots(const void *X, const void *C, void *W, double *basis,

@@ -365,10 +365,16 @@ __device__ __forceinline__ c128 crecip_nr(c128 a) {
 // no unsplit item: a handful of mixtures), which are summed here instead of by k_wcov_fold.
 // rec: c128 between consecutive records (rbins N^3 for k_wcov_fast; FastMNMF's records share a
 // wider scratch slot, mnmf_tail_doubles()).
+// logdet (optional): logdet[tile * logdet_stride + b] <- sum over the tile's bins of log|det W| of
+// the filters AS THEY COME IN (the state the loss of the previous iteration describes,
+// ssspy/bss/ilrma.py:1910-1967): wave 1, idle once the operands are staged, takes a lane per bin
+// while wave 0 runs the projections -- the dedicated one-block kernel was 13 us + a launch gap per
+// iteration of a one-mixture run with record_loss=True.
 __global__ __launch_bounds__(256) void k_ip1_small(c128 *W, const c128 *__restrict__ Usrc,
                                                    const c128 *__restrict__ C, double *qbuf, int F,
                                                    int nchunks, int rbins, long long rec,
-                                                   int floor_kind, double eps, int *info) {
+                                                   int floor_kind, double eps, int *info,
+                                                   double *logdet, long long logdet_stride) {
   constexpr int NN = N * N, G = 4;
   __shared__ __attribute__((aligned(16))) c128 Us[16][N][NN + 1];
   __shared__ __attribute__((aligned(16))) c128 Ws[16][NN + 1];
@@ -418,6 +424,23 @@ __global__ __launch_bounds__(256) void k_ip1_small(c128 *W, const c128 *__restri
     }
   }
   __syncthreads();
+  if (logdet && threadIdx.x >= 64 && threadIdx.x < 128) {
+    const int l = threadIdx.x - 64;
+    double ld = 0.0;
+    if (l < 16 && tile * 16 + l < F) {
+      Mat<N> A;
+#pragma unroll
+      for (int rr = 0; rr < N; ++rr)
+#pragma unroll
+        for (int c = 0; c < N; ++c) A.a[rr][c] = Ws[l][rr * N + c];
+      ld = logabsdet<N>(A);
+    }
+    // the 16 shares in lane order on lane 0 (fixed order: the loss list is the same on every run)
+    double total = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) total += __shfl(ld, q, 64);
+    if (l == 0) logdet[(long long)tile * logdet_stride + b] = total;
+  }
   if (threadIdx.x >= 64) return;
   const int bl = threadIdx.x >> 2, r = threadIdx.x & 3;  // 16 bins x 4 lanes
   const int bin = tile * 16 + bl;
@@ -674,7 +697,20 @@ int LAUNCHER(ilrma_small_ip1)(const void *Usrc, int nchunks, int rbins, long lon
   const long long rec = rec_stride > 0 ? rec_stride : (long long)rbins * (N * N * N);
   hipLaunchKernelGGL(k_ip1_small, dim3((F + 15) / 16, B), dim3(256), 0, st, (c128 *)W,
                      (const c128 *)Usrc, (const c128 *)C, C ? qbuf : (double *)nullptr, F, nchunks,
-                     rbins, rec, floor_kind, eps, info);
+                     rbins, rec, floor_kind, eps, info, (double *)nullptr, 0ll);
+  return check_launch("k_ip1_small");
+}
+
+// The same, leaving the log-determinants of the incoming filters as one share per tile of 16 bins:
+// logdet[tile * logdet_stride + b], tile < ceil(F / 16) (see k_ip1_small).
+int LAUNCHER(ilrma_small_ip1_logdet)(const void *Usrc, int nchunks, int rbins, long long rec_stride,
+                                     const void *C, void *W, int B, int F, int floor_kind,
+                                     double eps, double *qbuf, int *info, double *logdet,
+                                     long long logdet_stride, hipStream_t st) {
+  const long long rec = rec_stride > 0 ? rec_stride : (long long)rbins * (N * N * N);
+  hipLaunchKernelGGL(k_ip1_small, dim3((F + 15) / 16, B), dim3(256), 0, st, (c128 *)W,
+                     (const c128 *)Usrc, (const c128 *)C, C ? qbuf : (double *)nullptr, F, nchunks,
+                     rbins, rec, floor_kind, eps, info, logdet, logdet_stride);
   return check_launch("k_ip1_small");
 }
 
