@@ -286,7 +286,8 @@ class _MMILRMA(ILRMABase):
         """
         self._bind_input(input)
         self._reset(flooring_fn=self.flooring_fn, **kwargs)
-        if not self._iterate_with_deferred_loss(int(n_iter), initial_call):
+        if not (self._iterate_with_deferred_loss(int(n_iter), initial_call)
+                or self._iterate_with_resident_terms(int(n_iter), initial_call)):
             IterativeMethodBase.__call__(self, n_iter=n_iter, initial_call=initial_call)
         if self.scale_restoration:
             self.restore_scale()
@@ -418,6 +419,34 @@ class _MMILRMA(ILRMABase):
         _ops.ilrma_loss_data(self._X, W, Tb, Vb, float(self.domain), out=data[n_iter],
                              model=self._model)
         _ops.sum_logdet(W, out=logdet[n_iter])
+        self._check_device_errors()
+        values = dv.to_host(data) - 2.0 * dv.to_host(logdet)
+        if not initial_call:
+            values = values[1:]
+        self.loss.extend(v.copy() if self._batched else v[0].item() for v in values)
+        return True
+
+    def _iterate_with_resident_terms(self, n_iter: int, initial_call: bool) -> bool:
+        """``record_loss=True`` for every iteration the deferred form above does not serve (ISS /
+        ISS2 / IP2 / IPA, heavy-tailed models, ...) without a host round trip per iteration
+        (round 6): ``compute_loss()`` downloads two numbers per mixture and the wait for them
+        drains the queue after every iteration.  Here the terms stay in HBM and one download at
+        the end assembles the list.  Only with the library's own ``update_once`` /
+        ``compute_loss`` and no callbacks; otherwise (returns False) the reference's loop runs
+        unchanged.  ref: ssspy/bss/base.py:68-77, ssspy/bss/ilrma.py:1910-1967."""
+        cls = type(self)
+        if not (self.record_loss and not self.callbacks and n_iter > 0
+                and cls.update_once is _MMILRMA.update_once
+                and cls.compute_loss is _MMILRMA.compute_loss):
+            return False
+        B, dev = self._X.shape[0], self._X.device
+        data = dv.zeros((n_iter + 1, B), dv.f64, dev)
+        logdet = dv.zeros((n_iter + 1, B), dv.f64, dev)
+        for t in range(n_iter + 1):
+            if t > 0 or initial_call:
+                self._loss_terms(data[t], logdet[t])
+            if t < n_iter:
+                self.update_once()
         self._check_device_errors()
         values = dv.to_host(data) - 2.0 * dv.to_host(logdet)
         if not initial_call:
@@ -956,22 +985,32 @@ class _MMILRMA(ILRMABase):
 
     def compute_loss(self) -> float:
         """Negative log-likelihood (ref: ssspy/bss/ilrma.py:1910-1967)."""
+        return self._host_loss(*self._loss_terms())
+
+    def _loss_terms(self, data_out=None, logdet_out=None):
+        """(data term, sum_i log|det W_i|) of the current state on the device, each (B,)."""
         T, V = self._nmf_pair()
         if self._uses_filter():
             W = self._state_dev("demix_filter")
-            data = _ops.ilrma_loss_data(self._X, W, T, V, float(self.domain), model=self._model)
+            data = _ops.ilrma_loss_data(self._X, W, T, V, float(self.domain), out=data_out,
+                                        model=self._model)
         elif self._implied_filter() is not None:
             W = self._implied_filter()
-            data = _ops.ilrma_loss_data(self._X, W, T, V, float(self.domain), model=self._model)
+            data = _ops.ilrma_loss_data(self._X, W, T, V, float(self.domain), out=data_out,
+                                        model=self._model)
         else:
             Y = self._state_dev("output")
-            data = _ops.ilrma_loss_data(Y, None, T, V, float(self.domain), model=self._model)
+            data = _ops.ilrma_loss_data(Y, None, T, V, float(self.domain), out=data_out,
+                                        model=self._model)
             tracked = self._tracked_logdet()
             if tracked is not None:  # moved along by the sweeps and the normalisation
-                return self._host_loss(data, tracked)
+                if logdet_out is None:
+                    return data, tracked
+                logdet_out.copy_(tracked)  # (the next sweep moves the tracked sum in place)
+                return data, logdet_out
             W = _ops.demix_from_covariance(_ops.cross_covariance(Y, self._X), self._C(),
                                            self._info_tensor())
-        return self._host_loss(data, _ops.sum_logdet(W))
+        return data, _ops.sum_logdet(W, out=logdet_out)
 
 
 class GaussILRMA(_MMILRMA):
