@@ -78,7 +78,7 @@ class ILRMABase(DeviceStateMixin, IterativeMethodBase):
     # -- reset ------------------------------------------------------------------------
     def _reset(self, flooring_fn="self", **kwargs) -> None:
         """ref: ssspy/bss/ilrma.py:151-199."""
-        assert self.input is not None, "Specify data!"
+        assert self._has_input(), "Specify data!"
         flooring_fn = choose_flooring_fn(flooring_fn, method=self)
         for key, value in kwargs.items():
             setattr(self, key, value)

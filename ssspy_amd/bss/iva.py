@@ -66,7 +66,7 @@ class IVABase(DeviceStateMixin, IterativeMethodBase):
 
     def _reset(self, **kwargs) -> None:
         """ref: ssspy/bss/iva.py:138-169."""
-        assert self.input is not None, "Specify data!"
+        assert self._has_input(), "Specify data!"
         for key, value in kwargs.items():
             setattr(self, key, value)
         B, N, F, T = self._X.shape

@@ -151,7 +151,7 @@ class FastMNMFBase(MNMFBase):
 
     def _reset(self, flooring_fn="self", **kwargs) -> None:
         """ref: ssspy/bss/mnmf.py:499-540."""
-        assert self.input is not None, "Specify data!"
+        assert self._has_input(), "Specify data!"
         flooring_fn = choose_flooring_fn(flooring_fn, method=self)
         for key, value in kwargs.items():
             setattr(self, key, value)
@@ -477,7 +477,7 @@ class MNMF(MNMFBase):
 
     def _reset(self, **kwargs) -> None:
         """ref: ssspy/bss/mnmf.py:139-165."""
-        assert self.input is not None, "Specify data!"
+        assert self._has_input(), "Specify data!"
         for key, value in kwargs.items():
             setattr(self, key, value)
         B, M, F, T = self._X.shape
