@@ -142,3 +142,21 @@ if call:
                 r["Name"] = r["Name"][:120]
                 w.writerow(r)
 print(json.dumps({"bench_value": bench["value"], "roofline": bench["roofline"], "traffic": traffic}, indent=1))
+# round 6 additions: FastGaussMNMF above 4 channels, the leg survey, GaussMNMF per channel count, the
+# phases of one call of configs[1..3]
+for name, out_name in (("fmnmf_wide.txt", "{}_fmnmf_wide.txt"), ("leg_survey.txt", "{}_leg_survey.txt"),
+                       ("gmnmf_channels.txt", "{}_gmnmf_channels.txt"),
+                       ("call_phases.txt", "{}_call_phases.txt")):
+    path = os.path.join(src, name)
+    if os.path.exists(path) and os.path.getsize(path):
+        keep = [ln for ln in open(path) if "amdgpu.ids" not in ln]
+        open(os.path.join(dst, out_name.format(tag)), "w").writelines(keep)
+for path in sorted(glob.glob(os.path.join(src, "fmnmf_wide_m*_kernel_stats.csv"))):
+    rows = [r for r in csv.DictReader(open(path))]
+    with open(os.path.join(dst, "{}_{}".format(tag, os.path.basename(path))), "w") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        for r in rows:
+            if float(r.get("Percentage", 0) or 0) >= 0.05:
+                r["Name"] = r["Name"][:120]
+                w.writerow(r)

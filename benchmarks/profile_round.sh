@@ -7,7 +7,7 @@
 # configs[2] and configs[3] at 32 mixtures).  benchmarks/digest_profiles.py turns these
 # into the tracked files under profiles/.
 set -u
-tag=${1:-r04}
+tag=${1:-r06}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/$tag
 mkdir -p $out $out/legs
@@ -59,5 +59,19 @@ grep -h "ms per iteration" $out/legs/*.log > $out/legs_ms.txt
 python benchmarks/tools/call_timeline.py 100 2>/dev/null | grep -v "^$" | head -12 > $out/call_timeline.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/call_stats -- python benchmarks/tools/call_once.py 100 >> $out/call_timeline.txt 2>&1
 python benchmarks/cache_energy.py --seconds 4 > $out/cache_energy.json 2>/dev/null
-python benchmarks/subbatch_sweep.py --seconds 1.0 > $out/subbatch_sweep.txt 2>/dev/null
+# ---- round 6: FastGaussMNMF above 4 channels (iteration, Wiener filter, kernel statistics), the leg
+# survey at 4 / 5 / 6 / 7 / 8 sources, GaussMNMF per channel count, the phases of one call of
+# configs[2] / configs[3]
+for m in 5 6 7 8; do python benchmarks/tools/fmnmf_wide.py $m; done > $out/fmnmf_wide.txt 2>/dev/null
+for m in 6 8; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/fmw$m -- python benchmarks/tools/fmnmf_wide.py $m > /dev/null 2>&1
+  f=$(find $out/fmw$m -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cp "$f" $out/fmnmf_wide_m${m}_kernel_stats.csv
+  rm -rf $out/fmw$m
+done
+for n in 2 4 5 6 7 8; do python benchmarks/tools/leg_survey.py $n; done > $out/leg_survey.txt 2>/dev/null
+python benchmarks/gmnmf_channels.py 8 4 5 6 7 8 > $out/gmnmf_channels.txt 2>/dev/null
+for k in ilrma auxiva fmnmf; do python benchmarks/tools/call_any.py $k 100; done > $out/call_phases.txt 2>/dev/null
+python benchmarks/tools/call_phases.py auxiva >> $out/call_phases.txt 2>/dev/null
+python benchmarks/tools/call_phases.py fmnmf >> $out/call_phases.txt 2>/dev/null
 tail -c 600 $out/bench.json

@@ -762,6 +762,9 @@ def fastmnmf_separate(X, Q, D, basis, activation, reference_id, flooring, ws, ws
     return out
 
 
+_HOST_FLOOR_EIG_BYTES = 1 << 28  # eigenvector scratch of fastmnmf_separate_host_floor
+
+
 def fastmnmf_separate_host_floor(X, Q, D, basis, activation, reference_id, host_fn, ws, ws_bytes,
                                  info, out=None):
     """The Wiener filter with an arbitrary flooring callable on the eigenvalues of R_ij: stage 1
@@ -772,17 +775,25 @@ def fastmnmf_separate_host_floor(X, Q, D, basis, activation, reference_id, host_
     N, K = basis.shape[1], basis.shape[-1]
     if out is None:
         out = dv.empty((B, N, F, T), dv.c128, X.device)
-    lam = dv.empty((B, F, T, M), dv.f64, X.device)
-    P = dv.empty((B, F, T, M, M), dv.c128, X.device)
-    for stage in (1, 2):
-        _lib.check(
-            _L().ssspy_fastmnmf_separate_eig(ptr(X), ptr(Q), ptr(D), ptr(basis), ptr(activation),
-                                             ptr(out), B, N, M, F, T, K, reference_id, stage,
-                                             ptr(lam), ptr(P), ptr(ws), ws_bytes, ptr(info), _st()),
-            "fastmnmf_separate_eig",
-        )
-        if stage == 1:
-            lam.copy_(dv.to_device(_apply_host(host_fn, lam), dev=X.device))
+    # a few mixtures at a time: the eigenvectors of every point are (F, T, M, M) complex128 per
+    # mixture (34 MB at 4 channels of 513 x 256, 1 GB for 32 of them), the buffers are reused
+    per = F * T * M * M * 16
+    cb = max(1, min(B, _HOST_FLOOR_EIG_BYTES // per))
+    lam = dv.empty((cb, F, T, M), dv.f64, X.device)
+    P = dv.empty((cb, F, T, M, M), dv.c128, X.device)
+    for b0 in range(0, B, cb):
+        n = min(cb, B - b0)
+        sl = slice(b0, b0 + n)
+        for stage in (1, 2):
+            _lib.check(
+                _L().ssspy_fastmnmf_separate_eig(ptr(X[sl]), ptr(Q[sl]), ptr(D[sl]), ptr(basis[sl]),
+                                                 ptr(activation[sl]), ptr(out[sl]), n, N, M, F, T, K,
+                                                 reference_id, stage, ptr(lam), ptr(P), ptr(ws),
+                                                 ws_bytes, ptr(info), _st()),
+                "fastmnmf_separate_eig",
+            )
+            if stage == 1:
+                lam[:n].copy_(dv.to_device(_apply_host(host_fn, lam[:n]), dev=X.device))
     return out
 
 

@@ -31,7 +31,8 @@ struct FastModel {
 // less than half the instructions of the correctly rounded pow)
 // (e is uniform: beta = 1, the Laplace-like GGD, needs nothing but square roots)
 __device__ __forceinline__ double pow_nonneg(double x, double e) {
-  if (e == 0.5) return sqrt(x);
+  if (e == 0.5) return sqrt_nr(x);
+  if (e == 0.25) return sqrt_nr(sqrt_nr(x));  // (beta = 1/2)
   return x > 0.0 ? exp2(e * log2(x)) : 0.0;
 }
 

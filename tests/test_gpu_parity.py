@@ -2534,7 +2534,7 @@ def test_arbitrary_flooring_callable_unsupported_paths_fail_loudly():
 
 
 @pytest.mark.parametrize("algo,N,M,B", [("IP", 3, 3, 1), ("IP", 4, 4, 3), ("IP2", 3, 4, 2), ("IP", 2, 6, 1)])
-def test_fast_gauss_mnmf_host_evaluated_floor_equals_the_kernel_floor(algo, N, M, B):
+def test_fast_gauss_mnmf_host_evaluated_floor_equals_the_kernel_floor(algo, N, M, B, monkeypatch):
     """Round 5: FastGaussMNMF with a flooring callable the kernels do not recognise -- the steps run
     one by one with the floor off, the callable on basis / activation / IP denominators / psi on the
     host, and the Wiener filter is split at its eigenvalue floor (stage 1: eigen-decomposition of
@@ -2547,10 +2547,15 @@ def test_fast_gauss_mnmf_host_evaluated_floor_equals_the_kernel_floor(algo, N, M
     from ssspy_amd.special.flooring import max_flooring
     from ssspy_amd.utils.dataset import nmf_mixture
 
+    from ssspy_amd import _ops
+
     F, T, K = 33, 48, 3
     X = np.stack([nmf_mixture(700 + b, M, F, T) for b in range(B)])
     if B == 1:
         X = X[0]
+    # (round 6: the split Wiener filter walks the batch in chunks that fit a byte budget for the
+    #  eigenvectors; with room for two mixtures the batch of three takes a chunk of 2 and one of 1)
+    monkeypatch.setattr(_ops, "_HOST_FLOOR_EIG_BYTES", 2 * F * T * M * M * 16)
     for eps in (1e-10, 1e-2):
         def make(floor):
             return FastGaussMNMF(n_basis=K, n_sources=N, diagonalizer_algorithm=algo,
