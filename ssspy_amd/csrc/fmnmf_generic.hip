@@ -639,10 +639,12 @@ __global__ __launch_bounds__(128) void k_separate(const c128 *__restrict__ X,
         sm[m] = cmake(y.x * g, y.y * g);
       }
     } else if constexpr (REPAIR) {
+      // (A and P live in the lane's scratch memory: jacobi_eigh_rolled indexes them at run time.
+      //  Unrolled on registers this branch spilled 530-2 400 VGPRs at 5-8 channels.)
       c128 A[M][M], P[M][M];
-#pragma unroll
+#pragma unroll 1
       for (int a = 0; a < M; ++a)
-#pragma unroll
+#pragma unroll 1
         for (int c2 = a; c2 < M; ++c2) {
           c128 s = cmake(0.0, 0.0);
 #pragma unroll
@@ -665,20 +667,20 @@ __global__ __launch_bounds__(128) void k_separate(const c128 *__restrict__ X,
           for (int a = 0; a < M; ++a) P[a][k] = P_io[(point * M + a) * M + k];
         }
       } else {
-        jacobi_eigh<M>(A, P);
+        jacobi_eigh_rolled<M>(A, P);
 #pragma unroll
         for (int k = 0; k < M; ++k) evs[k] = apply_floor(A[k][k].x, floor_kind, eps);
       }
       if constexpr (EIG == 1) {
-        // ascending order without dynamic indexing (rank of every eigenvalue, ties by index)
-#pragma unroll
+        // ascending order (rank of every eigenvalue, ties by index)
+#pragma unroll 1
         for (int k = 0; k < M; ++k) {
           int rank = 0;
-#pragma unroll
+#pragma unroll 1
           for (int l = 0; l < M; ++l)
             rank += (A[l][l].x < A[k][k].x || (A[l][l].x == A[k][k].x && l < k)) ? 1 : 0;
           lam_io[point * M + rank] = A[k][k].x;
-#pragma unroll
+#pragma unroll 1
           for (int a = 0; a < M; ++a) P_io[(point * M + a) * M + rank] = P[a][k];
         }
         continue;

@@ -81,7 +81,7 @@ __device__ __forceinline__ void psd_inverse(c128 (&R)[M][M], c128 (&Rinv)[M][M],
   if (!ok) {
     c128 P[M][M];
     double ev[M], w[M];
-    psd_eigen<M>(R, P, ev, floor_kind, eps);
+    psd_eigen<M, (M >= 6)>(R, P, ev, floor_kind, eps);
     double ld = 0.0;
 #pragma unroll
     for (int k = 0; k < M; ++k) {
@@ -645,6 +645,22 @@ __global__ __launch_bounds__(GM_PB) void k_gmnmf_spatial_acc(const c128 *__restr
 }
 
 // H <- to_psd(P^-1 # (H Q H)) with P, HQH floored first.  One lane per (b, n, i).
+// the literal update's products: memory-resident from 5 channels on (eight M x M matrices per lane:
+// unrolled on registers the kernel spilled 136-5 858 VGPRs at 5-8 channels; it runs for flagged
+// blocks only)
+template <int M>
+__device__ __forceinline__ void su_matmul(const c128 (&A)[M][M], const c128 (&B)[M][M],
+                                          c128 (&C)[M][M]) {
+  if constexpr (M >= 5) matmul_rolled<M>(A, B, C);
+  else matmul<M>(A, B, C);
+}
+template <int M>
+__device__ __forceinline__ void su_rebuild(const c128 (&P)[M][M], const double (&w)[M],
+                                           c128 (&Out)[M][M]) {
+  if constexpr (M >= 5) herm_rebuild_rolled<M>(P, w, Out);
+  else herm_rebuild<M>(P, w, Out);
+}
+
 template <int M>
 __global__ __launch_bounds__(64) void k_gmnmf_spatial_update(c128 *H,
                                                              const double *__restrict__ PQacc,
@@ -662,34 +678,35 @@ __global__ __launch_bounds__(64) void k_gmnmf_spatial_update(c128 *H,
     for (int c = 0; c < M; ++c) Hm[a][c] = H[idx * (M * M) + a * M + c];
   unpack_hermitian<M>(PQacc + idx * (2 * M * M) + M * M, Qm);
   // HQH, floored
-  matmul<M>(Hm, Qm, Tm);
-  matmul<M>(Tm, Hm, C);
-  psd_eigen<M>(C, Pv, lam, floor_kind, eps);
+  su_matmul<M>(Hm, Qm, Tm);
+  su_matmul<M>(Tm, Hm, C);
+  psd_eigen<M, (M >= 5)>(C, Pv, lam, floor_kind, eps);
   c128 HQH[M][M];
-  herm_rebuild<M>(Pv, lam, HQH);
+  su_rebuild<M>(Pv, lam, HQH);
   // P floored, P^(1/2), P^(-1/2)
   unpack_hermitian<M>(PQacc + idx * (2 * M * M), C);
-  psd_eigen<M>(C, Pv, lam, floor_kind, eps);
+  psd_eigen<M, (M >= 5)>(C, Pv, lam, floor_kind, eps);
   c128 Ph[M][M], Pih[M][M];
 #pragma unroll
   for (int k = 0; k < M; ++k) w[k] = sqrt(lam[k]);
-  herm_rebuild<M>(Pv, w, Ph);
+  su_rebuild<M>(Pv, w, Ph);
 #pragma unroll
   for (int k = 0; k < M; ++k) w[k] = 1.0 / w[k];
-  herm_rebuild<M>(Pv, w, Pih);
+  su_rebuild<M>(Pv, w, Pih);
   // (P^1/2 HQH P^1/2)^1/2
-  matmul<M>(Ph, HQH, Tm);
-  matmul<M>(Tm, Ph, C);
+  su_matmul<M>(Ph, HQH, Tm);
+  su_matmul<M>(Tm, Ph, C);
   hermitize<M>(C);
-  jacobi_eigh<M>(C, Pv);
+  if constexpr (M >= 5) jacobi_eigh_rolled<M>(C, Pv);
+  else jacobi_eigh<M>(C, Pv);
 #pragma unroll
   for (int k = 0; k < M; ++k) w[k] = sqrt(fmax(C[k][k].x, 0.0));
-  herm_rebuild<M>(Pv, w, Qm);
+  su_rebuild<M>(Pv, w, Qm);
   // G = P^-1/2 (...) P^-1/2, floored
-  matmul<M>(Pih, Qm, Tm);
-  matmul<M>(Tm, Pih, C);
-  psd_eigen<M>(C, Pv, lam, floor_kind, eps);
-  herm_rebuild<M>(Pv, lam, Hm);
+  su_matmul<M>(Pih, Qm, Tm);
+  su_matmul<M>(Tm, Pih, C);
+  psd_eigen<M, (M >= 5)>(C, Pv, lam, floor_kind, eps);
+  su_rebuild<M>(Pv, lam, Hm);
 #pragma unroll
   for (int a = 0; a < M; ++a)
 #pragma unroll

@@ -76,6 +76,75 @@ __device__ __forceinline__ void jacobi_eigh(c128 (&A)[M][M], c128 (&P)[M][M]) {
   }
 }
 
+// The same sweeps with the pair loop ROLLED: A and P are indexed at run time and therefore live in
+// the lane's scratch memory instead of registers -- for the repair kernels that hold an M x M
+// working set per lane from 5 channels on (unrolled they spill 500-2 400 VGPRs and their code is
+// megabytes; they run only where an eigenvalue floor may act).  Same pair order, same formulas.
+template <int M>
+__device__ __noinline__ void jacobi_eigh_rolled(c128 (&A)[M][M], c128 (&P)[M][M]) {
+#pragma unroll 1
+  for (int r = 0; r < M; ++r)
+#pragma unroll 1
+    for (int cc = 0; cc < M; ++cc) P[r][cc] = cmake(r == cc ? 1.0 : 0.0, 0.0);
+#pragma unroll 1
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    double off = 0.0, diag = 0.0;
+#pragma unroll 1
+    for (int p = 0; p < M; ++p) {
+      diag = fma(A[p][p].x, A[p][p].x, diag);
+#pragma unroll 1
+      for (int qq = p + 1; qq < M; ++qq) off += cabs2(A[p][qq]);
+    }
+    if (__all(off <= 1e-34 * diag)) break;
+#pragma unroll 1
+    for (int p = 0; p < M - 1; ++p)
+#pragma unroll 1
+      for (int qq = p + 1; qq < M; ++qq) {
+        const c128 apq = A[p][qq];
+        const double mag2 = cabs2(apq);
+        const double mag = sqrt(mag2);
+        const bool tiny = mag2 < 1e-300;
+        const double inv = tiny ? 0.0 : 1.0 / mag;
+        const c128 u = tiny ? cmake(1.0, 0.0) : cmake(apq.x * inv, apq.y * inv);
+        const double app = A[p][p].x, aqq = A[qq][qq].x;
+        const double tau = tiny ? 0.0 : (aqq - app) * 0.5 * inv;
+        const double t = tiny ? 0.0 : ((tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau)));
+        const double cs = 1.0 / sqrt(1.0 + t * t);
+        const double sn = t * cs;
+        const c128 su = cmake(sn * u.x, sn * u.y);    // s u
+        const c128 sub = cmake(sn * u.x, -sn * u.y);  // s conj(u)
+#pragma unroll 1
+        for (int k = 0; k < M; ++k) {
+          if (k != p && k != qq) {
+            const c128 akp = A[k][p], akq = A[k][qq];
+            c128 nkp = cmake(cs * akp.x, cs * akp.y);
+            cfms(nkp, sub, akq);
+            c128 nkq = cmake(cs * akq.x, cs * akq.y);
+            cfma(nkq, su, akp);
+            A[k][p] = nkp;
+            A[p][k] = cconj(nkp);
+            A[k][qq] = nkq;
+            A[qq][k] = cconj(nkq);
+          }
+        }
+        A[p][p] = cmake(app - t * mag, 0.0);
+        A[qq][qq] = cmake(aqq + t * mag, 0.0);
+        A[p][qq] = cmake(0.0, 0.0);
+        A[qq][p] = cmake(0.0, 0.0);
+#pragma unroll 1
+        for (int k = 0; k < M; ++k) {
+          const c128 vkp = P[k][p], vkq = P[k][qq];
+          c128 nkp = cmake(cs * vkp.x, cs * vkp.y);
+          cfms(nkp, sub, vkq);
+          c128 nkq = cmake(cs * vkq.x, cs * vkq.y);
+          cfma(nkq, su, vkp);
+          P[k][p] = nkp;
+          P[k][qq] = nkq;
+        }
+      }
+  }
+}
+
 // (A + A^H) / 2 in place
 template <int M>
 __device__ __forceinline__ void hermitize(c128 (&A)[M][M]) {
@@ -127,13 +196,51 @@ __device__ __forceinline__ void matmul(const c128 (&A)[M][M], const c128 (&B)[M]
     }
 }
 
+// Memory-resident forms of herm_rebuild and matmul (same order of the sums) for the literal repair
+// kernels whose M x M working set does not fit the register file (see jacobi_eigh_rolled)
+template <int M>
+__device__ __noinline__ void herm_rebuild_rolled(const c128 (&P)[M][M], const double (&w)[M],
+                                                 c128 (&Out)[M][M]) {
+#pragma unroll 1
+  for (int a = 0; a < M; ++a)
+#pragma unroll 1
+    for (int b = a; b < M; ++b) {
+      c128 s = cmake(0.0, 0.0);
+#pragma unroll 1
+      for (int k = 0; k < M; ++k) {
+        const c128 t = cmulc(P[a][k], P[b][k]);  // P_ak conj(P_bk)
+        s.x = fma(w[k], t.x, s.x);
+        s.y = fma(w[k], t.y, s.y);
+      }
+      if (a == b) s.y = 0.0;
+      Out[a][b] = s;
+      Out[b][a] = cconj(s);
+    }
+}
+
+template <int M>
+__device__ __noinline__ void matmul_rolled(const c128 (&A)[M][M], const c128 (&B)[M][M],
+                                           c128 (&C)[M][M]) {
+#pragma unroll 1
+  for (int a = 0; a < M; ++a)
+#pragma unroll 1
+    for (int b = 0; b < M; ++b) {
+      c128 s = cmake(0.0, 0.0);
+#pragma unroll 1
+      for (int k = 0; k < M; ++k) cfma(s, A[a][k], B[k][b]);
+      C[a][b] = s;
+    }
+}
+
 // to_psd: Hermitise, eigen-decompose, floor the eigenvalues; returns the floored eigenvalues in
 // lam and the eigenvectors in P (A is destroyed).  ref: ssspy/special/psd.py:11-71.
-template <int M>
+// ROLLED: the memory-resident sweeps (jacobi_eigh_rolled) -- for repair kernels from 6 channels on
+template <int M, bool ROLLED = false>
 __device__ __forceinline__ void psd_eigen(c128 (&A)[M][M], c128 (&P)[M][M], double (&lam)[M],
                                           int floor_kind, double eps) {
   hermitize<M>(A);
-  jacobi_eigh<M>(A, P);
+  if constexpr (ROLLED) jacobi_eigh_rolled<M>(A, P);
+  else jacobi_eigh<M>(A, P);
 #pragma unroll
   for (int k = 0; k < M; ++k) lam[k] = apply_floor(A[k][k].x, floor_kind, eps);
 }
