@@ -694,10 +694,12 @@ int ssspy_lqpqm2_masked(const void *H, const void *v, const double *z, void *y, 
  * The transforms the reference's workflow takes from SciPy either side of a separator
  * (tests/package/bss/test_ilrma.py, test_iva.py, test_mnmf.py: scipy.signal.stft(x, window="hann",
  * nperseg=n_fft, noverlap=n_fft - hop) and scipy.signal.istft), with SciPy's defaults:
- * boundary="zeros", padded=True, one-sided, scaling="spectrum".  n_fft: a power of two <= 8192
- * (radix-2 in LDS) or ANY length in [2, 4096], even or odd, as SciPy's nperseg (Bluestein's chirp-z
- * on two radix-2 transforms; `workspace` = ssspy_stft_workspace_bytes(n_fft) bytes on the device for
- * the chirp's spectrum, 0 / NULL for a power of two).
+ * boundary="zeros", padded=True, one-sided, scaling="spectrum".  n_fft: a power of two <= 65536
+ * or ANY length in [2, 32768], even or odd, as SciPy's nperseg (Bluestein's chirp-z on two radix-2
+ * transforms).  Transforms of up to 8192 points run in LDS; longer ones (a power of two above 8192,
+ * any other length above 4096) on workgroup-private slices of the workspace.  `workspace` =
+ * ssspy_stft_workspace_bytes(n_fft) bytes on the device: the chirp's spectrum and those slices; 0 /
+ * NULL for a power of two <= 8192.
  * x (B, C, n_samples) f64 -> Z (B, C, n_fft/2+1, ssspy_stft_frames(...)) c128; `window` (n_fft) f64
  * on the device, `window_sum` its sum. */
 int ssspy_stft_frames(long long n_samples, int n_fft, int hop);

@@ -11,7 +11,11 @@
 // One workgroup transforms one segment in LDS: bit-reversed load, log2(n) radix-2 passes, twiddles
 // from sincospi.  A power-of-two n_fft up to 8192 (128 KB of complex128 in LDS) is transformed
 // directly; any other n_fft up to 4096 (SciPy takes any nperseg) goes through Bluestein's chirp-z
-// identity inside the same workgroup: x_t e^{-+ i pi t^2 / n} convolved with the chirp e^{+- i pi j^2 / n}
+// identity inside the same workgroup (below).  Longer transforms (round 6: a power of two up to
+// 65536, any other length up to 32768) run the same code on a workgroup-private slice of the
+// caller's workspace in HBM instead of LDS, STFT_GLOBAL_BLOCKS workgroups walking the segments --
+// the passes then go through the L2; correct, not tuned: SciPy takes any nperseg, these sizes are
+// rare.  Bluestein: x_t e^{-+ i pi t^2 / n} convolved with the chirp e^{+- i pi j^2 / n}
 // by two radix-2 transforms of length m = the power of two >= 2 n - 1, the chirp's spectrum computed
 // once per call into a caller-provided workspace (ssspy_stft_workspace_bytes).
 #include "common.hpp"
@@ -61,9 +65,9 @@ __device__ __forceinline__ void bitrev_permute(c128 *buf, int m, int log2m) {
 // Spectrum of the Bluestein chirp b_j = e^{-sign * i pi j^2 / n}, j = -(n-1) .. n-1 at index j mod m
 // (the DFT with exponent sign `sign` convolves with the chirp of the opposite sign).  One workgroup.
 __global__ __launch_bounds__(256) void k_bluestein_chirp(c128 *__restrict__ bhat, int n, int m,
-                                                         int log2m, double sign) {
+                                                         int log2m, double sign, c128 *gbuf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  c128 *buf = reinterpret_cast<c128 *>(smem);
+  c128 *buf = gbuf ? gbuf : reinterpret_cast<c128 *>(smem);
   for (int i = threadIdx.x; i < m; i += blockDim.x) {
     c128 v = cmake(0.0, 0.0);
     if (i < n) v = chirp(i, n, -sign);
@@ -98,57 +102,76 @@ __device__ __forceinline__ void dft_any(c128 *buf, int n, int log2n, int m, int 
   __syncthreads();
 }
 
-// grid: (n_frames, C, B).  x (B, C, L) real -> Z (B, C, n/2+1, n_frames) complex
+// grid: (n_frames, C, B) with the segment in LDS, or (blocks) walking the n_frames C B segments with
+// the segment in the block's slice of `gscratch` (lds_len c128 each).
+// x (B, C, L) real -> Z (B, C, n/2+1, n_frames) complex
 __global__ __launch_bounds__(256) void k_stft(const double *__restrict__ x, c128 *__restrict__ Z,
                                               long long L, int n, int log2n, int hop, int n_frames,
                                               const double *__restrict__ window, double scale, int m,
-                                              int log2m, const c128 *__restrict__ bhat) {
+                                              int log2m, const c128 *__restrict__ bhat, int C, int B,
+                                              c128 *gscratch, int lds_len) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  c128 *buf = reinterpret_cast<c128 *>(smem);
-  const int frame = blockIdx.x, ch = blockIdx.y, b = blockIdx.z;
-  const int C = gridDim.y;
-  const double *xs = x + ((long long)b * C + ch) * L;
-  const long long start = (long long)frame * hop - n / 2;
-  for (int t = threadIdx.x; t < n; t += blockDim.x) {
-    const long long sidx = start + t;
-    const double v = (sidx >= 0 && sidx < L) ? xs[sidx] * window[t] : 0.0;
-    buf[t] = cmake(v, 0.0);
+  c128 *buf = gscratch ? gscratch + (long long)blockIdx.x * lds_len : reinterpret_cast<c128 *>(smem);
+  const long long total = (long long)n_frames * C * B;
+  const long long first = gscratch ? blockIdx.x
+                                   : ((long long)blockIdx.z * C + blockIdx.y) * n_frames + blockIdx.x;
+  const long long step = gscratch ? gridDim.x : total;
+  for (long long sgm = first; sgm < total; sgm += step) {
+    const int frame = (int)(sgm % n_frames);
+    const long long bc = sgm / n_frames;  // b * C + ch
+    const double *xs = x + bc * L;
+    const long long start = (long long)frame * hop - n / 2;
+    __syncthreads();  // (the previous segment's reads of buf are done)
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+      const long long sidx = start + t;
+      const double v = (sidx >= 0 && sidx < L) ? xs[sidx] * window[t] : 0.0;
+      buf[t] = cmake(v, 0.0);
+    }
+    dft_any(buf, n, log2n, m, log2m, bhat, -1.0);
+    const int F = n / 2 + 1;
+    c128 *out = Z + bc * F * n_frames + frame;
+    for (int k = threadIdx.x; k < F; k += blockDim.x)
+      out[(long long)k * n_frames] = cmake(buf[k].x * scale, buf[k].y * scale);
   }
-  dft_any(buf, n, log2n, m, log2m, bhat, -1.0);
-  const int F = n / 2 + 1;
-  c128 *out = Z + ((long long)b * C + ch) * F * n_frames + frame;
-  for (int k = threadIdx.x; k < F; k += blockDim.x)
-    out[(long long)k * n_frames] = cmake(buf[k].x * scale, buf[k].y * scale);
 }
 
-// grid: (n_frames, C, B).  Z (B, C, n/2+1, n_frames) -> seg (B, C, n_frames, n) real, each segment
+// grid as k_stft.  Z (B, C, n/2+1, n_frames) -> seg (B, C, n_frames, n) real, each segment
 // = irfft(frame) * window * gain
 __global__ __launch_bounds__(256) void k_istft_segments(const c128 *__restrict__ Z,
                                                         double *__restrict__ seg, int n, int log2n,
                                                         int n_frames,
                                                         const double *__restrict__ window,
                                                         double gain, int m, int log2m,
-                                                        const c128 *__restrict__ bhat) {
+                                                        const c128 *__restrict__ bhat, int C, int B,
+                                                        c128 *gscratch, int lds_len) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  c128 *buf = reinterpret_cast<c128 *>(smem);
-  const int frame = blockIdx.x, ch = blockIdx.y, b = blockIdx.z;
-  const int C = gridDim.y, F = n / 2 + 1;
-  const c128 *in = Z + ((long long)b * C + ch) * F * n_frames + frame;
-  for (int k = threadIdx.x; k < n; k += blockDim.x) {
-    c128 v;
-    if (k < F) {
-      v = in[(long long)k * n_frames];
-      // irfft ignores the imaginary part of DC and (even n) of Nyquist
-      if (k == 0 || (2 * k == n)) v.y = 0.0;
-    } else {
-      v = cconj(in[(long long)(n - k) * n_frames]);
+  c128 *buf = gscratch ? gscratch + (long long)blockIdx.x * lds_len : reinterpret_cast<c128 *>(smem);
+  const int F = n / 2 + 1;
+  const long long total = (long long)n_frames * C * B;
+  const long long first = gscratch ? blockIdx.x
+                                   : ((long long)blockIdx.z * C + blockIdx.y) * n_frames + blockIdx.x;
+  const long long step = gscratch ? gridDim.x : total;
+  for (long long sgm = first; sgm < total; sgm += step) {
+    const int frame = (int)(sgm % n_frames);
+    const long long bc = sgm / n_frames;
+    const c128 *in = Z + bc * F * n_frames + frame;
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+      c128 v;
+      if (k < F) {
+        v = in[(long long)k * n_frames];
+        // irfft ignores the imaginary part of DC and (even n) of Nyquist
+        if (k == 0 || (2 * k == n)) v.y = 0.0;
+      } else {
+        v = cconj(in[(long long)(n - k) * n_frames]);
+      }
+      buf[k] = v;
     }
-    buf[k] = v;
+    dft_any(buf, n, log2n, m, log2m, bhat, 1.0);
+    double *out = seg + (bc * n_frames + frame) * n;
+    const double g = gain / (double)n;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) out[t] = buf[t].x * g * window[t];
   }
-  dft_any(buf, n, log2n, m, log2m, bhat, 1.0);
-  double *out = seg + (((long long)b * C + ch) * n_frames + frame) * n;
-  const double g = gain / (double)n;
-  for (int t = threadIdx.x; t < n; t += blockDim.x) out[t] = buf[t].x * g * window[t];
 }
 
 // x[b, c, s] = sum_k seg[k][s + n/2 - k hop] / sum_k window^2[...] (where > 1e-10)
@@ -199,43 +222,53 @@ static int allow_lds(const void *kernel, int len) {
   return e == hipSuccess ? SSSPY_OK : fail(SSSPY_ERR_HIP, hipGetErrorString(e));
 }
 
-// transform plan of a segment length: direct radix-2 (m = 0) or Bluestein of length m
+// transform plan of a segment length: direct radix-2 (m = 0) or Bluestein of length m; in LDS up to
+// STFT_MAX_LEN points, in a workgroup-private slice of the workspace up to STFT_GLOBAL_MAX
+constexpr int STFT_GLOBAL_MAX = 65536, STFT_GLOBAL_BLOCKS = 256;
 struct FftPlan {
   int log2n, m, log2m, lds_len;
-  bool ok;
+  bool ok, global;
 };
 static FftPlan fft_plan(int n) {
-  FftPlan p = {ilog2_exact(n), 0, 0, n, false};
+  FftPlan p = {ilog2_exact(n), 0, 0, n, false, false};
   if (n < 2) return p;
-  if (p.log2n >= 1) {
-    p.ok = n <= STFT_MAX_LEN;
-    return p;
+  if (p.log2n < 1) {
+    int m = 1, lg = 0;
+    while (m < 2 * n - 1) {
+      m <<= 1;
+      ++lg;
+    }
+    p.log2n = 0;
+    p.m = m;
+    p.log2m = lg;
+    p.lds_len = m;
   }
-  int m = 1, lg = 0;
-  while (m < 2 * n - 1) {
-    m <<= 1;
-    ++lg;
-  }
-  p.log2n = 0;
-  p.m = m;
-  p.log2m = lg;
-  p.lds_len = m;
-  p.ok = m <= STFT_MAX_LEN;
+  p.global = p.lds_len > STFT_MAX_LEN;
+  p.ok = p.lds_len <= STFT_GLOBAL_MAX;
   return p;
+}
+// workspace: the chirp's spectrum (m), then the workgroups' slices (STFT_GLOBAL_BLOCKS x lds_len)
+static size_t plan_chirp_bytes(const FftPlan &p) { return (size_t)p.m * sizeof(c128); }
+static size_t plan_scratch_bytes(const FftPlan &p) {
+  return p.global ? (size_t)STFT_GLOBAL_BLOCKS * p.lds_len * sizeof(c128) : 0;
 }
 
 size_t ssspy_stft_workspace_bytes(int n_fft) {
   const FftPlan p = fft_plan(n_fft);
-  return p.ok && p.m ? (size_t)p.m * sizeof(c128) : 0;
+  return p.ok ? plan_chirp_bytes(p) + plan_scratch_bytes(p) : 0;
 }
 
 static int prepare_chirp(const FftPlan &p, int n, double sign, void *workspace, hipStream_t st) {
-  if (!p.m) return SSSPY_OK;
+  if (!p.m && !p.global) return SSSPY_OK;
   SSSPY_REQUIRE(workspace, "stft: this n_fft needs ssspy_stft_workspace_bytes() of workspace");
-  int rc = allow_lds((const void *)k_bluestein_chirp, p.m);
+  if (!p.m) return SSSPY_OK;
+  c128 *gbuf = nullptr;  // (the first workgroup slice serves the one-block chirp kernel)
+  if (p.global) gbuf = (c128 *)((char *)workspace + plan_chirp_bytes(p));
+  int rc = p.global ? SSSPY_OK : allow_lds((const void *)k_bluestein_chirp, p.m);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_bluestein_chirp, dim3(1), dim3(256), (size_t)p.m * sizeof(c128), st,
-                     (c128 *)workspace, n, p.m, p.log2m, sign);
+  hipLaunchKernelGGL(k_bluestein_chirp, dim3(1), dim3(256),
+                     p.global ? 0 : (size_t)p.m * sizeof(c128), st, (c128 *)workspace, n, p.m,
+                     p.log2m, sign, gbuf);
   return check_launch("k_bluestein_chirp");
 }
 
@@ -256,16 +289,22 @@ int ssspy_stft(const double *x, void *Z, const double *window, double window_sum
   const FftPlan p = fft_plan(n_fft);
   if (!p.ok)
     return fail(SSSPY_ERR_UNSUPPORTED,
-                "stft: n_fft must be a power of two <= 8192 or any length in [2, 4096]");
+                "stft: n_fft must be a power of two <= 65536 or any length in [2, 32768]");
   hipStream_t st = as_stream(stream);
   int rc0 = prepare_chirp(p, n_fft, -1.0, workspace, st);
   if (rc0) return rc0;
-  rc0 = allow_lds((const void *)k_stft, p.lds_len);
-  if (rc0) return rc0;
+  if (!p.global) {
+    rc0 = allow_lds((const void *)k_stft, p.lds_len);
+    if (rc0) return rc0;
+  }
   const int n_frames = ssspy_stft_frames(n_samples, n_fft, hop);
-  hipLaunchKernelGGL(k_stft, dim3(n_frames, C, B), dim3(256), (size_t)p.lds_len * sizeof(c128), st,
-                     x, (c128 *)Z, n_samples, n_fft, p.log2n, hop, n_frames, window,
-                     1.0 / window_sum, p.m, p.log2m, (const c128 *)workspace);
+  const long long total = (long long)n_frames * C * B;
+  c128 *gscratch = p.global ? (c128 *)((char *)workspace + plan_chirp_bytes(p)) : nullptr;
+  const dim3 grid = p.global ? dim3((unsigned)(total < STFT_GLOBAL_BLOCKS ? total : STFT_GLOBAL_BLOCKS))
+                             : dim3(n_frames, C, B);
+  hipLaunchKernelGGL(k_stft, grid, dim3(256), p.global ? 0 : (size_t)p.lds_len * sizeof(c128), st, x,
+                     (c128 *)Z, n_samples, n_fft, p.log2n, hop, n_frames, window, 1.0 / window_sum,
+                     p.m, p.log2m, (const c128 *)workspace, C, B, gscratch, p.lds_len);
   return check_launch("k_stft");
 }
 
@@ -283,15 +322,22 @@ int ssspy_istft(const void *Z, double *x, const double *window, double window_su
   const FftPlan p = fft_plan(n_fft);
   if (!p.ok)
     return fail(SSSPY_ERR_UNSUPPORTED,
-                "istft: n_fft must be a power of two <= 8192 or any length in [2, 4096]");
+                "istft: n_fft must be a power of two <= 65536 or any length in [2, 32768]");
   hipStream_t st = as_stream(stream);
   int rc0 = prepare_chirp(p, n_fft, 1.0, workspace, st);
   if (rc0) return rc0;
-  rc0 = allow_lds((const void *)k_istft_segments, p.lds_len);
-  if (rc0) return rc0;
-  hipLaunchKernelGGL(k_istft_segments, dim3(n_frames, C, B), dim3(256),
-                     (size_t)p.lds_len * sizeof(c128), st, (const c128 *)Z, segments, n_fft, p.log2n,
-                     n_frames, window, window_sum, p.m, p.log2m, (const c128 *)workspace);
+  if (!p.global) {
+    rc0 = allow_lds((const void *)k_istft_segments, p.lds_len);
+    if (rc0) return rc0;
+  }
+  const long long total = (long long)n_frames * C * B;
+  c128 *gscratch = p.global ? (c128 *)((char *)workspace + plan_chirp_bytes(p)) : nullptr;
+  const dim3 grid = p.global ? dim3((unsigned)(total < STFT_GLOBAL_BLOCKS ? total : STFT_GLOBAL_BLOCKS))
+                             : dim3(n_frames, C, B);
+  hipLaunchKernelGGL(k_istft_segments, grid, dim3(256),
+                     p.global ? 0 : (size_t)p.lds_len * sizeof(c128), st, (const c128 *)Z, segments,
+                     n_fft, p.log2n, n_frames, window, window_sum, p.m, p.log2m,
+                     (const c128 *)workspace, C, B, gscratch, p.lds_len);
   int rc = check_launch("k_istft_segments");
   if (rc) return rc;
   const long long L_out = ssspy_istft_samples(n_frames, n_fft, hop);

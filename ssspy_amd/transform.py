@@ -8,8 +8,9 @@ reference's workflow uses either side of a separator (``window="hann"``, ``bound
 
 Both take NumPy arrays or device tensors; with ``device_output=True`` the result stays in HBM, so
 a separator can consume the spectrogram (``_bind_input`` accepts device tensors) and hand its
-output to ``istft`` without the spectrogram crossing PCIe.  ``n_fft``: a power of two <= 8192 or any
-length in [2, 4096] (Bluestein); ``window``: an array, or what ``scipy.signal.get_window`` takes for
+output to ``istft`` without the spectrogram crossing PCIe.  ``n_fft``: a power of two <= 65536 or any
+length in [2, 32768] (Bluestein; up to 8192 points in LDS, longer transforms on a workspace in HBM);
+``window``: an array, or what ``scipy.signal.get_window`` takes for
 its periodic windows (a name, or a ``(name, parameter)`` tuple).
 """
 
