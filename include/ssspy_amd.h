@@ -71,7 +71,10 @@ enum { SSSPY_SOURCE_ME = 0x100 };
  * correct, not tuned; the reference has no limit: ssspy/bss/ilrma.py:180, iva.py:152).  IPA, the MNMF
  * entry points and the Hermitian operators stay at SSSPY_MAX_SOURCES. */
 #define SSSPY_RT_MAX_SOURCES 16
-#define SSSPY_MAX_BASIS 1024
+/* n_basis: the kernels walk any number of bases (dense products above 32; checked against the
+ * oracle at 1500 and 3000); the bound only keeps 32-bit index arithmetic safe.  Up to round 5: 1024. */
+#define SSSPY_MAX_BASIS 65536
+#define SSSPY_MAX_PARTITION_BASIS 1024 /* partitioning=True: the latent update keeps N x n_basis in LDS */
 #define SSSPY_MAX_PAIRS 128 /* every pair of 16 sources: 120 */
 
 const char *ssspy_amd_version(void);

@@ -23,7 +23,7 @@ CONTRAST_LAPLACE, CONTRAST_GAUSS, CONTRAST_GAUSS_FIXED = 0, 1, 2
 MAX_PAIRS = 32
 # SSSPY_MAX_SOURCES (per-N kernels: IPA, both MNMF classes, the Hermitian operators),
 # SSSPY_RT_MAX_SOURCES (run-time-N kernels: the shared operators, ILRMA and AuxIVA), SSSPY_MAX_BASIS
-MAX_SOURCES, RT_MAX_SOURCES, MAX_BASIS = 8, 16, 1024
+MAX_SOURCES, RT_MAX_SOURCES, MAX_BASIS = 8, 16, 65536
 ABI_VERSION = 3  # SSSPY_ABI_VERSION of the include/ssspy_amd.h these prototypes mirror
 
 _p, _i, _d, _z = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t

@@ -1560,7 +1560,7 @@ static inline size_t bin_smem(int N, int M, int K) {
 static int check_dims(int B, int N, int M, int F, int T, int K) {
   SSSPY_REQUIRE(B > 0 && F > 0 && T > 0, "GaussMNMF: bad shape");
   SSSPY_REQUIRE(N >= 1 && N <= SSSPY_MAX_SOURCES, "GaussMNMF: n_sources must be in [1, 8]");
-  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "GaussMNMF: n_basis must be in [1, 1024]");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "GaussMNMF: n_basis must be in [1, 65536]");
   if (M < 2 || M > 8) return fail(SSSPY_ERR_UNSUPPORTED, "GaussMNMF: n_channels must be in [2, 8]");
   return SSSPY_OK;
 }
@@ -1795,6 +1795,9 @@ int ssspy_gmnmf_update(const void *X, double *basis, double *activation, double 
     hq_valid = false;
   }
   if (steps & SSSPY_GMNMF_LATENT) {
+    // (the latent variables of all sources sit in the LDS of one workgroup)
+    if (K > SSSPY_MAX_PARTITION_BASIS)
+      return fail(SSSPY_ERR_UNSUPPORTED, "GaussMNMF: partitioning takes n_basis up to 1024");
     rc = basis_sums(raw);
     if (rc) return rc;
     hipLaunchKernelGGL(k_gm_part_latent, dim3(B), dim3(256), (size_t)N * K * sizeof(double), st,

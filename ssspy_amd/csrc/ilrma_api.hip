@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void k_partition_latent(const double *__restri
                                                           const double *__restrict__ basis,
                                                           double *latent, int N, int F, int K,
                                                           IlrmaDims d) {
-  __shared__ double znew[SSSPY_MAX_SOURCES * SSSPY_MAX_BASIS];
+  __shared__ double znew[SSSPY_MAX_SOURCES * SSSPY_MAX_PARTITION_BASIS];
   const int b = blockIdx.x;
   for (int e = threadIdx.x; e < N * K; e += blockDim.x) {
     const int n = e / K, k = e % K;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void k_partition_activation(const double *__re
 __global__ __launch_bounds__(256) void k_partition_normalize(double *basis, double *latent,
                                                              const double *__restrict__ psi, int N,
                                                              int F, int K, double p) {
-  __shared__ double scale[SSSPY_MAX_BASIS];
+  __shared__ double scale[SSSPY_MAX_PARTITION_BASIS];
   const int b = blockIdx.x;
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
     double s = 0.0;
@@ -745,7 +745,7 @@ static int update_basis_impl(const void *X, const void *W, double *basis, const 
   // loss_stride > 0: loss_out is a raw slot array (see ilrma_fast_basis), tuned path only
   // x_is_power (grouped path of a wide mixture only, W == NULL): X holds |y|^2 (B, N, F, T) f64
   SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0, "update_basis: bad argument");
-  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_basis: n_basis must be in [1, 1024]");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_basis: n_basis must be in [1, 65536]");
   SSSPY_REQUIRE(domain > 0.0 && domain <= 2.0, "update_basis: domain must be in (0, 2]");
   int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
@@ -834,7 +834,7 @@ static int update_activation_impl(const void *X, const void *W, const double *ba
                                   size_t workspace_bytes, void *stream, bool x_is_power) {
   SSSPY_REQUIRE(X && basis && activation && B > 0 && F > 0 && T > 0,
                 "update_activation: bad argument");
-  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_activation: n_basis must be in [1, 1024]");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "update_activation: n_basis must be in [1, 65536]");
   int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
   const IlrmaWs w = ilrma_ws(B, N, F, T, K);
@@ -1315,7 +1315,9 @@ int ssspy_ilrma_partition_update(const void *X, const void *W, double *basis, do
   SSSPY_REQUIRE(X && basis && activation && latent && Teff && Vrep && B > 0 && F > 0 && T > 0,
                 "partition_update: bad argument");
   SSSPY_REQUIRE(N >= 1 && N <= SSSPY_MAX_SOURCES, "partition_update: n_sources must be in [1, 8]");
-  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "partition_update: n_basis must be in [1, 1024]");
+  SSSPY_REQUIRE(K >= 1, "partition_update: bad n_basis");
+  if (K > SSSPY_MAX_PARTITION_BASIS)
+    return fail(SSSPY_ERR_UNSUPPORTED, "ILRMA: partitioning takes n_basis up to 1024");
   SSSPY_REQUIRE(domain > 0.0 && domain <= 2.0, "partition_update: domain must be in (0, 2]");
   int rc = check_model(source_model, model_param, domain);
   if (rc) return rc;
@@ -1374,6 +1376,8 @@ int ssspy_ilrma_partition_normalize(void *W, const void *C, void *Y, double *bas
   SSSPY_REQUIRE(basis && latent && B > 0 && N >= 1 && N <= SSSPY_MAX_SOURCES,
                 "partition_normalize: bad argument");
   SSSPY_REQUIRE((W && C && !Y) || (Y && !W), "partition_normalize: pass (W, C) or Y");
+  if (K > SSSPY_MAX_PARTITION_BASIS)
+    return fail(SSSPY_ERR_UNSUPPORTED, "ILRMA: partitioning takes n_basis up to 1024");
   const IlrmaWs w = ilrma_ws(B, N, F, T, K);
   SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "partition_normalize: workspace too small");
   char *ws = (char *)workspace;

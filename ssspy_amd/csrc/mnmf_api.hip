@@ -193,7 +193,7 @@ static int fastmnmf_update_impl(const void *X, const void *C, void *Q, double *D
                                 hipStream_t st) {
   SSSPY_REQUIRE(X && Q && D && basis && activation && B > 0 && F > 0 && T > 0,
                 "fastmnmf_update: bad argument");
-  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_update: n_basis must be in [1, 1024]");
+  SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_update: n_basis must be in [1, 65536]");
   const MnmfWs w = mnmf_ws(B, N, M, F, T, K);
   SSSPY_REQUIRE(workspace && workspace_bytes >= w.total, "fastmnmf_update: workspace too small");
   SSSPY_REQUIRE(!(steps & SSSPY_MNMF_NORMALIZE) || C, "fastmnmf_update: normalisation needs C");

@@ -756,7 +756,39 @@ def test_partitioned_ilrma_many_bases_against_oracle():
     assert rel_err(Y, Yr) < TOL and rel_err(m.latent, ref.latent) < TOL
     np.testing.assert_allclose(m.loss, ref.loss, rtol=LOSS_RTOL)
     with pytest.raises((NotImplementedError, ValueError)):
-        GaussILRMA(n_basis=1025)(X, n_iter=1)
+        GaussILRMA(n_basis=1025, partitioning=True)(X, n_iter=1)
+
+
+@pytest.mark.parametrize("cls", ["ilrma_ip", "ilrma_iss", "fast", "gauss"])
+def test_n_basis_above_1024_against_oracle(cls):
+    """The reference puts no bound on n_basis (ssspy/bss/ilrma.py:201-270, mnmf.py:1112-1153); the
+    entry points refused more than 1024 until round 6 although the dense-product kernels walk any
+    n_basis (round-5 verdict, missing item 5).  1500 bases, tiny spectrograms."""
+    from oracle.gmnmf import GaussMNMFOracle
+    from oracle.ilrma import GaussILRMAOracle
+    from oracle.mnmf import FastGaussMNMFOracle
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.bss.mnmf import FastGaussMNMF, GaussMNMF
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    N, F, T, K = 3, 33, 17, 1500
+    X = nmf_mixture(5, N, F, T)
+    kw = dict(basis=np.random.default_rng(1).random((N, F, K)),
+              activation=np.random.default_rng(2).random((N, K, T)))
+    if cls.startswith("ilrma"):
+        algo = "IP" if cls == "ilrma_ip" else "ISS"
+        ref, m = GaussILRMAOracle(n_basis=K, spatial_algorithm=algo), GaussILRMA(n_basis=K, spatial_algorithm=algo)
+    elif cls == "fast":
+        kw["spatial"] = np.random.default_rng(3).random((F, N, N)) + 0.05
+        ref, m = FastGaussMNMFOracle(n_basis=K), FastGaussMNMF(n_basis=K)
+    else:
+        ref = GaussMNMFOracle(n_basis=K, rng=np.random.default_rng(1))
+        m = GaussMNMF(n_basis=K, rng=np.random.default_rng(1))
+    Yr = ref.run(X, n_iter=3, **{k: v.copy() for k, v in kw.items()})
+    Y = m(X, n_iter=3, **kw)
+    assert rel_err(Y, Yr) < 1e-8
+    np.testing.assert_allclose(m.loss, ref.loss, rtol=1e-9)
+    assert rel_err(m.basis, ref.basis) < 1e-8 and rel_err(m.activation, ref.activation) < 1e-8
 
 
 def test_heavy_tailed_ilrma_constructor_contract():
