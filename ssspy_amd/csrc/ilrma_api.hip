@@ -537,6 +537,10 @@ __global__ __launch_bounds__(256) void k_partition_normalize(double *basis, doub
 // (The previous thread-per-frame version fetched the basis entries one scalar load at a time:
 // 0.31 ms for 0.54 GB of output.)
 // (Ypow: |y|^2 handed in instead of y)
+// GAUSS2: the Gauss model at domain 2 without the (a, b) mode -- varphi = 1 / R and nothing else
+// compiled in (the general body carries the inlined pow() of every model and domain: 17 000 lines of
+// ISA around a 300-line hot path)
+template <bool GAUSS2 = false>
 __global__ __launch_bounds__(256) void k_ilrma_iss_weight(const c128 *__restrict__ Y,
                                                           const double *__restrict__ Ypow,
                                                           const double *__restrict__ basis,
@@ -567,13 +571,15 @@ __global__ __launch_bounds__(256) void k_ilrma_iss_weight(const c128 *__restrict
     const int kk = 4 * ks + q;
     ta[ks] = kk < K ? Tn[(long long)abin * K + kk] : 0.0;
   }
-  const bool need_y = d.model != SSSPY_SOURCE_GAUSS || bout != nullptr;
-  // two frame tiles per pass: their loads and MFMA chains are independent
-  for (int j0 = j_begin; j0 < j_end; j0 += 32) {
-    int jc[2];
-    double4_t R[2];
+  const bool need_y = !GAUSS2 && (d.model != SSSPY_SOURCE_GAUSS || bout != nullptr);
+  // two frame tiles per pass: their loads and MFMA chains are independent (four: slower, 431 us
+  // against 278 at 16 mixtures of 8 sources)
+  constexpr int U = 2;
+  for (int j0 = j_begin; j0 < j_end; j0 += 16 * U) {
+    int jc[U];
+    double4_t R[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
       jc[u] = min(j0 + 16 * u + c, T - 1);
       R[u] = double4_t{0.0, 0.0, 0.0, 0.0};
     }
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(256) void k_ilrma_iss_weight(const c128 *__restrict
       if (ks < ksteps) {
         const int kk = 4 * ks + q;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
           const double vb = kk < K ? Vn[(long long)kk * T + jc[u]] : 0.0;
           R[u] = mfma_f64(ta[ks], vb, R[u]);
         }
@@ -591,27 +597,31 @@ __global__ __launch_bounds__(256) void k_ilrma_iss_weight(const c128 *__restrict
       const int kk = 4 * ks + q;
       const double av = kk < K ? Tn[(long long)abin * K + kk] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < U; ++u) {
         const double vb = kk < K ? Vn[(long long)kk * T + jc[u]] : 0.0;
         R[u] = mfma_f64(av, vb, R[u]);
       }
     }
     // D: bin i0 + q + 4 r, frame j0 + 16 u + c
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int bin = i0 + q + 4 * r, jf = j0 + 16 * u + c;
         if (bin < F && jf < j_end) {
           const long long e = (row0 + bin) * T + jf;
-          const double P = need_y ? (Ypow ? Ypow[e] : cabs2(Y[e])) : 0.0;
-          if (bout) {
-            double wa, wb;
-            mm_weights(P, R[u][r], d, true, wa, wb);
-            varphi[e] = wa;
-            bout[e] = wb;
+          if constexpr (GAUSS2) {
+            varphi[e] = recip_weight(R[u][r]);
           } else {
-            varphi[e] = spatial_weight(P, R[u][r], d);
+            const double P = need_y ? (Ypow ? Ypow[e] : cabs2(Y[e])) : 0.0;
+            if (bout) {
+              double wa, wb;
+              mm_weights(P, R[u][r], d, true, wa, wb);
+              varphi[e] = wa;
+              bout[e] = wb;
+            } else {
+              varphi[e] = spatial_weight(P, R[u][r], d);
+            }
           }
         }
       }
@@ -943,8 +953,14 @@ static int wcov_into(const void *X, const void *W, const double *basis, const do
                   "spectrogram");
     const int chunks = iss_weight_chunks(d.B, N, d.F, d.T);
     dim3 grid(((d.F + 63) / 64) * chunks, N, d.B), block(256);
-    hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, st, ypow ? nullptr : (const c128 *)Y,
-                       ypow ? (const double *)Y : nullptr, basis, activation, wbuf, N, d, chunks);
+    if (d.model == SSSPY_SOURCE_GAUSS && d.p == 2.0)
+      hipLaunchKernelGGL(k_ilrma_iss_weight<true>, grid, block, 0, st, (const c128 *)nullptr,
+                         (const double *)nullptr, basis, activation, wbuf, N, d, chunks,
+                         (double *)nullptr);
+    else
+      hipLaunchKernelGGL(k_ilrma_iss_weight<false>, grid, block, 0, st,
+                         ypow ? nullptr : (const c128 *)Y, ypow ? (const double *)Y : nullptr, basis,
+                         activation, wbuf, N, d, chunks, (double *)nullptr);
     int rc = check_launch("k_ilrma_iss_weight");
     if (rc) return rc;
     return rt_covariance(X, X, wbuf, SSSPY_WEIGHT_BIN_FRAME, U, d.B, N, N, d.F, d.T, st);
@@ -966,8 +982,14 @@ static int wcov_into(const void *X, const void *W, const double *basis, const do
     if (d.model == SSSPY_SOURCE_GAUSS || Y) {
       const int chunks = iss_weight_chunks(d.B, N, d.F, d.T);
       dim3 grid(((d.F + 63) / 64) * chunks, N, d.B), block(256);
-      hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, st, ypow ? nullptr : (const c128 *)Y,
-                         ypow ? (const double *)Y : nullptr, basis, activation, wbuf, N, d, chunks);
+      if (d.model == SSSPY_SOURCE_GAUSS && d.p == 2.0)
+        hipLaunchKernelGGL(k_ilrma_iss_weight<true>, grid, block, 0, st, (const c128 *)nullptr,
+                           (const double *)nullptr, basis, activation, wbuf, N, d, chunks,
+                           (double *)nullptr);
+      else
+        hipLaunchKernelGGL(k_ilrma_iss_weight<false>, grid, block, 0, st,
+                           ypow ? nullptr : (const c128 *)Y, ypow ? (const double *)Y : nullptr,
+                           basis, activation, wbuf, N, d, chunks, (double *)nullptr);
       return wide_weighted_cov(X, wbuf, SSSPY_WEIGHT_BIN_FRAME, U, d.B, N, N, d.F, d.T, st);
     }
   }
@@ -1071,8 +1093,14 @@ int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *act
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
   const int chunks = iss_weight_chunks(B, N, F, T);
   dim3 grid(((F + 63) / 64) * chunks, N, B), block(256);
-  hipLaunchKernelGGL(k_ilrma_iss_weight, grid, block, 0, as_stream(stream), (const c128 *)Y,
-                     (const double *)nullptr, basis, activation, varphi, N, d, chunks);
+  if (source_model == SSSPY_SOURCE_GAUSS && domain == 2.0)
+    hipLaunchKernelGGL(k_ilrma_iss_weight<true>, grid, block, 0, as_stream(stream),
+                       (const c128 *)nullptr, (const double *)nullptr, basis, activation, varphi, N,
+                       d, chunks, (double *)nullptr);
+  else
+    hipLaunchKernelGGL(k_ilrma_iss_weight<false>, grid, block, 0, as_stream(stream), (const c128 *)Y,
+                       (const double *)nullptr, basis, activation, varphi, N, d, chunks,
+                       (double *)nullptr);
   return check_launch("k_ilrma_iss_weight");
 }
 

@@ -44,9 +44,25 @@ __device__ __forceinline__ double mm_ratio_pow(double num, double den, const Ilr
   return (d.p == 2.0) ? sqrt(ratio) : pow(ratio, d.p / (d.p + 2.0));
 }
 
+// 1 / x by v_rcp_f64 + two Newton steps (~1 ulp: the recipe of fast_tiles.hpp's rcp_nr) where the
+// weight pass of the wide covariance forms one reciprocal per (source, bin, frame) -- the IEEE
+// divide is ~40 instructions, 68 of that pass's 278 us at 16 mixtures of 8 sources; zero, Inf, NaN
+// and the ends of the range keep the divide
+// (a call, so that the compiler cannot if-convert the rare branch into a divide for every lane)
+__device__ __noinline__ double recip_ieee(double x) { return 1.0 / x; }
+__device__ __forceinline__ double recip_weight(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  if (__builtin_expect(!(x > 1e-290 && x < 1e290), 0)) r = recip_ieee(x);
+  return r;
+}
+
 // varphi = 1 / R~ of the spatial update (ref: :1494-1498, :2915-2935, :3987-4011)
 __device__ __forceinline__ double spatial_weight(double P, double R, const IlrmaDims &d) {
-  if (d.model == SSSPY_SOURCE_GAUSS) return (d.p == 2.0) ? 1.0 / R : 1.0 / pow(R, 2.0 / d.p);
+  if (d.model == SSSPY_SOURCE_GAUSS) return (d.p == 2.0) ? recip_weight(R) : 1.0 / pow(R, 2.0 / d.p);
   if (d.model == SSSPY_SOURCE_T) {
     const double w = d.mparam / (d.mparam + 2.0);
     const double r2p = (d.p == 2.0) ? R : pow(R, 2.0 / d.p);
