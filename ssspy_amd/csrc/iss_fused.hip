@@ -172,25 +172,26 @@ __device__ __forceinline__ void iss_sweeps(c128 (&y)[N][FPT], const double (&phi
     // The coefficient lane is the serial section of a sweep (every thread waits for it at the
     // readlanes below): v_rcp_f64 / v_rsq_f64 + two Newton steps (~1 ulp, benchmarks/micro/
     // rcp_precision.hip) instead of two IEEE divides and a square root (~90 dependent instructions).
-    double rd = __builtin_amdgcn_rcp(den);
-    double e1 = fma(-den, rd, 1.0);
-    rd = fma(rd, e1, rd);
+    // (den = 0, Inf or NaN, or so small that 1 / den overflows: the hardware seeds are what the
+    //  divide and the square root return there -- Inf, 0, NaN -- and the Newton steps would turn
+    //  them into NaN, so those lanes keep the seeds.  Round 6: the branch that called the IEEE
+    //  divide and sqrt instead sat in this serial section with its temporaries: hipcc spilled around
+    //  it and reloaded right here, a round trip through scratch per sweep.)
+    const bool special = !(den > 8.9e-308) || !(den < 1.7976931348623157e308);
+    const double rd0 = __builtin_amdgcn_rcp(den);
+    double e1 = fma(-den, rd0, 1.0);
+    double rd = fma(rd0, e1, rd0);
     e1 = fma(-den, rd, 1.0);
     rd = fma(rd, e1, rd);
-    double rs = __builtin_amdgcn_rsq(den);
-    double h = 0.5 * den * rs;
-    double e2 = fma(-h, rs, 0.5);
-    rs = fma(rs, e2, rs);
+    const double rs0 = __builtin_amdgcn_rsq(den);
+    double h = 0.5 * den * rs0;
+    double e2 = fma(-h, rs0, 0.5);
+    double rs = fma(rs0, e2, rs0);
     h = 0.5 * den * rs;
     e2 = fma(-h, rs, 0.5);
     rs = fma(rs, e2, rs);
-    // (den = 0, Inf or NaN, or so small that 1 / den overflows -- the reciprocal seed is Inf and the
-    //  Newton step turns it into NaN: keep what the divide and the square root return)
-    const bool special = !(den > 8.9e-308) || !(den < 1.7976931348623157e308);
-    if (special) {
-      rd = 1.0 / den;
-      rs = 1.0 / sqrt(den);
-    }
+    rd = special ? rd0 : rd;
+    rs = special ? rs0 : rs;
     const double vx = lane == n ? 1.0 - rs : t0 * invT * rd;
     const double vy = lane == n ? 0.0 : t1 * invT * rd;
 #endif
