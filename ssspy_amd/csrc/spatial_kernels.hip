@@ -417,6 +417,20 @@ __global__ __launch_bounds__(256) void k_scale_filter_row(c128 *W, const double 
 // and the covariance streamed still 325: 1.1 resp. 0.56 ms for 16 x 1025 bins; this one 0.26 ms).  The covariance entries are read where they are used: the G lanes of a bin
 // ask for the same address (one request).  (Four lanes per bin for N <= 4 at one mixture was tried
 // for latency: 115.5 -> 114.3 us per iteration, not kept.)
+// 1 / a by v_rcp_f64 + two Newton steps on |a|^2 (~1 ulp; the latency form k_ip1_small has used it
+// since round 3): the kernel below is a chain of dependent pivots, and the IEEE divide is ~12 of
+// them per reciprocal -- 80 divides per bin at 8 sources before round 6 (every pivot inverted twice,
+// 2 N divides by the normalisation)
+__device__ __forceinline__ c128 crecip_rows(c128 a) {
+  const double m2 = fma(a.x, a.x, a.y * a.y);
+  double r = __builtin_amdgcn_rcp(m2);
+  double e = fma(-m2, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-m2, r, 1.0);
+  r = fma(r, e, r);
+  return cmake(a.x * r, -a.y * r);
+}
+
 template <int N, int G>
 __global__ __launch_bounds__(256) void k_ip1_rows(c128 *W, const c128 *__restrict__ U,
                                                   long long nbins, int floor_kind, double eps,
@@ -447,6 +461,7 @@ __global__ __launch_bounds__(256) void k_ip1_rows(c128 *W, const c128 *__restric
     c128 rhs = cmake(r == n ? 1.0 : 0.0, 0.0);
     int order = row ? -1 : N;  // elimination step at which my row became the pivot row
     int plane[N];              // lane of the group that owns pivot k (uniform within the group)
+    c128 pinv[N];              // 1 / pivot k, reused by the back substitution
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       const bool cand = order < 0;
@@ -469,9 +484,9 @@ __global__ __launch_bounds__(256) void k_ip1_rows(c128 *W, const c128 *__restric
       const c128 prhs = cmake(__shfl(rhs.x, bl, G), __shfl(rhs.y, bl, G));
       const c128 piv = prow[k];
       ok = ok && (piv.x != 0.0 || piv.y != 0.0);
-      const c128 inv = crecip(piv);
+      pinv[k] = crecip_rows(piv);
       if (order < 0) {  // still unused: eliminate column k
-        const c128 f = cmul(a[k], inv);
+        const c128 f = cmul(a[k], pinv[k]);
 #pragma unroll
         for (int c = k + 1; c < N; ++c) cfms(a[c], f, prow[c]);
         cfms(rhs, f, prhs);
@@ -481,7 +496,7 @@ __global__ __launch_bounds__(256) void k_ip1_rows(c128 *W, const c128 *__restric
 #pragma unroll
     for (int k = N - 1; k >= 0; --k) {
       // the owner of pivot k has folded the unknowns above k into its right-hand side already
-      const c128 mine = cmul(rhs, crecip(a[k]));
+      const c128 mine = cmul(rhs, pinv[k]);
       w[k] = cmake(__shfl(mine.x, plane[k], G), __shfl(mine.y, plane[k], G));
       if (order < k) cfms(rhs, a[k], w[k]);
     }
@@ -501,8 +516,9 @@ __global__ __launch_bounds__(256) void k_ip1_rows(c128 *W, const c128 *__restric
     qf = qf < 0.0 ? 0.0 : qf;  // np.maximum(., 0): NaN propagates
     const double d = apply_floor(sqrt(qf), floor_kind, eps);
     if (r == n) {
+      const double dinv = 1.0 / d;
 #pragma unroll
-      for (int c = 0; c < N; ++c) Wr[c] = cmake(w[c].x / d, -w[c].y / d);
+      for (int c = 0; c < N; ++c) Wr[c] = cmake(w[c].x * dinv, -w[c].y * dinv);
     }
   }
   if (live && row) {
