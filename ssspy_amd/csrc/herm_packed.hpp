@@ -6,6 +6,7 @@
 #pragma once
 
 #include "common.hpp"
+#include "hermitian.hpp"
 
 namespace ssspy {
 
@@ -205,19 +206,11 @@ __device__ __forceinline__ void hp_jacobi_eigh(HermP<M> &A, c128 (&P)[M][M]) {
     for (int p = 0; p < M - 1; ++p)
 #pragma unroll
       for (int qq = p + 1; qq < M; ++qq) {
-        const c128 apq = A.o[tri<M>(p, qq)];
-        const double mag2 = cabs2(apq);
-        const double mag = sqrt(mag2);
-        const bool tiny = mag2 < 1e-300;
-        const double inv = tiny ? 0.0 : 1.0 / mag;
-        const c128 u = tiny ? cmake(1.0, 0.0) : cmake(apq.x * inv, apq.y * inv);
         const double app = A.d[p], aqq = A.d[qq];
-        const double tau = tiny ? 0.0 : (aqq - app) * 0.5 * inv;
-        const double t = tiny ? 0.0 : ((tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau)));
-        const double cs = 1.0 / sqrt(1.0 + t * t);
-        const double sn = t * cs;
-        const c128 su = cmake(sn * u.x, sn * u.y);    // s u
-        const c128 sub = cmake(sn * u.x, -sn * u.y);  // s conj(u)
+        const JacobiRot rot = jacobi_rot(A.o[tri<M>(p, qq)], app, aqq);
+        const double cs = rot.cs;
+        const c128 su = rot.su;           // s u
+        const c128 sub = cconj(rot.su);   // s conj(u)
 #pragma unroll
         for (int k = 0; k < M; ++k) {
           if (k != p && k != qq) {
@@ -230,8 +223,8 @@ __device__ __forceinline__ void hp_jacobi_eigh(HermP<M> &A, c128 (&P)[M][M]) {
             hp_set<M>(A, k, qq, nkq);
           }
         }
-        A.d[p] = app - t * mag;
-        A.d[qq] = aqq + t * mag;
+        A.d[p] = app - rot.tm;
+        A.d[qq] = aqq + rot.tm;
         A.o[tri<M>(p, qq)] = cmake(0.0, 0.0);
 #pragma unroll
         for (int k = 0; k < M; ++k) {
@@ -265,19 +258,11 @@ __device__ __forceinline__ void hp_jacobi_rows(HermP<M> &A, c128 (&W)[NR][M]) {
     for (int p = 0; p < M - 1; ++p)
 #pragma unroll
       for (int qq = p + 1; qq < M; ++qq) {
-        const c128 apq = A.o[tri<M>(p, qq)];
-        const double mag2 = cabs2(apq);
-        const double mag = sqrt(mag2);
-        const bool tiny = mag2 < 1e-300;
-        const double inv = tiny ? 0.0 : 1.0 / mag;
-        const c128 u = tiny ? cmake(1.0, 0.0) : cmake(apq.x * inv, apq.y * inv);
         const double app = A.d[p], aqq = A.d[qq];
-        const double tau = tiny ? 0.0 : (aqq - app) * 0.5 * inv;
-        const double t = tiny ? 0.0 : ((tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau)));
-        const double cs = 1.0 / sqrt(1.0 + t * t);
-        const double sn = t * cs;
-        const c128 su = cmake(sn * u.x, sn * u.y);    // s u
-        const c128 sub = cmake(sn * u.x, -sn * u.y);  // s conj(u)
+        const JacobiRot rot = jacobi_rot(A.o[tri<M>(p, qq)], app, aqq);
+        const double cs = rot.cs;
+        const c128 su = rot.su;           // s u
+        const c128 sub = cconj(rot.su);   // s conj(u)
 #pragma unroll
         for (int k = 0; k < M; ++k) {
           if (k != p && k != qq) {
@@ -290,8 +275,8 @@ __device__ __forceinline__ void hp_jacobi_rows(HermP<M> &A, c128 (&W)[NR][M]) {
             hp_set<M>(A, k, qq, nkq);
           }
         }
-        A.d[p] = app - t * mag;
-        A.d[qq] = aqq + t * mag;
+        A.d[p] = app - rot.tm;
+        A.d[qq] = aqq + rot.tm;
         A.o[tri<M>(p, qq)] = cmake(0.0, 0.0);
 #pragma unroll
         for (int r = 0; r < NR; ++r) {

@@ -9,6 +9,54 @@ namespace ssspy {
 
 // Hermitian eigen-decomposition by cyclic complex Jacobi rotations: A = P diag(lam) P^H, with lam
 // left on the diagonal of A.  Straight-line sweeps (no data-dependent branches inside a sweep);
+
+// The rotation that annihilates A[p][q] of a Hermitian matrix: cs, su = s u (u = apq / |apq|) and
+// tm = t |apq| (A_pp -= tm, A_qq += tm).  Round 6: reciprocals and square roots by v_rcp_f64 /
+// v_rsq_f64 + two Newton steps (~1 ulp; the 8-lane form herm_rows8.hpp has used them since round 5)
+// instead of three IEEE divides and two square roots -- ~170 of a rotation's dependent
+// instructions in kernels that are chains of rotations (IPA's LQPQM, the Hermitian operators).
+// Range: |apq|^2 is brought to [1/4, 2) by its exponent before the reciprocal square root and
+// scaled back, tau is capped at 1e150 (beyond it t < 5e-151: the rotation is the identity to any
+// rounding) -- no slow branch; |apq|^2 below 1e-300 (or NaN) leaves the pair alone.
+struct JacobiRot {
+  double cs, tm;
+  c128 su;
+};
+__device__ __forceinline__ double jr_rsq(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  double h = 0.5 * x * r;
+  double e = fma(-h, r, 0.5);
+  r = fma(r, e, r);
+  h = 0.5 * x * r;
+  e = fma(-h, r, 0.5);
+  return fma(r, e, r);
+}
+__device__ __forceinline__ double jr_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+__device__ __forceinline__ JacobiRot jacobi_rot(c128 apq, double app, double aqq) {
+  const double mag2 = cabs2(apq);
+  const bool tiny = !(mag2 >= 1e-300);
+  const int half = __builtin_amdgcn_frexp_exp(tiny ? 1.0 : mag2) >> 1;  // mag2 = s 4^half, s in [1/4, 2)
+  const double inv = tiny ? 0.0 : ldexp(jr_rsq(ldexp(mag2, -2 * half)), -half);  // 1 / |apq|
+  const double mag = tiny ? 0.0 : mag2 * inv;
+  const c128 u = tiny ? cmake(1.0, 0.0) : cmake(apq.x * inv, apq.y * inv);
+  const double tau = tiny ? 0.0 : (aqq - app) * 0.5 * inv;
+  const double atau = fmin(fabs(tau), 1e150);
+  const double w = fma(atau, atau, 1.0);
+  const double tabs = jr_rcp(fma(w, jr_rsq(w), atau));  // 1 / (|tau| + sqrt(1 + tau^2))
+  const double t = tiny ? 0.0 : (tau >= 0.0 ? tabs : -tabs);
+  JacobiRot r;
+  r.cs = jr_rsq(fma(t, t, 1.0));
+  const double sn = t * r.cs;
+  r.su = cmake(sn * u.x, sn * u.y);
+  r.tm = t * mag;
+  return r;
+}
 // the sweep loop ends when every lane of the wave has a negligible off-diagonal, at most 12 sweeps.
 template <int M>
 __device__ __forceinline__ void jacobi_eigh(c128 (&A)[M][M], c128 (&P)[M][M]) {
@@ -30,19 +78,11 @@ __device__ __forceinline__ void jacobi_eigh(c128 (&A)[M][M], c128 (&P)[M][M]) {
     for (int p = 0; p < M - 1; ++p)
 #pragma unroll
       for (int qq = p + 1; qq < M; ++qq) {
-        const c128 apq = A[p][qq];
-        const double mag2 = cabs2(apq);
-        const double mag = sqrt(mag2);
-        const bool tiny = mag2 < 1e-300;
-        const double inv = tiny ? 0.0 : 1.0 / mag;
-        const c128 u = tiny ? cmake(1.0, 0.0) : cmake(apq.x * inv, apq.y * inv);
         const double app = A[p][p].x, aqq = A[qq][qq].x;
-        const double tau = tiny ? 0.0 : (aqq - app) * 0.5 * inv;
-        const double t = tiny ? 0.0 : ((tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau)));
-        const double cs = 1.0 / sqrt(1.0 + t * t);
-        const double sn = t * cs;
-        const c128 su = cmake(sn * u.x, sn * u.y);    // s u
-        const c128 sub = cmake(sn * u.x, -sn * u.y);  // s conj(u)
+        const JacobiRot rot = jacobi_rot(A[p][qq], app, aqq);
+        const double cs = rot.cs;
+        const c128 su = rot.su;           // s u
+        const c128 sub = cconj(rot.su);   // s conj(u)
 #pragma unroll
         for (int k = 0; k < M; ++k) {
           if (k != p && k != qq) {
@@ -58,8 +98,8 @@ __device__ __forceinline__ void jacobi_eigh(c128 (&A)[M][M], c128 (&P)[M][M]) {
             A[qq][k] = cconj(nkq);
           }
         }
-        A[p][p] = cmake(app - t * mag, 0.0);
-        A[qq][qq] = cmake(aqq + t * mag, 0.0);
+        A[p][p] = cmake(app - rot.tm, 0.0);
+        A[qq][qq] = cmake(aqq + rot.tm, 0.0);
         A[p][qq] = cmake(0.0, 0.0);
         A[qq][p] = cmake(0.0, 0.0);
 #pragma unroll
@@ -100,19 +140,11 @@ __device__ __noinline__ void jacobi_eigh_rolled(c128 (&A)[M][M], c128 (&P)[M][M]
     for (int p = 0; p < M - 1; ++p)
 #pragma unroll 1
       for (int qq = p + 1; qq < M; ++qq) {
-        const c128 apq = A[p][qq];
-        const double mag2 = cabs2(apq);
-        const double mag = sqrt(mag2);
-        const bool tiny = mag2 < 1e-300;
-        const double inv = tiny ? 0.0 : 1.0 / mag;
-        const c128 u = tiny ? cmake(1.0, 0.0) : cmake(apq.x * inv, apq.y * inv);
         const double app = A[p][p].x, aqq = A[qq][qq].x;
-        const double tau = tiny ? 0.0 : (aqq - app) * 0.5 * inv;
-        const double t = tiny ? 0.0 : ((tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau)));
-        const double cs = 1.0 / sqrt(1.0 + t * t);
-        const double sn = t * cs;
-        const c128 su = cmake(sn * u.x, sn * u.y);    // s u
-        const c128 sub = cmake(sn * u.x, -sn * u.y);  // s conj(u)
+        const JacobiRot rot = jacobi_rot(A[p][qq], app, aqq);
+        const double cs = rot.cs;
+        const c128 su = rot.su;           // s u
+        const c128 sub = cconj(rot.su);   // s conj(u)
 #pragma unroll 1
         for (int k = 0; k < M; ++k) {
           if (k != p && k != qq) {
@@ -127,8 +159,8 @@ __device__ __noinline__ void jacobi_eigh_rolled(c128 (&A)[M][M], c128 (&P)[M][M]
             A[qq][k] = cconj(nkq);
           }
         }
-        A[p][p] = cmake(app - t * mag, 0.0);
-        A[qq][qq] = cmake(aqq + t * mag, 0.0);
+        A[p][p] = cmake(app - rot.tm, 0.0);
+        A[qq][qq] = cmake(aqq + rot.tm, 0.0);
         A[p][qq] = cmake(0.0, 0.0);
         A[qq][p] = cmake(0.0, 0.0);
 #pragma unroll 1
