@@ -156,6 +156,20 @@ __device__ __forceinline__ c128 crecip(c128 a) {
   }
 }
 __device__ __forceinline__ c128 cdiv(c128 a, c128 b) { return cmul(a, crecip(b)); }
+// 1 / a by v_rcp_f64 + two Newton steps on |a|^2 (~1 ulp) for the pivots of the row-distributed
+// solvers (k_ip1_rows, k_ip2_rows): those kernels are chains of dependent pivots, and Smith's form
+// above is two IEEE divides (~12 dependent instructions each) and a branch per reciprocal.  For
+// well-scaled arguments only: |a|^2 must neither overflow nor underflow (statistics of spectrograms;
+// the latency form k_ip1_small has used the same since round 3).
+__device__ __forceinline__ c128 crecip_fast(c128 a) {
+  const double m2 = fma(a.x, a.x, a.y * a.y);
+  double r = __builtin_amdgcn_rcp(m2);
+  double e = fma(-m2, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-m2, r, 1.0);
+  r = fma(r, e, r);
+  return cmake(a.x * r, -a.y * r);
+}
 
 __device__ __forceinline__ double apply_floor(double x, int kind, double eps) {
   // numpy.maximum propagates NaN; fmax would swallow it, so spell the compare out

@@ -155,6 +155,7 @@ __device__ __forceinline__ bool ip2_half_rows(const c128 (&Wr)[N], const c128 *_
   bool ok = true;
   int order = row ? -1 : N;  // elimination step at which my row became the pivot row
   int plane[N];              // lane of the group that owns pivot k (uniform within the group)
+  c128 pinv[N];              // 1 / pivot k (crecip_fast), reused by the back substitution
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const bool cand = order < 0;
@@ -177,9 +178,9 @@ __device__ __forceinline__ bool ip2_half_rows(const c128 (&Wr)[N], const c128 *_
     const c128 prhs1 = cmake(__shfl(rhs[1].x, bl, G), __shfl(rhs[1].y, bl, G));
     const c128 piv = prow[k];
     ok = ok && (piv.x != 0.0 || piv.y != 0.0);
-    const c128 inv = crecip(piv);
+    pinv[k] = crecip_fast(piv);
     if (order < 0) {  // still unused: eliminate column k
-      const c128 f = cmul(a[k], inv);
+      const c128 f = cmul(a[k], pinv[k]);
 #pragma unroll
       for (int c = k + 1; c < N; ++c) cfms(a[c], f, prow[c]);
       cfms(rhs[0], f, prhs0);
@@ -189,8 +190,7 @@ __device__ __forceinline__ bool ip2_half_rows(const c128 (&Wr)[N], const c128 *_
 #pragma unroll
   for (int k = N - 1; k >= 0; --k) {
     // the owner of pivot k has folded the unknowns above k into its right-hand sides already
-    const c128 inv = crecip(a[k]);
-    const c128 m0 = cmul(rhs[0], inv), m1 = cmul(rhs[1], inv);
+    const c128 m0 = cmul(rhs[0], pinv[k]), m1 = cmul(rhs[1], pinv[k]);
     P[k][0] = cmake(__shfl(m0.x, plane[k], G), __shfl(m0.y, plane[k], G));
     P[k][1] = cmake(__shfl(m1.x, plane[k], G), __shfl(m1.y, plane[k], G));
     if (order < k) {

@@ -417,20 +417,8 @@ __global__ __launch_bounds__(256) void k_scale_filter_row(c128 *W, const double 
 // and the covariance streamed still 325: 1.1 resp. 0.56 ms for 16 x 1025 bins; this one 0.26 ms).  The covariance entries are read where they are used: the G lanes of a bin
 // ask for the same address (one request).  (Four lanes per bin for N <= 4 at one mixture was tried
 // for latency: 115.5 -> 114.3 us per iteration, not kept.)
-// 1 / a by v_rcp_f64 + two Newton steps on |a|^2 (~1 ulp; the latency form k_ip1_small has used it
-// since round 3): the kernel below is a chain of dependent pivots, and the IEEE divide is ~12 of
-// them per reciprocal -- 80 divides per bin at 8 sources before round 6 (every pivot inverted twice,
-// 2 N divides by the normalisation)
-__device__ __forceinline__ c128 crecip_rows(c128 a) {
-  const double m2 = fma(a.x, a.x, a.y * a.y);
-  double r = __builtin_amdgcn_rcp(m2);
-  double e = fma(-m2, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-m2, r, 1.0);
-  r = fma(r, e, r);
-  return cmake(a.x * r, -a.y * r);
-}
-
+// (pivots inverted once, by crecip_fast, and kept for the back substitution; one divide for the
+//  normalisation: 80 IEEE divides per bin at 8 sources before round 6)
 template <int N, int G>
 __global__ __launch_bounds__(256) void k_ip1_rows(c128 *W, const c128 *__restrict__ U,
                                                   long long nbins, int floor_kind, double eps,
@@ -484,7 +472,7 @@ __global__ __launch_bounds__(256) void k_ip1_rows(c128 *W, const c128 *__restric
       const c128 prhs = cmake(__shfl(rhs.x, bl, G), __shfl(rhs.y, bl, G));
       const c128 piv = prow[k];
       ok = ok && (piv.x != 0.0 || piv.y != 0.0);
-      pinv[k] = crecip_rows(piv);
+      pinv[k] = crecip_fast(piv);
       if (order < 0) {  // still unused: eliminate column k
         const c128 f = cmul(a[k], pinv[k]);
 #pragma unroll
