@@ -2826,3 +2826,38 @@ def test_page_locked_downloads_are_counted_and_capped(monkeypatch):
     del kept, a
     gc.collect()
     assert dv.pinned_outstanding_bytes() == base
+
+
+# ------------------------------------------------------------- the private copy of the mixture
+@pytest.mark.parametrize("cls", ["ilrma", "auxiva", "fmnmf"])
+def test_input_attribute_is_a_private_copy_formed_on_demand(cls):
+    """The reference keeps ``self.input = input.copy()`` (ssspy/bss/ilrma.py:840, iva.py:152,
+    mnmf.py:153).  Round 6: the private copy is the HBM buffer and ``input`` is formed from it on
+    first access -- same values, same dtype, and untouched by what the caller does to the array
+    afterwards; a call never forms it by itself."""
+    from ssspy_amd.bss.ilrma import GaussILRMA
+    from ssspy_amd.bss.iva import AuxLaplaceIVA
+    from ssspy_amd.bss.mnmf import FastGaussMNMF
+    from ssspy_amd.utils.dataset import nmf_mixture
+
+    X = nmf_mixture(3, 3, 17, 40)
+    for dtype in (np.complex128, np.complex64):
+        Xin = X.astype(dtype)
+        keep = Xin.copy()
+        m = {"ilrma": lambda: GaussILRMA(n_basis=2, rng=np.random.default_rng(0)),
+             "auxiva": lambda: AuxLaplaceIVA(),
+             "fmnmf": lambda: FastGaussMNMF(n_basis=2, rng=np.random.default_rng(0))}[cls]()
+        with pytest.raises(AssertionError, match="Specify data"):
+            m._reset()
+        Y = m(Xin, n_iter=2)
+        assert m.__dict__.get("_input_value") is None  # (nothing on the path read it)
+        Xin *= 0.0  # the caller reuses its buffer
+        got = m.input
+        assert got.dtype == dtype and got.shape == keep.shape
+        assert np.array_equal(got, keep)
+        assert m.input is got  # formed once
+        assert Y.shape == keep.shape
+    batch = np.stack([X, 2.0 * X])
+    m = GaussILRMA(n_basis=2, rng=np.random.default_rng(0))
+    m(batch, n_iter=1)
+    assert np.array_equal(m.input, batch)
