@@ -561,6 +561,24 @@ int ssspy_fastmnmf_update_handover(const void *X, const void *C, void *Q, double
                                    size_t workspace_bytes, int *info, double *handover,
                                    int *handover_valid, void *stream);
 
+/* The same (handover / handover_valid both NULL: as ssspy_fastmnmf_update) for a record_loss loop:
+ * `steps` must hold SSSPY_MNMF_DIAGONALIZER, and the call also leaves sum_i log|det Q_i| of the
+ * diagonalisers AS THEY COME IN -- the log-determinant term of the loss of the state the call
+ * starts from (ssspy/bss/mnmf.py:1219-1261) -- as ssspy_fastmnmf_deferred_logdet_slots() shares per
+ * mixture at logdet[s * logdet_stride + b], to be added in slot order (ssspy_fold_scalar_slots; a
+ * run keeps one zeroed array of slots x (n_iter + 1) B doubles and passes logdet + t B): 1 where
+ * the finished sums are stored, ceil(F / 16) for a handful of mixtures of up to 4 channels, where
+ * the latency form of IP1 reads the diagonalisers anyway and leaves one share per tile of 16 bins
+ * instead of a one-block ssspy_sum_logdet launch per iteration (shares the call does not write
+ * stay as the caller zeroed them). */
+int ssspy_fastmnmf_deferred_logdet_slots(int B, int N, int M, int F, int T, int K);
+int ssspy_fastmnmf_update_handover_logdet(const void *X, const void *C, void *Q, double *D,
+                                          double *basis, double *activation, int B, int N, int M,
+                                          int F, int T, int K, int steps, int floor_kind,
+                                          double floor_eps, void *workspace, size_t workspace_bytes,
+                                          int *info, double *handover, int *handover_valid,
+                                          double *logdet, long long logdet_stride, void *stream);
+
 /* The data term of the loss (as ssspy_fastmnmf_loss_data) from a VALID hand-over buffer instead of
  * X and Q: half the bytes, no M x M products.  The caller guarantees that the buffer matches the
  * current Q and X (ssspy_fastmnmf_update_handover returned *handover_valid = 1 and neither moved
@@ -571,6 +589,18 @@ int ssspy_fastmnmf_loss_data_handover(const double *D, const double *basis,
                                       const double *activation, const double *handover,
                                       double *out, int B, int N, int M, int F, int T, int K,
                                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same with the per-wave shares left RAW: share s of mixture b at slots[s * slot_stride + b],
+ * s < ssspy_fastmnmf_loss_handover_slots() (0: no hand-over for the shape).  A record_loss run
+ * zeroes one array of slots x (n_iter + 1) B doubles, passes slots + t B with slot_stride =
+ * (n_iter + 1) B for the state after iteration t, and folds all of them in slot order with one
+ * ssspy_fold_scalar_slots at the end -- instead of two memsets and a fold launch per recorded loss
+ * (shares a launch does not write stay as the caller zeroed them). */
+int ssspy_fastmnmf_loss_handover_slots(int B, int N, int M, int F, int T, int K);
+int ssspy_fastmnmf_loss_data_handover_slots(const double *D, const double *basis,
+                                            const double *activation, const double *handover,
+                                            double *slots, long long slot_stride, int B, int N,
+                                            int M, int F, int T, int K, void *stream);
 
 /* U[b,i,m] = (1/T) sum_j x x^H / R~_ijm  -> (B,F,M,M,M): the covariances the diagonaliser update
  * (IP1 inside ssspy_fastmnmf_update, or ssspy_update_by_ip2 for diagonalizer_algorithm="IP2") needs.

@@ -124,6 +124,12 @@ PROTOTYPES = {
     "ssspy_fastmnmf_handover_doubles": (_z, [_i, _i, _i, _i, _i, _i]),
     "ssspy_fastmnmf_update_handover": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d,
                                             _p, _z, _p, _p, _p, _p]),
+    "ssspy_fastmnmf_deferred_logdet_slots": (_i, [_i, _i, _i, _i, _i, _i]),
+    "ssspy_fastmnmf_update_handover_logdet": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i,
+                                                   _i, _d, _p, _z, _p, _p, _p, _p, _q, _p]),
+    "ssspy_fastmnmf_loss_handover_slots": (_i, [_i, _i, _i, _i, _i, _i]),
+    "ssspy_fastmnmf_loss_data_handover_slots": (_i, [_p, _p, _p, _p, _p, _q, _i, _i, _i, _i, _i, _i,
+                                                     _p]),
     "ssspy_fastmnmf_loss_data_handover": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z,
                                                _p]),
     "ssspy_fastmnmf_loss_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),

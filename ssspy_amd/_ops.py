@@ -688,6 +688,32 @@ def fastmnmf_update_handover(X, C, Q, D, basis, activation, steps, flooring, ws,
     return bool(flag.value)
 
 
+def fastmnmf_deferred_logdet_slots(B, N, M, F, T, K):
+    """Shares per mixture ``fastmnmf_update_logdet`` leaves in ``logdet``."""
+    return int(_L().ssspy_fastmnmf_deferred_logdet_slots(B, N, M, F, T, K))
+
+
+def fastmnmf_update_logdet(X, C, Q, D, basis, activation, steps, flooring, ws, ws_bytes, info,
+                           handover, valid, logdet, logdet_stride):
+    """fastmnmf_update(_handover) that also leaves sum_i log|det Q_i| of the diagonalisers as they
+    come in, as shares at logdet[s * logdet_stride + b] (the caller zeroes the array once per run
+    and folds it once).  handover None: no hand-over buffer.  Returns the buffer's validity."""
+    import ctypes
+
+    B, M, F, T = X.shape
+    N, K = basis.shape[1], basis.shape[-1]
+    flag = ctypes.c_int(1 if valid else 0)
+    _lib.check(
+        _L().ssspy_fastmnmf_update_handover_logdet(
+            ptr(X), ptr(C), ptr(Q), ptr(D), ptr(basis), ptr(activation), B, N, M, F, T, K, steps,
+            flooring[0], flooring[1], ptr(ws), ws_bytes, ptr(info), ptr(handover),
+            ctypes.cast(ctypes.pointer(flag), ctypes.c_void_p) if handover is not None else None,
+            ptr(logdet), int(logdet_stride), _st()),
+        "fastmnmf_update_handover_logdet",
+    )
+    return bool(flag.value) if handover is not None else False
+
+
 def fastmnmf_diagonalizer_covariance(X, D, basis, activation, out=None, ws=None, ws_bytes=0):
     """ws (the separator's fastmnmf_workspace): the tuned covariance pass instead of the generic one."""
     B, M, F, T = X.shape
@@ -745,6 +771,24 @@ def fastmnmf_loss_data_handover(D, basis, activation, handover, n_channels, n_fr
         "fastmnmf_loss_data_handover",
     )
     return out
+
+
+def fastmnmf_loss_handover_slots(B, N, M, F, T, K):
+    """Shares per mixture ``fastmnmf_loss_data_handover_slots`` writes (0: no hand-over)."""
+    return int(_L().ssspy_fastmnmf_loss_handover_slots(B, N, M, F, T, K))
+
+
+def fastmnmf_loss_data_handover_slots(D, basis, activation, handover, n_channels, n_frames, slots,
+                                      slot_stride):
+    """fastmnmf_loss_data_handover with the per-wave shares left raw (share s of mixture b at
+    slots[s * slot_stride + b]); the caller zeroes the array once per run and folds it once."""
+    B, N, F, K = basis.shape
+    _lib.check(
+        _L().ssspy_fastmnmf_loss_data_handover_slots(
+            ptr(D), ptr(basis), ptr(activation), ptr(handover), ptr(slots), int(slot_stride), B, N,
+            n_channels, F, n_frames, K, _st()),
+        "fastmnmf_loss_data_handover_slots",
+    )
 
 
 def fastmnmf_separate(X, Q, D, basis, activation, reference_id, flooring, ws, ws_bytes, info,

@@ -244,9 +244,12 @@ class FastMNMFBase(MNMFBase):
             self._state_dev("basis"), self._state_dev("activation"))
         return _ops.weighted_covariance(self._X, weights, _lib.WEIGHT_BIN_FRAME, self.n_channels)
 
-    def _update(self, steps, flooring_fn="self") -> None:
+    def _update(self, steps, flooring_fn="self", logdet=None, logdet_stride=0) -> None:
+        """``logdet`` (the record_loss loop): the call also leaves sum_i log|det Q_i| of the
+        diagonalisers it starts from, as shares (``_ops.fastmnmf_update_logdet``)."""
         floor = self._resolve_floor(flooring_fn)
         if host_floor(floor) is not None:
+            assert logdet is None
             return self._update_host_floor(steps, floor)
         need_c = bool(steps & _lib.MNMF_NORMALIZE)
         args = (
@@ -255,11 +258,14 @@ class FastMNMFBase(MNMFBase):
             steps, floor, self._ws, self._ws_bytes, self._info_tensor(),
         )
         handover = getattr(self, "_handover", None)
-        if handover is None:
+        key = (self._state_rev("diagonalizer"), self._X.data_ptr())
+        if logdet is not None:
+            valid = _ops.fastmnmf_update_logdet(*args, handover, self._handover_key == key, logdet,
+                                                logdet_stride)
+        elif handover is None:
             _ops.fastmnmf_update(*args)
             valid = False
         else:
-            key = (self._state_rev("diagonalizer"), self._X.data_ptr())
             valid = _ops.fastmnmf_update_handover(*args, handover, self._handover_key == key)
         for name in ("diagonalizer", "spatial", "basis", "activation"):
             self._state_touch(name)
@@ -371,6 +377,8 @@ class FastGaussMNMF(FastMNMFBase):
                                                     self.n_frames, out=data_out)
         else:
             data = _ops.fastmnmf_loss_data(self._X, Q, D, Tb, Vb, out=data_out)
+        if data_out is not None and logdet_out is None:
+            return data, None  # (the resident loop: the log-determinants come from the updates)
         return data, _ops.sum_logdet(Q, out=logdet_out)
 
     def compute_loss(self) -> float:
@@ -407,13 +415,57 @@ class FastGaussMNMF(FastMNMFBase):
         B, dev = self._X.shape[0], self._X.device
         data = dv.zeros((n_iter + 1, B), dv.f64, dev)
         logdet = dv.zeros((n_iter + 1, B), dv.f64, dev)
-        if initial_call:
-            self._loss_terms(data[0], logdet[0])
-        for t in range(n_iter):
-            self.update_once()
-            self._loss_terms(data[t + 1], logdet[t + 1])
+        if host_floor(self._floor) is not None:
+            if initial_call:
+                self._loss_terms(data[0], logdet[0])
+            for t in range(n_iter):
+                self.update_once()
+                self._loss_terms(data[t + 1], logdet[t + 1])
+        else:
+            # Round 6: sum_i log|det Q_i| of the state iteration t + 1 starts from is a by-product of
+            # that iteration (the latency form of IP1 reads the diagonalisers anyway and leaves one
+            # share per 16-bin tile; elsewhere the call stores the finished sum) -- folded once at
+            # the end; only the last state needs sum_logdet.  The data term stays a pass per state.
+            stride = (n_iter + 1) * B
+            nld = _ops.fastmnmf_deferred_logdet_slots(B, self.n_sources, self.n_channels,
+                                                      self.n_bins, self.n_frames, self.n_basis)
+            ld = dv.zeros((nld, stride), dv.f64, dev) if nld > 1 else logdet
+            ld_flat = ld.reshape(-1)
+            steps = _lib.MNMF_ALL if self.normalization else _lib.MNMF_ALL & ~_lib.MNMF_NORMALIZE
+            # the data term from the |Q x|^2 hand-over leaves its per-wave shares raw in one array
+            # for the whole run (no memsets, no fold launch per loss)
+            nds = _ops.fastmnmf_loss_handover_slots(B, self.n_sources, self.n_channels, self.n_bins,
+                                                    self.n_frames, self.n_basis)
+            ds = dv.zeros((nds, stride), dv.f64, dev) if nds and nds * stride * 8 <= (1 << 28) else None
+            ds_flat = ds.reshape(-1) if ds is not None else None
+
+            def data_term(t):
+                if ds is not None and self._handover_valid():
+                    _ops.fastmnmf_loss_data_handover_slots(
+                        self._state_dev("spatial"), self._state_dev("basis"),
+                        self._state_dev("activation"), self._handover, self.n_channels,
+                        self.n_frames, ds_flat[t * B:], stride)
+                else:
+                    self._loss_terms(data[t], None)
+
+            if initial_call:
+                data_term(0)
+            for t in range(n_iter):
+                self._update(steps, "self", logdet=ld_flat[t * B:], logdet_stride=stride)
+                data_term(t + 1)
+            if nld > 1:
+                _ops.fold_scalar_slots(ld, stride, nld, logdet.reshape(-1))
+            _ops.sum_logdet(self._state_dev("diagonalizer"), out=logdet[n_iter])
+            if ds is not None:  # (every state has its data term in `data` or in the shares)
+                folded = dv.zeros((n_iter + 1, B), dv.f64, dev)
+                _ops.fold_scalar_slots(ds, stride, nds, folded.reshape(-1))
+                data = (data, folded)
         self._check_device_errors()
-        values = dv.to_host(data) - 2.0 * dv.to_host(logdet)
+        if isinstance(data, tuple):
+            data = dv.to_host(data[0]) + dv.to_host(data[1])
+        else:
+            data = dv.to_host(data)
+        values = data - 2.0 * dv.to_host(logdet)
         if not initial_call:
             values = values[1:]
         self.loss.extend(v.copy() if self._batched else v[0].item() for v in values)

@@ -8,6 +8,10 @@ namespace ssspy {
   int mnmf_loss_handover_n##n(const double *, const double *, const double *, const double *,   \
                               const double *, double *, void *, int, int, int, int, int,        \
                               hipStream_t);                                                     \
+  int mnmf_loss_handover_slots_n##n(int, int, int);                                             \
+  int mnmf_loss_handover_raw_n##n(const double *, const double *, const double *, const double *, \
+                                  const double *, double *, long long, int, int, int, int, int, \
+                                  hipStream_t);                                                 \
   size_t mnmf_loss_ws_bytes_n##n(int, int);                                                     \
   int mnmf_qx2_n##n(const void *, const void *, double *, double *, int, int, int, int,         \
                     hipStream_t);                                                               \
@@ -46,7 +50,8 @@ int row_power(const void *W, const void *C, double *qbuf, int B, int F, int N, h
 bool ip1_small_shape(int B, int F, int N);
 int ip1_from_records(void *W, const void *records, int nchunks, int rbins, long long rec_stride,
                      const void *C, double *qbuf, int B, int F, int N, int floor_kind,
-                     double floor_eps, int *info, hipStream_t st);
+                     double floor_eps, int *info, hipStream_t st, double *logdet,
+                     long long logdet_stride);
 
 // general shapes (n_sources or n_channels above 4): the point-wise path of fmnmf_generic.hip
 size_t fmnmf_generic_workspace_doubles(int B, int N, int M, int F, int T);
@@ -190,7 +195,11 @@ static int fastmnmf_update_impl(const void *X, const void *C, void *Q, double *D
                                 double *activation, int B, int N, int M, int F, int T, int K,
                                 int steps, int floor_kind, double floor_eps, void *workspace,
                                 size_t workspace_bytes, int *info, double *handover, int *valid,
-                                hipStream_t st) {
+                                hipStream_t st, double *logdet = nullptr,
+                                long long logdet_stride = 0) {
+  // logdet (optional; with SSSPY_MNMF_DIAGONALIZER among the steps): sum_i log|det Q_i| of the
+  // diagonalisers AS THEY COME IN, as ssspy_fastmnmf_deferred_logdet_slots() shares per mixture
+  // (logdet[s * logdet_stride + b]; see ssspy_fastmnmf_update_handover_logdet)
   SSSPY_REQUIRE(X && Q && D && basis && activation && B > 0 && F > 0 && T > 0,
                 "fastmnmf_update: bad argument");
   SSSPY_REQUIRE(K >= 1 && K <= SSSPY_MAX_BASIS, "fastmnmf_update: n_basis must be in [1, 65536]");
@@ -199,8 +208,15 @@ static int fastmnmf_update_impl(const void *X, const void *C, void *Q, double *D
   SSSPY_REQUIRE(!(steps & SSSPY_MNMF_NORMALIZE) || C, "fastmnmf_update: normalisation needs C");
   char *ws = (char *)workspace;
   int rc = SSSPY_OK;
+  if (logdet) {
+    SSSPY_REQUIRE(steps & SSSPY_MNMF_DIAGONALIZER, "fastmnmf_update: logdet without the IP1 step");
+  }
   if (!mnmf_tiled(N, M)) {
     SSSPY_REQUIRE(!handover, "fastmnmf_update: no hand-over for this shape");
+    if (logdet) {
+      rc = ssspy_sum_logdet(Q, logdet, B, F, M, (void *)st);
+      if (rc) return rc;
+    }
     return fmnmf_generic_update(X, C, Q, D, basis, activation, B, N, M, F, T, K, steps, floor_kind,
                                 floor_eps, (double *)(ws + w.generic), ws + w.U,
                                 (double *)(ws + w.qbuf), info, st);
@@ -243,11 +259,16 @@ static int fastmnmf_update_impl(const void *X, const void *C, void *Q, double *D
     rc = run();
     if (rc) return rc;
     // IP1 on the M x M diagonaliser with M weighted covariances per bin
-    if (split)
+    if (split) {
       rc = ip1_from_records(Q, ws + w.tail, split, 64, rec, C, C ? qbuf : nullptr, B, F, M,
-                            floor_kind, floor_eps, info, st);
-    else
+                            floor_kind, floor_eps, info, st, logdet, logdet_stride);
+    } else {
+      if (logdet) {  // (no by-product on this route: the finished sums go to share 0)
+        rc = ssspy_sum_logdet(Q, logdet, B, F, M, (void *)st);
+        if (rc) return rc;
+      }
       rc = ip1_with_power(Q, U, C, C ? qbuf : nullptr, B, F, M, floor_kind, floor_eps, info, st);
+    }
     if (rc) return rc;
     have_q = C != nullptr;
     have_p = false;  // Q moved
@@ -318,6 +339,25 @@ int ssspy_fastmnmf_update_handover(const void *X, const void *C, void *Q, double
   return fastmnmf_update_impl(X, C, Q, D, basis, activation, B, N, M, F, T, K, steps, floor_kind,
                               floor_eps, workspace, workspace_bytes, info, handover, handover_valid,
                               as_stream(stream));
+}
+
+int ssspy_fastmnmf_deferred_logdet_slots(int B, int N, int M, int F, int T, int K) {
+  if (B <= 0 || N <= 0 || M <= 0 || F <= 0 || T <= 0 || K <= 0) return 0;
+  return (mnmf_tiled(N, M) && ip1_small_shape(B, F, M)) ? (F + 15) / 16 : 1;
+}
+
+int ssspy_fastmnmf_update_handover_logdet(const void *X, const void *C, void *Q, double *D,
+                                          double *basis, double *activation, int B, int N, int M,
+                                          int F, int T, int K, int steps, int floor_kind,
+                                          double floor_eps, void *workspace, size_t workspace_bytes,
+                                          int *info, double *handover, int *handover_valid,
+                                          double *logdet, long long logdet_stride, void *stream) {
+  SSSPY_REQUIRE((handover == nullptr) == (handover_valid == nullptr) && logdet &&
+                    logdet_stride >= B,
+                "fastmnmf_update_handover_logdet: bad argument");
+  return fastmnmf_update_impl(X, C, Q, D, basis, activation, B, N, M, F, T, K, steps, floor_kind,
+                              floor_eps, workspace, workspace_bytes, info, handover, handover_valid,
+                              as_stream(stream), logdet, logdet_stride);
 }
 
 int ssspy_fastmnmf_diagonalizer_covariance(const void *X, const double *D, const double *basis,
@@ -398,6 +438,26 @@ int ssspy_fastmnmf_loss_data_handover(const double *D, const double *basis,
   const double *pscale = handover + (size_t)B * M * F * T;
   MNMF_DISPATCH(N, mnmf_loss_handover, D, basis, activation, handover, pscale, out, workspace, B, M,
                 F, T, K, st);
+}
+
+int ssspy_fastmnmf_loss_handover_slots(int B, int N, int M, int F, int T, int K) {
+  if (B <= 0 || N <= 0 || M <= 0 || F <= 0 || T <= 0 || K <= 0) return 0;
+  if (handover_ok(B, N, M, F, T, K) != 1) return 0;
+  MNMF_DISPATCH(N, mnmf_loss_handover_slots, B, F, T);
+}
+
+int ssspy_fastmnmf_loss_data_handover_slots(const double *D, const double *basis,
+                                            const double *activation, const double *handover,
+                                            double *slots, long long slot_stride, int B, int N,
+                                            int M, int F, int T, int K, void *stream) {
+  SSSPY_REQUIRE(D && basis && activation && handover && slots && B > 0 && slot_stride >= B &&
+                    slot_stride < (1ll << 31),
+                "fastmnmf_loss_data_handover_slots: bad argument");
+  if (handover_ok(B, N, M, F, T, K) != 1)
+    return fail(SSSPY_ERR_UNSUPPORTED, "fastmnmf_loss_data_handover: no hand-over for this shape");
+  const double *pscale = handover + (size_t)B * M * F * T;
+  MNMF_DISPATCH(N, mnmf_loss_handover_raw, D, basis, activation, handover, pscale, slots,
+                slot_stride, B, M, F, T, K, as_stream(stream));
 }
 
 int ssspy_fastmnmf_separate(const void *X, const void *Q, const double *D, const double *basis,

@@ -854,7 +854,8 @@ __global__ __launch_bounds__(256, PMODE == P_READ ? PBASIS_WAVES : 1) void k_mnm
   }
   if (MODE == MODE_LOSS) {
     // `tailpart` holds the loss slots here, [slot][B] with one slot per (bin group, chunk, wave) of
-    // the mixture; this mode has no floor, and the launcher passes B in `floor_kind`
+    // the mixture; this mode has no floor, and the launcher passes the slots' stride (B, or the
+    // caller's for raw slots) in `floor_kind`
     lacc += lr.value();
     lacc = wave_sum(lacc);
     const int maxsplit = plan.split > 1 ? plan.split : 1;
@@ -2427,6 +2428,30 @@ int LAUNCHER(mnmf_loss_handover)(const double *Dsp, const double *basis, const d
                                         const_cast<double *>(P), pscale));
   rc = check_launch("k_mnmf_loss_handover");
   return rc ? rc : scalar_slots_fold(loss_ws, B, nslots, out, 0, st);
+}
+
+// The same with the per-wave shares left RAW in the caller's array, share s of mixture b at
+// slots[s * stride + b] (s < mnmf_loss_handover_slots): a record_loss run zeroes one array for all
+// its iterations and folds it once, instead of two memsets and a fold launch per loss.
+int LAUNCHER(mnmf_loss_handover_slots)(int B, int F, int T) {
+  const TailPlan plan = make_tail_plan(B, (F + 63) / 64, (T + 15) / 16, 256 * PBASIS_WAVES);
+  return plan.groups * (plan.split > 1 ? plan.split : 1) * 4;
+}
+int LAUNCHER(mnmf_loss_handover_raw)(const double *Dsp, const double *basis, const double *act,
+                                     const double *P, const double *pscale, double *slots,
+                                     long long stride, int B, int M, int F, int T, int K,
+                                     hipStream_t st) {
+  if (!mnmf_fast_ok(B, F, T, K) || T % 2 != 0)
+    return fail(SSSPY_ERR_UNSUPPORTED, "fastmnmf_loss_data_handover: no hand-over for this shape");
+  const TailPlan plan = make_tail_plan(B, (F + 63) / 64, (T + 15) / 16, 256 * PBASIS_WAVES);
+  dim3 fgrid(plan.full + plan.tail * plan.split);
+  // (MODE_LOSS: `tailpart` = the slots, `floor_kind` = their stride, see the kernel)
+  MNMF_DISPATCH_M(M, hipLaunchKernelGGL((k_mnmf_binmajor_fast<MM, MODE_LOSS, P_READ>), fgrid,
+                                        dim3(256), 0, st, (const c128 *)nullptr,
+                                        (const c128 *)nullptr, (double *)Dsp, (double *)basis, act,
+                                        (c128 *)nullptr, F, T, K, (int)stride, 0.0, plan, slots,
+                                        const_cast<double *>(P), pscale));
+  return check_launch("k_mnmf_loss_handover");
 }
 
 int LAUNCHER(mnmf_norm_scale)(void *Q, double *Dsp, const double *qbuf, int B, int M, int F,

@@ -739,7 +739,10 @@ namespace ssspy {
 // ilrma_small.hip: the latency form (16-bin workgroups, four lanes per bin, operands in LDS)
 #define DECL_SMALL_IP1(n)                                                                          \
   int ilrma_small_ip1_n##n(const void *, int, int, long long, const void *, void *, int, int, int, \
-                           double, double *, int *, hipStream_t);
+                           double, double *, int *, hipStream_t);                                  \
+  int ilrma_small_ip1_logdet_n##n(const void *, int, int, long long, const void *, void *, int,    \
+                                  int, int, double, double *, int *, double *, long long,          \
+                                  hipStream_t);
 DECL_SMALL_IP1(2) DECL_SMALL_IP1(3) DECL_SMALL_IP1(4)
 #undef DECL_SMALL_IP1
 
@@ -757,9 +760,18 @@ bool ip1_small_shape(int B, int F, int N) {
 // IP1 (+ output power) straight from the partial covariance records of a pass whose every item was
 // split: records[(b * groups + group) * nchunks + ch] hold rbins bins x N^3 complex each, rec_stride
 // c128 apart.  Only for ip1_small_shape().
+// logdet (optional): the kernel also leaves sum log|det W| of the filters as they come in, one share
+// per tile of 16 bins at logdet[tile * logdet_stride + b] (k_ip1_small)
 int ip1_from_records(void *W, const void *records, int nchunks, int rbins, long long rec_stride,
                      const void *C, double *qbuf, int B, int F, int N, int floor_kind,
-                     double floor_eps, int *info, hipStream_t st) {
+                     double floor_eps, int *info, hipStream_t st, double *logdet,
+                     long long logdet_stride) {
+  if (logdet) switch (N) {
+    case 2: return ilrma_small_ip1_logdet_n2(records, nchunks, rbins, rec_stride, C, W, B, F, floor_kind, floor_eps, qbuf, info, logdet, logdet_stride, st);
+    case 3: return ilrma_small_ip1_logdet_n3(records, nchunks, rbins, rec_stride, C, W, B, F, floor_kind, floor_eps, qbuf, info, logdet, logdet_stride, st);
+    case 4: return ilrma_small_ip1_logdet_n4(records, nchunks, rbins, rec_stride, C, W, B, F, floor_kind, floor_eps, qbuf, info, logdet, logdet_stride, st);
+    default: return fail(SSSPY_ERR_INTERNAL, "ip1_from_records: shape off the small path");
+  }
   switch (N) {
     case 2: return ilrma_small_ip1_n2(records, nchunks, rbins, rec_stride, C, W, B, F, floor_kind, floor_eps, qbuf, info, st);
     case 3: return ilrma_small_ip1_n3(records, nchunks, rbins, rec_stride, C, W, B, F, floor_kind, floor_eps, qbuf, info, st);
@@ -775,7 +787,7 @@ int ip1_with_power(void *W, const void *U, const void *C, double *qbuf, int B, i
   // a handful of mixtures: one lane per bin would leave the chip to 17 waves running a chain of
   // ~5000 dependent fp64 instructions each (17 us at 1025 bins); four lanes per bin take 12
   if (ip1_small_shape(B, F, N))
-    return ip1_from_records(W, U, 0, 0, 0, C, qbuf, B, F, N, floor_kind, floor_eps, info, st);
+    return ip1_from_records(W, U, 0, 0, 0, C, qbuf, B, F, N, floor_kind, floor_eps, info, st, nullptr, 0);
   dim3 grid((unsigned)((nbins + 63) / 64)), block(64);
   if (N > 4) {  // a bin on 8 lanes, one per row
     dim3 g8((unsigned)((nbins * 8 + 255) / 256)), b8(256);
