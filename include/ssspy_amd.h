@@ -155,6 +155,18 @@ int ssspy_cross_covariance(const void *A, const void *Bm, void *C, int B, int N,
 int ssspy_update_by_ip1(void *W, const void *U, int B, int F, int N, int floor_kind,
                         double floor_eps, int *info, void *stream);
 
+/* The same for a record_loss loop: the call also leaves sum_i log|det W_i| of the filters AS THEY
+ * COME IN (the log-determinant term of the loss of the state the update starts from,
+ * ssspy/bss/iva.py:200-222) as ssspy_update_by_ip1_logdet_slots() shares per mixture at
+ * logdet[s * logdet_stride + b], to be added in slot order (ssspy_fold_scalar_slots): 1 where the
+ * finished sums are stored, ceil(F / 16) for a handful of mixtures of up to 4 sources, where the
+ * latency form of the kernel reads the filters anyway (shares the call does not write stay as the
+ * caller zeroed them). */
+int ssspy_update_by_ip1_logdet_slots(int B, int F, int N);
+int ssspy_update_by_ip1_logdet(void *W, const void *U, int B, int F, int N, int floor_kind,
+                               double floor_eps, int *info, double *logdet,
+                               long long logdet_stride, void *stream);
+
 /* The same sweep one source at a time, for a flooring_fn that is an arbitrary Python callable (the
  * reference accepts any, ssspy/bss/ilrma.py:70-89) and so cannot run in a kernel: the solve of source
  * `source_idx` leaves the unnormalised row conj(w) in W and denom (B,F) = sqrt(max(Re(w^H U_n w), 0));

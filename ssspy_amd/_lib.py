@@ -38,6 +38,8 @@ PROTOTYPES = {
     "ssspy_weighted_covariance": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "ssspy_cross_covariance": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "ssspy_update_by_ip1": (_i, [_p, _p, _i, _i, _i, _i, _d, _p, _p]),
+    "ssspy_update_by_ip1_logdet_slots": (_i, [_i, _i, _i]),
+    "ssspy_update_by_ip1_logdet": (_i, [_p, _p, _i, _i, _i, _i, _d, _p, _p, _q, _p]),
     "ssspy_ip1_source_solve": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "ssspy_scale_filter_row": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "ssspy_iss1_transform": (_i, [_p, _p, _i, _i, _i, _i, _d, _p]),

@@ -162,6 +162,23 @@ def update_by_ip1(W, U, flooring, info=None):
     return W
 
 
+def update_by_ip1_logdet_slots(B, F, N):
+    """Shares per mixture ``update_by_ip1_logdet`` leaves in ``logdet``."""
+    return int(_L().ssspy_update_by_ip1_logdet_slots(B, F, N))
+
+
+def update_by_ip1_logdet(W, U, flooring, info, logdet, logdet_stride):
+    """update_by_ip1 that also leaves sum_i log|det W_i| of the filters as they come in, as shares at
+    logdet[s * logdet_stride + b] (device floors only; the caller zeroes the array once per run)."""
+    B, F, N, _ = W.shape
+    _lib.check(
+        _L().ssspy_update_by_ip1_logdet(ptr(W), ptr(U), B, F, N, flooring[0], flooring[1], ptr(info),
+                                        ptr(logdet), int(logdet_stride), _st()),
+        "update_by_ip1_logdet",
+    )
+    return W
+
+
 def update_by_iss1_host_floor(Y, weight, kind, host):
     """ISS1 with an arbitrary flooring callable: per source one covariance pass and one pass that
     applies the steering step; the N x F denominators are floored on the host in between.

@@ -320,16 +320,26 @@ class AuxIVA(AuxIVABase):
         logdet = dv.zeros((n_iter + 1, B), dv.f64, dev)
         W = self._state_dev("demix_filter")
         floor = self._resolve_floor("self")
+        # (round 6) sum_i log|det W_i| of the state an update starts from is a by-product of that
+        # update: one share per 16-bin tile from the latency form of IP1 for a handful of mixtures
+        # (the one-block sum_logdet launch was 13 us of a 65 us iteration), else the finished sum;
+        # folded once at the end, only the last state needs sum_logdet
+        stride = (n_iter + 1) * B
+        nld = _ops.update_by_ip1_logdet_slots(B, self.n_bins, N)
+        ld = dv.zeros((nld, stride), dv.f64, dev) if nld > 1 else logdet
+        ld_flat = ld.reshape(-1)
         for t in range(n_iter + 1):
             r2 = _ops.iva_frame_power(self._X, W)
             if t > 0 or initial_call:
                 _ops.iva_loss_data(r2, None, self.n_bins, self._contrast, out=data[t])
-                _ops.sum_logdet(W, out=logdet[t])
             if t == n_iter:
                 break
             weight = _ops.iva_weight(r2, self.n_bins, self._contrast, floor, variance=None)
             U = _ops.weighted_covariance(self._X, weight, _lib.WEIGHT_FRAME, N)
-            _ops.update_by_ip1(W, U, floor, self._info_tensor())
+            _ops.update_by_ip1_logdet(W, U, floor, self._info_tensor(), ld_flat[t * B:], stride)
+        if nld > 1:
+            _ops.fold_scalar_slots(ld, stride, nld, logdet.reshape(-1))
+        _ops.sum_logdet(W, out=logdet[n_iter])
         self._state_touch("demix_filter")
         self._check_device_errors()
         values = dv.to_host(data) - 2.0 * dv.to_host(logdet)

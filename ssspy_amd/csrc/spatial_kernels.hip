@@ -943,7 +943,9 @@ int ssspy_update_by_ip1(void *W, const void *U, int B, int F, int N, int floor_k
     return rt_ip1(W, U, nullptr, nullptr, B, F, N, floor_kind, floor_eps, info, as_stream(stream));
   // (above 4 sources: a bin on 8 lanes -- the lane-per-bin form spilled 134 / 502 / 888 VGPRs at
   //  6 / 7 / 8 sources and was what AuxIVA-IP1 and the functional update_by_ip1 ran; round 5)
-  if (N > 4)
+  // (a handful of mixtures of up to 4 sources: the latency form, four lanes per bin -- round 6;
+  //  the lane-per-bin kernel below was what a one-mixture AuxIVA-IP1 iteration ran: 17 against 12 us)
+  if (N > 4 || ip1_small_shape(B, F, N))
     return ip1_with_power(W, U, nullptr, nullptr, B, F, N, floor_kind, floor_eps, info,
                           as_stream(stream));
   const long long nbins = (long long)B * F;
@@ -952,6 +954,23 @@ int ssspy_update_by_ip1(void *W, const void *U, int B, int F, int N, int floor_k
                                     (const c128 *)U, nbins, floor_kind, floor_eps, info,
                                     (const c128 *)nullptr, (double *)nullptr));
   return check_launch("k_ip1");
+}
+
+int ssspy_update_by_ip1_logdet_slots(int B, int F, int N) {
+  if (B <= 0 || F <= 0 || N < 1) return 0;
+  return ip1_small_shape(B, F, N) ? (F + 15) / 16 : 1;
+}
+
+int ssspy_update_by_ip1_logdet(void *W, const void *U, int B, int F, int N, int floor_kind,
+                               double floor_eps, int *info, double *logdet,
+                               long long logdet_stride, void *stream) {
+  SSSPY_REQUIRE(W && U && B > 0 && F > 0 && logdet && logdet_stride >= B,
+                "update_by_ip1_logdet: bad argument");
+  if (ip1_small_shape(B, F, N))
+    return ip1_from_records(W, U, 0, 0, 0, nullptr, nullptr, B, F, N, floor_kind, floor_eps, info,
+                            as_stream(stream), logdet, logdet_stride);
+  const int rc = ssspy_sum_logdet(W, logdet, B, F, N, stream);  // (the finished sums: share 0)
+  return rc ? rc : ssspy_update_by_ip1(W, U, B, F, N, floor_kind, floor_eps, info, stream);
 }
 
 int ssspy_ip1_source_solve(void *W, const void *U, double *denom, int source_idx, int B, int F,
