@@ -542,8 +542,8 @@ class _MMILRMA(ILRMABase):
         B, N, F, T = Y.shape
         Vc = self._output_statistics(Y, flooring_fn)
         if Vc is None:
-            if self._base_model[0] != _lib.SOURCE_GAUSS:  # (t / GGD weights floor per element)
-                require_device_floor(floor, "ISS2 / IPA with a heavy-tailed model")
+            if self._base_model[0] == _lib.SOURCE_GGD:  # (its weights floor |y|^(2 - beta) per element)
+                require_device_floor(floor, "ISS2 with the GGD model")
             varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y,
                                            model=self._model, flooring=floor)
             Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
@@ -788,11 +788,11 @@ class _MMILRMA(ILRMABase):
         filter; the t / GGD weights are functions of |y|^2, which the pass forms as |w_n^H x|^2:
         up to 4 sources it is handed Y with identity filters (round 6), above that it forms the
         weights from the spectrogram it is given.  None: the caller forms weights (a host floor on
-        the heavy-tailed weights)."""
+        the GGD weights; the t model's weights hold no floor)."""
         floor = self._resolve_floor(flooring_fn)
         gauss = self._base_model[0] == _lib.SOURCE_GAUSS
-        if not gauss and host_floor(floor) is not None:
-            return None
+        if self._base_model[0] == _lib.SOURCE_GGD and host_floor(floor) is not None:
+            return None  # (the callers refuse: GGD's weights floor |y|^(2 - beta) per element)
         B, N, F, T = Y.shape
         W = None
         if not gauss and N <= 4:
@@ -809,8 +809,10 @@ class _MMILRMA(ILRMABase):
 
     def update_spatial_model_ip2(self, flooring_fn="self") -> None:
         """Weighted covariance + pairwise iterative projection.  ref: ssspy/bss/ilrma.py:1509-1633."""
-        if self._base_model[0] != _lib.SOURCE_GAUSS:  # (t / GGD weights floor per element)
-            require_device_floor(self._resolve_floor(flooring_fn), "IP2 with a heavy-tailed model")
+        # (the t model's weights hold no floor, ssspy/bss/ilrma.py:2915-2935; GGD's floor
+        #  |y|^(2 - beta) per element, :3987-4011)
+        if self._base_model[0] == _lib.SOURCE_GGD:
+            require_device_floor(self._resolve_floor(flooring_fn), "IP2 with the GGD model")
         B, N, F, T = self._X.shape
         if self._U is None:
             self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
@@ -825,8 +827,8 @@ class _MMILRMA(ILRMABase):
 
     def update_spatial_model_iss2(self, flooring_fn="self") -> None:
         """Pairwise iterative source steering on per-bin statistics.  ref: ilrma.py:1698-1792."""
-        if self._base_model[0] != _lib.SOURCE_GAUSS:  # (t / GGD weights floor per element)
-            require_device_floor(self._resolve_floor(flooring_fn), "ISS2 with a heavy-tailed model")
+        if self._base_model[0] == _lib.SOURCE_GGD:  # (its weights floor |y|^(2 - beta) per element)
+            require_device_floor(self._resolve_floor(flooring_fn), "ISS2 with the GGD model")
         Y = self._state_dev("output")
         N = Y.shape[1]
         Vc = self._output_statistics(Y, flooring_fn)

@@ -324,6 +324,12 @@ def run_custom_floor(name, *, kind, seed, N, F, T, K=4, n_iter=6, gen=gen_mixtur
     if kind == "ilrma":
         snap = InitialAndFinal(["basis", "activation", "demix_filter", "output"], n_iter)
         m = GaussILRMA(n_basis=K, flooring_fn=custom_floor, callbacks=snap, rng=rng, **kwargs)
+    elif kind == "tilrma":  # (round 6: the t model's weights hold no floor -- IP2 / ISS2 on the device)
+        dof = kwargs.pop("dof")
+        snap = InitialAndFinal(["basis", "activation", "demix_filter", "output"], n_iter)
+        m = TILRMA(n_basis=K, dof=dof, flooring_fn=custom_floor, callbacks=snap, rng=rng, **kwargs)
+        kwargs = dict(kwargs, model="t", model_param=dof)
+        kind = "ilrma"
     elif kind == "iva":
         snap = InitialAndFinal(["demix_filter", "output"], n_iter)
         m = AuxLaplaceIVA(flooring_fn=custom_floor, callbacks=snap, **kwargs)
@@ -787,6 +793,10 @@ def main():
                      spatial_algorithm="ISS")
     run_custom_floor("customfloor_auxgauss_ip2_n3", kind="gaussiva", seed=168, N=3, F=14, T=30,
                      spatial_algorithm="IP2")
+    run_custom_floor("customfloor_tilrma_ip2_n3", kind="tilrma", seed=169, N=3, F=14, T=30, dof=5.0,
+                     spatial_algorithm="IP2")
+    run_custom_floor("customfloor_tilrma_iss2_n3", kind="tilrma", seed=170, N=3, F=14, T=30, dof=5.0,
+                     spatial_algorithm="ISS2")
     # --- more than 8 sources (the reference takes n_sources from input.shape without a limit) ---
     run_ilrma("gilrma_ip1_n10", N=10, F=12, T=80, K=3, algo="IP", seed=160, gen=gen_mixture, n_iter=6)
     run_ilrma("gilrma_iss1_n9_p1", N=9, F=10, T=72, K=2, algo="ISS", seed=161, domain=1, n_iter=6)

@@ -2524,7 +2524,8 @@ def _golden_custom_floor(x):
                                   "customfloor_gilrma_part_ip1_n3", "customfloor_gilrma_part_iss1_n2",
                                   "customfloor_auxlap_ip2_n3", "customfloor_auxlap_iss2_n3",
                                   "customfloor_auxgauss_ip1_n3", "customfloor_auxgauss_iss1_n2",
-                                  "customfloor_auxgauss_ip2_n3", "customfloor_fmnmf_m3"])
+                                  "customfloor_auxgauss_ip2_n3", "customfloor_fmnmf_m3",
+                                  "customfloor_tilrma_ip2_n3", "customfloor_tilrma_iss2_n3"])
 def test_arbitrary_flooring_callable_against_golden(case):
     """``flooring_fn`` may be any callable in the reference (ssspy/bss/ilrma.py:70-89).  One that is
     none of the three built-in floors is evaluated on the host on the small arrays it acts on (basis,
@@ -2533,7 +2534,8 @@ def test_arbitrary_flooring_callable_against_golden(case):
     _replay_uninjected(load_golden(case), flooring_fn=_golden_custom_floor)
 
 
-@pytest.mark.parametrize("kind", ["ilrma_ip", "ilrma_iss", "tilrma_ip", "auxiva_ip", "auxiva_iss"])
+@pytest.mark.parametrize("kind", ["ilrma_ip", "ilrma_iss", "tilrma_ip", "tilrma_ip2", "tilrma_iss2",
+                                  "auxiva_ip", "auxiva_iss"])
 def test_host_evaluated_floor_equals_the_kernel_floor(kind):
     """A callable the kernels do not recognise but that computes max(x, eps) takes the host path
     (split steps, floor on the small arrays); the recognised ``max_flooring`` runs inside the
@@ -2558,6 +2560,9 @@ def test_host_evaluated_floor_equals_the_kernel_floor(kind):
             return GaussILRMA(n_basis=6, spatial_algorithm="ISS", flooring_fn=floor, rng=rng)
         if kind == "tilrma_ip":
             return TILRMA(n_basis=6, dof=4.0, flooring_fn=floor, rng=rng)
+        if kind in ("tilrma_ip2", "tilrma_iss2"):  # (round 6: the t weights hold no floor)
+            return TILRMA(n_basis=6, dof=4.0, spatial_algorithm=kind[7:].upper(), flooring_fn=floor,
+                          rng=rng)
         return AuxLaplaceIVA(spatial_algorithm="IP" if kind.endswith("ip") else "ISS",
                              flooring_fn=floor)
 
@@ -2578,9 +2583,14 @@ def test_arbitrary_flooring_callable_unsupported_paths_fail_loudly():
         GaussILRMA(n_basis=2, spatial_algorithm="IPA", flooring_fn=_golden_custom_floor)(X, n_iter=1)
     from ssspy_amd.bss.ilrma import TILRMA
 
-    with pytest.raises(NotImplementedError, match="heavy-tailed"):
-        TILRMA(n_basis=2, dof=4.0, spatial_algorithm="IP2",
-               flooring_fn=_golden_custom_floor)(X, n_iter=1)
+    from ssspy_amd.bss.ilrma import GGDILRMA
+
+    # (the t model's weights hold no floor: TILRMA takes any callable with IP2 / ISS2 since round 6;
+    #  GGD's floor |y|^(2 - beta) per element of the spectrogram)
+    TILRMA(n_basis=2, dof=4.0, spatial_algorithm="IP2", flooring_fn=_golden_custom_floor)(X, n_iter=1)
+    with pytest.raises(NotImplementedError, match="GGD"):
+        GGDILRMA(n_basis=2, beta=1.0, spatial_algorithm="IP2",
+                 flooring_fn=_golden_custom_floor)(X, n_iter=1)
     from ssspy_amd.bss.mnmf import GaussMNMF
 
     with pytest.raises(NotImplementedError, match="GaussMNMF"):
