@@ -374,6 +374,16 @@ int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *act
                            int source_model, double model_param, int floor_kind, double floor_eps,
                            void *stream);
 
+/* The same from the POWER of the separated spectrogram, Ypow (B,N,F,T) f64 = |y|^2, instead of y.
+ * Also the seam for a flooring callable the kernels do not know on GGD's weights (round 6): the
+ * reference floors |y|^(2 - beta) per element (ssspy/bss/ilrma.py:3993-3995, :4123-4125); the
+ * binding evaluates q = |y|^(2 - beta) and the callable on the host and hands in
+ * Ypow = callable(q)^(2 / (2 - beta)) with SSSPY_FLOOR_NONE. */
+int ssspy_ilrma_iss_weight_power(const double *Ypow, const double *basis, const double *activation,
+                                 double *varphi, int B, int N, int F, int T, int K, double domain,
+                                 int source_model, double model_param, int floor_kind,
+                                 double floor_eps, void *stream);
+
 /* out[b] = sum_{n,i} mean_j ( data term of the model + (2/p) log R ), y = W x (or x when
  * W == NULL); `out` (B doubles) is overwritten.  The caller adds -2 * ssspy_sum_logdet.
  * The per-workgroup shares are parked in `workspace` (ssspy_ilrma_loss_workspace_bytes for this

@@ -82,6 +82,7 @@ PROTOTYPES = {
     "ssspy_ilrma_normalize_output_tracked": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p, _z,
                                                   _p, _p]),
     "ssspy_ilrma_iss_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _i, _d, _p]),
+    "ssspy_ilrma_iss_weight_power": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _i, _d, _p]),
     "ssspy_ilrma_loss_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "ssspy_ilrma_loss_data": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _p, _z, _p]),
     "ssspy_ilrma_ip1_update": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _d, _i, _i, _d,

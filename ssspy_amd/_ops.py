@@ -488,11 +488,21 @@ def ilrma_normalize_output(Y, basis, domain, flooring, ws, ws_bytes, frame_power
     )
 
 
-def ilrma_iss_weight(basis, activation, domain, out=None, Y=None, model=GAUSS, flooring=(0, 0.0)):
+def ilrma_iss_weight(basis, activation, domain, out=None, Y=None, model=GAUSS, flooring=(0, 0.0),
+                     Ypow=None):
+    """Ypow: |y|^2 (B, N, F, T) float64 handed in instead of y (ssspy_ilrma_iss_weight_power)."""
     B, N, F, K = basis.shape
     T = activation.shape[-1]
     if out is None:
         out = dv.empty((B, N, F, T), dv.f64, basis.device)
+    if Ypow is not None:
+        _lib.check(
+            _L().ssspy_ilrma_iss_weight_power(ptr(Ypow), ptr(basis), ptr(activation), ptr(out), B, N,
+                                              F, T, K, domain, model[0], model[1], flooring[0],
+                                              flooring[1], _st()),
+            "ilrma_iss_weight_power",
+        )
+        return out
     _lib.check(
         _L().ssspy_ilrma_iss_weight(ptr(Y), ptr(basis), ptr(activation), ptr(out), B, N, F, T, K,
                                     domain, model[0], model[1], flooring[0], flooring[1], _st()),

@@ -542,10 +542,11 @@ class _MMILRMA(ILRMABase):
         B, N, F, T = Y.shape
         Vc = self._output_statistics(Y, flooring_fn)
         if Vc is None:
-            if self._base_model[0] == _lib.SOURCE_GGD:  # (its weights floor |y|^(2 - beta) per element)
-                require_device_floor(floor, "ISS2 with the GGD model")
-            varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y,
-                                           model=self._model, flooring=floor)
+            if self._ggd_host_floor(flooring_fn):
+                varphi = self._ggd_weights_host_floor(Y, floor)
+            else:
+                varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y,
+                                               model=self._model, flooring=floor)
             Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
         if self.spatial_algorithm in _ISS1:
             G = _ops.iss1_transform(Vc, floor)
@@ -807,19 +808,44 @@ class _MMILRMA(ILRMABase):
                                        flooring=floor)
         return self._Vc
 
+    def _ggd_weights_host_floor(self, Y, floor):
+        """varphi (B, N, F, T) of the GGD model for a flooring callable the kernels do not know
+        (round 6).  The reference floors q = |y|^(2 - beta) per element before it forms
+        1 / ((2 / beta) q (T V)^(beta / p)) (ssspy/bss/ilrma.py:3993-4011, :4123-4141): q and the
+        callable are evaluated on the host, one mixture -- the reference's (N, F, T) array -- at a
+        time, and the weight kernel takes floor(q)^(2 / (2 - beta)) in place of |y|^2 with its own
+        floor off: one spectrogram down and one real array up per update, the price of an opaque
+        Python callable."""
+        beta = float(self.beta)
+        Yh = dv.to_host(Y)
+        q = np.abs(Yh) ** (2.0 - beta)
+        fq = np.stack([np.asarray(floor.host(qb), dtype=np.float64) for qb in q])
+        if fq.shape != q.shape:
+            raise ValueError("flooring_fn must return an array of the shape it was given")
+        ypow = dv.to_device(fq ** (2.0 / (2.0 - beta)), dtype=np.float64, dev=Y.device)
+        return _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), model=self._model,
+                                     flooring=(_lib.FLOOR_NONE, 0.0), Ypow=ypow)
+
+    def _ggd_host_floor(self, flooring_fn) -> bool:
+        return (self._base_model[0] == _lib.SOURCE_GGD
+                and host_floor(self._resolve_floor(flooring_fn)) is not None)
+
     def update_spatial_model_ip2(self, flooring_fn="self") -> None:
         """Weighted covariance + pairwise iterative projection.  ref: ssspy/bss/ilrma.py:1509-1633."""
         # (the t model's weights hold no floor, ssspy/bss/ilrma.py:2915-2935; GGD's floor
-        #  |y|^(2 - beta) per element, :3987-4011)
-        if self._base_model[0] == _lib.SOURCE_GGD:
-            require_device_floor(self._resolve_floor(flooring_fn), "IP2 with the GGD model")
+        #  |y|^(2 - beta) per element, :3987-4011: a callable goes through _ggd_weights_host_floor)
         B, N, F, T = self._X.shape
-        if self._U is None:
-            self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
-        _ops.ilrma_weighted_covariance(self._X, *self._nmf_pair(), float(self.domain),
-                                       self._ws, self._ws_bytes, out=self._U,
-                                       W=self._state_dev("demix_filter"), model=self._model,
-                                       flooring=self._resolve_floor(flooring_fn))
+        if self._ggd_host_floor(flooring_fn):
+            Y = _ops.separate(self._X, self._state_dev("demix_filter"))
+            varphi = self._ggd_weights_host_floor(Y, self._resolve_floor(flooring_fn))
+            self._U = _ops.weighted_covariance(self._X, varphi, _lib.WEIGHT_BIN_FRAME, N)
+        else:
+            if self._U is None:
+                self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
+            _ops.ilrma_weighted_covariance(self._X, *self._nmf_pair(), float(self.domain),
+                                           self._ws, self._ws_bytes, out=self._U,
+                                           W=self._state_dev("demix_filter"), model=self._model,
+                                           flooring=self._resolve_floor(flooring_fn))
         _ops.update_by_ip2(self._state_dev("demix_filter"), self._U,
                            resolve_pairs(getattr(self, "pair_selector", None), N),
                            self._resolve_floor(flooring_fn), self._info_tensor())
@@ -827,15 +853,16 @@ class _MMILRMA(ILRMABase):
 
     def update_spatial_model_iss2(self, flooring_fn="self") -> None:
         """Pairwise iterative source steering on per-bin statistics.  ref: ilrma.py:1698-1792."""
-        if self._base_model[0] == _lib.SOURCE_GGD:  # (its weights floor |y|^(2 - beta) per element)
-            require_device_floor(self._resolve_floor(flooring_fn), "ISS2 with the GGD model")
         Y = self._state_dev("output")
         N = Y.shape[1]
         Vc = self._output_statistics(Y, flooring_fn)
         if Vc is None:
-            varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y,
-                                           model=self._model,
-                                           flooring=self._resolve_floor(flooring_fn))
+            if self._ggd_host_floor(flooring_fn):
+                varphi = self._ggd_weights_host_floor(Y, self._resolve_floor(flooring_fn))
+            else:
+                varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y,
+                                               model=self._model,
+                                               flooring=self._resolve_floor(flooring_fn))
             Vc = _ops.weighted_covariance(Y, varphi, _lib.WEIGHT_BIN_FRAME, N)
         G = _ops.iss2_transform(Vc, resolve_pairs(getattr(self, "pair_selector", None), N),
                                 self._resolve_floor(flooring_fn), self._info_tensor())
@@ -844,15 +871,18 @@ class _MMILRMA(ILRMABase):
 
     def update_spatial_model_ip1(self, flooring_fn="self") -> None:
         """Weighted covariance + iterative projection.  ref: ssspy/bss/ilrma.py:1440-1507."""
-        if self._base_model[0] == _lib.SOURCE_GGD:  # (its weights floor |y|^(2 - beta) per element)
-            require_device_floor(self._resolve_floor(flooring_fn), "GGD-ILRMA")
         B, N, F, T = self._X.shape
-        if self._U is None:
-            self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
-        _ops.ilrma_weighted_covariance(self._X, *self._nmf_pair(), float(self.domain),
-                                       self._ws, self._ws_bytes, out=self._U,
-                                       W=self._state_dev("demix_filter"), model=self._model,
-                                       flooring=self._resolve_floor(flooring_fn))
+        if self._ggd_host_floor(flooring_fn):  # (its weights floor |y|^(2 - beta) per element)
+            Y = _ops.separate(self._X, self._state_dev("demix_filter"))
+            varphi = self._ggd_weights_host_floor(Y, self._resolve_floor(flooring_fn))
+            self._U = _ops.weighted_covariance(self._X, varphi, _lib.WEIGHT_BIN_FRAME, N)
+        else:
+            if self._U is None:
+                self._U = dv.empty((B, F, N, N, N), dv.c128, self._X.device)
+            _ops.ilrma_weighted_covariance(self._X, *self._nmf_pair(), float(self.domain),
+                                           self._ws, self._ws_bytes, out=self._U,
+                                           W=self._state_dev("demix_filter"), model=self._model,
+                                           flooring=self._resolve_floor(flooring_fn))
         _ops.update_by_ip1(self._state_dev("demix_filter"), self._U,
                            self._resolve_floor(flooring_fn), self._info_tensor())
         self._state_touch("demix_filter")
@@ -861,13 +891,14 @@ class _MMILRMA(ILRMABase):
         """Iterative source steering on per-bin statistics.  ref: ssspy/bss/ilrma.py:1635-1696."""
         Y = self._state_dev("output")
         N = Y.shape[1]
-        varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y, model=self._model,
-                                       flooring=self._resolve_floor(flooring_fn))
         floor = self._resolve_floor(flooring_fn)
+        if self._ggd_host_floor(flooring_fn):
+            varphi = self._ggd_weights_host_floor(Y, floor)
+        else:
+            varphi = _ops.ilrma_iss_weight(*self._nmf_pair(), float(self.domain), Y=Y,
+                                           model=self._model, flooring=floor)
         frame_power = None
         if host_floor(floor) is not None:
-            if self._base_model[0] == _lib.SOURCE_GGD:
-                require_device_floor(floor, "GGD-ILRMA")
             tracked = None
             _ops.update_by_iss1_host_floor(Y, varphi, _lib.WEIGHT_BIN_FRAME, floor.host)
         elif Y.shape[-1] <= _ops.iss1_fused_max_frames(N):

@@ -1082,6 +1082,22 @@ int ssspy_ilrma_normalize_output_tracked(void *Y, double *basis, const double *f
                                workspace, workspace_bytes, logdet, stream);
 }
 
+int ssspy_ilrma_iss_weight_power(const double *Ypow, const double *basis, const double *activation,
+                                 double *varphi, int B, int N, int F, int T, int K, double domain,
+                                 int source_model, double model_param, int floor_kind,
+                                 double floor_eps, void *stream) {
+  SSSPY_REQUIRE(Ypow && basis && activation && varphi && B > 0, "iss_weight_power: bad argument");
+  int rc = check_model(source_model, model_param, domain);
+  if (rc) return rc;
+  const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
+  const int chunks = iss_weight_chunks(B, N, F, T);
+  dim3 grid(((F + 63) / 64) * chunks, N, B), block(256);
+  hipLaunchKernelGGL(k_ilrma_iss_weight<false>, grid, block, 0, as_stream(stream),
+                     (const c128 *)nullptr, Ypow, basis, activation, varphi, N, d, chunks,
+                     (double *)nullptr);
+  return check_launch("k_ilrma_iss_weight");
+}
+
 int ssspy_ilrma_iss_weight(const void *Y, const double *basis, const double *activation,
                            double *varphi, int B, int N, int F, int T, int K, double domain,
                            int source_model, double model_param, int floor_kind, double floor_eps,

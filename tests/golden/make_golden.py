@@ -330,6 +330,12 @@ def run_custom_floor(name, *, kind, seed, N, F, T, K=4, n_iter=6, gen=gen_mixtur
         m = TILRMA(n_basis=K, dof=dof, flooring_fn=custom_floor, callbacks=snap, rng=rng, **kwargs)
         kwargs = dict(kwargs, model="t", model_param=dof)
         kind = "ilrma"
+    elif kind == "ggdilrma":  # (round 6: GGD floors |y|^(2 - beta) per element of the spectrogram)
+        beta = kwargs.pop("beta")
+        snap = InitialAndFinal(["basis", "activation", "demix_filter", "output"], n_iter)
+        m = GGDILRMA(n_basis=K, beta=beta, flooring_fn=custom_floor, callbacks=snap, rng=rng, **kwargs)
+        kwargs = dict(kwargs, model="ggd", model_param=beta)
+        kind = "ilrma"
     elif kind == "iva":
         snap = InitialAndFinal(["demix_filter", "output"], n_iter)
         m = AuxLaplaceIVA(flooring_fn=custom_floor, callbacks=snap, **kwargs)
@@ -796,6 +802,14 @@ def main():
     run_custom_floor("customfloor_tilrma_ip2_n3", kind="tilrma", seed=169, N=3, F=14, T=30, dof=5.0,
                      spatial_algorithm="IP2")
     run_custom_floor("customfloor_tilrma_iss2_n3", kind="tilrma", seed=170, N=3, F=14, T=30, dof=5.0,
+                     spatial_algorithm="ISS2")
+    run_custom_floor("customfloor_ggdilrma_ip1_n3", kind="ggdilrma", seed=171, N=3, F=14, T=30, beta=1.0,
+                     spatial_algorithm="IP")
+    run_custom_floor("customfloor_ggdilrma_iss1_n2", kind="ggdilrma", seed=172, N=2, F=15, T=28, beta=1.5,
+                     spatial_algorithm="ISS")
+    run_custom_floor("customfloor_ggdilrma_ip2_n3", kind="ggdilrma", seed=173, N=3, F=14, T=30, beta=0.7,
+                     spatial_algorithm="IP2")
+    run_custom_floor("customfloor_ggdilrma_iss2_n3", kind="ggdilrma", seed=174, N=3, F=14, T=30, beta=1.0,
                      spatial_algorithm="ISS2")
     # --- more than 8 sources (the reference takes n_sources from input.shape without a limit) ---
     run_ilrma("gilrma_ip1_n10", N=10, F=12, T=80, K=3, algo="IP", seed=160, gen=gen_mixture, n_iter=6)

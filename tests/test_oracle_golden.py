@@ -395,7 +395,9 @@ CUSTOM_FLOOR_CASES = ["customfloor_gilrma_ip1_n3", "customfloor_gilrma_iss1_n2",
                       "customfloor_auxlap_ip2_n3", "customfloor_auxlap_iss2_n3",
                       "customfloor_auxgauss_ip1_n3", "customfloor_auxgauss_iss1_n2",
                       "customfloor_auxgauss_ip2_n3",
-                      "customfloor_tilrma_ip2_n3", "customfloor_tilrma_iss2_n3"]
+                      "customfloor_tilrma_ip2_n3", "customfloor_tilrma_iss2_n3",
+                      "customfloor_ggdilrma_ip1_n3", "customfloor_ggdilrma_iss1_n2",
+                      "customfloor_ggdilrma_ip2_n3", "customfloor_ggdilrma_iss2_n3"]
 
 
 def _oracle_for(g, flooring=sp.DEFAULT_FLOOR):
