@@ -68,8 +68,9 @@ enum { SSSPY_SOURCE_ME = 0x100 };
 #define SSSPY_MAX_SOURCES 8 /* kernels compiled per source count (everything in registers) */
 /* Above that, up to SSSPY_RT_MAX_SOURCES, the shared operators, the AuxIVA entry points and the ILRMA
  * iteration on the Gauss model's tuned passes run with the source count at run time (wide_n.hip:
- * correct, not tuned; the reference has no limit: ssspy/bss/ilrma.py:180, iva.py:152).  IPA, the MNMF
- * entry points and the Hermitian operators stay at SSSPY_MAX_SOURCES. */
+ * correct, not tuned; the reference has no limit: ssspy/bss/ilrma.py:180, iva.py:152), IPA included
+ * (ssspy_ipa_sweep, ipa_rt.hip, round 6).  The MNMF entry points, the Hermitian operators and the
+ * standalone ssspy_lqpqm2 stay at SSSPY_MAX_SOURCES. */
 #define SSSPY_RT_MAX_SOURCES 16
 /* n_basis: the kernels walk any number of bases (dense products above 32; checked against the
  * oracle at 1500 and 3000); the bound only keeps 32-bit index arithmetic safe.  Up to round 5: 1024. */
@@ -457,7 +458,9 @@ int ssspy_fold_scalar_slots(const double *slots, long long total, int nslots, do
 
 /* IPA (iterative projection with adjustment): a whole sweep on per-bin statistics (round 5; the
  * per-source entry point ssspy_ipa_transform of rounds 3-5 went in round 6 with its 81 kernel
- * instantiations).  n_sources in [2, 8].  Vc (B,F,N,N,N) = ssspy_weighted_covariance(Y,
+ * instantiations).  n_sources in [2, 16]: a lane per bin up to 6 sources, a bin on 8 lanes at 7 / 8,
+ * and above 8 a lane per bin with the source count at run time and its working set in scratch
+ * memory (ipa_rt.hip, round 6: correct, not tuned).  Vc (B,F,N,N,N) = ssspy_weighted_covariance(Y,
  * weight) of the spectrogram BEFORE the sweep (overwritten: after source step s it holds
  * G_s Vc G_s^H, the covariances of the spectrogram the reference would have formed by then); G
  * (B,F,N,N) <- G_{N-1} ... G_0.  The caller applies ssspy_separate(Y, G) once: three passes over Y per

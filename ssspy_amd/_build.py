@@ -52,6 +52,7 @@ def _units():
         ("gmnmf_rows.hip", "gmnmf_rows.o", []),
         ("ipa_kernels.hip", "ipa_kernels.o", []),
         ("ipa_rows.hip", "ipa_rows.o", []),
+        ("ipa_rt.hip", "ipa_rt.o", []),
         ("stft_kernels.hip", "stft_kernels.o", []),
         ("hermitian_ops.hip", "hermitian_ops.o", []),
         ("hermitian_rows.hip", "hermitian_rows.o", []),

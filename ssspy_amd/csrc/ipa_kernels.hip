@@ -649,6 +649,11 @@ int ipa_rows_sweep(bool votes, void *Vc, void *G, int B, int F, int N, int norma
                    int max_iter, int floor_kind, double eps, int *info, unsigned long long *ws,
                    int *not_converged, hipStream_t st);
 int ipa_rows_barrier_timeouts();
+// ipa_rt.hip: 9..16 sources with the source count at run time (a lane per bin, scratch-resident)
+int ipa_rt_sweep(bool votes, void *Vc, void *G, int B, int F, int N, int normalization,
+                 int max_iter, int floor_kind, double eps, int *info, unsigned long long *ws,
+                 int *not_converged, hipStream_t st);
+int ipa_rt_barrier_timeouts();
 
 }  // namespace ssspy
 
@@ -659,8 +664,8 @@ extern "C" int ssspy_ipa_sweep(void *Vc, void *G, int B, int F, int N, int norma
                                void *newton_ws, int *not_converged, void *stream) {
   SSSPY_REQUIRE(Vc && G && B > 0 && F > 0, "ipa_sweep: bad argument");
   SSSPY_REQUIRE(max_iter >= 0, "ipa_sweep: max_iter must be non-negative");
-  if (N < 2 || N > SSSPY_MAX_SOURCES)
-    return fail(SSSPY_ERR_UNSUPPORTED, "IPA is built for n_sources in [2, 8]");
+  if (N < 2 || N > SSSPY_RT_MAX_SOURCES)
+    return fail(SSSPY_ERR_UNSUPPORTED, "IPA is built for n_sources in [2, 16]");
   // one launch for the whole sweep: a lane per bin up to 6 sources (k_ipa_sweep_fused), a bin on 8
   // lanes at 7 and 8 (k_ipa_rows)
   hipStream_t st = as_stream(stream);
@@ -671,6 +676,9 @@ extern "C" int ssspy_ipa_sweep(void *Vc, void *G, int B, int F, int N, int norma
     const int rc = check_launch("k_ipa_sweep_prepare");
     if (rc) return rc;
   }
+  if (N > SSSPY_MAX_SOURCES)
+    return ipa_rt_sweep(votes, Vc, G, B, F, N, normalization, max_iter, floor_kind, floor_eps, info,
+                        ws, not_converged, st);
   if (ipa_rows_wanted(N))
     return ipa_rows_sweep(votes, Vc, G, B, F, N, normalization, max_iter, floor_kind, floor_eps,
                           info, ws, not_converged, st);
@@ -700,8 +708,8 @@ extern "C" int ssspy_debug_barrier_timeouts(void) {
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ipa_barrier_timeouts), sizeof(int), 0,
                           hipMemcpyDeviceToHost) != hipSuccess)
     return -1;
-  const int rows = ipa_rows_barrier_timeouts();
-  return rows < 0 ? -1 : v + rows;
+  const int rows = ipa_rows_barrier_timeouts(), rt = ipa_rt_barrier_timeouts();
+  return (rows < 0 || rt < 0) ? -1 : v + rows + rt;
 }
 
 static int lqpqm2_launch(const void *H, const void *v, const double *z, void *y, long long n, int L,

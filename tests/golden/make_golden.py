@@ -824,6 +824,12 @@ def main():
     run_iva("auxlap_ip2_n9", N=9, F=8, T=72, algo="IP2", contrast="laplace", seed=171, n_iter=4)
     run_iva("auxlap_iss2_n12", N=12, F=6, T=96, algo="ISS2", contrast="laplace", seed=172,
             gen=gen_mixture, n_iter=4)
+    # (round 6: IPA with the source count at run time, ipa_rt.hip)
+    run_ilrma("gilrma_ipa_n9", N=9, F=7, T=108, K=2, algo="IPA", seed=175, gen=gen_mixture, n_iter=4)
+    run_ilrma("gilrma_ipa_n12_add", N=12, F=5, T=132, K=2, algo="IPA", seed=176, gen=gen_mixture, n_iter=3,
+              flooring=("add", 1e-9), newton_iter=3)
+    run_iva("auxlap_ipa_n10", N=10, F=6, T=110, algo="IPA", contrast="laplace", seed=177,
+            gen=gen_mixture, n_iter=4)
     # --- 3 / 4 sources with at least 16 frames per source (round 6): the device build runs these
     #     ISS / ISS2 / IPA iterations through the filters the updates imply (W <- G W, statistics
     #     W U W^H) -- reference vectors for that route, ISS1 on a batch-sized number of bins

@@ -33,7 +33,7 @@ ILRMA_CASES = [
     "gilrma_ipa_newton8_n3",
     "gilrma_mdp_ip1_n3", "gilrma_mdp_iss1_n2", "gilrma_pbnorm_ip1_n3", "gilrma_pbnorm_iss1_n2_p1",
     "gilrma_ip1_n10", "gilrma_iss1_n9_p1",  # above 8 sources: the run-time-N kernels (wide_n.hip)
-    "gilrma_ip2_n9", "gilrma_iss2_n10",
+    "gilrma_ip2_n9", "gilrma_iss2_n10", "gilrma_ipa_n9", "gilrma_ipa_n12_add",
     # 3 / 4 sources, >= 16 frames per source (round 6: the implied-filter route of the device build)
     "gilrma_iss1_n4_t80", "gilrma_iss2_n4_t72", "gilrma_iss2_n3_t64", "gilrma_ipa_n3_t56",
     "gilrma_ipa_n4_t72",
@@ -44,7 +44,7 @@ IVA_CASES = [
     "auxgauss_iss2_n3", "auxlap_ipa_n3", "auxgauss_ipa_n2", "auxlap_mdp_ip1_n3",
     "auxlap_mdp_iss1_n2",
     "auxlap_iss1_n12", "auxlap_ip1_n9", "auxgauss_ip1_n16_mdp",  # above 8 sources (wide_n.hip)
-    "auxlap_ip2_n9", "auxlap_iss2_n12",
+    "auxlap_ip2_n9", "auxlap_iss2_n12", "auxlap_ipa_n10",
     "auxlap_iss2_n4_t72", "auxlap_ipa_n3_t60", "auxgauss_ipa_n4_t70",  # (round 6, see above)
 ]
 
@@ -267,6 +267,40 @@ def test_ipa_above_four_sources_against_oracle(N):
             ref = oracle_ipa(Yin, varphi, **okw)
         # (the unnormalised problem stopped after 3 Newton steps amplifies rounding: 1e-9 at 5
         #  sources; everything else agrees to 1e-12)
+        assert rel_err(a, ref) < 1e-7, kw
+
+
+@pytest.mark.parametrize("N", [9, 13, 16])
+def test_ipa_above_eight_sources_against_oracle(N):
+    """Round 6: IPA with the source count at run time (ipa_rt.hip, 9..16 sources: the reference has no
+    limit, ssspy/bss/ilrma.py:180) against the oracle: the three floors -- the max floor made to act
+    on a tenth of the statistics (eigen route) --, both normalisations, several Newton step counts,
+    and a ragged last block of bins (70 = 64 + 6)."""
+    from oracle.ipa import update_by_ipa as oracle_ipa
+    from ssspy_amd.bss._update_spatial_model import update_by_ipa
+    from ssspy_amd.special.flooring import add_flooring, max_flooring
+
+    rng = np.random.default_rng(170 + N)
+    F, T = (70 if N == 9 else 7), 12 * N
+    Y = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+    varphi = 1.0 / (rng.random((N, F, T)) + 0.05)
+    A = rng.standard_normal((F, N, N)) + 1j * rng.standard_normal((F, N, N))
+    Ymix = 0.1 * np.einsum("fnm,mft->nft", A, Y)
+    YY = Ymix[:, None] * Ymix[None, :].conj()
+    U = np.mean(varphi[:, None, None] * YY, axis=-1).transpose(3, 0, 1, 2)
+    eps_act = float(np.quantile(np.linalg.eigvalsh(U).min(axis=-1), 0.1))
+    cases = ((Y, dict(), dict()),
+             (Y, dict(normalization=False, max_iter=3), dict(normalization=False, max_iter=3)),
+             (Y, dict(flooring_fn=functools.partial(add_flooring, eps=1e-3)),
+              dict(flooring=("add", 1e-3))),
+             (Ymix, dict(flooring_fn=functools.partial(max_flooring, eps=eps_act), max_iter=6),
+              dict(flooring=("max", eps_act), max_iter=6)),
+             (Y, dict(flooring_fn=None), dict(flooring=lambda x: x)))
+    for Yin, kw, okw in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            a = update_by_ipa(Yin, varphi, **kw)
+            ref = oracle_ipa(Yin, varphi, **okw)
         assert rel_err(a, ref) < 1e-7, kw
 
 

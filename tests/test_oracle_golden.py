@@ -31,7 +31,7 @@ ILRMA_CASES = [
     "gilrma_ipa_newton8_n3",
     "gilrma_mdp_ip1_n3", "gilrma_mdp_iss1_n2", "gilrma_pbnorm_ip1_n3", "gilrma_pbnorm_iss1_n2_p1",
     "gilrma_ip1_n10", "gilrma_iss1_n9_p1",  # above 8 sources: the run-time-N kernels (wide_n.hip)
-    "gilrma_ip2_n9", "gilrma_iss2_n10",
+    "gilrma_ip2_n9", "gilrma_iss2_n10", "gilrma_ipa_n9", "gilrma_ipa_n12_add",
     # 3 / 4 sources, >= 16 frames per source (round 6: the implied-filter route of the device build)
     "gilrma_iss1_n4_t80", "gilrma_iss2_n4_t72", "gilrma_iss2_n3_t64", "gilrma_ipa_n3_t56",
     "gilrma_ipa_n4_t72",
@@ -47,7 +47,7 @@ IVA_CASES = [
     "auxgauss_iss2_n3", "auxlap_ipa_n3", "auxgauss_ipa_n2", "auxlap_mdp_ip1_n3",
     "auxlap_mdp_iss1_n2",
     "auxlap_iss1_n12", "auxlap_ip1_n9", "auxgauss_ip1_n16_mdp",  # above 8 sources (wide_n.hip)
-    "auxlap_ip2_n9", "auxlap_iss2_n12",
+    "auxlap_ip2_n9", "auxlap_iss2_n12", "auxlap_ipa_n10",
     "auxlap_iss2_n4_t72", "auxlap_ipa_n3_t60", "auxgauss_ipa_n4_t70",  # (round 6, see above)
 ]
 MNMF_CASES = ["fmnmf_ip1_m3", "fmnmf_ip1_m4", "fmnmf_ip1_m3_n2", "fmnmf_ip1_m2_nonorm",
