@@ -271,9 +271,11 @@ int ssspy_demix_from_covariance(const void *YX, const void *XX, void *W, int B, 
 int ssspy_sum_logdet(const void *W, double *out, int B, int F, int N, void *stream);
 
 /* ------------------------------------------------------------------ batched small linear algebra */
-/* Device counterparts of ssspy.linalg / ssspy.special.psd: `n` independent matrices, one per lane. */
+/* Device counterparts of ssspy.linalg / ssspy.special.psd: `n` independent matrices, one per lane.
+ * Sizes up to 8 x 8 are instantiated per size; 9 x 9 .. SSSPY_RT_MAX_SOURCES (16) take the size at
+ * run time (csrc/hermitian_rt.hip: correct, not tuned); larger ones are SSSPY_ERR_UNSUPPORTED. */
 
-/* X = A^-1 B.  A (n,N,N), B (n,N,nrhs), X (n,N,nrhs) complex128; N <= 8; LU with partial pivoting.
+/* X = A^-1 B.  A (n,N,N), B (n,N,nrhs), X (n,N,nrhs) complex128; N <= 16; LU with partial pivoting.
  * replaces: ssspy/linalg/_solve.py:9-21 (np.linalg.solve). */
 int ssspy_solve(const void *A, const void *Bm, void *X, long long n, int N, int nrhs, int *info,
                 void *stream);
@@ -721,7 +723,8 @@ int ssspy_gmnmf_separate(const void *X, const double *basis, const double *activ
                          int reference_id, int floor_kind, double floor_eps, void *stream);
 
 /* ------------------------------------------------------------------ Hermitian matrix functions
- * One matrix per lane, M in [2, 8]; arrays flattened to (n, M, M) c128.
+ * One matrix per lane, M in [2, 16] (9 .. 16: the size at run time, csrc/hermitian_rt.hip); arrays
+ * flattened to (n, M, M) c128.
  * generalised eigh through the Cholesky factor of B, eigenvalues ascending -> lamb (n, M), Z (n, M, M):
  *   type 1: A z = lamb B z; 2: A B z = lamb z; 3: B A z = lamb z.   replaces: ssspy/linalg/eigh.py:8-81, :164-207 */
 int ssspy_eigh_general(const void *A, const void *Bm, double *lamb, void *Z, long long n, int M,
@@ -733,7 +736,8 @@ int ssspy_sqrtmh(const void *X, void *out, long long n, int M, int inverse, int 
 int ssspy_gmeanmh(const void *A, const void *Bm, void *G, long long n, int M, int type,
                   void *stream);
 /* y = argmin of the log-quadratically penalised quadratic (type 2): H (n, L, L) Hermitian, v (n, L),
- * z (n) -> y (n, L), L in [1, 7].  newton_ws (one 64-bit word of scratch) / not_converged: as for
+ * z (n) -> y (n, L), L in [1, 15] (8 .. 15: the dimension at run time, csrc/ipa_rt.hip).
+ * newton_ws (one 64-bit word of scratch) / not_converged: as for
  * ssspy_ipa_sweep, the n problems forming one group (the reference's loop stops when all of them
  * have converged); NULL: max_iter Newton steps per problem.
  * replaces: ssspy/linalg/lqpqm.py:13-352 (lqpqm2 with singular_fn = "x < flooring_fn(0)"). */

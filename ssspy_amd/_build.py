@@ -53,6 +53,7 @@ def _units():
         ("ipa_kernels.hip", "ipa_kernels.o", []),
         ("ipa_rows.hip", "ipa_rows.o", []),
         ("ipa_rt.hip", "ipa_rt.o", []),
+        ("hermitian_rt.hip", "hermitian_rt.o", []),
         ("stft_kernels.hip", "stft_kernels.o", []),
         ("hermitian_ops.hip", "hermitian_ops.o", []),
         ("hermitian_rows.hip", "hermitian_rows.o", []),

@@ -18,6 +18,15 @@ int gmeanmh_rows(const void *A, const void *Bm, void *G, long long n, int M, int
 int eigh_general_rows(const void *A, const void *Bm, double *lamb, void *Z, long long n, int M,
                       int type, int *info, hipStream_t st);
 
+// hermitian_rt.hip: 9 x 9 .. 16 x 16, the size at run time
+bool hermitian_rt_wanted(int M);
+int eigh_general_rt(const void *A, const void *Bm, double *lamb, void *Z, long long n, int M,
+                    int type, int *info, hipStream_t st);
+int sqrtmh_rt(const void *X, void *out, long long n, int M, int mode, int floor_kind, double eps,
+              hipStream_t st);
+int gmeanmh_rt(const void *A, const void *Bm, void *G, long long n, int M, int type,
+               hipStream_t st);
+
 // lower Cholesky factor of a Hermitian positive definite matrix, in place (upper part zeroed)
 template <int M>
 __device__ __forceinline__ bool cholesky_lower(c128 (&A)[M][M]) {
@@ -205,6 +214,8 @@ int ssspy_eigh_general(const void *A, const void *Bm, double *lamb, void *Z, lon
                        int type, int *info, void *stream) {
   SSSPY_REQUIRE(A && Bm && lamb && Z && n > 0, "eigh_general: bad argument");
   SSSPY_REQUIRE(type >= 1 && type <= 3, "eigh_general: type must be 1, 2 or 3");
+  if (hermitian_rt_wanted(M))
+    return eigh_general_rt(A, Bm, lamb, Z, n, M, type, info, as_stream(stream));
   if (hermitian_rows_wanted(M, 7))
     return eigh_general_rows(A, Bm, lamb, Z, n, M, type, info, as_stream(stream));
   dim3 grid((unsigned)((n + 63) / 64)), block(64);
@@ -217,6 +228,8 @@ int ssspy_eigh_general(const void *A, const void *Bm, double *lamb, void *Z, lon
 int ssspy_sqrtmh(const void *X, void *out, long long n, int M, int inverse, int floor_kind,
                  double floor_eps, void *stream) {
   SSSPY_REQUIRE(X && out && n > 0, "sqrtmh: bad argument");
+  if (hermitian_rt_wanted(M))
+    return sqrtmh_rt(X, out, n, M, inverse ? 1 : 0, floor_kind, floor_eps, as_stream(stream));
   if (hermitian_rows_wanted(M, 7))
     return sqrtmh_rows(X, out, n, M, inverse ? 1 : 0, floor_kind, floor_eps, as_stream(stream));
   dim3 grid((unsigned)((n + 63) / 64)), block(64);
@@ -230,6 +243,7 @@ int ssspy_gmeanmh(const void *A, const void *Bm, void *G, long long n, int M, in
                   void *stream) {
   SSSPY_REQUIRE(A && Bm && G && n > 0, "gmeanmh: bad argument");
   SSSPY_REQUIRE(type >= 1 && type <= 3, "gmeanmh: type must be 1, 2 or 3");
+  if (hermitian_rt_wanted(M)) return gmeanmh_rt(A, Bm, G, n, M, type, as_stream(stream));
   if (hermitian_rows_wanted(M, 7)) return gmeanmh_rows(A, Bm, G, n, M, type, as_stream(stream));
   dim3 grid((unsigned)((n + 63) / 64)), block(64);
   DISPATCH_N6(M, hipLaunchKernelGGL((k_gmeanmh<NN>), grid, block, 0, as_stream(stream),

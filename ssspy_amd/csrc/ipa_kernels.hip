@@ -62,12 +62,12 @@ __device__ __forceinline__ void lqpqm2(c128 (&H)[L][L], const c128 (&v)[L], doub
   // singular_override: the caller evaluated the reference's singular_fn on ||v|| itself (None:
   // x == 0, or any callable; lqpqm.py:61-78); -1: the default "x < flooring_fn(0)"
   const bool is_singular = singular_override < 0 ? sqrt(vnorm2) < f0 : singular_override != 0;
-  if (is_singular) {
-    // v = 0.  The reference returns scale * sigma[:, -1] taken on the (n_bins, L, L) eigenvector
-    // array (lqpqm.py:84-93), i.e. the LAST ROW of each eigenvector matrix in ascending-eigenvalue
-    // column order, not its last column: component a is the last entry of the eigenvector of the
-    // a-th smallest eigenvalue (every entry with that eigenvector's arbitrary phase).  Followed
-    // literally -- the moduli are what parity can pin.
+  // v = 0.  The reference returns scale * sigma[:, -1] taken on the (n_bins, L, L) eigenvector
+  // array (lqpqm.py:84-93), i.e. the LAST ROW of each eigenvector matrix in ascending-eigenvalue
+  // column order, not its last column: component a is the last entry of the eigenvector of the
+  // a-th smallest eigenvalue (every entry with that eigenvector's arbitrary phase).  Followed
+  // literally -- the moduli are what parity can pin.
+  auto singular_solution = [&]() {
     double pmax = phi[0];
 #pragma unroll
     for (int l = 1; l < L; ++l) pmax = fmax(pmax, phi[l]);
@@ -85,7 +85,12 @@ __device__ __forceinline__ void lqpqm2(c128 (&H)[L][L], const c128 (&v)[L], doub
       for (int a = 0; a < L; ++a)
         if (a == rank) y[a] = val;
     }
-    if (mode == NEWTON_FUSED) vote(0ull, false);
+  };
+  // NEWTON_FUSED: a singular lane walks through the Newton arithmetic with the others (its numbers
+  // are not used) so that the wave meets at ONE vote -- with a vote of its own in this branch, a
+  // wave whose lane 0 is singular handed in the singular lanes' empty ballot and lost the rest's.
+  if (is_singular && mode != NEWTON_FUSED) {
+    singular_solution();
     return;
   }
   c128 vt[L];  // sigma^H v
@@ -146,7 +151,11 @@ __device__ __forceinline__ void lqpqm2(c128 (&H)[L][L], const c128 (&v)[L], doub
     lamb = mu > 1.0 ? mu : 0.5 * (1.0 + lamb);
   }
   if (mode == NEWTON_FUSED) {
-    const int agreed = vote(bits, true);
+    const int agreed = vote(bits, !is_singular);
+    if (is_singular) {
+      singular_solution();
+      return;
+    }
     if (agreed != steps) {  // (the mixture converged early: the reference stopped there)
       lamb = lamb0;
       for (int it = 0; it < agreed; ++it) {
@@ -654,6 +663,9 @@ int ipa_rt_sweep(bool votes, void *Vc, void *G, int B, int F, int N, int normali
                  int max_iter, int floor_kind, double eps, int *info, unsigned long long *ws,
                  int *not_converged, hipStream_t st);
 int ipa_rt_barrier_timeouts();
+int lqpqm2_rt(int mode, const void *H, const void *v, const double *z, void *y, long long n, int L,
+              int max_iter, int floor_kind, double eps, unsigned long long *word,
+              const int *singular, hipStream_t st);
 
 }  // namespace ssspy
 
@@ -716,11 +728,25 @@ static int lqpqm2_launch(const void *H, const void *v, const double *z, void *y,
                          int max_iter, int floor_kind, double floor_eps, void *newton_ws,
                          int *not_converged, const int *singular, void *stream) {
   SSSPY_REQUIRE(H && v && z && y && n > 0 && max_iter >= 0, "lqpqm2: bad argument");
-  if (L < 1 || L > 7) return fail(SSSPY_ERR_UNSUPPORTED, "lqpqm2: dimension must be in [1, 7]");
+  if (L < 1 || L > SSSPY_RT_MAX_SOURCES - 1)
+    return fail(SSSPY_ERR_UNSUPPORTED, "lqpqm2: dimension must be in [1, 15]");
   dim3 grid((unsigned)((n + 63) / 64)), block(64);
   hipStream_t st = as_stream(stream);
   unsigned long long *ws = (unsigned long long *)newton_ws;
   const bool exact = ws && max_iter >= 1 && max_iter <= 62;
+  if (L > 7) {  // the dimension at run time (ipa_rt.hip)
+    if (!exact)
+      return lqpqm2_rt(NEWTON_FIXED, H, v, z, y, n, L, max_iter, floor_kind, floor_eps, ws, singular,
+                       st);
+    int rc = newton_prepare(ws, 1, st);
+    if (rc) return rc;
+    rc = lqpqm2_rt(NEWTON_PROBE, H, v, z, y, n, L, max_iter, floor_kind, floor_eps, ws, singular, st);
+    if (rc) return rc;
+    rc = newton_finish(ws, 1, max_iter, not_converged, st);
+    if (rc) return rc;
+    return lqpqm2_rt(NEWTON_APPLY, H, v, z, y, n, L, max_iter, floor_kind, floor_eps, ws, singular,
+                     st);
+  }
 #define LQ_LAUNCH(L_, MODE_)                                                                     \
   hipLaunchKernelGGL((k_lqpqm2<L_, MODE_>), grid, block, 0, st, (const c128 *)H, (const c128 *)v, \
                      z, (c128 *)y, n, max_iter, floor_kind, floor_eps, ws, singular)

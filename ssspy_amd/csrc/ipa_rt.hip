@@ -13,6 +13,7 @@
 #include "hermitian.hpp"
 #include "ipa_common.hpp"
 #include "rt_dense.hpp"
+#include "rt_hermitian.hpp"
 #include "ssspy_amd.h"
 
 namespace ssspy {
@@ -66,153 +67,12 @@ struct NoVoteRt {
   __device__ __forceinline__ int operator()(unsigned long long, bool) const { return 0; }
 };
 
-// (A + A^H) / 2 in place
-__device__ void rt_hermitize(c128 *A, int N) {
-  for (int a = 0; a < N; ++a) {
-    A[a * N + a] = cmake(A[a * N + a].x, 0.0);
-    for (int b = a + 1; b < N; ++b) {
-      const c128 z = cmake(0.5 * (A[a * N + b].x + A[b * N + a].x),
-                           0.5 * (A[a * N + b].y - A[b * N + a].y));
-      A[a * N + b] = z;
-      A[b * N + a] = cconj(z);
-    }
-  }
-}
-
-// lam_min(A) > shift by the pivots of the Cholesky factorisation of A - shift I (W: working copy)
-__device__ bool rt_shifted_pd(const c128 *A, c128 *W, int N, double shift) {
-  bool ok = true;
-  for (int c = 0; c < N; ++c) {
-    double d = A[c * N + c].x - shift;
-    for (int k = 0; k < c; ++k) d -= cabs2(W[c * N + k]);
-    ok = ok && (d > 0.0);
-    const double il = 1.0 / sqrt(d > 0.0 ? d : 1.0);
-    for (int r = c + 1; r < N; ++r) {
-      c128 sum = A[r * N + c];
-      for (int k = 0; k < c; ++k) cfms(sum, W[r * N + k], cconj(W[c * N + k]));
-      W[r * N + c] = cscale(sum, il);
-    }
-  }
-  return ok;
-}
-
-// cyclic complex Jacobi (the sweeps of jacobi_eigh, hermitian.hpp): A = P diag(lam) P^H, lam on the
-// diagonal of A.  (The sweep loop ends when every lane that is in the call has converged.)
-__device__ void rt_jacobi(c128 *A, c128 *P, int N) {
-  for (int r = 0; r < N; ++r)
-    for (int c = 0; c < N; ++c) P[r * N + c] = cmake(r == c ? 1.0 : 0.0, 0.0);
-  for (int sweep = 0; sweep < 12; ++sweep) {
-    double off = 0.0, diag = 0.0;
-    for (int p = 0; p < N; ++p) {
-      diag = fma(A[p * N + p].x, A[p * N + p].x, diag);
-      for (int q = p + 1; q < N; ++q) off += cabs2(A[p * N + q]);
-    }
-    if (__all(off <= 1e-34 * diag)) break;
-    for (int p = 0; p < N - 1; ++p)
-      for (int q = p + 1; q < N; ++q) {
-        const double app = A[p * N + p].x, aqq = A[q * N + q].x;
-        const JacobiRot rot = jacobi_rot(A[p * N + q], app, aqq);
-        const double cs = rot.cs;
-        const c128 su = rot.su, sub = cconj(rot.su);
-        for (int k = 0; k < N; ++k) {
-          if (k != p && k != q) {
-            const c128 akp = A[k * N + p], akq = A[k * N + q];
-            c128 nkp = cmake(cs * akp.x, cs * akp.y);
-            cfms(nkp, sub, akq);
-            c128 nkq = cmake(cs * akq.x, cs * akq.y);
-            cfma(nkq, su, akp);
-            A[k * N + p] = nkp;
-            A[p * N + k] = cconj(nkp);
-            A[k * N + q] = nkq;
-            A[q * N + k] = cconj(nkq);
-          }
-        }
-        A[p * N + p] = cmake(app - rot.tm, 0.0);
-        A[q * N + q] = cmake(aqq + rot.tm, 0.0);
-        A[p * N + q] = cmake(0.0, 0.0);
-        A[q * N + p] = cmake(0.0, 0.0);
-        for (int k = 0; k < N; ++k) {
-          const c128 vkp = P[k * N + p], vkq = P[k * N + q];
-          c128 nkp = cmake(cs * vkp.x, cs * vkp.y);
-          cfms(nkp, sub, vkq);
-          c128 nkq = cmake(cs * vkq.x, cs * vkq.y);
-          cfma(nkq, su, vkp);
-          P[k * N + p] = nkp;
-          P[k * N + q] = nkq;
-        }
-      }
-  }
-}
-
-// to_psd: Hermitise, eigen-decompose, floor the eigenvalues (psd_eigen, hermitian.hpp)
-__device__ void rt_psd_eigen(c128 *A, c128 *P, double *lam, int N, int floor_kind, double eps) {
-  rt_hermitize(A, N);
-  rt_jacobi(A, P, N);
-  for (int k = 0; k < N; ++k) lam[k] = apply_floor(A[k * N + k].x, floor_kind, eps);
-}
-
-// Out = P diag(w) P^H (exactly Hermitian)
-__device__ void rt_rebuild(const c128 *P, const double *w, c128 *Out, int N) {
-  for (int a = 0; a < N; ++a)
-    for (int b = a; b < N; ++b) {
-      c128 s = cmake(0.0, 0.0);
-      for (int k = 0; k < N; ++k) {
-        const c128 t = cmulc(P[a * N + k], P[b * N + k]);
-        s.x = fma(w[k], t.x, s.x);
-        s.y = fma(w[k], t.y, s.y);
-      }
-      if (a == b) s.y = 0.0;
-      Out[a * N + b] = s;
-      Out[b * N + a] = cconj(s);
-    }
-}
-
-// Inverse of a Hermitian positive definite matrix by Cholesky (chol_inverse, hermitian.hpp): A is
-// destroyed (its lower triangle becomes L), Li is scratch (L^-1).  False: a pivot was not positive.
-__device__ bool rt_chol_inverse(c128 *A, c128 *Inv, c128 *Li, int N) {
-  bool ok = true;
-  for (int c = 0; c < N; ++c) {
-    double d = A[c * N + c].x;
-    for (int k = 0; k < c; ++k) d -= cabs2(A[c * N + k]);
-    ok = ok && (d > 0.0);
-    const double dd = d > 0.0 ? d : 1.0;
-    const double l = sqrt(dd), il = 1.0 / l;
-    A[c * N + c] = cmake(l, 0.0);
-    for (int r = c + 1; r < N; ++r) {
-      c128 s = A[r * N + c];
-      for (int k = 0; k < c; ++k) cfms(s, A[r * N + k], cconj(A[c * N + k]));
-      A[r * N + c] = cscale(s, il);
-    }
-  }
-  for (int c = 0; c < N; ++c) {
-    for (int r = 0; r < N; ++r) Li[r * N + c] = cmake(0.0, 0.0);
-    Li[c * N + c] = cmake(1.0 / A[c * N + c].x, 0.0);
-    for (int r = c + 1; r < N; ++r) {
-      c128 s = cmake(0.0, 0.0);
-      for (int k = c; k < r; ++k) cfms(s, A[r * N + k], Li[k * N + c]);
-      Li[r * N + c] = cscale(s, 1.0 / A[r * N + r].x);
-    }
-  }
-  for (int a = 0; a < N; ++a)
-    for (int b = a; b < N; ++b) {
-      c128 s = cmake(0.0, 0.0);
-      for (int k = b; k < N; ++k) {
-        const c128 t = cmulc(Li[k * N + b], Li[k * N + a]);  // conj(Li[k][a]) Li[k][b]
-        s.x += t.x;
-        s.y += t.y;
-      }
-      if (a == b) s.y = 0.0;
-      Inv[a * N + b] = s;
-      Inv[b * N + a] = cconj(s);
-    }
-  return ok;
-}
-
 // y = argmin of the LQPQM (type 2), H (L x L) Hermitian, v (L): lqpqm2 of ipa_kernels.hip with the
 // NEWTON_FIXED (Vote = NoVoteRt) and NEWTON_FUSED (SweepVoteRt) modes.  sigma: scratch L x L.
 template <bool FUSED, class Vote>
 __device__ void rt_lqpqm2(c128 *H, c128 *sigma, const c128 *v, double z, int L, int floor_kind,
-                          double eps, int max_iter, c128 *y, Vote vote) {
+                          double eps, int max_iter, c128 *y, Vote vote,
+                          int singular_override = -1) {
   rt_jacobi(H, sigma, L);
   double phi[RN], ph[RN], w2[RN];
   c128 vt[RN];
@@ -220,7 +80,9 @@ __device__ void rt_lqpqm2(c128 *H, c128 *sigma, const c128 *v, double z, int L, 
   const double f0 = floor_of_zero(floor_kind, eps);
   double vnorm2 = 0.0;
   for (int l = 0; l < L; ++l) vnorm2 += cabs2(v[l]);
-  if (sqrt(vnorm2) < f0) {  // v = 0 (see lqpqm2: the reference's literal indexing)
+  // v = 0 (see lqpqm2: the reference's literal indexing; the override: the caller's singular_fn)
+  const bool is_singular = singular_override < 0 ? sqrt(vnorm2) < f0 : singular_override != 0;
+  auto singular_solution = [&]() {
     double pmax = phi[0];
     for (int l = 1; l < L; ++l) pmax = fmax(pmax, phi[l]);
     const double lamb = fmax(z, pmax);
@@ -231,7 +93,10 @@ __device__ void rt_lqpqm2(c128 *H, c128 *sigma, const c128 *v, double z, int L, 
       for (int m = 0; m < L; ++m) rank += (phi[m] < phi[l] || (phi[m] == phi[l] && m < l)) ? 1 : 0;
       y[rank] = cscale(sigma[(L - 1) * L + l], scale);
     }
-    if (FUSED) vote(0ull, false);
+  };
+  // (FUSED: a singular lane walks on with the others so that the wave meets at one vote)
+  if (is_singular && !FUSED) {
+    singular_solution();
     return;
   }
   for (int l = 0; l < L; ++l) {
@@ -284,7 +149,11 @@ __device__ void rt_lqpqm2(c128 *H, c128 *sigma, const c128 *v, double z, int L, 
     lamb = mu > 1.0 ? mu : 0.5 * (1.0 + lamb);
   }
   if (FUSED) {
-    const int agreed = vote(bits, true);
+    const int agreed = vote(bits, !is_singular);
+    if (is_singular) {
+      singular_solution();
+      return;
+    }
     if (agreed != steps) {  // (the mixture converged early: the reference stopped there)
       lamb = lamb0;
       for (int it = 0; it < agreed; ++it) {
@@ -502,7 +371,76 @@ __global__ __launch_bounds__(64) void k_ipa_sweep_rt(c128 *Vc, c128 *__restrict_
   }
 }
 
+// ---- the standalone lqpqm2 at 8 <= L <= 15 (ssspy_lqpqm2 / _masked; k_lqpqm2 of ipa_kernels.hip):
+// the probe pass ANDs the convergence bits of all problems into one word (the lanes of a wave that
+// are at the vote elect the first of them), k_newton_steps turns it into the reference's step count,
+// the apply pass repeats that many steps from the start value.
+struct ProbeVoteRt {
+  unsigned long long *word;
+  int max_iter;
+  __device__ __forceinline__ int operator()(unsigned long long bits, bool votes) const {
+    unsigned long long all = ~0ull;
+    for (int it = 0; it <= max_iter; ++it)
+      if (__ballot(votes && !((bits >> it) & 1ull)) != 0ull) all &= ~(1ull << it);
+    const unsigned long long here = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)here) - 1) atomicAnd(word, all);
+    return max_iter;
+  }
+};
+struct ApplyVoteRt {
+  const unsigned long long *word;  // the step count (k_newton_steps)
+  __device__ __forceinline__ int operator()(unsigned long long, bool) const { return (int)*word; }
+};
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_lqpqm2_rt(const c128 *__restrict__ H,
+                                                  const c128 *__restrict__ v,
+                                                  const double *__restrict__ z, c128 *y, long long n,
+                                                  int L, int max_iter, int floor_kind, double eps,
+                                                  unsigned long long *word,
+                                                  const int *__restrict__ singular) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n;
+  const long long idx = live ? i : n - 1;  // (every lane is in rt_jacobi's wave votes)
+  c128 Hm[RN * RN], sigma[RN * RN], vv[RN], yy[RN];
+  for (int r = 0; r < L; ++r) {
+    vv[r] = v[idx * L + r];
+    for (int c = 0; c < L; ++c) Hm[r * L + c] = H[(idx * L + r) * L + c];
+  }
+  rt_hermitize(Hm, L);
+  const int so = singular ? singular[idx] : -1;
+  if (MODE == NEWTON_FIXED) {
+    rt_lqpqm2<false, NoVoteRt>(Hm, sigma, vv, z[idx], L, floor_kind, eps, max_iter, yy, NoVoteRt(),
+                               so);
+  } else if (MODE == NEWTON_PROBE) {
+    // (a lane past the end repeats the last problem: its bits are that problem's)
+    rt_lqpqm2<true, ProbeVoteRt>(Hm, sigma, vv, z[idx], L, floor_kind, eps, max_iter, yy,
+                                 ProbeVoteRt{word, max_iter}, so);
+    return;
+  } else {
+    rt_lqpqm2<true, ApplyVoteRt>(Hm, sigma, vv, z[idx], L, floor_kind, eps, max_iter, yy,
+                                 ApplyVoteRt{word}, so);
+  }
+  if (live)
+    for (int r = 0; r < L; ++r) y[idx * L + r] = yy[r];
+}
+
 }  // namespace
+
+// one pass of the standalone lqpqm2 (mode: NEWTON_FIXED / NEWTON_PROBE / NEWTON_APPLY)
+int lqpqm2_rt(int mode, const void *H, const void *v, const double *z, void *y, long long n, int L,
+              int max_iter, int floor_kind, double eps, unsigned long long *word,
+              const int *singular, hipStream_t st) {
+  const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+#define LQ_RT(MODE_)                                                                              \
+  hipLaunchKernelGGL(k_lqpqm2_rt<MODE_>, grid, block, 0, st, (const c128 *)H, (const c128 *)v, z, \
+                     (c128 *)y, n, L, max_iter, floor_kind, eps, word, singular)
+  if (mode == NEWTON_FIXED) LQ_RT(NEWTON_FIXED);
+  else if (mode == NEWTON_PROBE) LQ_RT(NEWTON_PROBE);
+  else LQ_RT(NEWTON_APPLY);
+#undef LQ_RT
+  return check_launch("k_lqpqm2_rt");
+}
 
 // the whole sweep of 9..16 sources (ws prepared by the caller: k_ipa_sweep_prepare)
 int ipa_rt_sweep(bool votes, void *Vc, void *G, int B, int F, int N, int normalization,

@@ -13,6 +13,12 @@ namespace ssspy {
 bool hermitian_rows_wanted(int M, int always_from);
 int eigh_rows(const void *A, double *lamb, void *V, long long n, int M, int mode, int floor_kind,
               double eps, hipStream_t st);
+// hermitian_rt.hip: 9 x 9 .. 16 x 16, the size at run time
+bool hermitian_rt_wanted(int M);
+int solve_rt(const void *A, const void *Bm, void *X, long long n, int M, int nrhs, int *info,
+             hipStream_t st);
+int eigh_rt(const void *A, double *lamb, void *V, long long n, int M, int mode, int floor_kind,
+            double eps, hipStream_t st);
 
 // X = A^-1 B, B (N x nrhs)
 template <int N>
@@ -318,6 +324,7 @@ int ssspy_herm_rebuild(const void *P, const double *w, void *out, long long n, i
 int ssspy_solve(const void *A, const void *Bm, void *X, long long n, int N, int nrhs, int *info,
                 void *stream) {
   SSSPY_REQUIRE(A && Bm && X && n > 0 && nrhs > 0, "solve: bad argument");
+  if (hermitian_rt_wanted(N)) return solve_rt(A, Bm, X, n, N, nrhs, info, as_stream(stream));
   dim3 grid((unsigned)((n + 63) / 64)), block(64);
   DISPATCH_N(N, hipLaunchKernelGGL((k_solve<NN>), grid, block, 0, as_stream(stream),
                                    (const c128 *)A, (const c128 *)Bm, (c128 *)X, n, nrhs, info));
@@ -341,11 +348,12 @@ int ssspy_inv2(const void *A, void *out, long long n, void *stream) {
     case 3: { constexpr int NN = 3; CALL; } break;                                                \
     case 4: { constexpr int NN = 4; CALL; } break;                                                \
     case 5: { constexpr int NN = 5; CALL; } break;                                                \
-    default: return ::ssspy::fail(SSSPY_ERR_UNSUPPORTED, "eigh: size must be in [1, 8]");         \
+    default: return ::ssspy::fail(SSSPY_ERR_UNSUPPORTED, "eigh: size must be in [1, 16]");         \
   }
 
 int ssspy_eigh(const void *A, double *lamb, void *V, long long n, int M, void *stream) {
   SSSPY_REQUIRE(A && lamb && V && n > 0, "eigh: bad argument");
+  if (hermitian_rt_wanted(M)) return eigh_rt(A, lamb, V, n, M, 0, 0, 0.0, as_stream(stream));
   if (hermitian_rows_wanted(M, 7))
     return eigh_rows(A, lamb, V, n, M, 0, 0, 0.0, as_stream(stream));
   dim3 grid((unsigned)((n + 63) / 64)), block(64);
@@ -362,6 +370,8 @@ int ssspy_eigh(const void *A, double *lamb, void *V, long long n, int M, void *s
 int ssspy_to_psd(const void *A, void *out, long long n, int M, int floor_kind, double floor_eps,
                  void *stream) {
   SSSPY_REQUIRE(A && out && n > 0, "to_psd: bad argument");
+  if (hermitian_rt_wanted(M))
+    return eigh_rt(A, nullptr, out, n, M, 1, floor_kind, floor_eps, as_stream(stream));
   if (hermitian_rows_wanted(M, 7))
     return eigh_rows(A, nullptr, out, n, M, 1, floor_kind, floor_eps, as_stream(stream));
   dim3 grid((unsigned)((n + 63) / 64)), block(64);

@@ -4,7 +4,8 @@ Device counterparts of the reference's ``ssspy.linalg`` functions that the demix
 sits on (ssspy/linalg/_solve.py, inv.py, eigh.py): leading axes are batch axes, the trailing
 two are the matrix; one lane of a wavefront owns one matrix, and from 7 x 7 on the Hermitian
 functions (eigh, sqrtmh, invsqrtmh, gmeanmh) spread a matrix over 8 lanes, a row per lane
-(csrc/herm_rows8.hpp).
+(csrc/herm_rows8.hpp); 9 x 9 .. 16 x 16 run with the size as a kernel argument, a lane per matrix
+on private memory (csrc/hermitian_rt.hip) -- correct, not tuned.
 """
 
 from typing import Optional, Tuple, Union
@@ -26,7 +27,7 @@ def _flat(a, tail):
 
 
 def solve(a: np.ndarray, b: np.ndarray) -> np.ndarray:
-    """Solve ``a x = b`` for batches of N x N complex systems (N <= 8).
+    """Solve ``a x = b`` for batches of N x N complex systems (N <= 16).
 
     ``b`` may be a stack of vectors (``b.ndim == a.ndim - 1``) or of matrices, as in the
     reference (ref: ssspy/linalg/_solve.py:9-21).  Raises LinAlgError on a singular matrix.
@@ -71,7 +72,7 @@ def eigh(A: np.ndarray, B: Optional[np.ndarray] = None, type: int = 1
          ) -> Union[np.ndarray, Tuple[np.ndarray, np.ndarray]]:
     """Hermitian (generalised when ``B`` is given) eigen-decomposition, eigenvalues ascending.
 
-    M <= 8, cyclic complex Jacobi on the device; the generalised problem goes through the Cholesky
+    M <= 16, cyclic complex Jacobi on the device; the generalised problem goes through the Cholesky
     factor of ``B`` like the reference (type 1: ``A z = lamb B z``; 2: ``A B z = lamb z``;
     3: ``B A z = lamb z``).  Eigenvectors carry an arbitrary phase that differs from LAPACK's.
     ref: ssspy/linalg/eigh.py:8-81, :164-207.

@@ -23,8 +23,9 @@ def to_psd(
 ) -> np.ndarray:
     """Hermitise, floor the eigenvalues, rebuild, Hermitise (ref: ssspy/special/psd.py:11-71).
 
-    Complex Jacobi on the device, M <= 8: a lane per matrix up to 6 x 6, a matrix on 8 lanes (a row per
-    lane, csrc/hermitian_rows.hip) at 7 x 7 and 8 x 8.  ``flooring_fn`` as for the separators.
+    Complex Jacobi on the device, M <= 16: a lane per matrix up to 6 x 6 and from 9 x 9 (there with the
+    size at run time, csrc/hermitian_rt.hip), a matrix on 8 lanes (a row per lane,
+    csrc/hermitian_rows.hip) at 7 x 7 and 8 x 8.  ``flooring_fn`` as for the separators.
     """
     from ..utils.flooring import device_flooring
 

@@ -270,6 +270,37 @@ def test_ipa_above_four_sources_against_oracle(N):
         assert rel_err(a, ref) < 1e-7, kw
 
 
+@pytest.mark.parametrize("N", [3, 6, 8, 9])
+def test_ipa_sweep_with_singular_bins_in_the_wave(N):
+    """Bins whose linear term vanishes exactly (channels with disjoint time supports: diagonal
+    statistics, v = 0, the reference's singular branch, ssspy/linalg/lqpqm.py:84-93) sit at lane 0
+    and elsewhere in waves whose other bins vote on the Newton step count: the other bins must come
+    out as the oracle's (the mixture-wide vote is theirs alone), the singular ones -- defined by the
+    reference up to the phases LAPACK leaves in its eigenvectors -- finite."""
+    from oracle.ipa import update_by_ipa as oracle_ipa
+    from ssspy_amd.bss._update_spatial_model import update_by_ipa
+
+    rng = np.random.default_rng(900 + N)
+    F, T = 130, 12 * N
+    Y = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+    varphi = 1.0 / (rng.random((N, F, T)) + 0.05)
+    singular = [0, 5, 64, 65, 129]
+    seg = T // N
+    for f in singular:
+        for n in range(N):
+            mask = np.zeros(T)
+            mask[n * seg:(n + 1) * seg] = 1.0
+            Y[n, f] *= mask
+    regular = np.setdiff1d(np.arange(F), singular)
+    for kw in (dict(), dict(max_iter=30)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            a = update_by_ipa(Y, varphi, **kw)
+            ref = oracle_ipa(Y, varphi, **kw)
+        assert np.isfinite(a).all()
+        assert rel_err(a[:, regular], ref[:, regular]) < 1e-11, kw
+
+
 @pytest.mark.parametrize("N", [9, 13, 16])
 def test_ipa_above_eight_sources_against_oracle(N):
     """Round 6: IPA with the source count at run time (ipa_rt.hip, 9..16 sources: the reference has no
@@ -1450,7 +1481,7 @@ def test_inv2_against_golden_and_identity():
     assert np.allclose(X @ out, np.eye(2), atol=1e-10)
 
 
-@pytest.mark.parametrize("N", [2, 3, 4, 8])
+@pytest.mark.parametrize("N", [2, 3, 4, 8, 9, 13, 16])
 def test_solve_matches_numpy(N):
     from ssspy_amd.linalg import solve
 
@@ -1464,7 +1495,7 @@ def test_solve_matches_numpy(N):
         solve(np.zeros((2, N, N), dtype=complex), np.ones((2, N), dtype=complex))
 
 
-@pytest.mark.parametrize("M", [2, 3, 4, 6, 7, 8])
+@pytest.mark.parametrize("M", [2, 3, 4, 6, 7, 8, 9, 12, 16])
 def test_eigh_properties(M):
     """The reference's own property checks (tests/package/linalg/test_eigh.py): A z = lamb z,
     ascending eigenvalues; plus agreement with LAPACK eigenvalues and unitarity."""
@@ -1829,7 +1860,7 @@ def _psd(rng, lead, M, T=32, complex_=True):
     return np.mean(x[..., :, None, :] * x[..., None, :, :].conj(), axis=-1)
 
 
-@pytest.mark.parametrize("M", [3, 4, 6, 7, 8])
+@pytest.mark.parametrize("M", [3, 4, 6, 7, 8, 10, 16])
 @pytest.mark.parametrize("type", [1, 2, 3])
 def test_generalized_eigh(M, type):
     """The reference's property checks for the generalised problem (tests/package/linalg/test_eigh.py),
@@ -1854,7 +1885,7 @@ def test_generalized_eigh(M, type):
     np.testing.assert_allclose(lamb, np.linalg.eigvalsh(C), rtol=1e-11, atol=1e-13)
 
 
-@pytest.mark.parametrize("M", [3, 4, 6, 7, 8])
+@pytest.mark.parametrize("M", [3, 4, 6, 7, 8, 10, 16])
 @pytest.mark.parametrize("is_complex", [True, False])
 def test_sqrtmh_invsqrtmh(M, is_complex):
     """tests/package/linalg/test_sqrtm.py on the device."""
@@ -1893,12 +1924,12 @@ def test_gmeanmh(type):
     assert rel_err(G, G.swapaxes(-2, -1).conj()) < 1e-13
 
 
-@pytest.mark.parametrize("M", [6, 7, 8])
-def test_hermitian_operators_at_6_to_8_channels_against_lapack(M):
+@pytest.mark.parametrize("M", [6, 7, 8, 9, 11, 16])
+def test_hermitian_operators_at_6_to_16_channels_against_lapack(M):
     """eigh, to_psd, the generalised eigenproblem, sqrtmh / invsqrtmh and gmeanmh at 6 x 6 (a lane
-    per matrix) and 7 x 7 / 8 x 8 (a matrix on 8 lanes, hermitian_rows.hip) against LAPACK and the
-    defining identities; eigenvectors through the projectors z z^H (free of the phase each
-    decomposition leaves)."""
+    per matrix), 7 x 7 / 8 x 8 (a matrix on 8 lanes, hermitian_rows.hip) and 9 x 9 .. 16 x 16 (the
+    size at run time, hermitian_rt.hip) against LAPACK and the defining identities; eigenvectors
+    through the projectors z z^H (free of the phase each decomposition leaves)."""
     from ssspy_amd.linalg import eigh, gmeanmh, invsqrtmh, sqrtmh
     from ssspy_amd.special.flooring import max_flooring
     from ssspy_amd.special.psd import to_psd
@@ -1941,7 +1972,7 @@ def test_hermitian_operators_at_6_to_8_channels_against_lapack(M):
     assert rel_err(rows["gmean2"] @ A @ rows["gmean2"], B) < 1e-9
 
 
-@pytest.mark.parametrize("L", [1, 2, 3, 5, 7])
+@pytest.mark.parametrize("L", [1, 2, 3, 5, 7, 8, 11, 15])
 def test_lqpqm2_against_oracle(L):
     from oracle.ipa import lqpqm2 as oracle_lqpqm2
     from ssspy_amd.linalg import lqpqm2
@@ -1956,6 +1987,34 @@ def test_lqpqm2_against_oracle(L):
         y = lqpqm2(H, v, z, max_iter=max_iter)
         yr = oracle_lqpqm2(H, v, z, ("max", 1e-10), max_iter)
         assert rel_err(y, yr) < 1e-10
+
+
+@pytest.mark.parametrize("L", [6, 9, 15])
+def test_lqpqm2_singular_fn_against_oracle(L):
+    """singular_fn = default / None / a callable with problems whose v is exactly zero or small, up
+    to the largest dimension (the run-time-L kernel from 8 on): the other problems as the oracle's
+    (they alone decide the Newton step count), the singular ones in modulus."""
+    from oracle.ipa import lqpqm2 as oracle_lqpqm2
+    from test_oracle_golden import lqpqm_singular_check
+
+    from ssspy_amd.linalg import lqpqm2
+
+    rng = np.random.default_rng(140 + L)
+    n = 70
+    H = _psd(rng, (n,), L, T=3 * L)
+    H = H / np.real(np.trace(H, axis1=-2, axis2=-1))[:, None, None]
+    v = rng.standard_normal((n, L)) + 1j * rng.standard_normal((n, L))
+    v[[0, 7, 64]] = 0.0
+    v[[3, 65]] *= 1e-2
+    z = rng.random(n) * 2.0
+    norms = np.linalg.norm(v, axis=-1)
+    for kw, singular in ((dict(), norms < 1e-10), (dict(singular_fn=None), norms == 0),
+                         (dict(singular_fn=lambda x: x < 0.5), norms < 0.5)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            y = lqpqm2(H, v, z, **kw)
+            ref = oracle_lqpqm2(H, v, z, ("max", 1e-10), 10, **kw)
+        lqpqm_singular_check(y, np.asarray(ref), singular)
 
 
 @pytest.mark.parametrize("L", [1, 2, 3, 5])
