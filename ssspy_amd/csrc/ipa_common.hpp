@@ -54,4 +54,13 @@ __device__ __forceinline__ double largest_cubic_root(double A, double B, double 
   return root - A / 3.0;
 }
 
+// Ordering inside a mixture's Newton vote.  Only two words cross workgroups there -- the AND-ed
+// convergence bits and the arrival counter -- and both are touched with agent-scope atomics alone,
+// which are performed at the memory side (they pass the XCD's L2): all the vote needs is that a
+// workgroup's AND has been performed before its arrival is counted, and that the word is read
+// after the count was seen -- a wait for the outstanding memory operations of the lane.  The
+// agent-scope release / acquire fences that stood here wrote back and invalidated the XCD's whole
+// L2 at every vote of every workgroup (cf. DESIGN.md section 4 item 53 iv).
+__device__ __forceinline__ void vote_order() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 }  // namespace ssspy

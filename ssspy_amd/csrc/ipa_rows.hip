@@ -346,7 +346,7 @@ __device__ __forceinline__ void ipa_rows_step(const c128 *Ub, c128 *__restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
       unsigned *counter = (unsigned *)(newton_ws + (long long)B * N + (long long)blockIdx.y * N + S);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      vote_order();  // the AND has been performed
       __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       long long spins = 0;
       while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
@@ -356,7 +356,7 @@ __device__ __forceinline__ void ipa_rows_step(const c128 *Ub, c128 *__restrict__
           break;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      vote_order();
       *vote_word = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();

@@ -36,7 +36,7 @@ struct SweepVoteRt {
     unsigned long long w = 0ull;
     if ((threadIdx.x & 63) == 0) {
       __hip_atomic_fetch_and(word, all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      vote_order();  // the AND has been performed
       __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       long long spins = 0;
       while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
@@ -47,7 +47,7 @@ struct SweepVoteRt {
           break;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      vote_order();
       w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     w = __shfl(w, 0, 64);  // (one wave per workgroup)
