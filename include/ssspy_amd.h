@@ -69,8 +69,10 @@ enum { SSSPY_SOURCE_ME = 0x100 };
 /* Above that, up to SSSPY_RT_MAX_SOURCES, the shared operators, the AuxIVA entry points and the ILRMA
  * iteration on the Gauss model's tuned passes run with the source count at run time (wide_n.hip:
  * correct, not tuned; the reference has no limit: ssspy/bss/ilrma.py:180, iva.py:152), IPA included
- * (ssspy_ipa_sweep, ipa_rt.hip, round 6).  The MNMF entry points, the Hermitian operators and the
- * standalone ssspy_lqpqm2 stay at SSSPY_MAX_SOURCES. */
+ * (ssspy_ipa_sweep, ipa_rt.hip, round 6), and so do the Hermitian operators / ssspy_solve (to
+ * 16 x 16) and the standalone ssspy_lqpqm2 (to dimension 15; hermitian_rt.hip).  The MNMF entry
+ * points and the ssspy_ilrma_partition_* entry points (partitioning=True) stay at SSSPY_MAX_SOURCES
+ * (SSSPY_ERR_UNSUPPORTED above). */
 #define SSSPY_RT_MAX_SOURCES 16
 /* n_basis: the kernels walk any number of bases (dense products above 32; checked against the
  * oracle at 1500 and 3000); the bound only keeps 32-bit index arithmetic safe.  Up to round 5: 1024. */

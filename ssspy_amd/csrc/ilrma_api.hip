@@ -1016,9 +1016,17 @@ int ssspy_ilrma_weighted_covariance(const void *X, const void *W, const double *
                 "ilrma_weighted_covariance: workspace too small");
   hipStream_t st = as_stream(stream);
   const IlrmaDims d = make_dims(B, F, T, K, domain, source_model, model_param, floor_kind, floor_eps);
+  // more than 8 sources with a heavy-tailed model: the run-time-N weights need |W x|^2 (the fused
+  // IP1 iteration has it from its NMF passes; a caller of this entry alone -- IP2 -- has not)
+  const void *Ysep = nullptr;
+  if (rt_sources_ok(N) && source_model != SSSPY_SOURCE_GAUSS && W) {
+    rc = separate_power(X, W, (double *)((char *)workspace + w.ybuf), B, N, F, T, st);
+    if (rc) return rc;
+    Ysep = (const char *)workspace + w.ybuf;
+  }
   return wcov_into(X, W, basis, activation, U, N, d, (char *)workspace + w.upart,
                    (N > 4 || wide_basis_shape(N, K)) ? (double *)((char *)workspace + w.wbuf) : nullptr,
-                   nullptr, false, st);
+                   Ysep, Ysep != nullptr, st);
 }
 
 static int launch_norm_scale(void *W, double *basis, const double *qbuf, int B, int N, int F, int K,
@@ -1358,7 +1366,9 @@ int ssspy_ilrma_partition_update(const void *X, const void *W, double *basis, do
                                  size_t workspace_bytes, void *stream) {
   SSSPY_REQUIRE(X && basis && activation && latent && Teff && Vrep && B > 0 && F > 0 && T > 0,
                 "partition_update: bad argument");
-  SSSPY_REQUIRE(N >= 1 && N <= SSSPY_MAX_SOURCES, "partition_update: n_sources must be in [1, 8]");
+  SSSPY_REQUIRE(N >= 1, "partition_update: bad n_sources");
+  if (N > SSSPY_MAX_SOURCES)
+    return fail(SSSPY_ERR_UNSUPPORTED, "ILRMA: partitioning takes up to 8 sources");
   SSSPY_REQUIRE(K >= 1, "partition_update: bad n_basis");
   if (K > SSSPY_MAX_PARTITION_BASIS)
     return fail(SSSPY_ERR_UNSUPPORTED, "ILRMA: partitioning takes n_basis up to 1024");
@@ -1417,8 +1427,9 @@ int ssspy_ilrma_partition_normalize(void *W, const void *C, void *Y, double *bas
                                     int B, int N, int F, int T, int K, double domain,
                                     int floor_kind, double floor_eps, void *workspace,
                                     size_t workspace_bytes, void *stream) {
-  SSSPY_REQUIRE(basis && latent && B > 0 && N >= 1 && N <= SSSPY_MAX_SOURCES,
-                "partition_normalize: bad argument");
+  SSSPY_REQUIRE(basis && latent && B > 0 && N >= 1, "partition_normalize: bad argument");
+  if (N > SSSPY_MAX_SOURCES)
+    return fail(SSSPY_ERR_UNSUPPORTED, "ILRMA: partitioning takes up to 8 sources");
   SSSPY_REQUIRE((W && C && !Y) || (Y && !W), "partition_normalize: pass (W, C) or Y");
   if (K > SSSPY_MAX_PARTITION_BASIS)
     return fail(SSSPY_ERR_UNSUPPORTED, "ILRMA: partitioning takes n_basis up to 1024");
