@@ -14,6 +14,7 @@ length in [2, 32768] (Bluestein; up to 8192 points in LDS, longer transforms on 
 its periodic windows (a name, or a ``(name, parameter)`` tuple).
 """
 
+import warnings
 from typing import Optional, Union
 
 import numpy as np
@@ -150,9 +151,19 @@ def _stream():
 def stft(x, n_fft: int, hop_length: Optional[int] = None, window="hann", device_output=False):
     """x (..., n_samples) real -> (..., n_fft // 2 + 1, n_frames) complex128."""
     hop = n_fft // 2 if hop_length is None else int(hop_length)
-    w = _window(window, n_fft)
     xd = dv.to_device(x, dtype=np.float64) if isinstance(x, np.ndarray) else x
     lead, L = tuple(xd.shape[:-1]), int(xd.shape[-1])
+    if n_fft > L:
+        # a signal shorter than one window: scipy.signal.stft shrinks nperseg to the signal (with this
+        # warning) and keeps noverlap, so the transform has L // 2 + 1 bins
+        # (scipy/signal/_spectral_py.py, _triage_segments)
+        warnings.warn("nperseg = {0:d} is greater than input length  = {1:d}, using nperseg = {1:d}"
+                      .format(n_fft, L))
+        noverlap = n_fft - hop
+        if noverlap >= L:
+            raise ValueError("noverlap must be less than nperseg.")
+        n_fft, hop = L, L - noverlap
+    w = _window(window, n_fft)
     flat = xd.reshape(1, -1, L).contiguous()
     C = flat.shape[1]
     n_frames = int(_L().ssspy_stft_frames(L, n_fft, hop))

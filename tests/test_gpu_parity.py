@@ -1822,6 +1822,30 @@ def test_stft_any_length_and_named_windows_against_scipy(n_fft, hop, window):
     assert rel_err(y, yr) < 1e-11
 
 
+def test_stft_of_a_signal_shorter_than_the_window_follows_scipy():
+    """scipy.signal.stft shrinks nperseg to the signal's length (with a warning) and keeps noverlap,
+    raising when the overlap no longer fits (scipy/signal/_spectral_py.py, _triage_segments); found
+    by benchmarks/fuzz_transform.py."""
+    import scipy.signal as ss
+
+    from ssspy_amd.transform import stft
+
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 193))
+    with pytest.warns(UserWarning, match="nperseg = 256 is greater than input length"):
+        _, _, Zr = ss.stft(x, window="hann", nperseg=256, noverlap=128)
+    with pytest.warns(UserWarning, match="nperseg = 256 is greater than input length"):
+        Z = stft(x, n_fft=256, hop_length=128)
+    assert Z.shape == Zr.shape == (2, 97, 4)
+    assert rel_err(Z, Zr) < 1e-12
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(ValueError, match="noverlap must be less than nperseg"):
+            ss.stft(x[:, :100], window="hann", nperseg=256, noverlap=128)
+        with pytest.raises(ValueError, match="noverlap must be less than nperseg"):
+            stft(x[:, :100], n_fft=256, hop_length=128)
+
+
 @pytest.mark.parametrize("n_fft,hop,window", [(5000, 1250, "hann"), (6001, 2000, "hamming"),
                                              (16384, 4096, "hann"), (8191, 2048, "blackman")])
 def test_stft_beyond_the_lds_against_scipy(n_fft, hop, window):
