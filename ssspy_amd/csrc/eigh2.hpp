@@ -1,11 +1,105 @@
 // Generalised 2x2 Hermitian eigenproblem A z = lamb B z (type 1) for one lane.
 // ref: ssspy/linalg/eigh.py:164-207 with inv = inv2: L = chol(B), C = L^-1 A L^-H, eigh(C),
-// z = L^-H y.  A 2x2 Hermitian C is diagonalised exactly by one complex Jacobi rotation.
+// z = L^-H y.
 #pragma once
 
 #include "common.hpp"
 
 namespace ssspy {
+
+// Eigen-decomposition of the 2 x 2 Hermitian matrix [[c00, conj(b)], [b, c11]] WITH THE PHASES
+// np.linalg.eigh GIVES ITS EIGENVECTORS.  The reference solves its pairwise problems with
+// np.linalg.eigh on the 2 x 2 matrix C (ssspy/linalg/eigh.py:198), and without scale restoration
+// the phase of those eigenvectors stays in every (source, bin) row of the separated output, so
+// "the same results" includes LAPACK's convention.  What zheevd does at n = 2 (reference LAPACK, the
+// one NumPy's OpenBLAS carries), restated:
+//   zhetd2, lower triangle: the Householder "reflector" of the one subdiagonal entry b is the phase
+//     q = b / beta with beta = -sign(|b|, Re b) (zlarfg; b real: none, beta = b), leaving the real
+//     tridiagonal matrix [[c00, beta], [beta, c11]];
+//   zsteqr: a subdiagonal below eps sqrt(|c00| |c11|) is dropped (vectors = identity); otherwise
+//     dlaev2 gives (rt1, rt2) and the rotation (cs1, sn1), applied to the identity: columns
+//     (cs1, sn1) for rt1 and (-sn1, cs1) for rt2; then the eigenvalues are sorted ascending;
+//   zunmtr: row 2 of the vectors times q.
+// lamb ascending; y[r][k] = component r of eigenvector k.
+__device__ __forceinline__ void eigh2_lapack(double c00, double c11, c128 b, double (&lamb)[2],
+                                             c128 (&y)[2][2]) {
+  // zlarfg on the single entry b
+  double e = b.x;
+  c128 q = cmake(1.0, 0.0);
+  if (b.y != 0.0) {
+    const double beta = -copysign(hypot(b.x, b.y), b.x);
+    q = cmake(b.x / beta, b.y / beta);
+    e = beta;
+  }
+  double rt1 = c00, rt2 = c11, cs1 = 1.0, sn1 = 0.0;
+  const double eps = 1.1102230246251565e-16;  // dlamch('E')
+  if (fabs(e) > sqrt(fabs(c00)) * sqrt(fabs(c11)) * eps) {
+    // dlaev2(a = c00, b = e, c = c11)
+    const double a = c00, c = c11;
+    const double sm = a + c, df = a - c, adf = fabs(df), tb = e + e, ab = fabs(tb);
+    const double acmx = fabs(a) > fabs(c) ? a : c, acmn = fabs(a) > fabs(c) ? c : a;
+    double rt;
+    if (adf > ab) {
+      const double r = ab / adf;
+      rt = adf * sqrt(1.0 + r * r);
+    } else if (adf < ab) {
+      const double r = adf / ab;
+      rt = ab * sqrt(1.0 + r * r);
+    } else {
+      rt = ab * 1.4142135623730951;
+    }
+    int sgn1;
+    if (sm < 0.0) {
+      rt1 = 0.5 * (sm - rt);
+      sgn1 = -1;
+      rt2 = (acmx / rt1) * acmn - (e / rt1) * e;
+    } else if (sm > 0.0) {
+      rt1 = 0.5 * (sm + rt);
+      sgn1 = 1;
+      rt2 = (acmx / rt1) * acmn - (e / rt1) * e;
+    } else {
+      rt1 = 0.5 * rt;
+      rt2 = -0.5 * rt;
+      sgn1 = 1;
+    }
+    double cs;
+    int sgn2;
+    if (df >= 0.0) {
+      cs = df + rt;
+      sgn2 = 1;
+    } else {
+      cs = df - rt;
+      sgn2 = -1;
+    }
+    if (fabs(cs) > ab) {
+      const double ct = -tb / cs;
+      sn1 = 1.0 / sqrt(1.0 + ct * ct);
+      cs1 = ct * sn1;
+    } else if (ab == 0.0) {
+      cs1 = 1.0;
+      sn1 = 0.0;
+    } else {
+      const double tn = -cs / tb;
+      cs1 = 1.0 / sqrt(1.0 + tn * tn);
+      sn1 = tn * cs1;
+    }
+    if (sgn1 == sgn2) {
+      const double tn = cs1;
+      cs1 = -sn1;
+      sn1 = tn;
+    }
+  }
+  // columns (cs1, sn1) | (-sn1, cs1), sorted ascending (one swap), row 2 times q
+  const bool swap = rt2 < rt1;
+  lamb[0] = swap ? rt2 : rt1;
+  lamb[1] = swap ? rt1 : rt2;
+  const double v00 = swap ? -sn1 : cs1, v10 = swap ? cs1 : sn1;
+  const double v01 = swap ? cs1 : -sn1, v11 = swap ? sn1 : cs1;
+  y[0][0] = cmake(v00, 0.0);
+  y[0][1] = cmake(v01, 0.0);
+  y[1][0] = cmake(q.x * v10, q.y * v10);
+  y[1][1] = cmake(q.x * v11, q.y * v11);
+}
 
 // lamb ascending; z[r][k] = component r of eigenvector k.  Returns false if B is not PD.
 __device__ __forceinline__ bool eigh2_type1(const c128 (&A)[2][2], const c128 (&Bm)[2][2],
@@ -24,35 +118,17 @@ __device__ __forceinline__ bool eigh2_type1(const c128 (&A)[2][2], const c128 (&
   const c128 m10 = cadd(cmul(i10, A[0][0]), cscale(A[1][0], i11));
   const c128 m11 = cadd(cmul(i10, A[0][1]), cscale(A[1][1], i11));
   const double c00 = m00.x * i00;
-  const c128 c01a = cadd(cmulc(m00, i10), cscale(m01, i11));
-  const c128 c10a = cscale(m10, i00);
+  const c128 c10 = cscale(m10, i00);  // (numpy.linalg.eigh reads the lower triangle)
   const double c11 = cadd(cmulc(m10, i10), cscale(m11, i11)).x;
-  // Hermitise (numpy.linalg.eigh reads one triangle; the two agree to rounding)
-  const c128 c01 = cmake(0.5 * (c01a.x + c10a.x), 0.5 * (c01a.y - c10a.y));
-  // one Jacobi rotation: tan(2 theta) from (c11 - c00) / (2 |c01|)
-  const double mag2 = cabs2(c01);
-  const double mag = sqrt(mag2);
-  const bool tiny = mag2 < 1e-300;
-  const double inv = tiny ? 0.0 : 1.0 / mag;
-  const c128 u = tiny ? cmake(1.0, 0.0) : cmake(c01.x * inv, c01.y * inv);
-  const double tau = tiny ? 0.0 : (c11 - c00) * 0.5 * inv;
-  const double t = tiny ? 0.0 : ((tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau)));
-  const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
-  const double e0 = c00 - t * mag, e1 = c11 + t * mag;
-  // eigenvectors (columns of J): y_a = (cs, -sn conj(u)) for e0, y_b = (sn u, cs) for e1
-  const c128 ya[2] = {cmake(cs, 0.0), cmake(-sn * u.x, sn * u.y)};
-  const c128 yb[2] = {cmake(sn * u.x, sn * u.y), cmake(cs, 0.0)};
-  const bool swap = e1 < e0;
-  lamb[0] = swap ? e1 : e0;
-  lamb[1] = swap ? e0 : e1;
-  const c128 y0[2] = {swap ? yb[0] : ya[0], swap ? yb[1] : ya[1]};
-  const c128 y1[2] = {swap ? ya[0] : yb[0], swap ? ya[1] : yb[1]};
+  (void)m01;
+  c128 y[2][2];
+  eigh2_lapack(c00, c11, c10, lamb, y);
   // z = L^-H y,  L^-H = [[i00, conj(i10)], [0, i11]]
   const c128 i01 = cconj(i10);
-  z[0][0] = cadd(cscale(y0[0], i00), cmul(i01, y0[1]));
-  z[1][0] = cscale(y0[1], i11);
-  z[0][1] = cadd(cscale(y1[0], i00), cmul(i01, y1[1]));
-  z[1][1] = cscale(y1[1], i11);
+  z[0][0] = cadd(cscale(y[0][0], i00), cmul(i01, y[1][0]));
+  z[1][0] = cscale(y[1][0], i11);
+  z[0][1] = cadd(cscale(y[0][1], i00), cmul(i01, y[1][1]));
+  z[1][1] = cscale(y[1][1], i11);
   return ok;
 }
 

@@ -3,6 +3,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "eigh2.hpp"
 #include "hermitian.hpp"
 #include "herm_packed.hpp"
 #include "smallmat.hpp"
@@ -253,16 +254,12 @@ __global__ __launch_bounds__(256) void k_eigh2(const c128 *__restrict__ A, const
     Cm[1][0] = cadd(cscale(m10, l00), cmul(m11, l10));
     Cm[1][1] = cscale(m11, l11);
   }
-  hermitize<2>(Cm);
-  jacobi_eigh<2>(Cm, P);
-  const bool swap = Cm[1][1].x < Cm[0][0].x;
-  const int k0 = swap ? 1 : 0, k1 = swap ? 0 : 1;
-  lamb[idx * 2] = swap ? Cm[1][1].x : Cm[0][0].x;
-  lamb[idx * 2 + 1] = swap ? Cm[0][0].x : Cm[1][1].x;
-  c128 y0[2] = {swap ? P[0][1] : P[0][0], swap ? P[1][1] : P[1][0]};
-  c128 y1[2] = {swap ? P[0][0] : P[0][1], swap ? P[1][0] : P[1][1]};
-  (void)k0;
-  (void)k1;
+  // eigenvectors with np.linalg.eigh's phases (lower triangle; eigh2.hpp)
+  double ev[2];
+  eigh2_lapack(Cm[0][0].x, Cm[1][1].x, Cm[1][0], ev, P);
+  lamb[idx * 2] = ev[0];
+  lamb[idx * 2 + 1] = ev[1];
+  const c128 y0[2] = {P[0][0], P[1][0]}, y1[2] = {P[0][1], P[1][1]};
   c128 z0[2], z1[2];
   if (type == 3) {
     // z = L y
@@ -283,6 +280,23 @@ __global__ __launch_bounds__(256) void k_eigh2(const c128 *__restrict__ A, const
   Z[idx * 4 + 1] = z1[0];
   Z[idx * 4 + 2] = z0[1];
   Z[idx * 4 + 3] = z1[1];
+}
+
+// plain 2 x 2 Hermitian eigh with np.linalg.eigh's eigenvector phases (the reference's eigh2 without B
+// IS np.linalg.eigh, ssspy/linalg/eigh.py:155-157): lower triangle, eigh2_lapack
+__global__ __launch_bounds__(256) void k_eigh2_plain(const c128 *__restrict__ A, double *lamb,
+                                                     c128 *V, long long n) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  double ev[2];
+  c128 P[2][2];
+  eigh2_lapack(A[idx * 4].x, A[idx * 4 + 3].x, A[idx * 4 + 2], ev, P);
+  lamb[idx * 2] = ev[0];
+  lamb[idx * 2 + 1] = ev[1];
+  V[idx * 4] = P[0][0];
+  V[idx * 4 + 1] = P[0][1];
+  V[idx * 4 + 2] = P[1][0];
+  V[idx * 4 + 3] = P[1][1];
 }
 
 // out = P diag(w) P^H (optionally Hermitised), dimension at run time: one thread per entry.
@@ -354,6 +368,11 @@ int ssspy_inv2(const void *A, void *out, long long n, void *stream) {
 int ssspy_eigh(const void *A, double *lamb, void *V, long long n, int M, void *stream) {
   SSSPY_REQUIRE(A && lamb && V && n > 0, "eigh: bad argument");
   if (hermitian_rt_wanted(M)) return eigh_rt(A, lamb, V, n, M, 0, 0, 0.0, as_stream(stream));
+  if (M == 2) {
+    hipLaunchKernelGGL(k_eigh2_plain, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), (const c128 *)A, lamb, (c128 *)V, n);
+    return check_launch("k_eigh2_plain");
+  }
   if (hermitian_rows_wanted(M, 7))
     return eigh_rows(A, lamb, V, n, M, 0, 0, 0.0, as_stream(stream));
   dim3 grid((unsigned)((n + 63) / 64)), block(64);

@@ -13,6 +13,14 @@ import numpy as np
 import pytest
 
 from conftest import load_golden, rel_err, rel_err_up_to_phase
+
+
+def pair_err(a, b, name, N):
+    """Pairwise updates against a reference / oracle result.  From 3 sources on WITH the phases
+    np.linalg.eigh leaves in the 2 x 2 eigenvectors (csrc/eigh2.hpp restates LAPACK's convention,
+    round 6); with 2 sources the default selectors visit the one pair twice and the second visit's
+    phase is LAPACK's reading of rounding noise: up to a phase per row there."""
+    return rel_err(a, b) if N >= 3 else rel_err_up_to_phase(a, b, name)
 from conftest import option as _option
 
 from ssspy_amd import _routes
@@ -79,10 +87,20 @@ def _compare_snapshots(g, snap):
     for key, value in snap.store.items():
         assert key in g, key
         name = key.split("_", 1)[1]
-        if pairwise and name in ("demix_filter", "output"):
-            err = rel_err_up_to_phase(value, g[key], name)  # eigenvector phase, fixed only by PB
+        if pairwise and name in ("demix_filter", "output") and g["X"].shape[0] == 2:
+            # two sources: the default selectors visit the pair twice, and the second visit's
+            # eigenvector phase is LAPACK's reading of rounding noise (pair_phase_check.py)
+            err = rel_err_up_to_phase(value, g[key], name)
         else:
+            # (pairwise updates from 3 sources on: the reference's snapshots WITH the phases its
+            #  np.linalg.eigh leaves in the unrestored filters / outputs -- csrc/eigh2.hpp, round 6;
+            #  compared up to a phase per row before)
             err = rel_err(value, g[key])
+            if pairwise and name in ("demix_filter", "output"):
+                # (a phase is as well determined as the off-diagonal entry it is read from: 1e-7
+                #  after ten GGD iterations where the moduli agree to 1e-9)
+                assert err < 1e-6, "{}: {}".format(key, err)
+                err = rel_err_up_to_phase(value, g[key], name)
         assert err < TOL, "{}: {}".format(key, err)
         checked += 1
     assert checked > 0
@@ -575,14 +593,20 @@ def test_auxiva_implied_filter_iterations_equal_the_literal_form(contrast, algo,
     c = run(True)
     monkeypatch.setitem(_routes.VALUES, "implied_filter", True)
     assert a[3] and b[3] and not c[3]
+    # Two sources with the default pairs (0, 1), (1, 0): the second problem of every iteration is the
+    # pair the first one has just diagonalised, its off-diagonal entry is rounding noise and the
+    # phase np.linalg.eigh -- hence the reference, and csrc/eigh2.hpp since round 6 -- gives the
+    # eigenvectors is derived from it: the rows of an output that has NOT been through scale
+    # restoration are then defined in modulus only (benchmarks/tools/pair_phase_check.py).
+    unrestored = (lambda y: np.abs(y)) if (algo == "ISS2" and N == 2) else (lambda y: y)
     for r in (a, b):
         assert rel_err(r[1], c[1]) < 1e-9
         np.testing.assert_allclose(r[0].loss, c[0].loss, rtol=1e-9)
         np.testing.assert_allclose(r[4], c[4], rtol=1e-9)
-        assert rel_err(r[5], c[5]) < 1e-9
+        assert rel_err(unrestored(r[5]), unrestored(c[5])) < 1e-9
     assert len(b[2]) == len(c[2]) == 7
     for u, v in zip(b[2], c[2]):
-        assert rel_err(u, v) < 1e-9
+        assert rel_err(unrestored(u), unrestored(v)) < 1e-9
     ref = AuxIVAOracle(spatial_algorithm=algo, contrast=contrast)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -1548,15 +1572,39 @@ def test_eigh2_generalised(type):
     if type == 1:
         assert rel_err(A @ zk, (B @ zk) * lamb[..., None, :]) < 1e-11
         assert rel_err(lamb, g["eigh2_lamb"]) < 1e-12
-        # same eigenvectors as the reference up to a per-column phase
-        ref = g["eigh2_z"]
-        phase = np.sum(ref.conj() * zk, axis=-2, keepdims=True)
-        assert rel_err(zk * (phase.conj() / np.abs(phase)), ref) < 1e-10
+        # the reference's eigenvectors WITH their phases: its eigh2 takes them from np.linalg.eigh on
+        # the 2 x 2 matrix C (ssspy/linalg/eigh.py:198), and csrc/eigh2.hpp restates what LAPACK does
+        # there (round 6; before: equal up to a per-column phase)
+        assert rel_err(zk, g["eigh2_z"]) < 1e-10
     elif type == 2:
         assert rel_err(A @ B @ zk, zk * lamb[..., None, :]) < 1e-11
     else:
         assert rel_err(B @ A @ zk, zk * lamb[..., None, :]) < 1e-11
     assert np.all(lamb[..., 0] <= lamb[..., 1])
+    # every type, and the plain 2 x 2 problem, against NumPy's route (Cholesky + np.linalg.eigh) with
+    # the phases: real and complex, an off-diagonal entry that is real, imaginary, zero
+    rng = np.random.default_rng(type)
+    n = 200
+    X = rng.standard_normal((n, 2, 6)) + 1j * rng.standard_normal((n, 2, 6))
+    Y = rng.standard_normal((n, 2, 6)) + 1j * rng.standard_normal((n, 2, 6))
+    A2, B2 = X @ X.swapaxes(-2, -1).conj(), Y @ Y.swapaxes(-2, -1).conj()
+    A2[:40] = A2[:40].real                    # real symmetric problems
+    B2[:20] = B2[:20].real
+    A2[40:50, 0, 1] = A2[40:50, 0, 1].imag * 1j   # purely imaginary coupling
+    A2[40:50, 1, 0] = A2[40:50, 0, 1].conj()
+    A2[50:55, 0, 1] = A2[50:55, 1, 0] = 0.0   # already diagonal
+    L = np.linalg.cholesky(B2)
+    LH = L.swapaxes(-2, -1).conj()
+    Li = np.linalg.inv(L)
+    C = Li @ A2 @ Li.swapaxes(-2, -1).conj() if type == 1 else LH @ A2 @ L
+    lam_r, y = np.linalg.eigh(C)
+    z_r = L @ y if type == 3 else np.linalg.inv(LH) @ y
+    lam2, z2 = eigh2(A2, B2, type=type)
+    assert rel_err(lam2, lam_r) < 1e-11
+    assert rel_err(z2, z_r) < 1e-9
+    lam_p, V_p = eigh2(A2)
+    lam_n, V_n = np.linalg.eigh(A2)
+    assert rel_err(lam_p, lam_n) < 1e-12 and rel_err(V_p, V_n) < 1e-10
 
 
 @pytest.mark.parametrize("N", [2, 3, 4, 8])
@@ -1580,18 +1628,18 @@ def test_pairwise_operators_against_oracle(N):
     W, U = g["ip1_n{}_W".format(N)], g["ip1_n{}_U".format(N)]
     out = update_by_ip2(W.copy(), U)
     ref = sp.update_by_ip2(W, U)
-    assert rel_err_up_to_phase(out, ref, "demix_filter") < 1e-9
+    assert pair_err(out, ref, "demix_filter", N) < 1e-9
     out = update_by_ip2(W.copy(), U, pair_selector=combination_pair_selector)
     ref = sp.update_by_ip2(W, U, pairs=list(combination_pair_selector(N)))
-    assert rel_err_up_to_phase(out, ref, "demix_filter") < 1e-9
+    assert pair_err(out, ref, "demix_filter", N) < 1e-9
     Y, varphi = g["iss1_n{}_Y".format(N)], g["iss1_n{}_varphi".format(N)]
     out = update_by_iss2(Y, varphi)
     ref = sp.update_by_iss2(Y, varphi)
-    assert rel_err_up_to_phase(out, ref, "output") < 1e-9
+    assert pair_err(out, ref, "output", N) < 1e-9
     # negative indices wrap, as in the reference
     out = update_by_iss2(Y, varphi[:, :1, :], pair_selector=lambda n: [(-1, 0)])
     ref = sp.update_by_iss2(Y, varphi[:, :1, :], pairs=[(N - 1, 0)])
-    assert rel_err_up_to_phase(out, ref, "output") < 1e-9
+    assert pair_err(out, ref, "output", N) < 1e-9
 
 
 MNMF_IP2_CASES = ["fmnmf_ip2_m2", "fmnmf_ip2_m3", "fmnmf_ip2_m4", "fmnmf_ip2_m3_n2",
@@ -1657,28 +1705,29 @@ def test_pairwise_operators_against_golden(N):
     Wc = W.copy()
     out = update_by_ip2(Wc, U)
     assert out is Wc  # overwrite=True aliases, as in the reference
-    assert rel_err_up_to_phase(out, p("ip2_out"), "demix_filter") < tol
+    assert pair_err(out, p("ip2_out"), "demix_filter", N) < tol
     Wc = W.copy()
     out = update_by_ip2(Wc, U, overwrite=False)
     assert out is not Wc and np.array_equal(Wc, W)
-    assert rel_err_up_to_phase(out, p("ip2_out_copy"), "demix_filter") < tol
+    assert pair_err(out, p("ip2_out_copy"), "demix_filter", N) < tol
     out = update_by_ip2(W.copy(), U, pair_selector=combination_pair_selector)
-    assert rel_err_up_to_phase(out, p("ip2_out_comb"), "demix_filter") < tol
+    assert pair_err(out, p("ip2_out_comb"), "demix_filter", N) < tol
     out = update_by_ip2(W.copy(), U, flooring_fn=add)
-    assert rel_err_up_to_phase(out, p("ip2_out_add"), "demix_filter") < tol
+    assert pair_err(out, p("ip2_out_add"), "demix_filter", N) < tol
     pairs = [tuple(int(v) for v in pr) for pr in p("ip2_pairs")]
     out = update_by_ip2(W.copy(), U, pair_selector=lambda n: pairs)
+    # (this list visits one pair twice in a row: the second visit's phase is rounding noise)
     assert rel_err_up_to_phase(out, p("ip2_out_pairs"), "demix_filter") < tol
     Yc = Y.copy()
     out = update_by_iss2(Yc, varphi)
-    assert rel_err_up_to_phase(out, p("iss2_out"), "output") < tol
+    assert pair_err(out, p("iss2_out"), "output", N) < tol
     out = update_by_iss2(Y.copy(), varphi, pair_selector=combination_pair_selector)
-    assert rel_err_up_to_phase(out, p("iss2_out_comb"), "output") < tol
+    assert pair_err(out, p("iss2_out_comb"), "output", N) < tol
     out = update_by_iss2(Y.copy(), varphi[:, :1, :], flooring_fn=add)
-    assert rel_err_up_to_phase(out, p("iss2_out_bcast_add"), "output") < tol
+    assert pair_err(out, p("iss2_out_bcast_add"), "output", N) < tol
     pairs = [tuple(int(v) for v in pr) for pr in p("iss2_pairs")]
     out = update_by_iss2(Y.copy(), varphi, pair_selector=lambda n: pairs)
-    assert rel_err_up_to_phase(out, p("iss2_out_pairs"), "output") < tol
+    assert pair_err(out, p("iss2_out_pairs"), "output", N) < tol
 
 
 # ------------------------------------------------------------------------------- full BASELINE sizes
@@ -2596,8 +2645,9 @@ def _replay_uninjected(g, flooring_fn="default", tol=TOL):
         pairwise = "meta_spatial_algorithm" in g and str(g["meta_spatial_algorithm"]) in ("IP2", "ISS2")
         if key.startswith("it0_") and name not in ("output", "variance"):
             np.testing.assert_array_equal(value, g[key], err_msg=key)  # the draws themselves
-        elif pairwise and not key.startswith("it0_") and name in ("demix_filter", "output"):
-            # eigenvector phase of the pairwise updates, removed only by projection back
+        elif (pairwise and not key.startswith("it0_") and name in ("demix_filter", "output")
+              and g["X"].shape[0] == 2):
+            # (two sources: the second visit of the pair has a noise-derived phase, see above)
             assert rel_err_up_to_phase(value, g[key], name) < tol, key
         else:
             assert rel_err(value, g[key]) < tol, key
