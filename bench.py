@@ -98,14 +98,22 @@ def settle_host():
     gc.freeze()
 
 
-def time_loop(fn, n):
+def time_loop(fn, n, reps=3):
+    """Seconds per call: the median of `reps` regions of exactly `n` calls each (the side legs only;
+    the headline has its own five regions).  One region was what rounds 1-5 timed, and a 20 ms leg
+    that starts right after seconds of host work (input generation, a pageable upload) caught the
+    GPU's clocks on their way back up: configs[3] at 32 mixtures read 1.06 / 1.99 / 3.12 ms per
+    iteration on three boxes of the same code while benchmarks/other_configs.py gave 1.08 each time."""
     settle_host()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n
+    times = []
+    for _ in range(max(1, reps)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) / n)
+    return sorted(times)[len(times) // 2]
 
 
 def kernel_group_events(sep, steps):
@@ -745,6 +753,8 @@ def main():
             "value_max": round(units / min(regions), 2), "value_first_region": round(units / regions[0], 2),
             "note": "each region = exactly `steps` update_once() calls between barrier + synchronize; "
                     "`value` is the median region",
+            "side_legs": "every ms_per_step outside this block (configs, pairwise_ipa, auxiva_*) is the "
+                         "median of 3 regions of the stated number of iterations (time_loop)",
         },
         "per_rank": per_rank,
         "higher_is_better": True,

@@ -287,6 +287,9 @@ int ssspy_inv2(const void *A, void *out, long long n, void *stream);
 
 /* Hermitian eigen-decomposition (cyclic complex Jacobi): lamb (n,M) ascending, V (n,M,M) unit
  * eigenvectors in columns (phase convention differs from LAPACK; A V = V diag(lamb) holds).
+ * M = 2 (and ssspy_eigh2 below): the eigenvectors carry the phases reference LAPACK's zheevd gives
+ * them (zhetd2 + dlaev2, restated in csrc/eigh2.hpp) -- what np.linalg.eigh returns in the
+ * reference's eigh2 and pairwise updates (ssspy/linalg/eigh.py:155-157, :198).
  * replaces: np.linalg.eigh at ssspy/linalg/eigh.py:77,157,198 and ssspy/special/psd.py:54. */
 int ssspy_eigh(const void *A, double *lamb, void *V, long long n, int M, void *stream);
 
