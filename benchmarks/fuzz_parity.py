@@ -65,12 +65,20 @@ def flooring_draw(rng, allow_callable):
     if k == 0:
         return functools.partial(max_flooring, eps=1e-10), ("max", 1e-10)
     if k == 1:
-        return functools.partial(add_flooring, eps=1e-4), ("add", 1e-4)
+        # (IPA: floor(0) is its Newton stopping threshold and the mask threshold of the LQPQM terms;
+        #  at 1e-4 both flip with rounding and the reference's result moves in steps -- 1e-8 there)
+        eps = 1e-4 if allow_callable else 1e-8
+        return functools.partial(add_flooring, eps=eps), ("add", eps)
     if k == 2:
         return functools.partial(max_flooring, eps=1e-3), ("max", 1e-3)
     if k == 3:
         return None, ("none", 0.0)
     return custom_floor, custom_floor
+
+
+def okw_of(kw):
+    """The separator's keyword arguments without its flooring_fn (the oracle takes `flooring`)."""
+    return {k: v for k, v in kw.items() if k != "flooring_fn"}
 
 
 def restoration_options(rng, N):
@@ -128,6 +136,13 @@ def main():
                                reference_id=int(rng.integers(N)))
                     if kind == "fmnmf":
                         mkw["diagonalizer_algorithm"] = str(rng.choice(["IP", "IP1", "IP2"]))
+                fokw = {}
+                if os.environ.get("FUZZ_FLOOR"):
+                    ffn, fo = flooring_draw(rng, kind == "fmnmf")
+                    if kind == "gmnmf" and fo == ("max", 1e-3):
+                        ffn, fo = flooring_draw(rng, False)  # (once more: keep some default floors)
+                    mkw = dict(mkw, flooring_fn=ffn)
+                    fokw = dict(flooring=fo)
                 basis = rng.random((B, Ns, F, K)) + 0.05
                 act = rng.random((B, Ns, K, T)) + 0.05
                 if kind == "fmnmf":
@@ -139,11 +154,11 @@ def main():
                     Y = m(X, n_iter=2, basis=basis, activation=act)
                 for b in {0, B - 1}:
                     if kind == "fmnmf":
-                        ref = FastGaussMNMFOracle(n_basis=K, **mkw)
+                        ref = FastGaussMNMFOracle(n_basis=K, **okw_of(mkw), **fokw)
                         Yr = ref.run(X[b], n_iter=3, basis=basis[b], activation=act[b],
                                      spatial=sp0[b].copy())
                     else:
-                        ref = GaussMNMFOracle(n_basis=K, **mkw)
+                        ref = GaussMNMFOracle(n_basis=K, **okw_of(mkw), **fokw)
                         Yr = ref.run(X[b], n_iter=2, basis=basis[b], activation=act[b])
                     e = rel(Y[b], Yr)
                     el = np.max(np.abs(np.asarray(m.loss)[:, b] / np.asarray(ref.loss) - 1))
@@ -158,17 +173,24 @@ def main():
                 Z = Z / Z.sum(axis=1, keepdims=True)
                 src = str(rng.choice(["MM", "ME"]))
                 kw = dict(n_basis=K, spatial_algorithm=algo, source_algorithm=src, partitioning=True)
-                m = GaussILRMA(**kw)
+                fkw = {}
+                if os.environ.get("FUZZ_OPTIONS"):
+                    kw.update(restoration_options(rng, N), normalization=bool(rng.random() < 0.7))
+                if os.environ.get("FUZZ_FLOOR"):
+                    ffn, fo = flooring_draw(rng, False)
+                    fkw = dict(flooring_fn=ffn)
+                    kw = dict(kw, flooring=fo)
+                m = GaussILRMA(**okw_of({k: v for k, v in kw.items() if k != "flooring"}), **fkw)
                 Y = m(X, n_iter=3, basis=basis, activation=act, latent=Z)
                 for b in {0, B - 1}:
                     ref = GaussILRMAOracle(**kw)
                     Yr = ref.run(X[b], n_iter=3, basis=basis[b], activation=act[b], latent=Z[b])
-                    e = rel(Y[b], Yr)
+                    e = rel(*phase_free(Y[b], Yr, kw, algo))
                     el = np.max(np.abs(np.asarray(m.loss)[:, b] / np.asarray(ref.loss) - 1))
                     degenerate = K == 1 and algo in ("IP2", "ISS2")  # any rotation is optimal
                     if not ((degenerate or e < tol) and el < 1e-7):
                         bad += 1
-                        print("MISMATCH", tag, src, b, e, el)
+                        print("MISMATCH", tag, src, {k: v for k, v in kw.items() if k != "n_basis"}, b, e, el)
                 continue
             if kind.startswith("iva"):
                 cls = AuxLaplaceIVA if kind == "iva_lap" else AuxGaussIVA
