@@ -99,6 +99,8 @@ def main():
         T = int(rng.choice([2, 5, 15, 16, 17, 31, 32, 33, 47, 64, 65, 100, 130]))
         K = int(rng.choice([1, 2, 3, 4, 7, 8, 15, 16, 17, 24, 32, 33, 48, 64, 70]))  # 17..32 / 33..64: the two- / four-k-tile variants
         B = int(rng.choice([1, 1, 1, 2, 5, 40]))
+        if os.environ.get("FUZZ_BATCH"):  # batch sizes around the grouping / splitting edges
+            B = int(rng.choice([3, 31, 32, 33, 63, 64, 65, 127, 129, 200]))
         algo = str(rng.choice(["IP", "ISS", "IP2", "ISS2", "IPA"]))
         if os.environ.get("FUZZ_ALGOS"):
             algo = str(rng.choice(os.environ["FUZZ_ALGOS"].split(",")))
