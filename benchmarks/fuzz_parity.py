@@ -166,6 +166,8 @@ def main():
                         Yr = ref.run(X[b], n_iter=2, basis=basis[b], activation=act[b])
                     e = rel(Y[b], Yr)
                     el = np.max(np.abs(np.asarray(m.loss)[:, b] / np.asarray(ref.loss) - 1))
+                    if os.environ.get("FUZZ_VERBOSE"):
+                        print("case", tag, mkw, b, "%.2e %.2e" % (e, el))
                     if not (e < 1e-6 and el < 1e-7):
                         bad += 1
                         print("MISMATCH", tag, mkw, b, e, el)
