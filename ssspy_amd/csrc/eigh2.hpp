@@ -114,13 +114,12 @@ __device__ __forceinline__ bool eigh2_type1(const c128 (&A)[2][2], const c128 (&
   const double i00 = 1.0 / l00, i11 = 1.0 / l11;
   const c128 i10 = cmake(-l10.x * i00 * i11, -l10.y * i00 * i11);  // (L^-1)[1][0]
   // M1 = L^-1 A ;  C = M1 L^-H
-  const c128 m00 = cscale(A[0][0], i00), m01 = cscale(A[0][1], i00);
+  const c128 m00 = cscale(A[0][0], i00);
   const c128 m10 = cadd(cmul(i10, A[0][0]), cscale(A[1][0], i11));
   const c128 m11 = cadd(cmul(i10, A[0][1]), cscale(A[1][1], i11));
   const double c00 = m00.x * i00;
   const c128 c10 = cscale(m10, i00);  // (numpy.linalg.eigh reads the lower triangle)
   const double c11 = cadd(cmulc(m10, i10), cscale(m11, i11)).x;
-  (void)m01;
   c128 y[2][2];
   eigh2_lapack(c00, c11, c10, lamb, y);
   // z = L^-H y,  L^-H = [[i00, conj(i10)], [0, i11]]
