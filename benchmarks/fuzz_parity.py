@@ -7,7 +7,8 @@ frames), the split / unsplit work-item boundary and every option of the ILRMA / 
 
 FUZZ_KINDS / FUZZ_ALGOS / FUZZ_SOURCES (comma lists) and FUZZ_MAX_SOURCES narrow the draw, FUZZ_ITER sets the number
 of ILRMA iterations (default 3), FUZZ_OPTIONS=1 also draws scale_restoration / reference_id /
-the normalisation form.
+the normalisation form, FUZZ_FLOOR=1 the flooring function, FUZZ_INIT=1 a given initial demixing filter,
+FUZZ_BATCH=1 batch sizes around the grouping edges.
 """
 import os
 import sys
@@ -152,15 +153,21 @@ def main():
                 if kind == "fmnmf":
                     sp0 = rng.random((B, F, Ns, N)) + 0.05
                     m = FastGaussMNMF(n_basis=K, **mkw)
-                    Y = m(X, n_iter=3, basis=basis, activation=act, spatial=sp0)
+                    Q0 = None
+                    if os.environ.get("FUZZ_INIT") and rng.random() < 0.6:  # a given diagonaliser
+                        Q0 = np.eye(N) + 0.3 * (rng.standard_normal((B, F, N, N))
+                                                + 1j * rng.standard_normal((B, F, N, N)))
+                    qkw = {} if Q0 is None else dict(diagonalizer=Q0.copy())
+                    Y = m(X, n_iter=3, basis=basis, activation=act, spatial=sp0, **qkw)
                 else:
                     m = GaussMNMF(n_basis=K, **mkw)
                     Y = m(X, n_iter=2, basis=basis, activation=act)
                 for b in {0, B - 1}:
                     if kind == "fmnmf":
                         ref = FastGaussMNMFOracle(n_basis=K, **okw_of(mkw), **fokw)
+                        qkw = {} if Q0 is None else dict(diagonalizer=Q0[b].copy())
                         Yr = ref.run(X[b], n_iter=3, basis=basis[b], activation=act[b],
-                                     spatial=sp0[b].copy())
+                                     spatial=sp0[b].copy(), **qkw)
                     else:
                         ref = GaussMNMFOracle(n_basis=K, **okw_of(mkw), **fokw)
                         Yr = ref.run(X[b], n_iter=2, basis=basis[b], activation=act[b])
@@ -209,12 +216,18 @@ def main():
                 tagkw = dict(okw)
                 okw.pop("floor", None)
                 m = cls(spatial_algorithm=algo, **okw, **fkw)
-                Y = m(X, n_iter=3)
+                W0 = None
+                if os.environ.get("FUZZ_INIT") and rng.random() < 0.6:  # a given initial filter
+                    W0 = np.eye(N) + 0.3 * (rng.standard_normal((B, F, N, N))
+                                            + 1j * rng.standard_normal((B, F, N, N)))
+                    tagkw = dict(tagkw, W0=True)
+                Y = m(X, n_iter=3) if W0 is None else m(X, n_iter=3, demix_filter=W0.copy())
                 for b in {0, B - 1}:
                     ref = AuxIVAOracle(spatial_algorithm=algo,
                                        contrast="laplace" if kind == "iva_lap" else "gauss", **okw,
                                        **fokw)
-                    Yr = ref.run(X[b], n_iter=3)
+                    Yr = (ref.run(X[b], n_iter=3) if W0 is None
+                          else ref.run(X[b], n_iter=3, demix_filter=W0[b].copy()))
                     e = rel(*phase_free(Y[b], Yr, okw, algo))
                     el = np.max(np.abs(np.asarray(m.loss)[:, b] / np.asarray(ref.loss) - 1))
                     if not (e < tol and el < 1e-7):
@@ -249,10 +262,17 @@ def main():
                 m = GaussILRMA(**kw, **fkw)
             kw = dict(kw, **fokw)
             n_iter = int(os.environ.get("FUZZ_ITER", "3"))
-            Y = m(X, n_iter=n_iter, basis=basis, activation=act)
+            W0 = None
+            if os.environ.get("FUZZ_INIT") and rng.random() < 0.6:  # a given initial filter
+                W0 = np.eye(N) + 0.3 * (rng.standard_normal((B, F, N, N))
+                                        + 1j * rng.standard_normal((B, F, N, N)))
+                kw = dict(kw, W0=True)
+            ikw = {} if W0 is None else dict(demix_filter=W0.copy())
+            Y = m(X, n_iter=n_iter, basis=basis, activation=act, **ikw)
             for b in {0, B - 1}:
-                ref = GaussILRMAOracle(model=model, **kw)
-                Yr = ref.run(X[b], n_iter=n_iter, basis=basis[b], activation=act[b])
+                ref = GaussILRMAOracle(model=model, **{k: v for k, v in kw.items() if k != "W0"})
+                ikw = {} if W0 is None else dict(demix_filter=W0[b].copy())
+                Yr = ref.run(X[b], n_iter=n_iter, basis=basis[b], activation=act[b], **ikw)
                 e = rel(*phase_free(Y[b], Yr, kw, algo))
                 eb = rel(m.basis[b], ref.basis)
                 el = np.max(np.abs(np.asarray(m.loss)[:, b] / np.asarray(ref.loss) - 1))
