@@ -14,7 +14,9 @@ import scipy.linalg
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+import oracle.spatial as osp  # noqa: E402
 from oracle.ipa import lqpqm2 as oracle_lqpqm2  # noqa: E402
+from ssspy_amd.algorithm import minimal_distortion_principle, projection_back  # noqa: E402
 from ssspy_amd.linalg import eigh, gmeanmh, invsqrtmh, lqpqm2, solve, sqrtmh  # noqa: E402
 from ssspy_amd.special.flooring import add_flooring, max_flooring  # noqa: E402
 from ssspy_amd.special.psd import to_psd  # noqa: E402
@@ -44,7 +46,8 @@ def main():
         n = int(rng.choice([1, 2, 63, 64, 65, 130, 300]))
         cplx = bool(rng.random() < 0.7)
         T = M + int(rng.integers(2, 3 * M + 4))
-        op = str(rng.choice(["solve", "eigh", "to_psd", "sqrt", "invsqrt", "gmean", "geigh", "lqpqm2"]))
+        op = str(rng.choice(["solve", "eigh", "to_psd", "sqrt", "invsqrt", "gmean", "geigh", "lqpqm2",
+                             "restore"]))
         tag = (case, op, M, n, cplx, T)
         errs = {}
         with warnings.catch_warnings():
@@ -93,6 +96,20 @@ def main():
                 lhs, rhs = {1: (A @ z, lam[:, None, :] * (B @ z)), 2: (A @ B @ z, lam[:, None, :] * z),
                             3: (B @ A @ z, lam[:, None, :] * z)}[t]
                 errs["res%d" % t] = (rel(lhs, rhs), 1e-8)
+            elif op == "restore":
+                # projection back (filter and spectrogram form) and the minimal distortion principle,
+                # one reference channel or all of them (reference_id=None)
+                N, F, Tn = M, int(rng.choice([1, 3, 17, 33])), M + int(rng.integers(3, 40))
+                Y = rng.standard_normal((N, F, Tn)) + 1j * rng.standard_normal((N, F, Tn))
+                Xm = rng.standard_normal((N, F, Tn)) + 1j * rng.standard_normal((N, F, Tn))
+                W = np.eye(N) + 0.3 * (rng.standard_normal((F, N, N)) + 1j * rng.standard_normal((F, N, N)))
+                rid = [0, N - 1, int(rng.integers(N)), None][int(rng.integers(4))]
+                errs["pb_w"] = (rel(projection_back(W, reference_id=rid),
+                                    osp.projection_back_filter(W, rid)), 1e-9)
+                errs["pb_y"] = (rel(projection_back(Y, reference=Xm, reference_id=rid),
+                                    osp.projection_back_output(Y, Xm, rid)), 1e-8)
+                errs["mdp"] = (rel(minimal_distortion_principle(Y, reference=Xm, reference_id=rid),
+                                   osp.minimal_distortion_output(Y, Xm, rid)), 1e-8)
             else:
                 L = min(M, 15)
                 H = psd(rng, n, L, T, True)
